@@ -1,0 +1,165 @@
+"""Deterministic synthetic scenes for tests and bench.py (numpy only).
+
+The reference ships no scene fixtures (its asset submodules are empty), so the
+configurations of BASELINE.json are reconstructed from the loader's schema and
+the instantiator's parameter ranges as SURVEY.md section 8(d) specifies.  All
+randomness comes from numpy's PCG64 with fixed seeds -- never libc rand.
+
+Array conventions are the device SoA layout of include/clapgpu.h:
+``pos_scale[n,4] = (x, y, z, scale)``, ``rot[n,4] = quat (x, y, z, w)``,
+``parent[n]`` (-1 = root, otherwise ``parent[i] < i``), ``model[n]``,
+``model_aabb[m,6] = (min xyz, max xyz)``, ``flags[n]``, ``seqs[n]``.
+"""
+import math
+
+import numpy as np
+
+E_VISIBLE = np.uint32(1 << 0)
+E_SKIP_CULLING = np.uint32(1 << 14)
+E_DIRTY = np.uint32(1 << 16)
+E_ALIVE = np.uint32(1 << 31)
+
+F32 = np.float32
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def quat_from_euler_xyz(x, y, z):
+    """Same formula as the reference's quat_from_euler_xyz (linmath.h:857-870), fp32."""
+    x, y, z = (np.asarray(v, dtype=F32) for v in (x, y, z))
+    h = F32(0.5)
+    cx, sx = np.cos(x * h, dtype=F32), np.sin(x * h, dtype=F32)
+    cy, sy = np.cos(y * h, dtype=F32), np.sin(y * h, dtype=F32)
+    cz, sz = np.cos(z * h, dtype=F32), np.sin(z * h, dtype=F32)
+    q = np.stack([sx * cy * cz - cx * sy * sz,
+                  cx * sy * cz + sx * cy * sz,
+                  cx * cy * sz - sx * sy * cz,
+                  cx * cy * cz + sx * sy * sz], axis=-1)
+    return q.astype(F32)
+
+
+def camera(pos=(0.0, 0.0, 0.0), quat=(0.0, 0.0, 0.0, 1.0), fov_deg=70.0, aspect=16.0 / 9.0,
+           near=0.1, far=500.0, ndc_z_zero_one=0):
+    """Default scene camera (scene.c:74-76): fov 70 deg, near 0.1, far 500, looking down -Z."""
+    return dict(cam_pos=np.asarray(pos, F32), cam_quat=np.asarray(quat, F32),
+                persp=np.asarray([F32(fov_deg) * F32(math.pi) / F32(180.0), aspect, near, far], F32),
+                ndc_z_zero_one=np.asarray([ndc_z_zero_one], np.uint32))
+
+
+def _models_default():
+    return dict(model_aabb=np.asarray([[-1, -2, -3, 1, 2, 3]], F32),
+                model_skip=np.zeros(1, np.uint8))
+
+
+def _pack(pos, scale, rot, parent, model=None, flags=None):
+    n = pos.shape[0]
+    d = dict(n=n,
+             pos_scale=np.concatenate([pos, scale[:, None]], axis=1).astype(F32),
+             rot=rot.astype(F32),
+             parent=parent.astype(np.int32),
+             model=np.zeros(n, np.int32) if model is None else model.astype(np.int32),
+             flags=(np.full(n, E_ALIVE | E_VISIBLE | E_DIRTY, np.uint32) if flags is None else flags),
+             seqs=np.zeros(n, np.uint32))
+    d.update(_models_default())
+    return d
+
+
+def _root_population(rng, n, full_euler):
+    """Instantiator population (terrain.c:559-568 -> model.c:1863-1874): random yaw,
+    scale 1 + 0.5 (1 - 2u); positions U(-500,500) x U(-50,50) x U(-500,500)."""
+    pos = np.stack([rng.uniform(-500, 500, n), rng.uniform(-50, 50, n), rng.uniform(-500, 500, n)], 1)
+    scale = 1.0 + 0.5 * (1.0 - 2.0 * rng.uniform(0, 1, n))
+    if full_euler:
+        ang = rng.uniform(-math.pi, math.pi, (n, 3))
+        rot = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2])
+    else:
+        ry = rng.uniform(0, 2 * math.pi, n)
+        rot = quat_from_euler_xyz(np.zeros(n), ry, np.zeros(n))
+    return pos.astype(F32), scale.astype(F32), rot
+
+
+def entities_flat(n=10_000, seed=1234, full_euler=False):
+    """C1: flat (parentless) entities, one shared model AABB (-1,-2,-3)..(1,2,3)."""
+    rng = _rng(seed)
+    pos, scale, rot = _root_population(rng, n, full_euler)
+    return _pack(pos, scale, rot, np.full(n, -1))
+
+
+def entities_chains(n_chains=125_000, depth=8, seed=2):
+    """C2: n_chains x depth entities, level-major (entity = level * n_chains + chain).
+    Roots as C1; children local pos U(-2,2)^3, scale U(0.8,1.2), random full rotation."""
+    rng = _rng(seed)
+    n = n_chains * depth
+    pos = np.empty((n, 3), F32)
+    scale = np.empty(n, F32)
+    rot = np.empty((n, 4), F32)
+    parent = np.empty(n, np.int64)
+    p0, s0, r0 = _root_population(rng, n_chains, False)
+    pos[:n_chains], scale[:n_chains], rot[:n_chains] = p0, s0, r0
+    parent[:n_chains] = -1
+    for lvl in range(1, depth):
+        a, b = lvl * n_chains, (lvl + 1) * n_chains
+        pos[a:b] = rng.uniform(-2, 2, (n_chains, 3))
+        scale[a:b] = rng.uniform(0.8, 1.2, n_chains)
+        ang = rng.uniform(-math.pi, math.pi, (n_chains, 3))
+        rot[a:b] = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2])
+        parent[a:b] = np.arange(a - n_chains, b - n_chains)
+    d = _pack(pos, scale, rot, parent)
+    d["level_start"] = np.arange(0, n + 1, n_chains, dtype=np.uint32)
+    return d
+
+
+def entities_forest(n=5000, seed=7, max_depth=6, n_models=3, dead_frac=0.05, hidden_frac=0.05,
+                    skipcull_frac=0.05):
+    """Ragged random forest for parity tests: random fan-out, several models (one with
+    skip_aabb), dead / hidden / skip-culling entities.  Stored level-major."""
+    rng = _rng(seed)
+    depth = np.zeros(n, np.int64)
+    parent = np.full(n, -1, np.int64)
+    n_roots = max(1, n // 4)
+    for i in range(n_roots, n):
+        p = int(rng.integers(0, i))
+        if depth[p] + 1 >= max_depth:
+            p = int(rng.integers(0, n_roots))
+        parent[i] = p
+        depth[i] = depth[p] + 1
+    order = np.argsort(depth, kind="stable")          # level-major, parents first
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    parent = np.where(parent[order] >= 0, inv[np.maximum(parent[order], 0)], -1)
+    depth = depth[order]
+    pos_r, scale_r, rot_r = _root_population(rng, n, True)
+    is_child = parent >= 0
+    pos = np.where(is_child[:, None], rng.uniform(-3, 3, (n, 3)), pos_r).astype(F32)
+    scale = np.where(is_child, rng.uniform(0.7, 1.3, n), scale_r).astype(F32)
+    flags = np.full(n, E_ALIVE | E_VISIBLE | E_DIRTY, np.uint32)
+    u = rng.uniform(0, 1, n)
+    flags[u < dead_frac] &= ~E_ALIVE
+    flags[(u >= dead_frac) & (u < dead_frac + hidden_frac)] &= ~E_VISIBLE
+    flags[(u >= 1 - skipcull_frac)] |= E_SKIP_CULLING
+    model = rng.integers(0, n_models, n)
+    d = _pack(pos, scale, rot_r, parent, model=model, flags=flags)
+    aabb_lo = -rng.uniform(0.5, 3.0, (n_models, 3))
+    aabb_hi = rng.uniform(0.5, 3.0, (n_models, 3))
+    d["model_aabb"] = np.concatenate([aabb_lo, aabb_hi], 1).astype(F32)
+    d["model_skip"] = np.zeros(n_models, np.uint8)
+    if n_models > 1:
+        d["model_skip"][n_models - 1] = 1
+    counts = np.bincount(depth, minlength=int(depth.max()) + 1)
+    d["level_start"] = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    return d
+
+
+def level_starts(parent):
+    """Level boundaries of a level-major parent array (parents strictly before children)."""
+    parent = np.asarray(parent)
+    n = parent.shape[0]
+    depth = np.zeros(n, np.int64)
+    for i in range(n):
+        if parent[i] >= 0:
+            depth[i] = depth[parent[i]] + 1
+    assert np.all(np.diff(depth) >= 0), "entities are not stored level-major"
+    counts = np.bincount(depth, minlength=int(depth.max()) + 1 if n else 1)
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)

@@ -1,0 +1,92 @@
+/*
+ * oracle/clap_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference (virtuoso/clap) per-frame scene-update hot
+ * path over the same SoA arrays the HIP kernels use.  It exists to CHECK the
+ * GPU path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).
+ * Nothing under clap_amd/ may include, link or call it.
+ *
+ * Pinning status (details: oracle/README.md, DESIGN.md "Oracle"):
+ *   entity transform / inverse / AABB / frustum / cull ... pinned bit-exact against
+ *       the reference's own core/model.c, core/view.c, core/transform.c compiled
+ *       from /root/reference (oracle/ref -> oracle/_ref) and against the golden
+ *       vectors in tests/golden produced by that build.
+ *   pose (channels, slerp), joint palette ................. pinned <=1e-5 (same way)
+ *   particles ............................................. pinned bit-exact (same way)
+ *   vertex skinning ....................................... PARITY UNPINNED: the reference has
+ *       only GLSL (shaders/model.vert:32-48), no CPU implementation and no test.
+ *   rigid-body integrate + broadphase ..................... PARITY UNPINNED: ODE is an absent
+ *       submodule (deps/ode, .gitmodules:1-3); restated from ODE's published algorithm.
+ *
+ * Layout conventions (identical to include/clapgpu.h):
+ *   mat4   = float[16], column-major, (col c,row r) at [4c+r]   (linmath.h `M[c][r]`)
+ *   quat   = (x, y, z, w)                                       (linmath.h:835-840)
+ *   pos_scale[i] = (pos.x, pos.y, pos.z, entity scale)          (transform.h:8-12, model.h:412)
+ *   aabb[i]      = (min.x,min.y,min.z, max.x,max.y,max.z)       (model.h `vec3 aabb[2]`)
+ */
+#ifndef CLAP_ORACLE_H
+#define CLAP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* entity3d_flags bits the path reads (model.h:293-312) + one shim bit */
+#define CLAPO_E_VISIBLE       (1u << 0)
+#define CLAPO_E_SKIP_CULLING  (1u << 14)
+#define CLAPO_E_DIRTY         (1u << 16)   /* mirror of transform_t.updated (transform.h:11) */
+#define CLAPO_E_ALIVE         (1u << 31)
+
+typedef struct clapo_frustum {
+    float planes[6][4];     /* view.h:16  frustum_planes  */
+    float corners[8][4];    /* view.h:17  frustum_corners */
+} clapo_frustum;
+
+/* ---- view / frustum (host-side O(1) per frame) ---- */
+/* transform.c:132-138 transform_view_mat4x4 */
+void clapo_view_matrix(const float pos[3], const float quat[4], float view_mx[16]);
+/* linmath.h:709-776 via render-common.c:70-82 */
+void clapo_perspective(float fov, float aspect, float near_plane, float far_plane,
+                       int ndc_z_zero_one, float proj_mx[16]);
+/* view.c:248-289 subview_calc_frustum */
+void clapo_frustum_calc(const float view_mx[16], const float proj_mx[16],
+                        int ndc_z_zero_one, clapo_frustum *out);
+
+/* ---- single-entity pieces (used by unit tests against golden vectors) ---- */
+/* model.c:1618-1622 / 1670-1675: I -> translate_in_place -> *R -> scale_aniso */
+void clapo_trs_matrix(const float pos_scale[4], const float rot[4], float mx[16]);
+void clapo_mat4_mul(float out[16], const float a[16], const float b[16]);
+void clapo_mat4_invert(float out[16], const float m[16]);
+/* model.c:1200-1234 entity3d_aabb_update */
+void clapo_aabb_update(const float mx[16], const float model_aabb[6], float aabb[6], float center[3]);
+/* view.c:296-337 view_entity_in_frustum */
+int clapo_aabb_in_frustum(const clapo_frustum *f, const float aabb[6]);
+
+/*
+ * mq_update over default_update entities, converged level order
+ * (model.c:1953,1649-1695,1594-1647).  Requires parent[i] < i or parent[i] < 0.
+ * seqs[i] = seq | parent_seq << 16 (model.h:404-405, uint16 wrap).
+ * Returns the number of entities whose matrices were rebuilt.
+ */
+uint32_t clapo_entities_update(uint32_t n,
+                               const float *pos_scale, const float *rot,
+                               const int32_t *parent, const int32_t *model,
+                               const float *model_aabb, const uint8_t *model_skip_aabb,
+                               uint32_t *flags, uint32_t *seqs,
+                               float *mx, float *inv_mx, float *aabb, float *center);
+
+/*
+ * _models_render's per-entity draw predicate (model.c:959-973):
+ * ALIVE && VISIBLE && (SKIP_CULLING || view_entity_in_frustum).
+ * Writes ascending entity indices to visible[] (may be NULL) and one bit per
+ * entity to vis_mask[(n+63)/64] (may be NULL).  Returns the count.
+ */
+uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aabb,
+                             const clapo_frustum *f, uint32_t *visible, uint64_t *vis_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAP_ORACLE_H */

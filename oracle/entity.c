@@ -1,0 +1,213 @@
+/*
+ * oracle/entity.c -- TEST INFRASTRUCTURE ONLY (see clap_oracle.h).
+ *
+ * Entity transform hierarchy -> inverse -> world AABB -> frustum cull,
+ * restated from the reference's core/model.c, core/view.c, core/transform.c.
+ */
+#include "clap_oracle.h"
+#include "lm.h"
+
+/* transform.c:132-138: I, *= R(quat), transpose 3x3, translate_in_place(-pos) */
+void clapo_view_matrix(const float pos[3], const float quat[4], float view_mx[16])
+{
+    float r[16];
+
+    lm_m4_identity(view_mx);
+    lm_m4_from_quat(r, quat);                 /* transform.c:125-130 */
+    lm_m4_mul(view_mx, view_mx, r);
+    lm_m4_transpose_3x3(view_mx);
+    lm_m4_translate_in_place(view_mx, -pos[0], -pos[1], -pos[2]);
+}
+
+void clapo_perspective(float fov, float aspect, float near_plane, float far_plane,
+                       int ndc_z_zero_one, float proj_mx[16])
+{
+    lm_m4_perspective(proj_mx, fov, aspect, near_plane, far_plane, ndc_z_zero_one);
+}
+
+/* view.c:248-289 */
+void clapo_frustum_calc(const float view_mx[16], const float proj_mx[16],
+                        int ndc_z_zero_one, clapo_frustum *out)
+{
+    float mvp[16], trans[16], invmvp[16];
+    const float zn = ndc_z_zero_one ? 0.f : -1.f;      /* view.c:252-265 corner tables */
+    const float ndc[8][4] = {
+        { -1, -1, zn, 1 }, { 1, -1, zn, 1 }, { 1, 1, zn, 1 }, { -1, 1, zn, 1 },
+        { -1, -1,  1, 1 }, { 1, -1,  1, 1 }, { 1, 1,  1, 1 }, { -1, 1,  1, 1 },
+    };
+
+    lm_m4_mul(mvp, proj_mx, view_mx);                   /* view.c:270 */
+    lm_m4_transpose(trans, mvp);
+    lm_m4_invert(invmvp, mvp);
+
+    /* view.c:275-280: trans[3] +/- trans[0|1|2]; trans[c] is column c of the transpose */
+    for (int k = 0; k < 4; k++) {
+        out->planes[0][k] = trans[12 + k] + trans[0 + k];
+        out->planes[1][k] = trans[12 + k] - trans[0 + k];
+        out->planes[2][k] = trans[12 + k] + trans[4 + k];
+        out->planes[3][k] = trans[12 + k] - trans[4 + k];
+        out->planes[4][k] = trans[12 + k] + trans[8 + k];
+        out->planes[5][k] = trans[12 + k] - trans[8 + k];
+    }
+
+    /* view.c:283-288 */
+    for (int i = 0; i < 8; i++) {
+        float q[4];
+        lm_m4_mul_v4_post(q, invmvp, ndc[i]);
+        float s = 1.f / q[3];
+        for (int k = 0; k < 4; k++)
+            out->corners[i][k] = q[k] * s;
+    }
+}
+
+void clapo_trs_matrix(const float pos_scale[4], const float rot[4], float mx[16])
+{
+    float r[16];
+
+    lm_m4_identity(mx);                                            /* model.c:1619/1670 */
+    lm_m4_translate_in_place(mx, pos_scale[0], pos_scale[1], pos_scale[2]);   /* transform.c:57-60 */
+    lm_m4_from_quat(r, rot);                                       /* transform.c:125-130 */
+    lm_m4_mul(mx, mx, r);
+    lm_m4_scale_aniso(mx, mx, pos_scale[3], pos_scale[3], pos_scale[3]);      /* model.c:1622/1675 */
+}
+
+void clapo_mat4_mul(float out[16], const float a[16], const float b[16])
+{
+    lm_m4_mul(out, a, b);
+}
+
+void clapo_mat4_invert(float out[16], const float m[16])
+{
+    lm_m4_invert(out, m);
+}
+
+/* util.h:188-201: min/max are plain ternaries (NaN-order sensitive, kept literal) */
+#define O_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define O_MAX(a, b) ((a) > (b) ? (a) : (b))
+
+/* model.c:1200-1234 + util.h:104-109 */
+void clapo_aabb_update(const float mx[16], const float a[6], float aabb[6], float center[3])
+{
+    /* corner order of model.c:1207-1216: x-major, then z, then y toggling fastest */
+    const float corners[8][4] = {
+        { a[0], a[1], a[2], 1.0f }, { a[0], a[4], a[2], 1.0f },
+        { a[0], a[1], a[5], 1.0f }, { a[0], a[4], a[5], 1.0f },
+        { a[3], a[1], a[2], 1.0f }, { a[3], a[4], a[2], 1.0f },
+        { a[3], a[1], a[5], 1.0f }, { a[3], a[4], a[5], 1.0f },
+    };
+
+    aabb[0] = aabb[1] = aabb[2] = INFINITY;
+    aabb[3] = aabb[4] = aabb[5] = -INFINITY;
+    for (int i = 0; i < 8; i++) {
+        float v[4];
+        lm_m4_mul_v4_post(v, mx, corners[i]);
+        for (int k = 0; k < 3; k++) {
+            aabb[k]     = O_MIN(v[k], aabb[k]);
+            aabb[3 + k] = O_MAX(v[k], aabb[3 + k]);
+        }
+    }
+    /* aabb_center: (max - min) * 0.5 + min */
+    for (int k = 0; k < 3; k++) {
+        float d = aabb[3 + k] - aabb[k];
+        d = d * 0.5f;
+        center[k] = d + aabb[k];
+    }
+}
+
+/* view.c:296-337 */
+int clapo_aabb_in_frustum(const clapo_frustum *f, const float aabb[6])
+{
+    const float *mn = aabb, *mx = aabb + 3;
+
+    for (int i = 0; i < 6; i++) {
+        int r = 0;
+        /* corner order of view.c:308-323: x toggles fastest, then y, then z */
+        for (int k = 0; k < 8; k++) {
+            float v[4] = { (k & 1) ? mx[0] : mn[0], (k & 2) ? mx[1] : mn[1],
+                           (k & 4) ? mx[2] : mn[2], 1.0f };
+            r += (lm_dot4(f->planes[i], v) < 0.0) ? 1 : 0;
+        }
+        if (r == 8)
+            return 0;
+    }
+
+    for (int ax = 0; ax < 3; ax++) {
+        int r = 0;
+        for (int i = 0; i < 8; i++) r += f->corners[i][ax] > mx[ax] ? 1 : 0;
+        if (r == 8) return 0;
+        r = 0;
+        for (int i = 0; i < 8; i++) r += f->corners[i][ax] < mn[ax] ? 1 : 0;
+        if (r == 8) return 0;
+    }
+    return 1;
+}
+
+uint32_t clapo_entities_update(uint32_t n,
+                               const float *pos_scale, const float *rot,
+                               const int32_t *parent, const int32_t *model,
+                               const float *model_aabb, const uint8_t *model_skip_aabb,
+                               uint32_t *flags, uint32_t *seqs,
+                               float *mx, float *inv_mx, float *aabb, float *center)
+{
+    uint32_t rebuilt = 0;
+
+    for (uint32_t i = 0; i < n; i++) {
+        if (!(flags[i] & CLAPO_E_ALIVE))          /* mq_update: model.c:1955 */
+            continue;
+
+        int dirty = !!(flags[i] & CLAPO_E_DIRTY);
+        uint16_t seq = (uint16_t)(seqs[i] & 0xffff);
+        uint16_t pseq = (uint16_t)(seqs[i] >> 16);
+        int32_t p = parent[i];
+        float *m = mx + 16 * (size_t)i;
+
+        if (p >= 0) {
+            /* parent_transform_apply, jointless attachment: model.c:1609-1625 */
+            uint16_t parent_seq_now = (uint16_t)(seqs[p] & 0xffff);
+            if (pseq == parent_seq_now && !dirty)
+                continue;
+            pseq = parent_seq_now;
+            seq++;
+            float local[16];
+            clapo_trs_matrix(pos_scale + 4 * (size_t)i, rot + 4 * (size_t)i, local);
+            lm_m4_mul(m, mx + 16 * (size_t)p, local);
+        } else {
+            if (!dirty)                             /* model.c:1667 */
+                continue;
+            seq++;
+            clapo_trs_matrix(pos_scale + 4 * (size_t)i, rot + 4 * (size_t)i, m);
+        }
+        flags[i] &= ~CLAPO_E_DIRTY;
+        seqs[i] = (uint32_t)seq | ((uint32_t)pseq << 16);
+
+        lm_m4_invert(inv_mx + 16 * (size_t)i, m);  /* model.c:1643/1676 */
+        if (!model_skip_aabb[model[i]])             /* model.c:1204 */
+            clapo_aabb_update(m, model_aabb + 6 * (size_t)model[i],
+                              aabb + 6 * (size_t)i, center + 3 * (size_t)i);
+        rebuilt++;
+    }
+    return rebuilt;
+}
+
+uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aabb,
+                             const clapo_frustum *f, uint32_t *visible, uint64_t *vis_mask)
+{
+    uint32_t count = 0;
+
+    if (vis_mask)
+        memset(vis_mask, 0, ((size_t)n + 63) / 64 * sizeof(uint64_t));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t fl = flags[i];
+        if (!(fl & CLAPO_E_ALIVE) || !(fl & CLAPO_E_VISIBLE))       /* model.c:959-965 */
+            continue;
+        if (!(fl & CLAPO_E_SKIP_CULLING) &&
+            !clapo_aabb_in_frustum(f, aabb + 6 * (size_t)i))        /* model.c:967-971 */
+            continue;
+        if (visible)
+            visible[count] = i;
+        if (vis_mask)
+            vis_mask[i >> 6] |= 1ull << (i & 63);
+        count++;
+    }
+    return count;
+}

@@ -1,0 +1,308 @@
+/*
+ * oracle/ref/harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Drives the REFERENCE's own hot-path functions (compiled from the sources
+ * where they lie under /root/reference; see Makefile) over flat arrays, so
+ * tests can (1) pin oracle/'s restatement against the real thing and
+ * (2) regenerate tests/golden/.  It is never linked into the product.
+ *
+ * The reference sources are #include'd by absolute path so that their
+ * `static` hot-path functions (default_update, parent_transform_apply,
+ * channels_transform, one_joint_transform, particles_update,
+ * subview_calc_frustum) are callable.  Nothing is copied.
+ *
+ * One test double is defined here: renderer_get_caps().  The reference's
+ * definition (render-common.c:65-68) lives in a TU that needs GL headers this
+ * image lacks; on this path exactly one field of its result is read
+ * (ndc_z_zero_one, view.c:267), which the job file supplies.
+ *
+ * Usage: clap_ref <command> <in.clpio> <out.clpio>
+ *   entities   default_update x frames, then view_entity_in_frustum
+ *   pose       channels_transform + one_joint_transform per character
+ *   particles  particles_update x frames (drand48 stream from a given state)
+ *   bench_entities   time default_update + view_entity_in_frustum
+ */
+/* resolved through -I $(REF)/core (Makefile): /root/reference/core/{model,view,particle}.c */
+#include "model.c"
+#include "view.c"
+#include "particle.c"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <time.h>
+
+const char *build_date = "oracle";
+const char *clap_version = "oracle";
+
+static renderer_caps harness_caps;
+const renderer_caps *renderer_get_caps(renderer_t *r)
+{
+    return &harness_caps;
+}
+
+/* ------------------------------------------------------------------ */
+/* clpio: named flat arrays.  file = "CLPIO1\0\0" u64 count, records  */
+/* record = char name[24], u64 nbytes, payload padded to 8 bytes      */
+/* ------------------------------------------------------------------ */
+#define MAX_ARR 64
+struct arr { char name[24]; uint64_t nbytes; void *data; };
+struct arrset { struct arr a[MAX_ARR]; int n; };
+
+static void die(const char *msg, const char *arg)
+{
+    fprintf(stderr, "clap_ref: %s %s\n", msg, arg ? arg : "");
+    exit(2);
+}
+
+static void clpio_read(const char *path, struct arrset *s)
+{
+    FILE *f = fopen(path, "rb");
+    char magic[8];
+    uint64_t count;
+
+    if (!f) die("cannot open", path);
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "CLPIO1\0\0", 8)) die("bad magic", path);
+    if (fread(&count, 8, 1, f) != 1 || count > MAX_ARR) die("bad count", path);
+    s->n = (int)count;
+    for (int i = 0; i < s->n; i++) {
+        struct arr *a = &s->a[i];
+        if (fread(a->name, 1, 24, f) != 24 || fread(&a->nbytes, 8, 1, f) != 1) die("short read", path);
+        uint64_t padded = (a->nbytes + 7) & ~7ull;
+        a->data = malloc(padded ? padded : 8);
+        if (padded && fread(a->data, 1, padded, f) != padded) die("short payload", a->name);
+    }
+    fclose(f);
+}
+
+static void *arr_get(struct arrset *s, const char *name, uint64_t *nbytes)
+{
+    for (int i = 0; i < s->n; i++)
+        if (!strncmp(s->a[i].name, name, 24)) {
+            if (nbytes) *nbytes = s->a[i].nbytes;
+            return s->a[i].data;
+        }
+    die("missing array", name);
+    return NULL;
+}
+
+static int arr_has(struct arrset *s, const char *name)
+{
+    for (int i = 0; i < s->n; i++)
+        if (!strncmp(s->a[i].name, name, 24))
+            return 1;
+    return 0;
+}
+
+static void *arr_add(struct arrset *s, const char *name, uint64_t nbytes)
+{
+    struct arr *a = &s->a[s->n++];
+    if (s->n > MAX_ARR) die("too many outputs", name);
+    memset(a->name, 0, 24);
+    strncpy(a->name, name, 23);
+    a->nbytes = nbytes;
+    a->data = calloc(1, ((nbytes + 7) & ~7ull) + 8);
+    return a->data;
+}
+
+static void clpio_write(const char *path, struct arrset *s)
+{
+    FILE *f = fopen(path, "wb");
+    uint64_t count = s->n;
+
+    if (!f) die("cannot write", path);
+    fwrite("CLPIO1\0\0", 1, 8, f);
+    fwrite(&count, 8, 1, f);
+    for (int i = 0; i < s->n; i++) {
+        struct arr *a = &s->a[i];
+        fwrite(a->name, 1, 24, f);
+        fwrite(&a->nbytes, 8, 1, f);
+        fwrite(a->data, 1, (a->nbytes + 7) & ~7ull, f);
+    }
+    fclose(f);
+}
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+/* ------------------------------------------------------------------ */
+/* entity fixtures                                                     */
+/* ------------------------------------------------------------------ */
+struct ent_world {
+    uint32_t    n, n_models;
+    entity3d    *e;
+    model3d     *m;
+    model3dtx   *txm;
+};
+
+/* Mirrors what entity3d_make sets (model.c:1735-1744) without a renderer. */
+static void world_make(struct ent_world *w, uint32_t n, uint32_t n_models,
+                       const float *model_aabb, const uint8_t *model_skip,
+                       const int32_t *model_of, const int32_t *parent, const uint32_t *flags)
+{
+    w->n = n;
+    w->n_models = n_models;
+    w->e = calloc(n, sizeof(entity3d));
+    w->m = calloc(n_models, sizeof(model3d));
+    w->txm = calloc(n_models, sizeof(model3dtx));
+    for (uint32_t k = 0; k < n_models; k++) {
+        memcpy(w->m[k].aabb, model_aabb + 6 * k, 6 * sizeof(float));
+        w->m[k].skip_aabb = model_skip[k];
+        w->txm[k].model = &w->m[k];
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        entity3d *e = &w->e[i];
+        e->txmodel = &w->txm[model_of[i]];
+        transform_init(&e->xform);
+        e->scale = 1.0;
+        e->parent_joint = JOINT_TYPE_MAX;
+        e->light_idx = -1;
+        e->flags = flags[i] & ~(1u << 16);   /* bit 16 is the shim's dirty mirror, not a reference flag */
+        e->parent = parent[i] >= 0 ? &w->e[parent[i]] : NULL;
+        e->update = default_update;
+    }
+}
+
+static void view_setup(struct view *view, struct arrset *in, struct arrset *out)
+{
+    float *cam_pos = arr_get(in, "cam_pos", NULL);
+    float *cam_quat = arr_get(in, "cam_quat", NULL);
+    float *persp = arr_get(in, "persp", NULL);          /* fov, aspect, near, far */
+    uint32_t ndcz01 = *(uint32_t *)arr_get(in, "ndc_z_zero_one", NULL);
+    transform_t cam;
+
+    memset(view, 0, sizeof(*view));
+    harness_caps.ndc_z_zero_one = ndcz01;
+    transform_init(&cam);
+    transform_set_pos(&cam, cam_pos);
+    transform_set_quat(&cam, cam_quat);
+
+    transform_view_mat4x4(&cam, view->main.view_mx);                 /* view.c:165-169 */
+    mat4x4_invert(view->main.inv_view_mx, view->main.view_mx);
+    /* render-common.c:77-82 dispatch */
+    if (ndcz01)
+        mat4x4_perspective_ndc_z_1(view->main.proj_mx, persp[0], persp[1], persp[2], persp[3]);
+    else
+        mat4x4_perspective_ndc_z_2(view->main.proj_mx, persp[0], persp[1], persp[2], persp[3]);
+    subview_calc_frustum(&view->main, NULL);                          /* view.c:248 */
+
+    memcpy(arr_add(out, "view_mx", 64), view->main.view_mx, 64);
+    memcpy(arr_add(out, "proj_mx", 64), view->main.proj_mx, 64);
+    memcpy(arr_add(out, "planes", 96), view->main.frustum_planes, 96);
+    memcpy(arr_add(out, "corners", 128), view->main.frustum_corners, 128);
+}
+
+static int cmd_entities(struct arrset *in, struct arrset *out)
+{
+    uint32_t n = *(uint32_t *)arr_get(in, "n", NULL);
+    uint32_t frames = *(uint32_t *)arr_get(in, "frames", NULL);
+    uint64_t mbytes;
+    float *model_aabb = arr_get(in, "model_aabb", &mbytes);
+    uint32_t n_models = mbytes / 24;
+    uint8_t *model_skip = arr_get(in, "model_skip", NULL);
+    int32_t *model_of = arr_get(in, "model", NULL);
+    int32_t *parent = arr_get(in, "parent", NULL);
+    uint32_t *flags = arr_get(in, "flags", NULL);
+    float *pos_scale = arr_get(in, "pos_scale", NULL);     /* [frames][n][4] */
+    float *rot = arr_get(in, "rot", NULL);                 /* [frames][n][4] */
+    uint8_t *dirty = arr_get(in, "dirty", NULL);           /* [frames][n]    */
+    struct ent_world w;
+    struct view view;
+
+    world_make(&w, n, n_models, model_aabb, model_skip, model_of, parent, flags);
+    view_setup(&view, in, out);
+
+    float *o_mx = arr_add(out, "mx", (uint64_t)frames * n * 64);
+    float *o_inv = arr_add(out, "inv_mx", (uint64_t)frames * n * 64);
+    float *o_aabb = arr_add(out, "aabb", (uint64_t)frames * n * 24);
+    float *o_ctr = arr_add(out, "center", (uint64_t)frames * n * 12);
+    uint32_t *o_seq = arr_add(out, "seqs", (uint64_t)frames * n * 4);
+    uint8_t *o_vis = arr_add(out, "visible", (uint64_t)frames * n);
+
+    for (uint32_t f = 0; f < frames; f++) {
+        for (uint32_t i = 0; i < n; i++) {
+            size_t k = (size_t)f * n + i;
+            entity3d *e = &w.e[i];
+            if (!dirty[k])
+                continue;
+            /* the public mutators a game would use (model.c:1810-1842, transform.c:35-79) */
+            transform_set_pos(&e->xform, &pos_scale[4 * k]);
+            transform_set_quat(&e->xform, &rot[4 * k]);
+            e->scale = pos_scale[4 * k + 3];
+        }
+        /* mq_update (model.c:1953): ALIVE entities, list order == index order */
+        for (uint32_t i = 0; i < n; i++)
+            if (entity3d_matches(&w.e[i], ENTITY3D_ALIVE))
+                entity3d_update(&w.e[i], NULL);
+        for (uint32_t i = 0; i < n; i++) {
+            size_t k = (size_t)f * n + i;
+            entity3d *e = &w.e[i];
+            memcpy(o_mx + 16 * k, e->mx, 64);
+            memcpy(o_inv + 16 * k, e->inverse_mx, 64);
+            memcpy(o_aabb + 6 * k, e->aabb, 24);
+            memcpy(o_ctr + 3 * k, e->aabb_center, 12);
+            o_seq[k] = (uint32_t)e->seq | ((uint32_t)e->parent_seq << 16);
+            /* draw predicate of _models_render (model.c:959-973) */
+            o_vis[k] = entity3d_matches(e, ENTITY3D_ALIVE) && entity3d_matches(e, ENTITY3D_VISIBLE) &&
+                       (entity3d_matches(e, ENTITY3D_SKIP_CULLING) || view_entity_in_frustum(&view, e));
+        }
+    }
+    return 0;
+}
+
+static int cmd_bench_entities(struct arrset *in, struct arrset *out)
+{
+    uint32_t n = *(uint32_t *)arr_get(in, "n", NULL);
+    uint32_t reps = *(uint32_t *)arr_get(in, "reps", NULL);
+    uint64_t mbytes;
+    float *model_aabb = arr_get(in, "model_aabb", &mbytes);
+    uint32_t n_models = mbytes / 24;
+    struct ent_world w;
+    struct view view;
+    float *pos_scale = arr_get(in, "pos_scale", NULL);
+    float *rot = arr_get(in, "rot", NULL);
+
+    world_make(&w, n, n_models, model_aabb, arr_get(in, "model_skip", NULL), arr_get(in, "model", NULL),
+               arr_get(in, "parent", NULL), arr_get(in, "flags", NULL));
+    view_setup(&view, in, out);
+
+    double best = 1e30, total = 0;
+    uint64_t visible = 0;
+    for (uint32_t r = 0; r < reps; r++) {
+        for (uint32_t i = 0; i < n; i++) {       /* untimed: mark everything dirty */
+            transform_set_pos(&w.e[i].xform, &pos_scale[4 * (size_t)i]);
+            transform_set_quat(&w.e[i].xform, &rot[4 * (size_t)i]);
+            w.e[i].scale = pos_scale[4 * (size_t)i + 3];
+        }
+        double t0 = now_s();
+        for (uint32_t i = 0; i < n; i++)
+            entity3d_update(&w.e[i], NULL);
+        visible = 0;
+        for (uint32_t i = 0; i < n; i++)
+            visible += view_entity_in_frustum(&view, &w.e[i]);
+        double dt = now_s() - t0;
+        total += dt;
+        if (dt < best) best = dt;
+    }
+    double *o = arr_add(out, "seconds", 24);
+    o[0] = best; o[1] = total / reps; o[2] = (double)visible;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    struct arrset in = {}, out = {};
+    int rc;
+
+    if (argc != 4) die("usage: clap_ref <entities|bench_entities> <in> <out>", NULL);
+    clpio_read(argv[2], &in);
+    if (!strcmp(argv[1], "entities"))             rc = cmd_entities(&in, &out);
+    else if (!strcmp(argv[1], "bench_entities"))  rc = cmd_bench_entities(&in, &out);
+    else die("unknown command", argv[1]);
+    clpio_write(argv[3], &out);
+    return rc;
+}

@@ -1,0 +1,77 @@
+"""Runner for oracle/_ref/clap_ref (the real reference code) -- TEST INFRASTRUCTURE ONLY.
+
+The binary is built from /root/reference in the build container
+(``make -C oracle/ref``) and travels to the GPU box prebuilt; it is absent
+wherever it was never built, and callers must check ``available()``.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from . import clpio
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(_HERE, "_ref", "clap_ref")
+REF_ROOT = "/root/reference"
+
+
+def available():
+    return os.path.exists(BIN) and os.access(BIN, os.X_OK)
+
+
+def build():
+    """(Re)build from /root/reference when it is present; no-op otherwise."""
+    if os.path.isdir(os.path.join(REF_ROOT, "core")):
+        subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "ref")], check=True)
+
+
+def run(command, arrays, timeout=600):
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.clpio"), os.path.join(td, "out.clpio")
+        clpio.write(fin, arrays)
+        subprocess.run([BIN, command, fin, fout], check=True, timeout=timeout)
+        return clpio.read(fout)
+
+
+def _camera_arrays(cam):
+    return {k: cam[k] for k in ("cam_pos", "cam_quat", "persp", "ndc_z_zero_one")}
+
+
+def entities(scene, cam, frames=None):
+    """Run default_update x frames + view_entity_in_frustum on the reference.
+
+    frames: list of (pos_scale, rot, dirty) per frame; default = one frame, the
+    scene's own arrays with every entity dirty.
+    """
+    n = int(scene["n"])
+    if frames is None:
+        frames = [(scene["pos_scale"], scene["rot"], np.ones(n, np.uint8))]
+    f = len(frames)
+    arrays = dict(n=np.asarray([n], np.uint32), frames=np.asarray([f], np.uint32),
+                  pos_scale=np.stack([fr[0] for fr in frames]).astype(np.float32),
+                  rot=np.stack([fr[1] for fr in frames]).astype(np.float32),
+                  dirty=np.stack([fr[2] for fr in frames]).astype(np.uint8),
+                  parent=scene["parent"], model=scene["model"], model_aabb=scene["model_aabb"],
+                  model_skip=scene["model_skip"], flags=scene["flags"])
+    arrays.update(_camera_arrays(cam))
+    out = run("entities", arrays)
+    A = clpio.as_array
+    return dict(mx=A(out["mx"], np.float32, (f, n, 16)), inv_mx=A(out["inv_mx"], np.float32, (f, n, 16)),
+                aabb=A(out["aabb"], np.float32, (f, n, 6)), center=A(out["center"], np.float32, (f, n, 3)),
+                seqs=A(out["seqs"], np.uint32, (f, n)), visible=A(out["visible"], np.uint8, (f, n)),
+                view_mx=A(out["view_mx"], np.float32), proj_mx=A(out["proj_mx"], np.float32),
+                planes=A(out["planes"], np.float32, (6, 4)), corners=A(out["corners"], np.float32, (8, 4)))
+
+
+def bench_entities(scene, cam, reps=5):
+    n = int(scene["n"])
+    arrays = dict(n=np.asarray([n], np.uint32), reps=np.asarray([reps], np.uint32),
+                  pos_scale=scene["pos_scale"], rot=scene["rot"], parent=scene["parent"],
+                  model=scene["model"], model_aabb=scene["model_aabb"], model_skip=scene["model_skip"],
+                  flags=scene["flags"])
+    arrays.update(_camera_arrays(cam))
+    out = run("bench_entities", arrays)
+    best, mean, visible = clpio.as_array(out["seconds"], np.float64)
+    return dict(best_s=float(best), mean_s=float(mean), visible=int(visible))
