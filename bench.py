@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- the entity transform + cull hot path on N MI355X of one node.
+
+A "step" is one frame of BASELINE.json configs[1] on every GPU: 1M entities in a
+depth-8 transform hierarchy (125k chains x 8, synthetic, seed 2+rank), every entity
+dirty, resident in HBM: TRS -> world matrix -> inverse -> world AABB -> frustum cull
+-> ascending visible-index list.  With N > 1 each rank owns an independent entity
+range (weak scaling, no data-path collective) and the only exchange is the RCCL
+allgather of the compacted visible set.
+
+Prints ONE JSON line (rank 0).  `value` = entity updates / s over all GPUs.
+`roofline` = algorithmic bytes of the per-level update kernel / its mean duration
+measured with HIP events around every launch (a separate pass after the timed
+region, same process, same data).  `cpu_baseline` = the reference's own
+default_update + view_entity_in_frustum (oracle/_ref, built from the reference
+sources) on one host core, or the oracle port if that binary is absent.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ROUND = "r01"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chains", type=int, default=125_000, help="hierarchy chains per GPU (x depth = entities)")
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, cam, frames):
+    """Reported baseline, not the target: the reference (or the port) on one host core."""
+    from oracle import binding as ob, refrun
+    n_real = int(scene["n_real"])
+    cores = 1
+    if refrun.available():
+        r = refrun.bench_entities(scene, cam, reps=frames)
+        return dict(value=n_real / r["mean_s"], unit="entity updates/s", cores=cores, kind="reference",
+                    sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty): the reference's "
+                           "default_update + view_entity_in_frustum (core/model.c, core/view.c; ROCm clang -O2 "
+                           f"-ffp-contract=off), 1 thread; best frame {n_real / r['best_s']:.3e}/s")
+    fr, _v, _p = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    t = []
+    for _ in range(frames):
+        st["flags"] |= np.where(st["flags"] & 0x80000000, 1 << 16, 0).astype(np.uint32)
+        t0 = time.perf_counter()
+        ob.entities_update(scene, st)
+        ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr)
+        t.append(time.perf_counter() - t0)
+    return dict(value=n_real / (sum(t) / len(t)), unit="entity updates/s", cores=cores, kind="port",
+                sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty), oracle/ C "
+                       "restatement (gcc -O2 -ffp-contract=off), 1 thread")
+
+
+def pmc_traffic():
+    """HBM bytes per k_entities_level launch from the committed PMC summary, if one exists."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_entities_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from clap_amd import _lib, entities, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    _lib.check(_lib.lib().clapgpu_init(local_rank), "clapgpu_init")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    scene = synth.pad_levels(synth.entities_chains(args.chains, args.depth, seed=2 + rank))
+    cam = synth.camera()
+    fr, _view, _proj = entities.view_calc_frustum(cam)
+    batch = entities.EntityBatch(scene, device)
+    n_real, n_pad = batch.n_real, batch.n
+    index_base = rank * n_pad
+
+    counts = torch.zeros(world, dtype=torch.int32, device=device)
+    gather_buf = torch.zeros(world * n_pad if world > 1 else 1, dtype=torch.int32, device=device)
+
+    def step():
+        batch.mq_update(fr, all_dirty=True)             # one launch per hierarchy level
+        batch.compact_visible(index_base)               # ordered visible list (global ids)
+        if world > 1:
+            # the path's only exchange: every rank ends with all shards' visible ids.
+            dist.all_gather_into_tensor(counts, batch.visible_count)
+            cap = (int(counts.max().item()) + 4095) // 4096 * 4096
+            cap = min(max(cap, 4096), n_pad)
+            dist.all_gather_into_tensor(gather_buf[:world * cap], batch.visible[:cap])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_real * args.steps / elapsed
+    visible = int(batch.visible_count.item())
+
+    # ---- roofline pass: HIP events around every k_entities_level launch (same stream) ----
+    n_levels = batch.n_levels
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(n_levels)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    for s in range(args.steps):
+        for l in range(n_levels):
+            ev[s][l][0].record()
+            batch.update_level(l, fr, all_dirty=True)
+            ev[s][l][1].record()
+        batch.compact_visible(index_base)
+    torch.cuda.synchronize()
+    lvl_ms = np.asarray([[a.elapsed_time(b) for a, b in row] for row in ev])       # [steps][levels]
+    mean_launch_s = float(lvl_ms.mean()) * 1e-3
+    alg_bytes_step = batch.algorithmic_bytes()                                       # 276 B/child, 212 B/root
+    alg_bytes_launch = alg_bytes_step / n_levels
+    achieved = alg_bytes_launch / mean_launch_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "entity updates/sec (transform hierarchy + inverse + AABB + frustum cull + visible list)",
+            "value": value, "unit": "entity updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
+                                   f"{args.depth}, level-major SoA, all dirty, fused frustum cull + ordered visible "
+                                   f"list ({visible} visible on rank 0)",
+                       "entities_per_gpu": n_real, "levels": n_levels,
+                       "exchange": "RCCL allgather of visible ids" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                         "kernel": "k_entities_level<true>", "launches_per_step": n_levels,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "mean_launch_us": mean_launch_s * 1e6,
+                         "per_level_us": [float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of clap_amd/lib/libclapgpu.so (the C ABI of include/clapgpu.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails the
+binding raises.  Nothing here imports ``oracle``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+OK = 0
+ERR_NOMEM = -1
+ERR_INVALID_ARGUMENTS = -2
+ERR_NOT_SUPPORTED = -3
+ERR_TOO_LARGE = -11
+ERR_INIT_FAILED = -14
+ERR_OUT_OF_BOUNDS = -26
+ERR_UNKNOWN = -32
+
+E_VISIBLE = 1 << 0
+E_SKIP_CULLING = 1 << 14
+E_DIRTY = 1 << 16
+E_ALIVE = 1 << 31
+UPDATE_ALL_DIRTY = 1 << 0
+
+_ERR_NAMES = {ERR_NOMEM: "NOMEM", ERR_INVALID_ARGUMENTS: "INVALID_ARGUMENTS", ERR_NOT_SUPPORTED: "NOT_SUPPORTED",
+              ERR_TOO_LARGE: "TOO_LARGE", ERR_INIT_FAILED: "INITIALIZATION_FAILED",
+              ERR_OUT_OF_BOUNDS: "OUT_OF_BOUNDS", ERR_UNKNOWN: "UNKNOWN_ERROR"}
+
+
+class ClapGpuError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: CERR_{_ERR_NAMES.get(code, code)} ({code}) {detail}".rstrip())
+
+
+class Frustum(C.Structure):
+    """clapgpu_frustum: planes[6][4], corners[8][4] (view.h:16-17)."""
+    _fields_ = [("planes", C.c_float * 24), ("corners", C.c_float * 32)]
+
+
+class Entities(C.Structure):
+    """clapgpu_entities (include/clapgpu.h)."""
+    _fields_ = [("n", C.c_uint32), ("n_models", C.c_uint32),
+                ("pos_scale", C.c_void_p), ("rot", C.c_void_p), ("parent", C.c_void_p),
+                ("model", C.c_void_p), ("model_table", C.c_void_p), ("flags", C.c_void_p),
+                ("seqs", C.c_void_p), ("mx", C.c_void_p), ("inv_mx", C.c_void_p),
+                ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p)]
+
+
+# every symbol include/clapgpu.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "clapgpu_device_count": (C.c_int, []),
+    "clapgpu_init": (C.c_int, [C.c_int]),
+    "clapgpu_last_error": (C.c_char_p, []),
+    "clapgpu_abi_version": (C.c_uint32, []),
+    "clapgpu_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "clapgpu_free": (C.c_int, [C.c_void_p]),
+    "clapgpu_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clapgpu_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "clapgpu_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "clapgpu_stream_sync": (C.c_int, [C.c_void_p]),
+    "clapgpu_view_matrix": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "clapgpu_perspective": (None, [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float)]),
+    "clapgpu_frustum_calc": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(Frustum)]),
+    "clapgpu_entities_update": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.POINTER(C.c_uint32), C.c_uint32,
+                                          C.c_uint32, C.POINTER(Frustum)]),
+    "clapgpu_entities_update_level": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.POINTER(Frustum)]),
+    "clapgpu_entities_cull": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.POINTER(Frustum)]),
+    "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
+    "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into clap_amd/lib/libclapgpu.so (needs hipcc, no GPU)."""
+    subprocess.run(["make", "-C", CSRC] + ([] if verbose else ["-s"]), check=True)
+
+
+def lib():
+    """Load the library; raise loudly if it is missing or its ABI differs."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ClapGpuError(ERR_INIT_FAILED, "clap_amd",
+                               f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)           # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.clapgpu_abi_version() != ABI_VERSION:
+            raise ClapGpuError(ERR_INIT_FAILED, "clap_amd", "libclapgpu ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != OK:
+        detail = lib().clapgpu_last_error()
+        raise ClapGpuError(rc, where, detail.decode() if detail else "")

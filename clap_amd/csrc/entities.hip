@@ -1,0 +1,384 @@
+// entities.hip -- entity transform hierarchy -> inverse -> world AABB -> frustum cull
+// for gfx950 (MI355X).  One lane per entity, one launch per hierarchy level.
+//
+// Replaces, per entity, the reference's default_update() transform branch
+// (model.c:1649-1695), parent_transform_apply() jointless attachment
+// (model.c:1594-1647), mat4x4_invert (linmath.h:611-651), entity3d_aabb_update
+// (model.c:1200-1234) and the draw predicate of _models_render with
+// view_entity_in_frustum (model.c:959-973, view.c:296-337).
+//
+// HBM-bound: ~276 algorithmic bytes / entity.  Inputs are read as
+// coalesced float4 / dword streams, the parent matrix as 4 x 16 B per lane, and
+// every output row block (64 entities x 64 / 64 / 24 / 12 B) is transposed through
+// a wave-private LDS tile so each store instruction writes 1 KiB contiguous.
+#include <string.h>
+#include "common.h"
+#include "lm_dev.h"
+
+namespace clapgpu {
+
+struct EntK {                    // kernel-argument copy of clapgpu_entities
+    const float4   *pos_scale;
+    const float4   *rot;
+    const int32_t  *parent;
+    const int32_t  *model;
+    const float4   *model_table;
+    uint32_t       *flags;
+    uint32_t       *seqs;
+    float          *mx;
+    float          *inv_mx;
+    float          *aabb;
+    float          *center;
+    uint64_t       *vis_mask;
+};
+
+constexpr int ENT_BLOCK = 256;
+
+__device__ __forceinline__ void load_mat4(float (&m)[16], const float *src)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float4 v = p[c];
+        m[4 * c] = v.x; m[4 * c + 1] = v.y; m[4 * c + 2] = v.z; m[4 * c + 3] = v.w;
+    }
+}
+
+// first is a multiple of 64, so (first + blockIdx*256 + tid) / 64 is this wave's
+// vis_mask word and no other wave of any launch touches it.
+template <bool CULL>
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::Frustum fr)
+{
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];          // 4 KiB per wave
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    const uint32_t local = blockIdx.x * ENT_BLOCK + threadIdx.x; // index inside the level
+    const uint32_t wave_local0 = local - lane;
+    const bool in_range = local < count;
+    const uint32_t i = first + (in_range ? local : 0);           // clamp: idle lanes read entity `first`
+    float4 *tile = lds_tiles[wave];
+
+    const uint32_t fl = e.flags[i];
+    const bool alive = in_range && (fl & CLAPGPU_E_ALIVE);
+    const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
+    const int32_t p = e.parent[i];
+    uint32_t sq = e.seqs[i];
+    uint32_t seq = sq & 0xffffu, pseq = sq >> 16;
+
+    // parent_transform_apply's skip test (model.c:1609-1611) / default_update's dirty test (1667)
+    bool rebuild = alive;
+    if (p >= 0) {
+        const uint32_t parent_seq_now = e.seqs[p] & 0xffffu;
+        if (pseq == parent_seq_now && !dirty)
+            rebuild = false;
+        else
+            pseq = parent_seq_now;
+    } else if (!dirty) {
+        rebuild = false;
+    }
+
+    float mx[16], inv[16], bb[6], ctr[3];
+    bool has_aabb = false;
+
+    if (rebuild) {
+        const float4 ps = e.pos_scale[i];
+        const float4 q = e.rot[i];
+        float local_mx[16];
+        lmd::trs(local_mx, ps.x, ps.y, ps.z, ps.w, q.x, q.y, q.z, q.w);
+        if (p >= 0) {
+            float pm[16];
+            load_mat4(pm, e.mx + 16 * (size_t)p);
+            lmd::mul(mx, pm, local_mx);                          // model.c:1625
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
+        }
+        lmd::invert(inv, mx);
+
+        const int32_t mi = e.model[i];
+        const float4 lo = e.model_table[2 * mi];                 // min.xyz, skip_aabb bits
+        const float4 hi = e.model_table[2 * mi + 1];             // max.xyz, 0
+        has_aabb = __float_as_uint(lo.w) == 0u;                  // model.c:1204
+        if (has_aabb)
+            lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+
+        seq = (seq + 1) & 0xffffu;                               // uint16 wrap (model.h:404)
+        e.seqs[i] = seq | (pseq << 16);
+        if (!(mode & CLAPGPU_UPDATE_ALL_DIRTY) && (fl & CLAPGPU_E_DIRTY))
+            e.flags[i] = fl & ~CLAPGPU_E_DIRTY;                  // transform_clear_updated
+    }
+
+    // ---- stores: whole-wave fast path when all 64 lanes rebuilt (the common case) ----
+    const uint64_t rebuilt_mask = __ballot(rebuild);
+    const uint64_t aabb_mask = __ballot(rebuild && has_aabb);
+    const uint32_t wave_count = count - wave_local0 < WAVE ? count - wave_local0 : WAVE;   // valid lanes
+    const uint64_t full = wave_count == WAVE ? ~0ull : ((1ull << wave_count) - 1ull);
+    const size_t e0 = (size_t)first + wave_local0;               // first entity of this wave
+
+    if (wave_local0 < count) {
+        if (rebuilt_mask == full) {
+            wave_store_mat4(tile, e.mx + 16 * e0, mx, lane, (int)wave_count);
+            wave_store_mat4(tile, e.inv_mx + 16 * e0, inv, lane, (int)wave_count);
+        } else if (rebuild) {
+            float4 *dm = reinterpret_cast<float4 *>(e.mx + 16 * (size_t)i);
+            float4 *di = reinterpret_cast<float4 *>(e.inv_mx + 16 * (size_t)i);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                dm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
+                di[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
+            }
+        }
+        if (aabb_mask == full) {
+            wave_store_rows<6>(reinterpret_cast<float *>(tile), e.aabb + 6 * e0, bb, lane, (int)wave_count);
+            wave_store_rows<3>(reinterpret_cast<float *>(tile), e.center + 3 * e0, ctr, lane, (int)wave_count);
+        } else if (rebuild && has_aabb) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) e.aabb[6 * (size_t)i + k] = bb[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
+        }
+    }
+
+    if (CULL) {
+        // Entities that were not rebuilt (or whose model skips AABBs) are culled on their stored box.
+        if (in_range && !(rebuild && has_aabb)) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb[k] = e.aabb[6 * (size_t)i + k];
+        }
+        bool vis = in_range && (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);   // model.c:959-965
+        if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
+            vis = lmd::aabb_in_frustum(fr, bb);                                       // model.c:967-971
+        const uint64_t m = __ballot(vis);
+        if (lane == 0 && wave_local0 < count)
+            e.vis_mask[e0 >> 6] = m;
+    }
+}
+
+// Cull-only pass over stored AABBs (one per render pass in the reference).
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint32_t n,
+                     lmd::Frustum fr)
+{
+    const uint32_t i = blockIdx.x * ENT_BLOCK + threadIdx.x;
+    bool vis = false;
+    if (i < n) {
+        const uint32_t fl = flags[i];
+        vis = (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);
+        if (vis && !(fl & CLAPGPU_E_SKIP_CULLING)) {
+            float bb[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb[k] = aabb[6 * (size_t)i + k];
+            vis = lmd::aabb_in_frustum(fr, bb);
+        }
+    }
+    const uint64_t m = __ballot(vis);
+    if (lane_id() == 0 && (i - lane_id()) < n)
+        vis_mask[i >> 6] = m;
+}
+
+// ---- ordered compaction of the visibility bitmask ----
+// A group = 64 mask words = 4096 entities = one wave.
+constexpr int GROUP_WORDS = 64;
+
+__device__ __forceinline__ uint64_t load_mask_word(const uint64_t *vis_mask, uint32_t w, uint32_t n)
+{
+    const uint32_t nwords = (n + 63) / 64;
+    if (w >= nwords)
+        return 0;
+    uint64_t v = vis_mask[w];
+    const uint32_t rem = n - w * 64;                 // entities covered by this word
+    if (rem < 64)
+        v &= (1ull << rem) - 1ull;                   // bits past n are padding
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(WAVE)
+void k_mask_group_count(const uint64_t *vis_mask, uint32_t n, uint32_t *group_count)
+{
+    const uint32_t w = blockIdx.x * GROUP_WORDS + threadIdx.x;
+    const uint32_t c = wave_sum(__popcll(load_mask_word(vis_mask, w, n)));
+    if (threadIdx.x == 0)
+        group_count[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(WAVE)
+void k_visible_expand(const uint64_t *vis_mask, uint32_t n, const uint32_t *group_count,
+                      uint32_t n_groups, uint32_t index_base, uint32_t *visible, uint32_t *count)
+{
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+
+    uint32_t pre = 0;                                 // visible entities in groups before g
+    for (uint32_t j = lane; j < g; j += WAVE)
+        pre += group_count[j];
+    pre = wave_sum(pre);
+
+    const uint64_t word = load_mask_word(vis_mask, g * GROUP_WORDS + lane, n);
+    const uint32_t cnt = __popcll(word);
+    uint32_t incl = cnt;                              // inclusive scan of per-word counts over lanes
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - cnt;
+
+    // one mask word per iteration: lane l owns bit l, ranks come from the bits below it,
+    // so the 4-byte stores of an iteration are contiguous and ascending.
+    for (int k = 0; k < GROUP_WORDS; k++) {
+        const uint64_t wk = __shfl(word, k);
+        if (wk == 0) continue;                        // wave-uniform
+        const uint32_t base = pre + __shfl(excl, k);
+        if ((wk >> lane) & 1ull) {
+            const uint32_t rank = __popcll(wk & ((1ull << lane) - 1ull));
+            visible[base + rank] = index_base + (g * GROUP_WORDS + k) * 64u + lane;
+        }
+    }
+    if (g == n_groups - 1 && lane == WAVE - 1)
+        *count = pre + incl;
+}
+
+} // namespace clapgpu
+
+using namespace clapgpu;
+
+static EntK to_kernel_args(const clapgpu_entities *e)
+{
+    EntK k;
+    k.pos_scale = reinterpret_cast<const float4 *>(e->pos_scale);
+    k.rot = reinterpret_cast<const float4 *>(e->rot);
+    k.parent = e->parent;
+    k.model = e->model;
+    k.model_table = reinterpret_cast<const float4 *>(e->model_table);
+    k.flags = e->flags;
+    k.seqs = e->seqs;
+    k.mx = e->mx;
+    k.inv_mx = e->inv_mx;
+    k.aabb = e->aabb;
+    k.center = e->center;
+    k.vis_mask = e->vis_mask;
+    return k;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_entities(const clapgpu_entities *e, bool need_mask)
+{
+    if (!e || !e->pos_scale || !e->rot || !e->parent || !e->model || !e->model_table || !e->flags ||
+        !e->seqs || !e->mx || !e->inv_mx || !e->aabb || !e->center)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (need_mask && !e->vis_mask)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!aligned16(e->pos_scale) || !aligned16(e->rot) || !aligned16(e->model_table) || !aligned16(e->mx) ||
+        !aligned16(e->inv_mx) || !aligned16(e->aabb) || !aligned16(e->center))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    return CLAPGPU_OK;
+}
+
+static int launch_level(void *stream, const EntK &k, uint32_t first, uint32_t count, uint32_t mode,
+                        const clapgpu_frustum *frustum)
+{
+    static_assert(sizeof(lmd::Frustum) == sizeof(clapgpu_frustum), "frustum layout");
+    lmd::Frustum fr = {};
+    if (frustum)
+        memcpy(&fr, frustum, sizeof(fr));
+    const dim3 grid((count + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
+    if (frustum)
+        hipLaunchKernelGGL(k_entities_level<true>, grid, block, 0, as_stream(stream), k, first, count, mode, fr);
+    else
+        hipLaunchKernelGGL(k_entities_level<false>, grid, block, 0, as_stream(stream), k, first, count, mode, fr);
+    CLAPGPU_LAUNCH_CHECK("k_entities_level");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_update_level(void *stream, const clapgpu_entities *e,
+                                             uint32_t first, uint32_t count,
+                                             uint32_t mode, const clapgpu_frustum *frustum)
+{
+    int rc = check_entities(e, frustum != nullptr);
+    if (rc) return rc;
+    if (first & 63u)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (first > e->n || count > e->n - first)
+        return CLAPGPU_ERR_OUT_OF_BOUNDS;
+    if (!count)
+        return CLAPGPU_OK;
+    return launch_level(stream, to_kernel_args(e), first, count, mode, frustum);
+}
+
+extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
+                                       const uint32_t *level_start, uint32_t n_levels,
+                                       uint32_t mode, const clapgpu_frustum *frustum)
+{
+    int rc = check_entities(e, frustum != nullptr);
+    if (rc) return rc;
+    if (!level_start || (e->n && !n_levels))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->n == 0)
+        return CLAPGPU_OK;
+    if (level_start[0] != 0 || level_start[n_levels] != e->n)
+        return CLAPGPU_ERR_OUT_OF_BOUNDS;
+    for (uint32_t l = 0; l < n_levels; l++)
+        if (level_start[l] > level_start[l + 1] || (level_start[l] & 63u))
+            return CLAPGPU_ERR_INVALID_ARGUMENTS;
+
+    const EntK k = to_kernel_args(e);
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t first = level_start[l], count = level_start[l + 1] - first;
+        if (!count)
+            continue;
+        rc = launch_level(stream, k, first, count, mode, frustum);
+        if (rc) return rc;
+    }
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum)
+{
+    if (!e || !frustum || !e->flags || !e->aabb || !e->vis_mask)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->n == 0)
+        return CLAPGPU_OK;
+    lmd::Frustum fr;
+    memcpy(&fr, frustum, sizeof(fr));
+    const dim3 grid((e->n + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
+    hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask, e->n, fr);
+    CLAPGPU_LAUNCH_CHECK("k_entities_cull");
+    return CLAPGPU_OK;
+}
+
+extern "C" size_t clapgpu_visible_scratch_bytes(uint32_t n)
+{
+    const uint32_t n_groups = (n + GROUP_WORDS * 64 - 1) / (GROUP_WORDS * 64);
+    return (size_t)(n_groups ? n_groups : 1) * sizeof(uint32_t);
+}
+
+extern "C" int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, uint32_t n,
+                                       uint32_t index_base, uint32_t *visible, uint32_t *count,
+                                       void *scratch)
+{
+    if (!count || (n && (!vis_mask || !visible || !scratch)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (n == 0) {
+        CLAPGPU_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), as_stream(stream)));
+        return CLAPGPU_OK;
+    }
+    const uint32_t n_groups = (n + GROUP_WORDS * 64 - 1) / (GROUP_WORDS * 64);
+    uint32_t *group_count = static_cast<uint32_t *>(scratch);
+    hipLaunchKernelGGL(k_mask_group_count, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), vis_mask, n, group_count);
+    CLAPGPU_LAUNCH_CHECK("k_mask_group_count");
+    hipLaunchKernelGGL(k_visible_expand, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), vis_mask, n,
+                       group_count, n_groups, index_base, visible, count);
+    CLAPGPU_LAUNCH_CHECK("k_visible_expand");
+    return CLAPGPU_OK;
+}

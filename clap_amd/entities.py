@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference's entity update / cull interface over device SoA.
+
+Names follow the reference: ``mq_update`` (model.c:1953), ``view_entity_in_frustum``
+(view.c:296), ``view_calc_frustum`` (view.c:291).  torch is used only for device
+memory and streams; all arithmetic happens in libclapgpu's HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import synth
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def view_calc_frustum(cam):
+    """view_update_from_angles + perspective + view_calc_frustum on the host
+    (view.c:165-176, 178-193, 248-294).  cam: dict from synth.camera()."""
+    L = _lib.lib()
+    f32p = C.POINTER(C.c_float)
+    pos = np.ascontiguousarray(cam["cam_pos"], np.float32)
+    quat = np.ascontiguousarray(cam["cam_quat"], np.float32)
+    view = np.zeros(16, np.float32)
+    proj = np.zeros(16, np.float32)
+    L.clapgpu_view_matrix(pos.ctypes.data_as(f32p), quat.ctypes.data_as(f32p), view.ctypes.data_as(f32p))
+    fov, aspect, near, far = (float(v) for v in cam["persp"])
+    z01 = int(cam["ndc_z_zero_one"][0])
+    L.clapgpu_perspective(fov, aspect, near, far, z01, proj.ctypes.data_as(f32p))
+    fr = _lib.Frustum()
+    L.clapgpu_frustum_calc(view.ctypes.data_as(f32p), proj.ctypes.data_as(f32p), z01, C.byref(fr))
+    return fr, view, proj
+
+
+def frustum_arrays(fr):
+    return (np.ctypeslib.as_array(fr.planes).reshape(6, 4).copy(),
+            np.ctypeslib.as_array(fr.corners).reshape(8, 4).copy())
+
+
+class EntityBatch:
+    """Device-resident SoA of the entities whose update hook is default_update.
+
+    Layout and padding rules: include/clapgpu.h (`clapgpu_entities`).  Build it from a
+    level-padded scene dict (synth.pad_levels)."""
+
+    IN_KEYS = ("pos_scale", "rot", "parent", "model", "flags", "seqs")
+
+    def __init__(self, scene, device="cuda:0"):
+        ls = np.asarray(scene["level_start"], np.uint32)
+        if np.any(ls[:-1] % 64):
+            raise ValueError("level starts must be multiples of 64: use synth.pad_levels()")
+        self.device = torch.device(device)
+        self.n = int(scene["n"])
+        self.n_real = int(scene.get("n_real", self.n))
+        self.level_start = np.ascontiguousarray(ls)
+        self.n_levels = len(ls) - 1
+        dev = self.device
+        for k in self.IN_KEYS:
+            a = scene[k]
+            if a.dtype == np.uint32:
+                a = a.view(np.int32)
+            setattr(self, k, torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+        self.model_table = torch.from_numpy(synth.model_table(scene)).to(dev)
+        n = self.n
+        self.mx = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        self.inv_mx = torch.zeros((n, 16), dtype=torch.float32, device=dev)
+        self.aabb = torch.zeros((n, 6), dtype=torch.float32, device=dev)
+        self.center = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        self.vis_mask = torch.zeros(((n + 63) // 64 or 1,), dtype=torch.int64, device=dev)
+        self.visible = torch.zeros((max(n, 1),), dtype=torch.int32, device=dev)
+        self.visible_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        nscratch = _lib.lib().clapgpu_visible_scratch_bytes(n)
+        self.scratch = torch.zeros((nscratch // 4 or 1,), dtype=torch.int32, device=dev)
+        self._desc = _lib.Entities(
+            n=n, n_models=self.model_table.shape[0],
+            pos_scale=self.pos_scale.data_ptr(), rot=self.rot.data_ptr(), parent=self.parent.data_ptr(),
+            model=self.model.data_ptr(), model_table=self.model_table.data_ptr(), flags=self.flags.data_ptr(),
+            seqs=self.seqs.data_ptr(), mx=self.mx.data_ptr(), inv_mx=self.inv_mx.data_ptr(),
+            aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr())
+        self._ls_ptr = self.level_start.ctypes.data_as(C.POINTER(C.c_uint32))
+
+    # ---- reference-named operations -------------------------------------------------
+    def mq_update(self, frustum=None, all_dirty=False):
+        """mq_update over default_update entities; with `frustum` the cull of
+        _models_render is fused into the same pass (vis_mask is written)."""
+        mode = _lib.UPDATE_ALL_DIRTY if all_dirty else 0
+        rc = _lib.lib().clapgpu_entities_update(_stream(), C.byref(self._desc), self._ls_ptr, self.n_levels,
+                                                mode, C.byref(frustum) if frustum is not None else None)
+        _lib.check(rc, "clapgpu_entities_update")
+
+    def update_level(self, level, frustum=None, all_dirty=False):
+        """One hierarchy level of mq_update (callers that time or interleave per level)."""
+        first = int(self.level_start[level])
+        count = int(self.level_start[level + 1]) - first
+        mode = _lib.UPDATE_ALL_DIRTY if all_dirty else 0
+        rc = _lib.lib().clapgpu_entities_update_level(_stream(), C.byref(self._desc), first, count, mode,
+                                                      C.byref(frustum) if frustum is not None else None)
+        _lib.check(rc, "clapgpu_entities_update_level")
+
+    def cull(self, frustum):
+        """view_entity_in_frustum over every entity (one render pass)."""
+        rc = _lib.lib().clapgpu_entities_cull(_stream(), C.byref(self._desc), C.byref(frustum))
+        _lib.check(rc, "clapgpu_entities_cull")
+
+    def compact_visible(self, index_base=0):
+        """Build the ascending visible-index list on the device (visible[:visible_count])."""
+        rc = _lib.lib().clapgpu_visible_compact(_stream(), _ptr(self.vis_mask), self.n, index_base,
+                                                _ptr(self.visible), _ptr(self.visible_count), _ptr(self.scratch))
+        _lib.check(rc, "clapgpu_visible_compact")
+
+    def view_entity_in_frustum(self, idx):
+        """Served from the precomputed visibility bitmask (host sync)."""
+        w = int(self.vis_mask[idx >> 6].item()) & 0xFFFFFFFFFFFFFFFF
+        return bool((w >> (idx & 63)) & 1)
+
+    # ---- host access ----------------------------------------------------------------
+    def set_transforms(self, idx, pos_scale, rot):
+        """entity3d_position/rotate/scale on a batch of entities: writes TRS, sets dirty."""
+        idx_t = torch.as_tensor(np.asarray(idx, np.int64), device=self.device)
+        self.pos_scale[idx_t] = torch.from_numpy(np.ascontiguousarray(pos_scale, np.float32)).to(self.device)
+        self.rot[idx_t] = torch.from_numpy(np.ascontiguousarray(rot, np.float32)).to(self.device)
+        self.flags[idx_t] |= np.int32(_lib.E_DIRTY)
+
+    def download(self):
+        torch.cuda.synchronize(self.device)
+        cnt = int(self.visible_count.item())
+        return dict(mx=self.mx.cpu().numpy(), inv_mx=self.inv_mx.cpu().numpy(), aabb=self.aabb.cpu().numpy(),
+                    center=self.center.cpu().numpy(), flags=self.flags.cpu().numpy().view(np.uint32),
+                    seqs=self.seqs.cpu().numpy().view(np.uint32),
+                    vis_mask=self.vis_mask.cpu().numpy().view(np.uint64),
+                    visible=self.visible[:cnt].cpu().numpy().view(np.uint32), visible_count=cnt)
+
+    def algorithmic_bytes(self):
+        """Algorithmic bytes of one all-dirty frame: 276 B per child, 212 B per root."""
+        par = self.parent.cpu().numpy()
+        real = (self.flags.cpu().numpy().view(np.uint32) & np.uint32(_lib.E_ALIVE)) != 0
+        children = int(np.count_nonzero((par >= 0) & real))
+        roots = int(np.count_nonzero((par < 0) & real))
+        return 276 * children + 212 * roots

@@ -163,3 +163,58 @@ def level_starts(parent):
     assert np.all(np.diff(depth) >= 0), "entities are not stored level-major"
     counts = np.bincount(depth, minlength=int(depth.max()) + 1 if n else 1)
     return np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+
+
+def pad_levels(scene, align=64):
+    """Re-lay an entity scene so every hierarchy level starts at a multiple of `align`
+    (include/clapgpu.h: one wavefront owns one vis_mask word).  Padding slots are dead
+    entities (flags == 0).  Adds ``slot_of`` (original -> padded index) and
+    ``orig_of`` (padded -> original index, -1 for padding)."""
+    ls = scene.get("level_start")
+    if ls is None:
+        ls = level_starts(scene["parent"])
+    ls = np.asarray(ls, np.int64)
+    n = int(scene["n"])
+    slot_of = np.empty(n, np.int64)
+    new_ls = [0]
+    for l in range(len(ls) - 1):
+        a, b = int(ls[l]), int(ls[l + 1])
+        start = new_ls[-1]
+        slot_of[a:b] = start + np.arange(b - a)
+        end = start + (b - a)
+        new_ls.append(end if l == len(ls) - 2 else -(-end // align) * align)
+    n_pad = new_ls[-1]
+    orig_of = np.full(n_pad, -1, np.int64)
+    orig_of[slot_of] = np.arange(n)
+
+    def scatter(a, fill=0):
+        out = np.full((n_pad,) + a.shape[1:], fill, a.dtype)
+        out[slot_of] = a
+        return out
+
+    out = dict(scene)
+    out["n"] = n_pad
+    out["n_real"] = n
+    out["pos_scale"] = scatter(scene["pos_scale"])
+    out["pos_scale"][orig_of < 0, 3] = 1.0
+    out["rot"] = scatter(scene["rot"])
+    out["rot"][orig_of < 0, 3] = 1.0
+    par = scene["parent"].astype(np.int64)
+    out["parent"] = scatter(np.where(par >= 0, slot_of[np.maximum(par, 0)], -1).astype(np.int32), -1)
+    out["model"] = scatter(scene["model"])
+    out["flags"] = scatter(scene["flags"])
+    out["seqs"] = scatter(scene["seqs"])
+    out["level_start"] = np.asarray(new_ls, np.uint32)
+    out["slot_of"] = slot_of
+    out["orig_of"] = orig_of
+    return out
+
+
+def model_table(scene):
+    """Device model table float32[m][8]: (min.xyz, skip_aabb as uint32 bits, max.xyz, 0)."""
+    m = scene["model_aabb"].shape[0]
+    t = np.zeros((m, 8), np.float32)
+    t[:, 0:3] = scene["model_aabb"][:, 0:3]
+    t[:, 4:7] = scene["model_aabb"][:, 3:6]
+    t.view(np.uint32)[:, 3] = scene["model_skip"].astype(np.uint32)
+    return t

@@ -1,0 +1,170 @@
+/*
+ * clapgpu.h -- C ABI of libclapgpu.so: the MI355X (gfx950) batch replacement for
+ * the per-frame scene-update hot path of virtuoso/clap.
+ *
+ * Plain C, plain pointers and sizes.  All `dev` pointers are HIP device pointers
+ * (from clapgpu_malloc, hipMalloc, or any allocator sharing the HIP context, e.g.
+ * a torch tensor's data_ptr()); `stream` is a hipStream_t passed as void* (NULL =
+ * the default stream).  Every function returns a cerr_enum-compatible int
+ * (reference core/error.h:12-49): 0 = OK, negative = error; launches are
+ * asynchronous on `stream` unless stated otherwise.
+ *
+ * Each entry point names the reference interface it replaces (file:line relative
+ * to the reference tree).  INTEGRATION.md shows the binding a CLAP maintainer adds.
+ *
+ * Conventions (identical to oracle/clap_oracle.h):
+ *   mat4  = float[16], column-major, (col c,row r) at [4c+r]  (linmath.h `mat4x4 M`, M[c][r])
+ *   quat  = (x,y,z,w)                                          (linmath.h:835-840)
+ */
+#ifndef CLAPGPU_H
+#define CLAPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: the subset of cerr_enum (error.h:12-49) this library returns ---- */
+#define CLAPGPU_OK                      0
+#define CLAPGPU_ERR_NOMEM              -1   /* _CERR_NOMEM */
+#define CLAPGPU_ERR_INVALID_ARGUMENTS  -2   /* _CERR_INVALID_ARGUMENTS */
+#define CLAPGPU_ERR_NOT_SUPPORTED      -3   /* _CERR_NOT_SUPPORTED */
+#define CLAPGPU_ERR_TOO_LARGE         -11   /* _CERR_TOO_LARGE */
+#define CLAPGPU_ERR_INIT_FAILED       -14   /* _CERR_INITIALIZATION_FAILED */
+#define CLAPGPU_ERR_OUT_OF_BOUNDS     -26   /* _CERR_OUT_OF_BOUNDS */
+#define CLAPGPU_ERR_UNKNOWN           -32   /* _CERR_UNKNOWN_ERROR (a HIP runtime error; see clapgpu_last_error) */
+
+/* ---- entity3d_flags bits the path reads (model.h:293-312) + the dirty mirror ---- */
+#define CLAPGPU_E_VISIBLE       (1u << 0)    /* ENTITY3D_VISIBLE */
+#define CLAPGPU_E_SKIP_CULLING  (1u << 14)   /* ENTITY3D_SKIP_CULLING */
+#define CLAPGPU_E_DIRTY         (1u << 16)   /* mirror of transform_t.updated (transform.h:11) */
+#define CLAPGPU_E_ALIVE         (1u << 31)   /* ENTITY3D_ALIVE */
+
+/* ---- runtime ---- */
+/* Number of HIP devices visible; <0 on error.  Does not create a context. */
+int clapgpu_device_count(void);
+/* Bind the calling thread to `device` (hipSetDevice) and verify it is a gfx950 part. */
+int clapgpu_init(int device);
+/* Text of the last HIP error seen by this library on the calling thread ("" if none). */
+const char *clapgpu_last_error(void);
+/* ABI version: bumped whenever a signature or struct below changes. */
+uint32_t clapgpu_abi_version(void);
+
+int clapgpu_malloc(void **dev, size_t bytes);
+int clapgpu_free(void *dev);
+int clapgpu_memcpy_h2d(void *dev, const void *host, size_t bytes, void *stream);
+int clapgpu_memcpy_d2h(void *host, const void *dev, size_t bytes, void *stream);
+int clapgpu_memset(void *dev, int value, size_t bytes, void *stream);
+int clapgpu_stream_sync(void *stream);
+
+/* ======================================================================== */
+/* Entities: transform hierarchy -> inverse -> world AABB -> frustum cull    */
+/* ======================================================================== */
+
+/*
+ * View frustum of the main subview: view.h:16-17 (`frustum_planes[6]`,
+ * `frustum_corners[8]`), produced on the host by clapgpu_frustum_calc().
+ */
+typedef struct clapgpu_frustum {
+    float planes[6][4];
+    float corners[8][4];
+} clapgpu_frustum;
+
+/* transform.c:132-138 transform_view_mat4x4 (host, O(1) per frame) */
+void clapgpu_view_matrix(const float pos[3], const float quat[4], float view_mx[16]);
+/* linmath.h:709-776 mat4x4_perspective_ndc_z_{2,1} via render-common.c:77-82 (host) */
+void clapgpu_perspective(float fov, float aspect, float near_plane, float far_plane,
+                         int ndc_z_zero_one, float proj_mx[16]);
+/* view.c:248-289 subview_calc_frustum (host) */
+void clapgpu_frustum_calc(const float view_mx[16], const float proj_mx[16],
+                          int ndc_z_zero_one, clapgpu_frustum *out);
+
+/*
+ * SoA mirror of the entity3d fields on the path (model.h:372-429), all device
+ * pointers, `n` entities.  Entities are stored so that parent[i] < i; a
+ * "level" is a maximal index range whose parents all lie in earlier levels.
+ * Level starts must be multiples of 64 (pad with flags == 0 entities) so that
+ * each 64-entity wavefront owns exactly one vis_mask word.
+ *
+ *   inputs   pos_scale[n][4]  (pos.xyz, scale)       transform_t.pos, entity3d.scale
+ *            rot[n][4]        quat xyzw              transform_t.rotation
+ *            parent[n]        index or -1            entity3d.parent (jointless attach)
+ *            model[n]         index into model_table entity3d.txmodel->model
+ *            model_table[m][8]  (min.xyz, skip_aabb as uint32 bits, max.xyz, 0)
+ *                                                    model3d.aabb, model3d.skip_aabb
+ *   in/out   flags[n]         CLAPGPU_E_* bits       entity3d.flags + xform.updated
+ *            seqs[n]          seq | parent_seq<<16   entity3d.seq / .parent_seq (uint16 wrap)
+ *   outputs  mx[n][16], inv_mx[n][16]                entity3d.mx, .inverse_mx
+ *            aabb[n][6]  (min.xyz, max.xyz)          entity3d.aabb
+ *            center[n][3]                            entity3d.aabb_center
+ *            vis_mask[ceil(n/64)]  bit i%64 of word i/64 = entity i passes the
+ *                                  draw predicate of _models_render (model.c:959-973)
+ */
+typedef struct clapgpu_entities {
+    uint32_t        n;
+    uint32_t        n_models;
+    const float    *pos_scale;
+    const float    *rot;
+    const int32_t  *parent;
+    const int32_t  *model;
+    const float    *model_table;
+    uint32_t       *flags;
+    uint32_t       *seqs;
+    float          *mx;
+    float          *inv_mx;
+    float          *aabb;
+    float          *center;
+    uint64_t       *vis_mask;
+} clapgpu_entities;
+
+/* mode bits for clapgpu_entities_update */
+#define CLAPGPU_UPDATE_ALL_DIRTY  (1u << 0)   /* treat every ALIVE entity as xform.updated; flags[] is not written */
+
+/*
+ * Replaces mq_update() over default_update entities (model.c:1953 -> 1649-1695,
+ * parent_transform_apply 1594-1647, mat4x4_invert, entity3d_aabb_update 1200-1234)
+ * and, when `frustum` is non-NULL, the per-entity view_entity_in_frustum() test of
+ * _models_render (view.c:296-337, model.c:959-973) fused into the same pass.
+ *
+ * level_start is a HOST array of n_levels+1 ascending offsets (level_start[0] == 0,
+ * level_start[n_levels] == e->n, every start a multiple of 64).  One launch per level.
+ * With frustum == NULL vis_mask is left untouched.
+ */
+int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
+                            const uint32_t *level_start, uint32_t n_levels,
+                            uint32_t mode, const clapgpu_frustum *frustum);
+
+/*
+ * One hierarchy level of the above: entities [first, first+count), whose parents
+ * were all updated by earlier calls on the same stream.  `first` must be a multiple
+ * of 64.  (Used by callers that interleave their own work or timing between levels.)
+ */
+int clapgpu_entities_update_level(void *stream, const clapgpu_entities *e,
+                                  uint32_t first, uint32_t count,
+                                  uint32_t mode, const clapgpu_frustum *frustum);
+
+/*
+ * Cull only: view_entity_in_frustum() over all entities from the stored aabb[]
+ * (one call per render pass in the reference, model.c:969-970).  Writes vis_mask.
+ */
+int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum);
+
+/*
+ * Ordered compaction of vis_mask into the ascending entity-index list the draw
+ * loop iterates: visible[0..*count) = index_base + i for every set bit i.
+ * `visible` needs room for n entries, `count` is one device uint32, `scratch` is
+ * clapgpu_visible_scratch_bytes(n) bytes of device memory; index_base is the global
+ * id of this shard's entity 0 (0 on a single GPU).  (Build-defined: the reference
+ * walks its entity list and tests each entity in place, model.c:958-973.)
+ */
+size_t clapgpu_visible_scratch_bytes(uint32_t n);
+int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, uint32_t n,
+                            uint32_t index_base, uint32_t *visible, uint32_t *count,
+                            void *scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAPGPU_H */

@@ -1,0 +1,200 @@
+"""GPU: the HIP entity path (through the C ABI) against the oracle and the golden vectors.
+
+Bar: bit-exact mx / inverse_mx / aabb / aabb_center / seq state / visibility mask /
+ascending visible list."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from clap_amd import synth
+from oracle import binding as ob
+from helpers import apply_frame, assert_bits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "entities_*.npz")))
+
+
+def oracle_frame(scene, st, fr_o):
+    ob.entities_update(scene, st)
+    return ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr_o)
+
+
+def check_against(out, st, vis, mask, what, check_flags=True):
+    assert_bits_equal(out["mx"], st["mx"], what + " mx")
+    assert_bits_equal(out["inv_mx"], st["inv_mx"], what + " inverse_mx")
+    assert_bits_equal(out["aabb"], st["aabb"], what + " aabb")
+    assert_bits_equal(out["center"], st["center"], what + " aabb_center")
+    assert np.array_equal(out["seqs"], st["seqs"]), what + " seqs"
+    if check_flags:
+        assert np.array_equal(out["flags"], st["flags"]), what + " flags"
+    assert np.array_equal(out["vis_mask"][:mask.size], mask), what + " vis_mask"
+    assert out["visible_count"] == vis.size, what + " visible count"
+    assert np.array_equal(out["visible"], vis), what + " visible list"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_matches_reference_golden(path, cuda_device):
+    from clap_amd import entities
+    scene, cam, ref, frames = load_golden(path)
+    n = scene["n"]
+    fr, _view, _proj = entities.view_calc_frustum(cam)
+    scene["flags"] = scene["flags"] & ~synth.E_DIRTY
+    batch = entities.EntityBatch(scene, cuda_device)
+    if frames is None:
+        frames = [(scene["pos_scale"], scene["rot"], np.ones(n, np.uint8))]
+    for f, (ps, rot, dirty) in enumerate(frames):
+        idx = np.flatnonzero(dirty)
+        batch.set_transforms(idx, ps[idx], rot[idx])
+        batch.mq_update(fr)
+        batch.compact_visible()
+        out = batch.download()
+        assert_bits_equal(out["mx"], ref["mx"][f], f"frame {f} mx")
+        assert_bits_equal(out["inv_mx"], ref["inv_mx"][f], f"frame {f} inverse_mx")
+        assert_bits_equal(out["aabb"], ref["aabb"][f], f"frame {f} aabb")
+        assert_bits_equal(out["center"], ref["center"][f], f"frame {f} center")
+        assert np.array_equal(out["seqs"], ref["seqs"][f]), f"frame {f} seqs"
+        assert np.array_equal(out["visible"], np.flatnonzero(ref["visible"][f])), f"frame {f} visible list"
+
+
+@pytest.mark.parametrize("maker,camkw", [
+    (lambda: synth.entities_flat(10_000, 1234), {}),                       # BASELINE config 1
+    (lambda: synth.entities_flat(10_000, 77, True), dict(ndc_z_zero_one=1)),
+    (lambda: synth.entities_forest(20_000, 3, max_depth=9, n_models=5), dict(pos=(0, 20, 100))),
+    (lambda: synth.entities_chains(3_000, 8, 2), {}),
+    (lambda: synth.entities_flat(1, 5), {}),                               # single entity
+    (lambda: synth.entities_flat(63, 6), {}),                              # less than one wave
+    (lambda: synth.entities_flat(65, 7), {}),                              # one wave + 1
+    (lambda: synth.entities_chains(1, 12, 9), {}),                         # one 12-deep chain, 64-padded levels
+], ids=["c1_flat_10k", "flat_euler_z01", "forest_20k", "chains_3k_x8", "n1", "n63", "n65", "deep_chain"])
+def test_hip_matches_oracle(maker, camkw, cuda_device):
+    from clap_amd import entities
+    scene = synth.pad_levels(maker())
+    cam = synth.camera(**camkw)
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    vis, mask = oracle_frame(scene, st, fr_o)
+
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.mq_update(fr)
+    batch.compact_visible()
+    check_against(batch.download(), st, vis, mask, "fused update+cull")
+
+    # second frame with nothing dirty: nothing may change (seq/parent_seq skip path), cull repeats
+    vis2, mask2 = oracle_frame(scene, st, fr_o)
+    batch.mq_update(fr)
+    batch.compact_visible()
+    check_against(batch.download(), st, vis2, mask2, "clean second frame")
+    assert np.array_equal(vis, vis2)
+
+
+def test_all_dirty_mode_and_separate_cull(cuda_device):
+    """CLAPGPU_UPDATE_ALL_DIRTY (what bench.py times) == every entity marked dirty; the
+    stand-alone cull pass == the fused one."""
+    from clap_amd import entities
+    scene = synth.pad_levels(synth.entities_forest(8_000, 31))
+    cam = synth.camera(pos=(3, 4, 60))
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    for frame in range(3):
+        st["flags"] |= np.where(st["flags"] & synth.E_ALIVE, synth.E_DIRTY, 0).astype(np.uint32)
+        vis, mask = oracle_frame(scene, st, fr_o)
+    batch = entities.EntityBatch(scene, cuda_device)
+    for frame in range(3):
+        batch.mq_update(None, all_dirty=True)
+    batch.cull(fr)
+    batch.compact_visible()
+    out = batch.download()
+    check_against(out, st, vis, mask, "all-dirty x3 + cull", check_flags=False)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    out2 = batch.download()
+    assert np.array_equal(out2["visible"], out["visible"])
+
+
+def test_partial_dirty_frames(cuda_device):
+    """Random subsets move each frame: dirty roots drag their subtrees, clean subtrees are skipped."""
+    from clap_amd import entities
+    rng = np.random.Generator(np.random.PCG64(5))
+    scene = synth.pad_levels(synth.entities_forest(6_000, 17, max_depth=7))
+    cam = synth.camera(pos=(0, 0, 80))
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    batch = entities.EntityBatch(scene, cuda_device)
+    n = scene["n"]
+    for frame in range(4):
+        vis, mask = oracle_frame(scene, st, fr_o)
+        batch.mq_update(fr)
+        batch.compact_visible()
+        check_against(batch.download(), st, vis, mask, f"frame {frame}")
+        dirty = (rng.uniform(0, 1, n) < 0.1) & (scene["orig_of"] >= 0)
+        ps = scene["pos_scale"].copy()
+        ps[dirty, :3] += rng.uniform(-5, 5, (int(dirty.sum()), 3)).astype(np.float32)
+        apply_frame(scene, st, (ps, scene["rot"], dirty))
+        idx = np.flatnonzero(dirty)
+        batch.set_transforms(idx, ps[idx], scene["rot"][idx])
+
+
+def test_seq_wraps_like_uint16(cuda_device):
+    from clap_amd import entities
+    scene = synth.pad_levels(synth.entities_chains(70, 3, 4))
+    scene["seqs"][:] = 0xFFFF | (0xFFFF << 16)
+    st = ob.entity_state(scene)
+    fr, _v, _p = entities.view_calc_frustum(synth.camera())
+    fr_o, _vo, _po = ob.frustum_from_camera(synth.camera())
+    vis, mask = oracle_frame(scene, st, fr_o)
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.mq_update(fr)
+    batch.compact_visible()
+    check_against(batch.download(), st, vis, mask, "wrap")
+    alive = (st["flags"] & synth.E_ALIVE) != 0
+    assert np.all((st["seqs"][alive] & 0xFFFF) == 0)
+
+
+def test_argument_validation(cuda_device):
+    import ctypes as C
+    from clap_amd import _lib, entities
+    scene = synth.pad_levels(synth.entities_flat(100, 1))
+    batch = entities.EntityBatch(scene, cuda_device)
+    L = _lib.lib()
+    bad = np.asarray([0, 50, 100], np.uint32)            # level start not a multiple of 64
+    rc = L.clapgpu_entities_update(None, C.byref(batch._desc), bad.ctypes.data_as(C.POINTER(C.c_uint32)), 2, 0, None)
+    assert rc == _lib.ERR_INVALID_ARGUMENTS
+    bad = np.asarray([0, 64], np.uint32)                 # does not end at n
+    rc = L.clapgpu_entities_update(None, C.byref(batch._desc), bad.ctypes.data_as(C.POINTER(C.c_uint32)), 1, 0, None)
+    assert rc == _lib.ERR_OUT_OF_BOUNDS
+    rc = L.clapgpu_entities_update(None, None, None, 0, 0, None)
+    assert rc == _lib.ERR_INVALID_ARGUMENTS
+
+
+def test_c2_full_size_bit_exact_and_properties(cuda_device):
+    """BASELINE config 2 at full size: 1M entities, depth-8 hierarchy.  The C oracle does 1M
+    entities in well under a second, so the full-size check is bit-exact too; on top:
+    sortedness, count == popcount(mask), and idempotence of a clean frame."""
+    from clap_amd import entities
+    scene = synth.pad_levels(synth.entities_chains(125_000, 8, 2))
+    cam = synth.camera()
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    vis, mask = oracle_frame(scene, st, fr_o)
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    out = batch.download()
+    check_against(out, st, vis, mask, "C2", check_flags=False)
+    v = out["visible"]
+    assert np.all(np.diff(v.astype(np.int64)) > 0)
+    assert out["visible_count"] == int(sum(bin(int(w)).count("1") for w in out["vis_mask"]))
+    assert 0.15 < out["visible_count"] / scene["n_real"] < 0.45
+    mx_before = out["mx"].copy()
+    batch.mq_update(fr)                                   # nothing dirty -> no rebuild
+    batch.compact_visible()
+    out2 = batch.download()
+    assert np.array_equal(out2["mx"].view(np.uint32), mx_before.view(np.uint32))
+    assert np.array_equal(out2["visible"], v)

@@ -1,0 +1,99 @@
+"""CPU: the oracle's entity/frustum/cull restatement against the reference.
+
+Two pins: (1) golden vectors produced by the reference's own code
+(tools/make_golden.py -> tests/golden/*.npz); (2) when the reference build is present
+(this container only), a live comparison on larger seeded scenes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from clap_amd import synth
+from oracle import binding as ob
+from oracle import refrun
+from helpers import apply_frame, assert_bits_equal, load_golden
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "entities_*.npz")))
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) >= 4
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_reference_golden(path):
+    scene, cam, ref, frames = load_golden(path)
+    n = scene["n"]
+    fr, view, proj = ob.frustum_from_camera(cam)
+    planes, corners = fr.arrays()
+    assert_bits_equal(view, ref["view_mx"], "view_mx")
+    assert_bits_equal(proj, ref["proj_mx"], "proj_mx")
+    assert_bits_equal(planes, ref["planes"], "frustum planes")
+    assert_bits_equal(corners, ref["corners"], "frustum corners")
+
+    scene = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in scene.items()}
+    st = ob.entity_state(scene)
+    if frames is None:
+        frames = [(scene["pos_scale"].copy(), scene["rot"].copy(), np.ones(n, np.uint8))]
+        st["flags"] &= ~synth.E_DIRTY
+    else:
+        st["flags"] &= ~synth.E_DIRTY
+    for f, frame in enumerate(frames):
+        apply_frame(scene, st, frame)
+        ob.entities_update(scene, st)
+        vis, mask = ob.entities_cull(n, st["flags"], st["aabb"], fr)
+        assert_bits_equal(st["mx"], ref["mx"][f], f"frame {f} mx")
+        assert_bits_equal(st["inv_mx"], ref["inv_mx"][f], f"frame {f} inverse_mx")
+        assert_bits_equal(st["aabb"], ref["aabb"][f], f"frame {f} aabb")
+        assert_bits_equal(st["center"], ref["center"][f], f"frame {f} aabb_center")
+        assert np.array_equal(st["seqs"], ref["seqs"][f]), f"frame {f} seq/parent_seq"
+        assert np.array_equal(vis, np.flatnonzero(ref["visible"][f])), f"frame {f} visible set"
+        assert not np.any(st["flags"] & synth.E_DIRTY & np.where(st["flags"] & synth.E_ALIVE, 0xFFFFFFFF, 0))
+
+
+def test_multi_frame_golden_skips_clean_entities():
+    """The frames fixture must actually exercise the seq/parent_seq skip path."""
+    path = [p for p in GOLDEN if "frames" in p][0]
+    _scene, _cam, ref, frames = load_golden(path)
+    seqs = ref["seqs"] & 0xFFFF
+    assert len(frames) >= 3
+    assert np.any(seqs[1] == seqs[0]) and np.any(seqs[1] != seqs[0])
+
+
+@pytest.mark.skipif(not refrun.available(), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("maker", [lambda: synth.entities_flat(10_000, 1234),
+                                   lambda: synth.entities_flat(4_000, 5, True),
+                                   lambda: synth.entities_forest(6_000, 21),
+                                   lambda: synth.entities_chains(1_000, 8, 2)],
+                         ids=["c1_flat_10k", "flat_euler", "forest", "chains"])
+def test_oracle_matches_live_reference(maker):
+    scene = synth.pad_levels(maker())
+    cam = synth.camera(ndc_z_zero_one=0)
+    ref = refrun.entities(scene, cam)
+    fr, _view, _proj = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    ob.entities_update(scene, st)
+    vis, _mask = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr)
+    assert_bits_equal(st["mx"], ref["mx"][0], "mx")
+    assert_bits_equal(st["inv_mx"], ref["inv_mx"][0], "inverse_mx")
+    assert_bits_equal(st["aabb"], ref["aabb"][0], "aabb")
+    assert_bits_equal(st["center"], ref["center"][0], "center")
+    assert np.array_equal(vis, np.flatnonzero(ref["visible"][0]))
+
+
+def test_cull_edge_cases():
+    """Empty input, everything hidden, skip-culling entities far outside the frustum."""
+    fr, _v, _p = ob.frustum_from_camera(synth.camera())
+    vis, mask = ob.entities_cull(0, np.zeros(0, np.uint32), np.zeros((0, 6), np.float32), fr)
+    assert vis.size == 0
+    n = 130
+    aabb = np.tile(np.asarray([1e6, 1e6, 1e6, 1e6 + 1, 1e6 + 1, 1e6 + 1], np.float32), (n, 1))
+    flags = np.full(n, synth.E_ALIVE | synth.E_VISIBLE, np.uint32)
+    vis, mask = ob.entities_cull(n, flags, aabb, fr)
+    assert vis.size == 0 and not mask.any()
+    flags[5] |= synth.E_SKIP_CULLING
+    flags[129] |= synth.E_SKIP_CULLING
+    vis, mask = ob.entities_cull(n, flags, aabb, fr)
+    assert vis.tolist() == [5, 129]
+    assert int(mask[0]) == 1 << 5 and int(mask[2]) == 1 << 1
