@@ -9,7 +9,7 @@ range (weak scaling, no data-path collective) and the only exchange is the RCCL
 allgather of the compacted visible set.
 
 Prints ONE JSON line (rank 0).  `value` = entity updates / s over all GPUs.
-`roofline` = algorithmic bytes of the per-level update kernel / its mean duration
+`roofline` = algorithmic bytes of the update kernel / its mean launch duration
 measured with HIP events around every launch (a separate pass after the timed
 region, same process, same data).  `cpu_baseline` = the reference's own
 default_update + view_entity_in_frustum (oracle/_ref, built from the reference
@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chains", type=int, default=125_000, help="hierarchy chains per GPU (x depth = entities)")
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--layout", choices=["tiles", "levels"], default="tiles",
+                    help="tiles: subtree tiles, one launch for all levels; levels: level-major, one launch per level")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -69,7 +71,7 @@ def cpu_baseline(scene, cam, frames):
 
 def pmc_traffic():
     """HBM bytes per k_entities_level launch from the committed PMC summary, if one exists."""
-    path = os.path.join(ROOT, "profiles", f"{ROUND}_entities_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_entities_pmc.json")   # written by tools/pmc_summary.py
     try:
         with open(path) as f:
             return json.load(f).get("hbm_bytes_per_launch")
@@ -81,7 +83,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from clap_amd import _lib, entities, synth
+    from clap_amd import _lib, entities, synth, tiler
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,7 +97,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
-    scene = synth.pad_levels(synth.entities_chains(args.chains, args.depth, seed=2 + rank))
+    raw = synth.entities_chains(args.chains, args.depth, seed=2 + rank)
+    scene = tiler.tiled_scene(raw)[0] if args.layout == "tiles" else synth.pad_levels(raw)
     cam = synth.camera()
     fr, _view, _proj = entities.view_calc_frustum(cam)
     batch = entities.EntityBatch(scene, device)
@@ -136,23 +139,30 @@ def main():
     value = world * n_real * args.steps / elapsed
     visible = int(batch.visible_count.item())
 
-    # ---- roofline pass: HIP events around every k_entities_level launch (same stream) ----
-    n_levels = batch.n_levels
+    # ---- roofline pass: HIP events around every launch of the dominant kernel (same stream) ----
+    if batch.tiled:
+        kernel, launches = "k_entities_tiles<true>", 1
+    else:
+        kernel, launches = "k_entities_level<true>", batch.n_levels
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(n_levels)] for _ in range(args.steps)]
+           for _ in range(launches)] for _ in range(args.steps)]
     torch.cuda.synchronize()
     for s in range(args.steps):
-        for l in range(n_levels):
+        for l in range(launches):
             ev[s][l][0].record()
-            batch.update_level(l, fr, all_dirty=True)
+            if batch.tiled:
+                batch.mq_update(fr, all_dirty=True)
+            else:
+                batch.update_level(l, fr, all_dirty=True)
             ev[s][l][1].record()
         batch.compact_visible(index_base)
     torch.cuda.synchronize()
-    lvl_ms = np.asarray([[a.elapsed_time(b) for a, b in row] for row in ev])       # [steps][levels]
+    lvl_ms = np.asarray([[a.elapsed_time(b) for a, b in row] for row in ev])       # [steps][launches]
     mean_launch_s = float(lvl_ms.mean()) * 1e-3
     alg_bytes_step = batch.algorithmic_bytes()                                       # 276 B/child, 212 B/root
-    alg_bytes_launch = alg_bytes_step / n_levels
+    alg_bytes_launch = alg_bytes_step / launches
     achieved = alg_bytes_launch / mean_launch_s / 1e9
+    n_levels = args.depth
 
     if rank == 0:
         out = {
@@ -161,16 +171,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
-                                   f"{args.depth}, level-major SoA, all dirty, fused frustum cull + ordered visible "
+                                   f"{args.depth}, {args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
                                    f"list ({visible} visible on rank 0)",
                        "entities_per_gpu": n_real, "levels": n_levels,
                        "exchange": "RCCL allgather of visible ids" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "kernel": "k_entities_level<true>", "launches_per_step": n_levels,
+                         "kernel": kernel, "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "mean_launch_us": mean_launch_s * 1e6,
-                         "per_level_us": [float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]},
+                         "per_launch_us": [float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]},
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)

@@ -71,6 +71,8 @@ SYMBOLS = {
                                           C.c_uint32, C.POINTER(Frustum)]),
     "clapgpu_entities_update_level": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.POINTER(Frustum)]),
+    "clapgpu_entities_update_tiles": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_void_p, C.c_uint32,
+                                                C.c_uint32, C.POINTER(Frustum)]),
     "clapgpu_entities_cull": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.POINTER(Frustum)]),
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

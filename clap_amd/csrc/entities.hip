@@ -44,33 +44,48 @@ __device__ __forceinline__ void load_mat4(float (&m)[16], const float *src)
     }
 }
 
-// first is a multiple of 64, so (first + blockIdx*256 + tid) / 64 is this wave's
-// vis_mask word and no other wave of any launch touches it.
-template <bool CULL>
-__global__ __launch_bounds__(ENT_BLOCK)
-void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::Frustum fr)
+// One 64-entity row (= one vis_mask word) processed by one wave.
+//   row_first  first entity of the row (multiple of 64), row_count valid lanes (1..64)
+//   TILE       the wave walks a tile of consecutive rows (= hierarchy levels of a group of
+//              whole subtrees); a parent that sits in the previous row is taken from the
+//              registers of the lane that just computed it (16 cross-lane reads) instead of
+//              being re-read from HBM.  carry_* hold the previous row's results.
+template <bool CULL, bool TILE>
+__device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const int lane,
+                                            const uint32_t row_first, const uint32_t row_count,
+                                            const uint32_t mode, const lmd::Frustum &fr,
+                                            const bool have_prev, const uint32_t prev_first,
+                                            float (&carry_mx)[16], uint32_t &carry_seq, bool &carry_valid)
 {
-    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];          // 4 KiB per wave
-
-    const int lane = lane_id();
-    const int wave = threadIdx.x / WAVE;
-    const uint32_t local = blockIdx.x * ENT_BLOCK + threadIdx.x; // index inside the level
-    const uint32_t wave_local0 = local - lane;
-    const bool in_range = local < count;
-    const uint32_t i = first + (in_range ? local : 0);           // clamp: idle lanes read entity `first`
-    float4 *tile = lds_tiles[wave];
+    const bool in_range = (uint32_t)lane < row_count;
+    const uint32_t i = row_first + (in_range ? lane : 0);        // idle lanes re-read lane 0's entity
 
     const uint32_t fl = e.flags[i];
     const bool alive = in_range && (fl & CLAPGPU_E_ALIVE);
     const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
     const int32_t p = e.parent[i];
-    uint32_t sq = e.seqs[i];
+    const uint32_t sq = e.seqs[i];
     uint32_t seq = sq & 0xffffu, pseq = sq >> 16;
+
+    // ---- where does the parent live? ----
+    bool in_prev = false;
+    float pm[16];
+    uint32_t parent_seq_now = 0;
+    bool parent_in_regs = false;
+    if (TILE) {
+        in_prev = have_prev && p >= 0 && (uint32_t)p >= prev_first && (uint32_t)p < prev_first + WAVE;
+        const int src = in_prev ? (int)((uint32_t)p - prev_first) : lane;
+#pragma unroll
+        for (int k = 0; k < 16; k++) pm[k] = __shfl(carry_mx[k], src);
+        parent_seq_now = __shfl(carry_seq, src);
+        parent_in_regs = in_prev && (__shfl((int)carry_valid, src) != 0);
+    }
+    if (p >= 0 && !in_prev)
+        parent_seq_now = e.seqs[p] & 0xffffu;                    // parent updated by an earlier launch
 
     // parent_transform_apply's skip test (model.c:1609-1611) / default_update's dirty test (1667)
     bool rebuild = alive;
     if (p >= 0) {
-        const uint32_t parent_seq_now = e.seqs[p] & 0xffffu;
         if (pseq == parent_seq_now && !dirty)
             rebuild = false;
         else
@@ -88,8 +103,8 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
         float local_mx[16];
         lmd::trs(local_mx, ps.x, ps.y, ps.z, ps.w, q.x, q.y, q.z, q.w);
         if (p >= 0) {
-            float pm[16];
-            load_mat4(pm, e.mx + 16 * (size_t)p);
+            if (!parent_in_regs)
+                load_mat4(pm, e.mx + 16 * (size_t)p);            // stored matrix of a parent not rebuilt here
             lmd::mul(mx, pm, local_mx);                          // model.c:1625
         } else {
 #pragma unroll
@@ -110,35 +125,39 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
             e.flags[i] = fl & ~CLAPGPU_E_DIRTY;                  // transform_clear_updated
     }
 
-    // ---- stores: whole-wave fast path when all 64 lanes rebuilt (the common case) ----
+    if (TILE) {                                                  // hand this row to the next one
+#pragma unroll
+        for (int k = 0; k < 16; k++) carry_mx[k] = mx[k];
+        carry_seq = seq;
+        carry_valid = rebuild;
+    }
+
+    // ---- stores: whole-wave fast path when every valid lane rebuilt (the common case) ----
     const uint64_t rebuilt_mask = __ballot(rebuild);
     const uint64_t aabb_mask = __ballot(rebuild && has_aabb);
-    const uint32_t wave_count = count - wave_local0 < WAVE ? count - wave_local0 : WAVE;   // valid lanes
-    const uint64_t full = wave_count == WAVE ? ~0ull : ((1ull << wave_count) - 1ull);
-    const size_t e0 = (size_t)first + wave_local0;               // first entity of this wave
+    const uint64_t full = row_count == WAVE ? ~0ull : ((1ull << row_count) - 1ull);
+    const size_t e0 = row_first;
 
-    if (wave_local0 < count) {
-        if (rebuilt_mask == full) {
-            wave_store_mat4(tile, e.mx + 16 * e0, mx, lane, (int)wave_count);
-            wave_store_mat4(tile, e.inv_mx + 16 * e0, inv, lane, (int)wave_count);
-        } else if (rebuild) {
-            float4 *dm = reinterpret_cast<float4 *>(e.mx + 16 * (size_t)i);
-            float4 *di = reinterpret_cast<float4 *>(e.inv_mx + 16 * (size_t)i);
+    if (rebuilt_mask == full) {
+        wave_store_mat4(tile, e.mx + 16 * e0, mx, lane, (int)row_count);
+        wave_store_mat4(tile, e.inv_mx + 16 * e0, inv, lane, (int)row_count);
+    } else if (rebuild) {
+        float4 *dm = reinterpret_cast<float4 *>(e.mx + 16 * (size_t)i);
+        float4 *di = reinterpret_cast<float4 *>(e.inv_mx + 16 * (size_t)i);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                dm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
-                di[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
-            }
+        for (int c = 0; c < 4; c++) {
+            dm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
+            di[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
         }
-        if (aabb_mask == full) {
-            wave_store_rows<6>(reinterpret_cast<float *>(tile), e.aabb + 6 * e0, bb, lane, (int)wave_count);
-            wave_store_rows<3>(reinterpret_cast<float *>(tile), e.center + 3 * e0, ctr, lane, (int)wave_count);
-        } else if (rebuild && has_aabb) {
+    }
+    if (aabb_mask == full) {
+        wave_store_rows<6>(reinterpret_cast<float *>(tile), e.aabb + 6 * e0, bb, lane, (int)row_count);
+        wave_store_rows<3>(reinterpret_cast<float *>(tile), e.center + 3 * e0, ctr, lane, (int)row_count);
+    } else if (rebuild && has_aabb) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) e.aabb[6 * (size_t)i + k] = bb[k];
+        for (int k = 0; k < 6; k++) e.aabb[6 * (size_t)i + k] = bb[k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
-        }
+        for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
     }
 
     if (CULL) {
@@ -151,8 +170,60 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
         if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
             vis = lmd::aabb_in_frustum(fr, bb);                                       // model.c:967-971
         const uint64_t m = __ballot(vis);
-        if (lane == 0 && wave_local0 < count)
+        if (lane == 0)
             e.vis_mask[e0 >> 6] = m;
+    }
+}
+
+// One launch per hierarchy level: every parent was written by an earlier launch.
+// `first` is a multiple of 64, so each wave owns exactly one vis_mask word.
+template <bool CULL>
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::Frustum fr)
+{
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];          // 4 KiB per wave
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    const uint32_t wave_local0 = blockIdx.x * ENT_BLOCK + wave * WAVE;
+    if (wave_local0 >= count)
+        return;                                                  // whole wave; no block-level sync below
+    const uint32_t row_count = count - wave_local0 < WAVE ? count - wave_local0 : WAVE;
+    float carry_mx[16];
+    uint32_t carry_seq = 0;
+    bool carry_valid = false;
+    process_row<CULL, false>(e, lds_tiles[wave], lane, first + wave_local0, row_count, mode, fr,
+                             false, 0, carry_mx, carry_seq, carry_valid);
+}
+
+// One launch for the whole forest: wave t walks tile t = rows [tile_row_start[t], tile_row_start[t+1]),
+// row r = entities [64r, 64r+64) = one hierarchy level of the subtrees packed into the tile.
+template <bool CULL>
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
+                      uint32_t mode, lmd::Frustum fr)
+{
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    const uint32_t t = blockIdx.x * (ENT_BLOCK / WAVE) + wave;
+    if (t >= n_tiles)
+        return;
+    const uint32_t n_rows = (n + WAVE - 1) / WAVE;
+    uint32_t row = tile_row_start[t], row_end = tile_row_start[t + 1];
+    if (row_end > n_rows) row_end = n_rows;                      // never walk past the arrays
+
+    float carry_mx[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) carry_mx[k] = 0.f;
+    uint32_t carry_seq = 0;
+    bool carry_valid = false;
+    bool have_prev = false;
+    for (; row < row_end; row++) {
+        const uint32_t row_first = row * WAVE;
+        const uint32_t row_count = n - row_first < WAVE ? n - row_first : WAVE;
+        process_row<CULL, true>(e, lds_tiles[wave], lane, row_first, row_count, mode, fr,
+                                have_prev, row_first - WAVE, carry_mx, carry_seq, carry_valid);
+        have_prev = true;
     }
 }
 
@@ -340,6 +411,32 @@ extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
         rc = launch_level(stream, k, first, count, mode, frustum);
         if (rc) return rc;
     }
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entities *e,
+                                             const uint32_t *tile_row_start, uint32_t n_tiles,
+                                             uint32_t mode, const clapgpu_frustum *frustum)
+{
+    int rc = check_entities(e, frustum != nullptr);
+    if (rc) return rc;
+    if (e->n == 0 || n_tiles == 0)
+        return CLAPGPU_OK;
+    if (!tile_row_start)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    lmd::Frustum fr = {};
+    if (frustum)
+        memcpy(&fr, frustum, sizeof(fr));
+    const EntK k = to_kernel_args(e);
+    const uint32_t per_block = ENT_BLOCK / WAVE;
+    const dim3 grid((n_tiles + per_block - 1) / per_block), block(ENT_BLOCK);
+    if (frustum)
+        hipLaunchKernelGGL(k_entities_tiles<true>, grid, block, 0, as_stream(stream), k, tile_row_start, n_tiles,
+                           e->n, mode, fr);
+    else
+        hipLaunchKernelGGL(k_entities_tiles<false>, grid, block, 0, as_stream(stream), k, tile_row_start, n_tiles,
+                           e->n, mode, fr);
+    CLAPGPU_LAUNCH_CHECK("k_entities_tiles");
     return CLAPGPU_OK;
 }
 

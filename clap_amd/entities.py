@@ -53,15 +53,25 @@ class EntityBatch:
     IN_KEYS = ("pos_scale", "rot", "parent", "model", "flags", "seqs")
 
     def __init__(self, scene, device="cuda:0"):
-        ls = np.asarray(scene["level_start"], np.uint32)
-        if np.any(ls[:-1] % 64):
-            raise ValueError("level starts must be multiples of 64: use synth.pad_levels()")
         self.device = torch.device(device)
+        dev = self.device
         self.n = int(scene["n"])
         self.n_real = int(scene.get("n_real", self.n))
-        self.level_start = np.ascontiguousarray(ls)
-        self.n_levels = len(ls) - 1
-        dev = self.device
+        self.tiled = "tile_row_start" in scene
+        if self.tiled:      # tile layout (clap_amd.tiler): one launch for all levels
+            trs = np.ascontiguousarray(scene["tile_row_start"], np.uint32)
+            if int(trs[-1]) * 64 != self.n:
+                raise ValueError("tile_row_start does not cover the scene")
+            self.n_tiles = len(trs) - 1
+            self.tile_row_start = torch.from_numpy(trs.view(np.int32)).to(dev)
+            self.level_start, self.n_levels = None, 0
+        else:               # level-major layout (synth.pad_levels): one launch per level
+            ls = np.asarray(scene["level_start"], np.uint32)
+            if np.any(ls[:-1] % 64):
+                raise ValueError("level starts must be multiples of 64: use synth.pad_levels()")
+            self.level_start = np.ascontiguousarray(ls)
+            self.n_levels = len(ls) - 1
+            self._ls_ptr = self.level_start.ctypes.data_as(C.POINTER(C.c_uint32))
         for k in self.IN_KEYS:
             a = scene[k]
             if a.dtype == np.uint32:
@@ -84,16 +94,21 @@ class EntityBatch:
             model=self.model.data_ptr(), model_table=self.model_table.data_ptr(), flags=self.flags.data_ptr(),
             seqs=self.seqs.data_ptr(), mx=self.mx.data_ptr(), inv_mx=self.inv_mx.data_ptr(),
             aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr())
-        self._ls_ptr = self.level_start.ctypes.data_as(C.POINTER(C.c_uint32))
 
     # ---- reference-named operations -------------------------------------------------
     def mq_update(self, frustum=None, all_dirty=False):
         """mq_update over default_update entities; with `frustum` the cull of
         _models_render is fused into the same pass (vis_mask is written)."""
         mode = _lib.UPDATE_ALL_DIRTY if all_dirty else 0
-        rc = _lib.lib().clapgpu_entities_update(_stream(), C.byref(self._desc), self._ls_ptr, self.n_levels,
-                                                mode, C.byref(frustum) if frustum is not None else None)
-        _lib.check(rc, "clapgpu_entities_update")
+        fr = C.byref(frustum) if frustum is not None else None
+        if self.tiled:
+            rc = _lib.lib().clapgpu_entities_update_tiles(_stream(), C.byref(self._desc), _ptr(self.tile_row_start),
+                                                          self.n_tiles, mode, fr)
+            _lib.check(rc, "clapgpu_entities_update_tiles")
+        else:
+            rc = _lib.lib().clapgpu_entities_update(_stream(), C.byref(self._desc), self._ls_ptr, self.n_levels,
+                                                    mode, fr)
+            _lib.check(rc, "clapgpu_entities_update")
 
     def update_level(self, level, frustum=None, all_dirty=False):
         """One hierarchy level of mq_update (callers that time or interleave per level)."""

@@ -146,6 +146,21 @@ int clapgpu_entities_update_level(void *stream, const clapgpu_entities *e,
                                   uint32_t mode, const clapgpu_frustum *frustum);
 
 /*
+ * Single-launch form of clapgpu_entities_update for forests laid out in TILES.
+ * A tile is a run of consecutive 64-entity rows; row r = entities [64r, 64r+64).
+ * Tile t = rows [tile_row_start[t], tile_row_start[t+1]) and holds whole subtrees,
+ * one hierarchy level per row: a child in row r has its parent in row r-1 of the
+ * same tile (taken from registers, never re-read from HBM).  Unused lanes of a row
+ * are padding entities (flags == 0).  A parent outside the tile's previous row is
+ * legal only if it is not rebuilt by this call (it is read from mx[] / seqs[]).
+ * tile_row_start is a DEVICE array of n_tiles+1 ascending row indices.
+ * One wavefront walks one tile; tiles are independent, so one launch covers every level.
+ */
+int clapgpu_entities_update_tiles(void *stream, const clapgpu_entities *e,
+                                  const uint32_t *tile_row_start, uint32_t n_tiles,
+                                  uint32_t mode, const clapgpu_frustum *frustum);
+
+/*
  * Cull only: view_entity_in_frustum() over all entities from the stored aabb[]
  * (one call per render pass in the reference, model.c:969-970).  Writes vis_mask.
  */

@@ -8,13 +8,21 @@ import os
 import numpy as np
 import pytest
 
-from clap_amd import synth
+from clap_amd import synth, tiler
 from oracle import binding as ob
 from helpers import apply_frame, assert_bits_equal, load_golden
 
 pytestmark = pytest.mark.gpu
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "entities_*.npz")))
+
+
+LAYOUTS = ["levels", "tiles"]
+
+
+def lay_out(scene, layout):
+    """levels: level-major, one launch per level; tiles: subtree tiles, one launch in all."""
+    return synth.pad_levels(scene) if layout == "levels" else tiler.tiled_scene(scene)[0]
 
 
 def oracle_frame(scene, st, fr_o):
@@ -69,9 +77,10 @@ def test_hip_matches_reference_golden(path, cuda_device):
     (lambda: synth.entities_flat(65, 7), {}),                              # one wave + 1
     (lambda: synth.entities_chains(1, 12, 9), {}),                         # one 12-deep chain, 64-padded levels
 ], ids=["c1_flat_10k", "flat_euler_z01", "forest_20k", "chains_3k_x8", "n1", "n63", "n65", "deep_chain"])
-def test_hip_matches_oracle(maker, camkw, cuda_device):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hip_matches_oracle(maker, camkw, layout, cuda_device):
     from clap_amd import entities
-    scene = synth.pad_levels(maker())
+    scene = lay_out(maker(), layout)
     cam = synth.camera(**camkw)
     fr, _v, _p = entities.view_calc_frustum(cam)
     fr_o, _vo, _po = ob.frustum_from_camera(cam)
@@ -91,11 +100,12 @@ def test_hip_matches_oracle(maker, camkw, cuda_device):
     assert np.array_equal(vis, vis2)
 
 
-def test_all_dirty_mode_and_separate_cull(cuda_device):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_all_dirty_mode_and_separate_cull(layout, cuda_device):
     """CLAPGPU_UPDATE_ALL_DIRTY (what bench.py times) == every entity marked dirty; the
     stand-alone cull pass == the fused one."""
     from clap_amd import entities
-    scene = synth.pad_levels(synth.entities_forest(8_000, 31))
+    scene = lay_out(synth.entities_forest(8_000, 31), layout)
     cam = synth.camera(pos=(3, 4, 60))
     fr, _v, _p = entities.view_calc_frustum(cam)
     fr_o, _vo, _po = ob.frustum_from_camera(cam)
@@ -116,11 +126,13 @@ def test_all_dirty_mode_and_separate_cull(cuda_device):
     assert np.array_equal(out2["visible"], out["visible"])
 
 
-def test_partial_dirty_frames(cuda_device):
-    """Random subsets move each frame: dirty roots drag their subtrees, clean subtrees are skipped."""
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_partial_dirty_frames(layout, cuda_device):
+    """Random subsets move each frame: dirty roots drag their subtrees, clean subtrees are skipped
+    (in tile layout: children of a clean parent re-read its stored matrix)."""
     from clap_amd import entities
     rng = np.random.Generator(np.random.PCG64(5))
-    scene = synth.pad_levels(synth.entities_forest(6_000, 17, max_depth=7))
+    scene = lay_out(synth.entities_forest(6_000, 17, max_depth=7), layout)
     cam = synth.camera(pos=(0, 0, 80))
     fr, _v, _p = entities.view_calc_frustum(cam)
     fr_o, _vo, _po = ob.frustum_from_camera(cam)
@@ -140,9 +152,10 @@ def test_partial_dirty_frames(cuda_device):
         batch.set_transforms(idx, ps[idx], scene["rot"][idx])
 
 
-def test_seq_wraps_like_uint16(cuda_device):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_seq_wraps_like_uint16(layout, cuda_device):
     from clap_amd import entities
-    scene = synth.pad_levels(synth.entities_chains(70, 3, 4))
+    scene = lay_out(synth.entities_chains(70, 3, 4), layout)
     scene["seqs"][:] = 0xFFFF | (0xFFFF << 16)
     st = ob.entity_state(scene)
     fr, _v, _p = entities.view_calc_frustum(synth.camera())
@@ -172,12 +185,13 @@ def test_argument_validation(cuda_device):
     assert rc == _lib.ERR_INVALID_ARGUMENTS
 
 
-def test_c2_full_size_bit_exact_and_properties(cuda_device):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_c2_full_size_bit_exact_and_properties(layout, cuda_device):
     """BASELINE config 2 at full size: 1M entities, depth-8 hierarchy.  The C oracle does 1M
     entities in well under a second, so the full-size check is bit-exact too; on top:
     sortedness, count == popcount(mask), and idempotence of a clean frame."""
     from clap_amd import entities
-    scene = synth.pad_levels(synth.entities_chains(125_000, 8, 2))
+    scene = lay_out(synth.entities_chains(125_000, 8, 2), layout)
     cam = synth.camera()
     fr, _v, _p = entities.view_calc_frustum(cam)
     fr_o, _vo, _po = ob.frustum_from_camera(cam)
@@ -198,3 +212,31 @@ def test_c2_full_size_bit_exact_and_properties(cuda_device):
     out2 = batch.download()
     assert np.array_equal(out2["mx"].view(np.uint32), mx_before.view(np.uint32))
     assert np.array_equal(out2["visible"], v)
+
+
+def test_tile_external_parent(cuda_device):
+    """A tile whose first row hangs off parents OUTSIDE the tile (updated by an earlier call):
+    they are read from mx[] / seqs[] in HBM, the rest of the tile still chains through registers."""
+    from clap_amd import entities
+    base = synth.entities_chains(100, 5, 12)
+    scene, tl = tiler.tiled_scene(base)
+    n = scene["n"]
+    cam = synth.camera()
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    vis, mask = oracle_frame(scene, st, fr_o)
+    # split every tile in two: rows [0,2) form tile A, rows [2,5) form tile B whose row 0 has external parents
+    trs = scene["tile_row_start"].astype(np.int64)
+    top = np.stack([trs[:-1], trs[:-1] + 2], 1)
+    bottom = np.stack([trs[:-1] + 2, trs[1:]], 1)
+    batch = entities.EntityBatch(scene, cuda_device)
+    import torch
+    for part in (top, bottom):               # externals of `bottom` come from the earlier `top` calls
+        # the half-tiles of one part are not contiguous in rows: launch each through a 2-entry table
+        for a, b in part:
+            t = torch.from_numpy(np.asarray([a, b], np.uint32).view(np.int32)).to(cuda_device)
+            batch.tile_row_start, batch.n_tiles = t, 1
+            batch.mq_update(fr)
+    batch.compact_visible()
+    check_against(batch.download(), st, vis, mask, "external parents")
