@@ -40,42 +40,62 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Coalesced store of one mat4 per lane (64 consecutive matrices = 4 KiB) through a
-// wave-private 4 KiB LDS tile: each global_store_dwordx4 writes 1 KiB contiguous
-// instead of 64 x 16 B at a 64 B stride.  XOR swizzle keeps both the
-// ds_write_b128 (8-lane groups) and ds_read_b128 (16-lane groups) conflict-free.
-// All 64 lanes must call; `nvalid` = number of leading lanes whose matrix is stored.
-__device__ __forceinline__ void wave_store_mat4(float4 *tile, float *dst, const float (&m)[16],
-                                                int lane, int nvalid)
+// Wave-private LDS staging for coalesced output: each lane holds one row (a mat4, an
+// AABB, ...) of 64 consecutive entities; the rows are written to LDS lane-major and
+// read back 16 B per lane in memory order, so every global_store_dwordx4 writes 1 KiB
+// contiguous instead of 64 pieces at the row stride.  DS operations of one wave
+// execute in issue order, so reusing a region needs only the compiler-level fence.
+//
+// mat4: the XOR swizzle keeps ds_write_b128 (8-lane groups) and ds_read_b128
+// (16-lane groups) conflict-free.  All 64 lanes must call these.
+__device__ __forceinline__ void stage_mat4(float4 *tile, const float (&m)[16], int lane)
 {
     const int sw = (lane >> 1) & 3;
 #pragma unroll
     for (int c = 0; c < 4; c++)
         tile[lane * 4 + (c ^ sw)] = make_float4(m[4 * c], m[4 * c + 1], m[4 * c + 2], m[4 * c + 3]);
-    wave_lds_fence();
-    float4 *out = reinterpret_cast<float4 *>(dst);
+}
+
+__device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4], int lane)
+{
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int q = k * WAVE + lane;          // float4 index inside the wave's 4 KiB
         const int ent = q >> 2, col = q & 3;
-        float4 v = tile[ent * 4 + (col ^ ((ent >> 1) & 3))];
-        if (ent < nvalid)
-            out[q] = v;
+        v[k] = tile[ent * 4 + (col ^ ((ent >> 1) & 3))];
     }
-    wave_lds_fence();                            // tile is reused by the caller
 }
 
-// Coalesced store of ROW floats per lane (ROW = 6: aabb, ROW = 3: aabb_center).
+// dst = first matrix of the wave's 64; nvalid = leading lanes whose matrix is stored
+__device__ __forceinline__ void store_mat4_rows(float *dst, const float4 (&v)[4], int lane, int nvalid)
+{
+    float4 *out = reinterpret_cast<float4 *>(dst);
+    if (nvalid == WAVE) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k * WAVE + lane] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = k * WAVE + lane;
+            if ((q >> 2) < nvalid) out[q] = v[k];
+        }
+    }
+}
+
+// ROW floats per lane (ROW = 6: aabb, ROW = 3: aabb_center), tile region of 64*ROW floats.
 template <int ROW>
-__device__ __forceinline__ void wave_store_rows(float *tile, float *dst, const float (&v)[ROW],
-                                                int lane, int nvalid)
+__device__ __forceinline__ void stage_rows(float *tile, const float (&v)[ROW], int lane)
 {
 #pragma unroll
     for (int k = 0; k < ROW; k++)
         tile[lane * ROW + k] = v[k];
-    wave_lds_fence();
+}
+
+template <int ROW>
+__device__ __forceinline__ void store_rows(const float *tile, float *dst, int lane, int nvalid)
+{
     const int limit = nvalid * ROW;              // floats to store
-    constexpr int CHUNKS = (WAVE * ROW + 3) / 4; // float4 chunks in the tile
+    constexpr int CHUNKS = (WAVE * ROW + 3) / 4; // float4 chunks in the tile region
 #pragma unroll
     for (int k = 0; k < (CHUNKS + WAVE - 1) / WAVE; k++) {
         const int q = k * WAVE + lane;
@@ -90,7 +110,6 @@ __device__ __forceinline__ void wave_store_rows(float *tile, float *dst, const f
             }
         }
     }
-    wave_lds_fence();
 }
 
 } // namespace clapgpu

@@ -12,6 +12,7 @@
 // every output row block (64 entities x 64 / 64 / 24 / 12 B) is transposed through
 // a wave-private LDS tile so each store instruction writes 1 KiB contiguous.
 #include <string.h>
+#include <math.h>
 #include "common.h"
 #include "lm_dev.h"
 
@@ -44,28 +45,50 @@ __device__ __forceinline__ void load_mat4(float (&m)[16], const float *src)
     }
 }
 
+// Per-lane inputs of one row, all loaded unconditionally so that a tile-walking wave
+// can issue the NEXT row's loads before it computes the current one.
+struct RowIn {
+    uint32_t fl, sq;
+    int32_t  p, mi;
+    float4   ps, q;
+};
+
+__device__ __forceinline__ RowIn load_row(const EntK &e, const int lane, const uint32_t row_first,
+                                          const uint32_t row_count)
+{
+    const uint32_t i = row_first + ((uint32_t)lane < row_count ? lane : 0);   // idle lanes re-read lane 0's entity
+    RowIn r;
+    r.fl = e.flags[i];
+    r.p = e.parent[i];
+    r.sq = e.seqs[i];
+    r.mi = e.model[i];
+    r.ps = e.pos_scale[i];
+    r.q = e.rot[i];
+    return r;
+}
+
 // One 64-entity row (= one vis_mask word) processed by one wave.
 //   row_first  first entity of the row (multiple of 64), row_count valid lanes (1..64)
+//   tile       8 KiB of wave-private LDS
 //   TILE       the wave walks a tile of consecutive rows (= hierarchy levels of a group of
 //              whole subtrees); a parent that sits in the previous row is taken from the
 //              registers of the lane that just computed it (16 cross-lane reads) instead of
 //              being re-read from HBM.  carry_* hold the previous row's results.
 template <bool CULL, bool TILE>
-__device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const int lane,
+__device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, float4 *tile, const int lane,
                                             const uint32_t row_first, const uint32_t row_count,
-                                            const uint32_t mode, const lmd::Frustum &fr,
+                                            const uint32_t mode, const lmd::FrustumK &fr,
                                             const bool have_prev, const uint32_t prev_first,
                                             float (&carry_mx)[16], uint32_t &carry_seq, bool &carry_valid)
 {
     const bool in_range = (uint32_t)lane < row_count;
-    const uint32_t i = row_first + (in_range ? lane : 0);        // idle lanes re-read lane 0's entity
+    const uint32_t i = row_first + (in_range ? lane : 0);
 
-    const uint32_t fl = e.flags[i];
+    const uint32_t fl = in.fl;
     const bool alive = in_range && (fl & CLAPGPU_E_ALIVE);
     const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
-    const int32_t p = e.parent[i];
-    const uint32_t sq = e.seqs[i];
-    uint32_t seq = sq & 0xffffu, pseq = sq >> 16;
+    const int32_t p = in.p;
+    uint32_t seq = in.sq & 0xffffu, pseq = in.sq >> 16;
 
     // ---- where does the parent live? ----
     bool in_prev = false;
@@ -98,10 +121,10 @@ __device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const i
     bool has_aabb = false;
 
     if (rebuild) {
-        const float4 ps = e.pos_scale[i];
-        const float4 q = e.rot[i];
+        const float4 lo = e.model_table[2 * in.mi];              // min.xyz, skip_aabb bits
+        const float4 hi = e.model_table[2 * in.mi + 1];          // max.xyz, 0
         float local_mx[16];
-        lmd::trs(local_mx, ps.x, ps.y, ps.z, ps.w, q.x, q.y, q.z, q.w);
+        lmd::trs(local_mx, in.ps.x, in.ps.y, in.ps.z, in.ps.w, in.q.x, in.q.y, in.q.z, in.q.w);
         if (p >= 0) {
             if (!parent_in_regs)
                 load_mat4(pm, e.mx + 16 * (size_t)p);            // stored matrix of a parent not rebuilt here
@@ -112,9 +135,6 @@ __device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const i
         }
         lmd::invert(inv, mx);
 
-        const int32_t mi = e.model[i];
-        const float4 lo = e.model_table[2 * mi];                 // min.xyz, skip_aabb bits
-        const float4 hi = e.model_table[2 * mi + 1];             // max.xyz, 0
         has_aabb = __float_as_uint(lo.w) == 0u;                  // model.c:1204
         if (has_aabb)
             lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
@@ -137,10 +157,19 @@ __device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const i
     const uint64_t aabb_mask = __ballot(rebuild && has_aabb);
     const uint64_t full = row_count == WAVE ? ~0ull : ((1ull << row_count) - 1ull);
     const size_t e0 = row_first;
+    float4 *tile_a = tile, *tile_b = tile + 256;                 // 2 x 4 KiB
+    float *tile_f = reinterpret_cast<float *>(tile);
 
     if (rebuilt_mask == full) {
-        wave_store_mat4(tile, e.mx + 16 * e0, mx, lane, (int)row_count);
-        wave_store_mat4(tile, e.inv_mx + 16 * e0, inv, lane, (int)row_count);
+        float4 va[4], vb[4];
+        stage_mat4(tile_a, mx, lane);
+        stage_mat4(tile_b, inv, lane);
+        wave_lds_fence();
+        unstage_mat4(tile_a, va, lane);
+        unstage_mat4(tile_b, vb, lane);
+        store_mat4_rows(e.mx + 16 * e0, va, lane, (int)row_count);
+        store_mat4_rows(e.inv_mx + 16 * e0, vb, lane, (int)row_count);
+        wave_lds_fence();
     } else if (rebuild) {
         float4 *dm = reinterpret_cast<float4 *>(e.mx + 16 * (size_t)i);
         float4 *di = reinterpret_cast<float4 *>(e.inv_mx + 16 * (size_t)i);
@@ -151,8 +180,12 @@ __device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const i
         }
     }
     if (aabb_mask == full) {
-        wave_store_rows<6>(reinterpret_cast<float *>(tile), e.aabb + 6 * e0, bb, lane, (int)row_count);
-        wave_store_rows<3>(reinterpret_cast<float *>(tile), e.center + 3 * e0, ctr, lane, (int)row_count);
+        stage_rows<6>(tile_f, bb, lane);                         // 1536 B
+        stage_rows<3>(tile_f + 6 * WAVE, ctr, lane);             //  768 B
+        wave_lds_fence();
+        store_rows<6>(tile_f, e.aabb + 6 * e0, lane, (int)row_count);
+        store_rows<3>(tile_f + 6 * WAVE, e.center + 3 * e0, lane, (int)row_count);
+        wave_lds_fence();
     } else if (rebuild && has_aabb) {
 #pragma unroll
         for (int k = 0; k < 6; k++) e.aabb[6 * (size_t)i + k] = bb[k];
@@ -168,20 +201,22 @@ __device__ __forceinline__ void process_row(const EntK &e, float4 *tile, const i
         }
         bool vis = in_range && (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);   // model.c:959-965
         if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
-            vis = lmd::aabb_in_frustum(fr, bb);                                       // model.c:967-971
+            vis = lmd::aabb_in_frustum_fast(fr, bb);                                  // model.c:967-971
         const uint64_t m = __ballot(vis);
         if (lane == 0)
             e.vis_mask[e0 >> 6] = m;
     }
 }
 
+constexpr int LDS_F4_PER_WAVE = 512;                             // 8 KiB
+
 // One launch per hierarchy level: every parent was written by an earlier launch.
 // `first` is a multiple of 64, so each wave owns exactly one vis_mask word.
 template <bool CULL>
 __global__ __launch_bounds__(ENT_BLOCK)
-void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::Frustum fr)
+void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::FrustumK fr)
 {
-    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];          // 4 KiB per wave
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     const uint32_t wave_local0 = blockIdx.x * ENT_BLOCK + wave * WAVE;
@@ -191,18 +226,20 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
     float carry_mx[16];
     uint32_t carry_seq = 0;
     bool carry_valid = false;
-    process_row<CULL, false>(e, lds_tiles[wave], lane, first + wave_local0, row_count, mode, fr,
+    const RowIn in = load_row(e, lane, first + wave_local0, row_count);
+    process_row<CULL, false>(e, in, lds_tiles[wave], lane, first + wave_local0, row_count, mode, fr,
                              false, 0, carry_mx, carry_seq, carry_valid);
 }
 
 // One launch for the whole forest: wave t walks tile t = rows [tile_row_start[t], tile_row_start[t+1]),
 // row r = entities [64r, 64r+64) = one hierarchy level of the subtrees packed into the tile.
+// The next row's inputs are in flight while the current row is computed.
 template <bool CULL>
 __global__ __launch_bounds__(ENT_BLOCK)
 void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
-                      uint32_t mode, lmd::Frustum fr)
+                      uint32_t mode, lmd::FrustumK fr)
 {
-    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][256];
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     const uint32_t t = blockIdx.x * (ENT_BLOCK / WAVE) + wave;
@@ -211,6 +248,8 @@ void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, 
     const uint32_t n_rows = (n + WAVE - 1) / WAVE;
     uint32_t row = tile_row_start[t], row_end = tile_row_start[t + 1];
     if (row_end > n_rows) row_end = n_rows;                      // never walk past the arrays
+    if (row >= row_end)
+        return;
 
     float carry_mx[16];
 #pragma unroll
@@ -218,19 +257,32 @@ void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, 
     uint32_t carry_seq = 0;
     bool carry_valid = false;
     bool have_prev = false;
-    for (; row < row_end; row++) {
-        const uint32_t row_first = row * WAVE;
-        const uint32_t row_count = n - row_first < WAVE ? n - row_first : WAVE;
-        process_row<CULL, true>(e, lds_tiles[wave], lane, row_first, row_count, mode, fr,
+
+    uint32_t row_first = row * WAVE;
+    uint32_t row_count = n - row_first < WAVE ? n - row_first : WAVE;
+    RowIn cur = load_row(e, lane, row_first, row_count);
+    for (;;) {
+        const uint32_t next = row + 1;
+        const bool more = next < row_end;
+        const uint32_t nfirst = more ? next * WAVE : row_first;  // last row: harmless re-load
+        const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
+        const RowIn nxt = load_row(e, lane, nfirst, ncount);     // in flight during process_row
+        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, fr,
                                 have_prev, row_first - WAVE, carry_mx, carry_seq, carry_valid);
+        if (!more)
+            break;
         have_prev = true;
+        cur = nxt;
+        row = next;
+        row_first = nfirst;
+        row_count = ncount;
     }
 }
 
 // Cull-only pass over stored AABBs (one per render pass in the reference).
 __global__ __launch_bounds__(ENT_BLOCK)
 void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint32_t n,
-                     lmd::Frustum fr)
+                     lmd::FrustumK fr)
 {
     const uint32_t i = blockIdx.x * ENT_BLOCK + threadIdx.x;
     bool vis = false;
@@ -241,7 +293,7 @@ void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mas
             float bb[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) bb[k] = aabb[6 * (size_t)i + k];
-            vis = lmd::aabb_in_frustum(fr, bb);
+            vis = lmd::aabb_in_frustum_fast(fr, bb);
         }
     }
     const uint64_t m = __ballot(vis);
@@ -341,6 +393,36 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     return k;
 }
 
+// Kernel-side frustum: adds the per-axis extremes of the frustum corners (NaN if any corner is
+// NaN, so the comparison is false exactly when the reference's count cannot reach 8) and a flag
+// telling whether every plane component is finite.
+static lmd::FrustumK make_frustum_k(const clapgpu_frustum *frustum)
+{
+    static_assert(sizeof(lmd::Frustum) == sizeof(clapgpu_frustum), "frustum layout");
+    lmd::FrustumK k = {};
+    if (!frustum)
+        return k;
+    memcpy(&k.f, frustum, sizeof(k.f));
+    for (int ax = 0; ax < 3; ax++) {
+        float lo = INFINITY, hi = -INFINITY;
+        bool nan = false;
+        for (int i = 0; i < 8; i++) {
+            const float c = k.f.corners[i][ax];
+            nan = nan || (c != c);
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+        k.cmin[ax] = nan ? NAN : lo;
+        k.cmax[ax] = nan ? NAN : hi;
+    }
+    k.finite = 1;
+    for (int i = 0; i < 6; i++)
+        for (int c = 0; c < 4; c++)
+            if (!(fabsf(k.f.planes[i][c]) <= 3.402823466e+38f))
+                k.finite = 0;
+    return k;
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int check_entities(const clapgpu_entities *e, bool need_mask)
@@ -359,10 +441,7 @@ static int check_entities(const clapgpu_entities *e, bool need_mask)
 static int launch_level(void *stream, const EntK &k, uint32_t first, uint32_t count, uint32_t mode,
                         const clapgpu_frustum *frustum)
 {
-    static_assert(sizeof(lmd::Frustum) == sizeof(clapgpu_frustum), "frustum layout");
-    lmd::Frustum fr = {};
-    if (frustum)
-        memcpy(&fr, frustum, sizeof(fr));
+    const lmd::FrustumK fr = make_frustum_k(frustum);
     const dim3 grid((count + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
     if (frustum)
         hipLaunchKernelGGL(k_entities_level<true>, grid, block, 0, as_stream(stream), k, first, count, mode, fr);
@@ -424,9 +503,7 @@ extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entitie
         return CLAPGPU_OK;
     if (!tile_row_start)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    lmd::Frustum fr = {};
-    if (frustum)
-        memcpy(&fr, frustum, sizeof(fr));
+    const lmd::FrustumK fr = make_frustum_k(frustum);
     const EntK k = to_kernel_args(e);
     const uint32_t per_block = ENT_BLOCK / WAVE;
     const dim3 grid((n_tiles + per_block - 1) / per_block), block(ENT_BLOCK);
@@ -446,8 +523,7 @@ extern "C" int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, co
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (e->n == 0)
         return CLAPGPU_OK;
-    lmd::Frustum fr;
-    memcpy(&fr, frustum, sizeof(fr));
+    const lmd::FrustumK fr = make_frustum_k(frustum);
     const dim3 grid((e->n + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
     hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask, e->n, fr);
     CLAPGPU_LAUNCH_CHECK("k_entities_cull");

@@ -231,4 +231,50 @@ LMD bool aabb_in_frustum(const Frustum &f, const float (&bb)[6])
     return true;
 }
 
+// Kernel-side frustum: the reference's planes/corners plus per-axis extremes of the 8
+// frustum corners, precomputed on the host (make_frustum_k in entities.hip).
+struct FrustumK {
+    Frustum  f;
+    float    cmin[3];      // min_i corners[i][ax], NaN if any is NaN
+    float    cmax[3];      // max_i corners[i][ax], NaN if any is NaN
+    uint32_t finite;       // every plane component is finite
+};
+
+// Same decisions as aabb_in_frustum with ~1/8 of the arithmetic:
+//  * plane i rejects iff all 8 corner dots are < 0 iff the LARGEST dot is < 0.  Each dot is the
+//    fp32 chain (((0 + x px) + y py) + z pz) + pw; rounding is monotone, so the chain is
+//    non-decreasing in every product and the largest value is reached at the corner that takes
+//    max[a] where the plane component is >= 0 and min[a] otherwise -- the same fp32 operations
+//    on the same operands, hence the same bits.  With a non-finite box or plane (0 * inf = NaN
+//    breaks monotonicity) the literal 8-corner test is used.
+//  * "all 8 frustum corners beyond the box on axis a" compares the per-axis extreme only.
+LMD bool aabb_in_frustum_fast(const FrustumK &k, const float (&bb)[6])
+{
+    bool box_finite = true;
+#pragma unroll
+    for (int a = 0; a < 6; a++) box_finite = box_finite && (fabsf(bb[a]) <= 3.402823466e+38f);
+    if (!(k.finite && box_finite))
+        return aabb_in_frustum(k.f, bb);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        // (fmin/fmax: a stored box with max < min is still handled exactly)
+        const float x = (k.f.planes[i][0] >= 0.f) ? fmaxf(bb[0], bb[3]) : fminf(bb[0], bb[3]);
+        const float y = (k.f.planes[i][1] >= 0.f) ? fmaxf(bb[1], bb[4]) : fminf(bb[1], bb[4]);
+        const float z = (k.f.planes[i][2] >= 0.f) ? fmaxf(bb[2], bb[5]) : fminf(bb[2], bb[5]);
+        float p = 0.f;
+        p += x * k.f.planes[i][0];
+        p += y * k.f.planes[i][1];
+        p += z * k.f.planes[i][2];
+        p += 1.0f * k.f.planes[i][3];
+        if (p < 0.0f)
+            return false;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        if (k.cmin[ax] > bb[3 + ax]) return false;
+        if (k.cmax[ax] < bb[ax]) return false;
+    }
+    return true;
+}
+
 } // namespace lmd

@@ -240,3 +240,46 @@ def test_tile_external_parent(cuda_device):
             batch.mq_update(fr)
     batch.compact_visible()
     check_against(batch.download(), st, vis, mask, "external parents")
+
+
+def test_cull_kernel_exact_on_adversarial_boxes(cuda_device):
+    """The kernels decide each frustum plane on one corner (the one maximising the fp32 dot
+    chain) instead of eight.  That must give the reference's decision bit for bit, including
+    boxes lying exactly on planes, planes with zero components, inverted, infinite and NaN boxes."""
+    from clap_amd import entities
+    rng = np.random.Generator(np.random.PCG64(123))
+    n = 64 * 300
+    for camkw in (dict(), dict(ndc_z_zero_one=1), dict(pos=(3, -2, 7), quat=synth.quat_from_euler_xyz(0.3, -1.1, 0.4)),
+                  dict(quat=synth.quat_from_euler_xyz(0.0, np.pi / 2, 0.0))):
+        cam = synth.camera(**camkw)
+        fr, _v, _p = entities.view_calc_frustum(cam)
+        fr_o, _vo, _po = ob.frustum_from_camera(cam)
+        planes, corners = fr_o.arrays()
+        lo = rng.uniform(-600, 600, (n, 3)).astype(np.float32)
+        ext = rng.uniform(0, 50, (n, 3)).astype(np.float32)
+        aabb = np.concatenate([lo, lo + ext], 1).astype(np.float32)
+        # boxes whose corner sits (almost) exactly on a frustum corner / plane
+        k = np.arange(0, n, 7)
+        aabb[k, 3:6] = corners[rng.integers(0, 8, k.size), :3]
+        aabb[k, 0:3] = aabb[k, 3:6] - rng.uniform(0, 1, (k.size, 3)).astype(np.float32)
+        k = np.arange(3, n, 11)
+        aabb[k, 0:3] = corners[rng.integers(0, 8, k.size), :3]
+        aabb[k, 3:6] = np.nextafter(aabb[k, 0:3], np.float32(np.inf))
+        aabb[5::97, 3] = np.inf                      # infinite
+        aabb[9::101, 1] = -np.inf
+        aabb[13::103, 2] = np.nan                    # NaN
+        sw = np.arange(17, n, 89)                    # inverted (max < min)
+        aabb[sw] = aabb[sw][:, [3, 4, 5, 0, 1, 2]]
+        aabb[21::64] = 0.0                           # degenerate at the origin (camera position)
+        flags = np.full(n, synth.E_ALIVE | synth.E_VISIBLE, np.uint32)
+        vis, mask = ob.entities_cull(n, flags, aabb, fr_o)
+        scene = synth.pad_levels(synth.entities_flat(n, 1))
+        batch = entities.EntityBatch(scene, cuda_device)
+        import torch
+        batch.aabb.copy_(torch.from_numpy(aabb))
+        batch.cull(fr)
+        batch.compact_visible()
+        out = batch.download()
+        assert np.array_equal(out["vis_mask"], mask), camkw
+        assert np.array_equal(out["visible"], vis), camkw
+        assert 0 < vis.size < n
