@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_NOMEM = -1
@@ -49,7 +49,8 @@ class Entities(C.Structure):
                 ("pos_scale", C.c_void_p), ("rot", C.c_void_p), ("parent", C.c_void_p),
                 ("model", C.c_void_p), ("model_table", C.c_void_p), ("flags", C.c_void_p),
                 ("seqs", C.c_void_p), ("mx", C.c_void_p), ("inv_mx", C.c_void_p),
-                ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p)]
+                ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p),
+                ("vis_row_pop", C.c_void_p)]
 
 
 # every symbol include/clapgpu.h declares: name -> (restype, argtypes)
@@ -75,8 +76,8 @@ SYMBOLS = {
                                                 C.c_uint32, C.POINTER(Frustum)]),
     "clapgpu_entities_cull": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.POINTER(Frustum)]),
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
-    "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
-                                          C.c_void_p]),
+    "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

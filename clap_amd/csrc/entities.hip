@@ -31,6 +31,7 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     float          *aabb;
     float          *center;
     uint64_t       *vis_mask;
+    uint8_t        *vis_row_pop;
 };
 
 constexpr int ENT_BLOCK = 256;
@@ -203,8 +204,10 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
         if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
             vis = lmd::aabb_in_frustum_fast(fr, bb);                                  // model.c:967-971
         const uint64_t m = __ballot(vis);
-        if (lane == 0)
+        if (lane == 0) {
             e.vis_mask[e0 >> 6] = m;
+            e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);       // feeds the single-launch compaction
+        }
     }
 }
 
@@ -281,8 +284,8 @@ void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, 
 
 // Cull-only pass over stored AABBs (one per render pass in the reference).
 __global__ __launch_bounds__(ENT_BLOCK)
-void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint32_t n,
-                     lmd::FrustumK fr)
+void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint8_t *vis_row_pop,
+                     uint32_t n, lmd::FrustumK fr)
 {
     const uint32_t i = blockIdx.x * ENT_BLOCK + threadIdx.x;
     bool vis = false;
@@ -297,8 +300,10 @@ void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mas
         }
     }
     const uint64_t m = __ballot(vis);
-    if (lane_id() == 0 && (i - lane_id()) < n)
+    if (lane_id() == 0 && (i - lane_id()) < n) {
         vis_mask[i >> 6] = m;
+        vis_row_pop[i >> 6] = (uint8_t)__popcll(m);
+    }
 }
 
 // ---- ordered compaction of the visibility bitmask ----
@@ -371,6 +376,66 @@ void k_visible_expand(const uint64_t *vis_mask, uint32_t n, const uint32_t *grou
         *count = pre + incl;
 }
 
+// Single-launch compaction for up to RP_MAX_ROWS rows: the update / cull kernels leave one
+// popcount byte per 64-entity row, so a wave gets the number of visible entities before its
+// first row from at most RP_MAX_ROWS / 1024 16-byte loads per lane -- no separate count pass.
+constexpr int RP_ROWS = 16;                 // rows (mask words) per wave; 16 keeps the byte prefix 16-B aligned
+constexpr uint32_t RP_MAX_ROWS = 1u << 16;  // 4M entities; beyond that the two-pass path scales better
+
+__device__ __forceinline__ uint32_t sum_bytes(uint32_t v, uint32_t acc)
+{
+    return __builtin_amdgcn_sad_u8(v, 0u, acc);      // v_sad_u8: acc + sum of the 4 bytes
+}
+
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_visible_expand_rp(const uint64_t *vis_mask, const uint8_t *row_pop, uint32_t n,
+                         uint32_t index_base, uint32_t *visible, uint32_t *count)
+{
+    const int lane = lane_id();
+    const uint32_t g = blockIdx.x * (ENT_BLOCK / WAVE) + threadIdx.x / WAVE;
+    const uint32_t n_rows = (n + 63) / 64;
+    const uint32_t row0 = g * RP_ROWS;
+    if (row0 >= n_rows)
+        return;
+
+    uint32_t pre = 0;                                 // visible entities in rows [0, row0)
+    const uint4 *rp = reinterpret_cast<const uint4 *>(row_pop);
+    for (uint32_t c = lane; c * 16 < row0; c += WAVE) {
+        const uint4 v = rp[c];
+        pre = sum_bytes(v.x, pre);
+        pre = sum_bytes(v.y, pre);
+        pre = sum_bytes(v.z, pre);
+        pre = sum_bytes(v.w, pre);
+    }
+    pre = wave_sum(pre);
+
+    const uint64_t word = lane < RP_ROWS ? load_mask_word(vis_mask, row0 + lane, n) : 0ull;
+    const uint32_t cnt = __popcll(word);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < RP_ROWS; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - cnt;
+    const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+
+#pragma unroll
+    for (int k = 0; k < RP_ROWS; k++) {
+        // readlane returns int: go through uint32_t or bit 31 sign-extends into the high half
+        const uint64_t wk = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, k) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32);
+        if (wk == 0) continue;                        // scalar branch
+        const uint32_t base = pre + (uint32_t)__builtin_amdgcn_readlane(excl, k);
+        if ((wk >> lane) & 1ull) {
+            const uint32_t rank = __popcll(wk & ((1ull << lane) - 1ull));
+            visible[base + rank] = index_base + (row0 + k) * 64u + lane;
+        }
+    }
+    if (row0 + RP_ROWS >= n_rows && lane == RP_ROWS - 1)
+        *count = pre + incl;
+}
+
 } // namespace clapgpu
 
 using namespace clapgpu;
@@ -390,6 +455,7 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     k.aabb = e->aabb;
     k.center = e->center;
     k.vis_mask = e->vis_mask;
+    k.vis_row_pop = e->vis_row_pop;
     return k;
 }
 
@@ -430,7 +496,7 @@ static int check_entities(const clapgpu_entities *e, bool need_mask)
     if (!e || !e->pos_scale || !e->rot || !e->parent || !e->model || !e->model_table || !e->flags ||
         !e->seqs || !e->mx || !e->inv_mx || !e->aabb || !e->center)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    if (need_mask && !e->vis_mask)
+    if (need_mask && (!e->vis_mask || !e->vis_row_pop))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!aligned16(e->pos_scale) || !aligned16(e->rot) || !aligned16(e->model_table) || !aligned16(e->mx) ||
         !aligned16(e->inv_mx) || !aligned16(e->aabb) || !aligned16(e->center))
@@ -519,13 +585,14 @@ extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entitie
 
 extern "C" int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum)
 {
-    if (!e || !frustum || !e->flags || !e->aabb || !e->vis_mask)
+    if (!e || !frustum || !e->flags || !e->aabb || !e->vis_mask || !e->vis_row_pop)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (e->n == 0)
         return CLAPGPU_OK;
     const lmd::FrustumK fr = make_frustum_k(frustum);
     const dim3 grid((e->n + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
-    hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask, e->n, fr);
+    hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask,
+                       e->vis_row_pop, e->n, fr);
     CLAPGPU_LAUNCH_CHECK("k_entities_cull");
     return CLAPGPU_OK;
 }
@@ -536,16 +603,26 @@ extern "C" size_t clapgpu_visible_scratch_bytes(uint32_t n)
     return (size_t)(n_groups ? n_groups : 1) * sizeof(uint32_t);
 }
 
-extern "C" int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, uint32_t n,
-                                       uint32_t index_base, uint32_t *visible, uint32_t *count,
+extern "C" int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, const uint8_t *vis_row_pop,
+                                       uint32_t n, uint32_t index_base, uint32_t *visible, uint32_t *count,
                                        void *scratch)
 {
-    if (!count || (n && (!vis_mask || !visible || !scratch)))
+    if (!count || (n && (!vis_mask || !visible)))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (n == 0) {
         CLAPGPU_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), as_stream(stream)));
         return CLAPGPU_OK;
     }
+    const uint32_t n_rows = (n + 63) / 64;
+    if (vis_row_pop && n_rows <= RP_MAX_ROWS && aligned16(vis_row_pop)) {
+        const uint32_t waves = (n_rows + RP_ROWS - 1) / RP_ROWS, per_block = ENT_BLOCK / WAVE;
+        hipLaunchKernelGGL(k_visible_expand_rp, dim3((waves + per_block - 1) / per_block), dim3(ENT_BLOCK), 0,
+                           as_stream(stream), vis_mask, vis_row_pop, n, index_base, visible, count);
+        CLAPGPU_LAUNCH_CHECK("k_visible_expand_rp");
+        return CLAPGPU_OK;
+    }
+    if (!scratch)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const uint32_t n_groups = (n + GROUP_WORDS * 64 - 1) / (GROUP_WORDS * 64);
     uint32_t *group_count = static_cast<uint32_t *>(scratch);
     hipLaunchKernelGGL(k_mask_group_count, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), vis_mask, n, group_count);

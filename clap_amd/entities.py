@@ -84,6 +84,8 @@ class EntityBatch:
         self.aabb = torch.zeros((n, 6), dtype=torch.float32, device=dev)
         self.center = torch.zeros((n, 3), dtype=torch.float32, device=dev)
         self.vis_mask = torch.zeros(((n + 63) // 64 or 1,), dtype=torch.int64, device=dev)
+        n_rows = (n + 63) // 64
+        self.vis_row_pop = torch.zeros(((n_rows + 15) // 16 * 16 or 16,), dtype=torch.uint8, device=dev)
         self.visible = torch.zeros((max(n, 1),), dtype=torch.int32, device=dev)
         self.visible_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         nscratch = _lib.lib().clapgpu_visible_scratch_bytes(n)
@@ -93,7 +95,8 @@ class EntityBatch:
             pos_scale=self.pos_scale.data_ptr(), rot=self.rot.data_ptr(), parent=self.parent.data_ptr(),
             model=self.model.data_ptr(), model_table=self.model_table.data_ptr(), flags=self.flags.data_ptr(),
             seqs=self.seqs.data_ptr(), mx=self.mx.data_ptr(), inv_mx=self.inv_mx.data_ptr(),
-            aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr())
+            aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr(),
+            vis_row_pop=self.vis_row_pop.data_ptr())
 
     # ---- reference-named operations -------------------------------------------------
     def mq_update(self, frustum=None, all_dirty=False):
@@ -124,9 +127,11 @@ class EntityBatch:
         rc = _lib.lib().clapgpu_entities_cull(_stream(), C.byref(self._desc), C.byref(frustum))
         _lib.check(rc, "clapgpu_entities_cull")
 
-    def compact_visible(self, index_base=0):
-        """Build the ascending visible-index list on the device (visible[:visible_count])."""
-        rc = _lib.lib().clapgpu_visible_compact(_stream(), _ptr(self.vis_mask), self.n, index_base,
+    def compact_visible(self, index_base=0, two_pass=False):
+        """Build the ascending visible-index list on the device (visible[:visible_count]).
+        two_pass forces the large-n path (no per-row popcounts)."""
+        rc = _lib.lib().clapgpu_visible_compact(_stream(), _ptr(self.vis_mask),
+                                                None if two_pass else _ptr(self.vis_row_pop), self.n, index_base,
                                                 _ptr(self.visible), _ptr(self.visible_count), _ptr(self.scratch))
         _lib.check(rc, "clapgpu_visible_compact")
 

@@ -101,6 +101,8 @@ void clapgpu_frustum_calc(const float view_mx[16], const float proj_mx[16],
  *            center[n][3]                            entity3d.aabb_center
  *            vis_mask[ceil(n/64)]  bit i%64 of word i/64 = entity i passes the
  *                                  draw predicate of _models_render (model.c:959-973)
+ *            vis_row_pop[ceil(n/64)] popcount of each vis_mask word (uint8); allocate the
+ *                                  array rounded up to a multiple of 16 bytes, 16-B aligned
  */
 typedef struct clapgpu_entities {
     uint32_t        n;
@@ -117,6 +119,7 @@ typedef struct clapgpu_entities {
     float          *aabb;
     float          *center;
     uint64_t       *vis_mask;
+    uint8_t        *vis_row_pop;
 } clapgpu_entities;
 
 /* mode bits for clapgpu_entities_update */
@@ -169,14 +172,16 @@ int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu
 /*
  * Ordered compaction of vis_mask into the ascending entity-index list the draw
  * loop iterates: visible[0..*count) = index_base + i for every set bit i.
- * `visible` needs room for n entries, `count` is one device uint32, `scratch` is
- * clapgpu_visible_scratch_bytes(n) bytes of device memory; index_base is the global
- * id of this shard's entity 0 (0 on a single GPU).  (Build-defined: the reference
- * walks its entity list and tests each entity in place, model.c:958-973.)
+ * `visible` needs room for n entries, `count` is one device uint32; index_base is the
+ * global id of this shard's entity 0 (0 on a single GPU).  With vis_row_pop (as left by
+ * the update / cull kernels) and n <= 4M the list is built in ONE launch; otherwise
+ * (vis_row_pop == NULL or larger n) in two, using `scratch` =
+ * clapgpu_visible_scratch_bytes(n) bytes of device memory.  (Build-defined: the
+ * reference walks its entity list and tests each entity in place, model.c:958-973.)
  */
 size_t clapgpu_visible_scratch_bytes(uint32_t n);
-int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, uint32_t n,
-                            uint32_t index_base, uint32_t *visible, uint32_t *count,
+int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, const uint8_t *vis_row_pop,
+                            uint32_t n, uint32_t index_base, uint32_t *visible, uint32_t *count,
                             void *scratch);
 
 #ifdef __cplusplus

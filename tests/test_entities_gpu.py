@@ -91,6 +91,10 @@ def test_hip_matches_oracle(maker, camkw, layout, cuda_device):
     batch.mq_update(fr)
     batch.compact_visible()
     check_against(batch.download(), st, vis, mask, "fused update+cull")
+    batch.visible.zero_()
+    batch.compact_visible(index_base=7, two_pass=True)       # large-n compaction path, shard offset
+    out = batch.download()
+    assert np.array_equal(out["visible"], vis + 7) and out["visible_count"] == vis.size
 
     # second frame with nothing dirty: nothing may change (seq/parent_seq skip path), cull repeats
     vis2, mask2 = oracle_frame(scene, st, fr_o)
