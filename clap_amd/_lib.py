@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_NOMEM = -1
@@ -53,6 +53,14 @@ class Entities(C.Structure):
                 ("vis_row_pop", C.c_void_p)]
 
 
+class Particles(C.Structure):
+    """clapgpu_particles (include/clapgpu.h)."""
+    _fields_ = [("n", C.c_uint32), ("n_sys", C.c_uint32), ("sys", C.c_void_p), ("row_sys", C.c_void_p),
+                ("pos", C.c_void_p), ("vel", C.c_void_p), ("rng_state", C.c_void_p),
+                ("billboard_mx", C.c_void_p), ("respawn_mask", C.c_void_p), ("respawn_row_pop", C.c_void_p),
+                ("respawn_list", C.c_void_p), ("respawn_count", C.c_void_p), ("scratch", C.c_void_p)]
+
+
 # every symbol include/clapgpu.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "clapgpu_device_count": (C.c_int, []),
@@ -78,6 +86,7 @@ SYMBOLS = {
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -218,3 +218,44 @@ def model_table(scene):
     t[:, 4:7] = scene["model_aabb"][:, 3:6]
     t.view(np.uint32)[:, 3] = scene["model_skip"].astype(np.uint32)
     return t
+
+
+# ----------------------------------------------------------------------------- particles
+PART_DIST_LIN, PART_DIST_SQRT, PART_DIST_CBRT, PART_DIST_POW075 = 0, 1, 2, 3
+DRAND48_DEFAULT_STATE = 0x1234ABCD330E      # glibc's initial drand48 state (the reference never seeds it)
+
+PSYS_DTYPE = np.dtype([("center", np.float32, 3), ("dist", np.uint32),
+                       ("radius", np.float64), ("min_radius", np.float64),
+                       ("radius_squared", np.float64), ("velocity", np.float64),
+                       ("first", np.uint32), ("count", np.uint32), ("pad", np.uint32, 2)])
+assert PSYS_DTYPE.itemsize == 64
+
+
+def particle_systems(n_sys=4096, count=1024, radius=10.0, min_radius=0.0, velocity=0.005,
+                     dist=PART_DIST_SQRT, seed=4, ragged=False):
+    """C4 (particles part): n_sys systems x count particles, radius 10, velocity 0.005
+    (particle.c:223 default), PART_DIST_SQRT.  Every system starts at a multiple of 64
+    particles (one wavefront row belongs to one system); `ragged` varies counts, radii and
+    distributions for parity tests."""
+    rng = _rng(seed)
+    sys = np.zeros(n_sys, PSYS_DTYPE)
+    sys["center"] = rng.uniform(-200, 200, (n_sys, 3)).astype(F32)
+    if ragged:
+        sys["count"] = rng.integers(1, count + 1, n_sys)
+        sys["radius"] = rng.uniform(0.5, radius, n_sys)
+        sys["min_radius"] = sys["radius"] * rng.uniform(0, 0.9, n_sys) * (rng.uniform(0, 1, n_sys) < 0.5)
+        sys["velocity"] = rng.uniform(0.5, 2.0, n_sys) * velocity
+        sys["dist"] = rng.integers(0, 2, n_sys)          # LIN / SQRT: the bit-exact distributions
+    else:
+        sys["count"] = count
+        sys["radius"] = radius
+        sys["min_radius"] = min_radius
+        sys["velocity"] = velocity
+        sys["dist"] = dist
+    sys["radius_squared"] = sys["radius"] * sys["radius"]
+    rows = (sys["count"].astype(np.int64) + 63) // 64
+    first_row = np.concatenate([[0], np.cumsum(rows)])
+    sys["first"] = (first_row[:-1] * 64).astype(np.uint32)
+    n = int(first_row[-1]) * 64
+    row_sys = np.repeat(np.arange(n_sys, dtype=np.uint32), rows)
+    return dict(sys=sys, n=n, n_real=int(sys["count"].sum()), row_sys=row_sys)

@@ -184,6 +184,60 @@ int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, const uint8_
                             uint32_t n, uint32_t index_base, uint32_t *visible, uint32_t *count,
                             void *scratch);
 
+/* ======================================================================== */
+/* Particle systems: advect / respawn / billboard (core/particle.c)          */
+/* ======================================================================== */
+
+#define CLAPGPU_PART_DIST_LIN     0   /* particle_dist, particle.h:13-18 */
+#define CLAPGPU_PART_DIST_SQRT    1
+#define CLAPGPU_PART_DIST_CBRT    2
+#define CLAPGPU_PART_DIST_POW075  3
+
+/* struct particle_system's simulation fields (particle.c:17-29), 64 bytes */
+typedef struct clapgpu_particle_system {
+    float    center[3];          /* transform_pos(&ps->e->xform) */
+    uint32_t dist;               /* ps->dist */
+    double   radius, min_radius, radius_squared, velocity;
+    uint32_t first, count;       /* particles [first, first+count); first is a multiple of 64 */
+    uint32_t pad[2];
+} clapgpu_particle_system;
+
+/*
+ * All particle systems of a model queue, particles stored system after system, every
+ * system starting at a multiple of 64 (row_sys[r] = system of particles [64r, 64r+64)).
+ *   pos[n][3]   particle.pos; after the call it IS ps->pos_array (particle.c:116,124):
+ *               system s uploads pos + 3*first, count vec3s
+ *   vel[n][3]   particle.velocity
+ *   rng_state[2] the libc drand48 state as 48-bit integers: [1] = position of the stream
+ *               before this call (input) and after it (output); [0] is internal.
+ *               Initialise both to the same value (glibc default 0x1234ABCD330E).
+ *   billboard_mx[n_sys][16]  entity3d.mx of each system's entity (particle.c:93-100), or NULL
+ *   respawn_mask[n/64], respawn_row_pop[n/64 rounded up to 16], respawn_list[n],
+ *   respawn_count[1], scratch (clapgpu_visible_scratch_bytes(n)): work space
+ */
+typedef struct clapgpu_particles {
+    uint32_t  n;
+    uint32_t  n_sys;
+    const clapgpu_particle_system *sys;
+    const uint32_t *row_sys;
+    float    *pos;
+    float    *vel;
+    uint64_t *rng_state;
+    float    *billboard_mx;
+    uint64_t *respawn_mask;
+    uint8_t  *respawn_row_pop;
+    uint32_t *respawn_list;
+    uint32_t *respawn_count;
+    void     *scratch;
+} clapgpu_particles;
+
+/*
+ * Replaces particles_update() (particle.c:89-120) for every system, in system order, with
+ * the reference's single drand48 stream reproduced exactly (7 draws per respawn, in particle
+ * order).  view_mx = scene camera's view.main.view_mx (HOST pointer, 16 floats).
+ */
+int clapgpu_particles_update(void *stream, const clapgpu_particles *p, const float view_mx[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,16 @@ def _declare(L):
     L.clapo_entities_cull.restype = C.c_uint32
 
 
+    L.clapo_srand48.argtypes = [C.c_int64]
+    L.clapo_srand48.restype = C.c_uint64
+    L.clapo_drand48.argtypes = [C.POINTER(C.c_uint64)]
+    L.clapo_drand48.restype = C.c_double
+    L.clapo_particles_spawn.argtypes = [C.c_void_p, C.c_uint32, F32P, F32P, C.POINTER(C.c_uint64)]
+    L.clapo_particles_update.argtypes = [C.c_void_p, C.c_uint32, F32P, F32P, C.POINTER(C.c_uint64)]
+    L.clapo_particles_update.restype = C.c_uint32
+    L.clapo_particles_billboard.argtypes = [F32P, F32P, F32P]
+
+
 # ------------------------------------------------------------------ helpers
 def frustum_from_camera(cam):
     """cam: dict from clap_amd.synth.camera().  Returns (Frustum, view_mx, proj_mx)."""
@@ -98,3 +108,30 @@ def entities_cull(n, flags, aabb, fr):
     mask = np.zeros((n + 63) // 64 or 1, np.uint64)
     cnt = lib().clapo_entities_cull(n, flags, aabb, C.byref(fr), vis.ctypes.data, mask.ctypes.data)
     return vis[:cnt].copy(), mask
+
+
+# ------------------------------------------------------------------ particles
+def particles_spawn(ps, rng_state):
+    """ps: dict from synth.particle_systems().  Returns (pos[n,3], vel[n,3], new rng state)."""
+    n = int(ps["n"])
+    pos = np.zeros((n, 3), np.float32)
+    vel = np.zeros((n, 3), np.float32)
+    st = C.c_uint64(rng_state)
+    sys = np.ascontiguousarray(ps["sys"])
+    lib().clapo_particles_spawn(sys.ctypes.data, sys.shape[0], pos, vel, C.byref(st))
+    return pos, vel, st.value
+
+
+def particles_update(ps, pos, vel, rng_state):
+    """One frame in place.  Returns (respawn count, new rng state)."""
+    st = C.c_uint64(rng_state)
+    sys = np.ascontiguousarray(ps["sys"])
+    k = lib().clapo_particles_update(sys.ctypes.data, sys.shape[0], pos, vel, C.byref(st))
+    return k, st.value
+
+
+def particles_billboard(view_mx, center):
+    mx = np.zeros(16, np.float32)
+    lib().clapo_particles_billboard(np.ascontiguousarray(view_mx, np.float32),
+                                    np.ascontiguousarray(center, np.float32), mx)
+    return mx

@@ -86,6 +86,30 @@ uint32_t clapo_entities_update(uint32_t n,
 uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aabb,
                              const clapo_frustum *f, uint32_t *visible, uint64_t *vis_mask);
 
+/* ---- particles (core/particle.c) ---- */
+#define CLAPO_PART_DIST_LIN     0   /* particle.h:13-18 */
+#define CLAPO_PART_DIST_SQRT    1
+#define CLAPO_PART_DIST_CBRT    2
+#define CLAPO_PART_DIST_POW075  3
+
+/* one particle system; identical to clapgpu_particle_system (64 bytes) */
+typedef struct clapo_particle_system {
+    float    center[3];          /* transform_pos(&ps->e->xform) */
+    uint32_t dist;               /* particle_dist */
+    double   radius, min_radius, radius_squared, velocity;   /* particle.c:21-24 */
+    uint32_t first, count;       /* particles [first, first+count) of pos/vel */
+    uint32_t pad[2];
+} clapo_particle_system;
+
+uint64_t clapo_srand48(int64_t seed);            /* drand48 state after srand48(seed) */
+double   clapo_drand48(uint64_t *state);
+void     clapo_particles_spawn(const clapo_particle_system *sys, uint32_t n_sys,
+                               float *pos, float *vel, uint64_t *rng);
+/* returns the number of respawned particles; pos is also the pos_array the renderer uploads */
+uint32_t clapo_particles_update(const clapo_particle_system *sys, uint32_t n_sys,
+                                float *pos, float *vel, uint64_t *rng);
+void     clapo_particles_billboard(const float view_mx[16], const float center[3], float mx[16]);
+
 #ifdef __cplusplus
 }
 #endif

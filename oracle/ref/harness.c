@@ -293,6 +293,94 @@ static int cmd_bench_entities(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* particles: particle_spawn x count, then particles_update x frames   */
+/* ------------------------------------------------------------------ */
+static int cmd_particles(struct arrset *in, struct arrset *out)
+{
+    uint32_t n_sys = *(uint32_t *)arr_get(in, "n_sys", NULL);
+    uint32_t frames = *(uint32_t *)arr_get(in, "frames", NULL);
+    float *center = arr_get(in, "center", NULL);          /* [n_sys][3] */
+    uint32_t *dist = arr_get(in, "dist", NULL);
+    double *radius = arr_get(in, "radius", NULL);
+    double *min_radius = arr_get(in, "min_radius", NULL);
+    double *velocity = arr_get(in, "velocity", NULL);
+    uint32_t *count = arr_get(in, "count", NULL);
+    float *view_mx = arr_get(in, "view_mx", NULL);
+    uint64_t state0 = *(uint64_t *)arr_get(in, "rng_state", NULL);
+    struct scene *scene = calloc(1, sizeof(*scene));
+    particle_system *ps = calloc(n_sys, sizeof(*ps));
+    entity3d *ents = calloc(n_sys, sizeof(*ents));
+    uint64_t total = 0;
+
+    unsigned short seed16[3] = { state0 & 0xffff, (state0 >> 16) & 0xffff, (state0 >> 32) & 0xffff };
+    seed48(seed16);                                        /* the libc stream drand48() draws from */
+
+    scene->camera = &scene->cameras[0];
+    memcpy(scene->camera->view.main.view_mx, view_mx, 64);
+
+    for (uint32_t s = 0; s < n_sys; s++) {
+        entity3d *e = &ents[s];
+        transform_init(&e->xform);
+        transform_set_pos(&e->xform, &center[3 * s]);
+        e->flags = ENTITY3D_ALIVE | ENTITY3D_IS_PARTICLE | ENTITY3D_SKIP_CULLING;   /* particle.c:212-216 */
+        e->priv = &ps[s];
+        e->update = particles_update;
+        ps[s].e = e;
+        list_init(&ps[s].particles);
+        ps[s].count = count[s];                            /* particle.c:219-225 */
+        ps[s].radius = radius[s];
+        ps[s].min_radius = min_radius[s];
+        ps[s].radius_squared = radius[s] * radius[s];
+        ps[s].velocity = velocity[s];
+        ps[s].dist = dist[s];
+        ps[s].pos_array = calloc(count[s] ? count[s] : 1, sizeof(vec3));
+        total += count[s];
+    }
+    float *o_pos0 = arr_add(out, "pos0", total * 12);
+    float *o_vel0 = arr_add(out, "vel0", total * 12);
+    float *o_pos = arr_add(out, "pos", (uint64_t)frames * total * 12);
+    float *o_vel = arr_add(out, "vel", (uint64_t)frames * total * 12);
+    float *o_mx = arr_add(out, "mx", (uint64_t)frames * n_sys * 64);
+    uint64_t *o_state = arr_add(out, "rng_state", (uint64_t)(frames + 1) * 8);
+
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < n_sys; s++) {                 /* particle.c:229-234 */
+        for (uint32_t i = 0; i < ps[s].count; i++) {
+            particle_spawn(&ps[s]);
+            particle *p = list_last_entry(&ps[s].particles, particle, entry);
+            vec3_dup(ps[s].pos_array[i], p->pos);
+            memcpy(o_pos0 + 3 * (off + i), p->pos, 12);
+            memcpy(o_vel0 + 3 * (off + i), p->velocity, 12);
+        }
+        off += ps[s].count;
+    }
+    {
+        unsigned short z[3] = { 0, 0, 0 }, *old = seed48(z);
+        o_state[0] = (uint64_t)old[0] | ((uint64_t)old[1] << 16) | ((uint64_t)old[2] << 32);
+        unsigned short back[3] = { old[0], old[1], old[2] };
+        seed48(back);
+    }
+    for (uint32_t f = 0; f < frames; f++) {
+        off = 0;
+        for (uint32_t s = 0; s < n_sys; s++) {
+            entity3d_update(&ents[s], scene);              /* mq_update order = system order */
+            memcpy(o_pos + 3 * ((uint64_t)f * total + off), ps[s].pos_array, (uint64_t)ps[s].count * 12);
+            memcpy(o_mx + 16 * ((uint64_t)f * n_sys + s), ents[s].mx, 64);
+            particle *p;
+            uint64_t i = 0;
+            list_for_each_entry(p, &ps[s].particles, entry)
+                memcpy(o_vel + 3 * ((uint64_t)f * total + off + i++), p->velocity, 12);
+            off += ps[s].count;
+        }
+        unsigned short z[3] = { 0, 0, 0 }, *old = seed48(z);
+        o_state[f + 1] = (uint64_t)old[0] | ((uint64_t)old[1] << 16) | ((uint64_t)old[2] << 32);
+        unsigned short back[3] = { old[0], old[1], old[2] };
+        seed48(back);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     struct arrset in = {}, out = {};
@@ -302,6 +390,7 @@ int main(int argc, char **argv)
     clpio_read(argv[2], &in);
     if (!strcmp(argv[1], "entities"))             rc = cmd_entities(&in, &out);
     else if (!strcmp(argv[1], "bench_entities"))  rc = cmd_bench_entities(&in, &out);
+    else if (!strcmp(argv[1], "particles"))       rc = cmd_particles(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

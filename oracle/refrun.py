@@ -75,3 +75,32 @@ def bench_entities(scene, cam, reps=5):
     out = run("bench_entities", arrays)
     best, mean, visible = clpio.as_array(out["seconds"], np.float64)
     return dict(best_s=float(best), mean_s=float(mean), visible=int(visible))
+
+
+def particles(ps, view_mx, rng_state, frames):
+    """particle_spawn x count then particles_update x frames on the reference, systems in
+    order, one libc drand48 stream seeded to `rng_state`.  Arrays come back in the padded
+    particle layout of synth.particle_systems (padding rows zero)."""
+    sys = ps["sys"]
+    ns = sys.shape[0]
+    arrays = dict(n_sys=np.asarray([ns], np.uint32), frames=np.asarray([frames], np.uint32),
+                  center=sys["center"].astype(np.float32), dist=sys["dist"].astype(np.uint32),
+                  radius=sys["radius"].astype(np.float64), min_radius=sys["min_radius"].astype(np.float64),
+                  velocity=sys["velocity"].astype(np.float64), count=sys["count"].astype(np.uint32),
+                  view_mx=np.asarray(view_mx, np.float32), rng_state=np.asarray([rng_state], np.uint64))
+    out = run("particles", arrays)
+    total = int(sys["count"].sum())
+    A = clpio.as_array
+    n = int(ps["n"])
+    idx = np.concatenate([np.arange(int(f), int(f) + int(c)) for f, c in zip(sys["first"], sys["count"])])
+
+    def pad(a):          # packed [.., total, 3] -> padded [.., n, 3]
+        o = np.zeros(a.shape[:-2] + (n, 3), np.float32)
+        o[..., idx, :] = a
+        return o
+
+    return dict(pos0=pad(A(out["pos0"], np.float32, (total, 3))), vel0=pad(A(out["vel0"], np.float32, (total, 3))),
+                pos=pad(A(out["pos"], np.float32, (frames, total, 3))),
+                vel=pad(A(out["vel"], np.float32, (frames, total, 3))),
+                mx=A(out["mx"], np.float32, (frames, ns, 16)),
+                rng_state=A(out["rng_state"], np.uint64, (frames + 1,)))

@@ -1,0 +1,110 @@
+"""GPU: the HIP particle path (through the C ABI) against the oracle and the reference's
+golden vectors.  Bar: pos_array / velocity / billboard matrix / drand48 state bit-exact
+(LIN, SQRT and CBRT radial distributions; POW075 goes through libm pow() in the reference
+and is held to 1e-5 relative)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from clap_amd import synth
+from oracle import binding as ob
+from helpers import assert_bits_equal
+from test_oracle_particles import load_particles
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "particles_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_matches_reference_golden(path, cuda_device):
+    from clap_amd import particles
+    ps, view, _state, ref = load_particles(path)
+    batch = particles.ParticleBatch(ps, ref["pos0"], ref["vel0"], int(ref["rng_state"][0]), cuda_device)
+    exact = "pow075" not in path
+    for f in range(ref["pos"].shape[0]):
+        batch.particles_update(view)
+        out = batch.download()
+        if exact:
+            assert_bits_equal(out["pos"], ref["pos"][f], f"frame {f} pos_array")
+            assert_bits_equal(out["vel"], ref["vel"][f], f"frame {f} velocity")
+        else:
+            np.testing.assert_allclose(out["pos"], ref["pos"][f], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(out["vel"], ref["vel"][f], rtol=1e-5, atol=1e-9)
+        assert out["rng_state"] == int(ref["rng_state"][f + 1]), f"frame {f} drand48 state"
+        assert_bits_equal(out["billboard_mx"], ref["mx"][f], f"frame {f} billboard mx")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_sys=1, count=1, radius=1.0, velocity=2.0),                    # a single particle that always respawns
+    dict(n_sys=3, count=64, radius=2.0, velocity=0.7),
+    dict(n_sys=50, count=333, radius=3.0, velocity=0.9, ragged=True, seed=9),
+    dict(n_sys=20, count=1024, radius=10.0, velocity=0.005),             # reference defaults: respawns are rare
+    dict(n_sys=8, count=500, radius=1e-3, velocity=1.0),                 # everything respawns every frame
+    dict(n_sys=5, count=400, radius=2.0, min_radius=1.5, velocity=0.5, dist=synth.PART_DIST_CBRT),
+], ids=["one", "rows", "ragged", "defaults", "all_respawn", "cbrt_shell"])
+def test_hip_matches_oracle_over_frames(kw, cuda_device):
+    from clap_amd import particles
+    ps = synth.particle_systems(**kw)
+    state = 0x00C0FFEE1234
+    pos, vel, st = ob.particles_spawn(ps, state)
+    view = np.asarray(ob.frustum_from_camera(synth.camera(pos=(4, 5, 6)))[1])
+    batch = particles.ParticleBatch(ps, pos, vel, st, cuda_device)
+    total = 0
+    for f in range(8):
+        k, st = ob.particles_update(ps, pos, vel, st)
+        total += k
+        batch.particles_update(view)
+        out = batch.download()
+        assert out["respawned"] == k, f"frame {f} respawn count"
+        assert_bits_equal(out["pos"], pos, f"frame {f} pos_array")
+        assert_bits_equal(out["vel"], vel, f"frame {f} velocity")
+        assert out["rng_state"] == st, f"frame {f} drand48 state"
+    if kw["velocity"] > 0.1:
+        assert total > 0
+
+
+def test_emitter_motion(cuda_device):
+    """particle_system_position: a detached system leaves its particles behind (they respawn as
+    they fall out of the sphere); an attached one carries them."""
+    from clap_amd import particles
+    ps = synth.particle_systems(n_sys=4, count=256, radius=2.0, velocity=0.05)
+    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    view = np.eye(4, dtype=np.float32).ravel()
+    batch = particles.ParticleBatch(ps, pos, vel, st, cuda_device)
+    for f in range(5):
+        for s, attached in ((1, False), (2, True)):
+            c = ps["sys"]["center"][s] + np.asarray([0.8, -0.3, 0.1], np.float32)
+            if attached:                                   # particle.c:151-156
+                fr, cn = int(ps["sys"]["first"][s]), int(ps["sys"]["count"][s])
+                pos[fr:fr + cn] += (c - ps["sys"]["center"][s])
+            ps["sys"]["center"][s] = c
+            batch.particle_system_position(s, c, attached)
+        _k, st = ob.particles_update(ps, pos, vel, st)
+        batch.particles_update(view)
+        out = batch.download()
+        assert_bits_equal(out["pos"], pos, f"frame {f}")
+        assert out["rng_state"] == st
+        assert_bits_equal(out["billboard_mx"][1], ob.particles_billboard(view, ps["sys"]["center"][1]), "billboard")
+
+
+def test_c4_full_size_stream_exact(cuda_device):
+    """BASELINE config 4 (particle half): 4096 systems x 1024 = 4M particles.  The oracle does a
+    frame in tens of ms, so the full size is compared bit for bit, drand48 state included."""
+    from clap_amd import particles
+    ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.3, dist=synth.PART_DIST_SQRT)
+    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    view = np.eye(4, dtype=np.float32).ravel()
+    batch = particles.ParticleBatch(ps, pos, vel, st, cuda_device)
+    total = 0
+    for f in range(3):
+        k, st = ob.particles_update(ps, pos, vel, st)
+        total += k
+        batch.particles_update(view)
+    out = batch.download()
+    assert_bits_equal(out["pos"], pos, "pos_array after 3 frames")
+    assert_bits_equal(out["vel"], vel, "velocity after 3 frames")
+    assert out["rng_state"] == st
+    assert total > 1000

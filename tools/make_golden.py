@@ -60,11 +60,27 @@ def multi_frame(scene, seed, n_frames=3, dirty_frac=0.2):
     return frames
 
 
+def particle_fixture(name, ps, frames, view_mx, state=synth.DRAND48_DEFAULT_STATE):
+    ref = refrun.particles(ps, view_mx, state, frames)
+    save(name, in_sys=ps["sys"], in_row_sys=ps["row_sys"], in_n=np.asarray([ps["n"], ps["n_real"]], np.uint32),
+         in_view_mx=np.asarray(view_mx, np.float32), in_rng_state=np.asarray([state], np.uint64),
+         **{"ref_" + k: v for k, v in ref.items()})
+
+
 def main():
     if not refrun.available():
         refrun.build()
     os.makedirs(OUT, exist_ok=True)
     cam = synth.camera()
+    from oracle import binding as ob
+    _fr, view, _proj = ob.frustum_from_camera(synth.camera(pos=(1, 2, 3), quat=synth.quat_from_euler_xyz(0.1, 0.7, -0.2)))
+    # view_mx comes from the oracle here only as an INPUT matrix; outputs are the reference's
+    particle_fixture("particles_uniform", synth.particle_systems(n_sys=6, count=200, radius=3.0, velocity=0.5), 5, view)
+    particle_fixture("particles_ragged", synth.particle_systems(n_sys=9, count=150, radius=4.0, velocity=0.4,
+                                                                ragged=True, seed=5), 6, view, state=0x0BADC0FFEE42)
+    for dist, nm in ((synth.PART_DIST_CBRT, "cbrt"), (synth.PART_DIST_POW075, "pow075")):
+        particle_fixture("particles_" + nm, synth.particle_systems(n_sys=3, count=100, radius=2.0, velocity=0.6,
+                                                                    dist=dist, seed=6), 4, view)
     entity_fixture("entities_flat_c1", synth.entities_flat(512, seed=1234), cam)
     entity_fixture("entities_flat_euler", synth.entities_flat(512, seed=99, full_euler=True),
                    synth.camera(pos=(10, 5, -20), quat=synth.quat_from_euler_xyz(0.2, 2.5, -0.1),
