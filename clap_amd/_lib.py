@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_NOMEM = -1
@@ -61,6 +61,30 @@ class Particles(C.Structure):
                 ("respawn_list", C.c_void_p), ("respawn_count", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class Skeleton(C.Structure):
+    _fields_ = [("nr_joints", C.c_uint32), ("n_levels", C.c_uint32), ("parent", C.c_void_p), ("depth", C.c_void_p),
+                ("root_pose", C.c_void_p), ("invmx", C.c_void_p), ("bind", C.c_void_p)]
+
+
+class Animations(C.Structure):
+    _fields_ = [("n_anims", C.c_uint32), ("n_channels", C.c_uint32), ("chan_of", C.c_void_p),
+                ("ch_nr", C.c_void_p), ("ch_time_off", C.c_void_p), ("ch_data_off", C.c_void_p),
+                ("times", C.c_void_p), ("data", C.c_void_p)]
+
+
+class PoseBatch(C.Structure):
+    _fields_ = [("n_chars", C.c_uint32), ("anim", C.c_void_p), ("frame_time", C.c_void_p), ("entity", C.c_void_p),
+                ("entity_mx", C.c_void_p), ("trs", C.c_void_p), ("joint_transforms", C.c_void_p),
+                ("joint_pos", C.c_void_p)]
+
+
+class SkinBatch(C.Structure):
+    _fields_ = [("n_chars", C.c_uint32), ("nr_joints", C.c_uint32), ("vert_first", C.c_void_p),
+                ("vert_count", C.c_void_p), ("out_first", C.c_void_p), ("position", C.c_void_p),
+                ("normal", C.c_void_p), ("joints", C.c_void_p), ("weights", C.c_void_p),
+                ("joint_transforms", C.c_void_p), ("out_position", C.c_void_p), ("out_normal", C.c_void_p)]
+
+
 # every symbol include/clapgpu.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "clapgpu_device_count": (C.c_int, []),
@@ -86,6 +110,8 @@ SYMBOLS = {
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
+    "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
 }
 

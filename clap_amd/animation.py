@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's skeletal animation + skinning interface.
+
+``SkinnedModel`` holds what ``model3d_add_skinning`` (model.c:524-538), ``animation_new`` /
+``animation_add_channel`` (model.c:688-741) and ``model3d_make``'s vertex attributes set up
+once; ``CharacterBatch.animated_update`` is the batched ``animated_update`` (model.c:1563-1592:
+host time base -> channels_transform + one_joint_transform on the GPU) and
+``CharacterBatch.skin`` the compute form of the skinning loop of shaders/model.vert:32-48.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else 0
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(a, device, dtype=None):
+    a = np.ascontiguousarray(a, dtype) if dtype is not None else np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).to(device)
+
+
+def joint_depths(parent):
+    """Level of every joint under joint 0; -1 for joints the reference's recursion from joint 0
+    (model.c:1583, 1402-1403) never reaches."""
+    parent = np.asarray(parent, np.int64)
+    J = parent.shape[0]
+    depth = np.full(J, -1, np.int32)
+    if J:
+        depth[0] = 0
+    changed = True
+    while changed:
+        changed = False
+        for j in range(1, J):
+            p = parent[j]
+            if depth[j] < 0 and p >= 0 and depth[p] >= 0:
+                depth[j] = depth[p] + 1
+                changed = True
+    return depth
+
+
+def channel_table(anims, nr_joints):
+    """chan_of[a][joint][path] -> channel index (last listed channel wins), plus the pooled
+    channel arrays of all animations."""
+    chan_of = np.full((len(anims), nr_joints, 3), -1, np.int32)
+    nr, toff, doff, times, data = [], [], [], [], []
+    t_base = d_base = c_base = 0
+    for ai, an in enumerate(anims):
+        for c in range(int(an["n_channels"])):
+            tgt, path = int(an["ch_target"][c]), int(an["ch_path"][c])
+            if tgt < nr_joints and path < 3 and int(an["ch_nr"][c]) > 0:
+                chan_of[ai, tgt, path] = c_base + c
+        nr.append(an["ch_nr"])
+        toff.append(an["ch_time_off"].astype(np.int64) + t_base)
+        doff.append(an["ch_data_off"].astype(np.int64) + d_base)
+        times.append(an["times"])
+        data.append(an["data"])
+        t_base += an["times"].shape[0]
+        d_base += an["data"].shape[0]
+        c_base += int(an["n_channels"])
+    return dict(chan_of=chan_of, ch_nr=np.concatenate(nr).astype(np.uint32),
+                ch_time_off=np.concatenate(toff).astype(np.uint32),
+                ch_data_off=np.concatenate(doff).astype(np.uint32),
+                times=np.concatenate(times).astype(np.float32), data=np.concatenate(data).astype(np.float32),
+                n_channels=c_base)
+
+
+class SkinnedModel:
+    """Device copy of one model3d's skeleton, animations and (optionally) skinned mesh."""
+
+    def __init__(self, sk, anims, mesh=None, bind=None, device="cuda:0"):
+        self.device = dev = torch.device(device)
+        self.nr_joints = J = int(sk["nr_joints"])
+        self.depth_host = joint_depths(sk["parent"])
+        self.n_levels = int(self.depth_host.max()) + 1
+        self.parent = _dev(sk["parent"], dev, np.int32)
+        self.depth = _dev(self.depth_host, dev, np.int32)
+        self.root_pose = _dev(sk["root_pose"], dev, np.float32)
+        self.invmx = _dev(sk["invmx"], dev, np.float32)
+        if bind is None:
+            bind = np.stack([np.linalg.inv(m.reshape(4, 4).T.astype(np.float64)).T.reshape(16)
+                             for m in sk["invmx"]]).astype(np.float32)
+        self.bind = _dev(bind, dev, np.float32)
+        self.anims_host = anims
+        ct = channel_table(anims, J)
+        self.time_end = [float(a["time_end"]) for a in anims]
+        self._ct = {k: _dev(v, dev) for k, v in ct.items() if k != "n_channels"}
+        self.skel_desc = _lib.Skeleton(J, self.n_levels, _ptr(self.parent), _ptr(self.depth),
+                                       _ptr(self.root_pose), _ptr(self.invmx), _ptr(self.bind))
+        self.anim_desc = _lib.Animations(len(anims), ct["n_channels"], _ptr(self._ct["chan_of"]),
+                                         _ptr(self._ct["ch_nr"]), _ptr(self._ct["ch_time_off"]),
+                                         _ptr(self._ct["ch_data_off"]), _ptr(self._ct["times"]),
+                                         _ptr(self._ct["data"]))
+        self.mesh = None
+        if mesh is not None:
+            self.mesh = dict(n_verts=int(mesh["n_verts"]), position=_dev(mesh["position"], dev, np.float32),
+                             normal=_dev(mesh["normal"], dev, np.float32), joints=_dev(mesh["joints"], dev, np.uint8),
+                             weights=_dev(mesh["weights"], dev, np.float32))
+
+
+class CharacterBatch:
+    """The animated entities of one SkinnedModel."""
+
+    def __init__(self, model, n_chars, trs0, entity_mx, entity_index=None, vert_first=None, vert_count=None):
+        self.model = model
+        self.device = dev = model.device
+        self.n = n = int(n_chars)
+        J = model.nr_joints
+        trs0 = np.asarray(trs0, np.float32)
+        if trs0.ndim == 2:
+            trs0 = np.broadcast_to(trs0, (n, J, 10))
+        self.trs = _dev(trs0, dev, np.float32)
+        self.entity_mx = entity_mx if torch.is_tensor(entity_mx) else _dev(entity_mx, dev, np.float32)
+        self.entity_index = None if entity_index is None else _dev(entity_index, dev, np.uint32)
+        self.anim = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.frame_time = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.joint_transforms = torch.zeros((n, J, 16), dtype=torch.float32, device=dev)
+        self.joint_pos = torch.zeros((n, J, 4), dtype=torch.float32, device=dev)
+        # host animation state of animated_update(): start time, speed, current animation
+        self.ani_time = np.zeros(n, np.float64)
+        self.speed = np.ones(n, np.float64)
+        self.anim_host = np.zeros(n, np.int32)
+        self._pose_desc = _lib.PoseBatch(n, _ptr(self.anim), _ptr(self.frame_time), _ptr(self.entity_index),
+                                         _ptr(self.entity_mx), _ptr(self.trs), _ptr(self.joint_transforms),
+                                         _ptr(self.joint_pos))
+        self._skin_desc = None
+        if model.mesh is not None:
+            if vert_first is None:                       # every character instances the whole mesh
+                vert_first = np.zeros(n, np.uint32)
+                vert_count = np.full(n, model.mesh["n_verts"], np.uint32)
+            self.vert_first = _dev(vert_first, dev, np.uint32)
+            self.vert_count_host = np.asarray(vert_count, np.uint32)
+            self.vert_count = _dev(self.vert_count_host, dev, np.uint32)
+            of = np.concatenate([[0], np.cumsum(self.vert_count_host.astype(np.int64))])
+            self.out_first_host = of
+            self.out_first = _dev(of[:-1], dev, np.uint32)
+            total = int(of[-1])
+            self.n_out_verts = total
+            self.out_position = torch.zeros((total, 3), dtype=torch.float32, device=dev)
+            self.out_normal = torch.zeros((total, 3), dtype=torch.float32, device=dev)
+            m = model.mesh
+            self._skin_desc = _lib.SkinBatch(n, J, _ptr(self.vert_first), _ptr(self.vert_count), _ptr(self.out_first),
+                                             _ptr(m["position"]), _ptr(m["normal"]), _ptr(m["joints"]),
+                                             _ptr(m["weights"]), _ptr(self.joint_transforms),
+                                             _ptr(self.out_position), _ptr(self.out_normal))
+
+    # ---- animated_update (model.c:1563-1592) --------------------------------------------
+    def set_frame_times(self, frame_time, anim=None):
+        """Directly set each character's (float)frame_time (and animation id)."""
+        self.frame_time.copy_(torch.from_numpy(np.ascontiguousarray(frame_time, np.float32)))
+        if anim is not None:
+            self.anim_host[:] = anim
+            self.anim.copy_(torch.from_numpy(self.anim_host))
+
+    def animated_update(self, now):
+        """Host half: frame_time = (now - ani_time) * speed in double, passed on as float;
+        a repeating animation restarts once frame_time >= time_end (animation_next ->
+        animation_start, model.c:1590-1591, 1406-1424).  Device half: pose + palette."""
+        ft = (float(now) - self.ani_time) * self.speed
+        self.set_frame_times(ft.astype(np.float32))
+        self.pose_update()
+        te = np.asarray(self.model.time_end)[self.anim_host]
+        self.ani_time[ft >= te] = float(now)
+
+    def pose_update(self):
+        rc = _lib.lib().clapgpu_pose_update(_stream(), C.byref(self.model.skel_desc), C.byref(self.model.anim_desc),
+                                            C.byref(self._pose_desc))
+        _lib.check(rc, "clapgpu_pose_update")
+
+    def skin(self):
+        if self._skin_desc is None:
+            raise ValueError("model has no skinned mesh")
+        rc = _lib.lib().clapgpu_skin(_stream(), C.byref(self._skin_desc))
+        _lib.check(rc, "clapgpu_skin")
+
+    def download(self):
+        torch.cuda.synchronize(self.device)
+        out = dict(trs=self.trs.cpu().numpy(), joint_transforms=self.joint_transforms.cpu().numpy(),
+                   joint_pos=self.joint_pos.cpu().numpy())
+        if self._skin_desc is not None:
+            out["out_position"] = self.out_position.cpu().numpy()
+            out["out_normal"] = self.out_normal.cpu().numpy()
+        return out
+
+    def pose_algorithmic_bytes(self):
+        return 200 * self.n * self.model.nr_joints
+
+    def skin_algorithmic_bytes(self):
+        return 68 * self.n_out_verts + 64 * self.model.nr_joints * self.n

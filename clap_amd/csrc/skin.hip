@@ -1,0 +1,109 @@
+// skin.hip -- vertex skinning for gfx950.
+//
+// Materialises what the reference leaves to its vertex shader (shaders/model.vert:32-48, also
+// shadow.vert:19-23 and shadow_vsm.vert:19-23, i.e. recomputed in every geometry pass):
+//     p' = sum_{i<4} w_i * (J[j_i] * (p,1)),   n' = sum_{i<4} w_i * (J[j_i] * (n,0))
+// with J = the entity's joint_transforms, accumulated i = 0..3 in order, fp32, no weight
+// renormalisation.  Inputs are the reference's vertex attribute formats (mesh.h:125-131,
+// gltf.c:387-388): position f32x3, normal f32x3, joints u8x4, weights f32x4.
+//
+// Mapping: one workgroup per character; its palette (nr_joints x 64 B) is staged once in LDS
+// with an 80-byte row pitch (conflict-free 16-B column reads for lanes hitting different
+// joints) and every lane skins one vertex.  HBM: 44 B in + 24 B out per vertex + the palette
+// once per character (88.5 B / vertex at 64 joints, 200 vertices).
+#include "common.h"
+#include "lm_dev.h"
+
+namespace clapgpu {
+
+constexpr int SKIN_BLOCK = 256;
+constexpr int PAL_PITCH = 20;          // floats per palette row in LDS (16 + 4 pad)
+constexpr int PAL_MAX_JOINTS = 256;
+
+struct SkinArgs {
+    uint32_t        n_chars, J;
+    const uint32_t *vert_first, *vert_count, *out_first;
+    const float    *position, *normal;
+    const uint32_t *joints;            // u8x4 packed
+    const float4   *weights;
+    const float4   *joint_transforms;
+    float          *out_position, *out_normal;
+};
+
+__global__ __launch_bounds__(SKIN_BLOCK)
+void k_skin(SkinArgs a)
+{
+    __shared__ float pal[PAL_MAX_JOINTS * PAL_PITCH];             // 20 KiB
+
+    const uint32_t c = blockIdx.x;
+    const uint32_t J = a.J;
+    // stage the palette: J * 4 float4, coalesced
+    const float4 *src = a.joint_transforms + (size_t)c * J * 4;
+    for (uint32_t q = threadIdx.x; q < J * 4; q += SKIN_BLOCK) {
+        const float4 v = src[q];
+        *reinterpret_cast<float4 *>(pal + (q >> 2) * PAL_PITCH + (q & 3) * 4) = v;
+    }
+    __syncthreads();
+
+    const uint32_t vfirst = a.vert_first[c], vcount = a.vert_count[c], ofirst = a.out_first[c];
+    for (uint32_t k = threadIdx.x; k < vcount; k += SKIN_BLOCK) {
+        const size_t v = (size_t)vfirst + k;
+        const float px = a.position[3 * v], py = a.position[3 * v + 1], pz = a.position[3 * v + 2];
+        const float nx = a.normal[3 * v], ny = a.normal[3 * v + 1], nz = a.normal[3 * v + 2];
+        const uint32_t jj = a.joints[v];
+        const float4 w4 = a.weights[v];
+        const float w[4] = { w4.x, w4.y, w4.z, w4.w };
+        float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ji = (jj >> (8 * i)) & 0xffu;
+            const float4 *m = reinterpret_cast<const float4 *>(pal + ji * PAL_PITCH);
+            const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+            // ((M0 x + M1 y) + M2 z) + M3 w per component; w = 1 for positions, 0 for normals
+            const float lx = ((c0.x * px + c1.x * py) + c2.x * pz) + c3.x * 1.0f;
+            const float ly = ((c0.y * px + c1.y * py) + c2.y * pz) + c3.y * 1.0f;
+            const float lz = ((c0.z * px + c1.z * py) + c2.z * pz) + c3.z * 1.0f;
+            const float mx = ((c0.x * nx + c1.x * ny) + c2.x * nz) + c3.x * 0.0f;
+            const float my = ((c0.y * nx + c1.y * ny) + c2.y * nz) + c3.y * 0.0f;
+            const float mz = ((c0.z * nx + c1.z * ny) + c2.z * nz) + c3.z * 0.0f;
+            tp[0] += lx * w[i]; tp[1] += ly * w[i]; tp[2] += lz * w[i];
+            tn[0] += mx * w[i]; tn[1] += my * w[i]; tn[2] += mz * w[i];
+        }
+        const size_t o = (size_t)ofirst + k;
+        a.out_position[3 * o] = tp[0]; a.out_position[3 * o + 1] = tp[1]; a.out_position[3 * o + 2] = tp[2];
+        a.out_normal[3 * o] = tn[0];   a.out_normal[3 * o + 1] = tn[1];   a.out_normal[3 * o + 2] = tn[2];
+    }
+}
+
+} // namespace clapgpu
+
+using namespace clapgpu;
+
+extern "C" int clapgpu_skin(void *stream, const clapgpu_skin_batch *b)
+{
+    if (!b)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (b->n_chars == 0)
+        return CLAPGPU_OK;
+    if (!b->vert_first || !b->vert_count || !b->out_first || !b->position || !b->normal || !b->joints ||
+        !b->weights || !b->joint_transforms || !b->out_position || !b->out_normal)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (b->nr_joints == 0 || b->nr_joints > PAL_MAX_JOINTS)
+        return CLAPGPU_ERR_TOO_LARGE;
+    SkinArgs a;
+    a.n_chars = b->n_chars;
+    a.J = b->nr_joints;
+    a.vert_first = b->vert_first;
+    a.vert_count = b->vert_count;
+    a.out_first = b->out_first;
+    a.position = b->position;
+    a.normal = b->normal;
+    a.joints = reinterpret_cast<const uint32_t *>(b->joints);
+    a.weights = reinterpret_cast<const float4 *>(b->weights);
+    a.joint_transforms = reinterpret_cast<const float4 *>(b->joint_transforms);
+    a.out_position = b->out_position;
+    a.out_normal = b->out_normal;
+    hipLaunchKernelGGL(k_skin, dim3(b->n_chars), dim3(SKIN_BLOCK), 0, as_stream(stream), a);
+    CLAPGPU_LAUNCH_CHECK("k_skin");
+    return CLAPGPU_OK;
+}

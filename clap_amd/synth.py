@@ -259,3 +259,106 @@ def particle_systems(n_sys=4096, count=1024, radius=10.0, min_radius=0.0, veloci
     n = int(first_row[-1]) * 64
     row_sys = np.repeat(np.arange(n_sys, dtype=np.uint32), rows)
     return dict(sys=sys, n=n, n_real=int(sys["count"].sum()), row_sys=row_sys)
+
+
+# ----------------------------------------------------------------------------- skeletons / animation / meshes
+def _rigid_mat4(rng, n, spread=1.0):
+    """n random rigid transforms as column-major mat4 [n,16]."""
+    ang = rng.uniform(-math.pi, math.pi, (n, 3))
+    q = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2]).astype(np.float64)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    m = np.zeros((n, 4, 4))                       # m[i, col, row]
+    m[:, 0, 0] = 1 - 2 * (y * y + z * z); m[:, 0, 1] = 2 * (x * y + w * z); m[:, 0, 2] = 2 * (x * z - w * y)
+    m[:, 1, 0] = 2 * (x * y - w * z); m[:, 1, 1] = 1 - 2 * (x * x + z * z); m[:, 1, 2] = 2 * (y * z + w * x)
+    m[:, 2, 0] = 2 * (x * z + w * y); m[:, 2, 1] = 2 * (y * z - w * x); m[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    m[:, 3, :3] = rng.uniform(-spread, spread, (n, 3))
+    m[:, 3, 3] = 1
+    return m.reshape(n, 16).astype(F32)
+
+
+def skeleton(nr_joints=64, max_depth=8, seed=3, unreachable=0):
+    """One skinned model (C3): binary-ish joint tree of depth <= max_depth rooted at joint 0,
+    invmx = inverse of random rigid bind matrices, a rigid root_pose.  `unreachable` extra
+    joints hang off a second root (the reference only ever updates joints reachable from
+    joint 0, model.c:1583)."""
+    rng = _rng(seed)
+    J = nr_joints
+    parent = np.full(J, -1, np.int32)
+    depth = np.zeros(J, np.int64)
+    n_main = J - unreachable
+    for j in range(1, n_main):
+        while True:
+            p = int(rng.integers(max(0, (j - 1) // 2 - 2), j))
+            if depth[p] + 1 < max_depth:
+                break
+        parent[j], depth[j] = p, depth[p] + 1
+    for j in range(n_main, J):
+        parent[j] = -1 if j == n_main else j - 1
+    bind_world = _rigid_mat4(rng, J, 1.5).astype(np.float64).reshape(J, 4, 4)
+    invmx = np.stack([np.linalg.inv(b.T).T for b in bind_world]).reshape(J, 16).astype(F32)
+    root_pose = _rigid_mat4(rng, 1, 0.5)[0]
+    order = [j for j in np.argsort(depth[:n_main], kind="stable")]       # parents first, joints reachable from 0
+    return dict(nr_joints=J, parent=parent, invmx=invmx, root_pose=root_pose,
+                order=np.asarray(order, np.int32), depth=depth.astype(np.int32))
+
+
+def animation(nr_joints=64, keyframes=30, time_end=2.0, seed=3, missing_frac=0.0, ragged=False):
+    """One animation: T, R, S channels per joint (3*J channels), `keyframes` strictly increasing
+    key times on [0, time_end] each.  `missing_frac` drops channels, `ragged` varies key counts."""
+    rng = _rng(seed + 1000)
+    tgt, path, nr, toff, doff, times, data = [], [], [], [], [], [], []
+    t_at = d_at = 0
+    for j in range(nr_joints):
+        for p in range(3):
+            if rng.uniform() < missing_frac:
+                continue
+            k = int(rng.integers(2, keyframes + 1)) if ragged else keyframes
+            t = np.sort(rng.uniform(0, time_end, k)).astype(F32)
+            t[0], t[-1] = 0.0, time_end
+            t = np.unique(t)
+            k = t.shape[0]
+            if p == 1:
+                ang = rng.uniform(-1.2, 1.2, (k, 3))
+                d = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2])
+                flip = rng.uniform(0, 1, k) < 0.3                       # exercises the dot < 0 branch
+                d[flip] = -d[flip]
+                near = rng.uniform(0, 1, k) < 0.2                       # exercises the nlerp branch (dot > 0.9995)
+                d[1:][near[1:]] = d[:-1][near[1:]]
+            elif p == 0:
+                d = rng.uniform(-0.5, 0.5, (k, 3)).astype(F32)
+            else:
+                d = rng.uniform(0.8, 1.25, (k, 3)).astype(F32)
+            tgt.append(j); path.append(p); nr.append(k); toff.append(t_at); doff.append(d_at)
+            times.append(t); data.append(d.astype(F32).ravel())
+            t_at += k
+            d_at += d.size
+    return dict(n_channels=len(tgt), ch_target=np.asarray(tgt, np.uint32), ch_path=np.asarray(path, np.uint32),
+                ch_nr=np.asarray(nr, np.uint32), ch_time_off=np.asarray(toff, np.uint32),
+                ch_data_off=np.asarray(doff, np.uint32), times=np.concatenate(times).astype(F32),
+                data=np.concatenate(data).astype(F32), time_end=F32(time_end))
+
+
+def characters(n_chars=50_000, nr_joints=64, time_end=2.0, seed=3):
+    """Per-character inputs: entity world matrix (rigid, as the entity kernel produces) and an
+    animation phase; trs0 = the joints' rest T/R/S (used by joints no channel targets)."""
+    rng = _rng(seed + 2000)
+    mx = _rigid_mat4(rng, n_chars, 300.0)
+    phase = rng.uniform(0, time_end, n_chars).astype(F32)
+    trs0 = np.zeros((nr_joints, 10), F32)
+    trs0[:, 0:3] = rng.uniform(-0.3, 0.3, (nr_joints, 3))
+    ang = rng.uniform(-1, 1, (nr_joints, 3))
+    trs0[:, 3:7] = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2])
+    trs0[:, 7:10] = 1.0
+    return dict(n_chars=n_chars, char_mx=mx, phase=phase, trs0=trs0)
+
+
+def skinned_mesh(n_verts=200, nr_joints=64, seed=3, copies=1):
+    """A skinned mesh in the reference's vertex layout (mesh.h:125-131, gltf.c:387-388):
+    position f32x3, normal f32x3, joints u8x4, weights f32x4 (Dirichlet(4): sum to 1)."""
+    rng = _rng(seed + 3000)
+    n = n_verts * copies
+    nor = rng.normal(size=(n, 3))
+    nor /= np.linalg.norm(nor, axis=1, keepdims=True)
+    w = rng.dirichlet(np.ones(4), n)
+    return dict(n_verts=n, position=rng.uniform(-1, 1, (n, 3)).astype(F32), normal=nor.astype(F32),
+                joints=rng.integers(0, nr_joints, (n, 4)).astype(np.uint8), weights=w.astype(F32))

@@ -238,6 +238,107 @@ typedef struct clapgpu_particles {
  */
 int clapgpu_particles_update(void *stream, const clapgpu_particles *p, const float view_mx[16]);
 
+/* ======================================================================== */
+/* Skeletal pose blend + joint palette (core/model.c:1266-1404, interp.h)    */
+/* ======================================================================== */
+
+/*
+ * Skinning constants of one model3d (model.h:104-110,59; set once by model3d_add_skinning,
+ * model.c:524-538, and gltf_instantiate_one), device pointers.
+ *   parent[j]   parent joint or -1 (child of root_pose)        model_joint.children, inverted
+ *   depth[j]    level of joint j under joint 0, or -1 if j is NOT reachable from joint 0:
+ *               the reference starts its recursion at joint 0 (model.c:1583) and never
+ *               touches the others
+ *   n_levels    1 + max depth
+ *   invmx[j], bind[j] = invert(invmx[j])                       model_joint.invmx, .bind
+ */
+typedef struct clapgpu_skeleton {
+    uint32_t        nr_joints;          /* <= 256 (JOINTS_MAX = 200, shader_constants.h:6) */
+    uint32_t        n_levels;
+    const int32_t  *parent;
+    const int32_t  *depth;
+    const float    *root_pose;          /* mat4 */
+    const float    *invmx;              /* [nr_joints] mat4 */
+    const float    *bind;               /* [nr_joints] mat4 */
+} clapgpu_skeleton;
+
+/*
+ * Every animation of the model (struct animation / struct channel, model.h:133-142,
+ * model.c:678-685), keyframe times strictly increasing per channel (glTF).
+ *   chan_of[a][j][path]  channel of animation a that drives (joint j, path), -1 if none;
+ *                        path 0 translation, 1 rotation, 2 scale (enum chan_path); when the
+ *                        reference lists several, the last one wins (model.c:1348-1349)
+ *   ch_nr[c] keyframes; ch_time_off[c] offset into times[]; ch_data_off[c] offset into
+ *   data[] (floats, 3 per key for T/S, 4 for R)
+ */
+typedef struct clapgpu_animations {
+    uint32_t        n_anims;
+    uint32_t        n_channels;
+    const int32_t  *chan_of;
+    const uint32_t *ch_nr;
+    const uint32_t *ch_time_off;
+    const uint32_t *ch_data_off;
+    const float    *times;
+    const float    *data;
+} clapgpu_animations;
+
+/*
+ * The animated entities of that model.
+ *   anim[c]        queued_animation.animation of the current queue entry (model.c:1572-1576)
+ *   frame_time[c]  (float)((now - ani_time) * speed), model.c:1578-1582
+ *   entity[c]      index of the character's entity in entity_mx (NULL: c)
+ *   entity_mx      the entity world matrices (clapgpu_entities.mx)
+ *   trs[c][j][10]  joint translation(3) rotation(4) scale(3): struct joint (model.h:363-366),
+ *                  in/out -- a path no channel drives keeps its value
+ *   joint_transforms[c][j][16]  entity3d.joint_transforms, the UNIFORM_JOINT_TRANSFORMS payload
+ *                  (model.c:1020-1022); joints not reachable from joint 0 are not written
+ *   joint_pos[c][j][4]          struct joint.pos (camera.c:195-196)
+ */
+typedef struct clapgpu_pose_batch {
+    uint32_t        n_chars;
+    const uint32_t *anim;
+    const float    *frame_time;
+    const uint32_t *entity;
+    const float    *entity_mx;
+    float          *trs;
+    float          *joint_transforms;
+    float          *joint_pos;
+} clapgpu_pose_batch;
+
+/* Replaces channels_transform() + one_joint_transform(e, 0, -1) of animated_update()
+ * (model.c:1582-1583) for every character of the batch. */
+int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,
+                        const clapgpu_pose_batch *pb);
+
+/* ======================================================================== */
+/* Vertex skinning (shaders/model.vert:32-48)                                */
+/* ======================================================================== */
+
+/*
+ * Character c skins mesh vertices [vert_first[c], vert_first[c] + vert_count[c]) of the
+ * vertex pool with its palette joint_transforms[c][nr_joints] and writes them at
+ * out_first[c].  Vertex attributes in the reference's formats (mesh.h:125-131, gltf.c:387-388):
+ * position f32x3, normal f32x3, joints u8x4, weights f32x4 (16-B aligned).  Instances of one
+ * model share vert_first.  Outputs: position f32x3 + normal f32x3 in the joint-space-blended
+ * model space the shader would feed to `trs` (model.vert:44-45).
+ */
+typedef struct clapgpu_skin_batch {
+    uint32_t        n_chars;
+    uint32_t        nr_joints;
+    const uint32_t *vert_first;
+    const uint32_t *vert_count;
+    const uint32_t *out_first;
+    const float    *position;
+    const float    *normal;
+    const uint8_t  *joints;
+    const float    *weights;
+    const float    *joint_transforms;
+    float          *out_position;
+    float          *out_normal;
+} clapgpu_skin_batch;
+
+int clapgpu_skin(void *stream, const clapgpu_skin_batch *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,17 @@ class Frustum(C.Structure):
         return f
 
 
+class Skeleton(C.Structure):
+    _fields_ = [("nr_joints", C.c_uint32), ("n_order", C.c_uint32), ("parent", C.c_void_p),
+                ("order", C.c_void_p), ("root_pose", C.c_void_p), ("invmx", C.c_void_p), ("bind", C.c_void_p)]
+
+
+class Animation(C.Structure):
+    _fields_ = [("n_channels", C.c_uint32), ("ch_target", C.c_void_p), ("ch_path", C.c_void_p),
+                ("ch_nr", C.c_void_p), ("ch_time_off", C.c_void_p), ("ch_data_off", C.c_void_p),
+                ("times", C.c_void_p), ("data", C.c_void_p)]
+
+
 def build():
     """Compile the restatement (gcc).  Building the checker is not using it."""
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -72,6 +83,12 @@ def _declare(L):
     L.clapo_particles_update.argtypes = [C.c_void_p, C.c_uint32, F32P, F32P, C.POINTER(C.c_uint64)]
     L.clapo_particles_update.restype = C.c_uint32
     L.clapo_particles_billboard.argtypes = [F32P, F32P, F32P]
+
+
+    L.clapo_pose_channels.argtypes = [C.POINTER(Animation), C.c_float, F32P, I32P]
+    L.clapo_pose_palette.argtypes = [C.POINTER(Skeleton), F32P, F32P, F32P, F32P, F32P]
+    L.clapo_skeleton_bind.argtypes = [C.c_uint32, F32P, F32P]
+    L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
 
 
 # ------------------------------------------------------------------ helpers
@@ -135,3 +152,61 @@ def particles_billboard(view_mx, center):
     lib().clapo_particles_billboard(np.ascontiguousarray(view_mx, np.float32),
                                     np.ascontiguousarray(center, np.float32), mx)
     return mx
+
+
+# ------------------------------------------------------------------ pose / palette
+def skeleton_bind(sk):
+    bind = np.zeros_like(sk["invmx"])
+    lib().clapo_skeleton_bind(int(sk["nr_joints"]), np.ascontiguousarray(sk["invmx"]), bind)
+    return bind
+
+
+def _skel_struct(sk):
+    keep = [np.ascontiguousarray(sk[k]) for k in ("parent", "order", "root_pose", "invmx", "bind")]
+    st = Skeleton(int(sk["nr_joints"]), int(keep[1].shape[0]), *[a.ctypes.data for a in keep])
+    return st, keep
+
+
+def _anim_struct(an):
+    keep = [np.ascontiguousarray(an[k]) for k in ("ch_target", "ch_path", "ch_nr", "ch_time_off", "ch_data_off",
+                                                   "times", "data")]
+    st = Animation(int(an["n_channels"]), *[a.ctypes.data for a in keep])
+    return st, keep
+
+
+def pose(sk, an, times, char_mx, trs, cursor=None):
+    """channels_transform + one_joint_transform for every character at its frame time.
+    trs [n_chars, J, 10] is updated in place.  Returns (joint_transforms, global, joint_pos)."""
+    L = lib()
+    if "bind" not in sk:
+        sk["bind"] = skeleton_bind(sk)
+    ss, k1 = _skel_struct(sk)
+    aa, k2 = _anim_struct(an)
+    n, J = trs.shape[0], int(sk["nr_joints"])
+    if cursor is None:
+        cursor = np.zeros((n, J, 3), np.int32)
+    jt = np.zeros((n, J, 16), np.float32)
+    gl = np.zeros((n, J, 16), np.float32)
+    jp = np.zeros((n, J, 4), np.float32)
+    char_mx = np.ascontiguousarray(char_mx, np.float32)
+    for i in range(n):
+        L.clapo_pose_channels(C.byref(aa), float(times[i]), trs[i], cursor[i])
+        L.clapo_pose_palette(C.byref(ss), trs[i], char_mx[i], gl[i], jt[i], jp[i])
+    return jt, gl, jp
+
+
+def skin(mesh, vert_first, vert_count, joint_transforms):
+    """Skin every character: character c uses mesh vertices [vert_first[c], +vert_count[c]) and its
+    own palette joint_transforms[c].  Returns (out_pos, out_nor) concatenated per character."""
+    L = lib()
+    total = int(np.sum(vert_count))
+    out_p = np.zeros((total, 3), np.float32)
+    out_n = np.zeros((total, 3), np.float32)
+    at = 0
+    for c in range(len(vert_count)):
+        f, k = int(vert_first[c]), int(vert_count[c])
+        L.clapo_skin(k, np.ascontiguousarray(mesh["position"][f:f + k]), np.ascontiguousarray(mesh["normal"][f:f + k]),
+                     np.ascontiguousarray(mesh["joints"][f:f + k]), np.ascontiguousarray(mesh["weights"][f:f + k]),
+                     np.ascontiguousarray(joint_transforms[c]), out_p[at:at + k], out_n[at:at + k])
+        at += k
+    return out_p, out_n

@@ -110,6 +110,44 @@ uint32_t clapo_particles_update(const clapo_particle_system *sys, uint32_t n_sys
                                 float *pos, float *vel, uint64_t *rng);
 void     clapo_particles_billboard(const float view_mx[16], const float center[3], float mx[16]);
 
+/* ---- skeletal pose + joint palette (core/model.c:1266-1404, core/interp.h) ---- */
+/* struct model_joint[] + model3d.root_pose (model.h:104-110,59), flattened */
+typedef struct clapo_skeleton {
+    uint32_t       nr_joints;
+    uint32_t       n_order;
+    const int32_t *parent;       /* [nr_joints], -1 = child of root_pose */
+    const int32_t *order;        /* joints reachable from joint 0, parents first */
+    const float   *root_pose;    /* mat4 */
+    const float   *invmx;        /* [nr_joints] mat4 (inverse bind) */
+    const float   *bind;         /* [nr_joints] mat4 = invert(invmx) */
+} clapo_skeleton;
+
+/* struct animation / struct channel (model.c:678-685), flattened */
+typedef struct clapo_animation {
+    uint32_t        n_channels;
+    const uint32_t *ch_target;   /* joint */
+    const uint32_t *ch_path;     /* 0 translation, 1 rotation, 2 scale (enum chan_path) */
+    const uint32_t *ch_nr;       /* keyframes */
+    const uint32_t *ch_time_off; /* offset into times[] */
+    const uint32_t *ch_data_off; /* offset into data[] (floats; 3 or 4 per keyframe) */
+    const float    *times;
+    const float    *data;
+} clapo_animation;
+
+/* trs[j] = (T.xyz, R.xyzw, S.xyz): struct joint's translation/rotation/scale (model.h:363-370);
+ * cursor[j][path] = joint->off[path] */
+void clapo_pose_channels(const clapo_animation *an, float time, float *trs, int32_t *cursor);
+void clapo_pose_palette(const clapo_skeleton *sk, const float *trs, const float *entity_mx,
+                        float *global, float *joint_transforms, float *joint_pos);
+void clapo_skeleton_bind(uint32_t nr_joints, const float *invmx, float *bind);
+
+/* ---- vertex skinning (shaders/model.vert:32-48; PARITY UNPINNED, see skin.c) ---- */
+/* one character: n_verts vertices in the reference's attribute formats (mesh.h:125-131):
+ * position f32x3, normal f32x3, joints u8x4, weights f32x4; palette = its joint_transforms */
+void clapo_skin(uint32_t n_verts, const float *position, const float *normal,
+                const uint8_t *joints, const float *weights,
+                const float *joint_transforms, float *out_pos, float *out_nor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,10 +229,15 @@ static inline void lm_m4_perspective(float *m, float y_fov, float aspect, float 
     }
 }
 
-/* interp.h:25-29,59-64: linf_interp evaluates in double (the `1.0` literal) */
+/*
+ * interp.h:25-29,59-64: linf_interp is `a * (1.0 - blend) + b * blend` on floats: the `1.0`
+ * literal makes the FIRST product and the sum double, but `b * blend` is a float * float
+ * product (rounded to fp32) that is only then promoted for the addition.
+ */
 static inline float lm_lerp(float a, float b, float fac)
 {
-    return (float)((double)a * (1.0 - (double)fac) + (double)b * (double)fac);
+    float bf = b * fac;
+    return (float)((double)a * (1.0 - (double)fac) + (double)bf);
 }
 
 /* linmath.h:58-62 (vec4_norm): k = float(1.0 / (double)len) */

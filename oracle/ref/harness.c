@@ -381,6 +381,84 @@ static int cmd_particles(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* pose: channels_transform + one_joint_transform per character        */
+/* ------------------------------------------------------------------ */
+static int cmd_pose(struct arrset *in, struct arrset *out)
+{
+    uint32_t J = *(uint32_t *)arr_get(in, "nr_joints", NULL);
+    uint32_t n_chars = *(uint32_t *)arr_get(in, "n_chars", NULL);
+    uint32_t frames = *(uint32_t *)arr_get(in, "frames", NULL);
+    uint32_t n_ch = *(uint32_t *)arr_get(in, "n_channels", NULL);
+    int32_t *parent = arr_get(in, "parent", NULL);
+    float *invmx = arr_get(in, "invmx", NULL);
+    float *root_pose = arr_get(in, "root_pose", NULL);
+    uint32_t *ch_target = arr_get(in, "ch_target", NULL), *ch_path = arr_get(in, "ch_path", NULL);
+    uint32_t *ch_nr = arr_get(in, "ch_nr", NULL);
+    uint32_t *ch_time_off = arr_get(in, "ch_time_off", NULL), *ch_data_off = arr_get(in, "ch_data_off", NULL);
+    float *times = arr_get(in, "times", NULL), *data = arr_get(in, "data", NULL);
+    float *char_time = arr_get(in, "char_time", NULL);      /* [frames][n_chars] */
+    float *char_mx = arr_get(in, "char_mx", NULL);          /* [n_chars][16] */
+    float *trs0 = arr_get(in, "trs0", NULL);                /* [J][10] initial joint T,R,S */
+
+    model3d *m = calloc(1, sizeof(*m));
+    model3dtx *txm = calloc(1, sizeof(*txm));
+    txm->model = m;
+    darray_init(m->anis);
+    model3d_add_skinning(m, J, (mat4x4 *)invmx);            /* model.c:524-538: copies invmx, bind = invert */
+    memcpy(m->root_pose, root_pose, 64);
+    for (uint32_t j = 0; j < J; j++)
+        if (parent[j] >= 0) {
+            int *c = darray_add(m->joints[parent[j]].children);
+            *c = j;
+        }
+    struct animation *an = animation_new(m, "a", n_ch);
+    for (uint32_t c = 0; c < n_ch; c++)
+        animation_add_channel(an, ch_nr[c], times + ch_time_off[c], data + ch_data_off[c],
+                              (ch_path[c] == PATH_ROTATION ? 4 : 3) * sizeof(float), ch_target[c], ch_path[c]);
+
+    entity3d *ents = calloc(n_chars, sizeof(*ents));
+    for (uint32_t i = 0; i < n_chars; i++) {
+        entity3d *e = &ents[i];
+        e->txmodel = txm;
+        e->joints = calloc(J, sizeof(struct joint));        /* model.c:1751-1754 */
+        e->joint_transforms = calloc(J, sizeof(mat4x4));
+        memcpy(e->mx, char_mx + 16 * i, 64);
+        for (uint32_t j = 0; j < J; j++) {
+            memcpy(e->joints[j].translation, trs0 + 10 * j, 12);
+            memcpy(e->joints[j].rotation, trs0 + 10 * j + 3, 16);
+            memcpy(e->joints[j].scale, trs0 + 10 * j + 7, 12);
+        }
+    }
+    uint64_t per = (uint64_t)n_chars * J;
+    float *o_trs = arr_add(out, "trs", frames * per * 40);
+    float *o_jt = arr_add(out, "joint_transforms", frames * per * 64);
+    float *o_gl = arr_add(out, "global", frames * per * 64);
+    float *o_pos = arr_add(out, "joint_pos", frames * per * 16);
+    float *o_bind = arr_add(out, "bind", (uint64_t)J * 64);
+    float *o_time_end = arr_add(out, "time_end", 4);
+    for (uint32_t j = 0; j < J; j++)
+        memcpy(o_bind + 16 * j, m->joints[j].bind, 64);
+    *o_time_end = an->time_end;
+
+    for (uint32_t f = 0; f < frames; f++)
+        for (uint32_t i = 0; i < n_chars; i++) {
+            entity3d *e = &ents[i];
+            channels_transform(e, an, char_time[(uint64_t)f * n_chars + i]);   /* model.c:1582 */
+            one_joint_transform(e, 0, -1);                                      /* model.c:1583 */
+            for (uint32_t j = 0; j < J; j++) {
+                uint64_t k = (uint64_t)f * per + (uint64_t)i * J + j;
+                memcpy(o_trs + 10 * k, e->joints[j].translation, 12);
+                memcpy(o_trs + 10 * k + 3, e->joints[j].rotation, 16);
+                memcpy(o_trs + 10 * k + 7, e->joints[j].scale, 12);
+                memcpy(o_jt + 16 * k, e->joint_transforms[j], 64);
+                memcpy(o_gl + 16 * k, e->joints[j].global, 64);
+                memcpy(o_pos + 4 * k, e->joints[j].pos, 16);
+            }
+        }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     struct arrset in = {}, out = {};
@@ -391,6 +469,7 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "entities"))             rc = cmd_entities(&in, &out);
     else if (!strcmp(argv[1], "bench_entities"))  rc = cmd_bench_entities(&in, &out);
     else if (!strcmp(argv[1], "particles"))       rc = cmd_particles(&in, &out);
+    else if (!strcmp(argv[1], "pose"))            rc = cmd_pose(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

@@ -104,3 +104,24 @@ def particles(ps, view_mx, rng_state, frames):
                 vel=pad(A(out["vel"], np.float32, (frames, total, 3))),
                 mx=A(out["mx"], np.float32, (frames, ns, 16)),
                 rng_state=A(out["rng_state"], np.uint64, (frames + 1,)))
+
+
+def pose(sk, an, chars, char_times):
+    """channels_transform + one_joint_transform on the reference for every character;
+    char_times [frames, n_chars] (float32 frame times)."""
+    char_times = np.atleast_2d(np.asarray(char_times, np.float32))
+    frames, n = char_times.shape
+    J = int(sk["nr_joints"])
+    arrays = dict(nr_joints=np.asarray([J], np.uint32), n_chars=np.asarray([n], np.uint32),
+                  frames=np.asarray([frames], np.uint32), n_channels=np.asarray([an["n_channels"]], np.uint32),
+                  parent=sk["parent"], invmx=sk["invmx"], root_pose=sk["root_pose"],
+                  ch_target=an["ch_target"], ch_path=an["ch_path"], ch_nr=an["ch_nr"],
+                  ch_time_off=an["ch_time_off"], ch_data_off=an["ch_data_off"], times=an["times"], data=an["data"],
+                  char_time=char_times, char_mx=chars["char_mx"][:n], trs0=chars["trs0"])
+    out = run("pose", arrays)
+    A = clpio.as_array
+    return dict(trs=A(out["trs"], np.float32, (frames, n, J, 10)),
+                joint_transforms=A(out["joint_transforms"], np.float32, (frames, n, J, 16)),
+                globalmx=A(out["global"], np.float32, (frames, n, J, 16)),
+                joint_pos=A(out["joint_pos"], np.float32, (frames, n, J, 4)),
+                bind=A(out["bind"], np.float32, (J, 16)), time_end=float(A(out["time_end"], np.float32)[0]))

@@ -1,0 +1,165 @@
+"""GPU: pose blend + joint palette + vertex skinning (through the C ABI) against the oracle and
+the reference's golden vectors.
+
+Tolerance (BASELINE.json north_star: "within 1e-5 relative for float transforms/positions"):
+the reference evaluates lerp in double and slerp through double acos/sin/cos; device libm is not
+glibc, so these outputs are compared with rtol 1e-5 on a scale of the array's own magnitude.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from clap_amd import synth
+from oracle import binding as ob
+from test_oracle_pose import load_pose
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pose_*.npz")))
+
+
+def assert_close(got, exp, what, scale=None):
+    got = np.asarray(got, np.float64)
+    exp = np.asarray(exp, np.float64)
+    assert got.shape == exp.shape, what
+    s = max(float(np.abs(exp).max()), 1e-30) if scale is None else scale
+    err = float(np.abs(got - exp).max()) / s
+    assert err <= RTOL, f"{what}: max |diff| / max |ref| = {err:.3e} > {RTOL}"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_pose_matches_reference_golden(path, cuda_device):
+    from clap_amd import animation
+    sk, an, ch, times, ref = load_pose(path)
+    n, J = ch["char_mx"].shape[0], sk["nr_joints"]
+    model = animation.SkinnedModel(sk, [an], bind=ref["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    reach = sk["order"]
+    unreach = np.setdiff1d(np.arange(J), reach)
+    for f in range(times.shape[0]):
+        batch.set_frame_times(times[f])
+        batch.pose_update()
+        out = batch.download()
+        assert_close(out["trs"], ref["trs"][f], f"frame {f} T/R/S")
+        assert_close(out["joint_transforms"][:, reach], ref["joint_transforms"][f][:, reach], f"frame {f} joint_transforms")
+        assert_close(out["joint_pos"][:, reach], ref["joint_pos"][f][:, reach], f"frame {f} joint pos")
+        assert not out["joint_transforms"][:, unreach].any(), "joints outside joint 0's tree must stay untouched"
+
+
+@pytest.mark.parametrize("J,depth,skw,akw", [
+    (64, 8, {}, {}),                                                   # BASELINE config 3 skeleton
+    (64, 8, dict(unreachable=6), dict(missing_frac=0.25, ragged=True)),
+    (5, 3, {}, {}),
+    (100, 12, {}, dict(ragged=True)),                                  # two wavefronts per character
+    (200, 20, dict(unreachable=3), dict(missing_frac=0.1)),            # JOINTS_MAX
+], ids=["c3_64j", "ragged_64j", "tiny_5j", "two_wave_100j", "joints_max_200j"])
+def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
+    from clap_amd import animation
+    sk = synth.skeleton(J, depth, seed=11, **skw)
+    an0 = synth.animation(J, 30, 2.0, seed=11, **akw)
+    an1 = synth.animation(J, 7, 1.0, seed=12)
+    n = 37
+    ch = synth.characters(n, J, seed=11)
+    sk["bind"] = ob.skeleton_bind(sk)
+    model = animation.SkinnedModel(sk, [an0, an1], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    which = (np.arange(n) % 3 == 0).astype(np.int32)                   # a third of the characters play animation 1
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    reach = sk["order"]
+    for f, t in enumerate([ch["phase"], (ch["phase"] + 0.61) % 2.4, np.full(n, 2.0, np.float32), np.full(n, -1.0, np.float32)]):
+        t = t.astype(np.float32)
+        jt = np.zeros((n, J, 16), np.float32)
+        jp = np.zeros((n, J, 4), np.float32)
+        for a_id, an in ((0, an0), (1, an1)):
+            sel = np.flatnonzero(which == a_id)
+            sub = trs[sel].copy()
+            j1, _g, p1 = ob.pose(sk, an, t[sel], ch["char_mx"][sel], sub)
+            trs[sel], jt[sel], jp[sel] = sub, j1, p1
+        batch.set_frame_times(t, which)
+        batch.pose_update()
+        out = batch.download()
+        assert_close(out["trs"], trs, f"frame {f} T/R/S")
+        assert_close(out["joint_transforms"][:, reach], jt[:, reach], f"frame {f} joint_transforms")
+        assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
+
+
+def test_animated_update_time_base(cuda_device):
+    """Host half of animated_update: frame_time = (now - ani_time) * speed, restart at time_end."""
+    from clap_amd import animation
+    sk = synth.skeleton(16, 4, seed=5)
+    an = synth.animation(16, 6, 1.5, seed=5)
+    ch = synth.characters(8, 16, seed=5)
+    sk["bind"] = ob.skeleton_bind(sk)
+    model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, 8, ch["trs0"], ch["char_mx"])
+    batch.ani_time[:] = np.linspace(0, 1, 8)
+    batch.speed[:] = 1.25
+    trs = np.tile(ch["trs0"], (8, 1, 1))
+    ani_time = batch.ani_time.copy()
+    for now in (1.0, 1.7, 2.9):
+        ft = ((now - ani_time) * 1.25)
+        jt, _g, _p = ob.pose(sk, an, ft.astype(np.float32), ch["char_mx"], trs)
+        batch.animated_update(now)
+        assert_close(batch.download()["joint_transforms"], jt, f"now={now}")
+        ani_time[ft >= 1.5] = now
+        assert np.array_equal(batch.ani_time, ani_time)
+
+
+@pytest.mark.parametrize("shared_mesh", [True, False], ids=["instanced_mesh", "mesh_per_character"])
+def test_skin_matches_oracle(shared_mesh, cuda_device):
+    from clap_amd import animation
+    J, n = 64, 23
+    sk = synth.skeleton(J, 8, seed=3)
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n, J, seed=3)
+    sk["bind"] = ob.skeleton_bind(sk)
+    if shared_mesh:
+        mesh = synth.skinned_mesh(200, J, seed=3)
+        vf, vc = np.zeros(n, np.uint32), np.full(n, 200, np.uint32)
+    else:                                                             # ragged: 1 .. 700 vertices per character
+        vc = np.random.Generator(np.random.PCG64(4)).integers(1, 700, n).astype(np.uint32)
+        mesh = synth.skinned_mesh(int(vc.sum()), J, seed=3)
+        vf = np.concatenate([[0], np.cumsum(vc[:-1])]).astype(np.uint32)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
+    batch.set_frame_times(ch["phase"])
+    batch.pose_update()
+    batch.skin()
+    out = batch.download()
+    exp_p, exp_n = ob.skin(mesh, vf, vc, out["joint_transforms"])     # same palette in: isolates the skinning kernel
+    assert_close(out["out_position"], exp_p, "skinned positions")
+    assert_close(out["out_normal"], exp_n, "skinned normals")
+    # and end to end against the oracle's own palette
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    jt, _g, _p = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
+    exp_p2, _ = ob.skin(mesh, vf, vc, jt)
+    assert_close(out["out_position"], exp_p2, "pose -> skin end to end")
+
+
+def test_c3_shape_properties(cuda_device):
+    """BASELINE config 3 at reduced count (2k characters here; bench.py runs the 50k): palette of a
+    rest pose equals I (global * invmx with global == bind), skinning by it is the identity."""
+    from clap_amd import animation
+    J, n = 64, 2000
+    sk = synth.skeleton(J, 8, seed=3)
+    bind = ob.skeleton_bind(sk)
+    sk["bind"] = bind
+    # an "animation" whose keys hold each joint at its bind pose is not expressible without the
+    # local decomposition; use linearity instead: two palettes P1, P2 -> skin is linear in the palette
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n, J, seed=3)
+    mesh = synth.skinned_mesh(200, J, seed=3)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, bind=bind, device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    batch.set_frame_times(ch["phase"])
+    batch.pose_update()
+    batch.skin()
+    o1 = batch.download()
+    batch.joint_transforms.mul_(2.0)                                  # linearity: 2 * palette -> 2 * output
+    batch.skin()
+    o2 = batch.download()
+    assert_close(o2["out_position"], 2.0 * o1["out_position"], "skin linear in palette")
+    assert np.isfinite(o1["joint_transforms"]).all() and np.isfinite(o1["out_position"]).all()

@@ -67,6 +67,20 @@ def particle_fixture(name, ps, frames, view_mx, state=synth.DRAND48_DEFAULT_STAT
          **{"ref_" + k: v for k, v in ref.items()})
 
 
+SK_KEYS = ("parent", "invmx", "root_pose", "order")
+AN_KEYS = ("ch_target", "ch_path", "ch_nr", "ch_time_off", "ch_data_off", "times", "data")
+
+
+def pose_fixture(name, sk, an, chars, char_times):
+    ref = refrun.pose(sk, an, chars, char_times)
+    d = {"sk_" + k: sk[k] for k in SK_KEYS}
+    d.update({"an_" + k: an[k] for k in AN_KEYS})
+    d.update(in_char_mx=chars["char_mx"], in_trs0=chars["trs0"], in_char_times=np.asarray(char_times, np.float32))
+    d.update({"ref_" + k: v for k, v in ref.items() if k != "time_end"})
+    d["ref_time_end"] = np.asarray([ref["time_end"]], np.float32)
+    save(name, **d)
+
+
 def main():
     if not refrun.available():
         refrun.build()
@@ -81,6 +95,14 @@ def main():
     for dist, nm in ((synth.PART_DIST_CBRT, "cbrt"), (synth.PART_DIST_POW075, "pow075")):
         particle_fixture("particles_" + nm, synth.particle_systems(n_sys=3, count=100, radius=2.0, velocity=0.6,
                                                                     dist=dist, seed=6), 4, view)
+    for nm, skw, akw in (("pose_full", dict(), dict()),
+                         ("pose_ragged", dict(unreachable=4), dict(missing_frac=0.3, ragged=True))):
+        sk = synth.skeleton(24, 6, seed=8, **skw)
+        an = synth.animation(24, 9, 2.0, seed=8, **akw)
+        ch = synth.characters(12, 24, seed=8)
+        t = np.stack([ch["phase"], (ch["phase"] * 1.7) % 2.3, np.full(12, 2.0, np.float32),
+                      np.full(12, -0.25, np.float32), np.zeros(12, np.float32)]).astype(np.float32)
+        pose_fixture(nm, sk, an, ch, t)
     entity_fixture("entities_flat_c1", synth.entities_flat(512, seed=1234), cam)
     entity_fixture("entities_flat_euler", synth.entities_flat(512, seed=99, full_euler=True),
                    synth.camera(pos=(10, 5, -20), quat=synth.quat_from_euler_xyz(0.2, 2.5, -0.1),
