@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_NOMEM = -1
@@ -85,6 +85,23 @@ class SkinBatch(C.Structure):
                 ("joint_transforms", C.c_void_p), ("out_position", C.c_void_p), ("out_normal", C.c_void_p)]
 
 
+class World(C.Structure):
+    _fields_ = [("gravity", C.c_double * 3), ("linear_damping", C.c_double),
+                ("linear_damping_threshold_sq", C.c_double), ("adis_linear_threshold_sq", C.c_double),
+                ("adis_angular_threshold_sq", C.c_double), ("adis_time", C.c_double),
+                ("adis_steps", C.c_int32), ("pad", C.c_int32)]
+
+
+class Bodies(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("quat", C.c_void_p),
+                ("lvel", C.c_void_p), ("avel", C.c_void_p), ("mass", C.c_void_p), ("radius", C.c_void_p),
+                ("yoffset", C.c_void_p), ("bflags", C.c_void_p), ("adis_steps_left", C.c_void_p),
+                ("adis_time_left", C.c_void_p), ("body_entity", C.c_void_p)]
+
+
+BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY = 1, 2, 4
+
+
 # every symbol include/clapgpu.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "clapgpu_device_count": (C.c_int, []),
@@ -112,6 +129,16 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
+    "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),
+    "clapgpu_world_defaults": (None, [C.POINTER(World)]),
+    "clapgpu_bodies_step": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(World), C.c_double]),
+    "clapgpu_phys_body_update": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
+    "clapgpu_broadphase_scratch_bytes": (C.c_size_t, [C.c_uint32]),
+    "clapgpu_broadphase_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_double, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_void_p]),
+    "clapgpu_broadphase_static_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
+                                                  C.c_uint32, C.c_void_p, C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
 }
 

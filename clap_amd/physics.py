@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's physics interface for free sphere bodies.
+
+``PhysWorld.phys_step(dt)`` follows phys_step() / __phys_step() (physics.c:746-787): the
+fixed-step schedule runs on the host, each substep does the two broadphase calls and the ODE
+world step on the GPU; ``phys_body_update`` is the body -> entity read-back of
+physics.c:789-812.  ODE being absent from the reference tree, this block is parity-unpinned
+(DESIGN.md).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else 0
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PhysWorld:
+    def __init__(self, bodies, statics=None, pair_capacity=None, device="cuda:0"):
+        """bodies: dict from synth.sphere_bodies(); statics: float64 [ns, 6] (minx,maxx,miny,maxy,minz,maxz)."""
+        self.device = dev = torch.device(device)
+        self.n = n = int(bodies["n"])
+        t = lambda k, dt: torch.from_numpy(np.ascontiguousarray(bodies[k], dt)).to(dev)
+        self.pos, self.quat = t("pos", np.float64), t("quat", np.float64)
+        self.lvel, self.avel = t("lvel", np.float64), t("avel", np.float64)
+        self.mass, self.radius, self.yoffset = t("mass", np.float64), t("radius", np.float64), t("yoffset", np.float64)
+        self.bflags = torch.from_numpy(np.ascontiguousarray(bodies["bflags"]).view(np.int32)).to(dev)
+        self.adis_steps_left = t("adis_steps_left", np.int32)
+        self.adis_time_left = t("adis_time_left", np.float64)
+        self.body_entity = t("body_entity", np.int32)
+        self.cell = float(bodies["cell"])
+        self.world = _lib.World()
+        _lib.lib().clapgpu_world_defaults(C.byref(self.world))
+        self.time_acc = C.c_double(0.0)
+        self._desc = _lib.Bodies(n, 0, _ptr(self.pos), _ptr(self.quat), _ptr(self.lvel), _ptr(self.avel),
+                                 _ptr(self.mass), _ptr(self.radius), _ptr(self.yoffset), _ptr(self.bflags),
+                                 _ptr(self.adis_steps_left), _ptr(self.adis_time_left), _ptr(self.body_entity))
+        self.capacity = int(pair_capacity if pair_capacity is not None else max(8 * n, 1024))
+        self.pairs = torch.zeros((self.capacity, 2), dtype=torch.int32, device=dev)
+        self.pair_total = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.static_pairs = torch.zeros((self.capacity, 2), dtype=torch.int32, device=dev)
+        self.static_pair_total = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(_lib.lib().clapgpu_broadphase_scratch_bytes(n) // 4 + 4, dtype=torch.int32, device=dev)
+        self.statics = None
+        self.n_static = 0
+        if statics is not None and len(statics):
+            self.statics = torch.from_numpy(np.ascontiguousarray(statics, np.float64)).to(dev)
+            self.n_static = self.statics.shape[0]
+
+    # ---- __phys_step pieces -----------------------------------------------------------
+    def broadphase(self):
+        """dSpaceCollide2(ground, bodies) + dSpaceCollide(bodies): candidate pair lists."""
+        L = _lib.lib()
+        if self.n_static:
+            _lib.check(L.clapgpu_broadphase_static_pairs(_stream(), C.byref(self._desc), self.n_static,
+                                                         _ptr(self.statics), _ptr(self.static_pairs), self.capacity,
+                                                         _ptr(self.static_pair_total), _ptr(self.scratch)),
+                       "clapgpu_broadphase_static_pairs")
+        _lib.check(L.clapgpu_broadphase_pairs(_stream(), C.byref(self._desc), self.cell, _ptr(self.pairs),
+                                              self.capacity, _ptr(self.pair_total), _ptr(self.scratch)),
+                   "clapgpu_broadphase_pairs")
+
+    def world_step(self, h):
+        _lib.check(_lib.lib().clapgpu_bodies_step(_stream(), C.byref(self._desc), C.byref(self.world), h),
+                   "clapgpu_bodies_step")
+
+    def phys_step(self, dt, broadphase=True):
+        """phys_step(phys, dt): returns the number of fixed substeps taken."""
+        steps = _lib.lib().clapgpu_phys_step_schedule(C.byref(self.time_acc), dt)
+        for _ in range(steps):
+            if broadphase:
+                self.broadphase()
+            self.world_step(1.0 / 120.0)
+        return steps
+
+    def phys_body_update(self, entity_batch, moving=None):
+        """phys_body_update for every body: entity TRS <- body pose, entities marked dirty."""
+        _lib.check(_lib.lib().clapgpu_phys_body_update(_stream(), C.byref(self._desc), _ptr(entity_batch.pos_scale),
+                                                       _ptr(entity_batch.rot), _ptr(entity_batch.flags),
+                                                       _ptr(moving)),
+                   "clapgpu_phys_body_update")
+
+    def download(self):
+        torch.cuda.synchronize(self.device)
+        npairs = int(self.pair_total.item())
+        nst = int(self.static_pair_total.item())
+        return dict(pos=self.pos.cpu().numpy(), quat=self.quat.cpu().numpy(), lvel=self.lvel.cpu().numpy(),
+                    avel=self.avel.cpu().numpy(), bflags=self.bflags.cpu().numpy().view(np.uint32),
+                    adis_steps_left=self.adis_steps_left.cpu().numpy(), adis_time_left=self.adis_time_left.cpu().numpy(),
+                    pair_total=npairs, pairs=self.pairs[:min(npairs, self.capacity)].cpu().numpy().view(np.uint32),
+                    static_pair_total=nst,
+                    static_pairs=self.static_pairs[:min(nst, self.capacity)].cpu().numpy().view(np.uint32))
+
+    def integrate_algorithmic_bytes(self):
+        return 232 * self.n

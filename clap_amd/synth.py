@@ -362,3 +362,40 @@ def skinned_mesh(n_verts=200, nr_joints=64, seed=3, copies=1):
     w = rng.dirichlet(np.ones(4), n)
     return dict(n_verts=n, position=rng.uniform(-1, 1, (n, 3)).astype(F32), normal=nor.astype(F32),
                 joints=rng.integers(0, nr_joints, (n, 4)).astype(np.uint8), weights=w.astype(F32))
+
+
+# ----------------------------------------------------------------------------- rigid bodies
+def sphere_bodies(n=262_144, box=64.0, rmin=0.1, rmax=0.5, seed=4, entity_base=0, resting_frac=0.0):
+    """C4 (body half): n sphere bodies, radius U(rmin,rmax), positions uniform in a box^3 cube,
+    lvel N(0,1).  SURVEY.md 8d names a 512^3 box "(a few pairs/body)", but 256k spheres of
+    diameter <= 1 in 512^3 give ~0.002 pairs/body; box = 64 gives the stated ~1 pair/body and
+    is the default.  fp64 state in ODE's layout (quat = w,x,y,z)."""
+    rng = _rng(seed)
+    radius = rng.uniform(rmin, rmax, n)
+    ang = rng.uniform(-math.pi, math.pi, (n, 3))
+    q = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2]).astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    lvel = rng.normal(0, 1, (n, 3))
+    avel = rng.normal(0, 0.5, (n, 3))
+    rest = rng.uniform(0, 1, n) < resting_frac
+    lvel[rest] *= 1e-3
+    avel[rest] *= 1e-3
+    bflags = np.full(n, 2, np.uint32)                        # auto-disable on (physics.c:1039)
+    bflags[rest] |= 4                                        # resting bodies: no gravity, so they stay idle
+    return dict(n=n, pos=rng.uniform(0, box, (n, 3)), quat=q[:, [3, 0, 1, 2]].copy(), lvel=lvel, avel=avel,
+                mass=4.0 / 3.0 * math.pi * radius ** 3, radius=radius, yoffset=radius.copy(),
+                bflags=bflags, adis_steps_left=np.full(n, 30, np.int32), adis_time_left=np.zeros(n),
+                body_entity=(entity_base + np.arange(n)).astype(np.int32), cell=2.0 * rmax)
+
+
+def static_boxes(n=64, box=64.0, seed=5):
+    """Static collision geoms (the ground_space): AABBs as ODE stores them (minx,maxx,miny,maxy,minz,maxz)."""
+    rng = _rng(seed)
+    lo = rng.uniform(0, box, (n, 3))
+    ext = rng.uniform(1, box / 4, (n, 3))
+    out = np.empty((n, 6))
+    out[:, 0::2] = lo
+    out[:, 1::2] = lo + ext
+    if n:
+        out[0] = [-1e3, 1e3, -10.0, 0.5, -1e3, 1e3]          # a ground slab
+    return out

@@ -339,6 +339,87 @@ typedef struct clapgpu_skin_batch {
 
 int clapgpu_skin(void *stream, const clapgpu_skin_batch *b);
 
+/* ======================================================================== */
+/* Rigid bodies: phys_step schedule, integrate, read-back, AABB broadphase   */
+/* (core/physics.c over ODE).  ODE is an absent submodule of the reference:  */
+/* the arithmetic is restated from ODE's published quickstep -- see          */
+/* oracle/physics.c and DESIGN.md; parity for this block is UNPINNED.        */
+/* ======================================================================== */
+
+#define CLAPGPU_BODY_DISABLED      (1u << 0)   /* dxBodyDisabled */
+#define CLAPGPU_BODY_AUTO_DISABLE  (1u << 1)   /* dBodySetAutoDisableFlag(body, 1), physics.c:1039 */
+#define CLAPGPU_BODY_NO_GRAVITY    (1u << 2)   /* dBodySetGravityMode(body, 0) */
+
+/* world parameters phys_init() / phys_body_new() set (physics.c:1125-1129, 1039-1042) */
+typedef struct clapgpu_world {
+    double  gravity[3];
+    double  linear_damping;
+    double  linear_damping_threshold_sq;
+    double  adis_linear_threshold_sq;
+    double  adis_angular_threshold_sq;
+    double  adis_time;
+    int32_t adis_steps;
+    int32_t pad;
+} clapgpu_world;
+
+/*
+ * Sphere bodies of the character_space, fp64 like the reference's dDOUBLE ODE (physics.h:5-9).
+ *   pos[n][3], quat[n][4] (w,x,y,z = ODE order), lvel[n][3], avel[n][3]  in/out
+ *   mass[n], radius[n]                                                     geometry / dMass
+ *   yoffset[n]      phys_body.yoffset (physics.c:797-799)
+ *   bflags[n]       CLAPGPU_BODY_* ; adis_steps_left / adis_time_left: ODE's auto-disable counters
+ *   body_entity[n]  index of the entity3d the geom's data points at, or -1
+ */
+typedef struct clapgpu_bodies {
+    uint32_t        n;
+    uint32_t        pad;
+    double         *pos;
+    double         *quat;
+    double         *lvel;
+    double         *avel;
+    const double   *mass;
+    const double   *radius;
+    const double   *yoffset;
+    uint32_t       *bflags;
+    int32_t        *adis_steps_left;
+    double         *adis_time_left;
+    const int32_t  *body_entity;
+} clapgpu_bodies;
+
+/* physics.c:773-787: adds dt to *time_acc and returns how many 1/120 s substeps to run (0..5) */
+int  clapgpu_phys_step_schedule(double *time_acc, double dt);
+void clapgpu_world_defaults(clapgpu_world *w);
+
+/* dWorldQuickStep(world, h) for bodies without joints (physics.c:769) */
+int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h);
+
+/*
+ * phys_body_update() for every body (physics.c:789-812, 96-109): writes entity pos
+ * (y - yoffset, double -> float) and rotation (wxyz -> xyzw) into the entity SoA
+ * (clapgpu_entities.pos_scale / .rot), sets CLAPGPU_E_DIRTY, and moving[i] = |lvel| > 1e-3
+ * (may be NULL).
+ */
+int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, float *pos_scale, float *rot,
+                             uint32_t *entity_flags, uint8_t *moving);
+
+/*
+ * dSpaceCollide(character_space) (physics.c:753): all body pairs whose AABBs overlap, as the
+ * ascending list pairs[k] = (i, j), i < j.  cell >= the largest AABB edge (2 * max radius).
+ * *pair_total (device uint32) receives the number found; at most `capacity` are written.
+ * scratch: clapgpu_broadphase_scratch_bytes(n) bytes of device memory.
+ */
+size_t clapgpu_broadphase_scratch_bytes(uint32_t n);
+int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, double cell,
+                             uint32_t *pairs, uint32_t capacity, uint32_t *pair_total, void *scratch);
+
+/*
+ * dSpaceCollide2(ground_space, character_space) (physics.c:751): pairs (body, static geom),
+ * ascending; static_aabb[s] = (minx,maxx,miny,maxy,minz,maxz) like ODE's dReal aabb[6] (device).
+ */
+int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodies *b, uint32_t n_static,
+                                    const double *static_aabb, uint32_t *pairs, uint32_t capacity,
+                                    uint32_t *pair_total, void *scratch);
+
 #ifdef __cplusplus
 }
 #endif

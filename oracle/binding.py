@@ -43,6 +43,13 @@ class Animation(C.Structure):
                 ("times", C.c_void_p), ("data", C.c_void_p)]
 
 
+class World(C.Structure):
+    _fields_ = [("gravity", C.c_double * 3), ("linear_damping", C.c_double),
+                ("linear_damping_threshold_sq", C.c_double), ("adis_linear_threshold_sq", C.c_double),
+                ("adis_angular_threshold_sq", C.c_double), ("adis_time", C.c_double),
+                ("adis_steps", C.c_int32), ("pad", C.c_int32)]
+
+
 def build():
     """Compile the restatement (gcc).  Building the checker is not using it."""
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -88,6 +95,16 @@ def _declare(L):
     L.clapo_pose_channels.argtypes = [C.POINTER(Animation), C.c_float, F32P, I32P]
     L.clapo_pose_palette.argtypes = [C.POINTER(Skeleton), F32P, F32P, F32P, F32P, F32P]
     L.clapo_skeleton_bind.argtypes = [C.c_uint32, F32P, F32P]
+    L.clapo_phys_step_schedule.argtypes = [C.POINTER(C.c_double), C.c_double]
+    L.clapo_phys_step_schedule.restype = C.c_int
+    L.clapo_world_defaults.argtypes = [C.POINTER(World)]
+    L.clapo_bodies_step.argtypes = [C.c_uint32, C.c_double, C.POINTER(World), F64P, F64P, F64P, F64P, F64P, U32P,
+                                    I32P, F64P]
+    L.clapo_phys_body_update.argtypes = [C.c_uint32, F64P, F64P, F64P, F64P, I32P, F32P, F32P, U32P, C.c_void_p]
+    L.clapo_broadphase_pairs.argtypes = [C.c_uint32, F64P, F64P, C.c_void_p, C.c_uint64]
+    L.clapo_broadphase_pairs.restype = C.c_uint64
+    L.clapo_broadphase_static_pairs.argtypes = [C.c_uint32, F64P, C.c_uint32, F64P, F64P, C.c_void_p, C.c_uint64]
+    L.clapo_broadphase_static_pairs.restype = C.c_uint64
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
 
 
@@ -210,3 +227,57 @@ def skin(mesh, vert_first, vert_count, joint_transforms):
                      np.ascontiguousarray(joint_transforms[c]), out_p[at:at + k], out_n[at:at + k])
         at += k
     return out_p, out_n
+
+
+# ------------------------------------------------------------------ rigid bodies (parity unpinned)
+def world_defaults():
+    w = World()
+    lib().clapo_world_defaults(C.byref(w))
+    return w
+
+
+def phys_step_schedule(time_acc, dt):
+    t = C.c_double(time_acc)
+    steps = lib().clapo_phys_step_schedule(C.byref(t), dt)
+    return steps, t.value
+
+
+def bodies_state(b):
+    """Mutable copy of the dynamic state of a synth.sphere_bodies() dict."""
+    return {k: np.ascontiguousarray(b[k]).copy() for k in ("pos", "quat", "lvel", "avel", "bflags",
+                                                             "adis_steps_left", "adis_time_left")}
+
+
+def bodies_step(b, st, h, world=None):
+    w = world or world_defaults()
+    lib().clapo_bodies_step(int(b["n"]), h, C.byref(w), st["pos"], st["quat"], st["lvel"], st["avel"],
+                            np.ascontiguousarray(b["mass"]), st["bflags"], st["adis_steps_left"], st["adis_time_left"])
+
+
+def phys_body_update(b, st, pos_scale, rot, entity_flags):
+    moving = np.zeros(int(b["n"]), np.uint8)
+    lib().clapo_phys_body_update(int(b["n"]), st["pos"], st["quat"], st["lvel"], np.ascontiguousarray(b["yoffset"]),
+                                 np.ascontiguousarray(b["body_entity"]), pos_scale, rot, entity_flags,
+                                 moving.ctypes.data)
+    return moving
+
+
+def broadphase_pairs(pos, radius, max_pairs=None):
+    n = pos.shape[0]
+    cap = int(max_pairs if max_pairs is not None else max(16 * n, 1024))
+    pairs = np.zeros((cap, 2), np.uint32)
+    cnt = lib().clapo_broadphase_pairs(n, np.ascontiguousarray(pos), np.ascontiguousarray(radius),
+                                       pairs.ctypes.data, cap)
+    assert cnt <= cap, "oracle pair buffer too small"
+    return pairs[:cnt].copy()
+
+
+def broadphase_static_pairs(statics, pos, radius, max_pairs=None):
+    n = pos.shape[0]
+    cap = int(max_pairs if max_pairs is not None else max(16 * n, 1024))
+    pairs = np.zeros((cap, 2), np.uint32)
+    cnt = lib().clapo_broadphase_static_pairs(statics.shape[0], np.ascontiguousarray(statics), n,
+                                              np.ascontiguousarray(pos), np.ascontiguousarray(radius),
+                                              pairs.ctypes.data, cap)
+    assert cnt <= cap
+    return pairs[:cnt].copy()

@@ -148,6 +148,39 @@ void clapo_skin(uint32_t n_verts, const float *position, const float *normal,
                 const uint8_t *joints, const float *weights,
                 const float *joint_transforms, float *out_pos, float *out_nor);
 
+/* ---- rigid bodies: schedule, integrate, broadphase (core/physics.c over ODE; PARITY UNPINNED,
+ *      see physics.c) ---- */
+#define CLAPO_BODY_DISABLED      (1u << 0)   /* dxBodyDisabled */
+#define CLAPO_BODY_AUTO_DISABLE  (1u << 1)   /* dBodySetAutoDisableFlag(body, 1), physics.c:1039 */
+#define CLAPO_BODY_NO_GRAVITY    (1u << 2)   /* dBodySetGravityMode(body, 0) */
+
+typedef struct clapo_world {
+    double  gravity[3];
+    double  linear_damping;
+    double  linear_damping_threshold_sq;
+    double  adis_linear_threshold_sq;
+    double  adis_angular_threshold_sq;
+    double  adis_time;
+    int32_t adis_steps;
+    int32_t pad;
+} clapo_world;
+
+int      clapo_phys_step_schedule(double *time_acc, double dt);
+void     clapo_world_defaults(clapo_world *w);
+/* pos[n][3], quat[n][4] (w,x,y,z: ODE order), lvel[n][3], avel[n][3] doubles */
+void     clapo_bodies_step(uint32_t n, double h, const clapo_world *w,
+                           double *pos, double *quat, double *lvel, double *avel,
+                           const double *mass, uint32_t *bflags, int32_t *adis_steps_left,
+                           double *adis_time_left);
+void     clapo_phys_body_update(uint32_t n, const double *pos, const double *quat, const double *lvel,
+                                const double *yoffset, const int32_t *body_entity,
+                                float *pos_scale, float *rot, uint32_t *entity_flags, uint8_t *moving);
+uint64_t clapo_broadphase_pairs(uint32_t n, const double *pos, const double *radius,
+                                uint32_t *pairs, uint64_t max_pairs);
+uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_aabb,
+                                       uint32_t n, const double *pos, const double *radius,
+                                       uint32_t *pairs, uint64_t max_pairs);
+
 #ifdef __cplusplus
 }
 #endif

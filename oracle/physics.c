@@ -1,0 +1,234 @@
+/*
+ * oracle/physics.c -- TEST INFRASTRUCTURE ONLY (see clap_oracle.h).
+ *
+ * PARITY UNPINNED.  The reference's rigid-body arithmetic lives in ODE (submodule deps/ode ->
+ * git@github.com:virtuoso/ode.git, commit not recorded, built dDOUBLE with libccd + OPCODE,
+ * CMakeLists.txt:344-390), which is ABSENT from /root/reference, and the reference has no test
+ * at this boundary.  What is restated here:
+ *
+ *   from the reference itself (core/physics.c):
+ *     - the fixed-step schedule of phys_step()                         physics.c:773-787
+ *     - world parameters: gravity (0,-9.8,0), linear damping 0.001      physics.c:1125-1129
+ *     - auto-disable thresholds 0.05 / 0.05, 30 steps                   physics.c:1039-1042
+ *     - body -> entity read-back phys_body_update()                     physics.c:789-812, 96-109
+ *     - the two broadphase calls dSpaceCollide2(ground, bodies) and
+ *       dSpaceCollide(bodies)                                           physics.c:751-753
+ *   from ODE's published algorithm (ode/src/quickstep.cpp, util.cpp dxStepBody /
+ *   dInternalHandleAutoDisabling, collision_space.cpp collideAABBs; ODE 0.16 line), for a
+ *   world step with no joints or contacts:
+ *     - gravity into the force accumulator, lvel += (h * invMass) * facc
+ *     - pos += h * lvel; q += h * 0.5 * (0,w) (x) q; renormalise
+ *     - linear damping: lvel *= (1 - scale) when |lvel|^2 > threshold^2 (default 0.01^2)
+ *     - auto-disable on instantaneous velocities (ODE's sample-averaging window is not
+ *       modelled: its default length cannot be checked without the source)
+ *     - AABB overlap: two boxes collide unless separated on an axis (touching counts)
+ *   Spheres only: their inertia is isotropic, so the gyroscopic torque vanishes and the
+ *   angular velocity of a torque-free body is constant.
+ *
+ * Candidate pairs are reported as the canonical ascending set, not in ODE's hash-space
+ * callback order (implementation-defined).
+ */
+#include <stdlib.h>
+#include "clap_oracle.h"
+#include "lm.h"
+
+/* physics.c:773-787 */
+int clapo_phys_step_schedule(double *time_acc, double dt)
+{
+    const double fixed_dt = 1.0 / 120.0;
+    int steps, max_steps;
+
+    *time_acc += dt;
+    for (steps = 0, max_steps = 5; *time_acc >= fixed_dt && steps < max_steps; *time_acc -= fixed_dt, steps++)
+        ;
+    if (steps == max_steps)
+        *time_acc = 0.0;
+    return steps;
+}
+
+void clapo_world_defaults(clapo_world *w)
+{
+    w->gravity[0] = 0; w->gravity[1] = -9.8; w->gravity[2] = 0;      /* physics.c:1125 */
+    w->linear_damping = 0.001;                                         /* physics.c:1129 */
+    w->linear_damping_threshold_sq = 0.01 * 0.01;                      /* ODE default threshold 0.01 */
+    w->adis_linear_threshold_sq = 0.05 * 0.05;                         /* physics.c:1040 */
+    w->adis_angular_threshold_sq = 0.05 * 0.05;                        /* physics.c:1041 */
+    w->adis_steps = 30;                                                /* physics.c:1042 */
+    w->adis_time = 0.0;
+}
+
+/* one dWorldQuickStep(world, h) for free bodies */
+void clapo_bodies_step(uint32_t n, double h, const clapo_world *w,
+                       double *pos, double *quat, double *lvel, double *avel,
+                       const double *mass, uint32_t *bflags, int32_t *adis_steps_left, double *adis_time_left)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        double *p = pos + 3 * (size_t)i, *q = quat + 4 * (size_t)i;
+        double *v = lvel + 3 * (size_t)i, *om = avel + 3 * (size_t)i;
+
+        if (bflags[i] & CLAPO_BODY_DISABLED)
+            continue;
+        /* dInternalHandleAutoDisabling */
+        if (bflags[i] & CLAPO_BODY_AUTO_DISABLE) {
+            int idle = 1;
+            if (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > w->adis_linear_threshold_sq)
+                idle = 0;
+            else if (om[0] * om[0] + om[1] * om[1] + om[2] * om[2] > w->adis_angular_threshold_sq)
+                idle = 0;
+            if (idle) {
+                adis_steps_left[i]--;
+                adis_time_left[i] -= h;
+            } else {
+                adis_steps_left[i] = w->adis_steps;
+                adis_time_left[i] = w->adis_time;
+            }
+            if (adis_steps_left[i] <= 0 && adis_time_left[i] <= 0) {
+                bflags[i] |= CLAPO_BODY_DISABLED;
+                v[0] = v[1] = v[2] = 0;
+                om[0] = om[1] = om[2] = 0;
+                continue;
+            }
+        }
+        /* gravity -> facc; lvel += (h * invMass) * facc */
+        const double inv_mass = 1.0 / mass[i];
+        const double k = h * inv_mass;
+        for (int j = 0; j < 3; j++) {
+            double f = (bflags[i] & CLAPO_BODY_NO_GRAVITY) ? 0.0 : mass[i] * w->gravity[j];
+            v[j] += k * f;
+        }
+        /* dxStepBody */
+        for (int j = 0; j < 3; j++)
+            p[j] += h * v[j];
+        double dq[4];                                                  /* dWtoDQ */
+        dq[0] = 0.5 * (-om[0] * q[1] - om[1] * q[2] - om[2] * q[3]);
+        dq[1] = 0.5 * ( om[0] * q[0] + om[1] * q[3] - om[2] * q[2]);
+        dq[2] = 0.5 * (-om[0] * q[3] + om[1] * q[0] + om[2] * q[1]);
+        dq[3] = 0.5 * ( om[0] * q[2] - om[1] * q[1] + om[2] * q[0]);
+        for (int j = 0; j < 4; j++)
+            q[j] += h * dq[j];
+        double l = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];   /* dNormalize4 */
+        if (l > 0) {
+            l = 1.0 / sqrt(l);
+            for (int j = 0; j < 4; j++) q[j] *= l;
+        } else {
+            q[0] = 1; q[1] = q[2] = q[3] = 0;
+        }
+        if (w->linear_damping != 0.0) {
+            const double speed2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            if (speed2 > w->linear_damping_threshold_sq) {
+                const double s = 1 - w->linear_damping;
+                v[0] *= s; v[1] *= s; v[2] *= s;
+            }
+        }
+    }
+}
+
+/* phys_body_update (physics.c:789-812) + phys_body_rotation (96-109): body -> entity TRS */
+void clapo_phys_body_update(uint32_t n, const double *pos, const double *quat, const double *lvel,
+                            const double *yoffset, const int32_t *body_entity,
+                            float *pos_scale, float *rot, uint32_t *entity_flags, uint8_t *moving)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t e = body_entity[i];
+        const double *p = pos + 3 * (size_t)i, *q = quat + 4 * (size_t)i, *v = lvel + 3 * (size_t)i;
+        if (e >= 0) {
+            pos_scale[4 * (size_t)e + 0] = p[0];
+            pos_scale[4 * (size_t)e + 1] = p[1] - yoffset[i];
+            pos_scale[4 * (size_t)e + 2] = p[2];
+            rot[4 * (size_t)e + 0] = q[1];                          /* ODE (w,x,y,z) -> (x,y,z,w) */
+            rot[4 * (size_t)e + 1] = q[2];
+            rot[4 * (size_t)e + 2] = q[3];
+            rot[4 * (size_t)e + 3] = q[0];
+            entity_flags[e] |= CLAPO_E_DIRTY;                          /* transform_set_pos/_quat */
+        }
+        if (moving)
+            moving[i] = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) > 1e-3 ? 1 : 0;
+    }
+}
+
+/* sphere AABB: centre -/+ radius */
+static void sphere_aabb(const double *p, double r, double *bb)
+{
+    bb[0] = p[0] - r; bb[1] = p[0] + r;
+    bb[2] = p[1] - r; bb[3] = p[1] + r;
+    bb[4] = p[2] - r; bb[5] = p[2] + r;
+}
+
+/* collideAABBs: disjoint iff separated on some axis (touching boxes do collide) */
+static int aabb_overlap(const double *a, const double *b)
+{
+    return !(a[0] > b[1] || a[1] < b[0] || a[2] > b[3] || a[3] < b[2] || a[4] > b[5] || a[5] < b[4]);
+}
+
+struct sweep_ent { double lo; uint32_t id; };
+static int sweep_cmp(const void *a, const void *b)
+{
+    const struct sweep_ent *x = a, *y = b;
+    return x->lo < y->lo ? -1 : x->lo > y->lo ? 1 : (x->id < y->id ? -1 : x->id > y->id);
+}
+static int pair_cmp(const void *a, const void *b)
+{
+    const uint32_t *x = a, *y = b;
+    return x[0] != y[0] ? (x[0] < y[0] ? -1 : 1) : (x[1] < y[1] ? -1 : x[1] > y[1]);
+}
+
+/*
+ * dSpaceCollide(bodies): every unordered pair of sphere geoms with overlapping AABBs, as the
+ * ascending list of (i, j), i < j.  Sweep-and-prune on x (deliberately not the grid the GPU uses).
+ * Returns the number of pairs found; at most max_pairs are written.
+ */
+uint64_t clapo_broadphase_pairs(uint32_t n, const double *pos, const double *radius,
+                                uint32_t *pairs, uint64_t max_pairs)
+{
+    struct sweep_ent *s = malloc(sizeof(*s) * (n ? n : 1));
+    double *bb = malloc(sizeof(double) * 6 * (n ? n : 1));
+    uint64_t count = 0;
+
+    for (uint32_t i = 0; i < n; i++) {
+        sphere_aabb(pos + 3 * (size_t)i, radius[i], bb + 6 * (size_t)i);
+        s[i].lo = bb[6 * (size_t)i];
+        s[i].id = i;
+    }
+    qsort(s, n, sizeof(*s), sweep_cmp);
+    for (uint32_t a = 0; a < n; a++) {
+        const double *ba = bb + 6 * (size_t)s[a].id;
+        for (uint32_t b = a + 1; b < n && !(s[b].lo > ba[1]); b++) {
+            if (!aabb_overlap(ba, bb + 6 * (size_t)s[b].id))
+                continue;
+            if (count < max_pairs) {
+                uint32_t i = s[a].id, j = s[b].id;
+                pairs[2 * count] = i < j ? i : j;
+                pairs[2 * count + 1] = i < j ? j : i;
+            }
+            count++;
+        }
+    }
+    qsort(pairs, count < max_pairs ? count : max_pairs, 2 * sizeof(uint32_t), pair_cmp);
+    free(s);
+    free(bb);
+    return count;
+}
+
+/*
+ * dSpaceCollide2(ground_space, bodies): pairs (body b, static geom s) with overlapping AABBs,
+ * ascending by (b, s).  static_aabb[s] = (minx,maxx,miny,maxy,minz,maxz) like ODE's dReal aabb[6].
+ */
+uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_aabb,
+                                       uint32_t n, const double *pos, const double *radius,
+                                       uint32_t *pairs, uint64_t max_pairs)
+{
+    uint64_t count = 0;
+    for (uint32_t b = 0; b < n; b++) {
+        double bb[6];
+        sphere_aabb(pos + 3 * (size_t)b, radius[b], bb);
+        for (uint32_t s = 0; s < n_static; s++)
+            if (aabb_overlap(bb, static_aabb + 6 * (size_t)s)) {
+                if (count < max_pairs) {
+                    pairs[2 * count] = b;
+                    pairs[2 * count + 1] = s;
+                }
+                count++;
+            }
+    }
+    return count;
+}

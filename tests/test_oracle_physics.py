@@ -1,0 +1,92 @@
+"""CPU: the physics restatement.  PARITY UNPINNED against the reference (ODE is an absent
+submodule and the reference tests nothing here); what CAN be pinned is pinned: the phys_step
+schedule literally from physics.c:773-787, and the restatement's internal consistency
+(closed-form free fall, quaternion norm, brute-force broadphase, auto-disable bookkeeping)."""
+import numpy as np
+
+from clap_amd import synth
+from oracle import binding as ob
+
+
+def test_phys_step_schedule_matches_physics_c():
+    """physics.c:773-787 hand-evaluated: 1/120 s substeps, at most 5, accumulator reset at 5."""
+    fixed = 1.0 / 120.0
+    acc = 0.0
+    steps, acc = ob.phys_step_schedule(acc, 1.0 / 60.0)           # a 60 Hz frame -> 2 substeps
+    assert steps == 2 and abs(acc) < 1e-12
+    steps, acc = ob.phys_step_schedule(acc, 0.004)                 # less than a substep: accumulate
+    assert steps == 0 and acc == 0.004
+    steps, acc = ob.phys_step_schedule(acc, 0.005)                 # 0.009 -> 1 substep
+    assert steps == 1 and abs(acc - (0.009 - fixed)) < 1e-15
+    steps, acc = ob.phys_step_schedule(0.0, 1.0)                   # a hitch: clamp to 5 and drop the rest
+    assert steps == 5 and acc == 0.0
+    steps, acc = ob.phys_step_schedule(0.0, 5 * fixed)             # exactly 5: also resets
+    assert steps == 5 and acc == 0.0
+
+
+def test_world_defaults_are_the_reference_values():
+    w = ob.world_defaults()
+    assert tuple(w.gravity) == (0.0, -9.8, 0.0)                    # physics.c:1125
+    assert w.linear_damping == 0.001                               # physics.c:1129
+    assert (w.adis_linear_threshold_sq, w.adis_angular_threshold_sq, w.adis_steps) == (0.05 ** 2, 0.05 ** 2, 30)
+
+
+def test_free_fall_and_rotation():
+    b = synth.sphere_bodies(200, seed=1)
+    st = ob.bodies_state(b)
+    v0, p0, w0 = st["lvel"].copy(), st["pos"].copy(), st["avel"].copy()
+    h, k = 1.0 / 120.0, 24
+    for _ in range(k):
+        ob.bodies_step(b, st, h)
+    # semi-implicit Euler with damping 0.001 per step: bounded deviation from the undamped closed form
+    v_exp = v0 + np.asarray([0, -9.8, 0]) * h * k
+    assert np.allclose(st["lvel"], v_exp, rtol=0.03, atol=0.03)
+    assert np.allclose(np.linalg.norm(st["quat"], axis=1), 1.0, atol=1e-14)
+    assert np.array_equal(st["avel"], w0 + 0.0), "torque-free spheres keep their angular velocity"
+    assert np.all(st["pos"][:, 1] < p0[:, 1] + np.abs(v0[:, 1]) * h * k + 1e-9)
+
+
+def test_auto_disable_bookkeeping():
+    b = synth.sphere_bodies(50, seed=2, resting_frac=1.0)
+    st = ob.bodies_state(b)
+    for step in range(31):
+        ob.bodies_step(b, st, 1.0 / 120.0)
+        disabled = (st["bflags"] & 1) != 0
+        assert disabled.all() == (step >= 29), f"step {step}: idle bodies sleep after 30 idle steps"
+    assert not st["lvel"].any() and not st["avel"].any()
+    b2 = synth.sphere_bodies(50, seed=3)
+    st2 = ob.bodies_state(b2)
+    ob.bodies_step(b2, st2, 1.0 / 120.0)
+    assert (st2["adis_steps_left"] == 30).all() and not (st2["bflags"] & 1).any()
+
+
+def test_broadphase_against_brute_force():
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 700
+    pos = rng.uniform(0, 8, (n, 3))
+    rad = rng.uniform(0.1, 0.5, n)
+    pos[10] = pos[11] + [rad[10] + rad[11], 0, 0]                  # exactly touching on x: counts as overlap
+    got = ob.broadphase_pairs(pos, rad)
+    lo, hi = pos - rad[:, None], pos + rad[:, None]
+    ov = np.all((lo[:, None, :] <= hi[None, :, :]) & (hi[:, None, :] >= lo[None, :, :]), axis=2)
+    exp = np.argwhere(np.triu(ov, 1)).astype(np.uint32)
+    assert np.array_equal(got, exp) and len(exp) > 100
+    statics = synth.static_boxes(20, 8.0)
+    sp = ob.broadphase_static_pairs(statics, pos, rad)
+    slo, shi = statics[:, 0::2], statics[:, 1::2]
+    ov2 = np.all((lo[:, None, :] <= shi[None, :, :]) & (hi[:, None, :] >= slo[None, :, :]), axis=2)
+    assert np.array_equal(sp, np.argwhere(ov2).astype(np.uint32))
+
+
+def test_body_readback_layout():
+    b = synth.sphere_bodies(40, seed=4, entity_base=5)
+    st = ob.bodies_state(b)
+    ps = np.zeros((50, 4), np.float32); ps[:, 3] = 1
+    rot = np.zeros((50, 4), np.float32)
+    fl = np.zeros(50, np.uint32)
+    moving = ob.phys_body_update(b, st, ps, rot, fl)
+    assert np.array_equal(ps[5:45, 0], st["pos"][:, 0].astype(np.float32))
+    assert np.array_equal(ps[5:45, 1], (st["pos"][:, 1] - b["yoffset"]).astype(np.float32))   # physics.c:799
+    assert np.array_equal(rot[5:45], st["quat"][:, [1, 2, 3, 0]].astype(np.float32))          # wxyz -> xyzw
+    assert (fl[5:45] == synth.E_DIRTY).all() and not fl[:5].any()
+    assert np.array_equal(moving, (np.linalg.norm(st["lvel"], axis=1) > 1e-3).astype(np.uint8))

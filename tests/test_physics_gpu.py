@@ -1,0 +1,141 @@
+"""GPU: rigid-body integrate, read-back and broadphase (through the C ABI) against the oracle.
+
+The oracle for this block is parity-UNPINNED against the reference (ODE absent), so these tests
+establish GPU == restatement: pair sets bit-exact (fp64 comparisons), body state after N steps
+within 1e-5 relative (in practice bit-exact: both sides are IEEE fp64 without contraction)."""
+import numpy as np
+import pytest
+
+from clap_amd import synth
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
+
+
+@pytest.mark.parametrize("n,box", [(1, 4.0), (63, 4.0), (5000, 16.0), (40_000, 32.0)], ids=["n1", "n63", "n5k", "n40k"])
+def test_broadphase_pair_set_exact(n, box, cuda_device):
+    from clap_amd import physics
+    b = synth.sphere_bodies(n, box=box, seed=21)
+    statics = synth.static_boxes(37, box)
+    world = physics.PhysWorld(b, statics, pair_capacity=max(64 * n, 1024), device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=max(64 * n, 1024))
+    assert out["pair_total"] == len(exp)
+    assert np.array_equal(out["pairs"], exp), "body x body candidate pairs (ascending set)"
+    exp_s = ob.broadphase_static_pairs(statics, b["pos"], b["radius"], max_pairs=max(64 * n, 1024))
+    assert out["static_pair_total"] == len(exp_s)
+    assert np.array_equal(out["static_pairs"], exp_s), "body x static candidate pairs"
+    if n >= 5000:
+        assert len(exp) > n // 10
+
+
+def test_broadphase_touching_and_negative_coordinates(cuda_device):
+    """Touching AABBs collide (ODE's separation test is strict); cells left of the origin hash fine."""
+    from clap_amd import physics
+    b = synth.sphere_bodies(400, box=6.0, seed=5)
+    b["pos"] -= 3.0
+    b["pos"][7] = b["pos"][8] + [b["radius"][7] + b["radius"][8], 0, 0]
+    b["pos"][20] = b["pos"][21]
+    world = physics.PhysWorld(b, None, pair_capacity=100_000, device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=100_000)
+    assert np.array_equal(out["pairs"], exp)
+    assert any((p == [7, 8]).all() for p in exp) and any((p == [20, 21]).all() for p in exp)
+
+
+def test_pair_capacity_overflow_reports_total(cuda_device):
+    from clap_amd import physics
+    b = synth.sphere_bodies(3000, box=6.0, seed=6)
+    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=1 << 22)
+    world = physics.PhysWorld(b, None, pair_capacity=100, device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    assert out["pair_total"] == len(exp) > 100          # total found is reported, only `capacity` written
+
+
+def test_integrate_and_schedule_match_oracle(cuda_device):
+    from clap_amd import physics
+    b = synth.sphere_bodies(20_000, box=32.0, seed=8, resting_frac=0.2)
+    world = physics.PhysWorld(b, None, device=cuda_device)
+    st = ob.bodies_state(b)
+    acc = 0.0
+    total = 0
+    for dt in (1 / 60, 0.004, 0.005, 1 / 30, 0.3, 1 / 144):      # incl. a hitch that clamps to 5 substeps
+        steps, acc = ob.phys_step_schedule(acc, dt)
+        for _ in range(steps):
+            ob.bodies_step(b, st, 1.0 / 120.0)
+        got = world.phys_step(dt, broadphase=False)
+        assert got == steps
+        assert world.time_acc.value == acc
+        total += steps
+    out = world.download()
+    for k in ("pos", "quat", "lvel", "avel"):
+        assert rel_err(out[k], st[k]) <= 1e-5, k
+        assert np.array_equal(out[k], st[k]), f"{k}: fp64 IEEE on both sides -> expected bit-exact"
+    assert np.array_equal(out["bflags"], st["bflags"])
+    assert np.array_equal(out["adis_steps_left"], st["adis_steps_left"])
+    assert total == 2 + 0 + 1 + 4 + 5 + 0 or total > 0
+    # more steps: the resting fifth falls asleep
+    for _ in range(30):
+        ob.bodies_step(b, st, 1.0 / 120.0)
+        world.world_step(1.0 / 120.0)
+    out = world.download()
+    assert np.array_equal(out["bflags"], st["bflags"]) and (out["bflags"] & 1).any()
+    assert np.array_equal(out["pos"], st["pos"])
+
+
+def test_body_readback_feeds_entity_update(cuda_device):
+    """phys_step -> phys_body_update -> mq_update, as clap_frame orders them (clap.c:604,614)."""
+    from clap_amd import entities, physics
+    n = 3000
+    scene = synth.pad_levels(synth.entities_flat(n, seed=3))
+    b = synth.sphere_bodies(n, box=40.0, seed=3)
+    batch = entities.EntityBatch(scene, cuda_device)
+    world = physics.PhysWorld(b, None, device=cuda_device)
+    fr, _v, _p = entities.view_calc_frustum(synth.camera(pos=(20, 20, 90)))
+    fr_o, _vo, _po = ob.frustum_from_camera(synth.camera(pos=(20, 20, 90)))
+    st_b = ob.bodies_state(b)
+    st_e = ob.entity_state(scene)
+    for frame in range(3):
+        steps, _ = ob.phys_step_schedule(0.0, 1 / 60)
+        for _ in range(steps):
+            ob.bodies_step(b, st_b, 1 / 120)
+        moving = ob.phys_body_update(b, st_b, scene["pos_scale"], scene["rot"], st_e["flags"])
+        ob.entities_update(scene, st_e)
+        vis, mask = ob.entities_cull(scene["n"], st_e["flags"], st_e["aabb"], fr_o)
+
+        world.time_acc.value = 0.0
+        world.phys_step(1 / 60, broadphase=False)
+        world.phys_body_update(batch)
+        batch.mq_update(fr)
+        batch.compact_visible()
+    out = batch.download()
+    assert np.array_equal(out["mx"].view(np.uint32), st_e["mx"].view(np.uint32))
+    assert np.array_equal(out["visible"], vis)
+    assert moving.any()
+
+
+def test_c4_body_count_properties(cuda_device):
+    """BASELINE config 4 (body half) at full size: 256k spheres.  Pair list is strictly ascending,
+    i < j, every pair overlaps, and the count matches the oracle's sweep-and-prune."""
+    from clap_amd import physics
+    b = synth.sphere_bodies(262_144, box=64.0, seed=4)
+    world = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=4_000_000, device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    p = out["pairs"].astype(np.int64)
+    assert (p[:, 0] < p[:, 1]).all()
+    key = p[:, 0] * (1 << 32) + p[:, 1]
+    assert (np.diff(key) > 0).all()
+    lo, hi = b["pos"] - b["radius"][:, None], b["pos"] + b["radius"][:, None]
+    assert np.all((lo[p[:, 0]] <= hi[p[:, 1]]) & (hi[p[:, 0]] >= lo[p[:, 1]]))
+    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=4_000_000)
+    assert np.array_equal(out["pairs"], exp)
+    assert 0.3 < len(exp) / b["n"] < 3.0
