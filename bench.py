@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--layout", choices=["tiles", "levels"], default="tiles",
                     help="tiles: subtree tiles, one launch for all levels; levels: level-major, one launch per level")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary workloads (pose/skinning, particles, bodies) reported under 'extra'")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -69,6 +71,82 @@ def cpu_baseline(scene, cam, frames):
                        "restatement (gcc -O2 -ffp-contract=off), 1 thread")
 
 
+def time_launches(fn, iters, warmup=3):
+    """Mean duration (s) of fn() measured with HIP events on torch's current stream."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+
+
+def roof(alg_bytes, seconds):
+    gbs = alg_bytes / seconds / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": seconds * 1e6}
+
+
+def extras(device):
+    """The other rows of the hot path at BASELINE configs[2] and configs[3] sizes, each as
+    units/s plus the algorithmic-bytes roofline of its kernel (SURVEY.md 8d byte counts)."""
+    import torch
+    from clap_amd import animation, particles, physics, synth
+    from oracle import binding as ob          # cpu side only: bind = invert(invmx) and the initial spawn
+    out = {}
+
+    # ---- configs[2]: 50k characters x 64 joints, 10M vertices (one 200-vertex mesh per character) ----
+    J, n_chars, vpc = 64, 50_000, 200
+    sk = synth.skeleton(J, 8, seed=3)
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n_chars, J, seed=3)
+    mesh = synth.skinned_mesh(vpc, J, seed=3, copies=n_chars)          # distinct vertices per character
+    vf = (np.arange(n_chars, dtype=np.int64) * vpc).astype(np.uint32)
+    vc = np.full(n_chars, vpc, np.uint32)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, device=device)
+    cb = animation.CharacterBatch(model, n_chars, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
+    cb.set_frame_times(ch["phase"])
+    t_pose = time_launches(cb.pose_update, 20)
+    t_skin = time_launches(cb.skin, 20)
+    out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
+                           "kernel": "k_pose<64>", "roofline": roof(cb.pose_algorithmic_bytes(), t_pose)}
+    out["skinning"] = {"skinned_verts_per_s": n_chars * vpc / t_skin, "vertices": n_chars * vpc,
+                       "kernel": "k_skin", "roofline": roof(cb.skin_algorithmic_bytes(), t_skin),
+                       "mesh": "one distinct 200-vertex mesh per character (44 B/vertex read from HBM); instanced "
+                               "meshes read less"}
+    out["pose_plus_skinning_verts_per_s"] = n_chars * vpc / (t_pose + t_skin)
+    del cb, model, mesh
+    torch.cuda.empty_cache()
+
+    # ---- configs[3], particle half: 4096 systems x 1024 particles ----
+    ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
+    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pb = particles.ParticleBatch(ps, pos, vel, st, device)
+    view = np.eye(4, dtype=np.float32).ravel()
+    t_part = time_launches(lambda: pb.particles_update(view), 30)
+    out["particles"] = {"particles_per_s": pb.n_real / t_part, "particles": pb.n_real,
+                        "kernels": "k_particles_advect + k_visible_expand_rp + k_particles_respawn",
+                        "roofline": roof(pb.algorithmic_bytes(), t_part)}
+    del pb
+    # ---- configs[3], body half: 256k sphere bodies: integrate + both broadphase passes ----
+    b = synth.sphere_bodies(262_144, box=64.0, seed=4)
+    pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=device)
+    t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 30)
+    t_bp = time_launches(pw.broadphase, 10)
+    npairs = int(pw.pair_total.item())
+    out["bodies"] = {"bodies_per_s_integrate": pw.n / t_int, "bodies": pw.n, "kernel": "k_bodies_step",
+                     "roofline": roof(pw.integrate_algorithmic_bytes(), t_int),
+                     "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
+                                    "algorithmic_bytes": 24 * pw.n + 8 * npairs,
+                                    "note": "11 launches (hash build, two counted scans, emit); latency- not HBM-bound"}}
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per k_entities_level launch from the committed PMC summary, if one exists."""
     path = os.path.join(ROOT, "profiles", f"{ROUND}_entities_pmc.json")   # written by tools/pmc_summary.py
@@ -83,7 +161,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from clap_amd import _lib, entities, synth, tiler
+    from clap_amd import _lib, entities, shard, synth, tiler
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,11 +190,8 @@ def main():
         batch.mq_update(fr, all_dirty=True)             # one launch per hierarchy level
         batch.compact_visible(index_base)               # ordered visible list (global ids)
         if world > 1:
-            # the path's only exchange: every rank ends with all shards' visible ids.
-            dist.all_gather_into_tensor(counts, batch.visible_count)
-            cap = (int(counts.max().item()) + 4095) // 4096 * 4096
-            cap = min(max(cap, 4096), n_pad)
-            dist.all_gather_into_tensor(gather_buf[:world * cap], batch.visible[:cap])
+            # the path's only exchange: every rank ends with all shards' visible ids (RCCL allgather)
+            shard.allgather_visible(batch.visible, batch.visible_count, world, counts, gather_buf)
 
     def fence():
         if world > 1:
@@ -182,6 +257,10 @@ def main():
                          "mean_launch_us": mean_launch_s * 1e6,
                          "per_launch_us": [float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]},
         }
+        if world == 1 and not args.no_extras:
+            del batch
+            torch.cuda.empty_cache()
+            out["extra"] = extras(device)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,46 @@
+"""Multi-GPU sharding of the scene update: one process per GPU, contiguous tile ranges.
+
+The path shards by entity range with whole subtrees inside one shard, so the update itself
+needs no collective.  The single exchange is the allgather of each shard's compacted visible
+list (global entity ids): afterwards every rank holds the identical ascending visible set.
+``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code runs under "gloo" on CPU
+tensors (tests/test_shard_cpu.py, world_size 2).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_tile_ranges(rows_per_tile, world):
+    """Split tiles into `world` contiguous ranges of (nearly) equal row count.
+    rows_per_tile: rows of each tile (tile_row_start differences).  Returns [(t0, t1)] per rank."""
+    rows = np.asarray(rows_per_tile, np.int64)
+    cum = np.concatenate([[0], np.cumsum(rows)])
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, len(rows)
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
+def allgather_visible(visible, count, world, counts_buf=None, gather_buf=None, pad_to=4096, group=None):
+    """visible: this rank's ascending global ids (capacity >= its count), count: 1-element tensor.
+    Returns (counts[world] on device, gathered[world, cap] tensor); rank r's ids are
+    gathered[r, :counts[r]].  One small and one payload allgather; the payload is padded to the
+    largest count (RCCL has no allgatherv), rounded up to `pad_to`."""
+    if counts_buf is None:
+        counts_buf = torch.empty(world, dtype=count.dtype, device=count.device)
+    dist.all_gather_into_tensor(counts_buf, count, group=group)
+    cap = int(counts_buf.max().item())
+    cap = max((cap + pad_to - 1) // pad_to * pad_to, pad_to)
+    cap = min(cap, visible.shape[0])
+    if gather_buf is None or gather_buf.numel() < world * cap:
+        gather_buf = torch.empty(world * cap, dtype=visible.dtype, device=visible.device)
+    out = gather_buf[:world * cap]
+    dist.all_gather_into_tensor(out, visible[:cap].contiguous(), group=group)
+    return counts_buf, out.view(world, cap)
+
+
+def concat_visible(counts, gathered):
+    """The global visible set as one ascending 1-D tensor (shards are ascending id ranges)."""
+    c = counts.tolist()
+    return torch.cat([gathered[r, :c[r]] for r in range(len(c))])

@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py / clap_amd.shard -- range sharding by
+whole tiles and the allgather of the compacted visible set -- using the oracle as the per-rank
+"device".  (The HIP kernels themselves are covered single-GPU; the exchange is what N > 1 adds.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from clap_amd import shard, synth, tiler
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as ob
+        # one global scene, tiled; each rank updates its contiguous tile range only
+        scene, tl = tiler.tiled_scene(synth.entities_forest(6000, seed=31))
+        trs = scene["tile_row_start"].astype(np.int64)
+        t0, t1 = shard.shard_tile_ranges(np.diff(trs), world)[rank]
+        lo, hi = int(trs[t0]) * 64, int(trs[t1]) * 64
+        cam = synth.camera(pos=(0, 5, 60))
+        fr, _v, _p = ob.frustum_from_camera(cam)
+        sub = {k: (scene[k][lo:hi].copy() if isinstance(scene[k], np.ndarray) and scene[k].shape[:1] == (scene["n"],)
+                   else scene[k]) for k in scene}
+        sub["n"] = hi - lo
+        sub["parent"] = np.where(sub["parent"] >= 0, sub["parent"] - lo, -1).astype(np.int32)
+        assert sub["parent"].max(initial=-1) < sub["n"] and np.all(sub["parent"][sub["parent"] >= 0] >= 0), \
+            "a subtree crosses a shard border"
+        st = ob.entity_state(sub)
+        ob.entities_update(sub, st)
+        vis, _mask = ob.entities_cull(sub["n"], st["flags"], st["aabb"], fr)
+        vis_global = torch.zeros(max(sub["n"], 1), dtype=torch.int32)
+        vis_global[:len(vis)] = torch.from_numpy((vis.astype(np.int64) + lo).astype(np.int32))
+        counts, gathered = shard.allgather_visible(vis_global, torch.tensor([len(vis)], dtype=torch.int32), world,
+                                                   pad_to=64)
+        full = shard.concat_visible(counts, gathered).numpy()
+        # single-process answer
+        st_all = ob.entity_state(scene)
+        ob.entities_update(scene, st_all)
+        vis_all, _m = ob.entities_cull(scene["n"], st_all["flags"], st_all["aabb"], fr)
+        ok = np.array_equal(full.astype(np.uint32), vis_all) and bool(np.all(np.diff(full) > 0))
+        q.put((rank, ok, int(counts.sum()), len(vis_all), (t0, t1)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_and_visible_allgather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, total, expected, rng in sorted(res):
+        assert ok, f"rank {rank}: gathered visible set differs from the single-process result"
+        assert total == expected and expected > 0
+    assert sorted(r[4] for r in res)[0][0] == 0
+
+
+def test_shard_tile_ranges_cover_and_balance():
+    rows = np.asarray([8] * 100 + [1] * 37 + [3] * 11)
+    for world in (1, 2, 3, 4, 8):
+        rngs = shard.shard_tile_ranges(rows, world)
+        assert rngs[0][0] == 0 and rngs[-1][1] == len(rows)
+        assert all(a[1] == b[0] for a, b in zip(rngs, rngs[1:]))
+        loads = [int(rows[a:b].sum()) for a, b in rngs]
+        assert max(loads) - min(loads) <= 16
