@@ -1,0 +1,493 @@
+/*
+ * clapgpu_scene.c -- C host mirror of a CLAP model queue over libclapgpu (see
+ * include/clapgpu_scene.h).  Plain C11; owns the handle table, the tile layout
+ * (C counterpart of clap_amd/tiler.py), the host staging arrays and the device SoA.
+ *
+ * Reference structures mirrored: struct mq / model3dtx / entity3d lists (model.h:334,222,377),
+ * transform_t (transform.h:8-12), entity3d.parent / seq / parent_seq (model.h:402-405),
+ * entity3d_flags (model.h:293-312).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "clapgpu_scene.h"
+
+#define WAVE 64u
+
+struct ent {
+    float    pos_scale[4];
+    float    rot[4];
+    uint32_t flags;          /* entity3d_flags bits, no DIRTY */
+    uint32_t parent;         /* handle or CLAPGPU_NO_ENTITY */
+    uint32_t model;
+    uint32_t slot;
+    void    *user;
+    uint8_t  live, dirty;
+};
+
+struct clapgpu_scene {
+    struct ent *e;  uint32_t n_handles, cap_handles;
+    uint32_t   *free_list;  uint32_t n_free;
+    uint32_t   *dirty_list; uint32_t n_dirty, cap_dirty;
+    float      *models;     uint32_t n_models, cap_models;       /* [m][8] model_table rows */
+    int         topology_dirty, models_dirty, tiled;
+
+    /* layout */
+    uint32_t    n_slots, n_rows, n_tiles, n_levels;
+    uint32_t   *slot_handle;                                     /* slot -> handle or NO_ENTITY */
+    uint32_t   *tile_row_start_host, *level_start_host;
+
+    /* host staging (slot order) */
+    float      *h_pos_scale, *h_rot, *h_mx, *h_inv, *h_aabb, *h_center;
+    int32_t    *h_parent, *h_model;
+    uint32_t   *h_flags;
+    uint64_t   *h_mask;
+    uint32_t    cap_slots;
+
+    /* device */
+    clapgpu_entities d;
+    uint32_t   *d_tile_row_start;
+    float      *d_models; uint32_t d_models_cap;
+    int         have_results;
+};
+
+#define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static struct ent *get(const clapgpu_scene *s, uint32_t h)
+{
+    return (s && h < s->n_handles && s->e[h].live) ? &s->e[h] : NULL;
+}
+
+/* dirty bit 0: queued for upload; bit 1: xform.updated (transform_set_updated, transform.c:21-24) */
+static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
+{
+    if (!s->e[h].dirty) {
+        if (s->n_dirty == s->cap_dirty) {
+            s->cap_dirty = s->cap_dirty ? 2 * s->cap_dirty : 1024;
+            s->dirty_list = realloc(s->dirty_list, s->cap_dirty * sizeof(uint32_t));
+        }
+        s->dirty_list[s->n_dirty++] = h;
+    }
+    s->e[h].dirty |= xform_updated ? 3 : 1;
+}
+
+int clapgpu_scene_create(clapgpu_scene **out, int device)
+{
+    if (!out) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CK(clapgpu_init(device));
+    clapgpu_scene *s = calloc(1, sizeof(*s));
+    if (!s) return CLAPGPU_ERR_NOMEM;
+    s->topology_dirty = 1;
+    *out = s;
+    return CLAPGPU_OK;
+}
+
+static void free_device(clapgpu_scene *s)
+{
+    void *p[] = { (void *)s->d.pos_scale, (void *)s->d.rot, (void *)s->d.parent, (void *)s->d.model, s->d.flags,
+                  s->d.seqs, s->d.mx, s->d.inv_mx, s->d.aabb, s->d.center, s->d.vis_mask, s->d.vis_row_pop,
+                  s->d_tile_row_start };
+    for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++)
+        if (p[i]) clapgpu_free(p[i]);
+    memset(&s->d, 0, sizeof(s->d));
+    s->d_tile_row_start = NULL;
+}
+
+void clapgpu_scene_destroy(clapgpu_scene *s)
+{
+    if (!s) return;
+    free_device(s);
+    if (s->d_models) clapgpu_free(s->d_models);
+    free(s->e); free(s->free_list); free(s->dirty_list); free(s->models); free(s->slot_handle);
+    free(s->tile_row_start_host); free(s->level_start_host);
+    free(s->h_pos_scale); free(s->h_rot); free(s->h_mx); free(s->h_inv); free(s->h_aabb); free(s->h_center);
+    free(s->h_parent); free(s->h_model); free(s->h_flags); free(s->h_mask);
+    free(s);
+}
+
+int clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aabb, uint32_t *model)
+{
+    if (!s || !aabb || !model) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (s->n_models == s->cap_models) {
+        s->cap_models = s->cap_models ? 2 * s->cap_models : 16;
+        s->models = realloc(s->models, (size_t)s->cap_models * 8 * sizeof(float));
+        if (!s->models) return CLAPGPU_ERR_NOMEM;
+    }
+    float *row = s->models + 8 * (size_t)s->n_models;
+    uint32_t skip = skip_aabb ? 1u : 0u;
+    row[0] = aabb[0]; row[1] = aabb[1]; row[2] = aabb[2];
+    memcpy(&row[3], &skip, 4);
+    row[4] = aabb[3]; row[5] = aabb[4]; row[6] = aabb[5]; row[7] = 0.f;
+    *model = s->n_models++;
+    s->models_dirty = 1;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle)
+{
+    if (!s || !handle || model >= s->n_models) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    uint32_t h;
+    if (s->n_free) {
+        h = s->free_list[--s->n_free];
+    } else {
+        if (s->n_handles == s->cap_handles) {
+            s->cap_handles = s->cap_handles ? 2 * s->cap_handles : 1024;
+            s->e = realloc(s->e, (size_t)s->cap_handles * sizeof(struct ent));
+            if (!s->e) return CLAPGPU_ERR_NOMEM;
+        }
+        h = s->n_handles++;
+    }
+    struct ent *e = &s->e[h];
+    memset(e, 0, sizeof(*e));
+    e->pos_scale[3] = 1.f;                              /* model.c:1738 scale = 1 */
+    e->rot[3] = 1.f;                                    /* transform_init: identity quat */
+    e->flags = CLAPGPU_E_ALIVE | CLAPGPU_E_VISIBLE;
+    e->parent = CLAPGPU_NO_ENTITY;
+    e->model = model;
+    e->user = user;
+    e->live = 1;
+    s->topology_dirty = 1;
+    *handle = h;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    for (uint32_t h = 0; h < s->n_handles; h++)         /* orphans become roots, like a NULL e->parent */
+        if (s->e[h].live && s->e[h].parent == handle)
+            s->e[h].parent = CLAPGPU_NO_ENTITY;
+    e->live = 0;
+    s->free_list = realloc(s->free_list, ((size_t)s->n_free + 1) * sizeof(uint32_t));
+    s->free_list[s->n_free++] = handle;
+    s->topology_dirty = 1;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t parent)
+{
+    struct ent *e = get(s, handle);
+    if (!e || (parent != CLAPGPU_NO_ENTITY && (!get(s, parent) || parent == handle)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->parent != parent) {
+        e->parent = parent;
+        s->topology_dirty = 1;
+    }
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_position(clapgpu_scene *s, uint32_t handle, const float pos[3])
+{
+    struct ent *e = get(s, handle);
+    if (!e || !pos) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    memcpy(e->pos_scale, pos, 12);
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float q[4])
+{
+    struct ent *e = get(s, handle);
+    if (!e || !q) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    memcpy(e->rot, q, 16);
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    e->pos_scale[3] = scale;
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set, uint32_t clear)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    e->flags = ((e->flags | set) & ~clear) & ~CLAPGPU_E_DIRTY;
+    mark_dirty(s, handle, 0);                           /* flags upload only: entity3d_visible() does not touch xform */
+    return CLAPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- layout */
+static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
+{
+    if (n_slots <= s->cap_slots) return CLAPGPU_OK;
+    uint32_t cap = s->cap_slots ? s->cap_slots : 4096;
+    while (cap < n_slots) cap *= 2;
+    size_t n = cap;
+#define RE(p, bytes) do { void *q__ = realloc(p, bytes); if (!q__) return CLAPGPU_ERR_NOMEM; p = q__; } while (0)
+    RE(s->h_pos_scale, n * 16); RE(s->h_rot, n * 16); RE(s->h_mx, n * 64); RE(s->h_inv, n * 64);
+    RE(s->h_aabb, n * 24); RE(s->h_center, n * 12); RE(s->h_parent, n * 4); RE(s->h_model, n * 4);
+    RE(s->h_flags, n * 4); RE(s->h_mask, (n / 64 + 1) * 8); RE(s->slot_handle, n * 4);
+#undef RE
+    free_device(s);
+    s->models_dirty = 1;                                /* free_device() dropped d.model_table */
+    void **dp[] = { (void **)&s->d.pos_scale, (void **)&s->d.rot, (void **)&s->d.parent, (void **)&s->d.model,
+                    (void **)&s->d.flags, (void **)&s->d.seqs, (void **)&s->d.mx, (void **)&s->d.inv_mx,
+                    (void **)&s->d.aabb, (void **)&s->d.center, (void **)&s->d.vis_mask, (void **)&s->d.vis_row_pop,
+                    (void **)&s->d_tile_row_start };
+    size_t sz[] = { n * 16, n * 16, n * 4, n * 4, n * 4, n * 4, n * 64, n * 64, n * 24, n * 12,
+                    (n / 64 + 1) * 8, (n / 64 + 16) / 16 * 16, (n / 64 + 2) * 4 };
+    for (unsigned i = 0; i < sizeof(dp) / sizeof(dp[0]); i++)
+        CK(clapgpu_malloc(dp[i], sz[i]));
+    s->cap_slots = cap;
+    return CLAPGPU_OK;
+}
+
+/* depth of every live entity under its root; returns max depth + 1, or 0 on a parent cycle */
+static uint32_t compute_depths(clapgpu_scene *s, uint32_t *depth, uint32_t *root)
+{
+    const uint32_t UNK = 0xffffffffu;
+    uint32_t maxd = 0;
+    for (uint32_t h = 0; h < s->n_handles; h++) depth[h] = UNK;
+    for (uint32_t h = 0; h < s->n_handles; h++) {
+        if (!s->e[h].live || depth[h] != UNK) continue;
+        uint32_t cur = h, steps = 0;                    /* walk up to a known ancestor */
+        while (s->e[cur].parent != CLAPGPU_NO_ENTITY && depth[s->e[cur].parent] == UNK) {
+            cur = s->e[cur].parent;
+            if (++steps > s->n_handles) return 0;
+        }
+        uint32_t base_d, base_r;
+        if (s->e[cur].parent == CLAPGPU_NO_ENTITY) { base_d = 0; base_r = cur; }
+        else { base_d = depth[s->e[cur].parent] + 1; base_r = root[s->e[cur].parent]; }
+        /* second walk: assign from h upward needs distances; count chain length first */
+        uint32_t len = 0;
+        for (uint32_t x = h; x != cur; x = s->e[x].parent) len++;
+        uint32_t x = h;
+        for (uint32_t k = 0; k <= len; k++) {
+            depth[x] = base_d + (len - k);
+            root[x] = base_r;
+            if (depth[x] + 1 > maxd) maxd = depth[x] + 1;
+            x = s->e[x].parent;
+        }
+    }
+    return maxd ? maxd : 1;
+}
+
+static int retile(clapgpu_scene *s)
+{
+    const uint32_t H = s->n_handles;
+    uint32_t *depth = malloc(((size_t)H + 1) * 4), *root = malloc(((size_t)H + 1) * 4);
+    uint32_t *tree_of = malloc(((size_t)H + 1) * 4);
+    if (!depth || !root || !tree_of) return CLAPGPU_ERR_NOMEM;
+    uint32_t maxd = compute_depths(s, depth, root);
+    if (!maxd) { free(depth); free(root); free(tree_of); return CLAPGPU_ERR_INVALID_ARGUMENTS; }
+
+    uint32_t n_trees = 0, n_live = 0;
+    for (uint32_t h = 0; h < H; h++)
+        if (s->e[h].live) { n_live++; if (s->e[h].parent == CLAPGPU_NO_ENTITY) tree_of[h] = n_trees++; }
+    uint32_t *width = calloc((size_t)(n_trees ? n_trees : 1) * maxd, 4);
+    if (!width) return CLAPGPU_ERR_NOMEM;
+    int tiled = 1;
+    for (uint32_t h = 0; h < H; h++)
+        if (s->e[h].live) {
+            uint32_t t = tree_of[root[h]];
+            if (++width[(size_t)t * maxd + depth[h]] > WAVE) tiled = 0;
+        }
+
+    uint32_t n_rows = 0;
+    uint32_t *row_of_tree = malloc(((size_t)n_trees + 1) * 4);       /* first row of the tree's tile */
+    uint32_t *row_fill = NULL;
+    free(s->tile_row_start_host);
+    free(s->level_start_host);
+    s->tile_row_start_host = malloc(((size_t)n_trees + 2) * 4);      /* at most one tile per tree */
+    s->level_start_host = malloc(((size_t)maxd + 2) * 4);
+    if (!row_of_tree || !s->tile_row_start_host || !s->level_start_host) return CLAPGPU_ERR_NOMEM;
+    if (tiled) {
+        /* next-fit packing of whole trees: every level of a tile holds <= 64 entities */
+        uint32_t *fill = calloc(maxd, 4);
+        uint32_t tile_first_row = 0, tile_rows = 0;
+        s->n_tiles = 0;
+        for (uint32_t t = 0; t < n_trees; t++) {
+            const uint32_t *w = width + (size_t)t * maxd;
+            int fits = 1;
+            uint32_t rows = 0;
+            for (uint32_t d = 0; d < maxd; d++) { if (fill[d] + w[d] > WAVE) fits = 0; if (w[d]) rows = d + 1; }
+            if (!fits) {                                            /* close the tile */
+                s->tile_row_start_host[s->n_tiles++] = tile_first_row;
+                tile_first_row += tile_rows;
+                tile_rows = 0;
+                memset(fill, 0, maxd * 4);
+            }
+            for (uint32_t d = 0; d < maxd; d++) fill[d] += w[d];
+            if (rows > tile_rows) tile_rows = rows;
+            row_of_tree[t] = tile_first_row;
+        }
+        if (n_trees) { s->tile_row_start_host[s->n_tiles++] = tile_first_row; tile_first_row += tile_rows; }
+        s->tile_row_start_host[s->n_tiles] = tile_first_row;
+        n_rows = tile_first_row;
+        free(fill);
+    } else {
+        /* level-major: level d = rows [level_row[d], level_row[d+1]) */
+        uint32_t *cnt = calloc(maxd, 4);
+        for (uint32_t h = 0; h < H; h++) if (s->e[h].live) cnt[depth[h]]++;
+        s->n_levels = maxd;
+        uint32_t r = 0;
+        for (uint32_t d = 0; d < maxd; d++) { s->level_start_host[d] = r * WAVE; r += (cnt[d] + WAVE - 1) / WAVE; }
+        s->level_start_host[maxd] = r * WAVE;
+        n_rows = r;
+        free(cnt);
+    }
+    if (n_rows == 0) n_rows = 1;
+    int rc = ensure_slots(s, n_rows * WAVE);
+    if (rc) return rc;
+    s->n_rows = n_rows;
+    s->n_slots = n_rows * WAVE;
+    s->tiled = tiled;
+    if (!tiled) s->level_start_host[s->n_levels] = s->n_slots;      /* the kernel wants the last start == n */
+
+    /* slots: handle order inside each row */
+    row_fill = calloc(n_rows, 4);
+    for (uint32_t i = 0; i < s->n_slots; i++) s->slot_handle[i] = CLAPGPU_NO_ENTITY;
+    for (uint32_t h = 0; h < H; h++) {
+        if (!s->e[h].live) continue;
+        uint32_t row;
+        if (tiled) {
+            row = row_of_tree[tree_of[root[h]]] + depth[h];
+            s->e[h].slot = row * WAVE + row_fill[row]++;
+        } else {
+            uint32_t base = s->level_start_host[depth[h]] / WAVE;
+            uint32_t k = row_fill[base]++;                           /* counter kept in the level's first row */
+            s->e[h].slot = s->level_start_host[depth[h]] + k;
+        }
+        s->slot_handle[s->e[h].slot] = h;
+    }
+    /* full staging image */
+    for (uint32_t i = 0; i < s->n_slots; i++) {
+        const uint32_t h = s->slot_handle[i];
+        if (h == CLAPGPU_NO_ENTITY) {
+            const float id[4] = { 0, 0, 0, 1 };
+            memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
+            memcpy(s->h_rot + 4 * (size_t)i, id, 16);
+            s->h_parent[i] = -1; s->h_model[i] = 0; s->h_flags[i] = 0;
+            continue;
+        }
+        const struct ent *e = &s->e[h];
+        memcpy(s->h_pos_scale + 4 * (size_t)i, e->pos_scale, 16);
+        memcpy(s->h_rot + 4 * (size_t)i, e->rot, 16);
+        s->h_parent[i] = e->parent == CLAPGPU_NO_ENTITY ? -1 : (int32_t)s->e[e->parent].slot;
+        s->h_model[i] = (int32_t)e->model;
+        s->h_flags[i] = e->flags | CLAPGPU_E_DIRTY;                  /* everything is rebuilt after a re-tile */
+    }
+    free(depth); free(root); free(tree_of); free(width); free(row_of_tree); free(row_fill);
+
+    s->d.n = s->n_slots;
+    const size_t n = s->n_slots;
+    CK(clapgpu_memcpy_h2d((void *)s->d.parent, s->h_parent, n * 4, NULL));
+    CK(clapgpu_memcpy_h2d((void *)s->d.model, s->h_model, n * 4, NULL));
+    CK(clapgpu_memset(s->d.seqs, 0, n * 4, NULL));
+    CK(clapgpu_memset(s->d.aabb, 0, n * 24, NULL));
+    CK(clapgpu_memset(s->d.mx, 0, n * 64, NULL));
+    CK(clapgpu_memset(s->d.inv_mx, 0, n * 64, NULL));
+    CK(clapgpu_memset(s->d.center, 0, n * 12, NULL));
+    if (tiled)
+        CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
+    for (uint32_t k = 0; k < s->n_dirty; k++) s->e[s->dirty_list[k]].dirty = 0;
+    s->n_dirty = 0;
+    s->topology_dirty = 0;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
+{
+    if (!s) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    int upload = 0;
+    if (s->topology_dirty) {
+        CK(retile(s));
+        upload = 1;
+    } else if (s->n_dirty) {
+        for (uint32_t k = 0; k < s->n_dirty; k++) {      /* transform_set_* since the last frame */
+            struct ent *e = &s->e[s->dirty_list[k]];
+            const int xform = e->dirty & 2;
+            e->dirty = 0;
+            if (!e->live) continue;
+            memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
+            memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
+            s->h_flags[e->slot] = e->flags | (xform ? CLAPGPU_E_DIRTY : 0);
+        }
+        s->n_dirty = 0;
+        upload = 1;
+    }
+    if (s->models_dirty) {
+        if (s->n_models > s->d_models_cap) {
+            if (s->d_models) clapgpu_free(s->d_models);
+            s->d_models_cap = s->n_models * 2;
+            CK(clapgpu_malloc((void **)&s->d_models, (size_t)s->d_models_cap * 32));
+        }
+        CK(clapgpu_memcpy_h2d(s->d_models, s->models, (size_t)s->n_models * 32, NULL));
+        s->d.model_table = s->d_models;
+        s->d.n_models = s->n_models;
+        s->models_dirty = 0;
+    }
+    if (s->n_models == 0) return CLAPGPU_OK;
+    const size_t n = s->n_slots;
+    if (upload) {
+        CK(clapgpu_memcpy_h2d((void *)s->d.pos_scale, s->h_pos_scale, n * 16, NULL));
+        CK(clapgpu_memcpy_h2d((void *)s->d.rot, s->h_rot, n * 16, NULL));
+        CK(clapgpu_memcpy_h2d(s->d.flags, s->h_flags, n * 4, NULL));
+    }
+    if (s->tiled)
+        CK(clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum));
+    else
+        CK(clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, frustum));
+    CK(clapgpu_memcpy_d2h(s->h_mx, s->d.mx, n * 64, NULL));
+    CK(clapgpu_memcpy_d2h(s->h_inv, s->d.inv_mx, n * 64, NULL));
+    CK(clapgpu_memcpy_d2h(s->h_aabb, s->d.aabb, n * 24, NULL));
+    CK(clapgpu_memcpy_d2h(s->h_center, s->d.center, n * 12, NULL));
+    if (frustum)
+        CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (n / 64) * 8, NULL));
+    else
+        memset(s->h_mask, 0, (n / 64) * 8);
+    CK(clapgpu_stream_sync(NULL));
+    if (upload)
+        for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */
+    s->have_results = 1;
+    return CLAPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- results */
+#define RESULT(field, stride)                                                        \
+    const struct ent *e = get(s, handle);                                            \
+    return (e && s->have_results && e->slot < s->n_slots) ? s->field + (stride) * (size_t)e->slot : NULL
+
+const float *clapgpu_scene_entity_mx(const clapgpu_scene *s, uint32_t handle)          { RESULT(h_mx, 16); }
+const float *clapgpu_scene_entity_inverse_mx(const clapgpu_scene *s, uint32_t handle)  { RESULT(h_inv, 16); }
+const float *clapgpu_scene_entity_aabb(const clapgpu_scene *s, uint32_t handle)        { RESULT(h_aabb, 6); }
+const float *clapgpu_scene_entity_aabb_center(const clapgpu_scene *s, uint32_t handle) { RESULT(h_center, 3); }
+
+int clapgpu_scene_entity_in_frustum(const clapgpu_scene *s, uint32_t handle)
+{
+    const struct ent *e = get(s, handle);
+    if (!e || !s->have_results || e->slot >= s->n_slots) return 0;
+    return (int)((s->h_mask[e->slot >> 6] >> (e->slot & 63)) & 1);
+}
+
+void *clapgpu_scene_entity_user(const clapgpu_scene *s, uint32_t handle)
+{
+    const struct ent *e = get(s, handle);
+    return e ? e->user : NULL;
+}
+
+uint32_t clapgpu_scene_visible(const clapgpu_scene *s, uint32_t *handles, uint32_t capacity)
+{
+    uint32_t cnt = 0;
+    if (!s || !s->have_results) return 0;
+    for (uint32_t w = 0; w < s->n_slots / 64; w++) {
+        uint64_t m = s->h_mask[w];
+        while (m) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            if (handles && cnt < capacity) handles[cnt] = s->slot_handle[w * 64 + bit];
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+int clapgpu_scene_layout_is_tiled(const clapgpu_scene *s) { return s ? s->tiled : 0; }
+uint32_t clapgpu_scene_slot_count(const clapgpu_scene *s) { return s ? s->n_slots : 0; }

@@ -1,0 +1,66 @@
+/*
+ * clapgpu_scene.h -- C host mirror of a CLAP model queue over libclapgpu (libclapgpu_scene.so).
+ *
+ * This is the host side a CLAP maintainer links instead of walking `mq->txmodels` ->
+ * `txm->entities` (model.h:334,222,377): entities are registered once, mutated through the
+ * same verbs the engine uses (entity3d_position / _rotate / _scale / _visible, model.c:1810-1842;
+ * e->parent, model.h:402), and clapgpu_scene_mq_update() is `mq_update(mq)` (model.c:1953) +
+ * the per-entity view_entity_in_frustum() of _models_render (model.c:969-970) in one call:
+ * re-tile if the topology changed, upload dirty transforms, run the HIP kernel, download
+ * mx / inverse_mx / aabb / aabb_center / visibility, all visible on return (the reference's
+ * calls are synchronous, single-threaded).
+ *
+ * Plain C.  Returns cerr_enum-compatible ints (error.h:12-49).  Handles are stable until
+ * clapgpu_scene_entity_delete(); slots (device indices) are not.
+ */
+#ifndef CLAPGPU_SCENE_H
+#define CLAPGPU_SCENE_H
+
+#include "clapgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clapgpu_scene clapgpu_scene;
+#define CLAPGPU_NO_ENTITY 0xffffffffu
+
+int  clapgpu_scene_create(clapgpu_scene **out, int device);
+void clapgpu_scene_destroy(clapgpu_scene *s);
+
+/* model3d: local-space AABB (model3d.aabb, model.h:55) and skip_aabb (model.h:64) */
+int  clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aabb, uint32_t *model);
+
+/* entity3d_make (model.c:1735-1744): identity transform, scale 1, ALIVE | VISIBLE, dirty */
+int  clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle);
+/* entity3d_delete (model.c:1787): the slot becomes a tombstone until the next re-tile */
+int  clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle);
+/* e->parent = p (jointless attachment, model.h:386-402); CLAPGPU_NO_ENTITY detaches */
+int  clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t parent);
+
+/* entity3d_position / transform_set_quat / entity3d_scale / entity3d_visible: set xform.updated */
+int  clapgpu_scene_entity_position(clapgpu_scene *s, uint32_t handle, const float pos[3]);
+int  clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float quat_xyzw[4]);
+int  clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale);
+int  clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set, uint32_t clear);
+
+/* mq_update + cull against `frustum` (NULL: no cull) */
+int  clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum);
+
+/* results of the last mq_update; pointers stay valid until the next mq_update */
+const float *clapgpu_scene_entity_mx(const clapgpu_scene *s, uint32_t handle);          /* e->mx */
+const float *clapgpu_scene_entity_inverse_mx(const clapgpu_scene *s, uint32_t handle);  /* e->inverse_mx */
+const float *clapgpu_scene_entity_aabb(const clapgpu_scene *s, uint32_t handle);        /* e->aabb (6) */
+const float *clapgpu_scene_entity_aabb_center(const clapgpu_scene *s, uint32_t handle); /* e->aabb_center */
+int          clapgpu_scene_entity_in_frustum(const clapgpu_scene *s, uint32_t handle);  /* view_entity_in_frustum */
+void        *clapgpu_scene_entity_user(const clapgpu_scene *s, uint32_t handle);
+/* number of entities that pass the draw predicate; handles[] (ascending slot order) if non-NULL */
+uint32_t     clapgpu_scene_visible(const clapgpu_scene *s, uint32_t *handles, uint32_t capacity);
+/* 1 = tiles (one launch), 0 = level-major (a tree wider than 64 at some level); after mq_update */
+int          clapgpu_scene_layout_is_tiled(const clapgpu_scene *s);
+uint32_t     clapgpu_scene_slot_count(const clapgpu_scene *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAPGPU_SCENE_H */

@@ -1,0 +1,186 @@
+/*
+ * tests/c/test_scene.c -- drives the C host mirror (include/clapgpu_scene.h) the way CLAP's frame
+ * loop would and checks every result against the oracle (oracle/clap_oracle.h), bit for bit.
+ * Built and run by tests/test_scene_c.py (GPU).  Exit code 0 = pass.
+ *
+ * Scenario: entities are created in random order (children may precede their parents, as on the
+ * engine's creation-ordered lists), then across frames some move, some are re-parented, some are
+ * deleted and new ones appear.  After each clapgpu_scene_mq_update the oracle is run on a
+ * parents-first ordering of the same scene; mx / inverse_mx / aabb / aabb_center / in-frustum
+ * must match exactly.  argv[1] = "wide" makes one tree wider than 64 (level-major fallback).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "clapgpu_scene.h"
+#include "clap_oracle.h"
+
+#define MAXE 6000
+static uint64_t rng_s = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd(void) { uint64_t z = (rng_s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static float frand(float a, float b) { return a + (b - a) * (float)((rnd() >> 11) * (1.0 / 9007199254740992.0)); }
+
+struct host_ent { uint32_t handle, parent /* index into ents[] or -1u */, model; float ps[4], rot[4]; uint32_t flags; int live; };
+static struct host_ent ents[MAXE];
+static uint32_t n_ents;
+
+static void rand_trs(struct host_ent *e, int child)
+{
+    float q[4] = { frand(-1, 1), frand(-1, 1), frand(-1, 1), frand(-1, 1) };
+    float l = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) e->rot[i] = q[i] / l;
+    float r = child ? 3.f : 200.f;
+    e->ps[0] = frand(-r, r); e->ps[1] = frand(-r / 4, r / 4); e->ps[2] = frand(-r, r); e->ps[3] = frand(0.6f, 1.4f);
+}
+
+static int fail(const char *what, uint32_t i) { fprintf(stderr, "FAIL: %s (entity %u)\n", what, i); return 1; }
+
+/* oracle on a parents-first ordering; compare with the scene mirror */
+static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_keep /* [MAXE][16] persistent oracle state */,
+                       float *o_inv, float *o_aabb, float *o_ctr, uint32_t *o_seqs, uint32_t *o_flags_dirty)
+{
+    static uint32_t order[MAXE], pos_in_order[MAXE], depth[MAXE];
+    uint32_t n = 0, maxd = 0;
+    for (uint32_t i = 0; i < n_ents; i++) {
+        if (!ents[i].live) continue;
+        uint32_t d = 0, x = i;
+        while (ents[x].parent != UINT32_MAX) { x = ents[x].parent; d++; }
+        depth[i] = d; if (d > maxd) maxd = d;
+    }
+    for (uint32_t d = 0; d <= maxd; d++)
+        for (uint32_t i = 0; i < n_ents; i++)
+            if (ents[i].live && depth[i] == d) { pos_in_order[i] = n; order[n++] = i; }
+    static float ps[MAXE * 4], rot[MAXE * 4], mx[MAXE * 16], inv[MAXE * 16], aabb[MAXE * 6], ctr[MAXE * 3];
+    static int32_t parent[MAXE], model[MAXE];
+    static uint32_t flags[MAXE], seqs[MAXE];
+    static const float model_aabb[2][6] = { { -1, -2, -3, 1, 2, 3 }, { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f } };
+    static const uint8_t model_skip[2] = { 0, 0 };
+    for (uint32_t k = 0; k < n; k++) {
+        const struct host_ent *e = &ents[order[k]];
+        memcpy(ps + 4 * k, e->ps, 16); memcpy(rot + 4 * k, e->rot, 16);
+        parent[k] = e->parent == UINT32_MAX ? -1 : (int32_t)pos_in_order[e->parent];
+        model[k] = (int32_t)e->model;
+        flags[k] = e->flags | CLAPO_E_DIRTY;         /* converged result == everything rebuilt from current TRS */
+        seqs[k] = 0;
+    }
+    clapo_entities_update(n, ps, rot, parent, model, &model_aabb[0][0], model_skip, flags, seqs, mx, inv, aabb, ctr);
+    (void)o_mx_keep; (void)o_inv; (void)o_aabb; (void)o_ctr; (void)o_seqs; (void)o_flags_dirty;
+    uint32_t vis_exp = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const struct host_ent *e = &ents[order[k]];
+        const float *g;
+        if (!(g = clapgpu_scene_entity_mx(s, e->handle)) || memcmp(g, mx + 16 * k, 64)) return fail("mx", order[k]);
+        if (!(g = clapgpu_scene_entity_inverse_mx(s, e->handle)) || memcmp(g, inv + 16 * k, 64)) return fail("inverse_mx", order[k]);
+        if (!(g = clapgpu_scene_entity_aabb(s, e->handle)) || memcmp(g, aabb + 6 * k, 24)) return fail("aabb", order[k]);
+        if (!(g = clapgpu_scene_entity_aabb_center(s, e->handle)) || memcmp(g, ctr + 3 * k, 12)) return fail("aabb_center", order[k]);
+        int exp = (e->flags & CLAPO_E_VISIBLE) &&
+                  ((e->flags & CLAPO_E_SKIP_CULLING) || clapo_aabb_in_frustum((const clapo_frustum *)fr, aabb + 6 * k));
+        if (clapgpu_scene_entity_in_frustum(s, e->handle) != exp) return fail("view_entity_in_frustum", order[k]);
+        if (clapgpu_scene_entity_user(s, e->handle) != (void *)e) return fail("user pointer", order[k]);
+        vis_exp += exp;
+    }
+    if (clapgpu_scene_visible(s, NULL, 0) != vis_exp) return fail("visible count", vis_exp);
+    printf("  frame ok: %u live entities, %u visible, layout %s, %u slots\n", n, vis_exp,
+           clapgpu_scene_layout_is_tiled(s) ? "tiles" : "levels", clapgpu_scene_slot_count(s));
+    return 0;
+}
+
+static int add_entity(clapgpu_scene *s, uint32_t parent_idx)
+{
+    struct host_ent *e = &ents[n_ents];
+    memset(e, 0, sizeof(*e));
+    e->model = (uint32_t)(rnd() & 1);
+    e->parent = parent_idx;
+    e->flags = CLAPO_E_ALIVE | CLAPO_E_VISIBLE;
+    e->live = 1;
+    rand_trs(e, parent_idx != UINT32_MAX);
+    if (clapgpu_scene_entity_new(s, e->model, e, &e->handle)) return 1;
+    if (clapgpu_scene_entity_position(s, e->handle, e->ps) || clapgpu_scene_entity_rotation(s, e->handle, e->rot) ||
+        clapgpu_scene_entity_scale(s, e->handle, e->ps[3])) return 1;
+    n_ents++;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    const int wide = argc > 1 && !strcmp(argv[1], "wide");
+    clapgpu_scene *s;
+    if (clapgpu_scene_create(&s, 0)) { fprintf(stderr, "create: %s\n", clapgpu_last_error()); return 2; }
+    const float a0[6] = { -1, -2, -3, 1, 2, 3 }, a1[6] = { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f };
+    uint32_t m0, m1;
+    if (clapgpu_scene_model_new(s, a0, 0, &m0) || clapgpu_scene_model_new(s, a1, 0, &m1) || m0 != 0 || m1 != 1) return 2;
+
+    /* camera: scene.c:74-76 defaults */
+    float view[16], proj[16];
+    const float cpos[3] = { 0, 10, 120 }, cq[4] = { 0, 0, 0, 1 };
+    clapgpu_frustum fr;
+    clapgpu_view_matrix(cpos, cq, view);
+    clapgpu_perspective(70.f * 3.14159265f / 180.f, 16.f / 9.f, 0.1f, 500.f, 0, proj);
+    clapgpu_frustum_calc(view, proj, 0, &fr);
+
+    /* creation order: children first for a third of the scene (parents are attached afterwards) */
+    for (int i = 0; i < 1500; i++) if (add_entity(s, UINT32_MAX)) return 2;
+    for (int i = 0; i < 1500; i++) {
+        uint32_t c = (uint32_t)(rnd() % n_ents), p = (uint32_t)(rnd() % n_ents);
+        /* attach c under p if that keeps a forest of depth <= 7 and (unless "wide") narrow trees */
+        uint32_t d = 0, x = p; int cyc = 0;
+        while (ents[x].parent != UINT32_MAX) { x = ents[x].parent; if (x == c) cyc = 1; if (++d > 6) break; }
+        if (cyc || x == c || d > 5 || ents[c].parent != UINT32_MAX || c == p) continue;
+        int has_child = 0;
+        for (uint32_t k = 0; k < n_ents; k++) if (ents[k].parent == c) has_child = 1;
+        if (has_child && d > 2) continue;
+        ents[c].parent = p;
+        rand_trs(&ents[c], 1);
+        clapgpu_scene_entity_position(s, ents[c].handle, ents[c].ps);
+        if (clapgpu_scene_entity_set_parent(s, ents[c].handle, ents[p].handle)) return 2;
+    }
+    if (wide)                                           /* 200 children under one root: a level wider than a wavefront */
+        for (int i = 0; i < 200; i++) if (add_entity(s, 0)) return 2; else
+            if (clapgpu_scene_entity_set_parent(s, ents[n_ents - 1].handle, ents[0].handle)) return 2;
+    if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
+    if (clapgpu_scene_layout_is_tiled(s) == wide) return fail("layout choice", 0);
+    if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+
+    for (int frame = 0; frame < 4; frame++) {
+        for (int k = 0; k < 300; k++) {                  /* entity3d_position / rotate on a random subset */
+            struct host_ent *e = &ents[rnd() % n_ents];
+            if (!e->live) continue;
+            rand_trs(e, e->parent != UINT32_MAX);
+            clapgpu_scene_entity_position(s, e->handle, e->ps);
+            clapgpu_scene_entity_rotation(s, e->handle, e->rot);
+            clapgpu_scene_entity_scale(s, e->handle, e->ps[3]);
+        }
+        for (int k = 0; k < 40; k++) {                   /* entity3d_visible(e, false) / SKIP_CULLING */
+            struct host_ent *e = &ents[rnd() % n_ents];
+            if (!e->live) continue;
+            if (k & 1) { e->flags &= ~CLAPO_E_VISIBLE; clapgpu_scene_entity_flags(s, e->handle, 0, CLAPGPU_E_VISIBLE); }
+            else { e->flags |= CLAPO_E_SKIP_CULLING; clapgpu_scene_entity_flags(s, e->handle, CLAPGPU_E_SKIP_CULLING, 0); }
+        }
+        if (frame & 1) {                                 /* topology change: delete leaves, add new children */
+            for (int k = 0; k < 60; k++) {
+                uint32_t i = (uint32_t)(rnd() % n_ents);
+                int has_child = 0;
+                for (uint32_t c = 0; c < n_ents; c++) if (ents[c].live && ents[c].parent == i) has_child = 1;
+                if (!ents[i].live || has_child || i == 0) continue;
+                clapgpu_scene_entity_delete(s, ents[i].handle);
+                ents[i].live = 0;
+            }
+            for (int k = 0; k < 80 && n_ents < MAXE; k++) {
+                uint32_t p = (uint32_t)(rnd() % n_ents);
+                uint32_t d = 0, x = p;
+                while (ents[x].parent != UINT32_MAX) { x = ents[x].parent; d++; }
+                if (!ents[p].live || d > 5) continue;
+                if (add_entity(s, p) || clapgpu_scene_entity_set_parent(s, ents[n_ents - 1].handle, ents[p].handle)) return 2;
+            }
+        }
+        if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
+        if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+    }
+    if (clapgpu_scene_entity_position(s, 0xdeadbeef, cpos) != CLAPGPU_ERR_INVALID_ARGUMENTS) return fail("bad handle", 0);
+    clapgpu_scene_destroy(s);
+    printf("PASS\n");
+    return 0;
+}
