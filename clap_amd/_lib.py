@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_NOMEM = -1
@@ -67,8 +67,7 @@ class Skeleton(C.Structure):
 
 
 class Animations(C.Structure):
-    _fields_ = [("n_anims", C.c_uint32), ("n_channels", C.c_uint32), ("chan_of", C.c_void_p),
-                ("ch_nr", C.c_void_p), ("ch_time_off", C.c_void_p), ("ch_data_off", C.c_void_p),
+    _fields_ = [("n_anims", C.c_uint32), ("n_times", C.c_uint32), ("chan_table", C.c_void_p),
                 ("times", C.c_void_p), ("data", C.c_void_p)]
 
 

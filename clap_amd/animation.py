@@ -49,29 +49,22 @@ def joint_depths(parent):
 
 
 def channel_table(anims, nr_joints):
-    """chan_of[a][joint][path] -> channel index (last listed channel wins), plus the pooled
-    channel arrays of all animations."""
-    chan_of = np.full((len(anims), nr_joints, 3), -1, np.int32)
-    nr, toff, doff, times, data = [], [], [], [], []
-    t_base = d_base = c_base = 0
+    """chan_table[a][joint][path] = (time_off, data_off, nr, 0) into the pooled key times / values
+    of all animations; the last listed channel of a (joint, path) wins (model.c:1348-1349)."""
+    table = np.zeros((len(anims), nr_joints, 3, 4), np.uint32)
+    times, data = [], []
+    t_base = d_base = 0
     for ai, an in enumerate(anims):
         for c in range(int(an["n_channels"])):
-            tgt, path = int(an["ch_target"][c]), int(an["ch_path"][c])
-            if tgt < nr_joints and path < 3 and int(an["ch_nr"][c]) > 0:
-                chan_of[ai, tgt, path] = c_base + c
-        nr.append(an["ch_nr"])
-        toff.append(an["ch_time_off"].astype(np.int64) + t_base)
-        doff.append(an["ch_data_off"].astype(np.int64) + d_base)
+            tgt, path, nr = int(an["ch_target"][c]), int(an["ch_path"][c]), int(an["ch_nr"][c])
+            if tgt < nr_joints and path < 3 and nr > 0:
+                table[ai, tgt, path] = (t_base + int(an["ch_time_off"][c]), d_base + int(an["ch_data_off"][c]), nr, 0)
         times.append(an["times"])
         data.append(an["data"])
         t_base += an["times"].shape[0]
         d_base += an["data"].shape[0]
-        c_base += int(an["n_channels"])
-    return dict(chan_of=chan_of, ch_nr=np.concatenate(nr).astype(np.uint32),
-                ch_time_off=np.concatenate(toff).astype(np.uint32),
-                ch_data_off=np.concatenate(doff).astype(np.uint32),
-                times=np.concatenate(times).astype(np.float32), data=np.concatenate(data).astype(np.float32),
-                n_channels=c_base)
+    return dict(chan_table=table, times=np.concatenate(times).astype(np.float32),
+                data=np.concatenate(data).astype(np.float32))
 
 
 class SkinnedModel:
@@ -93,12 +86,11 @@ class SkinnedModel:
         self.anims_host = anims
         ct = channel_table(anims, J)
         self.time_end = [float(a["time_end"]) for a in anims]
-        self._ct = {k: _dev(v, dev) for k, v in ct.items() if k != "n_channels"}
+        self._ct = {k: _dev(v, dev) for k, v in ct.items()}
         self.skel_desc = _lib.Skeleton(J, self.n_levels, _ptr(self.parent), _ptr(self.depth),
                                        _ptr(self.root_pose), _ptr(self.invmx), _ptr(self.bind))
-        self.anim_desc = _lib.Animations(len(anims), ct["n_channels"], _ptr(self._ct["chan_of"]),
-                                         _ptr(self._ct["ch_nr"]), _ptr(self._ct["ch_time_off"]),
-                                         _ptr(self._ct["ch_data_off"]), _ptr(self._ct["times"]),
+        self.anim_desc = _lib.Animations(len(anims), int(ct["times"].shape[0]), _ptr(self._ct["chan_table"]),
+                                         _ptr(self._ct["times"]),
                                          _ptr(self._ct["data"]))
         self.mesh = None
         if mesh is not None:

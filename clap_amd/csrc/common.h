@@ -112,4 +112,33 @@ __device__ __forceinline__ void store_rows(const float *tile, float *dst, int la
     }
 }
 
+// Sum of bytes [0, nbytes) of a 16-byte aligned array, nbytes % 16 == 0, over the whole wave.
+// Eight independent 16-byte loads per lane are in flight per trip: the callers sit on the
+// critical path right behind a kernel boundary and would otherwise serialise L2 round trips.
+__device__ __forceinline__ uint32_t wave_byte_sum(const uint8_t *bytes, uint32_t nbytes, int lane)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(bytes);
+    const uint32_t chunks = nbytes >> 4;
+    uint32_t acc = 0;
+    for (uint32_t c = lane; c < chunks; c += WAVE * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t idx = c + u * WAVE;
+            v[u] = idx < chunks ? p[idx] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc = __builtin_amdgcn_sad_u8(v[u].x, 0u, acc);
+            acc = __builtin_amdgcn_sad_u8(v[u].y, 0u, acc);
+            acc = __builtin_amdgcn_sad_u8(v[u].z, 0u, acc);
+            acc = __builtin_amdgcn_sad_u8(v[u].w, 0u, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_xor(acc, off);
+    return acc;
+}
+
 } // namespace clapgpu

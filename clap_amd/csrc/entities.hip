@@ -398,16 +398,8 @@ void k_visible_expand_rp(const uint64_t *vis_mask, const uint8_t *row_pop, uint3
     if (row0 >= n_rows)
         return;
 
-    uint32_t pre = 0;                                 // visible entities in rows [0, row0)
-    const uint4 *rp = reinterpret_cast<const uint4 *>(row_pop);
-    for (uint32_t c = lane; c * 16 < row0; c += WAVE) {
-        const uint4 v = rp[c];
-        pre = sum_bytes(v.x, pre);
-        pre = sum_bytes(v.y, pre);
-        pre = sum_bytes(v.z, pre);
-        pre = sum_bytes(v.w, pre);
-    }
-    pre = wave_sum(pre);
+    // visible entities in rows [0, row0); row0 % 16 == 0
+    const uint32_t pre = wave_byte_sum(row_pop, row0, lane);
 
     const uint64_t word = lane < RP_ROWS ? load_mask_word(vis_mask, row0 + lane, n) : 0ull;
     const uint32_t cnt = __popcll(word);

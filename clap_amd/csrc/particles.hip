@@ -8,9 +8,11 @@
 //
 //   1. k_particles_advect   one lane per particle: respawn test, advect the survivors,
 //                           ballot the respawn flags into a bitmask (+ per-row popcounts)
-//   2. ordered compaction   (entities.hip) -> ascending list of respawning particle indices
-//   3. k_particles_respawn  lane k handles the k-th respawn: jump the LCG ahead by 7k draws
-//                           (affine-map power, mod 2^48), regenerate position and velocity
+//   2. k_particles_respawn_rp  a lane whose flag is set ranks itself among all respawns (byte
+//                           prefix over the per-row popcounts + bits below it in its row), jumps
+//                           the LCG ahead by 7 * rank draws (affine-map power, mod 2^48) and
+//                           regenerates position and velocity.
+//      (above 4M particles: ordered compaction (entities.hip) + k_particles_respawn over the list)
 //
 // HBM: 36 B / particle (pos 12 + vel 12 read, pos 12 written; pos doubles as the pos_array
 // the renderer uploads, particle.c:116,124).  Respawns are rare, passes 2-3 are tiny.
@@ -133,54 +135,107 @@ __device__ __forceinline__ double cbrt_glibc(double x)
     return ldexp(x > 0.0 ? ym : -ym, xe / 3);
 }
 
+// the rank-th respawn of the frame, for particle i (random_point_sphere + particle_set_velocity)
+__device__ __forceinline__ void respawn_one(const PartK &k, uint64_t state0, uint32_t rank, uint32_t i)
+{
+    const clapgpu_particle_system &ps = k.sys[k.row_sys[i >> 6]];
+    uint64_t x = lcg_skip(state0, 7ull * rank);
+
+    // random_point_sphere (particle.c:36-67)
+    float dx = (float)(drand48_next(x) * 2.0 - 1.0);
+    float dy = (float)(drand48_next(x) * 2.0 - 1.0);
+    float dz = (float)(drand48_next(x) * 2.0 - 1.0);
+    float dd = 0.f;
+    dd += dx * dx;
+    dd += dy * dy;
+    dd += dz * dz;
+    const float len = sqrtf(dd);
+    if (len) {                                                   // vec3_norm_safe
+        const float kk = (float)(1.0 / (double)len);
+        dx = dx * kk; dy = dy * kk; dz = dz * kk;
+    }
+    const double d3 = drand48_next(x);
+    double u;
+    switch (ps.dist) {
+    case CLAPGPU_PART_DIST_POW075: u = pow(d3, 0.75); break;
+    case CLAPGPU_PART_DIST_CBRT:   u = cbrt_glibc(d3); break;
+    case CLAPGPU_PART_DIST_SQRT:   u = sqrt(d3); break;
+    default:                       u = d3; break;
+    }
+    const float r = (float)(ps.min_radius + (ps.radius - ps.min_radius) * u);
+    const float px = ps.center[0] * 1.0f + dx * r;               // vec3_add_scaled(.., 1.0, r)
+    const float py = ps.center[1] * 1.0f + dy * r;
+    const float pz = ps.center[2] * 1.0f + dz * r;
+    // particle_set_velocity (particle.c:69-74)
+    const float vx = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
+    const float vy = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
+    const float vz = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
+    float *p = k.pos + 3 * (size_t)i, *v = k.vel + 3 * (size_t)i;
+    v[0] = vx; v[1] = vy; v[2] = vz;
+    p[0] = px + vx;                                              // particle.c:115
+    p[1] = py + vy;
+    p[2] = pz + vz;
+}
+
+// large-n path: respawns listed by the ordered compaction
 __global__ __launch_bounds__(PART_BLOCK)
 void k_particles_respawn(PartK k, const uint32_t *list, const uint32_t *count)
 {
     const uint32_t total = *count;
     const uint64_t state0 = k.rng_state[0];
     const uint32_t stride = gridDim.x * PART_BLOCK;
-    for (uint32_t j = blockIdx.x * PART_BLOCK + threadIdx.x; j < total; j += stride) {
-        const uint32_t i = list[j];
-        const clapgpu_particle_system &ps = k.sys[k.row_sys[i >> 6]];
-        uint64_t x = lcg_skip(state0, 7ull * j);
-
-        // random_point_sphere (particle.c:36-67)
-        float dx = (float)(drand48_next(x) * 2.0 - 1.0);
-        float dy = (float)(drand48_next(x) * 2.0 - 1.0);
-        float dz = (float)(drand48_next(x) * 2.0 - 1.0);
-        float dd = 0.f;
-        dd += dx * dx;
-        dd += dy * dy;
-        dd += dz * dz;
-        const float len = sqrtf(dd);
-        if (len) {                                                   // vec3_norm_safe
-            const float kk = (float)(1.0 / (double)len);
-            dx = dx * kk; dy = dy * kk; dz = dz * kk;
-        }
-        const double d3 = drand48_next(x);
-        double u;
-        switch (ps.dist) {
-        case CLAPGPU_PART_DIST_POW075: u = pow(d3, 0.75); break;
-        case CLAPGPU_PART_DIST_CBRT:   u = cbrt_glibc(d3); break;
-        case CLAPGPU_PART_DIST_SQRT:   u = sqrt(d3); break;
-        default:                       u = d3; break;
-        }
-        const float r = (float)(ps.min_radius + (ps.radius - ps.min_radius) * u);
-        float px = ps.center[0] * 1.0f + dx * r;                     // vec3_add_scaled(.., 1.0, r)
-        float py = ps.center[1] * 1.0f + dy * r;
-        float pz = ps.center[2] * 1.0f + dz * r;
-        // particle_set_velocity (particle.c:69-74)
-        const float vx = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
-        const float vy = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
-        const float vz = (float)((drand48_next(x) * 2.0 - 1.0) * ps.velocity);
-        float *p = k.pos + 3 * (size_t)i, *v = k.vel + 3 * (size_t)i;
-        v[0] = vx; v[1] = vy; v[2] = vz;
-        p[0] = px + vx;                                              // particle.c:115
-        p[1] = py + vy;
-        p[2] = pz + vz;
-    }
+    for (uint32_t j = blockIdx.x * PART_BLOCK + threadIdx.x; j < total; j += stride)
+        respawn_one(k, state0, j, list[j]);
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        k.rng_state[1] = lcg_skip(state0, 7ull * total);             // where the libc stream now stands
+        k.rng_state[1] = lcg_skip(state0, 7ull * total);         // where the libc stream now stands
+}
+
+// n <= 4M: a wave owns 64 rows (one mask word per lane).  Rows without respawns -- almost all of
+// them -- cost one load; a wave with work ranks its rows from the per-row popcount bytes.
+__global__ __launch_bounds__(PART_BLOCK)
+void k_particles_respawn_rp(PartK k, uint32_t *respawn_count)
+{
+    const int lane = lane_id();
+    const uint32_t w = blockIdx.x * (PART_BLOCK / WAVE) + threadIdx.x / WAVE;
+    const uint32_t n_rows = k.n / WAVE;
+    const uint32_t row0 = w * WAVE;
+    if (row0 >= n_rows)
+        return;
+    const uint32_t my_row = row0 + lane;
+    const uint64_t m = my_row < n_rows ? k.respawn_mask[my_row] : 0ull;
+    const uint64_t busy = __ballot(m != 0);
+    const bool last = row0 + WAVE >= n_rows;
+    if (busy == 0 && !last)
+        return;                                                  // the common case: nothing to do
+
+    // respawns in rows [0, row0); row0 % 64 == 0
+    const uint32_t pre = wave_byte_sum(k.respawn_row_pop, row0, lane);
+
+    const uint32_t cnt = __popcll(m);
+    uint32_t incl = cnt;                                         // inclusive scan of the 64 row counts
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - cnt;
+    const uint64_t state0 = k.rng_state[0];
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+
+    uint64_t todo = busy;
+    while (todo) {                                               // rows of this wave that have respawns
+        const int r = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t mr = (uint64_t)(uint32_t)__shfl((int)lo, r) | ((uint64_t)(uint32_t)__shfl((int)hi, r) << 32);
+        const uint32_t base = pre + (uint32_t)__shfl((int)excl, r);
+        if ((mr >> lane) & 1ull)
+            respawn_one(k, state0, base + __popcll(mr & ((1ull << lane) - 1ull)), (row0 + r) * WAVE + lane);
+    }
+    if (last && lane == WAVE - 1) {
+        const uint32_t total = pre + incl;
+        *respawn_count = total;
+        k.rng_state[1] = lcg_skip(state0, 7ull * total);         // where the libc stream now stands
+    }
 }
 
 } // namespace clapgpu
@@ -215,7 +270,14 @@ extern "C" int clapgpu_particles_update(void *stream, const clapgpu_particles *p
     hipLaunchKernelGGL(k_particles_advect, dim3((p->n + PART_BLOCK - 1) / PART_BLOCK), dim3(PART_BLOCK), 0,
                        as_stream(stream), k, view);
     CLAPGPU_LAUNCH_CHECK("k_particles_advect");
-    int rc = clapgpu_visible_compact(stream, p->respawn_mask, p->respawn_row_pop, p->n, 0, p->respawn_list,
+    if (p->n / WAVE <= (1u << 16) && (reinterpret_cast<uintptr_t>(p->respawn_row_pop) & 15u) == 0) {
+        const uint32_t waves = (p->n / WAVE + WAVE - 1) / WAVE, per_block = PART_BLOCK / WAVE;
+        hipLaunchKernelGGL(k_particles_respawn_rp, dim3((waves + per_block - 1) / per_block), dim3(PART_BLOCK), 0,
+                           as_stream(stream), k, p->respawn_count);
+        CLAPGPU_LAUNCH_CHECK("k_particles_respawn_rp");
+        return CLAPGPU_OK;
+    }
+    int rc = clapgpu_visible_compact(stream, p->respawn_mask, nullptr, p->n, 0, p->respawn_list,
                                      p->respawn_count, p->scratch);
     if (rc) return rc;
     const uint32_t blocks = p->n / PART_BLOCK < 256 ? (p->n / PART_BLOCK ? p->n / PART_BLOCK : 1) : 256;

@@ -29,9 +29,9 @@ struct PoseArgs {
     const float4   *invmx;
     const float4   *bind;
     // animations
-    const int32_t  *chan_of;
-    const uint32_t *ch_nr, *ch_time_off, *ch_data_off;
+    const uint4    *chan_table;     // [n_anims][J][3] = (time_off, data_off, nr, 0)
     const float    *times, *data;
+    uint32_t        n_times;
     // batch
     uint32_t        n_chars;
     const uint32_t *anim;
@@ -103,193 +103,223 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
         for (int i = 0; i < 4; i++) res[i] = t[i] * k;
         return;
     }
-    const float theta_0 = (float)acos((double)dot);
+    // The reference calls the double libm acos/sin/cos on float arguments and rounds the results
+    // back to float.  fp64 transcendentals are this kernel's single largest VALU cost, so the
+    // correctly-rounded-to-a-few-ulp fp32 forms are used instead: |error| <= ~3e-7 on unit
+    // quaternion components, inside the 1e-5 bar this path is held to (tests/test_pose_skin_gpu.py).
+    const float theta_0 = acosf(dot);
     const float theta = fac * theta_0;
-    const float sin_theta = (float)sin((double)theta);
-    const float sin_theta_0 = (float)sin((double)theta_0);
-    const float rf = (float)(cos((double)theta) - (double)(dot * sin_theta / sin_theta_0));
+    const float sin_theta = sinf(theta);
+    const float sin_theta_0 = sinf(theta_0);
+    const float rf = cosf(theta) - dot * sin_theta / sin_theta_0;
     const float f = sin_theta / sin_theta_0;
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
 }
 
-constexpr int POSE_BLOCK = 256;
-constexpr int G_STRIDE = 16;            // floats per joint global in LDS
+#ifndef POSE_WAVES
+#define POSE_WAVES 3
+#endif
+constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
+constexpr int POSE_TIMES_LDS_MAX = 6144;     // key times kept in LDS when the model's pool fits (24 KiB)
 
-// LPC = lanes per character (64, 128, 192 or 256); CPB = characters per block.
-template <int LPC>
-__global__ __launch_bounds__(POSE_BLOCK)
+// LPC = lanes per character (64, 128, 192 or 256); BLOCK threads = CPB characters per block.
+// LDS_TIMES: the model's whole key-time pool is staged in LDS once per block and the block is
+// persistent (it strides over character groups), so the per-lane binary searches -- five
+// dependent loads per path -- run at LDS latency instead of L2 latency.  Skeleton constants of
+// the lane's joint (invmx, bind column 3, depth, parent) live in registers across characters.
+template <int LPC, bool LDS_TIMES, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? POSE_WAVES : 1)
 void k_pose(PoseArgs a)
 {
-    constexpr int CPB = POSE_BLOCK / LPC;
-    __shared__ float g_lds[CPB][LPC * G_STRIDE];                                   // joint globals
-    __shared__ float4 stage[POSE_BLOCK / WAVE][256];                               // 4 KiB per wave
+    constexpr int CPB = BLOCK / LPC;
+    // joint globals, 4 KiB per wave; once a character's chain is done the same 4 KiB are the
+    // wave's staging tile for its coalesced stores
+    __shared__ __attribute__((aligned(16))) float g_lds[CPB][LPC * G_STRIDE];
+    __shared__ float times_lds[LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
 
     const int tid = threadIdx.x;
     const int cib = tid / LPC, j = tid % LPC;
-    const int lane = lane_id(), wave = tid / WAVE;
-    const uint32_t c = blockIdx.x * CPB + cib;
-    const bool char_ok = c < a.n_chars && cib < CPB;
+    const int lane = lane_id();
     const uint32_t J = a.J;
-    const bool joint_ok = char_ok && (uint32_t)j < J;
-    const int depth = joint_ok ? a.depth[j] : -1;
+    const bool lane_joint = cib < CPB && (uint32_t)j < J;
+    const int depth = lane_joint ? a.depth[j] : -1;
     const bool reachable = depth >= 0;
+    const int32_t parent = lane_joint ? a.parent[j] : -1;
     float *G = g_lds[cib < CPB ? cib : 0];
 
-    // ---- 1. channels_transform: this joint's T, R, S at the character's frame time ----
-    float T[3] = { 0, 0, 0 }, R[4] = { 0, 0, 0, 1 }, S[3] = { 1, 1, 1 };
-    const size_t cj = (size_t)c * J + j;
-    if (joint_ok) {
-        const uint32_t an = a.anim[c];
-        const float time = a.frame_time[c];
-        const int32_t *co = a.chan_of + ((size_t)an * J + j) * 3;
-        const int32_t c0 = co[0], c1 = co[1], c2 = co[2];
-        if (c0 < 0 || c1 < 0 || c2 < 0) {                        // a path without a channel keeps its value
-            const float *st = a.trs + 10 * cj;
-            T[0] = st[0]; T[1] = st[1]; T[2] = st[2];
-            R[0] = st[3]; R[1] = st[4]; R[2] = st[5]; R[3] = st[6];
-            S[0] = st[7]; S[1] = st[8]; S[2] = st[9];
-        }
-        if (c0 >= 0) {
-            const float *t = a.times + a.ch_time_off[c0];
-            const float *d = a.data + a.ch_data_off[c0];
-            int p, n;
-            key_bracket(t, (int)a.ch_nr[c0], time, p, n);
-            const float fac = key_fac(time, t[p], t[n]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) T[k] = lerp_ref(d[3 * p + k], d[3 * n + k], fac);
-        }
-        if (c1 >= 0) {
-            const float *t = a.times + a.ch_time_off[c1];
-            const float *d = a.data + a.ch_data_off[c1];
-            int p, n;
-            key_bracket(t, (int)a.ch_nr[c1], time, p, n);
-            const float fac = key_fac(time, t[p], t[n]);
-            const float qa[4] = { d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3] };
-            const float qb[4] = { d[4 * n], d[4 * n + 1], d[4 * n + 2], d[4 * n + 3] };
-            slerp_ref(R, qa, qb, fac);
-        }
-        if (c2 >= 0) {
-            const float *t = a.times + a.ch_time_off[c2];
-            const float *d = a.data + a.ch_data_off[c2];
-            int p, n;
-            key_bracket(t, (int)a.ch_nr[c2], time, p, n);
-            const float fac = key_fac(time, t[p], t[n]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) S[k] = lerp_ref(d[3 * p + k], d[3 * n + k], fac);
-        }
+    if (LDS_TIMES) {
+        for (uint32_t q = tid; q < a.n_times; q += blockDim.x)
+            times_lds[q] = a.times[q];
+        __syncthreads();
     }
+    const float *times = LDS_TIMES ? times_lds : a.times;
 
-    // ---- 2. one_joint_transform, level by level: global = ((parent * I) * T) * R, scale_aniso ----
-    // T is a pure translation and R a pure rotation matrix, so the products are evaluated on their
-    // non-trivial terms only (the dropped terms are exact +-0 in the reference's full 4x4 products).
-    float Gm[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) Gm[k] = 0.f;
-    float Rm[16];
-    lmd::from_quat(Rm, R[0], R[1], R[2], R[3]);
-    const int32_t parent = joint_ok ? a.parent[j] : -1;
-    for (uint32_t d = 0; d < a.n_levels; d++) {
-        if (reachable && (uint32_t)depth == d) {
-            float P[16];
-            if (parent >= 0) {
-                const float4 *src = reinterpret_cast<const float4 *>(G + parent * G_STRIDE);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 v = src[q];
-                    P[4 * q] = v.x; P[4 * q + 1] = v.y; P[4 * q + 2] = v.z; P[4 * q + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) P[k] = a.root_pose[k];
+    const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint32_t c = g * CPB + cib;
+        const bool char_ok = cib < CPB && c < a.n_chars;
+        const bool joint_ok = char_ok && lane_joint;
+        const size_t cj = (size_t)c * J + j;
+
+        // ---- 1. channels_transform: this joint's T, R, S at the character's frame time ----
+        float T[3] = { 0, 0, 0 }, R[4] = { 0, 0, 0, 1 }, S[3] = { 1, 1, 1 };
+        if (joint_ok) {
+            const uint32_t an = a.anim[c];
+            const float time = a.frame_time[c];
+            const uint4 *tab = a.chan_table + ((size_t)an * J + j) * 3;
+            const uint4 e0 = tab[0], e1 = tab[1], e2 = tab[2];   // (time_off, data_off, nr, -)
+            const int n0 = (int)e0.z, n1 = (int)e1.z, n2 = (int)e2.z;
+            if (n0 <= 0 || n1 <= 0 || n2 <= 0) {                 // a path without a channel keeps its value
+                const float *st = a.trs + 10 * cj;
+                T[0] = st[0]; T[1] = st[1]; T[2] = st[2];
+                R[0] = st[3]; R[1] = st[4]; R[2] = st[5]; R[3] = st[6];
+                S[0] = st[7]; S[1] = st[8]; S[2] = st[9];
             }
+            // one path at a time keeps the live state small (the searches run on LDS-resident times)
+            if (n0 > 0) {
+                int p, q;
+                const float *t = times + e0.x;
+                key_bracket(t, n0, time, p, q);
+                const float fac = key_fac(time, t[p], t[q]);
+                const float *d = a.data + e0.y;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float t3 = 0.f;                                   // column 3 of P * T
-                t3 += E_(P, 0, r) * T[0];
-                t3 += E_(P, 1, r) * T[1];
-                t3 += E_(P, 2, r) * T[2];
-                t3 += E_(P, 3, r) * 1.f;
-                E_(Gm, 3, r) = t3;
-#pragma unroll
-                for (int cc = 0; cc < 3; cc++) {                  // columns 0..2 of (P * T) * R, then scale
-                    float s = 0.f;
-                    s += E_(P, 0, r) * E_(Rm, cc, 0);
-                    s += E_(P, 1, r) * E_(Rm, cc, 1);
-                    s += E_(P, 2, r) * E_(Rm, cc, 2);
-                    E_(Gm, cc, r) = s * S[cc];
-                }
+                for (int k = 0; k < 3; k++) T[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
             }
-            float4 *dst = reinterpret_cast<float4 *>(G + j * G_STRIDE);
+            if (n1 > 0) {
+                int p, q;
+                const float *t = times + e1.x;
+                key_bracket(t, n1, time, p, q);
+                const float fac = key_fac(time, t[p], t[q]);
+                const float *d = a.data + e1.y;
+                const float qa[4] = { d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3] };
+                const float qb[4] = { d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3] };
+                slerp_ref(R, qa, qb, fac);
+            }
+            if (n2 > 0) {
+                int p, q;
+                const float *t = times + e2.x;
+                key_bracket(t, n2, time, p, q);
+                const float fac = key_fac(time, t[p], t[q]);
+                const float *d = a.data + e2.y;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                dst[q] = make_float4(Gm[4 * q], Gm[4 * q + 1], Gm[4 * q + 2], Gm[4 * q + 3]);
+                for (int k = 0; k < 3; k++) S[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
+            }
         }
-        if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
-    }
 
-    // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
-    float JT[16], pos[4] = { 0, 0, 0, 0 };
-    if (reachable) {
-        float IM[16];
+        // ---- 2. one_joint_transform, level by level: global = ((parent * I) * T) * R, scale_aniso ----
+        // T is a pure translation and R a pure rotation matrix, so the products are evaluated on their
+        // non-trivial terms only (the dropped terms are exact +-0 in the reference's full 4x4 products).
+        float Gm[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = a.invmx[4 * j + q];
-            IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
+        for (int k = 0; k < 16; k++) Gm[k] = 0.f;
+        float Rm[16];
+        lmd::from_quat(Rm, R[0], R[1], R[2], R[3]);
+        for (uint32_t d = 0; d < a.n_levels; d++) {
+            if (joint_ok && reachable && (uint32_t)depth == d) {
+                float P[16];
+                if (parent >= 0) {
+                    const float4 *src = reinterpret_cast<const float4 *>(G + parent * G_STRIDE);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 v = src[q];
+                        P[4 * q] = v.x; P[4 * q + 1] = v.y; P[4 * q + 2] = v.z; P[4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) P[k] = a.root_pose[k];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float t3 = 0.f;                               // column 3 of P * T
+                    t3 += E_(P, 0, r) * T[0];
+                    t3 += E_(P, 1, r) * T[1];
+                    t3 += E_(P, 2, r) * T[2];
+                    t3 += E_(P, 3, r) * 1.f;
+                    E_(Gm, 3, r) = t3;
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {              // columns 0..2 of (P * T) * R, then scale
+                        float s = 0.f;
+                        s += E_(P, 0, r) * E_(Rm, cc, 0);
+                        s += E_(P, 1, r) * E_(Rm, cc, 1);
+                        s += E_(P, 2, r) * E_(Rm, cc, 2);
+                        E_(Gm, cc, r) = s * S[cc];
+                    }
+                }
+                float4 *dst = reinterpret_cast<float4 *>(G + j * G_STRIDE);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    dst[q] = make_float4(Gm[4 * q], Gm[4 * q + 1], Gm[4 * q + 2], Gm[4 * q + 3]);
+            }
+            if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
         }
-        lmd::mul(JT, Gm, IM);                                     // model.c:1389
-        const float4 b3 = a.bind[4 * j + 3];                      // only column 3 of bind reaches mpos
-        const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
-        float mpos[4];
+
+        // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
+        float JT[16], pos[4] = { 0, 0, 0, 0 };
+        if (joint_ok && reachable) {
+            float IM[16];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {                             // column 3 of JT * bind (model.c:1393-1397)
-            float s = 0.f;
+            for (int q = 0; q < 4; q++) {
+                const float4 v = a.invmx[4 * j + q];
+                IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
+            }
+            const float4 b3 = a.bind[4 * j + 3];                  // only column 3 of bind reaches mpos
+            const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
+            lmd::mul(JT, Gm, IM);                                 // model.c:1389
+            float mpos[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) s += E_(JT, k, r) * bv[k];
-            mpos[r] = s;
+            for (int r = 0; r < 4; r++) {                         // column 3 of JT * bind (model.c:1393-1397)
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) s += E_(JT, k, r) * bv[k];
+                mpos[r] = s;
+            }
+            const uint32_t ei = a.entity ? a.entity[c] : c;
+            float EM[16];
+            const float4 *em = reinterpret_cast<const float4 *>(a.entity_mx + 16 * (size_t)ei);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = em[q];
+                EM[4 * q] = v.x; EM[4 * q + 1] = v.y; EM[4 * q + 2] = v.z; EM[4 * q + 3] = v.w;
+            }
+            lmd::mul_vec4(pos, EM, mpos);                         // model.c:1400
         }
-        const uint32_t ei = a.entity ? a.entity[c] : c;
-        float EM[16];
-        const float4 *em = reinterpret_cast<const float4 *>(a.entity_mx + 16 * (size_t)ei);
+
+        // ---- stores (64 joints of one character per wave row) ----
+        if (LPC != WAVE) __syncthreads();                         // every wave is done reading parents from G
+        const uint32_t row_j0 = (uint32_t)(j - lane);             // first joint of this wave's row
+        if (char_ok && row_j0 < J) {                              // wave-uniform
+            const int nvalid = (int)(J - row_j0 < WAVE ? J - row_j0 : WAVE);
+            const size_t row0 = (size_t)c * J + row_j0;
+            float *tile_f = G + (row_j0 / WAVE) * (WAVE * G_STRIDE);      // the 4 KiB this wave's joints occupied
+            float4 *tile = reinterpret_cast<float4 *>(tile_f);
+
+            const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
+            stage_rows<10>(tile_f, trs_row, lane);                // 2560 B
+            wave_lds_fence();
+            store_rows<10>(tile_f, a.trs + 10 * row0, lane, nvalid);
+            wave_lds_fence();
+
+            const uint64_t reach_mask = __ballot(joint_ok && reachable);
+            const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
+            if (reach_mask == full) {
+                float4 v[4];
+                stage_mat4(tile, JT, lane);
+                wave_lds_fence();
+                unstage_mat4(tile, v, lane);
+                store_mat4_rows(a.joint_transforms + 16 * row0, v, lane, nvalid);
+                if (lane < nvalid)
+                    reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
+                wave_lds_fence();
+            } else if (joint_ok && reachable) {                   // joints not under joint 0 are never written
+                float4 *dj = reinterpret_cast<float4 *>(a.joint_transforms + 16 * cj);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = em[q];
-            EM[4 * q] = v.x; EM[4 * q + 1] = v.y; EM[4 * q + 2] = v.z; EM[4 * q + 3] = v.w;
+                for (int q = 0; q < 4; q++)
+                    dj[q] = make_float4(JT[4 * q], JT[4 * q + 1], JT[4 * q + 2], JT[4 * q + 3]);
+                reinterpret_cast<float4 *>(a.joint_pos)[cj] = make_float4(pos[0], pos[1], pos[2], pos[3]);
+            }
         }
-        lmd::mul_vec4(pos, EM, mpos);                             // model.c:1400
-    }
-
-    // ---- stores (64 joints of one character per wave row) ----
-    if (!char_ok || (uint32_t)(j - lane) >= J)
-        return;                                                   // whole wave has nothing to store
-    const uint32_t row_j0 = j - lane;                             // first joint of this wave's row
-    const int nvalid = (int)(J - row_j0 < WAVE ? J - row_j0 : WAVE);
-    const size_t row0 = (size_t)c * J + row_j0;
-    float4 *tile = stage[wave];
-    float *tile_f = reinterpret_cast<float *>(tile);
-
-    const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
-    stage_rows<10>(tile_f, trs_row, lane);                        // 2560 B
-    wave_lds_fence();
-    store_rows<10>(tile_f, a.trs + 10 * row0, lane, nvalid);
-    wave_lds_fence();
-
-    const uint64_t reach_mask = __ballot(reachable);
-    const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
-    if (reach_mask == full) {
-        float4 v[4];
-        stage_mat4(tile, JT, lane);
-        wave_lds_fence();
-        unstage_mat4(tile, v, lane);
-        store_mat4_rows(a.joint_transforms + 16 * row0, v, lane, nvalid);
-        if (lane < nvalid)
-            reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
-    } else if (reachable) {                                       // joints not under joint 0 are never written
-        float4 *dj = reinterpret_cast<float4 *>(a.joint_transforms + 16 * cj);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            dj[q] = make_float4(JT[4 * q], JT[4 * q + 1], JT[4 * q + 2], JT[4 * q + 3]);
-        reinterpret_cast<float4 *>(a.joint_pos)[cj] = make_float4(pos[0], pos[1], pos[2], pos[3]);
+        if (LPC != WAVE) __syncthreads();                         // next character reuses the globals in LDS
     }
 }
 
@@ -302,8 +332,8 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
 {
     if (!sk || !an || !pb)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    if (!sk->parent || !sk->depth || !sk->root_pose || !sk->invmx || !sk->bind || !an->chan_of ||
-        !an->ch_nr || !an->ch_time_off || !an->ch_data_off || !an->times || !an->data)
+    if (!sk->parent || !sk->depth || !sk->root_pose || !sk->invmx || !sk->bind || !an->chan_table ||
+        !an->times || !an->data)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (pb->n_chars == 0)
         return CLAPGPU_OK;
@@ -320,11 +350,9 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     a.root_pose = sk->root_pose;
     a.invmx = reinterpret_cast<const float4 *>(sk->invmx);
     a.bind = reinterpret_cast<const float4 *>(sk->bind);
-    a.chan_of = an->chan_of;
-    a.ch_nr = an->ch_nr;
-    a.ch_time_off = an->ch_time_off;
-    a.ch_data_off = an->ch_data_off;
+    a.chan_table = reinterpret_cast<const uint4 *>(an->chan_table);
     a.times = an->times;
+    a.n_times = an->n_times;
     a.data = an->data;
     a.n_chars = pb->n_chars;
     a.anim = pb->anim;
@@ -336,12 +364,41 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     a.joint_pos = pb->joint_pos;
 
     const uint32_t lpc = (sk->nr_joints + 63) / 64 * 64;
+    const bool lds_times = an->n_times > 0 && an->n_times <= (uint32_t)POSE_TIMES_LDS_MAX;
     hipStream_t s = as_stream(stream);
-    switch (lpc) {
-    case 64:  hipLaunchKernelGGL(k_pose<64>,  dim3((pb->n_chars + 3) / 4), dim3(256), 0, s, a); break;
-    case 128: hipLaunchKernelGGL(k_pose<128>, dim3((pb->n_chars + 1) / 2), dim3(256), 0, s, a); break;
-    case 192: hipLaunchKernelGGL(k_pose<192>, dim3(pb->n_chars), dim3(192), 0, s, a); break;
-    default:  hipLaunchKernelGGL(k_pose<256>, dim3(pb->n_chars), dim3(256), 0, s, a); break;
+    if (lds_times) {
+        // persistent blocks (24 KiB key times + 16 KiB joint globals each): exactly as many as are
+        // resident at once, so no block waits for a slot while the others hold their LDS copy
+        const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
+        const uint32_t n_groups = (pb->n_chars + cpb - 1) / cpb;
+        const void *fn = lpc == 64 ? (const void *)k_pose<64, true, 256> : lpc == 128 ? (const void *)k_pose<128, true, 256>
+                       : lpc == 192 ? (const void *)k_pose<192, true, 192> : (const void *)k_pose<256, true, 256>;
+        static thread_local uint32_t resident[4] = { 0, 0, 0, 0 };
+        uint32_t &res = resident[lpc / 64 - 1];
+        if (!res) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            CLAPGPU_HIP(hipGetDevice(&dev));
+            CLAPGPU_HIP(hipGetDeviceProperties(&prop, dev));
+            CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, 0));
+            res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)prop.multiProcessorCount;
+        }
+        const dim3 grid(n_groups < res ? n_groups : res), block(threads);
+        switch (lpc) {
+        case 64:  hipLaunchKernelGGL((k_pose<64, true, 256>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_pose<128, true, 256>), grid, block, 0, s, a); break;
+        case 192: hipLaunchKernelGGL((k_pose<192, true, 192>), grid, block, 0, s, a); break;
+        default:  hipLaunchKernelGGL((k_pose<256, true, 256>), grid, block, 0, s, a); break;
+        }
+    } else {
+        const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
+        const dim3 grid((pb->n_chars + cpb - 1) / cpb), block(threads);
+        switch (lpc) {
+        case 64:  hipLaunchKernelGGL((k_pose<64, false, 256>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_pose<128, false, 256>), grid, block, 0, s, a); break;
+        case 192: hipLaunchKernelGGL((k_pose<192, false, 192>), grid, block, 0, s, a); break;
+        default:  hipLaunchKernelGGL((k_pose<256, false, 256>), grid, block, 0, s, a); break;
+        }
     }
     CLAPGPU_LAUNCH_CHECK("k_pose");
     return CLAPGPU_OK;

@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 5u
+#define CLAPGPU_ABI_VERSION 6u
 
 namespace clapgpu {
 

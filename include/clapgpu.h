@@ -265,19 +265,17 @@ typedef struct clapgpu_skeleton {
 /*
  * Every animation of the model (struct animation / struct channel, model.h:133-142,
  * model.c:678-685), keyframe times strictly increasing per channel (glTF).
- *   chan_of[a][j][path]  channel of animation a that drives (joint j, path), -1 if none;
- *                        path 0 translation, 1 rotation, 2 scale (enum chan_path); when the
- *                        reference lists several, the last one wins (model.c:1348-1349)
- *   ch_nr[c] keyframes; ch_time_off[c] offset into times[]; ch_data_off[c] offset into
- *   data[] (floats, 3 per key for T/S, 4 for R)
+ *   chan_table[a][j][path] = (time_off, data_off, nr, 0) uint32x4: the channel of animation a
+ *       that drives (joint j, path) -- key times at times[time_off .. +nr), key values at
+ *       data[data_off ..] (floats, 3 per key for T/S, 4 for R); nr == 0: no such channel.
+ *       path 0 translation, 1 rotation, 2 scale (enum chan_path); when the reference lists
+ *       several channels for one (joint, path) the last one wins (model.c:1348-1349).
+ *       16-byte aligned.
  */
 typedef struct clapgpu_animations {
     uint32_t        n_anims;
-    uint32_t        n_channels;
-    const int32_t  *chan_of;
-    const uint32_t *ch_nr;
-    const uint32_t *ch_time_off;
-    const uint32_t *ch_data_off;
+    uint32_t        n_times;        /* floats in times[]: pools of <= 6144 are kept in LDS */
+    const uint32_t *chan_table;
     const float    *times;
     const float    *data;
 } clapgpu_animations;

@@ -135,6 +135,8 @@ int main(int argc, char **argv)
         ents[c].parent = p;
         rand_trs(&ents[c], 1);
         clapgpu_scene_entity_position(s, ents[c].handle, ents[c].ps);
+        clapgpu_scene_entity_rotation(s, ents[c].handle, ents[c].rot);
+        clapgpu_scene_entity_scale(s, ents[c].handle, ents[c].ps[3]);
         if (clapgpu_scene_entity_set_parent(s, ents[c].handle, ents[p].handle)) return 2;
     }
     if (wide)                                           /* 200 children under one root: a level wider than a wavefront */

@@ -108,3 +108,20 @@ def test_c4_full_size_stream_exact(cuda_device):
     assert_bits_equal(out["vel"], vel, "velocity after 3 frames")
     assert out["rng_state"] == st
     assert total > 1000
+
+
+def test_above_4m_particles_uses_list_path(cuda_device):
+    """More than 65536 rows: respawns go through the ordered compaction + list kernel."""
+    from clap_amd import particles
+    ps = synth.particle_systems(n_sys=4200, count=1024, radius=5.0, velocity=0.4, dist=synth.PART_DIST_LIN)
+    assert ps["n"] // 64 > (1 << 16)
+    pos, vel, st = ob.particles_spawn(ps, 0x42)
+    view = np.eye(4, dtype=np.float32).ravel()
+    batch = particles.ParticleBatch(ps, pos, vel, st, cuda_device)
+    for f in range(2):
+        k, st = ob.particles_update(ps, pos, vel, st)
+        batch.particles_update(view)
+    out = batch.download()
+    assert out["respawned"] == k and k > 100
+    assert_bits_equal(out["pos"], pos, "pos_array")
+    assert out["rng_state"] == st

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Run ONE of the secondary kernels a few times (for rocprofv3 --pmc / --kernel-trace).
+
+    python tools/run_kernel.py pose|skin|particles|bodies|broadphase [iters]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    which = sys.argv[1]
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    import torch
+    from clap_amd import _lib, animation, particles, physics, synth
+    _lib.check(_lib.lib().clapgpu_init(0), "init")
+    dev = "cuda:0"
+    if which in ("pose", "skin"):
+        J, n_chars, vpc = 64, 50_000, 200
+        sk = synth.skeleton(J, 8, seed=3)
+        an = synth.animation(J, 30, 2.0, seed=3)
+        ch = synth.characters(n_chars, J, seed=3)
+        mesh = synth.skinned_mesh(vpc, J, seed=3, copies=n_chars) if which == "skin" else None
+        vf = (np.arange(n_chars, dtype=np.int64) * vpc).astype(np.uint32) if mesh else None
+        vc = np.full(n_chars, vpc, np.uint32) if mesh else None
+        model = animation.SkinnedModel(sk, [an], mesh=mesh, device=dev)
+        cb = animation.CharacterBatch(model, n_chars, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
+        cb.set_frame_times(ch["phase"])
+        cb.pose_update()
+        fn = cb.pose_update if which == "pose" else cb.skin
+    elif which == "particles":
+        from oracle import binding as ob
+        ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
+        pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+        pb = particles.ParticleBatch(ps, pos, vel, st, dev)
+        view = np.eye(4, dtype=np.float32).ravel()
+        fn = lambda: pb.particles_update(view)
+    else:
+        b = synth.sphere_bodies(262_144, box=64.0, seed=4)
+        pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=dev)
+        fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.broadphase
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
