@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK = 0
 ERR_NOMEM = -1
@@ -24,6 +24,7 @@ ERR_UNKNOWN = -32
 E_VISIBLE = 1 << 0
 E_SKIP_CULLING = 1 << 14
 E_DIRTY = 1 << 16
+E_JOINT_ATTACHED = 1 << 17
 E_ALIVE = 1 << 31
 UPDATE_ALL_DIRTY = 1 << 0
 
@@ -43,6 +44,12 @@ class Frustum(C.Structure):
     _fields_ = [("planes", C.c_float * 24), ("corners", C.c_float * 32)]
 
 
+class BvQuery(C.Structure):
+    """clapgpu_bv_query (include/clapgpu.h)."""
+    _fields_ = [("cam_pos", C.c_float * 3), ("has_ctl", C.c_uint32), ("ctl_pos", C.c_float * 3),
+                ("ctl_entity", C.c_uint32), ("result", C.c_void_p)]
+
+
 class Entities(C.Structure):
     """clapgpu_entities (include/clapgpu.h)."""
     _fields_ = [("n", C.c_uint32), ("n_models", C.c_uint32),
@@ -50,7 +57,9 @@ class Entities(C.Structure):
                 ("model", C.c_void_p), ("model_table", C.c_void_p), ("flags", C.c_void_p),
                 ("seqs", C.c_void_p), ("mx", C.c_void_p), ("inv_mx", C.c_void_p),
                 ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p),
-                ("vis_row_pop", C.c_void_p)]
+                ("vis_row_pop", C.c_void_p), ("n_attach", C.c_uint32), ("pad", C.c_uint32),
+                ("attach", C.c_void_p), ("jt_pool", C.c_void_p), ("bind_pool", C.c_void_p),
+                ("attach_local", C.c_void_p), ("bv", C.POINTER(BvQuery))]
 
 
 class Particles(C.Structure):

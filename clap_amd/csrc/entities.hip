@@ -32,6 +32,15 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     float          *center;
     uint64_t       *vis_mask;
     uint8_t        *vis_row_pop;
+    uint32_t        n_attach;
+    const clapgpu_attach *attach;
+    const float    *jt_pool;
+    const float    *bind_pool;
+    float          *attach_local;    // [n_attach] mat4 = (jt * bind) * local, written by k_attach_prepare
+    // camera bounding-volume query (bv_result == nullptr: off)
+    float           bv_cam[3], bv_ctl[3];
+    uint32_t        bv_has_ctl, bv_ctl_entity;
+    unsigned long long *bv_result;
 };
 
 constexpr int ENT_BLOCK = 256;
@@ -66,6 +75,22 @@ __device__ __forceinline__ RowIn load_row(const EntK &e, const int lane, const u
     r.ps = e.pos_scale[i];
     r.q = e.rot[i];
     return r;
+}
+
+// joint attachment of entity i: binary search of the (short, sorted) table; index or -1
+__device__ __forceinline__ int find_attach(const EntK &e, uint32_t i)
+{
+    uint32_t lo = 0, hi = e.n_attach;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (e.attach[mid].entity < i) lo = mid + 1; else hi = mid;
+    }
+    return (lo < e.n_attach && e.attach[lo].entity == i) ? (int)lo : -1;
+}
+
+__device__ __forceinline__ bool point_in_box(const float (&p)[3], const float (&bb)[6])
+{
+    return p[0] >= bb[0] && p[0] <= bb[3] && p[1] >= bb[1] && p[1] <= bb[4] && p[2] >= bb[2] && p[2] <= bb[5];
 }
 
 // One 64-entity row (= one vis_mask word) processed by one wave.
@@ -109,8 +134,12 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
 
     // parent_transform_apply's skip test (model.c:1609-1611) / default_update's dirty test (1667)
     bool rebuild = alive;
+    int at = -1;
+    if (alive && p >= 0 && (fl & CLAPGPU_E_JOINT_ATTACHED) && e.n_attach)
+        at = find_attach(e, i);
+    const bool attached = at >= 0;
     if (p >= 0) {
-        if (pseq == parent_seq_now && !dirty)
+        if (!attached && pseq == parent_seq_now && !dirty)     // joint attachments are rebuilt every frame
             rebuild = false;
         else
             pseq = parent_seq_now;
@@ -125,11 +154,14 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
         const float4 lo = e.model_table[2 * in.mi];              // min.xyz, skip_aabb bits
         const float4 hi = e.model_table[2 * in.mi + 1];          // max.xyz, 0
         float local_mx[16];
-        lmd::trs(local_mx, in.ps.x, in.ps.y, in.ps.z, in.ps.w, in.q.x, in.q.y, in.q.z, in.q.w);
+        if (attached)                                            // (jt * bind) * local from k_attach_prepare
+            load_mat4(local_mx, e.attach_local + 16 * (size_t)at);
+        else
+            lmd::trs(local_mx, in.ps.x, in.ps.y, in.ps.z, in.ps.w, in.q.x, in.q.y, in.q.z, in.q.w);
         if (p >= 0) {
             if (!parent_in_regs)
                 load_mat4(pm, e.mx + 16 * (size_t)p);            // stored matrix of a parent not rebuilt here
-            lmd::mul(mx, pm, local_mx);                          // model.c:1625
+            lmd::mul(mx, pm, local_mx);                          // model.c:1625 / 1640
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
@@ -194,12 +226,39 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
         for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
     }
 
-    if (CULL) {
-        // Entities that were not rebuilt (or whose model skips AABBs) are culled on their stored box.
+    const bool want_bv = e.bv_result != nullptr;
+    if (CULL || want_bv) {
+        // Entities that were not rebuilt (or whose model skips AABBs) use their stored box.
         if (in_range && !(rebuild && has_aabb)) {
 #pragma unroll
             for (int k = 0; k < 6; k++) bb[k] = e.aabb[6 * (size_t)i + k];
         }
+    }
+    if (want_bv) {                                               // model.c:1703-1713
+        bool inside = in_range && (fl & CLAPGPU_E_ALIVE) && point_in_box(e.bv_cam, bb);
+        if (!inside && e.bv_has_ctl)
+            inside = in_range && (fl & CLAPGPU_E_ALIVE) && point_in_box(e.bv_ctl, bb);
+        if (inside && e.bv_has_ctl && i == e.bv_ctl_entity)
+            inside = false;
+        if (__ballot(inside)) {                                  // rare: almost no box contains the camera
+            unsigned long long key = 0;
+            if (inside) {
+                const float4 lo = e.model_table[2 * in.mi], hi = e.model_table[2 * in.mi + 1];
+                const float X = fabsf(hi.x - lo.x) * in.ps.w, Y = fabsf(hi.y - lo.y) * in.ps.w,
+                            Z = fabsf(hi.z - lo.z) * in.ps.w;  // entity3d_aabb_X/Y/Z (model.c:1185-1198)
+                const float vol = X * Y * Z;
+                key = ((unsigned long long)__float_as_uint(vol) << 32) | (0xFFFFFFFFu - i);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off);
+                key = o > key ? o : key;
+            }
+            if (lane == 0 && key)
+                atomicMax(e.bv_result, key);
+        }
+    }
+    if (CULL) {
         bool vis = in_range && (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);   // model.c:959-965
         if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
             vis = lmd::aabb_in_frustum_fast(fr, bb);                                  // model.c:967-971
@@ -209,6 +268,27 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
             e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);       // feeds the single-launch compaction
         }
     }
+}
+
+// model.c:1618-1622 + 1633-1639: local = TRS of the attached entity, joint_mx = joint_transforms[j] * bind[j],
+// attach_local = joint_mx * local.  One lane per attachment (there are few).
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_attach_prepare(EntK e)
+{
+    const uint32_t k = blockIdx.x * ENT_BLOCK + threadIdx.x;
+    if (k >= e.n_attach) return;
+    const clapgpu_attach at = e.attach[k];
+    const float4 ps = e.pos_scale[at.entity], q = e.rot[at.entity];
+    float local_mx[16], jt[16], bd[16], joint_mx[16], out[16];
+    lmd::trs(local_mx, ps.x, ps.y, ps.z, ps.w, q.x, q.y, q.z, q.w);
+    load_mat4(jt, e.jt_pool + 16 * (size_t)at.jt);
+    load_mat4(bd, e.bind_pool + 16 * (size_t)at.bind);
+    lmd::mul(joint_mx, jt, bd);
+    lmd::mul(out, joint_mx, local_mx);
+    float4 *d = reinterpret_cast<float4 *>(e.attach_local + 16 * (size_t)k);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        d[c] = make_float4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3]);
 }
 
 constexpr int LDS_F4_PER_WAVE = 512;                             // 8 KiB
@@ -448,6 +528,21 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     k.center = e->center;
     k.vis_mask = e->vis_mask;
     k.vis_row_pop = e->vis_row_pop;
+    k.n_attach = (e->attach && e->jt_pool && e->bind_pool && e->attach_local) ? e->n_attach : 0;
+    k.attach = e->attach;
+    k.attach_local = e->attach_local;
+    k.jt_pool = e->jt_pool;
+    k.bind_pool = e->bind_pool;
+    k.bv_result = nullptr;
+    k.bv_has_ctl = k.bv_ctl_entity = 0;
+    for (int a = 0; a < 3; a++) k.bv_cam[a] = k.bv_ctl[a] = 0.f;
+    if (e->bv && e->bv->result) {
+        memcpy(k.bv_cam, e->bv->cam_pos, 12);
+        memcpy(k.bv_ctl, e->bv->ctl_pos, 12);
+        k.bv_has_ctl = e->bv->has_ctl;
+        k.bv_ctl_entity = e->bv->ctl_entity;
+        k.bv_result = reinterpret_cast<unsigned long long *>(e->bv->result);
+    }
     return k;
 }
 
@@ -496,6 +591,16 @@ static int check_entities(const clapgpu_entities *e, bool need_mask)
     return CLAPGPU_OK;
 }
 
+static int prepare_attachments(void *stream, const EntK &k)
+{
+    if (!k.n_attach)
+        return CLAPGPU_OK;
+    hipLaunchKernelGGL(k_attach_prepare, dim3((k.n_attach + ENT_BLOCK - 1) / ENT_BLOCK), dim3(ENT_BLOCK), 0,
+                       as_stream(stream), k);
+    CLAPGPU_LAUNCH_CHECK("k_attach_prepare");
+    return CLAPGPU_OK;
+}
+
 static int launch_level(void *stream, const EntK &k, uint32_t first, uint32_t count, uint32_t mode,
                         const clapgpu_frustum *frustum)
 {
@@ -521,7 +626,10 @@ extern "C" int clapgpu_entities_update_level(void *stream, const clapgpu_entitie
         return CLAPGPU_ERR_OUT_OF_BOUNDS;
     if (!count)
         return CLAPGPU_OK;
-    return launch_level(stream, to_kernel_args(e), first, count, mode, frustum);
+    const EntK k = to_kernel_args(e);
+    rc = prepare_attachments(stream, k);
+    if (rc) return rc;
+    return launch_level(stream, k, first, count, mode, frustum);
 }
 
 extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
@@ -541,6 +649,10 @@ extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
             return CLAPGPU_ERR_INVALID_ARGUMENTS;
 
     const EntK k = to_kernel_args(e);
+    if (k.bv_result)
+        CLAPGPU_HIP(hipMemsetAsync(k.bv_result, 0, sizeof(uint64_t), as_stream(stream)));
+    rc = prepare_attachments(stream, k);
+    if (rc) return rc;
     for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t first = level_start[l], count = level_start[l + 1] - first;
         if (!count)
@@ -563,6 +675,10 @@ extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entitie
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const lmd::FrustumK fr = make_frustum_k(frustum);
     const EntK k = to_kernel_args(e);
+    if (k.bv_result)
+        CLAPGPU_HIP(hipMemsetAsync(k.bv_result, 0, sizeof(uint64_t), as_stream(stream)));
+    rc = prepare_attachments(stream, k);
+    if (rc) return rc;
     const uint32_t per_block = ENT_BLOCK / WAVE;
     const dim3 grid((n_tiles + per_block - 1) / per_block), block(ENT_BLOCK);
     if (frustum)

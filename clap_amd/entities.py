@@ -98,6 +98,45 @@ class EntityBatch:
             aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr(),
             vis_row_pop=self.vis_row_pop.data_ptr())
 
+    # ---- optional inputs ---------------------------------------------------------------
+    def set_attachments(self, attach, jt_pool, bind_pool):
+        """Joint attachments (model.c:1626-1641).  attach: structured array (entity, jt, bind, pad)
+        sorted by entity; jt_pool: device tensor of mat4 (e.g. CharacterBatch.joint_transforms);
+        bind_pool: mat4 array.  Flags the entities CLAPGPU_E_JOINT_ATTACHED."""
+        a = np.ascontiguousarray(attach)
+        assert np.all(np.diff(a["entity"].astype(np.int64)) > 0), "attach table must be sorted by entity"
+        self._attach = torch.from_numpy(a.view(np.uint8).reshape(-1, 16).copy()).to(self.device)
+        self._jt_pool = jt_pool if torch.is_tensor(jt_pool) else torch.from_numpy(
+            np.ascontiguousarray(jt_pool, np.float32)).to(self.device)
+        self._bind_pool = torch.from_numpy(np.ascontiguousarray(bind_pool, np.float32)).to(self.device)
+        idx = torch.from_numpy(a["entity"].astype(np.int64)).to(self.device)
+        self.flags[idx] |= np.int32(_lib.E_JOINT_ATTACHED)
+        self._desc.n_attach = a.shape[0]
+        self._desc.attach = self._attach.data_ptr()
+        self._desc.jt_pool = self._jt_pool.data_ptr()
+        self._desc.bind_pool = self._bind_pool.data_ptr()
+        self._attach_local = torch.zeros((a.shape[0], 16), dtype=torch.float32, device=self.device)
+        self._desc.attach_local = self._attach_local.data_ptr()
+
+    def set_bv_query(self, cam_pos, ctl_pos=None, ctl_entity=0):
+        """Ask the next updates for default_update's camera bounding-volume pick."""
+        self.bv_result = torch.zeros(1, dtype=torch.int64, device=self.device)
+        q = _lib.BvQuery()
+        q.cam_pos[:] = [float(v) for v in cam_pos]
+        q.has_ctl = 0 if ctl_pos is None else 1
+        q.ctl_pos[:] = [0.0, 0.0, 0.0] if ctl_pos is None else [float(v) for v in ctl_pos]
+        q.ctl_entity = int(ctl_entity)
+        q.result = self.bv_result.data_ptr()
+        self._bv = q
+        self._desc.bv = C.pointer(q)
+
+    def camera_bv(self):
+        """(entity index or -1, volume) of the last update's pick (host sync)."""
+        key = int(self.bv_result.item()) & 0xFFFFFFFFFFFFFFFF
+        if key == 0:
+            return -1, 0.0
+        return 0xFFFFFFFF - (key & 0xFFFFFFFF), float(np.asarray([key >> 32], np.uint32).view(np.float32)[0])
+
     # ---- reference-named operations -------------------------------------------------
     def mq_update(self, frustum=None, all_dirty=False):
         """mq_update over default_update entities; with `frustum` the cull of

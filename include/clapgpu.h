@@ -40,6 +40,7 @@ extern "C" {
 #define CLAPGPU_E_VISIBLE       (1u << 0)    /* ENTITY3D_VISIBLE */
 #define CLAPGPU_E_SKIP_CULLING  (1u << 14)   /* ENTITY3D_SKIP_CULLING */
 #define CLAPGPU_E_DIRTY         (1u << 16)   /* mirror of transform_t.updated (transform.h:11) */
+#define CLAPGPU_E_JOINT_ATTACHED (1u << 17) /* e->parent_joint != JOINT_TYPE_MAX (model.h:386-403); see clapgpu_attach */
 #define CLAPGPU_E_ALIVE         (1u << 31)   /* ENTITY3D_ALIVE */
 
 /* ---- runtime ---- */
@@ -104,6 +105,36 @@ void clapgpu_frustum_calc(const float view_mx[16], const float proj_mx[16],
  *            vis_row_pop[ceil(n/64)] popcount of each vis_mask word (uint8); allocate the
  *                                  array rounded up to a multiple of 16 bytes, 16-B aligned
  */
+/*
+ * Joint attachment (parent_transform_apply's second flavour, model.c:1626-1641): entity `entity`
+ * (flag CLAPGPU_E_JOINT_ATTACHED) rides mx = parent.mx * ((jt_pool[jt] * bind_pool[bind]) * local)
+ * where jt_pool[jt] is the parent's joint_transforms[parent_joint] of THIS frame and
+ * bind_pool[bind] that joint's bind matrix; it is rebuilt every frame (never skipped).  Launch
+ * order is the caller's: parents' entity update -> clapgpu_pose_update -> the update of the
+ * tiles holding attached subtrees.  The table is sorted by `entity`.  (In the reference a
+ * resolved joint index equal to JOINT_TYPE_MAX (6) is indistinguishable from "no joint",
+ * model.c:1609,1624: do not flag such an entity.)
+ */
+typedef struct clapgpu_attach {
+    uint32_t entity, jt, bind, pad;
+} clapgpu_attach;
+
+/*
+ * default_update's camera bounding-volume pick (model.c:1703-1713, consumed by
+ * scene_camera_calc, scene.c:1018-1038): among ALIVE entities whose world AABB contains the
+ * camera position or the control entity's position (except the control entity itself) the one of
+ * largest volume (|model dx| scale)(|model dy| scale)(|model dz| scale).
+ * *result (device uint64, zeroed by the update call) = float bits of the volume << 32 |
+ * (0xFFFFFFFF - entity index), 0 if none: the largest key is the first entity of largest volume.
+ */
+typedef struct clapgpu_bv_query {
+    float     cam_pos[3];
+    uint32_t  has_ctl;
+    float     ctl_pos[3];
+    uint32_t  ctl_entity;
+    uint64_t *result;
+} clapgpu_bv_query;
+
 typedef struct clapgpu_entities {
     uint32_t        n;
     uint32_t        n_models;
@@ -120,6 +151,14 @@ typedef struct clapgpu_entities {
     float          *center;
     uint64_t       *vis_mask;
     uint8_t        *vis_row_pop;
+    /* optional (zero / NULL when unused) */
+    uint32_t        n_attach;
+    uint32_t        pad;
+    const clapgpu_attach *attach;        /* device, sorted by entity */
+    const float    *jt_pool;             /* device mat4[]: joint_transforms of the characters */
+    const float    *bind_pool;           /* device mat4[]: model_joint.bind */
+    float          *attach_local;        /* device work space, n_attach mat4 */
+    const clapgpu_bv_query *bv;          /* HOST pointer */
 } clapgpu_entities;
 
 /* mode bits for clapgpu_entities_update */

@@ -78,6 +78,13 @@ def _declare(L):
     L.clapo_entities_update.argtypes = [C.c_uint32, F32P, F32P, I32P, I32P, F32P, U8P,
                                         U32P, U32P, F32P, F32P, F32P, F32P]
     L.clapo_entities_update.restype = C.c_uint32
+    L.clapo_entities_update_range.argtypes = [C.c_uint32, C.c_uint32, F32P, F32P, I32P, I32P, F32P, U8P,
+                                              U32P, U32P, F32P, F32P, F32P, F32P, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
+    L.clapo_entities_update_range.restype = C.c_uint32
+    L.clapo_camera_bv.argtypes = [C.c_uint32, U32P, F32P, F32P, I32P, F32P, F32P, C.c_void_p, C.c_int32,
+                                  C.POINTER(C.c_float)]
+    L.clapo_camera_bv.restype = C.c_int32
     L.clapo_entities_cull.argtypes = [C.c_uint32, U32P, F32P, C.POINTER(Frustum), C.c_void_p, C.c_void_p]
     L.clapo_entities_cull.restype = C.c_uint32
 
@@ -135,6 +142,31 @@ def entities_update(scene, st):
     return lib().clapo_entities_update(int(scene["n"]), scene["pos_scale"], scene["rot"], scene["parent"],
                                        scene["model"], scene["model_aabb"], scene["model_skip"],
                                        st["flags"], st["seqs"], st["mx"], st["inv_mx"], st["aabb"], st["center"])
+
+
+ATTACH_DTYPE = np.dtype([("entity", np.uint32), ("jt", np.uint32), ("bind", np.uint32), ("pad", np.uint32)])
+
+
+def entities_update_range(scene, st, first, count, attach=None, jt_pool=None, bind_pool=None):
+    """clapo_entities_update over [first, first+count) with joint attachments
+    (attach: ATTACH_DTYPE array sorted by entity; pools: mat4 arrays)."""
+    na = 0 if attach is None else attach.shape[0]
+    keep = [np.ascontiguousarray(a) if a is not None else None for a in (attach, jt_pool, bind_pool)]
+    ptr = [a.ctypes.data if a is not None else None for a in keep]
+    return lib().clapo_entities_update_range(first, count, scene["pos_scale"], scene["rot"], scene["parent"],
+                                             scene["model"], scene["model_aabb"], scene["model_skip"],
+                                             st["flags"], st["seqs"], st["mx"], st["inv_mx"], st["aabb"], st["center"],
+                                             na, ptr[0], ptr[1], ptr[2])
+
+
+def camera_bv(scene, st, cam_pos, ctl_pos=None, ctl_entity=-1):
+    vol = C.c_float(0)
+    cp = np.ascontiguousarray(cam_pos, np.float32)
+    ctl = np.ascontiguousarray(ctl_pos, np.float32) if ctl_pos is not None else None
+    i = lib().clapo_camera_bv(int(scene["n"]), st["flags"], st["aabb"], scene["pos_scale"], scene["model"],
+                              scene["model_aabb"], cp, ctl.ctypes.data if ctl is not None else None, ctl_entity,
+                              C.byref(vol))
+    return i, vol.value
 
 
 def entities_cull(n, flags, aabb, fr):

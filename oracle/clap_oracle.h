@@ -37,6 +37,7 @@ extern "C" {
 #define CLAPO_E_VISIBLE       (1u << 0)
 #define CLAPO_E_SKIP_CULLING  (1u << 14)
 #define CLAPO_E_DIRTY         (1u << 16)   /* mirror of transform_t.updated (transform.h:11) */
+#define CLAPO_E_JOINT_ATTACHED (1u << 17) /* e->parent_joint != JOINT_TYPE_MAX (model.h:386-403) */
 #define CLAPO_E_ALIVE         (1u << 31)
 
 typedef struct clapo_frustum {
@@ -76,6 +77,33 @@ uint32_t clapo_entities_update(uint32_t n,
                                const float *model_aabb, const uint8_t *model_skip_aabb,
                                uint32_t *flags, uint32_t *seqs,
                                float *mx, float *inv_mx, float *aabb, float *center);
+
+/* joint attachment of entity `entity` (flag CLAPO_E_JOINT_ATTACHED): it rides joint matrix
+ * jt_pool[jt] * bind_pool[bind] of its parent (model.c:1626-1641) and is rebuilt every frame */
+typedef struct clapo_attach {
+    uint32_t entity, jt, bind, pad;
+} clapo_attach;
+
+/* clapo_entities_update restricted to [first, first+count) and aware of joint attachments
+ * (attach sorted by entity; jt_pool / bind_pool are arrays of mat4) */
+uint32_t clapo_entities_update_range(uint32_t first, uint32_t count,
+                                     const float *pos_scale, const float *rot,
+                                     const int32_t *parent, const int32_t *model,
+                                     const float *model_aabb, const uint8_t *model_skip_aabb,
+                                     uint32_t *flags, uint32_t *seqs,
+                                     float *mx, float *inv_mx, float *aabb, float *center,
+                                     uint32_t n_attach, const clapo_attach *attach,
+                                     const float *jt_pool, const float *bind_pool);
+
+/*
+ * default_update's camera bounding-volume pick (model.c:1703-1713): among ALIVE entities whose
+ * world AABB contains the camera position or (if ctl_pos) the control entity's position, other
+ * than the control entity itself, the first one of largest volume
+ * (|model dx| * scale) * (|model dy| * scale) * (|model dz| * scale).  Returns its index or -1.
+ */
+int32_t clapo_camera_bv(uint32_t n, const uint32_t *flags, const float *aabb, const float *pos_scale,
+                        const int32_t *model, const float *model_aabb,
+                        const float cam_pos[3], const float *ctl_pos, int32_t ctl_entity, float *volume);
 
 /*
  * _models_render's per-entity draw predicate (model.c:959-973):

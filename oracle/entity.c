@@ -142,16 +142,26 @@ int clapo_aabb_in_frustum(const clapo_frustum *f, const float aabb[6])
     return 1;
 }
 
-uint32_t clapo_entities_update(uint32_t n,
-                               const float *pos_scale, const float *rot,
-                               const int32_t *parent, const int32_t *model,
-                               const float *model_aabb, const uint8_t *model_skip_aabb,
-                               uint32_t *flags, uint32_t *seqs,
-                               float *mx, float *inv_mx, float *aabb, float *center)
+static const clapo_attach *find_attach(uint32_t n_attach, const clapo_attach *attach, uint32_t entity)
+{
+    for (uint32_t k = 0; k < n_attach; k++)
+        if (attach[k].entity == entity)
+            return &attach[k];
+    return NULL;
+}
+
+uint32_t clapo_entities_update_range(uint32_t first, uint32_t count,
+                                     const float *pos_scale, const float *rot,
+                                     const int32_t *parent, const int32_t *model,
+                                     const float *model_aabb, const uint8_t *model_skip_aabb,
+                                     uint32_t *flags, uint32_t *seqs,
+                                     float *mx, float *inv_mx, float *aabb, float *center,
+                                     uint32_t n_attach, const clapo_attach *attach,
+                                     const float *jt_pool, const float *bind_pool)
 {
     uint32_t rebuilt = 0;
 
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = first; i < first + count; i++) {
         if (!(flags[i] & CLAPO_E_ALIVE))          /* mq_update: model.c:1955 */
             continue;
 
@@ -160,17 +170,26 @@ uint32_t clapo_entities_update(uint32_t n,
         uint16_t pseq = (uint16_t)(seqs[i] >> 16);
         int32_t p = parent[i];
         float *m = mx + 16 * (size_t)i;
+        const clapo_attach *at = (p >= 0 && (flags[i] & CLAPO_E_JOINT_ATTACHED))
+                                 ? find_attach(n_attach, attach, i) : NULL;
 
         if (p >= 0) {
-            /* parent_transform_apply, jointless attachment: model.c:1609-1625 */
+            /* parent_transform_apply: model.c:1609-1641; joint attachments never skip */
             uint16_t parent_seq_now = (uint16_t)(seqs[p] & 0xffff);
-            if (pseq == parent_seq_now && !dirty)
+            if (!at && pseq == parent_seq_now && !dirty)
                 continue;
             pseq = parent_seq_now;
             seq++;
             float local[16];
             clapo_trs_matrix(pos_scale + 4 * (size_t)i, rot + 4 * (size_t)i, local);
-            lm_m4_mul(m, mx + 16 * (size_t)p, local);
+            if (at) {
+                float joint_mx[16];                                   /* model.c:1636-1640 */
+                lm_m4_mul(joint_mx, jt_pool + 16 * (size_t)at->jt, bind_pool + 16 * (size_t)at->bind);
+                lm_m4_mul(m, joint_mx, local);
+                lm_m4_mul(m, mx + 16 * (size_t)p, m);
+            } else {
+                lm_m4_mul(m, mx + 16 * (size_t)p, local);             /* model.c:1625 */
+            }
         } else {
             if (!dirty)                             /* model.c:1667 */
                 continue;
@@ -187,6 +206,48 @@ uint32_t clapo_entities_update(uint32_t n,
         rebuilt++;
     }
     return rebuilt;
+}
+
+uint32_t clapo_entities_update(uint32_t n,
+                               const float *pos_scale, const float *rot,
+                               const int32_t *parent, const int32_t *model,
+                               const float *model_aabb, const uint8_t *model_skip_aabb,
+                               uint32_t *flags, uint32_t *seqs,
+                               float *mx, float *inv_mx, float *aabb, float *center)
+{
+    return clapo_entities_update_range(0, n, pos_scale, rot, parent, model, model_aabb, model_skip_aabb,
+                                       flags, seqs, mx, inv_mx, aabb, center, 0, NULL, NULL, NULL);
+}
+
+/* model.c:1703-1713 + util.h:157-165 + model.c:433-447,1185-1198 */
+int32_t clapo_camera_bv(uint32_t n, const uint32_t *flags, const float *aabb, const float *pos_scale,
+                        const int32_t *model, const float *model_aabb,
+                        const float cam_pos[3], const float *ctl_pos, int32_t ctl_entity, float *volume)
+{
+    int32_t bv = -1;
+    float bv_volume = 0.f;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!(flags[i] & CLAPO_E_ALIVE))
+            continue;
+        const float *b = aabb + 6 * (size_t)i;
+        int inside = cam_pos[0] >= b[0] && cam_pos[0] <= b[3] && cam_pos[1] >= b[1] && cam_pos[1] <= b[4] &&
+                     cam_pos[2] >= b[2] && cam_pos[2] <= b[5];
+        if (!inside && ctl_pos)
+            inside = ctl_pos[0] >= b[0] && ctl_pos[0] <= b[3] && ctl_pos[1] >= b[1] && ctl_pos[1] <= b[4] &&
+                     ctl_pos[2] >= b[2] && ctl_pos[2] <= b[5];
+        if (!inside || (int32_t)i == ctl_entity)
+            continue;
+        const float *ma = model_aabb + 6 * (size_t)model[i];
+        const float s = pos_scale[4 * (size_t)i + 3];
+        float X = (float)fabs(ma[3] - ma[0]) * s, Y = (float)fabs(ma[4] - ma[1]) * s, Z = (float)fabs(ma[5] - ma[2]) * s;
+        float vol = X * Y * Z;
+        if (bv < 0 || vol > bv_volume) {
+            bv = (int32_t)i;
+            bv_volume = vol;
+        }
+    }
+    if (volume) *volume = bv_volume;
+    return bv;
 }
 
 uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aabb,

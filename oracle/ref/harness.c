@@ -11,10 +11,16 @@
  * channels_transform, one_joint_transform, particles_update,
  * subview_calc_frustum) are callable.  Nothing is copied.
  *
- * One test double is defined here: renderer_get_caps().  The reference's
- * definition (render-common.c:65-68) lives in a TU that needs GL headers this
- * image lacks; on this path exactly one field of its result is read
- * (ndc_z_zero_one, view.c:267), which the job file supplies.
+ * Two test doubles are defined here, both plain accessors whose real definitions live in
+ * translation units that cannot be built in this image:
+ *   renderer_get_caps()        (render-common.c:65-68, needs GL headers): on this path exactly
+ *                              one field of its result is read (ndc_z_zero_one, view.c:267),
+ *                              which the job file supplies;
+ *   clap_get_render_options()  (clap.c, the frame driver): default_update reads
+ *                              overlay_draws_enabled (model.c:1719) when given a scene; the
+ *                              double returns zeroed options (no debug overlay), which is what
+ *                              a CONFIG_FINAL build runs with.  Only used when a job asks for
+ *                              the camera bounding-volume pick (model.c:1703-1713).
  *
  * Usage: clap_ref <command> <in.clpio> <out.clpio>
  *   entities   default_update x frames, then view_entity_in_frustum
@@ -34,6 +40,12 @@
 
 const char *build_date = "oracle";
 const char *clap_version = "oracle";
+
+static render_options harness_ropts;
+render_options *clap_get_render_options(struct clap_context *ctx)
+{
+    return &harness_ropts;
+}
 
 static renderer_caps harness_caps;
 const renderer_caps *renderer_get_caps(renderer_t *r)
@@ -216,6 +228,47 @@ static int cmd_entities(struct arrset *in, struct arrset *out)
     world_make(&w, n, n_models, model_aabb, model_skip, model_of, parent, flags);
     view_setup(&view, in, out);
 
+    /* optional: joint attachments (model.c:1626-1641).  The parent of attach_entity[k] gets its own
+     * model3d whose joint attach_joint[k] has bind = attach_bind[k], and joint_transforms[attach_joint[k]]
+     * = attach_jt[k] -- exactly the two matrices parent_transform_apply reads. */
+    if (arr_has(in, "attach_entity")) {
+        uint64_t nb;
+        uint32_t *a_ent = arr_get(in, "attach_entity", &nb);
+        uint32_t na = nb / 4;
+        int32_t *a_joint = arr_get(in, "attach_joint", NULL);
+        float *a_jt = arr_get(in, "attach_jt", NULL), *a_bind = arr_get(in, "attach_bind", NULL);
+        for (uint32_t k = 0; k < na; k++) {
+            entity3d *e = &w.e[a_ent[k]], *par = e->parent;
+            if (!par->joint_transforms) {
+                model3d *pm = calloc(1, sizeof(*pm));
+                model3dtx *ptx = calloc(1, sizeof(*ptx));
+                *pm = *par->txmodel->model;
+                pm->nr_joints = JOINTS_MAX;
+                pm->joints = calloc(JOINTS_MAX, sizeof(struct model_joint));
+                ptx->model = pm;
+                par->txmodel = ptx;
+                par->joint_transforms = calloc(JOINTS_MAX, sizeof(mat4x4));
+            }
+            memcpy(par->joint_transforms[a_joint[k]], a_jt + 16 * k, 64);
+            memcpy(par->txmodel->model->joints[a_joint[k]].bind, a_bind + 16 * k, 64);
+            e->parent_joint = a_joint[k];
+        }
+    }
+    /* optional: camera bounding-volume pick needs a scene (model.c:1697-1713) */
+    struct scene *scene = NULL;
+    int32_t *o_bv = NULL;
+    float *o_bv_vol = NULL;
+    if (arr_has(in, "bv_cam_pos")) {
+        scene = calloc(1, sizeof(*scene));
+        scene->camera = &scene->cameras[0];
+        transform_init(&scene->camera->xform);
+        transform_set_pos(&scene->camera->xform, arr_get(in, "bv_cam_pos", NULL));
+        int32_t ctl = *(int32_t *)arr_get(in, "bv_ctl", NULL);
+        scene->control = ctl >= 0 ? &w.e[ctl] : NULL;
+        o_bv = arr_add(out, "bv", (uint64_t)frames * 4);
+        o_bv_vol = arr_add(out, "bv_volume", (uint64_t)frames * 4);
+    }
+
     float *o_mx = arr_add(out, "mx", (uint64_t)frames * n * 64);
     float *o_inv = arr_add(out, "inv_mx", (uint64_t)frames * n * 64);
     float *o_aabb = arr_add(out, "aabb", (uint64_t)frames * n * 24);
@@ -235,9 +288,15 @@ static int cmd_entities(struct arrset *in, struct arrset *out)
             e->scale = pos_scale[4 * k + 3];
         }
         /* mq_update (model.c:1953): ALIVE entities, list order == index order */
+        if (scene)
+            scene->camera->bv = NULL;                                  /* scene_camera_calc, scene.c:1018-1019 */
         for (uint32_t i = 0; i < n; i++)
             if (entity3d_matches(&w.e[i], ENTITY3D_ALIVE))
-                entity3d_update(&w.e[i], NULL);
+                entity3d_update(&w.e[i], scene);
+        if (scene) {
+            o_bv[f] = scene->camera->bv ? (int32_t)(scene->camera->bv - w.e) : -1;
+            o_bv_vol[f] = scene->camera->bv ? scene->camera->bv_volume : 0.f;
+        }
         for (uint32_t i = 0; i < n; i++) {
             size_t k = (size_t)f * n + i;
             entity3d *e = &w.e[i];

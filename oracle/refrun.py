@@ -39,11 +39,13 @@ def _camera_arrays(cam):
     return {k: cam[k] for k in ("cam_pos", "cam_quat", "persp", "ndc_z_zero_one")}
 
 
-def entities(scene, cam, frames=None):
+def entities(scene, cam, frames=None, attach=None, bv=None):
     """Run default_update x frames + view_entity_in_frustum on the reference.
 
     frames: list of (pos_scale, rot, dirty) per frame; default = one frame, the
     scene's own arrays with every entity dirty.
+    attach: dict(entity u32[k], joint i32[k], jt f32[k,16], bind f32[k,16]) joint attachments.
+    bv: dict(cam_pos f32[3], ctl int) -> also returns the camera bounding-volume pick per frame.
     """
     n = int(scene["n"])
     if frames is None:
@@ -56,9 +58,17 @@ def entities(scene, cam, frames=None):
                   parent=scene["parent"], model=scene["model"], model_aabb=scene["model_aabb"],
                   model_skip=scene["model_skip"], flags=scene["flags"])
     arrays.update(_camera_arrays(cam))
+    if attach is not None:
+        arrays.update(attach_entity=np.asarray(attach["entity"], np.uint32), attach_joint=np.asarray(attach["joint"], np.int32),
+                      attach_jt=np.asarray(attach["jt"], np.float32), attach_bind=np.asarray(attach["bind"], np.float32))
+    if bv is not None:
+        arrays.update(bv_cam_pos=np.asarray(bv["cam_pos"], np.float32), bv_ctl=np.asarray([bv["ctl"]], np.int32))
     out = run("entities", arrays)
     A = clpio.as_array
-    return dict(mx=A(out["mx"], np.float32, (f, n, 16)), inv_mx=A(out["inv_mx"], np.float32, (f, n, 16)),
+    extra = {}
+    if bv is not None:
+        extra = dict(bv=A(out["bv"], np.int32), bv_volume=A(out["bv_volume"], np.float32))
+    return dict(**extra, mx=A(out["mx"], np.float32, (f, n, 16)), inv_mx=A(out["inv_mx"], np.float32, (f, n, 16)),
                 aabb=A(out["aabb"], np.float32, (f, n, 6)), center=A(out["center"], np.float32, (f, n, 3)),
                 seqs=A(out["seqs"], np.uint32, (f, n)), visible=A(out["visible"], np.uint8, (f, n)),
                 view_mx=A(out["view_mx"], np.float32), proj_mx=A(out["proj_mx"], np.float32),

@@ -44,6 +44,32 @@ def entity_fixture(name, scene, cam, frames=None):
     save(name, **d)
 
 
+def attach_fixture(name):
+    """Joint attachments (model.c:1626-1641) + the camera bounding-volume pick (model.c:1703-1713)."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    scene = synth.pad_levels(synth.entities_forest(900, seed=13, n_models=3))
+    scene["model_skip"][:] = 0
+    kids = np.flatnonzero((scene["parent"] >= 0) & (scene["orig_of"] >= 0))
+    ent = np.sort(rng.choice(kids, 30, replace=False)).astype(np.uint32)
+    jt, bind = synth._rigid_mat4(rng, 30, 1.0), synth._rigid_mat4(rng, 30, 1.0)
+    joint = (np.arange(30) + 7).astype(np.int32)           # never JOINT_TYPE_MAX (6): the reference's "no joint"
+    cam = synth.camera(pos=(0, 5, 60))
+    plain = refrun.entities(scene, cam)
+    real = np.flatnonzero((scene["orig_of"] >= 0) & ((scene["flags"] & synth.E_ALIVE) != 0))
+    cam_pos = plain["center"][0][real[50]]                 # inside entity real[50]'s box
+    inside_of = real[120]                                  # the control entity (its own box is excluded)
+    frames = multi_frame(scene, seed=5, n_frames=3)
+    ref = refrun.entities(scene, cam, frames, attach=dict(entity=ent, joint=joint, jt=jt, bind=bind),
+                          bv=dict(cam_pos=cam_pos, ctl=int(inside_of)))
+    d = {"in_" + k: scene[k] for k in SCENE_KEYS}
+    d.update({"in_" + k: cam[k] for k in CAM_KEYS})
+    d.update(in_frames_pos_scale=np.stack([f[0] for f in frames]), in_frames_rot=np.stack([f[1] for f in frames]),
+             in_frames_dirty=np.stack([f[2] for f in frames]), in_attach_entity=ent, in_attach_jt=jt, in_attach_bind=bind,
+             in_bv_cam_pos=np.asarray(cam_pos, np.float32), in_bv_ctl=np.asarray([inside_of], np.int32))
+    d.update({"ref_" + k: v for k, v in ref.items()})
+    save(name, **d)
+
+
 def multi_frame(scene, seed, n_frames=3, dirty_frac=0.2):
     """Frames after the first move a random subset (exercises seq/parent_seq skipping)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -103,6 +129,7 @@ def main():
         t = np.stack([ch["phase"], (ch["phase"] * 1.7) % 2.3, np.full(12, 2.0, np.float32),
                       np.full(12, -0.25, np.float32), np.zeros(12, np.float32)]).astype(np.float32)
         pose_fixture(nm, sk, an, ch, t)
+    attach_fixture("attach_bv_frames")
     entity_fixture("entities_flat_c1", synth.entities_flat(512, seed=1234), cam)
     entity_fixture("entities_flat_euler", synth.entities_flat(512, seed=99, full_euler=True),
                    synth.camera(pos=(10, 5, -20), quat=synth.quat_from_euler_xyz(0.2, 2.5, -0.1),
