@@ -42,6 +42,8 @@ def parse():
                     help="tiles: subtree tiles, one launch for all levels; levels: level-major, one launch per level")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary workloads (pose/skinning, particles, bodies) reported under 'extra'")
+    ap.add_argument("--exchange", choices=["rccl", "c10d"], default="rccl",
+                    help="N > 1: call ncclAllGather directly (low host overhead) or through torch.distributed")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -171,8 +173,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     _lib.check(_lib.lib().clapgpu_init(local_rank), "clapgpu_init")
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CLAP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     raw = synth.entities_chains(args.chains, args.depth, seed=2 + rank)
@@ -183,18 +189,58 @@ def main():
     n_real, n_pad = batch.n_real, batch.n
     index_base = rank * n_pad
 
-    counts = torch.zeros(world, dtype=torch.int32, device=device)
-    gather_buf = torch.zeros(world * n_pad if world > 1 else 1, dtype=torch.int32, device=device)
+    # ---- N > 1: the path's only exchange.  Each rank's compacted visible set travels as its
+    # 1-bit-per-entity mask (one fixed-size RCCL allgather, no counts, no host sync); every rank
+    # then expands the gathered mask into the identical ascending global id list.  Exchange and
+    # expansion of frame f run on a side stream under the update of frame f + 1 (two mask buffers).
+    comm = torch.cuda.Stream(device=device) if use_dist else None
+    direct = None
+    if use_dist:
+        n_words = batch.vis_mask.numel()
+        masks = [batch.vis_mask, torch.zeros_like(batch.vis_mask)]
+        pops = [batch.vis_row_pop, torch.zeros_like(batch.vis_row_pop)]
+        g_mask = [torch.zeros(world * n_words, dtype=torch.int64, device=device) for _ in range(2)]
+        g_vis = [torch.zeros(world * n_pad, dtype=torch.int32, device=device) for _ in range(2)]
+        g_cnt = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+        g_scratch = torch.zeros(_lib.lib().clapgpu_visible_scratch_bytes(world * n_pad) // 4 + 4, dtype=torch.int32,
+                                device=device)
+        ev_upd = [torch.cuda.Event() for _ in range(2)]
+        ev_comm = [torch.cuda.Event() for _ in range(2)]
+        import ctypes as C
+        if args.exchange == "rccl":
+            try:
+                from clap_amd import rccl
+                direct = rccl.Communicator(rank, world, device)
+            except Exception as exc:                    # keep the run alive: c10d does the same exchange
+                print(f"[bench] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+    frame = [0]
 
     def step():
-        batch.mq_update(fr, all_dirty=True)             # one launch per hierarchy level
-        batch.compact_visible(index_base)               # ordered visible list (global ids)
-        if world > 1:
-            # the path's only exchange: every rank ends with all shards' visible ids (RCCL allgather)
-            shard.allgather_visible(batch.visible, batch.visible_count, world, counts, gather_buf)
+        if not use_dist:
+            batch.mq_update(fr, all_dirty=True)         # one launch for all hierarchy levels (tiles)
+            batch.compact_visible(index_base)           # ordered visible list
+            return
+        b = frame[0] & 1
+        frame[0] += 1
+        main = torch.cuda.current_stream()
+        main.wait_event(ev_comm[b])                     # the exchange that last read this mask buffer is done
+        batch.use_vis_buffers(masks[b], pops[b])
+        batch.mq_update(fr, all_dirty=True)
+        ev_upd[b].record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_upd[b])
+            if direct is not None:
+                direct.allgather_i64(masks[b], g_mask[b], comm)
+            else:
+                shard.allgather_visible_mask(masks[b], world, g_mask[b])
+            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(comm.cuda_stream), g_mask[b].data_ptr(), None,
+                                                    world * n_pad, 0, g_vis[b].data_ptr(), g_cnt[b].data_ptr(),
+                                                    g_scratch.data_ptr())
+            _lib.check(rc, "clapgpu_visible_compact(global)")
+            ev_comm[b].record(comm)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,13 +252,13 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_real * args.steps / elapsed
-    visible = int(batch.visible_count.item())
+    visible = int((g_cnt[(frame[0] - 1) & 1] if use_dist else batch.visible_count).item())
 
     # ---- roofline pass: HIP events around every launch of the dominant kernel (same stream) ----
     if batch.tiled:
@@ -247,9 +293,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
                                    f"{args.depth}, {args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
-                                   f"list ({visible} visible on rank 0)",
+                                   f"list ({visible} visible" + (" in the gathered global set)" if use_dist else ")"),
                        "entities_per_gpu": n_real, "levels": n_levels,
-                       "exchange": "RCCL allgather of visible ids" if world > 1 else "none"},
+                       "exchange": (("ncclAllGather (direct)" if direct is not None else "torch.distributed all_gather")
+                                    + " of the visibility mask + local expansion to global ids, overlapped with "
+                                    "the next frame's update") if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "kernel": kernel, "launches_per_step": launches,
@@ -264,8 +312,10 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
+        if direct is not None:
+            direct.destroy()
         dist.destroy_process_group()
 
 

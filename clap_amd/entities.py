@@ -98,6 +98,13 @@ class EntityBatch:
             aabb=self.aabb.data_ptr(), center=self.center.data_ptr(), vis_mask=self.vis_mask.data_ptr(),
             vis_row_pop=self.vis_row_pop.data_ptr())
 
+    def use_vis_buffers(self, vis_mask, vis_row_pop):
+        """Point the kernels at another visibility mask / popcount pair (double buffering while a
+        previous frame's mask is still being exchanged)."""
+        self.vis_mask, self.vis_row_pop = vis_mask, vis_row_pop
+        self._desc.vis_mask = vis_mask.data_ptr()
+        self._desc.vis_row_pop = vis_row_pop.data_ptr()
+
     # ---- optional inputs ---------------------------------------------------------------
     def set_attachments(self, attach, jt_pool, bind_pool):
         """Joint attachments (model.c:1626-1641).  attach: structured array (entity, jt, bind, pad)

@@ -40,6 +40,20 @@ def allgather_visible(visible, count, world, counts_buf=None, gather_buf=None, p
     return counts_buf, out.view(world, cap)
 
 
+def allgather_visible_mask(vis_mask, world, out=None, group=None):
+    """The compacted visible set as its 1-bit-per-entity mask: ONE fixed-size allgather, no counts,
+    no padding, no host sync, ~9x fewer bytes than the id list at 30 % visibility.  Rank r's
+    words land at out[r * n_words : (r + 1) * n_words], i.e. `out` is the visibility mask of the
+    global entity range when every shard has the same (padded) size; expanding it locally
+    (clapgpu_visible_compact over world * n entities) gives every rank the identical ascending
+    global id list."""
+    n_words = vis_mask.numel()
+    if out is None:
+        out = torch.empty(world * n_words, dtype=vis_mask.dtype, device=vis_mask.device)
+    dist.all_gather_into_tensor(out[:world * n_words], vis_mask, group=group)
+    return out
+
+
 def concat_visible(counts, gathered):
     """The global visible set as one ascending 1-D tensor (shards are ascending id ranges)."""
     c = counts.tolist()

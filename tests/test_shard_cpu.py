@@ -52,6 +52,18 @@ def _worker(rank, world, port, q):
         ob.entities_update(scene, st_all)
         vis_all, _m = ob.entities_cull(scene["n"], st_all["flags"], st_all["aabb"], fr)
         ok = np.array_equal(full.astype(np.uint32), vis_all) and bool(np.all(np.diff(full) > 0))
+        # the form bench.py uses: one fixed-size allgather of the 1-bit-per-entity mask (equal shard
+        # capacity on every rank), expanded locally into the same global list
+        cap_words = (scene["n"] + 63) // 64                       # common capacity: the whole scene
+        local = np.zeros(cap_words, np.uint64)
+        local[:len(_mask)] = _mask
+        g = shard.allgather_visible_mask(torch.from_numpy(local.view(np.int64)), world).numpy().view(np.uint64)
+        los = [int(trs[a]) * 64 for a, _b in shard.shard_tile_ranges(np.diff(trs), world)]
+        ids = []
+        for r in range(world):
+            bits = np.unpackbits(g[r * cap_words:(r + 1) * cap_words].view(np.uint8), bitorder="little")
+            ids.append(np.flatnonzero(bits) + los[r])
+        ok = ok and np.array_equal(np.concatenate(ids).astype(np.uint32), vis_all)
         q.put((rank, ok, int(counts.sum()), len(vis_all), (t0, t1)))
     finally:
         dist.destroy_process_group()
