@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK = 0
 ERR_NOMEM = -1
@@ -131,6 +131,8 @@ SYMBOLS = {
                                                 C.c_uint32, C.POINTER(Frustum)]),
     "clapgpu_entities_update_tiles": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_void_p, C.c_uint32,
                                                 C.c_uint32, C.POINTER(Frustum)]),
+    "clapgpu_entities_lod": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_entities_cull": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.POINTER(Frustum)]),
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

@@ -508,6 +508,65 @@ void k_visible_expand_rp(const uint64_t *vis_mask, const uint8_t *row_pop, uint3
         *count = pre + incl;
 }
 
+// ---- per-pass LOD pick for the entities on the visible list (model.c:975-992) ----
+// glibc 2.35 sysdeps/ieee754/flt-32/s_cbrtf.c restated (the reference calls libm cbrtf(),
+// model.c:1263): the float is rescaled by frexpf, a quadratic start and one Halley step run in
+// double, ldexpf rescales.  Bit-identical to libm on every one of 3.0e8 floats probed over the
+// whole normal range, which is what makes the integer LOD exact.
+__device__ __forceinline__ float cbrtf_glibc(float x)
+{
+    int xe;
+    const float xm = frexpf(fabsf(x), &xe);
+    if (xe == 0 && (x == 0.0f || x != x || isinf(x)))
+        return x + x;
+    const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
+    const float t2 = u * u * u;
+    const int r = xe % 3;
+    const double f = r == -2 ? 1.0 / 1.5874010519681994748 : r == -1 ? 1.0 / 1.2599210498948731648
+                   : r == 0 ? 1.0 : r == 1 ? 1.2599210498948731648 : 1.5874010519681994748;
+    const float ym = (float)((double)u * ((double)t2 + 2.0 * (double)xm) / (2.0 * (double)t2 + (double)xm) * f);
+    return ldexpf(x > 0.0f ? ym : -ym, xe / 3);
+}
+
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t index_base, float cx, float cy, float cz,
+                    const float *aabb, const float *center, const float4 *pos_scale, const int32_t *model,
+                    const float4 *model_table, const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod)
+{
+    const uint32_t total = *count;
+    for (uint32_t k = blockIdx.x * ENT_BLOCK + threadIdx.x; k < total; k += gridDim.x * ENT_BLOCK) {
+        const uint32_t i = visible[k] - index_base;
+        int32_t lod = cur_lod[i];
+        const int32_t forced = force_lod ? force_lod[i] : -1;
+        if (forced >= 0) {
+            lod = forced;                                                   // model.c:976-977
+        } else {
+            const float *b = aabb + 6 * (size_t)i;
+            const bool inside = cx >= b[0] && cx <= b[3] && cy >= b[1] && cy <= b[4] && cz >= b[2] && cz <= b[5];
+            if (!inside) {                                                  // model.c:982-990
+                const float *c = center + 3 * (size_t)i;
+                const float dx = c[0] - cx, dy = c[1] - cy, dz = c[2] - cz;
+                float dd = 0.f;
+                dd += dx * dx;
+                dd += dy * dy;
+                dd += dz * dz;
+                const int32_t mi = model[i];
+                const float4 lo = model_table[2 * mi], hi = model_table[2 * mi + 1];
+                const float s = pos_scale[i].w;
+                const float X = fabsf(hi.x - lo.x) * s, Y = fabsf(hi.y - lo.y) * s, Z = fabsf(hi.z - lo.z) * s;
+                const float side = cbrtf_glibc(X * Y * Z);                  // entity3d_aabb_avg_edge
+                const float scale = (float)((double)fabsf(dd - side * side) / 3600.0);
+                const uint32_t lm = __float_as_uint(hi.w);                  // lod_min | lod_max << 8
+                const int lmin = (int)(lm & 0xffu), lmax = (int)((lm >> 8) & 0xffu);
+                const int req = (int)scale;
+                lod = req < lmin ? lmin : (req > lmax ? lmax : req);        // model3d_validate_lod
+            }
+        }
+        cur_lod[i] = lod;
+        draw_lod[k] = lod;
+    }
+}
+
 } // namespace clapgpu
 
 using namespace clapgpu;
@@ -738,5 +797,24 @@ extern "C" int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, c
     hipLaunchKernelGGL(k_visible_expand, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), vis_mask, n,
                        group_count, n_groups, index_base, visible, count);
     CLAPGPU_LAUNCH_CHECK("k_visible_expand");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t *visible,
+                                    const uint32_t *count, uint32_t index_base, const float cam_pos[3],
+                                    const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod)
+{
+    if (!e || !visible || !count || !cam_pos || !cur_lod || !draw_lod || !e->aabb || !e->center ||
+        !e->pos_scale || !e->model || !e->model_table)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->n == 0)
+        return CLAPGPU_OK;
+    uint32_t blocks = (e->n + ENT_BLOCK - 1) / ENT_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_entities_lod, dim3(blocks), dim3(ENT_BLOCK), 0, as_stream(stream), visible, count, index_base,
+                       cam_pos[0], cam_pos[1], cam_pos[2], e->aabb, e->center,
+                       reinterpret_cast<const float4 *>(e->pos_scale), e->model,
+                       reinterpret_cast<const float4 *>(e->model_table), force_lod, cur_lod, draw_lod);
+    CLAPGPU_LAUNCH_CHECK("k_entities_lod");
     return CLAPGPU_OK;
 }

@@ -217,6 +217,9 @@ def model_table(scene):
     t[:, 0:3] = scene["model_aabb"][:, 0:3]
     t[:, 4:7] = scene["model_aabb"][:, 3:6]
     t.view(np.uint32)[:, 3] = scene["model_skip"].astype(np.uint32)
+    if "model_lod" in scene:                                  # (lod_min, lod_max) per model
+        ml = np.asarray(scene["model_lod"], np.uint32)
+        t.view(np.uint32)[:, 7] = ml[:, 0] | (ml[:, 1] << 8)
     return t
 
 

@@ -93,8 +93,9 @@ void clapgpu_frustum_calc(const float view_mx[16], const float proj_mx[16],
  *            rot[n][4]        quat xyzw              transform_t.rotation
  *            parent[n]        index or -1            entity3d.parent (jointless attach)
  *            model[n]         index into model_table entity3d.txmodel->model
- *            model_table[m][8]  (min.xyz, skip_aabb as uint32 bits, max.xyz, 0)
- *                                                    model3d.aabb, model3d.skip_aabb
+ *            model_table[m][8]  (min.xyz, skip_aabb as uint32 bits, max.xyz,
+ *                                lod_min | lod_max << 8 as uint32 bits)
+ *                                                    model3d.aabb, .skip_aabb, .lod_min, .lod_max
  *   in/out   flags[n]         CLAPGPU_E_* bits       entity3d.flags + xform.updated
  *            seqs[n]          seq | parent_seq<<16   entity3d.seq / .parent_seq (uint16 wrap)
  *   outputs  mx[n][16], inv_mx[n][16]                entity3d.mx, .inverse_mx
@@ -222,6 +223,19 @@ size_t clapgpu_visible_scratch_bytes(uint32_t n);
 int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, const uint8_t *vis_row_pop,
                             uint32_t n, uint32_t index_base, uint32_t *visible, uint32_t *count,
                             void *scratch);
+
+/*
+ * Per-pass LOD pick of _models_render for the entities on the visible list (model.c:975-992,
+ * SURVEY 8f rank 1): a forced LOD wins; otherwise, unless the camera is inside the entity's box,
+ * lod = clamp((int)(| |aabb_center - cam|^2 - avg_edge^2 | / 3600), lod_min, lod_max) with
+ * avg_edge = cbrtf(X Y Z) (entity3d_aabb_avg_edge, model.c:1261-1264).  visible / count as
+ * produced by clapgpu_visible_compact (ids minus index_base index this shard's arrays);
+ * force_lod[n] may be NULL (= -1 everywhere); cur_lod[n] is entity3d.cur_lod (in/out);
+ * draw_lod[k] is the LOD visible[k] is drawn with: (visible, draw_lod) is the draw list.
+ */
+int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t *visible,
+                         const uint32_t *count, uint32_t index_base, const float cam_pos[3],
+                         const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod);
 
 /* ======================================================================== */
 /* Particle systems: advect / respawn / billboard (core/particle.c)          */

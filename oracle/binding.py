@@ -112,6 +112,9 @@ def _declare(L):
     L.clapo_broadphase_pairs.restype = C.c_uint64
     L.clapo_broadphase_static_pairs.argtypes = [C.c_uint32, F64P, C.c_uint32, F64P, F64P, C.c_void_p, C.c_uint64]
     L.clapo_broadphase_static_pairs.restype = C.c_uint64
+    L.clapo_aabb_avg_edge.argtypes = [F32P, C.c_float]
+    L.clapo_aabb_avg_edge.restype = C.c_float
+    L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
 
 
@@ -313,3 +316,15 @@ def broadphase_static_pairs(statics, pos, radius, max_pairs=None):
                                               pairs.ctypes.data, cap)
     assert cnt <= cap
     return pairs[:cnt].copy()
+
+
+# ------------------------------------------------------------------ LOD
+def entities_lod(scene, st, visible, cam_pos, model_lod, force_lod, cur_lod):
+    """cur_lod updated in place; returns draw_lod[k] for visible[k]."""
+    draw = np.zeros(len(visible), np.int32)
+    lib().clapo_entities_lod(len(visible), np.ascontiguousarray(visible, np.uint32),
+                             np.ascontiguousarray(cam_pos, np.float32), st["aabb"], st["center"],
+                             scene["pos_scale"], scene["model"], scene["model_aabb"],
+                             np.ascontiguousarray(model_lod, np.uint8), np.ascontiguousarray(force_lod, np.int32),
+                             cur_lod, draw)
+    return draw

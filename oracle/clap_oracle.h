@@ -114,6 +114,13 @@ int32_t clapo_camera_bv(uint32_t n, const uint32_t *flags, const float *aabb, co
 uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aabb,
                              const clapo_frustum *f, uint32_t *visible, uint64_t *vis_mask);
 
+/* ---- per-pass LOD selection (model.c:975-992; lod.c) ---- */
+float clapo_aabb_avg_edge(const float model_aabb[6], float scale);
+void clapo_entities_lod(uint32_t n_visible, const uint32_t *visible, const float cam_pos[3],
+                        const float *aabb, const float *center, const float *pos_scale,
+                        const int32_t *model, const float *model_aabb, const uint8_t *model_lod,
+                        const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod);
+
 /* ---- particles (core/particle.c) ---- */
 #define CLAPO_PART_DIST_LIN     0   /* particle.h:13-18 */
 #define CLAPO_PART_DIST_SQRT    1

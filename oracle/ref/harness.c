@@ -518,6 +518,36 @@ static int cmd_pose(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* lod: the reference's building blocks of the per-pass LOD pick       */
+/* ------------------------------------------------------------------ */
+static int cmd_lod(struct arrset *in, struct arrset *out)
+{
+    uint32_t n = *(uint32_t *)arr_get(in, "n", NULL);
+    float *model_aabb = arr_get(in, "model_aabb", NULL);   /* [n][6]: one model per probe */
+    float *scale = arr_get(in, "scale", NULL);
+    int32_t *lod_min = arr_get(in, "lod_min", NULL), *lod_max = arr_get(in, "lod_max", NULL);
+    int32_t *request = arr_get(in, "request", NULL);
+    float *o_edge = arr_add(out, "avg_edge", (uint64_t)n * 4);
+    int32_t *o_lod = arr_add(out, "cur_lod", (uint64_t)n * 4);
+
+    for (uint32_t i = 0; i < n; i++) {
+        model3d m = {};
+        model3dtx txm = { .model = &m };
+        entity3d e = { .txmodel = &txm };
+        memcpy(m.aabb, model_aabb + 6 * i, 24);
+        m.lod_min = lod_min[i];
+        m.lod_max = lod_max[i];
+        m.nr_lods = lod_max[i] + 1;
+        e.scale = scale[i];
+        e.force_lod = -1;
+        o_edge[i] = entity3d_aabb_avg_edge(&e);            /* model.c:1261-1264 */
+        entity3d_set_lod(&e, request[i], false);           /* model.c:593-609 */
+        o_lod[i] = e.cur_lod;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     struct arrset in = {}, out = {};
@@ -529,6 +559,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[1], "bench_entities"))  rc = cmd_bench_entities(&in, &out);
     else if (!strcmp(argv[1], "particles"))       rc = cmd_particles(&in, &out);
     else if (!strcmp(argv[1], "pose"))            rc = cmd_pose(&in, &out);
+    else if (!strcmp(argv[1], "lod"))             rc = cmd_lod(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

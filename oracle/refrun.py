@@ -135,3 +135,12 @@ def pose(sk, an, chars, char_times):
                 globalmx=A(out["global"], np.float32, (frames, n, J, 16)),
                 joint_pos=A(out["joint_pos"], np.float32, (frames, n, J, 4)),
                 bind=A(out["bind"], np.float32, (J, 16)), time_end=float(A(out["time_end"], np.float32)[0]))
+
+
+def lod_blocks(model_aabb, scale, lod_min, lod_max, request):
+    """entity3d_aabb_avg_edge and entity3d_set_lod(e, request, false) of the reference per probe."""
+    n = len(scale)
+    out = run("lod", dict(n=np.asarray([n], np.uint32), model_aabb=np.asarray(model_aabb, np.float32),
+                          scale=np.asarray(scale, np.float32), lod_min=np.asarray(lod_min, np.int32),
+                          lod_max=np.asarray(lod_max, np.int32), request=np.asarray(request, np.int32)))
+    return clpio.as_array(out["avg_edge"], np.float32), clpio.as_array(out["cur_lod"], np.int32)
