@@ -72,7 +72,16 @@ __device__ __forceinline__ void store_mat4_rows(float *dst, const float4 (&v)[4]
     float4 *out = reinterpret_cast<float4 *>(dst);
     if (nvalid == WAVE) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) out[k * WAVE + lane] = v[k];
+        for (int k = 0; k < 4; k++) {
+#ifdef CLAPGPU_NT_STORES
+            __builtin_nontemporal_store(v[k].x, &out[k * WAVE + lane].x);
+            __builtin_nontemporal_store(v[k].y, &out[k * WAVE + lane].y);
+            __builtin_nontemporal_store(v[k].z, &out[k * WAVE + lane].z);
+            __builtin_nontemporal_store(v[k].w, &out[k * WAVE + lane].w);
+#else
+            out[k * WAVE + lane] = v[k];
+#endif
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {

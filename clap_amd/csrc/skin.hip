@@ -30,6 +30,22 @@ struct SkinArgs {
     float          *out_position, *out_normal;
 };
 
+struct SkinVert {
+    float    px, py, pz, nx, ny, nz;
+    uint32_t jj;
+    float4   w;
+};
+
+__device__ __forceinline__ SkinVert load_vert(const SkinArgs &a, size_t v)
+{
+    SkinVert r;
+    r.px = a.position[3 * v]; r.py = a.position[3 * v + 1]; r.pz = a.position[3 * v + 2];
+    r.nx = a.normal[3 * v];   r.ny = a.normal[3 * v + 1];   r.nz = a.normal[3 * v + 2];
+    r.jj = a.joints[v];
+    r.w = a.weights[v];
+    return r;
+}
+
 __global__ __launch_bounds__(SKIN_BLOCK)
 void k_skin(SkinArgs a)
 {
@@ -37,6 +53,15 @@ void k_skin(SkinArgs a)
 
     const uint32_t c = blockIdx.x;
     const uint32_t J = a.J;
+    const uint32_t vfirst = a.vert_first[c], vcount = a.vert_count[c], ofirst = a.out_first[c];
+
+    // this lane's first vertex is requested BEFORE the palette is staged, so the two HBM round
+    // trips of a block overlap instead of adding up (a block is one palette + ~one vertex pass)
+    uint32_t k = threadIdx.x;
+    SkinVert cur;
+    if (k < vcount)
+        cur = load_vert(a, (size_t)vfirst + k);
+
     // stage the palette: J * 4 float4, coalesced
     const float4 *src = a.joint_transforms + (size_t)c * J * 4;
     for (uint32_t q = threadIdx.x; q < J * 4; q += SKIN_BLOCK) {
@@ -45,33 +70,33 @@ void k_skin(SkinArgs a)
     }
     __syncthreads();
 
-    const uint32_t vfirst = a.vert_first[c], vcount = a.vert_count[c], ofirst = a.out_first[c];
-    for (uint32_t k = threadIdx.x; k < vcount; k += SKIN_BLOCK) {
-        const size_t v = (size_t)vfirst + k;
-        const float px = a.position[3 * v], py = a.position[3 * v + 1], pz = a.position[3 * v + 2];
-        const float nx = a.normal[3 * v], ny = a.normal[3 * v + 1], nz = a.normal[3 * v + 2];
-        const uint32_t jj = a.joints[v];
-        const float4 w4 = a.weights[v];
-        const float w[4] = { w4.x, w4.y, w4.z, w4.w };
+    while (k < vcount) {
+        const uint32_t knext = k + SKIN_BLOCK;
+        SkinVert nxt;
+        if (knext < vcount)
+            nxt = load_vert(a, (size_t)vfirst + knext);           // in flight during the blend below
+        const float w[4] = { cur.w.x, cur.w.y, cur.w.z, cur.w.w };
         float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 };
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t ji = (jj >> (8 * i)) & 0xffu;
+            const uint32_t ji = (cur.jj >> (8 * i)) & 0xffu;
             const float4 *m = reinterpret_cast<const float4 *>(pal + ji * PAL_PITCH);
             const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
             // ((M0 x + M1 y) + M2 z) + M3 w per component; w = 1 for positions, 0 for normals
-            const float lx = ((c0.x * px + c1.x * py) + c2.x * pz) + c3.x * 1.0f;
-            const float ly = ((c0.y * px + c1.y * py) + c2.y * pz) + c3.y * 1.0f;
-            const float lz = ((c0.z * px + c1.z * py) + c2.z * pz) + c3.z * 1.0f;
-            const float mx = ((c0.x * nx + c1.x * ny) + c2.x * nz) + c3.x * 0.0f;
-            const float my = ((c0.y * nx + c1.y * ny) + c2.y * nz) + c3.y * 0.0f;
-            const float mz = ((c0.z * nx + c1.z * ny) + c2.z * nz) + c3.z * 0.0f;
+            const float lx = ((c0.x * cur.px + c1.x * cur.py) + c2.x * cur.pz) + c3.x * 1.0f;
+            const float ly = ((c0.y * cur.px + c1.y * cur.py) + c2.y * cur.pz) + c3.y * 1.0f;
+            const float lz = ((c0.z * cur.px + c1.z * cur.py) + c2.z * cur.pz) + c3.z * 1.0f;
+            const float mx = ((c0.x * cur.nx + c1.x * cur.ny) + c2.x * cur.nz) + c3.x * 0.0f;
+            const float my = ((c0.y * cur.nx + c1.y * cur.ny) + c2.y * cur.nz) + c3.y * 0.0f;
+            const float mz = ((c0.z * cur.nx + c1.z * cur.ny) + c2.z * cur.nz) + c3.z * 0.0f;
             tp[0] += lx * w[i]; tp[1] += ly * w[i]; tp[2] += lz * w[i];
             tn[0] += mx * w[i]; tn[1] += my * w[i]; tn[2] += mz * w[i];
         }
         const size_t o = (size_t)ofirst + k;
         a.out_position[3 * o] = tp[0]; a.out_position[3 * o + 1] = tp[1]; a.out_position[3 * o + 2] = tp[2];
         a.out_normal[3 * o] = tn[0];   a.out_normal[3 * o + 1] = tn[1];   a.out_normal[3 * o + 2] = tn[2];
+        cur = nxt;
+        k = knext;
     }
 }
 
