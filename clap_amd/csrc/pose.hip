@@ -6,9 +6,9 @@
 // animated_update()'s time base and queue logic (model.c:1563-1592) and passes each
 // character's animation id and (float)frame_time.
 //
-// Mapping: one lane per joint, a 64-joint skeleton = one wavefront = one character; the
-// joint tree is walked level by level with the parents' globals in LDS (they never go to HBM,
-// as in the reference where `global` is scratch).  Keyframes are per model and stay in L2.
+// Mapping: one lane per joint, a 64-joint skeleton = one wavefront = one character; every
+// joint folds the locals on its ancestor path by pointer jumping through LDS (log2(levels)
+// rounds; the globals never go to HBM, as in the reference where `global` is scratch).  Keyframes are per model and stay in L2.
 // HBM: ~200 B / joint: T/R/S 40 B, joint_transforms 64 B, joint pos 16 B written.
 //
 // Numerics: same mixed precision as the reference (double lerp, double acos/sin/cos in slerp);
@@ -22,7 +22,7 @@ namespace clapgpu {
 
 struct PoseArgs {
     // skeleton
-    uint32_t        J, n_levels;
+    uint32_t        J, n_jump_steps;
     const int32_t  *parent;
     const int32_t  *depth;
     const float    *root_pose;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
 }
 
 #ifndef POSE_WAVES
-#define POSE_WAVES 3
+#define POSE_WAVES 4
 #endif
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144;     // key times kept in LDS when the model's pool fits (24 KiB)
@@ -145,7 +145,8 @@ void k_pose(PoseArgs a)
     const bool lane_joint = cib < CPB && (uint32_t)j < J;
     const int depth = lane_joint ? a.depth[j] : -1;
     const bool reachable = depth >= 0;
-    const int32_t parent = lane_joint ? a.parent[j] : -1;
+    int32_t parent = lane_joint ? a.parent[j] : -1;
+    if (parent >= (int32_t)J) parent = -1;
     float *G = g_lds[cib < CPB ? cib : 0];
 
     if (LDS_TIMES) {
@@ -207,51 +208,66 @@ void k_pose(PoseArgs a)
             }
         }
 
-        // ---- 2. one_joint_transform, level by level: global = ((parent * I) * T) * R, scale_aniso ----
-        // T is a pure translation and R a pure rotation matrix, so the products are evaluated on their
-        // non-trivial terms only (the dropped terms are exact +-0 in the reference's full 4x4 products).
-        float Gm[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) Gm[k] = 0.f;
-        float Rm[16];
-        lmd::from_quat(Rm, R[0], R[1], R[2], R[3]);
-        for (uint32_t d = 0; d < a.n_levels; d++) {
-            if (joint_ok && reachable && (uint32_t)depth == d) {
-                float P[16];
-                if (parent >= 0) {
-                    const float4 *src = reinterpret_cast<const float4 *>(G + parent * G_STRIDE);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 v = src[q];
-                        P[4 * q] = v.x; P[4 * q + 1] = v.y; P[4 * q + 2] = v.z; P[4 * q + 3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) P[k] = a.root_pose[k];
+        // ---- 2. one_joint_transform (model.c:1352-1404): global_j = root_pose * L_0 * ... * L_j over the
+        // joint's ancestor path, L = T * R * S.  The reference walks the tree top down; here every joint
+        // folds its path by pointer jumping: after step s a lane holds the product of the last 2^s locals
+        // of its path and the index of the ancestor 2^s above, so ceil(log2(levels)) LDS rounds replace
+        // `levels` dependent ones.  Locals are affine, so the running products are kept as three rows
+        // (the fourth is 0 0 0 1); only root_pose and invmx are treated as general 4x4.
+        float4 M0, M1, M2;                                        // rows of the running product
+        {
+            float Rm[16];
+            lmd::from_quat(Rm, R[0], R[1], R[2], R[3]);
+            M0 = make_float4(E_(Rm, 0, 0) * S[0], E_(Rm, 1, 0) * S[1], E_(Rm, 2, 0) * S[2], T[0]);
+            M1 = make_float4(E_(Rm, 0, 1) * S[0], E_(Rm, 1, 1) * S[1], E_(Rm, 2, 1) * S[2], T[1]);
+            M2 = make_float4(E_(Rm, 0, 2) * S[0], E_(Rm, 1, 2) * S[1], E_(Rm, 2, 2) * S[2], T[2]);
+        }
+        int anc = joint_ok ? parent : -1;
+        {
+            float4 *slots = reinterpret_cast<float4 *>(G);
+            const int sw_me = (j >> 2) & 3;                       // row swizzle: 16 neighbouring lanes hit 64 banks
+            for (uint32_t st = 0; st < a.n_jump_steps; st++) {
+                slots[4 * j + (0 ^ sw_me)] = M0;
+                slots[4 * j + (1 ^ sw_me)] = M1;
+                slots[4 * j + (2 ^ sw_me)] = M2;
+                reinterpret_cast<int *>(&slots[4 * j + (3 ^ sw_me)])[0] = anc;
+                if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
+                float4 A0, A1, A2;
+                int anc2 = -1;
+                const bool hop = anc >= 0;
+                if (hop) {
+                    const int sw = (anc >> 2) & 3;
+                    A0 = slots[4 * anc + (0 ^ sw)];
+                    A1 = slots[4 * anc + (1 ^ sw)];
+                    A2 = slots[4 * anc + (2 ^ sw)];
+                    anc2 = reinterpret_cast<const int *>(&slots[4 * anc + (3 ^ sw)])[0];
                 }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float t3 = 0.f;                               // column 3 of P * T
-                    t3 += E_(P, 0, r) * T[0];
-                    t3 += E_(P, 1, r) * T[1];
-                    t3 += E_(P, 2, r) * T[2];
-                    t3 += E_(P, 3, r) * 1.f;
-                    E_(Gm, 3, r) = t3;
-#pragma unroll
-                    for (int cc = 0; cc < 3; cc++) {              // columns 0..2 of (P * T) * R, then scale
-                        float s = 0.f;
-                        s += E_(P, 0, r) * E_(Rm, cc, 0);
-                        s += E_(P, 1, r) * E_(Rm, cc, 1);
-                        s += E_(P, 2, r) * E_(Rm, cc, 2);
-                        E_(Gm, cc, r) = s * S[cc];
-                    }
+                if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
+                if (hop) {
+#pragma clang fp contract(fast)
+                    const float4 B0 = M0, B1 = M1, B2 = M2;
+#define CLAPGPU_AFFINE_ROW(A, OUT)                                                                  \
+                    OUT = make_float4(A.x * B0.x + A.y * B1.x + A.z * B2.x,                          \
+                                      A.x * B0.y + A.y * B1.y + A.z * B2.y,                          \
+                                      A.x * B0.z + A.y * B1.z + A.z * B2.z,                          \
+                                      A.x * B0.w + A.y * B1.w + A.z * B2.w + A.w)
+                    CLAPGPU_AFFINE_ROW(A0, M0);
+                    CLAPGPU_AFFINE_ROW(A1, M1);
+                    CLAPGPU_AFFINE_ROW(A2, M2);
+#undef CLAPGPU_AFFINE_ROW
+                    anc = anc2;
                 }
-                float4 *dst = reinterpret_cast<float4 *>(G + j * G_STRIDE);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    dst[q] = make_float4(Gm[4 * q], Gm[4 * q + 1], Gm[4 * q + 2], Gm[4 * q + 3]);
             }
-            if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
+        }
+        float Gm[16];                                             // global = root_pose * path product
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma clang fp contract(fast)
+            const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
+            E_(Gm, 0, r) = p0 * M0.x + p1 * M1.x + p2 * M2.x;
+            E_(Gm, 1, r) = p0 * M0.y + p1 * M1.y + p2 * M2.y;
+            E_(Gm, 2, r) = p0 * M0.z + p1 * M1.z + p2 * M2.z;
+            E_(Gm, 3, r) = p0 * M0.w + p1 * M1.w + p2 * M2.w + p3;
         }
 
         // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
@@ -344,7 +360,8 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
 
     PoseArgs a;
     a.J = sk->nr_joints;
-    a.n_levels = sk->n_levels;
+    a.n_jump_steps = 0;                                        // ceil(log2(levels)): 2^steps >= longest path
+    while ((1u << a.n_jump_steps) < sk->n_levels) a.n_jump_steps++;
     a.parent = sk->parent;
     a.depth = sk->depth;
     a.root_pose = sk->root_pose;
