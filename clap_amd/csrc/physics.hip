@@ -211,16 +211,36 @@ static int exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, 
 }
 
 // ---------------------------------------------------------------- broadphase
+// Uniform hash grid over the sphere centres, cell edge >= the largest diameter, so every partner of a
+// body lies in the 27 cells around it.  HBM layout of the work space: the bodies are copied into
+// bucket order as 48-byte records (centre, radius, cell, index) so a cell's members are one contiguous
+// run, and the 27-cell walk of one body is spread over the 32 lanes of a half wave (one cell per lane)
+// instead of being a 27-long chain of dependent gathers in one lane.
+struct BpRec {
+    double   p[3], r;                 // centre, radius: the AABB is p -+ r as dGeomSphere computes it
+    int32_t  cx, cy, cz;
+    uint32_t idx;
+};
+static_assert(sizeof(BpRec) == 48, "record layout");
+
+#ifndef BP_GROUP
+#define BP_GROUP 16                       // lanes per body in the pair search
+#endif
+constexpr int BP_WORK = 64;               // candidate records listed per body and round
+
+constexpr int BP_LIST = 16;               // partners kept per body between the search and the emit pass
+
 struct BpK {
     uint32_t      n;
     const double *pos;
     const double *radius;
     double        cell;
     uint32_t      hash_mask;          // buckets - 1 (power of two)
-    uint32_t     *bucket_count;       // [buckets]   -> becomes bucket_start after the scan
-    uint32_t     *bucket_cursor;      // [buckets]
-    uint32_t     *bucket_items;       // [n]
-    uint32_t     *pair_count;         // [n]         -> becomes pair_start after the scan
+    uint32_t     *bucket_count;       // [buckets + 1] -> bucket starts after the scan
+    int4         *cells;              // [n]  (cx, cy, cz, rank of the body inside its bucket)
+    BpRec        *recs;               // [n]  bodies in bucket order
+    uint32_t     *pair_count;         // [n + 1] -> pair starts after the scan
+    uint32_t     *partners;           // [n][BP_LIST] ascending partners of bodies with <= BP_LIST of them
     uint32_t     *pairs;              // [2 * capacity]
     uint32_t      capacity;
 };
@@ -232,19 +252,28 @@ __device__ __forceinline__ void cell_of(const double *p, double cell, int32_t &c
     cz = (int32_t)floor(p[2] / cell);
 }
 
+// Bucket of a cell: the 4x4x4 block of cells it belongs to is hashed, the position inside the block
+// is kept in the low 6 bits.  Buckets (and with them the bucket-ordered records) of neighbouring
+// cells are therefore neighbours in memory, and one body's 27-cell walk touches a few cache lines
+// instead of 27 scattered ones.  Blocks that share a hash slot are told apart by the cell test.
 __device__ __forceinline__ uint32_t cell_hash(int32_t cx, int32_t cy, int32_t cz, uint32_t mask)
 {
-    return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u)) & mask;
+    const uint32_t hb = ((uint32_t)(cx >> 2) * 73856093u) ^ ((uint32_t)(cy >> 2) * 19349663u) ^
+                        ((uint32_t)(cz >> 2) * 83492791u);
+    const uint32_t fine = (uint32_t)(cx & 3) | ((uint32_t)(cy & 3) << 2) | ((uint32_t)(cz & 3) << 4);
+    return ((hb << 6) | fine) & mask;
 }
 
 __global__ __launch_bounds__(PHYS_BLOCK)
 void k_bp_histogram(BpK k)
 {
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
+    if (i == 0) k.pair_count[k.n] = 0;
     if (i >= k.n) return;
     int32_t cx, cy, cz;
     cell_of(k.pos + 3 * (size_t)i, k.cell, cx, cy, cz);
-    atomicAdd(&k.bucket_count[cell_hash(cx, cy, cz, k.hash_mask)], 1u);
+    const uint32_t rank = atomicAdd(&k.bucket_count[cell_hash(cx, cy, cz, k.hash_mask)], 1u);
+    k.cells[i] = make_int4(cx, cy, cz, (int)rank);
 }
 
 __global__ __launch_bounds__(PHYS_BLOCK)
@@ -252,93 +281,207 @@ void k_bp_scatter(BpK k)
 {
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
     if (i >= k.n) return;
-    int32_t cx, cy, cz;
-    cell_of(k.pos + 3 * (size_t)i, k.cell, cx, cy, cz);
-    const uint32_t h = cell_hash(cx, cy, cz, k.hash_mask);
-    const uint32_t slot = k.bucket_count[h] + atomicAdd(&k.bucket_cursor[h], 1u);   // bucket_count holds starts now
-    if (slot < k.n)
-        k.bucket_items[slot] = i;
+    const int4 c = k.cells[i];
+    const uint32_t slot = k.bucket_count[cell_hash(c.x, c.y, c.z, k.hash_mask)] + (uint32_t)c.w;   // starts now
+    if (slot >= k.n) return;
+    BpRec rec;
+#pragma unroll
+    for (int a = 0; a < 3; a++) rec.p[a] = k.pos[3 * (size_t)i + a];
+    rec.r = k.radius[i];
+    rec.cx = c.x; rec.cy = c.y; rec.cz = c.z; rec.idx = i;
+    k.recs[slot] = rec;
 }
 
 // collideAABBs: disjoint iff separated on an axis (touching boxes collide)
-__device__ __forceinline__ bool spheres_aabb_overlap(const double *pa, double ra, const double *pb, double rb)
+__device__ __forceinline__ bool aabb_overlap(const double (&alo)[3], const double (&ahi)[3], const BpRec &b)
 {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double alo = pa[a] - ra, ahi = pa[a] + ra, blo = pb[a] - rb, bhi = pb[a] + rb;
-        if (alo > bhi || ahi < blo) return false;
-    }
+    for (int a = 0; a < 3; a++)
+        if (alo[a] > b.p[a] + b.r || ahi[a] < b.p[a] - b.r) return false;
     return true;
 }
 
-// EMIT = false: count the partners j > i of body i; EMIT = true: write them, ascending, at pair_start[i]
-template <bool EMIT>
+// Search pass: BP_GROUP lanes per body, bodies taken in bucket order.  The lanes first look up the
+// record runs of the 27 neighbour cells and spread them into an LDS work list (run -> one entry per
+// record, tagged with the cell it was listed for), then test the listed records one per lane, so the
+// lanes stay busy whatever the individual runs' lengths are.  The partners j > i are gathered in LDS,
+// ranked (they are distinct, so rank = number of smaller ones) and written in ascending order to
+// partners[i][]; pair_count[i] gets their number.  Bodies with more than BP_LIST partners only get
+// the count here and are searched again by the emit pass.
 __global__ __launch_bounds__(PHYS_BLOCK)
-void k_bp_pairs(BpK k, const uint32_t *bucket_start_end /* [buckets + 1] */)
+void k_bp_search(BpK k)
 {
-    const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
-    if (i >= k.n) return;
-    const double *pi = k.pos + 3 * (size_t)i;
-    const double ri = k.radius[i];
-    int32_t cx, cy, cz;
-    cell_of(pi, k.cell, cx, cy, cz);
-    const uint32_t start = EMIT ? k.pair_count[i] : 0;              // pair_count holds starts when emitting
-    uint32_t cnt = 0;
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++)
-            for (int dx = -1; dx <= 1; dx++) {
-                const int32_t nx = cx + dx, ny = cy + dy, nz = cz + dz;
-                const uint32_t h = cell_hash(nx, ny, nz, k.hash_mask);
-                const uint32_t b0 = bucket_start_end[h], b1 = bucket_start_end[h + 1];
-                for (uint32_t s = b0; s < b1 && s < k.n; s++) {
-                    const uint32_t j = k.bucket_items[s];
-                    if (j <= i || j >= k.n) continue;
-                    const double *pj = k.pos + 3 * (size_t)j;
-                    int32_t jx, jy, jz;
-                    cell_of(pj, k.cell, jx, jy, jz);
-                    if (jx != nx || jy != ny || jz != nz) continue;  // another cell sharing the bucket
-                    if (!spheres_aabb_overlap(pi, ri, pj, k.radius[j])) continue;
-                    if (EMIT) {
-                        const uint32_t o = start + cnt;
-                        if (o < k.capacity) { k.pairs[2 * (size_t)o] = i; k.pairs[2 * (size_t)o + 1] = j; }
-                    }
-                    cnt++;
+    constexpr int G = BP_GROUP, GROUPS = PHYS_BLOCK / G, CPL = (27 + G - 1) / G;
+    constexpr uint32_t WL = BP_WORK;
+    __shared__ uint32_t list[GROUPS][BP_LIST];
+    __shared__ uint32_t work[GROUPS][WL];
+    const int grp = threadIdx.x / G, q = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * GROUPS + grp;                // neighbouring groups walk neighbouring cells
+    const bool body = slot < k.n;
+    const int sub = (lane_id() / G) * G;                            // first lane of this group in the wave
+    const uint64_t gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+
+    double alo[3] = { 0, 0, 0 }, ahi[3] = { 0, 0, 0 };
+    uint32_t b0[CPL], len[CPL], i = 0, mylen = 0;
+    int32_t mx = 0, my = 0, mz = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { b0[c] = 0; len[c] = 0; }
+    if (body) {
+        const BpRec me = k.recs[slot];
+        i = me.idx;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { alo[a] = me.p[a] - me.r; ahi[a] = me.p[a] + me.r; }
+        mx = me.cx - 1; my = me.cy - 1; mz = me.cz - 1;             // corner cell of the 3x3x3 neighbourhood
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int cq = q + c * G;
+            if (cq < 27) {
+                const uint32_t h = cell_hash(mx + cq % 3, my + (cq / 3) % 3, mz + cq / 9, k.hash_mask);
+                uint32_t se[2];                                     // start and end of the run: one 8-byte load
+                __builtin_memcpy(se, k.bucket_count + h, sizeof(se));
+                const uint32_t s0 = se[0];
+                uint32_t s1 = se[1];
+                if (s1 > k.n) s1 = k.n;
+                b0[c] = s0;
+                len[c] = s1 > s0 ? s1 - s0 : 0;
+                mylen += len[c];
+            }
+        }
+    }
+    // this lane's first entry in the group's candidate sequence, and the sequence's length
+    uint32_t incl = mylen;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, G);
+        if (q >= d) incl += up;
+    }
+    const uint32_t total = __shfl(incl, G - 1, G);
+    const uint32_t first = incl - mylen;
+
+    uint32_t cnt = 0;                                               // partners of this body so far (group-uniform)
+    for (uint32_t base = 0; __any(base < total); base += WL) {      // one round unless > WL candidates
+        uint32_t off = first;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int cq = q + c * G;                               // entry = record slot | cell offset (2+2+2 bits)
+            const uint32_t tag = (uint32_t)(cq % 3 | ((cq / 3) % 3) << 2 | (cq / 9) << 4) << 26;
+            for (uint32_t t = 0; __any(t < len[c]); t++) {
+                if (t < len[c]) {
+                    const uint32_t o = off + t - base;              // wraps below base: then >= WL
+                    if (o < WL) work[grp][o] = (b0[c] + t) | tag;
                 }
             }
-    if (!EMIT) {
-        k.pair_count[i] = cnt;
-    } else {
-        // ascending j: insertion sort of this body's own short run (cnt is a handful)
-        const uint32_t lim = start + cnt <= k.capacity ? cnt : (start < k.capacity ? k.capacity - start : 0);
-        for (uint32_t a = 1; a < lim; a++) {
-            const uint32_t key = k.pairs[2 * (size_t)(start + a) + 1];
-            uint32_t b = a;
-            while (b > 0 && k.pairs[2 * (size_t)(start + b - 1) + 1] > key) {
-                k.pairs[2 * (size_t)(start + b) + 1] = k.pairs[2 * (size_t)(start + b - 1) + 1];
-                b--;
+            off += len[c];
+        }
+        wave_lds_fence();
+        const uint32_t todo = total > base ? (total - base < WL ? total - base : WL) : 0;
+        for (uint32_t t = q; __any(t < todo); t += G) {
+            bool hit = false;
+            uint32_t j = 0;
+            if (t < todo) {
+                const uint32_t e = work[grp][t];
+                const BpRec r = k.recs[e & 0x3ffffffu];
+                j = r.idx;
+                hit = j > i && r.cx - mx == (int)((e >> 26) & 3) && r.cy - my == (int)((e >> 28) & 3) &&
+                      r.cz - mz == (int)(e >> 30) && aabb_overlap(alo, ahi, r);
             }
-            k.pairs[2 * (size_t)(start + b) + 1] = key;
+            const uint32_t gm = (uint32_t)((__ballot(hit) >> sub) & gmask);
+            if (hit) {
+                const uint32_t o = cnt + __popc(gm & ((1u << q) - 1u));
+                if (o < BP_LIST) list[grp][o] = j;
+            }
+            cnt += __popc(gm);
+        }
+        wave_lds_fence();
+    }
+    if (body) {
+        if (q == 0) k.pair_count[i] = cnt;
+        if (cnt <= BP_LIST)
+            for (uint32_t e = q; e < cnt; e += G) {
+                const uint32_t v = list[grp][e];
+                uint32_t rank = 0;
+                for (uint32_t t = 0; t < cnt; t++) rank += list[grp][t] < v;
+                k.partners[(size_t)i * BP_LIST + rank] = v;
+            }
+    }
+}
+
+// Emit pass: 16 lanes per body copy its partner list to pairs[] at pair_start[i]; a body with more
+// partners than the list holds is searched again by one lane (ascending by insertion).
+__global__ __launch_bounds__(PHYS_BLOCK)
+void k_bp_emit(BpK k)
+{
+    const uint32_t t = blockIdx.x * PHYS_BLOCK + threadIdx.x;
+    const uint32_t i = t / BP_LIST, q = t % BP_LIST;
+    if (i >= k.n) return;
+    const uint32_t start = k.pair_count[i], cnt = k.pair_count[i + 1] - start;
+    uint2 *out = reinterpret_cast<uint2 *>(k.pairs);
+    if (cnt <= BP_LIST) {
+        if (q < cnt && start + q < k.capacity)
+            out[start + q] = make_uint2(i, k.partners[(size_t)i * BP_LIST + q]);
+        return;
+    }
+    if (q != 0) return;
+    const int4 c = k.cells[i];
+    const double ri = k.radius[i];
+    double alo[3], ahi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double p = k.pos[3 * (size_t)i + a];
+        alo[a] = p - ri;
+        ahi[a] = p + ri;
+    }
+    uint32_t w = 0;
+    for (int cq = 0; cq < 27; cq++) {
+        const int32_t nx = c.x + cq % 3 - 1, ny = c.y + (cq / 3) % 3 - 1, nz = c.z + cq / 9 - 1;
+        const uint32_t h = cell_hash(nx, ny, nz, k.hash_mask);
+        uint32_t b0 = k.bucket_count[h], b1 = k.bucket_count[h + 1];
+        if (b1 > k.n) b1 = k.n;
+        for (uint32_t s = b0; s < b1; s++) {
+            const BpRec r = k.recs[s];
+            const uint32_t j = r.idx;
+            if (!(j > i && r.cx == nx && r.cy == ny && r.cz == nz && aabb_overlap(alo, ahi, r)))
+                continue;
+            if (start + w < k.capacity) {
+                uint32_t b = w;                                     // insertion keeps the run ascending
+                while (b > 0 && out[start + b - 1].y > j) {
+                    out[start + b] = out[start + b - 1];
+                    b--;
+                }
+                out[start + b] = make_uint2(i, j);
+            }
+            w++;
         }
     }
 }
 
-// bodies x static geoms: statics streamed through LDS tiles; pairs (body, static) ascending
+// bodies x static geoms (dSpaceCollide2(ground, bodies)): the statics are streamed through LDS tiles,
+// every body tests all of them; pairs (body, static) ascending.  The search pass keeps the first
+// BP_LIST hits of a body (already ascending) for the emit pass, which only re-tests the few bodies
+// with more.
 constexpr int STATIC_TILE = 256;
 template <bool EMIT>
 __global__ __launch_bounds__(PHYS_BLOCK)
 void k_bp_static(uint32_t n, const double *pos, const double *radius, uint32_t n_static, const double *static_aabb,
-                 uint32_t *pair_count, uint32_t *pairs, uint32_t capacity)
+                 uint32_t *pair_count, uint32_t *partners, uint32_t *pairs, uint32_t capacity)
 {
     __shared__ double tile[STATIC_TILE * 6];
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
-    const bool live = i < n;
+    bool live = i < n;
+    uint32_t start = 0;
+    if (EMIT) {
+        // only bodies whose hits did not fit the list come back here (the block still streams the tiles together)
+        const uint32_t cnt = live ? pair_count[i + 1] - pair_count[i] : 0;
+        start = live ? pair_count[i] : 0;
+        live = cnt > BP_LIST;
+        if (!__syncthreads_or(live)) return;
+    }
     double bb[6] = { 0, 0, 0, 0, 0, 0 };
     if (live) {
         const double r = radius[i];
 #pragma unroll
         for (int a = 0; a < 3; a++) { bb[2 * a] = pos[3 * (size_t)i + a] - r; bb[2 * a + 1] = pos[3 * (size_t)i + a] + r; }
     }
-    const uint32_t start = (EMIT && live) ? pair_count[i] : 0;
     uint32_t cnt = 0;
     for (uint32_t base = 0; base < n_static; base += STATIC_TILE) {
         const uint32_t m = n_static - base < STATIC_TILE ? n_static - base : STATIC_TILE;
@@ -354,12 +497,26 @@ void k_bp_static(uint32_t n, const double *pos, const double *radius, uint32_t n
                 if (EMIT) {
                     const uint32_t o = start + cnt;
                     if (o < capacity) { pairs[2 * (size_t)o] = i; pairs[2 * (size_t)o + 1] = base + s; }
+                } else if (cnt < BP_LIST) {
+                    partners[(size_t)i * BP_LIST + cnt] = base + s;
                 }
                 cnt++;
             }
     }
     if (!EMIT && live)
         pair_count[i] = cnt;
+}
+
+// 16 lanes per body copy its listed partners to pairs[] at pair_start[i]
+__global__ __launch_bounds__(PHYS_BLOCK)
+void k_bp_copy_lists(uint32_t n, const uint32_t *pair_start, const uint32_t *partners, uint32_t *pairs, uint32_t capacity)
+{
+    const uint32_t t = blockIdx.x * PHYS_BLOCK + threadIdx.x;
+    const uint32_t i = t / BP_LIST, q = t % BP_LIST;
+    if (i >= n) return;
+    const uint32_t start = pair_start[i], cnt = pair_start[i + 1] - start;
+    if (cnt <= BP_LIST && q < cnt && start + q < capacity)
+        reinterpret_cast<uint2 *>(pairs)[start + q] = make_uint2(i, partners[(size_t)i * BP_LIST + q]);
 }
 
 } // namespace clapgpu
@@ -437,14 +594,17 @@ static uint32_t bucket_count_for(uint32_t n)
     return b;
 }
 
-// layout of the broadphase work space (uint32 units)
-struct BpScratch { uint32_t *bucket, *cursor, *items, *pcount, *scan, *total; };
+// layout of the broadphase work space (uint32 units; cells and records are 16-byte aligned)
+struct BpScratch { uint32_t *bucket, *cells, *recs, *pcount, *partners, *scan, *total; };
+
+static size_t align4(size_t w) { return (w + 3) & ~(size_t)3; }
 
 static size_t bp_scratch_words(uint32_t n)
 {
     const size_t buckets = bucket_count_for(n);
-    const size_t scan = (buckets + 1 + SCAN_TILE - 1) / SCAN_TILE + ((size_t)n + SCAN_TILE) / SCAN_TILE + 8;
-    return (buckets + 1) + buckets + n + (n + 1) + scan + 8;
+    const size_t scan = (buckets + 1 + SCAN_TILE - 1) / SCAN_TILE + ((size_t)n + 1 + SCAN_TILE) / SCAN_TILE + 8;
+    return align4(buckets + 1) + 4 * (size_t)n + 12 * (size_t)n + align4((size_t)n + 1) +
+           (size_t)BP_LIST * n + 8 + scan + 8 + 16;
 }
 
 extern "C" size_t clapgpu_broadphase_scratch_bytes(uint32_t n)
@@ -457,11 +617,12 @@ static BpScratch carve(void *scratch, uint32_t n)
     const size_t buckets = bucket_count_for(n);
     BpScratch s;
     uint32_t *p = static_cast<uint32_t *>(scratch);
-    s.bucket = p;  p += buckets + 1;
-    s.cursor = p;  p += buckets;
-    s.items = p;   p += n;
-    s.pcount = p;  p += n + 1;
-    s.total = p;   p += 8;
+    s.bucket = p;   p += align4(buckets + 1);
+    s.cells = p;    p += 4 * (size_t)n;
+    s.recs = p;     p += 12 * (size_t)n;
+    s.pcount = p;   p += align4((size_t)n + 1);
+    s.partners = p; p += (size_t)BP_LIST * n;
+    s.total = p;    p += 8;
     s.scan = p;
     return s;
 }
@@ -471,8 +632,10 @@ extern "C" int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, d
 {
     int rc = check_bodies(b);
     if (rc) return rc;
-    if (!pair_total || !scratch || (capacity && !pairs) || !(cell > 0.0))
+    if (!pair_total || !scratch || (capacity && !pairs) || !(cell > 0.0) || ((uintptr_t)scratch & 15))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (b->n > (1u << 26))                                         // work-list entries carry the cell offset in 6 bits
+        return CLAPGPU_ERR_TOO_LARGE;
     hipStream_t s = as_stream(stream);
     if (b->n == 0) {
         CLAPGPU_HIP(hipMemsetAsync(pair_total, 0, sizeof(uint32_t), s));
@@ -480,12 +643,13 @@ extern "C" int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, d
     }
     const uint32_t n = b->n, buckets = bucket_count_for(n);
     BpScratch sc = carve(scratch, n);
-    CLAPGPU_HIP(hipMemsetAsync(sc.bucket, 0, ((size_t)buckets + 1 + buckets) * sizeof(uint32_t), s));   // counts + cursors
+    CLAPGPU_HIP(hipMemsetAsync(sc.bucket, 0, ((size_t)buckets + 1) * sizeof(uint32_t), s));
 
     BpK k;
     k.n = n; k.pos = b->pos; k.radius = b->radius; k.cell = cell; k.hash_mask = buckets - 1;
-    k.bucket_count = sc.bucket; k.bucket_cursor = sc.cursor; k.bucket_items = sc.items;
-    k.pair_count = sc.pcount; k.pairs = pairs; k.capacity = capacity;
+    k.bucket_count = sc.bucket;
+    k.cells = reinterpret_cast<int4 *>(sc.cells); k.recs = reinterpret_cast<BpRec *>(sc.recs);
+    k.pair_count = sc.pcount; k.partners = sc.partners; k.pairs = pairs; k.capacity = capacity;
     const dim3 grid((n + PHYS_BLOCK - 1) / PHYS_BLOCK), block(PHYS_BLOCK);
 
     hipLaunchKernelGGL(k_bp_histogram, grid, block, 0, s, k);
@@ -494,12 +658,14 @@ extern "C" int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, d
     if (rc) return rc;
     hipLaunchKernelGGL(k_bp_scatter, grid, block, 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
-    hipLaunchKernelGGL(k_bp_pairs<false>, grid, block, 0, s, k, sc.bucket);
-    CLAPGPU_LAUNCH_CHECK("k_bp_pairs<count>");
-    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n, pair_total, sc.scan);
+    constexpr uint32_t per_block = PHYS_BLOCK / BP_GROUP;
+    hipLaunchKernelGGL(k_bp_search, dim3((n + per_block - 1) / per_block), block, 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_search");
+    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan);       // starts; [n] = total
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bp_pairs<true>, grid, block, 0, s, k, sc.bucket);
-    CLAPGPU_LAUNCH_CHECK("k_bp_pairs<emit>");
+    const uint64_t emit_threads = (uint64_t)n * BP_LIST;
+    hipLaunchKernelGGL(k_bp_emit, dim3((uint32_t)((emit_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_emit");
     return CLAPGPU_OK;
 }
 
@@ -509,22 +675,28 @@ extern "C" int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodie
 {
     int rc = check_bodies(b);
     if (rc) return rc;
-    if (!pair_total || !scratch || (capacity && !pairs) || (n_static && !static_aabb))
+    if (!pair_total || !scratch || (capacity && !pairs) || (n_static && !static_aabb) || ((uintptr_t)scratch & 15))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     hipStream_t s = as_stream(stream);
     if (b->n == 0 || n_static == 0) {
         CLAPGPU_HIP(hipMemsetAsync(pair_total, 0, sizeof(uint32_t), s));
         return CLAPGPU_OK;
     }
-    BpScratch sc = carve(scratch, b->n);
-    const dim3 grid((b->n + PHYS_BLOCK - 1) / PHYS_BLOCK), block(PHYS_BLOCK);
-    hipLaunchKernelGGL(k_bp_static<false>, grid, block, 0, s, b->n, b->pos, b->radius, n_static, static_aabb,
-                       sc.pcount, pairs, capacity);
-    CLAPGPU_LAUNCH_CHECK("k_bp_static<count>");
-    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, b->n, pair_total, sc.scan);
+    const uint32_t n = b->n;
+    BpScratch sc = carve(scratch, n);
+    const dim3 grid((n + PHYS_BLOCK - 1) / PHYS_BLOCK), block(PHYS_BLOCK);
+    CLAPGPU_HIP(hipMemsetAsync(sc.pcount + n, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_bp_static<false>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
+                       sc.pcount, sc.partners, pairs, capacity);
+    CLAPGPU_LAUNCH_CHECK("k_bp_static<search>");
+    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan);       // starts; [n] = total
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bp_static<true>, grid, block, 0, s, b->n, b->pos, b->radius, n_static, static_aabb,
-                       sc.pcount, pairs, capacity);
+    const uint64_t copy_threads = (uint64_t)n * BP_LIST;
+    hipLaunchKernelGGL(k_bp_copy_lists, dim3((uint32_t)((copy_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s,
+                       n, sc.pcount, sc.partners, pairs, capacity);
+    CLAPGPU_LAUNCH_CHECK("k_bp_copy_lists");
+    hipLaunchKernelGGL(k_bp_static<true>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
+                       sc.pcount, sc.partners, pairs, capacity);
     CLAPGPU_LAUNCH_CHECK("k_bp_static<emit>");
     return CLAPGPU_OK;
 }

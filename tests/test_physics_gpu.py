@@ -50,6 +50,39 @@ def test_broadphase_touching_and_negative_coordinates(cuda_device):
     assert any((p == [7, 8]).all() for p in exp) and any((p == [20, 21]).all() for p in exp)
 
 
+def test_broadphase_dense_bodies_with_long_partner_lists(cuda_device):
+    """Crowded cells: most bodies have more partners than the search pass keeps per body, so the
+    emit pass's second search (insertion-ordered) produces their runs."""
+    from clap_amd import physics
+    b = synth.sphere_bodies(3000, box=6.0, seed=6)
+    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=1 << 22)
+    per_body = np.bincount(exp[:, 0], minlength=3000)
+    assert per_body.max() > 16 and (per_body <= 16).any()
+    world = physics.PhysWorld(b, None, pair_capacity=len(exp) + 8, device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    assert out["pair_total"] == len(exp)
+    assert np.array_equal(out["pairs"], exp)
+
+
+def test_static_pairs_with_more_hits_than_the_kept_list(cuda_device):
+    """Bodies inside 40 nested static boxes (more hits than the per-body list of the search pass)
+    next to bodies that hit only a few."""
+    from clap_amd import physics
+    b = synth.sphere_bodies(700, box=8.0, seed=9)
+    statics = synth.static_boxes(60, 8.0, seed=2)
+    for s_ in range(40):                                    # nested boxes around the low corner
+        statics[s_] = [-1.0, 3.0 + 0.05 * s_, -1.0, 3.0 + 0.05 * s_, -1.0, 3.0 + 0.05 * s_]
+    exp_s = ob.broadphase_static_pairs(statics, b["pos"], b["radius"], max_pairs=1 << 20)
+    per_body = np.bincount(exp_s[:, 0], minlength=700)
+    assert per_body.max() > 16 and ((per_body > 0) & (per_body <= 16)).any()
+    world = physics.PhysWorld(b, statics, pair_capacity=len(exp_s) + 8, device=cuda_device)
+    world.broadphase()
+    out = world.download()
+    assert out["static_pair_total"] == len(exp_s)
+    assert np.array_equal(out["static_pairs"], exp_s)
+
+
 def test_pair_capacity_overflow_reports_total(cuda_device):
     from clap_amd import physics
     b = synth.sphere_bodies(3000, box=6.0, seed=6)
