@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK = 0
 ERR_NOMEM = -1
@@ -110,6 +110,15 @@ class Bodies(C.Structure):
 BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY = 1, 2, 4
 
 
+class Lights(C.Structure):
+    """clapgpu_lights (include/clapgpu.h)."""
+    _fields_ = [("nr_lights", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("color", C.c_void_p),
+                ("attenuation", C.c_void_p), ("is_dir", C.c_void_p), ("active", C.c_void_p)]
+
+
+LIGHTS_MAX = 128
+
+
 # every symbol include/clapgpu.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "clapgpu_device_count": (C.c_int, []),
@@ -150,6 +159,12 @@ SYMBOLS = {
     "clapgpu_broadphase_static_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
                                                   C.c_uint32, C.c_void_p, C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
+    "clapgpu_light_grid_dims": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint32)]),
+    "clapgpu_light_grid_compute": (C.c_int, [C.c_void_p, C.POINTER(Lights), C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "clapgpu_lights_from_entities": (C.c_int, [C.c_void_p, C.POINTER(Entities), C.c_uint32, C.c_uint32, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.POINTER(Lights)]),
 }
 
 _lib = None

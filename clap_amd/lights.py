@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's light slots and clustered-lighting grid.
+
+``LightSet`` keeps what ``struct light`` keeps for the tile-mask pass (light.h:19-58): slot
+allocation (``light_get`` / ``light_put``, light.c:311-352), the per-slot setters
+(light.c:473-520) and the grid geometry (``light_handle_input`` resize, light.c:156-166, cell =
+TILE_WIDTH, light.c:210).  ``grid_compute`` is ``light_grid_compute`` (light.c:88-154) on the GPU;
+``from_entities`` the light hand-off of ``default_update`` (model.c:1689-1694).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+TILE_WIDTH = 64          # shader_constants.h:16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def grid_dims(width, height, cell=TILE_WIDTH):
+    tw, th = C.c_uint32(0), C.c_uint32(0)
+    _lib.lib().clapgpu_light_grid_dims(width, height, cell, C.byref(tw), C.byref(th))
+    return tw.value, th.value
+
+
+class LightSet:
+    def __init__(self, device="cuda:0", width=0, height=0, cell=TILE_WIDTH):
+        self.device = dev = torch.device(device)
+        M = _lib.LIGHTS_MAX
+        # host slots (authoritative, like struct light); uploaded when touched
+        self.pos = np.zeros((M, 3), np.float32)
+        self.color = np.zeros((M, 3), np.float32)
+        self.attenuation = np.zeros((M, 3), np.float32)
+        self.is_dir = np.zeros(M, np.int32)
+        self.active = np.zeros(M, np.uint32)
+        self.nr_lights = 0
+        self.width, self.height, self.cell = int(width), int(height), int(cell)
+        self._d = dict(pos=torch.zeros((M, 3), dtype=torch.float32, device=dev),
+                       color=torch.zeros((M, 3), dtype=torch.float32, device=dev),
+                       attenuation=torch.zeros((M, 3), dtype=torch.float32, device=dev),
+                       is_dir=torch.zeros(M, dtype=torch.int32, device=dev),
+                       active=torch.zeros(M, dtype=torch.int32, device=dev))
+        self._dirty = set(self._d)
+        self.tiles = None
+        self._carriers = None
+
+    # ---- slots (light.c:311-352, 473-520) ------------------------------------------------
+    def light_get(self):
+        free = np.flatnonzero(self.active == 0)
+        if free.size == 0:
+            raise _lib.ClapGpuError(_lib.ERR_TOO_LARGE, "light_get")
+        idx = int(free[0])                                  # bitmap_set_lowest
+        self.active[idx] = 1
+        self.nr_lights = max(self.nr_lights, idx + 1)
+        self.pos[idx] = 0
+        self.color[idx] = 0
+        self.attenuation[idx] = (1, 0, 0)
+        self.is_dir[idx] = 1
+        self._dirty.update(self._d)
+        return idx
+
+    def light_put(self, idx):
+        if self.light_is_valid(idx):
+            self.active[idx] = 0
+            self._dirty.add("active")
+
+    def light_is_valid(self, idx):
+        return 0 <= idx < self.nr_lights and bool(self.active[idx])
+
+    def _set(self, name, idx, value):
+        if self.light_is_valid(idx):                        # every setter is a no-op on a released slot
+            getattr(self, name)[idx] = value
+            self._dirty.add(name)
+
+    def light_set_pos(self, idx, pos):
+        self._set("pos", idx, pos)
+
+    def light_set_color(self, idx, color):
+        self._set("color", idx, color)
+
+    def light_set_attenuation(self, idx, att):
+        self._set("attenuation", idx, att)
+
+    def light_set_directional(self, idx, is_directional):
+        self._set("is_dir", idx, int(bool(is_directional)))
+
+    def load(self, lights):
+        """Take all slots from a dict as made by clap_amd.synth.lights()."""
+        n = int(lights["nr_lights"])
+        self.nr_lights = n
+        for k in ("pos", "color", "attenuation", "is_dir", "active"):
+            getattr(self, k)[:] = 0
+            getattr(self, k)[:n] = lights[k]
+        self._dirty.update(self._d)
+
+    def resize(self, width, height):
+        self.width, self.height = int(width), int(height)
+
+    # ---- device --------------------------------------------------------------------------
+    def _upload(self):
+        for k in self._dirty:
+            self._d[k].copy_(torch.from_numpy(getattr(self, k).view(np.int32) if k == "active" else getattr(self, k)))
+        self._dirty.clear()
+
+    def _desc(self):
+        d = self._d
+        return _lib.Lights(self.nr_lights, 0, d["pos"].data_ptr(), d["color"].data_ptr(),
+                           d["attenuation"].data_ptr(), d["is_dir"].data_ptr(), d["active"].data_ptr())
+
+    def set_carriers(self, entity, light, off):
+        """Entities that carry a light slot (e->light_idx, e->light_off; scene.c:1586-1608), in entity order."""
+        dev = self.device
+        self._carriers = (len(entity),
+                          torch.from_numpy(np.ascontiguousarray(entity, np.uint32).view(np.int32)).to(dev),
+                          torch.from_numpy(np.ascontiguousarray(light, np.int32)).to(dev),
+                          torch.from_numpy(np.ascontiguousarray(off, np.float32)).to(dev))
+
+    def from_entities(self, batch, all_dirty=False):
+        """model.c:1689-1694 for the carriers; run before batch.mq_update (which clears the dirty flags)."""
+        if not self._carriers or not self._carriers[0]:
+            return
+        self._upload()
+        n, ce, cl, co = self._carriers
+        desc = self._desc()
+        rc = _lib.lib().clapgpu_lights_from_entities(_stream(), C.byref(batch._desc),
+                                                     _lib.UPDATE_ALL_DIRTY if all_dirty else 0, n, ce.data_ptr(),
+                                                     cl.data_ptr(), co.data_ptr(), C.byref(desc))
+        _lib.check(rc, "clapgpu_lights_from_entities")
+
+    def download_pos(self):
+        """Light positions as the device holds them (after from_entities); also refreshes the host slots."""
+        torch.cuda.synchronize(self.device)
+        if "pos" not in self._dirty:
+            self.pos[:] = self._d["pos"].cpu().numpy()
+        return self.pos.copy()
+
+    def grid_compute(self, view_mx, proj_mx):
+        """light_grid_compute: returns the device tile masks int32[theight][twidth][4] (RGBA32UI texels)."""
+        self._upload()
+        tw, th = grid_dims(self.width, self.height, self.cell)
+        if not tw or not th:
+            return None
+        if self.tiles is None or self.tiles.shape[:2] != (th, tw):      # light_grid_update: reallocate on resize
+            self.tiles = torch.zeros((th, tw, 4), dtype=torch.int32, device=self.device)
+        desc = self._desc()
+        vm = np.ascontiguousarray(view_mx, np.float32)
+        pm = np.ascontiguousarray(proj_mx, np.float32)
+        rc = _lib.lib().clapgpu_light_grid_compute(_stream(), C.byref(desc), _fp(vm), _fp(pm), self.width,
+                                                   self.height, self.cell, self.tiles.data_ptr())
+        _lib.check(rc, "clapgpu_light_grid_compute")
+        return self.tiles
+
+    def download_tiles(self):
+        torch.cuda.synchronize(self.device)
+        return self.tiles.cpu().numpy().view(np.uint32)
+
+    def algorithmic_bytes(self):
+        tw, th = grid_dims(self.width, self.height, self.cell)
+        return 16 * tw * th                                 # the masks; the light slots are ~5 KB

@@ -402,3 +402,27 @@ def static_boxes(n=64, box=64.0, seed=5):
     if n:
         out[0] = [-1e3, 1e3, -10.0, 0.5, -1e3, 1e3]          # a ground slab
     return out
+
+
+LIGHTS_MAX = 128            # shader_constants.h:8
+LIGHT_TILE = 64             # TILE_WIDTH, shader_constants.h:16 (light.c:210)
+
+
+def lights(n=LIGHTS_MAX, seed=7, extent=60.0, n_dir=2, inactive_frac=0.1):
+    """Light slots as light_get / light_set_* leave them (light.c:311-340, 473-520): a few
+    directional slots (attenuation 1,0,0), point lights with glTF-style attenuation
+    (1, linear, quadratic) scattered around the origin -- in front of, beside and behind a camera
+    at the origin looking down -Z -- and some released slots inside [0, nr_lights)."""
+    rng = _rng(seed)
+    pos = np.stack([rng.uniform(-extent, extent, n), rng.uniform(-extent / 4, extent / 4, n),
+                    rng.uniform(-2 * extent, extent / 2, n)], 1).astype(F32)
+    color = (rng.uniform(0.2, 1.0, (n, 3)) * rng.uniform(0.5, 4.0, (n, 1))).astype(F32)
+    att = np.stack([np.ones(n), rng.uniform(0.02, 0.8, n), np.exp(rng.uniform(math.log(0.02), math.log(40.0), n))],
+                   1).astype(F32)
+    is_dir = np.zeros(n, np.int32)
+    is_dir[:min(n_dir, n)] = 1
+    att[is_dir != 0] = (1, 0, 0)
+    active = (rng.uniform(0, 1, n) >= inactive_frac).astype(np.uint32)
+    if n:
+        active[0] = 1
+    return dict(nr_lights=n, pos=pos, color=color, attenuation=att, is_dir=is_dir, active=active)

@@ -471,6 +471,52 @@ int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodies *b, uint3
                                     const double *static_aabb, uint32_t *pairs, uint32_t capacity,
                                     uint32_t *pair_total, void *scratch);
 
+/* ======================================================================== */
+/* Clustered lighting: lights x screen tiles bitmask (core/light.c)           */
+/* ======================================================================== */
+
+#define CLAPGPU_LIGHTS_MAX 128     /* LIGHTS_MAX, shader_constants.h:8: one bit per slot in an RGBA32UI texel */
+
+/*
+ * The slots of struct light (light.h:19-27) that light_grid_compute reads, as device arrays of
+ * CLAPGPU_LIGHTS_MAX entries: pos/color/attenuation are float[3] per slot, is_dir is the
+ * reference's int flag, active[i] != 0 <=> bit i of light->active is set.
+ */
+typedef struct clapgpu_lights {
+    uint32_t        nr_lights;     /* highest allocated slot + 1 (light.h:46) */
+    uint32_t        pad;
+    float          *pos;
+    const float    *color;
+    const float    *attenuation;
+    const int32_t  *is_dir;
+    const uint32_t *active;
+} clapgpu_lights;
+
+/* Tile counts light_grid_update gives the grid (light.c:51-52): ceilf((float)extent / cell).  Host. */
+void clapgpu_light_grid_dims(uint32_t width, uint32_t height, uint32_t cell, uint32_t *twidth, uint32_t *theight);
+
+/*
+ * light_grid_compute() (light.c:88-154): tiles[gy * twidth + gx][4] (device,
+ * the RGBA32UI image the reference uploads with texture_load, light.c:150-153) gets bit idx set
+ * iff light idx is active and directional, or is a point light in front of the far plane whose
+ * screen-space disc (radius from light_get_radius, light.c:301-309) reaches one of the tile's four
+ * corners.  view_mx / proj_mx: the main subview's matrices (host, column-major).
+ */
+int clapgpu_light_grid_compute(void *stream, const clapgpu_lights *lights, const float view_mx[16],
+                               const float proj_mx[16], uint32_t width, uint32_t height, uint32_t cell,
+                               uint32_t *tiles);
+
+/*
+ * default_update's light hand-off (model.c:1689-1694): carrier k = entity carrier_entity[k] holding
+ * light slot carrier_light[k] at offset carrier_off[k] (e->light_idx, e->light_off).  A carrier
+ * without a parent whose CLAPGPU_E_DIRTY is set (or any, under CLAPGPU_UPDATE_ALL_DIRTY) writes
+ * pos + offset into lights->pos[slot] if the slot is active (light_set_pos, light.c:473-480);
+ * carriers apply in list order.  Call BEFORE clapgpu_entities_update, which clears the dirty flags.
+ */
+int clapgpu_lights_from_entities(void *stream, const clapgpu_entities *e, uint32_t mode, uint32_t n_carriers,
+                                 const uint32_t *carrier_entity, const int32_t *carrier_light,
+                                 const float *carrier_off, const clapgpu_lights *lights);
+
 #ifdef __cplusplus
 }
 #endif

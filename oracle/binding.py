@@ -116,6 +116,12 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_light_radius.argtypes = [F32P, F32P, C.c_int]
+    L.clapo_light_radius.restype = C.c_float
+    L.clapo_light_grid_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, U32P, U32P]
+    L.clapo_light_grid_compute.argtypes = [C.c_uint32, U32P, I32P, F32P, F32P, F32P, F32P, F32P, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, U32P]
+    L.clapo_lights_from_entities.argtypes = [C.c_uint32, U32P, I32P, F32P, F32P, I32P, U8P, C.c_uint32, U32P, F32P]
 
 
 # ------------------------------------------------------------------ helpers
@@ -328,3 +334,41 @@ def entities_lod(scene, st, visible, cam_pos, model_lod, force_lod, cur_lod):
                              np.ascontiguousarray(model_lod, np.uint8), np.ascontiguousarray(force_lod, np.int32),
                              cur_lod, draw)
     return draw
+
+
+# ------------------------------------------------------------------ clustered lighting
+def light_grid_dims(width, height, cell):
+    tw, th = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    lib().clapo_light_grid_dims(width, height, cell, tw, th)
+    return int(tw[0]), int(th[0])
+
+
+def light_radius(color, attenuation, is_dir=False):
+    return float(lib().clapo_light_radius(np.ascontiguousarray(color, np.float32),
+                                          np.ascontiguousarray(attenuation, np.float32), int(is_dir)))
+
+
+def light_grid_compute(lights, view_mx, proj_mx, width, height, cell):
+    """lights: dict from clap_amd.synth.lights().  Returns tiles u32[theight][twidth][4]."""
+    tw, th = light_grid_dims(width, height, cell)
+    tiles = np.zeros((th, tw, 4), np.uint32)
+    lib().clapo_light_grid_compute(int(lights["nr_lights"]), np.ascontiguousarray(lights["active"], np.uint32),
+                                   np.ascontiguousarray(lights["is_dir"], np.int32),
+                                   np.ascontiguousarray(lights["pos"], np.float32),
+                                   np.ascontiguousarray(lights["color"], np.float32),
+                                   np.ascontiguousarray(lights["attenuation"], np.float32),
+                                   np.ascontiguousarray(view_mx, np.float32), np.ascontiguousarray(proj_mx, np.float32),
+                                   width, height, cell, tiles)
+    return tiles
+
+
+def lights_from_entities(carriers, pos_scale, parent, dirty, lights):
+    """carriers: dict(entity u32[k], light i32[k], off f32[k,3]).  Returns the new light positions."""
+    pos = np.ascontiguousarray(lights["pos"], np.float32).copy()
+    lib().clapo_lights_from_entities(len(carriers["entity"]), np.ascontiguousarray(carriers["entity"], np.uint32),
+                                     np.ascontiguousarray(carriers["light"], np.int32),
+                                     np.ascontiguousarray(carriers["off"], np.float32),
+                                     np.ascontiguousarray(pos_scale, np.float32), np.ascontiguousarray(parent, np.int32),
+                                     np.ascontiguousarray(dirty, np.uint8), int(lights["nr_lights"]),
+                                     np.ascontiguousarray(lights["active"], np.uint32), pos)
+    return pos

@@ -216,7 +216,19 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t n, const double *pos, const double *radius,
                                        uint32_t *pairs, uint64_t max_pairs);
 
+/* ---- clustered-lighting tile masks (light.c:88-154, 301-309; light.c) ---- */
+float clapo_light_radius(const float color[3], const float att[3], int is_dir);
+void clapo_light_grid_dims(uint32_t width, uint32_t height, uint32_t cell, uint32_t *twidth, uint32_t *theight);
+void clapo_light_grid_compute(uint32_t nr_lights, const uint32_t *active, const int32_t *is_dir,
+                              const float *pos, const float *color, const float *attenuation,
+                              const float view_mx[16], const float proj_mx[16],
+                              uint32_t width, uint32_t height, uint32_t cell, uint32_t *tiles);
+void clapo_lights_from_entities(uint32_t n_carriers, const uint32_t *carrier_entity, const int32_t *carrier_light,
+                                const float *carrier_off, const float *pos_scale, const int32_t *parent,
+                                const uint8_t *dirty, uint32_t nr_lights, const uint32_t *active, float *light_pos);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif /* CLAP_ORACLE_H */

@@ -11,8 +11,12 @@
  * channels_transform, one_joint_transform, particles_update,
  * subview_calc_frustum) are callable.  Nothing is copied.
  *
- * Two test doubles are defined here, both plain accessors whose real definitions live in
+ * Three test doubles are defined here, all for functions whose real definitions live in
  * translation units that cannot be built in this image:
+ *   texture_load()             (render-gl.c, needs GL headers): the sink light_grid_compute hands
+ *                              its finished tile masks to (light.c:150-153).  The double records
+ *                              format, size and the bytes handed over -- i.e. exactly what the
+ *                              reference would upload -- and reports success;
  *   renderer_get_caps()        (render-common.c:65-68, needs GL headers): on this path exactly
  *                              one field of its result is read (ndc_z_zero_one, view.c:267),
  *                              which the job file supplies;
@@ -27,11 +31,14 @@
  *   pose       channels_transform + one_joint_transform per character
  *   particles  particles_update x frames (drand48 stream from a given state)
  *   bench_entities   time default_update + view_entity_in_frustum
+ *   lod        entity3d_aabb_avg_edge + entity3d_set_lod
+ *   lightgrid  light_grid_compute: lights x screen tiles -> RGBA32UI masks
  */
 /* resolved through -I $(REF)/core (Makefile): /root/reference/core/{model,view,particle}.c */
 #include "model.c"
 #include "view.c"
 #include "particle.c"
+#include "light.c"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,6 +58,17 @@ static renderer_caps harness_caps;
 const renderer_caps *renderer_get_caps(renderer_t *r)
 {
     return &harness_caps;
+}
+
+static struct { texture_format format; unsigned int width, height; void *buf; int calls; } harness_tex;
+cerr texture_load(texture_t *tex, texture_format format, unsigned int width, unsigned int height, void *buf)
+{
+    harness_tex.format = format;
+    harness_tex.width = width;
+    harness_tex.height = height;
+    harness_tex.buf = buf;
+    harness_tex.calls++;
+    return CERR_OK;
 }
 
 /* ------------------------------------------------------------------ */
@@ -548,6 +566,56 @@ static int cmd_lod(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/* light_grid_compute (light.c:88-154) over given light slots; the grid's tile array is allocated here
+ * at the size light_grid_update (light.c:46-74) would give it, so that function returns early instead
+ * of touching the (unbuildable) texture object. */
+static int cmd_lightgrid(struct arrset *in, struct arrset *out)
+{
+    uint32_t nr_lights = *(uint32_t *)arr_get(in, "nr_lights", NULL);
+    uint32_t *gridp = arr_get(in, "grid", NULL);           /* width, height, cell */
+    uint32_t *active = arr_get(in, "active", NULL);        /* [nr_lights] 0/1 */
+    int32_t *is_dir = arr_get(in, "is_dir", NULL);
+    float *pos = arr_get(in, "pos", NULL), *color = arr_get(in, "color", NULL);
+    float *att = arr_get(in, "attenuation", NULL);
+    static struct light light;                              /* large (per-light views) */
+    struct view view;
+    struct arrset tmp = {};
+
+    view_setup(&view, in, &tmp);
+    memset(&light, 0, sizeof(light));
+    bitmap_init(&light.active, LIGHTS_MAX);
+    light.nr_lights = nr_lights;
+    for (uint32_t i = 0; i < nr_lights; i++) {
+        if (active[i]) bitmap_set(&light.active, i);
+        light.is_dir[i] = is_dir[i];
+        memcpy(&light.pos[3 * i], pos + 3 * i, 12);
+        memcpy(&light.color[3 * i], color + 3 * i, 12);
+        memcpy(&light.attenuation[3 * i], att + 3 * i, 12);
+    }
+    light.grid.width = gridp[0];
+    light.grid.height = gridp[1];
+    light.grid.cell = gridp[2];
+    light.grid.twidth = (unsigned int)ceilf((float)gridp[0] / gridp[2]);     /* light.c:51-52 */
+    light.grid.theight = (unsigned int)ceilf((float)gridp[1] / gridp[2]);
+    uint64_t ntiles = (uint64_t)light.grid.twidth * light.grid.theight;
+    light.grid.tiles = malloc(ntiles * sizeof(ui32vec4));
+    memset(light.grid.tiles, 0xa5, ntiles * sizeof(ui32vec4));
+
+    light_grid_compute(&light, &view);
+
+    if (harness_tex.calls != 1 || harness_tex.format != TEX_FMT_RGBA32UI)
+        die("light_grid_compute did not upload one RGBA32UI texture", NULL);
+    uint32_t dims[2] = { harness_tex.width, harness_tex.height };
+    memcpy(arr_add(out, "tile_dims", 8), dims, 8);
+    memcpy(arr_add(out, "tiles", ntiles * 16), harness_tex.buf, ntiles * 16);
+    float *o_rad = arr_add(out, "radius", (uint64_t)nr_lights * 4);
+    for (uint32_t i = 0; i < nr_lights; i++)
+        o_rad[i] = light_get_radius(&light, i);             /* light.c:301-309 */
+    memcpy(arr_add(out, "view_mx", 64), view.main.view_mx, 64);
+    memcpy(arr_add(out, "proj_mx", 64), view.main.proj_mx, 64);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     struct arrset in = {}, out = {};
@@ -560,6 +628,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[1], "particles"))       rc = cmd_particles(&in, &out);
     else if (!strcmp(argv[1], "pose"))            rc = cmd_pose(&in, &out);
     else if (!strcmp(argv[1], "lod"))             rc = cmd_lod(&in, &out);
+    else if (!strcmp(argv[1], "lightgrid"))       rc = cmd_lightgrid(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

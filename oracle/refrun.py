@@ -144,3 +144,18 @@ def lod_blocks(model_aabb, scale, lod_min, lod_max, request):
                           scale=np.asarray(scale, np.float32), lod_min=np.asarray(lod_min, np.int32),
                           lod_max=np.asarray(lod_max, np.int32), request=np.asarray(request, np.int32)))
     return clpio.as_array(out["avg_edge"], np.float32), clpio.as_array(out["cur_lod"], np.int32)
+
+
+def lightgrid(lights, cam, width, height, cell):
+    """The reference's light_grid_compute: returns (tiles u32[th][tw][4], radius f32[nr], view_mx, proj_mx)."""
+    nr = int(lights["nr_lights"])
+    arrays = dict(nr_lights=np.asarray([nr], np.uint32), grid=np.asarray([width, height, cell], np.uint32),
+                  active=np.asarray(lights["active"], np.uint32), is_dir=np.asarray(lights["is_dir"], np.int32),
+                  pos=np.asarray(lights["pos"], np.float32), color=np.asarray(lights["color"], np.float32),
+                  attenuation=np.asarray(lights["attenuation"], np.float32))
+    arrays.update(_camera_arrays(cam))
+    out = run("lightgrid", arrays)
+    tw, th = (int(v) for v in clpio.as_array(out["tile_dims"], np.uint32))
+    tiles = clpio.as_array(out["tiles"], np.uint32).reshape(th, tw, 4)
+    return (tiles, clpio.as_array(out["radius"], np.float32), clpio.as_array(out["view_mx"], np.float32),
+            clpio.as_array(out["proj_mx"], np.float32))

@@ -107,6 +107,15 @@ def pose_fixture(name, sk, an, chars, char_times):
     save(name, **d)
 
 
+def light_fixture(name, lights, cam, width, height, cell):
+    tiles, radius, view_mx, proj_mx = refrun.lightgrid(lights, cam, width, height, cell)
+    d = {"in_" + k: np.asarray(lights[k]) for k in ("pos", "color", "attenuation", "is_dir", "active")}
+    d.update({"cam_" + k: cam[k] for k in CAM_KEYS})
+    d.update(in_grid=np.asarray([width, height, cell], np.uint32), ref_tiles=tiles, ref_radius=radius,
+             ref_view_mx=view_mx, ref_proj_mx=proj_mx)
+    save(name, **d)
+
+
 def main():
     if not refrun.available():
         refrun.build()
@@ -130,6 +139,11 @@ def main():
                       np.full(12, -0.25, np.float32), np.zeros(12, np.float32)]).astype(np.float32)
         pose_fixture(nm, sk, an, ch, t)
     attach_fixture("attach_bv_frames")
+    tilted = synth.camera(pos=(1.0, 2.0, 3.0), quat=synth.quat_from_euler_xyz(0.1, 0.2, -0.05))
+    light_fixture("lightgrid_1080p", synth.lights(seed=7), tilted, 1920, 1080, synth.LIGHT_TILE)
+    light_fixture("lightgrid_odd_z01", synth.lights(97, seed=8, n_dir=1, inactive_frac=0.3),
+                  synth.camera(pos=(-4, 1, 9), quat=synth.quat_from_euler_xyz(-0.2, 2.8, 0.1), ndc_z_zero_one=1),
+                  333, 222, 16)
     entity_fixture("entities_flat_c1", synth.entities_flat(512, seed=1234), cam)
     entity_fixture("entities_flat_euler", synth.entities_flat(512, seed=99, full_euler=True),
                    synth.camera(pos=(10, 5, -20), quat=synth.quat_from_euler_xyz(0.2, 2.5, -0.1),
