@@ -145,7 +145,18 @@ def extras(device):
                      "roofline": roof(pw.integrate_algorithmic_bytes(), t_int),
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
-                                    "note": "11 launches (hash build, two counted scans, emit); latency- not HBM-bound"}}
+                                    "note": "hash build, bucket-ordered records, search, two counted scans, list copy; "
+                                            "latency- not HBM-bound"}}
+    del pw
+    # ---- 8f rank 2: clustered-lighting tile masks, 128 light slots x a 4K screen at the reference's 64-px tiles ----
+    from clap_amd import lights as gl
+    ls = gl.LightSet(device, 3840, 2160, gl.TILE_WIDTH)
+    ls.load(synth.lights(128, seed=7))
+    _fr, vm, pm = ob.frustum_from_camera(synth.camera(pos=(1.0, 2.0, 3.0)))
+    t_lg = time_launches(lambda: ls.grid_compute(vm, pm), 30)
+    tw, th = gl.grid_dims(3840, 2160, gl.TILE_WIDTH)
+    out["light_grid"] = {"tiles_per_s": tw * th / t_lg, "tiles": tw * th, "lights": 128, "us": t_lg * 1e6,
+                         "kernel": "k_light_grid", "note": "launch-bound: 2040 tiles x 128 lights, 32 KB out"}
     return out
 
 

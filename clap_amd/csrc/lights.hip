@@ -6,9 +6,10 @@
 // here the masks are produced in device memory in the same layout (tiles[gy * twidth + gx] =
 // 4 x u32, bit idx % 32 of word idx / 32).
 //
-// Mapping: one thread per tile; the <= 128 per-light constants (screen position, radius^2, kind) are
-// computed by the first 128 threads of every block into LDS -- 128 x ~40 flops, cheaper than a
-// separate launch -- and then read by all tiles as LDS broadcasts.  Output: 16 B per tile, coalesced.
+// Mapping: one lane per light, twice (lane l holds slots l and l + 64 in registers), one wavefront
+// per run of 16 tiles: a tile's mask is two 64-lane ballots of the disc test, so the 128-light loop
+// of the reference becomes two vector compares and the per-light constants never leave registers.
+// Lane k of the wave keeps tile k's mask and the run is stored as one 256-byte row.
 //
 // Numerics: the reference's fp32 operation order (no contraction, IEEE divide and sqrt); the two
 // double-typed comparisons (light.c:116,118) are made in double.  The masks are bit-exact.
@@ -41,71 +42,66 @@ __device__ __forceinline__ float light_radius(const float *color, const float *a
     return (-att[1] + sqrtf(att[1] * att[1] - 4.0f * att[2] * (att[0] - comp_max / cutoff))) / (2.0f * att[2]);
 }
 
+constexpr int LIGHT_TILES_PER_WAVE = 16;
+
+// Per-slot constants of the disc test (light.c:100-127).  A slot that contributes nothing gets
+// rsq = -1 (no squared distance is below it), a directional slot rsq = +inf at (0, 0): every
+// corner distance is finite, so its test always passes -- the `goto grid` / `continue` of the reference.
+__device__ __forceinline__ void light_constants(const LightGridArgs &a, uint32_t t, float &x, float &y, float &r2)
+{
+    x = 0.f; y = 0.f; r2 = -1.0f;
+    if (t >= a.nr_lights || !a.active[t]) return;
+    if (a.is_dir[t]) { r2 = __builtin_inff(); return; }
+    const float lp[4] = { a.pos[3 * t], a.pos[3 * t + 1], a.pos[3 * t + 2], 1.0f };
+    float vp[4], ndc[4];
+    lmd::mul_vec4(vp, a.view, lp);                                   // light.c:108-109
+    lmd::mul_vec4(ndc, a.mvp, lp);
+    const float s = 1.0f / ndc[3];                                   // vec3_scale: w itself is kept
+    ndc[0] = ndc[0] * s; ndc[1] = ndc[1] * s; ndc[2] = ndc[2] * s;
+    if ((double)fabsf(ndc[3]) < 1e-3 || (double)ndc[2] > 1.0) return;  // light.c:112-114
+    const float radius = light_radius(a.color + 3 * t, a.attenuation + 3 * t) * a.fx / -vp[2] * ((float)a.width / 2.0f);
+    r2 = radius * radius;
+    x = (ndc[0] + 1.0f) / 2.0f * (float)a.width;
+    y = (1.0f - ndc[1]) / 2.0f * (float)a.height;
+}
+
+// any of the tile's four corners inside the light's disc (light.c:138-147); vec2_mul_inner: p = 0; p += d0*d0; p += d1*d1
+__device__ __forceinline__ bool disc_reaches(float sx, float sy, float r2, float x0, float x1, float y0, float y1)
+{
+    const float dx0 = sx - x0, dx1 = sx - x1, dy0 = sy - y0, dy1 = sy - y1;
+    float d00 = 0.f; d00 += dx0 * dx0; d00 += dy0 * dy0;
+    float d10 = 0.f; d10 += dx1 * dx1; d10 += dy0 * dy0;
+    float d01 = 0.f; d01 += dx0 * dx0; d01 += dy1 * dy1;
+    float d11 = 0.f; d11 += dx1 * dx1; d11 += dy1 * dy1;
+    return d00 < r2 || d10 < r2 || d01 < r2 || d11 < r2;
+}
+
 __global__ __launch_bounds__(LIGHT_BLOCK)
 void k_light_grid(LightGridArgs a)
 {
-    // kind: 0 = contributes nothing, 1 = point light (sx, sy, rsq valid), 2 = directional
-    __shared__ float sx[CLAPGPU_LIGHTS_MAX], sy[CLAPGPU_LIGHTS_MAX], rsq[CLAPGPU_LIGHTS_MAX];
-    __shared__ uint32_t kind[CLAPGPU_LIGHTS_MAX];
-
-    const uint32_t t = threadIdx.x;
-    if (t < CLAPGPU_LIGHTS_MAX) {
-        uint32_t kd = 0;
-        float x = 0.f, y = 0.f, r2 = 0.f;
-        if (t < a.nr_lights && a.active[t]) {
-            if (a.is_dir[t]) {
-                kd = 2;                                              // light.c:100, 135
-            } else {
-                const float lp[4] = { a.pos[3 * t], a.pos[3 * t + 1], a.pos[3 * t + 2], 1.0f };
-                float vp[4], ndc[4];
-                lmd::mul_vec4(vp, a.view, lp);                       // light.c:108-109
-                lmd::mul_vec4(ndc, a.mvp, lp);
-                const float s = 1.0f / ndc[3];                       // vec3_scale: w itself is kept
-                ndc[0] = ndc[0] * s; ndc[1] = ndc[1] * s; ndc[2] = ndc[2] * s;
-                if (!((double)fabsf(ndc[3]) < 1e-3) && !((double)ndc[2] > 1.0)) {      // light.c:112-114
-                    const float radius = light_radius(a.color + 3 * t, a.attenuation + 3 * t) * a.fx / -vp[2] *
-                                         ((float)a.width / 2.0f);
-                    r2 = radius * radius;
-                    x = (ndc[0] + 1.0f) / 2.0f * (float)a.width;
-                    y = (1.0f - ndc[1]) / 2.0f * (float)a.height;
-                    kd = 1;
-                }
-            }
-        }
-        sx[t] = x; sy[t] = y; rsq[t] = r2; kind[t] = kd;
-    }
-    __syncthreads();
+    const int lane = lane_id();
+    float ax, ay, ar, bx, by, br;
+    light_constants(a, (uint32_t)lane, ax, ay, ar);
+    light_constants(a, (uint32_t)lane + 64u, bx, by, br);
 
     const uint32_t n_tiles = a.twidth * a.theight;
-    const uint32_t tile = blockIdx.x * LIGHT_BLOCK + t;
-    if (tile >= n_tiles) return;
-    const uint32_t gx = tile % a.twidth, gy = tile / a.twidth;
-    // the tile's corner coordinates: unsigned arithmetic, then float (light.c:140-143)
-    const float x0 = (float)(gx * a.cell), x1 = (float)(gx * a.cell + a.cell);
-    const float y0 = (float)(gy * a.cell), y1 = (float)(gy * a.cell + a.cell);
-    uint32_t w[4] = { 0, 0, 0, 0 };
-#pragma unroll
-    for (int word = 0; word < 4; word++) {
-        uint32_t m = 0;
-        for (int b = 0; b < 32; b++) {
-            const int idx = 32 * word + b;
-            const uint32_t kd = kind[idx];
-            bool set = kd == 2;
-            if (kd == 1) {
-                const float dx0 = sx[idx] - x0, dx1 = sx[idx] - x1, dy0 = sy[idx] - y0, dy1 = sy[idx] - y1;
-                const float r2 = rsq[idx];
-                // vec2_mul_inner: p = 0; p += d0*d0; p += d1*d1 (linmath.h:40-47)
-                float d00 = 0.f; d00 += dx0 * dx0; d00 += dy0 * dy0;
-                float d10 = 0.f; d10 += dx1 * dx1; d10 += dy0 * dy0;
-                float d01 = 0.f; d01 += dx0 * dx0; d01 += dy1 * dy1;
-                float d11 = 0.f; d11 += dx1 * dx1; d11 += dy1 * dy1;
-                set = d00 < r2 || d10 < r2 || d01 < r2 || d11 < r2;
-            }
-            m |= (uint32_t)set << b;
-        }
-        w[word] = m;
+    const uint32_t wave = blockIdx.x * (LIGHT_BLOCK / WAVE) + threadIdx.x / WAVE;
+    const uint32_t first = wave * LIGHT_TILES_PER_WAVE;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < LIGHT_TILES_PER_WAVE; k++) {
+        const uint32_t tile = first + k;                             // wave-uniform
+        if (tile >= n_tiles) break;
+        const uint32_t gx = tile % a.twidth, gy = tile / a.twidth;
+        // the tile's corner coordinates: unsigned arithmetic, then float (light.c:140-143)
+        const float x0 = (float)(gx * a.cell), x1 = (float)(gx * a.cell + a.cell);
+        const float y0 = (float)(gy * a.cell), y1 = (float)(gy * a.cell + a.cell);
+        const uint64_t lo = __ballot(disc_reaches(ax, ay, ar, x0, x1, y0, y1));      // slots 0..63
+        const uint64_t hi = __ballot(disc_reaches(bx, by, br, x0, x1, y0, y1));      // slots 64..127
+        if (lane == k)
+            mine = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
     }
-    a.tiles[tile] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (lane < LIGHT_TILES_PER_WAVE && first + lane < n_tiles)
+        a.tiles[first + lane] = mine;
 }
 
 struct LightCarrierArgs {
@@ -208,7 +204,8 @@ extern "C" int clapgpu_light_grid_compute(void *stream, const clapgpu_lights *li
     a.width = width; a.height = height; a.cell = cell; a.twidth = tw; a.theight = th;
     a.tiles = reinterpret_cast<uint4 *>(tiles);
     const uint32_t n_tiles = tw * th;
-    hipLaunchKernelGGL(k_light_grid, dim3((n_tiles + LIGHT_BLOCK - 1) / LIGHT_BLOCK), dim3(LIGHT_BLOCK), 0,
+    constexpr uint32_t per_block = LIGHT_TILES_PER_WAVE * (LIGHT_BLOCK / WAVE);
+    hipLaunchKernelGGL(k_light_grid, dim3((n_tiles + per_block - 1) / per_block), dim3(LIGHT_BLOCK), 0,
                        as_stream(stream), a);
     CLAPGPU_LAUNCH_CHECK("k_light_grid");
     return CLAPGPU_OK;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE of the secondary kernels a few times (for rocprofv3 --pmc / --kernel-trace).
 
-    python tools/run_kernel.py pose|skin|particles|bodies|broadphase [iters]
+    python tools/run_kernel.py pose|skin|particles|bodies|broadphase|lights [iters]
 """
 import os
 import sys
@@ -39,6 +39,13 @@ def main():
         pb = particles.ParticleBatch(ps, pos, vel, st, dev)
         view = np.eye(4, dtype=np.float32).ravel()
         fn = lambda: pb.particles_update(view)
+    elif which == "lights":
+        from clap_amd import lights as gl
+        from oracle import binding as ob
+        ls = gl.LightSet(dev, 3840, 2160, 16)                    # 4K at 16-px tiles: 32 400 tiles
+        ls.load(synth.lights(128, seed=7))
+        _fr, vm, pm = ob.frustum_from_camera(synth.camera(pos=(1.0, 2.0, 3.0)))
+        fn = lambda: ls.grid_compute(vm, pm)
     else:
         b = synth.sphere_bodies(262_144, box=64.0, seed=4)
         pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=dev)
