@@ -20,8 +20,6 @@
 
 namespace clapgpu {
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
 struct PoseArgs {
     // skeleton
     uint32_t        J, n_jump_steps;
@@ -117,13 +115,6 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
     const float f = sin_theta / sin_theta_0;
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
-}
-
-// value of another lane of the same quad (DPP quad_perm; no LDS traffic)
-template <int CTRL>
-__device__ __forceinline__ float quad_swap(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 #ifndef POSE_WAVES
@@ -268,96 +259,83 @@ void k_pose(PoseArgs a)
                 }
             }
         }
-        const int mb = lane >> 2, mi = lane & 3;                  // MFMA block (joint within a 16-run) and row/column
-        const uint32_t row_j0 = (uint32_t)(j - lane);             // first joint of this wave's row
-        float *tile_f = G + (row_j0 / WAVE) * (WAVE * G_STRIDE);  // this wave's 4 KiB of the character's LDS
-        float4 *tile = reinterpret_cast<float4 *>(tile_f);
-        const bool wave_ok = char_ok && row_j0 < J;               // wave-uniform
-        const int nvalid = wave_ok ? (int)(J - row_j0 < WAVE ? J - row_j0 : WAVE) : 0;
-        const size_t row0 = (size_t)c * J + row_j0;
-
-        // operands of the palette product below, requested now so that they arrive behind the T/R/S
-        // stores: for each of the four 16-joint runs, invmx column mi = IM(0..3, mi) and bind(mi, 3)
-        // (only column 3 of bind reaches pos) of joint 16g + mb, and row mi of e->mx
-        float4 Bq[4];
-        float bvq[4], em[4] = { 0.f, 0.f, 0.f, 0.f };
+        float Gm[16];                                             // global = root_pose * path product
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint32_t jj = row_j0 + (uint32_t)(16 * g + mb);
-            Bq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            bvq[g] = 0.f;
-            if (jj < J) {
-                Bq[g] = a.invmx[4 * jj + mi];
-                bvq[g] = reinterpret_cast<const float *>(a.bind + 4 * jj + 3)[mi];
+        for (int r = 0; r < 4; r++) {
+#pragma clang fp contract(fast)
+            const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
+            E_(Gm, 0, r) = p0 * M0.x + p1 * M1.x + p2 * M2.x;
+            E_(Gm, 1, r) = p0 * M0.y + p1 * M1.y + p2 * M2.y;
+            E_(Gm, 2, r) = p0 * M0.z + p1 * M1.z + p2 * M2.z;
+            E_(Gm, 3, r) = p0 * M0.w + p1 * M1.w + p2 * M2.w + p3;
+        }
+
+        // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
+        float JT[16], pos[4] = { 0, 0, 0, 0 };
+        if (joint_ok && reachable) {
+            float IM[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = a.invmx[4 * j + q];
+                IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
             }
-        }
-        if (wave_ok) {
-            const uint32_t ei = a.entity ? a.entity[c] : c;
+            const float4 b3 = a.bind[4 * j + 3];                  // only column 3 of bind reaches mpos
+            const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
+            lmd::mul(JT, Gm, IM);                                 // model.c:1389
+            float mpos[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) em[k] = a.entity_mx[16 * (size_t)ei + 4 * k + mi];
+            for (int r = 0; r < 4; r++) {                         // column 3 of JT * bind (model.c:1393-1397)
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) s += E_(JT, k, r) * bv[k];
+                mpos[r] = s;
+            }
+            const uint32_t ei = a.entity ? a.entity[c] : c;
+            float EM[16];
+            const float4 *em = reinterpret_cast<const float4 *>(a.entity_mx + 16 * (size_t)ei);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = em[q];
+                EM[4 * q] = v.x; EM[4 * q + 1] = v.y; EM[4 * q + 2] = v.z; EM[4 * q + 3] = v.w;
+            }
+            lmd::mul_vec4(pos, EM, mpos);                         // model.c:1400
         }
 
-        // ---- T/R/S out (64 joints of one character per wave row, staged for 1-KiB stores) ----
-        if (wave_ok) {
+        // ---- stores (64 joints of one character per wave row) ----
+        if (LPC != WAVE) __syncthreads();                         // every wave is done reading parents from G
+        const uint32_t row_j0 = (uint32_t)(j - lane);             // first joint of this wave's row
+        if (char_ok && row_j0 < J) {                              // wave-uniform
+            const int nvalid = (int)(J - row_j0 < WAVE ? J - row_j0 : WAVE);
+            const size_t row0 = (size_t)c * J + row_j0;
+            float *tile_f = G + (row_j0 / WAVE) * (WAVE * G_STRIDE);      // the 4 KiB this wave's joints occupied
+            float4 *tile = reinterpret_cast<float4 *>(tile_f);
+
             const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
             stage_rows<10>(tile_f, trs_row, lane);                // 2560 B
             wave_lds_fence();
             store_rows<10>(tile_f, a.trs + 10 * row0, lane, nvalid);
             wave_lds_fence();
-        }
 
-        // ---- 3. palette: joint_transforms = global * invmx (model.c:1389) on the matrix cores ----
-        // global = root_pose * path product, as rows (row r = G(r, 0..3)).  64 independent 4x4x4
-        // products per wave = four v_mfma_f32_4x4x1_16b_f32 chains (16 blocks each, K stepped 0..3).
-        // Operand layout of that instruction: lane 4b+i supplies A(i,k) and B(k,i) of block b and
-        // receives D(0..3, i) in its four accumulators -- one column of a column-major
-        // joint_transforms matrix, so the result is stored straight from the accumulators, 1 KiB
-        // contiguous per chain, with no staging pass.  The globals change lanes through the wave's
-        // LDS tile (row r of joint j at a swizzled float4 slot).
-        {
-            const int sw_me = (lane >> 2) & 3;
+            const uint64_t reach_mask = __ballot(joint_ok && reachable);
+            const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
+            if (reach_mask == full) {
+                float4 v[4];
+                stage_mat4(tile, JT, lane);
+                wave_lds_fence();
+                unstage_mat4(tile, v, lane);
+                store_mat4_rows(a.joint_transforms + 16 * row0, v, lane, nvalid);
+                if (lane < nvalid)
+                    reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
+                wave_lds_fence();
+            } else if (joint_ok && reachable) {                   // joints not under joint 0 are never written
+                float4 *dj = reinterpret_cast<float4 *>(a.joint_transforms + 16 * cj);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-#pragma clang fp contract(fast)
-                const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
-                tile[4 * lane + (r ^ sw_me)] =
-                    make_float4(p0 * M0.x + p1 * M1.x + p2 * M2.x, p0 * M0.y + p1 * M1.y + p2 * M2.y,
-                                p0 * M0.z + p1 * M1.z + p2 * M2.z, p0 * M0.w + p1 * M1.w + p2 * M2.w + p3);
+                for (int q = 0; q < 4; q++)
+                    dj[q] = make_float4(JT[4 * q], JT[4 * q + 1], JT[4 * q + 2], JT[4 * q + 3]);
+                reinterpret_cast<float4 *>(a.joint_pos)[cj] = make_float4(pos[0], pos[1], pos[2], pos[3]);
             }
         }
-        wave_lds_fence();
-        const uint64_t reach_mask = __ballot(joint_ok && reachable);
-        // pos = e->mx * (joint_transforms * bind)(.,3) (model.c:1393-1400): the four lanes of a joint add
-        // up their column's share of the product (quad DPP), lane mi keeps component mi
-        float4 *jt_out = reinterpret_cast<float4 *>(a.joint_transforms + 16 * row0);
-        float *pos_out = a.joint_pos + 4 * row0;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int src = 16 * g + mb;                          // lane of the joint this lane works for
-            const float4 A = tile[4 * src + (mi ^ ((src >> 2) & 3))];       // G(mi, 0..3) of that joint
-            const float4 B = Bq[g];
-            const float bvc = bvq[g];
-            floatx4 acc = { 0.f, 0.f, 0.f, 0.f };
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A.x, B.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A.y, B.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A.z, B.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A.w, B.w, acc, 0, 0, 0);
-            float m[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = acc[r] * bvc;
-                v += quad_swap<0xB1>(v);                          // lanes (1,0,3,2)
-                v += quad_swap<0x4E>(v);                          // lanes (2,3,0,1)
-                m[r] = v;
-            }
-            float t = em[0] * m[0] + em[1] * m[1] + em[2] * m[2];
-            t += em[3] * m[3];
-            if (wave_ok && ((reach_mask >> src) & 1ull)) {        // joints not under joint 0 are never written
-                jt_out[64 * g + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                pos_out[64 * g + lane] = t;
-            }
-        }
-        if (LPC != WAVE) __syncthreads();                         // next character reuses the LDS
+        if (LPC != WAVE) __syncthreads();                         // next character reuses the globals in LDS
     }
 }
 
