@@ -117,6 +117,9 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
 }
 
+#ifndef POSE_DIRECT_STORES
+#define POSE_DIRECT_STORES 0
+#endif
 #ifndef POSE_WAVES
 #define POSE_WAVES 4
 #endif
@@ -318,7 +321,7 @@ void k_pose(PoseArgs a)
 
             const uint64_t reach_mask = __ballot(joint_ok && reachable);
             const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
-            if (reach_mask == full) {
+            if (reach_mask == full && !POSE_DIRECT_STORES) {
                 float4 v[4];
                 stage_mat4(tile, JT, lane);
                 wave_lds_fence();
