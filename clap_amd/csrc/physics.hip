@@ -519,6 +519,65 @@ void k_bp_copy_lists(uint32_t n, const uint32_t *pair_start, const uint32_t *par
         reinterpret_cast<uint2 *>(pairs)[start + q] = make_uint2(i, partners[(size_t)i * BP_LIST + q]);
 }
 
+// dCollide for sphere pairs + phys_contact_surface (see include/clapgpu.h): one lane per candidate
+// pair; geometry as ODE's dCollideSpheres, IEEE fp64 (sqrt, divide), no contraction.
+__global__ __launch_bounds__(PHYS_BLOCK)
+void k_contacts_spheres(const double *pos, const double *radius, uint32_t n_bodies, const uint2 *pairs,
+                        const uint32_t *pair_total, uint32_t capacity, const double *material,
+                        clapgpu_contact *out, uint32_t *contact_total)
+{
+    const uint32_t n_pairs = *pair_total < capacity ? *pair_total : capacity;
+    const uint32_t k = blockIdx.x * PHYS_BLOCK + threadIdx.x;
+    bool touch = false;
+    if (k < n_pairs) {
+        const uint2 pr = pairs[k];
+        clapgpu_contact c;
+        memset(&c, 0, sizeof(c));
+        if (pr.x < n_bodies && pr.y < n_bodies) {
+            const double *p1 = pos + 3 * (size_t)pr.x, *p2 = pos + 3 * (size_t)pr.y;
+            const double r1 = radius[pr.x], r2 = radius[pr.y];
+            const double dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (!(d > r1 + r2)) {
+                touch = true;
+                if (d <= 0) {
+                    c.pos[0] = p1[0]; c.pos[1] = p1[1]; c.pos[2] = p1[2];
+                    c.normal[0] = 1; c.normal[1] = 0; c.normal[2] = 0;
+                    c.depth = r1 + r2;
+                } else {
+                    const double d1 = 1.0 / d;
+                    c.normal[0] = dx * d1; c.normal[1] = dy * d1; c.normal[2] = dz * d1;
+                    const double kk = 0.5 * (r2 - r1 - d);
+                    c.pos[0] = p1[0] + c.normal[0] * kk;
+                    c.pos[1] = p1[1] + c.normal[1] * kk;
+                    c.pos[2] = p1[2] + c.normal[2] * kk;
+                    c.depth = r1 + r2 - d;
+                }
+                double bounce = 0, bounce_vel = 0, mu = 0, soft_erp = 0.05, soft_cfm = 0.01;   // physics.c:293-294
+                if (material) {
+                    const double *m1 = material + 5 * (size_t)pr.x, *m2 = material + 5 * (size_t)pr.y;
+                    bounce = fmax(m1[0], m2[0]);
+                    bounce_vel = (m1[1] + m2[1]) * 0.5;
+                    mu = sqrt(m1[2] * m2[2]);
+                    if (m1[3] > 0 && m2[3] > 0) soft_erp = fmin(m1[3], m2[3]);
+                    else if (m1[3] > 0) soft_erp = m1[3];
+                    else if (m2[3] > 0) soft_erp = m2[3];
+                    if (m1[4] > 0 && m2[4] > 0) soft_cfm = fmax(m1[4], m2[4]);
+                    else if (m1[4] > 0) soft_cfm = m1[4];
+                    else if (m2[4] > 0) soft_cfm = m2[4];
+                }
+                c.mode = CLAPGPU_CONTACT_SOFT_CFM | CLAPGPU_CONTACT_SOFT_ERP | (bounce > 0 ? CLAPGPU_CONTACT_BOUNCE : 0);
+                c.mu = mu; c.bounce = bounce; c.bounce_vel = bounce_vel; c.soft_erp = soft_erp; c.soft_cfm = soft_cfm;
+                c.nc = 1;
+            }
+        }
+        out[k] = c;
+    }
+    const uint64_t m = __ballot(touch);
+    if (contact_total && lane_id() == 0 && m)
+        atomicAdd(contact_total, (uint32_t)__popcll(m));
+}
+
 } // namespace clapgpu
 
 using namespace clapgpu;
@@ -698,5 +757,26 @@ extern "C" int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodie
     hipLaunchKernelGGL(k_bp_static<true>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
                        sc.pcount, sc.partners, pairs, capacity);
     CLAPGPU_LAUNCH_CHECK("k_bp_static<emit>");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, const uint32_t *pairs,
+                                        const uint32_t *pair_total, uint32_t capacity, const double *material,
+                                        clapgpu_contact *contacts, uint32_t *contact_total)
+{
+    int rc = check_bodies(b);
+    if (rc) return rc;
+    if (!pair_total || (capacity && (!pairs || !contacts)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    hipStream_t s = as_stream(stream);
+    if (contact_total)
+        CLAPGPU_HIP(hipMemsetAsync(contact_total, 0, sizeof(uint32_t), s));
+    if (capacity == 0 || b->n == 0)
+        return CLAPGPU_OK;
+    // the pair count lives on the device: launch for the capacity, lanes past the count retire at once
+    hipLaunchKernelGGL(k_contacts_spheres, dim3((capacity + PHYS_BLOCK - 1) / PHYS_BLOCK), dim3(PHYS_BLOCK), 0, s,
+                       b->pos, b->radius, b->n, reinterpret_cast<const uint2 *>(pairs), pair_total, capacity,
+                       material, contacts, contact_total);
+    CLAPGPU_LAUNCH_CHECK("k_contacts_spheres");
     return CLAPGPU_OK;
 }

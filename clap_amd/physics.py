@@ -67,6 +67,27 @@ class PhysWorld:
                                               self.capacity, _ptr(self.pair_total), _ptr(self.scratch)),
                    "clapgpu_broadphase_pairs")
 
+    def set_materials(self, material):
+        """Per-body phys_body parameters (bounce, bounce_vel, mu, soft_erp, soft_cfm; physics.c:77-81)."""
+        self.material = torch.from_numpy(np.ascontiguousarray(material, np.float64)).to(self.device)
+
+    def contacts(self):
+        """near_callback on the body x body candidate pairs of the last broadphase(): one contact record
+        per pair (oracle.binding.CONTACT_DTYPE layout = clapgpu_contact) + the number of touching pairs."""
+        if getattr(self, "contact_buf", None) is None:
+            self.contact_buf = torch.zeros((self.capacity, 104), dtype=torch.uint8, device=self.device)
+            self.contact_total = torch.zeros(1, dtype=torch.int32, device=self.device)
+        mat = getattr(self, "material", None)
+        _lib.check(_lib.lib().clapgpu_contacts_spheres(_stream(), C.byref(self._desc), _ptr(self.pairs),
+                                                       _ptr(self.pair_total), self.capacity, _ptr(mat),
+                                                       _ptr(self.contact_buf), _ptr(self.contact_total)),
+                   "clapgpu_contacts_spheres")
+
+    def download_contacts(self, dtype):
+        torch.cuda.synchronize(self.device)
+        npairs = min(int(self.pair_total.item()), self.capacity)
+        return self.contact_buf[:npairs].cpu().numpy().view(dtype).reshape(-1), int(self.contact_total.item())
+
     def world_step(self, h):
         _lib.check(_lib.lib().clapgpu_bodies_step(_stream(), C.byref(self._desc), C.byref(self.world), h),
                    "clapgpu_bodies_step")

@@ -471,6 +471,30 @@ int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodies *b, uint3
                                     const double *static_aabb, uint32_t *pairs, uint32_t capacity,
                                     uint32_t *pair_total, void *scratch);
 
+/*
+ * near_callback() for the sphere bodies (physics.c:399-449): dCollide on every
+ * candidate pair of clapgpu_broadphase_pairs, plus the surface parameters phys_contact_surface
+ * (physics.c:291-330) gives each contact.  One record per pair, in pair order (the reference
+ * creates its contact joints in callback order; here the canonical pair order): nc = dCollide's
+ * return value (0 or 1 for spheres).  ODE's dContactGeom / dSurfaceParameters fields, doubles.
+ * material[b] = (bounce, bounce_vel, mu, soft_erp, soft_cfm) of body b's phys_body
+ * (physics.c:77-81), or NULL for bodies without parameters.  *contact_total (device, may be NULL)
+ * receives the number of touching pairs.  n_pairs is read from the device counter pair_total,
+ * clamped to capacity.  Contact joints and the LCP solve stay in ODE.
+ */
+#define CLAPGPU_CONTACT_BOUNCE   0x004   /* dContactBounce  (ode/contact.h) */
+#define CLAPGPU_CONTACT_SOFT_ERP 0x008   /* dContactSoftERP */
+#define CLAPGPU_CONTACT_SOFT_CFM 0x010   /* dContactSoftCFM */
+typedef struct clapgpu_contact {
+    double   pos[3], normal[3], depth;
+    double   mu, bounce, bounce_vel, soft_erp, soft_cfm;
+    uint32_t mode;
+    uint32_t nc;
+} clapgpu_contact;
+int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, const uint32_t *pairs,
+                             const uint32_t *pair_total, uint32_t capacity, const double *material,
+                             clapgpu_contact *contacts, uint32_t *contact_total);
+
 /* ======================================================================== */
 /* Clustered lighting: lights x screen tiles bitmask (core/light.c)           */
 /* ======================================================================== */

@@ -116,6 +116,8 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_contacts_spheres.argtypes = [C.c_uint32, U32P, F64P, F64P, C.c_void_p, C.c_void_p]
+    L.clapo_contacts_spheres.restype = C.c_uint32
     L.clapo_light_radius.argtypes = [F32P, F32P, C.c_int]
     L.clapo_light_radius.restype = C.c_float
     L.clapo_light_grid_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, U32P, U32P]
@@ -372,3 +374,20 @@ def lights_from_entities(carriers, pos_scale, parent, dirty, lights):
                                      np.ascontiguousarray(dirty, np.uint8), int(lights["nr_lights"]),
                                      np.ascontiguousarray(lights["active"], np.uint32), pos)
     return pos
+
+
+# ------------------------------------------------------------------ sphere contacts
+CONTACT_DTYPE = np.dtype([("pos", np.float64, 3), ("normal", np.float64, 3), ("depth", np.float64),
+                          ("mu", np.float64), ("bounce", np.float64), ("bounce_vel", np.float64),
+                          ("soft_erp", np.float64), ("soft_cfm", np.float64), ("mode", np.uint32), ("nc", np.uint32)])
+
+
+def contacts_spheres(pairs, pos, radius, material=None):
+    """One contact record per candidate pair (nc = 0 where the spheres do not touch); returns (records, total)."""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    out = np.zeros(len(pairs), CONTACT_DTYPE)
+    mat = None if material is None else np.ascontiguousarray(material, np.float64)
+    total = lib().clapo_contacts_spheres(len(pairs), pairs.ravel(), np.ascontiguousarray(pos, np.float64),
+                                         np.ascontiguousarray(radius, np.float64),
+                                         None if mat is None else mat.ctypes.data, out.ctypes.data)
+    return out, int(total)

@@ -216,6 +216,16 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t n, const double *pos, const double *radius,
                                        uint32_t *pairs, uint64_t max_pairs);
 
+/* ---- sphere contacts after the broadphase (physics.c:291-330, 399-449; physics.c) ---- */
+typedef struct clapo_contact {
+    double   pos[3], normal[3], depth;                  /* dContactGeom */
+    double   mu, bounce, bounce_vel, soft_erp, soft_cfm;/* dSurfaceParameters as phys_contact_surface fills them */
+    uint32_t mode;                                      /* dContactSoftCFM | dContactSoftERP [| dContactBounce] */
+    uint32_t nc;                                        /* dCollide's return value for the pair: 0 or 1 */
+} clapo_contact;
+uint32_t clapo_contacts_spheres(uint32_t n_pairs, const uint32_t *pairs, const double *pos, const double *radius,
+                                const double *material, clapo_contact *out);
+
 /* ---- clustered-lighting tile masks (light.c:88-154, 301-309; light.c) ---- */
 float clapo_light_radius(const float color[3], const float att[3], int is_dir);
 void clapo_light_grid_dims(uint32_t width, uint32_t height, uint32_t cell, uint32_t *twidth, uint32_t *theight);

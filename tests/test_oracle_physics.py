@@ -90,3 +90,29 @@ def test_body_readback_layout():
     assert np.array_equal(rot[5:45], st["quat"][:, [1, 2, 3, 0]].astype(np.float32))          # wxyz -> xyzw
     assert (fl[5:45] == synth.E_DIRTY).all() and not fl[:5].any()
     assert np.array_equal(moving, (np.linalg.norm(st["lvel"], axis=1) > 1e-3).astype(np.uint8))
+
+
+def test_sphere_contact_restatement_properties():
+    """dCollideSpheres + phys_contact_surface restated (parity unpinned: ODE absent): invariants."""
+    b = synth.sphere_bodies(4000, box=12.0, seed=8)
+    pairs = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=1 << 20)
+    c, total = ob.contacts_spheres(pairs, b["pos"], b["radius"])
+    hit = c["nc"] == 1
+    assert total == hit.sum() and 0 < total < len(pairs)
+    d = np.linalg.norm(b["pos"][pairs[:, 0]] - b["pos"][pairs[:, 1]], axis=1)
+    rsum = b["radius"][pairs[:, 0]] + b["radius"][pairs[:, 1]]
+    assert np.array_equal(hit, d <= rsum)
+    assert np.allclose(np.linalg.norm(c["normal"][hit], axis=1), 1.0, atol=1e-12)
+    assert np.allclose(c["depth"][hit], (rsum - d)[hit], atol=1e-12) and np.all(c["depth"][hit] >= 0)
+    # the contact point lies on the centre line, half the penetration inside sphere 1's surface
+    p1 = b["pos"][pairs[:, 0]][hit]
+    on_surface = p1 - c["normal"][hit] * b["radius"][pairs[:, 0]][hit, None]
+    assert np.allclose(c["pos"][hit], on_surface + c["normal"][hit] * (c["depth"][hit, None] / 2), atol=1e-9)
+    assert np.all(c["mode"][hit] == 0x18) and np.all(c["soft_erp"][hit] == 0.05) and np.all(c["soft_cfm"][hit] == 0.01)
+    assert not c[~hit].tobytes().strip(b"\0"), "non-touching pairs leave a zero record"
+    mat = np.tile(np.asarray([0.5, 0.1, 0.9, 0.0, 0.0]), (4000, 1))
+    mat[::2] = [0.2, 0.3, 0.4, 0.1, 0.02]
+    c2, _ = ob.contacts_spheres(pairs, b["pos"], b["radius"], mat)
+    k = np.flatnonzero(hit & (pairs[:, 0] % 2 == 0) & (pairs[:, 1] % 2 == 1))[0]
+    assert c2["bounce"][k] == 0.5 and c2["bounce_vel"][k] == 0.2 and c2["mu"][k] == np.sqrt(0.4 * 0.9)
+    assert c2["soft_erp"][k] == 0.1 and c2["soft_cfm"][k] == 0.02 and c2["mode"][k] == 0x1c

@@ -172,3 +172,51 @@ def test_c4_body_count_properties(cuda_device):
     exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=4_000_000)
     assert np.array_equal(out["pairs"], exp)
     assert 0.3 < len(exp) / b["n"] < 3.0
+
+
+def test_sphere_contacts_match_oracle(cuda_device):
+    """near_callback for spheres (8f rank 3): contact geometry and surface parameters per candidate
+    pair, bit-exact against the restatement (IEEE fp64 on both sides); the count of touching pairs."""
+    from clap_amd import physics
+    n = 20_000
+    b = synth.sphere_bodies(n, box=24.0, seed=33)
+    b["pos"][11] = b["pos"][10]                             # coincident centres: normal (1,0,0), depth r1 + r2
+    b["pos"][13] = b["pos"][12] + [b["radius"][12] + b["radius"][13], 0, 0]      # exactly touching
+    rng = np.random.Generator(np.random.PCG64(4))
+    mat = np.stack([rng.choice([0.0, 0.3, 0.8], n), rng.uniform(0, 0.2, n), rng.uniform(0.1, 1.5, n),
+                    rng.choice([0.0, 0.02, 0.2], n), rng.choice([0.0, 0.005, 0.05], n)], 1)
+    for material in (None, mat):
+        world = physics.PhysWorld(b, None, pair_capacity=8 * n, device=cuda_device)
+        if material is not None:
+            world.set_materials(material)
+        world.broadphase()
+        world.contacts()
+        got, total = world.download_contacts(ob.CONTACT_DTYPE)
+        pairs = world.download()["pairs"]
+        exp, exp_total = ob.contacts_spheres(pairs, b["pos"], b["radius"], material)
+        assert len(got) == len(pairs) and total == exp_total
+        assert 0 < exp_total < len(pairs), "AABB overlap without sphere contact exists in the sample"
+        assert got.tobytes() == exp.tobytes(), "contact records, every field bit-exact"
+        k = int(np.flatnonzero((pairs[:, 0] == 10) & (pairs[:, 1] == 11))[0])
+        assert got["nc"][k] == 1 and tuple(got["normal"][k]) == (1.0, 0.0, 0.0)
+        if material is not None:
+            assert len(np.unique(got["mode"][got["nc"] == 1])) == 2, "with and without dContactBounce"
+
+
+def test_sphere_contacts_empty_and_truncated(cuda_device):
+    from clap_amd import physics
+    b = synth.sphere_bodies(3000, box=6.0, seed=6)
+    world = physics.PhysWorld(b, None, pair_capacity=100, device=cuda_device)   # fewer slots than pairs found
+    world.broadphase()
+    world.contacts()
+    got, total = world.download_contacts(ob.CONTACT_DTYPE)
+    pairs = world.download()["pairs"]
+    assert len(got) == len(pairs) == 100
+    exp, exp_total = ob.contacts_spheres(pairs, b["pos"], b["radius"])
+    assert total == exp_total and got.tobytes() == exp.tobytes()
+    far = synth.sphere_bodies(50, box=4000.0, seed=1)       # nothing overlaps: no pairs, no contacts
+    world = physics.PhysWorld(far, None, pair_capacity=64, device=cuda_device)
+    world.broadphase()
+    world.contacts()
+    got, total = world.download_contacts(ob.CONTACT_DTYPE)
+    assert len(got) == 0 and total == 0
