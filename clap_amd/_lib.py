@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 OK = 0
 ERR_NOMEM = -1
@@ -67,7 +67,8 @@ class Particles(C.Structure):
     _fields_ = [("n", C.c_uint32), ("n_sys", C.c_uint32), ("sys", C.c_void_p), ("row_sys", C.c_void_p),
                 ("pos", C.c_void_p), ("vel", C.c_void_p), ("rng_state", C.c_void_p),
                 ("billboard_mx", C.c_void_p), ("respawn_mask", C.c_void_p), ("respawn_row_pop", C.c_void_p),
-                ("respawn_list", C.c_void_p), ("respawn_count", C.c_void_p), ("scratch", C.c_void_p)]
+                ("respawn_list", C.c_void_p), ("respawn_count", C.c_void_p), ("scratch", C.c_void_p),
+                ("respawn_groups", C.c_void_p)]
 
 
 class Skeleton(C.Structure):

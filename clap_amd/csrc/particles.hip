@@ -34,8 +34,16 @@ struct PartK {
     uint64_t *respawn_mask;
     uint8_t  *respawn_row_pop;
     float    *billboard_mx;
+    uint32_t *groups;             // respawn_groups (see include/clapgpu.h), or NULL
     uint32_t  n;
 };
+
+// respawn_groups layout: [0] frames completed (written by the respawn pass), [1] this frame's copy of
+// it (written by the advect pass), then two banks of per-group respawn counts, one group =
+// PART_GROUP_ROWS rows.  A frame accumulates into bank (frame & 1) while clearing the other one for
+// the next frame, so no separate clearing launch is needed.
+constexpr uint32_t PART_RESPAWN_LIST = 256;      // respawns of one wave's 64 rows handled in one pass
+constexpr uint32_t PART_GROUP_ROWS = 1024, PART_GROUPS = 64, PART_GROUP_BANK0 = 4;
 
 struct Mat4Arg { float m[16]; };
 
@@ -47,6 +55,15 @@ void k_particles_advect(PartK k, Mat4Arg view)
     const uint32_t row = (i - lane) >> 6;
     if (i - lane >= k.n)
         return;
+    uint32_t *bank = nullptr;
+    if (k.groups) {
+        const uint32_t frame = __builtin_amdgcn_readfirstlane(k.groups[0]);
+        bank = k.groups + PART_GROUP_BANK0 + PART_GROUPS * (frame & 1u);
+        if (i < PART_GROUPS)
+            k.groups[PART_GROUP_BANK0 + PART_GROUPS * ((frame & 1u) ^ 1u) + i] = 0;     // next frame's bank
+        if (i == 0)
+            k.groups[1] = frame;
+    }
     if (i == 0)
         k.rng_state[0] = k.rng_state[1];                  // last frame's respawn pass has finished
 
@@ -79,6 +96,8 @@ void k_particles_advect(PartK k, Mat4Arg view)
     if (lane == 0) {
         k.respawn_mask[row] = m;
         k.respawn_row_pop[row] = (uint8_t)__popcll(m);
+        if (bank && m)                                    // respawns are rare: a few hundred atomics per frame
+            atomicAdd(&bank[row / PART_GROUP_ROWS], (uint32_t)__popcll(m));
     }
 
     // billboard matrix of the system (particle.c:93-100), once per system
@@ -208,8 +227,21 @@ void k_particles_respawn_rp(PartK k, uint32_t *respawn_count)
     if (busy == 0 && !last)
         return;                                                  // the common case: nothing to do
 
-    // respawns in rows [0, row0); row0 % 64 == 0
-    const uint32_t pre = wave_byte_sum(k.respawn_row_pop, row0, lane);
+    // respawns in rows [0, row0); row0 % 64 == 0.  With the group counts of the advect pass this is
+    // one load of <= 64 counts plus <= 1 KiB of popcount bytes instead of up to 64 KiB of bytes.
+    uint32_t pre, frame = 0;
+    if (k.groups) {
+        frame = __builtin_amdgcn_readfirstlane(k.groups[1]);
+        const uint32_t *bank = k.groups + PART_GROUP_BANK0 + PART_GROUPS * (frame & 1u);
+        const uint32_t g0 = row0 / PART_GROUP_ROWS;
+        uint32_t before = (uint32_t)lane < g0 ? bank[lane] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            before += __shfl_xor(before, off);
+        pre = before + wave_byte_sum(k.respawn_row_pop + g0 * PART_GROUP_ROWS, row0 - g0 * PART_GROUP_ROWS, lane);
+    } else {
+        pre = wave_byte_sum(k.respawn_row_pop, row0, lane);
+    }
 
     const uint32_t cnt = __popcll(m);
     uint32_t incl = cnt;                                         // inclusive scan of the 64 row counts
@@ -222,19 +254,39 @@ void k_particles_respawn_rp(PartK k, uint32_t *respawn_count)
     const uint64_t state0 = k.rng_state[0];
     const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
 
-    uint64_t todo = busy;
-    while (todo) {                                               // rows of this wave that have respawns
-        const int r = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint64_t mr = (uint64_t)(uint32_t)__shfl((int)lo, r) | ((uint64_t)(uint32_t)__shfl((int)hi, r) << 32);
-        const uint32_t base = pre + (uint32_t)__shfl((int)excl, r);
-        if ((mr >> lane) & 1ull)
-            respawn_one(k, state0, base + __popcll(mr & ((1ull << lane) - 1ull)), (row0 + r) * WAVE + lane);
+    // All respawns of the wave's 64 rows at once, one per lane: each row lists its respawning particles
+    // at its rank offset in LDS (rank order = particle order), then lane t takes the wave's t-th one.
+    // (Walking the rows one after the other would leave a single lane busy per row for the whole
+    // jump-ahead + 7-draw chain.)
+    __shared__ uint32_t lists[PART_BLOCK / WAVE][PART_RESPAWN_LIST];
+    uint32_t *list = lists[threadIdx.x / WAVE];
+    const uint32_t wave_total = (uint32_t)__shfl((int)incl, WAVE - 1);
+    if (wave_total <= PART_RESPAWN_LIST) {
+        uint64_t mm = m;
+        uint32_t o = excl;
+        while (mm) {
+            list[o++] = my_row * WAVE + (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+        }
+        wave_lds_fence();
+        for (uint32_t t = lane; t < wave_total; t += WAVE)
+            respawn_one(k, state0, pre + t, list[t]);
+    } else {
+        uint64_t todo = busy;
+        while (todo) {                                           // crowded wave: row by row
+            const int r = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint64_t mr = (uint64_t)(uint32_t)__shfl((int)lo, r) | ((uint64_t)(uint32_t)__shfl((int)hi, r) << 32);
+            const uint32_t base = pre + (uint32_t)__shfl((int)excl, r);
+            if ((mr >> lane) & 1ull)
+                respawn_one(k, state0, base + __popcll(mr & ((1ull << lane) - 1ull)), (row0 + r) * WAVE + lane);
+        }
     }
     if (last && lane == WAVE - 1) {
         const uint32_t total = pre + incl;
         *respawn_count = total;
         k.rng_state[1] = lcg_skip(state0, 7ull * total);         // where the libc stream now stands
+        if (k.groups) k.groups[0] = frame + 1u;
     }
 }
 
@@ -264,13 +316,15 @@ extern "C" int clapgpu_particles_update(void *stream, const clapgpu_particles *p
     k.respawn_row_pop = p->respawn_row_pop;
     k.billboard_mx = p->billboard_mx;
     k.n = p->n;
+    const bool row_path = p->n / WAVE <= (1u << 16) && (reinterpret_cast<uintptr_t>(p->respawn_row_pop) & 15u) == 0;
+    k.groups = row_path ? p->respawn_groups : nullptr;
     Mat4Arg view;
     memcpy(view.m, view_mx, sizeof(view.m));
 
     hipLaunchKernelGGL(k_particles_advect, dim3((p->n + PART_BLOCK - 1) / PART_BLOCK), dim3(PART_BLOCK), 0,
                        as_stream(stream), k, view);
     CLAPGPU_LAUNCH_CHECK("k_particles_advect");
-    if (p->n / WAVE <= (1u << 16) && (reinterpret_cast<uintptr_t>(p->respawn_row_pop) & 15u) == 0) {
+    if (row_path) {
         const uint32_t waves = (p->n / WAVE + WAVE - 1) / WAVE, per_block = PART_BLOCK / WAVE;
         hipLaunchKernelGGL(k_particles_respawn_rp, dim3((waves + per_block - 1) / per_block), dim3(PART_BLOCK), 0,
                            as_stream(stream), k, p->respawn_count);

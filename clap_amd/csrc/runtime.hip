@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 10u
+#define CLAPGPU_ABI_VERSION 11u
 
 namespace clapgpu {
 

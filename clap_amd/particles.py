@@ -39,12 +39,14 @@ class ParticleBatch:
         self.respawn_count = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.scratch = torch.zeros((_lib.lib().clapgpu_visible_scratch_bytes(n) // 4 or 1,), dtype=torch.int32,
                                    device=dev)
+        self.respawn_groups = torch.zeros((132,), dtype=torch.int32, device=dev)    # CLAPGPU_RESPAWN_GROUP_WORDS
         self._desc = _lib.Particles(
             n=n, n_sys=self.n_sys, sys=self.sys.data_ptr(), row_sys=self.row_sys.data_ptr(),
             pos=self.pos.data_ptr(), vel=self.vel.data_ptr(), rng_state=self.rng_state.data_ptr(),
             billboard_mx=self.billboard_mx.data_ptr(), respawn_mask=self.respawn_mask.data_ptr(),
             respawn_row_pop=self.respawn_row_pop.data_ptr(), respawn_list=self.respawn_list.data_ptr(),
-            respawn_count=self.respawn_count.data_ptr(), scratch=self.scratch.data_ptr())
+            respawn_count=self.respawn_count.data_ptr(), scratch=self.scratch.data_ptr(),
+            respawn_groups=self.respawn_groups.data_ptr())
 
     def particles_update(self, view_mx):
         """particles_update for every system (mq order), one libc-compatible drand48 stream."""

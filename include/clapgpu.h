@@ -267,7 +267,12 @@ typedef struct clapgpu_particle_system {
  *   billboard_mx[n_sys][16]  entity3d.mx of each system's entity (particle.c:93-100), or NULL
  *   respawn_mask[n/64], respawn_row_pop[n/64 rounded up to 16], respawn_list[n],
  *   respawn_count[1], scratch (clapgpu_visible_scratch_bytes(n)): work space
+ *   respawn_groups[CLAPGPU_RESPAWN_GROUP_WORDS]: persistent work space, ZEROED ONCE by the caller
+ *               when the batch is created and then left alone (per-frame respawn counts of groups
+ *               of rows, double-banked by frame); may be NULL, which costs ~10 us per call at 4 M
+ *               particles (the respawn ranks then come from a scan of every row's count)
  */
+#define CLAPGPU_RESPAWN_GROUP_WORDS 132
 typedef struct clapgpu_particles {
     uint32_t  n;
     uint32_t  n_sys;
@@ -282,6 +287,7 @@ typedef struct clapgpu_particles {
     uint32_t *respawn_list;
     uint32_t *respawn_count;
     void     *scratch;
+    uint32_t *respawn_groups;
 } clapgpu_particles;
 
 /*

@@ -66,6 +66,22 @@ def test_hip_matches_oracle_over_frames(kw, cuda_device):
         assert total > 0
 
 
+def test_without_respawn_group_counts(cuda_device):
+    """respawn_groups is optional work space: NULL falls back to ranking from every row's count."""
+    from clap_amd import particles
+    ps = synth.particle_systems(n_sys=40, count=700, radius=2.5, velocity=0.6, ragged=True, seed=12)
+    pos, vel, st = ob.particles_spawn(ps, 0x5EED5EED)
+    view = np.eye(4, dtype=np.float32).ravel()
+    batch = particles.ParticleBatch(ps, pos, vel, st, cuda_device)
+    batch._desc.respawn_groups = None
+    for f in range(4):
+        k, st = ob.particles_update(ps, pos, vel, st)
+        batch.particles_update(view)
+        out = batch.download()
+        assert out["respawned"] == k and out["rng_state"] == st
+        assert_bits_equal(out["pos"], pos, f"frame {f} pos_array")
+
+
 def test_emitter_motion(cuda_device):
     """particle_system_position: a detached system leaves its particles behind (they respawn as
     they fall out of the sphere); an attached one carries them."""
