@@ -46,10 +46,16 @@ __device__ __forceinline__ SkinVert load_vert(const SkinArgs &a, size_t v)
     return r;
 }
 
-__global__ __launch_bounds__(SKIN_BLOCK)
+#ifndef SKIN_WAVES
+#define SKIN_WAVES 8
+#endif
+#ifndef SKIN_PREFETCH
+#define SKIN_PREFETCH 0
+#endif
+__global__ __launch_bounds__(SKIN_BLOCK, SKIN_WAVES)
 void k_skin(SkinArgs a)
 {
-    __shared__ float pal[PAL_MAX_JOINTS * PAL_PITCH];             // 20 KiB
+    extern __shared__ __attribute__((aligned(16))) float pal[];   // J rows of PAL_PITCH floats (5 KiB at 64 joints)
 
     const uint32_t c = blockIdx.x;
     const uint32_t J = a.J;
@@ -57,10 +63,12 @@ void k_skin(SkinArgs a)
 
     // this lane's first vertex is requested BEFORE the palette is staged, so the two HBM round
     // trips of a block overlap instead of adding up (a block is one palette + ~one vertex pass)
+#if SKIN_PREFETCH
     uint32_t k = threadIdx.x;
     SkinVert cur;
     if (k < vcount)
         cur = load_vert(a, (size_t)vfirst + k);
+#endif
 
     // stage the palette: J * 4 float4, coalesced
     const float4 *src = a.joint_transforms + (size_t)c * J * 4;
@@ -68,20 +76,33 @@ void k_skin(SkinArgs a)
         const float4 v = src[q];
         *reinterpret_cast<float4 *>(pal + (q >> 2) * PAL_PITCH + (q & 3) * 4) = v;
     }
+#if !SKIN_PREFETCH
+    uint32_t k = threadIdx.x;
+    SkinVert cur;
+    if (k < vcount)
+        cur = load_vert(a, (size_t)vfirst + k);                   // in flight across the barrier
+#endif
     __syncthreads();
 
     while (k < vcount) {
+#if SKIN_PREFETCH
         const uint32_t knext = k + SKIN_BLOCK;
         SkinVert nxt;
         if (knext < vcount)
             nxt = load_vert(a, (size_t)vfirst + knext);           // in flight during the blend below
+#endif
         const float w[4] = { cur.w.x, cur.w.y, cur.w.z, cur.w.w };
         float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 };
+#if SKIN_PREFETCH
 #pragma unroll
+#else
+#pragma unroll 1
+#endif
         for (int i = 0; i < 4; i++) {
             const uint32_t ji = (cur.jj >> (8 * i)) & 0xffu;
             const float4 *m = reinterpret_cast<const float4 *>(pal + ji * PAL_PITCH);
             const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+            const float wi = i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : w[3];
             // ((M0 x + M1 y) + M2 z) + M3 w per component; w = 1 for positions, 0 for normals
             const float lx = ((c0.x * cur.px + c1.x * cur.py) + c2.x * cur.pz) + c3.x * 1.0f;
             const float ly = ((c0.y * cur.px + c1.y * cur.py) + c2.y * cur.pz) + c3.y * 1.0f;
@@ -89,14 +110,20 @@ void k_skin(SkinArgs a)
             const float mx = ((c0.x * cur.nx + c1.x * cur.ny) + c2.x * cur.nz) + c3.x * 0.0f;
             const float my = ((c0.y * cur.nx + c1.y * cur.ny) + c2.y * cur.nz) + c3.y * 0.0f;
             const float mz = ((c0.z * cur.nx + c1.z * cur.ny) + c2.z * cur.nz) + c3.z * 0.0f;
-            tp[0] += lx * w[i]; tp[1] += ly * w[i]; tp[2] += lz * w[i];
-            tn[0] += mx * w[i]; tn[1] += my * w[i]; tn[2] += mz * w[i];
+            tp[0] += lx * wi; tp[1] += ly * wi; tp[2] += lz * wi;
+            tn[0] += mx * wi; tn[1] += my * wi; tn[2] += mz * wi;
         }
         const size_t o = (size_t)ofirst + k;
         a.out_position[3 * o] = tp[0]; a.out_position[3 * o + 1] = tp[1]; a.out_position[3 * o + 2] = tp[2];
         a.out_normal[3 * o] = tn[0];   a.out_normal[3 * o + 1] = tn[1];   a.out_normal[3 * o + 2] = tn[2];
+#if SKIN_PREFETCH
         cur = nxt;
         k = knext;
+#else
+        k += SKIN_BLOCK;
+        if (k < vcount)
+            cur = load_vert(a, (size_t)vfirst + k);
+#endif
     }
 }
 
@@ -128,7 +155,8 @@ extern "C" int clapgpu_skin(void *stream, const clapgpu_skin_batch *b)
     a.joint_transforms = reinterpret_cast<const float4 *>(b->joint_transforms);
     a.out_position = b->out_position;
     a.out_normal = b->out_normal;
-    hipLaunchKernelGGL(k_skin, dim3(b->n_chars), dim3(SKIN_BLOCK), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(k_skin, dim3(b->n_chars), dim3(SKIN_BLOCK), b->nr_joints * PAL_PITCH * sizeof(float),
+                       as_stream(stream), a);
     CLAPGPU_LAUNCH_CHECK("k_skin");
     return CLAPGPU_OK;
 }
