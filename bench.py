@@ -224,6 +224,12 @@ def main():
                 direct = rccl.Communicator(rank, world, device)
             except Exception as exc:                    # keep the run alive: c10d does the same exchange
                 print(f"[bench] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            # every rank must take the same route: one rank falling back alone would deadlock the others
+            ok = torch.tensor([1 if direct is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and direct is not None:
+                direct.destroy()
+                direct = None
     frame = [0]
 
     def step():
