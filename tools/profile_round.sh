@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-end evidence on the GPU box (run through gpurun): kernel-trace stats of bench.py, then the two
+# PMC passes (FETCH_SIZE, WRITE_SIZE: separately, as MI355X_MICROARCH.md prescribes; counters only,
+# with --kernel-trace) and an unprofiled bench line.  Output: gpurun_out/<tag>/ ; copy what should be
+# judged into profiles/<tag>/.
+#     tools/profile_round.sh r01_final
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+tag=${1:-r01_final}
+out=$R/gpurun_out/$tag
+rm -rf "$out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+python3 "$R/bench.py" > "$out/bench_unprofiled.json" 2> "$out/bench_unprofiled.err"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --steps 100 --warmup 10 --cpu-frames 0 > "$out/bench_under_rocprof.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 > "$out/bench_fetch.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 > "$out/bench_write.log" 2>&1
+f=$(find "$out/trace" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$out/kernel_stats.csv"
+fc=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
+wc=$(find "$out/write" -name '*counter_collection.csv' | head -1)
+if [ -n "$fc" ] && [ -n "$wc" ]; then
+    python3 "$R/tools/pmc_summary.py" --all "$fc" "$wc" "$out/pmc_hbm_bytes.json" > /dev/null
+    python3 "$R/tools/pmc_summary.py" "$fc" "$wc" k_entities_tiles "$out/entities_pmc.json" > /dev/null
+fi
+rm -rf "$out/trace" "$out/fetch" "$out/write"           # keep the summaries, not the per-dispatch dumps
+ls -la "$out"; tail -c 600 "$out/bench_unprofiled.json"; echo; [ -f "$out/kernel_stats.csv" ] && cut -d, -f1-4 "$out/kernel_stats.csv" | cut -c1-110 | head -40
