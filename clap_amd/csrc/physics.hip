@@ -214,8 +214,9 @@ static int exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, 
 // Uniform hash grid over the sphere centres, cell edge >= the largest diameter, so every partner of a
 // body lies in the 27 cells around it.  HBM layout of the work space: the bodies are copied into
 // bucket order as 48-byte records (centre, radius, cell, index) so a cell's members are one contiguous
-// run, and the 27-cell walk of one body is spread over the 32 lanes of a half wave (one cell per lane)
-// instead of being a 27-long chain of dependent gathers in one lane.
+// run, and a body's cell walk is spread over the lanes of a lane group (a cell or two per lane) instead
+// of being a long chain of dependent gathers in one lane.  Each unordered pair is tested once (own
+// cell + the 13 cells after it), see k_bp_search.
 struct BpRec {
     double   p[3], r;                 // centre, radius: the AABB is p -+ r as dGeomSphere computes it
     int32_t  cx, cy, cz;
@@ -224,7 +225,7 @@ struct BpRec {
 static_assert(sizeof(BpRec) == 48, "record layout");
 
 #ifndef BP_GROUP
-#define BP_GROUP 16                       // lanes per body in the pair search
+#define BP_GROUP 8                        // lanes per body in the pair search
 #endif
 constexpr int BP_WORK = 64;               // candidate records listed per body and round
 
@@ -240,7 +241,7 @@ struct BpK {
     int4         *cells;              // [n]  (cx, cy, cz, rank of the body inside its bucket)
     BpRec        *recs;               // [n]  bodies in bucket order
     uint32_t     *pair_count;         // [n + 1] -> pair starts after the scan
-    uint32_t     *partners;           // [n][BP_LIST] ascending partners of bodies with <= BP_LIST of them
+    uint32_t     *partners;           // [n][BP_LIST] partners (larger index) of bodies with <= BP_LIST of them
     uint32_t     *pairs;              // [2 * capacity]
     uint32_t      capacity;
 };
@@ -270,6 +271,7 @@ void k_bp_histogram(BpK k)
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
     if (i == 0) k.pair_count[k.n] = 0;
     if (i >= k.n) return;
+    k.pair_count[i] = 0;                                            // the search pass counts with atomics
     int32_t cx, cy, cz;
     cell_of(k.pos + 3 * (size_t)i, k.cell, cx, cy, cz);
     const uint32_t rank = atomicAdd(&k.bucket_count[cell_hash(cx, cy, cz, k.hash_mask)], 1u);
@@ -301,25 +303,24 @@ __device__ __forceinline__ bool aabb_overlap(const double (&alo)[3], const doubl
     return true;
 }
 
-// Search pass: BP_GROUP lanes per body, bodies taken in bucket order.  The lanes first look up the
-// record runs of the 27 neighbour cells and spread them into an LDS work list (run -> one entry per
-// record, tagged with the cell it was listed for), then test the listed records one per lane, so the
-// lanes stay busy whatever the individual runs' lengths are.  The partners j > i are gathered in LDS,
-// ranked (they are distinct, so rank = number of smaller ones) and written in ascending order to
-// partners[i][]; pair_count[i] gets their number.  Bodies with more than BP_LIST partners only get
-// the count here and are searched again by the emit pass.
+// Search pass: BP_GROUP lanes per body, bodies taken in bucket order.  Every unordered pair is tested
+// ONCE: a body scans its own cell (partners with a larger index) and the 13 neighbour cells that come
+// after its own in (z, y, x) order -- for two bodies in different cells exactly one of them has the
+// other's cell among those 13.  The lanes look up the 14 record runs and spread them into an LDS work
+// list (one entry per record, tagged with the cell it was listed for), then test the listed records
+// one per lane, so the lanes stay busy whatever the individual runs' lengths are.  A hit (i, j) is
+// appended to the partner list of min(i, j) with an atomic on that body's count; the emit pass puts
+// each list in ascending order.  Bodies with more than BP_LIST partners only get the count here and
+// are searched again by the emit pass.
 __global__ __launch_bounds__(PHYS_BLOCK)
 void k_bp_search(BpK k)
 {
-    constexpr int G = BP_GROUP, GROUPS = PHYS_BLOCK / G, CPL = (27 + G - 1) / G;
+    constexpr int G = BP_GROUP, GROUPS = PHYS_BLOCK / G, NCELL = 14, CPL = (NCELL + G - 1) / G;
     constexpr uint32_t WL = BP_WORK;
-    __shared__ uint32_t list[GROUPS][BP_LIST];
     __shared__ uint32_t work[GROUPS][WL];
     const int grp = threadIdx.x / G, q = threadIdx.x % G;
     const uint32_t slot = blockIdx.x * GROUPS + grp;                // neighbouring groups walk neighbouring cells
     const bool body = slot < k.n;
-    const int sub = (lane_id() / G) * G;                            // first lane of this group in the wave
-    const uint64_t gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
 
     double alo[3] = { 0, 0, 0 }, ahi[3] = { 0, 0, 0 };
     uint32_t b0[CPL], len[CPL], i = 0, mylen = 0;
@@ -334,7 +335,7 @@ void k_bp_search(BpK k)
         mx = me.cx - 1; my = me.cy - 1; mz = me.cz - 1;             // corner cell of the 3x3x3 neighbourhood
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int cq = q + c * G;
+            const int cq = 13 + q + c * G;                          // 13 = own cell, 14..26 = the cells after it
             if (cq < 27) {
                 const uint32_t h = cell_hash(mx + cq % 3, my + (cq / 3) % 3, mz + cq / 9, k.hash_mask);
                 uint32_t se[2];                                     // start and end of the run: one 8-byte load
@@ -358,12 +359,11 @@ void k_bp_search(BpK k)
     const uint32_t total = __shfl(incl, G - 1, G);
     const uint32_t first = incl - mylen;
 
-    uint32_t cnt = 0;                                               // partners of this body so far (group-uniform)
     for (uint32_t base = 0; __any(base < total); base += WL) {      // one round unless > WL candidates
         uint32_t off = first;
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int cq = q + c * G;                               // entry = record slot | cell offset (2+2+2 bits)
+            const int cq = 13 + q + c * G;                          // entry = record slot | cell offset (2+2+2 bits)
             const uint32_t tag = (uint32_t)(cq % 3 | ((cq / 3) % 3) << 2 | (cq / 9) << 4) << 26;
             for (uint32_t t = 0; __any(t < len[c]); t++) {
                 if (t < len[c]) {
@@ -376,38 +376,27 @@ void k_bp_search(BpK k)
         wave_lds_fence();
         const uint32_t todo = total > base ? (total - base < WL ? total - base : WL) : 0;
         for (uint32_t t = q; __any(t < todo); t += G) {
-            bool hit = false;
-            uint32_t j = 0;
             if (t < todo) {
                 const uint32_t e = work[grp][t];
                 const BpRec r = k.recs[e & 0x3ffffffu];
-                j = r.idx;
-                hit = j > i && r.cx - mx == (int)((e >> 26) & 3) && r.cy - my == (int)((e >> 28) & 3) &&
-                      r.cz - mz == (int)(e >> 30) && aabb_overlap(alo, ahi, r);
+                const uint32_t j = r.idx;
+                const bool own = (e >> 26) == (1u | 1u << 2 | 1u << 4);         // listed for the body's own cell
+                if (j != i && (!own || j > i) && r.cx - mx == (int)((e >> 26) & 3) &&
+                    r.cy - my == (int)((e >> 28) & 3) && r.cz - mz == (int)(e >> 30) && aabb_overlap(alo, ahi, r)) {
+                    const uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
+                    const uint32_t at = atomicAdd(&k.pair_count[lo], 1u);
+                    if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+                }
             }
-            const uint32_t gm = (uint32_t)((__ballot(hit) >> sub) & gmask);
-            if (hit) {
-                const uint32_t o = cnt + __popc(gm & ((1u << q) - 1u));
-                if (o < BP_LIST) list[grp][o] = j;
-            }
-            cnt += __popc(gm);
         }
         wave_lds_fence();
     }
-    if (body) {
-        if (q == 0) k.pair_count[i] = cnt;
-        if (cnt <= BP_LIST)
-            for (uint32_t e = q; e < cnt; e += G) {
-                const uint32_t v = list[grp][e];
-                uint32_t rank = 0;
-                for (uint32_t t = 0; t < cnt; t++) rank += list[grp][t] < v;
-                k.partners[(size_t)i * BP_LIST + rank] = v;
-            }
-    }
 }
 
-// Emit pass: 16 lanes per body copy its partner list to pairs[] at pair_start[i]; a body with more
-// partners than the list holds is searched again by one lane (ascending by insertion).
+// Emit pass: 16 lanes per body move its partner list to pairs[] at pair_start[i], each entry at its
+// rank (the partners are distinct, so rank = number of smaller ones): ascending whatever order the
+// atomics of the search pass took.  A body with more partners than the list holds is searched again
+// by one lane (all 27 cells, ascending by insertion).
 __global__ __launch_bounds__(PHYS_BLOCK)
 void k_bp_emit(BpK k)
 {
@@ -417,8 +406,14 @@ void k_bp_emit(BpK k)
     const uint32_t start = k.pair_count[i], cnt = k.pair_count[i + 1] - start;
     uint2 *out = reinterpret_cast<uint2 *>(k.pairs);
     if (cnt <= BP_LIST) {
-        if (q < cnt && start + q < k.capacity)
-            out[start + q] = make_uint2(i, k.partners[(size_t)i * BP_LIST + q]);
+        if (q < cnt) {
+            const uint32_t *mine = k.partners + (size_t)i * BP_LIST;
+            const uint32_t v = mine[q];
+            uint32_t rank = 0;
+            for (uint32_t e = 0; e < cnt; e++) rank += mine[e] < v;
+            if (start + rank < k.capacity)
+                out[start + rank] = make_uint2(i, v);
+        }
         return;
     }
     if (q != 0) return;
