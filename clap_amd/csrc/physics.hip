@@ -145,10 +145,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &b
     return wave_off + incl - v;
 }
 
+// Block sums of `in`; the block that finishes last (a ticket counter, zeroed by the caller) also turns
+// the sums into their exclusive scan and writes the grand total -- the middle launch of a classic
+// three-launch scan folded into the first.
 __global__ __launch_bounds__(PHYS_BLOCK)
-void k_scan_block_sums(const uint32_t *in, uint32_t n, uint32_t *block_sums)
+void k_scan_block_sums(const uint32_t *in, uint32_t n, uint32_t *block_sums, uint32_t n_blocks, uint32_t *ticket,
+                       uint32_t *total)
 {
     __shared__ uint32_t lds[PHYS_BLOCK / WAVE];
+    __shared__ bool is_last;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
 #pragma unroll
@@ -156,24 +161,27 @@ void k_scan_block_sums(const uint32_t *in, uint32_t n, uint32_t *block_sums)
         if (base + k < n) s += in[base + k];
     uint32_t tot;
     block_exclusive_scan(s, tot, lds);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// one block: exclusive scan of the block sums in place, grand total to *total
-__global__ __launch_bounds__(PHYS_BLOCK)
-void k_scan_sums(uint32_t *block_sums, uint32_t n_blocks, uint32_t *total)
-{
-    __shared__ uint32_t lds[PHYS_BLOCK / WAVE];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_blocks; base += PHYS_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n_blocks ? block_sums[i] : 0;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, tot, lds);
-        if (i < n_blocks) block_sums[i] = carry + ex;
-        carry += tot;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&block_sums[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                            // the sum is visible before the ticket is taken
+        is_last = atomicAdd(ticket, 1u) == n_blocks - 1;
     }
-    if (threadIdx.x == 0) *total = carry;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += PHYS_BLOCK) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < n_blocks ? __hip_atomic_load(&block_sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        uint32_t t2;
+        const uint32_t ex = block_exclusive_scan(v, t2, lds);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += t2;
+    }
+    if (threadIdx.x == 0) {
+        *total = carry;
+        *ticket = 0;                                                // ready for the next scan on this stream
+    }
 }
 
 __global__ __launch_bounds__(PHYS_BLOCK)
@@ -197,14 +205,13 @@ void k_scan_apply(const uint32_t *in, uint32_t n, const uint32_t *block_sums, ui
 }
 
 // out[i] = sum of in[0..i); *total = sum of all.  scratch: ceil(n / 2048) uint32.  in may equal out.
+// ticket: one device word that is zero when the scan starts (it is left zero again).
 static int exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total,
-                              uint32_t *scratch)
+                              uint32_t *scratch, uint32_t *ticket)
 {
     const uint32_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(blocks), dim3(PHYS_BLOCK), 0, s, in, n, scratch);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(blocks), dim3(PHYS_BLOCK), 0, s, in, n, scratch, blocks, ticket, total);
     CLAPGPU_LAUNCH_CHECK("k_scan_block_sums");
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(PHYS_BLOCK), 0, s, scratch, blocks, total);
-    CLAPGPU_LAUNCH_CHECK("k_scan_sums");
     hipLaunchKernelGGL(k_scan_apply, dim3(blocks), dim3(PHYS_BLOCK), 0, s, in, n, scratch, out);
     CLAPGPU_LAUNCH_CHECK("k_scan_apply");
     return CLAPGPU_OK;
@@ -657,7 +664,7 @@ static size_t bp_scratch_words(uint32_t n)
 {
     const size_t buckets = bucket_count_for(n);
     const size_t scan = (buckets + 1 + SCAN_TILE - 1) / SCAN_TILE + ((size_t)n + 1 + SCAN_TILE) / SCAN_TILE + 8;
-    return align4(buckets + 1) + 4 * (size_t)n + 12 * (size_t)n + align4((size_t)n + 1) +
+    return align4(buckets + 1) + 4 * (size_t)n + 12 * (size_t)n + align4((size_t)n + 2) +
            (size_t)BP_LIST * n + 8 + scan + 8 + 16;
 }
 
@@ -674,7 +681,7 @@ static BpScratch carve(void *scratch, uint32_t n)
     s.bucket = p;   p += align4(buckets + 1);
     s.cells = p;    p += 4 * (size_t)n;
     s.recs = p;     p += 12 * (size_t)n;
-    s.pcount = p;   p += align4((size_t)n + 1);
+    s.pcount = p;   p += align4((size_t)n + 2);          // [n + 1]: ticket of the statics' scan
     s.partners = p; p += (size_t)BP_LIST * n;
     s.total = p;    p += 8;
     s.scan = p;
@@ -697,7 +704,8 @@ extern "C" int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, d
     }
     const uint32_t n = b->n, buckets = bucket_count_for(n);
     BpScratch sc = carve(scratch, n);
-    CLAPGPU_HIP(hipMemsetAsync(sc.bucket, 0, ((size_t)buckets + 1) * sizeof(uint32_t), s));
+    // bucket counts and, in the padding word behind them, the scans' ticket
+    CLAPGPU_HIP(hipMemsetAsync(sc.bucket, 0, ((size_t)buckets + 2) * sizeof(uint32_t), s));
 
     BpK k;
     k.n = n; k.pos = b->pos; k.radius = b->radius; k.cell = cell; k.hash_mask = buckets - 1;
@@ -708,14 +716,14 @@ extern "C" int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, d
 
     hipLaunchKernelGGL(k_bp_histogram, grid, block, 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_histogram");
-    rc = exclusive_scan_u32(s, sc.bucket, sc.bucket, buckets + 1, sc.total, sc.scan);   // starts; [buckets] = n
+    rc = exclusive_scan_u32(s, sc.bucket, sc.bucket, buckets + 1, sc.total, sc.scan, sc.bucket + buckets + 1);   // starts; [buckets] = n
     if (rc) return rc;
     hipLaunchKernelGGL(k_bp_scatter, grid, block, 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
     constexpr uint32_t per_block = PHYS_BLOCK / BP_GROUP;
     hipLaunchKernelGGL(k_bp_search, dim3((n + per_block - 1) / per_block), block, 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_search");
-    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan);       // starts; [n] = total
+    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan, sc.bucket + buckets + 1);   // starts; [n] = total
     if (rc) return rc;
     const uint64_t emit_threads = (uint64_t)n * BP_LIST;
     hipLaunchKernelGGL(k_bp_emit, dim3((uint32_t)((emit_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s, k);
@@ -739,11 +747,11 @@ extern "C" int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodie
     const uint32_t n = b->n;
     BpScratch sc = carve(scratch, n);
     const dim3 grid((n + PHYS_BLOCK - 1) / PHYS_BLOCK), block(PHYS_BLOCK);
-    CLAPGPU_HIP(hipMemsetAsync(sc.pcount + n, 0, sizeof(uint32_t), s));
+    CLAPGPU_HIP(hipMemsetAsync(sc.pcount + n, 0, 2 * sizeof(uint32_t), s));     // [n] = 0 and the scan's ticket
     hipLaunchKernelGGL(k_bp_static<false>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
                        sc.pcount, sc.partners, pairs, capacity);
     CLAPGPU_LAUNCH_CHECK("k_bp_static<search>");
-    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan);       // starts; [n] = total
+    rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan, sc.pcount + n + 1);   // starts; [n] = total
     if (rc) return rc;
     const uint64_t copy_threads = (uint64_t)n * BP_LIST;
     hipLaunchKernelGGL(k_bp_copy_lists, dim3((uint32_t)((copy_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s,
