@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 OK = 0
 ERR_NOMEM = -1
@@ -111,6 +111,13 @@ class Bodies(C.Structure):
 BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY = 1, 2, 4
 
 
+class Characters(C.Structure):
+    """clapgpu_characters (include/clapgpu.h)."""
+    _fields_ = [("n", C.c_uint32), ("limbo_height", C.c_float), ("entity", C.c_void_p), ("body", C.c_void_p),
+                ("hist_pos", C.c_void_p), ("hist_head", C.c_void_p), ("hist_wrapped", C.c_void_p),
+                ("airborne", C.c_void_p), ("moved", C.c_void_p)]
+
+
 class Lights(C.Structure):
     """clapgpu_lights (include/clapgpu.h)."""
     _fields_ = [("nr_lights", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("color", C.c_void_p),
@@ -162,6 +169,8 @@ SYMBOLS = {
     "clapgpu_contacts_spheres": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
+    "clapgpu_characters_update": (C.c_int, [C.c_void_p, C.POINTER(Characters), C.POINTER(Entities),
+                                            C.POINTER(Bodies)]),
     "clapgpu_light_grid_dims": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_uint32)]),
     "clapgpu_light_grid_compute": (C.c_int, [C.c_void_p, C.POINTER(Lights), C.POINTER(C.c_float),

@@ -1,0 +1,131 @@
+// characters.hip -- the per-character feeder in front of default_update, for gfx950.
+//
+// Replaces character_update() (character.c:583-611) for every character of the scene: the limbo
+// teleport out of the 8-entry position history (history_newest / _fetch / _push, character.c:546-581),
+// the body read-back the function does itself (phys_body_update / phys_body_set_position,
+// physics.c:789-812, 208-225; characters keep their own rotation) and the `moved` result the host
+// turns into character_set_moved().  character_motion_reset() acts on the one controlled character
+// only and stays host code, like character_move()'s ODE sweeps.  The chained orig_update =
+// default_update is the entity kernel: run this first, it sets CLAPGPU_E_DIRTY on what it moves.
+//
+// One lane per character; state is SoA (history 96 B + 5 B per character).  C3 has 50 k characters:
+// ~10 MB of traffic, launch-latency bound.
+#include <string.h>
+#include "common.h"
+
+namespace clapgpu {
+
+constexpr int CHAR_BLOCK = 256;
+constexpr int HIST = CLAPGPU_POS_HISTORY_MAX;
+
+struct CharK {
+    uint32_t        n;
+    float           limbo_height;
+    const uint32_t *entity;
+    const int32_t  *body;
+    float          *hist_pos;
+    uint32_t       *hist_head;
+    uint8_t        *hist_wrapped;
+    const uint8_t  *airborne;
+    uint8_t        *moved;
+    float4         *pos_scale;
+    uint32_t       *entity_flags;
+    uint32_t        n_entities, n_bodies;
+    double         *body_pos;
+    const double   *body_lvel, *body_yoffset;
+};
+
+__global__ __launch_bounds__(CHAR_BLOCK)
+void k_characters_update(CharK k)
+{
+    const uint32_t c = blockIdx.x * CHAR_BLOCK + threadIdx.x;
+    if (c >= k.n) return;
+    const uint32_t e = k.entity[c];
+    if (e >= k.n_entities) return;
+    int32_t b = k.body ? k.body[c] : -1;
+    if (!k.body_pos || (uint32_t)b >= k.n_bodies) b = -1;
+    float *hp = k.hist_pos + (size_t)c * HIST * 3;
+    uint32_t head = k.hist_head[c];
+    bool wrapped = k.hist_wrapped[c] != 0;
+    float4 ps = k.pos_scale[e];
+    bool dirty = false;
+
+    float last[3] = { 0.f, 0.f, 0.f };                              // history_newest
+    if (head) { last[0] = hp[3 * (head - 1)]; last[1] = hp[3 * (head - 1) + 1]; last[2] = hp[3 * (head - 1) + 2]; }
+    else if (wrapped) { last[0] = hp[3 * (HIST - 1)]; last[1] = hp[3 * (HIST - 1) + 1]; last[2] = hp[3 * (HIST - 1) + 2]; }
+
+    float dot = 0.f;                                                // vec3_mul_inner
+    dot += last[0] * last[0];
+    dot += last[1] * last[1];
+    dot += last[2] * last[2];
+    if ((double)dot > 0.0 && fabsf(ps.y - last[1]) >= k.limbo_height) {        // character.c:595
+        const float *src = wrapped ? hp + 3 * head : hp;           // history_fetch
+        wrapped = false;
+        head = 0;
+        ps.x = src[0]; ps.y = src[1]; ps.z = src[2];                // entity3d_position
+        dirty = true;
+        if (b >= 0) {                                               // phys_body_set_position: y + yoffset
+            k.body_pos[3 * (size_t)b + 0] = (double)ps.x;
+            k.body_pos[3 * (size_t)b + 1] = (double)ps.y + k.body_yoffset[b];
+            k.body_pos[3 * (size_t)b + 2] = (double)ps.z;
+        }
+    }
+
+    uint8_t moved = 0;
+    if (b >= 0) {                                                   // phys_body_update, position only
+        const double *bp = k.body_pos + 3 * (size_t)b, *v = k.body_lvel + 3 * (size_t)b;
+        ps.x = (float)bp[0];
+        ps.y = (float)(bp[1] - k.body_yoffset[b]);
+        ps.z = (float)bp[2];
+        dirty = true;
+        if (sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) > 1e-3) {
+            if (!k.airborne[c]) {                                   // history_push
+                hp[3 * head] = ps.x; hp[3 * head + 1] = ps.y; hp[3 * head + 2] = ps.z;
+                head = (head + 1) % HIST;
+                if (!wrapped && !head) wrapped = true;
+            }
+            moved = 1;
+        }
+    }
+    k.hist_head[c] = head;
+    k.hist_wrapped[c] = wrapped ? 1 : 0;
+    k.moved[c] = moved;
+    if (dirty) {
+        k.pos_scale[e] = ps;
+        k.entity_flags[e] |= CLAPGPU_E_DIRTY;                       // one character per entity: no other writer
+    }
+}
+
+} // namespace clapgpu
+
+using namespace clapgpu;
+
+extern "C" int clapgpu_characters_update(void *stream, const clapgpu_characters *c, const clapgpu_entities *e,
+                                         const clapgpu_bodies *b)
+{
+    if (!c || !e)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (c->n == 0)
+        return CLAPGPU_OK;
+    if (!c->entity || !c->hist_pos || !c->hist_head || !c->hist_wrapped || !c->airborne || !c->moved ||
+        !e->pos_scale || !e->flags)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (b && b->n && (!b->pos || !b->lvel || !b->yoffset))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CharK k;
+    k.n = c->n; k.limbo_height = c->limbo_height;
+    k.entity = c->entity; k.body = c->body;
+    k.hist_pos = c->hist_pos; k.hist_head = c->hist_head; k.hist_wrapped = c->hist_wrapped;
+    k.airborne = c->airborne; k.moved = c->moved;
+    k.pos_scale = reinterpret_cast<float4 *>(const_cast<float *>(e->pos_scale));
+    k.entity_flags = e->flags;
+    k.n_entities = e->n;
+    k.n_bodies = b ? b->n : 0;
+    k.body_pos = b ? b->pos : nullptr;
+    k.body_lvel = b ? b->lvel : nullptr;
+    k.body_yoffset = b ? b->yoffset : nullptr;
+    hipLaunchKernelGGL(k_characters_update, dim3((c->n + CHAR_BLOCK - 1) / CHAR_BLOCK), dim3(CHAR_BLOCK), 0,
+                       as_stream(stream), k);
+    CLAPGPU_LAUNCH_CHECK("k_characters_update");
+    return CLAPGPU_OK;
+}

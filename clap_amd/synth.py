@@ -426,3 +426,39 @@ def lights(n=LIGHTS_MAX, seed=7, extent=60.0, n_dir=2, inactive_frac=0.1):
     if n:
         active[0] = 1
     return dict(nr_lights=n, pos=pos, color=color, attenuation=att, is_dir=is_dir, active=active)
+
+
+POS_HISTORY_MAX = 8         # character.h:21
+
+
+def character_feed(n=1000, seed=13, limbo_height=70.0, with_bodies=True, body_base=0, entity_base=0):
+    """Per-character feeder state (character.c:546-611): position histories in every state of the
+    ring (empty, partly filled, wrapped, a stored origin), entity positions near their last
+    grounded spot or far below it (limbo), airborne flags.  limbo_height: scene.c default 70."""
+    rng = _rng(seed)
+    H = POS_HISTORY_MAX
+    hist_pos = np.zeros((n, H, 3), F32)
+    head = rng.integers(0, H, n).astype(np.uint32)
+    wrapped = (rng.uniform(0, 1, n) < 0.4).astype(np.uint8)
+    empty = rng.uniform(0, 1, n) < 0.15
+    head[empty] = 0
+    wrapped[empty] = 0
+    ground = np.stack([rng.uniform(-200, 200, n), rng.uniform(0, 40, n), rng.uniform(-200, 200, n)], 1)
+    for k in range(H):
+        filled = (k < head) | (wrapped != 0)
+        hist_pos[filled, k] = (ground + rng.normal(0, 2, (n, 3)))[filled]
+    origin = rng.uniform(0, 1, n) < 0.05                     # newest entry exactly (0,0,0): never teleports
+    newest = np.where(head > 0, head - 1, H - 1)
+    hist_pos[origin, newest[origin]] = 0
+    pos = ground + rng.normal(0, 1, (n, 3))
+    fallen = rng.uniform(0, 1, n) < 0.3
+    pos[fallen, 1] -= rng.uniform(0.5 * limbo_height, 3 * limbo_height, fallen.sum())
+    edge = rng.uniform(0, 1, n) < 0.05                       # exactly limbo_height below the newest entry
+    last = hist_pos[np.arange(n), newest]
+    pos[edge, 1] = (last[edge, 1] - F32(limbo_height)).astype(F32)
+    d = dict(n=n, entity=(entity_base + np.arange(n)).astype(np.uint32),
+             body=((body_base + np.arange(n)) if with_bodies else np.full(n, -1)).astype(np.int32),
+             hist_pos=hist_pos, hist_head=head, hist_wrapped=wrapped,
+             airborne=(rng.uniform(0, 1, n) < 0.2).astype(np.uint8), pos=pos.astype(F32),
+             limbo_height=float(limbo_height))
+    return d

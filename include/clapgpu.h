@@ -502,6 +502,46 @@ int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, const uint32
                              clapgpu_contact *contacts, uint32_t *contact_total);
 
 /* ======================================================================== */
+/* Characters: the feeder in front of default_update (core/character.c)      */
+/* ======================================================================== */
+
+#define CLAPGPU_POS_HISTORY_MAX 8      /* POS_HISTORY_MAX, character.h:21 */
+
+/*
+ * struct character's per-frame feeder state (character.h:25-50), SoA over the characters of the
+ * scene in list order (scene->characters, character.c:627):
+ *   entity[c]         slot of character.entity in the entity SoA
+ *   body[c]           index into clapgpu_bodies of its phys body, or -1 (no ENTITY3D_HAS_PHYSICS);
+ *                     NULL = no character has one.  Give such bodies body_entity = -1 in
+ *                     clapgpu_phys_body_update: characters sync themselves here and keep their rotation
+ *   hist_pos[c][8][3], hist_head[c], hist_wrapped[c]   character.history (in/out)
+ *   airborne[c]       character.airborne (written by the host's character_move)
+ *   moved[c]          out: phys_body_update() reported motion -> host calls character_set_moved()
+ *   limbo_height      scene.limbo_height (scene.h:52)
+ */
+typedef struct clapgpu_characters {
+    uint32_t        n;
+    float           limbo_height;
+    const uint32_t *entity;
+    const int32_t  *body;
+    float          *hist_pos;
+    uint32_t       *hist_head;
+    uint8_t        *hist_wrapped;
+    const uint8_t  *airborne;
+    uint8_t        *moved;
+} clapgpu_characters;
+
+/*
+ * character_update() (character.c:583-611) for every character, without its tail call: limbo
+ * teleport out of the position history, body read-back (position only) + history_push when the
+ * body moves.  Writes the entity SoA (pos, CLAPGPU_E_DIRTY) and, on a teleport, the body position
+ * (y + yoffset, phys_body_set_position).  Run before clapgpu_entities_update (= the chained
+ * orig_update).  b may be NULL when no character has a body.
+ */
+int clapgpu_characters_update(void *stream, const clapgpu_characters *c, const clapgpu_entities *e,
+                              const clapgpu_bodies *b);
+
+/* ======================================================================== */
 /* Clustered lighting: lights x screen tiles bitmask (core/light.c)           */
 /* ======================================================================== */
 

@@ -116,6 +116,8 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, U8P]
     L.clapo_contacts_spheres.argtypes = [C.c_uint32, U32P, F64P, F64P, C.c_void_p, C.c_void_p]
     L.clapo_contacts_spheres.restype = C.c_uint32
     L.clapo_light_radius.argtypes = [F32P, F32P, C.c_int]
@@ -391,3 +393,21 @@ def contacts_spheres(pairs, pos, radius, material=None):
                                          np.ascontiguousarray(radius, np.float64),
                                          None if mat is None else mat.ctypes.data, out.ctypes.data)
     return out, int(total)
+
+
+# ------------------------------------------------------------------ character feeder
+def characters_update(chars, limbo_height, pos_scale, entity_flags, bodies=None):
+    """chars: dict(entity u32[n], body i32[n], hist_pos f32[n,8,3], hist_head u32[n], hist_wrapped u8[n],
+    airborne u8[n]) -- history arrays are updated in place, like pos_scale / entity_flags and
+    bodies["pos"].  Returns moved u8[n]."""
+    n = len(chars["entity"])
+    moved = np.zeros(n, np.uint8)
+    bp = bl = by = None
+    if bodies is not None:
+        bp, bl, by = bodies["pos"].ctypes.data, bodies["lvel"].ctypes.data, bodies["yoffset"].ctypes.data
+    lib().clapo_characters_update(n, np.ascontiguousarray(chars["entity"], np.uint32),
+                                  np.ascontiguousarray(chars["body"], np.int32), float(limbo_height),
+                                  chars["hist_pos"].reshape(-1), chars["hist_head"], chars["hist_wrapped"],
+                                  np.ascontiguousarray(chars["airborne"], np.uint8), pos_scale.reshape(-1),
+                                  entity_flags, bp, bl, by, moved)
+    return moved

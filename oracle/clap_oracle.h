@@ -216,6 +216,13 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t n, const double *pos, const double *radius,
                                        uint32_t *pairs, uint64_t max_pairs);
 
+/* ---- character feeder in front of default_update (character.c:546-611; character.c) ---- */
+void clapo_characters_update(uint32_t n_chars, const uint32_t *char_entity, const int32_t *char_body,
+                             float limbo_height, float *hist_pos, uint32_t *hist_head, uint8_t *hist_wrapped,
+                             const uint8_t *airborne, float *pos_scale, uint32_t *entity_flags,
+                             double *body_pos, const double *body_lvel, const double *body_yoffset,
+                             uint8_t *moved);
+
 /* ---- sphere contacts after the broadphase (physics.c:291-330, 399-449; physics.c) ---- */
 typedef struct clapo_contact {
     double   pos[3], normal[3], depth;                  /* dContactGeom */

@@ -33,12 +33,14 @@
  *   bench_entities   time default_update + view_entity_in_frustum
  *   lod        entity3d_aabb_avg_edge + entity3d_set_lod
  *   lightgrid  light_grid_compute: lights x screen tiles -> RGBA32UI masks
+ *   characters character_update (limbo teleport + history) for body-less characters
  */
 /* resolved through -I $(REF)/core (Makefile): /root/reference/core/{model,view,particle}.c */
 #include "model.c"
 #include "view.c"
 #include "particle.c"
 #include "light.c"
+#include "character.c"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -566,6 +568,68 @@ static int cmd_lod(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/*
+ * character_update (character.c:583-611) for characters WITHOUT a physics body: the limbo teleport
+ * out of the position history (history_newest / history_fetch, character.c:558-581), then the
+ * chained default_update.  (With a body the function also calls into ODE: not buildable here.)
+ * Per frame the entity positions are set with entity3d_position, like game code moving a character.
+ */
+static int cmd_characters(struct arrset *in, struct arrset *out)
+{
+    uint32_t n = *(uint32_t *)arr_get(in, "n", NULL);
+    uint32_t frames = *(uint32_t *)arr_get(in, "frames", NULL);
+    float limbo = *(float *)arr_get(in, "limbo_height", NULL);
+    float *pos = arr_get(in, "pos", NULL);                 /* [frames][n][3] */
+    float *rot = arr_get(in, "rot", NULL);                 /* [n][4] */
+    float *scale = arr_get(in, "scale", NULL);             /* [n] */
+    float *hpos = arr_get(in, "hist_pos", NULL);           /* [n][POS_HISTORY_MAX][3] */
+    uint32_t *hhead = arr_get(in, "hist_head", NULL);
+    uint8_t *hwrapped = arr_get(in, "hist_wrapped", NULL);
+    float aabb[6] = { -1, -2, -3, 1, 2, 3 };
+    uint8_t skip = 0;
+    int32_t *zero_i = calloc(n, 4), *no_parent = malloc(n * 4);
+    uint32_t *flags = malloc(n * 4);
+    struct ent_world w;
+    struct character *ch = calloc(n, sizeof(*ch));
+    struct scene *scene = calloc(1, sizeof(*scene));
+
+    for (uint32_t i = 0; i < n; i++) { no_parent[i] = -1; flags[i] = ENTITY3D_ALIVE | ENTITY3D_VISIBLE; }
+    world_make(&w, n, 1, aabb, &skip, zero_i, no_parent, flags);
+    scene->camera = &scene->cameras[0];
+    transform_init(&scene->camera->xform);
+    transform_set_pos(&scene->camera->xform, (vec3){ 1e6f, 1e6f, 1e6f });
+    scene->limbo_height = limbo;
+    for (uint32_t i = 0; i < n; i++) {
+        entity3d *e = &w.e[i];
+        struct character *c = &ch[i];
+        c->entity = e;
+        entity3d_set(e, ENTITY3D_IS_CHARACTER, c);          /* character_make, character.c:621-625 */
+        c->orig_update = e->update;
+        e->update = character_update;
+        memcpy(c->history.pos, hpos + (size_t)i * POS_HISTORY_MAX * 3, sizeof(c->history.pos));
+        c->history.head = hhead[i];
+        c->history.wrapped = hwrapped[i];
+        e->scale = scale[i];
+        transform_set_quat(&e->xform, rot + 4 * i);
+    }
+    float *o_pos = arr_add(out, "pos", (uint64_t)frames * n * 12);
+    float *o_mx = arr_add(out, "mx", (uint64_t)frames * n * 64);
+    uint32_t *o_head = arr_add(out, "hist_head", (uint64_t)frames * n * 4);
+    uint8_t *o_wr = arr_add(out, "hist_wrapped", (uint64_t)frames * n);
+    for (uint32_t f = 0; f < frames; f++)
+        for (uint32_t i = 0; i < n; i++) {
+            size_t k = (size_t)f * n + i;
+            entity3d *e = &w.e[i];
+            entity3d_position(e, pos + 3 * k);
+            e->update(e, scene);                            /* character_update -> default_update */
+            transform_pos(&e->xform, o_pos + 3 * k);
+            memcpy(o_mx + 16 * k, e->mx, 64);
+            o_head[k] = ch[i].history.head;
+            o_wr[k] = ch[i].history.wrapped;
+        }
+    return 0;
+}
+
 /* light_grid_compute (light.c:88-154) over given light slots; the grid's tile array is allocated here
  * at the size light_grid_update (light.c:46-74) would give it, so that function returns early instead
  * of touching the (unbuildable) texture object. */
@@ -629,6 +693,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[1], "pose"))            rc = cmd_pose(&in, &out);
     else if (!strcmp(argv[1], "lod"))             rc = cmd_lod(&in, &out);
     else if (!strcmp(argv[1], "lightgrid"))       rc = cmd_lightgrid(&in, &out);
+    else if (!strcmp(argv[1], "characters"))      rc = cmd_characters(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

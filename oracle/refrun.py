@@ -159,3 +159,19 @@ def lightgrid(lights, cam, width, height, cell):
     tiles = clpio.as_array(out["tiles"], np.uint32).reshape(th, tw, 4)
     return (tiles, clpio.as_array(out["radius"], np.float32), clpio.as_array(out["view_mx"], np.float32),
             clpio.as_array(out["proj_mx"], np.float32))
+
+
+def characters(pos_frames, rot, scale, hist_pos, hist_head, hist_wrapped, limbo_height):
+    """The reference's character_update (+ chained default_update) for body-less characters, one call per
+    frame after entity3d_position(pos_frames[f]).  Returns dict(pos, mx, hist_head, hist_wrapped) per frame."""
+    pos_frames = np.ascontiguousarray(pos_frames, np.float32)
+    f, n = pos_frames.shape[:2]
+    out = run("characters", dict(n=np.asarray([n], np.uint32), frames=np.asarray([f], np.uint32),
+                                 limbo_height=np.asarray([limbo_height], np.float32), pos=pos_frames,
+                                 rot=np.asarray(rot, np.float32), scale=np.asarray(scale, np.float32),
+                                 hist_pos=np.asarray(hist_pos, np.float32), hist_head=np.asarray(hist_head, np.uint32),
+                                 hist_wrapped=np.asarray(hist_wrapped, np.uint8)))
+    return dict(pos=clpio.as_array(out["pos"], np.float32).reshape(f, n, 3),
+                mx=clpio.as_array(out["mx"], np.float32).reshape(f, n, 16),
+                hist_head=clpio.as_array(out["hist_head"], np.uint32).reshape(f, n),
+                hist_wrapped=clpio.as_array(out["hist_wrapped"], np.uint8).reshape(f, n))

@@ -116,6 +116,19 @@ def light_fixture(name, lights, cam, width, height, cell):
     save(name, **d)
 
 
+def character_fixture(name, n=600, seed=13, frames=4):
+    feed = synth.character_feed(n, seed=seed, with_bodies=False)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rot = synth.quat_from_euler_xyz(*rng.uniform(-3, 3, (3, n))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    pos_frames = np.stack([feed["pos"] + np.float32(f) * np.asarray([0, -30, 0], np.float32) for f in range(frames)])
+    ref = refrun.characters(pos_frames, rot, scale, feed["hist_pos"], feed["hist_head"], feed["hist_wrapped"],
+                            feed["limbo_height"])
+    save(name, in_pos_frames=pos_frames.astype(np.float32), in_rot=rot, in_scale=scale, in_hist_pos=feed["hist_pos"],
+         in_hist_head=feed["hist_head"], in_hist_wrapped=feed["hist_wrapped"],
+         in_limbo_height=np.asarray([feed["limbo_height"]], np.float32), **{"ref_" + k: v for k, v in ref.items()})
+
+
 def main():
     if not refrun.available():
         refrun.build()
@@ -139,6 +152,7 @@ def main():
                       np.full(12, -0.25, np.float32), np.zeros(12, np.float32)]).astype(np.float32)
         pose_fixture(nm, sk, an, ch, t)
     attach_fixture("attach_bv_frames")
+    character_fixture("characters_limbo")
     tilted = synth.camera(pos=(1.0, 2.0, 3.0), quat=synth.quat_from_euler_xyz(0.1, 0.2, -0.05))
     light_fixture("lightgrid_1080p", synth.lights(seed=7), tilted, 1920, 1080, synth.LIGHT_TILE)
     light_fixture("lightgrid_odd_z01", synth.lights(97, seed=8, n_dir=1, inactive_frac=0.3),
