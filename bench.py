@@ -42,6 +42,9 @@ def parse():
                     help="tiles: subtree tiles, one launch for all levels; levels: level-major, one launch per level")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary workloads (pose/skinning, particles, bodies) reported under 'extra'")
+    ap.add_argument("--snapshot", default=None,
+                    help="run the entity step on a scene snapshot (include/clapgpu_snapshot.h; components "
+                         "'entities' and optionally 'camera') instead of the synthetic BASELINE workload")
     ap.add_argument("--exchange", choices=["rccl", "c10d"], default="rccl",
                     help="N > 1: call ncclAllGather directly (low host overhead) or through torch.distributed")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
@@ -192,9 +195,16 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
-    raw = synth.entities_chains(args.chains, args.depth, seed=2 + rank)
-    scene = tiler.tiled_scene(raw)[0] if args.layout == "tiles" else synth.pad_levels(raw)
     cam = synth.camera()
+    if args.snapshot:
+        from clap_amd import snapshot
+        comps = snapshot.load_scene(args.snapshot)
+        raw = comps["entities"]
+        cam = comps.get("camera", cam)
+        args.cpu_frames = 0                                  # the CPU baseline leg times the synthetic workload only
+    else:
+        raw = synth.entities_chains(args.chains, args.depth, seed=2 + rank)
+    scene = tiler.tiled_scene(raw)[0] if args.layout == "tiles" else synth.pad_levels(raw)
     fr, _view, _proj = entities.view_calc_frustum(cam)
     batch = entities.EntityBatch(scene, device)
     n_real, n_pad = batch.n_real, batch.n
@@ -308,8 +318,9 @@ def main():
             "value": value, "unit": "entity updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
-                                   f"{args.depth}, {args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
+            "config": {"workload": (f"snapshot {os.path.basename(args.snapshot)}: {n_real} entities/GPU, " if args.snapshot
+                                    else f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
+                                         f"{args.depth}, ") + f"{args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
                                    f"list ({visible} visible" + (" in the gathered global set)" if use_dist else ")"),
                        "entities_per_gpu": n_real, "levels": n_levels,
                        "exchange": (("ncclAllGather (direct)" if direct is not None else "torch.distributed all_gather")
