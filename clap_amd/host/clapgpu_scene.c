@@ -8,6 +8,7 @@
  * entity3d_flags (model.h:293-312).
  */
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <stdint.h>
 #include "clapgpu_scene.h"
@@ -193,6 +194,55 @@ int clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float
     memcpy(e->rot, q, 16);
     mark_dirty(s, handle, 1);
     return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3])
+{
+    struct ent *e = get(s, handle);
+    if (!e || !off) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    for (int i = 0; i < 3; i++)                             /* transform_move: vec3_add(pos, pos, off) */
+        e->pos_scale[i] = e->pos_scale[i] + off[i];
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+/* transform_set_angles (transform.c:62-73): clamp_radians / clamp_degrees + to_radians (util.h:77-95),
+ * then quat_from_euler_xyz (linmath.h:857-870) with the host's sinf / cosf, like the reference */
+void clapgpu_quat_from_angles(const float angles[3], int degrees, float q[4])
+{
+    float r[3];
+    for (int i = 0; i < 3; i++) {
+        float a = angles[i];
+        if (degrees) {
+            a = fabsf(a) <= 180.0 ? a : (a - copysignf(360.0, a));
+            a = a * M_PI / 180.0;
+        } else {
+            a = fabsf(a) <= M_PI ? a : (a - copysignf(M_PI * 2.0, a));
+        }
+        r[i] = a;
+    }
+    float cx = cosf(r[0] * 0.5f), sx = sinf(r[0] * 0.5f);
+    float cy = cosf(r[1] * 0.5f), sy = sinf(r[1] * 0.5f);
+    float cz = cosf(r[2] * 0.5f), sz = sinf(r[2] * 0.5f);
+    q[0] = sx * cy * cz - cx * sy * sz;
+    q[1] = cx * sy * cz + sx * cy * sz;
+    q[2] = cx * cy * sz - sx * sy * cz;
+    q[3] = cx * cy * cz + sx * sy * sz;
+}
+
+int clapgpu_scene_entity_rotate(clapgpu_scene *s, uint32_t handle, float rx, float ry, float rz)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const float angles[3] = { rx, ry, rz };
+    clapgpu_quat_from_angles(angles, 0, e->rot);            /* entity3d_rotate: radians (model.c:1818-1821) */
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_visible(clapgpu_scene *s, uint32_t handle, unsigned int visible)
+{
+    return clapgpu_scene_entity_flags(s, handle, visible ? CLAPGPU_E_VISIBLE : 0, visible ? 0 : CLAPGPU_E_VISIBLE);
 }
 
 int clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale)

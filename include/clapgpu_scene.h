@@ -42,6 +42,12 @@ int  clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t
 int  clapgpu_scene_entity_position(clapgpu_scene *s, uint32_t handle, const float pos[3]);
 int  clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float quat_xyzw[4]);
 int  clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale);
+/* entity3d_move / entity3d_rotate (radians) / entity3d_visible (model.c:1810-1842) */
+int  clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3]);
+int  clapgpu_scene_entity_rotate(clapgpu_scene *s, uint32_t handle, float rx, float ry, float rz);
+int  clapgpu_scene_entity_visible(clapgpu_scene *s, uint32_t handle, unsigned int visible);
+/* transform_set_angles' quaternion (transform.c:62-73): angle clamp, optional degrees, euler xyz -> (x,y,z,w) */
+void clapgpu_quat_from_angles(const float angles[3], int degrees, float quat_xyzw[4]);
 int  clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set, uint32_t clear);
 
 /* mq_update + cull against `frustum` (NULL: no cull) */

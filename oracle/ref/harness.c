@@ -34,6 +34,7 @@
  *   lod        entity3d_aabb_avg_edge + entity3d_set_lod
  *   lightgrid  light_grid_compute: lights x screen tiles -> RGBA32UI masks
  *   characters character_update (limbo teleport + history) for body-less characters
+ *   transform  transform_set_angles / transform_move
  */
 /* resolved through -I $(REF)/core (Makefile): /root/reference/core/{model,view,particle}.c */
 #include "model.c"
@@ -568,6 +569,27 @@ static int cmd_lod(struct arrset *in, struct arrset *out)
     return 0;
 }
 
+/* transform_set_angles (transform.c:62-73) and transform_move (transform.c:41-47) on given inputs */
+static int cmd_transform(struct arrset *in, struct arrset *out)
+{
+    uint32_t n = *(uint32_t *)arr_get(in, "n", NULL);
+    float *angles = arr_get(in, "angles", NULL);           /* [n][3] */
+    uint8_t *degrees = arr_get(in, "degrees", NULL);       /* [n] */
+    float *pos = arr_get(in, "pos", NULL), *off = arr_get(in, "off", NULL);
+    float *o_q = arr_add(out, "quat", (uint64_t)n * 16);
+    float *o_p = arr_add(out, "pos", (uint64_t)n * 12);
+    for (uint32_t i = 0; i < n; i++) {
+        transform_t t;
+        transform_init(&t);
+        transform_set_pos(&t, pos + 3 * i);
+        transform_move(&t, off + 3 * i);
+        transform_set_angles(&t, angles + 3 * i, degrees[i]);
+        memcpy(o_q + 4 * i, transform_rotation_quat(&t), 16);
+        transform_pos(&t, o_p + 3 * i);
+    }
+    return 0;
+}
+
 /*
  * character_update (character.c:583-611) for characters WITHOUT a physics body: the limbo teleport
  * out of the position history (history_newest / history_fetch, character.c:558-581), then the
@@ -694,6 +716,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[1], "lod"))             rc = cmd_lod(&in, &out);
     else if (!strcmp(argv[1], "lightgrid"))       rc = cmd_lightgrid(&in, &out);
     else if (!strcmp(argv[1], "characters"))      rc = cmd_characters(&in, &out);
+    else if (!strcmp(argv[1], "transform"))       rc = cmd_transform(&in, &out);
     else die("unknown command", argv[1]);
     clpio_write(argv[3], &out);
     return rc;

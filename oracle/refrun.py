@@ -175,3 +175,12 @@ def characters(pos_frames, rot, scale, hist_pos, hist_head, hist_wrapped, limbo_
                 mx=clpio.as_array(out["mx"], np.float32).reshape(f, n, 16),
                 hist_head=clpio.as_array(out["hist_head"], np.uint32).reshape(f, n),
                 hist_wrapped=clpio.as_array(out["hist_wrapped"], np.uint8).reshape(f, n))
+
+
+def transform(angles, degrees, pos, off):
+    """transform_set_pos + transform_move + transform_set_angles of the reference -> (quat xyzw, pos)."""
+    n = len(angles)
+    out = run("transform", dict(n=np.asarray([n], np.uint32), angles=np.asarray(angles, np.float32),
+                                degrees=np.asarray(degrees, np.uint8), pos=np.asarray(pos, np.float32),
+                                off=np.asarray(off, np.float32)))
+    return clpio.as_array(out["quat"], np.float32).reshape(n, 4), clpio.as_array(out["pos"], np.float32).reshape(n, 3)

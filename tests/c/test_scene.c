@@ -155,10 +155,20 @@ int main(int argc, char **argv)
             clapgpu_scene_entity_rotation(s, e->handle, e->rot);
             clapgpu_scene_entity_scale(s, e->handle, e->ps[3]);
         }
+        for (int k = 0; k < 80; k++) {                   /* entity3d_move / entity3d_rotate (euler, radians) */
+            struct host_ent *e = &ents[rnd() % n_ents];
+            if (!e->live) continue;
+            const float off[3] = { (float)(rnd() % 200) * 0.01f - 1.f, 0.25f, (float)(rnd() % 200) * -0.01f };
+            const float ang[3] = { (float)(rnd() % 1400) * 0.01f - 7.f, (float)(rnd() % 1400) * 0.01f - 7.f, 0.5f };
+            for (int a = 0; a < 3; a++) e->ps[a] = e->ps[a] + off[a];
+            clapgpu_quat_from_angles(ang, 0, e->rot);    /* the host copy follows the same (reference-pinned) helper */
+            clapgpu_scene_entity_move(s, e->handle, off);
+            clapgpu_scene_entity_rotate(s, e->handle, ang[0], ang[1], ang[2]);
+        }
         for (int k = 0; k < 40; k++) {                   /* entity3d_visible(e, false) / SKIP_CULLING */
             struct host_ent *e = &ents[rnd() % n_ents];
             if (!e->live) continue;
-            if (k & 1) { e->flags &= ~CLAPO_E_VISIBLE; clapgpu_scene_entity_flags(s, e->handle, 0, CLAPGPU_E_VISIBLE); }
+            if (k & 1) { e->flags &= ~CLAPO_E_VISIBLE; clapgpu_scene_entity_visible(s, e->handle, 0); }
             else { e->flags |= CLAPO_E_SKIP_CULLING; clapgpu_scene_entity_flags(s, e->handle, CLAPGPU_E_SKIP_CULLING, 0); }
         }
         if (frame & 1) {                                 /* topology change: delete leaves, add new children */

@@ -54,3 +54,23 @@ def test_scene_mirror_frames_match_oracle(mode, cuda_device):
     r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout and r.stdout.count("frame ok") == 5
+
+
+def test_quat_from_angles_matches_reference(golden_dir):
+    """transform_set_angles (clamp, degrees, euler xyz -> quaternion): the host helper against the
+    reference's own function, bit-exact (same libm)."""
+    import ctypes as C
+    import numpy as np
+    from clap_amd import snapshot
+    L = snapshot.lib()                                      # loads libclapgpu_scene.so
+    L.clapgpu_quat_from_angles.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
+    L.clapgpu_quat_from_angles.restype = None
+    z = np.load(os.path.join(golden_dir, "transform_verbs.npz"))
+    fp = C.POINTER(C.c_float)
+    q = np.zeros(4, np.float32)
+    for i in range(len(z["in_angles"])):
+        a = np.ascontiguousarray(z["in_angles"][i])
+        L.clapgpu_quat_from_angles(a.ctypes.data_as(fp), int(z["in_degrees"][i]), q.ctypes.data_as(fp))
+        assert np.array_equal(q.view(np.uint32), z["ref_quat"][i].view(np.uint32)), (i, a, q, z["ref_quat"][i])
+    # transform_move is a plain fp32 add
+    assert np.array_equal((z["in_pos"] + z["in_off"]).view(np.uint32), z["ref_pos"].view(np.uint32))

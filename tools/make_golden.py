@@ -129,6 +129,18 @@ def character_fixture(name, n=600, seed=13, frames=4):
          in_limbo_height=np.asarray([feed["limbo_height"]], np.float32), **{"ref_" + k: v for k, v in ref.items()})
 
 
+def transform_fixture(name, n=400, seed=21):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    degrees = (rng.uniform(0, 1, n) < 0.5).astype(np.uint8)
+    angles = np.where(degrees[:, None] != 0, rng.uniform(-400, 400, (n, 3)), rng.uniform(-7, 7, (n, 3))).astype(np.float32)
+    angles[:6] = [[0, 0, 0], [180, -180, 180.00002], [np.pi, -np.pi, 3.1415927], [360, 0, -360], [0, 90, 0], [1e-30, 0, 0]]
+    degrees[:6] = [0, 1, 0, 1, 1, 0]
+    pos = rng.uniform(-500, 500, (n, 3)).astype(np.float32)
+    off = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    quat, moved = refrun.transform(angles, degrees, pos, off)
+    save(name, in_angles=angles, in_degrees=degrees, in_pos=pos, in_off=off, ref_quat=quat, ref_pos=moved)
+
+
 def main():
     if not refrun.available():
         refrun.build()
@@ -153,6 +165,7 @@ def main():
         pose_fixture(nm, sk, an, ch, t)
     attach_fixture("attach_bv_frames")
     character_fixture("characters_limbo")
+    transform_fixture("transform_verbs")
     tilted = synth.camera(pos=(1.0, 2.0, 3.0), quat=synth.quat_from_euler_xyz(0.1, 0.2, -0.05))
     light_fixture("lightgrid_1080p", synth.lights(seed=7), tilted, 1920, 1080, synth.LIGHT_TILE)
     light_fixture("lightgrid_odd_z01", synth.lights(97, seed=8, n_dir=1, inactive_frac=0.3),
