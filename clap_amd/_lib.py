@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 OK = 0
 ERR_NOMEM = -1
@@ -69,6 +69,13 @@ class Particles(C.Structure):
                 ("billboard_mx", C.c_void_p), ("respawn_mask", C.c_void_p), ("respawn_row_pop", C.c_void_p),
                 ("respawn_list", C.c_void_p), ("respawn_count", C.c_void_p), ("scratch", C.c_void_p),
                 ("respawn_groups", C.c_void_p)]
+
+
+class AnimClock(C.Structure):
+    """clapgpu_anim_clock (include/clapgpu.h)."""
+    _fields_ = [("n_chars", C.c_uint32), ("n_anims", C.c_uint32), ("anim", C.c_void_p), ("time_end", C.c_void_p),
+                ("ani_time", C.c_void_p), ("speed", C.c_void_p), ("restart", C.c_void_p), ("frame_time", C.c_void_p),
+                ("ended", C.c_void_p)]
 
 
 class Skeleton(C.Structure):
@@ -154,6 +161,7 @@ SYMBOLS = {
     "clapgpu_visible_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_visible_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "clapgpu_animation_time": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_double]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
     "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),

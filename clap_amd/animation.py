@@ -154,14 +154,38 @@ class CharacterBatch:
             self.anim.copy_(torch.from_numpy(self.anim_host))
 
     def animated_update(self, now):
-        """Host half: frame_time = (now - ani_time) * speed in double, passed on as float;
-        a repeating animation restarts once frame_time >= time_end (animation_next ->
-        animation_start, model.c:1590-1591, 1406-1424).  Device half: pose + palette."""
-        ft = (float(now) - self.ani_time) * self.speed
-        self.set_frame_times(ft.astype(np.float32))
+        """animated_update (model.c:1563-1592) for the batch, all on the device: the clock kernel turns
+        (now, ani_time, speed) into the float frame times, flags `ended` and restarts repeating queue
+        entries (animation_next -> animation_start: ani_time = now); then pose + palette.  The host
+        only reads `ended` back when it has non-repeating entries or callbacks to serve."""
+        if getattr(self, "_clock", None) is None:
+            self.start_clock()
+        rc = _lib.lib().clapgpu_animation_time(_stream(), C.byref(self._clock), float(now))
+        _lib.check(rc, "clapgpu_animation_time")
         self.pose_update()
-        te = np.asarray(self.model.time_end)[self.anim_host]
-        self.ani_time[ft >= te] = float(now)
+
+    def start_clock(self, ani_time=None, speed=None, repeat=None):
+        """Device copies of entity3d.ani_time and the current queue entry's speed / repeat
+        (model.h:417, model.c:1538-1541), from the host fields of the same names."""
+        dev, n = self.device, self.n
+        if ani_time is not None:
+            self.ani_time[:] = ani_time
+        if speed is not None:
+            self.speed[:] = speed
+        self.repeat_host = np.ones(n, np.uint8) if repeat is None else np.ascontiguousarray(repeat, np.uint8)
+        self.ani_time_dev = torch.from_numpy(np.ascontiguousarray(self.ani_time, np.float64)).to(dev)
+        self.speed_dev = torch.from_numpy(np.ascontiguousarray(self.speed, np.float32)).to(dev)
+        self.repeat_dev = torch.from_numpy(self.repeat_host).to(dev)
+        self.ended = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        self.time_end_dev = torch.from_numpy(np.asarray(self.model.time_end, np.float32)).to(dev)
+        self._clock = _lib.AnimClock(n, len(self.model.time_end), _ptr(self.anim), _ptr(self.time_end_dev),
+                                     _ptr(self.ani_time_dev), _ptr(self.speed_dev), _ptr(self.repeat_dev),
+                                     _ptr(self.frame_time), _ptr(self.ended))
+
+    def download_clock(self):
+        torch.cuda.synchronize(self.device)
+        return dict(ani_time=self.ani_time_dev.cpu().numpy(), frame_time=self.frame_time.cpu().numpy(),
+                    ended=self.ended.cpu().numpy()[:self.n])
 
     def pose_update(self):
         rc = _lib.lib().clapgpu_pose_update(_stream(), C.byref(self.model.skel_desc), C.byref(self.model.anim_desc),

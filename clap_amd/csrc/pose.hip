@@ -347,9 +347,38 @@ void k_pose(PoseArgs a)
     }
 }
 
+// animated_update's clock (model.c:1563-1592): one lane per character
+__global__ __launch_bounds__(256)
+void k_animation_time(clapgpu_anim_clock k, double now)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= k.n_chars) return;
+    const double ft = (now - k.ani_time[c]) * (double)k.speed[c];
+    k.frame_time[c] = (float)ft;
+    const uint32_t an = k.anim[c];
+    const bool ended = an < k.n_anims && ft >= (double)k.time_end[an];
+    k.ended[c] = ended ? 1 : 0;
+    if (ended && k.restart[c])
+        k.ani_time[c] = now;                                        // animation_next -> animation_start
+}
+
 } // namespace clapgpu
 
 using namespace clapgpu;
+
+extern "C" int clapgpu_animation_time(void *stream, const clapgpu_anim_clock *clk, double now)
+{
+    if (!clk)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (clk->n_chars == 0)
+        return CLAPGPU_OK;
+    if (!clk->anim || !clk->time_end || !clk->ani_time || !clk->speed || !clk->restart || !clk->frame_time ||
+        !clk->ended)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    hipLaunchKernelGGL(k_animation_time, dim3((clk->n_chars + 255) / 256), dim3(256), 0, as_stream(stream), *clk, now);
+    CLAPGPU_LAUNCH_CHECK("k_animation_time");
+    return CLAPGPU_OK;
+}
 
 extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,
                                    const clapgpu_pose_batch *pb)

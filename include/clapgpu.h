@@ -362,6 +362,29 @@ typedef struct clapgpu_pose_batch {
     float          *joint_pos;
 } clapgpu_pose_batch;
 
+/*
+ * The time base of animated_update() (model.c:1563-1592) for the batch, on the device: per character
+ *   frame_time[c] = (float)((now - ani_time[c]) * speed[c])        (double arithmetic, model.c:1578-1582)
+ *   ended[c]      = (now - ani_time[c]) * speed[c] >= time_end[anim[c]]      (model.c:1590)
+ * and for a character whose current queue entry repeats (restart[c] != 0) the animation_next() ->
+ * animation_start() that follows: ani_time[c] = now (model.c:1406-1424, 1455-1483).  Entries that do
+ * not repeat are left to the host, which reads ended[] to run its queue logic and callbacks
+ * (animation_end, frame_cb, ani_cleared).  Run before clapgpu_pose_update with the same frame_time
+ * array.  time_end[a] = animation.time_end of the model's animation a; now = clap_get_current_time().
+ */
+typedef struct clapgpu_anim_clock {
+    uint32_t        n_chars;
+    uint32_t        n_anims;
+    const uint32_t *anim;
+    const float    *time_end;
+    double         *ani_time;
+    const float    *speed;
+    const uint8_t  *restart;
+    float          *frame_time;
+    uint8_t        *ended;
+} clapgpu_anim_clock;
+int clapgpu_animation_time(void *stream, const clapgpu_anim_clock *clk, double now);
+
 /* Replaces channels_transform() + one_joint_transform(e, 0, -1) of animated_update()
  * (model.c:1582-1583) for every character of the batch. */
 int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,

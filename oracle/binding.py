@@ -116,6 +116,7 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_animation_time.argtypes = [C.c_uint32, C.c_uint32, U32P, F32P, F64P, F32P, U8P, C.c_double, F32P, U8P]
     L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
                                           C.c_void_p, C.c_void_p, C.c_void_p, U8P]
     L.clapo_contacts_spheres.argtypes = [C.c_uint32, U32P, F64P, F64P, C.c_void_p, C.c_void_p]
@@ -411,3 +412,14 @@ def characters_update(chars, limbo_height, pos_scale, entity_flags, bodies=None)
                                   np.ascontiguousarray(chars["airborne"], np.uint8), pos_scale.reshape(-1),
                                   entity_flags, bp, bl, by, moved)
     return moved
+
+
+def animation_time(anim, time_end, ani_time, speed, restart, now):
+    """animated_update's clock: ani_time updated in place; returns (frame_time f32[n], ended u8[n])."""
+    n = len(anim)
+    ft, ended = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+    lib().clapo_animation_time(n, len(time_end), np.ascontiguousarray(anim, np.uint32),
+                               np.ascontiguousarray(time_end, np.float32), ani_time,
+                               np.ascontiguousarray(speed, np.float32), np.ascontiguousarray(restart, np.uint8),
+                               float(now), ft, ended)
+    return ft, ended

@@ -216,6 +216,11 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t n, const double *pos, const double *radius,
                                        uint32_t *pairs, uint64_t max_pairs);
 
+/* ---- animated_update's clock (model.c:1563-1592; pose.c) ---- */
+void clapo_animation_time(uint32_t n_chars, uint32_t n_anims, const uint32_t *anim, const float *time_end,
+                          double *ani_time, const float *speed, const uint8_t *restart, double now,
+                          float *frame_time, uint8_t *ended);
+
 /* ---- character feeder in front of default_update (character.c:546-611; character.c) ---- */
 void clapo_characters_update(uint32_t n_chars, const uint32_t *char_entity, const int32_t *char_body,
                              float limbo_height, float *hist_pos, uint32_t *hist_head, uint8_t *hist_wrapped,

@@ -99,3 +99,23 @@ void clapo_skeleton_bind(uint32_t nr_joints, const float *invmx, float *bind)
     for (uint32_t j = 0; j < nr_joints; j++)
         lm_m4_invert(bind + 16 * (size_t)j, invmx + 16 * (size_t)j);
 }
+
+
+/*
+ * The clock of animated_update (model.c:1563-1592) for a batch: frame_time in double from
+ * now / ani_time / speed, handed on as float (channels_transform takes a float); ended = the test of
+ * model.c:1590; a repeating entry restarts through animation_next -> animation_start
+ * (model.c:1455-1483, 1406-1424: ani_time = now).
+ */
+void clapo_animation_time(uint32_t n_chars, uint32_t n_anims, const uint32_t *anim, const float *time_end,
+                          double *ani_time, const float *speed, const uint8_t *restart, double now,
+                          float *frame_time, uint8_t *ended)
+{
+    for (uint32_t c = 0; c < n_chars; c++) {
+        double ft = (now - ani_time[c]) * speed[c];
+        frame_time[c] = ft;
+        ended[c] = anim[c] < n_anims && ft >= time_end[anim[c]];
+        if (ended[c] && restart[c])
+            ani_time[c] = now;
+    }
+}

@@ -11,8 +11,11 @@
  * channels_transform, one_joint_transform, particles_update,
  * subview_calc_frustum) are callable.  Nothing is copied.
  *
- * Three test doubles are defined here, all for functions whose real definitions live in
+ * Four test doubles are defined here, all for functions whose real definitions live in
  * translation units that cannot be built in this image:
+ *   clap_get_current_time()    (clap.c, the frame driver): the engine's frame clock; the double
+ *                              returns the time the job file gives for the frame being run
+ *                              (animated_update / animation_start read it, model.c:1423,1565);
  *   texture_load()             (render-gl.c, needs GL headers): the sink light_grid_compute hands
  *                              its finished tile masks to (light.c:150-153).  The double records
  *                              format, size and the bytes handed over -- i.e. exactly what the
@@ -55,6 +58,12 @@ static render_options harness_ropts;
 render_options *clap_get_render_options(struct clap_context *ctx)
 {
     return &harness_ropts;
+}
+
+static double harness_now;
+double clap_get_current_time(struct clap_context *ctx)
+{
+    return harness_now;
 }
 
 static renderer_caps harness_caps;
@@ -521,11 +530,38 @@ static int cmd_pose(struct arrset *in, struct arrset *out)
         memcpy(o_bind + 16 * j, m->joints[j].bind, 64);
     *o_time_end = an->time_end;
 
+    /* optional: drive the characters through animated_update (model.c:1563-1592) with a frame clock:
+     * "now"[frames] doubles, per character a start time, a speed and whether the queued entry repeats */
+    double *now = arr_has(in, "now") ? arr_get(in, "now", NULL) : NULL;
+    struct scene *scene = NULL;
+    double *o_ani = NULL;
+    if (now) {
+        double *start = arr_get(in, "start", NULL);
+        float *speed = arr_get(in, "speed", NULL);
+        uint8_t *repeat = arr_get(in, "repeat", NULL);
+        scene = calloc(1, sizeof(*scene));
+        scene->clap_ctx = (struct clap_context *)scene;     /* only handed to the clock double */
+        for (uint32_t i = 0; i < n_chars; i++) {
+            entity3d *e = &ents[i];
+            darray_init(e->aniq);
+            harness_now = start[i];
+            if (!animation_push_by_name(e, scene, "a", true, repeat[i])) die("animation_push_by_name", NULL);
+            ani_current(e)->speed = speed[i];               /* animation_set_speed's store (model.c:1517) */
+        }
+        o_ani = arr_add(out, "ani_time", (uint64_t)frames * n_chars * 8);
+    }
+
     for (uint32_t f = 0; f < frames; f++)
         for (uint32_t i = 0; i < n_chars; i++) {
             entity3d *e = &ents[i];
-            channels_transform(e, an, char_time[(uint64_t)f * n_chars + i]);   /* model.c:1582 */
-            one_joint_transform(e, 0, -1);                                      /* model.c:1583 */
+            if (now) {
+                harness_now = now[f];
+                animated_update(e, scene);
+                o_ani[(uint64_t)f * n_chars + i] = e->ani_time;
+            } else {
+                channels_transform(e, an, char_time[(uint64_t)f * n_chars + i]);   /* model.c:1582 */
+                one_joint_transform(e, 0, -1);                                      /* model.c:1583 */
+            }
             for (uint32_t j = 0; j < J; j++) {
                 uint64_t k = (uint64_t)f * per + (uint64_t)i * J + j;
                 memcpy(o_trs + 10 * k, e->joints[j].translation, 12);

@@ -116,9 +116,13 @@ def particles(ps, view_mx, rng_state, frames):
                 rng_state=A(out["rng_state"], np.uint64, (frames + 1,)))
 
 
-def pose(sk, an, chars, char_times):
+def pose(sk, an, chars, char_times=None, clock=None):
     """channels_transform + one_joint_transform on the reference for every character;
-    char_times [frames, n_chars] (float32 frame times)."""
+    char_times [frames, n_chars] (float32 frame times).  With clock = dict(now f64[frames],
+    start f64[n], speed f32[n], repeat u8[n]) the characters are driven through animated_update
+    (queue entry pushed at `start`, then one call per `now`) and ani_time per frame is returned too."""
+    if clock is not None:
+        char_times = np.zeros((len(clock["now"]), len(clock["start"])), np.float32)
     char_times = np.atleast_2d(np.asarray(char_times, np.float32))
     frames, n = char_times.shape
     J = int(sk["nr_joints"])
@@ -128,9 +132,13 @@ def pose(sk, an, chars, char_times):
                   ch_target=an["ch_target"], ch_path=an["ch_path"], ch_nr=an["ch_nr"],
                   ch_time_off=an["ch_time_off"], ch_data_off=an["ch_data_off"], times=an["times"], data=an["data"],
                   char_time=char_times, char_mx=chars["char_mx"][:n], trs0=chars["trs0"])
+    if clock is not None:
+        arrays.update(now=np.asarray(clock["now"], np.float64), start=np.asarray(clock["start"], np.float64),
+                      speed=np.asarray(clock["speed"], np.float32), repeat=np.asarray(clock["repeat"], np.uint8))
     out = run("pose", arrays)
     A = clpio.as_array
-    return dict(trs=A(out["trs"], np.float32, (frames, n, J, 10)),
+    extra = dict(ani_time=A(out["ani_time"], np.float64, (frames, n))) if clock is not None else {}
+    return dict(**extra, trs=A(out["trs"], np.float32, (frames, n, J, 10)),
                 joint_transforms=A(out["joint_transforms"], np.float32, (frames, n, J, 16)),
                 globalmx=A(out["global"], np.float32, (frames, n, J, 16)),
                 joint_pos=A(out["joint_pos"], np.float32, (frames, n, J, 4)),

@@ -94,3 +94,30 @@ def test_skin_oracle_identities():
     M = pal[0, 5].reshape(4, 4).T.astype(np.float64)
     exp = (M @ np.concatenate([mesh["position"], np.ones((300, 1))], 1).T).T[:, :3]
     np.testing.assert_allclose(p, exp, rtol=1e-6, atol=1e-6)
+
+
+def test_animation_clock_matches_reference_fixture(golden_dir):
+    """animated_update's time base and restart (model.c:1563-1592): ani_time after every frame of the
+    reference's own animated_update, and its poses reproduced from the oracle's float frame times."""
+    z = np.load(os.path.join(golden_dir, "animclock_frames.npz"))
+    sk = {k[3:]: z[k] for k in z.files if k.startswith("sk_")}
+    sk["nr_joints"] = sk["parent"].shape[0]
+    an = {k[3:]: z[k] for k in z.files if k.startswith("an_")}
+    an["n_channels"] = an["ch_target"].shape[0]
+    an["time_end"] = float(z["ref_time_end"][0])
+    sk["bind"] = ob.skeleton_bind(sk)
+    n, J = len(z["clock_start"]), sk["nr_joints"]
+    ani = z["clock_start"].astype(np.float64).copy()
+    te = np.asarray([an["time_end"]], np.float32)
+    trs = np.tile(z["in_trs0"], (n, 1, 1))
+    cur = np.zeros((n, J, 3), np.int32)
+    reach = sk["order"]
+    ended_total = 0
+    for f, now in enumerate(z["clock_now"]):
+        ft, ended = ob.animation_time(np.zeros(n, np.uint32), te, ani, z["clock_speed"], z["clock_repeat"], now)
+        assert np.array_equal(ani.view(np.uint64), z["ref_ani_time"][f].view(np.uint64)), f"frame {f} ani_time"
+        cur[ended != 0] = 0                                  # animation_start resets the search cursors
+        jt, _gl, _jp = ob.pose(sk, an, ft, z["in_char_mx"], trs, cur)
+        assert_bits_equal(jt[:, reach], z["ref_joint_transforms"][f][:, reach], f"frame {f} joint_transforms")
+        ended_total += int(ended.sum())
+    assert ended_total > n // 2

@@ -86,26 +86,58 @@ def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
         assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
 
 
-def test_animated_update_time_base(cuda_device):
-    """Host half of animated_update: frame_time = (now - ani_time) * speed, restart at time_end."""
+def test_animated_update_clock_on_device(cuda_device, golden_dir):
+    """animated_update's clock (model.c:1563-1592) as a kernel: frame times, `ended`, restart of
+    repeating entries -- against the reference's own animated_update (golden) and the oracle."""
+    import os
+    from clap_amd import animation
+    z = np.load(os.path.join(golden_dir, "animclock_frames.npz"))
+    sk = {k[3:]: z[k] for k in z.files if k.startswith("sk_")}
+    sk["nr_joints"] = sk["parent"].shape[0]
+    an = {k[3:]: z[k] for k in z.files if k.startswith("an_")}
+    an["n_channels"] = an["ch_target"].shape[0]
+    an["time_end"] = float(z["ref_time_end"][0])
+    sk["bind"] = ob.skeleton_bind(sk)
+    n = len(z["clock_start"])
+    model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, z["in_trs0"], z["in_char_mx"])
+    batch.start_clock(ani_time=z["clock_start"], speed=z["clock_speed"], repeat=z["clock_repeat"])
+    ani = z["clock_start"].astype(np.float64).copy()
+    te = np.asarray([an["time_end"]], np.float32)
+    reach = sk["order"]
+    restarts = 0
+    for f, now in enumerate(z["clock_now"]):
+        ft, ended = ob.animation_time(np.zeros(n, np.uint32), te, ani, z["clock_speed"], z["clock_repeat"], now)
+        batch.animated_update(now)
+        clk = batch.download_clock()
+        assert np.array_equal(clk["ani_time"].view(np.uint64), z["ref_ani_time"][f].view(np.uint64)), f"frame {f} ani_time"
+        assert np.array_equal(clk["ani_time"], ani) and np.array_equal(clk["ended"], ended)
+        assert np.array_equal(clk["frame_time"].view(np.uint32), ft.view(np.uint32)), f"frame {f} frame_time"
+        assert_close(batch.download()["joint_transforms"][:, reach], z["ref_joint_transforms"][f][:, reach], f"frame {f}")
+        restarts += int(ended.sum())
+    assert restarts > n // 2, "the fixture runs past the end of the animation"
+
+
+def test_animation_clock_non_repeating_entries_are_left_to_the_host(cuda_device):
     from clap_amd import animation
     sk = synth.skeleton(16, 4, seed=5)
     an = synth.animation(16, 6, 1.5, seed=5)
-    ch = synth.characters(8, 16, seed=5)
+    ch = synth.characters(64, 16, seed=5)
     sk["bind"] = ob.skeleton_bind(sk)
     model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
-    batch = animation.CharacterBatch(model, 8, ch["trs0"], ch["char_mx"])
-    batch.ani_time[:] = np.linspace(0, 1, 8)
-    batch.speed[:] = 1.25
-    trs = np.tile(ch["trs0"], (8, 1, 1))
-    ani_time = batch.ani_time.copy()
-    for now in (1.0, 1.7, 2.9):
-        ft = ((now - ani_time) * 1.25)
-        jt, _g, _p = ob.pose(sk, an, ft.astype(np.float32), ch["char_mx"], trs)
+    batch = animation.CharacterBatch(model, 64, ch["trs0"], ch["char_mx"])
+    repeat = (np.arange(64) % 2).astype(np.uint8)
+    start = np.linspace(0, 1, 64)
+    batch.start_clock(ani_time=start, speed=np.full(64, 1.25, np.float32), repeat=repeat)
+    ani = start.copy()
+    te = np.asarray(model.time_end, np.float32)
+    for now in (1.0, 1.7, 2.9, 3.0):
+        ft, ended = ob.animation_time(np.zeros(64, np.uint32), te, ani, np.full(64, 1.25, np.float32), repeat, now)
         batch.animated_update(now)
-        assert_close(batch.download()["joint_transforms"], jt, f"now={now}")
-        ani_time[ft >= 1.5] = now
-        assert np.array_equal(batch.ani_time, ani_time)
+        clk = batch.download_clock()
+        assert np.array_equal(clk["ani_time"], ani) and np.array_equal(clk["ended"], ended)
+    assert np.array_equal(ani[repeat == 0], start[repeat == 0]), "no restart without `repeat`"
+    assert (ani[repeat == 1] != start[repeat == 1]).any()
 
 
 @pytest.mark.parametrize("shared_mesh", [True, False], ids=["instanced_mesh", "mesh_per_character"])

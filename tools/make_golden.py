@@ -141,6 +141,23 @@ def transform_fixture(name, n=400, seed=21):
     save(name, in_angles=angles, in_degrees=degrees, in_pos=pos, in_off=off, ref_quat=quat, ref_pos=moved)
 
 
+def clock_fixture(name, n=12, J=24, frames=8, seed=8):
+    sk = synth.skeleton(J, 6, seed=seed)
+    an = synth.animation(J, 9, 2.0, seed=seed)
+    ch = synth.characters(n, J, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    clock = dict(start=rng.uniform(100.0, 101.0, n), speed=rng.choice([0.5, 1.0, 1.7, 3.0], n).astype(np.float32),
+                 repeat=np.ones(n, np.uint8), now=101.0 + np.cumsum(rng.uniform(0.05, 0.5, frames)))
+    ref = refrun.pose(sk, an, ch, clock=clock)
+    d = {"sk_" + k: sk[k] for k in SK_KEYS}
+    d.update({"an_" + k: an[k] for k in AN_KEYS})
+    d.update(in_char_mx=ch["char_mx"], in_trs0=ch["trs0"])
+    d.update({"clock_" + k: v for k, v in clock.items()})
+    d.update(ref_ani_time=ref["ani_time"], ref_joint_transforms=ref["joint_transforms"],
+             ref_time_end=np.asarray([ref["time_end"]], np.float32))
+    save(name, **d)
+
+
 def main():
     if not refrun.available():
         refrun.build()
@@ -165,6 +182,7 @@ def main():
         pose_fixture(nm, sk, an, ch, t)
     attach_fixture("attach_bv_frames")
     character_fixture("characters_limbo")
+    clock_fixture("animclock_frames")
     transform_fixture("transform_verbs")
     tilted = synth.camera(pos=(1.0, 2.0, 3.0), quat=synth.quat_from_euler_xyz(0.1, 0.2, -0.05))
     light_fixture("lightgrid_1080p", synth.lights(seed=7), tilted, 1920, 1080, synth.LIGHT_TILE)
