@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclapgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 OK = 0
 ERR_NOMEM = -1
@@ -174,6 +174,8 @@ SYMBOLS = {
                                            C.c_void_p, C.c_void_p]),
     "clapgpu_broadphase_static_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
                                                   C.c_uint32, C.c_void_p, C.c_void_p]),
+    "clapgpu_bodies_rotate_from_entities": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(Entities), C.c_uint32,
+                                                      C.c_uint32, C.c_void_p, C.c_void_p]),
     "clapgpu_contacts_spheres": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),

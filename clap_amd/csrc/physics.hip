@@ -521,6 +521,23 @@ void k_bp_copy_lists(uint32_t n, const uint32_t *pair_start, const uint32_t *par
         reinterpret_cast<uint2 *>(pairs)[start + q] = make_uint2(i, partners[(size_t)i * BP_LIST + q]);
 }
 
+// phys_body_rotate_xform (physics.c:136-145) for the linked entities that default_update rebuilt
+__global__ __launch_bounds__(PHYS_BLOCK)
+void k_bodies_rotate_from_entities(uint32_t n_links, const uint32_t *link_body, const uint32_t *link_entity,
+                                   uint32_t n_bodies, uint32_t n_entities, uint32_t mode, const float4 *rot,
+                                   const int32_t *parent, const uint32_t *flags, double *quat)
+{
+    const uint32_t k = blockIdx.x * PHYS_BLOCK + threadIdx.x;
+    if (k >= n_links) return;
+    const uint32_t b = link_body[k], e = link_entity[k];
+    if (b >= n_bodies || e >= n_entities || parent[e] >= 0) return;
+    if (!(mode & CLAPGPU_UPDATE_ALL_DIRTY) && !(flags[e] & CLAPGPU_E_DIRTY)) return;
+    const float4 r = rot[e];
+    double q[4] = { (double)r.w, (double)r.x, (double)r.y, (double)r.z };
+    const double l = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);   // dNormalize4
+    for (int a = 0; a < 4; a++) quat[4 * (size_t)b + a] = q[a] * l;
+}
+
 // dCollide for sphere pairs + phys_contact_surface (see include/clapgpu.h): one lane per candidate
 // pair; geometry as ODE's dCollideSpheres, IEEE fp64 (sqrt, divide), no contraction.
 __global__ __launch_bounds__(PHYS_BLOCK)
@@ -781,5 +798,22 @@ extern "C" int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, c
                        b->pos, b->radius, b->n, reinterpret_cast<const uint2 *>(pairs), pair_total, capacity,
                        material, contacts, contact_total);
     CLAPGPU_LAUNCH_CHECK("k_contacts_spheres");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_bodies_rotate_from_entities(void *stream, const clapgpu_bodies *b, const clapgpu_entities *e,
+                                                   uint32_t mode, uint32_t n_links, const uint32_t *link_body,
+                                                   const uint32_t *link_entity)
+{
+    int rc = check_bodies(b);
+    if (rc) return rc;
+    if (!e || !e->rot || !e->parent || !e->flags || (n_links && (!link_body || !link_entity)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (n_links == 0 || b->n == 0)
+        return CLAPGPU_OK;
+    hipLaunchKernelGGL(k_bodies_rotate_from_entities, dim3((n_links + PHYS_BLOCK - 1) / PHYS_BLOCK), dim3(PHYS_BLOCK), 0,
+                       as_stream(stream), n_links, link_body, link_entity, b->n, e->n, mode,
+                       reinterpret_cast<const float4 *>(e->rot), e->parent, e->flags, b->quat);
+    CLAPGPU_LAUNCH_CHECK("k_bodies_rotate_from_entities");
     return CLAPGPU_OK;
 }

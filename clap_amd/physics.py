@@ -67,6 +67,16 @@ class PhysWorld:
                                               self.capacity, _ptr(self.pair_total), _ptr(self.scratch)),
                    "clapgpu_broadphase_pairs")
 
+    def rotate_from_entities(self, entity_batch, link_body, link_entity, all_dirty=False):
+        """phys_body_rotate_xform for the (body, entity) links whose entity default_update is about to
+        rebuild (model.c:1680-1687); run before entity_batch.mq_update."""
+        lb = torch.from_numpy(np.ascontiguousarray(link_body, np.uint32).view(np.int32)).to(self.device)
+        le = torch.from_numpy(np.ascontiguousarray(link_entity, np.uint32).view(np.int32)).to(self.device)
+        rc = _lib.lib().clapgpu_bodies_rotate_from_entities(_stream(), C.byref(self._desc), C.byref(entity_batch._desc),
+                                                            _lib.UPDATE_ALL_DIRTY if all_dirty else 0, len(link_body),
+                                                            _ptr(lb), _ptr(le))
+        _lib.check(rc, "clapgpu_bodies_rotate_from_entities")
+
     def set_materials(self, material):
         """Per-body phys_body parameters (bounce, bounce_vel, mu, soft_erp, soft_cfm; physics.c:77-81)."""
         self.material = torch.from_numpy(np.ascontiguousarray(material, np.float64)).to(self.device)

@@ -483,6 +483,18 @@ int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, float *pos_s
                              uint32_t *entity_flags, uint8_t *moving);
 
 /*
+ * default_update's push of the entity rotation to the physics body of characters and static
+ * colliders (model.c:1680-1687 -> phys_body_rotate_xform, physics.c:136-145): link k = (body
+ * link_body[k], entity link_entity[k]).  For a linked entity without a parent whose CLAPGPU_E_DIRTY
+ * is set (or any, under CLAPGPU_UPDATE_ALL_DIRTY) the body quaternion becomes the entity's
+ * (x,y,z,w) -> (w,x,y,z) in double, normalised as dBodySetQuaternion does.  Call BEFORE
+ * clapgpu_entities_update, which clears the dirty flags.
+ */
+int clapgpu_bodies_rotate_from_entities(void *stream, const clapgpu_bodies *b, const clapgpu_entities *e,
+                                        uint32_t mode, uint32_t n_links, const uint32_t *link_body,
+                                        const uint32_t *link_entity);
+
+/*
  * dSpaceCollide(character_space) (physics.c:753): all body pairs whose AABBs overlap, as the
  * ascending list pairs[k] = (i, j), i < j.  cell >= the largest AABB edge (2 * max radius).
  * *pair_total (device uint32) receives the number found; at most `capacity` are written.

@@ -119,6 +119,7 @@ def _declare(L):
     L.clapo_animation_time.argtypes = [C.c_uint32, C.c_uint32, U32P, F32P, F64P, F32P, U8P, C.c_double, F32P, U8P]
     L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
                                           C.c_void_p, C.c_void_p, C.c_void_p, U8P]
+    L.clapo_bodies_rotate_from_entities.argtypes = [C.c_uint32, U32P, U32P, F32P, I32P, U8P, F64P]
     L.clapo_contacts_spheres.argtypes = [C.c_uint32, U32P, F64P, F64P, C.c_void_p, C.c_void_p]
     L.clapo_contacts_spheres.restype = C.c_uint32
     L.clapo_light_radius.argtypes = [F32P, F32P, C.c_int]
@@ -423,3 +424,12 @@ def animation_time(anim, time_end, ani_time, speed, restart, now):
                                np.ascontiguousarray(speed, np.float32), np.ascontiguousarray(restart, np.uint8),
                                float(now), ft, ended)
     return ft, ended
+
+
+def bodies_rotate_from_entities(link_body, link_entity, rot, parent, dirty, quat):
+    """quat (f64 [n_bodies, 4], w first) is updated in place."""
+    lib().clapo_bodies_rotate_from_entities(len(link_body), np.ascontiguousarray(link_body, np.uint32),
+                                            np.ascontiguousarray(link_entity, np.uint32),
+                                            np.ascontiguousarray(rot, np.float32).reshape(-1),
+                                            np.ascontiguousarray(parent, np.int32),
+                                            np.ascontiguousarray(dirty, np.uint8), quat.reshape(-1))

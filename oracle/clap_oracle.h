@@ -228,6 +228,9 @@ void clapo_characters_update(uint32_t n_chars, const uint32_t *char_entity, cons
                              double *body_pos, const double *body_lvel, const double *body_yoffset,
                              uint8_t *moved);
 
+void clapo_bodies_rotate_from_entities(uint32_t n_links, const uint32_t *link_body, const uint32_t *link_entity,
+                                       const float *rot, const int32_t *parent, const uint8_t *dirty, double *quat);
+
 /* ---- sphere contacts after the broadphase (physics.c:291-330, 399-449; physics.c) ---- */
 typedef struct clapo_contact {
     double   pos[3], normal[3], depth;                  /* dContactGeom */

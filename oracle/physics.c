@@ -294,3 +294,23 @@ uint32_t clapo_contacts_spheres(uint32_t n_pairs, const uint32_t *pairs, const d
     }
     return total;
 }
+
+
+/*
+ * default_update -> phys_body_rotate_xform (model.c:1680-1687, physics.c:136-145): entity rotation
+ * (x,y,z,w floats) -> body quaternion (w,x,y,z doubles), normalised as ODE's dBodySetQuaternion
+ * does (dNormalize4: scale by 1 / sqrt(sum of squares)) -- PARITY UNPINNED (ODE).  dirty[e] =
+ * transform_is_updated; entities with a parent take parent_transform_apply's branch and do not push.
+ */
+void clapo_bodies_rotate_from_entities(uint32_t n_links, const uint32_t *link_body, const uint32_t *link_entity,
+                                       const float *rot, const int32_t *parent, const uint8_t *dirty, double *quat)
+{
+    for (uint32_t k = 0; k < n_links; k++) {
+        const uint32_t b = link_body[k], e = link_entity[k];
+        if (parent[e] >= 0 || !dirty[e]) continue;
+        const float *r = rot + 4 * (size_t)e;
+        double q[4] = { r[3], r[0], r[1], r[2] };
+        const double l = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int a = 0; a < 4; a++) quat[4 * (size_t)b + a] = q[a] * l;
+    }
+}

@@ -220,3 +220,32 @@ def test_sphere_contacts_empty_and_truncated(cuda_device):
     world.contacts()
     got, total = world.download_contacts(ob.CONTACT_DTYPE)
     assert len(got) == 0 and total == 0
+
+
+def test_entity_rotation_pushed_to_linked_bodies(cuda_device):
+    """default_update -> phys_body_rotate_xform for characters / static colliders (model.c:1680-1687)."""
+    from clap_amd import _lib, entities, physics
+    n = 300
+    scene = synth.pad_levels(synth.entities_chains(120, 3, seed=6))
+    scene["flags"] = scene["flags"].copy()
+    roots = np.flatnonzero(scene["parent"] < 0)
+    child = np.flatnonzero(scene["parent"] >= 0)[:20]
+    scene["flags"][roots[::3]] &= ~np.uint32(_lib.E_DIRTY)               # a third of the roots did not move
+    b = synth.sphere_bodies(n, box=10.0, seed=6)
+    link_entity = np.concatenate([roots[:100], child]).astype(np.uint32)
+    link_body = np.arange(len(link_entity), dtype=np.uint32) * 2
+    batch = entities.EntityBatch(scene, cuda_device)
+    world = physics.PhysWorld(b, None, device=cuda_device)
+    dirty = ((scene["flags"] & _lib.E_DIRTY) != 0).astype(np.uint8)
+    for all_dirty in (False, True):
+        exp = b["quat"].copy()
+        ob.bodies_rotate_from_entities(link_body, link_entity, scene["rot"], scene["parent"],
+                                       np.ones_like(dirty) if all_dirty else dirty, exp)
+        world.quat.copy_(__import__("torch").from_numpy(b["quat"]))
+        world.rotate_from_entities(batch, link_body, link_entity, all_dirty=all_dirty)
+        got = world.download()["quat"]
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+        changed = (got != b["quat"]).any(axis=1)
+        assert changed[link_body[:100]].sum() == (66 if not all_dirty else 100)
+        assert not changed[link_body[100:]].any(), "attached entities take the parent branch: no push"
+        assert np.allclose(np.linalg.norm(got[changed], axis=1), 1.0, atol=1e-15)
