@@ -1,0 +1,60 @@
+"""One display frame of the batched path, in the reference's order.
+
+``clap_frame()`` (core/clap.c:551-665) runs: ``phys_step`` (clap.c:604) -> ``scene_update`` ->
+``mq_update`` with every entity's update hook in list order -- ``character_update`` (character.c:583)
+in front of ``default_update`` (model.c:1649: body read-back, TRS rebuild, light hand-off, rotation
+push to colliders, ``animated_update``), ``particles_update`` (particle.c:89) -> camera / light grid
+-> render passes (frustum test, LOD pick per drawn entity; the vertex shader skins).  ``FrameLoop``
+issues the same work as a fixed sequence of launches on one stream; nothing is read back unless asked.
+"""
+import numpy as np
+import torch
+
+from . import entities as ent_mod
+
+
+class FrameLoop:
+    def __init__(self, batch, cam, world=None, feed=None, body_links=None, lights=None, characters=None,
+                 particles=None, contacts=False):
+        """batch: EntityBatch.  world: PhysWorld (dynamic bodies write their entities through
+        body_entity; character bodies have body_entity = -1).  feed: CharacterFeed.  body_links:
+        (link_body, link_entity) of characters / static colliders whose rotation follows the entity.
+        lights: LightSet (with carriers).  characters: CharacterBatch (pose + skin).  particles:
+        ParticleBatch."""
+        self.batch, self.world, self.feed, self.lights = batch, world, feed, lights
+        self.characters, self.particles = characters, particles
+        self.body_links, self.contacts = body_links, contacts
+        self.set_camera(cam)
+
+    def set_camera(self, cam):
+        self.cam = cam
+        self.frustum, self.view_mx, self.proj_mx = ent_mod.view_calc_frustum(cam)
+
+    def clap_frame(self, now, dt):
+        b, w = self.batch, self.world
+        if w is not None:                                   # phys_step: per fixed substep broadphase, contacts, integrate
+            steps = w.phys_step_begin(dt)
+            for _ in range(steps):
+                w.broadphase()
+                if self.contacts:
+                    w.contacts()
+                w.world_step(1.0 / 120.0)
+        if self.feed is not None:                           # character_update hooks
+            self.feed.character_update(b, w)
+        if w is not None:                                   # default_update: phys_body_update of dynamic bodies
+            w.phys_body_update(b)
+            if self.body_links is not None:                 # ... phys_body_rotate_xform for the rebuilt ones
+                w.rotate_from_entities(b, *self.body_links)
+        if self.lights is not None:                         # ... light_set_pos of light carriers
+            self.lights.from_entities(b)
+        b.mq_update(self.frustum)                           # TRS -> mx -> inverse -> AABB (+ main-view cull)
+        if self.characters is not None:                     # ... animated_update: clock, pose, palette
+            self.characters.animated_update(now)
+            if self.characters._skin_desc is not None:
+                self.characters.skin()                      # the vertex shader's skinning loop, once per frame
+        if self.particles is not None:                      # particles_update hooks
+            self.particles.particles_update(self.view_mx)
+        if self.lights is not None:                         # scene_update: light_grid_compute
+            self.lights.grid_compute(self.view_mx, self.proj_mx)
+        b.compact_visible()                                 # render pass: visible list + LOD pick
+        b.select_lod(self.cam["cam_pos"])

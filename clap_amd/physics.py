@@ -102,6 +102,10 @@ class PhysWorld:
         _lib.check(_lib.lib().clapgpu_bodies_step(_stream(), C.byref(self._desc), C.byref(self.world), h),
                    "clapgpu_bodies_step")
 
+    def phys_step_begin(self, dt):
+        """The schedule half of phys_step (physics.c:773-787): number of fixed substeps for this frame."""
+        return _lib.lib().clapgpu_phys_step_schedule(C.byref(self.time_acc), dt)
+
     def phys_step(self, dt, broadphase=True):
         """phys_step(phys, dt): returns the number of fixed substeps taken."""
         steps = _lib.lib().clapgpu_phys_step_schedule(C.byref(self.time_acc), dt)
