@@ -160,7 +160,58 @@ def extras(device):
     tw, th = gl.grid_dims(3840, 2160, gl.TILE_WIDTH)
     out["light_grid"] = {"tiles_per_s": tw * th / t_lg, "tiles": tw * th, "lights": 128, "us": t_lg * 1e6,
                          "kernel": "k_light_grid", "note": "launch-bound: 2040 tiles x 128 lights, 32 KB out"}
+    del ls
+    torch.cuda.empty_cache()
+    out["full_frame"] = full_frame(device)
     return out
+
+
+def full_frame(device):
+    """One clap_frame() of everything at BASELINE sizes at once (clap_amd.frame.FrameLoop): configs[1]'s 1M-entity
+    hierarchy, configs[2]'s 50k characters (feeder, clock, pose, 10M skinned vertices), configs[3]'s 256k bodies
+    (broadphase x2, contacts, integrate, read-back into 75k entities) and 4M particles, 128 lights."""
+    import torch
+    from clap_amd import animation, characters, entities, frame, lights, particles, physics, synth, tiler
+    from oracle import binding as ob          # cpu side only: bind matrices and the initial particle spawn
+    raw = synth.entities_chains(125_000, 8, seed=2)
+    scene, tl = tiler.tiled_scene(raw)
+    roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
+    batch = entities.EntityBatch(scene, device)
+    cam = synth.camera()
+    n_bodies, n_bound, n_chars, J, vpc = 262_144, 75_000, 50_000, 64, 200
+    b = synth.sphere_bodies(n_bodies, box=64.0, seed=4)
+    b["body_entity"] = np.concatenate([roots[:n_bound], np.full(n_bodies - n_bound, -1)]).astype(np.int32)
+    world = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=device)
+    feed = synth.character_feed(n_chars, seed=13, with_bodies=False)
+    feed["entity"] = roots[n_bound:n_bound + n_chars].astype(np.uint32)
+    cf = characters.CharacterFeed(feed, device)
+    ls = lights.LightSet(device, 3840, 2160, lights.TILE_WIDTH)
+    ls.load(synth.lights(128, seed=7))
+    ls.set_carriers(roots[-64:].astype(np.uint32), np.arange(64, dtype=np.int32), np.zeros((64, 3), np.float32))
+    sk = synth.skeleton(J, 8, seed=3)
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n_chars, J, seed=3)
+    mesh = synth.skinned_mesh(vpc, J, seed=3, copies=n_chars)
+    vf = (np.arange(n_chars, dtype=np.int64) * vpc).astype(np.uint32)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, device=device)
+    cb = animation.CharacterBatch(model, n_chars, ch["trs0"], batch.mx, entity_index=feed["entity"], vert_first=vf,
+                                  vert_count=np.full(n_chars, vpc, np.uint32))
+    cb.start_clock(ani_time=-ch["phase"].astype(np.float64), speed=np.ones(n_chars, np.float32))
+    ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
+    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pb = particles.ParticleBatch(ps, pos, vel, st, device)
+    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True)
+    now = [0.0]
+
+    def one():
+        now[0] += 1.0 / 120.0
+        loop.clap_frame(now[0], 1.0 / 120.0)                 # one physics substep per frame
+    t = time_launches(one, 20)
+    return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t,
+            "contents": "1M entities (depth 8) + 50k characters x 64 joints + 10M skinned vertices + 262144 bodies "
+                        "(75k bound to entities; 2 broadphase passes, contacts, integrate) + 4M particles + 128 lights "
+                        "on a 4K light grid; one physics substep per frame",
+            "launches": "one stream, no host read-back inside the frame"}
 
 
 def pmc_traffic():
