@@ -42,6 +42,9 @@ def parse():
                     help="tiles: subtree tiles, one launch for all levels; levels: level-major, one launch per level")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary workloads (pose/skinning, particles, bodies) reported under 'extra'")
+    ap.add_argument("--particles", type=int, default=0,
+                    help="also update this many particles per GPU (whole 1024-particle systems) inside every step: "
+                         "BASELINE configs[4] is --gpus 8 --chains 250000 --particles 262144")
     ap.add_argument("--snapshot", default=None,
                     help="run the entity step on a scene snapshot (include/clapgpu_snapshot.h; components "
                          "'entities' and optionally 'camera') instead of the synthetic BASELINE workload")
@@ -260,6 +263,15 @@ def main():
     batch = entities.EntityBatch(scene, device)
     n_real, n_pad = batch.n_real, batch.n
     index_base = rank * n_pad
+    pbatch = None
+    if args.particles > 0:                                   # particle systems shard by whole system (own RNG stream per rank)
+        from clap_amd import particles as particles_mod
+        from oracle import binding as ob_spawn                # cpu side only: the initial spawn
+        n_sys = max(1, args.particles // 1024)
+        ps = synth.particle_systems(n_sys=n_sys, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT,
+                                    seed=40 + rank)
+        ppos, pvel, pstate = ob_spawn.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE + rank)
+        pbatch = particles_mod.ParticleBatch(ps, ppos, pvel, pstate, device)
 
     # ---- N > 1: the path's only exchange.  Each rank's compacted visible set travels as its
     # 1-bit-per-entity mask (one fixed-size RCCL allgather, no counts, no host sync); every rank
@@ -294,6 +306,8 @@ def main():
     frame = [0]
 
     def step():
+        if pbatch is not None:
+            pbatch.particles_update(_view)
         if not use_dist:
             batch.mq_update(fr, all_dirty=True)         # one launch for all hierarchy levels (tiles)
             batch.compact_visible(index_base)           # ordered visible list
@@ -374,6 +388,7 @@ def main():
                                          f"{args.depth}, ") + f"{args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
                                    f"list ({visible} visible" + (" in the gathered global set)" if use_dist else ")"),
                        "entities_per_gpu": n_real, "levels": n_levels,
+                       "particles_per_gpu": (pbatch.n_real if pbatch is not None else 0),
                        "exchange": (("ncclAllGather (direct)" if direct is not None else "torch.distributed all_gather")
                                     + " of the visibility mask + local expansion to global ids, overlapped with "
                                     "the next frame's update") if use_dist else "none"},

@@ -66,6 +66,17 @@ __device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4],
     }
 }
 
+// Streaming store: the big per-frame outputs (mx, inverse_mx, aabb, palettes) are written once and
+// read by a later kernel or the host, never by the writer.  Marked non-temporal they do not push the
+// inputs out of the 256 MB infinity cache: neutral at 1 M entities (everything fits), 112 -> 78 us at
+// 2 M entities, where the outputs alone are 330 MB.
+typedef float clapgpu_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
+{
+    const clapgpu_f4 t = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(t, reinterpret_cast<clapgpu_f4 *>(dst));
+}
+
 // dst = first matrix of the wave's 64; nvalid = leading lanes whose matrix is stored
 __device__ __forceinline__ void store_mat4_rows(float *dst, const float4 (&v)[4], int lane, int nvalid)
 {
@@ -73,14 +84,7 @@ __device__ __forceinline__ void store_mat4_rows(float *dst, const float4 (&v)[4]
     if (nvalid == WAVE) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-#ifdef CLAPGPU_NT_STORES
-            __builtin_nontemporal_store(v[k].x, &out[k * WAVE + lane].x);
-            __builtin_nontemporal_store(v[k].y, &out[k * WAVE + lane].y);
-            __builtin_nontemporal_store(v[k].z, &out[k * WAVE + lane].z);
-            __builtin_nontemporal_store(v[k].w, &out[k * WAVE + lane].w);
-#else
-            out[k * WAVE + lane] = v[k];
-#endif
+            store_stream(&out[k * WAVE + lane], v[k]);
         }
     } else {
 #pragma unroll
@@ -111,7 +115,7 @@ __device__ __forceinline__ void store_rows(const float *tile, float *dst, int la
         if (q < CHUNKS) {
             const int f0 = 4 * q;
             if (f0 + 4 <= limit) {
-                reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(tile)[q];
+                store_stream(&reinterpret_cast<float4 *>(dst)[q], reinterpret_cast<const float4 *>(tile)[q]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)

@@ -114,8 +114,13 @@ void k_skin(SkinArgs a)
             tn[0] += mx * wi; tn[1] += my * wi; tn[2] += mz * wi;
         }
         const size_t o = (size_t)ofirst + k;
-        a.out_position[3 * o] = tp[0]; a.out_position[3 * o + 1] = tp[1]; a.out_position[3 * o + 2] = tp[2];
-        a.out_normal[3 * o] = tn[0];   a.out_normal[3 * o + 1] = tn[1];   a.out_normal[3 * o + 2] = tn[2];
+        // written once, read by the draw path: streaming stores keep them out of the infinity cache
+        __builtin_nontemporal_store(tp[0], &a.out_position[3 * o]);
+        __builtin_nontemporal_store(tp[1], &a.out_position[3 * o + 1]);
+        __builtin_nontemporal_store(tp[2], &a.out_position[3 * o + 2]);
+        __builtin_nontemporal_store(tn[0], &a.out_normal[3 * o]);
+        __builtin_nontemporal_store(tn[1], &a.out_normal[3 * o + 1]);
+        __builtin_nontemporal_store(tn[2], &a.out_normal[3 * o + 2]);
 #if SKIN_PREFETCH
         cur = nxt;
         k = knext;
