@@ -290,10 +290,12 @@ def skeleton(nr_joints=64, max_depth=8, seed=3, unreachable=0):
     depth = np.zeros(J, np.int64)
     n_main = J - unreachable
     for j in range(1, n_main):
-        while True:
+        for _try in range(64):
             p = int(rng.integers(max(0, (j - 1) // 2 - 2), j))
             if depth[p] + 1 < max_depth:
                 break
+        else:                                            # the window only holds leaves at the depth limit
+            p = int(np.flatnonzero(depth[:j] + 1 < max_depth)[-1])
         parent[j], depth[j] = p, depth[p] + 1
     for j in range(n_main, J):
         parent[j] = -1 if j == n_main else j - 1
