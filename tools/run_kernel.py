@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run ONE of the secondary kernels a few times (for rocprofv3 --pmc / --kernel-trace).
 
-    python tools/run_kernel.py pose|skin|particles|bodies|broadphase|lights [iters]
+    python tools/run_kernel.py pose|skin|particles|bodies|broadphase|contacts|lights [iters]
 """
 import os
 import sys
@@ -49,7 +49,8 @@ def main():
     else:
         b = synth.sphere_bodies(262_144, box=64.0, seed=4)
         pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=dev)
-        fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.broadphase
+        pw.broadphase()
+        fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.contacts if which == "contacts" else pw.broadphase
     for _ in range(iters):
         fn()
     torch.cuda.synchronize()
