@@ -79,7 +79,7 @@ def cpu_baseline(scene, cam, frames):
                        "restatement (gcc -O2 -ffp-contract=off), 1 thread")
 
 
-def time_launches(fn, iters, warmup=3):
+def time_launches(fn, iters, warmup=10):
     """Mean duration (s) of fn() measured with HIP events on torch's current stream."""
     import torch
     for _ in range(warmup):
@@ -209,7 +209,7 @@ def full_frame(device):
     def one():
         now[0] += 1.0 / 120.0
         loop.clap_frame(now[0], 1.0 / 120.0)                 # one physics substep per frame
-    t = time_launches(one, 20)
+    t = time_launches(one, 40, warmup=40)                   # the first frames of a process run several times slower
     return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t,
             "contents": "1M entities (depth 8) + 50k characters x 64 joints + 10M skinned vertices + 262144 bodies "
                         "(75k bound to entities; 2 broadphase passes, contacts, integrate) + 4M particles + 128 lights "

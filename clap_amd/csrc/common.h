@@ -78,13 +78,15 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 }
 
 // dst = first matrix of the wave's 64; nvalid = leading lanes whose matrix is stored
+template <bool STREAM = true>
 __device__ __forceinline__ void store_mat4_rows(float *dst, const float4 (&v)[4], int lane, int nvalid)
 {
     float4 *out = reinterpret_cast<float4 *>(dst);
     if (nvalid == WAVE) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            store_stream(&out[k * WAVE + lane], v[k]);
+            if (STREAM) store_stream(&out[k * WAVE + lane], v[k]);
+            else out[k * WAVE + lane] = v[k];
         }
     } else {
 #pragma unroll

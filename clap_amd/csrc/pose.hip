@@ -121,6 +121,9 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
 }
 
+#ifndef POSE_STREAM_PALETTE
+#define POSE_STREAM_PALETTE 0
+#endif
 #ifndef POSE_DIRECT_STORES
 #define POSE_DIRECT_STORES 0
 #endif
@@ -331,7 +334,9 @@ void k_pose(PoseArgs a)
                 stage_mat4(tile, JT, lane);
                 wave_lds_fence();
                 unstage_mat4(tile, v, lane);
-                store_mat4_rows(a.joint_transforms + 16 * row0, v, lane, nvalid);
+                // the palette is what the skinning pass reads next: a plain store leaves it in the infinity
+                // cache (205 MB at 50 k characters), unlike T/R/S, which nothing on the device reads back
+                store_mat4_rows<POSE_STREAM_PALETTE>(a.joint_transforms + 16 * row0, v, lane, nvalid);
                 if (lane < nvalid)
                     reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
                 wave_lds_fence();

@@ -19,6 +19,10 @@ def main():
     from clap_amd import _lib, animation, particles, physics, synth
     _lib.check(_lib.lib().clapgpu_init(0), "init")
     dev = "cuda:0"
+    if which == "frame":                                        # one clap_frame() of everything, 23 times
+        import bench
+        print(bench.full_frame(dev)["ms_per_frame"], "ms per frame")
+        return
     if which in ("pose", "skin"):
         J, n_chars, vpc = 64, 50_000, 200
         sk = synth.skeleton(J, 8, seed=3)
