@@ -38,11 +38,19 @@ struct SkinVert {
 
 __device__ __forceinline__ SkinVert load_vert(const SkinArgs &a, size_t v)
 {
+    // vertex attributes are read once per frame: non-temporal loads keep them from evicting the
+    // palette (and everything else that is reused) from the infinity cache
     SkinVert r;
-    r.px = a.position[3 * v]; r.py = a.position[3 * v + 1]; r.pz = a.position[3 * v + 2];
-    r.nx = a.normal[3 * v];   r.ny = a.normal[3 * v + 1];   r.nz = a.normal[3 * v + 2];
-    r.jj = a.joints[v];
-    r.w = a.weights[v];
+    r.px = __builtin_nontemporal_load(&a.position[3 * v]);
+    r.py = __builtin_nontemporal_load(&a.position[3 * v + 1]);
+    r.pz = __builtin_nontemporal_load(&a.position[3 * v + 2]);
+    r.nx = __builtin_nontemporal_load(&a.normal[3 * v]);
+    r.ny = __builtin_nontemporal_load(&a.normal[3 * v + 1]);
+    r.nz = __builtin_nontemporal_load(&a.normal[3 * v + 2]);
+    r.jj = __builtin_nontemporal_load(&a.joints[v]);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 w = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(&a.weights[v]));
+    r.w = make_float4(w.x, w.y, w.z, w.w);
     return r;
 }
 
