@@ -317,9 +317,7 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
 // One launch for the whole forest: wave t walks tile t = rows [tile_row_start[t], tile_row_start[t+1]),
 // row r = entities [64r, 64r+64) = one hierarchy level of the subtrees packed into the tile.
 // The next row's inputs are in flight while the current row is computed.
-#ifndef ENT_TILE_WAVES
-#define ENT_TILE_WAVES 1
-#endif
+constexpr int ENT_TILE_WAVES = 1;       // occupancy hint; 4 measured the same 44 us
 template <bool CULL>
 __global__ __launch_bounds__(ENT_BLOCK, ENT_TILE_WAVES)
 void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,

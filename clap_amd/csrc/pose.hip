@@ -121,15 +121,7 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
 }
 
-#ifndef POSE_STREAM_PALETTE
-#define POSE_STREAM_PALETTE 0
-#endif
-#ifndef POSE_DIRECT_STORES
-#define POSE_DIRECT_STORES 0
-#endif
-#ifndef POSE_WAVES
-#define POSE_WAVES 4
-#endif
+constexpr int POSE_WAVES = 4;           // 128 VGPRs, 40 KiB LDS per block: four blocks per CU
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144;     // key times kept in LDS when the model's pool fits (24 KiB)
 
@@ -329,14 +321,14 @@ void k_pose(PoseArgs a)
 
             const uint64_t reach_mask = __ballot(joint_ok && reachable);
             const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
-            if (reach_mask == full && !POSE_DIRECT_STORES) {
+            if (reach_mask == full) {
                 float4 v[4];
                 stage_mat4(tile, JT, lane);
                 wave_lds_fence();
                 unstage_mat4(tile, v, lane);
                 // the palette is what the skinning pass reads next: a plain store leaves it in the infinity
                 // cache (205 MB at 50 k characters), unlike T/R/S, which nothing on the device reads back
-                store_mat4_rows<POSE_STREAM_PALETTE>(a.joint_transforms + 16 * row0, v, lane, nvalid);
+                store_mat4_rows<false>(a.joint_transforms + 16 * row0, v, lane, nvalid);
                 if (lane < nvalid)
                     reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
                 wave_lds_fence();

@@ -54,12 +54,7 @@ __device__ __forceinline__ SkinVert load_vert(const SkinArgs &a, size_t v)
     return r;
 }
 
-#ifndef SKIN_WAVES
-#define SKIN_WAVES 8
-#endif
-#ifndef SKIN_PREFETCH
-#define SKIN_PREFETCH 0
-#endif
+constexpr int SKIN_WAVES = 8;           // 56 VGPRs: eight workgroups per CU keep the vertex stream in flight
 __global__ __launch_bounds__(SKIN_BLOCK, SKIN_WAVES)
 void k_skin(SkinArgs a)
 {
@@ -69,43 +64,22 @@ void k_skin(SkinArgs a)
     const uint32_t J = a.J;
     const uint32_t vfirst = a.vert_first[c], vcount = a.vert_count[c], ofirst = a.out_first[c];
 
-    // this lane's first vertex is requested BEFORE the palette is staged, so the two HBM round
-    // trips of a block overlap instead of adding up (a block is one palette + ~one vertex pass)
-#if SKIN_PREFETCH
-    uint32_t k = threadIdx.x;
-    SkinVert cur;
-    if (k < vcount)
-        cur = load_vert(a, (size_t)vfirst + k);
-#endif
-
     // stage the palette: J * 4 float4, coalesced
     const float4 *src = a.joint_transforms + (size_t)c * J * 4;
     for (uint32_t q = threadIdx.x; q < J * 4; q += SKIN_BLOCK) {
         const float4 v = src[q];
         *reinterpret_cast<float4 *>(pal + (q >> 2) * PAL_PITCH + (q & 3) * 4) = v;
     }
-#if !SKIN_PREFETCH
     uint32_t k = threadIdx.x;
     SkinVert cur;
     if (k < vcount)
-        cur = load_vert(a, (size_t)vfirst + k);                   // in flight across the barrier
-#endif
+        cur = load_vert(a, (size_t)vfirst + k);                   // in flight across the barrier, beside the palette loads
     __syncthreads();
 
     while (k < vcount) {
-#if SKIN_PREFETCH
-        const uint32_t knext = k + SKIN_BLOCK;
-        SkinVert nxt;
-        if (knext < vcount)
-            nxt = load_vert(a, (size_t)vfirst + knext);           // in flight during the blend below
-#endif
         const float w[4] = { cur.w.x, cur.w.y, cur.w.z, cur.w.w };
         float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 };
-#if SKIN_PREFETCH
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
         for (int i = 0; i < 4; i++) {
             const uint32_t ji = (cur.jj >> (8 * i)) & 0xffu;
             const float4 *m = reinterpret_cast<const float4 *>(pal + ji * PAL_PITCH);
@@ -129,14 +103,9 @@ void k_skin(SkinArgs a)
         __builtin_nontemporal_store(tn[0], &a.out_normal[3 * o]);
         __builtin_nontemporal_store(tn[1], &a.out_normal[3 * o + 1]);
         __builtin_nontemporal_store(tn[2], &a.out_normal[3 * o + 2]);
-#if SKIN_PREFETCH
-        cur = nxt;
-        k = knext;
-#else
         k += SKIN_BLOCK;
         if (k < vcount)
             cur = load_vert(a, (size_t)vfirst + k);
-#endif
     }
 }
 
