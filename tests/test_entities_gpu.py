@@ -287,3 +287,48 @@ def test_cull_kernel_exact_on_adversarial_boxes(cuda_device):
         assert np.array_equal(out["vis_mask"], mask), camkw
         assert np.array_equal(out["visible"], vis), camkw
         assert 0 < vis.size < n
+
+
+@pytest.mark.parametrize("layout", ["levels", "tiles"])
+def test_special_values_in_the_transforms(layout, cuda_device):
+    """NaN / infinite / zero / denormal / huge positions, quaternions and scales, also on parents whose
+    subtrees inherit them: every finite result bit-exact, NaNs where the CPU path has NaNs, and the same
+    visible set (all comparisons with NaN are false on both sides)."""
+    from clap_amd import entities, tiler
+    base = synth.entities_chains(600, 4, seed=31)
+    n = base["n"]
+    rng = np.random.Generator(np.random.PCG64(31))
+    ps, rot = base["pos_scale"].copy(), base["rot"].copy()
+    specials = np.asarray([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -1e-42, 3e38, -3e38, 1e-20, 1e20], np.float32)
+    victims = rng.choice(n, 400, replace=False)
+    for k, e in enumerate(victims):
+        v = specials[k % len(specials)]
+        which = k % 3
+        if which == 0:
+            ps[e, rng.integers(0, 3)] = v                   # position component
+        elif which == 1:
+            ps[e, 3] = v                                    # scale (0 -> singular matrix -> inverse divides by 0)
+        else:
+            rot[e, rng.integers(0, 4)] = v                  # quaternion component
+    base["pos_scale"], base["rot"] = ps, rot
+    scene = synth.pad_levels(base) if layout == "levels" else tiler.tiled_scene(base)[0]
+    cam = synth.camera(pos=(0, 0, 30))
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    out = batch.download()
+    st = ob.entity_state(scene)
+    st["flags"] |= np.uint32(synth.E_DIRTY)
+    ob.entities_update(scene, st)
+    ofr, _ov, _op = ob.frustum_from_camera(cam)
+    vis, _mask = ob.entities_cull(scene["n"], st["flags"], st["aabb"], ofr)
+    real = scene["flags"] != 0
+    for key in ("mx", "inv_mx", "aabb", "center"):
+        a, b = out[key][real], st[key][real]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{key}: NaNs in the same places"
+        fin = ~np.isnan(b)
+        assert np.array_equal(a[fin].view(np.uint32), b[fin].view(np.uint32)), f"{key}: finite values and infinities bit-exact"
+    assert np.isnan(st["mx"][real]).any() and np.isinf(st["inv_mx"][real]).any() or np.isnan(st["inv_mx"][real]).any()
+    assert np.array_equal(out["visible"], vis), "visible set"
+    assert 0 < len(vis) < real.sum()

@@ -97,3 +97,37 @@ def test_cull_edge_cases():
     vis, mask = ob.entities_cull(n, flags, aabb, fr)
     assert vis.tolist() == [5, 129]
     assert int(mask[0]) == 1 << 5 and int(mask[2]) == 1 << 1
+
+
+@pytest.mark.skipif(not refrun.available(), reason="reference build (oracle/_ref) not present")
+def test_oracle_matches_live_reference_on_special_values():
+    """NaN / infinite / zero / denormal / huge transforms, inherited down the hierarchy: the restatement
+    follows the reference through its non-finite arithmetic too (NaN payloads aside)."""
+    base = synth.entities_chains(300, 4, seed=31)
+    n = base["n"]
+    rng = np.random.Generator(np.random.PCG64(31))
+    ps, rot = base["pos_scale"].copy(), base["rot"].copy()
+    specials = np.asarray([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -1e-42, 3e38, -3e38, 1e-20, 1e20], np.float32)
+    for k, e in enumerate(rng.choice(n, 300, replace=False)):
+        v = specials[k % len(specials)]
+        if k % 3 == 0:
+            ps[e, rng.integers(0, 3)] = v
+        elif k % 3 == 1:
+            ps[e, 3] = v
+        else:
+            rot[e, rng.integers(0, 4)] = v
+    base["pos_scale"], base["rot"] = ps, rot
+    scene = synth.pad_levels(base)
+    cam = synth.camera(pos=(0, 0, 30))
+    ref = refrun.entities(scene, cam)
+    fr, _view, _proj = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    ob.entities_update(scene, st)
+    vis, _mask = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr)
+    for key, r in (("mx", ref["mx"][0]), ("inv_mx", ref["inv_mx"][0]), ("aabb", ref["aabb"][0]), ("center", ref["center"][0])):
+        a = st[key]
+        assert np.array_equal(np.isnan(a), np.isnan(r)), key
+        fin = ~np.isnan(r)
+        assert np.array_equal(a[fin].view(np.uint32), r[fin].view(np.uint32)), key
+    assert np.array_equal(vis, np.flatnonzero(ref["visible"][0]))
+    assert np.isnan(ref["mx"][0]).any() and np.isinf(ref["inv_mx"][0]).any()
