@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "clap_amd", "lib")
 SCENE_SO = os.path.join(LIBDIR, "libclapgpu_scene.so")
 TEST_BIN = os.path.join(ROOT, "tests", "c", "_build", "test_scene")
+ABI_BIN = os.path.join(ROOT, "tests", "c", "_build", "test_abi")
 
 
 def build_c_test():
@@ -26,6 +27,19 @@ def build_c_test():
     subprocess.run(["gcc", "-O1", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
                     os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "c", "test_scene.c"), "-o", TEST_BIN,
                     "-L", LIBDIR, "-lclapgpu_scene", "-lclapgpu", "-L", odir, "-lclap_oracle", "-lm",
+                    f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{odir}"], check=True)
+
+
+def build_abi_test():
+    from clap_amd import _lib
+    from oracle import binding
+    _lib.lib()
+    binding.lib()
+    os.makedirs(os.path.dirname(ABI_BIN), exist_ok=True)
+    odir = os.path.join(ROOT, "oracle", "_build")
+    subprocess.run(["gcc", "-O1", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "c", "test_abi.c"), "-o", ABI_BIN,
+                    "-L", LIBDIR, "-lclapgpu", "-L", odir, "-lclap_oracle", "-lm",
                     f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{odir}"], check=True)
 
 
@@ -46,11 +60,24 @@ def test_c_program_links_against_the_host_mirror():
     assert os.access(TEST_BIN, os.X_OK)
 
 
+def test_c_caller_of_the_flat_abi_builds():
+    build_abi_test()
+    assert os.access(ABI_BIN, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_c_caller_of_the_flat_abi_matches_oracle(cuda_device):
+    """particles, bodies + broadphase + contacts + read-back, light grid: driven from plain C."""
+    build_abi_test()                                        # always from the current sources (a second's work)
+    r = subprocess.run([ABI_BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS" in r.stdout and all(k in r.stdout for k in ("particles ok", "bodies ok", "light grid ok"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["tiles", "wide"])
 def test_scene_mirror_frames_match_oracle(mode, cuda_device):
-    if not os.path.exists(TEST_BIN):
-        build_c_test()
+    build_c_test()
     r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout and r.stdout.count("frame ok") == 5
