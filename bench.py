@@ -50,7 +50,7 @@ def parse():
                          "'entities' and optionally 'camera') instead of the synthetic BASELINE workload")
     ap.add_argument("--exchange", choices=["rccl", "c10d"], default="rccl",
                     help="N > 1: call ncclAllGather directly (low host overhead) or through torch.distributed")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
 
