@@ -458,24 +458,15 @@ void k_bp_emit(BpK k)
 // bodies x static geoms (dSpaceCollide2(ground, bodies)): the statics are streamed through LDS tiles,
 // every body tests all of them; pairs (body, static) ascending.  The search pass keeps the first
 // BP_LIST hits of a body (already ascending) for the emit pass, which only re-tests the few bodies
-// with more.
+// with more (k_bp_static_emit).
 constexpr int STATIC_TILE = 256;
-template <bool EMIT>
 __global__ __launch_bounds__(PHYS_BLOCK)
-void k_bp_static(uint32_t n, const double *pos, const double *radius, uint32_t n_static, const double *static_aabb,
-                 uint32_t *pair_count, uint32_t *partners, uint32_t *pairs, uint32_t capacity)
+void k_bp_static_search(uint32_t n, const double *pos, const double *radius, uint32_t n_static, const double *static_aabb,
+                        uint32_t *pair_count, uint32_t *partners)
 {
     __shared__ double tile[STATIC_TILE * 6];
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
-    bool live = i < n;
-    uint32_t start = 0;
-    if (EMIT) {
-        // only bodies whose hits did not fit the list come back here (the block still streams the tiles together)
-        const uint32_t cnt = live ? pair_count[i + 1] - pair_count[i] : 0;
-        start = live ? pair_count[i] : 0;
-        live = cnt > BP_LIST;
-        if (!__syncthreads_or(live)) return;
-    }
+    const bool live = i < n;
     double bb[6] = { 0, 0, 0, 0, 0, 0 };
     if (live) {
         const double r = radius[i];
@@ -494,29 +485,48 @@ void k_bp_static(uint32_t n, const double *pos, const double *radius, uint32_t n
                 const double *sb = tile + 6 * s;
                 if (bb[0] > sb[1] || bb[1] < sb[0] || bb[2] > sb[3] || bb[3] < sb[2] || bb[4] > sb[5] || bb[5] < sb[4])
                     continue;
-                if (EMIT) {
-                    const uint32_t o = start + cnt;
-                    if (o < capacity) { pairs[2 * (size_t)o] = i; pairs[2 * (size_t)o + 1] = base + s; }
-                } else if (cnt < BP_LIST) {
+                if (cnt < BP_LIST)
                     partners[(size_t)i * BP_LIST + cnt] = base + s;
-                }
                 cnt++;
             }
     }
-    if (!EMIT && live)
+    if (live)
         pair_count[i] = cnt;
+    if (i == 0) {                                                   // the scan's end marker and its ticket
+        pair_count[n] = 0;
+        pair_count[n + 1] = 0;
+    }
 }
 
-// 16 lanes per body copy its listed partners to pairs[] at pair_start[i]
+// Emit pass of the statics: 16 lanes per body copy its listed hits to pairs[] at pair_start[i]; a body
+// with more hits than the list holds is re-tested by one lane against every static box (ascending).
 __global__ __launch_bounds__(PHYS_BLOCK)
-void k_bp_copy_lists(uint32_t n, const uint32_t *pair_start, const uint32_t *partners, uint32_t *pairs, uint32_t capacity)
+void k_bp_static_emit(uint32_t n, const double *pos, const double *radius, uint32_t n_static, const double *static_aabb,
+                      const uint32_t *pair_start, const uint32_t *partners, uint32_t *pairs, uint32_t capacity)
 {
     const uint32_t t = blockIdx.x * PHYS_BLOCK + threadIdx.x;
     const uint32_t i = t / BP_LIST, q = t % BP_LIST;
     if (i >= n) return;
     const uint32_t start = pair_start[i], cnt = pair_start[i + 1] - start;
-    if (cnt <= BP_LIST && q < cnt && start + q < capacity)
-        reinterpret_cast<uint2 *>(pairs)[start + q] = make_uint2(i, partners[(size_t)i * BP_LIST + q]);
+    uint2 *out = reinterpret_cast<uint2 *>(pairs);
+    if (cnt <= BP_LIST) {
+        if (q < cnt && start + q < capacity)
+            out[start + q] = make_uint2(i, partners[(size_t)i * BP_LIST + q]);
+        return;
+    }
+    if (q != 0) return;
+    const double r = radius[i];
+    double bb[6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bb[2 * a] = pos[3 * (size_t)i + a] - r; bb[2 * a + 1] = pos[3 * (size_t)i + a] + r; }
+    uint32_t w = 0;
+    for (uint32_t s = 0; s < n_static; s++) {
+        const double *sb = static_aabb + 6 * (size_t)s;
+        if (bb[0] > sb[1] || bb[1] < sb[0] || bb[2] > sb[3] || bb[3] < sb[2] || bb[4] > sb[5] || bb[5] < sb[4])
+            continue;
+        if (start + w < capacity) out[start + w] = make_uint2(i, s);
+        w++;
+    }
 }
 
 // phys_body_rotate_xform (physics.c:136-145) for the linked entities that default_update rebuilt
@@ -796,19 +806,15 @@ extern "C" int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodie
     const uint32_t n = b->n;
     BpScratch sc = carve(scratch, n);
     const dim3 grid((n + PHYS_BLOCK - 1) / PHYS_BLOCK), block(PHYS_BLOCK);
-    CLAPGPU_HIP(hipMemsetAsync(sc.pcount + n, 0, 2 * sizeof(uint32_t), s));     // [n] = 0 and the scan's ticket
-    hipLaunchKernelGGL(k_bp_static<false>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
-                       sc.pcount, sc.partners, pairs, capacity);
-    CLAPGPU_LAUNCH_CHECK("k_bp_static<search>");
+    hipLaunchKernelGGL(k_bp_static_search, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
+                       sc.pcount, sc.partners);
+    CLAPGPU_LAUNCH_CHECK("k_bp_static_search");
     rc = exclusive_scan_u32(s, sc.pcount, sc.pcount, n + 1, pair_total, sc.scan, sc.pcount + n + 1);   // starts; [n] = total
     if (rc) return rc;
     const uint64_t copy_threads = (uint64_t)n * BP_LIST;
-    hipLaunchKernelGGL(k_bp_copy_lists, dim3((uint32_t)((copy_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s,
-                       n, sc.pcount, sc.partners, pairs, capacity);
-    CLAPGPU_LAUNCH_CHECK("k_bp_copy_lists");
-    hipLaunchKernelGGL(k_bp_static<true>, grid, block, 0, s, n, b->pos, b->radius, n_static, static_aabb,
-                       sc.pcount, sc.partners, pairs, capacity);
-    CLAPGPU_LAUNCH_CHECK("k_bp_static<emit>");
+    hipLaunchKernelGGL(k_bp_static_emit, dim3((uint32_t)((copy_threads + PHYS_BLOCK - 1) / PHYS_BLOCK)), block, 0, s,
+                       n, b->pos, b->radius, n_static, static_aabb, sc.pcount, sc.partners, pairs, capacity);
+    CLAPGPU_LAUNCH_CHECK("k_bp_static_emit");
     return CLAPGPU_OK;
 }
 
