@@ -67,6 +67,15 @@ void k_particles_advect(PartK k, Mat4Arg view)
     if (i == 0)
         k.rng_state[0] = k.rng_state[1];                  // last frame's respawn pass has finished
 
+    // position and velocity are requested first: they do not depend on the system record, whose two
+    // dependent scalar loads would otherwise sit in front of them
+    float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    if (i < k.n) {
+        const float *p = k.pos + 3 * (size_t)i, *v = k.vel + 3 * (size_t)i;
+        px = p[0]; py = p[1]; pz = p[2];
+        vx = v[0]; vy = v[1]; vz = v[2];
+    }
+
     // one system per 64-particle row: wave-uniform -> scalar loads
     const uint32_t s = __builtin_amdgcn_readfirstlane(k.row_sys[row]);
     const clapgpu_particle_system &ps = k.sys[s];
@@ -78,8 +87,6 @@ void k_particles_advect(PartK k, Mat4Arg view)
     bool respawn = false;
     if (live) {
         float *p = k.pos + 3 * (size_t)i;
-        const float *v = k.vel + 3 * (size_t)i;
-        const float px = p[0], py = p[1], pz = p[2];
         const float dx = px - cx, dy = py - cy, dz = pz - cz;       // particle.c:109
         float dd = 0.f;
         dd += dx * dx;
@@ -87,9 +94,9 @@ void k_particles_advect(PartK k, Mat4Arg view)
         dd += dz * dz;
         respawn = (double)dd > r2;                                   // particle.c:110
         if (!respawn) {
-            p[0] = px + v[0];                                        // particle.c:115-116
-            p[1] = py + v[1];
-            p[2] = pz + v[2];
+            p[0] = px + vx;                                          // particle.c:115-116
+            p[1] = py + vy;
+            p[2] = pz + vz;
         }
     }
     const uint64_t m = __ballot(respawn);
