@@ -210,7 +210,18 @@ def full_frame(device):
         now[0] += 1.0 / 120.0
         loop.clap_frame(now[0], 1.0 / 120.0)                 # one physics substep per frame
     t = time_launches(one, 40, warmup=40)                   # the first frames of a process run several times slower
-    return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t,
+    graph_ms = None
+    try:                                                     # the same frame as one captured HIP graph
+        loop.capture(1.0 / 120.0, warmup_now=now[0] + 1.0 / 120.0)
+        now[0] += 1.0 / 120.0
+
+        def replay():
+            now[0] += 1.0 / 120.0
+            loop.clap_frame_replay(now[0])
+        graph_ms = time_launches(replay, 40, warmup=10) * 1e3
+    except Exception as exc:                                 # informational leg: never fail the benchmark on it
+        print(f"[bench] frame graph capture failed: {exc}", file=sys.stderr)
+    return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t, "ms_per_frame_graph_replay": graph_ms,
             "contents": "1M entities (depth 8) + 50k characters x 64 joints + 10M skinned vertices + 262144 bodies "
                         "(75k bound to entities; 2 broadphase passes, contacts, integrate) + 4M particles + 128 lights "
                         "on a 4K light grid; one physics substep per frame",

@@ -160,7 +160,10 @@ class CharacterBatch:
         only reads `ended` back when it has non-repeating entries or callbacks to serve."""
         if getattr(self, "_clock", None) is None:
             self.start_clock()
-        rc = _lib.lib().clapgpu_animation_time(_stream(), C.byref(self._clock), float(now))
+        if now is None:                                      # graph replay: the caller has written self.now_dev
+            rc = _lib.lib().clapgpu_animation_time_dev(_stream(), C.byref(self._clock), _ptr(self.now_dev))
+        else:
+            rc = _lib.lib().clapgpu_animation_time(_stream(), C.byref(self._clock), float(now))
         _lib.check(rc, "clapgpu_animation_time")
         self.pose_update()
 
@@ -177,6 +180,7 @@ class CharacterBatch:
         self.speed_dev = torch.from_numpy(np.ascontiguousarray(self.speed, np.float32)).to(dev)
         self.repeat_dev = torch.from_numpy(self.repeat_host).to(dev)
         self.ended = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+        self.now_dev = torch.zeros(1, dtype=torch.float64, device=dev)
         self.time_end_dev = torch.from_numpy(np.asarray(self.model.time_end, np.float32)).to(dev)
         self._clock = _lib.AnimClock(n, len(self.model.time_end), _ptr(self.anim), _ptr(self.time_end_dev),
                                      _ptr(self.ani_time_dev), _ptr(self.speed_dev), _ptr(self.repeat_dev),

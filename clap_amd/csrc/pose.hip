@@ -346,10 +346,11 @@ void k_pose(PoseArgs a)
 
 // animated_update's clock (model.c:1563-1592): one lane per character
 __global__ __launch_bounds__(256)
-void k_animation_time(clapgpu_anim_clock k, double now)
+void k_animation_time(clapgpu_anim_clock k, double now, const double *now_dev)
 {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= k.n_chars) return;
+    if (now_dev) now = *now_dev;
     const double ft = (now - k.ani_time[c]) * (double)k.speed[c];
     k.frame_time[c] = (float)ft;
     const uint32_t an = k.anim[c];
@@ -363,7 +364,21 @@ void k_animation_time(clapgpu_anim_clock k, double now)
 
 using namespace clapgpu;
 
+static int animation_time_launch(void *stream, const clapgpu_anim_clock *clk, double now, const double *now_dev);
+
 extern "C" int clapgpu_animation_time(void *stream, const clapgpu_anim_clock *clk, double now)
+{
+    return animation_time_launch(stream, clk, now, nullptr);
+}
+
+extern "C" int clapgpu_animation_time_dev(void *stream, const clapgpu_anim_clock *clk, const double *now_dev)
+{
+    if (!now_dev)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    return animation_time_launch(stream, clk, 0.0, now_dev);
+}
+
+static int animation_time_launch(void *stream, const clapgpu_anim_clock *clk, double now, const double *now_dev)
 {
     if (!clk)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
@@ -372,7 +387,8 @@ extern "C" int clapgpu_animation_time(void *stream, const clapgpu_anim_clock *cl
     if (!clk->anim || !clk->time_end || !clk->ani_time || !clk->speed || !clk->restart || !clk->frame_time ||
         !clk->ended)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    hipLaunchKernelGGL(k_animation_time, dim3((clk->n_chars + 255) / 256), dim3(256), 0, as_stream(stream), *clk, now);
+    hipLaunchKernelGGL(k_animation_time, dim3((clk->n_chars + 255) / 256), dim3(256), 0, as_stream(stream), *clk, now,
+                       now_dev);
     CLAPGPU_LAUNCH_CHECK("k_animation_time");
     return CLAPGPU_OK;
 }

@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 14u
+#define CLAPGPU_ABI_VERSION 15u
 
 namespace clapgpu {
 

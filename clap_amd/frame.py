@@ -30,10 +30,34 @@ class FrameLoop:
         self.cam = cam
         self.frustum, self.view_mx, self.proj_mx = ent_mod.view_calc_frustum(cam)
 
+    def capture(self, dt=1.0 / 120.0, warmup_now=0.0):
+        """Record one frame (with one physics substep, the current camera) as a HIP graph.  Afterwards
+        clap_frame_replay(now) costs one graph launch instead of ~35 kernel launches: what a
+        testbed-sized scene, whose frame is launch latency, needs.  Re-capture after a camera change
+        (the frustum and view matrices are kernel arguments)."""
+        self.clap_frame(warmup_now, dt)                      # everything allocated, lazily created state exists
+        torch.cuda.synchronize()
+        self._now_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+        self._graph = torch.cuda.CUDAGraph()
+        saved = (None if self.world is None else self.world.time_acc.value)
+        with torch.cuda.graph(self._graph):
+            self._issue(None, steps=1)
+        if self.world is not None:
+            self.world.time_acc.value = saved
+
+    def clap_frame_replay(self, now):
+        self._now_host[0] = float(now)
+        if self.characters is not None:
+            self.characters.now_dev.copy_(self._now_host, non_blocking=True)
+        self._graph.replay()
+
     def clap_frame(self, now, dt):
+        steps = self.world.phys_step_begin(dt) if self.world is not None else 0
+        self._issue(now, steps)
+
+    def _issue(self, now, steps):
         b, w = self.batch, self.world
         if w is not None:                                   # phys_step: per fixed substep broadphase, contacts, integrate
-            steps = w.phys_step_begin(dt)
             for _ in range(steps):
                 w.broadphase()
                 if self.contacts:

@@ -70,8 +70,12 @@ class PhysWorld:
     def rotate_from_entities(self, entity_batch, link_body, link_entity, all_dirty=False):
         """phys_body_rotate_xform for the (body, entity) links whose entity default_update is about to
         rebuild (model.c:1680-1687); run before entity_batch.mq_update."""
-        lb = torch.from_numpy(np.ascontiguousarray(link_body, np.uint32).view(np.int32)).to(self.device)
-        le = torch.from_numpy(np.ascontiguousarray(link_entity, np.uint32).view(np.int32)).to(self.device)
+        key = (id(link_body), id(link_entity))
+        if getattr(self, "_links_key", None) != key:         # uploaded once per link table (also keeps graph capture clean)
+            self._links_key = key
+            self._links = (torch.from_numpy(np.ascontiguousarray(link_body, np.uint32).view(np.int32)).to(self.device),
+                           torch.from_numpy(np.ascontiguousarray(link_entity, np.uint32).view(np.int32)).to(self.device))
+        lb, le = self._links
         rc = _lib.lib().clapgpu_bodies_rotate_from_entities(_stream(), C.byref(self._desc), C.byref(entity_batch._desc),
                                                             _lib.UPDATE_ALL_DIRTY if all_dirty else 0, len(link_body),
                                                             _ptr(lb), _ptr(le))

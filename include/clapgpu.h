@@ -384,6 +384,9 @@ typedef struct clapgpu_anim_clock {
     uint8_t        *ended;
 } clapgpu_anim_clock;
 int clapgpu_animation_time(void *stream, const clapgpu_anim_clock *clk, double now);
+/* The same with `now` read from device memory (one double): the launch then carries no per-frame value
+ * and can sit in a captured HIP graph; the caller writes *now_dev before replaying it. */
+int clapgpu_animation_time_dev(void *stream, const clapgpu_anim_clock *clk, const double *now_dev);
 
 /* Replaces channels_transform() + one_joint_transform(e, 0, -1) of animated_update()
  * (model.c:1582-1583) for every character of the batch. */

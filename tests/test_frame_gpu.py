@@ -142,3 +142,59 @@ def test_frames_match_oracle_sequence(cuda_device):
             st["flags"][idx] |= np.uint32(E_DIRTY)
             batch.set_transforms(idx, newp, o_scene["rot"][idx])
     assert world.download()["pair_total"] >= 0
+
+
+def test_captured_frame_graph_replays_the_same_frames(cuda_device):
+    """FrameLoop.capture(): one frame recorded as a HIP graph (device-resident clock) gives, replayed,
+    exactly what issuing the launches one by one gives."""
+    import torch
+    from clap_amd import animation, characters, entities, frame, lights, particles, physics, tiler
+
+    def build():
+        raw = synth.entities_flat(3000, seed=5)
+        scene, tl = tiler.tiled_scene(raw)
+        roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
+        scene["model_lod"] = np.asarray([[0, 3]], np.uint8)
+        batch = entities.EntityBatch(scene, cuda_device)
+        nb, nc, J, vpc = 200, 12, 24, 90
+        b = synth.sphere_bodies(nb, box=10.0, seed=5)
+        b["body_entity"] = roots[:nb].astype(np.int32)
+        world = physics.PhysWorld(b, synth.static_boxes(6, 10.0), pair_capacity=8192, device=cuda_device)
+        feed = synth.character_feed(nc, seed=5, with_bodies=False)
+        feed["entity"] = roots[nb:nb + nc].astype(np.uint32)
+        cf = characters.CharacterFeed(feed, cuda_device)
+        ls = lights.LightSet(cuda_device, 1280, 720, 64)
+        ls.load(synth.lights(12, seed=5))
+        ls.set_carriers(roots[-4:].astype(np.uint32), np.arange(4, dtype=np.int32), np.ones((4, 3), np.float32))
+        sk, an = synth.skeleton(J, 5, seed=5), synth.animation(J, 8, 0.05, seed=5)
+        ch = synth.characters(nc, J, seed=5)
+        model = animation.SkinnedModel(sk, [an], mesh=synth.skinned_mesh(vpc, J, seed=5), device=cuda_device)
+        cb = animation.CharacterBatch(model, nc, ch["trs0"], batch.mx, entity_index=feed["entity"],
+                                      vert_first=np.zeros(nc, np.uint32), vert_count=np.full(nc, vpc, np.uint32))
+        cb.start_clock(ani_time=np.zeros(nc), speed=np.ones(nc, np.float32))
+        ps = synth.particle_systems(n_sys=3, count=256, radius=2.0, velocity=0.5, seed=5)
+        ppos, pvel, pst = ob.particles_spawn(ps, 0x1234ABCD330E)
+        pb = particles.ParticleBatch(ps, ppos, pvel, pst, cuda_device)
+        loop = frame.FrameLoop(batch, synth.camera(pos=(0, 10, 60)), world=world, feed=cf, lights=ls, characters=cb,
+                               particles=pb, contacts=True)
+        return loop
+
+    def state(loop):
+        torch.cuda.synchronize()
+        e, c, p, w = loop.batch.download(), loop.characters.download(), loop.particles.download(), loop.world.download()
+        return dict(mx=e["mx"], visible=e["visible"], lod=loop.batch.draw_lod[:len(e["visible"])].cpu().numpy(),
+                    jt=c["joint_transforms"], skinned=c["out_position"], ani=loop.characters.download_clock()["ani_time"],
+                    ppos=p["pos"], rng=np.asarray([p["rng_state"]], np.uint64), bpos=w["pos"], pairs=w["pairs"],
+                    tiles=loop.lights.download_tiles())
+
+    eager, graph = build(), build()
+    dt = 1.0 / 120.0
+    eager.clap_frame(dt, dt)                                # frame 1 on both (capture() issues its warm-up frame eagerly)
+    graph.capture(dt, warmup_now=dt)
+    for f in range(2, 12):
+        eager.clap_frame(f * dt, dt)
+        graph.clap_frame_replay(f * dt)
+        a, b = state(eager), state(graph)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), f"frame {f}: {k}"
+    assert (state(graph)["ani"] != 0).any(), "the 0.05 s animation restarted during the replayed frames"

@@ -56,6 +56,20 @@ def main():
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / 200
     print(f"small frame: {t * 1e6:.1f} us on the device stream, {wall * 1e6:.1f} us wall per frame (host-side launches included)")
+    # the same frame as one captured HIP graph
+    loop.capture(1.0 / 120.0, warmup_now=now[0])
+
+    def replay():
+        now[0] += 1.0 / 120.0
+        loop.clap_frame_replay(now[0])
+    tg = bench.time_launches(replay, 200, warmup=100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        replay()
+    torch.cuda.synchronize()
+    wall_g = (time.perf_counter() - t0) / 200
+    print(f"small frame, graph replay: {tg * 1e6:.1f} us on the device stream, {wall_g * 1e6:.1f} us wall per frame")
 
 
 if __name__ == "__main__":
