@@ -166,7 +166,69 @@ def extras(device):
     del ls
     torch.cuda.empty_cache()
     out["full_frame"] = full_frame(device)
+    out["testbed_frame"] = testbed_frame(device)
     return out
+
+
+def testbed_frame(device):
+    """BASELINE configs[0] scale (the reference's own CPU-runnable case): 10k flat entities alone, and a whole
+    testbed-sized frame (10 characters, 128 bodies, 8 particle systems, 16 lights) issued launch by launch and
+    replayed as a captured HIP graph.  This regime is launch latency, not bytes."""
+    import torch
+    from clap_amd import animation, characters, entities, frame, lights, particles, physics, synth, tiler
+    from oracle import binding as ob          # cpu side only: the initial particle spawn
+    raw = synth.entities_flat(10_000, seed=1234)
+    scene, tl = tiler.tiled_scene(raw)
+    roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
+    batch = entities.EntityBatch(scene, device)
+    cam = synth.camera()
+    fr, _v, _p = entities.view_calc_frustum(cam)
+
+    def ent_step():
+        batch.mq_update(fr, all_dirty=True)
+        batch.compact_visible()
+    t_ent = time_launches(ent_step, 200, warmup=50)
+    n_bodies, n_chars, J, vpc = 128, 10, 64, 2000
+    b = synth.sphere_bodies(n_bodies, box=16.0, seed=4)
+    b["body_entity"] = roots[:n_bodies].astype(np.int32)
+    world = physics.PhysWorld(b, synth.static_boxes(16, 16.0), pair_capacity=4096, device=device)
+    feed = synth.character_feed(n_chars, seed=13, with_bodies=False)
+    feed["entity"] = roots[n_bodies:n_bodies + n_chars].astype(np.uint32)
+    cf = characters.CharacterFeed(feed, device)
+    ls = lights.LightSet(device, 1920, 1080, lights.TILE_WIDTH)
+    ls.load(synth.lights(16, seed=7))
+    ls.set_carriers(roots[-8:].astype(np.uint32), np.arange(8, dtype=np.int32), np.zeros((8, 3), np.float32))
+    sk, an = synth.skeleton(J, 8, seed=3), synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n_chars, J, seed=3)
+    model = animation.SkinnedModel(sk, [an], mesh=synth.skinned_mesh(vpc, J, seed=3), device=device)
+    cb = animation.CharacterBatch(model, n_chars, ch["trs0"], batch.mx, entity_index=feed["entity"],
+                                  vert_first=np.zeros(n_chars, np.uint32), vert_count=np.full(n_chars, vpc, np.uint32))
+    cb.start_clock(ani_time=-ch["phase"].astype(np.float64), speed=np.ones(n_chars, np.float32))
+    ps = synth.particle_systems(n_sys=8, count=1024, radius=10.0, velocity=0.005)
+    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pb = particles.ParticleBatch(ps, pos, vel, st, device)
+    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True)
+    now = [0.0]
+
+    def one():
+        now[0] += 1.0 / 120.0
+        loop.clap_frame(now[0], 1.0 / 120.0)
+    t_frame = time_launches(one, 100, warmup=50)
+    t_graph = None
+    try:
+        loop.capture(1.0 / 120.0, warmup_now=now[0] + 1.0 / 120.0)
+        now[0] += 1.0 / 120.0
+
+        def replay():
+            now[0] += 1.0 / 120.0
+            loop.clap_frame_replay(now[0])
+        t_graph = time_launches(replay, 100, warmup=20)
+    except Exception as exc:
+        print(f"[bench] testbed frame graph capture failed: {exc}", file=sys.stderr)
+    return {"entities": 10_000, "entity_step_us": t_ent * 1e6, "entity_updates_per_s": 10_000 / t_ent,
+            "frame_us": t_frame * 1e6, "frame_graph_replay_us": None if t_graph is None else t_graph * 1e6,
+            "contents": "10k flat entities + 10 characters x 64 joints / 20k skinned vertices + 128 bodies + 8k particles + "
+                        "16 lights; launch-latency bound (the reference's CPU path needs ~1.1 ms for the 10k entities alone)"}
 
 
 def full_frame(device):
