@@ -54,6 +54,25 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_all_cores(scene, cam, frames=8):
+    """Context for the 1-thread baseline: the port's same frame on every host core (OpenMP over tiles)."""
+    from oracle import binding as ob
+    if "tile_row_start" not in scene:
+        return None
+    fr, _v, _p = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    mask = np.zeros((int(scene["n"]) + 63) // 64, np.uint64)
+    t = []
+    for _ in range(frames + 1):
+        st["flags"] |= np.where(st["flags"] & 0x80000000, 1 << 16, 0).astype(np.uint32)
+        t0 = time.perf_counter()
+        ob.entities_frame_tiles_mt(scene, st, fr, mask)
+        t.append(time.perf_counter() - t0)
+    t = t[1:]                                                # first call spins up the thread pool
+    return dict(value=int(scene["n_real"]) / (sum(t) / len(t)), unit="entity updates/s", cores=os.cpu_count(),
+                kind="port", sample=f"{frames} frames, oracle/ C restatement, OpenMP over tiles on all host cores")
+
+
 def cpu_baseline(scene, cam, frames):
     """Reported baseline, not the target: the reference (or the port) on one host core."""
     from oracle import binding as ob, refrun
@@ -62,6 +81,7 @@ def cpu_baseline(scene, cam, frames):
     if refrun.available():
         r = refrun.bench_entities(scene, cam, reps=frames)
         return dict(value=n_real / r["mean_s"], unit="entity updates/s", cores=cores, kind="reference",
+                    all_cores=cpu_all_cores(scene, cam),
                     sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty): the reference's "
                            "default_update + view_entity_in_frustum (core/model.c, core/view.c; ROCm clang -O2 "
                            f"-ffp-contract=off), 1 thread; best frame {n_real / r['best_s']:.3e}/s")
@@ -75,6 +95,7 @@ def cpu_baseline(scene, cam, frames):
         ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr)
         t.append(time.perf_counter() - t0)
     return dict(value=n_real / (sum(t) / len(t)), unit="entity updates/s", cores=cores, kind="port",
+                all_cores=cpu_all_cores(scene, cam),
                 sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty), oracle/ C "
                        "restatement (gcc -O2 -ffp-contract=off), 1 thread")
 

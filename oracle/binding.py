@@ -116,6 +116,9 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_entities_frame_tiles_mt.argtypes = [C.c_uint32, U32P, C.c_uint32, F32P, F32P, I32P, I32P, F32P, U8P, U32P, U32P,
+                                                F32P, F32P, F32P, F32P, C.POINTER(Frustum), C.c_void_p]
+    L.clapo_entities_frame_tiles_mt.restype = C.c_uint32
     L.clapo_animation_time.argtypes = [C.c_uint32, C.c_uint32, U32P, F32P, F64P, F32P, U8P, C.c_double, F32P, U8P]
     L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
                                           C.c_void_p, C.c_void_p, C.c_void_p, U8P]
@@ -433,3 +436,13 @@ def bodies_rotate_from_entities(link_body, link_entity, rot, parent, dirty, quat
                                             np.ascontiguousarray(rot, np.float32).reshape(-1),
                                             np.ascontiguousarray(parent, np.int32),
                                             np.ascontiguousarray(dirty, np.uint8), quat.reshape(-1))
+
+
+def entities_frame_tiles_mt(scene, st, fr, vis_mask):
+    """update + cull of a tiled scene on all host cores (OpenMP); returns the visible count."""
+    return lib().clapo_entities_frame_tiles_mt(len(scene["tile_row_start"]) - 1,
+                                               np.ascontiguousarray(scene["tile_row_start"], np.uint32), int(scene["n"]),
+                                               scene["pos_scale"], scene["rot"], scene["parent"], scene["model"],
+                                               scene["model_aabb"], scene["model_skip"], st["flags"], st["seqs"],
+                                               st["mx"], st["inv_mx"], st["aabb"], st["center"], C.byref(fr),
+                                               vis_mask.ctypes.data)

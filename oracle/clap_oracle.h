@@ -216,6 +216,15 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t n, const double *pos, const double *radius,
                                        uint32_t *pairs, uint64_t max_pairs);
 
+/* the frame on all host cores (OpenMP over tiles / mask words): context for the 1-thread baseline */
+uint32_t clapo_entities_frame_tiles_mt(uint32_t n_tiles, const uint32_t *tile_row_start, uint32_t n,
+                                       const float *pos_scale, const float *rot,
+                                       const int32_t *parent, const int32_t *model,
+                                       const float *model_aabb, const uint8_t *model_skip_aabb,
+                                       uint32_t *flags, uint32_t *seqs,
+                                       float *mx, float *inv_mx, float *aabb, float *center,
+                                       const clapo_frustum *f, uint64_t *vis_mask);
+
 /* ---- animated_update's clock (model.c:1563-1592; pose.c) ---- */
 void clapo_animation_time(uint32_t n_chars, uint32_t n_anims, const uint32_t *anim, const float *time_end,
                           double *ani_time, const float *speed, const uint8_t *restart, double now,

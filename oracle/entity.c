@@ -272,3 +272,45 @@ uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aab
     }
     return count;
 }
+
+
+/*
+ * The same frame on all host cores, for context next to the single-threaded figure: the
+ * reference's frame loop is single-threaded, but whole subtrees are independent, so the tile layout
+ * (tile = contiguous range holding whole subtrees, parents first) parallelises over tiles, and the
+ * frustum test over 64-entity words.  OpenMP; same arithmetic as clapo_entities_update / _cull.
+ */
+uint32_t clapo_entities_frame_tiles_mt(uint32_t n_tiles, const uint32_t *tile_row_start, uint32_t n,
+                                       const float *pos_scale, const float *rot,
+                                       const int32_t *parent, const int32_t *model,
+                                       const float *model_aabb, const uint8_t *model_skip_aabb,
+                                       uint32_t *flags, uint32_t *seqs,
+                                       float *mx, float *inv_mx, float *aabb, float *center,
+                                       const clapo_frustum *f, uint64_t *vis_mask)
+{
+    const uint32_t n_rows = (n + 63) / 64;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t t = 0; t < n_tiles; t++) {
+        uint32_t r0 = tile_row_start[t], r1 = tile_row_start[t + 1];
+        if (r1 > n_rows) r1 = n_rows;
+        if (r0 >= r1) continue;
+        uint32_t first = r0 * 64, last = r1 * 64 < n ? r1 * 64 : n;
+        clapo_entities_update_range(first, last - first, pos_scale, rot, parent, model, model_aabb, model_skip_aabb,
+                                    flags, seqs, mx, inv_mx, aabb, center, 0, NULL, NULL, NULL);
+    }
+    uint32_t count = 0;
+#pragma omp parallel for schedule(static) reduction(+ : count)
+    for (uint32_t w = 0; w < n_rows; w++) {
+        uint64_t m = 0;
+        uint32_t end = (w + 1) * 64 < n ? (w + 1) * 64 : n;
+        for (uint32_t i = w * 64; i < end; i++) {
+            uint32_t fl = flags[i];
+            if (!(fl & CLAPO_E_ALIVE) || !(fl & CLAPO_E_VISIBLE)) continue;
+            if (!(fl & CLAPO_E_SKIP_CULLING) && !clapo_aabb_in_frustum(f, aabb + 6 * (size_t)i)) continue;
+            m |= 1ull << (i & 63);
+            count++;
+        }
+        vis_mask[w] = m;
+    }
+    return count;
+}
