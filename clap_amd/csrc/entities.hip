@@ -41,6 +41,7 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     float           bv_cam[3], bv_ctl[3];
     uint32_t        bv_has_ctl, bv_ctl_entity;
     unsigned long long *bv_result;
+    uint32_t        n, n_models;     // bounds of the two indices the caller supplies per entity
 };
 
 constexpr int ENT_BLOCK = 256;
@@ -72,6 +73,10 @@ __device__ __forceinline__ RowIn load_row(const EntK &e, const int lane, const u
     r.p = e.parent[i];
     r.sq = e.seqs[i];
     r.mi = e.model[i];
+    // a parent or model index outside the arrays would be a wild read: such an entity is treated as a
+    // root / as model 0 instead (the reference holds pointers here, which cannot be out of range)
+    if ((uint32_t)r.p >= e.n) r.p = -1;
+    if ((uint32_t)r.mi >= e.n_models) r.mi = 0;
     r.ps = e.pos_scale[i];
     r.q = e.rot[i];
     return r;
@@ -532,11 +537,13 @@ __device__ __forceinline__ float cbrtf_glibc(float x)
 __global__ __launch_bounds__(ENT_BLOCK)
 void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t index_base, float cx, float cy, float cz,
                     const float *aabb, const float *center, const float4 *pos_scale, const int32_t *model,
-                    const float4 *model_table, const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod)
+                    const float4 *model_table, const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod,
+                    uint32_t n, uint32_t n_models)
 {
-    const uint32_t total = *count;
+    const uint32_t total = *count < n ? *count : n;                       // a count beyond the batch would walk off the list
     for (uint32_t k = blockIdx.x * ENT_BLOCK + threadIdx.x; k < total; k += gridDim.x * ENT_BLOCK) {
         const uint32_t i = visible[k] - index_base;
+        if (i >= n) { draw_lod[k] = 0; continue; }                          // an id of another shard
         int32_t lod = cur_lod[i];
         const int32_t forced = force_lod ? force_lod[i] : -1;
         if (forced >= 0) {
@@ -551,7 +558,8 @@ void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t ind
                 dd += dx * dx;
                 dd += dy * dy;
                 dd += dz * dz;
-                const int32_t mi = model[i];
+                const int32_t mraw = model[i];
+                const int32_t mi = (uint32_t)mraw < n_models ? mraw : 0;
                 const float4 lo = model_table[2 * mi], hi = model_table[2 * mi + 1];
                 const float s = pos_scale[i].w;
                 const float X = fabsf(hi.x - lo.x) * s, Y = fabsf(hi.y - lo.y) * s, Z = fabsf(hi.z - lo.z) * s;
@@ -593,6 +601,8 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     k.attach_local = e->attach_local;
     k.jt_pool = e->jt_pool;
     k.bind_pool = e->bind_pool;
+    k.n = e->n;
+    k.n_models = e->n_models ? e->n_models : 1;
     k.bv_result = nullptr;
     k.bv_has_ctl = k.bv_ctl_entity = 0;
     for (int a = 0; a < 3; a++) k.bv_cam[a] = k.bv_ctl[a] = 0.f;
@@ -815,7 +825,8 @@ extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, con
     hipLaunchKernelGGL(k_entities_lod, dim3(blocks), dim3(ENT_BLOCK), 0, as_stream(stream), visible, count, index_base,
                        cam_pos[0], cam_pos[1], cam_pos[2], e->aabb, e->center,
                        reinterpret_cast<const float4 *>(e->pos_scale), e->model,
-                       reinterpret_cast<const float4 *>(e->model_table), force_lod, cur_lod, draw_lod);
+                       reinterpret_cast<const float4 *>(e->model_table), force_lod, cur_lod, draw_lod, e->n,
+                       e->n_models ? e->n_models : 1);
     CLAPGPU_LAUNCH_CHECK("k_entities_lod");
     return CLAPGPU_OK;
 }

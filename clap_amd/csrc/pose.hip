@@ -31,7 +31,7 @@ struct PoseArgs {
     // animations
     const uint4    *chan_table;     // [n_anims][J][3] = (time_off, data_off, nr, 0)
     const float    *times, *data;
-    uint32_t        n_times;
+    uint32_t        n_times, n_anims;
     // batch
     uint32_t        n_chars;
     const uint32_t *anim;
@@ -168,7 +168,8 @@ void k_pose(PoseArgs a)
         // ---- 1. channels_transform: this joint's T, R, S at the character's frame time ----
         float T[3] = { 0, 0, 0 }, R[4] = { 0, 0, 0, 1 }, S[3] = { 1, 1, 1 };
         if (joint_ok) {
-            const uint32_t an = a.anim[c];
+            uint32_t an = a.anim[c];
+            if (an >= a.n_anims) an = 0;                         // an id outside the table would be a wild read
             const float time = a.frame_time[c];
             const uint4 *tab = a.chan_table + ((size_t)an * J + j) * 3;
             const uint4 e0 = tab[0], e1 = tab[1], e2 = tab[2];   // (time_off, data_off, nr, -)
@@ -420,6 +421,7 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     a.chan_table = reinterpret_cast<const uint4 *>(an->chan_table);
     a.times = an->times;
     a.n_times = an->n_times;
+    a.n_anims = an->n_anims ? an->n_anims : 1;
     a.data = an->data;
     a.n_chars = pb->n_chars;
     a.anim = pb->anim;
