@@ -168,7 +168,7 @@ SYMBOLS = {
     "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),
     "clapgpu_world_defaults": (None, [C.POINTER(World)]),
     "clapgpu_bodies_step": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(World), C.c_double]),
-    "clapgpu_phys_body_update": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_void_p,
+    "clapgpu_phys_body_update": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
     "clapgpu_broadphase_scratch_bytes": (C.c_size_t, [C.c_uint32]),
     "clapgpu_broadphase_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_double, C.c_void_p, C.c_uint32,

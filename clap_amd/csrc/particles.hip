@@ -35,7 +35,7 @@ struct PartK {
     uint8_t  *respawn_row_pop;
     float    *billboard_mx;
     uint32_t *groups;             // respawn_groups (see include/clapgpu.h), or NULL
-    uint32_t  n;
+    uint32_t  n, n_sys;
 };
 
 // respawn_groups layout: [0] frames completed (written by the respawn pass), [1] this frame's copy of
@@ -77,7 +77,8 @@ void k_particles_advect(PartK k, Mat4Arg view)
     }
 
     // one system per 64-particle row: wave-uniform -> scalar loads
-    const uint32_t s = __builtin_amdgcn_readfirstlane(k.row_sys[row]);
+    uint32_t s = __builtin_amdgcn_readfirstlane(k.row_sys[row]);
+    if (s >= k.n_sys) s = 0;                              // a row that names no system would be a wild read
     const clapgpu_particle_system &ps = k.sys[s];
     const float cx = ps.center[0], cy = ps.center[1], cz = ps.center[2];
     const double r2 = ps.radius_squared;
@@ -323,6 +324,7 @@ extern "C" int clapgpu_particles_update(void *stream, const clapgpu_particles *p
     k.respawn_row_pop = p->respawn_row_pop;
     k.billboard_mx = p->billboard_mx;
     k.n = p->n;
+    k.n_sys = p->n_sys ? p->n_sys : 1;
     const bool row_path = p->n / WAVE <= (1u << 16) && (reinterpret_cast<uintptr_t>(p->respawn_row_pop) & 15u) == 0;
     k.groups = row_path ? p->respawn_groups : nullptr;
     Mat4Arg view;

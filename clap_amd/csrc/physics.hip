@@ -99,7 +99,7 @@ void k_bodies_step(uint32_t n, double h, WorldK w, double *pos, double *quat, do
 // phys_body_update (physics.c:789-812): scatter body pose into the entity SoA, mark it dirty
 __global__ __launch_bounds__(PHYS_BLOCK)
 void k_phys_body_update(uint32_t n, const double *pos, const double *quat, const double *lvel,
-                        const double *yoffset, const int32_t *body_entity,
+                        const double *yoffset, const int32_t *body_entity, uint32_t n_entities,
                         float *pos_scale, float *rot, uint32_t *entity_flags, uint8_t *moving)
 {
     const uint32_t i = blockIdx.x * PHYS_BLOCK + threadIdx.x;
@@ -107,7 +107,7 @@ void k_phys_body_update(uint32_t n, const double *pos, const double *quat, const
         return;
     const int32_t e = body_entity[i];
     const double *p = pos + 3 * (size_t)i, *q = quat + 4 * (size_t)i, *v = lvel + 3 * (size_t)i;
-    if (e >= 0) {
+    if (e >= 0 && (uint32_t)e < n_entities) {
         pos_scale[4 * (size_t)e + 0] = (float)p[0];
         pos_scale[4 * (size_t)e + 1] = (float)(p[1] - yoffset[i]);
         pos_scale[4 * (size_t)e + 2] = (float)p[2];
@@ -692,8 +692,8 @@ extern "C" int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const 
     return CLAPGPU_OK;
 }
 
-extern "C" int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, float *pos_scale, float *rot,
-                                        uint32_t *entity_flags, uint8_t *moving)
+extern "C" int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, uint32_t n_entities, float *pos_scale,
+                                        float *rot, uint32_t *entity_flags, uint8_t *moving)
 {
     int rc = check_bodies(b);
     if (rc) return rc;
@@ -701,8 +701,8 @@ extern "C" int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, f
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (b->n == 0) return CLAPGPU_OK;
     hipLaunchKernelGGL(k_phys_body_update, dim3((b->n + PHYS_BLOCK - 1) / PHYS_BLOCK), dim3(PHYS_BLOCK), 0,
-                       as_stream(stream), b->n, b->pos, b->quat, b->lvel, b->yoffset, b->body_entity, pos_scale,
-                       rot, entity_flags, moving);
+                       as_stream(stream), b->n, b->pos, b->quat, b->lvel, b->yoffset, b->body_entity, n_entities,
+                       pos_scale, rot, entity_flags, moving);
     CLAPGPU_LAUNCH_CHECK("k_phys_body_update");
     return CLAPGPU_OK;
 }

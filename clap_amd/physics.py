@@ -121,7 +121,8 @@ class PhysWorld:
 
     def phys_body_update(self, entity_batch, moving=None):
         """phys_body_update for every body: entity TRS <- body pose, entities marked dirty."""
-        _lib.check(_lib.lib().clapgpu_phys_body_update(_stream(), C.byref(self._desc), _ptr(entity_batch.pos_scale),
+        _lib.check(_lib.lib().clapgpu_phys_body_update(_stream(), C.byref(self._desc), entity_batch.n,
+                                                       _ptr(entity_batch.pos_scale),
                                                        _ptr(entity_batch.rot), _ptr(entity_batch.flags),
                                                        _ptr(moving)),
                    "clapgpu_phys_body_update")

@@ -479,11 +479,11 @@ int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const clapgpu_wor
 /*
  * phys_body_update() for every body (physics.c:789-812, 96-109): writes entity pos
  * (y - yoffset, double -> float) and rotation (wxyz -> xyzw) into the entity SoA
- * (clapgpu_entities.pos_scale / .rot), sets CLAPGPU_E_DIRTY, and moving[i] = |lvel| > 1e-3
- * (may be NULL).
+ * (clapgpu_entities.pos_scale / .rot, n_entities slots: a body_entity outside them writes nothing),
+ * sets CLAPGPU_E_DIRTY, and moving[i] = |lvel| > 1e-3 (may be NULL).
  */
-int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, float *pos_scale, float *rot,
-                             uint32_t *entity_flags, uint8_t *moving);
+int clapgpu_phys_body_update(void *stream, const clapgpu_bodies *b, uint32_t n_entities, float *pos_scale,
+                             float *rot, uint32_t *entity_flags, uint8_t *moving);
 
 /*
  * default_update's push of the entity rotation to the physics body of characters and static

@@ -157,7 +157,7 @@ static int test_bodies(void)
             CK(clapgpu_bodies_step(NULL, &gb, &gw, 1.0 / 120.0));
         }
         clapo_phys_body_update(N, pos, quat, lvel, yoff, body_entity, ps, rot, eflags, NULL);
-        CK(clapgpu_phys_body_update(NULL, &gb, d_ps, d_rot, d_eflags, NULL));
+        CK(clapgpu_phys_body_update(NULL, &gb, N, d_ps, d_rot, d_eflags, NULL));
         static double gpos[N * 3], gquat[N * 4];
         DOWN(gpos, gb.pos, N * 3); DOWN(gquat, gb.quat, N * 4); DOWN(gps, d_ps, N * 4); DOWN(grot, d_rot, N * 4); DOWN(geflags, d_eflags, N);
         CK(clapgpu_stream_sync(NULL));
