@@ -332,3 +332,32 @@ def test_special_values_in_the_transforms(layout, cuda_device):
     assert np.isnan(st["mx"][real]).any() and np.isinf(st["inv_mx"][real]).any() or np.isnan(st["inv_mx"][real]).any()
     assert np.array_equal(out["visible"], vis), "visible set"
     assert 0 < len(vis) < real.sum()
+
+
+def test_out_of_range_indices_from_the_host_are_harmless(cuda_device):
+    """A parent / model index outside the arrays (the reference holds pointers there) must not become a
+    wild device access: such an entity is updated as a root / with model 0, everything else is untouched."""
+    from clap_amd import entities
+    base = synth.entities_chains(200, 3, seed=3)
+    scene = synth.pad_levels(base)
+    n = scene["n"]
+    bad_parent = np.flatnonzero(scene["parent"] >= 0)[:5]
+    bad_model = np.flatnonzero(scene["flags"] != 0)[10:15]
+    broken = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    broken["parent"][bad_parent] = [n, n + 7, 2**31 - 1, 10**9, n * 3]
+    broken["model"][bad_model] = [1, 2, 99, 2**30, -5]
+    fixed = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    fixed["parent"][bad_parent] = -1                         # what the guards turn them into
+    fixed["model"][bad_model] = 0
+    cam = synth.camera()
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    batch = entities.EntityBatch(broken, cuda_device)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    batch.select_lod(cam["cam_pos"])
+    out = batch.download()
+    st = ob.entity_state(fixed)
+    st["flags"] |= np.uint32(synth.E_DIRTY)
+    ob.entities_update(fixed, st)
+    assert_bits_equal(out["mx"], st["mx"], "mx")
+    assert_bits_equal(out["aabb"], st["aabb"], "aabb")
