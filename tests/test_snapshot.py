@@ -86,6 +86,18 @@ def test_writer_and_reader_reject_bad_input(tmp_path):
     assert L.clapgpu_snapshot_open(C.byref(s), str(tmp_path / "missing.clps").encode()) != 0
 
 
+def test_c_reader_writer_under_sanitizers(tmp_path):
+    """tests/c/test_snapshot.c built with AddressSanitizer + UBSan (host code only): round trip from C,
+    and bit flips over the whole header and table must be refused or stay in bounds."""
+    exe = str(tmp_path / "test_snapshot_c")
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "test_snapshot.c"),
+                    os.path.join(ROOT, "clap_amd", "host", "clapgpu_snapshot.c"), "-o", exe], check=True)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS" in r.stdout
+
+
 def test_scene_components_round_trip(tmp_path):
     scene = synth.pad_levels(synth.entities_forest(300, seed=4))
     cam = synth.camera(pos=(1, 2, 3))
