@@ -1,0 +1,56 @@
+/*
+ * gpu-scene.h -- the CLAP-side binding of libclapgpu: the translation unit a CLAP maintainer adds
+ * to core/ (INTEGRATION.md section 2).  Unlike the rest of clap_amd/ it is written AGAINST THE
+ * ENGINE'S OWN HEADERS (model.h, view.h, scene.h) and works on the engine's own objects:
+ * `struct mq`, `model3dtx`, `entity3d`, `struct view`.  It needs the reference tree to compile
+ * (-I <clap>/core) and is therefore built only where that tree exists, by oracle/ref/Makefile,
+ * into the drop-in checker oracle/_ref/clap_dropin; libclapgpu_scene.so underneath has no such
+ * dependency.
+ *
+ * What it replaces:
+ *   mq_update(mq)                     model.h:342, model.c:1953   -> gpu_mq_update(gs, mq, view)
+ *   view_entity_in_frustum(view, e)   view.h:37,   view.c:296-337 -> gpu_view_entity_in_frustum(gs, view, e)
+ * Everything the draw path reads stays where it is: e->mx, e->inverse_mx, e->aabb, e->aabb_center,
+ * e->seq / e->parent_seq, xform.updated, scene->camera->bv / bv_volume are written exactly as
+ * default_update (model.c:1649-1723) writes them.
+ */
+#ifndef CLAP_GPU_SCENE_H
+#define CLAP_GPU_SCENE_H
+
+#include "model.h"
+#include "view.h"
+
+struct gpu_scene;
+
+struct gpu_scene_stats {
+    unsigned int batched;       /* entities whose update ran on the device this frame */
+    unsigned int host;          /* entities whose own hook ran on the host (foreign hook, animated, physics, light, joint-attached) */
+    unsigned int uploaded;      /* entities whose transform was pushed this frame */
+    unsigned int written_back;  /* entities whose mx / inverse_mx / aabb were rebuilt this frame */
+    unsigned int registered, deleted;
+    int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
+};
+
+/*
+ * `default_hook` is model.c's default_update (static there: the maintainer's patch passes it from
+ * mq_init or drops the `static`).  Entities with any other hook stay on the host.
+ * Returns a cerr_enum value (error.h:12-49): 0 or negative.
+ */
+int  gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entity3d *, void *));
+void gpu_scene_done(struct gpu_scene *gs);
+
+/*
+ * One mq_update(): on return every ALIVE entity of `mq` has been updated -- batched ones by the HIP
+ * kernel (results scattered back into the entity3d structs), the others by their own hook, both in
+ * the queue's list order.  `view` (may be NULL) is culled against in the same launch; its result
+ * serves gpu_view_entity_in_frustum() until the next call.  Synchronous, like the reference.
+ */
+int  gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view);
+
+/* view_entity_in_frustum(): bit lookup for batched entities tested against the view of the last
+ * gpu_mq_update(); the engine's own function for anything else. */
+bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e);
+
+const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
+
+#endif /* CLAP_GPU_SCENE_H */
