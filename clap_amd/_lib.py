@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 OK = 0
 ERR_NOMEM = -1
@@ -142,6 +142,8 @@ SYMBOLS = {
     "clapgpu_abi_version": (C.c_uint32, []),
     "clapgpu_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "clapgpu_free": (C.c_int, [C.c_void_p]),
+    "clapgpu_host_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "clapgpu_host_free": (C.c_int, [C.c_void_p]),
     "clapgpu_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clapgpu_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "clapgpu_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),

@@ -28,21 +28,29 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #include "gpu-scene.h"
 #include "scene.h"
 #include "clapgpu_scene.h"
 
+#define NO_REC 0xffffffffu
+
 struct gs_rec {
-    entity3d    *e;             /* key; NULL = empty bucket */
+    entity3d    *e;             /* key; NULL = free record */
     model3d     *model;
+    entity3d    *parent_e;      /* e->parent when parent_rec was resolved */
+    uint32_t    parent_rec;
+    uint32_t    next;           /* hash chain / free list */
     uint32_t    handle;         /* libclapgpu_scene handle, CLAPGPU_NO_ENTITY while on the host */
+    uint32_t    slot;           /* its row in the result arrays; refreshed when the layout is rebuilt */
     uint32_t    parent_handle;
     uint32_t    flags;
-    uint32_t    gen;
+    uint32_t    gen;            /* last frame this entity was met in the queue */
+    uint32_t    order_pos;      /* its position in that frame's walk */
     uint8_t     cls;            /* 0 unknown, 1 batched, 2 host */
     uint8_t     self_ok;
-    uint8_t     xform_dirty;    /* xform.updated as seen (and cleared) in step 3 */
+    uint8_t     xform_dirty;    /* xform.updated as seen in step 3 (cleared in step 5, like default_update) */
 };
 
 struct gs_model { model3d *model; uint32_t handle; };
@@ -50,10 +58,14 @@ struct gs_model { model3d *model; uint32_t handle; };
 struct gpu_scene {
     clapgpu_scene   *scene;
     int             (*default_hook)(entity3d *, void *);
-    struct gs_rec   *tab;   uint32_t tab_cap, tab_used;
-    entity3d        **order; uint32_t n_order, cap_order;     /* ALIVE entities in list order */
+    /* records: dense array + chained pointer hash.  A steady queue never hashes: the k-th entity of
+     * this walk is checked against the k-th record of the previous walk first. */
+    struct gs_rec   *rec;   uint32_t n_rec, cap_rec, free_rec, n_live;
+    uint32_t        *bucket; uint32_t n_bucket;
+    uint32_t        *order, *prev_order, *deferred; uint32_t n_order, n_prev, n_deferred, cap_order;
+    clapgpu_scene_arrays res;
     struct gs_model *models; uint32_t n_models, cap_models;
-    uint32_t        gen;
+    uint32_t        gen, vis_cursor;
     struct view     *culled_view;
     vec4            culled_planes[6];
     struct gpu_scene_stats stats;
@@ -66,52 +78,68 @@ static inline uint32_t ptr_hash(const void *p)
     return (uint32_t)x;
 }
 
-static struct gs_rec *tab_find(struct gpu_scene *gs, entity3d *e)
+static uint32_t rec_find(const struct gpu_scene *gs, const entity3d *e)
 {
-    if (!gs->tab_cap) return NULL;
-    for (uint32_t i = ptr_hash(e) & (gs->tab_cap - 1);; i = (i + 1) & (gs->tab_cap - 1)) {
-        if (!gs->tab[i].e) return NULL;
-        if (gs->tab[i].e == e) return &gs->tab[i];
-    }
+    if (!gs->n_bucket) return NO_REC;
+    for (uint32_t i = gs->bucket[ptr_hash(e) & (gs->n_bucket - 1)]; i != NO_REC; i = gs->rec[i].next)
+        if (gs->rec[i].e == e) return i;
+    return NO_REC;
 }
 
-static struct gs_rec *tab_insert_raw(struct gs_rec *tab, uint32_t cap, const struct gs_rec *r)
+static int rehash(struct gpu_scene *gs, uint32_t n_bucket)
 {
-    uint32_t i = ptr_hash(r->e) & (cap - 1);
-    while (tab[i].e) i = (i + 1) & (cap - 1);
-    tab[i] = *r;
-    return &tab[i];
-}
-
-/* Rebuild without the records of entities that are gone; also grows. */
-static int tab_rebuild(struct gpu_scene *gs, uint32_t min_live, bool drop_stale)
-{
-    uint32_t cap = 1024;
-    while (cap < 2 * min_live + 2) cap <<= 1;
-    struct gs_rec *nt = calloc(cap, sizeof(*nt));
-    if (!nt) return _CERR_NOMEM;
-    uint32_t used = 0;
-    for (uint32_t i = 0; i < gs->tab_cap; i++) {
-        struct gs_rec *r = &gs->tab[i];
-        if (!r->e || (drop_stale && r->gen != gs->gen)) continue;
-        tab_insert_raw(nt, cap, r);
-        used++;
+    uint32_t *nb = malloc((size_t)n_bucket * sizeof(*nb));
+    if (!nb) return _CERR_NOMEM;
+    memset(nb, 0xff, (size_t)n_bucket * sizeof(*nb));
+    for (uint32_t i = 0; i < gs->n_rec; i++) {
+        struct gs_rec *r = &gs->rec[i];
+        if (!r->e) continue;
+        uint32_t *b = &nb[ptr_hash(r->e) & (n_bucket - 1)];
+        r->next = *b;
+        *b = i;
     }
-    free(gs->tab);
-    gs->tab = nt; gs->tab_cap = cap; gs->tab_used = used;
+    free(gs->bucket);
+    gs->bucket = nb; gs->n_bucket = n_bucket;
     return 0;
 }
 
-static struct gs_rec *tab_get_or_add(struct gpu_scene *gs, entity3d *e, bool *is_new)
+static uint32_t rec_add(struct gpu_scene *gs, entity3d *e)
 {
-    struct gs_rec *r = tab_find(gs, e);
-    *is_new = !r;
-    if (r) return r;
-    if (2 * (gs->tab_used + 1) > gs->tab_cap && tab_rebuild(gs, gs->tab_used + 1, false))
-        return NULL;
-    struct gs_rec nr = { .e = e, .handle = CLAPGPU_NO_ENTITY, .parent_handle = CLAPGPU_NO_ENTITY };
-    gs->tab_used++;
-    return tab_insert_raw(gs->tab, gs->tab_cap, &nr);
+    uint32_t i;
+    if (gs->free_rec != NO_REC) {
+        i = gs->free_rec;
+        gs->free_rec = gs->rec[i].next;
+    } else {
+        if (gs->n_rec == gs->cap_rec) {
+            const uint32_t cap = gs->cap_rec ? 2 * gs->cap_rec : 4096;
+            struct gs_rec *nr = realloc(gs->rec, (size_t)cap * sizeof(*nr));
+            if (!nr) return NO_REC;
+            gs->rec = nr; gs->cap_rec = cap;
+        }
+        i = gs->n_rec++;
+    }
+    if (gs->n_live + 1 > gs->n_bucket) {
+        gs->rec[i].e = NULL;                                  /* not yet hashable */
+        if (rehash(gs, gs->n_bucket ? 2 * gs->n_bucket : 8192)) return NO_REC;
+    }
+    gs->rec[i] = (struct gs_rec){ .e = e, .parent_rec = NO_REC, .handle = CLAPGPU_NO_ENTITY, .slot = CLAPGPU_NO_ENTITY,
+                                  .parent_handle = CLAPGPU_NO_ENTITY };
+    uint32_t *b = &gs->bucket[ptr_hash(e) & (gs->n_bucket - 1)];
+    gs->rec[i].next = *b;
+    *b = i;
+    gs->n_live++;
+    return i;
+}
+
+static void rec_del(struct gpu_scene *gs, uint32_t i)
+{
+    uint32_t *link = &gs->bucket[ptr_hash(gs->rec[i].e) & (gs->n_bucket - 1)];
+    while (*link != i) link = &gs->rec[*link].next;
+    *link = gs->rec[i].next;
+    gs->rec[i].e = NULL;
+    gs->rec[i].next = gs->free_rec;
+    gs->free_rec = i;
+    gs->n_live--;
 }
 
 static int model_handle(struct gpu_scene *gs, model3d *m, uint32_t *out)
@@ -138,6 +166,7 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     int rc = clapgpu_scene_create(&gs->scene, device);
     if (rc) { free(gs); return rc; }
     gs->default_hook = default_hook;
+    gs->free_rec = NO_REC;
     *out = gs;
     return 0;
 }
@@ -146,7 +175,7 @@ void gpu_scene_done(struct gpu_scene *gs)
 {
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
-    free(gs->tab); free(gs->order); free(gs->models);
+    free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->deferred); free(gs->models);
     free(gs);
 }
 
@@ -162,14 +191,25 @@ static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
            e->parent_joint == JOINT_TYPE_MAX;
 }
 
+/* The record of r's parent, or NO_REC if the parent is not an ALIVE member of this queue. */
+static uint32_t parent_rec(struct gpu_scene *gs, struct gs_rec *r)
+{
+    entity3d *p = r->e->parent;
+    if (r->parent_e != p || (r->parent_rec != NO_REC && gs->rec[r->parent_rec].e != p)) {
+        r->parent_e = p;
+        r->parent_rec = rec_find(gs, p);
+    }
+    return (r->parent_rec != NO_REC && gs->rec[r->parent_rec].gen == gs->gen) ? r->parent_rec : NO_REC;
+}
+
 static uint8_t classify(struct gpu_scene *gs, struct gs_rec *r, int depth)
 {
     if (r->cls) return r->cls;
     if (!r->self_ok || depth > 64) return r->cls = 2;
     if (!r->e->parent) return r->cls = 1;
-    struct gs_rec *p = tab_find(gs, r->e->parent);
-    if (!p || p->gen != gs->gen) return r->cls = 2;      /* parent not alive in this queue */
-    return r->cls = classify(gs, p, depth + 1);
+    const uint32_t p = parent_rec(gs, r);
+    if (p == NO_REC) return r->cls = 2;                  /* parent not alive in this queue */
+    return r->cls = classify(gs, &gs->rec[p], depth + 1);
 }
 
 static int frustum_of(const struct view *view, clapgpu_frustum *fr)
@@ -195,7 +235,78 @@ static void bv_pick(struct scene *scene, entity3d *e)
     }
 }
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static inline void prefetch_entity(const entity3d *e)
+{
+    /* sizeof(entity3d) is seven cache lines and both passes touch most of them; the record array
+     * tells us which entity comes eight steps later without chasing the list */
+    const char *p = (const char *)e;
+    for (unsigned o = 0; o < sizeof(entity3d); o += 64)
+        __builtin_prefetch(p + o, 1, 1);
+}
+
+/* Step 3 for one batched entity: creation, flags, transform.  The parent link follows in link_parent(). */
+static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    entity3d *e = r->e;
+    model3d *model = e->txmodel->model;
+
+    if (r->handle != CLAPGPU_NO_ENTITY && r->model != model) {   /* same address, another entity */
+        CK(clapgpu_scene_entity_delete(gs->scene, r->handle));
+        r->handle = r->parent_handle = CLAPGPU_NO_ENTITY;
+        st->deleted++;
+    }
+    const bool fresh = r->handle == CLAPGPU_NO_ENTITY;
+    if (fresh) {
+        uint32_t mh;
+        CK(model_handle(gs, model, &mh));
+        CK(clapgpu_scene_entity_new(gs->scene, mh, e, &r->handle));
+        r->model = model;
+        r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;            /* what entity_new starts with */
+        st->registered++;
+    }
+    const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
+    if (flags != r->flags) {
+        CK(clapgpu_scene_entity_flags(gs->scene, r->handle, flags & ~r->flags, r->flags & ~flags));
+        r->flags = flags;
+    }
+    r->xform_dirty = transform_is_updated(&e->xform);
+    if (r->xform_dirty || fresh) {
+        CK(clapgpu_scene_entity_transform(gs->scene, r->handle, transform_pos(&e->xform, NULL),
+                                          transform_rotation_quat(&e->xform), e->scale));
+        st->uploaded++;
+    }
+    return 0;
+}
+
+static int link_parent(struct gpu_scene *gs, struct gs_rec *r)
+{
+    const uint32_t ph = r->e->parent ? gs->rec[parent_rec(gs, r)].handle : CLAPGPU_NO_ENTITY;
+    if (ph != r->parent_handle) {
+        CK(clapgpu_scene_entity_set_parent(gs->scene, r->handle, ph));
+        r->parent_handle = ph;
+    }
+    return 0;
+}
+
+static int unbatch(struct gpu_scene *gs, struct gs_rec *r)        /* left the batch (gained a body, a hook, ...) */
+{
+    if (r->handle != CLAPGPU_NO_ENTITY) {
+        CK(clapgpu_scene_entity_delete(gs->scene, r->handle));
+        r->handle = r->parent_handle = CLAPGPU_NO_ENTITY;
+        gs->stats.deleted++;
+    }
+    return 0;
+}
 
 int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
@@ -204,130 +315,154 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     struct scene *scene = mq->priv;
     memset(st, 0, sizeof(*st));
     gs->gen++;
-    gs->n_order = 0;
 
-    /* 1: list walk (order[] keeps the entities; the table may move while it grows) */
+    const double t0 = now_ms();
+    /*
+     * 1-3 in ONE walk of the queue (the entity structs are far larger than the caches, so every
+     * extra pass over them costs as much as the reference's whole update).  prev_order[] is last
+     * frame's walk: an unchanged queue is matched without hashing, and its entities are prefetched
+     * ahead of the list chase.  An entity whose parent comes later in the list (or is itself
+     * deferred) cannot be classified yet and goes to deferred[].
+     */
+    { uint32_t *t = gs->prev_order; gs->prev_order = gs->order; gs->order = t; }
+    gs->n_prev = gs->n_order;
+    gs->n_order = 0;
+    gs->n_deferred = 0;
+    uint32_t cursor = 0;
     model3dtx *txm;
     entity3d *e, *it;
     list_for_each_entry(txm, &mq->txmodels, entry) {
         list_for_each_entry_iter(e, it, &txm->entities, entry) {
             if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
-            bool is_new;
-            struct gs_rec *r = tab_get_or_add(gs, e, &is_new);
-            if (!r) return _CERR_NOMEM;
+            uint32_t i;
+            if (cursor < gs->n_prev && gs->rec[gs->prev_order[cursor]].e == e) {
+                i = gs->prev_order[cursor++];
+                if (cursor + 8 < gs->n_prev)
+                    prefetch_entity(gs->rec[gs->prev_order[cursor + 8]].e);
+            } else {
+                i = rec_find(gs, e);
+                if (i == NO_REC) {
+                    i = rec_add(gs, e);
+                    if (i == NO_REC) return _CERR_NOMEM;
+                } else if (gs->rec[i].gen + 1 == gs->gen) {
+                    cursor = gs->rec[i].order_pos + 1;            /* resynchronise after a deletion */
+                }
+            }
             if (gs->n_order == gs->cap_order) {
-                gs->cap_order = gs->cap_order ? 2 * gs->cap_order : 4096;
-                gs->order = realloc(gs->order, gs->cap_order * sizeof(*gs->order));
-                if (!gs->order) return _CERR_NOMEM;
+                const uint32_t cap = gs->cap_order ? 2 * gs->cap_order : 4096;
+                uint32_t *o = realloc(gs->order, (size_t)cap * sizeof(*o));
+                if (o) gs->order = o;
+                uint32_t *po = realloc(gs->prev_order, (size_t)cap * sizeof(*po));
+                if (po) gs->prev_order = po;
+                uint32_t *df = realloc(gs->deferred, (size_t)cap * sizeof(*df));
+                if (df) gs->deferred = df;
+                if (!o || !po || !df) return _CERR_NOMEM;
+                gs->cap_order = cap;
             }
+            struct gs_rec *r = &gs->rec[i];
             r->gen = gs->gen;
-            r->cls = 0;
+            r->order_pos = gs->n_order;
+            gs->order[gs->n_order++] = i;
             r->self_ok = self_batchable(gs, e);
-            gs->order[gs->n_order++] = e;
-        }
-    }
-
-    /* 2 + 3: classify, mirror */
-    for (uint32_t k = 0; k < gs->n_order; k++) {
-        e = gs->order[k];
-        struct gs_rec *r = tab_find(gs, e);
-        model3d *model = e->txmodel->model;
-
-        if (classify(gs, r, 0) != 1) {
-            if (r->handle != CLAPGPU_NO_ENTITY) {               /* left the batch (gained a body, a hook, ...) */
-                CK(clapgpu_scene_entity_delete(gs->scene, r->handle));
-                r->handle = r->parent_handle = CLAPGPU_NO_ENTITY;
-                st->deleted++;
+            if (!r->self_ok) {
+                r->cls = 2;
+            } else if (!e->parent) {
+                r->cls = 1;
+            } else {
+                const uint32_t p = parent_rec(gs, r);             /* NO_REC unless already met in THIS walk */
+                r->cls = p != NO_REC ? gs->rec[p].cls : 0;
             }
-            continue;
-        }
-        if (r->handle != CLAPGPU_NO_ENTITY && r->model != model) {   /* same address, another entity */
-            CK(clapgpu_scene_entity_delete(gs->scene, r->handle));
-            r->handle = r->parent_handle = CLAPGPU_NO_ENTITY;
-            st->deleted++;
-        }
-        const bool fresh = r->handle == CLAPGPU_NO_ENTITY;
-        if (fresh) {
-            uint32_t mh;
-            CK(model_handle(gs, model, &mh));
-            CK(clapgpu_scene_entity_new(gs->scene, mh, e, &r->handle));
-            r->model = model;
-            r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;        /* what entity_new starts with */
-            st->registered++;
-        }
-        const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
-        if (flags != r->flags) {
-            CK(clapgpu_scene_entity_flags(gs->scene, r->handle, flags & ~r->flags, r->flags & ~flags));
-            r->flags = flags;
-        }
-        r->xform_dirty = transform_is_updated(&e->xform);
-        if (r->xform_dirty || fresh) {
-            const float *q = transform_rotation_quat(&e->xform);
-            CK(clapgpu_scene_entity_position(gs->scene, r->handle, transform_pos(&e->xform, NULL)));
-            CK(clapgpu_scene_entity_rotation(gs->scene, r->handle, q));
-            CK(clapgpu_scene_entity_scale(gs->scene, r->handle, e->scale));
-            st->uploaded++;
+            if (r->cls == 1) {
+                CK(mirror_one(gs, r));
+                CK(link_parent(gs, r));
+            } else if (r->cls == 2) {
+                CK(unbatch(gs, r));
+            } else {
+                gs->deferred[gs->n_deferred++] = i;
+            }
         }
     }
-    /* parents after every batched entity has its handle */
-    for (uint32_t k = 0; k < gs->n_order; k++) {
-        e = gs->order[k];
-        struct gs_rec *r = tab_find(gs, e);
-        if (r->cls != 1) continue;
-        const uint32_t ph = e->parent ? tab_find(gs, e->parent)->handle : CLAPGPU_NO_ENTITY;
-        if (ph != r->parent_handle) {
-            CK(clapgpu_scene_entity_set_parent(gs->scene, r->handle, ph));
-            r->parent_handle = ph;
-        }
+    const double t1 = now_ms();
+    for (uint32_t k = 0; k < gs->n_deferred; k++) {
+        struct gs_rec *r = &gs->rec[gs->deferred[k]];
+        if (classify(gs, r, 0) == 1) CK(mirror_one(gs, r));
+        else CK(unbatch(gs, r));
     }
-    /* entities that left the queue (entity3d_delete, model.c:1787) */
-    if (gs->tab_used != gs->n_order) {
-        for (uint32_t i = 0; i < gs->tab_cap; i++) {
-            struct gs_rec *r = &gs->tab[i];
-            if (r->e && r->gen != gs->gen && r->handle != CLAPGPU_NO_ENTITY) {
+    for (uint32_t k = 0; k < gs->n_deferred; k++)               /* parents after every batched entity has its handle */
+        if (gs->rec[gs->deferred[k]].cls == 1)
+            CK(link_parent(gs, &gs->rec[gs->deferred[k]]));
+    /* entities that left the queue (entity3d_delete, model.c:1787): met last frame, not this one */
+    if (gs->n_live != gs->n_order) {
+        for (uint32_t k = 0; k < gs->n_prev; k++) {
+            const uint32_t i = gs->prev_order[k];
+            struct gs_rec *r = &gs->rec[i];
+            if (!r->e || r->gen == gs->gen) continue;
+            if (r->handle != CLAPGPU_NO_ENTITY) {
                 CK(clapgpu_scene_entity_delete(gs->scene, r->handle));
                 st->deleted++;
             }
+            rec_del(gs, i);
         }
-        CK(tab_rebuild(gs, gs->n_order, true));
     }
 
+    const double t2 = now_ms();
     /* 4: the device */
-    const uint32_t slots_before = clapgpu_scene_slot_count(gs->scene);
+    const uint32_t layout_before = clapgpu_scene_layout_generation(gs->scene);
     clapgpu_frustum fr;
     if (view) frustum_of(view, &fr);
     CK(clapgpu_scene_mq_update(gs->scene, view ? &fr : NULL));
-    st->retiled = st->registered || st->deleted || slots_before != clapgpu_scene_slot_count(gs->scene);
+    st->retiled = layout_before != clapgpu_scene_layout_generation(gs->scene);
     gs->culled_view = view;
+    gs->vis_cursor = 0;
     if (view) memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+    clapgpu_scene_arrays res = { 0 };
+    if (clapgpu_scene_results(gs->scene, &res))                  /* an empty batch has none */
+        memset(&res, 0, sizeof(res));
+    gs->res = res;
 
+    const double t3 = now_ms();
     /* 5: results and host hooks, list order */
     for (uint32_t k = 0; k < gs->n_order; k++) {
-        e = gs->order[k];
-        struct gs_rec *r = tab_find(gs, e);
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        e = r->e;
+        if (k + 8 < gs->n_order) {
+            /* the entity eight steps ahead, and its rows of the download (DMA left them out of the caches) */
+            const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
+            prefetch_entity(a->e);
+            if (a->cls == 1 && a->slot < res.n_slots && !st->retiled) {
+                __builtin_prefetch(res.mx + 16 * (size_t)a->slot, 0, 0);
+                __builtin_prefetch(res.inverse_mx + 16 * (size_t)a->slot, 0, 0);
+                __builtin_prefetch(res.aabb + 6 * (size_t)a->slot, 0, 0);
+                __builtin_prefetch(res.aabb_center + 3 * (size_t)a->slot, 0, 0);
+            }
+        }
         if (r->cls != 1) {
             entity3d_update(e, mq->priv);
             st->host++;
             continue;
         }
         st->batched++;
+        if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
+            r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
         entity3d *parent = e->parent;
         const bool rebuilt = parent ? (r->xform_dirty || e->parent_seq != parent->seq) : r->xform_dirty;
         if (rebuilt) {
+            const size_t slot = r->slot;
             if (parent) e->parent_seq = parent->seq;             /* model.c:1613 */
             if (r->xform_dirty) transform_clear_updated(&e->xform);
             e->seq++;                                            /* model.c:1616, 1669 */
-            memcpy(e->mx, clapgpu_scene_entity_mx(gs->scene, r->handle), sizeof(mat4x4));
-            memcpy(e->inverse_mx, clapgpu_scene_entity_inverse_mx(gs->scene, r->handle), sizeof(mat4x4));
+            memcpy(e->mx, res.mx + 16 * slot, sizeof(mat4x4));
+            memcpy(e->inverse_mx, res.inverse_mx + 16 * slot, sizeof(mat4x4));
             if (!r->model->skip_aabb) {                          /* entity3d_aabb_update, model.c:1204-1205 */
-                memcpy(e->aabb, clapgpu_scene_entity_aabb(gs->scene, r->handle), sizeof(e->aabb));
-                memcpy(e->aabb_center, clapgpu_scene_entity_aabb_center(gs->scene, r->handle), sizeof(vec3));
+                memcpy(e->aabb, res.aabb + 6 * slot, sizeof(e->aabb));
+                memcpy(e->aabb_center, res.aabb_center + 3 * slot, sizeof(vec3));
             }
             st->written_back++;
         }
         if (scene)
             bv_pick(scene, e);
     }
+    st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1; st->ms_device = t3 - t2; st->ms_scatter = now_ms() - t3;
     return 0;
 }
 
@@ -336,11 +471,18 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
     if (gs && view == gs->culled_view &&
         !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes)) &&
         (e->flags & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE)) {
-        const struct gs_rec *r = tab_find(gs, e);
+        /* _models_render asks in list order (model.c:958-973): try the next record of the walk first */
+        uint32_t i;
+        if (gs->vis_cursor < gs->n_order && gs->rec[gs->order[gs->vis_cursor]].e == e)
+            i = gs->order[gs->vis_cursor];
+        else
+            i = rec_find(gs, e);
+        const struct gs_rec *r = i != NO_REC ? &gs->rec[i] : NULL;
+        if (r) gs->vis_cursor = r->order_pos + 1 < gs->n_order ? r->order_pos + 1 : 0;
         /* the mask bit is the draw predicate ALIVE && VISIBLE && (SKIP_CULLING || in frustum):
          * for an alive, visible, culled entity it is the frustum test itself */
         if (r && r->gen == gs->gen && r->cls == 1 && r->flags == (e->flags & (ENTITY3D_ALIVE | 0xffffu)))
-            return clapgpu_scene_entity_in_frustum(gs->scene, r->handle);
+            return (gs->res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1;
     }
     return view_entity_in_frustum(view, e);
 }

@@ -29,6 +29,7 @@ struct gpu_scene_stats {
     unsigned int written_back;  /* entities whose mx / inverse_mx / aabb were rebuilt this frame */
     unsigned int registered, deleted;
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
+    double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
 };
 
 /*

@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 15u
+#define CLAPGPU_ABI_VERSION 16u
 
 namespace clapgpu {
 
@@ -71,6 +71,19 @@ extern "C" int clapgpu_malloc(void **dev, size_t bytes)
 extern "C" int clapgpu_free(void *dev)
 {
     CLAPGPU_HIP(hipFree(dev));
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_host_malloc(void **host, size_t bytes)
+{
+    if (!host) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CLAPGPU_HIP(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_host_free(void *host)
+{
+    CLAPGPU_HIP(hipHostFree(host));
     return CLAPGPU_OK;
 }
 

@@ -45,11 +45,18 @@ struct clapgpu_scene {
     uint64_t   *h_mask;
     uint32_t    cap_slots;
 
+    /* the arrays above that cross PCIe every frame are carved out of two page-locked slabs that
+     * mirror two device slabs: one copy up (pos_scale | rot | flags), one copy down
+     * (mx | inv_mx | aabb | center | vis_mask) */
+    void       *h_in, *h_out, *d_in, *d_out;
+    size_t      in_bytes, out_bytes;
+
     /* device */
     clapgpu_entities d;
     uint32_t   *d_tile_row_start;
     float      *d_models; uint32_t d_models_cap;
     int         have_results;
+    uint32_t    layout_gen;
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -85,12 +92,12 @@ int clapgpu_scene_create(clapgpu_scene **out, int device)
 
 static void free_device(clapgpu_scene *s)
 {
-    void *p[] = { (void *)s->d.pos_scale, (void *)s->d.rot, (void *)s->d.parent, (void *)s->d.model, s->d.flags,
-                  s->d.seqs, s->d.mx, s->d.inv_mx, s->d.aabb, s->d.center, s->d.vis_mask, s->d.vis_row_pop,
+    void *p[] = { s->d_in, s->d_out, (void *)s->d.parent, (void *)s->d.model, s->d.seqs, s->d.vis_row_pop,
                   s->d_tile_row_start };
     for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++)
         if (p[i]) clapgpu_free(p[i]);
     memset(&s->d, 0, sizeof(s->d));
+    s->d_in = s->d_out = NULL;
     s->d_tile_row_start = NULL;
 }
 
@@ -101,8 +108,9 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->d_models) clapgpu_free(s->d_models);
     free(s->e); free(s->free_list); free(s->dirty_list); free(s->models); free(s->slot_handle);
     free(s->tile_row_start_host); free(s->level_start_host);
-    free(s->h_pos_scale); free(s->h_rot); free(s->h_mx); free(s->h_inv); free(s->h_aabb); free(s->h_center);
-    free(s->h_parent); free(s->h_model); free(s->h_flags); free(s->h_mask);
+    if (s->h_in) clapgpu_host_free(s->h_in);
+    if (s->h_out) clapgpu_host_free(s->h_out);
+    free(s->h_parent); free(s->h_model);
     free(s);
 }
 
@@ -183,6 +191,17 @@ int clapgpu_scene_entity_position(clapgpu_scene *s, uint32_t handle, const float
     struct ent *e = get(s, handle);
     if (!e || !pos) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     memcpy(e->pos_scale, pos, 12);
+    mark_dirty(s, handle, 1);
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_transform(clapgpu_scene *s, uint32_t handle, const float pos[3], const float q[4], float scale)
+{
+    struct ent *e = get(s, handle);
+    if (!e || !pos || !q) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    memcpy(e->pos_scale, pos, 12);
+    e->pos_scale[3] = scale;
+    memcpy(e->rot, q, 16);
     mark_dirty(s, handle, 1);
     return CLAPGPU_OK;
 }
@@ -269,20 +288,36 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     if (n_slots <= s->cap_slots) return CLAPGPU_OK;
     uint32_t cap = s->cap_slots ? s->cap_slots : 4096;
     while (cap < n_slots) cap *= 2;
-    size_t n = cap;
+    size_t n = cap;                                     /* a multiple of 64: every sub-array below starts 16-B aligned */
 #define RE(p, bytes) do { void *q__ = realloc(p, bytes); if (!q__) return CLAPGPU_ERR_NOMEM; p = q__; } while (0)
-    RE(s->h_pos_scale, n * 16); RE(s->h_rot, n * 16); RE(s->h_mx, n * 64); RE(s->h_inv, n * 64);
-    RE(s->h_aabb, n * 24); RE(s->h_center, n * 12); RE(s->h_parent, n * 4); RE(s->h_model, n * 4);
-    RE(s->h_flags, n * 4); RE(s->h_mask, (n / 64 + 1) * 8); RE(s->slot_handle, n * 4);
+    RE(s->h_parent, n * 4); RE(s->h_model, n * 4); RE(s->slot_handle, n * 4);
 #undef RE
+    /* retile() rewrites the upload image in full and downloads are overwritten by the next frame, so
+     * nothing has to survive the growth */
+    if (s->h_in) clapgpu_host_free(s->h_in);
+    if (s->h_out) clapgpu_host_free(s->h_out);
+    s->h_in = s->h_out = NULL;
     free_device(s);
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
-    void **dp[] = { (void **)&s->d.pos_scale, (void **)&s->d.rot, (void **)&s->d.parent, (void **)&s->d.model,
-                    (void **)&s->d.flags, (void **)&s->d.seqs, (void **)&s->d.mx, (void **)&s->d.inv_mx,
-                    (void **)&s->d.aabb, (void **)&s->d.center, (void **)&s->d.vis_mask, (void **)&s->d.vis_row_pop,
+    s->have_results = 0;
+    s->in_bytes = n * 36;
+    s->out_bytes = n * 164 + (n / 64 + 2) * 8;
+    CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
+    CK(clapgpu_host_malloc(&s->h_out, s->out_bytes));
+    CK(clapgpu_malloc(&s->d_in, s->in_bytes));
+    CK(clapgpu_malloc(&s->d_out, s->out_bytes));
+    char *hi = s->h_in, *ho = s->h_out, *di = s->d_in, *dq = s->d_out;
+    s->h_pos_scale = (float *)hi;              s->d.pos_scale = (const float *)di;
+    s->h_rot = (float *)(hi + n * 16);         s->d.rot = (const float *)(di + n * 16);
+    s->h_flags = (uint32_t *)(hi + n * 32);    s->d.flags = (uint32_t *)(di + n * 32);
+    s->h_mx = (float *)ho;                     s->d.mx = (float *)dq;
+    s->h_inv = (float *)(ho + n * 64);         s->d.inv_mx = (float *)(dq + n * 64);
+    s->h_aabb = (float *)(ho + n * 128);       s->d.aabb = (float *)(dq + n * 128);
+    s->h_center = (float *)(ho + n * 152);     s->d.center = (float *)(dq + n * 152);
+    s->h_mask = (uint64_t *)(ho + n * 164);    s->d.vis_mask = (uint64_t *)(dq + n * 164);
+    void **dp[] = { (void **)&s->d.parent, (void **)&s->d.model, (void **)&s->d.seqs, (void **)&s->d.vis_row_pop,
                     (void **)&s->d_tile_row_start };
-    size_t sz[] = { n * 16, n * 16, n * 4, n * 4, n * 4, n * 4, n * 64, n * 64, n * 24, n * 12,
-                    (n / 64 + 1) * 8, (n / 64 + 16) / 16 * 16, (n / 64 + 2) * 4 };
+    size_t sz[] = { n * 4, n * 4, n * 4, (n / 64 + 16) / 16 * 16, (n / 64 + 2) * 4 };
     for (unsigned i = 0; i < sizeof(dp) / sizeof(dp[0]); i++)
         CK(clapgpu_malloc(dp[i], sz[i]));
     s->cap_slots = cap;
@@ -431,25 +466,24 @@ static int retile(clapgpu_scene *s)
     CK(clapgpu_memcpy_h2d((void *)s->d.parent, s->h_parent, n * 4, NULL));
     CK(clapgpu_memcpy_h2d((void *)s->d.model, s->h_model, n * 4, NULL));
     CK(clapgpu_memset(s->d.seqs, 0, n * 4, NULL));
-    CK(clapgpu_memset(s->d.aabb, 0, n * 24, NULL));
-    CK(clapgpu_memset(s->d.mx, 0, n * 64, NULL));
-    CK(clapgpu_memset(s->d.inv_mx, 0, n * 64, NULL));
-    CK(clapgpu_memset(s->d.center, 0, n * 12, NULL));
+    CK(clapgpu_memset(s->d_out, 0, s->out_bytes, NULL));
     if (tiled)
         CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
     for (uint32_t k = 0; k < s->n_dirty; k++) s->e[s->dirty_list[k]].dirty = 0;
     s->n_dirty = 0;
     s->topology_dirty = 0;
+    s->layout_gen++;
     return CLAPGPU_OK;
 }
 
 int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
 {
     if (!s) return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    int upload = 0;
+    int upload = 0, full = 0;
+    uint32_t lo = 0xffffffffu, hi = 0, n_touched = 0;
     if (s->topology_dirty) {
         CK(retile(s));
-        upload = 1;
+        upload = full = 1;
     } else if (s->n_dirty) {
         for (uint32_t k = 0; k < s->n_dirty; k++) {      /* transform_set_* since the last frame */
             struct ent *e = &s->e[s->dirty_list[k]];
@@ -459,9 +493,12 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
             memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
             memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
             s->h_flags[e->slot] = e->flags | (xform ? CLAPGPU_E_DIRTY : 0);
+            s->dirty_list[n_touched++] = e->slot;        /* the list is reused for the slots touched */
+            if (e->slot < lo) lo = e->slot;
+            if (e->slot >= hi) hi = e->slot + 1;
         }
         s->n_dirty = 0;
-        upload = 1;
+        upload = n_touched != 0;
     }
     if (s->models_dirty) {
         if (s->n_models > s->d_models_cap) {
@@ -473,29 +510,46 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         s->d.model_table = s->d_models;
         s->d.n_models = s->n_models;
         s->models_dirty = 0;
+        full = 1;
     }
     if (s->n_models == 0) return CLAPGPU_OK;
     const size_t n = s->n_slots;
+    const size_t cap = s->cap_slots;
     if (upload) {
-        CK(clapgpu_memcpy_h2d((void *)s->d.pos_scale, s->h_pos_scale, n * 16, NULL));
-        CK(clapgpu_memcpy_h2d((void *)s->d.rot, s->h_rot, n * 16, NULL));
-        CK(clapgpu_memcpy_h2d(s->d.flags, s->h_flags, n * 4, NULL));
+        /* one copy of the whole input slab after a re-tile or when most of it changed; else the slot range */
+        const size_t a = full ? 0 : lo, cnt = full ? n : (size_t)hi - lo;
+        if (full || 2 * cnt > n) {
+            CK(clapgpu_memcpy_h2d(s->d_in, s->h_in, cap * 32 + n * 4, NULL));
+        } else {
+            CK(clapgpu_memcpy_h2d((float *)s->d.pos_scale + 4 * a, s->h_pos_scale + 4 * a, cnt * 16, NULL));
+            CK(clapgpu_memcpy_h2d((float *)s->d.rot + 4 * a, s->h_rot + 4 * a, cnt * 16, NULL));
+            CK(clapgpu_memcpy_h2d(s->d.flags + a, s->h_flags + a, cnt * 4, NULL));
+        }
     }
     if (s->tiled)
         CK(clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum));
     else
         CK(clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, frustum));
-    CK(clapgpu_memcpy_d2h(s->h_mx, s->d.mx, n * 64, NULL));
-    CK(clapgpu_memcpy_d2h(s->h_inv, s->d.inv_mx, n * 64, NULL));
-    CK(clapgpu_memcpy_d2h(s->h_aabb, s->d.aabb, n * 24, NULL));
-    CK(clapgpu_memcpy_d2h(s->h_center, s->d.center, n * 12, NULL));
-    if (frustum)
+    if (upload || full || !s->have_results) {            /* otherwise the kernel rebuilt nothing: the last download stands */
+        if (cap == n || 4 * n > 3 * cap) {               /* one copy of the output slab (mask included) */
+            CK(clapgpu_memcpy_d2h(s->h_out, s->d_out, cap * 164 + (frustum ? (n / 64) * 8 : 0), NULL));
+        } else {
+            CK(clapgpu_memcpy_d2h(s->h_mx, s->d.mx, n * 64, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_inv, s->d.inv_mx, n * 64, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_aabb, s->d.aabb, n * 24, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_center, s->d.center, n * 12, NULL));
+            if (frustum) CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (n / 64) * 8, NULL));
+        }
+    } else if (frustum) {
         CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (n / 64) * 8, NULL));
-    else
+    }
+    if (!frustum)
         memset(s->h_mask, 0, (n / 64) * 8);
     CK(clapgpu_stream_sync(NULL));
-    if (upload)
+    if (full)
         for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */
+    else
+        for (uint32_t k = 0; k < n_touched; k++) s->h_flags[s->dirty_list[k]] &= ~CLAPGPU_E_DIRTY;
     s->have_results = 1;
     return CLAPGPU_OK;
 }
@@ -539,5 +593,21 @@ uint32_t clapgpu_scene_visible(const clapgpu_scene *s, uint32_t *handles, uint32
     return cnt;
 }
 
+uint32_t clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle)
+{
+    const struct ent *e = get(s, handle);
+    return (e && e->slot < s->n_slots) ? e->slot : CLAPGPU_NO_ENTITY;
+}
+
+int clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out)
+{
+    if (!s || !out || !s->have_results) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    out->n_slots = s->n_slots;
+    out->mx = s->h_mx; out->inverse_mx = s->h_inv; out->aabb = s->h_aabb; out->aabb_center = s->h_center;
+    out->vis_mask = s->h_mask;
+    return CLAPGPU_OK;
+}
+
 int clapgpu_scene_layout_is_tiled(const clapgpu_scene *s) { return s ? s->tiled : 0; }
 uint32_t clapgpu_scene_slot_count(const clapgpu_scene *s) { return s ? s->n_slots : 0; }
+uint32_t clapgpu_scene_layout_generation(const clapgpu_scene *s) { return s ? s->layout_gen : 0; }

@@ -55,6 +55,10 @@ uint32_t clapgpu_abi_version(void);
 
 int clapgpu_malloc(void **dev, size_t bytes);
 int clapgpu_free(void *dev);
+/* Page-locked host memory for the staging arrays of a binding: copies to and from it run at the
+ * link rate and truly asynchronously (pageable memory is bounced through a driver buffer). */
+int clapgpu_host_malloc(void **host, size_t bytes);
+int clapgpu_host_free(void *host);
 int clapgpu_memcpy_h2d(void *dev, const void *host, size_t bytes, void *stream);
 int clapgpu_memcpy_d2h(void *host, const void *dev, size_t bytes, void *stream);
 int clapgpu_memset(void *dev, int value, size_t bytes, void *stream);

@@ -42,6 +42,9 @@ int  clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t
 int  clapgpu_scene_entity_position(clapgpu_scene *s, uint32_t handle, const float pos[3]);
 int  clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float quat_xyzw[4]);
 int  clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale);
+/* the three above in one call: what a binding pushes when it finds xform.updated set */
+int  clapgpu_scene_entity_transform(clapgpu_scene *s, uint32_t handle, const float pos[3],
+                                    const float quat_xyzw[4], float scale);
 /* entity3d_move / entity3d_rotate (radians) / entity3d_visible (model.c:1810-1842) */
 int  clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3]);
 int  clapgpu_scene_entity_rotate(clapgpu_scene *s, uint32_t handle, float rx, float ry, float rz);
@@ -62,9 +65,28 @@ int          clapgpu_scene_entity_in_frustum(const clapgpu_scene *s, uint32_t ha
 void        *clapgpu_scene_entity_user(const clapgpu_scene *s, uint32_t handle);
 /* number of entities that pass the draw predicate; handles[] (ascending slot order) if non-NULL */
 uint32_t     clapgpu_scene_visible(const clapgpu_scene *s, uint32_t *handles, uint32_t capacity);
+/*
+ * Bulk form of the accessors above for a binding that scatters a whole frame back into entity3d
+ * structs: the page-locked result arrays of the last mq_update, indexed by SLOT, and an entity's
+ * slot.  Slots change only when the layout is rebuilt (creation, deletion, re-parenting); the
+ * pointers stay valid until the next mq_update.
+ */
+typedef struct clapgpu_scene_arrays {
+    uint32_t        n_slots;
+    const float    *mx;             /* [n_slots][16] */
+    const float    *inverse_mx;     /* [n_slots][16] */
+    const float    *aabb;           /* [n_slots][6]  */
+    const float    *aabb_center;    /* [n_slots][3]  */
+    const uint64_t *vis_mask;       /* bit (slot & 63) of word slot >> 6 */
+} clapgpu_scene_arrays;
+int          clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out);
+uint32_t     clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle);
+
 /* 1 = tiles (one launch), 0 = level-major (a tree wider than 64 at some level); after mq_update */
 int          clapgpu_scene_layout_is_tiled(const clapgpu_scene *s);
 uint32_t     clapgpu_scene_slot_count(const clapgpu_scene *s);
+/* incremented every time mq_update rebuilds the layout: cached slots are stale when it changes */
+uint32_t     clapgpu_scene_layout_generation(const clapgpu_scene *s);
 
 #ifdef __cplusplus
 }

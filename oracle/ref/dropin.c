@@ -302,7 +302,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     view_set(&A, cpos, cq);
     view_set(&B, cpos, cq);
 
-    double t_ref = 0, t_gpu = 0;
+    double t_ref = 0, t_gpu = 0, t_step[4] = { 0, 0, 0, 0 };
     uint64_t vis_a = 0, vis_b = 0;
     for (uint32_t f = 0; f < frames + 2; f++) {                          /* two untimed warm-up frames */
         for (uint32_t id = 0; id < n; id++) {
@@ -318,15 +318,21 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
         for (uint32_t id = 0; id < n; id++) vis_b += gpu_view_entity_in_frustum(gs, &B.view, B.e[id]);
         double t2 = now_s();
         if (rc) { fprintf(stderr, "gpu_mq_update: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
-        if (f >= 2) { t_ref += t1 - t0; t_gpu += t2 - t1; }
+        if (f >= 2) {
+            const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
+            t_ref += t1 - t0; t_gpu += t2 - t1;
+            t_step[0] += st->ms_walk; t_step[1] += st->ms_mirror; t_step[2] += st->ms_device; t_step[3] += st->ms_scatter;
+        }
     }
     uint64_t bad = 0;
     for (uint32_t id = 0; id < n; id++)
         bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24);
     printf("{\"mode\": \"bench\", \"entities\": %u, \"frames\": %u, \"dirty_permille\": %u, "
-           "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, \"visible_equal\": %s, \"mismatches\": %llu, "
+           "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, "
+           "\"binding_ms\": {\"walk\": %.4f, \"mirror\": %.4f, \"device\": %.4f, \"scatter\": %.4f}, \"visible_equal\": %s, \"mismatches\": %llu, "
            "\"note\": \"host entity3d structs in, host entity3d structs out: list walk, upload, kernel, download, scatter-back\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / frames, 1e3 * t_gpu / frames,
+           t_step[0] / frames, t_step[1] / frames, t_step[2] / frames, t_step[3] / frames,
            vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;

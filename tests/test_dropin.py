@@ -30,7 +30,7 @@ def test_dropin_checker_is_built_where_the_reference_is():
     out = subprocess.run(["nm", "-D", "--undefined-only", BIN], capture_output=True, text=True, check=True).stdout
     wanted = {l.split()[-1] for l in out.splitlines() if "clapgpu_" in l}
     assert {"clapgpu_scene_create", "clapgpu_scene_mq_update", "clapgpu_scene_entity_new",
-            "clapgpu_scene_entity_mx", "clapgpu_scene_entity_in_frustum"} <= wanted
+            "clapgpu_scene_entity_transform", "clapgpu_scene_results"} <= wanted
 
 
 def _run(*args):
