@@ -11,12 +11,18 @@
 // rounds; the globals never go to HBM, as in the reference where `global` is scratch).  Keyframes are per model and stay in L2.
 // HBM: ~200 B / joint: T/R/S 40 B, joint_transforms 64 B, joint pos 16 B written.
 //
-// Numerics: same mixed precision as the reference (double lerp, double acos/sin/cos in slerp);
-// device libm differs from glibc in the last ulp of a double, so this path is held to 1e-5
-// relative, not bit-exact.
+// Numerics: this path is held to 1e-5 relative, not bit-exact -- the reference itself
+// goes through the host's double libm here.  The kernel is VALU-bound, so the arithmetic is fp32
+// with FMA contraction, and slerp's acos / sin / cos are short polynomials valid on the only
+// intervals slerp can reach (max error 1.7e-7, checked against libm in tests/test_pose_skin_gpu.py).
 #include <string.h>
 #include "common.h"
 #include "lm_dev.h"
+
+// Everything below may contract a*b+c into one FMA (the rest of the library is built with
+// -ffp-contract=off for bit-exact parity with the reference's x86 arithmetic; k_animation_time
+// at the end of this file has no multiply-add to contract).
+#pragma clang fp contract(fast)
 
 namespace clapgpu {
 
@@ -44,21 +50,22 @@ struct PoseArgs {
 };
 
 // model.c:1266-1288 for strictly increasing key times (glTF): the bracket does not depend on
-// the reference's search cursor, so a binary search gives the same (prev, next).
-__device__ __forceinline__ void key_bracket(const float *t, int nr, float time, int &prev, int &next)
+// the reference's search cursor, so a search for lo = #{i : t[i] < time} gives the same (prev, next).
+// `top` = the largest power of two <= the longest channel of the wave (wave-uniform), so the loop has
+// no divergent exit: five steps of (add, compare, LDS read, compare, select) for 30 keys.
+__device__ __forceinline__ void key_bracket(const float *t, int nr, float time, int top, int &prev, int &next)
 {
-    if (time < t[0] || time > t[nr - 1]) {      // before the first / past the last key: wrap
-        prev = nr - 1;
-        next = 0;
-        return;
+    int lo = 0;
+    for (int step = top; step > 0; step >>= 1) {
+        const int cand = lo + step;
+        const float tc = t[cand <= nr ? cand - 1 : 0];
+        if (cand <= nr && tc < time) lo = cand;
     }
-    int lo = 0, hi = nr - 1;                    // first i with time <= t[i]
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (time <= t[mid]) hi = mid; else lo = mid + 1;
-    }
+    const bool wrap = time < t[0] || time > t[nr - 1];            // before the first / past the last key
     prev = lo > 0 ? lo - 1 : 0;
     next = prev + 1 < nr - 1 ? prev + 1 : nr - 1;
+    prev = wrap ? nr - 1 : prev;
+    next = wrap ? 0 : next;
 }
 
 // model.c:1312-1317.  The quotient uses the hardware reciprocal (<= 2 ulp): this path is held to
@@ -75,69 +82,111 @@ __device__ __forceinline__ float key_fac(float time, float p_time, float n_time)
 // costs a third of the VALU time (fp64 converts and multiplies run at half rate).
 __device__ __forceinline__ float lerp_ref(float a, float b, float fac)
 {
-    return fmaf(b, fac, a * (1.0f - fac));
+    return b * fac + a * (1.0f - fac);
+}
+
+// acos on [0, 1): the rational core of fdlibm's acosf (R(z) = z*P(z)/Q(z), |error| < 7e-9 on z <= 0.25)
+// without its hi/lo splitting; max error 1.4e-7 on the interval slerp reaches.
+__device__ __forceinline__ float acos01(float d)
+{
+    const bool big = d > 0.5f;
+    const float z = big ? (1.0f - d) * 0.5f : d * d;
+    const float pn = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
+    const float r = __fdividef(pn, 1.0f + z * -7.0662963390e-01f);
+    const float x = big ? sqrtf(z) : d;
+    const float y = x + x * r;                                   // asin(x)
+    return big ? 2.0f * y : 1.5707963267948966f - y;
+}
+
+// sin and cos on [0, pi/2]: no range reduction needed (theta = fac * acos(dot), fac in [0, 1], dot >= 0);
+// Taylor to x^11 / x^12, max error 1.7e-7 / 1.3e-7.
+__device__ __forceinline__ void sincos_halfpi(float x, float &sn, float &cs)
+{
+    const float x2 = x * x;
+    float ps = -2.5052108385e-08f;
+    ps = ps * x2 + 2.7557319224e-06f;
+    ps = ps * x2 - 1.9841269841e-04f;
+    ps = ps * x2 + 8.3333333333e-03f;
+    ps = ps * x2 - 1.6666666667e-01f;
+    sn = x + x * x2 * ps;
+    float pc = 2.0876756988e-09f;
+    pc = pc * x2 - 2.7557319224e-07f;
+    pc = pc * x2 + 2.4801587302e-05f;
+    pc = pc * x2 - 1.3888888889e-03f;
+    pc = pc * x2 + 4.1666666667e-02f;
+    pc = pc * x2 - 0.5f;
+    cs = 1.0f + x2 * pc;
 }
 
 // interp.h:67-118 quat_slerp / quat_interp
 __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], const float (&b_in)[4], float fac)
 {
-    float b[4] = { b_in[0], b_in[1], b_in[2], b_in[3] };
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) dot += b[i] * a[i];
-    if (dot < 0.0f) {
-        dot = -dot;
-#pragma unroll
-        for (int i = 0; i < 4; i++) b[i] = -b[i];
-    }
-    if ((double)dot > 0.9995) {                                  // nlerp + vec4_norm
+    float dot = b_in[0] * a[0] + b_in[1] * a[1] + b_in[2] * a[2] + b_in[3] * a[3];
+    const float sgn = dot < 0.0f ? -1.0f : 1.0f;                 // shortest arc: b = -b, dot = -dot
+    dot *= sgn;
+    const float b[4] = { b_in[0] * sgn, b_in[1] * sgn, b_in[2] * sgn, b_in[3] * sgn };
+    // (double)dot > 0.9995 in the reference; 0.9995f is the largest float below 0.9995, so the fp32
+    // comparison takes the same branch
+    if (dot > 0.9995f) {                                         // nlerp + vec4_norm (the recomputed dot is >= 0)
         const float rfac = 1.f - fac;
-        float t[4], d2 = 0.f, dd = 0.f;
+        float t[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) d2 += b[i] * a[i];           // quat_interp recomputes the dot
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            t[i] = d2 < 0 ? rfac * a[i] - fac * b[i] : rfac * a[i] + fac * b[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) dd += t[i] * t[i];
-        const float k = (float)(1.0 / (double)sqrtf(dd));
+        for (int i = 0; i < 4; i++) t[i] = rfac * a[i] + fac * b[i];
+        const float k = rsqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);
 #pragma unroll
         for (int i = 0; i < 4; i++) res[i] = t[i] * k;
         return;
     }
-    // The reference calls the double libm acos/sin/cos on float arguments and rounds the results
-    // back to float.  fp64 transcendentals are this kernel's single largest VALU cost, so the
-    // correctly-rounded-to-a-few-ulp fp32 forms are used instead: |error| <= ~3e-7 on unit
-    // quaternion components, inside the 1e-5 bar this path is held to (tests/test_pose_skin_gpu.py).
-    // Here dot is in [0, 0.9995]: sin(acos(dot)) = sqrt((1 - dot)(1 + dot)) to ~1e-7 relative (1 - dot
-    // is exact for dot >= 0.5), and one sincos serves sin(theta) and cos(theta).
-    const float theta_0 = acosf(dot);
-    const float theta = fac * theta_0;
+    // dot in [0, 0.9995]: sin(acos(dot)) = sqrt((1 - dot)(1 + dot)) (1 - dot is exact for dot >= 0.5)
+    const float theta = fac * acos01(dot);
     float sin_theta, cos_theta;
-    sincosf(theta, &sin_theta, &cos_theta);
-    const float f = __fdividef(sin_theta, sqrtf((1.0f - dot) * (1.0f + dot)));
+    sincos_halfpi(theta, sin_theta, cos_theta);
+    const float f = sin_theta * rsqrtf((1.0f - dot) * (1.0f + dot));
     const float rf = cos_theta - dot * f;
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = a[i] * rf + b[i] * f;
 }
 
+// A matrix row as two register pairs, so the affine products below are packed-fp32 FMAs whose scalar
+// factor comes out of a pair through op_sel (no moves): 18 v_pk_fma/mul per 3x4 product.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Row { v2f lo, hi; };
+__device__ __forceinline__ Row row_of(const float4 v) { Row r; r.lo = v2f{v.x, v.y}; r.hi = v2f{v.z, v.w}; return r; }
+__device__ __forceinline__ float4 f4_of(const Row r) { return make_float4(r.lo.x, r.lo.y, r.hi.x, r.hi.y); }
+// one row of A * B for affine A, B (fourth rows 0 0 0 1): A.x B0 + A.y B1 + A.z B2 + (0, 0, 0, A.w)
+__device__ __forceinline__ Row affine_row(const float4 A, const Row B0, const Row B1, const Row B2)
+{
+    Row o;
+    const v2f ax = { A.x, A.x }, ay = { A.y, A.y }, az = { A.z, A.z };
+    o.lo = ax * B0.lo + ay * B1.lo + az * B2.lo;
+    o.hi = ax * B0.hi + ay * B1.hi + az * B2.hi;
+    o.hi.y += A.w;
+    return o;
+}
+
 constexpr int POSE_WAVES = 4;           // 128 VGPRs, 40 KiB LDS per block: four blocks per CU
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
-constexpr int POSE_TIMES_LDS_MAX = 6144;     // key times kept in LDS when the model's pool fits (24 KiB)
+constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
 
 // LPC = lanes per character (64, 128, 192 or 256); BLOCK threads = CPB characters per block.
+// MODE 0: keyframes read through L2.  MODE 1: key times in LDS.  (Key VALUES in LDS as well -- one
+// 960-thread block per CU holding the model's whole 75 KiB pool -- was built and measured: no faster,
+// profiles/r01_experiments/pose_bounds.md.)
 // LDS_TIMES: the model's whole key-time pool is staged in LDS once per block and the block is
 // persistent (it strides over character groups), so the per-lane binary searches -- five
 // dependent loads per path -- run at LDS latency instead of L2 latency.  Skeleton constants of
 // the lane's joint (invmx, bind column 3, depth, parent) live in registers across characters.
-template <int LPC, bool LDS_TIMES, int BLOCK>
+template <int LPC, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? POSE_WAVES : 1)
 void k_pose(PoseArgs a)
 {
     constexpr int CPB = BLOCK / LPC;
     // joint globals, 4 KiB per wave; once a character's chain is done the same 4 KiB are the
     // wave's staging tile for its coalesced stores
-    __shared__ __attribute__((aligned(16))) float g_lds[CPB][LPC * G_STRIDE];
+    // slot LPC of every character is the identity with no ancestor: a lane that has reached the top of
+    // its path keeps multiplying by it, so the jump rounds below have no divergent branch
+    __shared__ __attribute__((aligned(16))) float g_lds[CPB][(LPC + 1) * G_STRIDE];
+    constexpr bool LDS_TIMES = MODE >= 1;
     __shared__ float times_lds[LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
 
     const int tid = threadIdx.x;
@@ -151,14 +200,54 @@ void k_pose(PoseArgs a)
     if (parent >= (int32_t)J) parent = -1;
     float *G = g_lds[cib < CPB ? cib : 0];
 
+    if (cib < CPB && j == 0) {                                   // beyond the 4 KiB the store staging uses
+        float4 *idn = reinterpret_cast<float4 *>(G) + 4 * LPC;   // (LPC >> 2) & 3 == 0: rows unswizzled
+        idn[0] = make_float4(1.f, 0.f, 0.f, 0.f);
+        idn[1] = make_float4(0.f, 1.f, 0.f, 0.f);
+        idn[2] = make_float4(0.f, 0.f, 1.f, 0.f);
+        idn[3] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    }
+    // first step of the key searches: the highest set bit of the model's longest channel (block-uniform)
+    __shared__ uint32_t nr_or;
+    if (tid == 0) nr_or = 0;
+    __syncthreads();
+    {
+        uint32_t m = 0;
+        for (uint32_t q = tid; q < a.n_anims * J * 3; q += blockDim.x)
+            m |= a.chan_table[q].z;
+        if (m) atomicOr(&nr_or, m);
+    }
     if (LDS_TIMES) {
         for (uint32_t q = tid; q < a.n_times; q += blockDim.x)
             times_lds[q] = a.times[q];
-        __syncthreads();
     }
+    __syncthreads();
     const float *times = LDS_TIMES ? times_lds : a.times;
+    const float *kdata = a.data;
+    const int top = nr_or ? 1 << (31 - __clz((int)nr_or)) : 0;
 
     const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
+
+    // A character's inputs (animation id, frame time, the joint's three channel records) are requested
+    // one character AHEAD, before the previous character's stores are issued: on gfx9-family hardware
+    // loads and stores retire through one in-order counter (vmcnt), so a load issued behind 6.5 KB of
+    // stores cannot be consumed until HBM has acknowledged them, while a load issued in front of them can.
+    struct CharIn { uint32_t an; float time; uint4 e0, e1, e2; };
+    const uint32_t jc = (uint32_t)j < J ? (uint32_t)j : J - 1;   // clamped: the loads below are always in bounds
+    auto request = [&](uint32_t g_) {
+        CharIn in;
+        uint32_t c_ = g_ * CPB + (cib < CPB ? cib : 0);
+        c_ = c_ < a.n_chars ? c_ : a.n_chars - 1;                 // past the end: a valid, unused character
+        uint32_t an = a.anim[c_];
+        if (an >= a.n_anims) an = 0;                             // an id outside the table would be a wild read
+        in.an = an;
+        in.time = a.frame_time[c_];
+        const uint4 *tab = a.chan_table + ((size_t)an * J + jc) * 3;
+        in.e0 = tab[0]; in.e1 = tab[1]; in.e2 = tab[2];          // (time_off, data_off, nr, -)
+        return in;
+    };
+    CharIn cur = request(blockIdx.x);
+
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t c = g * CPB + cib;
         const bool char_ok = cib < CPB && c < a.n_chars;
@@ -168,11 +257,8 @@ void k_pose(PoseArgs a)
         // ---- 1. channels_transform: this joint's T, R, S at the character's frame time ----
         float T[3] = { 0, 0, 0 }, R[4] = { 0, 0, 0, 1 }, S[3] = { 1, 1, 1 };
         if (joint_ok) {
-            uint32_t an = a.anim[c];
-            if (an >= a.n_anims) an = 0;                         // an id outside the table would be a wild read
-            const float time = a.frame_time[c];
-            const uint4 *tab = a.chan_table + ((size_t)an * J + j) * 3;
-            const uint4 e0 = tab[0], e1 = tab[1], e2 = tab[2];   // (time_off, data_off, nr, -)
+            const float time = cur.time;
+            const uint4 e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
             const int n0 = (int)e0.z, n1 = (int)e1.z, n2 = (int)e2.z;
             if (n0 <= 0 || n1 <= 0 || n2 <= 0) {                 // a path without a channel keeps its value
                 const float *st = a.trs + 10 * cj;
@@ -185,18 +271,18 @@ void k_pose(PoseArgs a)
             if (n0 > 0) {
                 int p, q;
                 const float *t = times + e0.x;
-                key_bracket(t, n0, time, p, q);
+                key_bracket(t, n0, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
-                const float *d = a.data + e0.y;
+                const float *d = kdata + e0.y;
 #pragma unroll
                 for (int k = 0; k < 3; k++) T[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
             }
             if (n1 > 0) {
                 int p, q;
                 const float *t = times + e1.x;
-                key_bracket(t, n1, time, p, q);
+                key_bracket(t, n1, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
-                const float *d = a.data + e1.y;
+                const float *d = kdata + e1.y;
                 const float qa[4] = { d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3] };
                 const float qb[4] = { d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3] };
                 slerp_ref(R, qa, qb, fac);
@@ -204,9 +290,9 @@ void k_pose(PoseArgs a)
             if (n2 > 0) {
                 int p, q;
                 const float *t = times + e2.x;
-                key_bracket(t, n2, time, p, q);
+                key_bracket(t, n2, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
-                const float *d = a.data + e2.y;
+                const float *d = kdata + e2.y;
 #pragma unroll
                 for (int k = 0; k < 3; k++) S[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
             }
@@ -218,60 +304,51 @@ void k_pose(PoseArgs a)
         // of its path and the index of the ancestor 2^s above, so ceil(log2(levels)) LDS rounds replace
         // `levels` dependent ones.  Locals are affine, so the running products are kept as three rows
         // (the fourth is 0 0 0 1); only root_pose and invmx are treated as general 4x4.
-        float4 M0, M1, M2;                                        // rows of the running product
+        Row M0, M1, M2;                                           // rows of the running product
         {
-            float Rm[16];
-            lmd::from_quat(Rm, R[0], R[1], R[2], R[3]);
-            M0 = make_float4(E_(Rm, 0, 0) * S[0], E_(Rm, 1, 0) * S[1], E_(Rm, 2, 0) * S[2], T[0]);
-            M1 = make_float4(E_(Rm, 0, 1) * S[0], E_(Rm, 1, 1) * S[1], E_(Rm, 2, 1) * S[2], T[1]);
-            M2 = make_float4(E_(Rm, 0, 2) * S[0], E_(Rm, 1, 2) * S[1], E_(Rm, 2, 2) * S[2], T[2]);
+            // L = T * R * S: mat4x4_from_quat (linmath.h:959-987) with the scale folded into the columns
+            const float qa = R[3], qb = R[0], qc = R[1], qd = R[2];
+            const float a2 = qa * qa, b2 = qb * qb, c2 = qc * qc, d2 = qd * qd;
+            const float bc = qb * qc, ad = qa * qd, bd = qb * qd, ac = qa * qc, cd = qc * qd, ab = qa * qb;
+            const v2f s01 = { S[0], S[1] };
+            M0.lo = v2f{ a2 + b2 - c2 - d2, 2.f * (bc - ad) } * s01;  M0.hi = v2f{ 2.f * (bd + ac) * S[2], T[0] };
+            M1.lo = v2f{ 2.f * (bc + ad), a2 - b2 + c2 - d2 } * s01;  M1.hi = v2f{ 2.f * (cd - ab) * S[2], T[1] };
+            M2.lo = v2f{ 2.f * (bd - ac), 2.f * (cd + ab) } * s01;    M2.hi = v2f{ (a2 - b2 - c2 + d2) * S[2], T[2] };
         }
         int anc = joint_ok ? parent : -1;
         {
             float4 *slots = reinterpret_cast<float4 *>(G);
             const int sw_me = (j >> 2) & 3;                       // row swizzle: 16 neighbouring lanes hit 64 banks
             for (uint32_t st = 0; st < a.n_jump_steps; st++) {
-                slots[4 * j + (0 ^ sw_me)] = M0;
-                slots[4 * j + (1 ^ sw_me)] = M1;
-                slots[4 * j + (2 ^ sw_me)] = M2;
+                slots[4 * j + (0 ^ sw_me)] = f4_of(M0);
+                slots[4 * j + (1 ^ sw_me)] = f4_of(M1);
+                slots[4 * j + (2 ^ sw_me)] = f4_of(M2);
                 reinterpret_cast<int *>(&slots[4 * j + (3 ^ sw_me)])[0] = anc;
                 if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
-                float4 A0, A1, A2;
-                int anc2 = -1;
-                const bool hop = anc >= 0;
-                if (hop) {
-                    const int sw = (anc >> 2) & 3;
-                    A0 = slots[4 * anc + (0 ^ sw)];
-                    A1 = slots[4 * anc + (1 ^ sw)];
-                    A2 = slots[4 * anc + (2 ^ sw)];
-                    anc2 = reinterpret_cast<const int *>(&slots[4 * anc + (3 ^ sw)])[0];
-                }
+                const int src = anc >= 0 ? anc : LPC;             // the identity slot once the path is folded
+                const int sw = (src >> 2) & 3;
+                const float4 A0 = slots[4 * src + (0 ^ sw)];
+                const float4 A1 = slots[4 * src + (1 ^ sw)];
+                const float4 A2 = slots[4 * src + (2 ^ sw)];
+                anc = reinterpret_cast<const int *>(&slots[4 * src + (3 ^ sw)])[0];
                 if (LPC == WAVE) wave_lds_fence(); else __syncthreads();
-                if (hop) {
-#pragma clang fp contract(fast)
-                    const float4 B0 = M0, B1 = M1, B2 = M2;
-#define CLAPGPU_AFFINE_ROW(A, OUT)                                                                  \
-                    OUT = make_float4(A.x * B0.x + A.y * B1.x + A.z * B2.x,                          \
-                                      A.x * B0.y + A.y * B1.y + A.z * B2.y,                          \
-                                      A.x * B0.z + A.y * B1.z + A.z * B2.z,                          \
-                                      A.x * B0.w + A.y * B1.w + A.z * B2.w + A.w)
-                    CLAPGPU_AFFINE_ROW(A0, M0);
-                    CLAPGPU_AFFINE_ROW(A1, M1);
-                    CLAPGPU_AFFINE_ROW(A2, M2);
-#undef CLAPGPU_AFFINE_ROW
-                    anc = anc2;
-                }
+                const Row B0 = M0, B1 = M1, B2 = M2;
+                M0 = affine_row(A0, B0, B1, B2);
+                M1 = affine_row(A1, B0, B1, B2);
+                M2 = affine_row(A2, B0, B1, B2);
             }
         }
         float Gm[16];                                             // global = root_pose * path product
+        {
+            const float4 m0 = f4_of(M0), m1 = f4_of(M1), m2 = f4_of(M2);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-#pragma clang fp contract(fast)
-            const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
-            E_(Gm, 0, r) = p0 * M0.x + p1 * M1.x + p2 * M2.x;
-            E_(Gm, 1, r) = p0 * M0.y + p1 * M1.y + p2 * M2.y;
-            E_(Gm, 2, r) = p0 * M0.z + p1 * M1.z + p2 * M2.z;
-            E_(Gm, 3, r) = p0 * M0.w + p1 * M1.w + p2 * M2.w + p3;
+            for (int r = 0; r < 4; r++) {
+                const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
+                E_(Gm, 0, r) = p0 * m0.x + p1 * m1.x + p2 * m2.x;
+                E_(Gm, 1, r) = p0 * m0.y + p1 * m1.y + p2 * m2.y;
+                E_(Gm, 2, r) = p0 * m0.z + p1 * m1.z + p2 * m2.z;
+                E_(Gm, 3, r) = p0 * m0.w + p1 * m1.w + p2 * m2.w + p3;
+            }
         }
 
         // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
@@ -285,7 +362,12 @@ void k_pose(PoseArgs a)
             }
             const float4 b3 = a.bind[4 * j + 3];                  // only column 3 of bind reaches mpos
             const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
-            lmd::mul(JT, Gm, IM);                                 // model.c:1389
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)                        // model.c:1389 (mat4x4_mul, contracted)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    E_(JT, cc, r) = E_(Gm, 0, r) * E_(IM, cc, 0) + E_(Gm, 1, r) * E_(IM, cc, 1) +
+                                    E_(Gm, 2, r) * E_(IM, cc, 2) + E_(Gm, 3, r) * E_(IM, cc, 3);
             float mpos[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {                         // column 3 of JT * bind (model.c:1393-1397)
@@ -302,8 +384,12 @@ void k_pose(PoseArgs a)
                 const float4 v = em[q];
                 EM[4 * q] = v.x; EM[4 * q + 1] = v.y; EM[4 * q + 2] = v.z; EM[4 * q + 3] = v.w;
             }
-            lmd::mul_vec4(pos, EM, mpos);                         // model.c:1400
+#pragma unroll
+            for (int r = 0; r < 4; r++)                           // model.c:1400 (mat4x4_mul_vec4_post)
+                pos[r] = E_(EM, 0, r) * mpos[0] + E_(EM, 1, r) * mpos[1] + E_(EM, 2, r) * mpos[2] + E_(EM, 3, r) * mpos[3];
         }
+
+        cur = request(g + gridDim.x);                             // the next character's inputs, ahead of the stores
 
         // ---- stores (64 joints of one character per wave row) ----
         if (LPC != WAVE) __syncthreads();                         // every wave is done reading parents from G
@@ -435,38 +521,43 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     const uint32_t lpc = (sk->nr_joints + 63) / 64 * 64;
     const bool lds_times = an->n_times > 0 && an->n_times <= (uint32_t)POSE_TIMES_LDS_MAX;
     hipStream_t s = as_stream(stream);
+    static thread_local int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        CLAPGPU_HIP(hipGetDevice(&dev));
+        CLAPGPU_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cus = prop.multiProcessorCount;
+    }
     if (lds_times) {
         // persistent blocks (24 KiB key times + 16 KiB joint globals each): exactly as many as are
         // resident at once, so no block waits for a slot while the others hold their LDS copy
         const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
         const uint32_t n_groups = (pb->n_chars + cpb - 1) / cpb;
-        const void *fn = lpc == 64 ? (const void *)k_pose<64, true, 256> : lpc == 128 ? (const void *)k_pose<128, true, 256>
-                       : lpc == 192 ? (const void *)k_pose<192, true, 192> : (const void *)k_pose<256, true, 256>;
+        const void *fn = lpc == 64 ? (const void *)k_pose<64, 1, 256> : lpc == 128 ? (const void *)k_pose<128, 1, 256>
+                       : lpc == 192 ? (const void *)k_pose<192, 1, 192> : (const void *)k_pose<256, 1, 256>;
         static thread_local uint32_t resident[4] = { 0, 0, 0, 0 };
         uint32_t &res = resident[lpc / 64 - 1];
         if (!res) {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            CLAPGPU_HIP(hipGetDevice(&dev));
-            CLAPGPU_HIP(hipGetDeviceProperties(&prop, dev));
+            int per_cu = 0;
             CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, 0));
-            res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)prop.multiProcessorCount;
+            res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
         }
         const dim3 grid(n_groups < res ? n_groups : res), block(threads);
         switch (lpc) {
-        case 64:  hipLaunchKernelGGL((k_pose<64, true, 256>), grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL((k_pose<128, true, 256>), grid, block, 0, s, a); break;
-        case 192: hipLaunchKernelGGL((k_pose<192, true, 192>), grid, block, 0, s, a); break;
-        default:  hipLaunchKernelGGL((k_pose<256, true, 256>), grid, block, 0, s, a); break;
+        case 64:  hipLaunchKernelGGL((k_pose<64, 1, 256>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_pose<128, 1, 256>), grid, block, 0, s, a); break;
+        case 192: hipLaunchKernelGGL((k_pose<192, 1, 192>), grid, block, 0, s, a); break;
+        default:  hipLaunchKernelGGL((k_pose<256, 1, 256>), grid, block, 0, s, a); break;
         }
     } else {
         const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
         const dim3 grid((pb->n_chars + cpb - 1) / cpb), block(threads);
         switch (lpc) {
-        case 64:  hipLaunchKernelGGL((k_pose<64, false, 256>), grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL((k_pose<128, false, 256>), grid, block, 0, s, a); break;
-        case 192: hipLaunchKernelGGL((k_pose<192, false, 192>), grid, block, 0, s, a); break;
-        default:  hipLaunchKernelGGL((k_pose<256, false, 256>), grid, block, 0, s, a); break;
+        case 64:  hipLaunchKernelGGL((k_pose<64, 0, 256>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_pose<128, 0, 256>), grid, block, 0, s, a); break;
+        case 192: hipLaunchKernelGGL((k_pose<192, 0, 192>), grid, block, 0, s, a); break;
+        default:  hipLaunchKernelGGL((k_pose<256, 0, 256>), grid, block, 0, s, a); break;
         }
     }
     CLAPGPU_LAUNCH_CHECK("k_pose");

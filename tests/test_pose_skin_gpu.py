@@ -86,6 +86,38 @@ def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
         assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
 
 
+@pytest.mark.parametrize("akw,two", [({}, False), (dict(ragged=True, missing_frac=0.1), True)], ids=["c3_pool", "two_ragged_anims"])
+def test_pose_many_characters_matches_oracle(akw, two, cuda_device):
+    """9000 characters = 2250 character groups over at most 1024 resident blocks: the persistent loop,
+    its one-character-ahead input requests and the staging tile reuse are all exercised against the oracle."""
+    from clap_amd import animation
+    J, n = 64, 9000
+    sk = synth.skeleton(J, 8, seed=21, unreachable=2)
+    anims = [synth.animation(J, 30, 2.0, seed=21, **akw)] + ([synth.animation(J, 7, 1.0, seed=22)] if two else [])
+    ch = synth.characters(n, J, seed=21)
+    sk["bind"] = ob.skeleton_bind(sk)
+    model = animation.SkinnedModel(sk, anims, bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    which = (np.arange(n) % 3 == 0).astype(np.int32) if two else np.zeros(n, np.int32)
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    reach = sk["order"]
+    for f, t in enumerate([ch["phase"], (ch["phase"] * 1.37 + 0.2) % 2.2]):
+        t = t.astype(np.float32)
+        jt = np.zeros((n, J, 16), np.float32)
+        jp = np.zeros((n, J, 4), np.float32)
+        for a_id, an in enumerate(anims):
+            sel = np.flatnonzero(which == a_id)
+            sub = trs[sel].copy()
+            j1, _g, p1 = ob.pose(sk, an, t[sel], ch["char_mx"][sel], sub)
+            trs[sel], jt[sel], jp[sel] = sub, j1, p1
+        batch.set_frame_times(t, which)
+        batch.pose_update()
+        out = batch.download()
+        assert_close(out["trs"], trs, f"frame {f} T/R/S")
+        assert_close(out["joint_transforms"][:, reach], jt[:, reach], f"frame {f} joint_transforms")
+        assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
+
+
 def test_animated_update_clock_on_device(cuda_device, golden_dir):
     """animated_update's clock (model.c:1563-1592) as a kernel: frame times, `ended`, restart of
     repeating entries -- against the reference's own animated_update (golden) and the oracle."""
