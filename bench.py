@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import subprocess
 import time
 
 import numpy as np
@@ -75,6 +76,29 @@ def cpu_all_cores(scene, cam, frames=8):
                                     "run on (a container CPU quota below that count is not visible here)")
 
 
+def dropin_boundary():
+    """The reference's own objects on both sides (oracle/_ref/clap_dropin, tests/test_dropin.py): its
+    mq_update + view_entity_in_frustum against the CLAP-side binding over libclapgpu_scene, host entity3d
+    structs in, host entity3d structs out -- the PCIe- and scatter-inclusive cost of the boundary."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "clap_dropin")
+    if not os.access(exe, os.X_OK):
+        return None
+    out = {}
+    for n, frames, permille in ((10_000, 50, 1000), (10_000, 50, 100), (1_000_000, 5, 1000)):
+        try:
+            p = subprocess.run([exe, "bench", str(n), str(frames), str(permille)], capture_output=True, text=True, timeout=180)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as e:                                   # a figure for context: never fail the bench on it
+            out[f"{n}_entities_{permille // 10}pct_dirty"] = {"error": repr(e)[:200]}
+            continue
+        out[f"{n}_entities_{permille // 10}pct_dirty"] = {
+            "reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
+            "binding_ms": r["binding_ms"], "identical": r["mismatches"] == 0 and r["visible_equal"]}
+    out["note"] = ("random forest (60 % of the entities parented), one frame = mq_update + one frustum verdict per entity; "
+                   "binding = list walk + upload + kernel + download + scatter-back into the entity3d structs, 1 host thread")
+    return out
+
+
 def cpu_baseline(scene, cam, frames):
     """Reported baseline, not the target: the reference (or the port) on one host core."""
     from oracle import binding as ob, refrun
@@ -83,7 +107,7 @@ def cpu_baseline(scene, cam, frames):
     if refrun.available():
         r = refrun.bench_entities(scene, cam, reps=frames)
         return dict(value=n_real / r["mean_s"], unit="entity updates/s", cores=cores, kind="reference",
-                    all_cores=cpu_all_cores(scene, cam),
+                    all_cores=cpu_all_cores(scene, cam), dropin_boundary=dropin_boundary(),
                     sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty): the reference's "
                            "default_update + view_entity_in_frustum (core/model.c, core/view.c; ROCm clang -O2 "
                            f"-ffp-contract=off), 1 thread; best frame {n_real / r['best_s']:.3e}/s")
