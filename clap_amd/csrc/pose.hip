@@ -164,7 +164,7 @@ __device__ __forceinline__ Row affine_row(const float4 A, const Row B0, const Ro
     return o;
 }
 
-constexpr int POSE_WAVES = 4;           // 128 VGPRs, 40 KiB LDS per block: four blocks per CU
+constexpr int POSE_WAVES = 3;           // three waves per SIMD (168 VGPRs) run as fast as four (measured): the registers go to the joint constants
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
 
@@ -248,6 +248,18 @@ void k_pose(PoseArgs a)
     };
     CharIn cur = request(blockIdx.x);
 
+    // the lane's joint constants, once per (persistent) block: 20 registers that three waves per SIMD afford
+    float IM[16], bv[4];
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = a.invmx[4 * jc + q];
+            IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
+        }
+        const float4 b3 = a.bind[4 * jc + 3];                     // only column 3 of bind reaches mpos
+        bv[0] = b3.x; bv[1] = b3.y; bv[2] = b3.z; bv[3] = b3.w;
+    }
+
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t c = g * CPB + cib;
         const bool char_ok = cib < CPB && c < a.n_chars;
@@ -266,8 +278,9 @@ void k_pose(PoseArgs a)
                 R[0] = st[3]; R[1] = st[4]; R[2] = st[5]; R[3] = st[6];
                 S[0] = st[7]; S[1] = st[8]; S[2] = st[9];
             }
-            // one path at a time keeps the live state small (the searches run on LDS-resident times);
-            // batching the three paths' key loads behind all three searches measured 205 us against 158
+            // one path at a time (the searches run on LDS-resident times); the three paths' searches and key
+            // loads interleaved in one block measured slower both at 128 VGPRs (205 us against 158) and at
+            // 146 (141.6 against 135.1)
             if (n0 > 0) {
                 int p, q;
                 const float *t = times + e0.x;
@@ -354,14 +367,6 @@ void k_pose(PoseArgs a)
         // ---- 3. palette: joint_transforms = global * invmx; pos = e->mx * (joint_transforms * bind) * (0,0,0,1) ----
         float JT[16], pos[4] = { 0, 0, 0, 0 };
         if (joint_ok && reachable) {
-            float IM[16];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v = a.invmx[4 * j + q];
-                IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
-            }
-            const float4 b3 = a.bind[4 * j + 3];                  // only column 3 of bind reaches mpos
-            const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
 #pragma unroll
             for (int cc = 0; cc < 4; cc++)                        // model.c:1389 (mat4x4_mul, contracted)
 #pragma unroll
