@@ -51,6 +51,9 @@ def parse():
                          "'entities' and optionally 'camera') instead of the synthetic BASELINE workload")
     ap.add_argument("--exchange", choices=["rccl", "c10d"], default="rccl",
                     help="N > 1: call ncclAllGather directly (low host overhead) or through torch.distributed")
+    ap.add_argument("--no-testbed", action="store_true",
+                    help="skip the testbed-sized (BASELINE configs[0]) extra: under rocprofv3 its small launches of "
+                         "the same kernels would be averaged into the full-size per-kernel statistics")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -147,7 +150,7 @@ def roof(alg_bytes, seconds):
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": seconds * 1e6}
 
 
-def extras(device):
+def extras(device, testbed=True):
     """The other rows of the hot path at BASELINE configs[2] and configs[3] sizes, each as
     units/s plus the algorithmic-bytes roofline of its kernel (SURVEY.md 8d byte counts)."""
     import torch
@@ -213,7 +216,8 @@ def extras(device):
     del ls
     torch.cuda.empty_cache()
     out["full_frame"] = full_frame(device)
-    out["testbed_frame"] = testbed_frame(device)
+    if testbed:
+        out["testbed_frame"] = testbed_frame(device)
     return out
 
 
@@ -522,7 +526,7 @@ def main():
         if world == 1 and not args.no_extras:
             del batch
             torch.cuda.empty_cache()
-            out["extra"] = extras(device)
+            out["extra"] = extras(device, testbed=not args.no_testbed)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
         print(json.dumps(out), flush=True)

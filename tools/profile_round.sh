@@ -10,9 +10,9 @@ out=$R/gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" > "$out/bench_unprofiled.json" 2> "$out/bench_unprofiled.err"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --steps 100 --warmup 10 --cpu-frames 0 > "$out/bench_under_rocprof.log" 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 > "$out/bench_fetch.log" 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 > "$out/bench_write.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --steps 100 --warmup 10 --cpu-frames 0 --no-testbed > "$out/bench_under_rocprof.log" 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed > "$out/bench_fetch.log" 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed > "$out/bench_write.log" 2>&1
 f=$(find "$out/trace" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/kernel_stats.csv"
 fc=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
