@@ -7,7 +7,9 @@ the binding over libclapgpu_scene -> HIP -- through a scripted game (moves, rota
 visibility and SKIP_CULLING toggles, creations, deletions, re-parenting, entities with a foreign
 update hook that must stay on the host) and compares mx, inverse_mx, aabb, aabb_center, seq,
 parent_seq, xform.updated, the frustum verdict and the camera bounding-volume pick bit for bit
-after every frame.  The binary needs the reference tree to BUILD (here) and a GPU to RUN.
+after every frame.  The same binary checks the particle path (`particles` mode): the reference's particles_update
+hooks drawing from libc's drand48 against clap_amd/binding/gpu-particles.inc.c.
+The binary needs the reference tree to BUILD (here) and a GPU to RUN.
 """
 import json
 import os
@@ -49,6 +51,18 @@ def test_binding_matches_reference_mq_update(n, frames, seed):
     assert r["batched_updates"] > 0 and r["host_updates"] > 0      # both halves of the split were exercised
     assert r["written_back"] > 0 and r["retiles"] > 0
     assert 0 < r["visible_verdicts_true"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_sys,per_sys,frames,seed", [(3, 100, 6, 1), (40, 300, 12, 2), (512, 1024, 8, 3)])
+def test_particle_binding_matches_reference_particles_update(n_sys, per_sys, frames, seed):
+    """particles_update hooks + libc drand48 (reference) vs gpu_particles_update (binding -> HIP) on the
+    reference's own particle_system / particle structs: pos_array, every particle's pos and velocity, the
+    billboard matrix and the libc stream position, with emitters moving (attached and free), systems dying
+    and appearing, and frames with and without the per-particle scatter-back."""
+    r = _run("particles", n_sys, per_sys, frames, seed)
+    assert r["mismatches"] == 0 and r["stream_draws_agree"] is True
+    assert r["respawns"] > 0 and r["particle_structs_compared"] > 0
 
 
 @pytest.mark.gpu
