@@ -66,6 +66,7 @@ struct gpu_scene {
     clapgpu_scene_arrays res;
     struct gs_model *models; uint32_t n_models, cap_models;
     uint32_t        gen, vis_cursor;
+    bool            anim_elsewhere;
     struct view     *culled_view;
     vec4            culled_planes[6];
     struct gpu_scene_stats stats;
@@ -181,11 +182,19 @@ void gpu_scene_done(struct gpu_scene *gs)
 
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs) { return &gs->stats; }
 
+void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere) { gs->anim_elsewhere = elsewhere; }
+
+bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e)
+{
+    const uint32_t i = rec_find(gs, e);
+    return i != NO_REC && gs->rec[i].gen == gs->gen && gs->rec[i].cls == 1;
+}
+
 /* Criteria an entity meets on its own (step 2); the parent's class is folded in by classify(). */
 static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
 {
     return e->update == gs->default_hook &&
-           !entity_animated(e) &&
+           (gs->anim_elsewhere || !entity_animated(e)) &&
            !(e->flags & (ENTITY3D_HAS_PHYSICS | ENTITY3D_IS_CHARACTER | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE)) &&
            e->light_idx < 0 &&
            e->parent_joint == JOINT_TYPE_MAX;

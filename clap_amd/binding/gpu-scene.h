@@ -54,4 +54,14 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
 
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 
+/*
+ * Skeletal animation.  By default an entity whose model has animations stays on the host, because
+ * default_update ends in animated_update (model.c:1715-1716).  When the pose is computed elsewhere
+ * (gpu-anim.inc.c: gpu_anim_update() after gpu_mq_update()), say so: such entities' transforms are then
+ * batched like any other and nothing runs animated_update for them here.
+ */
+void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere);
+/* true if `e` was updated on the device by the last gpu_mq_update() */
+bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);
+
 #endif /* CLAP_GPU_SCENE_H */

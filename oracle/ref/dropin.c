@@ -17,12 +17,19 @@
  * drawing from libc's drand48 stream against gpu_particles_update() of clap_amd/binding/gpu-particles.inc.c:
  * pos_array, every particle's pos / velocity, the billboard matrix and the libc stream position, bit for bit.
  *
+ * `anim`: skeletal animation -- default_update's animated_update() tail (clock, queue, channels_transform,
+ * one_joint_transform; model.c:1563-1592) against gpu_mq_update() + gpu_anim_update() of
+ * clap_amd/binding/gpu-anim.inc.c: transforms bit for bit, joint_transforms / joint T,R,S / joint positions
+ * to 1e-5 of the largest magnitude, queue state and ani_time exactly.
+ *
  * Needs a GPU (libclapgpu).  Usage:
  *   clap_dropin test  <entities> <frames> <seed>     exit 0 = every frame identical
  *   clap_dropin bench <entities> <frames> <dirty_permille>
  *   clap_dropin particles <systems> <particles_per_system> <frames> <seed>
+ *   clap_dropin anim <characters> <joints> <frames> <seed>
  */
 #include "model.c"
+#include "gpu-anim.inc.c"               /* clap_amd/binding: lives at the end of model.c's translation unit */
 #include "view.c"
 #include "particle.c"
 #include "gpu-particles.inc.c"          /* clap_amd/binding: lives at the end of particle.c's translation unit */
@@ -40,7 +47,8 @@ const char *clap_version = "oracle";
 
 static render_options dbl_ropts;
 render_options *clap_get_render_options(struct clap_context *ctx) { return &dbl_ropts; }
-double clap_get_current_time(struct clap_context *ctx) { return 0.0; }
+static double dbl_now;                  /* the frame clock (clap.c is the frame driver: not buildable here) */
+double clap_get_current_time(struct clap_context *ctx) { return dbl_now; }
 static renderer_caps dbl_caps;
 const renderer_caps *renderer_get_caps(renderer_t *r) { return &dbl_caps; }
 
@@ -508,14 +516,241 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
     return bad ? 1 : 0;
 }
 
+/* ---------------------------------------------------------------- skeletal animation */
+struct aworld {
+    struct scene    *scene;
+    model3d         model, prop_model;
+    model3dtx       txm, prop_txm;
+    struct view     view;
+    entity3d        **e;
+    uint64_t        libc;
+};
+
+static void txm_init(struct mq *mq, model3dtx *txm, model3d *m)
+{
+    txm->model = m;
+    txm->ref.refclass = &REFCLASS_NAME(model3dtx);
+    txm->ref.count = 1 << 30;
+    list_init(&txm->entities);
+    list_append(&mq->txmodels, &txm->entry);
+}
+
+/* Same skeleton and animations in both worlds: built through model3d_add_skinning / animation_new /
+ * animation_add_channel (model.c:524-538, 687-738), as gltf_instantiate_one does. */
+static void amodel_build(model3d *m, uint32_t J, uint64_t seed)
+{
+    const uint64_t keep = rng_state;
+    rng_state = seed;
+    mat4x4 *invmx = calloc(J, sizeof(mat4x4));
+    int *parent = calloc(J, sizeof(int));
+    for (uint32_t j = 0; j < J; j++) {
+        mat4x4 b, r;
+        quat q; quat_from_euler_xyz(q, rndf(-1, 1), rndf(-1, 1), rndf(-1, 1));
+        mat4x4_from_quat(r, q);
+        mat4x4_translate(b, rndf(-1, 1), rndf(0, 2), rndf(-1, 1));
+        mat4x4_mul(b, b, r);
+        mat4x4_invert(invmx[j], b);
+        parent[j] = j == 0 ? -1 : (j + 2 >= J && J > 4) ? -2 : (int)rndn(j);     /* the last two: outside joint 0's tree */
+        if (j > 8 && parent[j] >= 0 && rndn(3)) parent[j] = (int)(j - 1 - rndn(3));   /* some long chains */
+    }
+    memcpy(m->aabb, (float[6]){ -1, 0, -1, 1, 2, 1 }, 24);
+    darray_init(m->anis);
+    model3d_add_skinning(m, J, invmx);
+    mat4x4_identity(m->root_pose);
+    m->root_pose[3][1] = 0.25f; m->root_pose[0][0] = 1.5f;
+    for (uint32_t j = 0; j < J; j++)
+        if (parent[j] >= 0) *(int *)darray_add(m->joints[parent[j]].children) = (int)j;
+    const char *names[2] = { "idle", "walk" };
+    for (int a = 0; a < 2; a++) {
+        const float time_end = a ? 1.25f : 2.0f;
+        struct animation *an = animation_new(m, names[a], J * 3);
+        for (uint32_t j = 0; j < J; j++)
+            for (int path = 0; path < 3; path++) {
+                if (a && rndn(6) == 0) continue;                                  /* "walk" leaves some paths alone */
+                const unsigned int nr = 2 + rndn(a ? 9 : 29);
+                float t[32], d[32 * 4];
+                for (unsigned int k = 0; k < nr; k++) t[k] = time_end * (float)k / (float)(nr - 1) + (k && k + 1 < nr ? rndf(-0.4f, 0.4f) * time_end / (float)nr : 0.f);
+                for (unsigned int k = 0; k < nr; k++) {
+                    if (path == PATH_ROTATION) {
+                        quat q; quat_from_euler_xyz(q, rndf(-1.2f, 1.2f), rndf(-1.2f, 1.2f), rndf(-1.2f, 1.2f));
+                        if (rndn(3) == 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
+                        if (k && rndn(5) == 0) memcpy(q, &d[4 * (k - 1)], 16);    /* nlerp branch */
+                        memcpy(&d[4 * k], q, 16);
+                    } else {
+                        for (int i = 0; i < 3; i++) d[3 * k + i] = path == PATH_SCALE ? rndf(0.8f, 1.25f) : rndf(-0.5f, 0.5f);
+                    }
+                }
+                animation_add_channel(an, nr, t, d, (path == PATH_ROTATION ? 4 : 3) * sizeof(float), j, path);
+            }
+    }
+    free(invmx); free(parent);
+    rng_state = keep;
+}
+
+static void aworld_init(struct aworld *w, uint32_t cap, uint32_t J, uint64_t seed)
+{
+    memset(w, 0, sizeof(*w));
+    w->scene = calloc(1, sizeof(*w->scene));
+    w->scene->clap_ctx = (struct clap_context *)w->scene;             /* only ever handed to the clock double */
+    mq_init(&w->scene->mq, w->scene);
+    w->scene->camera = &w->scene->cameras[0];
+    transform_init(&w->scene->camera->xform);
+    amodel_build(&w->model, J, seed);
+    memcpy(w->prop_model.aabb, (float[6]){ -1, -1, -1, 1, 1, 1 }, 24);
+    txm_init(&w->scene->mq, &w->prop_txm, &w->prop_model);
+    txm_init(&w->scene->mq, &w->txm, &w->model);
+    w->e = calloc(cap, sizeof(*w->e));
+}
+
+static double rel_err(const float *a, const float *b, size_t n)
+{
+    double mx = 1.0, err = 0.0;
+    for (size_t i = 0; i < n; i++) { const double v = fabs((double)a[i]); if (v > mx) mx = v; }
+    for (size_t i = 0; i < n; i++) { const double d = fabs((double)a[i] - (double)b[i]); if (!(d <= err)) err = d; }
+    return err / mx;
+}
+
+static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed)
+{
+    struct gpu_scene *gs;
+    struct gpu_anim *ga;
+    int rc = gpu_scene_init(&gs, 0, default_update);
+    if (!rc) rc = gpu_anim_init(&ga, 0);
+    if (rc) { fprintf(stderr, "init: %d\n", rc); return 2; }
+    gpu_scene_animation_elsewhere(gs, true);
+
+    struct aworld WA, WB, *W[2] = { &WA, &WB };
+    const uint32_t n = n_chars + n_chars / 4 + 1;                       /* characters + a few plain props */
+    dbl_now = 10.0;
+    aworld_init(&WA, n, J, seed * 77 + 1);
+    aworld_init(&WB, n, J, seed * 77 + 1);
+    rng_state = seed;
+    const uint64_t s0 = 0x1234ABCD330Eull;
+    int *reach = calloc(J, sizeof(int));                                /* joints under joint 0 */
+    reach[0] = 1;
+    for (bool grew = true; grew;) {
+        grew = false;
+        for (uint32_t j = 0; j < J; j++) {
+            int *c;
+            if (reach[j])
+                darray_for_each(c, WA.model.joints[j].children)
+                    if (!reach[*c]) { reach[*c] = 1; grew = true; }
+        }
+    }
+    for (uint32_t id = 0; id < n; id++) {
+        const bool prop = id >= n_chars;
+        vec3 pos = { rndf(-300, 300), rndf(-5, 5), rndf(-300, 300) };
+        const float ry = rndf(-3, 3), sc = rndf(0.7f, 1.3f), speed = rndf(0.5f, 2.f);
+        const uint32_t start = rndn(4);                                  /* 0: empty queue -> "idle" with a random phase */
+        const bool repeat = rndn(3) != 0;
+        float rest[10];
+        for (int i = 0; i < 10; i++) rest[i] = i == 6 ? 1.f : i >= 7 ? 1.f : i >= 3 ? 0.f : rndf(-0.2f, 0.2f);
+        for (int k = 0; k < 2; k++) {
+            struct aworld *w = W[k];
+            entity3d *e = ref_new(entity3d, .txmodel = prop ? &w->prop_txm : &w->txm);
+            entity3d_position(e, pos);
+            entity3d_rotate(e, 0, ry, 0);
+            entity3d_scale(e, sc);
+            if (!prop) {
+                for (uint32_t j = 0; j < J; j++) {                        /* mem_alloc'ed uninitialised (model.c:1751-1754) */
+                    memset(&e->joints[j], 0, sizeof(e->joints[j]));
+                    memcpy(e->joints[j].translation, rest, 12);
+                    memcpy(e->joints[j].rotation, rest + 3, 16);
+                    memcpy(e->joints[j].scale, rest + 7, 12);
+                }
+                memset(e->joint_transforms, 0, J * sizeof(mat4x4));
+                if (start) {
+                    if (!animation_push_by_name(e, w->scene, start == 1 ? "idle" : "walk", true, repeat)) return 2;
+                    ani_current(e)->speed = speed;                        /* animation_set_speed's store (model.c:1517) */
+                }
+            }
+            w->e[id] = e;
+        }
+    }
+    WA.libc = WB.libc = s0;
+
+    uint64_t bad = 0, posed = 0, restarts = 0;
+    double worst = 0.0;
+    for (uint32_t f = 0; f < frames; f++) {
+        dbl_now = 10.0 + 0.37 * f + (f % 4 == 3 ? 0.0 : 0.013 * f);
+        for (uint32_t id = 0; id < n; id++) {
+            if (rndn(3)) continue;
+            vec3 off = { rndf(-1, 1), 0, rndf(-1, 1) };
+            entity3d_move(WA.e[id], off); entity3d_move(WB.e[id], off);
+        }
+        vec3 cpos = { rndf(-50, 50), rndf(2, 10), rndf(-50, 50) };
+        quat cq; quat_from_euler_xyz(cq, rndf(-0.3f, 0.3f), rndf(-3, 3), 0);
+        for (int k = 0; k < 2; k++) {
+            transform_t cam;
+            transform_init(&cam); transform_set_pos(&cam, cpos); transform_set_quat(&cam, cq);
+            transform_set_pos(&W[k]->scene->camera->xform, cpos);
+            transform_view_mat4x4(&cam, W[k]->view.main.view_mx);
+            mat4x4_perspective_ndc_z_2(W[k]->view.main.proj_mx, 70.f * (float)M_PI / 180.f, 16.f / 9.f, 0.1f, 500.f);
+            subview_calc_frustum(&W[k]->view.main, NULL);
+            W[k]->scene->camera->bv = NULL;
+        }
+        const int anim_before = WA.e[0]->animation;
+        (void)anim_before;
+        gp_libc_state_set(WA.libc);
+        mq_update(&WA.scene->mq);                                       /* default_update -> animated_update per entity */
+        WA.libc = gp_libc_state_get();
+        gp_libc_state_set(WB.libc);
+        rc = gpu_mq_update(gs, &WB.scene->mq, &WB.view);
+        if (!rc) rc = gpu_anim_update(ga, gs, &WB.scene->mq, WB.scene);
+        WB.libc = gp_libc_state_get();
+        if (rc) { fprintf(stderr, "frame %u: binding failed: %d (%s)\n", f, rc, clapgpu_last_error()); return 2; }
+        if (WA.libc != WB.libc) { fprintf(stderr, "frame %u: drand48 stream position differs\n", f); bad++; }
+
+        for (uint32_t id = 0; id < n; id++) {
+            entity3d *a = WA.e[id], *b = WB.e[id];
+            int diff = 0;
+            diff |= !!memcmp(a->mx, b->mx, 64) << 0;
+            diff |= !!memcmp(a->aabb, b->aabb, sizeof(a->aabb)) << 1;
+            diff |= (a->seq != b->seq) << 2;
+            if (id < n_chars) {
+                diff |= (a->animation != b->animation || a->aniq.da.nr_el != b->aniq.da.nr_el) << 3;
+                diff |= !!memcmp(&a->ani_time, &b->ani_time, 8) << 4;
+                for (uint32_t j = 0; j < J; j++) {
+                    double err = rel_err(a->joints[j].translation, b->joints[j].translation, 3);
+                    const double e2 = rel_err(a->joints[j].rotation, b->joints[j].rotation, 4);
+                    const double e3 = rel_err(a->joints[j].scale, b->joints[j].scale, 3);
+                    err = err > e2 ? err : e2; err = err > e3 ? err : e3;
+                    if (reach[j]) {
+                        const double e4 = rel_err((const float *)a->joint_transforms[j], (const float *)b->joint_transforms[j], 16);
+                        const double e5 = rel_err(a->joints[j].pos, b->joints[j].pos, 4);
+                        err = err > e4 ? err : e4; err = err > e5 ? err : e5;
+                    } else {
+                        diff |= !!memcmp(a->joint_transforms[j], b->joint_transforms[j], 64) << 6;   /* untouched on both sides */
+                    }
+                    if (err > worst) worst = err;
+                    if (!(err <= 1e-5)) diff |= 1 << 5;
+                    posed++;
+                }
+            }
+            if (diff && bad++ < 8)
+                fprintf(stderr, "frame %u entity %u: mismatch mask 0x%x\n", f, id, diff);
+        }
+        for (uint32_t id = 0; id < n_chars; id++)
+            restarts += WA.e[id]->ani_time == dbl_now;                   /* animation_start this frame */
+    }
+    printf("{\"mode\": \"anim\", \"frames\": %u, \"characters\": %u, \"joints\": %u, \"joint_poses_compared\": %llu, "
+           "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
+           frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, worst, (unsigned long long)bad);
+    gpu_anim_done(ga);
+    gpu_scene_done(gs);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 6 && !strcmp(argv[1], "anim"))
+        return cmd_anim((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "particles"))
         return cmd_particles((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "test"))
         return cmd_test((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "bench"))
         return cmd_bench((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]));
-    fprintf(stderr, "usage: clap_dropin test <entities> <frames> <seed> | bench <entities> <frames> <dirty_permille> | particles <systems> <per_system> <frames> <seed>\n");
+    fprintf(stderr, "usage: clap_dropin test <entities> <frames> <seed> | bench <entities> <frames> <dirty_permille> | particles <systems> <per_system> <frames> <seed> | anim <characters> <joints> <frames> <seed>\n");
     return 2;
 }

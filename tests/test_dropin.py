@@ -9,6 +9,7 @@ update hook that must stay on the host) and compares mx, inverse_mx, aabb, aabb_
 parent_seq, xform.updated, the frustum verdict and the camera bounding-volume pick bit for bit
 after every frame.  The same binary checks the particle path (`particles` mode): the reference's particles_update
 hooks drawing from libc's drand48 against clap_amd/binding/gpu-particles.inc.c.
+`anim` mode does the same for skeletal animation (clap_amd/binding/gpu-anim.inc.c).
 The binary needs the reference tree to BUILD (here) and a GPU to RUN.
 """
 import json
@@ -63,6 +64,21 @@ def test_particle_binding_matches_reference_particles_update(n_sys, per_sys, fra
     r = _run("particles", n_sys, per_sys, frames, seed)
     assert r["mismatches"] == 0 and r["stream_draws_agree"] is True
     assert r["respawns"] > 0 and r["particle_structs_compared"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_chars,joints,frames,seed", [(5, 8, 6, 1), (200, 64, 12, 2), (3000, 40, 8, 3), (50, 200, 6, 4)])
+def test_animation_binding_matches_reference_animated_update(n_chars, joints, frames, seed):
+    """default_update -> animated_update per entity (reference: clock, queue, channels_transform,
+    one_joint_transform) vs gpu_mq_update + gpu_anim_update (binding -> HIP) on the reference's own model3d
+    (model3d_add_skinning, animation_new / _add_channel), entities from ref_new(entity3d) and queues from
+    animation_push_by_name: transforms bit for bit; joint_transforms, joint T/R/S and joint positions within
+    1e-5 of the largest magnitude; e->animation, the queue length, ani_time and the libc drand48 position (the
+    random idle phase of animation_next) exactly; joints outside joint 0's tree untouched on both sides."""
+    r = _run("anim", n_chars, joints, frames, seed)
+    assert r["mismatches"] == 0
+    assert r["worst_relative_error"] <= 1e-5
+    assert r["animation_restarts"] > 0 and r["joint_poses_compared"] == frames * n_chars * joints
 
 
 @pytest.mark.gpu
