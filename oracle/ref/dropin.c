@@ -10,8 +10,9 @@
  * parent_seq, xform.updated, the frustum verdict, and the camera bounding-volume pick.
  *
  * The reference sources are #include'd where they lie (see Makefile) to reach default_update;
- * nothing is copied.  Test doubles: the same three of harness.c that this path touches
- * (clap_get_render_options, clap_get_current_time, renderer_get_caps).
+ * nothing is copied.  Test doubles: the same four as harness.c (clap_get_render_options,
+ * clap_get_current_time, renderer_get_caps, texture_load -- see there for why each exists) and
+ * texture_loaded(), for the resizes of the `lights` mode.
  *
  * `particles`: the same for particle systems -- the reference's particles_update() hooks (particle.c:89)
  * drawing from libc's drand48 stream against gpu_particles_update() of clap_amd/binding/gpu-particles.inc.c:
@@ -22,15 +23,22 @@
  * clap_amd/binding/gpu-anim.inc.c: transforms bit for bit, joint_transforms / joint T,R,S / joint positions
  * to 1e-5 of the largest magnitude, queue state and ani_time exactly.
  *
+ * `lights`: light_grid_compute() (light.c:88-154) against gpu_light_grid_compute() of
+ * clap_amd/binding/gpu-light.inc.c on the reference's own `struct light`: the RGBA32UI tile masks handed to
+ * texture_load(), bit for bit, over random cameras, grids, slot sets and resizes.
+ *
  * Needs a GPU (libclapgpu).  Usage:
  *   clap_dropin test  <entities> <frames> <seed>     exit 0 = every frame identical
  *   clap_dropin bench <entities> <frames> <dirty_permille>
  *   clap_dropin particles <systems> <particles_per_system> <frames> <seed>
  *   clap_dropin anim <characters> <joints> <frames> <seed>
+ *   clap_dropin lights <frames> <seed>
  */
 #include "model.c"
 #include "gpu-anim.inc.c"               /* clap_amd/binding: lives at the end of model.c's translation unit */
 #include "view.c"
+#include "light.c"
+#include "gpu-light.inc.c"              /* clap_amd/binding: lives at the end of light.c's translation unit */
 #include "particle.c"
 #include "gpu-particles.inc.c"          /* clap_amd/binding: lives at the end of particle.c's translation unit */
 
@@ -51,6 +59,16 @@ static double dbl_now;                  /* the frame clock (clap.c is the frame 
 double clap_get_current_time(struct clap_context *ctx) { return dbl_now; }
 static renderer_caps dbl_caps;
 const renderer_caps *renderer_get_caps(renderer_t *r) { return &dbl_caps; }
+/* the sink light_grid_compute hands its finished masks to (render-gl.c needs GL headers): records the upload */
+static struct { texture_format format; unsigned int width, height; void *buf; int calls; } dbl_tex;
+/* light_grid_update asks whether the grid texture exists before resizing it (light.c:55-59; render-gl.c):
+ * the double answers "not yet", the state every run passes through before its first upload */
+bool texture_loaded(texture_t *tex) { return false; }
+cerr texture_load(texture_t *tex, texture_format format, unsigned int width, unsigned int height, void *buf)
+{
+    dbl_tex.format = format; dbl_tex.width = width; dbl_tex.height = height; dbl_tex.buf = buf; dbl_tex.calls++;
+    return CERR_OK;
+}
 
 static double now_s(void)
 {
@@ -741,8 +759,75 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
     return bad ? 1 : 0;
 }
 
+/* ---------------------------------------------------------------- light grid */
+static int cmd_lights(uint32_t frames, uint64_t seed)
+{
+    struct gpu_lights *gl;
+    int rc = gpu_lights_init(&gl, 0);
+    if (rc) { fprintf(stderr, "gpu_lights_init: %d\n", rc); return 2; }
+    static struct light LA, LB;                                     /* large (per-light views) */
+    struct light *L[2] = { &LA, &LB };
+    struct view view;
+    rng_state = seed;
+    for (int k = 0; k < 2; k++) {
+        memset(L[k], 0, sizeof(*L[k]));
+        bitmap_init(&L[k]->active, LIGHTS_MAX);
+    }
+    uint64_t bad = 0, bits = 0, tiles_total = 0;
+    for (uint32_t f = 0; f < frames; f++) {
+        /* the game: lights come, go and move; the window is resized now and then */
+        const uint32_t widths[4] = { 1920, 3840, 1280, 333 }, heights[4] = { 1080, 2160, 720, 777 }, cells[3] = { 16, 8, 32 };
+        const uint32_t wi = (f / 3) % 4, cell = cells[(f / 5) % 3];
+        const int nr = 1 + (int)rndn(LIGHTS_MAX);
+        for (int i = 0; i < LIGHTS_MAX; i++) {
+            const bool on = i < nr && rndn(5) != 0, dir = rndn(12) == 0;
+            float p[3] = { rndf(-60, 60), rndf(0, 12), rndf(-60, 60) }, c[3] = { rndf(0, 4), rndf(0, 4), rndf(0, 4) };
+            float a[3] = { 1.f, rndf(0.01f, 0.3f), rndf(0.001f, 0.2f) };
+            for (int k = 0; k < 2; k++) {
+                if (on) bitmap_set(&L[k]->active, i); else bitmap_clear(&L[k]->active, i);
+                L[k]->is_dir[i] = dir;
+                memcpy(&L[k]->pos[3 * i], p, 12); memcpy(&L[k]->color[3 * i], c, 12); memcpy(&L[k]->attenuation[3 * i], a, 12);
+            }
+        }
+        for (int k = 0; k < 2; k++) {
+            L[k]->nr_lights = nr;
+            L[k]->grid.width = widths[wi]; L[k]->grid.height = heights[wi]; L[k]->grid.cell = cell;
+        }
+        vec3 cpos = { rndf(-40, 40), rndf(1, 20), rndf(-40, 40) };
+        quat cq; quat_from_euler_xyz(cq, rndf(-0.8f, 0.3f), rndf(-3, 3), 0);
+        transform_t cam;
+        transform_init(&cam); transform_set_pos(&cam, cpos); transform_set_quat(&cam, cq);
+        memset(&view, 0, sizeof(view));
+        transform_view_mat4x4(&cam, view.main.view_mx);
+        mat4x4_perspective_ndc_z_2(view.main.proj_mx, 70.f * (float)M_PI / 180.f, (float)widths[wi] / heights[wi], 0.1f, 500.f);
+
+        dbl_tex.calls = 0;
+        light_grid_compute(&LA, &view);                              /* the reference */
+        const int calls_ref = dbl_tex.calls;
+        const unsigned int tw = dbl_tex.width, th = dbl_tex.height;
+        rc = gpu_light_grid_compute(gl, &LB, &view);                 /* the binding */
+        if (rc) { fprintf(stderr, "gpu_light_grid_compute: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+        const size_t ntiles = (size_t)LA.grid.twidth * LA.grid.theight;
+        int diff = 0;
+        diff |= (calls_ref != 1 || dbl_tex.calls != 2 || dbl_tex.format != TEX_FMT_RGBA32UI) << 0;
+        diff |= (LA.grid.twidth != LB.grid.twidth || LA.grid.theight != LB.grid.theight || tw != dbl_tex.width || th != dbl_tex.height) << 1;
+        diff |= (dbl_tex.buf != LB.grid.tiles) << 2;
+        if (!(diff & 2)) diff |= !!memcmp(LA.grid.tiles, LB.grid.tiles, ntiles * sizeof(ui32vec4)) << 3;
+        for (size_t t = 0; t < ntiles; t++)
+            for (int q = 0; q < 4; q++) bits += (uint64_t)__builtin_popcount(LA.grid.tiles[t].v[q]);
+        tiles_total += ntiles;
+        if (diff && bad++ < 8) fprintf(stderr, "frame %u (%ux%u cell %u, %d slots): mismatch mask 0x%x\n", f, widths[wi], heights[wi], cell, nr, diff);
+    }
+    printf("{\"mode\": \"lights\", \"frames\": %u, \"tiles_compared\": %llu, \"mask_bits_set\": %llu, \"mismatches\": %llu}\n",
+           frames, (unsigned long long)tiles_total, (unsigned long long)bits, (unsigned long long)bad);
+    gpu_lights_done(gl);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "lights"))
+        return cmd_lights((uint32_t)atoi(argv[2]), strtoull(argv[3], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "anim"))
         return cmd_anim((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "particles"))
@@ -751,6 +836,6 @@ int main(int argc, char **argv)
         return cmd_test((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "bench"))
         return cmd_bench((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]));
-    fprintf(stderr, "usage: clap_dropin test <entities> <frames> <seed> | bench <entities> <frames> <dirty_permille> | particles <systems> <per_system> <frames> <seed> | anim <characters> <joints> <frames> <seed>\n");
+    fprintf(stderr, "usage: clap_dropin test <entities> <frames> <seed> | bench <entities> <frames> <dirty_permille> | particles <systems> <per_system> <frames> <seed> | anim <characters> <joints> <frames> <seed> | lights <frames> <seed>\n");
     return 2;
 }

@@ -9,7 +9,8 @@ update hook that must stay on the host) and compares mx, inverse_mx, aabb, aabb_
 parent_seq, xform.updated, the frustum verdict and the camera bounding-volume pick bit for bit
 after every frame.  The same binary checks the particle path (`particles` mode): the reference's particles_update
 hooks drawing from libc's drand48 against clap_amd/binding/gpu-particles.inc.c.
-`anim` mode does the same for skeletal animation (clap_amd/binding/gpu-anim.inc.c).
+`anim` mode does the same for skeletal animation (clap_amd/binding/gpu-anim.inc.c), `lights` for the
+clustered-lighting masks (clap_amd/binding/gpu-light.inc.c).
 The binary needs the reference tree to BUILD (here) and a GPU to RUN.
 """
 import json
@@ -79,6 +80,16 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     assert r["mismatches"] == 0
     assert r["worst_relative_error"] <= 1e-5
     assert r["animation_restarts"] > 0 and r["joint_poses_compared"] == frames * n_chars * joints
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames,seed", [(30, 1), (60, 2)])
+def test_light_grid_binding_matches_reference_light_grid_compute(frames, seed):
+    """light_grid_compute on the reference's own struct light vs gpu_light_grid_compute (binding -> HIP): the
+    RGBA32UI masks handed to texture_load, the tile counts after resizes (1080p / 4K / 720p / an odd size at
+    8-, 16- and 32-pixel tiles) and the upload call itself."""
+    r = _run("lights", frames, seed)
+    assert r["mismatches"] == 0 and r["mask_bits_set"] > 0 and r["tiles_compared"] > 0
 
 
 @pytest.mark.gpu
