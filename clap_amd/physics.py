@@ -55,10 +55,24 @@ class PhysWorld:
             self.n_static = self.statics.shape[0]
 
     # ---- __phys_step pieces -----------------------------------------------------------
-    def broadphase(self):
-        """dSpaceCollide2(ground, bodies) + dSpaceCollide(bodies): candidate pair lists."""
+    def broadphase(self, side=None):
+        """dSpaceCollide2(ground, bodies) + dSpaceCollide(bodies): candidate pair lists.
+
+        side: a second stream.  The two passes read the same body state and write disjoint outputs, and both
+        are chains of small latency-bound launches, so with `side` the statics pass runs there (on its own
+        scratch) while the bodies pass runs on the current stream; world_step() joins before it moves bodies."""
         L = _lib.lib()
-        if self.n_static:
+        if self.n_static and side is not None:
+            if getattr(self, "scratch_static", None) is None:
+                self.scratch_static = torch.zeros_like(self.scratch)
+            side.wait_stream(torch.cuda.current_stream())        # the bodies are where the last step left them
+            with torch.cuda.stream(side):
+                _lib.check(L.clapgpu_broadphase_static_pairs(_stream(), C.byref(self._desc), self.n_static,
+                                                             _ptr(self.statics), _ptr(self.static_pairs), self.capacity,
+                                                             _ptr(self.static_pair_total), _ptr(self.scratch_static)),
+                           "clapgpu_broadphase_static_pairs")
+                self._static_done = side.record_event()
+        elif self.n_static:
             _lib.check(L.clapgpu_broadphase_static_pairs(_stream(), C.byref(self._desc), self.n_static,
                                                          _ptr(self.statics), _ptr(self.static_pairs), self.capacity,
                                                          _ptr(self.static_pair_total), _ptr(self.scratch)),
@@ -103,6 +117,10 @@ class PhysWorld:
         return self.contact_buf[:npairs].cpu().numpy().view(dtype).reshape(-1), int(self.contact_total.item())
 
     def world_step(self, h):
+        ev = getattr(self, "_static_done", None)
+        if ev is not None:                                   # the statics pass on the side stream still reads pos
+            torch.cuda.current_stream().wait_event(ev)
+            self._static_done = None
         _lib.check(_lib.lib().clapgpu_bodies_step(_stream(), C.byref(self._desc), C.byref(self.world), h),
                    "clapgpu_bodies_step")
 
