@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 OK = 0
 ERR_NOMEM = -1
@@ -181,6 +181,8 @@ SYMBOLS = {
                                                       C.c_uint32, C.c_void_p, C.c_void_p]),
     "clapgpu_contacts_spheres": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_contacts_sphere_box": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
     "clapgpu_characters_update": (C.c_int, [C.c_void_p, C.POINTER(Characters), C.POINTER(Entities),
                                             C.POINTER(Bodies)]),

@@ -546,12 +546,110 @@ void k_bodies_rotate_from_entities(uint32_t n_links, const uint32_t *link_body, 
     for (int a = 0; a < 4; a++) quat[4 * (size_t)b + a] = q[a] * l;
 }
 
-// dCollide for sphere pairs + phys_contact_surface (see include/clapgpu.h): one lane per candidate
-// pair; geometry as ODE's dCollideSpheres, IEEE fp64 (sqrt, divide), no contraction.
+// phys_contact_surface (physics.c:291-330) for the two colliders' parameter rows (NULL: defaults)
+__device__ __forceinline__ void contact_surface(clapgpu_contact &c, const double *m1, const double *m2)
+{
+    double bounce = 0, bounce_vel = 0, mu = 0, soft_erp = 0.05, soft_cfm = 0.01;   // physics.c:293-294
+    if (m1 && m2) {
+        bounce = fmax(m1[0], m2[0]);
+        bounce_vel = (m1[1] + m2[1]) * 0.5;
+        mu = sqrt(m1[2] * m2[2]);
+        if (m1[3] > 0 && m2[3] > 0) soft_erp = fmin(m1[3], m2[3]);
+        else if (m1[3] > 0) soft_erp = m1[3];
+        else if (m2[3] > 0) soft_erp = m2[3];
+        if (m1[4] > 0 && m2[4] > 0) soft_cfm = fmax(m1[4], m2[4]);
+        else if (m1[4] > 0) soft_cfm = m1[4];
+        else if (m2[4] > 0) soft_cfm = m2[4];
+    }
+    c.mode = CLAPGPU_CONTACT_SOFT_CFM | CLAPGPU_CONTACT_SOFT_ERP | (bounce > 0 ? CLAPGPU_CONTACT_BOUNCE : 0);
+    c.mu = mu; c.bounce = bounce; c.bounce_vel = bounce_vel; c.soft_erp = soft_erp; c.soft_cfm = soft_cfm;
+    c.nc = 1;
+}
+
+// ODE's dCollideSpheres
+__device__ __forceinline__ bool contact_sphere_sphere(clapgpu_contact &c, const double *p1, double r1, const double *p2,
+                                                      double r2)
+{
+    const double dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
+    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+    if (d > r1 + r2) return false;
+    if (d <= 0) {
+        c.pos[0] = p1[0]; c.pos[1] = p1[1]; c.pos[2] = p1[2];
+        c.normal[0] = 1; c.normal[1] = 0; c.normal[2] = 0;
+        c.depth = r1 + r2;
+    } else {
+        const double d1 = 1.0 / d;
+        c.normal[0] = dx * d1; c.normal[1] = dy * d1; c.normal[2] = dz * d1;
+        const double kk = 0.5 * (r2 - r1 - d);
+        c.pos[0] = p1[0] + c.normal[0] * kk;
+        c.pos[1] = p1[1] + c.normal[1] * kk;
+        c.pos[2] = p1[2] + c.normal[2] * kk;
+        c.depth = r1 + r2 - d;
+    }
+    return true;
+}
+
+// ODE's dCollideSphereBox for an axis-aligned box given as aabb[6] = (minx,maxx,miny,maxy,minz,maxz):
+// box position = centre, side = max - min, R = identity (oracle/physics.c has the restated algorithm)
+__device__ __forceinline__ bool contact_sphere_box(clapgpu_contact &c, const double *c0, double rad, const double *bb)
+{
+    double bp[3], l[3], p[3], t[3];
+    bool onborder = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        bp[a] = (bb[2 * a] + bb[2 * a + 1]) * 0.5;
+        l[a] = (bb[2 * a + 1] - bb[2 * a]) * 0.5;
+        p[a] = c0[a] - bp[a];
+        t[a] = p[a];
+        if (t[a] < -l[a]) { t[a] = -l[a]; onborder = true; }
+        if (t[a] > l[a]) { t[a] = l[a]; onborder = true; }
+    }
+    if (!onborder) {                                                // centre inside: push out through the closest face
+        double min_distance = l[0] - fabs(t[0]);
+        int mini = 0;
+#pragma unroll
+        for (int a = 1; a < 3; a++) {
+            const double face_distance = l[a] - fabs(t[a]);
+            if (face_distance < min_distance) { min_distance = face_distance; mini = a; }
+        }
+        c.pos[0] = c0[0]; c.pos[1] = c0[1]; c.pos[2] = c0[2];
+        const double sgn = t[mini] > 0 ? 1.0 : -1.0;
+        c.normal[0] = mini == 0 ? sgn : 0.0; c.normal[1] = mini == 1 ? sgn : 0.0; c.normal[2] = mini == 2 ? sgn : 0.0;
+        c.depth = min_distance + rad;
+        return true;
+    }
+    double r[3] = { p[0] - t[0], p[1] - t[1], p[2] - t[2] };
+    const double depth = rad - sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (depth < 0) return false;
+    c.pos[0] = t[0] + bp[0]; c.pos[1] = t[1] + bp[1]; c.pos[2] = t[2] + bp[2];
+    {                                                               // dSafeNormalize3
+        const double aa[3] = { fabs(r[0]), fabs(r[1]), fabs(r[2]) };
+        int idx = 0;
+        bool zero = false;
+        if (aa[1] > aa[0]) idx = aa[2] > aa[1] ? 2 : 1;
+        else if (aa[2] > aa[0]) idx = 2;
+        else zero = aa[0] <= 0;
+        if (zero) { r[0] = 1; r[1] = 0; r[2] = 0; }
+        else {
+            const double m = idx == 0 ? aa[0] : idx == 1 ? aa[1] : aa[2];
+            r[0] /= m; r[1] /= m; r[2] /= m;
+            const double k = 1.0 / sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            r[0] *= k; r[1] *= k; r[2] *= k;
+        }
+    }
+    c.normal[0] = r[0]; c.normal[1] = r[1]; c.normal[2] = r[2];
+    c.depth = depth;
+    return true;
+}
+
+// near_callback's dCollide + phys_contact_surface (see include/clapgpu.h): one lane per candidate pair,
+// IEEE fp64 (sqrt, divide), no contraction.  BOX = false: (body, body) sphere pairs; BOX = true: (body,
+// static box) pairs, `other` = static_aabb, `other_material` = the static colliders' parameter rows.
+template <bool BOX>
 __global__ __launch_bounds__(PHYS_BLOCK)
-void k_contacts_spheres(const double *pos, const double *radius, uint32_t n_bodies, const uint2 *pairs,
-                        const uint32_t *pair_total, uint32_t capacity, const double *material,
-                        clapgpu_contact *out, uint32_t *contact_total)
+void k_contacts(const double *pos, const double *radius, uint32_t n_bodies, const double *other, uint32_t n_other,
+                const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity, const double *material,
+                const double *other_material, clapgpu_contact *out, uint32_t *contact_total)
 {
     __shared__ __attribute__((aligned(16))) double recs[PHYS_BLOCK / WAVE][WAVE * 13];
     static_assert(sizeof(clapgpu_contact) == 13 * sizeof(double), "contact record layout");
@@ -567,42 +665,17 @@ void k_contacts_spheres(const double *pos, const double *radius, uint32_t n_bodi
         const uint2 pr = pairs[k];
         clapgpu_contact c;
         memset(&c, 0, sizeof(c));
-        if (pr.x < n_bodies && pr.y < n_bodies) {
-            const double *p1 = pos + 3 * (size_t)pr.x, *p2 = pos + 3 * (size_t)pr.y;
-            const double r1 = radius[pr.x], r2 = radius[pr.y];
-            const double dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
-            const double d = sqrt(dx * dx + dy * dy + dz * dz);
-            if (!(d > r1 + r2)) {
-                touch = true;
-                if (d <= 0) {
-                    c.pos[0] = p1[0]; c.pos[1] = p1[1]; c.pos[2] = p1[2];
-                    c.normal[0] = 1; c.normal[1] = 0; c.normal[2] = 0;
-                    c.depth = r1 + r2;
-                } else {
-                    const double d1 = 1.0 / d;
-                    c.normal[0] = dx * d1; c.normal[1] = dy * d1; c.normal[2] = dz * d1;
-                    const double kk = 0.5 * (r2 - r1 - d);
-                    c.pos[0] = p1[0] + c.normal[0] * kk;
-                    c.pos[1] = p1[1] + c.normal[1] * kk;
-                    c.pos[2] = p1[2] + c.normal[2] * kk;
-                    c.depth = r1 + r2 - d;
-                }
-                double bounce = 0, bounce_vel = 0, mu = 0, soft_erp = 0.05, soft_cfm = 0.01;   // physics.c:293-294
-                if (material) {
-                    const double *m1 = material + 5 * (size_t)pr.x, *m2 = material + 5 * (size_t)pr.y;
-                    bounce = fmax(m1[0], m2[0]);
-                    bounce_vel = (m1[1] + m2[1]) * 0.5;
-                    mu = sqrt(m1[2] * m2[2]);
-                    if (m1[3] > 0 && m2[3] > 0) soft_erp = fmin(m1[3], m2[3]);
-                    else if (m1[3] > 0) soft_erp = m1[3];
-                    else if (m2[3] > 0) soft_erp = m2[3];
-                    if (m1[4] > 0 && m2[4] > 0) soft_cfm = fmax(m1[4], m2[4]);
-                    else if (m1[4] > 0) soft_cfm = m1[4];
-                    else if (m2[4] > 0) soft_cfm = m2[4];
-                }
-                c.mode = CLAPGPU_CONTACT_SOFT_CFM | CLAPGPU_CONTACT_SOFT_ERP | (bounce > 0 ? CLAPGPU_CONTACT_BOUNCE : 0);
-                c.mu = mu; c.bounce = bounce; c.bounce_vel = bounce_vel; c.soft_erp = soft_erp; c.soft_cfm = soft_cfm;
-                c.nc = 1;
+        if (pr.x < n_bodies && pr.y < (BOX ? n_other : n_bodies)) {
+            if (BOX) {
+                touch = contact_sphere_box(c, pos + 3 * (size_t)pr.x, radius[pr.x], other + 6 * (size_t)pr.y);
+                if (touch)
+                    contact_surface(c, material && other_material ? material + 5 * (size_t)pr.x : nullptr,
+                                    material && other_material ? other_material + 5 * (size_t)pr.y : nullptr);
+            } else {
+                touch = contact_sphere_sphere(c, pos + 3 * (size_t)pr.x, radius[pr.x], pos + 3 * (size_t)pr.y, radius[pr.y]);
+                if (touch)
+                    contact_surface(c, material ? material + 5 * (size_t)pr.x : nullptr,
+                                    material ? material + 5 * (size_t)pr.y : nullptr);
             }
         }
         // the 104-byte records of a wave are contiguous in memory: stage them in LDS and write the run as
@@ -833,10 +906,32 @@ extern "C" int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, c
         return CLAPGPU_OK;
     // the pair count lives on the device: launch for the capacity, lanes past the count retire at once
     const uint32_t blocks = (capacity + PHYS_BLOCK - 1) / PHYS_BLOCK;
-    hipLaunchKernelGGL(k_contacts_spheres, dim3(blocks < 512 ? blocks : 512), dim3(PHYS_BLOCK), 0, s,
-                       b->pos, b->radius, b->n, reinterpret_cast<const uint2 *>(pairs), pair_total, capacity,
-                       material, contacts, contact_total);
-    CLAPGPU_LAUNCH_CHECK("k_contacts_spheres");
+    hipLaunchKernelGGL(k_contacts<false>, dim3(blocks < 512 ? blocks : 512), dim3(PHYS_BLOCK), 0, s,
+                       b->pos, b->radius, b->n, nullptr, 0u, reinterpret_cast<const uint2 *>(pairs), pair_total, capacity,
+                       material, nullptr, contacts, contact_total);
+    CLAPGPU_LAUNCH_CHECK("k_contacts<spheres>");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_contacts_sphere_box(void *stream, const clapgpu_bodies *b, uint32_t n_static,
+                                           const double *static_aabb, const uint32_t *pairs, const uint32_t *pair_total,
+                                           uint32_t capacity, const double *material, const double *static_material,
+                                           clapgpu_contact *contacts, uint32_t *contact_total)
+{
+    int rc = check_bodies(b);
+    if (rc) return rc;
+    if (!pair_total || (n_static && !static_aabb) || (capacity && (!pairs || !contacts)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    hipStream_t s = as_stream(stream);
+    if (contact_total)
+        CLAPGPU_HIP(hipMemsetAsync(contact_total, 0, sizeof(uint32_t), s));
+    if (capacity == 0 || b->n == 0 || n_static == 0)
+        return CLAPGPU_OK;
+    const uint32_t blocks = (capacity + PHYS_BLOCK - 1) / PHYS_BLOCK;
+    hipLaunchKernelGGL(k_contacts<true>, dim3(blocks < 512 ? blocks : 512), dim3(PHYS_BLOCK), 0, s,
+                       b->pos, b->radius, b->n, static_aabb, n_static, reinterpret_cast<const uint2 *>(pairs), pair_total,
+                       capacity, material, static_material, contacts, contact_total);
+    CLAPGPU_LAUNCH_CHECK("k_contacts<sphere_box>");
     return CLAPGPU_OK;
 }
 

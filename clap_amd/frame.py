@@ -79,6 +79,8 @@ class FrameLoop:
                 w.broadphase(side)
                 if self.contacts:
                     w.contacts()
+                    if w.n_static:
+                        w.contacts_static()
                 w.world_step(1.0 / 120.0)
         if self.feed is not None:                           # character_update hooks
             self.feed.character_update(b, w)

@@ -111,6 +111,28 @@ class PhysWorld:
                                                        _ptr(self.contact_buf), _ptr(self.contact_total)),
                    "clapgpu_contacts_spheres")
 
+    def contacts_static(self, static_material=None):
+        """near_callback on the (body, static box) candidate pairs of the last broadphase(): ODE's
+        dCollideSphereBox + phys_contact_surface, one record per pair."""
+        if getattr(self, "static_contact_buf", None) is None:
+            self.static_contact_buf = torch.zeros((self.capacity, 104), dtype=torch.uint8, device=self.device)
+            self.static_contact_total = torch.zeros(1, dtype=torch.int32, device=self.device)
+        if static_material is not None:
+            self.static_material = torch.from_numpy(np.ascontiguousarray(static_material, np.float64)).to(self.device)
+        mat, smat = getattr(self, "material", None), getattr(self, "static_material", None)
+        _lib.check(_lib.lib().clapgpu_contacts_sphere_box(_stream(), C.byref(self._desc), self.n_static,
+                                                          _ptr(self.statics), _ptr(self.static_pairs),
+                                                          _ptr(self.static_pair_total), self.capacity, _ptr(mat),
+                                                          _ptr(smat), _ptr(self.static_contact_buf),
+                                                          _ptr(self.static_contact_total)),
+                   "clapgpu_contacts_sphere_box")
+
+    def download_static_contacts(self, dtype):
+        torch.cuda.synchronize(self.device)
+        npairs = min(int(self.static_pair_total.item()), self.capacity)
+        return (self.static_contact_buf[:npairs].cpu().numpy().view(dtype).reshape(-1),
+                int(self.static_contact_total.item()))
+
     def download_contacts(self, dtype):
         torch.cuda.synchronize(self.device)
         npairs = min(int(self.pair_total.item()), self.capacity)

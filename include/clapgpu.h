@@ -542,6 +542,19 @@ typedef struct clapgpu_contact {
 int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, const uint32_t *pairs,
                              const uint32_t *pair_total, uint32_t capacity, const double *material,
                              clapgpu_contact *contacts, uint32_t *contact_total);
+/*
+ * The same for the (body, static geom) candidate pairs of clapgpu_broadphase_static_pairs: dCollide of a
+ * sphere (g1) against an axis-aligned box (g2) -- ODE's dCollideSphereBox with the box given as static_aabb[s]
+ * (position = centre, side = max - min, no rotation): the sphere centre clamped to the box, contact at the
+ * clamped point with the normal from the box to the sphere, or, for a centre inside the box, at the
+ * centre with the normal through the closest face and depth = distance to that face + radius.
+ * static_material[s] = the static collider's phys_body parameters (same 5 doubles); surface defaults
+ * unless both material arrays are given (phys_contact_surface needs both phys bodies, physics.c:296).
+ */
+int clapgpu_contacts_sphere_box(void *stream, const clapgpu_bodies *b, uint32_t n_static,
+                                const double *static_aabb, const uint32_t *pairs, const uint32_t *pair_total,
+                                uint32_t capacity, const double *material, const double *static_material,
+                                clapgpu_contact *contacts, uint32_t *contact_total);
 
 /* ======================================================================== */
 /* Characters: the feeder in front of default_update (core/character.c)      */

@@ -125,6 +125,8 @@ def _declare(L):
     L.clapo_bodies_rotate_from_entities.argtypes = [C.c_uint32, U32P, U32P, F32P, I32P, U8P, F64P]
     L.clapo_contacts_spheres.argtypes = [C.c_uint32, U32P, F64P, F64P, C.c_void_p, C.c_void_p]
     L.clapo_contacts_spheres.restype = C.c_uint32
+    L.clapo_contacts_sphere_box.argtypes = [C.c_uint32, U32P, F64P, F64P, F64P, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clapo_contacts_sphere_box.restype = C.c_uint32
     L.clapo_light_radius.argtypes = [F32P, F32P, C.c_int]
     L.clapo_light_radius.restype = C.c_float
     L.clapo_light_grid_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, U32P, U32P]
@@ -397,6 +399,20 @@ def contacts_spheres(pairs, pos, radius, material=None):
     total = lib().clapo_contacts_spheres(len(pairs), pairs.ravel(), np.ascontiguousarray(pos, np.float64),
                                          np.ascontiguousarray(radius, np.float64),
                                          None if mat is None else mat.ctypes.data, out.ctypes.data)
+    return out, int(total)
+
+
+def contacts_sphere_box(pairs, pos, radius, static_aabb, material=None, static_material=None):
+    """The same for (body, static box) pairs: ODE's dCollideSphereBox restated + phys_contact_surface."""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    out = np.zeros(len(pairs), CONTACT_DTYPE)
+    mat = None if material is None else np.ascontiguousarray(material, np.float64)
+    smat = None if static_material is None else np.ascontiguousarray(static_material, np.float64)
+    total = lib().clapo_contacts_sphere_box(len(pairs), pairs.ravel(), np.ascontiguousarray(pos, np.float64),
+                                            np.ascontiguousarray(radius, np.float64),
+                                            np.ascontiguousarray(static_aabb, np.float64),
+                                            None if mat is None else mat.ctypes.data,
+                                            None if smat is None else smat.ctypes.data, out.ctypes.data)
     return out, int(total)
 
 

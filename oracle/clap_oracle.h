@@ -249,6 +249,10 @@ typedef struct clapo_contact {
 } clapo_contact;
 uint32_t clapo_contacts_spheres(uint32_t n_pairs, const uint32_t *pairs, const double *pos, const double *radius,
                                 const double *material, clapo_contact *out);
+/* the same for (sphere body, static axis-aligned box) pairs: ODE's dCollideSphereBox, restated (PARITY UNPINNED) */
+uint32_t clapo_contacts_sphere_box(uint32_t n_pairs, const uint32_t *pairs, const double *pos, const double *radius,
+                                   const double *static_aabb, const double *material, const double *static_material,
+                                   clapo_contact *out);
 
 /* ---- clustered-lighting tile masks (light.c:88-154, 301-309; light.c) ---- */
 float clapo_light_radius(const float color[3], const float att[3], int is_dir);

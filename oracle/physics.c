@@ -295,6 +295,95 @@ uint32_t clapo_contacts_spheres(uint32_t n_pairs, const uint32_t *pairs, const d
     return total;
 }
 
+/*
+ * near_callback for (sphere body, static box) candidate pairs (physics.c:399-449 after
+ * dSpaceCollide2(ground, bodies), physics.c:751): ODE's dCollideSphereBox (ode/src/sphere.cpp) for an
+ * axis-aligned box given as ODE's aabb[6] = (minx,maxx,miny,maxy,minz,maxz) -- box position = its centre,
+ * side = max - min, R = identity -- followed by phys_contact_surface (physics.c:291-330) with the parameters
+ * of the body and of the static collider.  g1 = sphere, g2 = box, so the normal points from the box to the
+ * sphere.  PARITY UNPINNED: ODE is not part of the reference tree; the algorithm is restated from ODE 0.16:
+ *   p = c - boxpos;  t = clamp(p, -l, l) per axis, l = side / 2, onborder = any clamp happened;
+ *   centre inside (not onborder): the face with the smallest l_i - |t_i| (first on ties): pos = c,
+ *       normal = +-e_i (sign of t_i, +1 only if t_i > 0), depth = that distance + radius;
+ *   else r = p - t, depth = radius - |r|, no contact if depth < 0; pos = t + boxpos, normal =
+ *       dSafeNormalize3(r): scaled by its largest |component| first, then by 1/sqrt(sum of squares); (1,0,0) if r = 0.
+ */
+static void clapo_safe_normalize3(double a[3])
+{
+    const double aa[3] = { fabs(a[0]), fabs(a[1]), fabs(a[2]) };
+    int idx;
+    if (aa[1] > aa[0]) idx = aa[2] > aa[1] ? 2 : 1;
+    else if (aa[2] > aa[0]) idx = 2;
+    else {
+        if (aa[0] <= 0) { a[0] = 1; a[1] = 0; a[2] = 0; return; }
+        idx = 0;
+    }
+    a[0] /= aa[idx]; a[1] /= aa[idx]; a[2] /= aa[idx];
+    const double l = 1.0 / sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    a[0] *= l; a[1] *= l; a[2] *= l;
+}
+
+uint32_t clapo_contacts_sphere_box(uint32_t n_pairs, const uint32_t *pairs, const double *pos, const double *radius,
+                                   const double *static_aabb, const double *material, const double *static_material,
+                                   clapo_contact *out)
+{
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < n_pairs; k++) {
+        const uint32_t i = pairs[2 * k], s = pairs[2 * k + 1];
+        const double *c0 = pos + 3 * (size_t)i, *bb = static_aabb + 6 * (size_t)s;
+        const double rad = radius[i];
+        clapo_contact *c = out + k;
+        memset(c, 0, sizeof(*c));
+        double bp[3], l[3], p[3], t[3];
+        int onborder = 0;
+        for (int a = 0; a < 3; a++) {
+            bp[a] = (bb[2 * a] + bb[2 * a + 1]) * 0.5;
+            l[a] = (bb[2 * a + 1] - bb[2 * a]) * 0.5;
+            p[a] = c0[a] - bp[a];
+            t[a] = p[a];
+            if (t[a] < -l[a]) { t[a] = -l[a]; onborder = 1; }
+            if (t[a] > l[a]) { t[a] = l[a]; onborder = 1; }
+        }
+        if (!onborder) {
+            double min_distance = l[0] - fabs(t[0]);
+            int mini = 0;
+            for (int a = 1; a < 3; a++) {
+                const double face_distance = l[a] - fabs(t[a]);
+                if (face_distance < min_distance) { min_distance = face_distance; mini = a; }
+            }
+            c->pos[0] = c0[0]; c->pos[1] = c0[1]; c->pos[2] = c0[2];
+            c->normal[mini] = t[mini] > 0 ? 1.0 : -1.0;
+            c->depth = min_distance + rad;
+        } else {
+            double r[3] = { p[0] - t[0], p[1] - t[1], p[2] - t[2] };
+            const double depth = rad - sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            if (depth < 0) continue;
+            c->pos[0] = t[0] + bp[0]; c->pos[1] = t[1] + bp[1]; c->pos[2] = t[2] + bp[2];
+            clapo_safe_normalize3(r);
+            c->normal[0] = r[0]; c->normal[1] = r[1]; c->normal[2] = r[2];
+            c->depth = depth;
+        }
+        double bounce = 0, bounce_vel = 0, mu = 0, soft_erp = 0.05, soft_cfm = 0.01;
+        if (material && static_material) {
+            const double *m1 = material + 5 * (size_t)i, *m2 = static_material + 5 * (size_t)s;
+            bounce = fmax(m1[0], m2[0]);
+            bounce_vel = (m1[1] + m2[1]) * 0.5;
+            mu = sqrt(m1[2] * m2[2]);
+            if (m1[3] > 0 && m2[3] > 0) soft_erp = fmin(m1[3], m2[3]);
+            else if (m1[3] > 0) soft_erp = m1[3];
+            else if (m2[3] > 0) soft_erp = m2[3];
+            if (m1[4] > 0 && m2[4] > 0) soft_cfm = fmax(m1[4], m2[4]);
+            else if (m1[4] > 0) soft_cfm = m1[4];
+            else if (m2[4] > 0) soft_cfm = m2[4];
+        }
+        c->mode = CLAPO_CONTACT_SOFT_CFM | CLAPO_CONTACT_SOFT_ERP | (bounce > 0 ? CLAPO_CONTACT_BOUNCE : 0);
+        c->mu = mu; c->bounce = bounce; c->bounce_vel = bounce_vel; c->soft_erp = soft_erp; c->soft_cfm = soft_cfm;
+        c->nc = 1;
+        total++;
+    }
+    return total;
+}
+
 
 /*
  * default_update -> phys_body_rotate_xform (model.c:1680-1687, physics.c:136-145): entity rotation

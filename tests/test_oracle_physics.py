@@ -116,3 +116,58 @@ def test_sphere_contact_restatement_properties():
     k = np.flatnonzero(hit & (pairs[:, 0] % 2 == 0) & (pairs[:, 1] % 2 == 1))[0]
     assert c2["bounce"][k] == 0.5 and c2["bounce_vel"][k] == 0.2 and c2["mu"][k] == np.sqrt(0.4 * 0.9)
     assert c2["soft_erp"][k] == 0.1 and c2["soft_cfm"][k] == 0.02 and c2["mode"][k] == 0x1c
+
+
+def test_sphere_box_contact_restatement_properties():
+    """dCollideSphereBox for axis-aligned boxes + phys_contact_surface restated (parity unpinned: ODE absent):
+    invariants against an independent numpy formulation (closest point on the box)."""
+    rng = np.random.Generator(np.random.PCG64(12))
+    n, ns = 6000, 40
+    lo = rng.uniform(-10, 8, (ns, 3))
+    hi = lo + rng.uniform(0.5, 6, (ns, 3))
+    aabb = np.stack([lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1], lo[:, 2], hi[:, 2]], 1)
+    pos = rng.uniform(-12, 12, (n, 3))
+    radius = rng.uniform(0.1, 1.5, n)
+    pairs = np.stack([rng.integers(0, n, 20000), rng.integers(0, ns, 20000)], 1).astype(np.uint32)
+    # special cases: a centre exactly on a face, exactly on a corner, exactly in the middle of a cube, grazing contact
+    pos[0] = [hi[0, 0], (lo[0, 1] + hi[0, 1]) / 2, (lo[0, 2] + hi[0, 2]) / 2]
+    pos[1] = hi[1]
+    lo[2] = [0, 0, 0]; hi[2] = [2, 2, 2]; aabb[2] = [0, 2, 0, 2, 0, 2]; pos[2] = [1, 1, 1]
+    pos[3] = [hi[3, 0] + radius[3], (lo[3, 1] + hi[3, 1]) / 2, (lo[3, 2] + hi[3, 2]) / 2]
+    pairs[:4] = [[0, 0], [1, 1], [2, 2], [3, 3]]
+    c, total = ob.contacts_sphere_box(pairs, pos, radius, aabb)
+    hit = c["nc"] == 1
+    P, R = pos[pairs[:, 0]], radius[pairs[:, 0]]
+    LO, HI = lo[pairs[:, 1]], hi[pairs[:, 1]]
+    closest = np.clip(P, LO, HI)
+    dist = np.linalg.norm(P - closest, axis=1)
+    inside = np.all((P >= LO) & (P <= HI), axis=1)
+    assert total == hit.sum() and 0 < total < len(pairs)
+    far = dist > R + 1e-9
+    near = dist < R - 1e-9
+    assert not hit[far & ~inside].any() and hit[near | inside].all()
+    out = hit & ~inside
+    assert np.allclose(c["depth"][out], (R - dist)[out], atol=1e-12) and np.all(c["depth"][hit] >= 0)
+    assert np.allclose(c["pos"][out], closest[out], atol=1e-12)
+    nz = out & (dist > 1e-9)
+    assert np.allclose(c["normal"][nz], ((P - closest) / np.maximum(dist, 1e-300)[:, None])[nz], atol=1e-12)
+    assert np.allclose(np.linalg.norm(c["normal"][hit], axis=1), 1.0, atol=1e-12)
+    ins = hit & inside
+    face = np.minimum(P - LO, HI - P)[ins]                  # distance to the faces, per axis
+    assert np.allclose(c["depth"][ins], face.min(axis=1) + R[ins], atol=1e-12)
+    assert np.all(np.abs(c["normal"][ins]).sum(axis=1) == 1.0) and np.array_equal(c["pos"][ins], P[ins])
+    # the named cases
+    assert c["nc"][0] == 1 and c["depth"][0] == radius[0] and tuple(c["normal"][0]) == (1.0, 0.0, 0.0)   # on a face: inside branch
+    assert c["nc"][1] == 1 and c["depth"][1] == radius[1]
+    assert c["nc"][2] == 1 and tuple(c["normal"][2]) == (-1.0, 0.0, 0.0) and c["depth"][2] == 1.0 + radius[2]   # ties: first axis, t = 0 -> -1
+    assert c["nc"][3] == 1 and abs(c["depth"][3]) < 1e-12
+    assert np.all(c["mode"][hit] == 0x18) and np.all(c["soft_erp"][hit] == 0.05) and np.all(c["soft_cfm"][hit] == 0.01)
+    assert not c[~hit].tobytes().strip(b"\0"), "non-touching pairs leave a zero record"
+    mat = np.tile(np.asarray([0.5, 0.1, 0.9, 0.0, 0.0]), (n, 1))
+    smat = np.tile(np.asarray([0.2, 0.3, 0.4, 0.1, 0.02]), (ns, 1))
+    c2, _ = ob.contacts_sphere_box(pairs, pos, radius, aabb, mat, smat)
+    k = int(np.flatnonzero(hit)[0])
+    assert c2["bounce"][k] == 0.5 and c2["bounce_vel"][k] == 0.2 and c2["mu"][k] == np.sqrt(0.9 * 0.4)
+    assert c2["soft_erp"][k] == 0.1 and c2["soft_cfm"][k] == 0.02 and c2["mode"][k] == 0x1c
+    c3, _ = ob.contacts_sphere_box(pairs, pos, radius, aabb, mat, None)      # one side without parameters: defaults
+    assert c3["mu"][k] == 0.0 and c3["mode"][k] == 0x18

@@ -203,6 +203,40 @@ def test_sphere_contacts_match_oracle(cuda_device):
             assert len(np.unique(got["mode"][got["nc"] == 1])) == 2, "with and without dContactBounce"
 
 
+def test_sphere_box_contacts_match_restatement(cuda_device):
+    """(body, static box) narrowphase: dCollideSphereBox + phys_contact_surface, every field bit-exact against
+    the restatement, over the statics broadphase's own candidate pairs."""
+    from clap_amd import physics
+    n = 30_000
+    b = synth.sphere_bodies(n, box=24.0, seed=41)
+    statics = synth.static_boxes(48, 24.0)
+    lo, hi = statics[:, 0::2], statics[:, 1::2]
+    b["pos"][5] = (lo[0] + hi[0]) / 2                       # a centre in the middle of a box
+    b["pos"][6] = hi[1]                                     # exactly on a corner
+    b["pos"][7] = [hi[2, 0], (lo[2, 1] + hi[2, 1]) / 2, (lo[2, 2] + hi[2, 2]) / 2]   # exactly on a face
+    rng = np.random.Generator(np.random.PCG64(5))
+    mat = np.stack([rng.choice([0.0, 0.3, 0.8], n), rng.uniform(0, 0.2, n), rng.uniform(0.1, 1.5, n),
+                    rng.choice([0.0, 0.02, 0.2], n), rng.choice([0.0, 0.005, 0.05], n)], 1)
+    smat = np.stack([rng.choice([0.0, 0.5], 48), rng.uniform(0, 0.2, 48), rng.uniform(0.1, 1.5, 48),
+                     rng.choice([0.0, 0.1], 48), rng.choice([0.0, 0.03], 48)], 1)
+    for material, static_material in ((None, None), (mat, smat)):
+        world = physics.PhysWorld(b, statics, pair_capacity=8 * n, device=cuda_device)
+        if material is not None:
+            world.set_materials(material)
+        world.broadphase()
+        world.contacts_static(static_material)
+        got, total = world.download_static_contacts(ob.CONTACT_DTYPE)
+        pairs = world.download()["static_pairs"]
+        exp, exp_total = ob.contacts_sphere_box(pairs, b["pos"], b["radius"], statics, material, static_material)
+        assert len(got) == len(pairs) and total == exp_total
+        assert 0 < exp_total < len(pairs), "sphere-AABB overlap without sphere-box contact exists in the sample"
+        assert got.tobytes() == exp.tobytes(), "contact records, every field bit-exact"
+        inside = (np.abs(got["normal"]).sum(axis=1) == 1.0) & (got["nc"] == 1)
+        assert inside.any() and (~inside & (got["nc"] == 1)).any(), "both branches of dCollideSphereBox were taken"
+        if material is not None:
+            assert len(np.unique(got["mode"][got["nc"] == 1])) == 2, "with and without dContactBounce"
+
+
 def test_sphere_contacts_empty_and_truncated(cuda_device):
     from clap_amd import physics
     b = synth.sphere_bodies(3000, box=6.0, seed=6)
