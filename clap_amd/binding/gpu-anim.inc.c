@@ -98,7 +98,7 @@ static int ga_model_build(struct ga_model *m, model3d *model)
 
     int32_t *parent = malloc(J * 4), *depth = malloc(J * 4);
     float *invmx = malloc((size_t)J * 64), *bind = malloc((size_t)J * 64);
-    if (!parent || !depth || !invmx || !bind) return _CERR_NOMEM;
+    if (!parent || !depth || !invmx || !bind) { free(parent); free(depth); free(invmx); free(bind); return _CERR_NOMEM; }
     for (uint32_t j = 0; j < J; j++) { parent[j] = -1; depth[j] = -1; }
     for (uint32_t j = 0; j < J; j++) {                        /* model_joint.children, inverted */
         int *c;
@@ -130,7 +130,10 @@ static int ga_model_build(struct ga_model *m, model3d *model)
         }
     uint32_t *table = calloc((size_t)(A ? A : 1) * J * 3 * 4, 4);
     float *times = malloc((n_times ? n_times : 1) * 4), *data = malloc((n_data ? n_data : 1) * 4);
-    if (!table || !times || !data) return _CERR_NOMEM;
+    if (!table || !times || !data) {
+        free(parent); free(depth); free(invmx); free(bind); free(table); free(times); free(data);
+        return _CERR_NOMEM;
+    }
     size_t t_at = 0, d_at = 0;
     for (uint32_t a = 0; a < A; a++)
         for (unsigned int ch = 0; ch < model->anis.x[a].nr_channels; ch++) {

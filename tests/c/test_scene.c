@@ -69,9 +69,20 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
     clapo_entities_update(n, ps, rot, parent, model, &model_aabb[0][0], model_skip, flags, seqs, mx, inv, aabb, ctr);
     (void)o_mx_keep; (void)o_inv; (void)o_aabb; (void)o_ctr; (void)o_seqs; (void)o_flags_dirty;
     uint32_t vis_exp = 0;
+    clapgpu_scene_arrays res;                            /* the bulk form a binding scatters from */
+    static uint32_t last_layout = 0xffffffffu;
+    if (clapgpu_scene_results(s, &res) || res.n_slots != clapgpu_scene_slot_count(s)) return fail("clapgpu_scene_results", 0);
+    const uint32_t layout = clapgpu_scene_layout_generation(s);
+    if (last_layout != 0xffffffffu && layout < last_layout) return fail("layout generation went backwards", layout);
+    last_layout = layout;
     for (uint32_t k = 0; k < n; k++) {
         const struct host_ent *e = &ents[order[k]];
         const float *g;
+        const uint32_t slot = clapgpu_scene_entity_slot(s, e->handle);
+        if (slot >= res.n_slots) return fail("entity slot", order[k]);
+        if (memcmp(res.mx + 16 * (size_t)slot, mx + 16 * k, 64) || memcmp(res.inverse_mx + 16 * (size_t)slot, inv + 16 * k, 64) ||
+            memcmp(res.aabb + 6 * (size_t)slot, aabb + 6 * k, 24) || memcmp(res.aabb_center + 3 * (size_t)slot, ctr + 3 * k, 12))
+            return fail("bulk result arrays", order[k]);
         if (!(g = clapgpu_scene_entity_mx(s, e->handle)) || memcmp(g, mx + 16 * k, 64)) return fail("mx", order[k]);
         if (!(g = clapgpu_scene_entity_inverse_mx(s, e->handle)) || memcmp(g, inv + 16 * k, 64)) return fail("inverse_mx", order[k]);
         if (!(g = clapgpu_scene_entity_aabb(s, e->handle)) || memcmp(g, aabb + 6 * k, 24)) return fail("aabb", order[k]);
@@ -79,6 +90,7 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
         int exp = (e->flags & CLAPO_E_VISIBLE) &&
                   ((e->flags & CLAPO_E_SKIP_CULLING) || clapo_aabb_in_frustum((const clapo_frustum *)fr, aabb + 6 * k));
         if (clapgpu_scene_entity_in_frustum(s, e->handle) != exp) return fail("view_entity_in_frustum", order[k]);
+        if ((int)((res.vis_mask[slot >> 6] >> (slot & 63)) & 1) != exp) return fail("bulk visibility mask", order[k]);
         if (clapgpu_scene_entity_user(s, e->handle) != (void *)e) return fail("user pointer", order[k]);
         vis_exp += exp;
     }
@@ -98,8 +110,10 @@ static int add_entity(clapgpu_scene *s, uint32_t parent_idx)
     e->live = 1;
     rand_trs(e, parent_idx != UINT32_MAX);
     if (clapgpu_scene_entity_new(s, e->model, e, &e->handle)) return 1;
-    if (clapgpu_scene_entity_position(s, e->handle, e->ps) || clapgpu_scene_entity_rotation(s, e->handle, e->rot) ||
-        clapgpu_scene_entity_scale(s, e->handle, e->ps[3])) return 1;
+    if (n_ents & 1) {                                    /* the one-call form of the three pushes below */
+        if (clapgpu_scene_entity_transform(s, e->handle, e->ps, e->rot, e->ps[3])) return 1;
+    } else if (clapgpu_scene_entity_position(s, e->handle, e->ps) || clapgpu_scene_entity_rotation(s, e->handle, e->rot) ||
+               clapgpu_scene_entity_scale(s, e->handle, e->ps[3])) return 1;
     n_ents++;
     return 0;
 }
