@@ -33,6 +33,7 @@
  *   clap_dropin particles <systems> <particles_per_system> <frames> <seed>
  *   clap_dropin anim <characters> <joints> <frames> <seed>
  *   clap_dropin lights <frames> <seed>
+ *   clap_dropin edge                                  small hand-made scenes (empty queue, one entity, ...)
  */
 #include "model.c"
 #include "gpu-anim.inc.c"               /* clap_amd/binding: lives at the end of model.c's translation unit */
@@ -315,6 +316,95 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
            (unsigned long long)written, (unsigned long long)retiles, (unsigned long long)visible,
            (unsigned long long)bad);
     gpu_scene_done(gs);
+    return bad ? 1 : 0;
+}
+
+/* ---- edge cases of the entity binding: small hand-made scenes, three frames each ---- */
+static void mk(uint8_t model, uint32_t parent, bool hooked, bool positioned)
+{
+    const uint32_t id = n_ids++;
+    struct meta *m = &meta[id];
+    m->model = model; m->alive = 1; m->parent = parent; m->hooked = hooked;
+    vec3 pos = { rndf(-30, 30), rndf(-5, 5), rndf(-30, 30) };
+    const float ry = rndf(-3, 3), sc = rndf(0.5f, 1.5f);
+    for (int k = 0; k < 2; k++) {
+        struct world *w = k ? &B : &A;
+        entity3d *e = ref_new(entity3d, .txmodel = &w->txm[model]);
+        if (positioned) {
+            entity3d_position(e, pos);
+            entity3d_rotate(e, 0, ry, 0);
+            entity3d_scale(e, sc);
+        }
+        if (parent != NONE) e->parent = w->e[parent];
+        if (hooked) e->update = wobble_update;
+        w->e[id] = e;
+    }
+    if (parent != NONE) meta[parent].n_children++;
+}
+
+static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t frames, uint32_t expect_batched_min)
+{
+    uint64_t bad = 0, visible = 0, batched = 0;
+    for (uint32_t f = 0; f < frames; f++) {
+        for (uint32_t id = 0; id < n_ids; id++)
+            if (meta[id].alive && f && rndn(2)) {
+                vec3 off = { rndf(-1, 1), 0, rndf(-1, 1) };
+                entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
+            }
+        vec3 cpos = { 0, 2, 40 };
+        quat cq; quat_identity(cq);
+        view_set(&A, cpos, cq); view_set(&B, cpos, cq);
+        A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        mq_update(A.mq);
+        const int rc = gpu_mq_update(gs, B.mq, &B.view);
+        if (rc) { fprintf(stderr, "%s: gpu_mq_update: %d (%s)\n", name, rc, clapgpu_last_error()); return 1000; }
+        batched += gpu_scene_last_stats(gs)->batched;
+        bad += compare_frame(gs, f, &visible);
+    }
+    if (batched < expect_batched_min) { fprintf(stderr, "%s: only %llu batched updates\n", name, (unsigned long long)batched); bad++; }
+    fprintf(stderr, "  %-34s %s (%llu batched updates)\n", name, bad ? "FAIL" : "ok", (unsigned long long)batched);
+    return bad;
+}
+
+static void edge_reset(void)
+{
+    n_ids = 0;
+    memset(meta, 0, cap_ids * sizeof(*meta));
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+}
+
+static int cmd_edge(void)
+{
+    uint64_t bad = 0;
+    int cases = 0;
+    rng_state = 99;
+    cap_ids = 4096;
+    meta = calloc(cap_ids, sizeof(*meta));
+#define CASE(name, min_batched, build) do { struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2; \
+        edge_reset(); build; bad += edge_frames(gs, name, 3, min_batched); gpu_scene_done(gs); cases++; } while (0)
+    CASE("empty queue", 0, (void)0);
+    CASE("one entity", 3, mk(0, NONE, false, true));
+    CASE("every hook foreign: nothing batched", 0, { for (int i = 0; i < 20; i++) mk(i % 3, NONE, true, true); });
+    CASE("a parent with 200 children (level layout)", 603, { mk(0, NONE, false, true); for (int i = 0; i < 200; i++) mk(1 + i % 3, 0, false, true); });
+    CASE("a chain 40 deep", 120, { mk(0, NONE, false, true); for (uint32_t i = 1; i < 40; i++) mk(0, i - 1, false, true); });
+    CASE("never positioned: mx stays as made", 30, { for (int i = 0; i < 10; i++) mk(0, NONE, false, i & 1); });
+    CASE("children of a hooked parent stay on the host", 3, { mk(0, NONE, true, true); mk(1, 0, false, true); mk(1, 1, false, true); mk(2, NONE, false, true); });
+    CASE("dead entities in the list", 15, { for (int i = 0; i < 10; i++) mk(i % 4, NONE, false, true);
+                                              for (int i = 0; i < 10; i += 2) { entity3d_clear(A.e[i], ENTITY3D_ALIVE); entity3d_clear(B.e[i], ENTITY3D_ALIVE); meta[i].alive = 0; } });
+    CASE("skip_aabb model only", 15, { for (int i = 0; i < 5; i++) mk(3, NONE, false, true); });
+    {   /* everything deleted, then a new population */
+        struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2;
+        edge_reset();
+        for (int i = 0; i < 30; i++) mk(i % 3, NONE, false, true);
+        bad += edge_frames(gs, "before the wipe", 2, 60);
+        for (uint32_t id = 0; id < 30; id++) { entity3d_delete(A.e[id]); entity3d_delete(B.e[id]); A.e[id] = B.e[id] = NULL; meta[id].alive = 0; }
+        bad += edge_frames(gs, "after deleting everything", 2, 0);
+        for (int i = 0; i < 17; i++) mk(i % 3, NONE, false, true);
+        bad += edge_frames(gs, "a new population", 2, 34);
+        gpu_scene_done(gs); cases += 3;
+    }
+    printf("{\"mode\": \"edge\", \"cases\": %d, \"mismatches\": %llu}\n", cases, (unsigned long long)bad);
     return bad ? 1 : 0;
 }
 
@@ -826,6 +916,8 @@ static int cmd_lights(uint32_t frames, uint64_t seed)
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "edge"))
+        return cmd_edge();
     if (argc >= 4 && !strcmp(argv[1], "lights"))
         return cmd_lights((uint32_t)atoi(argv[2]), strtoull(argv[3], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "anim"))

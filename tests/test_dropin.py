@@ -93,6 +93,16 @@ def test_light_grid_binding_matches_reference_light_grid_compute(frames, seed):
 
 
 @pytest.mark.gpu
+def test_binding_edge_cases():
+    """Hand-made scenes through reference and binding: an empty queue, a single entity, only foreign hooks
+    (nothing batched), a parent with 200 children (level-major fallback), a chain 40 deep, entities that were
+    never positioned (mx must stay as entity3d_make left it), children of a hooked parent (host), dead
+    entities in the list, a skip_aabb model, and a queue emptied and repopulated."""
+    r = _run("edge")
+    assert r["mismatches"] == 0 and r["cases"] == 12
+
+
+@pytest.mark.gpu
 def test_binding_bench_mode_is_consistent():
     r = _run("bench", 10000, 5, 1000)
     assert r["mismatches"] == 0 and r["visible_equal"] is True
