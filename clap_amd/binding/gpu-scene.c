@@ -8,7 +8,7 @@
  *   2. decide which entities are batched: hook == default_update, no skeleton animation
  *      (animated_update, model.c:1715-1716), no physics body (phys_body_update /
  *      phys_body_rotate_xform, model.c:1659-1687), no light (light_set_pos, model.c:1689-1694),
- *      no joint attachment, and a batched (or no) parent;
+ *      no joint attachment, and a batched (or no) parent that comes EARLIER in the list;
  *   3. mirror creations, deletions, e->parent, e->flags and -- where xform.updated is set --
  *      position / rotation / scale into libclapgpu_scene, clearing xform.updated as
  *      default_update does (model.c:1615, 1668);
@@ -21,9 +21,10 @@
  *      host entities see their device parents' fresh matrices and the list order of side effects
  *      is the reference's.
  *
- * Deliberate difference: a child that precedes its parent in list order lags one frame in the
- * reference (model.c:1911-1922 walks creation order); the device computes the converged
- * parents-first result, and step 5 hands it over when the reference's own rule fires.
+ * A child that precedes its parent in list order lags one frame in the reference (model.c:1911-1922
+ * walks creation order).  The device computes converged, parents-first results, so such a child -- and
+ * its subtree -- is left on the host, where the lag is reproduced exactly: every entity, batched or not,
+ * ends the frame with the reference's bits.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -62,7 +63,7 @@ struct gpu_scene {
      * this walk is checked against the k-th record of the previous walk first. */
     struct gs_rec   *rec;   uint32_t n_rec, cap_rec, free_rec, n_live;
     uint32_t        *bucket; uint32_t n_bucket;
-    uint32_t        *order, *prev_order, *deferred; uint32_t n_order, n_prev, n_deferred, cap_order;
+    uint32_t        *order, *prev_order; uint32_t n_order, n_prev, cap_order;
     clapgpu_scene_arrays res;
     struct gs_model *models; uint32_t n_models, cap_models;
     uint32_t        gen, vis_cursor;
@@ -176,7 +177,7 @@ void gpu_scene_done(struct gpu_scene *gs)
 {
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
-    free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->deferred); free(gs->models);
+    free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs);
 }
 
@@ -190,7 +191,7 @@ bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e)
     return i != NO_REC && gs->rec[i].gen == gs->gen && gs->rec[i].cls == 1;
 }
 
-/* Criteria an entity meets on its own (step 2); the parent's class is folded in by classify(). */
+/* Criteria an entity meets on its own (step 2); the parent's class is folded in during the walk. */
 static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
 {
     return e->update == gs->default_hook &&
@@ -204,21 +205,11 @@ static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
 static uint32_t parent_rec(struct gpu_scene *gs, struct gs_rec *r)
 {
     entity3d *p = r->e->parent;
-    if (r->parent_e != p || (r->parent_rec != NO_REC && gs->rec[r->parent_rec].e != p)) {
+    if (r->parent_e != p || r->parent_rec == NO_REC || gs->rec[r->parent_rec].e != p) {   /* a miss is retried: the parent may be met later in the walk */
         r->parent_e = p;
         r->parent_rec = rec_find(gs, p);
     }
     return (r->parent_rec != NO_REC && gs->rec[r->parent_rec].gen == gs->gen) ? r->parent_rec : NO_REC;
-}
-
-static uint8_t classify(struct gpu_scene *gs, struct gs_rec *r, int depth)
-{
-    if (r->cls) return r->cls;
-    if (!r->self_ok || depth > 64) return r->cls = 2;
-    if (!r->e->parent) return r->cls = 1;
-    const uint32_t p = parent_rec(gs, r);
-    if (p == NO_REC) return r->cls = 2;                  /* parent not alive in this queue */
-    return r->cls = classify(gs, &gs->rec[p], depth + 1);
 }
 
 static int frustum_of(const struct view *view, clapgpu_frustum *fr)
@@ -330,13 +321,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
      * 1-3 in ONE walk of the queue (the entity structs are far larger than the caches, so every
      * extra pass over them costs as much as the reference's whole update).  prev_order[] is last
      * frame's walk: an unchanged queue is matched without hashing, and its entities are prefetched
-     * ahead of the list chase.  An entity whose parent comes later in the list (or is itself
-     * deferred) cannot be classified yet and goes to deferred[].
+     * ahead of the list chase.
      */
     { uint32_t *t = gs->prev_order; gs->prev_order = gs->order; gs->order = t; }
     gs->n_prev = gs->n_order;
     gs->n_order = 0;
-    gs->n_deferred = 0;
     uint32_t cursor = 0;
     model3dtx *txm;
     entity3d *e, *it;
@@ -363,9 +352,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 if (o) gs->order = o;
                 uint32_t *po = realloc(gs->prev_order, (size_t)cap * sizeof(*po));
                 if (po) gs->prev_order = po;
-                uint32_t *df = realloc(gs->deferred, (size_t)cap * sizeof(*df));
-                if (df) gs->deferred = df;
-                if (!o || !po || !df) return _CERR_NOMEM;
+                if (!o || !po) return _CERR_NOMEM;
                 gs->cap_order = cap;
             }
             struct gs_rec *r = &gs->rec[i];
@@ -378,28 +365,21 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             } else if (!e->parent) {
                 r->cls = 1;
             } else {
-                const uint32_t p = parent_rec(gs, r);             /* NO_REC unless already met in THIS walk */
-                r->cls = p != NO_REC ? gs->rec[p].cls : 0;
+                /* NO_REC unless already met in THIS walk.  A child that precedes its parent in list order sees the
+                 * parent's matrix of the previous frame in the reference (model.c:1911-1922 walks creation order):
+                 * it stays on the host, where that lag is reproduced exactly, and so does everything below it. */
+                const uint32_t p = parent_rec(gs, r);
+                r->cls = p != NO_REC ? gs->rec[p].cls : 2;
             }
             if (r->cls == 1) {
                 CK(mirror_one(gs, r));
                 CK(link_parent(gs, r));
-            } else if (r->cls == 2) {
-                CK(unbatch(gs, r));
             } else {
-                gs->deferred[gs->n_deferred++] = i;
+                CK(unbatch(gs, r));
             }
         }
     }
     const double t1 = now_ms();
-    for (uint32_t k = 0; k < gs->n_deferred; k++) {
-        struct gs_rec *r = &gs->rec[gs->deferred[k]];
-        if (classify(gs, r, 0) == 1) CK(mirror_one(gs, r));
-        else CK(unbatch(gs, r));
-    }
-    for (uint32_t k = 0; k < gs->n_deferred; k++)               /* parents after every batched entity has its handle */
-        if (gs->rec[gs->deferred[k]].cls == 1)
-            CK(link_parent(gs, &gs->rec[gs->deferred[k]]));
     /* entities that left the queue (entity3d_delete, model.c:1787): met last frame, not this one */
     if (gs->n_live != gs->n_order) {
         for (uint32_t k = 0; k < gs->n_prev; k++) {

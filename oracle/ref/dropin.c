@@ -342,6 +342,8 @@ static void mk(uint8_t model, uint32_t parent, bool hooked, bool positioned)
     if (parent != NONE) meta[parent].n_children++;
 }
 
+static bool edge_no_view, edge_no_scene;   /* gpu_mq_update(gs, mq, NULL) / a queue whose priv is NULL */
+
 static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t frames, uint32_t expect_batched_min)
 {
     uint64_t bad = 0, visible = 0, batched = 0;
@@ -355,8 +357,10 @@ static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t fra
         quat cq; quat_identity(cq);
         view_set(&A, cpos, cq); view_set(&B, cpos, cq);
         A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        A.mq->priv = edge_no_scene ? NULL : A.scene;            /* entity3d_reset's form: default_update(e, NULL) */
+        B.mq->priv = edge_no_scene ? NULL : B.scene;
         mq_update(A.mq);
-        const int rc = gpu_mq_update(gs, B.mq, &B.view);
+        const int rc = gpu_mq_update(gs, B.mq, edge_no_view ? NULL : &B.view);
         if (rc) { fprintf(stderr, "%s: gpu_mq_update: %d (%s)\n", name, rc, clapgpu_last_error()); return 1000; }
         batched += gpu_scene_last_stats(gs)->batched;
         bad += compare_frame(gs, f, &visible);
@@ -393,6 +397,15 @@ static int cmd_edge(void)
     CASE("dead entities in the list", 15, { for (int i = 0; i < 10; i++) mk(i % 4, NONE, false, true);
                                               for (int i = 0; i < 10; i += 2) { entity3d_clear(A.e[i], ENTITY3D_ALIVE); entity3d_clear(B.e[i], ENTITY3D_ALIVE); meta[i].alive = 0; } });
     CASE("skip_aabb model only", 15, { for (int i = 0; i < 5; i++) mk(3, NONE, false, true); });
+    edge_no_view = true;
+    CASE("no view to cull against", 60, { for (int i = 0; i < 20; i++) mk(0, i ? (uint32_t)(i - 1) / 2 : NONE, false, true); });
+    edge_no_view = false;
+    /* children whose model list comes BEFORE their parent's: the reference lags them one frame; they stay on the host */
+    CASE("children that precede their parent", 6, { mk(2, NONE, false, true); mk(2, 0, false, true);
+                                                    for (int i = 0; i < 6; i++) mk(i % 2, (uint32_t)(i & 1), false, true); mk(1, 3, false, true); });
+    edge_no_view = false; edge_no_scene = true;
+    CASE("a queue without a scene (priv == NULL)", 57, { for (int i = 0; i < 20; i++) mk(i % 3, NONE, i == 7, true); });
+    edge_no_scene = false;
     {   /* everything deleted, then a new population */
         struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2;
         edge_reset();
