@@ -97,7 +97,7 @@ def dropin_boundary():
         out[f"{n}_entities_{permille // 10}pct_dirty"] = {
             "reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
             "binding_ms": r["binding_ms"], "identical": r["mismatches"] == 0 and r["visible_equal"]}
-    out["note"] = ("random forest (60 % of the entities parented), one frame = mq_update + one frustum verdict per entity; "
+    out["note"] = ("random forest (60 % of the entities parented, parents listed before their children), one frame = mq_update + one frustum verdict per entity; "
                    "binding = list walk + upload + kernel + download + scatter-back into the entity3d structs, 1 host thread")
     return out
 

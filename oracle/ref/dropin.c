@@ -153,9 +153,15 @@ static struct world A, B;
 static struct meta *meta;
 static uint32_t n_ids, cap_ids;
 
-static bool may_parent(uint32_t p, uint32_t c)     /* p strictly earlier than c in mq list order */
+/* Any live entity created earlier may be a parent (no cycles).  When its model list comes AFTER the child's,
+ * the child precedes it in the queue and the reference reads the parent's matrix one frame late
+ * (model.c:1911-1922): the binding has to reproduce that too. */
+static bool parents_first;                 /* bench: every parent also precedes its children in the queue */
+static bool may_parent(uint32_t p, uint32_t c)
 {
-    return meta[p].alive && (meta[p].model < meta[c].model || (meta[p].model == meta[c].model && p < c));
+    if (parents_first)
+        return meta[p].alive && (meta[p].model < meta[c].model || (meta[p].model == meta[c].model && p < c));
+    return meta[p].alive && p < c;
 }
 
 static void op_create(float spread, bool allow_hook)
@@ -428,6 +434,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     int rc = gpu_scene_init(&gs, 0, default_update);
     if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
     rng_state = 7;
+    parents_first = true;
     cap_ids = n;
     meta = calloc(cap_ids, sizeof(*meta));
     world_init(&A, cap_ids);

@@ -4,8 +4,9 @@ oracle/_ref/clap_dropin (built by oracle/ref/Makefile from the reference's sourc
 plus clap_amd/binding/gpu-scene.c) advances two identical scenes made of the reference's struct mq /
 model3dtx / entity3d -- one with the reference's mq_update() + view_entity_in_frustum(), one with
 the binding over libclapgpu_scene -> HIP -- through a scripted game (moves, rotations, scales,
-visibility and SKIP_CULLING toggles, creations, deletions, re-parenting, entities with a foreign
-update hook that must stay on the host) and compares mx, inverse_mx, aabb, aabb_center, seq,
+visibility and SKIP_CULLING toggles, creations, deletions, re-parenting -- also to parents that come later
+in the queue, which the reference reads one frame late -- entities with a foreign update hook that must stay
+on the host) and compares mx, inverse_mx, aabb, aabb_center, seq,
 parent_seq, xform.updated, the frustum verdict and the camera bounding-volume pick bit for bit
 after every frame.  The same binary checks the particle path (`particles` mode): the reference's particles_update
 hooks drawing from libc's drand48 against clap_amd/binding/gpu-particles.inc.c.
@@ -46,7 +47,7 @@ def _run(*args):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,frames,seed", [(300, 12, 1), (5000, 16, 2), (40000, 8, 3)])
+@pytest.mark.parametrize("n,frames,seed", [(300, 12, 1), (5000, 16, 2), (40000, 8, 3), (2000, 40, 7)])
 def test_binding_matches_reference_mq_update(n, frames, seed):
     r = _run("test", n, frames, seed)
     assert r["mismatches"] == 0
