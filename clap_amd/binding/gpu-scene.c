@@ -34,6 +34,7 @@
 #include "gpu-scene.h"
 #include "scene.h"
 #include "clapgpu_scene.h"
+#include "clapgpu_snapshot.h"
 
 #define NO_REC 0xffffffffu
 
@@ -474,4 +475,67 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
             return (gs->res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1;
     }
     return view_entity_in_frustum(view, e);
+}
+
+int gpu_scene_snapshot_begin(struct gpu_scene *gs, const char *path, struct clapgpu_snapshot_writer **out)
+{
+    if (!gs || !path || !out) return _CERR_INVALID_ARGUMENTS;
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < gs->n_order; k++) n += gs->rec[gs->order[k]].cls == 1;
+    const uint32_t nm = gs->n_models ? gs->n_models : 1;
+    uint32_t *index_of = malloc((size_t)(gs->n_rec ? gs->n_rec : 1) * 4);       /* record -> row of the dump */
+    float *pos_scale = calloc((size_t)(n ? n : 1) * 4, 4), *rot = calloc((size_t)(n ? n : 1) * 4, 4);
+    int32_t *parent = calloc(n ? n : 1, 4), *model = calloc(n ? n : 1, 4);
+    uint32_t *flags = calloc(n ? n : 1, 4), *seqs = calloc(n ? n : 1, 4);
+    float *maabb = calloc((size_t)nm * 6, 4);
+    uint8_t *mskip = calloc(nm, 1);
+    int rc = _CERR_NOMEM;
+    clapgpu_snapshot_writer *w = NULL;
+    if (!index_of || !pos_scale || !rot || !parent || !model || !flags || !seqs || !maabb || !mskip) goto done;
+    uint32_t row = 0;
+    for (uint32_t k = 0; k < gs->n_order; k++)
+        if (gs->rec[gs->order[k]].cls == 1) index_of[gs->order[k]] = row++;
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (r->cls != 1) continue;
+        entity3d *e = r->e;
+        const uint32_t i = index_of[gs->order[k]];
+        memcpy(pos_scale + 4 * (size_t)i, transform_pos(&e->xform, NULL), 12);
+        pos_scale[4 * (size_t)i + 3] = e->scale;
+        memcpy(rot + 4 * (size_t)i, transform_rotation_quat(&e->xform), 16);
+        parent[i] = e->parent ? (int32_t)index_of[parent_rec(gs, r)] : -1;
+        flags[i] = (e->flags & (ENTITY3D_ALIVE | 0xffffu)) | CLAPGPU_E_DIRTY;     /* a replay rebuilds everything */
+        for (uint32_t m = 0; m < gs->n_models; m++)
+            if (gs->models[m].model == r->model) model[i] = (int32_t)m;
+    }
+    for (uint32_t m = 0; m < gs->n_models; m++) {
+        const model3d *md = gs->models[m].model;
+        const float a[6] = { md->aabb[0][0], md->aabb[0][1], md->aabb[0][2], md->aabb[1][0], md->aabb[1][1], md->aabb[1][2] };
+        memcpy(maabb + 6 * (size_t)m, a, 24);
+        mskip[m] = md->skip_aabb;
+    }
+    rc = clapgpu_snapshot_create(&w, path);
+    if (rc) goto done;
+    const int64_t n64 = n;
+#define ADD(name, dt, nd, d0, d1, ptr) do { const uint64_t dims__[2] = { d0, d1 }; \
+        if ((rc = clapgpu_snapshot_add(w, name, dt, nd, dims__, ptr))) { clapgpu_snapshot_abort(w); w = NULL; goto done; } } while (0)
+    ADD("entities.n", CLAPGPU_DT_I64, 1, 1, 0, &n64);
+    ADD("entities.pos_scale", CLAPGPU_DT_F32, 2, n, 4, pos_scale);
+    ADD("entities.rot", CLAPGPU_DT_F32, 2, n, 4, rot);
+    ADD("entities.parent", CLAPGPU_DT_I32, 1, n, 0, parent);
+    ADD("entities.model", CLAPGPU_DT_I32, 1, n, 0, model);
+    ADD("entities.flags", CLAPGPU_DT_U32, 1, n, 0, flags);
+    ADD("entities.seqs", CLAPGPU_DT_U32, 1, n, 0, seqs);
+    ADD("entities.model_aabb", CLAPGPU_DT_F32, 2, nm, 6, maabb);
+    ADD("entities.model_skip", CLAPGPU_DT_U8, 1, nm, 0, mskip);
+    if (gs->culled_view) {
+        ADD("frustum.planes", CLAPGPU_DT_F32, 2, 6, 4, gs->culled_view->main.frustum_planes);
+        ADD("frustum.corners", CLAPGPU_DT_F32, 2, 8, 4, gs->culled_view->main.frustum_corners);
+    }
+#undef ADD
+    *out = w;
+    rc = 0;
+done:
+    free(index_of); free(pos_scale); free(rot); free(parent); free(model); free(flags); free(seqs); free(maabb); free(mskip);
+    return rc;
 }

@@ -64,4 +64,15 @@ void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere);
 /* true if `e` was updated on the device by the last gpu_mq_update() */
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);
 
+/*
+ * Dump the batched part of the queue, as mirrored by the last gpu_mq_update(), into a scene snapshot
+ * (include/clapgpu_snapshot.h): entities.pos_scale / rot / parent / model / flags / seqs / n in list order
+ * (parents by index, -1 for none), entities.model_aabb / model_skip, and -- if a view was culled against --
+ * frustum.planes / frustum.corners.  `python bench.py --snapshot file` and clap_amd.snapshot.load_scene()
+ * replay it through the kernels without the engine.  The writer is returned open so that the caller can
+ * add arrays of its own (clapgpu_snapshot_add) before clapgpu_snapshot_finish().
+ */
+struct clapgpu_snapshot_writer;
+int gpu_scene_snapshot_begin(struct gpu_scene *gs, const char *path, struct clapgpu_snapshot_writer **out);
+
 #endif /* CLAP_GPU_SCENE_H */

@@ -34,6 +34,7 @@
  *   clap_dropin anim <characters> <joints> <frames> <seed>
  *   clap_dropin lights <frames> <seed>
  *   clap_dropin edge                                  small hand-made scenes (empty queue, one entity, ...)
+ *   clap_dropin snapshot <entities> <file>            dump a scene through the binding + the reference's results
  */
 #include "model.c"
 #include "gpu-anim.inc.c"               /* clap_amd/binding: lives at the end of model.c's translation unit */
@@ -50,6 +51,7 @@
 
 #include "gpu-scene.h"
 #include "clapgpu_scene.h"
+#include "clapgpu_snapshot.h"
 
 const char *build_date = "oracle";
 const char *clap_version = "oracle";
@@ -425,6 +427,50 @@ static int cmd_edge(void)
     }
     printf("{\"mode\": \"edge\", \"cases\": %d, \"mismatches\": %llu}\n", cases, (unsigned long long)bad);
     return bad ? 1 : 0;
+}
+
+/* A scene of the reference's objects dumped through the binding into a snapshot file, together with the
+ * REFERENCE's results for it (expect.*): tests/test_dropin.py replays the file through the Python harness
+ * and the kernels and expects those bits. */
+static int cmd_snapshot(uint32_t n, const char *path)
+{
+    struct gpu_scene *gs;
+    int rc = gpu_scene_init(&gs, 0, default_update);
+    if (rc) return 2;
+    rng_state = 11;
+    parents_first = true;
+    cap_ids = n;
+    meta = calloc(cap_ids, sizeof(*meta));
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+    while (n_ids < n) op_create(300.f, false);
+    vec3 cpos = { 10, 5, 60 };
+    quat cq; quat_from_euler_xyz(cq, -0.1f, 0.3f, 0);
+    view_set(&A, cpos, cq); view_set(&B, cpos, cq);
+    mq_update(A.mq);
+    if ((rc = gpu_mq_update(gs, B.mq, &B.view))) { fprintf(stderr, "gpu_mq_update: %d\n", rc); return 2; }
+    struct clapgpu_snapshot_writer *w;
+    if ((rc = gpu_scene_snapshot_begin(gs, path, &w))) { fprintf(stderr, "snapshot: %d\n", rc); return 2; }
+    /* the reference's results, in the dump's row order = list order of the batched entities (here: all) */
+    float *mx = malloc((size_t)n * 64), *aabb = malloc((size_t)n * 24);
+    uint8_t *vis = malloc(n);
+    uint32_t row = 0;
+    model3dtx *txm; entity3d *e, *it;
+    list_for_each_entry(txm, &A.mq->txmodels, entry)
+        list_for_each_entry_iter(e, it, &txm->entities, entry) {
+            memcpy(mx + 16 * (size_t)row, e->mx, 64);
+            memcpy(aabb + 6 * (size_t)row, e->aabb, 24);
+            vis[row] = entity3d_matches(e, ENTITY3D_VISIBLE) && (entity3d_matches(e, ENTITY3D_SKIP_CULLING) || view_entity_in_frustum(&A.view, e));
+            row++;
+        }
+    const uint64_t d2[2] = { row, 16 }, d3[2] = { row, 6 }, d1[1] = { row };
+    rc = clapgpu_snapshot_add(w, "expect.mx", CLAPGPU_DT_F32, 2, d2, mx);
+    if (!rc) rc = clapgpu_snapshot_add(w, "expect.aabb", CLAPGPU_DT_F32, 2, d3, aabb);
+    if (!rc) rc = clapgpu_snapshot_add(w, "expect.visible", CLAPGPU_DT_U8, 1, d1, vis);
+    if (!rc) rc = clapgpu_snapshot_finish(w);
+    printf("{\"mode\": \"snapshot\", \"entities\": %u, \"batched\": %u, \"rc\": %d}\n", row, gpu_scene_last_stats(gs)->batched, rc);
+    gpu_scene_done(gs);
+    return rc ? 1 : 0;
 }
 
 /* Frame cost at the boundary, host structs to host structs (PCIe and scatter-back included). */
@@ -936,6 +982,8 @@ static int cmd_lights(uint32_t frames, uint64_t seed)
 
 int main(int argc, char **argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "snapshot"))
+        return cmd_snapshot((uint32_t)atoi(argv[2]), argv[3]);
     if (argc >= 2 && !strcmp(argv[1], "edge"))
         return cmd_edge();
     if (argc >= 4 && !strcmp(argv[1], "lights"))

@@ -106,6 +106,37 @@ def test_binding_edge_cases():
 
 
 @pytest.mark.gpu
+def test_scene_dumped_by_the_binding_replays_to_the_reference_bits(tmp_path, cuda_device):
+    """The loop SURVEY 8f rank 4 is about: a scene made of the reference's objects is dumped by the binding
+    (gpu_scene_snapshot_begin -> include/clapgpu_snapshot.h), loaded by clap_amd.snapshot, tiled and run through the
+    kernels by the Python harness -- and gives the matrices, AABBs and visible set the REFERENCE computed for it."""
+    import ctypes as C
+
+    import numpy as np
+    from clap_amd import _lib, entities, snapshot, tiler
+    path = str(tmp_path / "scene.clps")
+    r = _run("snapshot", 6000, path)
+    assert r["rc"] == 0 and r["batched"] == r["entities"] == 6000
+    comps = snapshot.load_scene(path)
+    raw, exp = comps["entities"], comps["expect"]
+    assert (raw["parent"] >= 0).sum() > 1000, "a real hierarchy"
+    scene, tl = tiler.tiled_scene(raw)
+    fr = _lib.Frustum()
+    C.memmove(fr.planes, np.ascontiguousarray(comps["frustum"]["planes"], np.float32).ctypes.data, 96)
+    C.memmove(fr.corners, np.ascontiguousarray(comps["frustum"]["corners"], np.float32).ctypes.data, 128)
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    out = batch.download()
+    slot = tl["slot_of"]
+    assert np.array_equal(out["mx"][slot].view(np.uint32), exp["mx"].reshape(-1, 16).view(np.uint32))
+    assert np.array_equal(out["aabb"][slot].view(np.uint32), exp["aabb"].reshape(-1, 6).view(np.uint32))
+    vis = np.zeros(scene["n"], bool)
+    vis[out["visible"]] = True
+    assert np.array_equal(vis[slot], exp["visible"].astype(bool)) and 0 < vis.sum() < 6000
+
+
+@pytest.mark.gpu
 def test_binding_bench_mode_is_consistent():
     r = _run("bench", 10000, 5, 1000)
     assert r["mismatches"] == 0 and r["visible_equal"] is True
