@@ -144,9 +144,32 @@ def time_launches(fn, iters, warmup=10):
     return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
 
-def roof(alg_bytes, seconds):
+def pmc_kernel_traffic(*names):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) of the named kernels from the
+    newest committed summary profiles/<round>_*/pmc_hbm_bytes.json (tools/profile_round.sh), or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*", "pmc_hbm_bytes.json")), key=os.path.getmtime):
+        try:
+            with open(path) as f:
+                best = json.load(f).get("kernels", {})
+        except (OSError, ValueError):
+            pass
+    if not best:
+        return None
+    total = 0.0
+    for want in names:
+        hit = [v for k, v in best.items() if want in k]
+        if not hit:
+            return None
+        total += hit[0]["hbm_bytes_per_launch"]
+    return total
+
+
+def roof(alg_bytes, seconds, *kernels):
     gbs = alg_bytes / seconds / 1e9
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": pmc_kernel_traffic(*kernels) if kernels else None,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": seconds * 1e6}
 
 
@@ -172,9 +195,9 @@ def extras(device, testbed=True):
     t_pose = time_launches(cb.pose_update, 20)
     t_skin = time_launches(cb.skin, 20)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
-                           "kernel": "k_pose<64>", "roofline": roof(cb.pose_algorithmic_bytes(), t_pose)}
+                           "kernel": "k_pose<64>", "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<")}
     out["skinning"] = {"skinned_verts_per_s": n_chars * vpc / t_skin, "vertices": n_chars * vpc,
-                       "kernel": "k_skin", "roofline": roof(cb.skin_algorithmic_bytes(), t_skin),
+                       "kernel": "k_skin", "roofline": roof(cb.skin_algorithmic_bytes(), t_skin, "k_skin"),
                        "mesh": "one distinct 200-vertex mesh per character (44 B/vertex read from HBM); instanced "
                                "meshes read less"}
     out["pose_plus_skinning_verts_per_s"] = n_chars * vpc / (t_pose + t_skin)
@@ -189,7 +212,7 @@ def extras(device, testbed=True):
     t_part = time_launches(lambda: pb.particles_update(view), 30)
     out["particles"] = {"particles_per_s": pb.n_real / t_part, "particles": pb.n_real,
                         "kernels": "k_particles_advect + k_visible_expand_rp + k_particles_respawn",
-                        "roofline": roof(pb.algorithmic_bytes(), t_part)}
+                        "roofline": roof(pb.algorithmic_bytes(), t_part, "k_particles_advect", "k_particles_respawn_rp")}
     del pb
     # ---- configs[3], body half: 256k sphere bodies: integrate + both broadphase passes ----
     b = synth.sphere_bodies(262_144, box=64.0, seed=4)
@@ -198,7 +221,7 @@ def extras(device, testbed=True):
     t_bp = time_launches(pw.broadphase, 10)
     npairs = int(pw.pair_total.item())
     out["bodies"] = {"bodies_per_s_integrate": pw.n / t_int, "bodies": pw.n, "kernel": "k_bodies_step",
-                     "roofline": roof(pw.integrate_algorithmic_bytes(), t_int),
+                     "roofline": roof(pw.integrate_algorithmic_bytes(), t_int, "k_bodies_step"),
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
                                     "note": "hash build, bucket-ordered records, search, two counted scans, list copy; "
