@@ -28,7 +28,9 @@ REF = "/root/reference/core"
 def test_dropin_checker_is_built_where_the_reference_is():
     if not os.path.isdir(REF):
         pytest.skip("reference tree absent: the checker is prebuilt elsewhere")
+    from clap_amd import _lib
     from oracle import refrun
+    _lib.build()                                           # the checker links clap_amd/lib/libclapgpu*.so
     refrun.build()
     assert os.access(BIN, os.X_OK)
     # the binding's calls into the product resolve to libclapgpu_scene / libclapgpu, nothing else
