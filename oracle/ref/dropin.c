@@ -350,14 +350,15 @@ static void mk(uint8_t model, uint32_t parent, bool hooked, bool positioned)
     if (parent != NONE) meta[parent].n_children++;
 }
 
-static bool edge_no_view, edge_no_scene;   /* gpu_mq_update(gs, mq, NULL) / a queue whose priv is NULL */
+static bool edge_no_view, edge_no_scene;
+static uint32_t edge_move_lo, edge_move_hi;   /* != 0: only entities [lo, hi) move (a short slot range is uploaded) */   /* gpu_mq_update(gs, mq, NULL) / a queue whose priv is NULL */
 
 static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t frames, uint32_t expect_batched_min)
 {
     uint64_t bad = 0, visible = 0, batched = 0;
     for (uint32_t f = 0; f < frames; f++) {
         for (uint32_t id = 0; id < n_ids; id++)
-            if (meta[id].alive && f && rndn(2)) {
+            if (meta[id].alive && f && (edge_move_hi ? (id >= edge_move_lo && id < edge_move_hi) : rndn(2))) {
                 vec3 off = { rndf(-1, 1), 0, rndf(-1, 1) };
                 entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
             }
@@ -405,6 +406,11 @@ static int cmd_edge(void)
     CASE("dead entities in the list", 15, { for (int i = 0; i < 10; i++) mk(i % 4, NONE, false, true);
                                               for (int i = 0; i < 10; i += 2) { entity3d_clear(A.e[i], ENTITY3D_ALIVE); entity3d_clear(B.e[i], ENTITY3D_ALIVE); meta[i].alive = 0; } });
     CASE("skip_aabb model only", 15, { for (int i = 0; i < 5; i++) mk(3, NONE, false, true); });
+    edge_move_lo = 300; edge_move_hi = 310;
+    CASE("ten neighbours of 1000 move (range upload)", 3000, { for (int i = 0; i < 1000; i++) mk(0, NONE, false, true); });
+    edge_move_lo = 5; edge_move_hi = 6;
+    CASE("one root of a 3-level tree moves", 1200, { for (int i = 0; i < 400; i++) mk(0, i >= 10 ? (uint32_t)(i % 10 + (i >= 100 ? 10 * ((i - 100) % 9 + 1) : 0)) : NONE, false, true); });
+    edge_move_lo = edge_move_hi = 0;
     edge_no_view = true;
     CASE("no view to cull against", 60, { for (int i = 0; i < 20; i++) mk(0, i ? (uint32_t)(i - 1) / 2 : NONE, false, true); });
     edge_no_view = false;

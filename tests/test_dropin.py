@@ -100,11 +100,12 @@ def test_binding_edge_cases():
     """Hand-made scenes through reference and binding: an empty queue, a single entity, only foreign hooks
     (nothing batched), a parent with 200 children (level-major fallback), a chain 40 deep, entities that were
     never positioned (mx must stay as entity3d_make left it), children of a hooked parent (host), dead
-    entities in the list, a skip_aabb model, no view to cull against, a queue whose priv is NULL, children listed
+    entities in the list, a skip_aabb model, a few moving neighbours among 1000 (the range-upload path), one moving root of a
+    three-level tree, no view to cull against, a queue whose priv is NULL, children listed
     before their parents (the reference's one-frame lag, reproduced on the host), and a queue
     emptied and repopulated."""
     r = _run("edge")
-    assert r["mismatches"] == 0 and r["cases"] == 15
+    assert r["mismatches"] == 0 and r["cases"] == 17
 
 
 @pytest.mark.gpu
