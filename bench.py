@@ -424,33 +424,7 @@ def main():
     # 1-bit-per-entity mask (one fixed-size RCCL allgather, no counts, no host sync); every rank
     # then expands the gathered mask into the identical ascending global id list.  Exchange and
     # expansion of frame f run on a side stream under the update of frame f + 1 (two mask buffers).
-    comm = torch.cuda.Stream(device=device) if use_dist else None
-    direct = None
-    if use_dist:
-        n_words = batch.vis_mask.numel()
-        masks = [batch.vis_mask, torch.zeros_like(batch.vis_mask)]
-        pops = [batch.vis_row_pop, torch.zeros_like(batch.vis_row_pop)]
-        g_mask = [torch.zeros(world * n_words, dtype=torch.int64, device=device) for _ in range(2)]
-        g_vis = [torch.zeros(world * n_pad, dtype=torch.int32, device=device) for _ in range(2)]
-        g_cnt = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
-        g_scratch = torch.zeros(_lib.lib().clapgpu_visible_scratch_bytes(world * n_pad) // 4 + 4, dtype=torch.int32,
-                                device=device)
-        ev_upd = [torch.cuda.Event() for _ in range(2)]
-        ev_comm = [torch.cuda.Event() for _ in range(2)]
-        import ctypes as C
-        if args.exchange == "rccl":
-            try:
-                from clap_amd import rccl
-                direct = rccl.Communicator(rank, world, device)
-            except Exception as exc:                    # keep the run alive: c10d does the same exchange
-                print(f"[bench] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
-            # every rank must take the same route: one rank falling back alone would deadlock the others
-            ok = torch.tensor([1 if direct is not None else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and direct is not None:
-                direct.destroy()
-                direct = None
-    frame = [0]
+    xch = shard.VisibleExchange(batch, rank, world, device, route=args.exchange) if use_dist else None
 
     def step():
         if pbatch is not None:
@@ -459,24 +433,9 @@ def main():
             batch.mq_update(fr, all_dirty=True)         # one launch for all hierarchy levels (tiles)
             batch.compact_visible(index_base)           # ordered visible list
             return
-        b = frame[0] & 1
-        frame[0] += 1
-        main = torch.cuda.current_stream()
-        main.wait_event(ev_comm[b])                     # the exchange that last read this mask buffer is done
-        batch.use_vis_buffers(masks[b], pops[b])
+        xch.begin()
         batch.mq_update(fr, all_dirty=True)
-        ev_upd[b].record(main)
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev_upd[b])
-            if direct is not None:
-                direct.allgather_i64(masks[b], g_mask[b], comm)
-            else:
-                shard.allgather_visible_mask(masks[b], world, g_mask[b])
-            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(comm.cuda_stream), g_mask[b].data_ptr(), None,
-                                                    world * n_pad, 0, g_vis[b].data_ptr(), g_cnt[b].data_ptr(),
-                                                    g_scratch.data_ptr())
-            _lib.check(rc, "clapgpu_visible_compact(global)")
-            ev_comm[b].record(comm)
+        xch.submit()
 
     def fence():
         if use_dist:
@@ -497,7 +456,7 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_real * args.steps / elapsed
-    visible = int((g_cnt[(frame[0] - 1) & 1] if use_dist else batch.visible_count).item())
+    visible = int((xch.last()[0] if use_dist else batch.visible_count).item())
 
     # ---- roofline pass: HIP events around every launch of the dominant kernel (same stream) ----
     if batch.tiled:
@@ -536,7 +495,7 @@ def main():
                                    f"list ({visible} visible" + (" in the gathered global set)" if use_dist else ")"),
                        "entities_per_gpu": n_real, "levels": n_levels,
                        "particles_per_gpu": (pbatch.n_real if pbatch is not None else 0),
-                       "exchange": (("ncclAllGather (direct)" if direct is not None else "torch.distributed all_gather")
+                       "exchange": (xch.route
                                     + " of the visibility mask + local expansion to global ids, overlapped with "
                                     "the next frame's update") if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -555,8 +514,7 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
-        if direct is not None:
-            direct.destroy()
+        xch.destroy()
         dist.destroy_process_group()
 
 

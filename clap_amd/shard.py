@@ -58,3 +58,86 @@ def concat_visible(counts, gathered):
     """The global visible set as one ascending 1-D tensor (shards are ascending id ranges)."""
     c = counts.tolist()
     return torch.cat([gathered[r, :c[r]] for r in range(len(c))])
+
+
+class VisibleExchange:
+    """The path's one exchange, double-buffered: each rank's visibility mask travels in ONE fixed-size
+    allgather on a side stream (RCCL's ncclAllGather called directly, or torch.distributed as the
+    fallback), and every rank expands the gathered mask into the identical ascending global id list
+    (clapgpu_visible_compact over world * n entities).  Exchange + expansion of frame f overlap the update
+    of frame f + 1: `begin()` hands the update kernel the mask buffer of this frame, `submit()` queues
+    the exchange behind it.  Requires an initialised default process group."""
+
+    def __init__(self, batch, rank, world, device, route="rccl"):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.batch, self.rank, self.world, self.device = batch, rank, world, device
+        self.n_pad = batch.n
+        n_words = batch.vis_mask.numel()
+        self.masks = [batch.vis_mask, torch.zeros_like(batch.vis_mask)]
+        self.pops = [batch.vis_row_pop, torch.zeros_like(batch.vis_row_pop)]
+        self.g_mask = [torch.zeros(world * n_words, dtype=torch.int64, device=device) for _ in range(2)]
+        self.g_vis = [torch.zeros(world * self.n_pad, dtype=torch.int32, device=device) for _ in range(2)]
+        self.g_cnt = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+        nscratch = _lib.lib().clapgpu_visible_scratch_bytes(world * self.n_pad)
+        self.g_scratch = torch.zeros(nscratch // 4 + 4, dtype=torch.int32, device=device)
+        self.comm = torch.cuda.Stream(device=device)
+        self.ev_upd = [torch.cuda.Event() for _ in range(2)]
+        self.ev_comm = [torch.cuda.Event() for _ in range(2)]
+        self.frame = 0
+        self.direct = None
+        if route == "rccl":
+            try:
+                from . import rccl
+                self.direct = rccl.Communicator(rank, world, device)
+            except Exception as exc:                        # keep the run alive: c10d does the same exchange
+                import sys
+                print(f"[clap_amd.shard] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+            # every rank must take the same route: one rank falling back alone would deadlock the others
+            ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and self.direct is not None:
+                self.direct.destroy()
+                self.direct = None
+
+    @property
+    def route(self):
+        return "ncclAllGather (direct)" if self.direct is not None else "torch.distributed all_gather"
+
+    def begin(self):
+        """Before the frame's update: wait until the exchange that last read this frame's mask buffer is done."""
+        b = self.frame & 1
+        torch.cuda.current_stream().wait_event(self.ev_comm[b])
+        self.batch.use_vis_buffers(self.masks[b], self.pops[b])
+        return b
+
+    def submit(self):
+        """After the frame's update was issued on the current stream."""
+        C, _lib = self._C, self._lib
+        b = self.frame & 1
+        self.frame += 1
+        main = torch.cuda.current_stream()
+        self.ev_upd[b].record(main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ev_upd[b])
+            if self.direct is not None:
+                self.direct.allgather_i64(self.masks[b], self.g_mask[b], self.comm)
+            else:
+                allgather_visible_mask(self.masks[b], self.world, self.g_mask[b])
+            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(self.comm.cuda_stream), self.g_mask[b].data_ptr(), None,
+                                                    self.world * self.n_pad, 0, self.g_vis[b].data_ptr(),
+                                                    self.g_cnt[b].data_ptr(), self.g_scratch.data_ptr())
+            _lib.check(rc, "clapgpu_visible_compact(global)")
+            self.ev_comm[b].record(self.comm)
+
+    def last(self):
+        """(count tensor, id tensor) of the most recently submitted frame's global visible set; the caller
+        synchronises (torch.cuda.synchronize or ev_comm) before reading."""
+        b = (self.frame - 1) & 1
+        return self.g_cnt[b], self.g_vis[b]
+
+    def destroy(self):
+        if self.direct is not None:
+            self.direct.destroy()
+            self.direct = None

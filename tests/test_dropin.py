@@ -23,6 +23,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "clap_dropin")
 REF = "/root/reference/core"
+# Share of entity updates that must go through the HIP path (the rest runs the reference's own default_update on
+# the host on BOTH sides and so proves nothing about the kernels).  `test` is the scripted game, which deliberately
+# keeps foreign hooks and children listed before their parents in the mix.
+BATCHED_FLOOR = {"test": 0.55}
 
 
 def test_dropin_checker_is_built_where_the_reference_is():
@@ -54,6 +58,8 @@ def test_binding_matches_reference_mq_update(n, frames, seed):
     r = _run("test", n, frames, seed)
     assert r["mismatches"] == 0
     assert r["batched_updates"] > 0 and r["host_updates"] > 0      # both halves of the split were exercised
+    frac = r["batched_updates"] / (r["batched_updates"] + r["host_updates"])
+    assert frac >= BATCHED_FLOOR["test"], f"only {frac:.2f} of the updates went through the device"
     assert r["written_back"] > 0 and r["retiles"] > 0
     assert 0 < r["visible_verdicts_true"]
 

@@ -1,0 +1,107 @@
+"""GPU, world size 1: the path's one exchange exactly as bench.py --gpus N runs it (clap_amd.shard.VisibleExchange):
+rccl.Communicator bootstrapped through the process group, ncclAllGather of the visibility mask on the side stream,
+clapgpu_visible_compact over the gathered mask with a non-zero index base -- against the oracle's visible list.
+(N > 1 on hardware is the driver's scaling run; the multi-rank logic is covered on CPU by test_shard_cpu.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from clap_amd import synth, tiler
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def process_group(cuda_device):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(cuda_device))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _oracle_visible(scene, cam):
+    fr, _v, _p = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    ob.entities_update(scene, st)
+    vis, mask = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr)
+    return vis, mask
+
+
+@pytest.mark.parametrize("route", ["rccl", "c10d"])
+def test_world1_exchange_matches_oracle(route, cuda_device, process_group):
+    import torch
+    from clap_amd import entities, shard
+    scene, _tl = tiler.tiled_scene(synth.entities_forest(20_000, seed=77))
+    cams = [synth.camera(pos=(0, 5, 60)), synth.camera(pos=(30, 0, -20)), synth.camera(pos=(0, 0, 0))]
+    batch = entities.EntityBatch(scene, cuda_device)
+    xch = shard.VisibleExchange(batch, 0, 1, cuda_device, route=route)
+    if route == "rccl":
+        assert xch.direct is not None, "direct RCCL communicator must come up on the GPU box"
+        assert "ncclAllGather" in xch.route
+    else:
+        assert xch.direct is None
+    try:
+        for f, cam in enumerate(cams * 2):                  # six frames: both mask buffers reused several times
+            fr, _v, _p = entities.view_calc_frustum(cam)
+            xch.begin()
+            batch.mq_update(fr, all_dirty=True)
+            xch.submit()
+            torch.cuda.synchronize()
+            cnt, ids = xch.last()
+            got = ids[:int(cnt.item())].cpu().numpy().view(np.uint32)
+            vis, mask = _oracle_visible(scene, cam)
+            assert np.array_equal(got, vis), f"frame {f} ({route}): gathered visible set differs from the oracle"
+            g = xch.g_mask[(xch.frame - 1) & 1].cpu().numpy().view(np.uint64)
+            assert np.array_equal(g[:len(mask)], mask)
+    finally:
+        xch.destroy()
+
+
+def test_gathered_mask_expands_with_index_base(cuda_device, process_group):
+    """What rank r > 0 contributes: its ids offset by its range start.  Emulated on one GPU by compacting the
+    same gathered mask with index_base = r * n_pad, the id arithmetic of shard.py / bench.py."""
+    import ctypes as C
+    import torch
+    from clap_amd import _lib, entities, rccl
+    scene, _tl = tiler.tiled_scene(synth.entities_chains(700, 5, seed=5))
+    cam = synth.camera(pos=(0, 0, 40))
+    batch = entities.EntityBatch(scene, cuda_device)
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    batch.mq_update(fr, all_dirty=True)
+    comm = rccl.Communicator(0, 1, cuda_device)
+    side = torch.cuda.Stream(device=cuda_device)
+    gathered = torch.zeros_like(batch.vis_mask)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            comm.allgather_i64(batch.vis_mask, gathered, side)
+            out = torch.zeros(batch.n, dtype=torch.int32, device=cuda_device)
+            cnt = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+            scratch = torch.zeros(_lib.lib().clapgpu_visible_scratch_bytes(batch.n) // 4 + 4, dtype=torch.int32,
+                                  device=cuda_device)
+            base = 3 * batch.n
+            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(side.cuda_stream), gathered.data_ptr(), None, batch.n,
+                                                    base, out.data_ptr(), cnt.data_ptr(), scratch.data_ptr())
+            _lib.check(rc, "clapgpu_visible_compact")
+        torch.cuda.synchronize()
+    finally:
+        comm.destroy()
+    vis, _mask = _oracle_visible(scene, cam)
+    got = out[:int(cnt.item())].cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, vis.astype(np.int64) + base)

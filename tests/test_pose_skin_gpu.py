@@ -227,3 +227,46 @@ def test_c3_shape_properties(cuda_device):
     o2 = batch.download()
     assert_close(o2["out_position"], 2.0 * o1["out_position"], "skin linear in palette")
     assert np.isfinite(o1["joint_transforms"]).all() and np.isfinite(o1["out_position"]).all()
+
+
+def test_c3_full_size_pose_and_skin_match_oracle(cuda_device):
+    """BASELINE configs[2] at FULL size, the launch bench.py times: 50 000 characters x 64 joints, one distinct
+    200-vertex mesh per character (10 M vertices, 50 000 distinct vert_first offsets), pose_update + skin against
+    the oracle on EVERY output to 1e-5 -- the persistent grid wrapping 50 000 characters over the resident blocks,
+    the ragged last block and the per-character vertex windows are all inside the comparison."""
+    from clap_amd import animation
+    J, n, vpc = 64, 50_000, 200
+    sk = synth.skeleton(J, 8, seed=3)
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n, J, seed=3)
+    sk["bind"] = ob.skeleton_bind(sk)
+    mesh = synth.skinned_mesh(vpc, J, seed=3, copies=n)                # what bench.py builds
+    assert mesh["n_verts"] == n * vpc
+    vf = (np.arange(n, dtype=np.int64) * vpc).astype(np.uint32)
+    vc = np.full(n, vpc, np.uint32)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
+    batch.set_frame_times(ch["phase"])
+    batch.pose_update()
+    batch.skin()
+    out = batch.download()
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    jt, _g, jp = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
+    reach = sk["order"]
+    assert_close(out["trs"], trs, "C3 full size T/R/S")
+    assert_close(out["joint_transforms"][:, reach], jt[:, reach], "C3 full size joint_transforms")
+    assert_close(out["joint_pos"][:, reach], jp[:, reach], "C3 full size joint pos")
+    # per-character worst case too, so one bad character cannot hide in the global maximum
+    d = np.abs(out["joint_transforms"][:, reach].astype(np.float64) - jt[:, reach]).reshape(n, -1).max(axis=1)
+    s = np.abs(jt[:, reach]).reshape(n, -1).max(axis=1)
+    assert float((d / s).max()) <= RTOL, f"worst character {int((d / s).argmax())}: {(d / s).max():.3e}"
+    exp_p, exp_n = ob.skin(mesh, vf, vc, out["joint_transforms"])      # same palette in: isolates k_skin
+    assert_close(out["out_position"], exp_p, "C3 full size skinned positions")
+    assert_close(out["out_normal"], exp_n, "C3 full size skinned normals")
+    exp_p2, exp_n2 = ob.skin(mesh, vf, vc, jt)                         # end to end against the oracle's palette
+    assert_close(out["out_position"], exp_p2, "C3 full size pose -> skin positions")
+    assert_close(out["out_normal"], exp_n2, "C3 full size pose -> skin normals")
+    # per-vertex bound (positions scale with the character, so bound each vertex by its own character's extent)
+    ext = np.abs(exp_p2).reshape(n, vpc * 3).max(axis=1)
+    dv = np.abs(out["out_position"].astype(np.float64) - exp_p2).reshape(n, vpc * 3).max(axis=1)
+    assert float((dv / np.maximum(ext, 1e-30)).max()) <= RTOL
