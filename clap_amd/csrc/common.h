@@ -73,8 +73,12 @@ __device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4],
 typedef float clapgpu_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 {
+#ifdef CLAPGPU_PLAIN_STORES          // A/B builds only (tools/profile_entities_scale.sh): default-policy stores
+    *dst = v;
+#else
     const clapgpu_f4 t = { v.x, v.y, v.z, v.w };
     __builtin_nontemporal_store(t, reinterpret_cast<clapgpu_f4 *>(dst));
+#endif
 }
 
 // dst = first matrix of the wave's 64; nvalid = leading lanes whose matrix is stored

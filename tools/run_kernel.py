@@ -19,6 +19,18 @@ def main():
     from clap_amd import _lib, animation, particles, physics, synth
     _lib.check(_lib.lib().clapgpu_init(0), "init")
     dev = "cuda:0"
+    if which == "entities":                                     # entities <chains> <iters>: chains x depth 8, all dirty
+        from clap_amd import entities, tiler
+        chains, iters = iters, int(sys.argv[3]) if len(sys.argv) > 3 else 20
+        scene = tiler.tiled_scene(synth.entities_chains(chains, 8, seed=2))[0]
+        fr, _v, _p = entities.view_calc_frustum(synth.camera())
+        batch = entities.EntityBatch(scene, dev)
+        for _ in range(iters):
+            batch.mq_update(fr, all_dirty=True)
+            batch.compact_visible()
+        torch.cuda.synchronize()
+        print(f"{batch.n_real} entities, {batch.algorithmic_bytes()} algorithmic bytes per launch")
+        return
     if which == "frame":                                        # one clap_frame() of everything, 23 times
         import bench
         print(bench.full_frame(dev)["ms_per_frame"], "ms per frame")
