@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ROUND = "r01"
+ROUND = "r02"
 
 
 def parse():
@@ -149,7 +149,7 @@ def pmc_kernel_traffic(*names):
     newest committed summary profiles/<round>_*/pmc_hbm_bytes.json (tools/profile_round.sh), or None."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*", "pmc_hbm_bytes.json")), key=os.path.getmtime):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*", "pmc_hbm_bytes.json"))):   # by name: r02_a < r02_b < ...
         try:
             with open(path) as f:
                 best = json.load(f).get("kernels", {})
@@ -168,8 +168,11 @@ def pmc_kernel_traffic(*names):
 
 def roof(alg_bytes, seconds, *kernels):
     gbs = alg_bytes / seconds / 1e9
+    traffic = pmc_kernel_traffic(*kernels) if kernels else None
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": pmc_kernel_traffic(*kernels) if kernels else None,
+            "traffic": traffic,
+            # bytes that really moved (PMC, profiles/<round>_*/pmc_hbm_bytes.json of this tree) / this run's launch time / peak
+            "moved_frac": None if traffic is None else traffic / seconds / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": seconds * 1e6}
 
 
@@ -364,16 +367,6 @@ def full_frame(device):
             "launches": "one stream, no host read-back inside the frame"}
 
 
-def pmc_traffic():
-    """HBM bytes per k_entities_level launch from the committed PMC summary, if one exists."""
-    path = os.path.join(ROOT, "profiles", f"{ROUND}_entities_pmc.json")   # written by tools/pmc_summary.py
-    try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
-
-
 def main():
     args = parse()
     import torch
@@ -480,8 +473,9 @@ def main():
     mean_launch_s = float(lvl_ms.mean()) * 1e-3
     alg_bytes_step = batch.algorithmic_bytes()                                       # 276 B/child, 212 B/root
     alg_bytes_launch = alg_bytes_step / launches
-    achieved = alg_bytes_launch / mean_launch_s / 1e9
     n_levels = args.depth
+    # the committed PMC summary was taken on the default workload: only then is it this launch's traffic
+    default_workload = args.chains == 125_000 and args.depth == 8 and not args.snapshot and args.layout == "tiles"
 
     if rank == 0:
         out = {
@@ -498,12 +492,9 @@ def main():
                        "exchange": (xch.route
                                     + " of the visibility mask + local expansion to global ids, overlapped with "
                                     "the next frame's update") if use_dist else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "kernel": kernel, "launches_per_step": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "mean_launch_us": mean_launch_s * 1e6,
-                         "per_launch_us": [float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]},
+            "roofline": dict(roof(alg_bytes_launch, mean_launch_s, *([kernel] if default_workload else [])),
+                             kernel=kernel, launches_per_step=launches,
+                             per_launch_us=[float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]),
         }
         if world == 1 and not args.no_extras:
             del batch
