@@ -217,9 +217,10 @@ def extras(device, testbed=True):
                         "kernels": "k_particles_advect + k_visible_expand_rp + k_particles_respawn",
                         "roofline": roof(pb.algorithmic_bytes(), t_part, "k_particles_advect", "k_particles_respawn_rp")}
     del pb
-    # ---- configs[3], body half: 256k sphere bodies: integrate + both broadphase passes ----
-    b = synth.sphere_bodies(262_144, box=64.0, seed=4)
-    pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=device)
+    # ---- configs[3], body half: 256k bodies with the reference's geoms (capsules, "puppy" capsules, spheres): integrate +
+    #      both broadphase passes + narrowphase ----
+    b = synth.capsule_bodies(262_144, box=100.0, seed=4)
+    pw = physics.PhysWorld(b, synth.static_boxes(64, 100.0), pair_capacity=2_000_000, device=device)
     t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 30)
     t_bp = time_launches(pw.broadphase, 10)
     npairs = int(pw.pair_total.item())
@@ -227,8 +228,9 @@ def extras(device, testbed=True):
                      "roofline": roof(pw.integrate_algorithmic_bytes(), t_int, "k_bodies_step"),
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
-                                    "note": "hash build, bucket-ordered records, search, two counted scans, list copy; "
-                                            "latency- not HBM-bound"}}
+                                    "launches": 4,
+                                    "note": "both passes (bodies x bodies, statics x bodies) in k_bp_bin, k_bp_scatter, "
+                                            "k_bp_search, k_bp_emit; latency- not HBM-bound"}}
     del pw
     # ---- 8f rank 2: clustered-lighting tile masks, 128 light slots x a 4K screen at the reference's 64-px tiles ----
     from clap_amd import lights as gl
@@ -321,9 +323,9 @@ def full_frame(device):
     batch = entities.EntityBatch(scene, device)
     cam = synth.camera()
     n_bodies, n_bound, n_chars, J, vpc = 262_144, 75_000, 50_000, 64, 200
-    b = synth.sphere_bodies(n_bodies, box=64.0, seed=4)
+    b = synth.capsule_bodies(n_bodies, box=100.0, seed=4)
     b["body_entity"] = np.concatenate([roots[:n_bound], np.full(n_bodies - n_bound, -1)]).astype(np.int32)
-    world = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=2_000_000, device=device)
+    world = physics.PhysWorld(b, synth.static_boxes(64, 100.0), pair_capacity=2_000_000, device=device)
     feed = synth.character_feed(n_chars, seed=13, with_bodies=False)
     feed["entity"] = roots[n_bound:n_bound + n_chars].astype(np.uint32)
     cf = characters.CharacterFeed(feed, device)

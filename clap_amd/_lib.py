@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 OK = 0
 ERR_NOMEM = -1
@@ -109,13 +109,25 @@ class World(C.Structure):
 
 
 class Bodies(C.Structure):
-    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("quat", C.c_void_p),
+    """clapgpu_bodies (include/clapgpu.h)."""
+    _fields_ = [("n", C.c_uint32), ("adis_average_samples", C.c_uint32), ("pos", C.c_void_p), ("quat", C.c_void_p),
                 ("lvel", C.c_void_p), ("avel", C.c_void_p), ("mass", C.c_void_p), ("radius", C.c_void_p),
                 ("yoffset", C.c_void_p), ("bflags", C.c_void_p), ("adis_steps_left", C.c_void_p),
-                ("adis_time_left", C.c_void_p), ("body_entity", C.c_void_p)]
+                ("adis_time_left", C.c_void_p), ("body_entity", C.c_void_p),
+                ("length", C.c_void_p), ("inertia", C.c_void_p), ("geom_offset_R", C.c_double * 12),
+                ("aabb", C.c_void_p), ("axis", C.c_void_p), ("adis_samples", C.c_void_p), ("adis_counter", C.c_void_p)]
 
 
-BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY = 1, 2, 4
+class Geoms(C.Structure):
+    """clapgpu_geoms (include/clapgpu.h)."""
+    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("axis", C.c_void_p),
+                ("radius", C.c_void_p), ("length", C.c_void_p), ("kind", C.c_void_p), ("aabb", C.c_void_p),
+                ("material", C.c_void_p)]
+
+
+BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY, BODY_GYROSCOPIC, BODY_HAS_JOINT = 1, 2, 4, 8, 16
+GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_OTHER = 0, 1, 2, 3
+CONTACT_DEEP = 0x80000000
 
 
 class Characters(C.Structure):
@@ -172,11 +184,22 @@ SYMBOLS = {
     "clapgpu_bodies_step": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(World), C.c_double]),
     "clapgpu_phys_body_update": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
-    "clapgpu_broadphase_scratch_bytes": (C.c_size_t, [C.c_uint32]),
-    "clapgpu_broadphase_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_double, C.c_void_p, C.c_uint32,
-                                           C.c_void_p, C.c_void_p]),
-    "clapgpu_broadphase_static_pairs": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
-                                                  C.c_uint32, C.c_void_p, C.c_void_p]),
+    "clapgpu_geom_offset_rotation": (None, [C.POINTER(C.c_double)]),
+    "clapgpu_mass_sphere_total": (None, [C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "clapgpu_mass_capsule_total": (None, [C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "clapgpu_capsule_geom": (None, [C.c_float, C.c_float, C.c_float, C.c_double, C.c_double, C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "clapgpu_bodies_aabb": (C.c_int, [C.c_void_p, C.POINTER(Bodies)]),
+    "clapgpu_bp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_double, C.c_uint32, C.c_void_p]),
+    "clapgpu_bp_destroy": (None, [C.c_void_p]),
+    "clapgpu_bp_collide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.c_uint32, C.c_void_p]),
+    "clapgpu_bp_status": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "clapgpu_bp_static_aabb": (C.c_void_p, [C.c_void_p]),
+    "clapgpu_contacts_geoms": (C.c_int, [C.c_void_p, C.POINTER(Geoms), C.POINTER(Geoms), C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_sweep_capsules": (C.c_int, [C.c_void_p, C.POINTER(Geoms), C.POINTER(Geoms), C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_bodies_rotate_from_entities": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(Entities), C.c_uint32,
                                                       C.c_uint32, C.c_void_p, C.c_void_p]),
     "clapgpu_contacts_spheres": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_void_p, C.c_void_p, C.c_uint32,

@@ -76,11 +76,9 @@ class FrameLoop:
                     self.particles.particles_update(self.view_mx)
         if w is not None:                                   # phys_step: per fixed substep broadphase, contacts, integrate
             for _ in range(steps):
-                w.broadphase(side)
+                w.broadphase()
                 if self.contacts:
-                    w.contacts()
-                    if w.n_static:
-                        w.contacts_static()
+                    w.contacts_geoms()
                 w.world_step(1.0 / 120.0)
         if self.feed is not None:                           # character_update hooks
             self.feed.character_update(b, w)

@@ -393,6 +393,56 @@ def sphere_bodies(n=262_144, box=64.0, rmin=0.1, rmax=0.5, seed=4, entity_base=0
                 body_entity=(entity_base + np.arange(n)).astype(np.int32), cell=2.0 * rmax)
 
 
+def capsule_bodies(n=262_144, box=64.0, seed=4, sphere_frac=0.3, entity_base=0, resting_frac=0.0):
+    """C4 with the reference's body geoms: every body goes through phys_geom_capsule_new (physics.c:814-873) on a
+    random entity AABB -- upright capsules, "puppy" capsules along Z, and spheres where the capsule length comes
+    out 0 (`sphere_frac` of the bodies get a cube AABB, which does exactly that) -- with dMassSetCapsuleTotal /
+    dMassSetSphereTotal inertia, random orientations and spins, gyroscopic mode on (dBodyCreate's default)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()                                          # host helpers only: no GPU needed
+    rng = _rng(seed)
+    ext = np.empty((n, 3), np.float32)
+    kind = rng.uniform(0, 1, n)
+    ext[:, 0] = rng.uniform(0.2, 0.5, n)
+    ext[:, 1] = rng.uniform(0.9, 1.8, n)                     # tall: upright capsule
+    ext[:, 2] = rng.uniform(0.2, 0.5, n)
+    puppy = kind > 0.75
+    ext[puppy, 1] = rng.uniform(0.3, 0.5, int(puppy.sum()))
+    ext[puppy, 0] = rng.uniform(0.2, 0.3, int(puppy.sum()))
+    ext[puppy, 2] = rng.uniform(0.8, 1.6, int(puppy.sum())) # long in Z: direction 3
+    sph = kind < sphere_frac
+    ext[sph] = rng.uniform(0.2, 1.0, int(sph.sum()))[:, None]
+    radius, length, yoffset = np.zeros(n), np.zeros(n), np.zeros(n)
+    inertia = np.zeros((n, 3))
+    mass = rng.uniform(0.5, 5.0, n)
+    r, l, off, ro, d, I = C.c_float(), C.c_float(), C.c_float(), C.c_float(), C.c_int(), (C.c_double * 3)()
+    for i in range(n):
+        L.clapgpu_capsule_geom(float(ext[i, 0]), float(ext[i, 1]), float(ext[i, 2]), 0.0, 0.0, C.byref(r), C.byref(l),
+                               C.byref(off), C.byref(d), C.byref(ro))
+        radius[i], length[i], yoffset[i] = r.value, l.value, off.value
+        if l.value:
+            L.clapgpu_mass_capsule_total(float(mass[i]), d.value, float(r.value), float(l.value), I)
+        else:
+            L.clapgpu_mass_sphere_total(float(mass[i]), float(r.value), I)
+        inertia[i] = I[0], I[1], I[2]
+    ang = rng.uniform(-math.pi, math.pi, (n, 3))
+    q = quat_from_euler_xyz(ang[:, 0], ang[:, 1], ang[:, 2]).astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    lvel = rng.normal(0, 1, (n, 3))
+    avel = rng.normal(0, 2.0, (n, 3))
+    rest = rng.uniform(0, 1, n) < resting_frac
+    lvel[rest] *= 1e-3
+    avel[rest] *= 1e-3
+    bflags = np.full(n, 2 | 8, np.uint32)                    # auto-disable (physics.c:1039) + gyroscopic (dBodyCreate)
+    bflags[rest] |= 4
+    return dict(n=n, pos=rng.uniform(0, box, (n, 3)), quat=q[:, [3, 0, 1, 2]].copy(), lvel=lvel, avel=avel, mass=mass,
+                radius=radius, length=length, inertia=inertia, yoffset=yoffset, bflags=bflags,
+                adis_steps_left=np.full(n, 30, np.int32), adis_time_left=np.zeros(n),
+                body_entity=(entity_base + np.arange(n)).astype(np.int32),
+                cell=float((length + 2 * radius).max()) if n else 1.0)
+
+
 def static_boxes(n=64, box=64.0, seed=5):
     """Static collision geoms (the ground_space): AABBs as ODE stores them (minx,maxx,miny,maxy,minz,maxz)."""
     rng = _rng(seed)

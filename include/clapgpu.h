@@ -449,17 +449,37 @@ typedef struct clapgpu_world {
     int32_t pad;
 } clapgpu_world;
 
+#define CLAPGPU_BODY_GYROSCOPIC    (1u << 3)   /* dxBodyGyroscopic: dBodyCreate sets it, dBodySetGyroscopicMode(b, 0) clears it */
+#define CLAPGPU_BODY_HAS_JOINT     (1u << 4)   /* the body holds a (contact) joint this step: ODE never auto-disables a jointless
+                                                  body; set by clapgpu_contacts_geoms, cleared by clapgpu_bodies_step */
+#define CLAPGPU_GEOM_SPHERE  0
+#define CLAPGPU_GEOM_CAPSULE 1
+#define CLAPGPU_GEOM_BOX     2                 /* an axis-aligned box given by its AABB (stand-in for any static geom) */
+#define CLAPGPU_GEOM_OTHER   3                 /* trimesh etc.: broadphase only, no narrowphase here */
+
 /*
- * Sphere bodies of the character_space, fp64 like the reference's dDOUBLE ODE (physics.h:5-9).
+ * Bodies of the character_space, fp64 like the reference's dDOUBLE ODE (physics.h:5-9): capsules
+ * (phys_geom_capsule_new -> dCreateCapsule + dMassSetCapsuleTotal, physics.c:814-873) and, when the
+ * capsule's length comes out 0, spheres (dCreateSphere + dMassSetSphereTotal, physics.c:866-873).
  *   pos[n][3], quat[n][4] (w,x,y,z = ODE order), lvel[n][3], avel[n][3]  in/out
- *   mass[n], radius[n]                                                     geometry / dMass
+ *   mass[n], radius[n]                                                     dMass.mass, geom radius
  *   yoffset[n]      phys_body.yoffset (physics.c:797-799)
  *   bflags[n]       CLAPGPU_BODY_* ; adis_steps_left / adis_time_left: ODE's auto-disable counters
  *   body_entity[n]  index of the entity3d the geom's data points at, or -1
+ *   length[n]       capsule cylinder length, 0 = sphere; NULL = all spheres
+ *   inertia[n][3]   diagonal of dMass.I in the body frame (clapgpu_mass_capsule_total / _sphere_total);
+ *                   NULL = no rotational dynamics beyond the free spin (as if dBodySetGyroscopicMode(b, 0))
+ *   geom_offset_R   dGeomSetOffsetRotation of the capsule geoms (physics.c:974-978), ODE dMatrix3
+ *                   (3 rows of 4); clapgpu_geom_offset_rotation() fills it
+ *   aabb[n][6]      out: the geom's AABB (minx,maxx,miny,maxy,minz,maxz), ODE's dReal aabb[6]; written by
+ *                   clapgpu_bodies_aabb and by clapgpu_bodies_step for the bodies it moves; may be NULL
+ *   axis[n][3]      out: the capsule's axis in world space (column 2 of body R * offset R); may be NULL
+ *   adis_average_samples  dBodySetAutoDisableAverageSamplesCount (ODE's default: 1 = the instantaneous
+ *                   velocity); > 1 needs adis_samples[n][samples][6] (lvel, avel ring) and adis_counter[n]
  */
 typedef struct clapgpu_bodies {
     uint32_t        n;
-    uint32_t        pad;
+    uint32_t        adis_average_samples;
     double         *pos;
     double         *quat;
     double         *lvel;
@@ -471,13 +491,35 @@ typedef struct clapgpu_bodies {
     int32_t        *adis_steps_left;
     double         *adis_time_left;
     const int32_t  *body_entity;
+    const double   *length;
+    const double   *inertia;
+    double          geom_offset_R[12];
+    double         *aabb;
+    double         *axis;
+    double         *adis_samples;
+    uint32_t       *adis_counter;
 } clapgpu_bodies;
+
+/* host helpers for the set-up the reference does once per body (no device work) */
+void clapgpu_geom_offset_rotation(double R[12]);                        /* dRFromAxisAndAngle(1,1,1,-2pi/3), physics.c:974-978 */
+void clapgpu_mass_sphere_total(double total_mass, double radius, double I[3]);                 /* dMassSetSphereTotal */
+void clapgpu_mass_capsule_total(double total_mass, int direction, double radius, double length, double I[3]);
+/* phys_geom_capsule_new (physics.c:814-873): entity AABB extents -> capsule radius, length, yoffset, direction, ray_off */
+void clapgpu_capsule_geom(float X, float Y, float Z, double geom_radius, double geom_offset,
+                          float *radius, float *length, float *yoffset, int *direction, float *ray_off);
+/* axis + AABB of every body geom from the current pose (dxCapsule::computeAABB / dxSphere::computeAABB) */
+int clapgpu_bodies_aabb(void *stream, const clapgpu_bodies *b);
 
 /* physics.c:773-787: adds dt to *time_acc and returns how many 1/120 s substeps to run (0..5) */
 int  clapgpu_phys_step_schedule(double *time_acc, double dt);
 void clapgpu_world_defaults(clapgpu_world *w);
 
-/* dWorldQuickStep(world, h) for bodies without joints (physics.c:769) */
+/*
+ * dWorldQuickStep(world, h) for bodies without constraint rows (physics.c:769): auto-disable bookkeeping
+ * (bodies holding a joint only, averaged over adis_average_samples), gravity, the implicit gyroscopic torque
+ * of CLAPGPU_BODY_GYROSCOPIC bodies with an inertia tensor, velocity and pose update, linear damping, then
+ * the moved geom's axis and AABB.
+ */
 int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h);
 
 /*
@@ -502,26 +544,8 @@ int clapgpu_bodies_rotate_from_entities(void *stream, const clapgpu_bodies *b, c
                                         const uint32_t *link_entity);
 
 /*
- * dSpaceCollide(character_space) (physics.c:753): all body pairs whose AABBs overlap, as the
- * ascending list pairs[k] = (i, j), i < j.  cell >= the largest AABB edge (2 * max radius).
- * *pair_total (device uint32) receives the number found; at most `capacity` are written.
- * scratch: clapgpu_broadphase_scratch_bytes(n) bytes of device memory.
- */
-size_t clapgpu_broadphase_scratch_bytes(uint32_t n);
-int clapgpu_broadphase_pairs(void *stream, const clapgpu_bodies *b, double cell,
-                             uint32_t *pairs, uint32_t capacity, uint32_t *pair_total, void *scratch);
-
-/*
- * dSpaceCollide2(ground_space, character_space) (physics.c:751): pairs (body, static geom),
- * ascending; static_aabb[s] = (minx,maxx,miny,maxy,minz,maxz) like ODE's dReal aabb[6] (device).
- */
-int clapgpu_broadphase_static_pairs(void *stream, const clapgpu_bodies *b, uint32_t n_static,
-                                    const double *static_aabb, uint32_t *pairs, uint32_t capacity,
-                                    uint32_t *pair_total, void *scratch);
-
-/*
  * near_callback() for the sphere bodies (physics.c:399-449): dCollide on every
- * candidate pair of clapgpu_broadphase_pairs, plus the surface parameters phys_contact_surface
+ * candidate pair of clapgpu_bp_collide, plus the surface parameters phys_contact_surface
  * (physics.c:291-330) gives each contact.  One record per pair, in pair order (the reference
  * creates its contact joints in callback order; here the canonical pair order): nc = dCollide's
  * return value (0 or 1 for spheres).  ODE's dContactGeom / dSurfaceParameters fields, doubles.
@@ -543,7 +567,7 @@ int clapgpu_contacts_spheres(void *stream, const clapgpu_bodies *b, const uint32
                              const uint32_t *pair_total, uint32_t capacity, const double *material,
                              clapgpu_contact *contacts, uint32_t *contact_total);
 /*
- * The same for the (body, static geom) candidate pairs of clapgpu_broadphase_static_pairs: dCollide of a
+ * The same for the (body, static geom) candidate pairs of clapgpu_bp_collide: dCollide of a
  * sphere (g1) against an axis-aligned box (g2) -- ODE's dCollideSphereBox with the box given as static_aabb[s]
  * (position = centre, side = max - min, no rotation): the sphere centre clamped to the box, contact at the
  * clamped point with the normal from the box to the sphere, or, for a centre inside the box, at the
@@ -555,6 +579,68 @@ int clapgpu_contacts_sphere_box(void *stream, const clapgpu_bodies *b, uint32_t 
                                 const double *static_aabb, const uint32_t *pairs, const uint32_t *pair_total,
                                 uint32_t capacity, const double *material, const double *static_material,
                                 clapgpu_contact *contacts, uint32_t *contact_total);
+
+/*
+ * Broadphase over explicit fp64 AABBs (round 2): both calls of __phys_step (physics.c:751-753) in one pass of
+ * four launches.  Bodies are binned by their AABB centre into a hash grid of 4x4x4-cell blocks (cell >= the
+ * largest body AABB edge); one wavefront per block tests the block's own bodies against the block + its halo
+ * staged in LDS, and against the static geoms registered for that block.
+ *   clapgpu_bp_create   n_max bodies; statics: n_static AABBs in HOST memory (copied; binned once: statics do
+ *                       not move; those spanning more than 64 blocks are kept in a list every block tests)
+ *   clapgpu_bp_collide  aabb: device [n][6] (clapgpu_bodies.aabb).  pairs / static_pairs are ascending (i, j), i < j resp. (body, static);
+ *                       *_total = number found (device uint32), at most `capacity` written (when a total
+ *                       exceeds its capacity the written part is incomplete).  static outputs may be NULL.
+ *   clapgpu_bp_status   host sync; bit 0: a body AABB edge exceeded `cell` (pairs may be missing)
+ */
+typedef struct clapgpu_bp clapgpu_bp;
+int  clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, uint32_t n_static, const double *static_aabb_host);
+void clapgpu_bp_destroy(clapgpu_bp *bp);
+int  clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, const double *aabb,
+                        uint32_t *pairs, uint32_t capacity, uint32_t *pair_total,
+                        uint32_t *static_pairs, uint32_t static_capacity, uint32_t *static_pair_total);
+int  clapgpu_bp_status(void *stream, clapgpu_bp *bp, uint32_t *status);
+const double *clapgpu_bp_static_aabb(const clapgpu_bp *bp);            /* the device copy of the static AABBs */
+
+/*
+ * near_callback (physics.c:399-449) on candidate pairs (ia in A, ib in B; g1 = A's geom): dCollide for spheres,
+ * capsules and axis-aligned boxes (dCollideSpheres, dCollideCapsuleSphere, dCollideCapsuleCapsule with its
+ * two-contact parallel case, dCollideSphereBox, dCollideCapsuleBox; reversed like dCollide when only the
+ * swapped collider exists) + phys_contact_surface (physics.c:291-330).  One 160-byte record per pair.
+ * A capsule whose axis touches a box is where ODE switches to dBoxBox: flagged CLAPGPU_CONTACT_DEEP, nc bits 0.
+ * body_flags_a / _b (may be NULL): bflags of the body sets behind A / B; touching pairs set CLAPGPU_BODY_HAS_JOINT.
+ */
+typedef struct clapgpu_geoms {
+    uint32_t        n, pad;
+    const double   *pos;            /* [n][3] geom position (boxes: the centre of aabb is used) */
+    const double   *axis;           /* [n][3] capsule axis (clapgpu_bodies.axis) */
+    const double   *radius, *length;/* [n]; length NULL = no capsules */
+    const uint8_t  *kind;           /* [n] CLAPGPU_GEOM_*; NULL = sphere when length is 0, else capsule */
+    const double   *aabb;           /* [n][6] boxes */
+    const double   *material;       /* [n][5] bounce, bounce_vel, mu, soft_erp, soft_cfm (physics.c:77-81); may be NULL */
+} clapgpu_geoms;
+#define CLAPGPU_CONTACT_DEEP 0x80000000u
+typedef struct clapgpu_contact2 {
+    double   pos[3], normal[3], depth;
+    double   mu, bounce, bounce_vel, soft_erp, soft_cfm;
+    uint32_t mode;
+    uint32_t nc;                    /* 0, 1, 2, or CLAPGPU_CONTACT_DEEP */
+    double   pos2[3], normal2[3], depth2;
+} clapgpu_contact2;
+int clapgpu_contacts_geoms(void *stream, const clapgpu_geoms *A, const clapgpu_geoms *B, const uint32_t *pairs,
+                           const uint32_t *pair_total, uint32_t capacity, clapgpu_contact2 *contacts,
+                           uint32_t *contact_total, uint32_t *body_flags_a, uint32_t *body_flags_b);
+
+/*
+ * phys_body_sweep_capsule (physics.c:559-670) for a batch of sweeps: sweep k marches a probe copy of body
+ * sweep_body[k] (a geom of A) along delta[k] in max(2, ceil(|delta| / (radius / 2))) steps and collides it at
+ * every step with its candidate geoms cand[cand_first[k] .. cand_first[k + 1]): an index into B (statics) or,
+ * with bit 31 set, into A (other bodies; the body itself is skipped).  Out per sweep: frac (best_frac),
+ * normal[3], hit (body index, -2 - static index, or -1).  Contacts are taken in candidate order, 16 per
+ * step at most (MAX_CONTACTS).  One wavefront per sweep.
+ */
+int clapgpu_sweep_capsules(void *stream, const clapgpu_geoms *A, const clapgpu_geoms *B, uint32_t n_sweeps,
+                           const uint32_t *sweep_body, const float *delta, const uint32_t *cand_first,
+                           const uint32_t *cand, float *frac, float *normal, int32_t *hit);
 
 /* ======================================================================== */
 /* Characters: the feeder in front of default_update (core/character.c)      */

@@ -50,6 +50,23 @@ class World(C.Structure):
                 ("adis_steps", C.c_int32), ("pad", C.c_int32)]
 
 
+class Bodies(C.Structure):
+    """clapo_bodies (clap_oracle.h; same layout as clapgpu_bodies)."""
+    _fields_ = [("n", C.c_uint32), ("adis_average_samples", C.c_uint32), ("pos", C.c_void_p), ("quat", C.c_void_p),
+                ("lvel", C.c_void_p), ("avel", C.c_void_p), ("mass", C.c_void_p), ("radius", C.c_void_p),
+                ("yoffset", C.c_void_p), ("bflags", C.c_void_p), ("adis_steps_left", C.c_void_p),
+                ("adis_time_left", C.c_void_p), ("body_entity", C.c_void_p),
+                ("length", C.c_void_p), ("inertia", C.c_void_p), ("geom_offset_R", C.c_double * 12),
+                ("aabb", C.c_void_p), ("axis", C.c_void_p), ("adis_samples", C.c_void_p), ("adis_counter", C.c_void_p)]
+
+
+class Geoms(C.Structure):
+    """clapo_geoms."""
+    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("axis", C.c_void_p),
+                ("radius", C.c_void_p), ("length", C.c_void_p), ("kind", C.c_void_p), ("aabb", C.c_void_p),
+                ("material", C.c_void_p)]
+
+
 def build():
     """Compile the restatement (gcc).  Building the checker is not using it."""
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -105,13 +122,27 @@ def _declare(L):
     L.clapo_phys_step_schedule.argtypes = [C.POINTER(C.c_double), C.c_double]
     L.clapo_phys_step_schedule.restype = C.c_int
     L.clapo_world_defaults.argtypes = [C.POINTER(World)]
-    L.clapo_bodies_step.argtypes = [C.c_uint32, C.c_double, C.POINTER(World), F64P, F64P, F64P, F64P, F64P, U32P,
-                                    I32P, F64P]
     L.clapo_phys_body_update.argtypes = [C.c_uint32, F64P, F64P, F64P, F64P, I32P, F32P, F32P, U32P, C.c_void_p]
     L.clapo_broadphase_pairs.argtypes = [C.c_uint32, F64P, F64P, C.c_void_p, C.c_uint64]
     L.clapo_broadphase_pairs.restype = C.c_uint64
     L.clapo_broadphase_static_pairs.argtypes = [C.c_uint32, F64P, C.c_uint32, F64P, F64P, C.c_void_p, C.c_uint64]
     L.clapo_broadphase_static_pairs.restype = C.c_uint64
+    L.clapo_geom_offset_rotation.argtypes = [C.POINTER(C.c_double)]
+    L.clapo_mass_sphere_total.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.clapo_mass_capsule_total.argtypes = [C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.clapo_capsule_geom.argtypes = [C.c_float, C.c_float, C.c_float, C.c_double, C.c_double, C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L.clapo_bodies_aabb.argtypes = [C.POINTER(Bodies)]
+    L.clapo_bodies_step2.argtypes = [C.POINTER(Bodies), C.POINTER(World), C.c_double]
+    L.clapo_broadphase_aabb_pairs.argtypes = [C.c_uint32, F64P, C.c_void_p, C.c_uint64]
+    L.clapo_broadphase_aabb_pairs.restype = C.c_uint64
+    L.clapo_broadphase_aabb_static_pairs.argtypes = [C.c_uint32, F64P, C.c_uint32, F64P, C.c_void_p, C.c_uint64]
+    L.clapo_broadphase_aabb_static_pairs.restype = C.c_uint64
+    L.clapo_contacts_geoms.argtypes = [C.c_uint32, U32P, C.POINTER(Geoms), C.POINTER(Geoms), C.c_void_p]
+    L.clapo_contacts_geoms.restype = C.c_uint32
+    L.clapo_sweep_capsule.argtypes = [C.POINTER(Geoms), C.c_uint32, F32P, C.POINTER(Geoms), C.c_uint32, U32P, F32P,
+                                      C.POINTER(C.c_int32)]
+    L.clapo_sweep_capsule.restype = C.c_float
     L.clapo_aabb_avg_edge.argtypes = [F32P, C.c_float]
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
@@ -295,15 +326,130 @@ def phys_step_schedule(time_acc, dt):
 
 
 def bodies_state(b):
-    """Mutable copy of the dynamic state of a synth.sphere_bodies() dict."""
-    return {k: np.ascontiguousarray(b[k]).copy() for k in ("pos", "quat", "lvel", "avel", "bflags",
-                                                             "adis_steps_left", "adis_time_left")}
+    """Mutable copy of the dynamic state of a synth.sphere_bodies() / capsule_bodies() dict (+ geom outputs)."""
+    st = {k: np.ascontiguousarray(b[k]).copy() for k in ("pos", "quat", "lvel", "avel", "bflags",
+                                                           "adis_steps_left", "adis_time_left")}
+    n = int(b["n"])
+    st["aabb"] = np.zeros((n, 6))
+    st["axis"] = np.zeros((n, 3))
+    samples = int(b.get("adis_average_samples", 1))
+    if samples > 1:
+        st["adis_samples"] = np.zeros((n, samples, 6))
+        st["adis_counter"] = np.zeros(n, np.uint32)
+    return st
+
+
+def _bodies_struct(b, st):
+    keep = dict(mass=np.ascontiguousarray(b["mass"], np.float64), radius=np.ascontiguousarray(b["radius"], np.float64),
+                yoffset=np.ascontiguousarray(b["yoffset"], np.float64),
+                body_entity=np.ascontiguousarray(b["body_entity"], np.int32))
+    s = Bodies(int(b["n"]), int(b.get("adis_average_samples", 1)), st["pos"].ctypes.data, st["quat"].ctypes.data,
+               st["lvel"].ctypes.data, st["avel"].ctypes.data, keep["mass"].ctypes.data, keep["radius"].ctypes.data,
+               keep["yoffset"].ctypes.data, st["bflags"].ctypes.data, st["adis_steps_left"].ctypes.data,
+               st["adis_time_left"].ctypes.data, keep["body_entity"].ctypes.data)
+    for k in ("length", "inertia"):
+        if k in b:
+            keep[k] = np.ascontiguousarray(b[k], np.float64)
+            setattr(s, k, keep[k].ctypes.data)
+    lib().clapo_geom_offset_rotation(s.geom_offset_R)
+    s.aabb, s.axis = st["aabb"].ctypes.data, st["axis"].ctypes.data
+    if "adis_samples" in st:
+        s.adis_samples, s.adis_counter = st["adis_samples"].ctypes.data, st["adis_counter"].ctypes.data
+    return s, keep
+
+
+def bodies_aabb(b, st):
+    """Geom axis + AABB of every body (st["axis"], st["aabb"])."""
+    s, _keep = _bodies_struct(b, st)
+    lib().clapo_bodies_aabb(C.byref(s))
 
 
 def bodies_step(b, st, h, world=None):
     w = world or world_defaults()
-    lib().clapo_bodies_step(int(b["n"]), h, C.byref(w), st["pos"], st["quat"], st["lvel"], st["avel"],
-                            np.ascontiguousarray(b["mass"]), st["bflags"], st["adis_steps_left"], st["adis_time_left"])
+    s, _keep = _bodies_struct(b, st)
+    lib().clapo_bodies_step2(C.byref(s), C.byref(w), h)
+
+
+def geom_offset_rotation():
+    R = (C.c_double * 12)()
+    lib().clapo_geom_offset_rotation(R)
+    return np.array(R)
+
+
+def capsule_geom(X, Y, Z, geom_radius=0.0, geom_offset=0.0):
+    r, l, off, ro = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    d = C.c_int()
+    lib().clapo_capsule_geom(X, Y, Z, geom_radius, geom_offset, C.byref(r), C.byref(l), C.byref(off), C.byref(d), C.byref(ro))
+    return r.value, l.value, off.value, d.value, ro.value
+
+
+def mass_capsule_total(mass, direction, radius, length):
+    I = (C.c_double * 3)()
+    lib().clapo_mass_capsule_total(mass, direction, radius, length, I)
+    return np.array(I)
+
+
+def mass_sphere_total(mass, radius):
+    I = (C.c_double * 3)()
+    lib().clapo_mass_sphere_total(mass, radius, I)
+    return np.array(I)
+
+
+def broadphase_aabb_pairs(aabb, max_pairs=None):
+    n = aabb.shape[0]
+    cap = int(max_pairs if max_pairs is not None else max(16 * n, 1024))
+    pairs = np.zeros((cap, 2), np.uint32)
+    cnt = lib().clapo_broadphase_aabb_pairs(n, np.ascontiguousarray(aabb, np.float64), pairs.ctypes.data, cap)
+    assert cnt <= cap, "oracle pair buffer too small"
+    return pairs[:cnt].copy()
+
+
+def broadphase_aabb_static_pairs(statics, aabb, max_pairs=None):
+    n = aabb.shape[0]
+    cap = int(max_pairs if max_pairs is not None else max(16 * n, 1024))
+    pairs = np.zeros((cap, 2), np.uint32)
+    cnt = lib().clapo_broadphase_aabb_static_pairs(statics.shape[0], np.ascontiguousarray(statics, np.float64), n,
+                                                   np.ascontiguousarray(aabb, np.float64), pairs.ctypes.data, cap)
+    assert cnt <= cap
+    return pairs[:cnt].copy()
+
+
+CONTACT2_DTYPE = np.dtype([("pos", np.float64, 3), ("normal", np.float64, 3), ("depth", np.float64),
+                           ("mu", np.float64), ("bounce", np.float64), ("bounce_vel", np.float64),
+                           ("soft_erp", np.float64), ("soft_cfm", np.float64), ("mode", np.uint32), ("nc", np.uint32),
+                           ("pos2", np.float64, 3), ("normal2", np.float64, 3), ("depth2", np.float64)])
+
+
+def geoms(n, pos=None, axis=None, radius=None, length=None, kind=None, aabb=None, material=None):
+    """clapo_geoms over numpy arrays; returns (struct, keep-alive list)."""
+    keep = []
+
+    def p(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
+    g = Geoms(int(n), 0, p(pos, np.float64), p(axis, np.float64), p(radius, np.float64), p(length, np.float64),
+              p(kind, np.uint8), p(aabb, np.float64), p(material, np.float64))
+    return g, keep
+
+
+def contacts_geoms(pairs, A, B):
+    """A, B: (struct, keep) from geoms().  One clapo_contact2 per pair; returns (records, touching pairs)."""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    out = np.zeros(len(pairs), CONTACT2_DTYPE)
+    total = lib().clapo_contacts_geoms(len(pairs), pairs.ravel(), C.byref(A[0]), C.byref(B[0]), out.ctypes.data)
+    return out, int(total)
+
+
+def sweep_capsule(A, self_idx, delta, B, cand):
+    normal = np.zeros(3, np.float32)
+    hit = C.c_int32(-1)
+    cand = np.ascontiguousarray(cand, np.uint32)
+    frac = lib().clapo_sweep_capsule(C.byref(A[0]), int(self_idx), np.ascontiguousarray(delta, np.float32), C.byref(B[0]),
+                                     len(cand), cand, normal, C.byref(hit))
+    return float(frac), normal, int(hit.value)
 
 
 def phys_body_update(b, st, pos_scale, rot, entity_flags):

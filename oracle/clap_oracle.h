@@ -202,11 +202,6 @@ typedef struct clapo_world {
 
 int      clapo_phys_step_schedule(double *time_acc, double dt);
 void     clapo_world_defaults(clapo_world *w);
-/* pos[n][3], quat[n][4] (w,x,y,z: ODE order), lvel[n][3], avel[n][3] doubles */
-void     clapo_bodies_step(uint32_t n, double h, const clapo_world *w,
-                           double *pos, double *quat, double *lvel, double *avel,
-                           const double *mass, uint32_t *bflags, int32_t *adis_steps_left,
-                           double *adis_time_left);
 void     clapo_phys_body_update(uint32_t n, const double *pos, const double *quat, const double *lvel,
                                 const double *yoffset, const int32_t *body_entity,
                                 float *pos_scale, float *rot, uint32_t *entity_flags, uint8_t *moving);
@@ -253,6 +248,73 @@ uint32_t clapo_contacts_spheres(uint32_t n_pairs, const uint32_t *pairs, const d
 uint32_t clapo_contacts_sphere_box(uint32_t n_pairs, const uint32_t *pairs, const double *pos, const double *radius,
                                    const double *static_aabb, const double *material, const double *static_material,
                                    clapo_contact *out);
+
+
+/* ---- round 2: capsule bodies, general AABBs, capsule contacts, capsule sweep (physics2.c; PARITY UNPINNED: ODE) ---- */
+#define CLAPO_BODY_GYROSCOPIC    (1u << 3)   /* dxBodyGyroscopic: set by dBodyCreate, cleared by dBodySetGyroscopicMode(b, 0) */
+#define CLAPO_BODY_HAS_JOINT     (1u << 4)   /* the body has a (contact) joint this step: dInternalHandleAutoDisabling skips jointless bodies */
+#define CLAPO_GEOM_SPHERE  0
+#define CLAPO_GEOM_CAPSULE 1
+#define CLAPO_GEOM_BOX     2                 /* an axis-aligned box given by its AABB (stand-in for any static geom) */
+#define CLAPO_GEOM_OTHER   3                 /* trimesh / anything without a narrowphase here: broadphase only */
+
+/* same layout as clapgpu_bodies (include/clapgpu.h) */
+typedef struct clapo_bodies {
+    uint32_t        n;
+    uint32_t        adis_average_samples;   /* dBodySetAutoDisableAverageSamplesCount; 0 and 1 = ODE's default single sample */
+    double         *pos, *quat, *lvel, *avel;
+    const double   *mass, *radius, *yoffset;
+    uint32_t       *bflags;
+    int32_t        *adis_steps_left;
+    double         *adis_time_left;
+    const int32_t  *body_entity;
+    const double   *length;                 /* [n] capsule cylinder length, 0 = sphere; NULL = all spheres */
+    const double   *inertia;                /* [n][3] diagonal of dMass.I (body frame); NULL = no gyroscopic torque */
+    double          geom_offset_R[12];      /* dGeomSetOffsetRotation of the capsule geoms (physics.c:974-978), dMatrix3 */
+    double         *aabb;                   /* [n][6] out: geom AABB (minx,maxx,miny,maxy,minz,maxz) */
+    double         *axis;                   /* [n][3] out: capsule axis = column 2 of the geom's final rotation */
+    double         *adis_samples;           /* [n][samples][6] lvel, avel ring (samples > 1 only) */
+    uint32_t       *adis_counter;           /* [n] average_counter | average_ready << 31 */
+} clapo_bodies;
+
+void clapo_geom_offset_rotation(double R[12]);                                         /* physics.c:974-978 */
+void clapo_mass_sphere_total(double total_mass, double radius, double I[3]);           /* dMassSetSphereTotal */
+void clapo_mass_capsule_total(double total_mass, int direction, double radius, double length, double I[3]);
+/* phys_geom_capsule_new (physics.c:814-873): entity AABB extents X, Y, Z -> radius, length, yoffset, direction, ray_off */
+void clapo_capsule_geom(float X, float Y, float Z, double geom_radius, double geom_offset,
+                        float *r, float *length, float *yoffset, int *direction, float *ray_off);
+void clapo_bodies_aabb(const clapo_bodies *b);
+void clapo_bodies_step2(const clapo_bodies *b, const clapo_world *w, double h);
+uint64_t clapo_broadphase_aabb_pairs(uint32_t n, const double *aabb, uint32_t *pairs, uint64_t max_pairs);
+uint64_t clapo_broadphase_aabb_static_pairs(uint32_t n_static, const double *static_aabb, uint32_t n, const double *aabb,
+                                            uint32_t *pairs, uint64_t max_pairs);
+
+/* narrowphase view of a geom set (bodies after clapo_bodies_aabb, or statics) */
+typedef struct clapo_geoms {
+    uint32_t        n, pad;
+    const double   *pos;                    /* [n][3] geom position (box: unused, the centre of aabb is taken) */
+    const double   *axis;                   /* [n][3] capsule axis (unit) */
+    const double   *radius, *length;        /* [n] (length NULL = all spheres / boxes) */
+    const uint8_t  *kind;                   /* [n] CLAPO_GEOM_*; NULL = sphere when length is 0, else capsule */
+    const double   *aabb;                   /* [n][6] boxes: position = centre, side = extent */
+    const double   *material;               /* [n][5] bounce, bounce_vel, mu, soft_erp, soft_cfm; may be NULL */
+} clapo_geoms;
+
+#define CLAPO_CONTACT_DEEP 0x80000000u      /* capsule axis inside a box: ODE switches to dBoxBox; left to the host */
+typedef struct clapo_contact2 {
+    double   pos[3], normal[3], depth;                  /* first dContactGeom */
+    double   mu, bounce, bounce_vel, soft_erp, soft_cfm;
+    uint32_t mode;
+    uint32_t nc;                                        /* 0, 1 or 2 (| CLAPO_CONTACT_DEEP) */
+    double   pos2[3], normal2[3], depth2;               /* second dContactGeom (parallel capsules) */
+} clapo_contact2;
+/* near_callback on candidate pairs (ia in A, ib in B): g1 = A's geom, g2 = B's geom.  Returns the number of touching pairs. */
+uint32_t clapo_contacts_geoms(uint32_t n_pairs, const uint32_t *pairs, const clapo_geoms *A, const clapo_geoms *B,
+                              clapo_contact2 *out);
+/* phys_body_sweep_capsule (physics.c:559-670) of body `self` of A along delta against candidate geoms:
+ * cand[k] = index into B (statics) or, with bit 31 set, into A (other bodies).  Returns best_frac. */
+float clapo_sweep_capsule(const clapo_geoms *A, uint32_t self, const float delta[3], const clapo_geoms *B,
+                          uint32_t n_cand, const uint32_t *cand, float normal[3], int32_t *hit);
 
 /* ---- clustered-lighting tile masks (light.c:88-154, 301-309; light.c) ---- */
 float clapo_light_radius(const float color[3], const float att[3], int is_dir);

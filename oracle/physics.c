@@ -19,11 +19,9 @@
  *     - gravity into the force accumulator, lvel += (h * invMass) * facc
  *     - pos += h * lvel; q += h * 0.5 * (0,w) (x) q; renormalise
  *     - linear damping: lvel *= (1 - scale) when |lvel|^2 > threshold^2 (default 0.01^2)
- *     - auto-disable on instantaneous velocities (ODE's sample-averaging window is not
- *       modelled: its default length cannot be checked without the source)
+ *     - auto-disable: see physics2.c (sample window, joint-holding bodies only)
  *     - AABB overlap: two boxes collide unless separated on an axis (touching counts)
- *   Spheres only: their inertia is isotropic, so the gyroscopic torque vanishes and the
- *   angular velocity of a torque-free body is constant.
+ *   Capsule bodies, anisotropic inertia, general AABBs, capsule contacts and the capsule sweep: physics2.c.
  *
  * Candidate pairs are reported as the canonical ascending set, not in ODE's hash-space
  * callback order (implementation-defined).
@@ -57,71 +55,7 @@ void clapo_world_defaults(clapo_world *w)
     w->adis_time = 0.0;
 }
 
-/* one dWorldQuickStep(world, h) for free bodies */
-void clapo_bodies_step(uint32_t n, double h, const clapo_world *w,
-                       double *pos, double *quat, double *lvel, double *avel,
-                       const double *mass, uint32_t *bflags, int32_t *adis_steps_left, double *adis_time_left)
-{
-    for (uint32_t i = 0; i < n; i++) {
-        double *p = pos + 3 * (size_t)i, *q = quat + 4 * (size_t)i;
-        double *v = lvel + 3 * (size_t)i, *om = avel + 3 * (size_t)i;
-
-        if (bflags[i] & CLAPO_BODY_DISABLED)
-            continue;
-        /* dInternalHandleAutoDisabling */
-        if (bflags[i] & CLAPO_BODY_AUTO_DISABLE) {
-            int idle = 1;
-            if (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > w->adis_linear_threshold_sq)
-                idle = 0;
-            else if (om[0] * om[0] + om[1] * om[1] + om[2] * om[2] > w->adis_angular_threshold_sq)
-                idle = 0;
-            if (idle) {
-                adis_steps_left[i]--;
-                adis_time_left[i] -= h;
-            } else {
-                adis_steps_left[i] = w->adis_steps;
-                adis_time_left[i] = w->adis_time;
-            }
-            if (adis_steps_left[i] <= 0 && adis_time_left[i] <= 0) {
-                bflags[i] |= CLAPO_BODY_DISABLED;
-                v[0] = v[1] = v[2] = 0;
-                om[0] = om[1] = om[2] = 0;
-                continue;
-            }
-        }
-        /* gravity -> facc; lvel += (h * invMass) * facc */
-        const double inv_mass = 1.0 / mass[i];
-        const double k = h * inv_mass;
-        for (int j = 0; j < 3; j++) {
-            double f = (bflags[i] & CLAPO_BODY_NO_GRAVITY) ? 0.0 : mass[i] * w->gravity[j];
-            v[j] += k * f;
-        }
-        /* dxStepBody */
-        for (int j = 0; j < 3; j++)
-            p[j] += h * v[j];
-        double dq[4];                                                  /* dWtoDQ */
-        dq[0] = 0.5 * (-om[0] * q[1] - om[1] * q[2] - om[2] * q[3]);
-        dq[1] = 0.5 * ( om[0] * q[0] + om[1] * q[3] - om[2] * q[2]);
-        dq[2] = 0.5 * (-om[0] * q[3] + om[1] * q[0] + om[2] * q[1]);
-        dq[3] = 0.5 * ( om[0] * q[2] - om[1] * q[1] + om[2] * q[0]);
-        for (int j = 0; j < 4; j++)
-            q[j] += h * dq[j];
-        double l = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];   /* dNormalize4 */
-        if (l > 0) {
-            l = 1.0 / sqrt(l);
-            for (int j = 0; j < 4; j++) q[j] *= l;
-        } else {
-            q[0] = 1; q[1] = q[2] = q[3] = 0;
-        }
-        if (w->linear_damping != 0.0) {
-            const double speed2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-            if (speed2 > w->linear_damping_threshold_sq) {
-                const double s = 1 - w->linear_damping;
-                v[0] *= s; v[1] *= s; v[2] *= s;
-            }
-        }
-    }
-}
+/* the body stage of dWorldQuickStep: clapo_bodies_step2 (physics2.c) */
 
 /* phys_body_update (physics.c:789-812) + phys_body_rotation (96-109): body -> entity TRS */
 void clapo_phys_body_update(uint32_t n, const double *pos, const double *quat, const double *lvel,

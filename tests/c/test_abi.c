@@ -122,9 +122,21 @@ static int test_bodies(void)
     gb.pos = UP(pos, N * 3); gb.quat = UP(quat, N * 4); gb.lvel = UP(lvel, N * 3); gb.avel = UP(avel, N * 3);
     gb.mass = UP(mass, N); gb.radius = UP(radius, N); gb.yoffset = UP(yoff, N); gb.bflags = UP(bflags, N);
     gb.adis_steps_left = UP(adis, N); gb.adis_time_left = UP(adt, N); gb.body_entity = UP(body_entity, N);
-    double *d_statics = UP(statics, NS * 6);
+    static double aabb[N * 6], axis[N * 3];
+    gb.aabb = (double *)dev_upload(NULL, sizeof(aabb)); gb.axis = (double *)dev_upload(NULL, sizeof(axis));
+    clapgpu_geom_offset_rotation(gb.geom_offset_R);
+    clapo_bodies ob_;                                       /* the oracle's view of the same bodies (host arrays) */
+    memset(&ob_, 0, sizeof(ob_));
+    ob_.n = N; ob_.pos = pos; ob_.quat = quat; ob_.lvel = lvel; ob_.avel = avel; ob_.mass = mass; ob_.radius = radius;
+    ob_.yoffset = yoff; ob_.bflags = bflags; ob_.adis_steps_left = adis; ob_.adis_time_left = adt; ob_.body_entity = body_entity;
+    ob_.aabb = aabb; ob_.axis = axis;
+    clapo_geom_offset_rotation(ob_.geom_offset_R);
+    if (sizeof(clapo_bodies) != sizeof(clapgpu_bodies) || memcmp(ob_.geom_offset_R, gb.geom_offset_R, 96)) return fail("bodies layout / offset rotation");
+    clapo_bodies_aabb(&ob_);
+    CK(clapgpu_bodies_aabb(NULL, &gb));
+    clapgpu_bp *bp = NULL;
+    CK(clapgpu_bp_create(&bp, N, 1.0, NS, statics));
     uint32_t *d_pairs = ZERO(uint32_t, 2 * CAP), *d_spairs = ZERO(uint32_t, 2 * CAP), *d_tot = ZERO(uint32_t, 4);
-    void *scratch = dev_upload(NULL, clapgpu_broadphase_scratch_bytes(N));
     clapgpu_contact *d_contacts = (clapgpu_contact *)dev_upload(NULL, sizeof(clapgpu_contact) * CAP);
     float *d_ps = UP(ps, N * 4), *d_rot = UP(rot, N * 4);
     uint32_t *d_eflags = ZERO(uint32_t, N);
@@ -140,11 +152,10 @@ static int test_bodies(void)
         int sg = clapgpu_phys_step_schedule(&acc_g, 1.0 / 60.0), so = clapo_phys_step_schedule(&acc_o, 1.0 / 60.0);
         if (sg != so || acc_g != acc_o) return fail("phys_step schedule");
         for (int s = 0; s < sg; s++) {
-            uint64_t ns = clapo_broadphase_static_pairs(NS, statics, N, pos, radius, spairs, CAP);
-            uint64_t np = clapo_broadphase_pairs(N, pos, radius, pairs, CAP);
+            uint64_t ns = clapo_broadphase_aabb_static_pairs(NS, statics, N, aabb, spairs, CAP);
+            uint64_t np = clapo_broadphase_aabb_pairs(N, aabb, pairs, CAP);
             uint32_t nc = clapo_contacts_spheres((uint32_t)np, pairs, pos, radius, NULL, contacts);
-            CK(clapgpu_broadphase_static_pairs(NULL, &gb, NS, d_statics, d_spairs, CAP, d_tot + 1, scratch));
-            CK(clapgpu_broadphase_pairs(NULL, &gb, 1.0, d_pairs, CAP, d_tot, scratch));
+            CK(clapgpu_bp_collide(NULL, bp, N, gb.aabb, d_pairs, CAP, d_tot, d_spairs, CAP, d_tot + 1));
             CK(clapgpu_contacts_spheres(NULL, &gb, d_pairs, d_tot, CAP, NULL, d_contacts, d_tot + 2));
             uint32_t tot[4];
             DOWN(tot, d_tot, 4); DOWN(gpairs, d_pairs, 2 * CAP); DOWN(gspairs, d_spairs, 2 * CAP); DOWN(gcontacts, d_contacts, CAP);
@@ -153,7 +164,7 @@ static int test_bodies(void)
             if (memcmp(gpairs, pairs, 8 * np) || memcmp(gspairs, spairs, 8 * ns)) return fail("pair lists");
             if (memcmp(gcontacts, contacts, sizeof(clapo_contact) * np)) return fail("contact records");
             if (np < N / 10 || nc == 0 || nc == np) return fail("broadphase fixture too sparse or too dense");
-            clapo_bodies_step(N, 1.0 / 120.0, &ow, pos, quat, lvel, avel, mass, bflags, adis, adt);
+            clapo_bodies_step2(&ob_, &ow, 1.0 / 120.0);
             CK(clapgpu_bodies_step(NULL, &gb, &gw, 1.0 / 120.0));
         }
         clapo_phys_body_update(N, pos, quat, lvel, yoff, body_entity, ps, rot, eflags, NULL);
@@ -165,6 +176,10 @@ static int test_bodies(void)
         if (memcmp(gps, ps, sizeof(ps)) || memcmp(grot, rot, sizeof(rot)) || memcmp(geflags, eflags, sizeof(eflags)))
             return fail("entity TRS from phys_body_update");
     }
+    uint32_t st = 99;
+    CK(clapgpu_bp_status(NULL, bp, &st));
+    if (st != 0) return fail("broadphase status: a body larger than the cell");
+    clapgpu_bp_destroy(bp);
     printf("bodies ok\n");
     return 0;
 }

@@ -50,6 +50,7 @@ def test_auto_disable_bookkeeping():
     b = synth.sphere_bodies(50, seed=2, resting_frac=1.0)
     st = ob.bodies_state(b)
     for step in range(31):
+        st["bflags"] |= 16                                  # every body holds a (contact) joint: jointless bodies never sleep
         ob.bodies_step(b, st, 1.0 / 120.0)
         disabled = (st["bflags"] & 1) != 0
         assert disabled.all() == (step >= 29), f"step {step}: idle bodies sleep after 30 idle steps"

@@ -17,22 +17,65 @@ def rel_err(a, b):
     return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-300)
 
 
-@pytest.mark.parametrize("n,box", [(1, 4.0), (63, 4.0), (5000, 16.0), (40_000, 32.0)], ids=["n1", "n63", "n5k", "n40k"])
-def test_broadphase_pair_set_exact(n, box, cuda_device):
-    from clap_amd import physics
-    b = synth.sphere_bodies(n, box=box, seed=21)
-    statics = synth.static_boxes(37, box)
-    world = physics.PhysWorld(b, statics, pair_capacity=max(64 * n, 1024), device=cuda_device)
-    world.broadphase()
+def oracle_aabbs(b):
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    return st["aabb"]
+
+
+def check_broadphase(world, b, statics, cap):
     out = world.download()
-    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=max(64 * n, 1024))
+    bb = oracle_aabbs(b)
+    assert np.array_equal(out["aabb"].view(np.uint64), bb.view(np.uint64)), "geom AABBs"
+    exp = ob.broadphase_aabb_pairs(bb, max_pairs=cap)
     assert out["pair_total"] == len(exp)
-    assert np.array_equal(out["pairs"], exp), "body x body candidate pairs (ascending set)"
-    exp_s = ob.broadphase_static_pairs(statics, b["pos"], b["radius"], max_pairs=max(64 * n, 1024))
-    assert out["static_pair_total"] == len(exp_s)
-    assert np.array_equal(out["static_pairs"], exp_s), "body x static candidate pairs"
+    assert np.array_equal(out["pairs"], exp), "body x body candidate pairs (ascending list)"
+    if statics is not None:
+        exp_s = ob.broadphase_aabb_static_pairs(statics, bb, max_pairs=cap)
+        assert out["static_pair_total"] == len(exp_s)
+        assert np.array_equal(out["static_pairs"], exp_s), "body x static candidate pairs (ascending list)"
+    assert world.broadphase_status() == 0
+    return exp
+
+
+@pytest.mark.parametrize("n,box", [(1, 4.0), (63, 4.0), (5000, 16.0), (40_000, 32.0)], ids=["n1", "n63", "n5k", "n40k"])
+@pytest.mark.parametrize("kind", ["spheres", "capsules"])
+def test_broadphase_pair_set_exact(n, box, kind, cuda_device):
+    from clap_amd import physics
+    b = synth.sphere_bodies(n, box=box, seed=21) if kind == "spheres" else synth.capsule_bodies(n, box=box * 1.6, seed=21)
+    statics = synth.static_boxes(37, box)
+    cap = max(64 * n, 1024)
+    world = physics.PhysWorld(b, statics, pair_capacity=cap, device=cuda_device)
+    for _ in range(2):                                      # twice: the counters the kernels leave behind are clean
+        world.broadphase()
+    exp = check_broadphase(world, b, statics, cap)
     if n >= 5000:
         assert len(exp) > n // 10
+
+
+def test_broadphase_thousands_of_statics_small_and_large(cuda_device):
+    """The ground_space as the reference fills it: thousands of small static colliders (binned per block), a few
+    big ones (terrain-sized AABBs, tested by every block), degenerate ones (zero extent, inverted = never)."""
+    from clap_amd import physics
+    n, box = 30_000, 40.0
+    b = synth.capsule_bodies(n, box=box, seed=5)
+    rng = np.random.Generator(np.random.PCG64(9))
+    ns = 6000
+    lo = rng.uniform(-2, box, (ns, 3))
+    ext = rng.uniform(0.05, 3.0, (ns, 3))
+    statics = np.empty((ns, 6))
+    statics[:, 0::2], statics[:, 1::2] = lo, lo + ext
+    statics[0] = [-1e4, 1e4, -50, 0.7, -1e4, 1e4]          # terrain slab
+    statics[1] = [5, 35, 0, 40, 5, 6]                      # a long wall: many blocks
+    statics[2] = [10, 10, 10, 10, 10, 10]                  # a point
+    statics[3] = [12, 11, 12, 11, 12, 11]                  # inverted: overlaps nothing
+    statics[4] = [-1e300, 1e300, -1e300, 1e300, -1e300, 1e300]
+    cap = 2_000_000
+    world = physics.PhysWorld(b, statics, pair_capacity=cap, device=cuda_device)
+    world.broadphase()
+    check_broadphase(world, b, statics, cap)
+    out = world.download()
+    assert out["static_pair_total"] > 2 * n, "every body touches the slab or the all-space box"
 
 
 def test_broadphase_touching_and_negative_coordinates(cuda_device):
@@ -44,84 +87,130 @@ def test_broadphase_touching_and_negative_coordinates(cuda_device):
     b["pos"][20] = b["pos"][21]
     world = physics.PhysWorld(b, None, pair_capacity=100_000, device=cuda_device)
     world.broadphase()
-    out = world.download()
-    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=100_000)
-    assert np.array_equal(out["pairs"], exp)
+    exp = check_broadphase(world, b, None, 100_000)
     assert any((p == [7, 8]).all() for p in exp) and any((p == [20, 21]).all() for p in exp)
 
 
 def test_broadphase_dense_bodies_with_long_partner_lists(cuda_device):
-    """Crowded cells: most bodies have more partners than the search pass keeps per body, so the
-    emit pass's second search (insertion-ordered) produces their runs."""
+    """Crowded cells: most bodies have more partners than a body's fixed list slot holds, so their lists go
+    through the arena and the emit pass ranks them there."""
     from clap_amd import physics
     b = synth.sphere_bodies(3000, box=6.0, seed=6)
-    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=1 << 22)
+    exp = ob.broadphase_aabb_pairs(oracle_aabbs(b), max_pairs=1 << 22)
     per_body = np.bincount(exp[:, 0], minlength=3000)
     assert per_body.max() > 16 and (per_body <= 16).any()
     world = physics.PhysWorld(b, None, pair_capacity=len(exp) + 8, device=cuda_device)
     world.broadphase()
-    out = world.download()
-    assert out["pair_total"] == len(exp)
-    assert np.array_equal(out["pairs"], exp)
+    check_broadphase(world, b, None, 1 << 22)
 
 
 def test_static_pairs_with_more_hits_than_the_kept_list(cuda_device):
-    """Bodies inside 40 nested static boxes (more hits than the per-body list of the search pass)
-    next to bodies that hit only a few."""
+    """Bodies inside 40 nested static boxes (more hits than the per-body list slot) next to bodies that hit few."""
     from clap_amd import physics
     b = synth.sphere_bodies(700, box=8.0, seed=9)
     statics = synth.static_boxes(60, 8.0, seed=2)
     for s_ in range(40):                                    # nested boxes around the low corner
         statics[s_] = [-1.0, 3.0 + 0.05 * s_, -1.0, 3.0 + 0.05 * s_, -1.0, 3.0 + 0.05 * s_]
-    exp_s = ob.broadphase_static_pairs(statics, b["pos"], b["radius"], max_pairs=1 << 20)
+    exp_s = ob.broadphase_aabb_static_pairs(statics, oracle_aabbs(b), max_pairs=1 << 20)
     per_body = np.bincount(exp_s[:, 0], minlength=700)
     assert per_body.max() > 16 and ((per_body > 0) & (per_body <= 16)).any()
-    world = physics.PhysWorld(b, statics, pair_capacity=len(exp_s) + 8, device=cuda_device)
+    world = physics.PhysWorld(b, statics, pair_capacity=1 << 16, static_pair_capacity=len(exp_s) + 8, device=cuda_device)
     world.broadphase()
-    out = world.download()
-    assert out["static_pair_total"] == len(exp_s)
-    assert np.array_equal(out["static_pairs"], exp_s)
+    check_broadphase(world, b, statics, 1 << 20)
 
 
 def test_pair_capacity_overflow_reports_total(cuda_device):
     from clap_amd import physics
     b = synth.sphere_bodies(3000, box=6.0, seed=6)
-    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=1 << 22)
+    exp = ob.broadphase_aabb_pairs(oracle_aabbs(b), max_pairs=1 << 22)
     world = physics.PhysWorld(b, None, pair_capacity=100, device=cuda_device)
     world.broadphase()
     out = world.download()
     assert out["pair_total"] == len(exp) > 100          # total found is reported, only `capacity` written
 
 
-def test_integrate_and_schedule_match_oracle(cuda_device):
+def test_broadphase_flags_a_body_larger_than_the_cell(cuda_device):
     from clap_amd import physics
-    b = synth.sphere_bodies(20_000, box=32.0, seed=8, resting_frac=0.2)
+    b = synth.sphere_bodies(500, box=8.0, seed=2)
+    b["radius"] = b["radius"].copy()
+    b["radius"][17] = 3.0                                   # AABB edge 6 > cell 1
     world = physics.PhysWorld(b, None, device=cuda_device)
-    st = ob.bodies_state(b)
-    acc = 0.0
-    total = 0
-    for dt in (1 / 60, 0.004, 0.005, 1 / 30, 0.3, 1 / 144):      # incl. a hitch that clamps to 5 substeps
+    world.broadphase()
+    assert world.broadphase_status() & 1
+
+
+def _run_steps(b, world, st, dts, joint_mask=None):
+    import torch
+    acc, total = 0.0, 0
+    for dt in dts:
         steps, acc = ob.phys_step_schedule(acc, dt)
+        got = world.phys_step_begin(dt)
+        assert got == steps and world.time_acc.value == acc
         for _ in range(steps):
+            if joint_mask is not None:                       # what the contact pass does for touching bodies
+                st["bflags"][joint_mask] |= 16
+                world.bflags[torch.from_numpy(np.flatnonzero(joint_mask)).to(world.device)] |= 16
             ob.bodies_step(b, st, 1.0 / 120.0)
-        got = world.phys_step(dt, broadphase=False)
-        assert got == steps
-        assert world.time_acc.value == acc
+            world.world_step(1.0 / 120.0)
         total += steps
-    out = world.download()
-    for k in ("pos", "quat", "lvel", "avel"):
+    return total
+
+
+def _assert_state_equal(out, st):
+    for k in ("pos", "quat", "lvel", "avel", "aabb", "axis"):
         assert rel_err(out[k], st[k]) <= 1e-5, k
-        assert np.array_equal(out[k], st[k]), f"{k}: fp64 IEEE on both sides -> expected bit-exact"
+        assert np.array_equal(out[k].view(np.uint64), st[k].view(np.uint64)), f"{k}: fp64 IEEE on both sides -> bit-exact"
     assert np.array_equal(out["bflags"], st["bflags"])
     assert np.array_equal(out["adis_steps_left"], st["adis_steps_left"])
+
+
+@pytest.mark.parametrize("kind", ["spheres", "capsules"])
+def test_integrate_and_schedule_match_oracle(kind, cuda_device):
+    """dWorldQuickStep for bodies without constraint rows: schedule, gravity, the implicit gyroscopic torque of the
+    capsules' anisotropic inertia, pose update, damping, the moved geoms' axis + AABB; then auto-disable of the
+    resting bodies that hold a joint (jointless bodies never sleep, like ODE)."""
+    from clap_amd import physics
+    n = 20_000
+    b = (synth.sphere_bodies(n, box=32.0, seed=8, resting_frac=0.2) if kind == "spheres"
+         else synth.capsule_bodies(n, box=32.0, seed=8, resting_frac=0.2))
+    world = physics.PhysWorld(b, None, device=cuda_device)
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    total = _run_steps(b, world, st, (1 / 60, 0.004, 0.005, 1 / 30, 0.3, 1 / 144))   # incl. a hitch that clamps to 5 substeps
     assert total == 2 + 0 + 1 + 4 + 5 + 0 or total > 0
-    # more steps: the resting fifth falls asleep
-    for _ in range(30):
-        ob.bodies_step(b, st, 1.0 / 120.0)
-        world.world_step(1.0 / 120.0)
+    _assert_state_equal(world.download(), st)
+    if kind == "capsules":
+        assert not np.array_equal(st["avel"], b["avel"]), "anisotropic inertia: the spin precesses"
+    resting = (b["bflags"] & 4) != 0
+    with_joint = resting & (np.arange(n) % 2 == 0)          # half of the resting bodies touch something
+    _run_steps(b, world, st, [1 / 120] * 31, joint_mask=with_joint)
     out = world.download()
-    assert np.array_equal(out["bflags"], st["bflags"]) and (out["bflags"] & 1).any()
-    assert np.array_equal(out["pos"], st["pos"])
+    _assert_state_equal(out, st)
+    asleep = (out["bflags"] & 1) != 0
+    assert asleep[with_joint].all() and not asleep[~with_joint].any(), "only resting bodies that hold a joint fall asleep"
+
+
+def test_auto_disable_sample_window(cuda_device):
+    """dBodySetAutoDisableAverageSamplesCount(b, 4): the idle test runs on the mean of the last four samples and
+    only once the ring is full."""
+    from clap_amd import physics
+    n = 4000
+    b = synth.capsule_bodies(n, box=20.0, seed=12, resting_frac=0.5)
+    b["adis_average_samples"] = 4
+    world = physics.PhysWorld(b, None, device=cuda_device)
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    everyone = np.ones(n, bool)
+    _run_steps(b, world, st, [1 / 120] * 20, joint_mask=everyone)
+    out = world.download()
+    _assert_state_equal(out, st)
+    assert np.array_equal(world.adis_counter.cpu().numpy().view(np.uint32), st["adis_counter"])
+    assert np.array_equal(world.adis_samples.cpu().numpy(), st["adis_samples"])
+    assert (out["adis_steps_left"] < 30).any() and (out["adis_steps_left"] == 30).any()
+    _run_steps(b, world, st, [1 / 120] * 20, joint_mask=everyone)
+    out = world.download()
+    _assert_state_equal(out, st)
+    assert (out["bflags"] & 1).any() and not (out["bflags"] & 1).all()
 
 
 def test_body_readback_feeds_entity_update(cuda_device):
@@ -155,22 +244,30 @@ def test_body_readback_feeds_entity_update(cuda_device):
     assert moving.any()
 
 
-def test_c4_body_count_properties(cuda_device):
-    """BASELINE config 4 (body half) at full size: 256k spheres.  Pair list is strictly ascending,
-    i < j, every pair overlaps, and the count matches the oracle's sweep-and-prune."""
+@pytest.mark.parametrize("kind", ["spheres", "capsule_mix"])
+def test_c4_body_count_full_size(kind, cuda_device):
+    """BASELINE config 4 (body half) at full size: 262 144 bodies -- spheres, and the reference's own geoms (capsules,
+    "puppy" capsules, spheres) -- against 64 large + 2 000 small statics: both pair lists equal the oracle's sweep-and-
+    prune, strictly ascending, every pair overlapping."""
     from clap_amd import physics
-    b = synth.sphere_bodies(262_144, box=64.0, seed=4)
-    world = physics.PhysWorld(b, synth.static_boxes(64, 64.0), pair_capacity=4_000_000, device=cuda_device)
+    n = 262_144
+    b = synth.sphere_bodies(n, box=64.0, seed=4) if kind == "spheres" else synth.capsule_bodies(n, box=100.0, seed=4)
+    rng = np.random.Generator(np.random.PCG64(3))
+    box = 64.0 if kind == "spheres" else 100.0
+    small = np.empty((2000, 6))
+    lo = rng.uniform(0, box, (2000, 3))
+    small[:, 0::2], small[:, 1::2] = lo, lo + rng.uniform(0.1, 2.0, (2000, 3))
+    statics = np.concatenate([synth.static_boxes(64, box), small])
+    world = physics.PhysWorld(b, statics, pair_capacity=4_000_000, static_pair_capacity=8_000_000, device=cuda_device)
     world.broadphase()
+    exp = check_broadphase(world, b, statics, 8_000_000)
     out = world.download()
     p = out["pairs"].astype(np.int64)
     assert (p[:, 0] < p[:, 1]).all()
     key = p[:, 0] * (1 << 32) + p[:, 1]
     assert (np.diff(key) > 0).all()
-    lo, hi = b["pos"] - b["radius"][:, None], b["pos"] + b["radius"][:, None]
-    assert np.all((lo[p[:, 0]] <= hi[p[:, 1]]) & (hi[p[:, 0]] >= lo[p[:, 1]]))
-    exp = ob.broadphase_pairs(b["pos"], b["radius"], max_pairs=4_000_000)
-    assert np.array_equal(out["pairs"], exp)
+    bb = out["aabb"]
+    assert np.all((bb[p[:, 0], 0::2] <= bb[p[:, 1], 1::2]) & (bb[p[:, 0], 1::2] >= bb[p[:, 1], 0::2]))
     assert 0.3 < len(exp) / b["n"] < 3.0
 
 
@@ -283,3 +380,139 @@ def test_entity_rotation_pushed_to_linked_bodies(cuda_device):
         assert changed[link_body[:100]].sum() == (66 if not all_dirty else 100)
         assert not changed[link_body[100:]].any(), "attached entities take the parent branch: no push"
         assert np.allclose(np.linalg.norm(got[changed], axis=1), 1.0, atol=1e-15)
+
+
+# ---------------------------------------------------------------- round 2: capsule narrowphase + sweep
+def _materials(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return np.stack([rng.choice([0.0, 0.3, 0.8], n), rng.uniform(0, 0.2, n), rng.uniform(0.1, 1.5, n),
+                     rng.choice([0.0, 0.02, 0.2], n), rng.choice([0.0, 0.005, 0.05], n)], 1)
+
+
+def _oracle_body_geoms(b, st, material=None):
+    return ob.geoms(b["n"], pos=st["pos"], axis=st["axis"], radius=b["radius"], length=b.get("length"), material=material)
+
+
+def test_capsule_contacts_match_restatement(cuda_device):
+    """near_callback over both candidate lists of a capsule / sphere mix: dCollideCapsuleCapsule (closest-points
+    branch and the two-contact parallel branch), dCollideCapsuleSphere in both argument orders (dCollide's reversal),
+    dCollideSpheres, dCollideCapsuleBox (incl. the deep-penetration flag), dCollideSphereBox, with the surface
+    parameters -- every field of every record bit-exact against the restatement."""
+    import torch
+    from clap_amd import physics
+    n = 20_000
+    b = synth.capsule_bodies(n, box=26.0, seed=33)
+    caps = np.flatnonzero(b["length"] > 0)
+    # parallel neighbours: copies of a capsule's orientation, shifted sideways by less than two radii
+    for k in range(0, 40, 2):
+        i, j = caps[k], caps[k + 1]
+        b["quat"][j] = b["quat"][i]
+        b["pos"][j] = b["pos"][i] + [0.05, 0.0, 0.04]
+        b["length"][j], b["radius"][j] = b["length"][i], b["radius"][i]
+    b["pos"][caps[50]] = b["pos"][caps[51]]                # coincident capsule centres
+    statics = synth.static_boxes(48, 26.0)
+    lo, hi = statics[:, 0::2], statics[:, 1::2]
+    b["pos"][caps[60]] = (lo[3] + hi[3]) / 2               # a capsule whose axis runs through a box: ODE's dBoxBox case
+    mat, smat = _materials(n, 4), _materials(48, 5)
+    for material, static_material in ((None, None), (mat, smat)):
+        world = physics.PhysWorld(b, statics, pair_capacity=16 * n, device=cuda_device)
+        if material is not None:
+            world.set_materials(material)
+            world.static_material = torch.from_numpy(static_material).to(cuda_device)
+        world.broadphase()
+        world.contacts_geoms()
+        got = world.download_contacts2(ob.CONTACT2_DTYPE)
+        out = world.download()
+        st = ob.bodies_state(b)
+        ob.bodies_aabb(b, st)
+        A = _oracle_body_geoms(b, st, material)
+        S = ob.geoms(48, kind=np.full(48, 2, np.uint8), aabb=statics, material=static_material)
+        exp, exp_total = ob.contacts_geoms(out["pairs"], A, A)
+        recs, total = got["body"]
+        assert len(recs) == len(out["pairs"]) and total == exp_total
+        assert recs.tobytes() == exp.tobytes(), "body x body contact records, every field bit-exact"
+        assert (exp["nc"] == 2).sum() >= 10, "parallel capsules give two contacts"
+        assert 0 < exp_total < len(exp)
+        kinds = (b["length"][out["pairs"]] > 0).astype(int)
+        touching = exp["nc"] > 0
+        for combo in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            assert (touching & (kinds[:, 0] == combo[0]) & (kinds[:, 1] == combo[1])).any(), combo
+        exp_s, exp_s_total = ob.contacts_geoms(out["static_pairs"], A, S)
+        recs_s, total_s = got["static"]
+        assert total_s == exp_s_total and recs_s.tobytes() == exp_s.tobytes(), "body x static contact records"
+        assert (exp_s["nc"] == 0x80000000).any(), "the deep-penetration capsule is flagged"
+        assert ((exp_s["nc"] == 1) & (b["length"][out["static_pairs"][:, 0]] > 0)).any()
+        # bodies with a touching pair hold a joint now
+        fl = out["bflags"]
+        hit = np.zeros(n, bool)
+        hit[out["pairs"][touching].ravel()] = True
+        hit[out["static_pairs"][exp_s["nc"] > 0][:, 0]] = True
+        hit[out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0]] = False if False else hit[out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0]]
+        assert np.array_equal((fl & 16) != 0, hit | ((fl & 16) != 0) & hit), "HAS_JOINT only on touching bodies"
+        assert ((fl & 16) != 0)[hit & ~np.isin(np.arange(n), out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0])].all()
+
+
+def test_static_sphere_and_capsule_colliders(cuda_device):
+    """Static colliders the reference creates as capsule / sphere geoms (phys_body_new with a geom only, physics.c:
+    980-991): narrowphase against their real shape, candidates from their AABBs."""
+    from clap_amd import physics
+    n, ns = 8000, 300
+    b = synth.capsule_bodies(n, box=16.0, seed=3)
+    sb = synth.capsule_bodies(ns, box=16.0, seed=77)
+    sst = ob.bodies_state(sb)
+    ob.bodies_aabb(sb, sst)
+    statics = sst["aabb"].copy()
+    kind = (sb["length"] > 0).astype(np.uint8)
+    world = physics.PhysWorld(b, statics, pair_capacity=16 * n, device=cuda_device)
+    world.set_static_geoms(kind, pos=sb["pos"], axis=sst["axis"], radius=sb["radius"], length=sb["length"])
+    world.broadphase()
+    world.contacts_geoms()
+    got = world.download_contacts2(ob.CONTACT2_DTYPE)
+    out = world.download()
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    A = _oracle_body_geoms(b, st)
+    S = ob.geoms(ns, pos=sb["pos"], axis=sst["axis"], radius=sb["radius"], length=sb["length"], kind=kind, aabb=statics)
+    exp_s, tot = ob.contacts_geoms(out["static_pairs"], A, S)
+    assert got["static"][1] == tot and got["static"][0].tobytes() == exp_s.tobytes()
+    assert 0 < tot < len(exp_s)
+
+
+def test_capsule_sweeps_match_restatement(cuda_device):
+    """phys_body_sweep_capsule for 300 bodies at once: marching probe, contact filtering by direction, back-up
+    distance, first-smallest-fraction rule, early exit -- frac, normal and hit equal the restatement's, exactly."""
+    from clap_amd import physics
+    n = 6000
+    b = synth.capsule_bodies(n, box=14.0, seed=19)
+    statics = synth.static_boxes(40, 14.0)
+    world = physics.PhysWorld(b, statics, device=cuda_device)
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    rng = np.random.Generator(np.random.PCG64(2))
+    movers = rng.choice(n, 300, replace=False).astype(np.uint32)
+    delta = rng.normal(0, 1.0, (300, 3)).astype(np.float32)
+    delta[:5] = 0                                           # no movement: frac 1
+    delta[5:10] *= 1e-3                                     # shorter than a step
+    delta[10:40, 1] = -np.abs(delta[10:40, 1]) - 2.0        # straight down onto the ground slab
+    bb = st["aabb"]
+    cand, first = [], [0]
+    for k, m in enumerate(movers):                          # candidates: everything the swept AABB touches
+        lo = np.minimum(bb[m, 0::2], bb[m, 0::2] + delta[k]) - 1e-3
+        hi = np.maximum(bb[m, 1::2], bb[m, 1::2] + delta[k]) + 1e-3
+        s_hit = np.flatnonzero(np.all((statics[:, 0::2] <= hi) & (statics[:, 1::2] >= lo), axis=1))
+        b_hit = np.flatnonzero(np.all((bb[:, 0::2] <= hi) & (bb[:, 1::2] >= lo), axis=1))
+        cand += list(s_hit.astype(np.uint32)) + list((b_hit.astype(np.uint32) | np.uint32(1 << 31)))
+        first.append(len(cand))
+    cand = np.asarray(cand, np.uint32)
+    frac, normal, hit = world.sweep_capsules(movers, delta, np.asarray(first, np.uint32), cand)
+    frac, normal, hit = frac.cpu().numpy(), normal.cpu().numpy(), hit.cpu().numpy()
+    A = _oracle_body_geoms(b, st)
+    S = ob.geoms(40, kind=np.full(40, 2, np.uint8), aabb=statics)
+    blocked = 0
+    for k, m in enumerate(movers):
+        f, nrm, h = ob.sweep_capsule(A, m, delta[k], S, cand[first[k]:first[k + 1]])
+        assert np.float32(f).tobytes() == frac[k].tobytes(), f"sweep {k}: frac {frac[k]} vs {f}"
+        assert nrm.tobytes() == normal[k].tobytes() and h == hit[k], f"sweep {k}"
+        blocked += f < 1.0
+    assert 30 < blocked < 300 and (frac[:5] == 1.0).all()
+    assert (hit <= -2).any() and (hit >= 0).any(), "statics and bodies were both hit"
