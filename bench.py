@@ -219,8 +219,8 @@ def extras(device, testbed=True):
     del pb
     # ---- configs[3], body half: 256k bodies with the reference's geoms (capsules, "puppy" capsules, spheres): integrate +
     #      both broadphase passes + narrowphase ----
-    b = synth.capsule_bodies(262_144, box=100.0, seed=4)
-    pw = physics.PhysWorld(b, synth.static_boxes(64, 100.0), pair_capacity=2_000_000, device=device)
+    b = synth.capsule_bodies(262_144, box=60.0, seed=4)
+    pw = physics.PhysWorld(b, synth.static_boxes(64, 60.0), pair_capacity=2_000_000, device=device)
     t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 30)
     t_bp = time_launches(pw.broadphase, 10)
     npairs = int(pw.pair_total.item())
@@ -323,9 +323,9 @@ def full_frame(device):
     batch = entities.EntityBatch(scene, device)
     cam = synth.camera()
     n_bodies, n_bound, n_chars, J, vpc = 262_144, 75_000, 50_000, 64, 200
-    b = synth.capsule_bodies(n_bodies, box=100.0, seed=4)
+    b = synth.capsule_bodies(n_bodies, box=60.0, seed=4)
     b["body_entity"] = np.concatenate([roots[:n_bound], np.full(n_bodies - n_bound, -1)]).astype(np.int32)
-    world = physics.PhysWorld(b, synth.static_boxes(64, 100.0), pair_capacity=2_000_000, device=device)
+    world = physics.PhysWorld(b, synth.static_boxes(64, 60.0), pair_capacity=2_000_000, device=device)
     feed = synth.character_feed(n_chars, seed=13, with_bodies=False)
     feed["entity"] = roots[n_bound:n_bound + n_chars].astype(np.uint32)
     cf = characters.CharacterFeed(feed, device)

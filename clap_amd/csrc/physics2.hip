@@ -197,11 +197,31 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
 }
 
 // ================================================================================== broadphase
-constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot; longer lists go to the arena
-constexpr int BP_TILE = 64;            // candidates staged per round (one per lane)
+// Hash grid over the AABB centres, cell >= the largest body AABB edge, so a body's partners have their centres in
+// the 27 cells around its own.  Cells are grouped in 4x4x4 blocks: a cell's slot = (hash of its block) * 64 + its
+// position inside the block, so the 64 cells of a block are neighbours in memory and the per-frame prefix work
+// splits into a wave-sized piece per block (k_bp_cells) and a scan over blocks small enough for one workgroup.
+// Five launches for BOTH passes of __phys_step (bodies x bodies and statics x bodies):
+//   k_bp_bin      one atomic per body on its cell's counter (the return value is its rank in the cell)
+//   k_bp_cells    one wavefront per block: exclusive prefix of its 64 cell counts, block total; the workgroup that
+//                 finishes last scans the block totals
+//   k_bp_scatter  body indices into cell order
+//   k_bp_search   8 lanes per body, bodies taken in cell order: own cell (partners with a larger index) + the 13
+//                 cells after it, so every unordered pair is tested once; the runs are spread into an LDS work list
+//                 and tested one candidate per lane; hits go to the partner list of min(i, j).  Then the statics
+//                 registered for the body's block (binned once on the host) and the large statics.  The workgroup
+//                 that finishes last turns the per-tile partner sums into tile offsets and totals.
+//   k_bp_emit     one thread per body in index order: offset = tile offset + scan inside the tile, its list written in
+//                 ascending partner order, so the output is the canonical ascending list whatever order the atomics took
+// Two different cells of one 3x3x3 neighbourhood never share a slot (same position inside a block means at least four
+// cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge), so no cell
+// coordinates need to be stored with the entries.
+constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
+constexpr int BP_GROUP = 8;            // lanes per body in the search
+constexpr int BP_WORK = 64;            // candidate entries listed per body and round
 constexpr int BP_EMIT_TILE = 256;      // bodies per tile of the pair-offset scan (= emit block)
-constexpr int BP_MAX_TARGETS = 8;      // own block + at most 7 neighbour blocks a cell can touch
-constexpr int CTRL_TICKET_BIN = 0, CTRL_TICKET_SEARCH = 1, CTRL_ARENA = 2, CTRL_SARENA = 3, CTRL_STATUS = 4;
+constexpr int CTRL_STATUS = 2, CTRL_TICKET_CELLS = 8, CTRL_TICKET_SEARCH = 80;   // tickets: 65 words each
+static_assert(BP_EMIT_TILE == PB, "k_bp_tiles sums one emit tile per workgroup");
 
 __host__ __device__ __forceinline__ uint32_t block_hash(int32_t bx, int32_t by, int32_t bz, uint32_t mask)
 {
@@ -217,20 +237,28 @@ __host__ __device__ __forceinline__ int32_t cell_coord(double x, double cell)
     return (int32_t)c;
 }
 
+__host__ __device__ __forceinline__ uint32_t cell_slot(int32_t cx, int32_t cy, int32_t cz, uint32_t mask)
+{
+    return block_hash(cx >> 2, cy >> 2, cz >> 2, mask) << 6 | (uint32_t)(cx & 3) | (uint32_t)(cy & 3) << 2 | (uint32_t)(cz & 3) << 4;
+}
+
+struct BpRec { double bb[6]; uint32_t idx, pad[3]; };            // 64 bytes
+
 struct BpK {
     uint32_t n;
     double cell;
-    uint32_t mask;                       // buckets - 1
+    uint32_t mask;                       // block buckets - 1
     const double *aabb;
-    unsigned long long *bucket_cnt;      // [buckets] own << 32 | total, zero between frames
-    uint32_t *bucket_start;              // [buckets + 1]
-    uint32_t *bucket_own;                // [buckets]
-    uint32_t *ranks;                     // [n][8]
-    uint32_t *entries;                   // [8 n] body indices in bucket order: own ... | ... halo
-    uint32_t *cnt, *scnt;                // [n] partners (larger index) / statics per body
-    uint32_t *ref, *sref;                // [n] arena offsets of lists longer than BP_LIST
+    uint32_t *cell_cnt;                  // [buckets * 64] the bin pass's counters, zero between frames
+    uint32_t *cell_len;                  // [buckets * 64] bodies per cell
+    uint32_t *cell_prefix;               // [buckets * 64] exclusive prefix inside the block
+    uint32_t *block_tot;                 // [buckets]
+    uint32_t *block_start;               // [buckets + 1]
+    uint32_t *key, *rank;                // [n] cell slot and rank inside the cell
+    uint32_t *entries;                   // [n] body indices in cell order
+    struct BpRec *recs;                  // [n] the same with the boxes: what the search reads
+    uint32_t *cnt, *scnt;                // [n] partners (larger index) / statics per body: atomics in the search
     uint32_t *partners, *spartners;      // [n][BP_LIST]
-    uint32_t *arena, *sarena;            // [capacity], [static capacity]
     uint32_t *tile_sum, *stile_sum;      // [tiles] zero between frames
     uint32_t *tile_off, *stile_off;      // [tiles]
     uint32_t *ctrl;
@@ -246,30 +274,6 @@ struct BpK {
     uint32_t *spairs, scapacity, *spair_total;
 };
 
-// the buckets a body is entered into: its own block first, then the neighbour blocks its cell borders
-// (distinct bucket ids only: blocks that share a hash slot get one entry)
-__device__ __forceinline__ int bp_targets(const double (&bb)[6], double cell, uint32_t mask, uint32_t (&t)[BP_MAX_TARGETS])
-{
-    const int32_t cx = cell_coord((bb[0] + bb[1]) * 0.5, cell), cy = cell_coord((bb[2] + bb[3]) * 0.5, cell),
-                  cz = cell_coord((bb[4] + bb[5]) * 0.5, cell);
-    const int32_t bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
-    const int dx = (cx & 3) == 0 ? -1 : (cx & 3) == 3 ? 1 : 0;
-    const int dy = (cy & 3) == 0 ? -1 : (cy & 3) == 3 ? 1 : 0;
-    const int dz = (cz & 3) == 0 ? -1 : (cz & 3) == 3 ? 1 : 0;
-    int nt = 0;
-    t[nt++] = block_hash(bx, by, bz, mask);
-#pragma unroll
-    for (int m = 1; m < 8; m++) {
-        const int ox = (m & 1) ? dx : 0, oy = (m & 2) ? dy : 0, oz = (m & 4) ? dz : 0;
-        if (((m & 1) && !dx) || ((m & 2) && !dy) || ((m & 4) && !dz)) continue;
-        const uint32_t h = block_hash(bx + ox, by + oy, bz + oz, mask);
-        bool dup = false;
-        for (int e = 0; e < nt; e++) dup |= t[e] == h;
-        if (!dup) t[nt++] = h;
-    }
-    return nt;
-}
-
 __device__ __forceinline__ void load_box(const double *aabb, uint32_t i, double (&bb)[6])
 {
     const double2 *p = reinterpret_cast<const double2 *>(aabb + 6 * (size_t)i);
@@ -277,284 +281,370 @@ __device__ __forceinline__ void load_box(const double *aabb, uint32_t i, double 
     bb[0] = a.x; bb[1] = a.y; bb[2] = b.x; bb[3] = b.y; bb[4] = c.x; bb[5] = c.y;
 }
 
-constexpr int BIN_BLOCK = 1024;
-
-// Launch 1: count the entries per bucket (the atomic's return value is the entry's rank); the block that
-// finishes last turns the counts into bucket starts and clears them for the next frame.
-__global__ __launch_bounds__(BIN_BLOCK)
-void k_bp_bin(BpK k)
+__device__ __forceinline__ void box_cell(const double (&bb)[6], double cell, int32_t &cx, int32_t &cy, int32_t &cz)
 {
-    __shared__ uint32_t lds[BIN_BLOCK / WAVE];
-    __shared__ bool is_last;
-    const uint32_t i = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (i < k.n) {
-        double bb[6];
-        load_box(k.aabb, i, bb);
-        if (bb[1] - bb[0] > k.cell || bb[3] - bb[2] > k.cell || bb[5] - bb[4] > k.cell)
-            atomicOr(&k.ctrl[CTRL_STATUS], 1u);
-        uint32_t t[BP_MAX_TARGETS];
-        const int nt = bp_targets(bb, k.cell, k.mask, t);
-        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-        uint32_t r[BP_MAX_TARGETS] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int e = 0; e < BP_MAX_TARGETS; e++) {
-            if (e < nt) {
-                const unsigned long long old = atomicAdd(&k.bucket_cnt[t[e]], e == 0 ? ((1ull << 32) | 1ull) : 1ull);
-                r[e] = e == 0 ? (uint32_t)(old >> 32) : (uint32_t)old - (uint32_t)(old >> 32);
-            }
-        }
-        r0 = make_uint4(r[0], r[1], r[2], r[3]);
-        r1 = make_uint4(r[4], r[5], r[6], r[7]);
-        uint4 *rp = reinterpret_cast<uint4 *>(k.ranks + 8 * (size_t)i);
-        rp[0] = r0;
-        rp[1] = r1;
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-        is_last = atomicAdd(&k.ctrl[CTRL_TICKET_BIN], 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    // exclusive scan of the bucket totals by this one block
-    const uint32_t nb = k.mask + 1;
-    const int lane = lane_id(), wave = threadIdx.x / WAVE;
-    uint32_t carry = 0;
-    constexpr int ITEMS = 8;
-    for (uint32_t base = 0; base < nb; base += BIN_BLOCK * ITEMS) {
-        const uint32_t first = base + threadIdx.x * ITEMS;
-        uint32_t tot[ITEMS], own[ITEMS], s = 0;
-#pragma unroll
-        for (int e = 0; e < ITEMS; e++) {
-            unsigned long long c = 0;
-            if (first + e < nb) {
-                c = __hip_atomic_load(&k.bucket_cnt[first + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                k.bucket_cnt[first + e] = 0;
-            }
-            tot[e] = (uint32_t)c;
-            own[e] = (uint32_t)(c >> 32);
-            s += tot[e];
-        }
-        uint32_t incl = s;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        if (lane == WAVE - 1) lds[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0, chunk_total = 0;
-        for (int q = 0; q < BIN_BLOCK / WAVE; q++) {
-            const uint32_t v = lds[q];
-            if (q < wave) wave_off += v;
-            chunk_total += v;
-        }
-        __syncthreads();
-        uint32_t run = carry + wave_off + incl - s;
-#pragma unroll
-        for (int e = 0; e < ITEMS; e++) {
-            if (first + e < nb) {
-                k.bucket_start[first + e] = run;
-                k.bucket_own[first + e] = own[e];
-            }
-            run += tot[e];
-        }
-        carry += chunk_total;
-    }
-    if (threadIdx.x == 0) {
-        k.bucket_start[nb] = carry;
-        k.ctrl[CTRL_TICKET_BIN] = 0;
-        k.ctrl[CTRL_ARENA] = 0;
-        k.ctrl[CTRL_SARENA] = 0;
-    }
+    cx = cell_coord((bb[0] + bb[1]) * 0.5, cell);
+    cy = cell_coord((bb[2] + bb[3]) * 0.5, cell);
+    cz = cell_coord((bb[4] + bb[5]) * 0.5, cell);
 }
 
-// Launch 2: body indices into bucket order, the owners of a bucket in front, its halo behind
+__device__ __forceinline__ bool boxes_overlap(const double (&a)[6], const double (&b)[6])
+{
+    return !(a[0] > b[1] || a[1] < b[0] || a[2] > b[3] || a[3] < b[2] || a[4] > b[5] || a[5] < b[4]);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Four 16-byte loads that bypass this XCD's L2 (sc0 sc1): what they read was stored through to memory by other
+// workgroups of the same launch, and a plain load could return a line this L2 still holds from an earlier frame.
+// The wait is part of the block: the compiler cannot see that the destination registers are written asynchronously.
+__device__ __forceinline__ void load_coherent_4x4(const uint32_t *p0, const uint32_t *p1, const uint32_t *p2, const uint32_t *p3,
+                                                  u32x4 &v0, u32x4 &v1, u32x4 &v2, u32x4 &v3)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+
+// "the last workgroup to arrive does the epilogue", without thousands of atomics on one address (each costs ~12 ns,
+// serialised): 64 first-level counters, the last arrival of each goes on to the second level.
+__device__ __forceinline__ bool last_block_ticket(uint32_t *tickets /* [65], zero */, uint32_t block, uint32_t n_blocks)
+{
+    const uint32_t shard = block & 63u;
+    const uint32_t in_shard = (n_blocks >> 6) + (shard < (n_blocks & 63u) ? 1u : 0u);
+    const uint32_t n_shards = n_blocks < 64u ? n_blocks : 64u;
+    if (atomicAdd(&tickets[1 + shard], 1u) != in_shard - 1) return false;
+    tickets[1 + shard] = 0;                                            // ready for the next launch
+    if (atomicAdd(&tickets[0], 1u) != n_shards - 1) return false;
+    tickets[0] = 0;
+    return true;
+}
+
+// exclusive scan of v over the 256 threads of a block (two barriers); returns the block total in `total`
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t &total, uint32_t *lds /* [4] */)
+{
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == WAVE - 1) lds[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < PB / WAVE; q++) {
+        const uint32_t x = lds[q];
+        if (q < wave) wave_off += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return wave_off + incl - v;
+}
+
+// Launch 1
 __global__ __launch_bounds__(PB)
-void k_bp_scatter(BpK k)
+void k_bp_bin(BpK k)
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
     if (i >= k.n) return;
     double bb[6];
     load_box(k.aabb, i, bb);
-    uint32_t t[BP_MAX_TARGETS];
-    const int nt = bp_targets(bb, k.cell, k.mask, t);
-    const uint4 *rp = reinterpret_cast<const uint4 *>(k.ranks + 8 * (size_t)i);
-    const uint4 r0 = rp[0], r1 = rp[1];
-    const uint32_t r[BP_MAX_TARGETS] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+    if (bb[1] - bb[0] > k.cell || bb[3] - bb[2] > k.cell || bb[5] - bb[4] > k.cell)
+        atomicOr(&k.ctrl[CTRL_STATUS], 1u);
+    int32_t cx, cy, cz;
+    box_cell(bb, k.cell, cx, cy, cz);
+    const uint32_t slot = cell_slot(cx, cy, cz, k.mask);
+    k.key[i] = slot;
+    k.rank[i] = atomicAdd(&k.cell_cnt[slot], 1u);
+}
+
+// Launch 2: wave w = block bucket w
+__global__ __launch_bounds__(PB)
+void k_bp_cells(BpK k)
+{
+    __shared__ uint32_t lds[PB / WAVE];
+    __shared__ bool is_last;
+    const int lane = lane_id();
+    const uint32_t b = blockIdx.x * (PB / WAVE) + threadIdx.x / WAVE;
+    if (b <= k.mask) {
+        const uint32_t c = k.cell_cnt[(size_t)b * 64 + lane];
+        k.cell_cnt[(size_t)b * 64 + lane] = 0;                          // ready for the next frame
+        k.cell_len[(size_t)b * 64 + lane] = c;
+        uint32_t incl = c;
 #pragma unroll
-    for (int e = 0; e < BP_MAX_TARGETS; e++) {
-        if (e < nt) {
-            const uint32_t slot = e == 0 ? k.bucket_start[t[e]] + r[e] : k.bucket_start[t[e] + 1] - 1 - r[e];
-            k.entries[slot] = i;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
         }
+        k.cell_prefix[(size_t)b * 64 + lane] = incl - c;
+        if (lane == WAVE - 1)                                           // stored through to memory: read by another workgroup below
+            __hip_atomic_store(&k.block_tot[b], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-struct Tile {
-    double lo[3][BP_TILE], hi[3][BP_TILE];
-    uint32_t idx[BP_TILE];
-};
-
-// one round of tests of the lane's own box against the nc staged boxes; all lanes read the same box (LDS broadcast)
-template <bool ORDERED, typename F>
-__device__ __forceinline__ void test_tile(const Tile &t, int nc, bool has, uint32_t ia, const double (&a)[6], F &&on_hit)
-{
-    for (int c = 0; c < nc; c++) {
-        const uint32_t jc = t.idx[c];
-        const bool hit = has && (!ORDERED || jc > ia) &&
-                         !(a[0] > t.hi[0][c] || a[1] < t.lo[0][c] || a[2] > t.hi[1][c] || a[3] < t.lo[1][c] ||
-                           a[4] > t.hi[2][c] || a[5] < t.lo[2][c]);
-        if (hit) on_hit(jc);
-    }
-}
-
-__device__ __forceinline__ void stage(Tile &t, int lane, int nc, uint32_t j, const double *aabb)
-{
-    if (lane < nc) {
-        double bb[6];
-        load_box(aabb, j, bb);
-        t.idx[lane] = j;
+    // No __threadfence() (on gfx950 a whole-L2 write-back + invalidate per workgroup): the totals were stored through,
+    // the barrier's s_waitcnt has them acknowledged before the ticket is taken, the last workgroup loads them coherently.
+    __syncthreads();
+    if (threadIdx.x == 0)
+        is_last = last_block_ticket(k.ctrl + CTRL_TICKET_CELLS, blockIdx.x, gridDim.x);
+    __syncthreads();
+    if (!is_last) return;
+    const uint32_t nbk = k.mask + 1, units = nbk / 4;                    // 16-byte units of four block totals
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < units; base += PB * 4) {
+        u32x4 c[4];
+        const uint32_t *src[4];
 #pragma unroll
-        for (int a = 0; a < 3; a++) { t.lo[a][lane] = bb[2 * a]; t.hi[a][lane] = bb[2 * a + 1]; }
+        for (int e = 0; e < 4; e++) {
+            const uint32_t u = base + e * PB + threadIdx.x;
+            src[e] = k.block_tot + (size_t)(u < units ? u : 0) * 4;
+        }
+        load_coherent_4x4(src[0], src[1], src[2], src[3], c[0], c[1], c[2], c[3]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t u = base + e * PB + threadIdx.x;
+            if (u >= units) c[e] = u32x4{ 0, 0, 0, 0 };
+            uint32_t slice_total;
+            const uint32_t s0 = carry + block_scan_256(c[e].x + c[e].y + c[e].z + c[e].w, slice_total, lds);
+            if (u < units)
+                *reinterpret_cast<u32x4 *>(k.block_start + (size_t)u * 4) =
+                    u32x4{ s0, s0 + c[e].x, s0 + c[e].x + c[e].y, s0 + c[e].x + c[e].y + c[e].z };
+            carry += slice_total;
+        }
     }
+    if (threadIdx.x == 0) k.block_start[nbk] = carry;
 }
 
-// every candidate of one own chunk: the bucket's bodies (ordered: partner index > own index), then the statics
-// registered for the bucket and the large statics
-template <typename FB, typename FS>
-__device__ __forceinline__ void sweep_candidates(const BpK &k, Tile &t, int lane, uint32_t start, uint32_t T, uint32_t s0, uint32_t s1,
-                                                 bool has, uint32_t ia, const double (&a)[6], bool bodies, bool statics,
-                                                 FB &&on_body, FS &&on_static)
+// Launch 3
+__global__ __launch_bounds__(PB)
+void k_bp_scatter(BpK k)
 {
-    if (bodies) {
-        for (uint32_t c0 = 0; c0 < T; c0 += BP_TILE) {
-            const int nc = T - c0 < BP_TILE ? (int)(T - c0) : BP_TILE;
-            stage(t, lane, nc, lane < nc ? k.entries[start + c0 + lane] : 0, k.aabb);
-            wave_lds_fence();
-            test_tile<true>(t, nc, has, ia, a, on_body);
-            wave_lds_fence();
-        }
-    }
-    if (statics) {
-        for (uint32_t c0 = s0; c0 < s1; c0 += BP_TILE) {
-            const int nc = s1 - c0 < BP_TILE ? (int)(s1 - c0) : BP_TILE;
-            stage(t, lane, nc, lane < nc ? k.s_entries[c0 + lane] : 0, k.s_aabb);
-            wave_lds_fence();
-            test_tile<false>(t, nc, has, ia, a, on_static);
-            wave_lds_fence();
-        }
-        for (uint32_t c0 = 0; c0 < k.n_large; c0 += BP_TILE) {
-            const int nc = k.n_large - c0 < BP_TILE ? (int)(k.n_large - c0) : BP_TILE;
-            stage(t, lane, nc, lane < nc ? k.s_large[c0 + lane] : 0, k.s_aabb);
-            wave_lds_fence();
-            test_tile<false>(t, nc, has, ia, a, on_static);
-            wave_lds_fence();
-        }
-    }
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= k.n) return;
+    const uint32_t slot = k.key[i];
+    const uint32_t at = k.block_start[slot >> 6] + k.cell_prefix[slot] + k.rank[i];
+    k.entries[at] = i;
+    const double2 *p = reinterpret_cast<const double2 *>(k.aabb + 6 * (size_t)i);
+    double2 *o = reinterpret_cast<double2 *>(k.recs + at);
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    o[3] = make_double2(__longlong_as_double((long long)i), 0.0);
 }
 
-// Launch 3: one wavefront per bucket.  Lane = one of the bucket's own bodies (its box in registers); the bucket's
-// entries are staged 64 at a time in the wave's LDS tile and every lane walks the tile.  A pair (i, j), i < j, is
-// recorded by the lane that owns i: all partners of a body are found by one lane, so its list needs no atomics.
-// Lists go to the body's fixed slot (unsorted; the emit pass ranks them), longer ones to the arena.  Per-tile
-// partner sums are accumulated for the emit pass; the last block turns them into tile offsets and totals.
+// Launch 4 (see the section comment)
 __global__ __launch_bounds__(PB)
 void k_bp_search(BpK k)
 {
-    __shared__ Tile tiles[PB / WAVE];
-    __shared__ uint32_t lds[PB / WAVE];
-    __shared__ bool is_last;
-    const int lane = lane_id(), wave = threadIdx.x / WAVE;
-    const uint32_t b = blockIdx.x * (PB / WAVE) + wave;
-    Tile &t = tiles[wave];
-    if (b <= k.mask) {
-        const uint32_t start = k.bucket_start[b], T = k.bucket_start[b + 1] - start, M = k.bucket_own[b];
-        const bool with_statics = k.n_static != 0;
-        const uint32_t s0 = with_statics ? k.s_start[b] : 0, s1 = with_statics ? k.s_start[b + 1] : 0;
-        for (uint32_t oc = 0; oc < M; oc += WAVE) {
-            const bool has = oc + lane < M;
-            const uint32_t ia = has ? k.entries[start + oc + lane] : 0xffffffffu;
-            double a[6] = { 0, 0, 0, 0, 0, 0 };
-            if (has) load_box(k.aabb, ia, a);
-            uint32_t cnt = 0, scnt = 0;
-            uint32_t *mine = k.partners + (size_t)BP_LIST * (has ? ia : 0), *smine = k.spartners + (size_t)BP_LIST * (has ? ia : 0);
-            sweep_candidates(k, t, lane, start, T, s0, s1, has, ia, a, true, with_statics,
-                             [&](uint32_t j) { if (cnt < BP_LIST) mine[cnt] = j; cnt++; },
-                             [&](uint32_t s) { if (scnt < BP_LIST) smine[scnt] = s; scnt++; });
-            // long lists: a second walk writes them whole into the arena
-            const bool ovf = has && cnt > BP_LIST, sovf = has && scnt > BP_LIST;
-            if (__any(ovf || sovf)) {
-                uint32_t base = 0, sbase = 0;
-                if (ovf) base = atomicAdd(&k.ctrl[CTRL_ARENA], cnt);
-                if (sovf) sbase = atomicAdd(&k.ctrl[CTRL_SARENA], scnt);
-                const bool w_ok = ovf && (unsigned long long)base + cnt <= k.capacity;
-                const bool s_ok = sovf && (unsigned long long)sbase + scnt <= k.scapacity;
-                uint32_t e = 0, se = 0;
-                sweep_candidates(k, t, lane, start, T, s0, s1, has, ia, a, __any(w_ok), __any(s_ok),
-                                 [&](uint32_t j) { if (w_ok) k.arena[base + e] = j; e++; },
-                                 [&](uint32_t s) { if (s_ok) k.sarena[sbase + se] = s; se++; });
-                if (ovf) k.ref[ia] = w_ok ? base : 0xffffffffu;
-                if (sovf) k.sref[ia] = s_ok ? sbase : 0xffffffffu;
+    constexpr int G = BP_GROUP, GROUPS = PB / G, NCELL = 14, CPL = (NCELL + G - 1) / G;
+    constexpr uint32_t WL = BP_WORK;
+    constexpr int LARGE_TILE = 128;                                     // large statics staged per round
+    __shared__ uint32_t work[GROUPS][WL];
+    __shared__ double large_box[LARGE_TILE][6];
+    __shared__ uint32_t large_idx[LARGE_TILE];
+    const int grp = threadIdx.x / G, q = threadIdx.x % G;
+    const uint32_t t = blockIdx.x * GROUPS + grp;                      // neighbouring groups walk neighbouring cells
+    const bool body = t < k.n;
+
+    double a[6] = { 0, 0, 0, 0, 0, 0 };
+    uint32_t b0[CPL], len[CPL], i = 0, mylen = 0, own_block = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { b0[c] = 0; len[c] = 0; }
+    if (body) {
+        const BpRec me = k.recs[t];
+        i = me.idx;
+#pragma unroll
+        for (int x = 0; x < 6; x++) a[x] = me.bb[x];
+        int32_t cx, cy, cz;
+        box_cell(a, k.cell, cx, cy, cz);
+        own_block = block_hash(cx >> 2, cy >> 2, cz >> 2, k.mask);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int cq = 13 + q + c * G;                              // 13 = own cell, 14..26 = the cells after it
+            if (cq < 27) {
+                const uint32_t slot = cell_slot(cx - 1 + cq % 3, cy - 1 + (cq / 3) % 3, cz - 1 + cq / 9, k.mask);
+                b0[c] = k.block_start[slot >> 6] + k.cell_prefix[slot];
+                len[c] = k.cell_len[slot];
+                mylen += len[c];
             }
-            if (has) {
-                k.cnt[ia] = cnt;
-                if (cnt) atomicAdd(&k.tile_sum[ia / BP_EMIT_TILE], cnt);
-                if (with_statics) {
-                    k.scnt[ia] = scnt;
-                    if (scnt) atomicAdd(&k.stile_sum[ia / BP_EMIT_TILE], scnt);
+        }
+    }
+    // this lane's first entry in the group's candidate sequence, and the sequence's length
+    uint32_t incl = mylen;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, G);
+        if (q >= d) incl += up;
+    }
+    const uint32_t total = __shfl(incl, G - 1, G);
+    const uint32_t first = incl - mylen;
+
+    for (uint32_t base = 0; __any(base < total); base += WL) {          // one round unless > WL candidates
+        uint32_t off = first;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const uint32_t own = (c == 0 && q == 0) ? 0x80000000u : 0u; // the run listed for the body's own cell
+            for (uint32_t e = 0; __any(e < len[c]); e++) {
+                if (e < len[c]) {
+                    const uint32_t o = off + e - base;                  // wraps below base: then >= WL
+                    if (o < WL) work[grp][o] = (b0[c] + e) | own;
+                }
+            }
+            off += len[c];
+        }
+        wave_lds_fence();
+        const uint32_t todo = total > base ? (total - base < WL ? total - base : WL) : 0;
+        for (uint32_t e = q; __any(e < todo); e += G) {
+            if (e < todo) {
+                const uint32_t w = work[grp][e];
+                const BpRec r = k.recs[w & 0x7fffffffu];
+                const uint32_t j = r.idx;
+                if (j != i && (!(w >> 31) || j > i)) {
+                    if (boxes_overlap(a, r.bb)) {
+                        const uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
+                        const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
+                        if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+                    }
                 }
             }
         }
+        wave_lds_fence();
     }
-    __threadfence();
+    // statics x this body: the statics registered for its block (the group's lanes take turns), then the large ones,
+    // staged through LDS for the whole workgroup
+    if (k.n_static) {
+        uint32_t s0 = 0, s1 = 0;
+        if (body) { s0 = k.s_start[own_block]; s1 = k.s_start[own_block + 1]; }
+        const uint32_t nloc = body ? s1 - s0 : 0;
+        uint32_t hits = 0;                                               // of the whole group so far (same in its 8 lanes)
+        const int gshift = (lane_id() / G) * G;
+        // a hit's slot in the body's list: hits so far + hits of the lower lanes of the group in this round (no atomics)
+        auto record = [&](bool hit, uint32_t sidx) {
+            const uint32_t m = (uint32_t)(__ballot(hit) >> gshift) & ((1u << G) - 1u);
+            if (hit) {
+                const uint32_t at = hits + __popc(m & ((1u << q) - 1u));
+                if (at < BP_LIST) k.spartners[(size_t)i * BP_LIST + at] = sidx;
+            }
+            hits += __popc(m);
+        };
+        for (uint32_t e = q; __any(e < nloc); e += G) {
+            bool hit = false;
+            uint32_t sidx = 0;
+            if (e < nloc) {
+                sidx = k.s_entries[s0 + e];
+                double bs[6];
+                load_box(k.s_aabb, sidx, bs);
+                hit = boxes_overlap(a, bs);
+            }
+            record(hit, sidx);
+        }
+        for (uint32_t base = 0; base < k.n_large; base += LARGE_TILE) {
+            const uint32_t m = k.n_large - base < LARGE_TILE ? k.n_large - base : LARGE_TILE;
+            __syncthreads();
+            for (uint32_t x = threadIdx.x; x < m; x += PB) {
+                const uint32_t sidx = k.s_large[base + x];
+                large_idx[x] = sidx;
+                double bs[6];
+                load_box(k.s_aabb, sidx, bs);
+#pragma unroll
+                for (int y = 0; y < 6; y++) large_box[x][y] = bs[y];
+            }
+            __syncthreads();
+            for (uint32_t e = q; e < m + q; e += G) {                    // uniform trip count: every lane takes part in the ballot
+                bool hit = false;
+                if (body && e < m) {
+                    double bs[6];
+#pragma unroll
+                    for (int y = 0; y < 6; y++) bs[y] = large_box[e][y];
+                    hit = boxes_overlap(a, bs);
+                }
+                record(hit, e < m ? large_idx[e] : 0);
+            }
+        }
+        if (body && q == 0) k.scnt[i] = hits;
+    }
+}
+
+// Launch 5: partner counts per tile of 256 bodies (both lists); the workgroup that finishes last scans them into tile
+// offsets and writes the totals
+__global__ __launch_bounds__(PB)
+void k_bp_tiles(BpK k)
+{
+    __shared__ uint32_t lds[PB / WAVE];
+    __shared__ bool is_last;
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    uint32_t t0, t1 = 0;
+    block_scan_256(i < k.n ? k.cnt[i] : 0, t0, lds);
+    if (k.n_static) block_scan_256(i < k.n ? k.scnt[i] : 0, t1, lds);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&k.tile_sum[blockIdx.x], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&k.stile_sum[blockIdx.x], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (threadIdx.x == 0)
-        is_last = atomicAdd(&k.ctrl[CTRL_TICKET_SEARCH], 1u) == gridDim.x - 1;
+        is_last = last_block_ticket(k.ctrl + CTRL_TICKET_SEARCH, blockIdx.x, gridDim.x);
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
-    // exclusive scan of the tile sums (both lists) by this block
     for (int which = 0; which < 2; which++) {
-        uint32_t *sum = which ? k.stile_sum : k.tile_sum, *off = which ? k.stile_off : k.tile_off;
-        uint32_t *total = which ? k.spair_total : k.pair_total;
+        uint32_t *sum = which ? k.stile_sum : k.tile_sum, *offs = which ? k.stile_off : k.tile_off;
+        uint32_t *tot_out = which ? k.spair_total : k.pair_total;
         if (which && !k.n_static) {
-            if (threadIdx.x == 0 && total) *total = 0;
+            if (threadIdx.x == 0 && tot_out) *tot_out = 0;
             continue;
         }
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < k.n_tiles; base += PB) {
-            const uint32_t i = base + threadIdx.x;
-            uint32_t v = 0;
-            if (i < k.n_tiles) {
-                v = __hip_atomic_load(&sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sum[i] = 0;
-            }
-            uint32_t incl = v;
+        for (uint32_t base = 0; base < k.n_tiles; base += PB * 4) {     // four tiles per thread and round, loads in flight together
+            uint32_t v[4];
 #pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const uint32_t u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
+            for (int e = 0; e < 4; e++) {
+                const uint32_t x = base + e * PB + threadIdx.x;
+                v[e] = x < k.n_tiles ? __hip_atomic_load(&sum[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             }
-            if (lane == WAVE - 1) lds[wave] = incl;
-            __syncthreads();
-            uint32_t wave_off = 0, chunk = 0;
-            for (int q = 0; q < PB / WAVE; q++) {
-                const uint32_t x = lds[q];
-                if (q < wave) wave_off += x;
-                chunk += x;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t x = base + e * PB + threadIdx.x;
+                uint32_t chunk;
+                const uint32_t ex = block_scan_256(v[e], chunk, lds);
+                if (x < k.n_tiles) offs[x] = carry + ex;
+                carry += chunk;
             }
-            __syncthreads();
-            if (i < k.n_tiles) off[i] = carry + wave_off + incl - v;
-            carry += chunk;
         }
-        if (threadIdx.x == 0 && total) *total = carry;
+        if (threadIdx.x == 0 && tot_out) *tot_out = carry;
     }
-    if (threadIdx.x == 0) k.ctrl[CTRL_TICKET_SEARCH] = 0;
 }
 
-// Launch 4: one thread per body in index order: its offset = tile offset + scan inside the tile; its list is
-// written in ascending partner order (rank = number of smaller entries: the lists are short).
+// all partners of body i (larger index) in ascending order, for a body whose list did not fit its slot: one lane
+// walks its 27 cells
+template <typename F>
+__device__ __forceinline__ void research_body(const BpK &k, uint32_t i, F &&emit_sorted)
+{
+    double a[6];
+    load_box(k.aabb, i, a);
+    int32_t cx, cy, cz;
+    box_cell(a, k.cell, cx, cy, cz);
+    uint32_t last = i;                                                   // partners > i, ascending: repeated minimum search
+    for (;;) {
+        uint32_t best = 0xffffffffu;
+        for (int cq = 0; cq < 27; cq++) {
+            const uint32_t slot = cell_slot(cx - 1 + cq % 3, cy - 1 + (cq / 3) % 3, cz - 1 + cq / 9, k.mask);
+            const uint32_t s0 = k.block_start[slot >> 6] + k.cell_prefix[slot], s1 = s0 + k.cell_len[slot];
+            for (uint32_t s = s0; s < s1; s++) {
+                const uint32_t j = k.entries[s];
+                if (j <= last || j >= best) continue;
+                double bj[6];
+                load_box(k.aabb, j, bj);
+                if (boxes_overlap(a, bj)) best = j;
+            }
+        }
+        if (best == 0xffffffffu) break;
+        emit_sorted(best);
+        last = best;
+    }
+}
+
+// Launch 6
 __global__ __launch_bounds__(BP_EMIT_TILE)
 void k_bp_emit(BpK k)
 {
@@ -562,7 +652,12 @@ void k_bp_emit(BpK k)
     const uint32_t i = blockIdx.x * BP_EMIT_TILE + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const bool with_statics = k.n_static != 0;
-    const uint32_t c[2] = { i < k.n ? k.cnt[i] : 0, (with_statics && i < k.n) ? k.scnt[i] : 0 };
+    uint32_t c[2] = { 0, 0 };
+    if (i < k.n) {
+        c[0] = k.cnt[i];
+        k.cnt[i] = 0;                                                    // ready for the next frame's atomics
+        if (with_statics) { c[1] = k.scnt[i]; k.scnt[i] = 0; }
+    }
     uint32_t incl[2] = { c[0], c[1] };
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) {
@@ -572,28 +667,58 @@ void k_bp_emit(BpK k)
     if (lane == WAVE - 1) { lds[0][wave] = incl[0]; lds[1][wave] = incl[1]; }
     __syncthreads();
     uint32_t woff[2] = { 0, 0 };
-    for (int q = 0; q < wave; q++) { woff[0] += lds[0][q]; woff[1] += lds[1][q]; }
+    for (int qq = 0; qq < wave; qq++) { woff[0] += lds[0][qq]; woff[1] += lds[1][qq]; }
     if (i >= k.n) return;
-    for (int which = 0; which < (with_statics ? 2 : 1); which++) {
-        const uint32_t n_mine = c[which];
-        if (!n_mine) continue;
-        uint32_t *out = which ? k.spairs : k.pairs;
-        const uint32_t cap = which ? k.scapacity : k.capacity;
-        const uint32_t off = (which ? k.stile_off : k.tile_off)[blockIdx.x] + woff[which] + incl[which] - n_mine;
-        const uint32_t *src;
-        if (n_mine <= BP_LIST) {
-            src = (which ? k.spartners : k.partners) + (size_t)BP_LIST * i;
+    if (c[0]) {
+        const uint32_t off = k.tile_off[blockIdx.x] + woff[0] + incl[0] - c[0];
+        uint2 *out = reinterpret_cast<uint2 *>(k.pairs);
+        if (c[0] <= BP_LIST) {
+            const uint32_t *src = k.partners + (size_t)BP_LIST * i;
+            for (uint32_t e = 0; e < c[0]; e++) {
+                const uint32_t v = src[e];
+                uint32_t rank = 0;
+                for (uint32_t f = 0; f < c[0]; f++) rank += src[f] < v;
+                if (off + rank < k.capacity) out[off + rank] = make_uint2(i, v);
+            }
         } else {
-            const uint32_t r = (which ? k.sref : k.ref)[i];
-            if (r == 0xffffffffu) continue;                                 // arena full: total > capacity anyway
-            src = (which ? k.sarena : k.arena) + r;
+            uint32_t w = 0;
+            research_body(k, i, [&](uint32_t j) { if (off + w < k.capacity) out[off + w] = make_uint2(i, j); w++; });
         }
-        for (uint32_t e = 0; e < n_mine; e++) {
-            const uint32_t v = src[e];
-            uint32_t rank = 0;
-            for (uint32_t f = 0; f < n_mine; f++) rank += src[f] < v;
-            if (off + rank < cap)
-                reinterpret_cast<uint2 *>(out)[off + rank] = make_uint2(i, v);
+    }
+    if (c[1]) {
+        const uint32_t off = k.stile_off[blockIdx.x] + woff[1] + incl[1] - c[1];
+        uint2 *out = reinterpret_cast<uint2 *>(k.spairs);
+        if (c[1] <= BP_LIST) {
+            const uint32_t *src = k.spartners + (size_t)BP_LIST * i;
+            for (uint32_t e = 0; e < c[1]; e++) {
+                const uint32_t v = src[e];
+                uint32_t rank = 0;
+                for (uint32_t f = 0; f < c[1]; f++) rank += src[f] < v;
+                if (off + rank < k.scapacity) out[off + rank] = make_uint2(i, v);
+            }
+        } else {                                                         // every static of the block + the large ones, ascending
+            double a[6];
+            load_box(k.aabb, i, a);
+            int32_t cx, cy, cz;
+            box_cell(a, k.cell, cx, cy, cz);
+            const uint32_t ob = block_hash(cx >> 2, cy >> 2, cz >> 2, k.mask);
+            const uint32_t s0 = k.s_start[ob], nloc = k.s_start[ob + 1] - s0;
+            uint32_t w = 0;
+            int64_t last = -1;
+            for (;;) {
+                uint32_t best = 0xffffffffu;
+                for (uint32_t e = 0; e < nloc + k.n_large; e++) {
+                    const uint32_t sidx = e < nloc ? k.s_entries[s0 + e] : k.s_large[e - nloc];
+                    if ((int64_t)sidx <= last || sidx >= best) continue;
+                    double bs[6];
+                    load_box(k.s_aabb, sidx, bs);
+                    if (boxes_overlap(a, bs)) best = sidx;
+                }
+                if (best == 0xffffffffu) break;
+                if (off + w < k.scapacity) out[off + w] = make_uint2(i, best);
+                w++;
+                last = best;
+            }
         }
     }
 }
@@ -671,8 +796,9 @@ void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pa
                                  (A.material && B.material) ? B.material + 5 * (size_t)pr.y : nullptr);
                 c.nc = (uint32_t)nc;
                 mine++;
-                if (flags_a) atomicOr(&flags_a[pr.x], CLAPGPU_BODY_HAS_JOINT);
-                if (flags_b) atomicOr(&flags_b[pr.y], CLAPGPU_BODY_HAS_JOINT);
+                // plain read-modify-write: every writer of this launch sets the same bit and nothing else changes the word
+                if (flags_a && !(flags_a[pr.x] & CLAPGPU_BODY_HAS_JOINT)) flags_a[pr.x] |= CLAPGPU_BODY_HAS_JOINT;
+                if (flags_b && !(flags_b[pr.y] & CLAPGPU_BODY_HAS_JOINT)) flags_b[pr.y] |= CLAPGPU_BODY_HAS_JOINT;
             }
         }
         out[p] = c;
@@ -919,13 +1045,12 @@ struct clapgpu_bp {
     double cell;
     void *dev;                     // one allocation
     BpK k;                         // device pointers filled in
-    uint32_t arena_cap, sarena_cap;
 };
 
 static uint32_t buckets_for(uint32_t n)
 {
-    uint32_t b = 1024;
-    while (b < n / 16 && b < (1u << 22)) b <<= 1;
+    uint32_t b = 1024;                                                  // block buckets: 64 cell slots each, about two slots per body
+    while (b < n / 32 && b < (1u << 22)) b <<= 1;
     return b;
 }
 
@@ -933,7 +1058,7 @@ static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, uint32_t n_static, const double *static_aabb)
 {
-    if (!out || !(cell > 0.0) || (n_static && !static_aabb) || n_max > (1u << 27))
+    if (!out || !(cell > 0.0) || (n_static && !static_aabb) || n_max > (1u << 30))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     clapgpu_bp *bp = static_cast<clapgpu_bp *>(calloc(1, sizeof(*bp)));
     if (!bp) return CLAPGPU_ERR_NOMEM;
@@ -982,13 +1107,14 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     // one device allocation, carved
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_bcnt = take(sizeof(unsigned long long) * nb), o_bstart = take(4 * ((size_t)nb + 1)), o_bown = take(4 * (size_t)nb);
-    const size_t o_ranks = take(32 * (size_t)n), o_entries = take(4 * 8 * (size_t)n);
-    const size_t o_cnt = take(4 * (size_t)n), o_scnt = take(4 * (size_t)n), o_ref = take(4 * (size_t)n), o_sref = take(4 * (size_t)n);
+    const size_t o_ccnt = take(4 * (size_t)nb * 64), o_cpre = take(4 * (size_t)nb * 64), o_clen = take(4 * (size_t)nb * 64);
+    const size_t o_btot = take(4 * (size_t)nb), o_bstart = take(4 * ((size_t)nb + 4));
+    const size_t o_key = take(4 * (size_t)n), o_ranks = take(4 * (size_t)n), o_entries = take(4 * (size_t)n), o_recs = take(64 * (size_t)n);
+    const size_t o_cnt = take(4 * (size_t)n), o_scnt = take(4 * (size_t)n);
     const size_t o_part = take(4 * (size_t)BP_LIST * n), o_spart = take(4 * (size_t)BP_LIST * n);
     const size_t o_tsum = take(4 * (size_t)bp->n_tiles), o_stsum = take(4 * (size_t)bp->n_tiles);
     const size_t o_toff = take(4 * (size_t)bp->n_tiles), o_stoff = take(4 * (size_t)bp->n_tiles);
-    const size_t o_ctrl = take(64);
+    const size_t o_ctrl = take(4 * 160);
     const size_t o_sstart = take(4 * ((size_t)nb + 1)), o_sent = take(4 * s_entries.size()), o_slarge = take(4 * s_large.size());
     const size_t o_saabb = take(48 * (size_t)(n_static ? n_static : 1));
     const size_t fixed = off;
@@ -1011,11 +1137,12 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     BpK &k = bp->k;
     memset(&k, 0, sizeof(k));
     k.cell = cell; k.mask = nb - 1;
-    k.bucket_cnt = reinterpret_cast<unsigned long long *>(d + o_bcnt);
-    k.bucket_start = reinterpret_cast<uint32_t *>(d + o_bstart); k.bucket_own = reinterpret_cast<uint32_t *>(d + o_bown);
-    k.ranks = reinterpret_cast<uint32_t *>(d + o_ranks); k.entries = reinterpret_cast<uint32_t *>(d + o_entries);
+    k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt); k.cell_prefix = reinterpret_cast<uint32_t *>(d + o_cpre);
+    k.cell_len = reinterpret_cast<uint32_t *>(d + o_clen);
+    k.block_tot = reinterpret_cast<uint32_t *>(d + o_btot); k.block_start = reinterpret_cast<uint32_t *>(d + o_bstart);
+    k.key = reinterpret_cast<uint32_t *>(d + o_key); k.rank = reinterpret_cast<uint32_t *>(d + o_ranks);
+    k.entries = reinterpret_cast<uint32_t *>(d + o_entries); k.recs = reinterpret_cast<BpRec *>(d + o_recs);
     k.cnt = reinterpret_cast<uint32_t *>(d + o_cnt); k.scnt = reinterpret_cast<uint32_t *>(d + o_scnt);
-    k.ref = reinterpret_cast<uint32_t *>(d + o_ref); k.sref = reinterpret_cast<uint32_t *>(d + o_sref);
     k.partners = reinterpret_cast<uint32_t *>(d + o_part); k.spartners = reinterpret_cast<uint32_t *>(d + o_spart);
     k.tile_sum = reinterpret_cast<uint32_t *>(d + o_tsum); k.stile_sum = reinterpret_cast<uint32_t *>(d + o_stsum);
     k.tile_off = reinterpret_cast<uint32_t *>(d + o_toff); k.stile_off = reinterpret_cast<uint32_t *>(d + o_stoff);
@@ -1031,8 +1158,6 @@ extern "C" void clapgpu_bp_destroy(clapgpu_bp *bp)
 {
     if (!bp) return;
     if (bp->dev) (void)hipFree(bp->dev);
-    if (bp->k.arena) (void)hipFree(bp->k.arena);
-    if (bp->k.sarena) (void)hipFree(bp->k.sarena);
     free(bp);
 }
 
@@ -1052,30 +1177,21 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
         if (static_pair_total) CLAPGPU_HIP(hipMemsetAsync(static_pair_total, 0, sizeof(uint32_t), s));
         return CLAPGPU_OK;
     }
-    // the arenas hold the lists longer than BP_LIST: never more entries than the caller's capacity
-    if (capacity > bp->arena_cap) {
-        if (bp->k.arena) CLAPGPU_HIP(hipFree(bp->k.arena));
-        bp->k.arena = nullptr;
-        CLAPGPU_HIP(hipMalloc(reinterpret_cast<void **>(&bp->k.arena), 4 * (size_t)capacity));
-        bp->arena_cap = capacity;
-    }
-    if (statics && static_capacity > bp->sarena_cap) {
-        if (bp->k.sarena) CLAPGPU_HIP(hipFree(bp->k.sarena));
-        bp->k.sarena = nullptr;
-        CLAPGPU_HIP(hipMalloc(reinterpret_cast<void **>(&bp->k.sarena), 4 * (size_t)static_capacity));
-        bp->sarena_cap = static_capacity;
-    }
     BpK k = bp->k;
     k.n = n; k.aabb = aabb; k.n_tiles = (n + BP_EMIT_TILE - 1) / BP_EMIT_TILE;
     k.pairs = pairs; k.capacity = capacity; k.pair_total = pair_total;
     k.spairs = static_pairs; k.scapacity = static_capacity; k.spair_total = static_pair_total;
     if (!statics) { k.n_static = 0; k.n_large = 0; if (static_pair_total) CLAPGPU_HIP(hipMemsetAsync(static_pair_total, 0, 4, s)); }
-    hipLaunchKernelGGL(k_bp_bin, dim3((n + BIN_BLOCK - 1) / BIN_BLOCK), dim3(BIN_BLOCK), 0, s, k);
+    hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_bin");
+    hipLaunchKernelGGL(k_bp_cells, dim3((bp->buckets + PB / WAVE - 1) / (PB / WAVE)), dim3(PB), 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_cells");
     hipLaunchKernelGGL(k_bp_scatter, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
-    hipLaunchKernelGGL(k_bp_search, dim3((bp->buckets + PB / WAVE - 1) / (PB / WAVE)), dim3(PB), 0, s, k);
+    hipLaunchKernelGGL(k_bp_search, dim3((n + PB / BP_GROUP - 1) / (PB / BP_GROUP)), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_search");
+    hipLaunchKernelGGL(k_bp_tiles, dim3(k.n_tiles), dim3(PB), 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_tiles");
     hipLaunchKernelGGL(k_bp_emit, dim3(k.n_tiles), dim3(BP_EMIT_TILE), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_emit");
     return CLAPGPU_OK;

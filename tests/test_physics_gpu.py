@@ -75,7 +75,7 @@ def test_broadphase_thousands_of_statics_small_and_large(cuda_device):
     world.broadphase()
     check_broadphase(world, b, statics, cap)
     out = world.download()
-    assert out["static_pair_total"] > 2 * n, "every body touches the slab or the all-space box"
+    assert out["static_pair_total"] > n, "every body touches the all-space box"
 
 
 def test_broadphase_touching_and_negative_coordinates(cuda_device):
@@ -141,7 +141,7 @@ def test_broadphase_flags_a_body_larger_than_the_cell(cuda_device):
 
 def _run_steps(b, world, st, dts, joint_mask=None):
     import torch
-    acc, total = 0.0, 0
+    acc, total = world.time_acc.value, 0               # the accumulator carries over between calls
     for dt in dts:
         steps, acc = ob.phys_step_schedule(acc, dt)
         got = world.phys_step_begin(dt)
@@ -251,9 +251,9 @@ def test_c4_body_count_full_size(kind, cuda_device):
     prune, strictly ascending, every pair overlapping."""
     from clap_amd import physics
     n = 262_144
-    b = synth.sphere_bodies(n, box=64.0, seed=4) if kind == "spheres" else synth.capsule_bodies(n, box=100.0, seed=4)
+    b = synth.sphere_bodies(n, box=64.0, seed=4) if kind == "spheres" else synth.capsule_bodies(n, box=60.0, seed=4)
     rng = np.random.Generator(np.random.PCG64(3))
-    box = 64.0 if kind == "spheres" else 100.0
+    box = 64.0 if kind == "spheres" else 60.0
     small = np.empty((2000, 6))
     lo = rng.uniform(0, box, (2000, 3))
     small[:, 0::2], small[:, 1::2] = lo, lo + rng.uniform(0.1, 2.0, (2000, 3))
@@ -442,14 +442,11 @@ def test_capsule_contacts_match_restatement(cuda_device):
         assert total_s == exp_s_total and recs_s.tobytes() == exp_s.tobytes(), "body x static contact records"
         assert (exp_s["nc"] == 0x80000000).any(), "the deep-penetration capsule is flagged"
         assert ((exp_s["nc"] == 1) & (b["length"][out["static_pairs"][:, 0]] > 0)).any()
-        # bodies with a touching pair hold a joint now
-        fl = out["bflags"]
+        # bodies of a touching pair hold a joint now (the flagged deep pairs are left to the host: no joint here)
         hit = np.zeros(n, bool)
-        hit[out["pairs"][touching].ravel()] = True
-        hit[out["static_pairs"][exp_s["nc"] > 0][:, 0]] = True
-        hit[out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0]] = False if False else hit[out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0]]
-        assert np.array_equal((fl & 16) != 0, hit | ((fl & 16) != 0) & hit), "HAS_JOINT only on touching bodies"
-        assert ((fl & 16) != 0)[hit & ~np.isin(np.arange(n), out["static_pairs"][exp_s["nc"] == 0x80000000][:, 0])].all()
+        hit[out["pairs"][np.isin(exp["nc"], (1, 2))].ravel()] = True
+        hit[out["static_pairs"][np.isin(exp_s["nc"], (1, 2))][:, 0]] = True
+        assert np.array_equal((out["bflags"] & 16) != 0, hit), "CLAPGPU_BODY_HAS_JOINT on exactly the touching bodies"
 
 
 def test_static_sphere_and_capsule_colliders(cuda_device):

@@ -63,8 +63,12 @@ def main():
         _fr, vm, pm = ob.frustum_from_camera(synth.camera(pos=(1.0, 2.0, 3.0)))
         fn = lambda: ls.grid_compute(vm, pm)
     else:
-        b = synth.capsule_bodies(262_144, box=100.0, seed=4)
-        pw = physics.PhysWorld(b, synth.static_boxes(64, 100.0), pair_capacity=2_000_000, device=dev)
+        if which.endswith("_spheres"):
+            which = which[:-8]
+            b = synth.sphere_bodies(262_144, box=64.0, seed=4)
+        else:
+            b = synth.capsule_bodies(262_144, box=60.0, seed=4)
+        pw = physics.PhysWorld(b, synth.static_boxes(64, 60.0), pair_capacity=2_000_000, device=dev)
         pw.broadphase()
         fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.contacts_geoms if which == "contacts" else pw.broadphase
     for _ in range(iters):
