@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 OK = 0
 ERR_NOMEM = -1
@@ -89,7 +89,7 @@ class Animations(C.Structure):
 
 
 class PoseBatch(C.Structure):
-    _fields_ = [("n_chars", C.c_uint32), ("anim", C.c_void_p), ("frame_time", C.c_void_p), ("entity", C.c_void_p),
+    _fields_ = [("n_chars", C.c_uint32), ("skip", C.c_uint32), ("anim", C.c_void_p), ("frame_time", C.c_void_p), ("entity", C.c_void_p),
                 ("entity_mx", C.c_void_p), ("trs", C.c_void_p), ("joint_transforms", C.c_void_p),
                 ("joint_pos", C.c_void_p)]
 
@@ -125,6 +125,7 @@ class Geoms(C.Structure):
                 ("material", C.c_void_p)]
 
 
+POSE_SKIP_TRS, POSE_SKIP_JOINT_POS = 1, 2
 BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY, BODY_GYROSCOPIC, BODY_HAS_JOINT = 1, 2, 4, 8, 16
 GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_OTHER = 0, 1, 2, 3
 CONTACT_DEEP = 0x80000000

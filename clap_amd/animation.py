@@ -121,7 +121,7 @@ class CharacterBatch:
         self.ani_time = np.zeros(n, np.float64)
         self.speed = np.ones(n, np.float64)
         self.anim_host = np.zeros(n, np.int32)
-        self._pose_desc = _lib.PoseBatch(n, _ptr(self.anim), _ptr(self.frame_time), _ptr(self.entity_index),
+        self._pose_desc = _lib.PoseBatch(n, 0, _ptr(self.anim), _ptr(self.frame_time), _ptr(self.entity_index),
                                          _ptr(self.entity_mx), _ptr(self.trs), _ptr(self.joint_transforms),
                                          _ptr(self.joint_pos))
         self._skin_desc = None
@@ -190,6 +190,10 @@ class CharacterBatch:
         torch.cuda.synchronize(self.device)
         return dict(ani_time=self.ani_time_dev.cpu().numpy(), frame_time=self.frame_time.cpu().numpy(),
                     ended=self.ended.cpu().numpy()[:self.n])
+
+    def set_outputs(self, trs=True, joint_pos=True):
+        """Which host-visible by-products pose_update writes besides the palette (clapgpu_pose_batch.skip)."""
+        self._pose_desc.skip = (0 if trs else _lib.POSE_SKIP_TRS) | (0 if joint_pos else _lib.POSE_SKIP_JOINT_POS)
 
     def pose_update(self):
         rc = _lib.lib().clapgpu_pose_update(_stream(), C.byref(self.model.skel_desc), C.byref(self.model.anim_desc),

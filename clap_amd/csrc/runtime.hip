@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 18u
+#define CLAPGPU_ABI_VERSION 19u
 
 namespace clapgpu {
 

@@ -353,10 +353,18 @@ typedef struct clapgpu_animations {
  *                  in/out -- a path no channel drives keeps its value
  *   joint_transforms[c][j][16]  entity3d.joint_transforms, the UNIFORM_JOINT_TRANSFORMS payload
  *                  (model.c:1020-1022); joints not reachable from joint 0 are not written
- *   joint_pos[c][j][4]          struct joint.pos (camera.c:195-196)
+ *   joint_pos[c][j][4]          struct joint.pos (camera.c:195-196); NULL = not computed
+ *   skip           CLAPGPU_POSE_SKIP_*: outputs nothing reads this frame.  struct joint's translation / rotation / scale
+ *                  and pos are host-visible state whose only per-frame reader is one_joint_transform itself
+ *                  (model.c:1352-1404) and camera_target (camera.c:191-205); the draw path consumes joint_transforms
+ *                  alone (model.c:1020-1022).  With SKIP_TRS the blended T/R/S stay in registers (trs is still read
+ *                  for paths no channel drives); that is 40 of the 120 bytes a joint writes, joint_pos another 16.
  */
+#define CLAPGPU_POSE_SKIP_TRS        (1u << 0)
+#define CLAPGPU_POSE_SKIP_JOINT_POS  (1u << 1)
 typedef struct clapgpu_pose_batch {
     uint32_t        n_chars;
+    uint32_t        skip;
     const uint32_t *anim;
     const float    *frame_time;
     const uint32_t *entity;

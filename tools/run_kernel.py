@@ -46,6 +46,8 @@ def main():
         model = animation.SkinnedModel(sk, [an], mesh=mesh, device=dev)
         cb = animation.CharacterBatch(model, n_chars, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
         cb.set_frame_times(ch["phase"])
+        sk_ = int(os.environ.get("CLAP_POSE_SKIP", "0"))       # 1: no T/R/S write-back, 2: no joint positions
+        cb.set_outputs(trs=not (sk_ & 1), joint_pos=not (sk_ & 2))
         cb.pose_update()
         fn = cb.pose_update if which == "pose" else cb.skin
     elif which == "particles":
