@@ -16,7 +16,6 @@
 // with FMA contraction, and slerp's acos / sin / cos are short polynomials valid on the only
 // intervals slerp can reach (max error 1.7e-7, checked against libm in tests/test_pose_skin_gpu.py).
 #include <string.h>
-#include <stdlib.h>
 #include "common.h"
 #include "lm_dev.h"
 
@@ -171,6 +170,8 @@ constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
 
 // LPC = lanes per character (64, 128, 192 or 256); BLOCK threads = CPB characters per block.
+// A producer / consumer split of this chain inside a block (keyframe waves -> LDS -> hierarchy waves) was built in
+// round 2 and measured slower, 172 us against 145 (profiles/r02_experiments/pose_producer_consumer.md, commit af48632).
 // MODE 0: keyframes read through L2.  MODE 1: key times in LDS.  (Key VALUES in LDS as well -- one
 // 960-thread block per CU holding the model's whole 75 KiB pool -- was built and measured: no faster,
 // profiles/r01_experiments/pose_bounds.md.)
@@ -444,260 +445,6 @@ void k_pose(PoseArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The 64-joint case as a producer / consumer pair of wavefronts (what pose_bounds.md ended on): in k_pose above one
-// wave walks a character's whole chain -- key search, gathers, blend, hierarchy fold, palette, staging, stores --
-// so the CU's waves tend to load the same unit at the same time and the 6.5 KB a character writes are only issued
-// at the end of the chain.  Here a block is two pairs of waves.  The producer of a pair does the keyframe stage
-// (channels_transform: search on the LDS-resident key times, key gathers, lerp / slerp), builds the joint's local
-// matrix, hands its three rows to the consumer through a double-buffered LDS slot and stores T/R/S; the consumer
-// folds the hierarchy by pointer jumping, forms the palette and stores it -- one character behind, so texture-path
-// work, LDS rounds and the two store streams of a pair overlap by construction.  One block barrier per character.
-// SKIP: compile-time copy of PoseArgs.skip (T/R/S not written back, joint positions not computed).
-constexpr int PC_BLOCK = 256;
-template <int SKIP>
-__global__ __launch_bounds__(PC_BLOCK, POSE_WAVES)
-void k_pose_pc(PoseArgs a)
-{
-    constexpr int LPC = WAVE, PAIRS = PC_BLOCK / (2 * WAVE);
-    constexpr bool STORE_TRS = !(SKIP & CLAPGPU_POSE_SKIP_TRS), WITH_POS = !(SKIP & CLAPGPU_POSE_SKIP_JOINT_POS);
-    __shared__ float times_lds[POSE_TIMES_LDS_MAX];
-    __shared__ __attribute__((aligned(16))) float4 hand[PAIRS][2][3 * LPC];            // local rows, producer -> consumer
-    __shared__ __attribute__((aligned(16))) float g_lds[PAIRS][(LPC + 1) * G_STRIDE];  // consumer: globals / store tile
-    __shared__ __attribute__((aligned(16))) float trs_tile[PAIRS][LPC * 10];           // producer: T/R/S store tile
-    __shared__ uint32_t nr_or;
-
-    const int tid = threadIdx.x, wave = tid / WAVE, lane = lane_id();
-    const bool producer = wave < PAIRS;
-    const int pair = producer ? wave : wave - PAIRS;
-    const int j = lane;
-    const uint32_t J = a.J;
-    const bool lane_joint = (uint32_t)j < J;
-    const uint32_t jc = lane_joint ? (uint32_t)j : J - 1;
-
-    if (tid == 0) nr_or = 0;
-    __syncthreads();
-    {
-        uint32_t m = 0;
-        for (uint32_t q = tid; q < a.n_anims * J * 3; q += PC_BLOCK) m |= a.chan_table[q].z;
-        if (m) atomicOr(&nr_or, m);
-    }
-    for (uint32_t q = tid; q < a.n_times; q += PC_BLOCK) times_lds[q] = a.times[q];
-    float *G = g_lds[pair];
-    if (!producer && j == 0) {                                    // the identity slot of the jump rounds
-        float4 *idn = reinterpret_cast<float4 *>(G) + 4 * LPC;
-        idn[0] = make_float4(1.f, 0.f, 0.f, 0.f);
-        idn[1] = make_float4(0.f, 1.f, 0.f, 0.f);
-        idn[2] = make_float4(0.f, 0.f, 1.f, 0.f);
-        idn[3] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    const int top = nr_or ? 1 << (31 - __clz((int)nr_or)) : 0;
-    const float *kdata = a.data;
-
-    // this pair's characters: first + k * stride
-    const uint32_t first = blockIdx.x * PAIRS + pair, stride = gridDim.x * PAIRS;
-    const uint32_t n_iter = a.n_chars > blockIdx.x * PAIRS ? (a.n_chars - blockIdx.x * PAIRS + stride - 1) / stride : 0;
-
-    // producer state: the next character's inputs, requested one character ahead of its stores
-    struct CharIn { uint32_t an; float time; uint4 e0, e1, e2; };
-    auto request = [&](uint32_t c_) {
-        CharIn in;
-        c_ = c_ < a.n_chars ? c_ : a.n_chars - 1;
-        uint32_t an = a.anim[c_];
-        if (an >= a.n_anims) an = 0;
-        in.an = an;
-        in.time = a.frame_time[c_];
-        const uint4 *tab = a.chan_table + ((size_t)an * J + jc) * 3;
-        in.e0 = tab[0]; in.e1 = tab[1]; in.e2 = tab[2];
-        return in;
-    };
-    CharIn cur;
-    // consumer state: the lane's joint constants
-    float IM[16], bv[4];
-    int32_t parent = -1;
-    bool reachable = false;
-    if (producer) {
-        cur = request(first);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 v = a.invmx[4 * jc + q];
-            IM[4 * q] = v.x; IM[4 * q + 1] = v.y; IM[4 * q + 2] = v.z; IM[4 * q + 3] = v.w;
-        }
-        const float4 b3 = a.bind[4 * jc + 3];
-        bv[0] = b3.x; bv[1] = b3.y; bv[2] = b3.z; bv[3] = b3.w;
-        parent = lane_joint ? a.parent[j] : -1;
-        if (parent >= (int32_t)J) parent = -1;
-        reachable = lane_joint && a.depth[j] >= 0;
-    }
-
-    for (uint32_t k = 0; k <= n_iter; k++) {
-        if (producer) {
-            const uint32_t c = first + k * stride;
-            const bool char_ok = k < n_iter && c < a.n_chars;
-            const bool joint_ok = char_ok && lane_joint;
-            float T[3] = { 0, 0, 0 }, R[4] = { 0, 0, 0, 1 }, S[3] = { 1, 1, 1 };
-            if (joint_ok) {
-                const size_t cj = (size_t)c * J + j;
-                const float time = cur.time;
-                const uint4 e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
-                const int n0 = (int)e0.z, n1 = (int)e1.z, n2 = (int)e2.z;
-                if (n0 <= 0 || n1 <= 0 || n2 <= 0) {             // a path without a channel keeps its value
-                    const float *st = a.trs + 10 * cj;
-                    T[0] = st[0]; T[1] = st[1]; T[2] = st[2];
-                    R[0] = st[3]; R[1] = st[4]; R[2] = st[5]; R[3] = st[6];
-                    S[0] = st[7]; S[1] = st[8]; S[2] = st[9];
-                }
-                if (n0 > 0) {
-                    int p, q;
-                    const float *t = times_lds + e0.x;
-                    key_bracket(t, n0, time, top, p, q);
-                    const float fac = key_fac(time, t[p], t[q]);
-                    const float *d = kdata + e0.y;
-#pragma unroll
-                    for (int x = 0; x < 3; x++) T[x] = lerp_ref(d[3 * p + x], d[3 * q + x], fac);
-                }
-                if (n1 > 0) {
-                    int p, q;
-                    const float *t = times_lds + e1.x;
-                    key_bracket(t, n1, time, top, p, q);
-                    const float fac = key_fac(time, t[p], t[q]);
-                    const float *d = kdata + e1.y;
-                    const float qa[4] = { d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3] };
-                    const float qb[4] = { d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3] };
-                    slerp_ref(R, qa, qb, fac);
-                }
-                if (n2 > 0) {
-                    int p, q;
-                    const float *t = times_lds + e2.x;
-                    key_bracket(t, n2, time, top, p, q);
-                    const float fac = key_fac(time, t[p], t[q]);
-                    const float *d = kdata + e2.y;
-#pragma unroll
-                    for (int x = 0; x < 3; x++) S[x] = lerp_ref(d[3 * p + x], d[3 * q + x], fac);
-                }
-            }
-            if (k < n_iter) {
-                // L = T * R * S (linmath.h:959-987 with the scale folded into the columns): three rows to the consumer
-                const float qa = R[3], qb = R[0], qc = R[1], qd = R[2];
-                const float a2 = qa * qa, b2 = qb * qb, c2 = qc * qc, d2 = qd * qd;
-                const float bc = qb * qc, ad = qa * qd, bd = qb * qd, ac = qa * qc, cd = qc * qd, ab = qa * qb;
-                float4 *h = hand[pair][k & 1];
-                h[j] = make_float4((a2 + b2 - c2 - d2) * S[0], 2.f * (bc - ad) * S[1], 2.f * (bd + ac) * S[2], T[0]);
-                h[LPC + j] = make_float4(2.f * (bc + ad) * S[0], (a2 - b2 + c2 - d2) * S[1], 2.f * (cd - ab) * S[2], T[1]);
-                h[2 * LPC + j] = make_float4(2.f * (bd - ac) * S[0], 2.f * (cd + ab) * S[1], (a2 - b2 - c2 + d2) * S[2], T[2]);
-                cur = request(c + stride);                       // ahead of the stores below (in-order vmcnt)
-                if (STORE_TRS && char_ok) {
-                    const int nvalid = (int)(J < WAVE ? J : WAVE);
-                    const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
-                    float *tile_f = trs_tile[pair];
-                    stage_rows<10>(tile_f, trs_row, lane);
-                    wave_lds_fence();
-                    store_rows<10>(tile_f, a.trs + 10 * (size_t)c * J, lane, nvalid);
-                    wave_lds_fence();
-                }
-            }
-        } else if (k > 0) {
-            const uint32_t c = first + (k - 1) * stride;
-            const bool char_ok = c < a.n_chars;
-            const bool joint_ok = char_ok && lane_joint;
-            const float4 *h = hand[pair][(k - 1) & 1];
-            Row M0 = row_of(h[j]), M1 = row_of(h[LPC + j]), M2 = row_of(h[2 * LPC + j]);
-            int anc = joint_ok ? parent : -1;
-            {
-                float4 *slots = reinterpret_cast<float4 *>(G);
-                const int sw_me = (j >> 2) & 3;
-                for (uint32_t st = 0; st < a.n_jump_steps; st++) {
-                    slots[4 * j + (0 ^ sw_me)] = f4_of(M0);
-                    slots[4 * j + (1 ^ sw_me)] = f4_of(M1);
-                    slots[4 * j + (2 ^ sw_me)] = f4_of(M2);
-                    reinterpret_cast<int *>(&slots[4 * j + (3 ^ sw_me)])[0] = anc;
-                    wave_lds_fence();
-                    const int src = anc >= 0 ? anc : LPC;
-                    const int sw = (src >> 2) & 3;
-                    const float4 A0 = slots[4 * src + (0 ^ sw)];
-                    const float4 A1 = slots[4 * src + (1 ^ sw)];
-                    const float4 A2 = slots[4 * src + (2 ^ sw)];
-                    anc = reinterpret_cast<const int *>(&slots[4 * src + (3 ^ sw)])[0];
-                    wave_lds_fence();
-                    const Row B0 = M0, B1 = M1, B2 = M2;
-                    M0 = affine_row(A0, B0, B1, B2);
-                    M1 = affine_row(A1, B0, B1, B2);
-                    M2 = affine_row(A2, B0, B1, B2);
-                }
-            }
-            float Gm[16];
-            {
-                const float4 m0 = f4_of(M0), m1 = f4_of(M1), m2 = f4_of(M2);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float p0 = a.root_pose[r], p1 = a.root_pose[4 + r], p2 = a.root_pose[8 + r], p3 = a.root_pose[12 + r];
-                    E_(Gm, 0, r) = p0 * m0.x + p1 * m1.x + p2 * m2.x;
-                    E_(Gm, 1, r) = p0 * m0.y + p1 * m1.y + p2 * m2.y;
-                    E_(Gm, 2, r) = p0 * m0.z + p1 * m1.z + p2 * m2.z;
-                    E_(Gm, 3, r) = p0 * m0.w + p1 * m1.w + p2 * m2.w + p3;
-                }
-            }
-            float JT[16], pos[4] = { 0, 0, 0, 0 };
-            if (joint_ok && reachable) {
-#pragma unroll
-                for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        E_(JT, cc, r) = E_(Gm, 0, r) * E_(IM, cc, 0) + E_(Gm, 1, r) * E_(IM, cc, 1) +
-                                        E_(Gm, 2, r) * E_(IM, cc, 2) + E_(Gm, 3, r) * E_(IM, cc, 3);
-                if (WITH_POS) {
-                    float mpos[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int x = 0; x < 4; x++) sum += E_(JT, x, r) * bv[x];
-                        mpos[r] = sum;
-                    }
-                    const uint32_t ei = a.entity ? a.entity[c] : c;
-                    float EM[16];
-                    const float4 *em = reinterpret_cast<const float4 *>(a.entity_mx + 16 * (size_t)ei);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 v = em[q];
-                        EM[4 * q] = v.x; EM[4 * q + 1] = v.y; EM[4 * q + 2] = v.z; EM[4 * q + 3] = v.w;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        pos[r] = E_(EM, 0, r) * mpos[0] + E_(EM, 1, r) * mpos[1] + E_(EM, 2, r) * mpos[2] + E_(EM, 3, r) * mpos[3];
-                }
-            }
-            if (char_ok) {
-                const int nvalid = (int)(J < WAVE ? J : WAVE);
-                const size_t row0 = (size_t)c * J;
-                float4 *tile = reinterpret_cast<float4 *>(G);
-                const uint64_t reach_mask = __ballot(joint_ok && reachable);
-                const uint64_t full = nvalid == WAVE ? ~0ull : ((1ull << nvalid) - 1ull);
-                if (reach_mask == full) {
-                    float4 v[4];
-                    stage_mat4(tile, JT, lane);
-                    wave_lds_fence();
-                    unstage_mat4(tile, v, lane);
-                    store_mat4_rows<false>(a.joint_transforms + 16 * row0, v, lane, nvalid);
-                    if (WITH_POS && lane < nvalid)
-                        reinterpret_cast<float4 *>(a.joint_pos)[row0 + lane] = make_float4(pos[0], pos[1], pos[2], pos[3]);
-                    wave_lds_fence();
-                } else if (joint_ok && reachable) {
-                    float4 *dj = reinterpret_cast<float4 *>(a.joint_transforms + 16 * (row0 + j));
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        dj[q] = make_float4(JT[4 * q], JT[4 * q + 1], JT[4 * q + 2], JT[4 * q + 3]);
-                    if (WITH_POS)
-                        reinterpret_cast<float4 *>(a.joint_pos)[row0 + j] = make_float4(pos[0], pos[1], pos[2], pos[3]);
-                }
-            }
-        }
-        __syncthreads();                                         // the slot written in this round is read in the next
-    }
-}
-
 // animated_update's clock (model.c:1563-1592): one lane per character
 __global__ __launch_bounds__(256)
 void k_animation_time(clapgpu_anim_clock k, double now, const double *now_dev)
@@ -799,26 +546,7 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
         CLAPGPU_HIP(hipGetDeviceProperties(&prop, dev));
         n_cus = prop.multiProcessorCount;
     }
-    static const bool pc_off = getenv("CLAPGPU_POSE_ONE_WAVE") != nullptr;   // A/B switch: the one-wave-per-character kernel
-    if (lds_times && lpc == 64 && !pc_off) {
-        // producer / consumer pairs (k_pose_pc), persistent: as many blocks as are resident at once
-        const void *fns[4] = { (const void *)k_pose_pc<0>, (const void *)k_pose_pc<1>, (const void *)k_pose_pc<2>, (const void *)k_pose_pc<3> };
-        static thread_local uint32_t res_pc[4] = { 0, 0, 0, 0 };
-        uint32_t &res = res_pc[a.skip & 3];
-        if (!res) {
-            int per_cu = 0;
-            CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[a.skip & 3], PC_BLOCK, 0));
-            res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
-        }
-        const uint32_t n_groups = (pb->n_chars + 1) / 2;
-        const dim3 grid(n_groups < res ? n_groups : res), block(PC_BLOCK);
-        switch (a.skip & 3) {
-        case 0: hipLaunchKernelGGL(k_pose_pc<0>, grid, block, 0, s, a); break;
-        case 1: hipLaunchKernelGGL(k_pose_pc<1>, grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_pose_pc<2>, grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(k_pose_pc<3>, grid, block, 0, s, a); break;
-        }
-    } else if (lds_times) {
+    if (lds_times) {
         // persistent blocks (24 KiB key times + 16 KiB joint globals each): exactly as many as are
         // resident at once, so no block waits for a slot while the others hold their LDS copy
         const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
