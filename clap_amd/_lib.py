@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 OK = 0
 ERR_NOMEM = -1
@@ -47,7 +47,7 @@ class Frustum(C.Structure):
 class BvQuery(C.Structure):
     """clapgpu_bv_query (include/clapgpu.h)."""
     _fields_ = [("cam_pos", C.c_float * 3), ("has_ctl", C.c_uint32), ("ctl_pos", C.c_float * 3),
-                ("ctl_entity", C.c_uint32), ("result", C.c_void_p)]
+                ("ctl_entity", C.c_uint32), ("result", C.c_void_p), ("inside_mask", C.c_void_p)]
 
 
 class Entities(C.Structure):
@@ -59,7 +59,7 @@ class Entities(C.Structure):
                 ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p),
                 ("vis_row_pop", C.c_void_p), ("n_attach", C.c_uint32), ("pad", C.c_uint32),
                 ("attach", C.c_void_p), ("jt_pool", C.c_void_p), ("bind_pool", C.c_void_p),
-                ("attach_local", C.c_void_p), ("bv", C.POINTER(BvQuery))]
+                ("attach_local", C.c_void_p), ("bv", C.POINTER(BvQuery)), ("rebuilt_mask", C.c_void_p)]
 
 
 class Particles(C.Structure):

@@ -1,0 +1,76 @@
+/*
+ * gpu-exports.inc.c -- CONFIG_GPU_SCENE: the engine's OWN entry points for the batched path, served by the binding.
+ *
+ * "batch entry points a C-ABI replacement must export (same names / signatures so clap_frame /
+ * _models_render link unchanged)".  This file defines them under the reference's names; the reference's bodies
+ * stay available as ref_<name> (in the engine: the same functions behind `#ifndef CONFIG_GPU_SCENE`, or renamed by
+ * a two-line patch each; in the drop-in checker oracle/ref/dropin.c the renaming is done
+ * by the preprocessor around its #include of model.c / view.c / light.c, so not a line of the reference changes).
+ *
+ *   void mq_update(struct mq *mq)                                   model.h:342   model.c:1953
+ *   bool view_entity_in_frustum(struct view *view, entity3d *e)     view.h:37     view.c:296-337
+ *   void view_calc_frustum(clap_context *ctx, struct view *view)    view.h:36     view.c:291
+ *   void light_grid_compute(struct light *light, struct view *view) light.h:61    light.c:88-154
+ *   void entity3d_position / _move / _rotate / _scale / _visible    model.h:712-770  model.c:1810-1842
+ *       the reference's bodies + gpu_scene_touch(): the dirty notification that lets gpu_mq_update() run in
+ *       O(touched) instead of walking every entity3d
+ *
+ * A queue the binding is not bound to (the UI queue, ui.c:188) takes the reference's path unchanged.
+ * Included at the end of the translation unit that holds model.c (after gpu-anim.inc.c), view.c and light.c.
+ */
+#ifdef CONFIG_GPU_SCENE
+
+void ref_mq_update(struct mq *mq);
+bool ref_view_entity_in_frustum(struct view *view, entity3d *e);
+void ref_light_grid_compute(struct light *light, struct view *view);
+void ref_view_calc_frustum(clap_context *ctx, struct view *view);
+
+static struct gpu_lights *g_bound_lights;
+void gpu_lights_bind(struct gpu_lights *gl) { g_bound_lights = gl; }
+
+void mq_update(struct mq *mq)
+{
+    struct gpu_scene *gs = gpu_scene_bound();
+    if (gs && mq == gpu_scene_bound_mq()) {
+        if (!gpu_mq_update(gs, mq, gpu_scene_bound_view()))
+            return;
+        /* a device error is not fatal to the frame: the reference's loop still works on the same objects */
+    }
+    ref_mq_update(mq);
+}
+
+bool view_entity_in_frustum(struct view *view, entity3d *e)
+{
+    struct gpu_scene *gs = gpu_scene_bound();
+    return gs ? gpu_view_entity_in_frustum(gs, view, e) : ref_view_entity_in_frustum(view, e);
+}
+
+/* view.h:36, view.c:291: the reference's body, then the binding learns that the planes moved */
+void view_calc_frustum(clap_context *ctx, struct view *view)
+{
+    ref_view_calc_frustum(ctx, view);
+    gpu_scene_view_changed(gpu_scene_bound(), view);
+}
+
+void light_grid_compute(struct light *light, struct view *view)
+{
+    if (g_bound_lights && !gpu_light_grid_compute(g_bound_lights, light, view))
+        return;
+    ref_light_grid_compute(light, view);
+}
+
+#define GPU_EXPORT_MUTATOR(name, params, args)                  \
+    void ref_##name params;                                     \
+    void name params                                            \
+    {                                                           \
+        ref_##name args;                                        \
+        gpu_scene_touch(gpu_scene_bound(), e);                  \
+    }
+
+GPU_EXPORT_MUTATOR(entity3d_position, (entity3d *e, vec3 pos), (e, pos))
+GPU_EXPORT_MUTATOR(entity3d_move, (entity3d *e, vec3 off), (e, off))
+GPU_EXPORT_MUTATOR(entity3d_rotate, (entity3d *e, float rx, float ry, float rz), (e, rx, ry, rz))
+GPU_EXPORT_MUTATOR(entity3d_scale, (entity3d *e, float scale), (e, scale))
+GPU_EXPORT_MUTATOR(entity3d_visible, (entity3d *e, unsigned int visible), (e, visible))
+
+#endif /* CONFIG_GPU_SCENE */

@@ -26,13 +26,25 @@
  * its subtree -- is left on the host, where the lag is reproduced exactly: every entity, batched or not,
  * ends the frame with the reference's bits.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE                 /* qsort_r */
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include <time.h>
+#include <pthread.h>
+#include <unistd.h>
+#include <stdio.h>
 
 #include "gpu-scene.h"
 #include "scene.h"
+
+#ifdef CONFIG_GPU_SCENE
+/* the engine's view_entity_in_frustum IS the binding then (gpu-exports.inc.c): fall back to the reference's body */
+bool ref_view_entity_in_frustum(struct view *view, entity3d *e);
+#define view_entity_in_frustum ref_view_entity_in_frustum
+#endif
 #include "clapgpu_scene.h"
 #include "clapgpu_snapshot.h"
 
@@ -53,9 +65,12 @@ struct gs_rec {
     uint8_t     cls;            /* 0 unknown, 1 batched, 2 host */
     uint8_t     self_ok;
     uint8_t     xform_dirty;    /* xform.updated as seen in step 3 (cleared in step 5, like default_update) */
+    uint8_t     pending;        /* on the touched list (notification mode) */
 };
 
 struct gs_model { model3d *model; uint32_t handle; };
+
+static struct gpu_scene *g_bound;     /* the scene the engine-named entry points (gpu-exports.inc.c) serve */
 
 struct gpu_scene {
     clapgpu_scene   *scene;
@@ -69,6 +84,19 @@ struct gpu_scene {
     struct gs_model *models; uint32_t n_models, cap_models;
     uint32_t        gen, vis_cursor;
     bool            anim_elsewhere;
+    /* notification mode: the engine's mutators report what they touch (gpu_scene_touch / gpu_scene_topology) and
+     * a frame costs O(touched + rebuilt + host-class entities) instead of two walks over every entity3d */
+    bool            notify, topology_pending, walked, last_fast;
+    /* verdict table by queue position: entity, slot, 'the mask bit is the answer' -- 13 bytes per entity read in order
+     * by _models_render's loop instead of a 64-byte record and the 448-byte entity */
+    entity3d        **vq_e; uint32_t *vq_slot; uint8_t *vq_ok; uint32_t cap_vq;
+    bool            cull_checked, cull_ok;                         /* the culled view's planes were compared since they last changed */
+    uint32_t        *touched; uint32_t n_touched, cap_touched;
+    uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
+    uint64_t        *posmap; uint32_t cap_posmap;                  /* scratch: bounding-volume candidates by queue position */
+    uint32_t        *slots; uint32_t cap_slots;                    /* scratch: rebuilt slots of the frame */
+    uint32_t        n_batched;
+    struct mq       *bound_mq; struct view *bound_view;
     struct view     *culled_view;
     vec4            culled_planes[6];
     struct gpu_scene_stats stats;
@@ -179,6 +207,8 @@ void gpu_scene_done(struct gpu_scene *gs)
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
+    free(gs->touched); free(gs->host_list); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
+    if (g_bound == gs) g_bound = NULL;
     free(gs);
 }
 
@@ -270,7 +300,7 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
     if (fresh) {
         uint32_t mh;
         CK(model_handle(gs, model, &mh));
-        CK(clapgpu_scene_entity_new(gs->scene, mh, e, &r->handle));
+        CK(clapgpu_scene_entity_new(gs->scene, mh, (void *)(uintptr_t)((uint32_t)(r - gs->rec) + 1u), &r->handle));
         r->model = model;
         r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;            /* what entity_new starts with */
         st->registered++;
@@ -309,6 +339,359 @@ static int unbatch(struct gpu_scene *gs, struct gs_rec *r)        /* left the ba
     return 0;
 }
 
+static inline uint8_t verdict_ok(const struct gs_rec *r)
+{
+    return r->cls == 1 &&
+           (r->flags & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE);
+}
+
+static int push_u32(uint32_t **arr, uint32_t *n, uint32_t *cap, uint32_t v)
+{
+    if (*n == *cap) {
+        const uint32_t c = *cap ? 2 * *cap : 1024;
+        uint32_t *p = realloc(*arr, (size_t)c * sizeof(*p));
+        if (!p) return _CERR_NOMEM;
+        *arr = p; *cap = c;
+    }
+    (*arr)[(*n)++] = v;
+    return 0;
+}
+
+bool gpu_scene_last_was_fast(const struct gpu_scene *gs) { return gs->last_fast; }
+
+void gpu_scene_set_notify(struct gpu_scene *gs, bool on) { gs->notify = on; gs->topology_pending = true; }
+
+void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view)
+{
+    g_bound = gs;
+    if (gs) { gs->bound_mq = mq; gs->bound_view = view; }
+}
+
+struct gpu_scene *gpu_scene_bound(void) { return g_bound; }
+struct mq *gpu_scene_bound_mq(void) { return g_bound ? g_bound->bound_mq : NULL; }
+struct view *gpu_scene_bound_view(void) { return g_bound ? g_bound->bound_view : NULL; }
+
+/* an engine mutator (entity3d_position / _move / _rotate / _scale / _visible, model.c:1810-1842) changed e */
+void gpu_scene_touch(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !gs->notify) return;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return;                                         /* not ours (another queue), or new: its creator reports it */
+    struct gs_rec *r = &gs->rec[i];
+    if (r->pending) return;
+    r->pending = 1;
+    if (r->order_pos < gs->n_order && gs->vq_ok) gs->vq_ok[r->order_pos] = 0;      /* until the next update has mirrored it */
+    if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) gs->topology_pending = true;
+}
+
+/* entity3d_make / entity3d_delete, e->parent = ..., e->update = ..., a body / light / joint attached: the next
+ * gpu_mq_update() walks the queue once */
+void gpu_scene_topology(struct gpu_scene *gs) { if (gs) gs->topology_pending = true; }
+
+static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq)
+{
+    entity3d *e = r->e, *parent = e->parent;
+    if (parent && parent_seq) e->parent_seq = parent->seq;                     /* model.c:1613 (parents sit in lower slots: already advanced) */
+    if (transform_is_updated(&e->xform)) transform_clear_updated(&e->xform);
+    e->seq++;                                                    /* model.c:1616, 1669 */
+    memcpy(e->mx, res->mx + 16 * slot, sizeof(mat4x4));
+    memcpy(e->inverse_mx, res->inverse_mx + 16 * slot, sizeof(mat4x4));
+    if (!r->model->skip_aabb) {                                  /* entity3d_aabb_update, model.c:1204-1205 */
+        memcpy(e->aabb, res->aabb + 6 * slot, sizeof(e->aabb));
+        memcpy(e->aabb_center, res->aabb_center + 3 * slot, sizeof(vec3));
+    }
+}
+
+/*
+ * Frames that touch or rebuild hundreds of thousands of entities: the two passes over the 448-byte entity3d structs
+ * are memory latency on one core, so they are split over a few worker threads (the engine's frame is single-threaded;
+ * the binding may use workers as long as every call is synchronous, SURVEY 8b "Threading").  Threads are created per
+ * pass: ~0.1 ms against passes of tens of ms.
+ */
+#define GS_PAR_MIN 65536u
+static inline void prefetch_entity(const entity3d *e);
+
+struct par_job {
+    struct gpu_scene *gs;
+    const clapgpu_scene_arrays *res;
+    uint32_t lo, hi;            /* range of touched[] or order[] */
+    int phase;
+    uint32_t count;             /* out: uploaded / written back */
+    int need_walk, rc;
+    uint32_t *deferred; uint32_t n_deferred, cap_deferred;       /* children whose parent lies in an earlier chunk */
+};
+
+static int par_threads(void)
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n > 8) n = 8;
+    return n < 1 ? 1 : (int)n;
+}
+
+static void par_run(void *(*fn)(void *), struct par_job *jobs, int nt)
+{
+    pthread_t th[8];
+    bool started[8] = { false };
+    for (int t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, fn, &jobs[t]) == 0;
+    fn(&jobs[0]);
+    for (int t = 1; t < nt; t++) {
+        if (started[t]) pthread_join(th[t], NULL);
+        else fn(&jobs[t]);
+    }
+}
+
+static bool self_batchable(const struct gpu_scene *gs, entity3d *e);
+
+static void *par_mirror(void *arg)
+{
+    struct par_job *j = arg;
+    struct gpu_scene *gs = j->gs;
+    for (uint32_t k = j->lo; k < j->hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->touched[k]];
+        if (k + 8 < j->hi) {
+            const struct gs_rec *a = &gs->rec[gs->touched[k + 8]];
+            if (a->e) { __builtin_prefetch(&a->e->xform, 0, 1); __builtin_prefetch(&a->e->flags, 0, 1); }
+        }
+        r->pending = 0;
+        if (!r->e) continue;
+        entity3d *e = r->e;
+        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (r->cls == 1) || e->parent != r->parent_e ||
+            (r->cls == 1 && (r->model != e->txmodel->model || r->handle == CLAPGPU_NO_ENTITY))) {
+            j->need_walk = 1;
+            continue;
+        }
+        if (r->cls != 1) continue;
+        const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
+        r->flags = flags;
+        if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
+        r->xform_dirty = transform_is_updated(&e->xform);
+        const int rc = clapgpu_scene_entity_transform_mt(gs->scene, r->handle, transform_pos(&e->xform, NULL),
+                                                         transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty);
+        if (rc) j->rc = rc;
+        j->count++;
+    }
+    return NULL;
+}
+
+static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq);
+
+/* A list-order chunk of the rebuilt entities.  A batched entity's parent precedes it in the list, so inside a chunk
+ * parent_seq can be taken at once; a child whose parent lies in an EARLIER chunk (another thread) is noted and
+ * finished after the join. */
+static void *par_scatter(void *arg)
+{
+    struct par_job *j = arg;
+    struct gpu_scene *gs = j->gs;
+    const clapgpu_scene_arrays *res = j->res;
+    for (uint32_t k = j->lo; k < j->hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (k + 8 < j->hi) {
+            const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
+            if (a->cls == 1 && a->slot < res->n_slots && ((res->rebuilt_mask[a->slot >> 6] >> (a->slot & 63)) & 1)) {
+                prefetch_entity(a->e);
+                __builtin_prefetch(res->mx + 16 * (size_t)a->slot, 0, 0);
+                __builtin_prefetch(res->inverse_mx + 16 * (size_t)a->slot, 0, 0);
+                __builtin_prefetch(res->aabb + 6 * (size_t)a->slot, 0, 0);
+            }
+        }
+        if (r->cls != 1 || r->slot >= res->n_slots || !((res->rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+        bool here = true;
+        if (r->e->parent) {
+            const uint32_t pr = r->parent_rec;
+            here = pr != NO_REC && gs->rec[pr].e == r->e->parent && gs->rec[pr].order_pos >= j->lo;
+            if (!here && push_u32(&j->deferred, &j->n_deferred, &j->cap_deferred, gs->order[k])) j->rc = _CERR_NOMEM;
+        }
+        scatter_one(gs, r, res, r->slot, here);
+        j->count++;
+    }
+    return NULL;
+}
+
+static void *par_deferred(void *arg)
+{
+    struct par_job *j = arg;
+    struct gpu_scene *gs = j->gs;
+    for (uint32_t d = 0; d < j->n_deferred; d++) {
+        if (d + 8 < j->n_deferred) {
+            const entity3d *a = gs->rec[j->deferred[d + 8]].e;
+            __builtin_prefetch(&a->parent_seq, 1, 1);
+            __builtin_prefetch(&a->parent->seq, 0, 1);
+        }
+        entity3d *c = gs->rec[j->deferred[d]].e;
+        c->parent_seq = c->parent->seq;                          /* model.c:1613: every parent is final by now */
+    }
+    return NULL;
+}
+
+/*
+ * One frame in notification mode, nothing created / deleted / re-parented since the last walk:
+ *   touched batched entities -> flags + transform to the mirror; the device; the slots the kernel reports as rebuilt
+ *   -> back into their entity3d (ascending slot = parents first); host-class entities' own hooks and the camera
+ *   bounding-volume pick of the few entities whose box contains a query point, merged in list order.
+ * Returns 1 if the frame has to be done by the full walk after all (a touched entity changed class or parent).
+ */
+static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    struct scene *scene = mq->priv;
+    const double t0 = now_ms();
+    if (gs->n_touched >= GS_PAR_MIN) {
+        struct par_job jobs[8] = { 0 };
+        const int nt = par_threads();
+        for (int t = 0; t < nt; t++)
+            jobs[t] = (struct par_job){ .gs = gs, .lo = (uint32_t)((uint64_t)gs->n_touched * t / nt),
+                                        .hi = (uint32_t)((uint64_t)gs->n_touched * (t + 1) / nt) };
+        par_run(par_mirror, jobs, nt);
+        int need_walk = 0;
+        for (int t = 0; t < nt; t++) { need_walk |= jobs[t].need_walk; st->uploaded += jobs[t].count; if (jobs[t].rc) return jobs[t].rc; }
+        clapgpu_scene_mark_all_dirty(gs->scene);
+        if (need_walk) { gs->n_touched = 0; return 1; }
+    } else
+    for (uint32_t k = 0; k < gs->n_touched; k++) {
+        struct gs_rec *r = &gs->rec[gs->touched[k]];
+        r->pending = 0;
+        if (!r->e) continue;
+        entity3d *e = r->e;
+        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (r->cls == 1) || e->parent != r->parent_e ||
+            (r->cls == 1 && r->model != e->txmodel->model)) {
+            for (k++; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
+            gs->n_touched = 0;
+            return 1;
+        }
+        if (r->cls == 1) CK(mirror_one(gs, r));
+        if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
+    }
+    gs->n_touched = 0;
+    if (scene && scene->camera)
+        clapgpu_scene_set_bv_points(gs->scene, transform_pos(&scene->camera->xform, NULL),
+                                    scene->control ? transform_pos(&scene->control->xform, NULL) : NULL, CLAPGPU_NO_ENTITY);
+    else
+        clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);
+    const double t1 = now_ms();
+    clapgpu_frustum fr;
+    if (view) frustum_of(view, &fr);
+    CK(clapgpu_scene_mq_update(gs->scene, view ? &fr : NULL));
+    gs->culled_view = view;
+    gs->vis_cursor = 0;
+    if (view) memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+    gs->cull_checked = false;
+    clapgpu_scene_arrays res = { 0 };
+    if (clapgpu_scene_results(gs->scene, &res)) memset(&res, 0, sizeof(res));
+    gs->res = res;
+    const double t2 = now_ms();
+
+    /* results: only what the kernel rebuilt.  Few of them: straight off the mask, in slot order (parents first), each
+     * entity and its rows prefetched a few steps ahead.  Many: in LIST order -- the entity3d structs lie in memory in
+     * creation order, a slot-order pass over most of them would miss the caches on every one. */
+    const uint32_t words = res.n_slots / 64;
+    uint64_t n_rebuilt = 0;
+    if (res.rebuilt_mask)
+        for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(res.rebuilt_mask[w]);
+    if (n_rebuilt >= 2 * GS_PAR_MIN && par_threads() > 1) {
+        const int nt = par_threads();
+        struct par_job jobs[8] = { 0 };
+        for (int t = 0; t < nt; t++)
+            jobs[t] = (struct par_job){ .gs = gs, .res = &res, .lo = (uint32_t)((uint64_t)gs->n_order * t / nt),
+                                        .hi = (uint32_t)((uint64_t)gs->n_order * (t + 1) / nt) };
+        par_run(par_scatter, jobs, nt);
+        par_run(par_deferred, jobs, nt);
+        int rc = 0;
+        for (int t = 0; t < nt; t++) {
+            st->written_back += jobs[t].count;
+            free(jobs[t].deferred);
+            if (jobs[t].rc) rc = jobs[t].rc;
+        }
+        if (rc) return rc;
+    } else if (4 * n_rebuilt > gs->n_order) {
+        /* a batched entity's parent precedes it in the list (else it would be host-class): one pass, parents first */
+        for (uint32_t k = 0; k < gs->n_order; k++) {
+            struct gs_rec *r = &gs->rec[gs->order[k]];
+            if (k + 8 < gs->n_order) {
+                const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
+                if (a->cls == 1 && a->slot < res.n_slots && ((res.rebuilt_mask[a->slot >> 6] >> (a->slot & 63)) & 1)) {
+                    prefetch_entity(a->e);
+                    __builtin_prefetch(res.mx + 16 * (size_t)a->slot, 0, 0);
+                    __builtin_prefetch(res.inverse_mx + 16 * (size_t)a->slot, 0, 0);
+                    __builtin_prefetch(res.aabb + 6 * (size_t)a->slot, 0, 0);
+                }
+            }
+            if (r->cls != 1 || r->slot >= res.n_slots || !((res.rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+            scatter_one(gs, r, &res, r->slot, true);
+            st->written_back++;
+        }
+    } else {
+        /* the rebuilt slots off the mask (ascending = parents first), then a plain loop that asks for the record eight
+         * steps ahead and, once that has arrived, for the entity four steps ahead */
+        uint32_t R = 0;
+        for (uint32_t w = 0; w < words; w++) {
+            uint64_t m = res.rebuilt_mask ? res.rebuilt_mask[w] : 0;
+            while (m) {
+                const uint32_t slot = w * 64 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (res.slot_user[slot] && push_u32(&gs->slots, &R, &gs->cap_slots, slot)) return _CERR_NOMEM;
+            }
+        }
+        for (uint32_t k = 0; k < R; k++) {
+            if (k + 8 < R) {
+                const uint32_t sl = gs->slots[k + 8];
+                __builtin_prefetch(&gs->rec[(uintptr_t)res.slot_user[sl] - 1], 0, 1);
+                __builtin_prefetch(res.mx + 16 * (size_t)sl, 0, 0);
+                __builtin_prefetch(res.inverse_mx + 16 * (size_t)sl, 0, 0);
+            }
+            if (k + 4 < R)
+                prefetch_entity(gs->rec[(uintptr_t)res.slot_user[gs->slots[k + 4]] - 1].e);
+            const uint32_t slot = gs->slots[k];
+            scatter_one(gs, &gs->rec[(uintptr_t)res.slot_user[slot] - 1], &res, slot, true);
+        }
+        st->written_back += R;
+    }
+    const double t3 = now_ms();
+    /* host hooks + bounding-volume pick, merged in list order */
+    /* candidates come off the mask in slot order; list order is restored through a bitmap over the walk's positions
+     * (one bit per queue position: 125 KB per million entities), which the merge below scans upwards */
+    uint32_t n_cand = 0;
+    const uint32_t pos_words = (gs->n_order + 63) / 64;
+    if (scene && res.inside_mask) {
+        if (pos_words > gs->cap_posmap) {
+            uint64_t *pm = realloc(gs->posmap, (size_t)pos_words * 8);
+            if (!pm) return _CERR_NOMEM;
+            gs->posmap = pm; gs->cap_posmap = pos_words;
+        }
+        bool cleared = false;
+        for (uint32_t w = 0; w < words; w++) {
+            uint64_t m = res.inside_mask[w];
+            while (m) {
+                const size_t slot = (size_t)w * 64 + (size_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const uintptr_t u = (uintptr_t)res.slot_user[slot];
+                if (!u) continue;
+                if (!cleared) { memset(gs->posmap, 0, (size_t)pos_words * 8); cleared = true; }
+                const uint32_t op = gs->rec[u - 1].order_pos;
+                gs->posmap[op >> 6] |= 1ull << (op & 63);
+                n_cand++;
+            }
+        }
+    }
+    uint32_t hc = 0, cw = 0;
+    uint64_t cm = n_cand ? gs->posmap[0] : 0;
+    for (;;) {
+        while (n_cand && !cm && cw + 1 < pos_words) cm = gs->posmap[++cw];
+        const uint32_t co = cm ? cw * 64 + (uint32_t)__builtin_ctzll(cm) : 0xffffffffu;
+        const uint32_t ho = hc < gs->n_host ? gs->rec[gs->host_list[hc]].order_pos : 0xffffffffu;
+        if (co == 0xffffffffu && ho == 0xffffffffu) break;
+        if (ho < co) {
+            entity3d_update(gs->rec[gs->host_list[hc++]].e, mq->priv);
+        } else {
+            cm &= cm - 1;
+            bv_pick(scene, gs->rec[gs->order[co]].e);
+        }
+    }
+    st->batched = gs->n_batched; st->host = gs->n_host;
+    if (getenv("GPU_SCENE_TIMING")) fprintf(stderr, "fast_frame: mirror %.3f device %.3f scatter %.3f (rebuilt %llu) hooks+bv %.3f (cand %u host %u)\n", t1 - t0, t2 - t1, t3 - t2, (unsigned long long)n_rebuilt, now_ms() - t3, n_cand, gs->n_host);
+    st->ms_walk = t1 - t0; st->ms_device = t2 - t1; st->ms_scatter = now_ms() - t2;
+    return 0;
+}
+
 int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
     if (!gs || !mq) return _CERR_INVALID_ARGUMENTS;
@@ -316,6 +699,20 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     struct scene *scene = mq->priv;
     memset(st, 0, sizeof(*st));
     gs->gen++;
+    if (gs->notify && gs->walked && !gs->topology_pending) {
+        gs->gen--;                                                /* nothing entered or left the queue: the records' generation stands */
+        const int rc = fast_frame(gs, mq, view);
+        gs->last_fast = rc == 0;
+        if (rc <= 0) return rc;
+        gs->gen++;
+        memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
+    }
+    for (uint32_t k = 0; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
+    gs->n_touched = 0;
+    gs->topology_pending = false;
+    gs->last_fast = false;
+    gs->n_host = 0; gs->n_batched = 0;
+    clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);   /* the walk does the pick per entity */
 
     const double t0 = now_ms();
     /*
@@ -363,6 +760,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             r->self_ok = self_batchable(gs, e);
             if (!r->self_ok) {
                 r->cls = 2;
+                r->parent_e = e->parent; r->parent_rec = NO_REC;
             } else if (!e->parent) {
                 r->cls = 1;
             } else {
@@ -405,6 +803,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->culled_view = view;
     gs->vis_cursor = 0;
     if (view) memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+    gs->cull_checked = false;
     clapgpu_scene_arrays res = { 0 };
     if (clapgpu_scene_results(gs->scene, &res))                  /* an empty batch has none */
         memset(&res, 0, sizeof(res));
@@ -429,9 +828,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (r->cls != 1) {
             entity3d_update(e, mq->priv);
             st->host++;
+            if (gs->notify && push_u32(&gs->host_list, &gs->n_host, &gs->cap_host, gs->order[k])) return _CERR_NOMEM;
             continue;
         }
         st->batched++;
+        gs->n_batched++;
         if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
             r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
         entity3d *parent = e->parent;
@@ -453,26 +854,73 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             bv_pick(scene, e);
     }
     st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1; st->ms_device = t3 - t2; st->ms_scatter = now_ms() - t3;
+    if (gs->n_order > gs->cap_vq) {
+        const uint32_t cap = gs->cap_order;
+        entity3d **ve = realloc(gs->vq_e, (size_t)cap * sizeof(*ve));
+        if (ve) gs->vq_e = ve;
+        uint32_t *vs = realloc(gs->vq_slot, (size_t)cap * 4);
+        if (vs) gs->vq_slot = vs;
+        uint8_t *vo = realloc(gs->vq_ok, cap);
+        if (vo) gs->vq_ok = vo;
+        if (!ve || !vs || !vo) return _CERR_NOMEM;
+        gs->cap_vq = cap;
+    }
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
+    }
+    gs->walked = true;
     return 0;
+}
+
+/* view_calc_frustum() ran for `view` (view.c:291): the next verdict for it re-culls on the device if the planes changed */
+void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view)
+{
+    if (gs && view == gs->culled_view) gs->cull_checked = false;
 }
 
 bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e)
 {
-    if (gs && view == gs->culled_view &&
-        !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes)) &&
-        (e->flags & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE)) {
-        /* _models_render asks in list order (model.c:958-973): try the next record of the walk first */
-        uint32_t i;
-        if (gs->vis_cursor < gs->n_order && gs->rec[gs->order[gs->vis_cursor]].e == e)
-            i = gs->order[gs->vis_cursor];
-        else
-            i = rec_find(gs, e);
-        const struct gs_rec *r = i != NO_REC ? &gs->rec[i] : NULL;
-        if (r) gs->vis_cursor = r->order_pos + 1 < gs->n_order ? r->order_pos + 1 : 0;
-        /* the mask bit is the draw predicate ALIVE && VISIBLE && (SKIP_CULLING || in frustum):
-         * for an alive, visible, culled entity it is the frustum test itself */
-        if (r && r->gen == gs->gen && r->cls == 1 && r->flags == (e->flags & (ENTITY3D_ALIVE | 0xffffu)))
-            return (gs->res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1;
+    if (gs && view == gs->culled_view) {
+        if (!gs->cull_checked) {
+            /* once per frustum, not per entity: same planes as the fused cull of the last update, or one cull launch */
+            gs->cull_checked = true;
+            gs->cull_ok = !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+            if (!gs->cull_ok) {
+                clapgpu_frustum fr;
+                frustum_of(view, &fr);
+                if (!clapgpu_scene_cull(gs->scene, &fr)) {
+                    memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+                    gs->cull_ok = true;
+                }
+            }
+        }
+        if (gs->cull_ok && gs->notify && gs->vis_cursor < gs->n_order && gs->vq_e[gs->vis_cursor] == e) {
+            /* notification mode, asked in list order (model.c:958-973): the table answers */
+            const uint32_t c = gs->vis_cursor;
+            gs->vis_cursor = c + 1 < gs->n_order ? c + 1 : 0;
+            if (gs->vq_ok[c])
+                return (gs->res.vis_mask[gs->vq_slot[c] >> 6] >> (gs->vq_slot[c] & 63)) & 1;
+        } else
+        if (gs->cull_ok) {
+            /* _models_render asks in list order (model.c:958-973): try the next record of the walk first */
+            uint32_t i;
+            if (gs->vis_cursor < gs->n_order && gs->rec[gs->order[gs->vis_cursor]].e == e)
+                i = gs->order[gs->vis_cursor];
+            else
+                i = rec_find(gs, e);
+            const struct gs_rec *r = i != NO_REC ? &gs->rec[i] : NULL;
+            if (r) gs->vis_cursor = r->order_pos + 1 < gs->n_order ? r->order_pos + 1 : 0;
+            /* the mask bit is the draw predicate ALIVE && VISIBLE && (SKIP_CULLING || in frustum):
+             * for an alive, visible, culled entity it is the frustum test itself */
+            if (r && r->gen == gs->gen && r->cls == 1) {
+                /* with notifications an untouched record's flags ARE the entity's: the 448-byte struct is not read at all */
+                const uint32_t fl = (gs->notify && !r->pending) ? r->flags : (e->flags & (ENTITY3D_ALIVE | 0xffffu));
+                if (fl == r->flags &&
+                    (fl & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE))
+                    return (gs->res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1;
+            }
+        }
     }
     return view_entity_in_frustum(view, e);
 }

@@ -52,7 +52,31 @@ int  gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view);
  * gpu_mq_update(); the engine's own function for anything else. */
 bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e);
 
+/* view_calc_frustum() ran for `view` (the engine recomputes its frusta in scene_cameras_calc, after mq_update,
+ * clap.c:614-616): the first verdict asked for it afterwards compares the planes once and, if they differ from the ones
+ * the update culled against, runs the cull kernel alone for the new ones.  Code that writes frustum_planes by any other
+ * route has to call this too. */
+void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view);
+
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
+
+/*
+ * Notification mode.  The reference's mutators already mark what they change (transform_set_updated behind
+ * entity3d_position / _move / _rotate / _scale, model.c:1810-1842); with CONFIG_GPU_SCENE they also tell the binding
+ * (gpu-exports.inc.c), and gpu_mq_update() stops walking every entity3d twice a frame: it costs
+ * O(touched + rebuilt + host-class entities).  Whatever changes the queue's make-up -- entity3d creation / deletion,
+ * a write to e->parent or e->update, a body / light / joint attachment -- is reported with gpu_scene_topology(); the
+ * next update then walks the queue once, as without notifications.
+ */
+void gpu_scene_set_notify(struct gpu_scene *gs, bool on);
+bool gpu_scene_last_was_fast(const struct gpu_scene *gs);      /* the last gpu_mq_update() did not walk the queue */
+void gpu_scene_touch(struct gpu_scene *gs, entity3d *e);
+void gpu_scene_topology(struct gpu_scene *gs);
+/* the scene, queue and view the engine-named entry points (mq_update, view_entity_in_frustum, ...) serve */
+void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view);
+struct gpu_scene *gpu_scene_bound(void);
+struct mq *gpu_scene_bound_mq(void);
+struct view *gpu_scene_bound_view(void);
 
 /*
  * Skeletal animation.  By default an entity whose model has animations stays on the host, because

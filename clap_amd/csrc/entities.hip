@@ -41,6 +41,8 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     float           bv_cam[3], bv_ctl[3];
     uint32_t        bv_has_ctl, bv_ctl_entity;
     unsigned long long *bv_result;
+    uint64_t       *bv_inside;       // optional: one bit per entity, set where the query's boxes contain the point(s)
+    uint64_t       *rebuilt_mask;    // optional: one bit per entity, set where this launch rebuilt the entity
     uint32_t        n, n_models;     // bounds of the two indices the caller supplies per entity
 };
 
@@ -192,6 +194,7 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
 
     // ---- stores: whole-wave fast path when every valid lane rebuilt (the common case) ----
     const uint64_t rebuilt_mask = __ballot(rebuild);
+    if (e.rebuilt_mask && lane == 0) e.rebuilt_mask[row_first >> 6] = rebuilt_mask;
     const uint64_t aabb_mask = __ballot(rebuild && has_aabb);
     const uint64_t full = row_count == WAVE ? ~0ull : ((1ull << row_count) - 1ull);
     const size_t e0 = row_first;
@@ -245,7 +248,9 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
             inside = in_range && (fl & CLAPGPU_E_ALIVE) && point_in_box(e.bv_ctl, bb);
         if (inside && e.bv_has_ctl && i == e.bv_ctl_entity)
             inside = false;
-        if (__ballot(inside)) {                                  // rare: almost no box contains the camera
+        const uint64_t inside_mask = __ballot(inside);
+        if (e.bv_inside && lane == 0) e.bv_inside[e0 >> 6] = inside_mask;
+        if (inside_mask) {                                       // rare: almost no box contains the camera
             unsigned long long key = 0;
             if (inside) {
                 const float4 lo = e.model_table[2 * in.mi], hi = e.model_table[2 * in.mi + 1];
@@ -604,6 +609,8 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     k.n = e->n;
     k.n_models = e->n_models ? e->n_models : 1;
     k.bv_result = nullptr;
+    k.bv_inside = nullptr;
+    k.rebuilt_mask = e->rebuilt_mask;
     k.bv_has_ctl = k.bv_ctl_entity = 0;
     for (int a = 0; a < 3; a++) k.bv_cam[a] = k.bv_ctl[a] = 0.f;
     if (e->bv && e->bv->result) {
@@ -612,6 +619,7 @@ static EntK to_kernel_args(const clapgpu_entities *e)
         k.bv_has_ctl = e->bv->has_ctl;
         k.bv_ctl_entity = e->bv->ctl_entity;
         k.bv_result = reinterpret_cast<unsigned long long *>(e->bv->result);
+        k.bv_inside = e->bv->inside_mask;
     }
     return k;
 }

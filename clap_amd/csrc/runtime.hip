@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 19u
+#define CLAPGPU_ABI_VERSION 20u
 
 namespace clapgpu {
 

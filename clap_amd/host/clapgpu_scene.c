@@ -31,7 +31,7 @@ struct clapgpu_scene {
     uint32_t   *free_list;  uint32_t n_free;
     uint32_t   *dirty_list; uint32_t n_dirty, cap_dirty;
     float      *models;     uint32_t n_models, cap_models;       /* [m][8] model_table rows */
-    int         topology_dirty, models_dirty, tiled;
+    int         topology_dirty, models_dirty, tiled, bulk_dirty;
 
     /* layout */
     uint32_t    n_slots, n_rows, n_tiles, n_levels;
@@ -42,8 +42,13 @@ struct clapgpu_scene {
     float      *h_pos_scale, *h_rot, *h_mx, *h_inv, *h_aabb, *h_center;
     int32_t    *h_parent, *h_model;
     uint32_t   *h_flags;
-    uint64_t   *h_mask;
+    uint64_t   *h_mask, *h_rebuilt, *h_inside;
+    void      **slot_user;                                       /* slot -> the entity's user pointer (NULL: padding) */
     uint32_t    cap_slots;
+    uint32_t    up_lo, up_hi, n_staged;                           /* slots whose upload image was written since the last frame */
+    /* camera bounding-volume points (default_update's pick, model.c:1703-1713) */
+    int         bv_on, bv_has_ctl; float bv_cam[3], bv_ctl[3]; uint32_t bv_ctl_handle;
+    clapgpu_bv_query bvq; uint64_t *d_bv_result;
 
     /* the arrays above that cross PCIe every frame are carved out of two page-locked slabs that
      * mirror two device slabs: one copy up (pos_scale | rot | flags), one copy down
@@ -77,6 +82,16 @@ static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
         s->dirty_list[s->n_dirty++] = h;
     }
     s->e[h].dirty |= xform_updated ? 3 : 1;
+    /* the layout stands: write the upload image now, while the caller's data is hot, instead of in a second pass */
+    if (!s->topology_dirty && s->h_in && s->e[h].slot < s->n_slots) {
+        const struct ent *e = &s->e[h];
+        const uint32_t slot = e->slot;
+        memcpy(s->h_pos_scale + 4 * (size_t)slot, e->pos_scale, 16);
+        memcpy(s->h_rot + 4 * (size_t)slot, e->rot, 16);
+        s->h_flags[slot] = e->flags | ((e->dirty & 2) ? CLAPGPU_E_DIRTY : 0);
+        if (slot < s->up_lo) s->up_lo = slot;
+        if (slot >= s->up_hi) s->up_hi = slot + 1;
+    }
 }
 
 int clapgpu_scene_create(clapgpu_scene **out, int device)
@@ -110,7 +125,8 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     free(s->tile_row_start_host); free(s->level_start_host);
     if (s->h_in) clapgpu_host_free(s->h_in);
     if (s->h_out) clapgpu_host_free(s->h_out);
-    free(s->h_parent); free(s->h_model);
+    free(s->h_parent); free(s->h_model); free(s->slot_user);
+    if (s->d_bv_result) clapgpu_free(s->d_bv_result);
     free(s);
 }
 
@@ -206,6 +222,30 @@ int clapgpu_scene_entity_transform(clapgpu_scene *s, uint32_t handle, const floa
     return CLAPGPU_OK;
 }
 
+/* entity_transform + entity_flags for callers that update many DIFFERENT handles from several threads at once (no
+ * topology verb may run meanwhile): nothing shared is touched, so the caller has to finish with
+ * clapgpu_scene_mark_all_dirty(), which makes the next mq_update upload the whole image. */
+int clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float q[4], float scale,
+                                      uint32_t flags, int xform_updated)
+{
+    struct ent *e = get(s, handle);
+    if (!e || !pos || !q) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    memcpy(e->pos_scale, pos, 12);
+    e->pos_scale[3] = scale;
+    memcpy(e->rot, q, 16);
+    e->flags = flags & ~CLAPGPU_E_DIRTY;
+    if (!s->topology_dirty && s->h_in && e->slot < s->n_slots) {
+        memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
+        memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
+        s->h_flags[e->slot] = e->flags | (xform_updated ? CLAPGPU_E_DIRTY : 0);
+    } else {
+        e->dirty |= xform_updated ? 3 : 1;               /* picked up by the re-tile's full image */
+    }
+    return CLAPGPU_OK;
+}
+
+void clapgpu_scene_mark_all_dirty(clapgpu_scene *s) { if (s) s->bulk_dirty = 1; }
+
 int clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float q[4])
 {
     struct ent *e = get(s, handle);
@@ -286,11 +326,11 @@ int clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set, 
 static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
 {
     if (n_slots <= s->cap_slots) return CLAPGPU_OK;
-    uint32_t cap = s->cap_slots ? s->cap_slots : 4096;
-    while (cap < n_slots) cap *= 2;
+    /* an eighth of head room, in 4096-slot steps: the slabs cross PCIe whole, so capacity is traffic */
+    uint32_t cap = (n_slots + n_slots / 8 + 4095u) & ~4095u;
     size_t n = cap;                                     /* a multiple of 64: every sub-array below starts 16-B aligned */
 #define RE(p, bytes) do { void *q__ = realloc(p, bytes); if (!q__) return CLAPGPU_ERR_NOMEM; p = q__; } while (0)
-    RE(s->h_parent, n * 4); RE(s->h_model, n * 4); RE(s->slot_handle, n * 4);
+    RE(s->h_parent, n * 4); RE(s->h_model, n * 4); RE(s->slot_handle, n * 4); RE(s->slot_user, n * sizeof(void *));
 #undef RE
     /* retile() rewrites the upload image in full and downloads are overwritten by the next frame, so
      * nothing has to survive the growth */
@@ -301,7 +341,7 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
     s->have_results = 0;
     s->in_bytes = n * 36;
-    s->out_bytes = n * 164 + (n / 64 + 2) * 8;
+    s->out_bytes = n * 164 + 3 * (n / 64 + 2) * 8;           /* + visibility, rebuilt and bounding-volume masks */
     CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
     CK(clapgpu_host_malloc(&s->h_out, s->out_bytes));
     CK(clapgpu_malloc(&s->d_in, s->in_bytes));
@@ -315,6 +355,8 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->h_aabb = (float *)(ho + n * 128);       s->d.aabb = (float *)(dq + n * 128);
     s->h_center = (float *)(ho + n * 152);     s->d.center = (float *)(dq + n * 152);
     s->h_mask = (uint64_t *)(ho + n * 164);    s->d.vis_mask = (uint64_t *)(dq + n * 164);
+    s->h_rebuilt = s->h_mask + (n / 64 + 2);   s->d.rebuilt_mask = s->d.vis_mask + (n / 64 + 2);
+    s->h_inside = s->h_rebuilt + (n / 64 + 2); s->bvq.inside_mask = s->d.rebuilt_mask + (n / 64 + 2);
     void **dp[] = { (void **)&s->d.parent, (void **)&s->d.model, (void **)&s->d.seqs, (void **)&s->d.vis_row_pop,
                     (void **)&s->d_tile_row_start };
     size_t sz[] = { n * 4, n * 4, n * 4, (n / 64 + 16) / 16 * 16, (n / 64 + 2) * 4 };
@@ -445,6 +487,7 @@ static int retile(clapgpu_scene *s)
     /* full staging image */
     for (uint32_t i = 0; i < s->n_slots; i++) {
         const uint32_t h = s->slot_handle[i];
+        s->slot_user[i] = h == CLAPGPU_NO_ENTITY ? NULL : s->e[h].user;
         if (h == CLAPGPU_NO_ENTITY) {
             const float id[4] = { 0, 0, 0, 1 };
             memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
@@ -472,6 +515,7 @@ static int retile(clapgpu_scene *s)
     for (uint32_t k = 0; k < s->n_dirty; k++) s->e[s->dirty_list[k]].dirty = 0;
     s->n_dirty = 0;
     s->topology_dirty = 0;
+    s->up_lo = 0xffffffffu; s->up_hi = 0;
     s->layout_gen++;
     return CLAPGPU_OK;
 }
@@ -485,21 +529,22 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         CK(retile(s));
         upload = full = 1;
     } else if (s->n_dirty) {
-        for (uint32_t k = 0; k < s->n_dirty; k++) {      /* transform_set_* since the last frame */
+        /* the upload image was written as the verbs came in (mark_dirty); here only the bookkeeping */
+        for (uint32_t k = 0; k < s->n_dirty; k++) {
             struct ent *e = &s->e[s->dirty_list[k]];
-            const int xform = e->dirty & 2;
             e->dirty = 0;
             if (!e->live) continue;
-            memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
-            memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
-            s->h_flags[e->slot] = e->flags | (xform ? CLAPGPU_E_DIRTY : 0);
             s->dirty_list[n_touched++] = e->slot;        /* the list is reused for the slots touched */
-            if (e->slot < lo) lo = e->slot;
-            if (e->slot >= hi) hi = e->slot + 1;
         }
+        lo = s->up_lo; hi = s->up_hi;
         s->n_dirty = 0;
-        upload = n_touched != 0;
+        upload = n_touched != 0 && hi > lo;
     }
+    if (s->bulk_dirty && !full) {                        /* clapgpu_scene_entity_transform_mt wrote the image directly */
+        upload = 1; lo = 0; hi = s->n_slots; n_touched = s->n_slots;   /* whole image up, flags cleared linearly */
+    }
+    s->bulk_dirty = 0;
+    s->up_lo = 0xffffffffu; s->up_hi = 0;
     if (s->models_dirty) {
         if (s->n_models > s->d_models_cap) {
             if (s->d_models) clapgpu_free(s->d_models);
@@ -526,27 +571,39 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
             CK(clapgpu_memcpy_h2d(s->d.flags + a, s->h_flags + a, cnt * 4, NULL));
         }
     }
+    if (s->bv_on) {
+        if (!s->d_bv_result) CK(clapgpu_malloc((void **)&s->d_bv_result, 8));
+        memcpy(s->bvq.cam_pos, s->bv_cam, 12); memcpy(s->bvq.ctl_pos, s->bv_ctl, 12);
+        const struct ent *ce = s->bv_has_ctl ? get(s, s->bv_ctl_handle) : NULL;
+        s->bvq.has_ctl = s->bv_has_ctl; s->bvq.ctl_entity = ce ? ce->slot : 0xffffffffu;
+        s->bvq.result = s->d_bv_result;
+        s->d.bv = &s->bvq;
+    } else {
+        s->d.bv = NULL;
+    }
     if (s->tiled)
         CK(clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum));
     else
         CK(clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, frustum));
+    const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
     if (upload || full || !s->have_results) {            /* otherwise the kernel rebuilt nothing: the last download stands */
-        if (cap == n || 4 * n > 3 * cap) {               /* one copy of the output slab (mask included) */
-            CK(clapgpu_memcpy_d2h(s->h_out, s->d_out, cap * 164 + (frustum ? (n / 64) * 8 : 0), NULL));
+        if (1) {                                         /* one copy of the output slab (the three masks included): cap <= 9/8 n + 4096 */
+            CK(clapgpu_memcpy_d2h(s->h_out, s->d_out, cap * 164 + (2 * mask_stride + mask_words) * 8, NULL));
         } else {
             CK(clapgpu_memcpy_d2h(s->h_mx, s->d.mx, n * 64, NULL));
             CK(clapgpu_memcpy_d2h(s->h_inv, s->d.inv_mx, n * 64, NULL));
             CK(clapgpu_memcpy_d2h(s->h_aabb, s->d.aabb, n * 24, NULL));
             CK(clapgpu_memcpy_d2h(s->h_center, s->d.center, n * 12, NULL));
-            if (frustum) CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (n / 64) * 8, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
         }
-    } else if (frustum) {
-        CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (n / 64) * 8, NULL));
+    } else {                                             /* masks only: visibility of this view, nothing rebuilt */
+        CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
     }
     if (!frustum)
-        memset(s->h_mask, 0, (n / 64) * 8);
+        memset(s->h_mask, 0, mask_words * 8);
     CK(clapgpu_stream_sync(NULL));
-    if (full)
+    if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
+    if (full || 4 * (size_t)n_touched > n)
         for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */
     else
         for (uint32_t k = 0; k < n_touched; k++) s->h_flags[s->dirty_list[k]] &= ~CLAPGPU_E_DIRTY;
@@ -604,8 +661,31 @@ int clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out)
     if (!s || !out || !s->have_results) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     out->n_slots = s->n_slots;
     out->mx = s->h_mx; out->inverse_mx = s->h_inv; out->aabb = s->h_aabb; out->aabb_center = s->h_center;
-    out->vis_mask = s->h_mask;
+    out->vis_mask = s->h_mask; out->rebuilt_mask = s->h_rebuilt; out->inside_mask = s->h_inside;
+    out->slot_user = (void *const *)s->slot_user;
     return CLAPGPU_OK;
+}
+
+/* view_entity_in_frustum for a frustum other than the one of the last mq_update (the engine recomputes its frusta in
+ * scene_cameras_calc, AFTER mq_update: clap.c:614-616): re-tests every entity's stored box, refreshes vis_mask */
+int clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum)
+{
+    if (!s || !frustum) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
+    CK(clapgpu_entities_cull(NULL, &s->d, frustum));
+    CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, ((size_t)s->n_slots / 64) * 8, NULL));
+    CK(clapgpu_stream_sync(NULL));
+    return CLAPGPU_OK;
+}
+
+void clapgpu_scene_set_bv_points(clapgpu_scene *s, const float cam_pos[3], const float *ctl_pos, uint32_t ctl_handle)
+{
+    if (!s) return;
+    s->bv_on = cam_pos != NULL;
+    if (cam_pos) memcpy(s->bv_cam, cam_pos, 12);
+    s->bv_has_ctl = ctl_pos != NULL;
+    if (ctl_pos) memcpy(s->bv_ctl, ctl_pos, 12);
+    s->bv_ctl_handle = ctl_handle;
 }
 
 int clapgpu_scene_layout_is_tiled(const clapgpu_scene *s) { return s ? s->tiled : 0; }

@@ -131,6 +131,9 @@ typedef struct clapgpu_attach {
  * largest volume (|model dx| scale)(|model dy| scale)(|model dz| scale).
  * *result (device uint64, zeroed by the update call) = float bits of the volume << 32 |
  * (0xFFFFFFFF - entity index), 0 if none: the largest key is the first entity of largest volume.
+ * inside_mask (device, n / 64 words, may be NULL): bit i = entity i passed the containment test.  A caller whose
+ * entity order differs from the device's index order (the reference breaks volume ties by LIST order) replays
+ * the pick over those few entities itself.
  */
 typedef struct clapgpu_bv_query {
     float     cam_pos[3];
@@ -138,6 +141,7 @@ typedef struct clapgpu_bv_query {
     float     ctl_pos[3];
     uint32_t  ctl_entity;
     uint64_t *result;
+    uint64_t *inside_mask;
 } clapgpu_bv_query;
 
 typedef struct clapgpu_entities {
@@ -164,6 +168,8 @@ typedef struct clapgpu_entities {
     const float    *bind_pool;           /* device mat4[]: model_joint.bind */
     float          *attach_local;        /* device work space, n_attach mat4 */
     const clapgpu_bv_query *bv;          /* HOST pointer */
+    uint64_t       *rebuilt_mask;        /* device, n / 64 words, may be NULL: bit i = this update rebuilt entity i
+                                            (mx / inverse_mx / aabb / seq changed): what a host mirror has to copy back */
 } clapgpu_entities;
 
 /* mode bits for clapgpu_entities_update */

@@ -45,6 +45,11 @@ int  clapgpu_scene_entity_scale(clapgpu_scene *s, uint32_t handle, float scale);
 /* the three above in one call: what a binding pushes when it finds xform.updated set */
 int  clapgpu_scene_entity_transform(clapgpu_scene *s, uint32_t handle, const float pos[3],
                                     const float quat_xyzw[4], float scale);
+/* the same + the entity's flags, for a binding that mirrors many DIFFERENT entities from several threads at once (no
+ * creation / deletion / re-parenting meanwhile); finish with clapgpu_scene_mark_all_dirty() */
+int  clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float quat_xyzw[4],
+                                       float scale, uint32_t flags, int xform_updated);
+void clapgpu_scene_mark_all_dirty(clapgpu_scene *s);
 /* entity3d_move / entity3d_rotate (radians) / entity3d_visible (model.c:1810-1842) */
 int  clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3]);
 int  clapgpu_scene_entity_rotate(clapgpu_scene *s, uint32_t handle, float rx, float ry, float rz);
@@ -55,6 +60,10 @@ int  clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set,
 
 /* mq_update + cull against `frustum` (NULL: no cull) */
 int  clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum);
+
+/* the cull alone, against another frustum (scene_cameras_calc recomputes the frusta after mq_update, clap.c:614-616):
+ * refreshes the visibility results below; CLAPGPU_ERR_NOT_SUPPORTED before the first mq_update */
+int  clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum);
 
 /* results of the last mq_update; pointers stay valid until the next mq_update */
 const float *clapgpu_scene_entity_mx(const clapgpu_scene *s, uint32_t handle);          /* e->mx */
@@ -78,9 +87,20 @@ typedef struct clapgpu_scene_arrays {
     const float    *aabb;           /* [n_slots][6]  */
     const float    *aabb_center;    /* [n_slots][3]  */
     const uint64_t *vis_mask;       /* bit (slot & 63) of word slot >> 6 */
+    const uint64_t *rebuilt_mask;   /* same indexing: the last mq_update rebuilt this slot (mx, inverse_mx, aabb, seq changed):
+                                       all a binding has to copy back.  Parents sit in lower slots than their children. */
+    const uint64_t *inside_mask;    /* same indexing: the slot's box contains a bounding-volume point (clapgpu_scene_set_bv_points) */
+    void *const    *slot_user;      /* [n_slots] the `user` pointer given to clapgpu_scene_entity_new, NULL for padding slots */
 } clapgpu_scene_arrays;
 int          clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out);
 uint32_t     clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle);
+
+/*
+ * default_update's camera bounding-volume pick (model.c:1703-1713): the points to test every entity's box against in
+ * the next mq_update -- camera position, and the control entity's position (NULL: none; ctl_handle is that entity,
+ * which never counts).  cam_pos == NULL switches the test off.  Result: clapgpu_scene_arrays.inside_mask.
+ */
+void         clapgpu_scene_set_bv_points(clapgpu_scene *s, const float cam_pos[3], const float *ctl_pos, uint32_t ctl_handle);
 
 /* 1 = tiles (one launch), 0 = level-major (a tree wider than 64 at some level); after mq_update */
 int          clapgpu_scene_layout_is_tiled(const clapgpu_scene *s);
