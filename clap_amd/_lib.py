@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 OK = 0
 ERR_NOMEM = -1
@@ -207,6 +207,14 @@ SYMBOLS = {
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_contacts_sphere_box": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_shard_tile_range": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32)]),
+    "clapgpu_exchange_set_library": (None, [C.c_char_p]),
+    "clapgpu_exchange_unique_id": (C.c_int, [C.c_void_p]),
+    "clapgpu_exchange_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "clapgpu_exchange_destroy": (None, [C.c_void_p]),
+    "clapgpu_exchange_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
     "clapgpu_characters_update": (C.c_int, [C.c_void_p, C.POINTER(Characters), C.POINTER(Entities),
                                             C.POINTER(Bodies)]),

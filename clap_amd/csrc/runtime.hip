@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 20u
+#define CLAPGPU_ABI_VERSION 21u
 
 namespace clapgpu {
 

@@ -12,14 +12,20 @@ import torch.distributed as dist
 
 
 def shard_tile_ranges(rows_per_tile, world):
-    """Split tiles into `world` contiguous ranges of (nearly) equal row count.
-    rows_per_tile: rows of each tile (tile_row_start differences).  Returns [(t0, t1)] per rank."""
+    """Split tiles into `world` contiguous ranges of (nearly) equal row count (clapgpu_shard_tile_range, the C
+    function every rank of an engine would call).  rows_per_tile: rows of each tile (tile_row_start differences).
+    Returns [(t0, t1)] per rank."""
+    import ctypes as C
+    from . import _lib
     rows = np.asarray(rows_per_tile, np.int64)
-    cum = np.concatenate([[0], np.cumsum(rows)])
-    total = int(cum[-1])
-    cuts = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world + 1)]
-    cuts[0], cuts[-1] = 0, len(rows)
-    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+    trs = np.ascontiguousarray(np.concatenate([[0], np.cumsum(rows)]), np.uint32)
+    out = []
+    for r in range(world):
+        t0, t1 = C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.lib().clapgpu_shard_tile_range(trs.ctypes.data, len(rows), r, world, C.byref(t0), C.byref(t1)),
+                   "clapgpu_shard_tile_range")
+        out.append((t0.value, t1.value))
+    return out
 
 
 def allgather_visible(visible, count, world, counts_buf=None, gather_buf=None, pad_to=4096, group=None):
@@ -62,7 +68,7 @@ def concat_visible(counts, gathered):
 
 class VisibleExchange:
     """The path's one exchange, double-buffered: each rank's visibility mask travels in ONE fixed-size
-    allgather on a side stream (RCCL's ncclAllGather called directly, or torch.distributed as the
+    allgather on a side stream (clapgpu_exchange_visible: ncclAllGather from C, or torch.distributed as the
     fallback), and every rank expands the gathered mask into the identical ascending global id list
     (clapgpu_visible_compact over world * n entities).  Exchange + expansion of frame f overlap the update
     of frame f + 1: `begin()` hands the update kernel the mask buffer of this frame, `submit()` queues
@@ -89,21 +95,39 @@ class VisibleExchange:
         self.direct = None
         if route == "rccl":
             try:
-                from . import rccl
-                self.direct = rccl.Communicator(rank, world, device)
+                self.direct = self._create_exchange(rank, world, device)
             except Exception as exc:                        # keep the run alive: c10d does the same exchange
                 import sys
-                print(f"[clap_amd.shard] direct RCCL unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                print(f"[clap_amd.shard] clapgpu_exchange unavailable ({exc}); using torch.distributed", file=sys.stderr)
             # every rank must take the same route: one rank falling back alone would deadlock the others
             ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32, device=device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0 and self.direct is not None:
-                self.direct.destroy()
+                _lib.lib().clapgpu_exchange_destroy(self.direct)
                 self.direct = None
+
+    def _create_exchange(self, rank, world, device):
+        """libclapgpu's own exchange object (exchange.hip): RCCL opened at run time -- the copy torch has loaded --, the
+        unique id carried to the ranks by the process group, once."""
+        import os
+        C, _lib = self._C, self._lib
+        L = _lib.lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(path):
+            L.clapgpu_exchange_set_library(path.encode())
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(L.clapgpu_exchange_unique_id(uid), "clapgpu_exchange_unique_id")
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(t, src=0)
+        raw = (C.c_uint8 * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        x = C.c_void_p()
+        _lib.check(L.clapgpu_exchange_create(C.byref(x), raw, rank, world), "clapgpu_exchange_create")
+        return x
 
     @property
     def route(self):
-        return "ncclAllGather (direct)" if self.direct is not None else "torch.distributed all_gather"
+        return "ncclAllGather via clapgpu_exchange_visible (C)" if self.direct is not None else "torch.distributed all_gather"
 
     def begin(self):
         """Before the frame's update: wait until the exchange that last read this frame's mask buffer is done."""
@@ -121,14 +145,18 @@ class VisibleExchange:
         self.ev_upd[b].record(main)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ev_upd[b])
-            if self.direct is not None:
-                self.direct.allgather_i64(self.masks[b], self.g_mask[b], self.comm)
+            if self.direct is not None:                    # allgather + expansion: one C call on the side stream
+                rc = _lib.lib().clapgpu_exchange_visible(C.c_void_p(self.comm.cuda_stream), self.direct,
+                                                         self.masks[b].data_ptr(), self.n_pad, self.g_mask[b].data_ptr(),
+                                                         self.g_vis[b].data_ptr(), self.g_cnt[b].data_ptr(),
+                                                         self.g_scratch.data_ptr())
+                _lib.check(rc, "clapgpu_exchange_visible")
             else:
                 allgather_visible_mask(self.masks[b], self.world, self.g_mask[b])
-            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(self.comm.cuda_stream), self.g_mask[b].data_ptr(), None,
-                                                    self.world * self.n_pad, 0, self.g_vis[b].data_ptr(),
-                                                    self.g_cnt[b].data_ptr(), self.g_scratch.data_ptr())
-            _lib.check(rc, "clapgpu_visible_compact(global)")
+                rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(self.comm.cuda_stream), self.g_mask[b].data_ptr(), None,
+                                                        self.world * self.n_pad, 0, self.g_vis[b].data_ptr(),
+                                                        self.g_cnt[b].data_ptr(), self.g_scratch.data_ptr())
+                _lib.check(rc, "clapgpu_visible_compact(global)")
             self.ev_comm[b].record(self.comm)
 
     def last(self):
@@ -139,5 +167,5 @@ class VisibleExchange:
 
     def destroy(self):
         if self.direct is not None:
-            self.direct.destroy()
+            self._lib.lib().clapgpu_exchange_destroy(self.direct)
             self.direct = None

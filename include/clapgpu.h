@@ -248,6 +248,39 @@ int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t
                          const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod);
 
 /* ======================================================================== */
+/* Multi-GPU: range sharding + the one exchange                  */
+/* ======================================================================== */
+
+/*
+ * The path shards by entity range with whole subtrees on one rank: contiguous TILE ranges of (nearly) equal row
+ * count.  tile_row_start: HOST array of n_tiles + 1 row offsets (clapgpu_entities_update_tiles).  Rank r of `world`
+ * owns tiles [*first_tile, *end_tile).  Pure function: every rank computes the same cuts.
+ */
+int clapgpu_shard_tile_range(const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t rank, uint32_t world,
+                             uint32_t *first_tile, uint32_t *end_tile);
+
+/*
+ * The only exchange of a frame: the RCCL allgather (over xGMI) of every rank's compacted visible set, sent as its
+ * 1-bit-per-entity mask -- one fixed-size collective, no counts, no padding, no host sync -- and its local expansion
+ * into the identical ascending GLOBAL id list on every rank (shards are equal padded ranges: rank r's entity i has
+ * global id r * n_pad + i).  RCCL is opened at run time (clapgpu_exchange_set_library: a path, e.g. the copy the
+ * process already has; default: librccl.so of the process / the system); CLAPGPU_ERR_NOT_SUPPORTED without one.
+ * Bootstrap: rank 0 calls clapgpu_exchange_unique_id(), the launcher carries the 128 bytes to every rank.
+ *   vis_mask       this rank's mask, device, n_pad / 64 words
+ *   gathered_mask  device, world * n_pad / 64 words (out)
+ *   visible, visible_count, scratch   as clapgpu_visible_compact over world * n_pad entities; visible NULL = mask only
+ * Issued on `stream`: put it on a side stream to overlap the next frame's update (two mask buffers).
+ */
+#define CLAPGPU_EXCHANGE_ID_BYTES 128
+typedef struct clapgpu_exchange clapgpu_exchange;
+void clapgpu_exchange_set_library(const char *path);
+int  clapgpu_exchange_unique_id(uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES]);
+int  clapgpu_exchange_create(clapgpu_exchange **out, const uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES], int rank, int world);
+void clapgpu_exchange_destroy(clapgpu_exchange *x);
+int  clapgpu_exchange_visible(void *stream, clapgpu_exchange *x, const uint64_t *vis_mask, uint32_t n_pad,
+                              uint64_t *gathered_mask, uint32_t *visible, uint32_t *visible_count, void *scratch);
+
+/* ======================================================================== */
 /* Particle systems: advect / respawn / billboard (core/particle.c)          */
 /* ======================================================================== */
 

@@ -42,6 +42,12 @@ def test_dropin_checker_is_built_where_the_reference_is():
     wanted = {l.split()[-1] for l in out.splitlines() if "clapgpu_" in l}
     assert {"clapgpu_scene_create", "clapgpu_scene_mq_update", "clapgpu_scene_entity_new",
             "clapgpu_scene_entity_transform", "clapgpu_scene_results"} <= wanted
+    # the replacement exports the engine's own entry points for the path; the reference's bodies are ref_<name>
+    defined = subprocess.run(["nm", "--defined-only", BIN], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1] for l in defined.splitlines() if " T " in l}
+    for fn in ("mq_update", "view_entity_in_frustum", "view_calc_frustum", "light_grid_compute", "entity3d_position",
+               "entity3d_move", "entity3d_rotate", "entity3d_scale", "entity3d_visible"):
+        assert fn in names and "ref_" + fn in names, fn
 
 
 def _run(*args):
@@ -53,10 +59,17 @@ def _run(*args):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,frames,seed", [(300, 12, 1), (5000, 16, 2), (40000, 8, 3), (2000, 40, 7)])
-def test_binding_matches_reference_mq_update(n, frames, seed):
-    r = _run("test", n, frames, seed)
+@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
+@pytest.mark.parametrize("n,frames,seed", [(300, 12, 1), (5000, 16, 2), (40000, 8, 3), (2000, 40, 7), (300000, 6, 5)])
+def test_binding_matches_reference_mq_update(n, frames, seed, notify):
+    """World B is driven through the ENGINE'S OWN NAMES -- mq_update(), view_entity_in_frustum(), entity3d_position /
+    _move / _rotate / _scale / _visible -- which gpu-exports.inc.c serves from the binding (link-time substitution: the
+    reference's bodies are ref_<name>, world A calls those).  `notify`: the mutators report what they touch and frames
+    without creations / deletions / re-parenting run in O(touched + rebuilt) (the 300 000-entity case also takes the
+    worker-thread passes)."""
+    r = _run("test", n, frames, seed, *(["notify"] if notify else []))
     assert r["mismatches"] == 0
+    assert r["notify"] is notify and (r["fast_frames"] > 0) == notify
     assert r["batched_updates"] > 0 and r["host_updates"] > 0      # both halves of the split were exercised
     frac = r["batched_updates"] / (r["batched_updates"] + r["host_updates"])
     assert frac >= BATCHED_FLOOR["test"], f"only {frac:.2f} of the updates went through the device"
@@ -146,6 +159,8 @@ def test_scene_dumped_by_the_binding_replays_to_the_reference_bits(tmp_path, cud
 
 
 @pytest.mark.gpu
-def test_binding_bench_mode_is_consistent():
-    r = _run("bench", 10000, 5, 1000)
+@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
+def test_binding_bench_mode_is_consistent(notify):
+    r = _run("bench", 10000, 5, 300, *(["notify"] if notify else []))
     assert r["mismatches"] == 0 and r["visible_equal"] is True
+    assert r["binding_mq_update_ms"] > 0 and r["reference_mq_update_ms"] > 0

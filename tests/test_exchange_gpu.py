@@ -1,6 +1,7 @@
 """GPU, world size 1: the path's one exchange exactly as bench.py --gpus N runs it (clap_amd.shard.VisibleExchange):
-rccl.Communicator bootstrapped through the process group, ncclAllGather of the visibility mask on the side stream,
-clapgpu_visible_compact over the gathered mask with a non-zero index base -- against the oracle's visible list.
+libclapgpu's clapgpu_exchange (RCCL opened at run time from C, unique id carried by the process group),
+clapgpu_exchange_visible = ncclAllGather of the visibility mask + expansion on the side stream, and
+clapgpu_visible_compact over a gathered mask with a non-zero index base -- against the oracle's visible list.
 (N > 1 on hardware is the driver's scaling run; the multi-rank logic is covered on CPU by test_shard_cpu.py.)"""
 import os
 import socket
@@ -51,7 +52,7 @@ def test_world1_exchange_matches_oracle(route, cuda_device, process_group):
     xch = shard.VisibleExchange(batch, 0, 1, cuda_device, route=route)
     if route == "rccl":
         assert xch.direct is not None, "direct RCCL communicator must come up on the GPU box"
-        assert "ncclAllGather" in xch.route
+        assert "clapgpu_exchange_visible" in xch.route
     else:
         assert xch.direct is None
     try:
@@ -72,36 +73,39 @@ def test_world1_exchange_matches_oracle(route, cuda_device, process_group):
 
 
 def test_gathered_mask_expands_with_index_base(cuda_device, process_group):
-    """What rank r > 0 contributes: its ids offset by its range start.  Emulated on one GPU by compacting the
-    same gathered mask with index_base = r * n_pad, the id arithmetic of shard.py / bench.py."""
+    """What rank r > 0 contributes: its ids offset by its range start.  Emulated on one GPU: clapgpu_exchange_visible in
+    its mask-only form (visible = NULL), then clapgpu_visible_compact over the gathered mask with index_base = r * n_pad,
+    the id arithmetic of exchange.hip / bench.py."""
     import ctypes as C
     import torch
-    from clap_amd import _lib, entities, rccl
+    from clap_amd import _lib, entities, shard
     scene, _tl = tiler.tiled_scene(synth.entities_chains(700, 5, seed=5))
     cam = synth.camera(pos=(0, 0, 40))
     batch = entities.EntityBatch(scene, cuda_device)
     fr, _v, _p = entities.view_calc_frustum(cam)
     batch.mq_update(fr, all_dirty=True)
-    comm = rccl.Communicator(0, 1, cuda_device)
+    xch = shard.VisibleExchange(batch, 0, 1, cuda_device, route="rccl")
+    assert xch.direct is not None
     side = torch.cuda.Stream(device=cuda_device)
     gathered = torch.zeros_like(batch.vis_mask)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
+    L = _lib.lib()
     try:
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            comm.allgather_i64(batch.vis_mask, gathered, side)
+            _lib.check(L.clapgpu_exchange_visible(C.c_void_p(side.cuda_stream), xch.direct, batch.vis_mask.data_ptr(), batch.n,
+                                                  gathered.data_ptr(), None, None, None), "clapgpu_exchange_visible(mask only)")
             out = torch.zeros(batch.n, dtype=torch.int32, device=cuda_device)
             cnt = torch.zeros(1, dtype=torch.int32, device=cuda_device)
-            scratch = torch.zeros(_lib.lib().clapgpu_visible_scratch_bytes(batch.n) // 4 + 4, dtype=torch.int32,
-                                  device=cuda_device)
+            scratch = torch.zeros(L.clapgpu_visible_scratch_bytes(batch.n) // 4 + 4, dtype=torch.int32, device=cuda_device)
             base = 3 * batch.n
-            rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(side.cuda_stream), gathered.data_ptr(), None, batch.n,
-                                                    base, out.data_ptr(), cnt.data_ptr(), scratch.data_ptr())
+            rc = L.clapgpu_visible_compact(C.c_void_p(side.cuda_stream), gathered.data_ptr(), None, batch.n,
+                                           base, out.data_ptr(), cnt.data_ptr(), scratch.data_ptr())
             _lib.check(rc, "clapgpu_visible_compact")
         torch.cuda.synchronize()
     finally:
-        comm.destroy()
+        xch.destroy()
     vis, _mask = _oracle_visible(scene, cam)
     got = out[:int(cnt.item())].cpu().numpy().astype(np.int64)
     assert np.array_equal(got, vis.astype(np.int64) + base)

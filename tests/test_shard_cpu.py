@@ -95,3 +95,51 @@ def test_shard_tile_ranges_cover_and_balance():
         assert all(a[1] == b[0] for a, b in zip(rngs, rngs[1:]))
         loads = [int(rows[a:b].sum()) for a, b in rngs]
         assert max(loads) - min(loads) <= 16
+
+
+def test_c_shard_ranges_cover_and_balance():
+    """clapgpu_shard_tile_range (exchange.hip, host code): contiguous, complete, balanced to within one tile, identical
+    on every rank; edge cases: more ranks than tiles, a single tile, equal tiles."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    for rows in ([8] * 16, [1], rng.integers(1, 9, 1000).tolist(), [5, 1, 1, 1, 9, 2], [3] * 5):
+        for world in (1, 2, 3, 4, 8):
+            r = shard.shard_tile_ranges(rows, world)
+            assert r[0][0] == 0 and r[-1][1] == len(rows)
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1)), "contiguous"
+            assert all(a <= b for a, b in r)
+            if len(rows) >= 4 * world:
+                per = [sum(rows[a:b]) for a, b in r]
+                assert max(per) - min(per) <= 2 * max(rows), (rows[:8], world, per)
+
+
+def test_blocks_of_the_global_forest_are_the_shards():
+    """bench.py --gpus N builds rank r's scene as block r of ONE global forest (synth.entities_chains, seed 2 + r).
+    Tiling the concatenated forest and cutting it with clapgpu_shard_tile_range gives every rank exactly its block: same
+    rows, same entities, and the union of the shard-local visible sets (ids + rank * n_pad) is the global visible set."""
+    from oracle import binding as ob
+    world, chains, depth = 4, 256, 4
+    blocks = [tiler.tiled_scene(synth.entities_chains(chains, depth, seed=2 + r))[0] for r in range(world)]
+    n_pad = blocks[0]["n"]
+    assert all(b["n"] == n_pad for b in blocks), "equal padded shard sizes"
+    trs = np.concatenate([[0]] + [b["tile_row_start"][1:].astype(np.int64) + r * (n_pad // 64) for r, b in enumerate(blocks)])
+    cuts = shard.shard_tile_ranges(np.diff(trs), world)
+    tiles_per_block = len(blocks[0]["tile_row_start"]) - 1
+    assert cuts == [(r * tiles_per_block, (r + 1) * tiles_per_block) for r in range(world)]
+    cam = synth.camera(pos=(0, 5, 60))
+    fr, _v, _p = ob.frustum_from_camera(cam)
+    union = []
+    for r, b in enumerate(blocks):
+        st = ob.entity_state(b)
+        ob.entities_update(b, st)
+        vis, _m = ob.entities_cull(b["n"], st["flags"], st["aabb"], fr)
+        union.append(vis.astype(np.int64) + r * n_pad)
+    union = np.concatenate(union)
+    # the global forest as one scene: parents shifted by the block offset
+    g = {k: (np.concatenate([b[k] for b in blocks]) if isinstance(blocks[0][k], np.ndarray) and blocks[0][k].shape[:1] == (n_pad,)
+             else blocks[0][k]) for k in blocks[0]}
+    g["parent"] = np.concatenate([np.where(b["parent"] >= 0, b["parent"] + r * n_pad, -1) for r, b in enumerate(blocks)]).astype(np.int32)
+    g["n"] = world * n_pad
+    st = ob.entity_state(g)
+    ob.entities_update(g, st)
+    vis_all, _m = ob.entities_cull(g["n"], st["flags"], st["aabb"], fr)
+    assert np.array_equal(union, vis_all.astype(np.int64)) and np.all(np.diff(union) > 0)
