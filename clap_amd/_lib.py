@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 OK = 0
 ERR_NOMEM = -1
@@ -144,6 +144,31 @@ class Lights(C.Structure):
                 ("attenuation", C.c_void_p), ("is_dir", C.c_void_p), ("active", C.c_void_p)]
 
 
+class Frame(C.Structure):
+    """clapgpu_frame (include/clapgpu.h)."""
+    _fields_ = [("entities", C.POINTER(Entities)), ("tile_row_start", C.c_void_p), ("n_tiles", C.c_uint32),
+                ("level_start", C.c_void_p), ("n_levels", C.c_uint32), ("frustum", C.POINTER(Frustum)),
+                ("bodies", C.POINTER(Bodies)), ("world", C.POINTER(World)), ("bp", C.c_void_p),
+                ("pairs", C.c_void_p), ("pair_capacity", C.c_uint32), ("pair_total", C.c_void_p),
+                ("static_pairs", C.c_void_p), ("static_pair_capacity", C.c_uint32), ("static_pair_total", C.c_void_p),
+                ("body_geoms", C.POINTER(Geoms)), ("static_geoms", C.POINTER(Geoms)),
+                ("contacts", C.c_void_p), ("static_contacts", C.c_void_p),
+                ("contact_total", C.c_void_p), ("static_contact_total", C.c_void_p),
+                ("n_body_links", C.c_uint32), ("link_body", C.c_void_p), ("link_entity", C.c_void_p),
+                ("characters", C.POINTER(Characters)),
+                ("lights", C.POINTER(Lights)),
+                ("n_light_carriers", C.c_uint32), ("carrier_entity", C.c_void_p), ("carrier_light", C.c_void_p),
+                ("carrier_offset", C.c_void_p),
+                ("light_width", C.c_uint32), ("light_height", C.c_uint32), ("light_cell", C.c_uint32), ("light_tiles", C.c_void_p),
+                ("view_mx", C.POINTER(C.c_float)), ("proj_mx", C.POINTER(C.c_float)),
+                ("anim_clock", C.POINTER(AnimClock)), ("now_dev", C.c_void_p),
+                ("skeleton", C.POINTER(Skeleton)), ("animations", C.POINTER(Animations)), ("pose", C.POINTER(PoseBatch)),
+                ("skin", C.POINTER(SkinBatch)),
+                ("particles", C.POINTER(Particles)),
+                ("index_base", C.c_uint32), ("visible", C.c_void_p), ("visible_count", C.c_void_p), ("visible_scratch", C.c_void_p),
+                ("cam_pos", C.c_float * 3), ("force_lod", C.c_void_p), ("cur_lod", C.c_void_p), ("draw_lod", C.c_void_p)]
+
+
 LIGHTS_MAX = 128
 
 
@@ -215,6 +240,7 @@ SYMBOLS = {
     "clapgpu_exchange_destroy": (None, [C.c_void_p]),
     "clapgpu_exchange_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
+    "clapgpu_frame_issue": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_double, C.c_uint32]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
     "clapgpu_characters_update": (C.c_int, [C.c_void_p, C.POINTER(Characters), C.POINTER(Entities),
                                             C.POINTER(Bodies)]),

@@ -6,7 +6,7 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 21u
+#define CLAPGPU_ABI_VERSION 22u
 
 namespace clapgpu {
 

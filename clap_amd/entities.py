@@ -181,13 +181,16 @@ class EntityBatch:
                                                 _ptr(self.visible), _ptr(self.visible_count), _ptr(self.scratch))
         _lib.check(rc, "clapgpu_visible_compact")
 
-    def select_lod(self, cam_pos, force_lod=None):
-        """LOD pick of the render pass for the compacted visible list (model.c:975-992):
-        updates cur_lod, fills draw_lod[:visible_count] (the draw list is (visible, draw_lod))."""
+    def alloc_lod(self):
         if not hasattr(self, "cur_lod"):
             self.cur_lod = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
             self.draw_lod = torch.zeros(max(self.n, 1), dtype=torch.int32, device=self.device)
             self.force_lod = None
+
+    def select_lod(self, cam_pos, force_lod=None):
+        """LOD pick of the render pass for the compacted visible list (model.c:975-992):
+        updates cur_lod, fills draw_lod[:visible_count] (the draw list is (visible, draw_lod))."""
+        self.alloc_lod()
         if force_lod is not None:
             self.force_lod = torch.from_numpy(np.ascontiguousarray(force_lod, np.int32)).to(self.device)
         cp = (C.c_float * 3)(*[float(v) for v in cam_pos])

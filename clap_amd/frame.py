@@ -4,14 +4,12 @@
 ``mq_update`` with every entity's update hook in list order -- ``character_update`` (character.c:583)
 in front of ``default_update`` (model.c:1649: body read-back, TRS rebuild, light hand-off, rotation
 push to colliders, ``animated_update``), ``particles_update`` (particle.c:89) -> camera / light grid
--> render passes (frustum test, LOD pick per drawn entity; the vertex shader skins).  ``FrameLoop``
-issues the same work as a fixed sequence of launches on one stream; nothing is read back unless asked.
-``overlap=True`` puts the two pieces that depend on nothing else in the frame on a side stream next to
-the physics chain (the statics x bodies broadphase pass beside the bodies x bodies pass, and the
-particle systems), forking from and joining the main stream so the frame stays one unit and still captures
-into one HIP graph.  Results are identical (tests/test_frame_gpu.py), but it is off by default: measured on
-MI355X it does not shorten the BASELINE-size frame (0.604 vs 0.59 ms issued, 0.595 vs 0.60 ms replayed) and
-the extra stream switches cost the testbed-size frame 80 us issued / 40 us replayed.
+-> render passes (frustum test, LOD pick per drawn entity; the vertex shader skins).  The sequence itself
+lives in C: ``clapgpu_frame_issue`` (clap_amd/csrc/frame.hip) issues it as a fixed series of launches on one
+stream from a ``clapgpu_frame`` descriptor; ``FrameLoop`` only gathers the descriptor from the harness objects,
+keeps the host-side time base and captures / replays the call as a HIP graph.  Nothing is read back unless asked.
+(A variant that forked the particle systems and one broadphase pass onto a side stream was measured in round 1:
+no faster at BASELINE size, slower at testbed size; removed.)
 """
 import numpy as np
 import torch
@@ -21,7 +19,7 @@ from . import entities as ent_mod
 
 class FrameLoop:
     def __init__(self, batch, cam, world=None, feed=None, body_links=None, lights=None, characters=None,
-                 particles=None, contacts=False, overlap=False):
+                 particles=None, contacts=False):
         """batch: EntityBatch.  world: PhysWorld (dynamic bodies write their entities through
         body_entity; character bodies have body_entity = -1).  feed: CharacterFeed.  body_links:
         (link_body, link_entity) of characters / static colliders whose rotation follows the entity.
@@ -30,12 +28,85 @@ class FrameLoop:
         self.batch, self.world, self.feed, self.lights = batch, world, feed, lights
         self.characters, self.particles = characters, particles
         self.body_links, self.contacts = body_links, contacts
-        self.overlap, self._side = overlap, None
+        self._desc = None
         self.set_camera(cam)
 
     def set_camera(self, cam):
         self.cam = cam
         self.frustum, self.view_mx, self.proj_mx = ent_mod.view_calc_frustum(cam)
+        self._desc = None                                   # frustum / matrices are part of the descriptor
+
+    # ---- the clapgpu_frame descriptor ---------------------------------------------------
+    def _build(self):
+        import ctypes as C
+        from . import _lib
+        b, w = self.batch, self.world
+        f = _lib.Frame()
+        keep = []                                           # ctypes objects the descriptor points into
+        f.entities = C.pointer(b._desc)
+        if b.tiled:
+            f.tile_row_start, f.n_tiles = b.tile_row_start.data_ptr(), b.n_tiles
+        else:
+            f.level_start, f.n_levels = b.level_start.ctypes.data, b.n_levels
+        f.frustum = C.pointer(self.frustum)
+        if w is not None:
+            f.bodies, f.world, f.bp = C.pointer(w._desc), C.pointer(w.world), w._bp
+            f.pairs, f.pair_capacity, f.pair_total = w.pairs.data_ptr(), w.capacity, w.pair_total.data_ptr()
+            if w.n_static:
+                f.static_pairs, f.static_pair_capacity = w.static_pairs.data_ptr(), w.static_capacity
+                f.static_pair_total = w.static_pair_total.data_ptr()
+            if self.contacts:
+                w.alloc_contacts()
+                g = w.body_geoms()
+                keep.append(g)
+                f.body_geoms = C.pointer(g)
+                f.contacts, f.contact_total = w.contact2_buf.data_ptr(), w.contact2_total.data_ptr()
+                if w.n_static:
+                    sg = w.static_geoms()
+                    keep.append(sg)
+                    f.static_geoms = C.pointer(sg)
+                    f.static_contacts = w.static_contact2_buf.data_ptr()
+                    f.static_contact_total = w.static_contact2_total.data_ptr()
+            if self.body_links is not None:
+                lb, le = w.upload_links(*self.body_links)
+                f.n_body_links, f.link_body, f.link_entity = len(self.body_links[0]), lb.data_ptr(), le.data_ptr()
+        if self.feed is not None:
+            f.characters = C.pointer(self.feed._desc)
+        vm = np.ascontiguousarray(self.view_mx, np.float32)
+        pm = np.ascontiguousarray(self.proj_mx, np.float32)
+        keep += [vm, pm]
+        f.view_mx = vm.ctypes.data_as(C.POINTER(C.c_float))
+        f.proj_mx = pm.ctypes.data_as(C.POINTER(C.c_float))
+        ls = self.lights
+        if ls is not None:
+            d = ls._desc()
+            keep.append(d)
+            f.lights = C.pointer(d)
+            if ls._carriers and ls._carriers[0]:
+                n, ce, cl, co = ls._carriers
+                f.n_light_carriers, f.carrier_entity, f.carrier_light, f.carrier_offset = n, ce.data_ptr(), cl.data_ptr(), co.data_ptr()
+            tiles = ls.alloc_tiles()
+            if tiles is not None:
+                f.light_width, f.light_height, f.light_cell, f.light_tiles = ls.width, ls.height, ls.cell, tiles.data_ptr()
+        cb = self.characters
+        if cb is not None:
+            if getattr(cb, "_clock", None) is None:
+                cb.start_clock()
+            f.anim_clock = C.pointer(cb._clock)
+            f.skeleton, f.animations = C.pointer(cb.model.skel_desc), C.pointer(cb.model.anim_desc)
+            f.pose = C.pointer(cb._pose_desc)
+            if cb._skin_desc is not None:
+                f.skin = C.pointer(cb._skin_desc)
+        if self.particles is not None:
+            f.particles = C.pointer(self.particles._desc)
+        b.alloc_lod()
+        f.index_base = 0
+        f.visible, f.visible_count, f.visible_scratch = b.visible.data_ptr(), b.visible_count.data_ptr(), b.scratch.data_ptr()
+        f.cam_pos[:] = [float(v) for v in self.cam["cam_pos"]]
+        f.force_lod = b.force_lod.data_ptr() if b.force_lod is not None else None
+        f.cur_lod, f.draw_lod = b.cur_lod.data_ptr(), b.draw_lod.data_ptr()
+        self._desc, self._keep = f, keep
+        return f
 
     def capture(self, dt=1.0 / 120.0, warmup_now=0.0):
         """Record one frame (with one physics substep, the current camera) as a HIP graph.  Afterwards
@@ -63,41 +134,13 @@ class FrameLoop:
         self._issue(now, steps)
 
     def _issue(self, now, steps):
-        b, w = self.batch, self.world
-        side = None
-        if self.overlap:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            side = self._side
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)                          # fork: everything of the previous frame is done
-            if self.particles is not None:                  # particles_update hooks: independent of the rest of the frame
-                with torch.cuda.stream(side):
-                    self.particles.particles_update(self.view_mx)
-        if w is not None:                                   # phys_step: per fixed substep broadphase, contacts, integrate
-            for _ in range(steps):
-                w.broadphase()
-                if self.contacts:
-                    w.contacts_geoms()
-                w.world_step(1.0 / 120.0)
-        if self.feed is not None:                           # character_update hooks
-            self.feed.character_update(b, w)
-        if w is not None:                                   # default_update: phys_body_update of dynamic bodies
-            w.phys_body_update(b)
-            if self.body_links is not None:                 # ... phys_body_rotate_xform for the rebuilt ones
-                w.rotate_from_entities(b, *self.body_links)
-        if self.lights is not None:                         # ... light_set_pos of light carriers
-            self.lights.from_entities(b)
-        b.mq_update(self.frustum)                           # TRS -> mx -> inverse -> AABB (+ main-view cull)
-        if self.characters is not None:                     # ... animated_update: clock, pose, palette
-            self.characters.animated_update(now)
-            if self.characters._skin_desc is not None:
-                self.characters.skin()                      # the vertex shader's skinning loop, once per frame
-        if self.particles is not None and side is None:     # particles_update hooks
-            self.particles.particles_update(self.view_mx)
-        if self.lights is not None:                         # scene_update: light_grid_compute
-            self.lights.grid_compute(self.view_mx, self.proj_mx)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)   # join
-        b.compact_visible()                                 # render pass: visible list + LOD pick
-        b.select_lod(self.cam["cam_pos"])
+        import ctypes as C
+        from . import _lib
+        f = self._desc or self._build()
+        if self.lights is not None:
+            self.lights._upload()                            # slot edits made on the host since the last frame
+        # graph capture: the clock comes from a device double written before every replay
+        f.now_dev = self.characters.now_dev.data_ptr() if (now is None and self.characters is not None) else None
+        rc = _lib.lib().clapgpu_frame_issue(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(f),
+                                            0.0 if now is None else float(now), int(steps))
+        _lib.check(rc, "clapgpu_frame_issue")

@@ -141,14 +141,20 @@ class LightSet:
             self.pos[:] = self._d["pos"].cpu().numpy()
         return self.pos.copy()
 
-    def grid_compute(self, view_mx, proj_mx):
-        """light_grid_compute: returns the device tile masks int32[theight][twidth][4] (RGBA32UI texels)."""
-        self._upload()
+    def alloc_tiles(self):
+        """light_grid_update's (re)allocation of the tile array: device int32[theight][twidth][4], or None for an empty grid."""
         tw, th = grid_dims(self.width, self.height, self.cell)
         if not tw or not th:
             return None
-        if self.tiles is None or self.tiles.shape[:2] != (th, tw):      # light_grid_update: reallocate on resize
+        if self.tiles is None or self.tiles.shape[:2] != (th, tw):
             self.tiles = torch.zeros((th, tw, 4), dtype=torch.int32, device=self.device)
+        return self.tiles
+
+    def grid_compute(self, view_mx, proj_mx):
+        """light_grid_compute: returns the device tile masks int32[theight][twidth][4] (RGBA32UI texels)."""
+        self._upload()
+        if self.alloc_tiles() is None:
+            return None
         desc = self._desc()
         vm = np.ascontiguousarray(view_mx, np.float32)
         pm = np.ascontiguousarray(proj_mx, np.float32)

@@ -130,15 +130,27 @@ class PhysWorld:
                                         _ptr(keep["length"]), _ptr(keep["kind"]), self.statics_ptr,
                                         _ptr(getattr(self, "static_material", None)))
 
-    def contacts_geoms(self, set_joint_flags=True):
-        """near_callback on both candidate lists of the last broadphase(): 160-byte records (clapgpu_contact2)."""
-        L = _lib.lib()
+    def alloc_contacts(self):
         if getattr(self, "contact2_buf", None) is None:
             self.contact2_buf = torch.zeros((self.capacity, 160), dtype=torch.uint8, device=self.device)
             self.contact2_total = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.static_contact2_buf = torch.zeros((self.static_capacity if self.n_static else 1, 160), dtype=torch.uint8,
                                                    device=self.device)
             self.static_contact2_total = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def upload_links(self, link_body, link_entity):
+        """Device copies of a (body, entity) link table, uploaded once per table."""
+        key = (id(link_body), id(link_entity))
+        if getattr(self, "_links_key", None) != key:
+            self._links_key = key
+            self._links = (torch.from_numpy(np.ascontiguousarray(link_body, np.uint32).view(np.int32)).to(self.device),
+                           torch.from_numpy(np.ascontiguousarray(link_entity, np.uint32).view(np.int32)).to(self.device))
+        return self._links
+
+    def contacts_geoms(self, set_joint_flags=True):
+        """near_callback on both candidate lists of the last broadphase(): 160-byte records (clapgpu_contact2)."""
+        L = _lib.lib()
+        self.alloc_contacts()
         g = self.body_geoms()
         fl = _ptr(self.bflags) if set_joint_flags else 0
         _lib.check(L.clapgpu_contacts_geoms(_stream(), C.byref(g), C.byref(g), _ptr(self.pairs), _ptr(self.pair_total),
@@ -178,12 +190,7 @@ class PhysWorld:
     def rotate_from_entities(self, entity_batch, link_body, link_entity, all_dirty=False):
         """phys_body_rotate_xform for the (body, entity) links whose entity default_update is about to
         rebuild (model.c:1680-1687); run before entity_batch.mq_update."""
-        key = (id(link_body), id(link_entity))
-        if getattr(self, "_links_key", None) != key:         # uploaded once per link table (also keeps graph capture clean)
-            self._links_key = key
-            self._links = (torch.from_numpy(np.ascontiguousarray(link_body, np.uint32).view(np.int32)).to(self.device),
-                           torch.from_numpy(np.ascontiguousarray(link_entity, np.uint32).view(np.int32)).to(self.device))
-        lb, le = self._links
+        lb, le = self.upload_links(link_body, link_entity)     # once per link table (also keeps graph capture clean)
         rc = _lib.lib().clapgpu_bodies_rotate_from_entities(_stream(), C.byref(self._desc), C.byref(entity_batch._desc),
                                                             _lib.UPDATE_ALL_DIRTY if all_dirty else 0, len(link_body),
                                                             _ptr(lb), _ptr(le))

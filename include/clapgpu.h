@@ -775,6 +775,57 @@ int clapgpu_lights_from_entities(void *stream, const clapgpu_entities *e, uint32
                                  const uint32_t *carrier_entity, const int32_t *carrier_light,
                                  const float *carrier_off, const clapgpu_lights *lights);
 
+/* ======================================================================== */
+/* One frame (core/clap.c:551-665)                                           */
+/* ======================================================================== */
+
+/*
+ * Everything clap_frame() does on the batched path, as one C call that issues the launches in the reference's
+ * order on `stream` -- phys_step's substeps (broadphase x2, contact records, world step), character hooks, body
+ * read-back + rotation push + light hand-off, the entity update with the main view's cull, animation clock + pose +
+ * skinning, particles, the light grid, the ordered visible list + LOD pick -- without reading anything back.
+ * Every pointer except `entities` may be NULL: that part of the frame is skipped.  The descriptor holds no state: a
+ * caller builds it once and reuses it; capturing the call in a HIP graph (now_dev for the clock) replays the frame
+ * with one launch.
+ */
+typedef struct clapgpu_frame {
+    /* entities: tile layout (tile_row_start, device) or level-major (level_start, host) */
+    const clapgpu_entities   *entities;
+    const uint32_t           *tile_row_start;  uint32_t n_tiles;
+    const uint32_t           *level_start;     uint32_t n_levels;
+    const clapgpu_frustum    *frustum;         /* main view: fused cull; NULL = no cull, no visible list */
+    /* physics (physics.c:746-812) */
+    const clapgpu_bodies     *bodies;
+    const clapgpu_world      *world;
+    clapgpu_bp               *bp;
+    uint32_t *pairs, pair_capacity, *pair_total;
+    uint32_t *static_pairs, static_pair_capacity, *static_pair_total;
+    const clapgpu_geoms      *body_geoms, *static_geoms;
+    clapgpu_contact2 *contacts, *static_contacts;
+    uint32_t *contact_total, *static_contact_total;
+    uint32_t n_body_links; const uint32_t *link_body, *link_entity;
+    /* character feeder (character.c:583-611) */
+    const clapgpu_characters *characters;
+    /* lights: hand-off from their carrier entities, then the tile masks */
+    const clapgpu_lights     *lights;
+    uint32_t n_light_carriers; const uint32_t *carrier_entity; const int32_t *carrier_light; const float *carrier_offset;
+    uint32_t light_width, light_height, light_cell; uint32_t *light_tiles;
+    const float              *view_mx, *proj_mx;     /* HOST, 16 floats each */
+    /* skeletal animation */
+    const clapgpu_anim_clock *anim_clock;      const double *now_dev;   /* device clock for graph replay, or NULL: `now` */
+    const clapgpu_skeleton   *skeleton;
+    const clapgpu_animations *animations;
+    const clapgpu_pose_batch *pose;
+    const clapgpu_skin_batch *skin;
+    /* particles */
+    const clapgpu_particles  *particles;
+    /* render-pass glue */
+    uint32_t index_base; uint32_t *visible, *visible_count; void *visible_scratch;
+    float cam_pos[3]; const int32_t *force_lod; int32_t *cur_lod, *draw_lod;
+} clapgpu_frame;
+
+int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double now, uint32_t physics_substeps);
+
 #ifdef __cplusplus
 }
 #endif

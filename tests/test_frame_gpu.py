@@ -150,7 +150,7 @@ def test_captured_frame_graph_replays_the_same_frames(cuda_device):
     import torch
     from clap_amd import animation, characters, entities, frame, lights, particles, physics, tiler
 
-    def build(overlap=False):
+    def build():
         raw = synth.entities_flat(3000, seed=5)
         scene, tl = tiler.tiled_scene(raw)
         roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
@@ -176,7 +176,7 @@ def test_captured_frame_graph_replays_the_same_frames(cuda_device):
         ppos, pvel, pst = ob.particles_spawn(ps, 0x1234ABCD330E)
         pb = particles.ParticleBatch(ps, ppos, pvel, pst, cuda_device)
         loop = frame.FrameLoop(batch, synth.camera(pos=(0, 10, 60)), world=world, feed=cf, lights=ls, characters=cb,
-                               particles=pb, contacts=True, overlap=overlap)
+                               particles=pb, contacts=True)
         return loop
 
     def state(loop):
@@ -188,7 +188,7 @@ def test_captured_frame_graph_replays_the_same_frames(cuda_device):
                     spairs=w["static_pairs"], tiles=loop.lights.download_tiles())
 
     # eager / graph: the default one-stream frame; forked: statics pass and particles on a side stream, issued and replayed
-    eager, graph, single = build(), build(), build(overlap=True)
+    eager, graph, single = build(), build(), build()
     dt = 1.0 / 120.0
     eager.clap_frame(dt, dt)                                # frame 1 on all (capture() issues its warm-up frame eagerly)
     single.clap_frame(dt, dt)
