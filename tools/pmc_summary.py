@@ -25,22 +25,30 @@ def mean_kib(path, needle, counter):
 
 def all_kernels(fetch_csv, write_csv, out):
     """Every clapgpu kernel of the two passes -> {kernel: corrected bytes per launch}."""
+    # bench.py launches most kernels at several sizes (BASELINE size, the testbed-sized frame, the drop-in scenes): only
+    # the dispatches with the kernel's LARGEST grid -- the BASELINE-size launches -- are averaged.
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path, counter in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter and "clapgpu" in r["Kernel_Name"]:
-                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][counter].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][counter].append(
+                    (int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
     kernels = {}
     for name, c in sorted(acc.items()):
         if not c["FETCH_SIZE"] or not c["WRITE_SIZE"]:
             continue
-        f_kib = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
-        w_kib = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
-        kernels[name] = dict(dispatches=len(c["FETCH_SIZE"]), FETCH_SIZE_mean_kib_raw=f_kib, WRITE_SIZE_mean_kib=w_kib,
+        grid = max(g for g, _ in c["FETCH_SIZE"])
+        fv = [v for g, v in c["FETCH_SIZE"] if g == grid]
+        wv = [v for g, v in c["WRITE_SIZE"] if g == grid]
+        if not wv:
+            continue
+        f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
+        kernels[name] = dict(dispatches=len(fv), dispatches_all_sizes=len(c["FETCH_SIZE"]), grid_size=grid,
+                             FETCH_SIZE_mean_kib_raw=f_kib, WRITE_SIZE_mean_kib=w_kib,
                              fetch_bytes_corrected_x2=f_kib * 2048, write_bytes=w_kib * 1024,
                              hbm_bytes_per_launch=f_kib * 2048 + w_kib * 1024)
     res = dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 10 "
-                    "--warmup 2`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
+                    "--warmup 2`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); per kernel, the dispatches with its largest grid (the BASELINE-size launches) only",
                kernels=kernels)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -15,11 +15,15 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$o
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed > "$out/bench_write.log" 2>&1
 f=$(find "$out/trace" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/kernel_stats.csv"
+# the headline kernel alone (no extras, no testbed frame, no drop-in scenes): every k_entities_tiles launch is BASELINE size
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_h" -- python3 "$R/bench.py" --steps 200 --warmup 20 --cpu-frames 0 --no-testbed --no-extras > "$out/bench_headline_under_rocprof.log" 2>&1
+f=$(find "$out/trace_h" -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" "$out/kernel_stats_headline.csv"
 fc=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
 wc=$(find "$out/write" -name '*counter_collection.csv' | head -1)
 if [ -n "$fc" ] && [ -n "$wc" ]; then
     python3 "$R/tools/pmc_summary.py" --all "$fc" "$wc" "$out/pmc_hbm_bytes.json" > /dev/null
     python3 "$R/tools/pmc_summary.py" "$fc" "$wc" k_entities_tiles "$out/entities_pmc.json" > /dev/null
 fi
-rm -rf "$out/trace" "$out/fetch" "$out/write"           # keep the summaries, not the per-dispatch dumps
+rm -rf "$out/trace" "$out/trace_h" "$out/fetch" "$out/write"           # keep the summaries, not the per-dispatch dumps
 ls -la "$out"; tail -c 600 "$out/bench_unprofiled.json"; echo; [ -f "$out/kernel_stats.csv" ] && cut -d, -f1-4 "$out/kernel_stats.csv" | cut -c1-110 | head -40
