@@ -188,6 +188,44 @@ def roof(alg_bytes, seconds, *kernels):
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_us": seconds * 1e6}
 
 
+def snapshot_characters(comps, raw, device, steps, warmup):
+    """--snapshot: pose + skinning of the snapshot's own skinned models (a scene loaded from scene.json + glTF by
+    clapgpu_load_scene carries them as model<k>.* and characters.*), one batch per model, timed like a step."""
+    import torch
+    from clap_amd import animation, snapshot
+    models = snapshot.skinned_models(comps)
+    chars = comps.get("characters")
+    if not models or chars is None or not len(chars["entity"]):
+        return None
+    out = []
+    for k, (sk, anims, mesh) in models.items():
+        ents = np.asarray(chars["entity"])[np.asarray(chars["model"]) == k]
+        if not len(ents) or not anims:
+            continue
+        n, J, V = len(ents), sk["nr_joints"], mesh["n_verts"]
+        mx = np.tile(np.eye(4, dtype=np.float32).reshape(16), (n, 1))
+        mx[:, 12:15] = raw["pos_scale"][ents, :3]
+        model = animation.SkinnedModel(sk, anims, mesh=mesh, bind=sk["bind"], device=device)
+        cb = animation.CharacterBatch(model, n, np.zeros((J, 10), np.float32), mx, vert_first=np.zeros(n, np.uint32),
+                                      vert_count=np.full(n, V, np.uint32))
+        cb.set_frame_times(np.linspace(0.0, float(anims[0]["time_end"]), n, dtype=np.float32))
+
+        def step():
+            cb.pose_update()
+            cb.skin()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out.append({"model": int(k), "characters": n, "joints": J, "vertices_per_character": V, "animations": len(anims),
+                    "us_per_step": dt * 1e6, "skinned_verts_per_s": n * V / dt})
+    return out
+
+
 def extras(device, testbed=True):
     """The other rows of the hot path at BASELINE configs[2] and configs[3] sizes, each as
     units/s plus the algorithmic-bytes roofline of its kernel (SURVEY.md 8d byte counts)."""
@@ -512,7 +550,12 @@ def main():
                              kernel=kernel, launches_per_step=launches,
                              per_launch_us=[float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]),
         }
-        if world == 1 and not args.no_extras:
+        if args.snapshot:
+            out["data"] = "snapshot"
+            extra = snapshot_characters(comps, raw, device, args.steps, args.warmup)
+            if extra:
+                out["extra"] = {"snapshot_characters": extra}
+        if world == 1 and not args.no_extras and not args.snapshot:
             del batch
             torch.cuda.empty_cache()
             out["extra"] = extras(device, testbed=not args.no_testbed)

@@ -240,6 +240,8 @@ SYMBOLS = {
     "clapgpu_exchange_destroy": (None, [C.c_void_p]),
     "clapgpu_exchange_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
+    "clapgpu_mat4_invert": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "clapgpu_mat4_from_quat": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "clapgpu_frame_issue": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_double, C.c_uint32]),
     "clapgpu_particles_update": (C.c_int, [C.c_void_p, C.POINTER(Particles), C.POINTER(C.c_float)]),
     "clapgpu_characters_update": (C.c_int, [C.c_void_p, C.POINTER(Characters), C.POINTER(Entities),
@@ -268,6 +270,13 @@ def lib():
             raise ClapGpuError(ERR_INIT_FAILED, "clap_amd",
                                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)")
+        # This harness shares device memory and streams with torch, and torch ships its own copy of the HIP / HSA runtime:
+        # whichever copy is loaded first serves the whole process, and a second HSA runtime finds no device ("no HIP
+        # device" from clapgpu_init).  Let torch load its copy before the library resolves libamdhip64.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)           # AttributeError if the .so does not export it

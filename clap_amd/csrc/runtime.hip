@@ -131,6 +131,23 @@ extern "C" void clapgpu_view_matrix(const float pos[3], const float quat[4], flo
     memcpy(view_mx, t, sizeof(t));
 }
 
+// linmath.h:611-651 / 959-987: the kernels' own arithmetic for host callers (the scene loader's bind = invert(invmx),
+// model.c:532; a skin's root pose, gltf.c:1246-1252)
+extern "C" void clapgpu_mat4_invert(const float m[16], float out[16])
+{
+    float a[16], t[16];
+    memcpy(a, m, sizeof(a));
+    lmd::invert(t, a);
+    memcpy(out, t, sizeof(t));
+}
+
+extern "C" void clapgpu_mat4_from_quat(const float quat_xyzw[4], float out[16])
+{
+    float t[16];
+    lmd::from_quat(t, quat_xyzw[0], quat_xyzw[1], quat_xyzw[2], quat_xyzw[3]);
+    memcpy(out, t, sizeof(t));
+}
+
 // linmath.h:709-734 (NDC z in [-1,1]) / 753-776 (NDC z in [0,1])
 extern "C" void clapgpu_perspective(float fov, float aspect, float n, float f,
                                     int ndc_z_zero_one, float proj_mx[16])

@@ -79,6 +79,9 @@ typedef struct clapgpu_frustum {
 
 /* transform.c:132-138 transform_view_mat4x4 (host, O(1) per frame) */
 void clapgpu_view_matrix(const float pos[3], const float quat[4], float view_mx[16]);
+/* linmath.h:611-651 mat4x4_invert, 959-987 mat4x4_from_quat (host; the arithmetic the kernels use) */
+void clapgpu_mat4_invert(const float m[16], float out[16]);
+void clapgpu_mat4_from_quat(const float quat_xyzw[4], float out[16]);
 /* linmath.h:709-776 mat4x4_perspective_ndc_z_{2,1} via render-common.c:77-82 (host) */
 void clapgpu_perspective(float fov, float aspect, float near_plane, float far_plane,
                          int ndc_z_zero_one, float proj_mx[16]);
