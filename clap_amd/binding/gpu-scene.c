@@ -7,8 +7,11 @@
  *      model.c:1911-1922); look every ALIVE entity up in a pointer -> record table;
  *   2. decide which entities are batched: hook == default_update, no skeleton animation
  *      (animated_update, model.c:1715-1716), no physics body (phys_body_update /
- *      phys_body_rotate_xform, model.c:1659-1687), no light (light_set_pos, model.c:1689-1694),
- *      no joint attachment, and a batched (or no) parent that comes EARLIER in the list;
+ *      phys_body_rotate_xform, model.c:1659-1687 -- ODE is an absent submodule of the reference, so nothing that
+ *      reads a dBody can be built into the checker), no joint attachment (it rides the palette of the SAME frame,
+ *      which gpu-anim.inc.c computes after this update), and a batched (or no) parent that comes EARLIER in the
+ *      list.  An entity that carries a light IS batched: step 5 hands its position on (light_set_pos,
+ *      model.c:1689-1694);
  *   3. mirror creations, deletions, e->parent, e->flags and -- where xform.updated is set --
  *      position / rotation / scale into libclapgpu_scene, clearing xform.updated as
  *      default_update does (model.c:1615, 1668);
@@ -97,6 +100,7 @@ struct gpu_scene {
     uint32_t        *slots; uint32_t cap_slots;                    /* scratch: rebuilt slots of the frame */
     uint32_t        n_batched;
     struct mq       *bound_mq; struct view *bound_view;
+    void            *hook_data;                                    /* mq->priv of the running gpu_mq_update(): what the hooks get as `data` */
     struct view     *culled_view;
     vec4            culled_planes[6];
     struct gpu_scene_stats stats;
@@ -228,8 +232,7 @@ static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
     return e->update == gs->default_hook &&
            (gs->anim_elsewhere || !entity_animated(e)) &&
            !(e->flags & (ENTITY3D_HAS_PHYSICS | ENTITY3D_IS_CHARACTER | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE)) &&
-           e->light_idx < 0 &&
-           e->parent_joint == JOINT_TYPE_MAX;
+           e->parent_joint == JOINT_TYPE_MAX;      /* light carriers are batched: scatter_one() hands the position on */
 }
 
 /* The record of r's parent, or NO_REC if the parent is not an ALIVE member of this queue. */
@@ -388,6 +391,18 @@ void gpu_scene_touch(struct gpu_scene *gs, entity3d *e)
  * gpu_mq_update() walks the queue once */
 void gpu_scene_topology(struct gpu_scene *gs) { if (gs) gs->topology_pending = true; }
 
+/* A rebuilt entity WITHOUT a parent hands its position to the light it carries (model.c:1687-1692).  At most LIGHTS_MAX
+ * entities do, each to its own slot, so this is safe from the scatter workers. */
+static inline void light_hand_off(struct gpu_scene *gs, entity3d *e)
+{
+    if (e->parent || e->light_idx < 0 || !gs->hook_data) return;
+    struct scene *scene = gs->hook_data;
+    vec3 pos;
+    transform_pos(&e->xform, pos);
+    vec3_add(pos, pos, e->light_off);
+    light_set_pos(&scene->light, e->light_idx, pos);
+}
+
 static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq)
 {
     entity3d *e = r->e, *parent = e->parent;
@@ -400,6 +415,7 @@ static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_sc
         memcpy(e->aabb, res->aabb + 6 * slot, sizeof(e->aabb));
         memcpy(e->aabb_center, res->aabb_center + 3 * slot, sizeof(vec3));
     }
+    light_hand_off(gs, e);
 }
 
 /*
@@ -697,6 +713,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     if (!gs || !mq) return _CERR_INVALID_ARGUMENTS;
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
+    gs->hook_data = mq->priv;
     memset(st, 0, sizeof(*st));
     gs->gen++;
     if (gs->notify && gs->walked && !gs->topology_pending) {
@@ -848,6 +865,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 memcpy(e->aabb, res.aabb + 6 * slot, sizeof(e->aabb));
                 memcpy(e->aabb_center, res.aabb_center + 3 * slot, sizeof(vec3));
             }
+            light_hand_off(gs, e);
             st->written_back++;
         }
         if (scene)

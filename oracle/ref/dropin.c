@@ -157,6 +157,7 @@ static void world_init(struct world *w, uint32_t cap)
         list_init(&w->txm[k].entities);
         list_append(&w->mq->txmodels, &w->txm[k].entry);
     }
+    bitmap_init(&w->scene->light.active, LIGHTS_MAX);            /* light_init (light.c:192-194) without the grid texture */
     w->e = calloc(cap, sizeof(*w->e));
 }
 
@@ -211,6 +212,8 @@ static void op_create(float spread, bool allow_hook)
         if (may_parent(p, id)) parent = p;
     }
     if (parent != NONE) { pos[0] = rndf(-2, 2); pos[1] = rndf(-2, 2); pos[2] = rndf(-2, 2); }
+    const bool carries = rndn(24) == 0;                            /* light carriers: batched; the binding hands the position on */
+    const vec3 loff = { rndf(-1, 1), rndf(0, 3), rndf(-1, 1) };
     for (int k = 0; k < 2; k++) {
         struct world *w = k ? &B : &A;
         entity3d *e = ref_new(entity3d, .txmodel = &w->txm[m->model]);
@@ -218,6 +221,10 @@ static void op_create(float spread, bool allow_hook)
         else   { ref_entity3d_position(e, pos); ref_entity3d_rotate(e, rx, ry, rz); ref_entity3d_scale(e, sc); }
         if (parent != NONE) e->parent = w->e[parent];
         if (m->hooked) e->update = wobble_update;
+        if (carries) {                                               /* scene.c:1587-1632: the entity carries a light */
+            cres(int) li = light_get(&w->scene->light);
+            if (!IS_CERR(li)) { e->light_idx = li.val; e->light = &w->scene->light; memcpy(e->light_off, loff, sizeof(loff)); }
+        }
         if (k) gpu_scene_topology(gpu_scene_bound());              /* what entity3d_make does under CONFIG_GPU_SCENE */
         w->e[id] = e;
     }
@@ -309,6 +316,20 @@ static uint64_t compare_frame(struct gpu_scene *gs, uint32_t frame, uint64_t *n_
     }
     if (ia != ib || (bva && memcmp(&A.scene->camera->bv_volume, &B.scene->camera->bv_volume, 4))) {
         fprintf(stderr, "frame %u: bounding-volume pick %d vs %d\n", frame, (int)ia, (int)ib);
+        bad++;
+    }
+    /* the lights the entities carry: default_update's hand-off (model.c:1687-1692) against the binding's */
+    if (memcmp(A.scene->light.pos, B.scene->light.pos, sizeof(A.scene->light.pos)) || A.scene->light.nr_lights != B.scene->light.nr_lights) {
+        fprintf(stderr, "frame %u: carried light positions differ\n", frame);
+        for (uint32_t id = 0; id < n_ids && bad < 8; id++) {
+            if (!meta[id].alive || A.e[id]->light_idx < 0) continue;
+            const int li = A.e[id]->light_idx;
+            if (li != B.e[id]->light_idx || memcmp(&A.scene->light.pos[3 * li], &B.scene->light.pos[3 * li], 12))
+                fprintf(stderr, "  entity %u (parent %d hooked %u batched %d): light %d / %d at (%g %g %g) vs (%g %g %g)\n", id, (int)meta[id].parent,
+                        meta[id].hooked, (int)gpu_scene_entity_is_batched(gs, B.e[id]), li, B.e[id]->light_idx,
+                        A.scene->light.pos[3 * li], A.scene->light.pos[3 * li + 1], A.scene->light.pos[3 * li + 2],
+                        B.scene->light.pos[3 * li], B.scene->light.pos[3 * li + 1], B.scene->light.pos[3 * li + 2]);
+        }
         bad++;
     }
     return bad;
