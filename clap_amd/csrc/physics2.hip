@@ -217,8 +217,8 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
 // cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge), so no cell
 // coordinates need to be stored with the entries.
 constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
-constexpr int BP_GROUP = 8;            // lanes per body in the search
-constexpr int BP_WORK = 64;            // candidate entries listed per body and round
+constexpr int BP_TILE = 16;            // bodies per wavefront of the search
+constexpr int BP_WORK = 512;           // candidate entries listed per tile and round
 constexpr int BP_EMIT_TILE = 256;      // bodies per tile of the pair-offset scan (= emit block)
 constexpr int CTRL_STATUS = 2, CTRL_TICKET_CELLS = 8, CTRL_TICKET_SEARCH = 80;   // tickets: 65 words each
 static_assert(BP_EMIT_TILE == PB, "k_bp_tiles sums one emit tile per workgroup");
@@ -242,7 +242,7 @@ __host__ __device__ __forceinline__ uint32_t cell_slot(int32_t cx, int32_t cy, i
     return block_hash(cx >> 2, cy >> 2, cz >> 2, mask) << 6 | (uint32_t)(cx & 3) | (uint32_t)(cy & 3) << 2 | (uint32_t)(cz & 3) << 4;
 }
 
-struct BpRec { double bb[6]; uint32_t idx, pad[3]; };            // 64 bytes
+struct BpRec { double bb[6]; uint32_t idx; int32_t cell[3]; };    // 64 bytes; cell = the box centre's cell (dynamic records)
 
 struct BpK {
     uint32_t n;
@@ -268,6 +268,8 @@ struct BpK {
     const uint32_t *s_entries;
     const double *s_aabb;
     const uint32_t *s_large;
+    const struct BpRec *s_recs;          // s_entries with their boxes (what the search gathers)
+    const struct BpRec *s_lrecs;         // the large statics with their boxes
     uint32_t n_large, n_static;
     // outputs
     uint32_t *pairs, capacity, *pair_total;
@@ -430,141 +432,204 @@ void k_bp_scatter(BpK k)
     k.entries[at] = i;
     const double2 *p = reinterpret_cast<const double2 *>(k.aabb + 6 * (size_t)i);
     double2 *o = reinterpret_cast<double2 *>(k.recs + at);
-    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
-    o[3] = make_double2(__longlong_as_double((long long)i), 0.0);
+    const double2 b0 = p[0], b1 = p[1], b2 = p[2];
+    o[0] = b0; o[1] = b1; o[2] = b2;
+    // the cell coordinates travel with the record: the search would otherwise redo three fp64 divisions per body
+    const int32_t cx = cell_coord((b0.x + b0.y) * 0.5, k.cell), cy = cell_coord((b1.x + b1.y) * 0.5, k.cell),
+                  cz = cell_coord((b2.x + b2.y) * 0.5, k.cell);
+    reinterpret_cast<int4 *>(o)[3] = make_int4((int)i, cx, cy, cz);
 }
 
-// Launch 4 (see the section comment)
+// Launch 4.  One wavefront per tile of BP_TILE bodies that are neighbours in cell order.  Bodies of one cell have the
+// same 14 candidate cells, so the tile's candidates are listed per DISTINCT cell ("leader": the first body of each run
+// of equal cell coordinates), each entry with the range of tile bodies it has to be tested against: a candidate record is
+// gathered once per cell, not once per body, and the tile's own boxes are read back from LDS as broadcasts.  The
+// statics registered for a block are listed the same way, once per distinct block bucket.  Steps that depend on memory:
+// tile records (+ the large statics' records) -> cell / static ranges (up to four per lane, loaded together) -> the work
+// list in LDS -> candidate records, two per lane and round -> hit atomics.  Hits on bodies go to the partner list of
+// min(i, j) (global atomics); static hits count in LDS, because only this wavefront writes its bodies' static lists.
 __global__ __launch_bounds__(PB)
 void k_bp_search(BpK k)
 {
-    constexpr int G = BP_GROUP, GROUPS = PB / G, NCELL = 14, CPL = (NCELL + G - 1) / G;
-    constexpr uint32_t WL = BP_WORK;
+    constexpr int WAVES = PB / WAVE, T = BP_TILE, LOOKUPS = 4;          // lookups per lane: T * 14 + T <= 64 * LOOKUPS
+    constexpr uint32_t WL = BP_WORK, OWN = 0x80000000u, STAT = 0x40000000u, IDX = 0x3fffffffu;
     constexpr int LARGE_TILE = 128;                                     // large statics staged per round
-    __shared__ uint32_t work[GROUPS][WL];
-    __shared__ double large_box[LARGE_TILE][6];
-    __shared__ uint32_t large_idx[LARGE_TILE];
-    const int grp = threadIdx.x / G, q = threadIdx.x % G;
-    const uint32_t t = blockIdx.x * GROUPS + grp;                      // neighbouring groups walk neighbouring cells
-    const bool body = t < k.n;
+    constexpr uint32_t HITS = 128;                                      // body x body hits parked per round
+    static_assert(T * 15 <= WAVE * LOOKUPS && T <= 16, "tile lookups");
+    __shared__ __attribute__((aligned(8))) uint32_t work[WAVES][WL][2];  // (record | flags, a_lo | a_hi << 8)
+    __shared__ double abox[WAVES][T][6];
+    __shared__ uint32_t aidx[WAVES][T];
+    __shared__ int32_t lead[WAVES][2 * T][4];                           // cell leaders: (cx, cy, cz, range); then block leaders: (bucket, -, -, range)
+    __shared__ uint32_t shits[WAVES][T];
+    __shared__ uint32_t hits[WAVES][HITS][2], nhits[WAVES];
+    __shared__ BpRec large[LARGE_TILE];
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const uint32_t t0 = (blockIdx.x * WAVES + wave) * T;
+    const uint32_t nA = t0 < k.n ? (k.n - t0 < (uint32_t)T ? k.n - t0 : (uint32_t)T) : 0;
+    const bool statics = k.n_static != 0;
 
-    double a[6] = { 0, 0, 0, 0, 0, 0 };
-    uint32_t b0[CPL], len[CPL], i = 0, mylen = 0, own_block = 0;
+    const uint32_t m0 = statics ? (k.n_large < LARGE_TILE ? k.n_large : LARGE_TILE) : 0;
+    if (threadIdx.x < m0) large[threadIdx.x] = k.s_lrecs[threadIdx.x];  // issued with the tile's own records: no extra step
+    // ---- the tile's bodies, cell leaders and block leaders
+    int32_t cx = 0, cy = 0, cz = 0;
+    uint32_t ob = 0;
+    const bool isA = (uint32_t)lane < nA;
+    if (isA) {
+        const BpRec me = k.recs[t0 + lane];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) { b0[c] = 0; len[c] = 0; }
-    if (body) {
-        const BpRec me = k.recs[t];
-        i = me.idx;
-#pragma unroll
-        for (int x = 0; x < 6; x++) a[x] = me.bb[x];
-        int32_t cx, cy, cz;
-        box_cell(a, k.cell, cx, cy, cz);
-        own_block = block_hash(cx >> 2, cy >> 2, cz >> 2, k.mask);
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int cq = 13 + q + c * G;                              // 13 = own cell, 14..26 = the cells after it
-            if (cq < 27) {
-                const uint32_t slot = cell_slot(cx - 1 + cq % 3, cy - 1 + (cq / 3) % 3, cz - 1 + cq / 9, k.mask);
-                b0[c] = k.block_start[slot >> 6] + k.cell_prefix[slot];
-                len[c] = k.cell_len[slot];
-                mylen += len[c];
-            }
+        for (int x = 0; x < 6; x++) abox[wave][lane][x] = me.bb[x];
+        aidx[wave][lane] = me.idx;
+        cx = me.cell[0]; cy = me.cell[1]; cz = me.cell[2];
+        ob = block_hash(cx >> 2, cy >> 2, cz >> 2, k.mask);
+    }
+    if (lane < T) shits[wave][lane] = 0;
+    if (lane == 0) nhits[wave] = 0;
+    const int32_t px = __shfl_up(cx, 1), py = __shfl_up(cy, 1), pz = __shfl_up(cz, 1);
+    const uint32_t pob = __shfl_up(ob, 1);
+    const bool cell_leader = isA && (lane == 0 || px != cx || py != cy || pz != cz);
+    const bool block_leader = isA && statics && (lane == 0 || pob != ob);
+    const uint32_t cmask = (uint32_t)__ballot(cell_leader), bmask = (uint32_t)__ballot(block_leader);
+    const uint32_t n_lead = __popc(cmask), n_blead = __popc(bmask);
+    if (isA) {
+        const uint32_t below = (1u << lane) - 1u;
+        if (cell_leader) {
+            const uint32_t above = cmask >> (lane + 1);
+            const uint32_t hi = above ? lane + 1 + __builtin_ctz(above) : nA;
+            int32_t *d = lead[wave][__popc(cmask & below)];
+            d[0] = cx; d[1] = cy; d[2] = cz; d[3] = (int32_t)((uint32_t)lane | hi << 8);
+        }
+        if (block_leader) {
+            const uint32_t above = bmask >> (lane + 1);
+            const uint32_t hi = above ? lane + 1 + __builtin_ctz(above) : nA;
+            int32_t *d = lead[wave][T + __popc(bmask & below)];
+            d[0] = (int32_t)ob; d[3] = (int32_t)((uint32_t)lane | hi << 8);
         }
     }
-    // this lane's first entry in the group's candidate sequence, and the sequence's length
+    wave_lds_fence();
+    // ---- candidate runs: (leader, cell) and (block leader) lookups, up to four per lane, loads in flight together
+    const uint32_t n_cell_runs = n_lead * 14u, n_runs = n_cell_runs + n_blead;
+    uint32_t b0[LOOKUPS], len[LOOKUPS], rng[LOOKUPS], mylen = 0;
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) {
+        const uint32_t u = lane + WAVE * r;
+        b0[r] = 0; len[r] = 0; rng[r] = 0;
+        if (u < n_cell_runs) {
+            const uint32_t l = u / 14u, cq = 13u + u % 14u;             // 13 = own cell, 14..26 = the cells after it
+            const int32_t *d = lead[wave][l];
+            const uint32_t slot = cell_slot(d[0] - 1 + (int32_t)(cq % 3), d[1] - 1 + (int32_t)((cq / 3) % 3), d[2] - 1 + (int32_t)(cq / 9), k.mask);
+            b0[r] = (k.block_start[slot >> 6] + k.cell_prefix[slot]) | (cq == 13u ? OWN : 0u);
+            len[r] = k.cell_len[slot];
+            rng[r] = (uint32_t)d[3];
+        } else if (u < n_runs) {
+            const int32_t *d = lead[wave][T + (u - n_cell_runs)];
+            const uint32_t s0 = k.s_start[d[0]];
+            b0[r] = s0 | STAT;
+            len[r] = k.s_start[d[0] + 1] - s0;
+            rng[r] = (uint32_t)d[3];
+        }
+        mylen += len[r];
+    }
     uint32_t incl = mylen;
 #pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, G);
-        if (q >= d) incl += up;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
-    const uint32_t total = __shfl(incl, G - 1, G);
+    const uint32_t total = __shfl(incl, WAVE - 1);
     const uint32_t first = incl - mylen;
 
-    for (uint32_t base = 0; __any(base < total); base += WL) {          // one round unless > WL candidates
+    // A hit on another body needs one returning atomic on the partner count of min(i, j), ~2 us under load: hits are
+    // parked in LDS while the candidates are tested and their atomics issued together once per round.
+    auto flush_hits = [&]() {
+        wave_lds_fence();
+        const uint32_t nh = nhits[wave] < HITS ? nhits[wave] : HITS;
+        for (uint32_t h = lane; h < nh; h += WAVE) {
+            const uint32_t lo = hits[wave][h][0], hi = hits[wave][h][1];
+            const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
+            if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+        }
+        wave_lds_fence();
+        if (lane == 0) nhits[wave] = 0;
+        wave_lds_fence();
+    };
+    auto test = [&](uint32_t w, uint32_t range, const BpRec &r) {
+        const uint32_t j = r.idx, a_hi = range >> 8;
+        for (uint32_t x = range & 0xffu; x < a_hi; x++) {
+            const double2 *ab = reinterpret_cast<const double2 *>(abox[wave][x]);
+            const double2 a01 = ab[0], a23 = ab[1], a45 = ab[2];         // all six before any compare: one LDS wait per body
+            const bool apart = (a01.x > r.bb[1]) | (a01.y < r.bb[0]) | (a23.x > r.bb[3]) | (a23.y < r.bb[2]) |
+                               (a45.x > r.bb[5]) | (a45.y < r.bb[4]);
+            if (apart) continue;
+            const uint32_t i = aidx[wave][x];
+            if (w & STAT) {
+                const uint32_t at = atomicAdd(&shits[wave][x], 1u);
+                if (at < BP_LIST) k.spartners[(size_t)i * BP_LIST + at] = j;
+            } else if (j != i && (!(w & OWN) || j > i)) {
+                const uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
+                const uint32_t h = atomicAdd(&nhits[wave], 1u);
+                if (h < HITS) { hits[wave][h][0] = lo; hits[wave][h][1] = hi; }
+                else {                                                   // list full (a pile-up): straight to memory
+                    const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
+                    if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+                }
+            }
+        }
+    };
+
+    for (uint32_t base = 0; base < total; base += WL) {                 // one round unless > WL candidates (total is wave-uniform)
         uint32_t off = first;
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const uint32_t own = (c == 0 && q == 0) ? 0x80000000u : 0u; // the run listed for the body's own cell
-            for (uint32_t e = 0; __any(e < len[c]); e++) {
-                if (e < len[c]) {
+        for (int r = 0; r < LOOKUPS; r++) {
+            for (uint32_t e = 0; __any(e < len[r]); e++) {
+                if (e < len[r]) {
                     const uint32_t o = off + e - base;                  // wraps below base: then >= WL
-                    if (o < WL) work[grp][o] = (b0[c] + e) | own;
+                    if (o < WL) *reinterpret_cast<uint2 *>(work[wave][o]) = make_uint2(b0[r] + e, rng[r]);
                 }
             }
-            off += len[c];
+            off += len[r];
         }
         wave_lds_fence();
-        const uint32_t todo = total > base ? (total - base < WL ? total - base : WL) : 0;
-        for (uint32_t e = q; __any(e < todo); e += G) {
-            if (e < todo) {
-                const uint32_t w = work[grp][e];
-                const BpRec r = k.recs[w & 0x7fffffffu];
-                const uint32_t j = r.idx;
-                if (j != i && (!(w >> 31) || j > i)) {
-                    if (boxes_overlap(a, r.bb)) {
-                        const uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
-                        const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
-                        if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
-                    }
+        const uint32_t todo = total - base < WL ? total - base : WL;
+        for (uint32_t e = lane; e < todo + lane; e += 2 * WAVE) {       // wave-uniform trip count; two records in flight per lane
+            const bool v0 = e < todo, v1 = e + WAVE < todo;
+            const uint2 e0 = v0 ? *reinterpret_cast<const uint2 *>(work[wave][e]) : make_uint2(0u, 0u);
+            const uint2 e1 = v1 ? *reinterpret_cast<const uint2 *>(work[wave][e + WAVE]) : make_uint2(0u, 0u);
+            const uint32_t w0 = e0.x, g0 = e0.y, w1 = e1.x, g1 = e1.y;
+            BpRec r0, r1;
+            if (v0) r0 = ((w0 & STAT) ? k.s_recs : k.recs)[w0 & IDX];
+            if (v1) r1 = ((w1 & STAT) ? k.s_recs : k.recs)[w1 & IDX];
+            if (v0) test(w0, g0, r0);
+            if (v1) test(w1, g1, r1);
+        }
+        flush_hits();
+    }
+    if (!statics) return;
+    // ---- the large statics (tested by every body), staged through LDS for the whole workgroup
+    for (uint32_t base = 0; base < k.n_large; base += LARGE_TILE) {
+        const uint32_t m = k.n_large - base < LARGE_TILE ? k.n_large - base : LARGE_TILE;
+        if (base) {
+            __syncthreads();
+            if (threadIdx.x < m) large[threadIdx.x] = k.s_lrecs[base + threadIdx.x];
+        }
+        __syncthreads();
+        const uint32_t x = lane % T;                                    // tile body of this lane; the large list is strided by WAVE / T
+        if (x < nA) {
+            double a[6];
+#pragma unroll
+            for (int y = 0; y < 6; y++) a[y] = abox[wave][x][y];
+            for (uint32_t e = lane / T; e < m; e += WAVE / T) {
+                double bs[6];
+#pragma unroll
+                for (int y = 0; y < 6; y++) bs[y] = large[e].bb[y];
+                if (boxes_overlap(a, bs)) {
+                    const uint32_t at = atomicAdd(&shits[wave][x], 1u);
+                    if (at < BP_LIST) k.spartners[(size_t)aidx[wave][x] * BP_LIST + at] = large[e].idx;
                 }
             }
         }
-        wave_lds_fence();
     }
-    // statics x this body: the statics registered for its block (the group's lanes take turns), then the large ones,
-    // staged through LDS for the whole workgroup
-    if (k.n_static) {
-        uint32_t s0 = 0, s1 = 0;
-        if (body) { s0 = k.s_start[own_block]; s1 = k.s_start[own_block + 1]; }
-        const uint32_t nloc = body ? s1 - s0 : 0;
-        uint32_t hits = 0;                                               // of the whole group so far (same in its 8 lanes)
-        const int gshift = (lane_id() / G) * G;
-        // a hit's slot in the body's list: hits so far + hits of the lower lanes of the group in this round (no atomics)
-        auto record = [&](bool hit, uint32_t sidx) {
-            const uint32_t m = (uint32_t)(__ballot(hit) >> gshift) & ((1u << G) - 1u);
-            if (hit) {
-                const uint32_t at = hits + __popc(m & ((1u << q) - 1u));
-                if (at < BP_LIST) k.spartners[(size_t)i * BP_LIST + at] = sidx;
-            }
-            hits += __popc(m);
-        };
-        for (uint32_t e = q; __any(e < nloc); e += G) {
-            bool hit = false;
-            uint32_t sidx = 0;
-            if (e < nloc) {
-                sidx = k.s_entries[s0 + e];
-                double bs[6];
-                load_box(k.s_aabb, sidx, bs);
-                hit = boxes_overlap(a, bs);
-            }
-            record(hit, sidx);
-        }
-        for (uint32_t base = 0; base < k.n_large; base += LARGE_TILE) {
-            const uint32_t m = k.n_large - base < LARGE_TILE ? k.n_large - base : LARGE_TILE;
-            __syncthreads();
-            for (uint32_t x = threadIdx.x; x < m; x += PB) {
-                const uint32_t sidx = k.s_large[base + x];
-                large_idx[x] = sidx;
-                double bs[6];
-                load_box(k.s_aabb, sidx, bs);
-#pragma unroll
-                for (int y = 0; y < 6; y++) large_box[x][y] = bs[y];
-            }
-            __syncthreads();
-            for (uint32_t e = q; e < m + q; e += G) {                    // uniform trip count: every lane takes part in the ballot
-                bool hit = false;
-                if (body && e < m) {
-                    double bs[6];
-#pragma unroll
-                    for (int y = 0; y < 6; y++) bs[y] = large_box[e][y];
-                    hit = boxes_overlap(a, bs);
-                }
-                record(hit, e < m ? large_idx[e] : 0);
-            }
-        }
-        if (body && q == 0) k.scnt[i] = hits;
-    }
+    wave_lds_fence();
+    if (isA) k.scnt[aidx[wave][lane]] = shits[wave][lane];
 }
 
 // Launch 5: partner counts per tile of 256 bodies (both lists); the workgroup that finishes last scans them into tile
@@ -1102,7 +1167,16 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
         for (auto &e : ins) s_entries[cur[e.first]++] = e.second;                 // ascending static index inside a bucket
     }
     bp->n_large = (uint32_t)s_large.size();
-    if (s_large.empty()) s_large.push_back(0);
+    std::vector<BpRec> s_recs(s_entries.size()), s_lrecs(s_large.size() ? s_large.size() : 1);
+    auto fill_rec = [&](BpRec &r, uint32_t sidx) {
+        memset(&r, 0, sizeof(r));
+        if (n_static) memcpy(r.bb, static_aabb + 6 * (size_t)sidx, sizeof(r.bb));
+        r.idx = sidx;
+    };
+    for (size_t e = 0; e < ins.size(); e++) fill_rec(s_recs[e], s_entries[e]);
+    for (size_t e = 0; e < s_large.size(); e++) fill_rec(s_lrecs[e], s_large[e]);
+    if (ins.empty()) memset(&s_recs[0], 0, sizeof(BpRec));
+    if (s_large.empty()) { memset(&s_lrecs[0], 0, sizeof(BpRec)); s_large.push_back(0); }
 
     // one device allocation, carved
     size_t off = 0;
@@ -1117,6 +1191,7 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     const size_t o_ctrl = take(4 * 160);
     const size_t o_sstart = take(4 * ((size_t)nb + 1)), o_sent = take(4 * s_entries.size()), o_slarge = take(4 * s_large.size());
     const size_t o_saabb = take(48 * (size_t)(n_static ? n_static : 1));
+    const size_t o_srecs = take(sizeof(BpRec) * s_recs.size()), o_slrecs = take(sizeof(BpRec) * s_lrecs.size());
     const size_t fixed = off;
     if (hipMalloc(&bp->dev, fixed) != hipSuccess) {
         (void)hipGetLastError();
@@ -1128,6 +1203,8 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
         hipMemcpy(d + o_sstart, s_count.data(), 4 * ((size_t)nb + 1), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + o_sent, s_entries.data(), 4 * s_entries.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + o_slarge, s_large.data(), 4 * s_large.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + o_srecs, s_recs.data(), sizeof(BpRec) * s_recs.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + o_slrecs, s_lrecs.data(), sizeof(BpRec) * s_lrecs.size(), hipMemcpyHostToDevice) != hipSuccess ||
         (n_static && hipMemcpy(d + o_saabb, static_aabb, 48 * (size_t)n_static, hipMemcpyHostToDevice) != hipSuccess)) {
         (void)hipGetLastError();
         (void)hipFree(bp->dev);
@@ -1149,6 +1226,7 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     k.ctrl = reinterpret_cast<uint32_t *>(d + o_ctrl);
     k.s_start = reinterpret_cast<const uint32_t *>(d + o_sstart); k.s_entries = reinterpret_cast<const uint32_t *>(d + o_sent);
     k.s_large = reinterpret_cast<const uint32_t *>(d + o_slarge); k.s_aabb = reinterpret_cast<const double *>(d + o_saabb);
+    k.s_recs = reinterpret_cast<const BpRec *>(d + o_srecs); k.s_lrecs = reinterpret_cast<const BpRec *>(d + o_slrecs);
     k.n_large = bp->n_large; k.n_static = n_static;
     *out = bp;
     return CLAPGPU_OK;
@@ -1188,7 +1266,7 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
     CLAPGPU_LAUNCH_CHECK("k_bp_cells");
     hipLaunchKernelGGL(k_bp_scatter, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
-    hipLaunchKernelGGL(k_bp_search, dim3((n + PB / BP_GROUP - 1) / (PB / BP_GROUP)), dim3(PB), 0, s, k);
+    hipLaunchKernelGGL(k_bp_search, dim3((n + (PB / WAVE) * BP_TILE - 1) / ((PB / WAVE) * BP_TILE)), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_search");
     hipLaunchKernelGGL(k_bp_tiles, dim3(k.n_tiles), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_tiles");

@@ -2,7 +2,7 @@ import sys, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from clap_amd import _lib, physics, synth
 _lib.check(_lib.lib().clapgpu_init(0),"init")
-for kind in ("spheres","capsules"):
+for kind in (sys.argv[1:] or ("spheres","capsules")):
     b = synth.sphere_bodies(262_144, box=64.0, seed=4) if kind=="spheres" else synth.capsule_bodies(262_144, box=60.0, seed=4)
     pw = physics.PhysWorld(b, synth.static_boxes(64, 64.0 if kind=="spheres" else 60.0), pair_capacity=2_000_000, device="cuda:0")
     def t(fn, it=30):
