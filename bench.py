@@ -156,6 +156,20 @@ def time_launches(fn, iters, warmup=10):
     return float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
 
 
+_SPAWNED = {}
+
+
+def spawn_cached(ps, state):
+    """synth.particles_spawn (the harness's own host-side spawn), once per particle-system table."""
+    from clap_amd import synth
+    key = (ps["sys"].tobytes(), int(state))
+    if key not in _SPAWNED:
+        _SPAWNED.clear()
+        _SPAWNED[key] = synth.particles_spawn(ps, state)
+    pos, vel, st = _SPAWNED[key]
+    return pos.copy(), vel.copy(), st
+
+
 def pmc_kernel_traffic(*names):
     """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) of the named kernels from the
     newest committed summary profiles/<round>_*/pmc_hbm_bytes.json (tools/profile_round.sh), or None."""
@@ -231,7 +245,6 @@ def extras(device, testbed=True):
     units/s plus the algorithmic-bytes roofline of its kernel (SURVEY.md 8d byte counts)."""
     import torch
     from clap_amd import animation, particles, physics, synth
-    from oracle import binding as ob          # cpu side only: bind = invert(invmx) and the initial spawn
     out = {}
 
     # ---- configs[2]: 50k characters x 64 joints, 10M vertices (one 200-vertex mesh per character) ----
@@ -249,6 +262,15 @@ def extras(device, testbed=True):
     t_skin = time_launches(cb.skin, 20)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
                            "kernel": "k_pose<64>", "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<")}
+    # what a frame whose skinning runs on the device needs from the pose: the palette alone.  The joints' T/R/S and
+    # world positions (56 B of the 120 B a joint writes) are host-visible state of animated_update; a caller that does
+    # not read them back switches them off (clapgpu_pose_batch.skip)
+    cb.set_outputs(trs=False, joint_pos=False)
+    t_pal = time_launches(cb.pose_update, 20)
+    cb.set_outputs(trs=True, joint_pos=True)
+    out["pose_palette"]["palette_only"] = {"us": t_pal * 1e6, "joints_per_s": n_chars * J / t_pal,
+                                           "bytes_written_per_joint": 64,
+                                           "note": "CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS"}
     out["skinning"] = {"skinned_verts_per_s": n_chars * vpc / t_skin, "vertices": n_chars * vpc,
                        "kernel": "k_skin", "roofline": roof(cb.skin_algorithmic_bytes(), t_skin, "k_skin"),
                        "mesh": "one distinct 200-vertex mesh per character (44 B/vertex read from HBM); instanced "
@@ -259,7 +281,7 @@ def extras(device, testbed=True):
 
     # ---- configs[3], particle half: 4096 systems x 1024 particles ----
     ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
-    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
     view = np.eye(4, dtype=np.float32).ravel()
     t_part = time_launches(lambda: pb.particles_update(view), 30)
@@ -286,7 +308,8 @@ def extras(device, testbed=True):
     from clap_amd import lights as gl
     ls = gl.LightSet(device, 3840, 2160, gl.TILE_WIDTH)
     ls.load(synth.lights(128, seed=7))
-    _fr, vm, pm = ob.frustum_from_camera(synth.camera(pos=(1.0, 2.0, 3.0)))
+    from clap_amd import entities as _ent
+    _fr, vm, pm = _ent.view_calc_frustum(synth.camera(pos=(1.0, 2.0, 3.0)))
     t_lg = time_launches(lambda: ls.grid_compute(vm, pm), 30)
     tw, th = gl.grid_dims(3840, 2160, gl.TILE_WIDTH)
     out["light_grid"] = {"tiles_per_s": tw * th / t_lg, "tiles": tw * th, "lights": 128, "us": t_lg * 1e6,
@@ -305,7 +328,6 @@ def testbed_frame(device):
     replayed as a captured HIP graph.  This regime is launch latency, not bytes."""
     import torch
     from clap_amd import animation, characters, entities, frame, lights, particles, physics, synth, tiler
-    from oracle import binding as ob          # cpu side only: the initial particle spawn
     raw = synth.entities_flat(10_000, seed=1234)
     scene, tl = tiler.tiled_scene(raw)
     roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
@@ -334,7 +356,7 @@ def testbed_frame(device):
                                   vert_first=np.zeros(n_chars, np.uint32), vert_count=np.full(n_chars, vpc, np.uint32))
     cb.start_clock(ani_time=-ch["phase"].astype(np.float64), speed=np.ones(n_chars, np.float32))
     ps = synth.particle_systems(n_sys=8, count=1024, radius=10.0, velocity=0.005)
-    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
     loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True)
     now = [0.0]
@@ -366,7 +388,6 @@ def full_frame(device):
     (broadphase x2, contacts, integrate, read-back into 75k entities) and 4M particles, 128 lights."""
     import torch
     from clap_amd import animation, characters, entities, frame, lights, particles, physics, synth, tiler
-    from oracle import binding as ob          # cpu side only: bind matrices and the initial particle spawn
     raw = synth.entities_chains(125_000, 8, seed=2)
     scene, tl = tiler.tiled_scene(raw)
     roots = tl["slot_of"][np.flatnonzero(raw["parent"] < 0)]
@@ -392,7 +413,7 @@ def full_frame(device):
                                   vert_count=np.full(n_chars, vpc, np.uint32))
     cb.start_clock(ani_time=-ch["phase"].astype(np.float64), speed=np.ones(n_chars, np.float32))
     ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
-    pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+    pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
     loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True)
     now = [0.0]
@@ -460,11 +481,10 @@ def main():
     pbatch = None
     if args.particles > 0:                                   # particle systems shard by whole system (own RNG stream per rank)
         from clap_amd import particles as particles_mod
-        from oracle import binding as ob_spawn                # cpu side only: the initial spawn
         n_sys = max(1, args.particles // 1024)
         ps = synth.particle_systems(n_sys=n_sys, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT,
                                     seed=40 + rank)
-        ppos, pvel, pstate = ob_spawn.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE + rank)
+        ppos, pvel, pstate = synth.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE + rank)
         pbatch = particles_mod.ParticleBatch(ps, ppos, pvel, pstate, device)
 
     # ---- N > 1: the path's only exchange.  Each rank's compacted visible set travels as its
@@ -538,6 +558,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"snapshot {os.path.basename(args.snapshot)}: {n_real} entities/GPU, " if args.snapshot
+                                    else f"BASELINE configs[4] per-GPU share (--c5; 16 M entities + 2 M particles at 8 GPUs): "
+                                         f"{n_real} entities/GPU, {args.chains} chains x depth {args.depth}, " if args.c5
                                     else f"BASELINE configs[1]: {n_real} entities/GPU, {args.chains} chains x depth "
                                          f"{args.depth}, ") + f"{args.layout} SoA layout, all dirty, fused frustum cull + ordered visible "
                                    f"list ({visible} visible" + (" in the gathered global set)" if use_dist else ")"),

@@ -67,6 +67,16 @@ def channel_table(anims, nr_joints):
                 data=np.concatenate(data).astype(np.float32))
 
 
+def skeleton_bind(invmx):
+    """model3d_add_skinning's bind = mat4x4_invert(invmx) per joint (model.c:524-537), with the library's arithmetic."""
+    inv = np.ascontiguousarray(invmx, np.float32).reshape(-1, 16)
+    out = np.zeros_like(inv)
+    L, fp = _lib.lib(), C.POINTER(C.c_float)
+    for j in range(inv.shape[0]):
+        L.clapgpu_mat4_invert(inv[j].ctypes.data_as(fp), out[j].ctypes.data_as(fp))
+    return out
+
+
 class SkinnedModel:
     """Device copy of one model3d's skeleton, animations and (optionally) skinned mesh."""
 
@@ -80,8 +90,7 @@ class SkinnedModel:
         self.root_pose = _dev(sk["root_pose"], dev, np.float32)
         self.invmx = _dev(sk["invmx"], dev, np.float32)
         if bind is None:
-            bind = np.stack([np.linalg.inv(m.reshape(4, 4).T.astype(np.float64)).T.reshape(16)
-                             for m in sk["invmx"]]).astype(np.float32)
+            bind = skeleton_bind(sk["invmx"])
         self.bind = _dev(bind, dev, np.float32)
         self.anims_host = anims
         ct = channel_table(anims, J)

@@ -264,6 +264,78 @@ def particle_systems(n_sys=4096, count=1024, radius=10.0, min_radius=0.0, veloci
     return dict(sys=sys, n=n, n_real=int(sys["count"].sum()), row_sys=row_sys)
 
 
+_R48_A, _R48_C, _M24 = 0x5DEECE66D, 0xB, (1 << 24) - 1
+
+
+def _mul48(a, b):
+    """a * b mod 2^48 on uint64 arrays (24-bit limbs: no product exceeds 2^48)."""
+    a_lo, a_hi, b_lo, b_hi = a & _M24, a >> np.uint64(24), b & _M24, b >> np.uint64(24)
+    mid = (a_hi * b_lo + a_lo * b_hi) & np.uint64(_M24)
+    return (a_lo * b_lo + (mid << np.uint64(24))) & np.uint64((1 << 48) - 1)
+
+
+def drand48_stream(state, count):
+    """The next `count` values of glibc's drand48 from `state` (X' = (0x5DEECE66D X + 0xB) mod 2^48, value = X' / 2^48)
+    and the state after them, by jump-ahead: the maps of 1..B steps (A_i, C_i) are built by doubling once, the block
+    starts X_{kB} follow one another through the B-step map, and X_{kB+i} = A_i X_{kB} + C_i for all of them at once."""
+    mask = np.uint64((1 << 48) - 1)
+    if count <= 0:
+        return np.zeros(0, np.float64), int(state)
+    B = 1 << min(16, max(0, int(count - 1).bit_length()))
+    A = np.asarray([_R48_A], np.uint64)
+    Cc = np.asarray([_R48_C], np.uint64)
+    while A.shape[0] < B:                                  # (A, C)[m + i] = (A[m-1] A[i], A[i] C[m-1] + C[i])
+        a_m, c_m = A[-1], Cc[-1]
+        A, Cc = (np.concatenate([A, _mul48(A, np.full_like(A, a_m))]),
+                 np.concatenate([Cc, (_mul48(A, np.full_like(A, c_m)) + Cc) & mask]))
+    n_blocks = (count + B - 1) // B
+    starts = np.empty(n_blocks, np.uint64)
+    x = int(state)
+    a_b, c_b = int(A[B - 1]), int(Cc[B - 1])
+    for k in range(n_blocks):
+        starts[k] = x
+        x = (a_b * x + c_b) & ((1 << 48) - 1)
+    xs = (_mul48(np.broadcast_to(A[None, :B], (n_blocks, B)), np.broadcast_to(starts[:, None], (n_blocks, B)))
+          + Cc[None, :B]) & mask
+    xs = xs.reshape(-1)[:count]
+    return xs.astype(np.float64) * (1.0 / 281474976710656.0), int(xs[-1])
+
+
+def particles_spawn(ps, rng_state):
+    """particle_system_make's spawn loop (particle.c:36-87, 229-234) for every system in order on one drand48 stream:
+    per particle a point in the system's sphere (3 draws for the direction, 1 for the radius under the system's
+    distribution) and a velocity (3 draws).  Returns (pos[n,3], vel[n,3], stream state afterwards).  Harness-side
+    preparation of the device arrays (the engine spawns on the host as well)."""
+    sys = ps["sys"]
+    n = int(ps["n"])
+    pos, vel = np.zeros((n, 3), F32), np.zeros((n, 3), F32)
+    counts = sys["count"].astype(np.int64)
+    total = int(counts.sum())
+    if not total:
+        return pos, vel, int(rng_state)
+    draws, state = drand48_stream(rng_state, 7 * total)
+    d = draws.reshape(total, 7)
+    which = np.repeat(np.arange(sys.shape[0]), counts)
+    idx = np.repeat(sys["first"].astype(np.int64), counts) + (np.arange(total) - np.repeat(np.cumsum(counts) - counts, counts))
+    dirv = (d[:, 0:3] * 2.0 - 1.0).astype(F32)
+    dot = F32(0) + dirv[:, 0] * dirv[:, 0]                  # lm_dot3: p = 0; p += b[i] * a[i]
+    dot = dot + dirv[:, 1] * dirv[:, 1]
+    dot = dot + dirv[:, 2] * dirv[:, 2]
+    ln = np.sqrt(dot)
+    with np.errstate(divide="ignore"):
+        k = (1.0 / ln.astype(np.float64)).astype(F32)       # vec3_norm: double divide, float store
+    dirv = np.where((ln != 0)[:, None], dirv * k[:, None], dirv)
+    u = d[:, 3].copy()
+    dist = sys["dist"][which]
+    u = np.where(dist == PART_DIST_SQRT, np.sqrt(d[:, 3]), u)
+    u = np.where(dist == PART_DIST_CBRT, np.cbrt(d[:, 3]), u)
+    u = np.where(dist == PART_DIST_POW075, np.power(d[:, 3], 0.75), u)
+    r = (sys["min_radius"][which] + (sys["radius"][which] - sys["min_radius"][which]) * u).astype(F32)
+    pos[idx] = sys["center"][which] * F32(1.0) + dirv * r[:, None]
+    vel[idx] = ((d[:, 4:7] * 2.0 - 1.0) * sys["velocity"][which][:, None]).astype(F32)
+    return pos, vel, state
+
+
 # ----------------------------------------------------------------------------- skeletons / animation / meshes
 def _rigid_mat4(rng, n, spread=1.0):
     """n random rigid transforms as column-major mat4 [n,16]."""

@@ -71,3 +71,26 @@ def test_oracle_matches_live_reference_many_systems():
         _k, st = ob.particles_update(ps, pos, vel, st)
         assert_bits_equal(pos, ref["pos"][f], f"frame {f}")
         assert st == int(ref["rng_state"][f + 1])
+
+
+def test_harness_spawn_matches_oracle_bits():
+    """clap_amd.synth.particles_spawn (numpy, drand48 by jump-ahead: what bench.py and the tools prepare device arrays
+    with) against the oracle's sequential spawn: positions, velocities and the stream state, bit for bit, for every
+    radius distribution and for ragged systems."""
+    for kw in (dict(n_sys=7, count=100, ragged=True, seed=9), dict(n_sys=40, count=1024), dict(n_sys=1, count=1),
+               dict(n_sys=9, count=77, dist=synth.PART_DIST_CBRT), dict(n_sys=9, count=77, dist=synth.PART_DIST_POW075),
+               dict(n_sys=9, count=77, dist=synth.PART_DIST_LIN, min_radius=2.5)):
+        ps = synth.particle_systems(**kw)
+        for state in (synth.DRAND48_DEFAULT_STATE, 1, (1 << 48) - 1):
+            a = synth.particles_spawn(ps, state)
+            b = ob.particles_spawn(ps, state)
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), kw
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), kw
+            assert a[2] == b[2], kw
+    vals, st = synth.drand48_stream(synth.DRAND48_DEFAULT_STATE, 200_001)
+    s = synth.DRAND48_DEFAULT_STATE
+    for k in range(200_001):
+        s = (0x5DEECE66D * s + 0xB) & ((1 << 48) - 1)
+        if k in (0, 1, 65535, 65536, 131071, 200_000):
+            assert vals[k] == s / 2.0 ** 48, k
+    assert st == s

@@ -51,18 +51,17 @@ def main():
         cb.pose_update()
         fn = cb.pose_update if which == "pose" else cb.skin
     elif which == "particles":
-        from oracle import binding as ob
         ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
-        pos, vel, st = ob.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
+        pos, vel, st = synth.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
         pb = particles.ParticleBatch(ps, pos, vel, st, dev)
         view = np.eye(4, dtype=np.float32).ravel()
         fn = lambda: pb.particles_update(view)
     elif which == "lights":
         from clap_amd import lights as gl
-        from oracle import binding as ob
+        from clap_amd import entities as _ent
         ls = gl.LightSet(dev, 3840, 2160, 16)                    # 4K at 16-px tiles: 32 400 tiles
         ls.load(synth.lights(128, seed=7))
-        _fr, vm, pm = ob.frustum_from_camera(synth.camera(pos=(1.0, 2.0, 3.0)))
+        _fr, vm, pm = _ent.view_calc_frustum(synth.camera(pos=(1.0, 2.0, 3.0)))
         fn = lambda: ls.grid_compute(vm, pm)
     else:
         if which.endswith("_spheres"):
