@@ -23,7 +23,13 @@ fc=$(find "$out/fetch" -name '*counter_collection.csv' | head -1)
 wc=$(find "$out/write" -name '*counter_collection.csv' | head -1)
 if [ -n "$fc" ] && [ -n "$wc" ]; then
     python3 "$R/tools/pmc_summary.py" --all "$fc" "$wc" "$out/pmc_hbm_bytes.json" > /dev/null
-    python3 "$R/tools/pmc_summary.py" "$fc" "$wc" k_entities_tiles "$out/entities_pmc.json" > /dev/null
 fi
-rm -rf "$out/trace" "$out/trace_h" "$out/fetch" "$out/write"           # keep the summaries, not the per-dispatch dumps
+# the headline kernel's traffic from headline-only passes: in the full bench the whole-frame extra launches the same grid
+# with only part of the scene dirty, which would pull the per-launch mean down
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch_h" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed --no-extras > "$out/bench_fetch_headline.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/write_h" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed --no-extras > "$out/bench_write_headline.log" 2>&1
+fch=$(find "$out/fetch_h" -name '*counter_collection.csv' | head -1)
+wch=$(find "$out/write_h" -name '*counter_collection.csv' | head -1)
+[ -n "$fch" ] && [ -n "$wch" ] && python3 "$R/tools/pmc_summary.py" "$fch" "$wch" k_entities_tiles "$out/entities_pmc.json" > /dev/null
+rm -rf "$out/trace" "$out/trace_h" "$out/fetch" "$out/write" "$out/fetch_h" "$out/write_h"           # keep the summaries, not the per-dispatch dumps
 ls -la "$out"; tail -c 600 "$out/bench_unprofiled.json"; echo; [ -f "$out/kernel_stats.csv" ] && cut -d, -f1-4 "$out/kernel_stats.csv" | cut -c1-110 | head -40
