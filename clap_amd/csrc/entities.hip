@@ -173,11 +173,25 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
 #pragma unroll
             for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
         }
+#ifdef CLAPGPU_EXP_NO_INVERT                                     // sensitivity experiments only (tools/entities_sensitivity.sh): wrong results
+#pragma unroll
+        for (int k = 0; k < 16; k++) inv[k] = mx[k];
+#else
         lmd::invert(inv, mx);
+#endif
 
         has_aabb = __float_as_uint(lo.w) == 0u;                  // model.c:1204
+#ifdef CLAPGPU_EXP_NO_AABB
+        if (has_aabb) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb[k] = mx[12 + k % 3] + (k < 3 ? lo.x : hi.x);
+#pragma unroll
+            for (int k = 0; k < 3; k++) ctr[k] = mx[12 + k];
+        }
+#else
         if (has_aabb)
             lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+#endif
 
         seq = (seq + 1) & 0xffffu;                               // uint16 wrap (model.h:404)
         e.seqs[i] = seq | (pseq << 16);
@@ -328,11 +342,20 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
 // row r = entities [64r, 64r+64) = one hierarchy level of the subtrees packed into the tile.
 // The next row's inputs are in flight while the current row is computed.
 constexpr int ENT_TILE_WAVES = 1;       // occupancy hint; 4 measured the same 44 us
+// The frustum (63 dwords) is the FIRST kernel argument and is read where it is used, through the kernarg segment
+// pointer, with the pointer laundered once per row: held in SGPRs across the row loop next to ~30 array pointers it
+// cost 194 spilled SGPRs -- some 300 v_readlane / s_nop per row of a kernel that issues 850 vector instructions per row.
 template <bool CULL>
 __global__ __launch_bounds__(ENT_BLOCK, ENT_TILE_WAVES)
-void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
-                      uint32_t mode, lmd::FrustumK fr)
+void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
+                      uint32_t mode)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)fr_arg;
+    const lmd::FrustumK *frp = (const lmd::FrustumK *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const lmd::FrustumK *frp = &fr_arg;                          // host pass of the compiler only
+#endif
     __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
@@ -361,7 +384,8 @@ void k_entities_tiles(EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, 
         const uint32_t nfirst = more ? next * WAVE : row_first;  // last row: harmless re-load
         const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
         const RowIn nxt = load_row(e, lane, nfirst, ncount);     // in flight during process_row
-        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, fr,
+        asm volatile("" : "+s"(frp));                            // the planes are re-read (scalar cache) each row
+        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, *frp,
                                 have_prev, row_first - WAVE, carry_mx, carry_seq, carry_valid);
         if (!more)
             break;
@@ -760,11 +784,11 @@ extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entitie
     const uint32_t per_block = ENT_BLOCK / WAVE;
     const dim3 grid((n_tiles + per_block - 1) / per_block), block(ENT_BLOCK);
     if (frustum)
-        hipLaunchKernelGGL(k_entities_tiles<true>, grid, block, 0, as_stream(stream), k, tile_row_start, n_tiles,
-                           e->n, mode, fr);
+        hipLaunchKernelGGL(k_entities_tiles<true>, grid, block, 0, as_stream(stream), fr, k, tile_row_start, n_tiles,
+                           e->n, mode);
     else
-        hipLaunchKernelGGL(k_entities_tiles<false>, grid, block, 0, as_stream(stream), k, tile_row_start, n_tiles,
-                           e->n, mode, fr);
+        hipLaunchKernelGGL(k_entities_tiles<false>, grid, block, 0, as_stream(stream), fr, k, tile_row_start, n_tiles,
+                           e->n, mode);
     CLAPGPU_LAUNCH_CHECK("k_entities_tiles");
     return CLAPGPU_OK;
 }
