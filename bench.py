@@ -309,9 +309,9 @@ def extras(device, testbed=True):
                      "roofline": roof(pw.integrate_algorithmic_bytes(), t_int, "k_bodies_step"),
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
-                                    "launches": 6,
-                                    "note": "both passes (bodies x bodies, statics x bodies) in the same six launches: "
-                                            "k_bp_bin, k_bp_cells, k_bp_scatter, k_bp_search, k_bp_tiles, k_bp_emit; bound "
+                                    "launches": 5,
+                                    "note": "both passes (bodies x bodies, statics x bodies) in the same five launches: "
+                                            "k_bp_bin, k_bp_cells, k_bp_scatter, k_bp_search, k_bp_emit; bound "
                                             "by the fabric's atomic rate (bin), launch floors and the search's chain of "
                                             "dependent steps, not by HBM (profiles/r02_experiments/broadphase_tiles.md)"}}
     del pw

@@ -200,28 +200,27 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
 // Hash grid over the AABB centres, cell >= the largest body AABB edge, so a body's partners have their centres in
 // the 27 cells around its own.  Cells are grouped in 4x4x4 blocks: a cell's slot = (hash of its block) * 64 + its
 // position inside the block, so the 64 cells of a block are neighbours in memory and the per-frame prefix work
-// splits into a wave-sized piece per block (k_bp_cells) and a scan over blocks small enough for one workgroup.
+// splits into a wave-sized piece per block (k_bp_cells) and a scan over the block totals.
 // Five launches for BOTH passes of __phys_step (bodies x bodies and statics x bodies):
 //   k_bp_bin      one atomic per body on its cell's counter (the return value is its rank in the cell)
-//   k_bp_cells    one wavefront per block: exclusive prefix of its 64 cell counts, block total; the workgroup that
-//                 finishes last scans the block totals
-//   k_bp_scatter  body indices into cell order
-//   k_bp_search   8 lanes per body, bodies taken in cell order: own cell (partners with a larger index) + the 13
-//                 cells after it, so every unordered pair is tested once; the runs are spread into an LDS work list
-//                 and tested one candidate per lane; hits go to the partner list of min(i, j).  Then the statics
-//                 registered for the body's block (binned once on the host) and the large statics.  The workgroup
-//                 that finishes last turns the per-tile partner sums into tile offsets and totals.
-//   k_bp_emit     one thread per body in index order: offset = tile offset + scan inside the tile, its list written in
-//                 ascending partner order, so the output is the canonical ascending list whatever order the atomics took
+//   k_bp_cells    one wavefront per block: exclusive prefix of its 64 cell counts; block starts by a single-pass scan
+//                 with decoupled look-back over the workgroups' totals
+//   k_bp_scatter  64-byte records (box, index, cell coordinates) into cell order
+//   k_bp_search   one wavefront per tile of 16 bodies in cell order; candidates (own cell: partners with a larger
+//                 index; the 13 cells after it; the statics registered for the block) listed once per DISTINCT cell /
+//                 block bucket of the tile in an LDS work list and tested against the tile's boxes; hits go to the
+//                 partner list of min(i, j); then the large statics from LDS
+//   k_bp_emit     one thread per body in index order: offset = tile offset (look-back scan over the 256-body tiles) +
+//                 scan inside the tile, its list written in ascending partner order, so the output is the canonical
+//                 ascending list whatever order the atomics took
 // Two different cells of one 3x3x3 neighbourhood never share a slot (same position inside a block means at least four
-// cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge), so no cell
-// coordinates need to be stored with the entries.
+// cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge), so candidates need
+// no cell check beyond the box test.
 constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
 constexpr int BP_TILE = 16;            // bodies per wavefront of the search
 constexpr int BP_WORK = 512;           // candidate entries listed per tile and round
 constexpr int BP_EMIT_TILE = 256;      // bodies per tile of the pair-offset scan (= emit block)
-constexpr int CTRL_STATUS = 2, CTRL_TICKET_CELLS = 8, CTRL_TICKET_SEARCH = 80;   // tickets: 65 words each
-static_assert(BP_EMIT_TILE == PB, "k_bp_tiles sums one emit tile per workgroup");
+constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3;     // the frame counter lives on the device: a captured graph replays the same arguments
 
 __host__ __device__ __forceinline__ uint32_t block_hash(int32_t bx, int32_t by, int32_t bz, uint32_t mask)
 {
@@ -252,15 +251,14 @@ struct BpK {
     uint32_t *cell_cnt;                  // [buckets * 64] the bin pass's counters, zero between frames
     uint32_t *cell_len;                  // [buckets * 64] bodies per cell
     uint32_t *cell_prefix;               // [buckets * 64] exclusive prefix inside the block
-    uint32_t *block_tot;                 // [buckets]
     uint32_t *block_start;               // [buckets + 1]
     uint32_t *key, *rank;                // [n] cell slot and rank inside the cell
     uint32_t *entries;                   // [n] body indices in cell order
     struct BpRec *recs;                  // [n] the same with the boxes: what the search reads
     uint32_t *cnt, *scnt;                // [n] partners (larger index) / statics per body: atomics in the search
     uint32_t *partners, *spartners;      // [n][BP_LIST]
-    uint32_t *tile_sum, *stile_sum;      // [tiles] zero between frames
-    uint32_t *tile_off, *stile_off;      // [tiles]
+    uint64_t *lb_body, *lb_static;       // [tiles] look-back words of the pair-offset scan (k_bp_emit)
+    uint64_t *lb_cells;                  // [buckets / 4] look-back words of the block-start scan (k_bp_cells)
     uint32_t *ctrl;
     uint32_t n_tiles;
     // statics (binned on the host at create time)
@@ -295,65 +293,12 @@ __device__ __forceinline__ bool boxes_overlap(const double (&a)[6], const double
     return !(a[0] > b[1] || a[1] < b[0] || a[2] > b[3] || a[3] < b[2] || a[4] > b[5] || a[5] < b[4]);
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// Four 16-byte loads that bypass this XCD's L2 (sc0 sc1): what they read was stored through to memory by other
-// workgroups of the same launch, and a plain load could return a line this L2 still holds from an earlier frame.
-// The wait is part of the block: the compiler cannot see that the destination registers are written asynchronously.
-__device__ __forceinline__ void load_coherent_4x4(const uint32_t *p0, const uint32_t *p1, const uint32_t *p2, const uint32_t *p3,
-                                                  u32x4 &v0, u32x4 &v1, u32x4 &v2, u32x4 &v3)
-{
-    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-                 "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-}
-
-// "the last workgroup to arrive does the epilogue", without thousands of atomics on one address (each costs ~12 ns,
-// serialised): 64 first-level counters, the last arrival of each goes on to the second level.
-__device__ __forceinline__ bool last_block_ticket(uint32_t *tickets /* [65], zero */, uint32_t block, uint32_t n_blocks)
-{
-    const uint32_t shard = block & 63u;
-    const uint32_t in_shard = (n_blocks >> 6) + (shard < (n_blocks & 63u) ? 1u : 0u);
-    const uint32_t n_shards = n_blocks < 64u ? n_blocks : 64u;
-    if (atomicAdd(&tickets[1 + shard], 1u) != in_shard - 1) return false;
-    tickets[1 + shard] = 0;                                            // ready for the next launch
-    if (atomicAdd(&tickets[0], 1u) != n_shards - 1) return false;
-    tickets[0] = 0;
-    return true;
-}
-
-// exclusive scan of v over the 256 threads of a block (two barriers); returns the block total in `total`
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t &total, uint32_t *lds /* [4] */)
-{
-    const int lane = lane_id(), wave = threadIdx.x / WAVE;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t u = __shfl_up(incl, o);
-        if (lane >= o) incl += u;
-    }
-    if (lane == WAVE - 1) lds[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0, tot = 0;
-#pragma unroll
-    for (int q = 0; q < PB / WAVE; q++) {
-        const uint32_t x = lds[q];
-        if (q < wave) wave_off += x;
-        tot += x;
-    }
-    __syncthreads();
-    total = tot;
-    return wave_off + incl - v;
-}
-
 // Launch 1
 __global__ __launch_bounds__(PB)
 void k_bp_bin(BpK k)
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i == 0) k.ctrl[CTRL_EPOCH] = k.ctrl[CTRL_EPOCH] + 1;          // first launch of the frame; read by the later ones
     if (i >= k.n) return;
     double bb[6];
     load_box(k.aabb, i, bb);
@@ -366,14 +311,61 @@ void k_bp_bin(BpK k)
     k.rank[i] = atomicAdd(&k.cell_cnt[slot], 1u);
 }
 
-// Launch 2: wave w = block bucket w
+// Single-pass scans with decoupled look-back (the block starts in k_bp_cells, the pair offsets of the 256-body emit
+// tiles in k_bp_emit): a tile's offset = the sum of everything before it.  Tile b publishes (flag, epoch, value) as ONE 64-bit word -- its own sum first
+// (AGGREGATE), its inclusive prefix once known (PREFIX) -- and a wavefront walks back over its predecessors' words, 64 at
+// a time, until it meets a PREFIX.  Workgroups are dispatched in index order and wait only on lower indices, so the
+// walk always terminates; the frame's epoch in the word makes last frame's entries read as empty (no clearing pass).
+constexpr uint64_t LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_FLAGS = 3ull << 62;
+__device__ __forceinline__ uint64_t lb_word(uint64_t flag, uint32_t epoch, uint32_t value)
+{
+    return flag | ((uint64_t)(epoch & 0x3fffffffu) << 32) | value;
+}
+
+// exclusive prefix of tile `b` (called by one whole wavefront); publishes the tile's own words
+__device__ __forceinline__ uint32_t lb_exclusive(uint64_t *state, uint32_t b, uint32_t sum, uint32_t epoch, uint32_t *status)
+{
+    const int lane = lane_id();
+    if (b == 0) {
+        if (lane == 0) __hip_atomic_store(&state[0], lb_word(LB_PREFIX, epoch, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&state[b], lb_word(LB_AGG, epoch, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    for (int64_t top = (int64_t)b - 1; top >= 0; top -= WAVE) {         // window: tiles top, top-1, ..., top-63
+        const int64_t t = top - lane;
+        uint64_t w = 0;
+        if (t >= 0) {
+            uint32_t spins = 0;
+            do {
+                w = __hip_atomic_load(&state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((w & LB_FLAGS) && (uint32_t)((w >> 32) & 0x3fffffffu) == (epoch & 0x3fffffffu)) break;
+                w = 0;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < (1u << 22));                               // a bound, not an expectation: see above
+            if (!w) atomicOr(status, 4u);
+        }
+        const uint64_t is_prefix = __ballot(t >= 0 && (w & LB_FLAGS) == LB_PREFIX);
+        const int stop = is_prefix ? __builtin_ctzll(is_prefix) : WAVE - 1;   // nearest predecessor that knows its prefix
+        uint32_t v = (t >= 0 && lane <= stop) ? (uint32_t)w : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        excl += v;
+        if (is_prefix) break;
+    }
+    if (lane == 0) __hip_atomic_store(&state[b], lb_word(LB_PREFIX, epoch, excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// Launch 2: wave w = block bucket w; a workgroup's four block totals enter the look-back scan as one tile
 __global__ __launch_bounds__(PB)
 void k_bp_cells(BpK k)
 {
-    __shared__ uint32_t lds[PB / WAVE];
-    __shared__ bool is_last;
-    const int lane = lane_id();
-    const uint32_t b = blockIdx.x * (PB / WAVE) + threadIdx.x / WAVE;
+    __shared__ uint32_t tot[PB / WAVE];
+    __shared__ uint32_t excl_s;
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const uint32_t b = blockIdx.x * (PB / WAVE) + wave;
+    uint32_t block_total = 0;
     if (b <= k.mask) {
         const uint32_t c = k.cell_cnt[(size_t)b * 64 + lane];
         k.cell_cnt[(size_t)b * 64 + lane] = 0;                          // ready for the next frame
@@ -385,40 +377,26 @@ void k_bp_cells(BpK k)
             if (lane >= o) incl += u;
         }
         k.cell_prefix[(size_t)b * 64 + lane] = incl - c;
-        if (lane == WAVE - 1)                                           // stored through to memory: read by another workgroup below
-            __hip_atomic_store(&k.block_tot[b], incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        block_total = __shfl(incl, WAVE - 1);
     }
-    // No __threadfence() (on gfx950 a whole-L2 write-back + invalidate per workgroup): the totals were stored through,
-    // the barrier's s_waitcnt has them acknowledged before the ticket is taken, the last workgroup loads them coherently.
+    if (lane == 0) tot[wave] = block_total;
     __syncthreads();
-    if (threadIdx.x == 0)
-        is_last = last_block_ticket(k.ctrl + CTRL_TICKET_CELLS, blockIdx.x, gridDim.x);
-    __syncthreads();
-    if (!is_last) return;
-    const uint32_t nbk = k.mask + 1, units = nbk / 4;                    // 16-byte units of four block totals
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < units; base += PB * 4) {
-        u32x4 c[4];
-        const uint32_t *src[4];
+    if (wave == 0) {
+        uint32_t sum = 0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const uint32_t u = base + e * PB + threadIdx.x;
-            src[e] = k.block_tot + (size_t)(u < units ? u : 0) * 4;
-        }
-        load_coherent_4x4(src[0], src[1], src[2], src[3], c[0], c[1], c[2], c[3]);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const uint32_t u = base + e * PB + threadIdx.x;
-            if (u >= units) c[e] = u32x4{ 0, 0, 0, 0 };
-            uint32_t slice_total;
-            const uint32_t s0 = carry + block_scan_256(c[e].x + c[e].y + c[e].z + c[e].w, slice_total, lds);
-            if (u < units)
-                *reinterpret_cast<u32x4 *>(k.block_start + (size_t)u * 4) =
-                    u32x4{ s0, s0 + c[e].x, s0 + c[e].x + c[e].y, s0 + c[e].x + c[e].y + c[e].z };
-            carry += slice_total;
+        for (int q = 0; q < PB / WAVE; q++) sum += tot[q];
+        const uint32_t excl = lb_exclusive(k.lb_cells, blockIdx.x, sum, k.ctrl[CTRL_EPOCH], k.ctrl + CTRL_STATUS);
+        if (lane == 0) {
+            excl_s = excl;
+            if (blockIdx.x == gridDim.x - 1) k.block_start[k.mask + 1] = excl + sum;
         }
     }
-    if (threadIdx.x == 0) k.block_start[nbk] = carry;
+    __syncthreads();
+    if (b <= k.mask && lane == 0) {
+        uint32_t start = excl_s;
+        for (int q = 0; q < wave; q++) start += tot[q];
+        k.block_start[b] = start;
+    }
 }
 
 // Launch 3
@@ -632,54 +610,6 @@ void k_bp_search(BpK k)
     if (isA) k.scnt[aidx[wave][lane]] = shits[wave][lane];
 }
 
-// Launch 5: partner counts per tile of 256 bodies (both lists); the workgroup that finishes last scans them into tile
-// offsets and writes the totals
-__global__ __launch_bounds__(PB)
-void k_bp_tiles(BpK k)
-{
-    __shared__ uint32_t lds[PB / WAVE];
-    __shared__ bool is_last;
-    const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    uint32_t t0, t1 = 0;
-    block_scan_256(i < k.n ? k.cnt[i] : 0, t0, lds);
-    if (k.n_static) block_scan_256(i < k.n ? k.scnt[i] : 0, t1, lds);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&k.tile_sum[blockIdx.x], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&k.stile_sum[blockIdx.x], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        is_last = last_block_ticket(k.ctrl + CTRL_TICKET_SEARCH, blockIdx.x, gridDim.x);
-    __syncthreads();
-    if (!is_last) return;
-    for (int which = 0; which < 2; which++) {
-        uint32_t *sum = which ? k.stile_sum : k.tile_sum, *offs = which ? k.stile_off : k.tile_off;
-        uint32_t *tot_out = which ? k.spair_total : k.pair_total;
-        if (which && !k.n_static) {
-            if (threadIdx.x == 0 && tot_out) *tot_out = 0;
-            continue;
-        }
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < k.n_tiles; base += PB * 4) {     // four tiles per thread and round, loads in flight together
-            uint32_t v[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t x = base + e * PB + threadIdx.x;
-                v[e] = x < k.n_tiles ? __hip_atomic_load(&sum[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t x = base + e * PB + threadIdx.x;
-                uint32_t chunk;
-                const uint32_t ex = block_scan_256(v[e], chunk, lds);
-                if (x < k.n_tiles) offs[x] = carry + ex;
-                carry += chunk;
-            }
-        }
-        if (threadIdx.x == 0 && tot_out) *tot_out = carry;
-    }
-}
-
 // all partners of body i (larger index) in ascending order, for a body whose list did not fit its slot: one lane
 // walks its 27 cells
 template <typename F>
@@ -709,11 +639,12 @@ __device__ __forceinline__ void research_body(const BpK &k, uint32_t i, F &&emit
     }
 }
 
-// Launch 6
+// Launch 5
 __global__ __launch_bounds__(BP_EMIT_TILE)
 void k_bp_emit(BpK k)
 {
     __shared__ uint32_t lds[2][BP_EMIT_TILE / WAVE];
+    __shared__ uint32_t tile_excl[2];
     const uint32_t i = blockIdx.x * BP_EMIT_TILE + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const bool with_statics = k.n_static != 0;
@@ -731,11 +662,26 @@ void k_bp_emit(BpK k)
     }
     if (lane == WAVE - 1) { lds[0][wave] = incl[0]; lds[1][wave] = incl[1]; }
     __syncthreads();
+    if (wave < 2) {                                                      // wavefront 0: the body list's offsets; wavefront 1: the statics'
+        uint32_t sum = 0;
+        for (int qq = 0; qq < BP_EMIT_TILE / WAVE; qq++) sum += lds[wave][qq];
+        uint32_t excl = 0;
+        if (wave == 0 || with_statics)
+            excl = lb_exclusive(wave ? k.lb_static : k.lb_body, blockIdx.x, sum, k.ctrl[CTRL_EPOCH], k.ctrl + CTRL_STATUS);
+        if (lane == 0) {
+            tile_excl[wave] = excl;
+            if (blockIdx.x == gridDim.x - 1) {                           // the last tile's inclusive prefix is the total
+                uint32_t *tot = wave ? k.spair_total : k.pair_total;
+                if (tot) *tot = (wave == 0 || with_statics) ? excl + sum : 0u;
+            }
+        }
+    }
+    __syncthreads();
     uint32_t woff[2] = { 0, 0 };
     for (int qq = 0; qq < wave; qq++) { woff[0] += lds[0][qq]; woff[1] += lds[1][qq]; }
     if (i >= k.n) return;
     if (c[0]) {
-        const uint32_t off = k.tile_off[blockIdx.x] + woff[0] + incl[0] - c[0];
+        const uint32_t off = tile_excl[0] + woff[0] + incl[0] - c[0];
         uint2 *out = reinterpret_cast<uint2 *>(k.pairs);
         if (c[0] <= BP_LIST) {
             const uint32_t *src = k.partners + (size_t)BP_LIST * i;
@@ -751,7 +697,7 @@ void k_bp_emit(BpK k)
         }
     }
     if (c[1]) {
-        const uint32_t off = k.stile_off[blockIdx.x] + woff[1] + incl[1] - c[1];
+        const uint32_t off = tile_excl[1] + woff[1] + incl[1] - c[1];
         uint2 *out = reinterpret_cast<uint2 *>(k.spairs);
         if (c[1] <= BP_LIST) {
             const uint32_t *src = k.spartners + (size_t)BP_LIST * i;
@@ -1182,12 +1128,11 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
     const size_t o_ccnt = take(4 * (size_t)nb * 64), o_cpre = take(4 * (size_t)nb * 64), o_clen = take(4 * (size_t)nb * 64);
-    const size_t o_btot = take(4 * (size_t)nb), o_bstart = take(4 * ((size_t)nb + 4));
+    const size_t o_bstart = take(4 * ((size_t)nb + 4));
     const size_t o_key = take(4 * (size_t)n), o_ranks = take(4 * (size_t)n), o_entries = take(4 * (size_t)n), o_recs = take(64 * (size_t)n);
     const size_t o_cnt = take(4 * (size_t)n), o_scnt = take(4 * (size_t)n);
     const size_t o_part = take(4 * (size_t)BP_LIST * n), o_spart = take(4 * (size_t)BP_LIST * n);
-    const size_t o_tsum = take(4 * (size_t)bp->n_tiles), o_stsum = take(4 * (size_t)bp->n_tiles);
-    const size_t o_toff = take(4 * (size_t)bp->n_tiles), o_stoff = take(4 * (size_t)bp->n_tiles);
+    const size_t o_lbb = take(8 * (size_t)bp->n_tiles), o_lbs = take(8 * (size_t)bp->n_tiles), o_lbc = take(8 * ((size_t)nb / 4 + 1));
     const size_t o_ctrl = take(4 * 160);
     const size_t o_sstart = take(4 * ((size_t)nb + 1)), o_sent = take(4 * s_entries.size()), o_slarge = take(4 * s_large.size());
     const size_t o_saabb = take(48 * (size_t)(n_static ? n_static : 1));
@@ -1216,13 +1161,13 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     k.cell = cell; k.mask = nb - 1;
     k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt); k.cell_prefix = reinterpret_cast<uint32_t *>(d + o_cpre);
     k.cell_len = reinterpret_cast<uint32_t *>(d + o_clen);
-    k.block_tot = reinterpret_cast<uint32_t *>(d + o_btot); k.block_start = reinterpret_cast<uint32_t *>(d + o_bstart);
+    k.block_start = reinterpret_cast<uint32_t *>(d + o_bstart);
     k.key = reinterpret_cast<uint32_t *>(d + o_key); k.rank = reinterpret_cast<uint32_t *>(d + o_ranks);
     k.entries = reinterpret_cast<uint32_t *>(d + o_entries); k.recs = reinterpret_cast<BpRec *>(d + o_recs);
     k.cnt = reinterpret_cast<uint32_t *>(d + o_cnt); k.scnt = reinterpret_cast<uint32_t *>(d + o_scnt);
     k.partners = reinterpret_cast<uint32_t *>(d + o_part); k.spartners = reinterpret_cast<uint32_t *>(d + o_spart);
-    k.tile_sum = reinterpret_cast<uint32_t *>(d + o_tsum); k.stile_sum = reinterpret_cast<uint32_t *>(d + o_stsum);
-    k.tile_off = reinterpret_cast<uint32_t *>(d + o_toff); k.stile_off = reinterpret_cast<uint32_t *>(d + o_stoff);
+    k.lb_body = reinterpret_cast<uint64_t *>(d + o_lbb); k.lb_static = reinterpret_cast<uint64_t *>(d + o_lbs);
+    k.lb_cells = reinterpret_cast<uint64_t *>(d + o_lbc);
     k.ctrl = reinterpret_cast<uint32_t *>(d + o_ctrl);
     k.s_start = reinterpret_cast<const uint32_t *>(d + o_sstart); k.s_entries = reinterpret_cast<const uint32_t *>(d + o_sent);
     k.s_large = reinterpret_cast<const uint32_t *>(d + o_slarge); k.s_aabb = reinterpret_cast<const double *>(d + o_saabb);
@@ -1268,8 +1213,6 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
     hipLaunchKernelGGL(k_bp_search, dim3((n + (PB / WAVE) * BP_TILE - 1) / ((PB / WAVE) * BP_TILE)), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_search");
-    hipLaunchKernelGGL(k_bp_tiles, dim3(k.n_tiles), dim3(PB), 0, s, k);
-    CLAPGPU_LAUNCH_CHECK("k_bp_tiles");
     hipLaunchKernelGGL(k_bp_emit, dim3(k.n_tiles), dim3(BP_EMIT_TILE), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_emit");
     return CLAPGPU_OK;
