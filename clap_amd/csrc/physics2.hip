@@ -5,9 +5,9 @@
 //   k_bodies_step     dWorldQuickStep's body stage (quickstep.cpp stage 0 + dxStepBody + auto-disable), fused with
 //                     the moved geom's axis / AABB (dxCapsule::computeAABB)                      HBM-bound, 1 lane / body
 //   k_bp_*            dSpaceCollide2(ground, bodies) + dSpaceCollide(bodies) (physics.c:751-753) as ascending
-//                     candidate-pair lists, four launches for both passes: bodies binned by AABB centre into a hash
-//                     grid of 4x4x4-cell blocks (own block + the neighbour blocks its cell touches), one wavefront
-//                     per block with the block's candidates staged through LDS and read back as broadcasts
+//                     candidate-pair lists, five launches for both passes: bodies binned by AABB centre into a hash
+//                     grid of 4x4x4-cell blocks, copied into cell order, searched one wavefront per 16-body tile with
+//                     the candidates of each distinct cell listed once in LDS (section comment below)
 //   k_contacts_geoms  near_callback's dCollide + phys_contact_surface (physics.c:399-449, 291-330)
 //   k_sweep_capsules  phys_body_sweep_capsule (physics.c:559-670), one wavefront per sweep
 // fp64 throughout (the reference builds ODE with dDOUBLE, physics.h:5-9), no FMA contraction.
