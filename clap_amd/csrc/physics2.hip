@@ -218,8 +218,11 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
 // no cell check beyond the box test.
 constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
 constexpr int BP_TILE = 16;            // bodies per wavefront of the search
-constexpr int BP_WORK = 512;           // candidate entries listed per tile and round
+constexpr int BP_WORK = 512;           // candidate entries listed per tile and round (256: spheres -2 us, capsules +5 us)
 constexpr int BP_EMIT_TILE = 256;      // bodies per tile of the pair-offset scan (= emit block)
+#ifndef BP_SEARCH_IN_FLIGHT
+#define BP_SEARCH_IN_FLIGHT 1            // candidate records gathered per lane and round
+#endif
 constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3;     // the frame counter lives on the device: a captured graph replays the same arguments
 
 __host__ __device__ __forceinline__ uint32_t block_hash(int32_t bx, int32_t by, int32_t bz, uint32_t mask)
@@ -431,8 +434,8 @@ void k_bp_search(BpK k)
 {
     constexpr int WAVES = PB / WAVE, T = BP_TILE, LOOKUPS = 4;          // lookups per lane: T * 14 + T <= 64 * LOOKUPS
     constexpr uint32_t WL = BP_WORK, OWN = 0x80000000u, STAT = 0x40000000u, IDX = 0x3fffffffu;
-    constexpr int LARGE_TILE = 128;                                     // large statics staged per round
-    constexpr uint32_t HITS = 128;                                      // body x body hits parked per round
+    constexpr int LARGE_TILE = 32;                                      // large statics staged per round (LDS <= 26 KB: six workgroups per CU)
+    constexpr uint32_t HITS = 64;                                       // body x body hits parked per round
     static_assert(T * 15 <= WAVE * LOOKUPS && T <= 16, "tile lookups");
     __shared__ __attribute__((aligned(8))) uint32_t work[WAVES][WL][2];  // (record | flags, a_lo | a_hi << 8)
     __shared__ double abox[WAVES][T][6];
@@ -568,6 +571,7 @@ void k_bp_search(BpK k)
         }
         wave_lds_fence();
         const uint32_t todo = total - base < WL ? total - base : WL;
+#if BP_SEARCH_IN_FLIGHT == 2
         for (uint32_t e = lane; e < todo + lane; e += 2 * WAVE) {       // wave-uniform trip count; two records in flight per lane
             const bool v0 = e < todo, v1 = e + WAVE < todo;
             const uint2 e0 = v0 ? *reinterpret_cast<const uint2 *>(work[wave][e]) : make_uint2(0u, 0u);
@@ -579,6 +583,13 @@ void k_bp_search(BpK k)
             if (v0) test(w0, g0, r0);
             if (v1) test(w1, g1, r1);
         }
+#else
+        for (uint32_t e = lane; e < todo; e += WAVE) {
+            const uint2 e0 = *reinterpret_cast<const uint2 *>(work[wave][e]);
+            const BpRec r0 = ((e0.x & STAT) ? k.s_recs : k.recs)[e0.x & IDX];
+            test(e0.x, e0.y, r0);
+        }
+#endif
         flush_hits();
     }
     if (!statics) return;
