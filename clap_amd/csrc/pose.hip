@@ -165,13 +165,22 @@ __device__ __forceinline__ Row affine_row(const float4 A, const Row B0, const Ro
     return o;
 }
 
+// One key value (vec3 / quat) as ONE load per lane: the pools are only 4-byte aligned, which global loads take
+// (unaligned access mode); as scalar loads every component was its own trip through the texture path -- a lane's keys
+// are nobody else's, so nothing coalesces -- 20 per lane and character instead of 6 (147.6 -> 137.3 us).
+typedef float key3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float key4 __attribute__((ext_vector_type(4), aligned(4)));
+
 constexpr int POSE_WAVES = 3;           // three waves per SIMD (168 VGPRs) run as fast as four (measured): the registers go to the joint constants
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
 
 // LPC = lanes per character (64, 128, 192 or 256); BLOCK threads = CPB characters per block.
 // A producer / consumer split of this chain inside a block (keyframe waves -> LDS -> hierarchy waves) was built in
-// round 2 and measured slower, 172 us against 145 (profiles/r02_experiments/pose_producer_consumer.md, commit af48632).
+// round 2 and measured slower, 172 us against 145 (profiles/r02_experiments/pose_producer_consumer.md, commit af48632);
+// so was a split into two launches (keyframe stage writing T/R/S, hierarchy stage reading them back): 66 + 78 us with
+// the keyframe stage at six wavefronts per SIMD, 85 + 78 us with all of the model's keys in LDS
+// (profiles/r02_experiments/pose_two_launches.md).
 // MODE 0: keyframes read through L2.  MODE 1: key times in LDS.  (Key VALUES in LDS as well -- one
 // 960-thread block per CU holding the model's whole 75 KiB pool -- was built and measured: no faster,
 // profiles/r01_experiments/pose_bounds.md.)
@@ -290,8 +299,8 @@ void k_pose(PoseArgs a)
                 key_bracket(t, n0, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
                 const float *d = kdata + e0.y;
-#pragma unroll
-                for (int k = 0; k < 3; k++) T[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
+                const key3 ka = *reinterpret_cast<const key3 *>(d + 3 * p), kb = *reinterpret_cast<const key3 *>(d + 3 * q);
+                T[0] = lerp_ref(ka.x, kb.x, fac); T[1] = lerp_ref(ka.y, kb.y, fac); T[2] = lerp_ref(ka.z, kb.z, fac);
             }
             if (n1 > 0) {
                 int p, q;
@@ -299,8 +308,9 @@ void k_pose(PoseArgs a)
                 key_bracket(t, n1, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
                 const float *d = kdata + e1.y;
-                const float qa[4] = { d[4 * p], d[4 * p + 1], d[4 * p + 2], d[4 * p + 3] };
-                const float qb[4] = { d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3] };
+                const key4 ka = *reinterpret_cast<const key4 *>(d + 4 * p), kb = *reinterpret_cast<const key4 *>(d + 4 * q);
+                const float qa[4] = { ka.x, ka.y, ka.z, ka.w };
+                const float qb[4] = { kb.x, kb.y, kb.z, kb.w };
                 slerp_ref(R, qa, qb, fac);
             }
             if (n2 > 0) {
@@ -309,8 +319,8 @@ void k_pose(PoseArgs a)
                 key_bracket(t, n2, time, top, p, q);
                 const float fac = key_fac(time, t[p], t[q]);
                 const float *d = kdata + e2.y;
-#pragma unroll
-                for (int k = 0; k < 3; k++) S[k] = lerp_ref(d[3 * p + k], d[3 * q + k], fac);
+                const key3 ka = *reinterpret_cast<const key3 *>(d + 3 * p), kb = *reinterpret_cast<const key3 *>(d + 3 * q);
+                S[0] = lerp_ref(ka.x, kb.x, fac); S[1] = lerp_ref(ka.y, kb.y, fac); S[2] = lerp_ref(ka.z, kb.z, fac);
             }
         }
 
