@@ -167,7 +167,8 @@ __device__ __forceinline__ Row affine_row(const float4 A, const Row B0, const Ro
 
 // One key value (vec3 / quat) as ONE load per lane: the pools are only 4-byte aligned, which global loads take
 // (unaligned access mode); as scalar loads every component was its own trip through the texture path -- a lane's keys
-// are nobody else's, so nothing coalesces -- 20 per lane and character instead of 6 (147.6 -> 137.3 us).
+// are nobody else's, so nothing coalesces -- 20 per lane and character instead of 6.  (Time-neutral in a same-session
+// A/B: 139-148 us either way; kept for the instruction count.)
 typedef float key3 __attribute__((ext_vector_type(3), aligned(4)));
 typedef float key4 __attribute__((ext_vector_type(4), aligned(4)));
 
