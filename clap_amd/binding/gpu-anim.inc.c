@@ -316,5 +316,6 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
                 animation_next(e, s);
         }
     }
+    if (gs) gpu_scene_run_deferred(gs, mq);                      /* joint-attached subtrees: the palettes of this frame are in place */
     return 0;
 }

@@ -65,7 +65,7 @@ struct gs_rec {
     uint32_t    flags;
     uint32_t    gen;            /* last frame this entity was met in the queue */
     uint32_t    order_pos;      /* its position in that frame's walk */
-    uint8_t     cls;            /* 0 unknown, 1 batched, 2 host */
+    uint8_t     cls;            /* 0 unknown, 1 batched, 2 host, 3 host but deferred behind the frame's pose (joint-attached subtrees) */
     uint8_t     self_ok;
     uint8_t     xform_dirty;    /* xform.updated as seen in step 3 (cleared in step 5, like default_update) */
     uint8_t     pending;        /* on the touched list (notification mode) */
@@ -96,6 +96,7 @@ struct gpu_scene {
     bool            cull_checked, cull_ok;                         /* the culled view's planes were compared since they last changed */
     uint32_t        *touched; uint32_t n_touched, cap_touched;
     uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
+    uint32_t        *deferred; uint32_t n_deferred, cap_deferred;  /* class 3 records in list order (last walk) */
     uint64_t        *posmap; uint32_t cap_posmap;                  /* scratch: bounding-volume candidates by queue position */
     uint32_t        *slots; uint32_t cap_slots;                    /* scratch: rebuilt slots of the frame */
     uint32_t        n_batched;
@@ -211,7 +212,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
-    free(gs->touched); free(gs->host_list); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
+    free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
 }
@@ -219,6 +220,18 @@ void gpu_scene_done(struct gpu_scene *gs)
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs) { return &gs->stats; }
 
 void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere) { gs->anim_elsewhere = elsewhere; }
+
+/* The joint-attached subtrees this frame's gpu_mq_update() held back (class 3), in list order, now that the parents'
+ * joint transforms of the frame exist.  Called by gpu_anim_update(); a frame driver without it calls this itself. */
+void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq)
+{
+    if (!gs || !mq) return;
+    for (uint32_t k = 0; k < gs->n_deferred; k++) {
+        struct gs_rec *r = &gs->rec[gs->deferred[k]];
+        if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE))
+            entity3d_update(r->e, mq->priv);
+    }
+}
 
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e)
 {
@@ -728,7 +741,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->n_touched = 0;
     gs->topology_pending = false;
     gs->last_fast = false;
-    gs->n_host = 0; gs->n_batched = 0;
+    gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0;
     clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);   /* the walk does the pick per entity */
 
     const double t0 = now_ms();
@@ -778,6 +791,18 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             if (!r->self_ok) {
                 r->cls = 2;
                 r->parent_e = e->parent; r->parent_rec = NO_REC;
+                /* With the pose computed after this update (gpu_anim_update), an entity riding a parent's joint
+                 * (model.c:1626-1641) must wait for it: the reference gives it the joint transforms of THIS frame,
+                 * written by the parent's animated_update earlier in the list.  It -- and everything below it -- is
+                 * run by gpu_scene_run_deferred(), which gpu_anim_update calls when the palettes are back. */
+                if (gs->anim_elsewhere && e->parent) {
+                    /* only behind a parent that comes EARLIER in the list: one that comes later is read one frame late
+                     * by the reference, joint transforms included, which running the hook right here reproduces */
+                    const uint32_t p = rec_find(gs, e->parent);
+                    if (p != NO_REC && gs->rec[p].gen == gs->gen &&
+                        (e->parent_joint != JOINT_TYPE_MAX || gs->rec[p].cls == 3))
+                        r->cls = 3;
+                }
             } else if (!e->parent) {
                 r->cls = 1;
             } else {
@@ -843,8 +868,12 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             }
         }
         if (r->cls != 1) {
-            entity3d_update(e, mq->priv);
             st->host++;
+            if (r->cls == 3) {                                   /* after the pose: gpu_scene_run_deferred() */
+                if (push_u32(&gs->deferred, &gs->n_deferred, &gs->cap_deferred, gs->order[k])) return _CERR_NOMEM;
+                continue;
+            }
+            entity3d_update(e, mq->priv);
             if (gs->notify && push_u32(&gs->host_list, &gs->n_host, &gs->cap_host, gs->order[k])) return _CERR_NOMEM;
             continue;
         }

@@ -85,6 +85,10 @@ struct view *gpu_scene_bound_view(void);
  * batched like any other and nothing runs animated_update for them here.
  */
 void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere);
+/* With the pose elsewhere, an entity riding a parent's JOINT (e->parent_joint, model.c:1626-1641) needs the joint
+ * transforms of the same frame, which exist only after gpu_anim_update(): gpu_mq_update() holds such entities and
+ * everything below them back, and this runs their own hooks, in list order (gpu_anim_update() ends with it). */
+void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq);
 /* true if `e` was updated on the device by the last gpu_mq_update() */
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);
 

@@ -765,8 +765,8 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
 /* ---------------------------------------------------------------- skeletal animation */
 struct aworld {
     struct scene    *scene;
-    model3d         model, prop_model;
-    model3dtx       txm, prop_txm;
+    model3d         model, prop_model, held_model;
+    model3dtx       txm, prop_txm, held_txm;                      /* list order: props, characters, held items */
     struct view     view;
     entity3d        **e;
     uint64_t        libc;
@@ -845,6 +845,8 @@ static void aworld_init(struct aworld *w, uint32_t cap, uint32_t J, uint64_t see
     memcpy(w->prop_model.aabb, (float[6]){ -1, -1, -1, 1, 1, 1 }, 24);
     txm_init(&w->scene->mq, &w->prop_txm, &w->prop_model);
     txm_init(&w->scene->mq, &w->txm, &w->model);
+    memcpy(w->held_model.aabb, (float[6]){ -0.2f, -0.2f, -0.6f, 0.2f, 0.2f, 0.6f }, 24);
+    txm_init(&w->scene->mq, &w->held_txm, &w->held_model);
     w->e = calloc(cap, sizeof(*w->e));
 }
 
@@ -866,7 +868,11 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
     gpu_scene_animation_elsewhere(gs, true);
 
     struct aworld WA, WB, *W[2] = { &WA, &WB };
-    const uint32_t n = n_chars + n_chars / 4 + 1;                       /* characters + a few plain props */
+    const uint32_t n_plain = n_chars + n_chars / 4 + 1;                 /* characters + a few plain props */
+    /* + entities riding a character's joint (model.c:1626-1641): "held" ones listed AFTER the characters, which get the
+     * joint transforms of the same frame; props listed BEFORE them, which the reference serves one frame late; and
+     * plain children of held items */
+    const uint32_t n_held = n_chars / 3 + 2, n = n_plain + 3 * n_held;
     dbl_now = 10.0;
     aworld_init(&WA, n, J, seed * 77 + 1);
     aworld_init(&WB, n, J, seed * 77 + 1);
@@ -883,8 +889,30 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
                     if (!reach[*c]) { reach[*c] = 1; grew = true; }
         }
     }
+    uint32_t *reach_list = calloc(J, sizeof(uint32_t)), n_reach = 0;
+    for (uint32_t j = 0; j < J; j++) if (reach[j]) reach_list[n_reach++] = j;
     for (uint32_t id = 0; id < n; id++) {
         const bool prop = id >= n_chars;
+        if (id >= n_plain) {
+            const uint32_t k3 = (id - n_plain) % 3, owner = rndn(n_chars), joint = reach_list[rndn(n_reach)];
+            vec3 hpos = { rndf(-0.5f, 0.5f), rndf(-0.5f, 0.5f), rndf(-0.5f, 0.5f) };
+            const float hx = rndf(-3, 3), hy = rndf(-3, 3), hsc = rndf(0.5f, 1.5f);
+            for (int k = 0; k < 2; k++) {
+                struct aworld *w = W[k];
+                entity3d *e = ref_new(entity3d, .txmodel = k3 == 1 ? &w->prop_txm : &w->held_txm);
+                entity3d_position(e, hpos);
+                entity3d_rotate(e, hx, hy, 0);
+                entity3d_scale(e, hsc);
+                if (k3 == 2) {
+                    e->parent = w->e[id - 2];                     /* a plain child of the held item created two ids ago */
+                } else {
+                    e->parent = w->e[owner];
+                    e->parent_joint = (int)joint;
+                }
+                w->e[id] = e;
+            }
+            continue;
+        }
         vec3 pos = { rndf(-300, 300), rndf(-5, 5), rndf(-300, 300) };
         const float ry = rndf(-3, 3), sc = rndf(0.7f, 1.3f), speed = rndf(0.5f, 2.f);
         const uint32_t start = rndn(4);                                  /* 0: empty queue -> "idle" with a random phase */
@@ -915,8 +943,8 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
     }
     WA.libc = WB.libc = s0;
 
-    uint64_t bad = 0, posed = 0, restarts = 0;
-    double worst = 0.0;
+    uint64_t bad = 0, posed = 0, restarts = 0, held_checked = 0;
+    double worst = 0.0, worst_held = 0.0;
     for (uint32_t f = 0; f < frames; f++) {
         dbl_now = 10.0 + 0.37 * f + (f % 4 == 3 ? 0.0 : 0.013 * f);
         for (uint32_t id = 0; id < n; id++) {
@@ -953,6 +981,14 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
             diff |= !!memcmp(a->mx, b->mx, 64) << 0;
             diff |= !!memcmp(a->aabb, b->aabb, sizeof(a->aabb)) << 1;
             diff |= (a->seq != b->seq) << 2;
+            if (id >= n_plain) {                                  /* rides a palette computed on the device: within the pose bar */
+                diff &= ~3;
+                const double em = rel_err((const float *)a->mx, (const float *)b->mx, 16);
+                const double eb = rel_err((const float *)a->aabb, (const float *)b->aabb, 6);
+                if (!(em <= 1e-5) || !(eb <= 1e-5)) diff |= 1 << 7;
+                if (em > worst_held) worst_held = em;
+                held_checked++;
+            }
             if (id < n_chars) {
                 diff |= (a->animation != b->animation || a->aniq.da.nr_el != b->aniq.da.nr_el) << 3;
                 diff |= !!memcmp(&a->ani_time, &b->ani_time, 8) << 4;
@@ -980,8 +1016,10 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
             restarts += WA.e[id]->ani_time == dbl_now;                   /* animation_start this frame */
     }
     printf("{\"mode\": \"anim\", \"frames\": %u, \"characters\": %u, \"joints\": %u, \"joint_poses_compared\": %llu, "
-           "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
-           frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, worst, (unsigned long long)bad);
+           "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"joint_attached_checks\": %llu, "
+           "\"worst_joint_attached_error\": %.3g, \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
+           frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, worst, (unsigned long long)held_checked,
+           worst_held, (unsigned long long)bad);
     gpu_anim_done(ga);
     gpu_scene_done(gs);
     return bad ? 1 : 0;

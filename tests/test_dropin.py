@@ -97,11 +97,16 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     (model3d_add_skinning, animation_new / _add_channel), entities from ref_new(entity3d) and queues from
     animation_push_by_name: transforms bit for bit; joint_transforms, joint T/R/S and joint positions within
     1e-5 of the largest magnitude; e->animation, the queue length, ani_time and the libc drand48 position (the
-    random idle phase of animation_next) exactly; joints outside joint 0's tree untouched on both sides."""
+    random idle phase of animation_next) exactly; joints outside joint 0's tree untouched on both sides.
+    Entities riding a character's joint (e->parent_joint, model.c:1626-1641) and their children: those listed after the
+    character get the joint transforms of the SAME frame (the binding holds them back until the pose is in place,
+    gpu_scene_run_deferred), those listed before it the previous frame's, as in the reference; their matrices and
+    boxes within the pose bar, their seq counters exactly."""
     r = _run("anim", n_chars, joints, frames, seed)
     assert r["mismatches"] == 0
     assert r["worst_relative_error"] <= 1e-5
     assert r["animation_restarts"] > 0 and r["joint_poses_compared"] == frames * n_chars * joints
+    assert r["joint_attached_checks"] == frames * 3 * (n_chars // 3 + 2) and r["worst_joint_attached_error"] <= 1e-5
 
 
 @pytest.mark.gpu
