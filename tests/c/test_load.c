@@ -272,6 +272,39 @@ int main(int argc, char **argv)
     spit(tmp, glb, n);
     CHECK(!clapgpu_load_scene(tmp_scene, NULL, out, err, sizeof(err)), "the intact copy: %s", err);
     free(glb);
+    /* the same for the scene file itself and for the .gltf with its base64 buffer: truncations and byte flips of the
+     * JSON text (the fixture's assets stay in place next to the damaged copy) */
+    {
+        char src[1024], dst[1024], cmd[4096];
+        snprintf(cmd, sizeof(cmd), "cp %s/hero.glb %s/crate.gltf %s/lamp.gltf %s/ 2>/dev/null", argv[1], argv[1], argv[1], argv[2]);
+        CHECK(system(cmd) == 0, "copying the assets");
+        static const char *victims[2] = { "scene.json", "crate.gltf" };
+        for (int v = 0; v < 2; v++) {
+            size_t jn = 0;
+            snprintf(src, sizeof(src), "%s/%s", argv[1], victims[v]);
+            snprintf(dst, sizeof(dst), "%s/%s", argv[2], victims[v]);
+            uint8_t *js = slurp(src, &jn);
+            CHECK(js != NULL, "reading %s", src);
+            snprintf(tmp_scene, sizeof(tmp_scene), "%s/scene.json", argv[2]);
+            if (v == 1) { size_t sn = 0; uint8_t *sj = slurp(scene, &sn); spit(tmp_scene, sj, sn); free(sj); }
+            for (size_t cut = 0; js && cut < jn; cut += 53) {
+                spit(dst, js, cut);
+                if (clapgpu_load_scene(tmp_scene, NULL, out, err, sizeof(err))) refused++; else loaded++;
+            }
+            for (int k = 0; js && k < 600; k++) {
+                uint8_t *b = malloc(jn);
+                memcpy(b, js, jn);
+                for (int j = 0; j < 2; j++) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; b[r % jn] = (uint8_t)(r >> 33); }
+                spit(dst, b, jn);
+                if (clapgpu_load_scene(tmp_scene, NULL, out, err, sizeof(err))) refused++; else loaded++;
+                free(b);
+            }
+            spit(dst, js, jn);
+            free(js);
+        }
+        snprintf(tmp_scene, sizeof(tmp_scene), "%s/scene.json", argv[2]);
+        CHECK(!clapgpu_load_scene(tmp_scene, NULL, out, err, sizeof(err)), "the intact scene copy: %s", err);
+    }
     printf("damaged inputs: %u refused, %u loaded\n", refused, loaded);
 #ifndef TEST_LOAD_NO_GPU
     replay(s);
