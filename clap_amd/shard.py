@@ -116,11 +116,13 @@ class VisibleExchange:
         if os.path.exists(path):
             L.clapgpu_exchange_set_library(path.encode())
         uid = (C.c_uint8 * 128)()
-        if rank == 0:
-            _lib.check(L.clapgpu_exchange_unique_id(uid), "clapgpu_exchange_unique_id")
+        if rank == 0 and L.clapgpu_exchange_unique_id(uid) != 0:
+            uid = (C.c_uint8 * 128)()                        # all zero = "no id": every rank then takes the fallback together
         t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
-        dist.broadcast(t, src=0)
+        dist.broadcast(t, src=0)                             # rank 0 always takes part, whatever happened above
         raw = (C.c_uint8 * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        if not any(raw):
+            raise RuntimeError("rank 0 could not create an RCCL unique id: " + (L.clapgpu_last_error() or b"").decode())
         x = C.c_void_p()
         _lib.check(L.clapgpu_exchange_create(C.byref(x), raw, rank, world), "clapgpu_exchange_create")
         return x
