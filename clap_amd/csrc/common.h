@@ -71,6 +71,8 @@ __device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4],
 // inputs out of the 256 MB infinity cache: neutral at 1 M entities (everything fits), 112 -> 78 us at
 // 2 M entities, where the outputs alone are 330 MB.
 typedef float clapgpu_f4 __attribute__((ext_vector_type(4)));
+typedef float clapgpu_f2 __attribute__((ext_vector_type(2)));
+typedef float clapgpu_f3 __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 {
 #ifdef CLAPGPU_PLAIN_STORES          // A/B builds only (tools/profile_entities_scale.sh): default-policy stores

@@ -294,6 +294,88 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
     }
 }
 
+// The common row of a tile walk, as straight-line code: all 64 lanes alive and rebuilt, every parent in the
+// previous row's registers (or none), no joint attachment, every model with a box (taken from the LDS copy `mt` of
+// the model table), no camera query.  Same arithmetic as process_row; what differs is what the wavefront waits for.
+// gfx950 has one counter for vector loads AND stores, retired in issue order: a wait for the newest load is a wait
+// for every store before it.  process_row loads the model table (and, on its other paths, parents) between the
+// previous row's stores and its own arithmetic, and its stores sit in branches, so the compiler can only wait for
+// "everything" there and again before the row hand-over -- each row's 10 KB of stores was drained twice while the
+// SIMD idled.  Here no vector load is issued between the prefetch of the next row and the hand-over, and the big
+// stores are unconditional, so the hand-over waits for "all but the last N operations" and the stores stay in
+// flight under the next row's arithmetic.
+template <bool CULL>
+__device__ __forceinline__ void process_row_fast(const EntK &e, const RowIn &in, float4 *tile, const float4 *mt,
+                                                 const int lane, const uint32_t row_first, const uint32_t mode,
+                                                 const lmd::FrustumK &fr, const int src, const uint32_t parent_seq_now,
+                                                 float (&carry_mx)[16], uint32_t &carry_seq)
+{
+    const uint32_t i = row_first + lane;
+    const uint32_t fl = in.fl;
+    const int32_t p = in.p;
+    uint32_t seq = in.sq & 0xffffu, pseq = in.sq >> 16;
+    float pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pm[k] = __shfl(carry_mx[k], src);
+    if (p >= 0) pseq = parent_seq_now;
+
+    const float4 lo = mt[2 * in.mi], hi = mt[2 * in.mi + 1];
+    float mx[16], inv[16], bb[6], ctr[3], local_mx[16];
+    lmd::trs(local_mx, in.ps.x, in.ps.y, in.ps.z, in.ps.w, in.q.x, in.q.y, in.q.z, in.q.w);
+    if (p >= 0) {
+        lmd::mul(mx, pm, local_mx);                              // model.c:1625
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
+    }
+    lmd::invert(inv, mx);
+    lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+    seq = (seq + 1) & 0xffffu;
+#pragma unroll
+    for (int k = 0; k < 16; k++) carry_mx[k] = mx[k];
+    carry_seq = seq;
+
+    const size_t e0 = row_first;
+    float4 *tile_a = tile, *tile_b = tile + 256;
+    float *tile_f = reinterpret_cast<float *>(tile);
+    float4 va[4], vb[4];
+    stage_mat4(tile_a, mx, lane);
+    stage_mat4(tile_b, inv, lane);
+    wave_lds_fence();
+    unstage_mat4(tile_a, va, lane);
+    unstage_mat4(tile_b, vb, lane);
+    store_mat4_rows(e.mx + 16 * e0, va, lane, WAVE);
+    store_mat4_rows(e.inv_mx + 16 * e0, vb, lane, WAVE);
+    e.seqs[i] = seq | (pseq << 16);
+    wave_lds_fence();
+    // every store below is issued by all 64 lanes, none under a lane test: a store in a branch is one the compiler
+    // cannot count.  The row's 1536 B of boxes = one 16-byte and one 8-byte piece per lane; the centres are the
+    // lanes' own 12 bytes in lane order already.
+    stage_rows<6>(tile_f, bb, lane);
+    wave_lds_fence();
+    {
+        float *ab = e.aabb + 6 * e0;
+        store_stream(&reinterpret_cast<float4 *>(ab)[lane], reinterpret_cast<const float4 *>(tile_f)[lane]);
+        const float2 t2 = reinterpret_cast<const float2 *>(tile_f + 4 * WAVE)[lane];
+        const clapgpu_f2 v2 = { t2.x, t2.y };
+        __builtin_nontemporal_store(v2, reinterpret_cast<clapgpu_f2 *>(ab + 4 * WAVE) + lane);
+        const clapgpu_f3 v3 = { ctr[0], ctr[1], ctr[2] };
+        __builtin_nontemporal_store(v3, reinterpret_cast<clapgpu_f3 *>(e.center + 3 * (e0 + lane)));   // sizeof(f3) is 16: index in floats
+    }
+    wave_lds_fence();
+    if (!(mode & CLAPGPU_UPDATE_ALL_DIRTY) && (fl & CLAPGPU_E_DIRTY))
+        e.flags[i] = fl & ~CLAPGPU_E_DIRTY;                      // transform_clear_updated
+    if (e.rebuilt_mask && lane == 0) e.rebuilt_mask[row_first >> 6] = ~0ull;
+    if (CULL) {
+        bool vis = (fl & CLAPGPU_E_VISIBLE) != 0;                                      // model.c:959-965
+        if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
+            vis = lmd::aabb_in_frustum_fast(fr, bb);                                  // model.c:967-971
+        const uint64_t m = __ballot(vis);
+        e.vis_mask[e0 >> 6] = m;                                 // the same word from all 64 lanes: one request
+        e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);
+    }
+}
+
 // model.c:1618-1622 + 1633-1639: local = TRS of the attached entity, joint_mx = joint_transforms[j] * bind[j],
 // attach_local = joint_mx * local.  One lane per attachment (there are few).
 __global__ __launch_bounds__(ENT_BLOCK)
@@ -341,6 +423,7 @@ void k_entities_level(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd
 // One launch for the whole forest: wave t walks tile t = rows [tile_row_start[t], tile_row_start[t+1]),
 // row r = entities [64r, 64r+64) = one hierarchy level of the subtrees packed into the tile.
 // The next row's inputs are in flight while the current row is computed.
+constexpr int ENT_MT_CAP = 256;       // models whose table the tile kernel keeps in LDS (8 KiB); more: general loop only
 constexpr int ENT_TILE_WAVES = 1;       // occupancy hint; 4 measured the same 44 us
 // The frustum (63 dwords) is the FIRST kernel argument and is read where it is used, through the kernarg segment
 // pointer, with the pointer laundered once per row: held in SGPRs across the row loop next to ~30 array pointers it
@@ -352,13 +435,22 @@ void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_sta
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)fr_arg;
-    const lmd::FrustumK *frp = (const lmd::FrustumK *)__builtin_amdgcn_kernarg_segment_ptr();
+    // kept in the constant address space through the laundering below: the planes then come through the scalar cache
+    // (s_load, counted with LDS), not as flat loads, whose wait is a wait for every vector store before them
+    typedef const __attribute__((address_space(4))) lmd::FrustumK *frustum_ptr;
+    frustum_ptr frp = (frustum_ptr)__builtin_amdgcn_kernarg_segment_ptr();
 #else
-    const lmd::FrustumK *frp = &fr_arg;                          // host pass of the compiler only
+    typedef const lmd::FrustumK *frustum_ptr;
+    frustum_ptr frp = &fr_arg;                                   // host pass of the compiler only
 #endif
     __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
+    __shared__ float4 mt_lds[2 * ENT_MT_CAP];                    // the model table, for process_row_fast
     const int lane = lane_id();
-    const int wave = threadIdx.x / WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // uniform, and known to be: the row loops stay scalar
+    const bool mt_cached = e.n_models <= (uint32_t)ENT_MT_CAP;
+    if (mt_cached)
+        for (uint32_t k = threadIdx.x; k < 2 * e.n_models; k += ENT_BLOCK) mt_lds[k] = e.model_table[k];
+    __syncthreads();                                             // the only workgroup barrier: ahead of every return
     const uint32_t t = blockIdx.x * (ENT_BLOCK / WAVE) + wave;
     if (t >= n_tiles)
         return;
@@ -378,14 +470,57 @@ void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_sta
     uint32_t row_first = row * WAVE;
     uint32_t row_count = n - row_first < WAVE ? n - row_first : WAVE;
     RowIn cur = load_row(e, lane, row_first, row_count);
+
+    // ---- rows that qualify for process_row_fast, until the first one that does not: the rest of the tile (and every
+    // tile of a launch with a camera query or a model table too large for LDS) goes through the general loop below.
+    // Two loops, not a branch inside one: the straight-line loop must never be re-entered from a path whose stores
+    // the compiler cannot count.
+    if (mt_cached && e.bv_result == nullptr) {
+        // the first row's inputs are waited for HERE: left pending into the loop, their wait would sit inside it and,
+        // on the way round, stand for "all but seven operations" -- the previous row's stores again
+        asm volatile("" : : "v"(cur.ps.w), "v"(cur.q.w), "v"(cur.fl), "v"(cur.sq), "v"(cur.mi), "v"(cur.p));
+        for (;;) {
+            const uint32_t fl = cur.fl;
+            const int32_t p = cur.p;
+            const bool in_prev = have_prev && p >= 0 && (uint32_t)p >= row_first - WAVE && (uint32_t)p < row_first;
+            const int src = in_prev ? (int)((uint32_t)p - (row_first - WAVE)) : lane;
+            const uint32_t parent_seq_now = __shfl(carry_seq, src);
+            const bool parent_ok = p < 0 || (in_prev && __shfl((int)carry_valid, src) != 0);
+            const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
+            const bool rebuild = p >= 0 ? !((cur.sq >> 16) == parent_seq_now && !dirty) : dirty;
+            const bool lane_ok = (fl & CLAPGPU_E_ALIVE) && rebuild && parent_ok &&
+                                 !((fl & CLAPGPU_E_JOINT_ATTACHED) && e.n_attach) &&
+                                 __float_as_uint(mt_lds[2 * cur.mi].w) == 0u;
+            if (row_count != WAVE || __ballot(lane_ok) != ~0ull)
+                break;
+            const uint32_t next = row + 1;
+            const bool more = next < row_end;
+            const uint32_t nfirst = more ? next * WAVE : row_first;
+            const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
+            const RowIn nxt = load_row(e, lane, nfirst, ncount);
+            frustum_ptr frr = frp;
+            asm volatile("" : "+s"(frr));
+            process_row_fast<CULL>(e, cur, lds_tiles[wave], mt_lds, lane, row_first, mode, *(const lmd::FrustumK *)frr, src, parent_seq_now,
+                                   carry_mx, carry_seq);
+            carry_valid = true;
+            if (!more)
+                return;
+            have_prev = true;
+            cur = nxt;
+            row = next;
+            row_first = nfirst;
+            row_count = ncount;
+        }
+    }
     for (;;) {
         const uint32_t next = row + 1;
         const bool more = next < row_end;
         const uint32_t nfirst = more ? next * WAVE : row_first;  // last row: harmless re-load
         const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
         const RowIn nxt = load_row(e, lane, nfirst, ncount);     // in flight during process_row
-        asm volatile("" : "+s"(frp));                            // the planes are re-read (scalar cache) each row
-        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, *frp,
+        frustum_ptr frr = frp;
+        asm volatile("" : "+s"(frr));                            // the planes are re-read (scalar cache) each row
+        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, *(const lmd::FrustumK *)frr,
                                 have_prev, row_first - WAVE, carry_mx, carry_seq, carry_valid);
         if (!more)
             break;
