@@ -176,6 +176,252 @@ constexpr int POSE_WAVES = 3;           // three waves per SIMD (168 VGPRs) run 
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
 constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
 
+// ---- the one-wavefront-per-character loop without store waits ---------------------------------------------------
+// gfx950 retires vector loads and stores through ONE counter, in issue order: waiting for a load means waiting for
+// every store issued before it, and the compiler can only wait for "all but the last N operations" when it can count
+// the operations behind the load on every path.  The general loop below cannot offer that (its stores sit in lane
+// and row tests, its key gathers follow the previous character's stores), so each character's first load waits for
+// the previous character's 11 KB of stores to be acknowledged by memory while the SIMD's other two wavefronts do the
+// same.  Here:
+//   * every store is a buffer store issued by all 64 lanes under no branch; rows shorter than 64 joints, characters
+//     past the end and masked outputs are clipped by the descriptor's size (range check per dword), not by exec;
+//   * per-character scalars (animation id, frame time, entity matrix, root pose) come through the scalar cache;
+//   * the order per character g is: interpolate g's keys -> search + gather the keys of g+1 -> hierarchy and palette
+//     of g -> request the channel records of g+2's... of the character after next -> stores of g.  Every wait is then
+//     for an operation with a known number of younger ones behind it, and the gathers of g+1 fly under g's
+//     hierarchy rounds.
+typedef int pose_v4i __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) float *pose_cfloat;
+typedef const __attribute__((address_space(4))) uint32_t *pose_cu32;
+constexpr int POSE_RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit data format
+
+__device__ __forceinline__ void buffer_store4(const float4 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off, bool stream)
+{
+    const pose_v4i d = { __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w) };
+    if (stream) __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 2);      // nt
+    else __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 0);
+}
+
+struct PoseKeys { key3 ta, tb; key4 ra, rb; key3 sa, sb; float f0, f1, f2; };
+
+// The three paths' searches as ONE loop: three independent LDS reads per step instead of three loops of five dependent
+// ones (114.7 / 121.6 / 115.6 us against 131.6 / 121.9 / 129.4 in a same-session A/B; in the general loop, whose
+// wavefronts wait on their stores anyway, the same interleaving measured slower).
+__device__ __forceinline__ PoseKeys pose_gather_keys(const float *times, const float *kdata, int top, float time,
+                                                     const uint4 e0, const uint4 e1, const uint4 e2)
+{
+    PoseKeys k;
+    const float *t0 = times + e0.x, *t1 = times + e1.x, *t2 = times + e2.x;
+    const int n0 = (int)e0.z, n1 = (int)e1.z, n2 = (int)e2.z;
+    int l0 = 0, l1 = 0, l2 = 0;
+    for (int step = top; step > 0; step >>= 1) {
+        const int c0 = l0 + step, c1 = l1 + step, c2 = l2 + step;
+        const float a0 = t0[c0 <= n0 ? c0 - 1 : 0], a1 = t1[c1 <= n1 ? c1 - 1 : 0], a2 = t2[c2 <= n2 ? c2 - 1 : 0];
+        if (c0 <= n0 && a0 < time) l0 = c0;
+        if (c1 <= n1 && a1 < time) l1 = c1;
+        if (c2 <= n2 && a2 < time) l2 = c2;
+    }
+    // model.c:1266-1288's wrap (time before the first / past the last key) without reading t[0] and t[nr - 1] again:
+    // lo counts the keys below `time`, so lo == nr <=> time > t[nr - 1], and with lo == 0 the bracket's own first
+    // key IS t[0].  Six LDS reads per joint and character fewer; a wrapped lane (rare) re-reads its two keys.
+    auto finish = [&](const float *t, int nr, int lo, int &prev, int &next, float &tp, float &tn) {
+        prev = lo > 0 ? lo - 1 : 0;
+        next = prev + 1 < nr - 1 ? prev + 1 : nr - 1;
+        tp = t[prev]; tn = t[next];
+        if (lo == nr || (lo == 0 && time < tp)) {
+            prev = nr - 1; next = 0;
+            tp = t[prev]; tn = t[next];
+        }
+    };
+    int p0, q0, p1, q1, p2, q2;
+    float tp0, tn0, tp1, tn1, tp2, tn2;
+    finish(t0, n0, l0, p0, q0, tp0, tn0); finish(t1, n1, l1, p1, q1, tp1, tn1); finish(t2, n2, l2, p2, q2, tp2, tn2);
+    const float *d0 = kdata + e0.y, *d1 = kdata + e1.y, *d2 = kdata + e2.y;
+    k.ta = *reinterpret_cast<const key3 *>(d0 + 3 * p0); k.tb = *reinterpret_cast<const key3 *>(d0 + 3 * q0);
+    k.ra = *reinterpret_cast<const key4 *>(d1 + 4 * p1); k.rb = *reinterpret_cast<const key4 *>(d1 + 4 * q1);
+    k.sa = *reinterpret_cast<const key3 *>(d2 + 3 * p2); k.sb = *reinterpret_cast<const key3 *>(d2 + 3 * q2);
+    k.f0 = key_fac(time, tp0, tn0);
+    k.f1 = key_fac(time, tp1, tn1);
+    k.f2 = key_fac(time, tp2, tn2);
+    return k;
+}
+
+template <int CPB>
+__device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, const float *times, const float *kdata,
+                                                 const int top, uint4 e0, uint4 e1, uint4 e2, const float4 *jconst,
+                                                 const int parent, const int j, const int cib_v)
+{
+    constexpr int LPC = WAVE;
+    const int lane = j;
+    const uint32_t J = a.J;
+    const uint32_t cib = (uint32_t)__builtin_amdgcn_readfirstlane(cib_v);
+    const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
+    const uint32_t jc = (uint32_t)j < J ? (uint32_t)j : J - 1;
+    const pose_cu32 anim_s = (pose_cu32)a.anim, entity_s = (pose_cu32)a.entity;
+    const pose_cfloat time_s = (pose_cfloat)a.frame_time, root_s = (pose_cfloat)a.root_pose;
+    const bool with_trs = !(a.skip & CLAPGPU_POSE_SKIP_TRS), with_pos = !(a.skip & CLAPGPU_POSE_SKIP_JOINT_POS);
+
+    auto char_of = [&](uint32_t g_) {                            // past the end: a valid character whose stores are clipped
+        const uint32_t c_ = g_ * CPB + cib;
+        return c_ < a.n_chars ? c_ : a.n_chars - 1;
+    };
+    auto anim_of = [&](uint32_t c_) { const uint32_t an = anim_s[c_]; return an < a.n_anims ? an : 0u; };
+
+    // Per-character scalars travel one character ahead in SGPRs: a scalar load consumed where it is issued costs its
+    // round trip to L2 (the scalar cache does not hold 50 000 characters' worth), three of them per character.
+    auto entity_of = [&](uint32_t c_) { return a.entity ? entity_s[c_] : c_; };
+    uint32_t g = blockIdx.x;
+    const uint32_t c0 = char_of(g), c1 = char_of(g + gridDim.x);
+    // the character's entity matrix: element (lane & 15) per lane, one vector load a character ahead, read back with
+    // v_readlane where joint positions are formed (as a scalar load its 64 bytes were waited for where they were asked for)
+    float em_v = with_pos ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
+    float tm_next = time_s[c1];
+    // the first character's keys (its channel records were requested by the caller) -- waited for HERE, so that no
+    // wait for them is left pending into the loop, where it would stand for "all but a few operations" on the way round
+    PoseKeys kv = pose_gather_keys(times, kdata, top, time_s[c0], e0, e1, e2);
+    {
+        const uint4 *tab = a.chan_table + ((size_t)anim_of(c1) * J + jc) * 3;
+        e0 = tab[0]; e1 = tab[1]; e2 = tab[2];
+    }
+    asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x),
+                        "v"(e0.x), "v"(e1.x), "v"(e2.x), "v"(em_v));
+
+    for (; g < n_groups; g += gridDim.x) {
+        const uint32_t c_raw = g * CPB + cib;
+        const bool c_ok = c_raw < a.n_chars;                     // wave-uniform
+        const uint32_t c = c_ok ? c_raw : a.n_chars - 1;
+        // scalars of the characters after this one: issued now, consumed a phase or a character later
+        const uint32_t c2 = char_of(g + 2 * gridDim.x);
+        const uint32_t an2 = anim_of(c2);
+        const float tm_next2 = time_s[c2];
+        const uint32_t ei_next = entity_of(char_of(g + gridDim.x));
+
+        // ---- 1. this character's T, R, S from its keys
+        float T[3], R[4], S[3];
+        T[0] = lerp_ref(kv.ta.x, kv.tb.x, kv.f0); T[1] = lerp_ref(kv.ta.y, kv.tb.y, kv.f0); T[2] = lerp_ref(kv.ta.z, kv.tb.z, kv.f0);
+        {
+            const float qa[4] = { kv.ra.x, kv.ra.y, kv.ra.z, kv.ra.w };
+            const float qb[4] = { kv.rb.x, kv.rb.y, kv.rb.z, kv.rb.w };
+            slerp_ref(R, qa, qb, kv.f1);
+        }
+        S[0] = lerp_ref(kv.sa.x, kv.sb.x, kv.f2); S[1] = lerp_ref(kv.sa.y, kv.sb.y, kv.f2); S[2] = lerp_ref(kv.sa.z, kv.sb.z, kv.f2);
+
+        // ---- 2. the next character's key search (LDS) and key gathers, in flight under the hierarchy below
+        kv = pose_gather_keys(times, kdata, top, tm_next, e0, e1, e2);
+
+        // ---- 3. hierarchy by pointer jumping, palette, joint position: as in the general loop
+        Row M0, M1, M2;
+        {
+            const float qa = R[3], qb = R[0], qc = R[1], qd = R[2];
+            const float a2 = qa * qa, b2 = qb * qb, c2 = qc * qc, d2 = qd * qd;
+            const float bc = qb * qc, ad = qa * qd, bd = qb * qd, ac = qa * qc, cd = qc * qd, ab = qa * qb;
+            const v2f s01 = { S[0], S[1] };
+            M0.lo = v2f{ a2 + b2 - c2 - d2, 2.f * (bc - ad) } * s01;  M0.hi = v2f{ 2.f * (bd + ac) * S[2], T[0] };
+            M1.lo = v2f{ 2.f * (bc + ad), a2 - b2 + c2 - d2 } * s01;  M1.hi = v2f{ 2.f * (cd - ab) * S[2], T[1] };
+            M2.lo = v2f{ 2.f * (bd - ac), 2.f * (cd + ab) } * s01;    M2.hi = v2f{ (a2 - b2 - c2 + d2) * S[2], T[2] };
+        }
+        int anc = parent;
+        {
+            float4 *slots = reinterpret_cast<float4 *>(G);
+            const int sw_me = (j >> 2) & 3;
+            for (uint32_t st = 0; st < a.n_jump_steps; st++) {
+                slots[4 * j + (0 ^ sw_me)] = f4_of(M0);
+                slots[4 * j + (1 ^ sw_me)] = f4_of(M1);
+                slots[4 * j + (2 ^ sw_me)] = f4_of(M2);
+                reinterpret_cast<int *>(&slots[4 * j + (3 ^ sw_me)])[0] = anc;
+                wave_lds_fence();
+                const int src = anc >= 0 ? anc : LPC;
+                const int sw = (src >> 2) & 3;
+                const float4 A0 = slots[4 * src + (0 ^ sw)];
+                const float4 A1 = slots[4 * src + (1 ^ sw)];
+                const float4 A2 = slots[4 * src + (2 ^ sw)];
+                anc = reinterpret_cast<const int *>(&slots[4 * src + (3 ^ sw)])[0];
+                wave_lds_fence();
+                const Row B0 = M0, B1 = M1, B2 = M2;
+                M0 = affine_row(A0, B0, B1, B2);
+                M1 = affine_row(A1, B0, B1, B2);
+                M2 = affine_row(A2, B0, B1, B2);
+            }
+        }
+        float Gm[16];
+        {
+            const float4 m0 = f4_of(M0), m1 = f4_of(M1), m2 = f4_of(M2);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float p0 = root_s[r], p1 = root_s[4 + r], p2 = root_s[8 + r], p3 = root_s[12 + r];
+                E_(Gm, 0, r) = p0 * m0.x + p1 * m1.x + p2 * m2.x;
+                E_(Gm, 1, r) = p0 * m0.y + p1 * m1.y + p2 * m2.y;
+                E_(Gm, 2, r) = p0 * m0.z + p1 * m1.z + p2 * m2.z;
+                E_(Gm, 3, r) = p0 * m0.w + p1 * m1.w + p2 * m2.w + p3;
+            }
+        }
+        // the joint's constants (invmx, column 3 of bind) come from LDS here: held in registers across characters, as the
+        // general loop holds them, they push this loop's extra live values (the next character's keys) into scratch
+        float JT[16], pos[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+            const float4 im = jconst[cc * WAVE + j];             // column cc of invmx
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                E_(JT, cc, r) = E_(Gm, 0, r) * im.x + E_(Gm, 1, r) * im.y + E_(Gm, 2, r) * im.z + E_(Gm, 3, r) * im.w;
+        }
+        if (with_pos) {                                          // uniform
+            const float4 b3 = jconst[4 * WAVE + j];
+            const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
+            float mpos[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float sm = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sm += E_(JT, k, r) * bv[k];
+                mpos[r] = sm;
+            }
+            float em[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) em[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(em_v), k));
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                pos[r] = E_(em, 0, r) * mpos[0] + E_(em, 1, r) * mpos[1] + E_(em, 2, r) * mpos[2] + E_(em, 3, r) * mpos[3];
+        }
+
+        // ---- 4. the channel records of the character after next, ahead of the stores
+        {
+            const uint4 *tab = a.chan_table + ((size_t)an2 * J + jc) * 3;
+            e0 = tab[0]; e1 = tab[1]; e2 = tab[2];
+        }
+        if (with_pos) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
+        tm_next = tm_next2;
+
+        // ---- 5. stores: all lanes, no branch; the descriptors clip
+        const size_t row0 = (size_t)c * J;
+        const __amdgpu_buffer_rsrc_t rs_trs = __builtin_amdgcn_make_buffer_rsrc(a.trs + 10 * row0, 0, (c_ok && with_trs) ? (int)(J * 40u) : 0, POSE_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs_jt = __builtin_amdgcn_make_buffer_rsrc(a.joint_transforms + 16 * row0, 0, c_ok ? (int)(J * 64u) : 0, POSE_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc(a.joint_pos ? a.joint_pos + 4 * row0 : a.joint_transforms, 0, (c_ok && with_pos) ? (int)(J * 16u) : 0, POSE_RSRC_FLAGS);
+        float *tile_f = G;
+        float4 *tile = reinterpret_cast<float4 *>(tile_f);
+        {
+            const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
+            stage_rows<10>(tile_f, trs_row, lane);
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 3; k++)                           // 160 16-byte pieces; the third round's upper half lies past the row
+                buffer_store4(tile[k * WAVE + lane], rs_trs, (uint32_t)(k * WAVE + lane) * 16u, true);
+            wave_lds_fence();
+        }
+        {
+            float4 v[4];
+            stage_mat4(tile, JT, lane);
+            wave_lds_fence();
+            unstage_mat4(tile, v, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                buffer_store4(v[k], rs_jt, (uint32_t)(k * WAVE + lane) * 16u, false);
+            buffer_store4(make_float4(pos[0], pos[1], pos[2], pos[3]), rs_pos, (uint32_t)lane * 16u, false);
+            wave_lds_fence();
+        }
+    }
+}
+
 // LPC = lanes per character (64, 128, 192 or 256); BLOCK threads = CPB characters per block.
 // A producer / consumer split of this chain inside a block (keyframe waves -> LDS -> hierarchy waves) was built in
 // round 2 and measured slower, 172 us against 145 (profiles/r02_experiments/pose_producer_consumer.md, commit af48632);
@@ -201,6 +447,8 @@ void k_pose(PoseArgs a)
     __shared__ __attribute__((aligned(16))) float g_lds[CPB][(LPC + 1) * G_STRIDE];
     constexpr bool LDS_TIMES = MODE >= 1;
     __shared__ float times_lds[LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
+    constexpr bool STREAM = LPC == WAVE && MODE == 1;            // pose_stream_loop's instantiation
+    __shared__ float4 jconst_lds[STREAM ? 5 * WAVE : 1];         // per joint: the four columns of invmx, column 3 of bind
 
     const int tid = threadIdx.x;
     const int cib = tid / LPC, j = tid % LPC;
@@ -221,18 +469,28 @@ void k_pose(PoseArgs a)
         idn[3] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
     }
     // first step of the key searches: the highest set bit of the model's longest channel (block-uniform)
-    __shared__ uint32_t nr_or;
-    if (tid == 0) nr_or = 0;
+    __shared__ uint32_t nr_or, not_streamable;
+    if (tid == 0) { nr_or = 0; not_streamable = 0; }
     __syncthreads();
     {
-        uint32_t m = 0;
-        for (uint32_t q = tid; q < a.n_anims * J * 3; q += blockDim.x)
-            m |= a.chan_table[q].z;
+        uint32_t m = 0, bad = 0;
+        for (uint32_t q = tid; q < a.n_anims * J * 3; q += blockDim.x) {
+            const uint32_t nr = a.chan_table[q].z;
+            m |= nr;
+            bad |= (int)nr <= 0;                                 // a path without a channel keeps its stored value: general loop
+        }
         if (m) atomicOr(&nr_or, m);
+        if (bad || (lane_joint && !reachable)) atomicOr(&not_streamable, 1u);
     }
     if (LDS_TIMES) {
         for (uint32_t q = tid; q < a.n_times; q += blockDim.x)
             times_lds[q] = a.times[q];
+    }
+    if (STREAM && tid < WAVE) {
+        const uint32_t jq = (uint32_t)tid < J ? (uint32_t)tid : J - 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) jconst_lds[q * WAVE + tid] = a.invmx[4 * jq + q];
+        jconst_lds[4 * WAVE + tid] = a.bind[4 * jq + 3];
     }
     __syncthreads();
     const float *times = LDS_TIMES ? times_lds : a.times;
@@ -273,6 +531,16 @@ void k_pose(PoseArgs a)
         bv[0] = b3.x; bv[1] = b3.y; bv[2] = b3.z; bv[3] = b3.w;
     }
 
+    if constexpr (LPC == WAVE && MODE == 1) {
+        // One wavefront per character, every joint animated on all three paths and under joint 0, outputs within
+        // 2 GB: the loop below, in which the wavefront never waits for its own stores.  (A block's four wavefronts
+        // share nothing but the key times; there is no block barrier past this point.)
+        const uint64_t out_bytes = (uint64_t)a.n_chars * J * 64u;
+        if (!not_streamable && out_bytes < (1ull << 31)) {
+            pose_stream_loop<CPB>(a, G, times, kdata, top, cur.e0, cur.e1, cur.e2, jconst_lds, lane_joint ? parent : -1, j, cib);
+            return;
+        }
+    }
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint32_t c = g * CPB + cib;
         const bool char_ok = cib < CPB && c < a.n_chars;

@@ -9,6 +9,7 @@ import glob
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from clap_amd import synth
@@ -84,6 +85,57 @@ def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
         assert_close(out["trs"], trs, f"frame {f} T/R/S")
         assert_close(out["joint_transforms"][:, reach], jt[:, reach], f"frame {f} joint_transforms")
         assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
+
+
+@pytest.mark.parametrize("J", [64, 40, 1], ids=["64j", "40j_short_rows", "one_joint"])
+def test_pose_streaming_loop_clips_rows_masks_and_tail(J, cuda_device):
+    """The one-wavefront-per-character loop (every joint animated on all paths and reachable) stores through buffer
+    descriptors that clip rows shorter than 64 joints, the characters past the end of the last group and masked
+    outputs: the arrays carry guard values around and inside them that must survive, characters map to entity
+    matrices through an index list, key counts are ragged (incl. channels of two keys) and the times reach
+    before the first / past the last key."""
+    from clap_amd import animation
+    n = 1003                                                        # not a multiple of the 4 characters of a block
+    sk = synth.skeleton(J, min(8, J), seed=31)
+    an0 = synth.animation(J, 30, 2.0, seed=31, ragged=True)
+    an1 = synth.animation(J, 2, 1.0, seed=32)
+    ch = synth.characters(n, J, seed=31)
+    sk["bind"] = ob.skeleton_bind(sk)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n + 7).astype(np.uint32)[:n]             # character -> entity (matrices of n + 7 entities)
+    ent_mx = rng.standard_normal((n + 7, 16)).astype(np.float32)
+    model = animation.SkinnedModel(sk, [an0, an1], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ent_mx, entity_index=perm)
+    which = (np.arange(n) % 4 == 1).astype(np.int32)
+    t = ((ch["phase"] * 1.3) - 0.2).astype(np.float32)              # some below 0, some past an1's end
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    jt = np.zeros((n, J, 16), np.float32)
+    jp = np.zeros((n, J, 4), np.float32)
+    for a_id, an in ((0, an0), (1, an1)):
+        sel = np.flatnonzero(which == a_id)
+        sub = trs[sel].copy()
+        j1, _g, p1 = ob.pose(sk, an, t[sel], ent_mx[perm[sel]], sub)
+        trs[sel], jt[sel], jp[sel] = sub, j1, p1
+    batch.set_frame_times(t, which)
+    reach = sk["order"]
+    for trs_on, pos_on in ((True, True), (False, True), (True, False), (False, False)):
+        batch.trs.fill_(7.5); batch.joint_transforms.fill_(-3.25); batch.joint_pos.fill_(9.0)
+        batch.trs.copy_(torch.from_numpy(np.tile(ch["trs0"], (n, 1, 1))))
+        if not trs_on:
+            batch.trs.fill_(7.5)
+        batch.set_outputs(trs=trs_on, joint_pos=pos_on)
+        batch.pose_update()
+        out = batch.download()
+        what = f"J={J} trs={trs_on} pos={pos_on}"
+        if trs_on:
+            assert_close(out["trs"], trs, what + " T/R/S")
+        else:
+            assert (out["trs"] == 7.5).all(), what + ": masked T/R/S was written"
+        assert_close(out["joint_transforms"][:, reach], jt[:, reach], what + " joint_transforms")
+        if pos_on:
+            assert_close(out["joint_pos"][:, reach], jp[:, reach], what + " joint pos")
+        else:
+            assert (out["joint_pos"] == 9.0).all(), what + ": masked joint positions were written"
 
 
 @pytest.mark.parametrize("akw,two", [({}, False), (dict(ragged=True, missing_frac=0.1), True)], ids=["c3_pool", "two_ragged_anims"])
