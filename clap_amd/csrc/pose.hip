@@ -74,7 +74,7 @@ __device__ __forceinline__ void key_bracket(const float *t, int nr, float time, 
 __device__ __forceinline__ float key_fac(float time, float p_time, float n_time)
 {
     if (p_time > n_time) return time < n_time ? 1.f : 0.f;
-    if (p_time < n_time) return __fdividef(time - p_time, n_time - p_time);
+    if (p_time < n_time) return (time - p_time) * __builtin_amdgcn_rcpf(n_time - p_time);   // __fdividef expands to the IEEE sequence here
     return 0.f;
 }
 
@@ -93,8 +93,8 @@ __device__ __forceinline__ float acos01(float d)
     const bool big = d > 0.5f;
     const float z = big ? (1.0f - d) * 0.5f : d * d;
     const float pn = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
-    const float r = __fdividef(pn, 1.0f + z * -7.0662963390e-01f);
-    const float x = big ? sqrtf(z) : d;
+    const float r = pn * __builtin_amdgcn_rcpf(1.0f + z * -7.0662963390e-01f);
+    const float x = big ? __builtin_amdgcn_sqrtf(z) : d;       // v_sqrt_f32 (1 ulp), z in [0, 0.25]: no denormal scaling needed
     const float y = x + x * r;                                   // asin(x)
     return big ? 2.0f * y : 1.5707963267948966f - y;
 }
