@@ -37,6 +37,8 @@ def main():
         return
     if which in ("pose", "skin"):
         J, n_chars, vpc = 64, 50_000, 200
+        if len(sys.argv) > 4:                                   # pose|skin <iters> <characters> <vertices per character>
+            n_chars, vpc = int(sys.argv[3]), int(sys.argv[4])
         sk = synth.skeleton(J, 8, seed=3)
         an = synth.animation(J, 30, 2.0, seed=3)
         ch = synth.characters(n_chars, J, seed=3)
