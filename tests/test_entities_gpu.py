@@ -130,6 +130,47 @@ def test_all_dirty_mode_and_separate_cull(layout, cuda_device):
     assert np.array_equal(out2["visible"], out["visible"])
 
 
+@pytest.mark.parametrize("n_models,dead", [(300, 0.0), (1, 0.0), (40, 0.002), (256, 0.0)],
+                         ids=["300_models_no_lds_table", "one_model_all_rows_straight", "rare_dead_rows_leave_the_loop",
+                              "256_models_table_full"])
+def test_tile_kernel_row_loops(n_models, dead, cuda_device):
+    """The tile kernel runs rows whose 64 lanes are all alive, rebuilt and boxed through a straight-line loop with
+    the model table in LDS (<= 256 models) and leaves it for the general loop at the first row that does not
+    qualify: a table too large for LDS (general loop only), a scene where every row qualifies, one where a few dead
+    entities / models without a box (the last model skips its AABB) break rows in the middle of tiles, and the
+    largest cached table -- three frames each, all dirty and then a tenth dirty, bit-exact against the oracle."""
+    from clap_amd import entities
+    rng = np.random.Generator(np.random.PCG64(n_models))
+    raw = synth.entities_forest(20_000, 40 + n_models, max_depth=8, n_models=n_models, dead_frac=dead,
+                                hidden_frac=0.05, skipcull_frac=0.02)
+    if n_models == 1:
+        raw["model_skip"][:] = 0
+    scene = tiler.tiled_scene(raw)[0]
+    cam = synth.camera(pos=(10, 5, 120))
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    st = ob.entity_state(scene)
+    batch = entities.EntityBatch(scene, cuda_device)
+    n = scene["n"]
+    for frame in range(3):
+        vis, mask = oracle_frame(scene, st, fr_o)
+        batch.mq_update(fr)
+        batch.compact_visible()
+        check_against(batch.download(), st, vis, mask, f"{n_models} models, frame {frame}")
+        dirty = (rng.uniform(0, 1, n) < 0.1) & (scene["orig_of"] >= 0)      # later frames: a tenth of the entities move
+        ps = scene["pos_scale"].copy()
+        ps[dirty, :3] += rng.uniform(-1, 1, (int(dirty.sum()), 3)).astype(np.float32)
+        apply_frame(scene, st, (ps, scene["rot"], dirty))
+        idx = np.flatnonzero(dirty)
+        batch.set_transforms(idx, ps[idx], scene["rot"][idx])
+    # and once with everything dirty after the partial frames (what bench.py times)
+    st["flags"] |= np.where(st["flags"] & synth.E_ALIVE, synth.E_DIRTY, 0).astype(np.uint32)
+    vis, mask = oracle_frame(scene, st, fr_o)
+    batch.mq_update(fr, all_dirty=True)
+    batch.compact_visible()
+    check_against(batch.download(), st, vis, mask, f"{n_models} models, all dirty", check_flags=False)
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_partial_dirty_frames(layout, cuda_device):
     """Random subsets move each frame: dirty roots drag their subtrees, clean subtrees are skipped
