@@ -489,25 +489,43 @@ void k_bp_search(BpK k)
     wave_lds_fence();
     // ---- candidate runs: (leader, cell) and (block leader) lookups, up to four per lane, loads in flight together
     const uint32_t n_cell_runs = n_lead * 14u, n_runs = n_cell_runs + n_blead;
+    // All of a lane's lookups are addressed first and loaded together, under no lane test (a lookup that does not exist
+    // reads entry 0 and is given length 0): written as "if cell run ... else if block run ..." per lookup, each of the
+    // four became its own branch with its own waits -- eight dependent trips to L2 before the first candidate.
     uint32_t b0[LOOKUPS], len[LOOKUPS], rng[LOOKUPS], mylen = 0;
+    uint32_t slot[LOOKUPS], sidx[LOOKUPS];
+    bool is_cell[LOOKUPS], is_stat[LOOKUPS], own[LOOKUPS];
 #pragma unroll
     for (int r = 0; r < LOOKUPS; r++) {
         const uint32_t u = lane + WAVE * r;
-        b0[r] = 0; len[r] = 0; rng[r] = 0;
-        if (u < n_cell_runs) {
-            const uint32_t l = u / 14u, cq = 13u + u % 14u;             // 13 = own cell, 14..26 = the cells after it
-            const int32_t *d = lead[wave][l];
-            const uint32_t slot = cell_slot(d[0] - 1 + (int32_t)(cq % 3), d[1] - 1 + (int32_t)((cq / 3) % 3), d[2] - 1 + (int32_t)(cq / 9), k.mask);
-            b0[r] = (k.block_start[slot >> 6] + k.cell_prefix[slot]) | (cq == 13u ? OWN : 0u);
-            len[r] = k.cell_len[slot];
-            rng[r] = (uint32_t)d[3];
-        } else if (u < n_runs) {
-            const int32_t *d = lead[wave][T + (u - n_cell_runs)];
-            const uint32_t s0 = k.s_start[d[0]];
-            b0[r] = s0 | STAT;
-            len[r] = k.s_start[d[0] + 1] - s0;
-            rng[r] = (uint32_t)d[3];
-        }
+        is_cell[r] = u < n_cell_runs;
+        is_stat[r] = !is_cell[r] && u < n_runs;
+        const uint32_t l = is_cell[r] ? u / 14u : 0u, cq = 13u + u % 14u;           // 13 = own cell, 14..26 = the cells after it
+        const int32_t *d = lead[wave][is_stat[r] ? T + (u - n_cell_runs) : l];
+        const int32_t d0 = d[0], d1 = d[1], d2 = d[2];
+        rng[r] = (is_cell[r] || is_stat[r]) ? (uint32_t)d[3] : 0u;
+        own[r] = is_cell[r] && cq == 13u;
+        slot[r] = is_cell[r] ? cell_slot(d0 - 1 + (int32_t)(cq % 3), d1 - 1 + (int32_t)((cq / 3) % 3), d2 - 1 + (int32_t)(cq / 9), k.mask) : 0u;
+        sidx[r] = is_stat[r] ? (uint32_t)d0 : 0u;
+    }
+    uint32_t v_bs[LOOKUPS], v_cp[LOOKUPS], v_cl[LOOKUPS], v_s0[LOOKUPS], v_s1[LOOKUPS];
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) {
+        v_bs[r] = k.block_start[slot[r] >> 6];
+        v_cp[r] = k.cell_prefix[slot[r]];
+        v_cl[r] = k.cell_len[slot[r]];
+    }
+    if (statics) {                                                       // uniform
+#pragma unroll
+        for (int r = 0; r < LOOKUPS; r++) { v_s0[r] = k.s_start[sidx[r]]; v_s1[r] = k.s_start[sidx[r] + 1]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < LOOKUPS; r++) { v_s0[r] = 0; v_s1[r] = 0; }
+    }
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) {
+        b0[r] = is_cell[r] ? ((v_bs[r] + v_cp[r]) | (own[r] ? OWN : 0u)) : is_stat[r] ? (v_s0[r] | STAT) : 0u;
+        len[r] = is_cell[r] ? v_cl[r] : is_stat[r] ? v_s1[r] - v_s0[r] : 0u;
         mylen += len[r];
     }
     uint32_t incl = mylen;
