@@ -267,15 +267,16 @@ def extras(device, testbed=True):
     model = animation.SkinnedModel(sk, [an], mesh=mesh, device=device)
     cb = animation.CharacterBatch(model, n_chars, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
     cb.set_frame_times(ch["phase"])
-    t_pose = time_launches(cb.pose_update, 20)
-    t_skin = time_launches(cb.skin, 20)
+    # these two settle only after some tens of launches of a process (the first ones run 10-20 us slower): steady state
+    t_pose = time_launches(cb.pose_update, 200, warmup=100)
+    t_skin = time_launches(cb.skin, 200, warmup=100)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
-                           "kernel": "k_pose<64>", "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<")}
+                           "kernel": "k_pose<64>", "launches_timed": 200, "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<")}
     # what a frame whose skinning runs on the device needs from the pose: the palette alone.  The joints' T/R/S and
     # world positions (56 B of the 120 B a joint writes) are host-visible state of animated_update; a caller that does
     # not read them back switches them off (clapgpu_pose_batch.skip)
     cb.set_outputs(trs=False, joint_pos=False)
-    t_pal = time_launches(cb.pose_update, 20)
+    t_pal = time_launches(cb.pose_update, 200, warmup=100)
     cb.set_outputs(trs=True, joint_pos=True)
     out["pose_palette"]["palette_only"] = {"us": t_pal * 1e6, "joints_per_s": n_chars * J / t_pal,
                                            "bytes_written_per_joint": 64,
