@@ -294,7 +294,7 @@ def extras(device, testbed=True):
     pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
     view = np.eye(4, dtype=np.float32).ravel()
-    t_part = time_launches(lambda: pb.particles_update(view), 30)
+    t_part = time_launches(lambda: pb.particles_update(view), 200, warmup=100)
     out["particles"] = {"particles_per_s": pb.n_real / t_part, "particles": pb.n_real,
                         "kernels": "k_particles_advect + k_visible_expand_rp + k_particles_respawn",
                         "roofline": roof(pb.algorithmic_bytes(), t_part, "k_particles_advect", "k_particles_respawn_rp")}
@@ -303,8 +303,8 @@ def extras(device, testbed=True):
     #      both broadphase passes + narrowphase ----
     b = synth.capsule_bodies(262_144, box=60.0, seed=4)
     pw = physics.PhysWorld(b, synth.static_boxes(64, 60.0), pair_capacity=2_000_000, device=device)
-    t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 30)
-    t_bp = time_launches(pw.broadphase, 10)
+    t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 200, warmup=100)
+    t_bp = time_launches(pw.broadphase, 100, warmup=50)
     npairs = int(pw.pair_total.item())
     out["bodies"] = {"bodies_per_s_integrate": pw.n / t_int, "bodies": pw.n, "kernel": "k_bodies_step",
                      "roofline": roof(pw.integrate_algorithmic_bytes(), t_int, "k_bodies_step"),
