@@ -40,7 +40,7 @@ def main():
         if len(sys.argv) > 4:                                   # pose|skin <iters> <characters> <vertices per character>
             n_chars, vpc = int(sys.argv[3]), int(sys.argv[4])
         sk = synth.skeleton(J, 8, seed=3)
-        an = synth.animation(J, 30, 2.0, seed=3)
+        an = synth.animation(J, 30, 2.0, seed=3, missing_frac=float(os.environ.get("CLAP_POSE_MISSING", "0")))   # share of channels absent
         ch = synth.characters(n_chars, J, seed=3)
         mesh = synth.skinned_mesh(vpc, J, seed=3, copies=n_chars) if which == "skin" else None
         vf = (np.arange(n_chars, dtype=np.int64) * vpc).astype(np.uint32) if mesh else None
