@@ -52,6 +52,12 @@ def main():
         cb.set_outputs(trs=not (sk_ & 1), joint_pos=not (sk_ & 2))
         cb.pose_update()
         fn = cb.pose_update if which == "pose" else cb.skin
+        if which == "pose" and os.environ.get("CLAP_POSE_PLAYBACK"):      # animated_update at 60 Hz: the clock kernel moves every
+            cb.start_clock(ani_time=-ch["phase"].astype(np.float64))     # character's frame time on by 1 / 60 s per launch
+            clock = [0.0]
+            def fn():
+                clock[0] += 1.0 / 60.0
+                cb.animated_update(clock[0])
     elif which == "particles":
         ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
         pos, vel, st = synth.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE)
