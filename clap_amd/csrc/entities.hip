@@ -358,9 +358,14 @@ __device__ __forceinline__ void process_row_fast(const EntK &e, const RowIn &in,
         store_stream(&reinterpret_cast<float4 *>(ab)[lane], reinterpret_cast<const float4 *>(tile_f)[lane]);
         const float2 t2 = reinterpret_cast<const float2 *>(tile_f + 4 * WAVE)[lane];
         const clapgpu_f2 v2 = { t2.x, t2.y };
-        __builtin_nontemporal_store(v2, reinterpret_cast<clapgpu_f2 *>(ab + 4 * WAVE) + lane);
         const clapgpu_f3 v3 = { ctr[0], ctr[1], ctr[2] };
+#ifdef CLAPGPU_PLAIN_STORES          // A/B builds only (tools/profile_entities_scale.sh)
+        reinterpret_cast<clapgpu_f2 *>(ab + 4 * WAVE)[lane] = v2;
+        *reinterpret_cast<clapgpu_f3 *>(e.center + 3 * (e0 + lane)) = v3;
+#else
+        __builtin_nontemporal_store(v2, reinterpret_cast<clapgpu_f2 *>(ab + 4 * WAVE) + lane);
         __builtin_nontemporal_store(v3, reinterpret_cast<clapgpu_f3 *>(e.center + 3 * (e0 + lane)));   // sizeof(f3) is 16: index in floats
+#endif
     }
     wave_lds_fence();
     if (!(mode & CLAPGPU_UPDATE_ALL_DIRTY) && (fl & CLAPGPU_E_DIRTY))
