@@ -328,8 +328,20 @@ __device__ __forceinline__ void process_row_fast(const EntK &e, const RowIn &in,
 #pragma unroll
         for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
     }
+#ifdef CLAPGPU_EXP_NO_INVERT                                     // sensitivity experiments only (tools/entities_sensitivity.sh): wrong results
+#pragma unroll
+    for (int k = 0; k < 16; k++) inv[k] = mx[k];
+#else
     lmd::invert(inv, mx);
+#endif
+#ifdef CLAPGPU_EXP_NO_AABB
+#pragma unroll
+    for (int k = 0; k < 6; k++) bb[k] = mx[12 + k % 3] + (k < 3 ? lo.x : hi.x);
+#pragma unroll
+    for (int k = 0; k < 3; k++) ctr[k] = mx[12 + k];
+#else
     lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+#endif
     seq = (seq + 1) & 0xffffu;
 #pragma unroll
     for (int k = 0; k < 16; k++) carry_mx[k] = mx[k];
