@@ -32,7 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ROUND = "r02"
+ROUND = "r03"
 
 
 def parse():
@@ -62,7 +62,73 @@ def parse():
                     help="skip the testbed-sized (BASELINE configs[0]) extra: under rocprofv3 its small launches of "
                          "the same kernels would be averaged into the full-size per-kernel statistics")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="self-test of the --gpus N launcher: the ranks rendezvous over gloo on the CPU, reduce their ranks and "
+                         "rank 0 prints one JSON line; no GPU is touched (tests/test_bench_launcher.py)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started plainly (no torch.distributed.run environment): start the N ranks ourselves, one
+    fresh process per GPU, BEFORE this process makes any GPU call -- a process that has initialised the GPU must never
+    be replaced or forked into ranks.  Rank 0's stdout (the ONE JSON line) is passed through; the other ranks' stdout
+    goes to stderr.  Returns the exit code: 0 only if every rank exited 0; a failing rank takes the others down (exact
+    PIDs, never a pattern)."""
+    n = args.gpus
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+        if have < n:
+            print(f"[bench] --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this pool
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=(None if r == 0 else sys.stderr)))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def dry_launch():
+    """The launcher's self-test body (one rank): gloo rendezvous on the CPU with the environment launch_ranks() made."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("CLAP_BENCH_DRY_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank, int(os.environ["LOCAL_RANK"]), 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher": "dry", "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1]),
+                          "ranks": int(t[2])}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def cpu_all_cores(scene, cam, frames=8):
@@ -80,10 +146,34 @@ def cpu_all_cores(scene, cam, frames=8):
         ob.entities_frame_tiles_mt(scene, st, fr, mask)
         t.append(time.perf_counter() - t0)
     t = t[1:]                                                # first call spins up the thread pool
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    return dict(value=int(scene["n_real"]) / (sum(t) / len(t)), unit="entity updates/s", cores=cores,
-                kind="port", sample=f"{frames} frames, oracle/ C restatement, OpenMP over tiles on every core the process may "
-                                    "run on (a container CPU quota below that count is not visible here)")
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    threads = ob.omp_max_threads()
+    quota = cgroup_cpu_limit()
+    # what the figure really ran on: OpenMP's thread count, capped by a container CPU quota when there is one
+    effective = threads if quota is None else max(1, min(threads, int(np.ceil(quota))))
+    return dict(value=int(scene["n_real"]) / (sum(t) / len(t)), unit="entity updates/s", cores=effective,
+                omp_threads=threads, affinity_cores=affinity, cgroup_cpu_limit=quota,
+                kind="port", sample=f"{frames} frames, oracle/ C restatement, OpenMP over tiles: {threads} threads "
+                                    f"(omp_get_max_threads) on {affinity} schedulable cores, container CPU quota "
+                                    f"{'none' if quota is None else f'{quota:.1f} cores'}")
+
+
+def cgroup_cpu_limit():
+    """CPU quota of this container in cores (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def dropin_boundary():
@@ -175,7 +265,8 @@ def pmc_kernel_traffic(*names):
     newest committed summary profiles/<round>_*/pmc_hbm_bytes.json (tools/profile_round.sh), or None."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{ROUND}_*", "pmc_hbm_bytes.json"))):   # by name: r02_a < r02_b < ...
+    # by name: r02_a < r02_b < ... < r03_a; the newest summary wins (an older round's stands until this round has one)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*", "pmc_hbm_bytes.json"))):
         try:
             with open(path) as f:
                 best = json.load(f).get("kernels", {})
@@ -452,10 +543,62 @@ def full_frame(device):
             "launches": "one stream, no host read-back inside the frame"}
 
 
+class RankStep:
+    """One rank's share of the workload and its step, exactly what the timed loop runs (tests/test_c5_gpu.py drives this same
+    object at BASELINE configs[4]'s per-rank size against the oracle).  Rank r owns block r of ONE global forest
+    (synth.entities_chains seeded by its global chain numbers), global entity id = r * n_pad + local slot; particle
+    systems shard by whole system with the rank's own drand48 stream.  With `use_dist` the frame's visible set leaves
+    through the path's only exchange: the 1-bit-per-entity mask in ONE fixed-size RCCL allgather (no counts, no host
+    sync), expanded on every rank into the identical ascending global id list; exchange + expansion of frame f run on a
+    side stream under the update of frame f + 1 (two mask buffers)."""
+
+    def __init__(self, chains, depth, particles, rank, world, device, use_dist, route="rccl", layout="tiles", raw=None,
+                 cam=None, block=None):
+        from clap_amd import entities, shard, synth, tiler
+        self.rank, self.world, self.use_dist = rank, world, use_dist
+        comm_rank = rank
+        if block is not None:                                # a test stepping block b of the forest in a smaller world
+            rank = block
+        self.cam = cam if cam is not None else synth.camera()
+        if raw is None:
+            raw = synth.entities_chains(chains, depth, seed=2 + rank)
+        self.scene = tiler.tiled_scene(raw)[0] if layout == "tiles" else synth.pad_levels(raw)
+        self.fr, self.view, _proj = entities.view_calc_frustum(self.cam)
+        self.batch = entities.EntityBatch(self.scene, device)
+        self.index_base = rank * self.batch.n
+        self.pbatch = self.psys = None
+        if particles > 0:                                    # whole 1024-particle systems, own RNG stream per rank
+            from clap_amd import particles as particles_mod
+            n_sys = max(1, particles // 1024)
+            self.psys = synth.particle_systems(n_sys=n_sys, count=1024, radius=10.0, velocity=0.005,
+                                               dist=synth.PART_DIST_SQRT, seed=40 + rank)
+            self.pstate0 = synth.DRAND48_DEFAULT_STATE + rank
+            ppos, pvel, pstate = synth.particles_spawn(self.psys, self.pstate0)
+            self.pbatch = particles_mod.ParticleBatch(self.psys, ppos, pvel, pstate, device)
+        self.xch = shard.VisibleExchange(self.batch, comm_rank, world, device, route=route) if use_dist else None
+
+    def step(self):
+        if self.pbatch is not None:
+            self.pbatch.particles_update(self.view)
+        if not self.use_dist:
+            self.batch.mq_update(self.fr, all_dirty=True)    # one launch for all hierarchy levels (tiles)
+            self.batch.compact_visible(self.index_base)      # ordered visible list
+            return
+        self.xch.begin()
+        self.batch.mq_update(self.fr, all_dirty=True)
+        self.xch.submit()
+
+
 def main():
     args = parse()
     if args.c5:
         args.chains, args.depth, args.particles = 250_000, 8, 262_144
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: be our own launcher
+        raise SystemExit(launch_ranks(args))
+    if args.dry_launch:
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        return dry_launch()
     import torch
     import torch.distributed as dist
     from clap_amd import _lib, entities, shard, synth, tiler
@@ -464,7 +607,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     _lib.check(_lib.lib().clapgpu_init(local_rank), "clapgpu_init")
@@ -477,44 +620,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     cam = synth.camera()
+    comps = raw = None
     if args.snapshot:
         from clap_amd import snapshot
         comps = snapshot.load_scene(args.snapshot)
         raw = comps["entities"]
         cam = comps.get("camera", cam)
         args.cpu_frames = 0                                  # the CPU baseline leg times the synthetic workload only
-    else:
-        raw = synth.entities_chains(args.chains, args.depth, seed=2 + rank)
-    scene = tiler.tiled_scene(raw)[0] if args.layout == "tiles" else synth.pad_levels(raw)
-    fr, _view, _proj = entities.view_calc_frustum(cam)
-    batch = entities.EntityBatch(scene, device)
-    n_real, n_pad = batch.n_real, batch.n
-    index_base = rank * n_pad
-    pbatch = None
-    if args.particles > 0:                                   # particle systems shard by whole system (own RNG stream per rank)
-        from clap_amd import particles as particles_mod
-        n_sys = max(1, args.particles // 1024)
-        ps = synth.particle_systems(n_sys=n_sys, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT,
-                                    seed=40 + rank)
-        ppos, pvel, pstate = synth.particles_spawn(ps, synth.DRAND48_DEFAULT_STATE + rank)
-        pbatch = particles_mod.ParticleBatch(ps, ppos, pvel, pstate, device)
-
-    # ---- N > 1: the path's only exchange.  Each rank's compacted visible set travels as its
-    # 1-bit-per-entity mask (one fixed-size RCCL allgather, no counts, no host sync); every rank
-    # then expands the gathered mask into the identical ascending global id list.  Exchange and
-    # expansion of frame f run on a side stream under the update of frame f + 1 (two mask buffers).
-    xch = shard.VisibleExchange(batch, rank, world, device, route=args.exchange) if use_dist else None
-
-    def step():
-        if pbatch is not None:
-            pbatch.particles_update(_view)
-        if not use_dist:
-            batch.mq_update(fr, all_dirty=True)         # one launch for all hierarchy levels (tiles)
-            batch.compact_visible(index_base)           # ordered visible list
-            return
-        xch.begin()
-        batch.mq_update(fr, all_dirty=True)
-        xch.submit()
+    rs = RankStep(args.chains, args.depth, args.particles, rank, world, device, use_dist=use_dist, route=args.exchange,
+                  layout=args.layout, raw=raw, cam=cam)
+    scene, batch, pbatch, xch, fr, step = rs.scene, rs.batch, rs.pbatch, rs.xch, rs.fr, rs.step
+    n_real, n_pad, index_base = batch.n_real, batch.n, rs.index_base
 
     def fence():
         if use_dist:
@@ -542,20 +658,28 @@ def main():
         kernel, launches = "k_entities_tiles<true>", 1
     else:
         kernel, launches = "k_entities_level<true>", batch.n_levels
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(launches)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    for s in range(args.steps):
-        for l in range(launches):
-            ev[s][l][0].record()
-            if batch.tiled:
-                batch.mq_update(fr, all_dirty=True)
-            else:
-                batch.update_level(l, fr, all_dirty=True)
-            ev[s][l][1].record()
-        batch.compact_visible(index_base)
-    torch.cuda.synchronize()
-    lvl_ms = np.asarray([[a.elapsed_time(b) for a, b in row] for row in ev])       # [steps][launches]
+    # K launches back to back between ONE event pair (events on torch's current stream, the stream the kernels are
+    # launched on): an event pair around every single launch adds its own ~5 us of record latency to a 39 us kernel
+    # and reads LONGER than the whole step.  The expansion launch is timed the same way, so that
+    # mean_launch_us + expand_us ~= ms_per_step * 1000 can be checked from the line itself.
+    K = max(args.steps, 20)
+
+    def timed(fn, reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps                       # ms per call
+
+    if batch.tiled:
+        lvl_ms = np.asarray([timed(lambda: batch.mq_update(fr, all_dirty=True), K)])
+    else:
+        lvl_ms = np.asarray([timed(lambda l=l: batch.update_level(l, fr, all_dirty=True), K) for l in range(launches)])
+    expand_ms = timed(lambda: batch.compact_visible(index_base), K)
     mean_launch_s = float(lvl_ms.mean()) * 1e-3
     alg_bytes_step = batch.algorithmic_bytes()                                       # 276 B/child, 212 B/root
     alg_bytes_launch = alg_bytes_step / launches
@@ -582,7 +706,14 @@ def main():
                                     "the next frame's update") if use_dist else "none"},
             "roofline": dict(roof(alg_bytes_launch, mean_launch_s, *([kernel] if default_workload else [])),
                              kernel=kernel, launches_per_step=launches,
-                             per_launch_us=[float(x) for x in (lvl_ms.mean(axis=0) * 1e3)]),
+                             per_launch_us=[float(x) for x in (lvl_ms * 1e3)],
+                             launches_timed=K, timing="K launches back to back between one HIP event pair",
+                             expand_launch_us=float(expand_ms * 1e3),
+                             step_us=float(ms_per_step * 1e3),
+                             note="mean_launch_us is launch-to-launch in a dependent stream: the kernel plus the few us between "
+                                  "two dependent launches (rocprofv3's kernel-only average is in profiles/); expand_launch_us "
+                                  "issued alone is bound by the host's launch rate -- inside a step it costs step_us - "
+                                  "mean_launch_us"),
         }
         if args.snapshot:
             out["data"] = "snapshot"
@@ -590,7 +721,9 @@ def main():
             if extra:
                 out["extra"] = {"snapshot_characters": extra}
         if world == 1 and not args.no_extras and not args.snapshot:
-            del batch
+            if xch is not None:
+                xch.destroy()
+            xch = batch = pbatch = step = rs = None           # the extras want the HBM the headline scene holds
             torch.cuda.empty_cache()
             out["extra"] = extras(device, testbed=not args.no_testbed)
         if world == 1 and args.cpu_frames > 0:
@@ -598,7 +731,8 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
-        xch.destroy()
+        if xch is not None:
+            xch.destroy()
         dist.destroy_process_group()
 
 

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 OK = 0
 ERR_NOMEM = -1
@@ -98,7 +98,8 @@ class SkinBatch(C.Structure):
     _fields_ = [("n_chars", C.c_uint32), ("nr_joints", C.c_uint32), ("vert_first", C.c_void_p),
                 ("vert_count", C.c_void_p), ("out_first", C.c_void_p), ("position", C.c_void_p),
                 ("normal", C.c_void_p), ("joints", C.c_void_p), ("weights", C.c_void_p),
-                ("joint_transforms", C.c_void_p), ("out_position", C.c_void_p), ("out_normal", C.c_void_p)]
+                ("joint_transforms", C.c_void_p), ("out_position", C.c_void_p), ("out_normal", C.c_void_p),
+                ("out_w", C.c_void_p)]
 
 
 class World(C.Structure):
@@ -282,8 +283,14 @@ def lib():
             fn = getattr(L, name)           # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        if L.clapgpu_abi_version() != ABI_VERSION:
-            raise ClapGpuError(ERR_INIT_FAILED, "clap_amd", "libclapgpu ABI version mismatch; rebuild")
+        got = L.clapgpu_abi_version()
+        if got & 0x80000000 and os.environ.get("CLAPGPU_ALLOW_EXPERIMENT") == "1":
+            got &= 0x7FFFFFFF                # an experiment build (csrc/common.h), asked for by name: A/B tools only
+        if got != ABI_VERSION:
+            raise ClapGpuError(ERR_INIT_FAILED, "clap_amd",
+                               "libclapgpu ABI version mismatch; rebuild" if not got & 0x80000000 else
+                               "libclapgpu is an EXPERIMENT build (-DCLAPGPU_EXPERIMENT: kernels compiled with parts "
+                               "switched off); rebuild without EXTRA=, or set CLAPGPU_ALLOW_EXPERIMENT=1 for an A/B run")
         _lib = L
     return _lib
 

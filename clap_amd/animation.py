@@ -152,7 +152,8 @@ class CharacterBatch:
             self._skin_desc = _lib.SkinBatch(n, J, _ptr(self.vert_first), _ptr(self.vert_count), _ptr(self.out_first),
                                              _ptr(m["position"]), _ptr(m["normal"]), _ptr(m["joints"]),
                                              _ptr(m["weights"]), _ptr(self.joint_transforms),
-                                             _ptr(self.out_position), _ptr(self.out_normal))
+                                             _ptr(self.out_position), _ptr(self.out_normal), None)
+            self.out_w = None
 
     # ---- animated_update (model.c:1563-1592) --------------------------------------------
     def set_frame_times(self, frame_time, anim=None):
@@ -209,6 +210,12 @@ class CharacterBatch:
                                             C.byref(self._pose_desc))
         _lib.check(rc, "clapgpu_pose_update")
 
+    def set_skin_w(self, on=True):
+        """Also write total_local_pos.w per vertex (clapgpu_skin_batch.out_w; model.vert:36-38,44)."""
+        if on and self.out_w is None:
+            self.out_w = torch.zeros(self.n_out_verts, dtype=torch.float32, device=self.device)
+        self._skin_desc.out_w = _ptr(self.out_w) if on else None
+
     def skin(self):
         if self._skin_desc is None:
             raise ValueError("model has no skinned mesh")
@@ -222,6 +229,8 @@ class CharacterBatch:
         if self._skin_desc is not None:
             out["out_position"] = self.out_position.cpu().numpy()
             out["out_normal"] = self.out_normal.cpu().numpy()
+            if self.out_w is not None:
+                out["out_w"] = self.out_w.cpu().numpy()
         return out
 
     def pose_algorithmic_bytes(self):

@@ -66,6 +66,18 @@ __device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4],
     }
 }
 
+// ---- experiment switches --------------------------------------------------------------------------------------------
+// A few A/B and sensitivity builds (tools/entities_sensitivity.sh, tools/profile_entities_scale.sh) compile parts of the
+// kernels out or change their store policy; some of them produce WRONG results on purpose.  None of them can reach a
+// release build by a stray EXTRA= flag: every such macro requires -DCLAPGPU_EXPERIMENT, and an experiment build
+// reports an ABI version with the top bit set (runtime.hip), which clap_amd/_lib.py and any caller checking
+// clapgpu_abi_version() against its header refuse to load.
+#if defined(CLAPGPU_EXP_NO_INVERT) || defined(CLAPGPU_EXP_NO_AABB) || defined(CLAPGPU_PLAIN_STORES) || defined(BP_SEARCH_IN_FLIGHT)
+#  ifndef CLAPGPU_EXPERIMENT
+#    error "CLAPGPU_EXP_* / CLAPGPU_PLAIN_STORES / BP_SEARCH_IN_FLIGHT are experiment switches: add -DCLAPGPU_EXPERIMENT (the library then reports an experiment ABI version)"
+#  endif
+#endif
+
 // Streaming store: the big per-frame outputs (mx, inverse_mx, aabb, palettes) are written once and
 // read by a later kernel or the host, never by the writer.  Marked non-temporal they do not push the
 // inputs out of the 256 MB infinity cache: neutral at 1 M entities (everything fits), 112 -> 78 us at

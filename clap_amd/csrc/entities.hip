@@ -13,6 +13,7 @@
 // a wave-private LDS tile so each store instruction writes 1 KiB contiguous.
 #include <string.h>
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 #include "lm_dev.h"
 
@@ -451,7 +452,7 @@ void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_sta
                       uint32_t mode)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    (void)fr_arg;
+    (void)fr_arg;                                                // read at kernarg offset 0: see the static_assert behind this kernel
     // kept in the constant address space through the laundering below: the planes then come through the scalar cache
     // (s_load, counted with LDS), not as flat loads, whose wait is a wait for every vector store before them
     typedef const __attribute__((address_space(4))) lmd::FrustumK *frustum_ptr;
@@ -756,6 +757,16 @@ void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t ind
         draw_lod[k] = lod;
     }
 }
+
+// k_entities_tiles reads its frustum through the kernarg segment pointer at offset 0.  The AMDGPU kernel ABI lays the
+// explicit arguments out first and in declaration order, so that holds exactly as long as the frustum is the FIRST
+// parameter: reordering the signature must not compile.
+template <class F> struct first_param;
+template <class R, class A0, class... A> struct first_param<R (*)(A0, A...)> { using type = A0; };
+static_assert(std::is_same<first_param<decltype(&k_entities_tiles<true>)>::type, lmd::FrustumK>::value &&
+              std::is_same<first_param<decltype(&k_entities_tiles<false>)>::type, lmd::FrustumK>::value,
+              "k_entities_tiles: the frustum must stay the first kernel argument (it is read at kernarg offset 0)");
+static_assert(alignof(lmd::FrustumK) <= 8, "kernarg offset 0 holds for any alignment the segment start guarantees");
 
 } // namespace clapgpu
 

@@ -6,7 +6,11 @@
 #include "common.h"
 #include "lm_dev.h"
 
-#define CLAPGPU_ABI_VERSION 22u
+#ifdef CLAPGPU_EXPERIMENT               // an A/B or sensitivity build (common.h): never loadable as the product
+#define CLAPGPU_ABI_VERSION (23u | 0x80000000u)
+#else
+#define CLAPGPU_ABI_VERSION 23u
+#endif
 
 namespace clapgpu {
 

@@ -4,7 +4,10 @@
 // shadow.vert:19-23 and shadow_vsm.vert:19-23, i.e. recomputed in every geometry pass):
 //     p' = sum_{i<4} w_i * (J[j_i] * (p,1)),   n' = sum_{i<4} w_i * (J[j_i] * (n,0))
 // with J = the entity's joint_transforms, accumulated i = 0..3 in order, fp32, no weight
-// renormalisation.  Inputs are the reference's vertex attribute formats (mesh.h:125-131,
+// renormalisation.  The shader goes on with the vec4 (model.vert:44: proj * view * trs * total_local_pos), whose
+// w = sum_i w_i * (row 3 of J[j_i] . (p,1)) -- the sum of the weights for affine palettes, NOT 1 unless the
+// asset's weights are normalised: out_w (optional) carries it, so a pre-skinned draw can feed the same vec4.
+// Inputs are the reference's vertex attribute formats (mesh.h:125-131,
 // gltf.c:387-388): position f32x3, normal f32x3, joints u8x4, weights f32x4.
 //
 // Mapping: one workgroup per character; its palette (nr_joints x 64 B) is staged once in LDS
@@ -27,7 +30,7 @@ struct SkinArgs {
     const uint32_t *joints;            // u8x4 packed
     const float4   *weights;
     const float4   *joint_transforms;
-    float          *out_position, *out_normal;
+    float          *out_position, *out_normal, *out_w;
 };
 
 struct SkinVert {
@@ -55,6 +58,7 @@ __device__ __forceinline__ SkinVert load_vert(const SkinArgs &a, size_t v)
 }
 
 constexpr int SKIN_WAVES = 8;           // 56 VGPRs: eight workgroups per CU keep the vertex stream in flight
+template <bool W>                      // W: also total_local_pos.w (4 B / vertex more)
 __global__ __launch_bounds__(SKIN_BLOCK, SKIN_WAVES)
 void k_skin(SkinArgs a)
 {
@@ -78,7 +82,7 @@ void k_skin(SkinArgs a)
 
     while (k < vcount) {
         const float w[4] = { cur.w.x, cur.w.y, cur.w.z, cur.w.w };
-        float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 };
+        float tp[3] = { 0, 0, 0 }, tn[3] = { 0, 0, 0 }, tw = 0.f;
 #pragma unroll 1
         for (int i = 0; i < 4; i++) {
             const uint32_t ji = (cur.jj >> (8 * i)) & 0xffu;
@@ -94,6 +98,10 @@ void k_skin(SkinArgs a)
             const float mz = ((c0.z * cur.nx + c1.z * cur.ny) + c2.z * cur.nz) + c3.z * 0.0f;
             tp[0] += lx * wi; tp[1] += ly * wi; tp[2] += lz * wi;
             tn[0] += mx * wi; tn[1] += my * wi; tn[2] += mz * wi;
+            if (W) {
+                const float lw = ((c0.w * cur.px + c1.w * cur.py) + c2.w * cur.pz) + c3.w * 1.0f;
+                tw += lw * wi;
+            }
         }
         const size_t o = (size_t)ofirst + k;
         // written once, read by the draw path: streaming stores keep them out of the infinity cache
@@ -103,6 +111,8 @@ void k_skin(SkinArgs a)
         __builtin_nontemporal_store(tn[0], &a.out_normal[3 * o]);
         __builtin_nontemporal_store(tn[1], &a.out_normal[3 * o + 1]);
         __builtin_nontemporal_store(tn[2], &a.out_normal[3 * o + 2]);
+        if (W)
+            __builtin_nontemporal_store(tw, &a.out_w[o]);
         k += SKIN_BLOCK;
         if (k < vcount)
             cur = load_vert(a, (size_t)vfirst + k);
@@ -137,8 +147,13 @@ extern "C" int clapgpu_skin(void *stream, const clapgpu_skin_batch *b)
     a.joint_transforms = reinterpret_cast<const float4 *>(b->joint_transforms);
     a.out_position = b->out_position;
     a.out_normal = b->out_normal;
-    hipLaunchKernelGGL(k_skin, dim3(b->n_chars), dim3(SKIN_BLOCK), b->nr_joints * PAL_PITCH * sizeof(float),
-                       as_stream(stream), a);
+    a.out_w = b->out_w;
+    if (b->out_w)
+        hipLaunchKernelGGL(k_skin<true>, dim3(b->n_chars), dim3(SKIN_BLOCK), b->nr_joints * PAL_PITCH * sizeof(float),
+                           as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(k_skin<false>, dim3(b->n_chars), dim3(SKIN_BLOCK), b->nr_joints * PAL_PITCH * sizeof(float),
+                           as_stream(stream), a);
     CLAPGPU_LAUNCH_CHECK("k_skin");
     return CLAPGPU_OK;
 }

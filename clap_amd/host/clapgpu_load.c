@@ -860,12 +860,25 @@ static int write_model(clapgpu_snapshot_writer *w, unsigned k, const struct ld_m
     if (J) {
         A("joints", CLAPGPU_DT_U8, 2, V, 4, m->joints);
         A("weights", CLAPGPU_DT_F32, 2, V, 4, m->weights);
+        {   /* model.vert:36-38 never renormalises: total_local_pos.w = sum of the weights.  How far this mesh is from 1
+             * decides whether a pre-skinned draw may feed vec4(p, 1) (clapgpu_skin_batch.out_w, clapgpu.h) */
+            float dev = 0.f;
+            for (uint32_t v = 0; v < V; v++) {
+                const float *q = m->weights + 4 * (size_t)v;
+                float sum = 0.f;
+                for (int i = 0; i < 4; i++) sum += q[i];          /* the shader's accumulation order */
+                const float d = fabsf(sum - 1.f);
+                if (!(d <= dev)) dev = d;                         /* NaN weights surface as NaN */
+            }
+            A("weight_sum_max_dev", CLAPGPU_DT_F32, 1, 1, 0, &dev);
+        }
         A("joint_parent", CLAPGPU_DT_I32, 1, J, 0, m->joint_parent);
         A("invmx", CLAPGPU_DT_F32, 2, J, 16, m->invmx);
         A("bind", CLAPGPU_DT_F32, 2, J, 16, m->bind);
         A("root_pose", CLAPGPU_DT_F32, 1, 16, 0, m->root_pose);
         A("joint_types", CLAPGPU_DT_I32, 1, JOINT_TYPE_MAX, 0, m->joint_types);
         if (!rc) rc = add_i64(w, comp, "n_anims", m->n_anims);
+        uint64_t nonstrict_total = 0;
         for (uint32_t a = 0; a < m->n_anims && !rc; a++) {
             const struct ld_anim *an = &m->anims[a];
 #define AK(suffix, dt, n, p) do { snprintf(key, sizeof(key), "a%u_%s", a, suffix); A(key, dt, 1, n, 0, p); } while (0)
@@ -877,8 +890,25 @@ static int write_model(clapgpu_snapshot_writer *w, unsigned k, const struct ld_m
             AK("times", CLAPGPU_DT_F32, an->n_times, an->times);
             AK("data", CLAPGPU_DT_F32, an->n_data, an->data);
             AK("time_end", CLAPGPU_DT_F32, 1, &an->time_end);
+            {   /* channel_time_to_idx scans from the cursor joint->off[path] (model.c:1266-1288, 1310): with key times that
+                 * do not strictly increase the bracket it finds depends on that cursor's history, which the stateless
+                 * device search (pose.hip) does not have.  Flag such channels: count of keys with t[i] <= t[i-1]. */
+                uint32_t *ns = calloc(an->n_channels ? an->n_channels : 1, sizeof(*ns));
+                if (!ns) { rc = LD_NOMEM; break; }
+                uint32_t total = 0;
+                for (uint32_t c = 0; c < an->n_channels; c++) {
+                    const float *t = an->times + an->ch_time_off[c];
+                    for (uint32_t i = 1; i < an->ch_nr[c]; i++)
+                        ns[c] += !(t[i] > t[i - 1]);
+                    total += ns[c];
+                }
+                AK("ch_nonstrict", CLAPGPU_DT_U32, an->n_channels, ns);
+                free(ns);
+                nonstrict_total += total;
+            }
 #undef AK
         }
+        if (!rc) rc = add_i64(w, comp, "key_times_nonstrict", (int64_t)nonstrict_total);
     }
 #undef A
     return rc;

@@ -458,6 +458,16 @@ int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_
  * position f32x3, normal f32x3, joints u8x4, weights f32x4 (16-B aligned).  Instances of one
  * model share vert_first.  Outputs: position f32x3 + normal f32x3 in the joint-space-blended
  * model space the shader would feed to `trs` (model.vert:44-45).
+ *
+ * The w component.  The shader multiplies proj * view * trs by the vec4 total_local_pos (model.vert:32-45), whose
+ * w = sum_i weights[i] * (row 3 of joint_transforms[joints[i]] . (position, 1)) -- for affine palettes the SUM OF THE
+ * WEIGHTS, which the reference never renormalises.  A draw that feeds vec4(out_position, 1) therefore equals the
+ * shader only for vertices whose weights sum to 1.  Two ways to stay exact:
+ *   - out_w != NULL: the kernel also writes that w (f32 per vertex, 28 B / vertex out instead of 24) and the draw
+ *     feeds vec4(out_position, out_w);
+ *   - out_w == NULL: the caller vouches that |sum(weights) - 1| is negligible for every vertex of the pool;
+ *     clapgpu_load_gltf() reports the worst deviation per mesh (clapgpu_load.h: weight_sum_max_dev) so that a
+ *     caller can decide.
  */
 typedef struct clapgpu_skin_batch {
     uint32_t        n_chars;
@@ -472,6 +482,7 @@ typedef struct clapgpu_skin_batch {
     const float    *joint_transforms;
     float          *out_position;
     float          *out_normal;
+    float          *out_w;              /* optional: total_local_pos.w per output vertex (see above) */
 } clapgpu_skin_batch;
 
 int clapgpu_skin(void *stream, const clapgpu_skin_batch *b);

@@ -16,7 +16,10 @@
  *                 invmx[J][16], bind[J][16] (mat4x4_invert, model.c:524-537), root_pose[16], joint_types[6],
  *                 n_verts, position / normal / joints (u8x4) / weights; n_anims, and per animation a:
  *                 a<a>_ch_target / _ch_path / _ch_nr / _ch_time_off / _ch_data_off / _times / _data / _time_end
- *                 (channel order and time_end as animation_add_channel leaves them, model.c:725-742)
+ *                 (channel order and time_end as animation_add_channel leaves them, model.c:725-742);
+ *                 weight_sum_max_dev = max over vertices of |sum(weights) - 1| (the shader's total_local_pos.w is that
+ *                 sum, model.vert:36-38: clapgpu_skin_batch.out_w); a<a>_ch_nonstrict[c] = keys of channel c whose time
+ *                 does not exceed the previous key's, key_times_nonstrict = their total over the model (see below)
  *   characters.*  entity[], model[], speed[], can_jump[], can_dash[]      ("character" arrays, scene.c:1508-1515)
  *   lights.*      nr_lights, pos / color / attenuation / dir [128][3], cutoff[128], is_dir[128], active[128],
  *                 ambient[3], shadow_tint[3]                               (light.c:311-340, 473-530)
@@ -28,6 +31,10 @@
  * Channels are kept as listed.  Should two channels of one animation drive the same (joint, path), the engine shares one
  * keyframe cursor between them (joint->off[path], model.c:1305-1311) and its result depends on that cursor's history;
  * the device path evaluates the last listed one statelessly.  Assets the engine plays correctly have no such pair.
+ * Key times that do not strictly increase (equal or descending neighbours) are kept and FLAGGED (a<a>_ch_nonstrict,
+ * key_times_nonstrict): channel_time_to_idx scans from the cursor joint->off[path] of the previous frame (model.c:1266-1288,
+ * 1310), so the bracket it finds among equal times depends on that history; the device search is stateless and
+ * takes the first key with time <= t[i] as if the cursor were 0.  glTF requires strictly increasing input accessors.
  * Not restated: mesh_optimize()'s vertex reordering (meshoptimizer, an absent third-party dependency:
  * vertices stay in file order, which permutes the skinned output, not its values), textures, materials,
  * sfx, the editor's instantiators (models without an "entity" / "character" array create no entities here).

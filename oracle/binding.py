@@ -147,9 +147,11 @@ def _declare(L):
     L.clapo_aabb_avg_edge.restype = C.c_float
     L.clapo_entities_lod.argtypes = [C.c_uint32, U32P, F32P, F32P, F32P, F32P, I32P, F32P, U8P, I32P, I32P, I32P]
     L.clapo_skin.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P]
+    L.clapo_skin_w.argtypes = [C.c_uint32, F32P, F32P, U8P, F32P, F32P, F32P, F32P, F32P]
     L.clapo_entities_frame_tiles_mt.argtypes = [C.c_uint32, U32P, C.c_uint32, F32P, F32P, I32P, I32P, F32P, U8P, U32P, U32P,
                                                 F32P, F32P, F32P, F32P, C.POINTER(Frustum), C.c_void_p]
     L.clapo_entities_frame_tiles_mt.restype = C.c_uint32
+    L.clapo_omp_max_threads.restype = C.c_uint32
     L.clapo_animation_time.argtypes = [C.c_uint32, C.c_uint32, U32P, F32P, F64P, F32P, U8P, C.c_double, F32P, U8P]
     L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
                                           C.c_void_p, C.c_void_p, C.c_void_p, U8P]
@@ -295,21 +297,23 @@ def pose(sk, an, times, char_mx, trs, cursor=None):
     return jt, gl, jp
 
 
-def skin(mesh, vert_first, vert_count, joint_transforms):
+def skin(mesh, vert_first, vert_count, joint_transforms, with_w=False):
     """Skin every character: character c uses mesh vertices [vert_first[c], +vert_count[c]) and its
-    own palette joint_transforms[c].  Returns (out_pos, out_nor) concatenated per character."""
+    own palette joint_transforms[c].  Returns (out_pos, out_nor) concatenated per character; with_w also the
+    fourth component of total_local_pos (model.vert:36-38)."""
     L = lib()
     total = int(np.sum(vert_count))
     out_p = np.zeros((total, 3), np.float32)
     out_n = np.zeros((total, 3), np.float32)
+    out_w = np.zeros(total, np.float32)
     at = 0
     for c in range(len(vert_count)):
         f, k = int(vert_first[c]), int(vert_count[c])
-        L.clapo_skin(k, np.ascontiguousarray(mesh["position"][f:f + k]), np.ascontiguousarray(mesh["normal"][f:f + k]),
-                     np.ascontiguousarray(mesh["joints"][f:f + k]), np.ascontiguousarray(mesh["weights"][f:f + k]),
-                     np.ascontiguousarray(joint_transforms[c]), out_p[at:at + k], out_n[at:at + k])
+        L.clapo_skin_w(k, np.ascontiguousarray(mesh["position"][f:f + k]), np.ascontiguousarray(mesh["normal"][f:f + k]),
+                       np.ascontiguousarray(mesh["joints"][f:f + k]), np.ascontiguousarray(mesh["weights"][f:f + k]),
+                       np.ascontiguousarray(joint_transforms[c]), out_p[at:at + k], out_n[at:at + k], out_w[at:at + k])
         at += k
-    return out_p, out_n
+    return (out_p, out_n, out_w) if with_w else (out_p, out_n)
 
 
 # ------------------------------------------------------------------ rigid bodies (parity unpinned)
@@ -598,6 +602,10 @@ def bodies_rotate_from_entities(link_body, link_entity, rot, parent, dirty, quat
                                             np.ascontiguousarray(rot, np.float32).reshape(-1),
                                             np.ascontiguousarray(parent, np.int32),
                                             np.ascontiguousarray(dirty, np.uint8), quat.reshape(-1))
+
+
+def omp_max_threads():
+    return int(lib().clapo_omp_max_threads())
 
 
 def entities_frame_tiles_mt(scene, st, fr, vis_mask):

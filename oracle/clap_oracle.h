@@ -182,6 +182,9 @@ void clapo_skeleton_bind(uint32_t nr_joints, const float *invmx, float *bind);
 void clapo_skin(uint32_t n_verts, const float *position, const float *normal,
                 const uint8_t *joints, const float *weights,
                 const float *joint_transforms, float *out_pos, float *out_nor);
+void clapo_skin_w(uint32_t n_verts, const float *position, const float *normal,
+                  const uint8_t *joints, const float *weights,
+                  const float *joint_transforms, float *out_pos, float *out_nor, float *out_w);
 
 /* ---- rigid bodies: schedule, integrate, broadphase (core/physics.c over ODE; PARITY UNPINNED,
  *      see physics.c) ---- */
@@ -212,6 +215,7 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
                                        uint32_t *pairs, uint64_t max_pairs);
 
 /* the frame on all host cores (OpenMP over tiles / mask words): context for the 1-thread baseline */
+uint32_t clapo_omp_max_threads(void);
 uint32_t clapo_entities_frame_tiles_mt(uint32_t n_tiles, const uint32_t *tile_row_start, uint32_t n,
                                        const float *pos_scale, const float *rot,
                                        const int32_t *parent, const int32_t *model,

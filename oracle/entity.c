@@ -4,6 +4,9 @@
  * Entity transform hierarchy -> inverse -> world AABB -> frustum cull,
  * restated from the reference's core/model.c, core/view.c, core/transform.c.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "clap_oracle.h"
 #include "lm.h"
 
@@ -280,6 +283,16 @@ uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aab
  * (tile = contiguous range holding whole subtrees, parents first) parallelises over tiles, and the
  * frustum test over 64-entity words.  OpenMP; same arithmetic as clapo_entities_update / _cull.
  */
+/* threads the OpenMP figure below really runs on (bench.py reports it beside the figure) */
+uint32_t clapo_omp_max_threads(void)
+{
+#ifdef _OPENMP
+    return (uint32_t)omp_get_max_threads();
+#else
+    return 1u;
+#endif
+}
+
 uint32_t clapo_entities_frame_tiles_mt(uint32_t n_tiles, const uint32_t *tile_row_start, uint32_t n,
                                        const float *pos_scale, const float *rot,
                                        const int32_t *parent, const int32_t *model,

@@ -19,6 +19,15 @@ void clapo_skin(uint32_t n_verts, const float *position, const float *normal,
                 const uint8_t *joints, const float *weights,
                 const float *joint_transforms, float *out_pos, float *out_nor)
 {
+    clapo_skin_w(n_verts, position, normal, joints, weights, joint_transforms, out_pos, out_nor, 0);
+}
+
+/* The same with total_local_pos.w (model.vert:36-38,44: the shader carries the vec4 on into proj * view * trs), the
+ * fourth component of the very loop above; out_w may be NULL. */
+void clapo_skin_w(uint32_t n_verts, const float *position, const float *normal,
+                  const uint8_t *joints, const float *weights,
+                  const float *joint_transforms, float *out_pos, float *out_nor, float *out_w)
+{
     for (uint32_t v = 0; v < n_verts; v++) {
         const float p[4] = { position[3 * (size_t)v], position[3 * (size_t)v + 1], position[3 * (size_t)v + 2], 1.0f };
         const float n[4] = { normal[3 * (size_t)v], normal[3 * (size_t)v + 1], normal[3 * (size_t)v + 2], 0.0f };
@@ -38,5 +47,7 @@ void clapo_skin(uint32_t n_verts, const float *position, const float *normal,
             out_pos[3 * (size_t)v + r] = tp[r];
             out_nor[3 * (size_t)v + r] = tn[r];
         }
+        if (out_w)
+            out_w[v] = tp[3];
     }
 }

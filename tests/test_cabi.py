@@ -62,3 +62,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.ClapGpuError):
         _lib.lib()
+
+
+def test_experiment_switches_cannot_reach_a_release_build():
+    """The A/B and sensitivity macros of the kernels (some compile arithmetic out: wrong results on purpose) need
+    -DCLAPGPU_EXPERIMENT, and an experiment build reports an ABI version with the top bit set, which _lib refuses."""
+    import subprocess
+    src = os.path.join(ROOT, "clap_amd", "csrc", "runtime.hip")
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-E", src,
+            "--cuda-host-only", "-o", "-"]
+    for macro in ("CLAPGPU_EXP_NO_INVERT", "CLAPGPU_EXP_NO_AABB", "CLAPGPU_PLAIN_STORES", "BP_SEARCH_IN_FLIGHT=2"):
+        p = subprocess.run(base + ["-D" + macro], capture_output=True, text=True)
+        assert p.returncode != 0 and "experiment switches" in p.stderr, macro
+    p = subprocess.run(base + ["-DCLAPGPU_EXPERIMENT", "-DCLAPGPU_EXP_NO_AABB"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-500:]
+    line = [l for l in p.stdout.splitlines() if "clapgpu_abi_version(void)" in l and "return" in l][-1]
+    assert "0x80000000u" in line
+    p = subprocess.run(base, capture_output=True, text=True)
+    line = [l for l in p.stdout.splitlines() if "clapgpu_abi_version(void)" in l and "return" in l][-1]
+    assert p.returncode == 0 and "0x80000000u" not in line

@@ -3,9 +3,6 @@ libclapgpu's clapgpu_exchange (RCCL opened at run time from C, unique id carried
 clapgpu_exchange_visible = ncclAllGather of the visibility mask + expansion on the side stream, and
 clapgpu_visible_compact over a gathered mask with a non-zero index base -- against the oracle's visible list.
 (N > 1 on hardware is the driver's scaling run; the multi-rank logic is covered on CPU by test_shard_cpu.py.)"""
-import os
-import socket
-
 import numpy as np
 import pytest
 
@@ -13,25 +10,6 @@ from clap_amd import synth, tiler
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-@pytest.fixture(scope="module")
-def process_group(cuda_device):
-    import torch
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(cuda_device))
-    yield dist
-    dist.destroy_process_group()
 
 
 def _oracle_visible(scene, cam):

@@ -3,7 +3,9 @@ the reference's golden vectors.
 
 Tolerance (BASELINE.json north_star: "within 1e-5 relative for float transforms/positions"):
 the reference evaluates lerp in double and slerp through double acos/sin/cos; device libm is not
-glibc, so these outputs are compared with rtol 1e-5 on a scale of the array's own magnitude.
+glibc, so these outputs are compared with rtol 1e-5 -- every OBJECT against its own magnitude: each joint's T, R and S,
+the 3x3 block and the translation column of each joint's palette matrix, each joint position, each skinned vertex
+position and normal (tests/helpers.py; the worst cases seen go to gpurun_out/parity_bounds.json).
 """
 import glob
 import os
@@ -14,21 +16,46 @@ import pytest
 
 from clap_amd import synth
 from oracle import binding as ob
+from helpers import (RTOL, assert_mat4_close, assert_trs_close, assert_vec_close, pose_term_scales, skin_term_scales)
 from test_oracle_pose import load_pose
 
 pytestmark = pytest.mark.gpu
-RTOL = 1e-5
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pose_*.npz")))
 
 
-def assert_close(got, exp, what, scale=None):
-    got = np.asarray(got, np.float64)
-    exp = np.asarray(exp, np.float64)
-    assert got.shape == exp.shape, what
-    s = max(float(np.abs(exp).max()), 1e-30) if scale is None else scale
-    err = float(np.abs(got - exp).max()) / s
-    assert err <= RTOL, f"{what}: max |diff| / max |ref| = {err:.3e} > {RTOL}"
+def assert_pose_close(out, trs, jt, jp, reach, what, trs_on=True, pos_on=True, sk=None, gl=None, ent_mx=None):
+    """Every joint's T, R, S, its palette matrix (3x3 block and translation column separately) and its world position,
+    each against its OWN magnitude (tests/helpers.py): the 1e-5 bar per object, not per array.  With the oracle's globals
+    (sk, gl, ent_mx) the summed quantities -- translation columns, joint positions -- whose result cancelled far below
+    their terms are held to helpers.COND_ULPS fp32 ulps of those terms instead (helpers._hold)."""
+    s_jt = s_pos = None
+    if gl is not None:
+        s_jt, s_pos = pose_term_scales(sk, gl, jt, ent_mx)
+        s_jt, s_pos = s_jt[:, reach], s_pos[:, reach]
+    if trs_on:
+        assert_trs_close(out["trs"], trs, what + " T/R/S", key="pose T/R/S")
+    assert_mat4_close(out["joint_transforms"][:, reach], jt[:, reach], what + " joint_transforms", key="pose joint_transforms",
+                      t_terms=s_jt)
+    if pos_on:
+        assert_vec_close(out["joint_pos"][:, reach], jp[:, reach], what + " joint pos", key="pose joint_pos", terms=s_pos)
+
+
+def oracle_pose(sk, anims, which, t, ent_mx, trs):
+    """The oracle for a batch whose characters play different animations: (joint_transforms, globals, joint_pos);
+    trs is updated in place."""
+    n, J = trs.shape[0], sk["nr_joints"]
+    jt = np.zeros((n, J, 16), np.float32)
+    gl = np.zeros((n, J, 16), np.float32)
+    jp = np.zeros((n, J, 4), np.float32)
+    for a_id, an in enumerate(anims):
+        sel = np.flatnonzero(which == a_id)
+        if not sel.size:
+            continue
+        sub = trs[sel].copy()
+        j1, g1, p1 = ob.pose(sk, an, t[sel], ent_mx[sel], sub)
+        trs[sel], jt[sel], gl[sel], jp[sel] = sub, j1, g1, p1
+    return jt, gl, jp
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -44,9 +71,10 @@ def test_pose_matches_reference_golden(path, cuda_device):
         batch.set_frame_times(times[f])
         batch.pose_update()
         out = batch.download()
-        assert_close(out["trs"], ref["trs"][f], f"frame {f} T/R/S")
-        assert_close(out["joint_transforms"][:, reach], ref["joint_transforms"][f][:, reach], f"frame {f} joint_transforms")
-        assert_close(out["joint_pos"][:, reach], ref["joint_pos"][f][:, reach], f"frame {f} joint pos")
+        trs_o = np.tile(ch["trs0"], (n, 1, 1)) if f == 0 else trs_o        # the oracle's globals: term magnitudes only
+        _jt, gl, _jp = ob.pose(dict(sk, bind=ref["bind"]), an, times[f], ch["char_mx"], trs_o)
+        assert_pose_close(out, ref["trs"][f], ref["joint_transforms"][f], ref["joint_pos"][f], reach, f"frame {f}",
+                          sk=dict(sk, bind=ref["bind"]), gl=gl, ent_mx=ch["char_mx"])
         assert not out["joint_transforms"][:, unreach].any(), "joints outside joint 0's tree must stay untouched"
 
 
@@ -72,19 +100,11 @@ def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
     reach = sk["order"]
     for f, t in enumerate([ch["phase"], (ch["phase"] + 0.61) % 2.4, np.full(n, 2.0, np.float32), np.full(n, -1.0, np.float32)]):
         t = t.astype(np.float32)
-        jt = np.zeros((n, J, 16), np.float32)
-        jp = np.zeros((n, J, 4), np.float32)
-        for a_id, an in ((0, an0), (1, an1)):
-            sel = np.flatnonzero(which == a_id)
-            sub = trs[sel].copy()
-            j1, _g, p1 = ob.pose(sk, an, t[sel], ch["char_mx"][sel], sub)
-            trs[sel], jt[sel], jp[sel] = sub, j1, p1
+        jt, gl, jp = oracle_pose(sk, (an0, an1), which, t, ch["char_mx"], trs)
         batch.set_frame_times(t, which)
         batch.pose_update()
         out = batch.download()
-        assert_close(out["trs"], trs, f"frame {f} T/R/S")
-        assert_close(out["joint_transforms"][:, reach], jt[:, reach], f"frame {f} joint_transforms")
-        assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
+        assert_pose_close(out, trs, jt, jp, reach, f"frame {f}", sk=sk, gl=gl, ent_mx=ch["char_mx"])
 
 
 @pytest.mark.parametrize("J", [64, 40, 1], ids=["64j", "40j_short_rows", "one_joint"])
@@ -109,13 +129,7 @@ def test_pose_streaming_loop_clips_rows_masks_and_tail(J, cuda_device):
     which = (np.arange(n) % 4 == 1).astype(np.int32)
     t = ((ch["phase"] * 1.3) - 0.2).astype(np.float32)              # some below 0, some past an1's end
     trs = np.tile(ch["trs0"], (n, 1, 1))
-    jt = np.zeros((n, J, 16), np.float32)
-    jp = np.zeros((n, J, 4), np.float32)
-    for a_id, an in ((0, an0), (1, an1)):
-        sel = np.flatnonzero(which == a_id)
-        sub = trs[sel].copy()
-        j1, _g, p1 = ob.pose(sk, an, t[sel], ent_mx[perm[sel]], sub)
-        trs[sel], jt[sel], jp[sel] = sub, j1, p1
+    jt, gl, jp = oracle_pose(sk, (an0, an1), which, t, ent_mx[perm], trs)
     batch.set_frame_times(t, which)
     reach = sk["order"]
     for trs_on, pos_on in ((True, True), (False, True), (True, False), (False, False)):
@@ -127,14 +141,10 @@ def test_pose_streaming_loop_clips_rows_masks_and_tail(J, cuda_device):
         batch.pose_update()
         out = batch.download()
         what = f"J={J} trs={trs_on} pos={pos_on}"
-        if trs_on:
-            assert_close(out["trs"], trs, what + " T/R/S")
-        else:
+        assert_pose_close(out, trs, jt, jp, reach, what, trs_on=trs_on, pos_on=pos_on, sk=sk, gl=gl, ent_mx=ent_mx[perm])
+        if not trs_on:
             assert (out["trs"] == 7.5).all(), what + ": masked T/R/S was written"
-        assert_close(out["joint_transforms"][:, reach], jt[:, reach], what + " joint_transforms")
-        if pos_on:
-            assert_close(out["joint_pos"][:, reach], jp[:, reach], what + " joint pos")
-        else:
+        if not pos_on:
             assert (out["joint_pos"] == 9.0).all(), what + ": masked joint positions were written"
 
 
@@ -155,19 +165,11 @@ def test_pose_many_characters_matches_oracle(akw, two, cuda_device):
     reach = sk["order"]
     for f, t in enumerate([ch["phase"], (ch["phase"] * 1.37 + 0.2) % 2.2]):
         t = t.astype(np.float32)
-        jt = np.zeros((n, J, 16), np.float32)
-        jp = np.zeros((n, J, 4), np.float32)
-        for a_id, an in enumerate(anims):
-            sel = np.flatnonzero(which == a_id)
-            sub = trs[sel].copy()
-            j1, _g, p1 = ob.pose(sk, an, t[sel], ch["char_mx"][sel], sub)
-            trs[sel], jt[sel], jp[sel] = sub, j1, p1
+        jt, gl, jp = oracle_pose(sk, anims, which, t, ch["char_mx"], trs)
         batch.set_frame_times(t, which)
         batch.pose_update()
         out = batch.download()
-        assert_close(out["trs"], trs, f"frame {f} T/R/S")
-        assert_close(out["joint_transforms"][:, reach], jt[:, reach], f"frame {f} joint_transforms")
-        assert_close(out["joint_pos"][:, reach], jp[:, reach], f"frame {f} joint pos")
+        assert_pose_close(out, trs, jt, jp, reach, f"frame {f}", sk=sk, gl=gl, ent_mx=ch["char_mx"])
 
 
 def test_animated_update_clock_on_device(cuda_device, golden_dir):
@@ -197,7 +199,8 @@ def test_animated_update_clock_on_device(cuda_device, golden_dir):
         assert np.array_equal(clk["ani_time"].view(np.uint64), z["ref_ani_time"][f].view(np.uint64)), f"frame {f} ani_time"
         assert np.array_equal(clk["ani_time"], ani) and np.array_equal(clk["ended"], ended)
         assert np.array_equal(clk["frame_time"].view(np.uint32), ft.view(np.uint32)), f"frame {f} frame_time"
-        assert_close(batch.download()["joint_transforms"][:, reach], z["ref_joint_transforms"][f][:, reach], f"frame {f}")
+        assert_mat4_close(batch.download()["joint_transforms"][:, reach], z["ref_joint_transforms"][f][:, reach], f"frame {f}",
+                          key="pose joint_transforms")
         restarts += int(ended.sum())
     assert restarts > n // 2, "the fixture runs past the end of the animation"
 
@@ -246,13 +249,59 @@ def test_skin_matches_oracle(shared_mesh, cuda_device):
     batch.skin()
     out = batch.download()
     exp_p, exp_n = ob.skin(mesh, vf, vc, out["joint_transforms"])     # same palette in: isolates the skinning kernel
-    assert_close(out["out_position"], exp_p, "skinned positions")
-    assert_close(out["out_normal"], exp_n, "skinned normals")
+    assert_vec_close(out["out_position"], exp_p, "skinned positions", key="skin position (same palette)")
+    assert_vec_close(out["out_normal"], exp_n, "skinned normals", key="skin normal (same palette)")
     # and end to end against the oracle's own palette
     trs = np.tile(ch["trs0"], (n, 1, 1))
-    jt, _g, _p = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
+    jt, gl, _p = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
     exp_p2, _ = ob.skin(mesh, vf, vc, jt)
-    assert_close(out["out_position"], exp_p2, "pose -> skin end to end")
+    s_jt, _s = pose_term_scales(sk, gl, jt, ch["char_mx"])
+    assert_vec_close(out["out_position"], exp_p2, "pose -> skin end to end", key="pose -> skin position",
+                     terms=skin_term_scales(mesh, vf, vc, jt, s_jt))
+
+
+def test_skin_w_output_with_unnormalised_weights(cuda_device):
+    """shaders/model.vert:32-45: the shader feeds proj * view * trs the VEC4 total_local_pos, whose w is the sum of the
+    vertex's weights (times row 3 of the palette matrices) -- never renormalised.  With clapgpu_skin_batch.out_w the
+    kernel emits that w; vec4(out_position, out_w) is then what the shader would have used, also for weights that
+    do not sum to 1.  Same palette in on both sides: bit-exact against oracle/skin.c's fourth component."""
+    from clap_amd import animation
+    from helpers import assert_bits_equal
+    J, n = 64, 19
+    sk = synth.skeleton(J, 8, seed=3)
+    an = synth.animation(J, 30, 2.0, seed=3)
+    ch = synth.characters(n, J, seed=3)
+    sk["bind"] = ob.skeleton_bind(sk)
+    vc = np.random.Generator(np.random.PCG64(9)).integers(1, 600, n).astype(np.uint32)
+    mesh = synth.skinned_mesh(int(vc.sum()), J, seed=5)
+    rng = np.random.Generator(np.random.PCG64(10))
+    mesh["weights"] = (mesh["weights"] * rng.uniform(0.25, 1.75, (mesh["n_verts"], 1))).astype(np.float32)   # sums in [0.25, 1.75]
+    mesh["weights"][::7] = 0.0                                          # and vertices without any influence: w = 0
+    vf = np.concatenate([[0], np.cumsum(vc[:-1])]).astype(np.uint32)
+    model = animation.SkinnedModel(sk, [an], mesh=mesh, bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
+    batch.set_frame_times(ch["phase"])
+    batch.pose_update()
+    batch.skin()
+    o0 = batch.download()
+    assert "out_w" not in o0
+    batch.set_skin_w(True)
+    batch.out_w.fill_(-7.0)
+    batch.skin()
+    o1 = batch.download()
+    ep, en, ew = ob.skin(mesh, vf, vc, o1["joint_transforms"], with_w=True)
+    assert_bits_equal(o1["out_position"], ep, "positions (w on)")
+    assert_bits_equal(o1["out_normal"], en, "normals (w on)")
+    assert_bits_equal(o1["out_w"], ew, "total_local_pos.w")
+    assert_bits_equal(o1["out_position"], o0["out_position"], "positions do not depend on the w output")
+    wsum = mesh["weights"].astype(np.float64).sum(axis=1)
+    cat = np.concatenate([np.arange(f, f + k) for f, k in zip(vf, vc)])
+    assert np.abs(o1["out_w"] - wsum[cat]).max() <= 1e-6, "affine palettes: w is the sum of the weights"
+    assert np.abs(o1["out_w"] - 1.0).max() > 0.5, "the fixture's weights are far from normalised"
+    batch.set_skin_w(False)                                            # and off again: the buffer is left alone
+    batch.out_w.fill_(-7.0)
+    batch.skin()
+    assert (batch.out_w == -7.0).all()
 
 
 def test_c3_shape_properties(cuda_device):
@@ -277,7 +326,7 @@ def test_c3_shape_properties(cuda_device):
     batch.joint_transforms.mul_(2.0)                                  # linearity: 2 * palette -> 2 * output
     batch.skin()
     o2 = batch.download()
-    assert_close(o2["out_position"], 2.0 * o1["out_position"], "skin linear in palette")
+    assert_vec_close(o2["out_position"], 2.0 * o1["out_position"], "skin linear in palette")
     assert np.isfinite(o1["joint_transforms"]).all() and np.isfinite(o1["out_position"]).all()
 
 
@@ -303,22 +352,16 @@ def test_c3_full_size_pose_and_skin_match_oracle(cuda_device):
     batch.skin()
     out = batch.download()
     trs = np.tile(ch["trs0"], (n, 1, 1))
-    jt, _g, jp = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
+    jt, gl, jp = ob.pose(sk, an, ch["phase"], ch["char_mx"], trs)
     reach = sk["order"]
-    assert_close(out["trs"], trs, "C3 full size T/R/S")
-    assert_close(out["joint_transforms"][:, reach], jt[:, reach], "C3 full size joint_transforms")
-    assert_close(out["joint_pos"][:, reach], jp[:, reach], "C3 full size joint pos")
-    # per-character worst case too, so one bad character cannot hide in the global maximum
-    d = np.abs(out["joint_transforms"][:, reach].astype(np.float64) - jt[:, reach]).reshape(n, -1).max(axis=1)
-    s = np.abs(jt[:, reach]).reshape(n, -1).max(axis=1)
-    assert float((d / s).max()) <= RTOL, f"worst character {int((d / s).argmax())}: {(d / s).max():.3e}"
+    assert_pose_close(out, trs, jt, jp, reach, "C3 full size", sk=sk, gl=gl, ent_mx=ch["char_mx"])
     exp_p, exp_n = ob.skin(mesh, vf, vc, out["joint_transforms"])      # same palette in: isolates k_skin
-    assert_close(out["out_position"], exp_p, "C3 full size skinned positions")
-    assert_close(out["out_normal"], exp_n, "C3 full size skinned normals")
+    assert_vec_close(out["out_position"], exp_p, "C3 full size skinned positions", key="skin position (same palette)")
+    assert_vec_close(out["out_normal"], exp_n, "C3 full size skinned normals", key="skin normal (same palette)")
     exp_p2, exp_n2 = ob.skin(mesh, vf, vc, jt)                         # end to end against the oracle's palette
-    assert_close(out["out_position"], exp_p2, "C3 full size pose -> skin positions")
-    assert_close(out["out_normal"], exp_n2, "C3 full size pose -> skin normals")
-    # per-vertex bound (positions scale with the character, so bound each vertex by its own character's extent)
-    ext = np.abs(exp_p2).reshape(n, vpc * 3).max(axis=1)
-    dv = np.abs(out["out_position"].astype(np.float64) - exp_p2).reshape(n, vpc * 3).max(axis=1)
-    assert float((dv / np.maximum(ext, 1e-30)).max()) <= RTOL
+    s_jt, _s = pose_term_scales(sk, gl, jt, ch["char_mx"])
+    s_v = skin_term_scales(mesh, vf, vc, jt, s_jt)
+    assert_vec_close(out["out_position"], exp_p2, "C3 full size pose -> skin positions", key="pose -> skin position", terms=s_v)
+    # normals: sum_i w_i * (J3_i n): no translation term, |n| <= 1
+    assert_vec_close(out["out_normal"], exp_n2, "C3 full size pose -> skin normals", key="pose -> skin normal",
+                     terms=skin_term_scales(dict(mesh, position=mesh["normal"]), vf, vc, jt, np.zeros_like(s_jt)))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Is k_entities_tiles bound by instruction issue?  The same launch (same bytes in and out) with parts of the arithmetic
-# compiled out (wrong results; A/B builds made by `make -C clap_amd/csrc OUT=../lib_x1 EXTRA=-DCLAPGPU_EXP_NO_AABB` and
-# `OUT=../lib_x2 EXTRA="-DCLAPGPU_EXP_NO_AABB -DCLAPGPU_EXP_NO_INVERT"`), timed under rocprofv3 at 1 M and 4 M entities.
+# compiled out (wrong results; A/B builds made by `make -C clap_amd/csrc OUT=../lib_x1 EXTRA="-DCLAPGPU_EXPERIMENT -DCLAPGPU_EXP_NO_AABB"` and
+# `OUT=../lib_x2 EXTRA="-DCLAPGPU_EXPERIMENT -DCLAPGPU_EXP_NO_AABB -DCLAPGPU_EXP_NO_INVERT"`), timed under rocprofv3 at 1 M and 4 M entities.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/${1:-ent_sens}
 rm -rf "$out"; mkdir -p "$out"

@@ -3,7 +3,7 @@
 #   tools/profile_entities_scale.sh r02_entities_scale
 # For 1 M / 2 M / 4 M entities (125k / 250k / 500k chains x depth 8): rocprofv3 --kernel-trace --stats, then FETCH_SIZE and
 # WRITE_SIZE in separate counter-only passes, for the shipped library (non-temporal stores) and for an A/B build with
-# default-policy stores (clap_amd/lib_plain, make EXTRA=-DCLAPGPU_PLAIN_STORES OUT=../lib_plain).  Output: gpurun_out/<tag>/.
+# default-policy stores (clap_amd/lib_plain, make EXTRA="-DCLAPGPU_EXPERIMENT -DCLAPGPU_PLAIN_STORES" OUT=../lib_plain).  Output: gpurun_out/<tag>/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tag=${1:-r02_entities_scale}
 out=$R/gpurun_out/$tag
