@@ -235,7 +235,12 @@ SYMBOLS = {
                                               C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_shard_tile_range": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32)]),
+    "clapgpu_host_malloc_mapped": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
+    "clapgpu_entities_apply_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "clapgpu_entities_export_rebuilt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_wait_word": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "clapgpu_exchange_set_library": (None, [C.c_char_p]),
+    "clapgpu_exchange_available": (C.c_int, []),
     "clapgpu_exchange_unique_id": (C.c_int, [C.c_void_p]),
     "clapgpu_exchange_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "clapgpu_exchange_destroy": (None, [C.c_void_p]),

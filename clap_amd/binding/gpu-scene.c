@@ -52,6 +52,7 @@ bool ref_view_entity_in_frustum(struct view *view, entity3d *e);
 #include "clapgpu_snapshot.h"
 
 #define NO_REC 0xffffffffu
+#define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
 struct gs_rec {
     entity3d    *e;             /* key; NULL = free record */
@@ -65,10 +66,13 @@ struct gs_rec {
     uint32_t    flags;
     uint32_t    gen;            /* last frame this entity was met in the queue */
     uint32_t    order_pos;      /* its position in that frame's walk */
-    uint8_t     cls;            /* 0 unknown, 1 batched, 2 host, 3 host but deferred behind the frame's pose (joint-attached subtrees) */
+    uint8_t     cls;            /* 0 unknown, 1 batched, 2 host, 3 host but deferred behind the frame's pose, 4 batched in the frame's
+                                   SECOND entity launch, behind the pose: subtrees riding a batched character's joint */
+    uint8_t     att;            /* the mirror has this entity marked as joint-attached */
     uint8_t     self_ok;
     uint8_t     xform_dirty;    /* xform.updated as seen in step 3 (cleared in step 5, like default_update) */
     uint8_t     pending;        /* on the touched list (notification mode) */
+    uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
 };
 
 struct gs_model { model3d *model; uint32_t handle; };
@@ -97,6 +101,13 @@ struct gpu_scene {
     uint32_t        *touched; uint32_t n_touched, cap_touched;
     uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
     uint32_t        *deferred; uint32_t n_deferred, cap_deferred;  /* class 3 records in list order (last walk) */
+    uint32_t        *att_list; uint32_t n_att, cap_att;            /* class 4 records in list order (last walk) */
+    uint32_t        *att_handles; float *att_jt, *att_bind; uint32_t cap_att_roots;   /* scratch of the second launch */
+    /* host-class entities whose BATCHED parent comes later in the list (last walk): the reference runs such a child
+     * before its parent, i.e. against the parent's mx / seq of the PREVIOUS frame (model.c:1911-1922); a fast frame
+     * writes all batched results back first, so it keeps each such parent's old mx / seq aside for the child's hook */
+    uint32_t        *lag_parent; uint32_t n_lag, cap_lag;
+    struct lag_keep { mat4x4 mx; uint16_t seq; } *lag_keep;
     uint64_t        *posmap; uint32_t cap_posmap;                  /* scratch: bounding-volume candidates by queue position */
     uint32_t        *slots; uint32_t cap_slots;                    /* scratch: rebuilt slots of the frame */
     uint32_t        n_batched;
@@ -212,6 +223,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
+    free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -223,9 +235,77 @@ void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere) { gs->a
 
 /* The joint-attached subtrees this frame's gpu_mq_update() held back (class 3), in list order, now that the parents'
  * joint transforms of the frame exist.  Called by gpu_anim_update(); a frame driver without it calls this itself. */
+static void bv_pick(struct scene *scene, entity3d *e);
+static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq);
+
+/* The frame's second entity launch: the subtrees riding a batched character's joint (class 4), now that the palettes of
+ * the frame are in the entities (e->parent->joint_transforms[e->parent_joint], model.c:1633-1640). */
+static int attached_pass(struct gpu_scene *gs, struct mq *mq)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    uint32_t n_roots = 0;
+    for (uint32_t k = 0; k < gs->n_att; k++) {
+        const struct gs_rec *r = &gs->rec[gs->att_list[k]];
+        n_roots += r->e && r->att;
+    }
+    if (!n_roots) return 0;
+    if (n_roots > gs->cap_att_roots) {
+        uint32_t cap = gs->cap_att_roots ? gs->cap_att_roots : 64;
+        while (cap < n_roots) cap *= 2;
+        uint32_t *h = realloc(gs->att_handles, (size_t)cap * 4);
+        if (h) gs->att_handles = h;
+        float *a = realloc(gs->att_jt, (size_t)cap * 64);
+        if (a) gs->att_jt = a;
+        float *b = realloc(gs->att_bind, (size_t)cap * 64);
+        if (b) gs->att_bind = b;
+        if (!h || !a || !b) return _CERR_NOMEM;
+        gs->cap_att_roots = cap;
+    }
+    uint32_t q = 0;
+    for (uint32_t k = 0; k < gs->n_att; k++) {
+        const struct gs_rec *r = &gs->rec[gs->att_list[k]];
+        if (!r->e || !r->att) continue;
+        entity3d *e = r->e, *parent = e->parent;
+        if (!parent || !parent->joint_transforms || e->parent_joint < 0 ||
+            e->parent_joint >= (int)parent->txmodel->model->nr_joints) return _CERR_INVALID_ARGUMENTS;
+        gs->att_handles[q] = r->handle;
+        memcpy(gs->att_jt + 16 * (size_t)q, parent->joint_transforms[e->parent_joint], 64);
+        memcpy(gs->att_bind + 16 * (size_t)q, parent->txmodel->model->joints[e->parent_joint].bind, 64);
+        q++;
+    }
+    CK(clapgpu_scene_attached_update(gs->scene, q, gs->att_handles, gs->att_jt, gs->att_bind));
+    clapgpu_scene_arrays res = { 0 };
+    CK(clapgpu_scene_results(gs->scene, &res));
+    gs->res = res;
+    struct scene *scene = mq->priv;
+    for (uint32_t k = 0; k < gs->n_att; k++) {                   /* list order, parents first */
+        struct gs_rec *r = &gs->rec[gs->att_list[k]];
+        if (!r->e || r->slot >= res.n_slots) continue;
+        if ((res.rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1) {
+            scatter_one(gs, r, &res, r->slot, true);
+            st->written_back++;
+        }
+        if (scene) bv_pick(scene, r->e);                         /* default_update's pick, with this frame's box (model.c:1697-1713) */
+        st->attached++;
+    }
+    return 0;
+}
+
 void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq)
 {
     if (!gs || !mq) return;
+    if (gs->n_att) {
+        const int rc = attached_pass(gs, mq);
+        if (rc) {
+            /* the device pass could not run: the entities' own hooks keep the frame whole, and the failure is loud */
+            fprintf(stderr, "gpu_scene: joint-attached pass failed (%d, %s): running %u hooks on the host\n", rc, clapgpu_last_error(), gs->n_att);
+            gs->stats.attach_failures++;
+            for (uint32_t k = 0; k < gs->n_att; k++) {
+                struct gs_rec *r = &gs->rec[gs->att_list[k]];
+                if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE)) entity3d_update(r->e, mq->priv);
+            }
+        }
+    }
     for (uint32_t k = 0; k < gs->n_deferred; k++) {
         struct gs_rec *r = &gs->rec[gs->deferred[k]];
         if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE))
@@ -236,16 +316,18 @@ void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq)
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e)
 {
     const uint32_t i = rec_find(gs, e);
-    return i != NO_REC && gs->rec[i].gen == gs->gen && gs->rec[i].cls == 1;
+    return i != NO_REC && gs->rec[i].gen == gs->gen && (gs->rec[i].cls == 1 || gs->rec[i].cls == 4);
 }
 
 /* Criteria an entity meets on its own (step 2); the parent's class is folded in during the walk. */
 static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
 {
+    /* light carriers are batched: scatter_one() hands the position on.  An entity riding a joint (e->parent_joint) is
+     * batchable too -- in the frame's second launch, if its parent's palette is computed on the device this frame: the walk
+     * decides (class 4), since that depends on the parent */
     return e->update == gs->default_hook &&
            (gs->anim_elsewhere || !entity_animated(e)) &&
-           !(e->flags & (ENTITY3D_HAS_PHYSICS | ENTITY3D_IS_CHARACTER | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE)) &&
-           e->parent_joint == JOINT_TYPE_MAX;      /* light carriers are batched: scatter_one() hands the position on */
+           !(e->flags & (ENTITY3D_HAS_PHYSICS | ENTITY3D_IS_CHARACTER | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE));
 }
 
 /* The record of r's parent, or NO_REC if the parent is not an ALIVE member of this queue. */
@@ -289,7 +371,6 @@ static double now_ms(void)
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-#define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
 static inline void prefetch_entity(const entity3d *e)
 {
@@ -332,6 +413,12 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
                                           transform_rotation_quat(&e->xform), e->scale));
         st->uploaded++;
     }
+    const uint8_t att = r->cls == 4 && e->parent_joint != JOINT_TYPE_MAX;
+    if (fresh) r->att = 0;
+    if (att != r->att) {
+        CK(clapgpu_scene_entity_set_attach(gs->scene, r->handle, att));
+        r->att = att;
+    }
     return 0;
 }
 
@@ -357,7 +444,7 @@ static int unbatch(struct gpu_scene *gs, struct gs_rec *r)        /* left the ba
 
 static inline uint8_t verdict_ok(const struct gs_rec *r)
 {
-    return r->cls == 1 &&
+    return (r->cls == 1 || r->cls == 4) &&
            (r->flags & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE);
 }
 
@@ -484,12 +571,14 @@ static void *par_mirror(void *arg)
         r->pending = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
-        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (r->cls == 1) || e->parent != r->parent_e ||
-            (r->cls == 1 && (r->model != e->txmodel->model || r->handle == CLAPGPU_NO_ENTITY))) {
+        /* the entity's OWN criteria as the last walk saw them (self_ok): a plain entity that is host-class only because of
+         * where its parent stands in the list (cls 2, self_ok 1) may be touched without forcing a walk */
+        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
+            ((r->cls == 1 || r->cls == 4) && (r->model != e->txmodel->model || r->handle == CLAPGPU_NO_ENTITY))) {
             j->need_walk = 1;
             continue;
         }
-        if (r->cls != 1) continue;
+        if (r->cls != 1 && r->cls != 4) continue;
         const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
         r->flags = flags;
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
@@ -581,13 +670,13 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         r->pending = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
-        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (r->cls == 1) || e->parent != r->parent_e ||
-            (r->cls == 1 && r->model != e->txmodel->model)) {
+        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
+            ((r->cls == 1 || r->cls == 4) && r->model != e->txmodel->model)) {
             for (k++; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
             gs->n_touched = 0;
             return 1;
         }
-        if (r->cls == 1) CK(mirror_one(gs, r));
+        if (r->cls == 1 || r->cls == 4) CK(mirror_one(gs, r));
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
     }
     gs->n_touched = 0;
@@ -608,6 +697,11 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     if (clapgpu_scene_results(gs->scene, &res)) memset(&res, 0, sizeof(res));
     gs->res = res;
     const double t2 = now_ms();
+    for (uint32_t k = 0; k < gs->n_lag; k++) {                  /* last frame's bits of the parents some host child still has to see */
+        const entity3d *p = gs->rec[gs->lag_parent[k]].e;
+        memcpy(gs->lag_keep[k].mx, p->mx, sizeof(mat4x4));
+        gs->lag_keep[k].seq = p->seq;
+    }
 
     /* results: only what the kernel rebuilt.  Few of them: straight off the mask, in slot order (parents first), each
      * entity and its rows prefetched a few steps ahead.  Many: in LIST order -- the entity3d structs lie in memory in
@@ -670,9 +764,11 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
             if (k + 4 < R)
                 prefetch_entity(gs->rec[(uintptr_t)res.slot_user[gs->slots[k + 4]] - 1].e);
             const uint32_t slot = gs->slots[k];
-            scatter_one(gs, &gs->rec[(uintptr_t)res.slot_user[slot] - 1], &res, slot, true);
+            struct gs_rec *rr = &gs->rec[(uintptr_t)res.slot_user[slot] - 1];
+            if (rr->cls != 1) continue;                          /* class 4: after the pose, from the second launch */
+            scatter_one(gs, rr, &res, slot, true);
+            st->written_back++;
         }
-        st->written_back += R;
     }
     const double t3 = now_ms();
     /* host hooks + bounding-volume pick, merged in list order */
@@ -709,13 +805,24 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         const uint32_t ho = hc < gs->n_host ? gs->rec[gs->host_list[hc]].order_pos : 0xffffffffu;
         if (co == 0xffffffffu && ho == 0xffffffffu) break;
         if (ho < co) {
-            entity3d_update(gs->rec[gs->host_list[hc++]].e, mq->priv);
+            struct gs_rec *hr = &gs->rec[gs->host_list[hc++]];
+            if (hr->lag) {
+                /* listed before its batched parent: the reference has not updated that parent yet when this hook runs */
+                struct lag_keep *kp = &gs->lag_keep[hr->lag - 1], now;
+                entity3d *p = gs->rec[gs->lag_parent[hr->lag - 1]].e;
+                memcpy(now.mx, p->mx, sizeof(mat4x4)); now.seq = p->seq;
+                memcpy(p->mx, kp->mx, sizeof(mat4x4)); p->seq = kp->seq;
+                entity3d_update(hr->e, mq->priv);
+                memcpy(p->mx, now.mx, sizeof(mat4x4)); p->seq = now.seq;
+            } else
+                entity3d_update(hr->e, mq->priv);
         } else {
             cm &= cm - 1;
-            bv_pick(scene, gs->rec[gs->order[co]].e);
+            if (gs->rec[gs->order[co]].cls == 1)                 /* class 4 boxes are last frame's until the second launch */
+                bv_pick(scene, gs->rec[gs->order[co]].e);
         }
     }
-    st->batched = gs->n_batched; st->host = gs->n_host;
+    st->batched = gs->n_batched; st->host = gs->n_host + gs->n_deferred;
     if (getenv("GPU_SCENE_TIMING")) fprintf(stderr, "fast_frame: mirror %.3f device %.3f scatter %.3f (rebuilt %llu) hooks+bv %.3f (cand %u host %u)\n", t1 - t0, t2 - t1, t3 - t2, (unsigned long long)n_rebuilt, now_ms() - t3, n_cand, gs->n_host);
     st->ms_walk = t1 - t0; st->ms_device = t2 - t1; st->ms_scatter = now_ms() - t2;
     return 0;
@@ -741,7 +848,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->n_touched = 0;
     gs->topology_pending = false;
     gs->last_fast = false;
-    gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0;
+    gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0;
     clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);   /* the walk does the pick per entity */
 
     const double t0 = now_ms();
@@ -788,6 +895,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             r->order_pos = gs->n_order;
             gs->order[gs->n_order++] = i;
             r->self_ok = self_batchable(gs, e);
+            const bool rides_joint = e->parent && e->parent_joint != JOINT_TYPE_MAX;
             if (!r->self_ok) {
                 r->cls = 2;
                 r->parent_e = e->parent; r->parent_rec = NO_REC;
@@ -800,7 +908,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                      * by the reference, joint transforms included, which running the hook right here reproduces */
                     const uint32_t p = rec_find(gs, e->parent);
                     if (p != NO_REC && gs->rec[p].gen == gs->gen &&
-                        (e->parent_joint != JOINT_TYPE_MAX || gs->rec[p].cls == 3))
+                        (rides_joint || gs->rec[p].cls == 3 || gs->rec[p].cls == 4))
                         r->cls = 3;
                 }
             } else if (!e->parent) {
@@ -810,9 +918,21 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                  * parent's matrix of the previous frame in the reference (model.c:1911-1922 walks creation order):
                  * it stays on the host, where that lag is reproduced exactly, and so does everything below it. */
                 const uint32_t p = parent_rec(gs, r);
-                r->cls = p != NO_REC ? gs->rec[p].cls : 2;
+                const uint8_t pc = p != NO_REC ? gs->rec[p].cls : 2;
+                if (!rides_joint) {
+                    r->cls = pc;                                  /* 1, 4 (below a joint rider), or the parent's host class */
+                    if (pc == 4 && entity_animated(e)) r->cls = 3;   /* its own pose would need its matrix before the second launch */
+                } else if (gs->anim_elsewhere && pc == 1 && !entity_animated(e)) {
+                    /* rides a joint of a character whose palette the device computes this frame: the frame's second
+                     * entity launch, behind the pose (gpu_scene_run_deferred) */
+                    r->cls = 4;
+                } else {
+                    /* the parent's hook runs on the host (its palette is fresh when it returns), or the rider is nested
+                     * below another rider / animated itself: its own hook, deferred behind the pose when that runs elsewhere */
+                    r->cls = (gs->anim_elsewhere && p != NO_REC) ? 3 : 2;
+                }
             }
-            if (r->cls == 1) {
+            if (r->cls == 1 || r->cls == 4) {
                 CK(mirror_one(gs, r));
                 CK(link_parent(gs, r));
             } else {
@@ -867,6 +987,14 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 __builtin_prefetch(res.aabb_center + 3 * (size_t)a->slot, 0, 0);
             }
         }
+        if (r->cls == 4) {                                       /* after the pose, from the second launch: gpu_scene_run_deferred() */
+            st->batched++;
+            gs->n_batched++;
+            if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
+                r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
+            if (push_u32(&gs->att_list, &gs->n_att, &gs->cap_att, gs->order[k])) return _CERR_NOMEM;
+            continue;
+        }
         if (r->cls != 1) {
             st->host++;
             if (r->cls == 3) {                                   /* after the pose: gpu_scene_run_deferred() */
@@ -915,6 +1043,22 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     for (uint32_t k = 0; k < gs->n_order; k++) {
         const struct gs_rec *r = &gs->rec[gs->order[k]];
         gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
+    }
+    /* host-class children that precede their BATCHED parent in the list (see lag_parent above) */
+    gs->n_lag = 0;
+    for (uint32_t k = 0; k < gs->n_host; k++) {
+        struct gs_rec *r = &gs->rec[gs->host_list[k]];
+        r->lag = 0;
+        if (!r->e->parent) continue;
+        const uint32_t pr = rec_find(gs, r->e->parent);
+        if (pr == NO_REC || gs->rec[pr].gen != gs->gen || gs->rec[pr].cls != 1 || gs->rec[pr].order_pos < r->order_pos) continue;
+        if (push_u32(&gs->lag_parent, &gs->n_lag, &gs->cap_lag, pr)) return _CERR_NOMEM;
+        r->lag = gs->n_lag;
+    }
+    if (gs->n_lag) {
+        struct lag_keep *lk = realloc(gs->lag_keep, (size_t)gs->cap_lag * sizeof(*lk));
+        if (!lk) return _CERR_NOMEM;
+        gs->lag_keep = lk;
     }
     gs->walked = true;
     return 0;

@@ -27,6 +27,9 @@ struct gpu_scene_stats {
     unsigned int host;          /* entities whose own hook ran on the host (foreign hook, animated, physics, light, joint-attached) */
     unsigned int uploaded;      /* entities whose transform was pushed this frame */
     unsigned int written_back;  /* entities whose mx / inverse_mx / aabb were rebuilt this frame */
+    unsigned int attached;      /* of `batched`: entities of joint-attached subtrees, updated by the frame's second launch
+                                   (gpu_scene_run_deferred, behind the pose) */
+    unsigned int attach_failures;
     unsigned int registered, deleted;
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
     double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
@@ -87,7 +90,10 @@ struct view *gpu_scene_bound_view(void);
 void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere);
 /* With the pose elsewhere, an entity riding a parent's JOINT (e->parent_joint, model.c:1626-1641) needs the joint
  * transforms of the same frame, which exist only after gpu_anim_update(): gpu_mq_update() holds such entities and
- * everything below them back, and this runs their own hooks, in list order (gpu_anim_update() ends with it). */
+ * everything below them back, and this call finishes them (gpu_anim_update() ends with it): subtrees riding a BATCHED
+ * character's joint go through the frame's second entity launch (clapgpu_scene_attached_update: TRS -> (joint * bind) *
+ * local -> parent.mx * ... -> inverse, box, cull on the device), the rest -- riders of host-class parents, nested riders,
+ * riders that are animated themselves -- run their own hooks, in list order. */
 void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq);
 /* true if `e` was updated on the device by the last gpu_mq_update() */
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);

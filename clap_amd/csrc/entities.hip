@@ -38,9 +38,9 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     const float    *jt_pool;
     const float    *bind_pool;
     float          *attach_local;    // [n_attach] mat4 = (jt * bind) * local, written by k_attach_prepare
-    // camera bounding-volume query (bv_result == nullptr: off)
+    // camera bounding-volume query (bv_on == 0: off); bv_result may be NULL when only the containment mask is wanted
     float           bv_cam[3], bv_ctl[3];
-    uint32_t        bv_has_ctl, bv_ctl_entity;
+    uint32_t        bv_has_ctl, bv_ctl_entity, bv_on;
     unsigned long long *bv_result;
     uint64_t       *bv_inside;       // optional: one bit per entity, set where the query's boxes contain the point(s)
     uint64_t       *rebuilt_mask;    // optional: one bit per entity, set where this launch rebuilt the entity
@@ -249,7 +249,7 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
         for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
     }
 
-    const bool want_bv = e.bv_result != nullptr;
+    const bool want_bv = e.bv_on != 0;
     if (CULL || want_bv) {
         // Entities that were not rebuilt (or whose model skips AABBs) use their stored box.
         if (in_range && !(rebuild && has_aabb)) {
@@ -279,7 +279,7 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
                 const unsigned long long o = __shfl_xor(key, off);
                 key = o > key ? o : key;
             }
-            if (lane == 0 && key)
+            if (lane == 0 && key && e.bv_result)
                 atomicMax(e.bv_result, key);
         }
     }
@@ -493,7 +493,7 @@ void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_sta
     // tile of a launch with a camera query or a model table too large for LDS) goes through the general loop below.
     // Two loops, not a branch inside one: the straight-line loop must never be re-entered from a path whose stores
     // the compiler cannot count.
-    if (mt_cached && e.bv_result == nullptr) {
+    if (mt_cached && !e.bv_on) {
         // the first row's inputs are waited for HERE: left pending into the loop, their wait would sit inside it and,
         // on the way round, stand for "all but seven operations" -- the previous row's stores again
         asm volatile("" : : "v"(cur.ps.w), "v"(cur.q.w), "v"(cur.fl), "v"(cur.sq), "v"(cur.mi), "v"(cur.p));
@@ -758,6 +758,82 @@ void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t ind
     }
 }
 
+// ---- a host mirror's small frames: touched inputs in, rebuilt outputs out, through device-mapped host memory -----------
+// A frame of a testbed-sized scene (BASELINE configs[0]: 10 k entities) is a 15-30 us kernel; staged through device
+// slabs it paid three copies' fixed latencies and a blocking wait on top (0.15 ms).  Letting the update kernel itself
+// work on mapped host memory removes the copies but puts a PCIe round trip under every dependent load of its row walk
+// (measured: 27 -> 54 us).  So the update kernel stays on device memory, untouched, between two small streaming kernels:
+//   k_entities_apply_inputs   reads the frame's touched (slot, flags, TRS) records from mapped host memory -- one
+//                             coalesced 40-byte stream -- and scatters them into the device arrays;
+//   k_entities_export_rebuilt copies what the update rebuilt (its own rebuilt_mask says which slots) and the three bit
+//                             masks into the host's result arrays, then raises a completion word the host polls.
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_apply_inputs(float4 *pos_scale, float4 *rot, uint32_t *flags, const clapgpu_entity_input *list,
+                             uint32_t n_list, uint32_t n)
+{
+    const uint32_t k = blockIdx.x * ENT_BLOCK + threadIdx.x;
+    if (k >= n_list) return;
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(list + k);     // 40-byte records: ten dwords, 8-byte aligned
+    const uint2 h = *reinterpret_cast<const uint2 *>(r);
+    const uint32_t slot = h.x;
+    if (slot >= n) return;
+    const uint2 a = *reinterpret_cast<const uint2 *>(r + 2), b = *reinterpret_cast<const uint2 *>(r + 4);
+    const uint2 c = *reinterpret_cast<const uint2 *>(r + 6), d = *reinterpret_cast<const uint2 *>(r + 8);
+    pos_scale[slot] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x), __uint_as_float(b.y));
+    rot[slot] = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(d.x), __uint_as_float(d.y));
+    flags[slot] = h.y;
+}
+
+struct ExportK {
+    const float *mx, *inv_mx, *aabb, *center;            // device (the update's outputs)
+    const uint64_t *vis_mask, *rebuilt_mask, *inside_mask;
+    float *o_mx, *o_inv, *o_aabb, *o_center;             // device-mapped host memory
+    uint64_t *o_vis, *o_rebuilt, *o_inside;
+    uint32_t *counter, *done, done_value, n_rows;
+};
+
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_export_rebuilt(ExportK x)
+{
+    const int lane = lane_id();
+    const uint32_t row = blockIdx.x * (ENT_BLOCK / WAVE) + threadIdx.x / WAVE;
+    if (row < x.n_rows) {
+        const uint64_t m = x.rebuilt_mask[row];
+        if (lane == 0) {
+            x.o_rebuilt[row] = m;
+            if (x.vis_mask) x.o_vis[row] = x.vis_mask[row];
+            if (x.o_inside) x.o_inside[row] = x.inside_mask ? x.inside_mask[row] : 0ull;
+        }
+        if ((m >> lane) & 1ull) {
+            const size_t i = (size_t)row * WAVE + lane;
+            const float4 *a = reinterpret_cast<const float4 *>(x.mx + 16 * i), *b = reinterpret_cast<const float4 *>(x.inv_mx + 16 * i);
+            float4 *oa = reinterpret_cast<float4 *>(x.o_mx + 16 * i), *ob = reinterpret_cast<float4 *>(x.o_inv + 16 * i);
+            const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+            const float2 *bb = reinterpret_cast<const float2 *>(x.aabb + 6 * i);
+            const float2 c0 = bb[0], c1 = bb[1], c2 = bb[2];
+            const float *ct = x.center + 3 * i;
+            const float t0 = ct[0], t1 = ct[1], t2 = ct[2];
+            oa[0] = a0; oa[1] = a1; oa[2] = a2; oa[3] = a3;
+            ob[0] = b0; ob[1] = b1; ob[2] = b2; ob[3] = b3;
+            float2 *obb = reinterpret_cast<float2 *>(x.o_aabb + 6 * i);
+            obb[0] = c0; obb[1] = c1; obb[2] = c2;
+            float *oc = x.o_center + 3 * i;
+            oc[0] = t0; oc[1] = t1; oc[2] = t2;
+        }
+    }
+    // completion: every workgroup releases its stores to the system, the last one to arrive raises the word
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t arrived = atomicAdd(x.counter, 1u);
+        if (arrived == gridDim.x - 1) {
+            *x.counter = 0;                                       // ready for the next frame (stream order)
+            __threadfence_system();
+            __hip_atomic_store(x.done, x.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // k_entities_tiles reads its frustum through the kernarg segment pointer at offset 0.  The AMDGPU kernel ABI lays the
 // explicit arguments out first and in declaration order, so that holds exactly as long as the frustum is the FIRST
 // parameter: reordering the signature must not compile.
@@ -798,9 +874,10 @@ static EntK to_kernel_args(const clapgpu_entities *e)
     k.bv_result = nullptr;
     k.bv_inside = nullptr;
     k.rebuilt_mask = e->rebuilt_mask;
-    k.bv_has_ctl = k.bv_ctl_entity = 0;
+    k.bv_has_ctl = k.bv_ctl_entity = k.bv_on = 0;
     for (int a = 0; a < 3; a++) k.bv_cam[a] = k.bv_ctl[a] = 0.f;
-    if (e->bv && e->bv->result) {
+    if (e->bv && (e->bv->result || e->bv->inside_mask)) {
+        k.bv_on = 1;
         memcpy(k.bv_cam, e->bv->cam_pos, 12);
         memcpy(k.bv_ctl, e->bv->ctl_pos, 12);
         k.bv_has_ctl = e->bv->has_ctl;
@@ -967,6 +1044,42 @@ extern "C" int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, co
     hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask,
                        e->vis_row_pop, e->n, fr);
     CLAPGPU_LAUNCH_CHECK("k_entities_cull");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list,
+                                             uint32_t n_list)
+{
+    static_assert(sizeof(clapgpu_entity_input) == 40, "record layout");
+    if (!e || !e->pos_scale || !e->rot || !e->flags || (n_list && !list))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!n_list || !e->n)
+        return CLAPGPU_OK;
+    hipLaunchKernelGGL(k_entities_apply_inputs, dim3((n_list + ENT_BLOCK - 1) / ENT_BLOCK), dim3(ENT_BLOCK), 0, as_stream(stream),
+                       reinterpret_cast<float4 *>(const_cast<float *>(e->pos_scale)),
+                       reinterpret_cast<float4 *>(const_cast<float *>(e->rot)), e->flags, list, n_list, e->n);
+    CLAPGPU_LAUNCH_CHECK("k_entities_apply_inputs");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x)
+{
+    if (!e || !x || !e->mx || !e->inv_mx || !e->aabb || !e->center || !e->rebuilt_mask || !x->mx || !x->inv_mx || !x->aabb ||
+        !x->center || !x->rebuilt_mask || !x->counter || !x->done || (e->vis_mask && !x->vis_mask))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->n & 63u)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    ExportK k;
+    k.mx = e->mx; k.inv_mx = e->inv_mx; k.aabb = e->aabb; k.center = e->center;
+    k.vis_mask = e->vis_mask; k.rebuilt_mask = e->rebuilt_mask;
+    k.inside_mask = (e->bv && e->bv->inside_mask) ? e->bv->inside_mask : nullptr;
+    k.o_mx = x->mx; k.o_inv = x->inv_mx; k.o_aabb = x->aabb; k.o_center = x->center;
+    k.o_vis = x->vis_mask; k.o_rebuilt = x->rebuilt_mask; k.o_inside = x->inside_mask;
+    k.counter = x->counter; k.done = x->done; k.done_value = x->done_value; k.n_rows = e->n / 64;
+    const uint32_t per_block = ENT_BLOCK / WAVE;
+    const uint32_t blocks = k.n_rows ? (k.n_rows + per_block - 1) / per_block : 1;
+    hipLaunchKernelGGL(k_entities_export_rebuilt, dim3(blocks), dim3(ENT_BLOCK), 0, as_stream(stream), k);
+    CLAPGPU_LAUNCH_CHECK("k_entities_export_rebuilt");
     return CLAPGPU_OK;
 }
 

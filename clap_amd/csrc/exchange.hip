@@ -64,6 +64,11 @@ struct clapgpu_exchange {
 
 extern "C" void clapgpu_exchange_set_library(const char *path) { g_rccl_path = path ? path : ""; }
 
+// Can this process open RCCL at all?  Cheap (a dlopen + five dlsym, once), no communicator: every rank asks BEFORE any of
+// them enters the collective ncclCommInitRank, so that a rank which cannot load the library does not leave the others
+// waiting inside it (the launcher reduces the answers with MIN and only then calls clapgpu_exchange_create everywhere).
+extern "C" int clapgpu_exchange_available(void) { return load_rccl() == CLAPGPU_OK ? 1 : 0; }
+
 extern "C" int clapgpu_exchange_unique_id(uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES])
 {
     if (!id) return CLAPGPU_ERR_INVALID_ARGUMENTS;

@@ -1,6 +1,7 @@
 // runtime.hip -- device binding, memory helpers and the O(1)-per-frame host math
 // (view matrix, projection, frustum planes/corners) of libclapgpu.
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string>
 #include "common.h"
@@ -83,6 +84,39 @@ extern "C" int clapgpu_host_malloc(void **host, size_t bytes)
     if (!host) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     CLAPGPU_HIP(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocDefault));
     return CLAPGPU_OK;
+}
+
+// Page-locked host memory the device can address (zero-copy): *dev_alias is the pointer kernels use.  Coherent
+// (fine-grained): a kernel's stores are visible to the host once the kernel has completed, no copy, no cache flush call.
+extern "C" int clapgpu_host_malloc_mapped(void **host, void **dev_alias, size_t bytes)
+{
+    if (!host || !dev_alias) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CLAPGPU_HIP(hipHostMalloc(host, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocCoherent));
+    const hipError_t e = hipHostGetDevicePointer(dev_alias, *host, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(*host);
+        *host = nullptr;
+        return hip_fail(e, "hipHostGetDevicePointer");
+    }
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_wait_word(const volatile uint32_t *word, uint32_t value, void *stream)
+{
+    if (!word) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    for (uint32_t spins = 0;; spins++) {
+        if (*word == value) return CLAPGPU_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xffffu) == 0xffffu) {                      // ~ every millisecond: is anything still running?
+            const hipError_t e = hipStreamQuery(as_stream(stream));
+            if (e == hipSuccess) {
+                if (*word == value) return CLAPGPU_OK;
+                g_last_error = "clapgpu_wait_word: the stream drained without the word being stored";
+                return CLAPGPU_ERR_UNKNOWN;
+            }
+            if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+        }
+    }
 }
 
 extern "C" int clapgpu_host_free(void *host)

@@ -14,6 +14,7 @@
  */
 #include <ctype.h>
 #include <math.h>
+#include <stdbool.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -374,13 +375,29 @@ static const void *accr_buf(const struct gltf *g, int accr, size_t *elsz, unsign
 {
     if (accr < 0 || (unsigned)accr >= g->n_accrs) return NULL;
     const struct g_accessor *a = &g->accrs[accr];
+    if (a->bufview >= g->n_bufvws) return NULL;
     const struct g_bufview *bv = &g->bufvws[a->bufview];
     if (bv->buffer >= g->n_buffers || !g->buffers[bv->buffer]) return NULL;
     const size_t es = a->comps * comp_size(a->comptype);                /* gltf_accessor_stride: tightly packed */
-    if (!es || a->offset + bv->offset + es * a->count > g->buffer_size[bv->buffer]) return NULL;
+    const size_t size = g->buffer_size[bv->buffer];
+    /* overflow-safe: every term is checked against what is left of the buffer before it is added */
+    if (!es || bv->offset > size || a->offset > size - bv->offset) return NULL;
+    const size_t room = size - bv->offset - a->offset;
+    if (a->count > room / es) return NULL;
     if (elsz) *elsz = es;
     if (count) *count = a->count;
     return g->buffers[bv->buffer] + a->offset + bv->offset;
+}
+
+/* A JSON number usable as an index / size / offset: a finite, non-negative integer value below 2^53 (negative, NaN or
+ * huge doubles cast to unsigned / size_t are undefined behaviour, and (unsigned)-1 would index wildly). */
+static bool jnum_index(const struct jnode *n, double *out)
+{
+    if (!n || n->tag != J_NUMBER) return false;
+    const double v = n->num;
+    if (!(v >= 0.0) || !(v < 9007199254740992.0) || v != floor(v)) return false;
+    if (out) *out = v;
+    return true;
 }
 
 static char *jstrdup(const struct jnode *n) { return n && n->tag == J_STRING ? strdup(n->str) : NULL; }
@@ -473,10 +490,13 @@ static int gltf_json_parse(struct gltf *g, const char *buf, size_t len, struct l
     if (!g->bufvws) { rc = LD_NOMEM; goto out; }
     for (struct jnode *n = bufvws->head; n; n = n->next) {
         struct jnode *jbuf = jfind(n, "buffer"), *jlen = jfind(n, "byteLength"), *joff = jfind(n, "byteOffset");
-        if (!jbuf || !jlen || !joff) continue;
-        if (jbuf->num >= g->n_buffers) continue;
+        /* skipped entries do not take a number, as in the engine (gltf.c:857-861); on top of its rules, numbers that are
+         * negative, non-finite or fractional are skipped too (the engine would cast them: undefined behaviour) */
+        double vbuf, vlen, voff;
+        if (!jnum_index(jbuf, &vbuf) || !jnum_index(jlen, &vlen) || !jnum_index(joff, &voff)) continue;
+        if (vbuf >= g->n_buffers) continue;
         struct g_bufview *bv = &g->bufvws[g->n_bufvws++];
-        bv->buffer = (unsigned)jbuf->num; bv->offset = (size_t)joff->num; bv->length = (size_t)jlen->num;
+        bv->buffer = (unsigned)vbuf; bv->offset = (size_t)voff; bv->length = (size_t)vlen;
     }
     /* accessors (gltf.c:869-897) */
     g->accrs = calloc(accrs->count ? accrs->count : 1, sizeof(*g->accrs));
@@ -484,13 +504,15 @@ static int gltf_json_parse(struct gltf *g, const char *buf, size_t len, struct l
     for (struct jnode *n = accrs->head; n; n = n->next) {
         struct jnode *jbv = jfind(n, "bufferView"), *joff = jfind(n, "byteOffset"), *jcount = jfind(n, "count"),
                      *jtype = jfind(n, "type"), *jct = jfind(n, "componentType");
-        if (!jbv || !jcount || !jtype || !jct || jtype->tag != J_STRING) continue;
-        if (jbv->num >= g->n_bufvws) continue;
+        double vbv, vcount, vct, voff = 0.0;
+        if (!jtype || jtype->tag != J_STRING || !jnum_index(jbv, &vbv) || !jnum_index(jcount, &vcount) || !jnum_index(jct, &vct)) continue;
+        if (joff && joff->tag == J_NUMBER && !jnum_index(joff, &voff)) continue;
+        if (vbv >= g->n_bufvws || vcount > 4294967295.0 || vct > 65535.0) continue;
         const unsigned comps = comps_of(jtype->str);
         if (!comps) continue;
         struct g_accessor *a = &g->accrs[g->n_accrs++];
-        a->bufview = (unsigned)jbv->num; a->comptype = (unsigned)jct->num; a->count = (unsigned)jcount->num; a->comps = comps;
-        a->offset = joff && joff->tag == J_NUMBER ? (size_t)joff->num : 0;
+        a->bufview = (unsigned)vbv; a->comptype = (unsigned)vct; a->count = (unsigned)vcount; a->comps = comps;
+        a->offset = (size_t)voff;
     }
     /* animations (gltf.c:491-581) */
     if (anis) {

@@ -11,6 +11,8 @@
 #include <math.h>
 #include <string.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <time.h>
 #include "clapgpu_scene.h"
 
 #define WAVE 64u
@@ -23,8 +25,14 @@ struct ent {
     uint32_t model;
     uint32_t slot;
     void    *user;
-    uint8_t  live, dirty;
+    uint8_t  live, dirty, attached;   /* attached: rides a joint of its parent (e->parent_joint, model.c:1626-1641) */
 };
+
+/* the flags word of the upload image: the entity3d bits + what only the device knows */
+static inline uint32_t img_flags(const struct ent *e, int xform_updated)
+{
+    return e->flags | (e->attached ? CLAPGPU_E_JOINT_ATTACHED : 0) | (xform_updated ? CLAPGPU_E_DIRTY : 0);
+}
 
 struct clapgpu_scene {
     struct ent *e;  uint32_t n_handles, cap_handles;
@@ -55,6 +63,20 @@ struct clapgpu_scene {
      * (mx | inv_mx | aabb | center | vis_mask) */
     void       *h_in, *h_out, *d_in, *d_out;
     size_t      in_bytes, out_bytes;
+    /* small scenes (zero_copy): no copy calls and no blocking wait in a frame.  The touched entities' records go into
+     * a device-mapped host list which clapgpu_entities_apply_inputs scatters into the device arrays; the result slab
+     * h_out is device-mapped and clapgpu_entities_export_rebuilt writes what the update rebuilt (and the masks)
+     * straight into it, then raises *h_done, which mq_update polls.  At a testbed-sized scene (10 k entities) the
+     * three copies' fixed latencies and the blocking wait were 0.13 of a 0.15 ms device step around a 15-30 us kernel. */
+    int         zero_copy;
+    uint32_t    zero_copy_max_slots;
+    clapgpu_entity_input *h_list; void *d_list; uint32_t cap_list;    /* mapped: host pointer / device alias */
+    void       *d_out_host;                                            /* device alias of h_out */
+    uint32_t   *h_done, *d_done, *d_counter, frame_id;
+    /* joint attachments (clapgpu_scene_attached_update): table + the two matrix pools + the kernel's work space */
+    void       *h_att, *d_att; size_t att_bytes; uint32_t cap_att; int att_mapped;
+    float      *d_att_local;
+    clapgpu_frustum last_frustum; int have_frustum;
 
     /* device */
     clapgpu_entities d;
@@ -65,6 +87,13 @@ struct clapgpu_scene {
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static double scene_now_us(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 
 static struct ent *get(const clapgpu_scene *s, uint32_t h)
 {
@@ -88,7 +117,7 @@ static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
         const uint32_t slot = e->slot;
         memcpy(s->h_pos_scale + 4 * (size_t)slot, e->pos_scale, 16);
         memcpy(s->h_rot + 4 * (size_t)slot, e->rot, 16);
-        s->h_flags[slot] = e->flags | ((e->dirty & 2) ? CLAPGPU_E_DIRTY : 0);
+        s->h_flags[slot] = img_flags(e, e->dirty & 2);
         if (slot < s->up_lo) s->up_lo = slot;
         if (slot >= s->up_hi) s->up_hi = slot + 1;
     }
@@ -101,9 +130,22 @@ int clapgpu_scene_create(clapgpu_scene **out, int device)
     clapgpu_scene *s = calloc(1, sizeof(*s));
     if (!s) return CLAPGPU_ERR_NOMEM;
     s->topology_dirty = 1;
+    s->zero_copy_max_slots = CLAPGPU_SCENE_ZERO_COPY_SLOTS;
+    const char *zc = getenv("CLAPGPU_SCENE_ZERO_COPY_SLOTS");   /* tuning knob: 0 = always copy */
+    if (zc) s->zero_copy_max_slots = (uint32_t)strtoul(zc, NULL, 0);
     *out = s;
     return CLAPGPU_OK;
 }
+
+void clapgpu_scene_set_zero_copy_slots(clapgpu_scene *s, uint32_t max_slots)
+{
+    if (!s || s->zero_copy_max_slots == max_slots) return;
+    s->zero_copy_max_slots = max_slots;
+    s->cap_slots = 0;                                   /* the slabs are re-made in the new mode by the next re-tile */
+    s->topology_dirty = 1;
+}
+
+int clapgpu_scene_is_zero_copy(const clapgpu_scene *s) { return s ? s->zero_copy : 0; }
 
 static void free_device(clapgpu_scene *s)
 {
@@ -127,6 +169,12 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->h_out) clapgpu_host_free(s->h_out);
     free(s->h_parent); free(s->h_model); free(s->slot_user);
     if (s->d_bv_result) clapgpu_free(s->d_bv_result);
+    if (s->h_list) clapgpu_host_free(s->h_list);
+    if (s->h_done) clapgpu_host_free(s->h_done);
+    if (s->d_counter) clapgpu_free(s->d_counter);
+    if (s->h_att) clapgpu_host_free(s->h_att);
+    if (s->d_att && !s->att_mapped) clapgpu_free(s->d_att);
+    if (s->d_att_local) clapgpu_free(s->d_att_local);
     free(s);
 }
 
@@ -237,7 +285,7 @@ int clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const f
     if (!s->topology_dirty && s->h_in && e->slot < s->n_slots) {
         memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
         memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
-        s->h_flags[e->slot] = e->flags | (xform_updated ? CLAPGPU_E_DIRTY : 0);
+        s->h_flags[e->slot] = img_flags(e, xform_updated);
     } else {
         e->dirty |= xform_updated ? 3 : 1;               /* picked up by the re-tile's full image */
     }
@@ -334,16 +382,29 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
 #undef RE
     /* retile() rewrites the upload image in full and downloads are overwritten by the next frame, so
      * nothing has to survive the growth */
+    free_device(s);
     if (s->h_in) clapgpu_host_free(s->h_in);
     if (s->h_out) clapgpu_host_free(s->h_out);
     s->h_in = s->h_out = NULL;
-    free_device(s);
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
     s->have_results = 0;
     s->in_bytes = n * 36;
     s->out_bytes = n * 164 + 3 * (n / 64 + 2) * 8;           /* + visibility, rebuilt and bounding-volume masks */
+    s->zero_copy = cap <= s->zero_copy_max_slots;
     CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
-    CK(clapgpu_host_malloc(&s->h_out, s->out_bytes));
+    if (s->zero_copy) {
+        CK(clapgpu_host_malloc_mapped(&s->h_out, &s->d_out_host, s->out_bytes));
+        if (!s->h_done) {
+            void *dd = NULL;
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_done, &dd, 64));
+            s->d_done = dd;
+            *s->h_done = 0;
+            CK(clapgpu_malloc((void **)&s->d_counter, 4));
+            CK(clapgpu_memset(s->d_counter, 0, 4, NULL));
+        }
+    } else {
+        CK(clapgpu_host_malloc(&s->h_out, s->out_bytes));
+    }
     CK(clapgpu_malloc(&s->d_in, s->in_bytes));
     CK(clapgpu_malloc(&s->d_out, s->out_bytes));
     char *hi = s->h_in, *ho = s->h_out, *di = s->d_in, *dq = s->d_out;
@@ -500,7 +561,7 @@ static int retile(clapgpu_scene *s)
         memcpy(s->h_rot + 4 * (size_t)i, e->rot, 16);
         s->h_parent[i] = e->parent == CLAPGPU_NO_ENTITY ? -1 : (int32_t)s->e[e->parent].slot;
         s->h_model[i] = (int32_t)e->model;
-        s->h_flags[i] = e->flags | CLAPGPU_E_DIRTY;                  /* everything is rebuilt after a re-tile */
+        s->h_flags[i] = img_flags(e, 1);                             /* everything is rebuilt after a re-tile */
     }
     free(depth); free(root); free(tree_of); free(width); free(row_of_tree); free(row_fill);
 
@@ -510,6 +571,7 @@ static int retile(clapgpu_scene *s)
     CK(clapgpu_memcpy_h2d((void *)s->d.model, s->h_model, n * 4, NULL));
     CK(clapgpu_memset(s->d.seqs, 0, n * 4, NULL));
     CK(clapgpu_memset(s->d_out, 0, s->out_bytes, NULL));
+    if (s->zero_copy) memset(s->h_out, 0, s->out_bytes);          /* the export kernel only writes what an update rebuilt */
     if (tiled)
         CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
     for (uint32_t k = 0; k < s->n_dirty; k++) s->e[s->dirty_list[k]].dirty = 0;
@@ -530,17 +592,34 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         upload = full = 1;
     } else if (s->n_dirty) {
         /* the upload image was written as the verbs came in (mark_dirty); here only the bookkeeping */
+        if (s->zero_copy && s->n_dirty > s->cap_list) {  /* the mapped record list grows with the busiest frame seen */
+            uint32_t cap = s->cap_list ? s->cap_list : 1024;
+            while (cap < s->n_dirty) cap *= 2;
+            if (s->h_list) clapgpu_host_free(s->h_list);
+            s->h_list = NULL; s->cap_list = 0;
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_list, &s->d_list, (size_t)cap * sizeof(*s->h_list)));
+            s->cap_list = cap;
+        }
         for (uint32_t k = 0; k < s->n_dirty; k++) {
             struct ent *e = &s->e[s->dirty_list[k]];
+            const uint8_t was = e->dirty;
             e->dirty = 0;
             if (!e->live) continue;
+            if (s->zero_copy) {
+                clapgpu_entity_input *r = &s->h_list[n_touched];
+                r->slot = e->slot;
+                r->flags = img_flags(e, was & 2);
+                memcpy(r->pos_scale, e->pos_scale, 16);
+                memcpy(r->rot, e->rot, 16);
+            }
             s->dirty_list[n_touched++] = e->slot;        /* the list is reused for the slots touched */
         }
         lo = s->up_lo; hi = s->up_hi;
         s->n_dirty = 0;
         upload = n_touched != 0 && hi > lo;
     }
-    if (s->bulk_dirty && !full) {                        /* clapgpu_scene_entity_transform_mt wrote the image directly */
+    const int bulk = s->bulk_dirty && !full;
+    if (bulk) {                                          /* clapgpu_scene_entity_transform_mt wrote the image directly */
         upload = 1; lo = 0; hi = s->n_slots; n_touched = s->n_slots;   /* whole image up, flags cleared linearly */
     }
     s->bulk_dirty = 0;
@@ -560,7 +639,10 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     if (s->n_models == 0) return CLAPGPU_OK;
     const size_t n = s->n_slots;
     const size_t cap = s->cap_slots;
-    if (upload) {
+    const int by_list = s->zero_copy && upload && !full && !bulk && n_touched <= s->cap_list;   /* same bytes as the image, no copy call */
+    if (by_list) {
+        CK(clapgpu_entities_apply_inputs(NULL, &s->d, (const clapgpu_entity_input *)s->d_list, n_touched));
+    } else if (upload) {
         /* one copy of the whole input slab after a re-tile or when most of it changed; else the slot range */
         const size_t a = full ? 0 : lo, cnt = full ? n : (size_t)hi - lo;
         if (full || 2 * cnt > n) {
@@ -572,20 +654,39 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         }
     }
     if (s->bv_on) {
-        if (!s->d_bv_result) CK(clapgpu_malloc((void **)&s->d_bv_result, 8));
         memcpy(s->bvq.cam_pos, s->bv_cam, 12); memcpy(s->bvq.ctl_pos, s->bv_ctl, 12);
         const struct ent *ce = s->bv_has_ctl ? get(s, s->bv_ctl_handle) : NULL;
         s->bvq.has_ctl = s->bv_has_ctl; s->bvq.ctl_entity = ce ? ce->slot : 0xffffffffu;
-        s->bvq.result = s->d_bv_result;
+        s->bvq.result = NULL;                            /* the containment mask is what the callers replay: no result word, no fill launch */
         s->d.bv = &s->bvq;
     } else {
         s->d.bv = NULL;
     }
+    s->have_frustum = frustum != NULL;
+    if (frustum) s->last_frustum = *frustum;
+    s->d.n_attach = 0;                                   /* joint attachments ride the palettes of THIS frame: clapgpu_scene_attached_update */
+    const double tt0 = scene_now_us();
     if (s->tiled)
         CK(clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum));
     else
         CK(clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, frustum));
     const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
+    if (s->zero_copy) {
+        /* what the update rebuilt, and the masks, straight into the mapped result slab; then the completion word */
+        char *mo = s->d_out_host;
+        const size_t cn = cap;
+        clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cn * 64), .aabb = (float *)(mo + cn * 128),
+                                      .center = (float *)(mo + cn * 152), .vis_mask = (uint64_t *)(mo + cn * 164) };
+        x.rebuilt_mask = x.vis_mask + (cn / 64 + 2);
+        x.inside_mask = s->bv_on ? x.rebuilt_mask + (cn / 64 + 2) : NULL;
+        x.counter = s->d_counter; x.done = s->d_done; x.done_value = ++s->frame_id;
+        CK(clapgpu_entities_export_rebuilt(NULL, &s->d, &x));
+        const double tt2 = scene_now_us();
+        CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (getenv("CLAPGPU_SCENE_TIMING"))
+            fprintf(stderr, "scene small frame: %u inputs by %s, launches %.1f us, wait %.1f us\n", n_touched,
+                    by_list ? "list" : upload ? "copy" : "none", tt2 - tt0, scene_now_us() - tt2);
+    } else
     if (upload || full || !s->have_results) {            /* otherwise the kernel rebuilt nothing: the last download stands */
         if (1) {                                         /* one copy of the output slab (the three masks included): cap <= 9/8 n + 4096 */
             CK(clapgpu_memcpy_d2h(s->h_out, s->d_out, cap * 164 + (2 * mask_stride + mask_words) * 8, NULL));
@@ -599,15 +700,119 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     } else {                                             /* masks only: visibility of this view, nothing rebuilt */
         CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
     }
+    if (!s->zero_copy) CK(clapgpu_stream_sync(NULL));
     if (!frustum)
         memset(s->h_mask, 0, mask_words * 8);
-    CK(clapgpu_stream_sync(NULL));
     if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
     if (full || 4 * (size_t)n_touched > n)
         for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */
     else
         for (uint32_t k = 0; k < n_touched; k++) s->h_flags[s->dirty_list[k]] &= ~CLAPGPU_E_DIRTY;
     s->have_results = 1;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_set_attach(clapgpu_scene *s, uint32_t handle, int attached)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->attached != (attached ? 1 : 0)) {
+        e->attached = attached ? 1 : 0;
+        s->topology_dirty = 1;                           /* the flag travels with the upload image */
+    }
+    return CLAPGPU_OK;
+}
+
+struct att_key { uint32_t slot, k; };
+static int att_cmp(const void *a, const void *b)
+{
+    const struct att_key *x = a, *y = b;
+    return x->slot < y->slot ? -1 : x->slot > y->slot;
+}
+
+/*
+ * The second launch of a frame with joint attachments (model.c:1626-1641): entity handles[k] rides
+ * parent.mx * ((jt[k] * bind[k]) * local), jt[k] = its parent's joint_transforms[parent_joint] of THIS frame -- which
+ * exist only after the pose that followed clapgpu_scene_mq_update() -- and bind[k] that joint's bind matrix.  Such
+ * entities are rebuilt every frame, everything below them follows through the seq counters; nothing else is touched.
+ * On return the result arrays hold the rebuilt rows and rebuilt_mask says which they are.
+ */
+int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *handles, const float *jt, const float *bind)
+{
+    if (!s || (n && (!handles || !jt || !bind))) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!n) return CLAPGPU_OK;
+    if (s->topology_dirty || !s->have_results || !s->n_models) return CLAPGPU_ERR_NOT_SUPPORTED;   /* mq_update first */
+    const size_t need = (size_t)n * (sizeof(clapgpu_attach) + 128);
+    if (n > s->cap_att || s->att_mapped != s->zero_copy) {
+        uint32_t cap = s->cap_att ? s->cap_att : 64;
+        while (cap < n) cap *= 2;
+        if (s->h_att) clapgpu_host_free(s->h_att);
+        if (s->d_att && !s->att_mapped) clapgpu_free(s->d_att);
+        if (s->d_att_local) clapgpu_free(s->d_att_local);
+        s->h_att = s->d_att = NULL; s->d_att_local = NULL; s->cap_att = 0;
+        const size_t bytes = (size_t)cap * (sizeof(clapgpu_attach) + 128);
+        s->att_mapped = s->zero_copy;
+        if (s->att_mapped) CK(clapgpu_host_malloc_mapped(&s->h_att, &s->d_att, bytes));
+        else { CK(clapgpu_host_malloc(&s->h_att, bytes)); CK(clapgpu_malloc(&s->d_att, bytes)); }
+        CK(clapgpu_malloc((void **)&s->d_att_local, (size_t)cap * 64));
+        s->cap_att = cap;
+    }
+    struct att_key *key = malloc((size_t)n * sizeof(*key));
+    if (!key) return CLAPGPU_ERR_NOMEM;
+    for (uint32_t k = 0; k < n; k++) {
+        const struct ent *e = get(s, handles[k]);
+        if (!e || !e->attached || e->parent == CLAPGPU_NO_ENTITY || e->slot >= s->n_slots) { free(key); return CLAPGPU_ERR_INVALID_ARGUMENTS; }
+        key[k].slot = e->slot; key[k].k = k;
+    }
+    qsort(key, n, sizeof(*key), att_cmp);                /* the kernel looks an entity up by binary search */
+    clapgpu_attach *tab = s->h_att;
+    float *pj = (float *)((char *)s->h_att + (size_t)n * sizeof(clapgpu_attach)), *pb = pj + 16 * (size_t)n;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i && key[i].slot == key[i - 1].slot) { free(key); return CLAPGPU_ERR_INVALID_ARGUMENTS; }
+        tab[i] = (clapgpu_attach){ .entity = key[i].slot, .jt = i, .bind = i };
+        memcpy(pj + 16 * (size_t)i, jt + 16 * (size_t)key[i].k, 64);
+        memcpy(pb + 16 * (size_t)i, bind + 16 * (size_t)key[i].k, 64);
+    }
+    free(key);
+    if (!s->att_mapped) CK(clapgpu_memcpy_h2d(s->d_att, s->h_att, need, NULL));
+    s->d.n_attach = n;
+    s->d.attach = s->d_att;
+    s->d.jt_pool = (const float *)((const char *)s->d_att + (size_t)n * sizeof(clapgpu_attach));
+    s->d.bind_pool = s->d.jt_pool + 16 * (size_t)n;
+    s->d.attach_local = s->d_att_local;
+    const clapgpu_frustum *fr = s->have_frustum ? &s->last_frustum : NULL;
+    int rc = s->tiled ? clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr)
+                      : clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, fr);
+    s->d.n_attach = 0;
+    if (rc) return rc;
+    const size_t nn = s->n_slots, cap = s->cap_slots, mask_words = nn / 64, mask_stride = cap / 64 + 2;
+    if (s->zero_copy) {
+        char *mo = s->d_out_host;
+        clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cap * 64), .aabb = (float *)(mo + cap * 128),
+                                      .center = (float *)(mo + cap * 152), .vis_mask = (uint64_t *)(mo + cap * 164) };
+        x.rebuilt_mask = x.vis_mask + mask_stride;
+        x.inside_mask = s->bv_on ? x.rebuilt_mask + mask_stride : NULL;
+        x.counter = s->d_counter; x.done = s->d_done; x.done_value = ++s->frame_id;
+        CK(clapgpu_entities_export_rebuilt(NULL, &s->d, &x));
+        CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+    } else {
+        /* staged: the masks first, then only the span of rows this launch rebuilt */
+        CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
+        CK(clapgpu_stream_sync(NULL));
+        size_t lo = mask_words, hi = 0;
+        for (size_t w = 0; w < mask_words; w++)
+            if (s->h_rebuilt[w]) { if (w < lo) lo = w; hi = w + 1; }
+        if (hi > lo) {
+            const size_t a = lo * 64, cnt = (hi - lo) * 64;
+            CK(clapgpu_memcpy_d2h(s->h_mx + 16 * a, s->d.mx + 16 * a, cnt * 64, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_inv + 16 * a, s->d.inv_mx + 16 * a, cnt * 64, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_aabb + 6 * a, s->d.aabb + 6 * a, cnt * 24, NULL));
+            CK(clapgpu_memcpy_d2h(s->h_center + 3 * a, s->d.center + 3 * a, cnt * 12, NULL));
+            CK(clapgpu_stream_sync(NULL));
+        }
+    }
+    if (!fr) memset(s->h_mask, 0, mask_words * 8);
+    if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
     return CLAPGPU_OK;
 }
 

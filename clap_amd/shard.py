@@ -94,27 +94,35 @@ class VisibleExchange:
         self.frame = 0
         self.direct = None
         if route == "rccl":
-            try:
-                self.direct = self._create_exchange(rank, world, device)
-            except Exception as exc:                        # keep the run alive: c10d does the same exchange
-                import sys
-                print(f"[clap_amd.shard] clapgpu_exchange unavailable ({exc}); using torch.distributed", file=sys.stderr)
-            # every rank must take the same route: one rank falling back alone would deadlock the others
-            ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and self.direct is not None:
-                _lib.lib().clapgpu_exchange_destroy(self.direct)
-                self.direct = None
+            import os
+            import sys
+            L = _lib.lib()
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(path):
+                L.clapgpu_exchange_set_library(path.encode())
+            # clapgpu_exchange_create is collective (ncclCommInitRank): ranks first agree that ALL of them can open RCCL
+            # -- a rank that cannot would otherwise leave the others blocked inside the call -- and only then create it
+            can = torch.tensor([int(L.clapgpu_exchange_available())], dtype=torch.int32, device=device)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
+            if int(can.item()) == 1:
+                try:
+                    self.direct = self._create_exchange(rank, world, device)
+                except Exception as exc:                    # keep the run alive: c10d does the same exchange
+                    print(f"[clap_amd.shard] clapgpu_exchange unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                # and the same route afterwards: one rank falling back alone would deadlock the others
+                ok = torch.tensor([1 if self.direct is not None else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and self.direct is not None:
+                    L.clapgpu_exchange_destroy(self.direct)
+                    self.direct = None
+            elif rank == 0:
+                print("[clap_amd.shard] RCCL cannot be opened on every rank; using torch.distributed", file=sys.stderr)
 
     def _create_exchange(self, rank, world, device):
         """libclapgpu's own exchange object (exchange.hip): RCCL opened at run time -- the copy torch has loaded --, the
         unique id carried to the ranks by the process group, once."""
-        import os
         C, _lib = self._C, self._lib
         L = _lib.lib()
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(path):
-            L.clapgpu_exchange_set_library(path.encode())
         uid = (C.c_uint8 * 128)()
         if rank == 0 and L.clapgpu_exchange_unique_id(uid) != 0:
             uid = (C.c_uint8 * 128)()                        # all zero = "no id": every rank then takes the fallback together

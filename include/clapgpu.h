@@ -58,6 +58,12 @@ int clapgpu_free(void *dev);
 /* Page-locked host memory for the staging arrays of a binding: copies to and from it run at the
  * link rate and truly asynchronously (pageable memory is bounced through a driver buffer). */
 int clapgpu_host_malloc(void **host, size_t bytes);
+/* Page-locked host memory that kernels address directly (zero-copy over PCIe): *dev_alias is what goes into the
+ * device-pointer fields of the structs below; free with clapgpu_host_free(*host).  Coherent: a kernel's stores are
+ * visible to the host once the kernel has completed (or, inside a kernel, after __threadfence_system()).  For batches
+ * small enough that the copies' fixed latencies (one each way + a blocking wait) exceed the transfer itself:
+ * libclapgpu_scene uses it below ~128 k entities (clapgpu_entities_apply_inputs / _export_rebuilt). */
+int clapgpu_host_malloc_mapped(void **host, void **dev_alias, size_t bytes);
 int clapgpu_host_free(void *host);
 int clapgpu_memcpy_h2d(void *dev, const void *host, size_t bytes, void *stream);
 int clapgpu_memcpy_d2h(void *host, const void *dev, size_t bytes, void *stream);
@@ -134,6 +140,7 @@ typedef struct clapgpu_attach {
  * largest volume (|model dx| scale)(|model dy| scale)(|model dz| scale).
  * *result (device uint64, zeroed by the update call) = float bits of the volume << 32 |
  * (0xFFFFFFFF - entity index), 0 if none: the largest key is the first entity of largest volume.
+ * result may be NULL when inside_mask is given (no maximum is formed then, and the update call queues no fill for it).
  * inside_mask (device, n / 64 words, may be NULL): bit i = entity i passed the containment test.  A caller whose
  * entity order differs from the device's index order (the reference breaks volume ties by LIST order) replays
  * the pick over those few entities itself.
@@ -223,6 +230,31 @@ int clapgpu_entities_update_tiles(void *stream, const clapgpu_entities *e,
 int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum);
 
 /*
+ * Small frames of a HOST mirror (what libclapgpu_scene does below CLAPGPU_SCENE_ZERO_COPY_SLOTS): the frame's touched
+ * entities travel as one list of 40-byte records in device-mapped host memory (clapgpu_host_malloc_mapped) and are
+ * scattered into pos_scale / rot / flags by clapgpu_entities_apply_inputs(); after the update,
+ * clapgpu_entities_export_rebuilt() copies the rows of mx / inv_mx / aabb / center the update rebuilt (e->rebuilt_mask)
+ * and the three bit masks into the mirror's mapped result arrays and then stores done_value into *done, which the host
+ * polls (clapgpu_wait_word) -- no copy calls, no blocking wait.  counter: one zeroed device uint32 of scratch.
+ */
+typedef struct clapgpu_entity_input {
+    uint32_t slot, flags;               /* flags as in clapgpu_entities.flags (CLAPGPU_E_DIRTY where xform.updated) */
+    float    pos_scale[4], rot[4];
+} clapgpu_entity_input;
+typedef struct clapgpu_entities_export {
+    float    *mx, *inv_mx, *aabb, *center;                 /* device-mapped host arrays, same shapes as clapgpu_entities' */
+    uint64_t *vis_mask, *rebuilt_mask, *inside_mask;       /* inside_mask may be NULL */
+    uint32_t *counter;                                     /* device scratch */
+    uint32_t *done;                                        /* device-mapped host word */
+    uint32_t  done_value, pad;
+} clapgpu_entities_export;
+int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list, uint32_t n_list);
+int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x);
+/* Busy-wait until *word == value (a word a kernel stores into mapped host memory).  Checks `stream` every so often: if
+ * it has drained and the word still differs, the signalling launch failed -> CLAPGPU_ERR_UNKNOWN instead of a hang. */
+int clapgpu_wait_word(const volatile uint32_t *word, uint32_t value, void *stream);
+
+/*
  * Ordered compaction of vis_mask into the ascending entity-index list the draw
  * loop iterates: visible[0..*count) = index_base + i for every set bit i.
  * `visible` needs room for n entries, `count` is one device uint32; index_base is the
@@ -277,6 +309,10 @@ int clapgpu_shard_tile_range(const uint32_t *tile_row_start, uint32_t n_tiles, u
 #define CLAPGPU_EXCHANGE_ID_BYTES 128
 typedef struct clapgpu_exchange clapgpu_exchange;
 void clapgpu_exchange_set_library(const char *path);
+/* 1 if RCCL can be opened in this process (no communicator is made).  clapgpu_exchange_create() is COLLECTIVE -- it
+ * returns when every rank has called it -- so ranks agree on this answer first (MIN over ranks) and only create the
+ * exchange when all of them can; otherwise all take the launcher's fallback together. */
+int  clapgpu_exchange_available(void);
 int  clapgpu_exchange_unique_id(uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES]);
 int  clapgpu_exchange_create(clapgpu_exchange **out, const uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES], int rank, int world);
 void clapgpu_exchange_destroy(clapgpu_exchange *x);

@@ -25,8 +25,17 @@ extern "C" {
 typedef struct clapgpu_scene clapgpu_scene;
 #define CLAPGPU_NO_ENTITY 0xffffffffu
 
+/* Scenes of at most this many slots (64-entity rows, padding included) run ZERO-COPY: the mirror's host arrays are
+ * page-locked, device-mapped memory which the kernels read (transforms, flags) and write (mx, inverse_mx, aabb, masks) in
+ * place over PCIe, and mq_update waits on a polled fence -- no upload copy, no download copy, no blocking runtime wait.
+ * Larger scenes stage through device slabs (one copy up, one down), where the copies run at the link's full rate. */
+#define CLAPGPU_SCENE_ZERO_COPY_SLOTS 131072u
 int  clapgpu_scene_create(clapgpu_scene **out, int device);
 void clapgpu_scene_destroy(clapgpu_scene *s);
+/* 0 = always stage through device slabs; takes effect at the next layout rebuild (the call forces one).  The
+ * environment variable CLAPGPU_SCENE_ZERO_COPY_SLOTS overrides the default at create time. */
+void clapgpu_scene_set_zero_copy_slots(clapgpu_scene *s, uint32_t max_slots);
+int  clapgpu_scene_is_zero_copy(const clapgpu_scene *s);
 
 /* model3d: local-space AABB (model3d.aabb, model.h:55) and skip_aabb (model.h:64) */
 int  clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aabb, uint32_t *model);
@@ -60,6 +69,17 @@ int  clapgpu_scene_entity_flags(clapgpu_scene *s, uint32_t handle, uint32_t set,
 
 /* mq_update + cull against `frustum` (NULL: no cull) */
 int  clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum);
+/*
+ * Joint attachments (e->parent_joint != JOINT_TYPE_MAX: parent_transform_apply's second flavour, model.c:1626-1641).
+ * clapgpu_scene_entity_set_attach() marks an entity (which has a parent) as riding one of its parent's joints;
+ * clapgpu_scene_mq_update() then computes everything but the attached subtrees' final matrices, the caller runs the
+ * frame's pose, and clapgpu_scene_attached_update() -- the frame's SECOND entity launch -- rebuilds each attached entity
+ * as parent.mx * ((jt[k] * bind[k]) * local) with jt[k] = its parent's joint_transforms[parent_joint] of this frame and
+ * bind[k] = that joint's bind matrix (16 floats each, column-major), and everything below it.  Culls against the
+ * frustum of the preceding mq_update; afterwards the result arrays hold the rebuilt rows, rebuilt_mask names them.
+ */
+int  clapgpu_scene_entity_set_attach(clapgpu_scene *s, uint32_t handle, int attached);
+int  clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *handles, const float *jt, const float *bind);
 
 /* the cull alone, against another frustum (scene_cameras_calc recomputes the frusta after mq_update, clap.c:614-616):
  * refreshes the visibility results below; CLAPGPU_ERR_NOT_SUPPORTED before the first mq_update */

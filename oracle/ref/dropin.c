@@ -406,7 +406,8 @@ static void mk(uint8_t model, uint32_t parent, bool hooked, bool positioned)
     if (parent != NONE) meta[parent].n_children++;
 }
 
-static bool edge_no_view, edge_no_scene;
+static bool edge_no_view, edge_no_scene, edge_notify;
+static uint64_t edge_fast_frames;
 static uint32_t edge_move_lo, edge_move_hi;   /* != 0: only entities [lo, hi) move (a short slot range is uploaded) */   /* gpu_mq_update(gs, mq, NULL) / a queue whose priv is NULL */
 
 static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t frames, uint32_t expect_batched_min)
@@ -425,9 +426,11 @@ static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t fra
         A.mq->priv = edge_no_scene ? NULL : A.scene;            /* entity3d_reset's form: default_update(e, NULL) */
         B.mq->priv = edge_no_scene ? NULL : B.scene;
         ref_mq_update(A.mq);
+        if (edge_notify && !f) { gpu_scene_set_notify(gs, true); gpu_scene_bind(gs, B.mq, &B.view); }
         const int rc = gpu_mq_update(gs, B.mq, edge_no_view ? NULL : &B.view);
         if (rc) { fprintf(stderr, "%s: gpu_mq_update: %d (%s)\n", name, rc, clapgpu_last_error()); return 1000; }
         batched += gpu_scene_last_stats(gs)->batched;
+        edge_fast_frames += gpu_scene_last_was_fast(gs);
         bad += compare_frame(gs, f, &visible);
     }
     if (batched < expect_batched_min) { fprintf(stderr, "%s: only %llu batched updates\n", name, (unsigned long long)batched); bad++; }
@@ -473,6 +476,21 @@ static int cmd_edge(void)
     /* children whose model list comes BEFORE their parent's: the reference lags them one frame; they stay on the host */
     CASE("children that precede their parent", 6, { mk(2, NONE, false, true); mk(2, 0, false, true);
                                                     for (int i = 0; i < 6; i++) mk(i % 2, (uint32_t)(i & 1), false, true); mk(1, 3, false, true); });
+    /* the same in notification mode with moves only: from the second frame on nothing is walked (fast frames), all
+     * batched results are written back before the host hooks run -- and a host child listed before its batched
+     * parent must still see that parent's matrix and seq of the PREVIOUS frame, as in the reference's list walk */
+    edge_notify = true; edge_fast_frames = 0;
+    {
+        struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2;
+        edge_reset();
+        mk(2, NONE, false, true); mk(2, 0, false, true);
+        for (int i = 0; i < 40; i++) mk(i % 2, (uint32_t)(i & 1), false, true);     /* lists 0 / 1 come before list 2: children first */
+        mk(1, 3, false, true); mk(0, 2, true, true);                                 /* a hooked child before its batched parent too */
+        bad += edge_frames(gs, "notify: children before batched parents", 8, 16);
+        if (edge_fast_frames < 6) { fprintf(stderr, "notify: only %llu fast frames of 8\n", (unsigned long long)edge_fast_frames); bad++; }
+        gpu_scene_done(gs); cases++;
+    }
+    edge_notify = false;
     edge_no_view = false; edge_no_scene = true;
     CASE("a queue without a scene (priv == NULL)", 57, { for (int i = 0; i < 20; i++) mk(i % 3, NONE, i == 7, true); });
     edge_no_scene = false;
@@ -850,12 +868,46 @@ static void aworld_init(struct aworld *w, uint32_t cap, uint32_t J, uint64_t see
     w->e = calloc(cap, sizeof(*w->e));
 }
 
-static double rel_err(const float *a, const float *b, size_t n)
+/* The 1e-5 bar of the floating-point rows, per OBJECT (tests/helpers.py has the same in numpy): max |a - b| over the
+ * listed components / max |a| over the same components (floor 1e-30) -- a joint's T, R, S, the 3x3 block of its palette
+ * matrix, that matrix's translation column, its world position, each against its own magnitude. */
+static double obj_abs(const float *a, const float *b, const int *idx, int n)
 {
-    double mx = 1.0, err = 0.0;
-    for (size_t i = 0; i < n; i++) { const double v = fabs((double)a[i]); if (v > mx) mx = v; }
-    for (size_t i = 0; i < n; i++) { const double d = fabs((double)a[i] - (double)b[i]); if (!(d <= err)) err = d; }
-    return err / mx;
+    double err = 0.0;
+    for (int i = 0; i < n; i++) { const int k = idx ? idx[i] : i; const double d = fabs((double)a[k] - (double)b[k]); if (!(d <= err)) err = d; }
+    return err;
+}
+static double obj_mag(const float *a, const int *idx, int n)
+{
+    double mx = 0.0;
+    for (int i = 0; i < n; i++) { const int k = idx ? idx[i] : i; const double v = fabs((double)a[k]); if (v > mx) mx = v; }
+    return mx;
+}
+static double rel_own(const float *a, const float *b, const int *idx, int n)
+{
+    const double m = obj_mag(a, idx, n);
+    return obj_abs(a, b, idx, n) / (m > 1e-30 ? m : 1e-30);
+}
+static const int M3_IDX[9] = { 0, 1, 2, 4, 5, 6, 8, 9, 10 }, TC_IDX[3] = { 12, 13, 14 };
+/* largest absolute row sum of a column-major mat4's linear block */
+static double rowsum3(const float *m)
+{
+    double best = 0.0;
+    for (int r = 0; r < 3; r++) { const double v = fabs((double)m[r]) + fabs((double)m[4 + r]) + fabs((double)m[8 + r]); if (v > best) best = v; }
+    return best;
+}
+/* A SUM whose result cancelled far below its terms carries the rounding of those terms (about an fp32 ulp of them per
+ * operation, in any evaluation order but the reference's own): held to COND_ULPS ulps of the terms instead of 1e-5 of itself. */
+#define COND_ULPS 64.0
+struct tol_stats { double worst_own, worst_ulps; uint64_t cancelled; };
+static bool held(struct tol_stats *ts, double err_abs, double own_mag, double terms)
+{
+    const double rel = err_abs / (own_mag > 1e-30 ? own_mag : 1e-30);
+    if (rel <= 1e-5) { if (rel > ts->worst_own) ts->worst_own = rel; return true; }
+    const double ulps = err_abs / (ldexp(1.0, -24) * (terms > 1e-300 ? terms : 1e-300));
+    ts->cancelled++;
+    if (ulps > ts->worst_ulps) ts->worst_ulps = ulps;
+    return ulps <= COND_ULPS;
 }
 
 static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed)
@@ -873,6 +925,8 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
      * joint transforms of the same frame; props listed BEFORE them, which the reference serves one frame late; and
      * plain children of held items */
     const uint32_t n_held = n_chars / 3 + 2, n = n_plain + 3 * n_held;
+    uint64_t attached_expected = 0;
+    uint32_t riders_after = 0;
     dbl_now = 10.0;
     aworld_init(&WA, n, J, seed * 77 + 1);
     aworld_init(&WB, n, J, seed * 77 + 1);
@@ -895,6 +949,10 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
         const bool prop = id >= n_chars;
         if (id >= n_plain) {
             const uint32_t k3 = (id - n_plain) % 3, owner = rndn(n_chars), joint = reach_list[rndn(n_reach)];
+            /* a rider listed after its character, and its plain child: the device's second launch -- unless the joint
+             * number happens to be JOINT_TYPE_MAX, which the reference itself reads as "no joint" (model.c:1609,1624) */
+            if (k3 == 0) riders_after = joint != JOINT_TYPE_MAX;
+            if (k3 != 1) attached_expected += riders_after;
             vec3 hpos = { rndf(-0.5f, 0.5f), rndf(-0.5f, 0.5f), rndf(-0.5f, 0.5f) };
             const float hx = rndf(-3, 3), hy = rndf(-3, 3), hsc = rndf(0.5f, 1.5f);
             for (int k = 0; k < 2; k++) {
@@ -943,8 +1001,9 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
     }
     WA.libc = WB.libc = s0;
 
-    uint64_t bad = 0, posed = 0, restarts = 0, held_checked = 0;
-    double worst = 0.0, worst_held = 0.0;
+    uint64_t bad = 0, posed = 0, restarts = 0, held_checked = 0, attached_batched = 0, batched = 0;
+    attached_expected *= frames;
+    struct tol_stats ts = { 0 }, ts_held = { 0 };
     for (uint32_t f = 0; f < frames; f++) {
         dbl_now = 10.0 + 0.37 * f + (f % 4 == 3 ? 0.0 : 0.013 * f);
         for (uint32_t id = 0; id < n; id++) {
@@ -972,6 +1031,9 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
         rc = gpu_mq_update(gs, &WB.scene->mq, &WB.view);
         if (!rc) rc = gpu_anim_update(ga, gs, &WB.scene->mq, WB.scene);
         WB.libc = gp_libc_state_get();
+        attached_batched += gpu_scene_last_stats(gs)->attached;
+        batched += gpu_scene_last_stats(gs)->batched;
+        if (gpu_scene_last_stats(gs)->attach_failures) { fprintf(stderr, "frame %u: the joint-attached device pass failed\n", f); bad++; }
         if (rc) { fprintf(stderr, "frame %u: binding failed: %d (%s)\n", f, rc, clapgpu_last_error()); return 2; }
         if (WA.libc != WB.libc) { fprintf(stderr, "frame %u: drand48 stream position differs\n", f); bad++; }
 
@@ -983,29 +1045,48 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
             diff |= (a->seq != b->seq) << 2;
             if (id >= n_plain) {                                  /* rides a palette computed on the device: within the pose bar */
                 diff &= ~3;
-                const double em = rel_err((const float *)a->mx, (const float *)b->mx, 16);
-                const double eb = rel_err((const float *)a->aabb, (const float *)b->aabb, 6);
-                if (!(em <= 1e-5) || !(eb <= 1e-5)) diff |= 1 << 7;
-                if (em > worst_held) worst_held = em;
+                /* mx = parent.mx * ((joint * bind) * local): linear block against itself; the translation is a sum whose
+                 * terms are as large as the parent's placement in the world (characters stand at |x|, |z| <= 300) */
+                const entity3d *root = a;
+                while (root->parent) root = root->parent;
+                const double terms = obj_mag((const float *)root->mx, TC_IDX, 3) + rowsum3((const float *)root->mx) * 8.0;
+                bool ok = held(&ts_held, obj_abs((const float *)a->mx, (const float *)b->mx, M3_IDX, 9), obj_mag((const float *)a->mx, M3_IDX, 9), 0.0);
+                ok &= held(&ts_held, obj_abs((const float *)a->mx, (const float *)b->mx, TC_IDX, 3), obj_mag((const float *)a->mx, TC_IDX, 3), terms);
+                for (int h = 0; h < 2; h++)
+                    ok &= held(&ts_held, obj_abs((const float *)a->aabb[h], (const float *)b->aabb[h], NULL, 3), obj_mag((const float *)a->aabb[h], NULL, 3), terms);
+                if (!ok) diff |= 1 << 7;
                 held_checked++;
             }
             if (id < n_chars) {
                 diff |= (a->animation != b->animation || a->aniq.da.nr_el != b->aniq.da.nr_el) << 3;
                 diff |= !!memcmp(&a->ani_time, &b->ani_time, 8) << 4;
+                /* the character's term scale: the largest of its joints' global translations, rotated inverse-bind and bind
+                 * translations (the terms of joint_transforms' translation column and of the joint positions) */
+                double s_char = 0.0;
                 for (uint32_t j = 0; j < J; j++) {
-                    double err = rel_err(a->joints[j].translation, b->joints[j].translation, 3);
-                    const double e2 = rel_err(a->joints[j].rotation, b->joints[j].rotation, 4);
-                    const double e3 = rel_err(a->joints[j].scale, b->joints[j].scale, 3);
-                    err = err > e2 ? err : e2; err = err > e3 ? err : e3;
+                    if (!reach[j]) continue;
+                    const struct model_joint *mj = &WA.model.joints[j];
+                    double v = obj_mag((const float *)a->joints[j].global, TC_IDX, 3);
+                    const double v2 = rowsum3((const float *)a->joints[j].global) * obj_mag((const float *)mj->invmx, TC_IDX, 3);
+                    const double v3 = rowsum3((const float *)a->joint_transforms[j]) * obj_mag((const float *)mj->bind, TC_IDX, 3);
+                    v = v > v2 ? v : v2; v = v > v3 ? v : v3;
+                    if (v > s_char) s_char = v;
+                }
+                const double s_pos = rowsum3((const float *)a->mx) * s_char + obj_mag((const float *)a->mx, TC_IDX, 3);
+                for (uint32_t j = 0; j < J; j++) {
+                    bool ok = held(&ts, obj_abs(a->joints[j].translation, b->joints[j].translation, NULL, 3), obj_mag(a->joints[j].translation, NULL, 3), 0.0);
+                    ok &= held(&ts, obj_abs(a->joints[j].rotation, b->joints[j].rotation, NULL, 4), obj_mag(a->joints[j].rotation, NULL, 4), 0.0);
+                    ok &= held(&ts, obj_abs(a->joints[j].scale, b->joints[j].scale, NULL, 3), obj_mag(a->joints[j].scale, NULL, 3), 0.0);
                     if (reach[j]) {
-                        const double e4 = rel_err((const float *)a->joint_transforms[j], (const float *)b->joint_transforms[j], 16);
-                        const double e5 = rel_err(a->joints[j].pos, b->joints[j].pos, 4);
-                        err = err > e4 ? err : e4; err = err > e5 ? err : e5;
+                        const float *ja = (const float *)a->joint_transforms[j], *jb = (const float *)b->joint_transforms[j];
+                        ok &= held(&ts, obj_abs(ja, jb, M3_IDX, 9), obj_mag(ja, M3_IDX, 9), 0.0);
+                        ok &= held(&ts, obj_abs(ja, jb, TC_IDX, 3), obj_mag(ja, TC_IDX, 3), s_char);
+                        ok &= held(&ts, obj_abs(a->joints[j].pos, b->joints[j].pos, NULL, 3), obj_mag(a->joints[j].pos, NULL, 3), s_pos);
+                        ok &= a->joints[j].pos[3] == b->joints[j].pos[3] || fabs((double)a->joints[j].pos[3] - b->joints[j].pos[3]) <= 1e-5;
                     } else {
                         diff |= !!memcmp(a->joint_transforms[j], b->joint_transforms[j], 64) << 6;   /* untouched on both sides */
                     }
-                    if (err > worst) worst = err;
-                    if (!(err <= 1e-5)) diff |= 1 << 5;
+                    if (!ok) diff |= 1 << 5;
                     posed++;
                 }
             }
@@ -1016,10 +1097,14 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
             restarts += WA.e[id]->ani_time == dbl_now;                   /* animation_start this frame */
     }
     printf("{\"mode\": \"anim\", \"frames\": %u, \"characters\": %u, \"joints\": %u, \"joint_poses_compared\": %llu, "
-           "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"joint_attached_checks\": %llu, "
-           "\"worst_joint_attached_error\": %.3g, \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
-           frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, worst, (unsigned long long)held_checked,
-           worst_held, (unsigned long long)bad);
+           "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"cancelled_objects\": %llu, \"worst_cancelled_ulps\": %.3g, "
+           "\"joint_attached_checks\": %llu, \"worst_joint_attached_error\": %.3g, \"joint_attached_cancelled\": %llu, "
+           "\"worst_joint_attached_ulps\": %.3g, \"batched_updates\": %llu, \"attached_batched_updates\": %llu, \"attached_expected\": %llu, "
+           "\"norm\": \"per object: each joint's T, R, S, palette 3x3 block, palette translation, world position against its own magnitude; "
+           "cancelled sums against 64 fp32 ulps of their terms\", \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
+           frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, ts.worst_own, (unsigned long long)ts.cancelled,
+           ts.worst_ulps, (unsigned long long)held_checked, ts_held.worst_own, (unsigned long long)ts_held.cancelled, ts_held.worst_ulps,
+           (unsigned long long)batched, (unsigned long long)attached_batched, (unsigned long long)attached_expected, (unsigned long long)bad);
     gpu_anim_done(ga);
     gpu_scene_done(gs);
     return bad ? 1 : 0;

@@ -219,6 +219,28 @@ def test_errors_are_reported_not_crashed_on(tmp_path):
             snapshot.load_scene_json(str(bad / "scene.json"), str(bad / "out.clps"))
         except _lib.ClapGpuError:
             pass
+    # indices and offsets that are negative, fractional, non-finite or huge (a cast of those is undefined behaviour and
+    # (unsigned)-1 would index wildly): such bufferViews / accessors are skipped, the asset is refused or loads, no crash
+    import struct
+    jl = struct.unpack_from("<I", glb, 12)[0]
+    doc = json.loads(glb[20:20 + jl].decode())
+    pos_acc = doc["meshes"][0]["primitives"][0]["attributes"]["POSITION"]
+    for field, where, value in (("bufferView", "accessors", -1), ("bufferView", "accessors", 1e300), ("byteOffset", "accessors", -5),
+                                ("count", "accessors", -3), ("count", "accessors", 2.5), ("buffer", "bufferViews", -1),
+                                ("byteOffset", "bufferViews", -1e9), ("byteOffset", "bufferViews", 1.8e19),
+                                ("byteLength", "bufferViews", -1)):
+        d = json.loads(json.dumps(doc))
+        idx = pos_acc if where == "accessors" else d["accessors"][pos_acc]["bufferView"]
+        d[where][idx][field] = value
+        js = json.dumps(d, separators=(",", ":")).encode()
+        js += b" " * (-len(js) % 4)
+        bin_chunk = glb[20 + jl:]
+        out = struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(js) + len(bin_chunk)) + struct.pack("<II", len(js), 0x4E4F534A) + js + bin_chunk
+        (bad / "h.glb").write_bytes(out)
+        try:
+            snapshot.load_scene_json(str(bad / "scene.json"), str(bad / "out.clps"))
+        except _lib.ClapGpuError:
+            pass
 
 
 def test_loader_under_sanitizers(tmp_path):
@@ -298,3 +320,78 @@ def test_c_program_loads_and_replays_the_fixture(tmp_path, cuda_device):
     r = subprocess.run([exe, FIX, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout
+
+
+def _glb_patch(path_in, path_out, patch):
+    """Rewrite bytes of a GLB's BIN chunk: patch(doc, view_of) -> [(byte offset in BIN, bytes)]."""
+    import struct
+    raw = bytearray(open(path_in, "rb").read())
+    jl = struct.unpack_from("<I", raw, 12)[0]
+    doc = json.loads(raw[20:20 + jl].decode())
+    bin0 = 20 + jl + 8
+
+    def span(acc_index):
+        a = doc["accessors"][acc_index]
+        v = doc["bufferViews"][a["bufferView"]]
+        return v.get("byteOffset", 0) + a.get("byteOffset", 0), a["count"]
+    for off, data in patch(doc, span):
+        raw[bin0 + off:bin0 + off + len(data)] = data
+    open(path_out, "wb").write(bytes(raw))
+    return doc
+
+
+def test_loader_flags_unnormalised_weights_and_non_strict_key_times(tmp_path):
+    """weight_sum_max_dev: the shader's total_local_pos.w is the weight sum (model.vert:36-38; clapgpu_skin_batch.out_w).
+    a<k>_ch_nonstrict / key_times_nonstrict: equal or descending neighbouring key times make channel_time_to_idx's
+    bracket depend on its cursor (model.c:1266-1288, 1310), which the stateless device search does not have."""
+    src = os.path.join(FIX, "hero.glb")
+    clean = str(tmp_path / "clean.clps")
+    snapshot.load_gltf(src, clean)
+    m = snapshot.load_scene(clean)["model0"]
+    assert m["key_times_nonstrict"] == 0 and not m["a0_ch_nonstrict"].any() and not m["a1_ch_nonstrict"].any()
+    assert 0.0 <= float(m["weight_sum_max_dev"][0]) <= 2e-7             # the fixture's Dirichlet weights, rounded to fp32
+
+    picked = {}
+
+    def patch(doc, span):
+        out = []
+        # vertex 5: weights scaled by 1.5; vertex 9: all zero
+        w_acc = doc["meshes"][0]["primitives"][0]["attributes"]["WEIGHTS_0"]
+        off, _n = span(w_acc)
+        w = np.frombuffer(open(src, "rb").read(), np.uint8)             # re-read: offsets are relative to BIN
+        import struct
+        jl = struct.unpack_from("<I", w, 12)[0]
+        bin0 = 20 + jl + 8
+        w5 = np.frombuffer(w[bin0 + off + 5 * 16:bin0 + off + 6 * 16].tobytes(), np.float32) * np.float32(1.5)
+        out.append((off + 5 * 16, w5.astype(np.float32).tobytes()))
+        out.append((off + 9 * 16, np.zeros(4, np.float32).tobytes()))
+        picked["sum5"] = float(w5.astype(np.float32).sum(dtype=np.float32))
+        # the first joint channel of animation 0 with >= 3 keys: key 2 := key 1 (equal neighbours);
+        # the first of animation 1 with >= 3 keys: key 1 > key 2 (descending)
+        for ai, mode in ((0, "equal"), (1, "descending")):
+            an = doc["animations"][ai]
+            for ci, ch in enumerate(an["channels"]):
+                if ch["target"]["node"] >= 12:
+                    continue
+                t_off, cnt = span(an["samplers"][ch["sampler"]]["input"])
+                if cnt >= 3:
+                    t = np.frombuffer(w[bin0 + t_off:bin0 + t_off + 4 * cnt].tobytes(), np.float32).copy()
+                    if mode == "equal":
+                        t[2] = t[1]
+                    else:
+                        t[1], t[2] = t[2] + np.float32(0.01), t[1]
+                    out.append((t_off, t.tobytes()))
+                    picked[ai] = sum(1 for c in an["channels"][:ci] if c["target"]["node"] < 12)   # index among kept channels
+                    break
+        return out
+
+    bad = str(tmp_path / "bad.glb")
+    _glb_patch(src, bad, patch)
+    snap = str(tmp_path / "bad.clps")
+    snapshot.load_gltf(bad, snap)                                       # kept and flagged, not rejected
+    m2 = snapshot.load_scene(snap)["model0"]
+    dev = float(m2["weight_sum_max_dev"][0])
+    assert abs(dev - max(abs(picked["sum5"] - 1.0), 1.0)) <= 1e-6       # the all-zero vertex: |0 - 1| = 1
+    assert m2["key_times_nonstrict"] == 2
+    assert m2["a0_ch_nonstrict"][picked[0]] == 1 and m2["a0_ch_nonstrict"].sum() == 1
+    assert m2["a1_ch_nonstrict"][picked[1]] == 1 and m2["a1_ch_nonstrict"].sum() == 1
