@@ -229,8 +229,10 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
         if (!model->anis.da.nr_el || !model->nr_joints || model->nr_joints > 256) continue;
         struct ga_model *m = NULL;
         list_for_each_entry_iter(e, it, &txm->entities, entry) {
-            if (!entity3d_matches(e, ENTITY3D_ALIVE) || e->update != default_update) continue;
-            if (gs && !gpu_scene_entity_is_batched(gs, e)) continue;     /* its own hook ran animated_update already */
+            if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
+            /* whoever ran the entity's own hook ran its animated_update too; what gpu_mq_update batched (default_update
+             * entities, and body-less characters, whose hook ends in default_update) is posed here */
+            if (gs ? !gpu_scene_entity_is_batched(gs, e) : e->update != default_update) continue;
             if (e->animation < 0)
                 animation_next(e, s);
             struct queued_animation *qa = ani_current(e);

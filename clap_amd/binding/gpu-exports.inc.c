@@ -14,6 +14,14 @@
  *   void entity3d_position / _move / _rotate / _scale / _visible    model.h:712-770  model.c:1810-1842
  *       the reference's bodies + gpu_scene_touch(): the dirty notification that lets gpu_mq_update() run in
  *       O(touched) instead of walking every entity3d
+ *   void entity3d_update(entity3d *e, void *data)                   model.h:647   model.c:1793
+ *   void entity3d_reset(entity3d *e)                                model.h:532   model.c:1726
+ *       one entity's update outside the frame loop (instantiate_entity model.c:1872, terrain.c:551): the reference's
+ *       body -- a single entity is host work -- + gpu_scene_host_updated(), which brings the device's copy of a
+ *       batched entity (and, through its seq, its children) up to date with the next mq_update
+ *   void particle_system_position(particle_system *ps, const vec3 c) particle.h:47  particle.c:132-157
+ *       in gpu-particles.inc.c (the struct is private to particle.c): an attached, mirrored system carries its
+ *       device-resident particles along
  *
  * A queue the binding is not bound to (the UI queue, ui.c:188) takes the reference's path unchanged.
  * Included at the end of the translation unit that holds model.c (after gpu-anim.inc.c), view.c and light.c.
@@ -72,5 +80,19 @@ GPU_EXPORT_MUTATOR(entity3d_move, (entity3d *e, vec3 off), (e, off))
 GPU_EXPORT_MUTATOR(entity3d_rotate, (entity3d *e, float rx, float ry, float rz), (e, rx, ry, rz))
 GPU_EXPORT_MUTATOR(entity3d_scale, (entity3d *e, float scale), (e, scale))
 GPU_EXPORT_MUTATOR(entity3d_visible, (entity3d *e, unsigned int visible), (e, visible))
+
+void ref_entity3d_update(entity3d *e, void *data);
+void entity3d_update(entity3d *e, void *data)
+{
+    ref_entity3d_update(e, data);
+    gpu_scene_host_updated(gpu_scene_bound(), e);
+}
+
+void ref_entity3d_reset(entity3d *e);
+void entity3d_reset(entity3d *e)
+{
+    ref_entity3d_reset(e);
+    gpu_scene_host_updated(gpu_scene_bound(), e);
+}
 
 #endif /* CONFIG_GPU_SCENE */

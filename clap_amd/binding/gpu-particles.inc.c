@@ -281,3 +281,19 @@ int gpu_particle_system_position(struct gpu_particles *gp, particle_system *ps, 
     gp->host_stale = true;
     return 0;
 }
+
+/* CONFIG_GPU_SCENE: the engine's own name (particle.h:47), served by the binding for the bound particle mirror.  This
+ * file is included while `particle_system_position` still names the reference's body (ref_particle_system_position:
+ * the includer renames it around particle.c, like gpu-exports.inc.c's functions), so the calls above reach that body. */
+#ifdef CONFIG_GPU_SCENE
+static struct gpu_particles *g_bound_particles;
+void gpu_particles_bind(struct gpu_particles *gp) { g_bound_particles = gp; }
+#undef particle_system_position
+void ref_particle_system_position(particle_system *ps, const vec3 center);
+void particle_system_position(particle_system *ps, const vec3 center)
+{
+    if (g_bound_particles && !gpu_particle_system_position(g_bound_particles, ps, center))
+        return;
+    ref_particle_system_position(ps, center);
+}
+#endif

@@ -47,6 +47,9 @@
 /* the engine's view_entity_in_frustum IS the binding then (gpu-exports.inc.c): fall back to the reference's body */
 bool ref_view_entity_in_frustum(struct view *view, entity3d *e);
 #define view_entity_in_frustum ref_view_entity_in_frustum
+/* and so is entity3d_update: the hooks this file runs itself are the reference's dispatch, not a notification */
+void ref_entity3d_update(entity3d *e, void *data);
+#define entity3d_update ref_entity3d_update
 #endif
 #include "clapgpu_scene.h"
 #include "clapgpu_snapshot.h"
@@ -72,6 +75,8 @@ struct gs_rec {
     uint8_t     self_ok;
     uint8_t     xform_dirty;    /* xform.updated as seen in step 3 (cleared in step 5, like default_update) */
     uint8_t     pending;        /* on the touched list (notification mode) */
+    uint8_t     host_done;      /* entity3d_update() / entity3d_reset() ran this entity's update on the host between frames: the device
+                                   still has to rebuild it (its children follow its seq), the host fields are already final */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
 };
 
@@ -91,6 +96,11 @@ struct gpu_scene {
     struct gs_model *models; uint32_t n_models, cap_models;
     uint32_t        gen, vis_cursor;
     bool            anim_elsewhere;
+    /* body-less characters (gpu-character.inc.c): is this entity's hook character_update over default_update, and the
+     * host half of that hook, run before the entity is mirrored */
+    bool            (*char_plain)(entity3d *, int (*)(entity3d *, void *));
+    int             (*char_half)(entity3d *, void *);
+    uint32_t        *char_list; uint32_t n_char, cap_char;         /* batched characters in list order (last walk) */
     /* notification mode: the engine's mutators report what they touch (gpu_scene_touch / gpu_scene_topology) and
      * a frame costs O(touched + rebuilt + host-class entities) instead of two walks over every entity3d */
     bool            notify, topology_pending, walked, last_fast;
@@ -223,6 +233,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     if (!gs) return;
     clapgpu_scene_destroy(gs->scene);
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
+    free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
@@ -232,6 +243,14 @@ void gpu_scene_done(struct gpu_scene *gs)
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs) { return &gs->stats; }
 
 void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere) { gs->anim_elsewhere = elsewhere; }
+
+void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int (*)(entity3d *, void *)),
+                          int (*host_half)(entity3d *, void *))
+{
+    if (!gs) return;
+    gs->char_plain = is_plain; gs->char_half = host_half;
+    gs->topology_pending = true;
+}
 
 /* The joint-attached subtrees this frame's gpu_mq_update() held back (class 3), in list order, now that the parents'
  * joint transforms of the frame exist.  Called by gpu_anim_update(); a frame driver without it calls this itself. */
@@ -325,9 +344,10 @@ static bool self_batchable(const struct gpu_scene *gs, entity3d *e)
     /* light carriers are batched: scatter_one() hands the position on.  An entity riding a joint (e->parent_joint) is
      * batchable too -- in the frame's second launch, if its parent's palette is computed on the device this frame: the walk
      * decides (class 4), since that depends on the parent */
-    return e->update == gs->default_hook &&
+    const bool plain_char = gs->char_plain && gs->hook_data && (e->flags & ENTITY3D_IS_CHARACTER) && gs->char_plain(e, gs->default_hook);
+    return (e->update == gs->default_hook || plain_char) &&
            (gs->anim_elsewhere || !entity_animated(e)) &&
-           !(e->flags & (ENTITY3D_HAS_PHYSICS | ENTITY3D_IS_CHARACTER | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE));
+           !(e->flags & (ENTITY3D_HAS_PHYSICS | (plain_char ? 0 : ENTITY3D_IS_CHARACTER) | ENTITY3D_IS_UI | ENTITY3D_IS_PARTICLE));
 }
 
 /* The record of r's parent, or NO_REC if the parent is not an ALIVE member of this queue. */
@@ -408,7 +428,7 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
         r->flags = flags;
     }
     r->xform_dirty = transform_is_updated(&e->xform);
-    if (r->xform_dirty || fresh) {
+    if (r->xform_dirty || fresh || r->host_done) {       /* host_done: the flag is already cleared, the device copy is not yet current */
         CK(clapgpu_scene_entity_transform(gs->scene, r->handle, transform_pos(&e->xform, NULL),
                                           transform_rotation_quat(&e->xform), e->scale));
         st->uploaded++;
@@ -487,6 +507,24 @@ void gpu_scene_touch(struct gpu_scene *gs, entity3d *e)
     if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) gs->topology_pending = true;
 }
 
+/* entity3d_update(e, data) / entity3d_reset(e) (model.c:1793, 1726; callers outside the frame loop: instantiate_entity
+ * model.c:1872, terrain.c:551) ran e's update on the host just now: mx, inverse_mx, aabb, seq, xform.updated are final, as
+ * the reference leaves them.  The device's copy of a batched entity is not: it gets the transform with the next update and
+ * rebuilds the entity there (its children follow its seq counter), and the write-back skips the fields the host owns. */
+void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs) return;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return;
+    struct gs_rec *r = &gs->rec[i];
+    if (r->cls != 1 && r->cls != 4) return;                      /* host-class: nothing is mirrored */
+    r->host_done = 1;
+    if (!gs->notify || r->pending) return;
+    r->pending = 1;
+    if (r->order_pos < gs->n_order && gs->vq_ok) gs->vq_ok[r->order_pos] = 0;
+    if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) gs->topology_pending = true;
+}
+
 /* entity3d_make / entity3d_delete, e->parent = ..., e->update = ..., a body / light / joint attached: the next
  * gpu_mq_update() walks the queue once */
 void gpu_scene_topology(struct gpu_scene *gs) { if (gs) gs->topology_pending = true; }
@@ -506,6 +544,11 @@ static inline void light_hand_off(struct gpu_scene *gs, entity3d *e)
 static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq)
 {
     entity3d *e = r->e, *parent = e->parent;
+    if (r->host_done) {                                          /* gpu_scene_host_updated(): the host wrote these fields itself */
+        r->host_done = 0;
+        if (!transform_is_updated(&e->xform) && !(parent && e->parent_seq != parent->seq)) return;
+        /* ... but it was touched again since (or its parent moved): an ordinary rebuild */
+    }
     if (parent && parent_seq) e->parent_seq = parent->seq;                     /* model.c:1613 (parents sit in lower slots: already advanced) */
     if (transform_is_updated(&e->xform)) transform_clear_updated(&e->xform);
     e->seq++;                                                    /* model.c:1616, 1669 */
@@ -584,7 +627,7 @@ static void *par_mirror(void *arg)
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
         r->xform_dirty = transform_is_updated(&e->xform);
         const int rc = clapgpu_scene_entity_transform_mt(gs->scene, r->handle, transform_pos(&e->xform, NULL),
-                                                         transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty);
+                                                         transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty || r->host_done);
         if (rc) j->rc = rc;
         j->count++;
     }
@@ -653,6 +696,11 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
     const double t0 = now_ms();
+    /* batched characters: the host half of character_update (limbo teleport, motion reset), which may touch them */
+    for (uint32_t k = 0; k < gs->n_char; k++) {
+        struct gs_rec *r = &gs->rec[gs->char_list[k]];
+        if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE)) gs->char_half(r->e, mq->priv);
+    }
     if (gs->n_touched >= GS_PAR_MIN) {
         struct par_job jobs[8] = { 0 };
         const int nt = par_threads();
@@ -848,7 +896,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->n_touched = 0;
     gs->topology_pending = false;
     gs->last_fast = false;
-    gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0;
+    gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0; gs->n_char = 0;
     clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);   /* the walk does the pick per entity */
 
     const double t0 = now_ms();
@@ -933,6 +981,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 }
             }
             if (r->cls == 1 || r->cls == 4) {
+                if (e->update != gs->default_hook) {             /* a body-less character: its hook's host half, at its place in the list */
+                    gs->char_half(e, mq->priv);
+                    if (push_u32(&gs->char_list, &gs->n_char, &gs->cap_char, i)) return _CERR_NOMEM;
+                    r = &gs->rec[i];
+                }
                 CK(mirror_one(gs, r));
                 CK(link_parent(gs, r));
             } else {
@@ -1011,6 +1064,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
         entity3d *parent = e->parent;
         const bool rebuilt = parent ? (r->xform_dirty || e->parent_seq != parent->seq) : r->xform_dirty;
+        r->host_done = 0;                                        /* the host fields decide here: a host-updated entity is simply not dirty */
         if (rebuilt) {
             const size_t slot = r->slot;
             if (parent) e->parent_seq = parent->seq;             /* model.c:1613 */

@@ -74,6 +74,8 @@ const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 void gpu_scene_set_notify(struct gpu_scene *gs, bool on);
 bool gpu_scene_last_was_fast(const struct gpu_scene *gs);      /* the last gpu_mq_update() did not walk the queue */
 void gpu_scene_touch(struct gpu_scene *gs, entity3d *e);
+/* entity3d_update(e, data) / entity3d_reset(e) ran e's update on the host, outside the frame loop (gpu-exports.inc.c) */
+void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_topology(struct gpu_scene *gs);
 /* the scene, queue and view the engine-named entry points (mq_update, view_entity_in_frustum, ...) serve */
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view);
@@ -95,6 +97,15 @@ void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere);
  * local -> parent.mx * ... -> inverse, box, cull on the device), the rest -- riders of host-class parents, nested riders,
  * riders that are animated themselves -- run their own hooks, in list order. */
 void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq);
+/*
+ * Characters without a physics body (gpu-character.inc.c, #include'd at the end of character.c, calls this through
+ * gpu_scene_bind_characters): is_plain(e, default_hook) says whether e's hook is character_update chained to
+ * default_update with no body behind it; host_half(e, data) runs everything character_update does before the chained call
+ * (character.c:583-609).  Such entities are batched: host half first, at their place in the list, then the device.
+ */
+void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int (*)(entity3d *, void *)),
+                          int (*host_half)(entity3d *, void *));
+void gpu_scene_bind_characters(struct gpu_scene *gs);          /* gpu-character.inc.c */
 /* true if `e` was updated on the device by the last gpu_mq_update() */
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);
 

@@ -33,6 +33,7 @@
  *   clap_dropin particles <systems> <particles_per_system> <frames> <seed>
  *   clap_dropin anim <characters> <joints> <frames> <seed>
  *   clap_dropin lights <frames> <seed>
+ *   clap_dropin characters <characters> <frames> <seed>   body-less characters: character_update, host half + device
  *   clap_dropin edge                                  small hand-made scenes (empty queue, one entity, ...)
  *   clap_dropin snapshot <entities> <file>            dump a scene through the binding + the reference's results
  */
@@ -48,6 +49,8 @@
 #define entity3d_rotate         ref_entity3d_rotate
 #define entity3d_scale          ref_entity3d_scale
 #define entity3d_visible        ref_entity3d_visible
+#define entity3d_update         ref_entity3d_update
+#define entity3d_reset          ref_entity3d_reset
 #define view_entity_in_frustum  ref_view_entity_in_frustum
 #define view_calc_frustum       ref_view_calc_frustum
 #define light_grid_compute      ref_light_grid_compute
@@ -62,13 +65,20 @@
 #undef entity3d_rotate
 #undef entity3d_scale
 #undef entity3d_visible
+#undef entity3d_update
+#undef entity3d_reset
 #undef view_entity_in_frustum
 #undef view_calc_frustum
 #undef light_grid_compute
 #include "gpu-scene.h"
 #include "gpu-exports.inc.c"            /* the engine's names, served by the binding */
+#define particle_system_position ref_particle_system_position
 #include "particle.c"
-#include "gpu-particles.inc.c"          /* clap_amd/binding: lives at the end of particle.c's translation unit */
+#include "gpu-particles.inc.c"          /* clap_amd/binding: lives at the end of particle.c's translation unit; ends by defining
+                                           the engine's particle_system_position on top of the binding */
+
+#include "character.c"
+#include "gpu-character.inc.c"          /* clap_amd/binding: lives at the end of character.c's translation unit */
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -240,6 +250,7 @@ static uint32_t pick_alive(void)
     return NONE;
 }
 
+static uint64_t n_host_updates;            /* entity3d_update / entity3d_reset calls between frames */
 static void game_frame(uint32_t n_ops)
 {
     for (uint32_t k = 0; k < n_ops; k++) {
@@ -248,6 +259,11 @@ static void game_frame(uint32_t n_ops)
         if (what < 600) {
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
             ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
+            /* now and then the game updates the entity on the spot instead of waiting for the frame (entity3d_update:
+             * instantiate_entity, model.c:1872; entity3d_reset: terrain.c:551) -- under the engine's names in world B */
+            const uint32_t now = rndn(24);
+            if (now == 0) { ref_entity3d_update(A.e[id], A.mq->priv); entity3d_update(B.e[id], B.mq->priv); n_host_updates++; }
+            else if (now == 1 && !meta[id].hooked) { ref_entity3d_reset(A.e[id]); entity3d_reset(B.e[id]); n_host_updates++; }
         } else if (what < 800) {
             const float rx = rndf(-3, 3), ry = rndf(-3, 3), rz = rndf(-3, 3);
             ref_entity3d_rotate(A.e[id], rx, ry, rz); entity3d_rotate(B.e[id], rx, ry, rz);
@@ -375,10 +391,103 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
     for (uint32_t id = 0; id < n_ids; id++) alive += meta[id].alive;
     printf("{\"mode\": \"test\", \"frames\": %u, \"entities_created\": %u, \"entities_alive\": %u, "
            "\"batched_updates\": %llu, \"host_updates\": %llu, \"written_back\": %llu, \"retiles\": %llu, "
-           "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"mismatches\": %llu}\n",
+           "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"entity3d_update_calls\": %llu, \"mismatches\": %llu}\n",
            frames, n_ids, alive, (unsigned long long)batched, (unsigned long long)host,
            (unsigned long long)written, (unsigned long long)retiles, (unsigned long long)visible,
-           opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)bad);
+           opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates, (unsigned long long)bad);
+    gpu_scene_done(gs);
+    return bad ? 1 : 0;
+}
+
+/* ---- body-less characters: character_update (character.c:583-611) on the reference's own struct character ---- */
+/* World A: every character's own hook (character_update -> default_update) through the reference's mq_update.  World B:
+ * the binding batches them (gpu_scene_bind_characters): the hook's host half -- limbo teleport out of the position
+ * history, the controlled character's motion reset -- by the reference's own character_update with its tail parked,
+ * then the transform on the device.  Plain props hang below some characters.  Compared bit for bit every frame: the
+ * entities' matrices, boxes and counters, and each character's history ring, state and motion fields. */
+static int cmd_characters(uint32_t n_chars, uint32_t frames, uint64_t seed)
+{
+    struct gpu_scene *gs;
+    int rc = gpu_scene_init(&gs, 0, default_update);
+    if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
+    gpu_scene_bind_characters(gs);
+    rng_state = seed;
+    const uint32_t n_props = n_chars / 3 + 1, n = n_chars + n_props;
+    cap_ids = n + 1;
+    meta = calloc(cap_ids, sizeof(*meta));
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+    struct character *CA = calloc(n_chars, sizeof(*CA)), *CB = calloc(n_chars, sizeof(*CB));
+    for (uint32_t id = 0; id < n; id++) {
+        const bool is_char = id < n_chars;
+        vec3 pos = { rndf(-100, 100), rndf(0, 40), rndf(-100, 100) };
+        const float ry = rndf(-3, 3), sc = rndf(0.7f, 1.4f);
+        const uint32_t owner = is_char ? NONE : rndn(n_chars);
+        if (!is_char) { pos[0] = rndf(-1, 1); pos[1] = rndf(0, 2); pos[2] = rndf(-1, 1); }
+        vec3 hist[POS_HISTORY_MAX];
+        for (int h = 0; h < POS_HISTORY_MAX; h++) { hist[h][0] = pos[0] + rndf(-3, 3); hist[h][1] = pos[1] + rndf(-1, 1); hist[h][2] = pos[2] + rndf(-3, 3); }
+        const unsigned int head = rndn(POS_HISTORY_MAX);
+        const bool wrapped = rndn(2);
+        for (int k = 0; k < 2; k++) {
+            struct world *w = k ? &B : &A;
+            entity3d *e = ref_new(entity3d, .txmodel = &w->txm[is_char ? 1 : 2]);   /* the props' list comes after the characters' */
+            ref_entity3d_position(e, pos); ref_entity3d_rotate(e, 0, ry, 0); ref_entity3d_scale(e, sc);
+            if (is_char) {
+                struct character *c = &(k ? CB : CA)[id];
+                c->entity = e;
+                entity3d_set(e, ENTITY3D_IS_CHARACTER, c);               /* character_make, character.c:621-625 */
+                c->orig_update = e->update;
+                e->update = character_update;
+                c->state = CS_AWAKE; c->jump_forward = 0.5; c->jump_upward = 3.5;
+                memcpy(c->history.pos, hist, sizeof(hist));
+                c->history.head = head; c->history.wrapped = wrapped;
+            } else {
+                e->parent = w->e[owner];
+            }
+            w->e[id] = e;
+        }
+        meta[id].alive = 1;
+    }
+    n_ids = n;
+    A.scene->control = A.e[0]; B.scene->control = B.e[0];
+    A.scene->limbo_height = B.scene->limbo_height = 25.f;
+
+    uint64_t bad = 0, visible = 0, batched = 0, host = 0, teleports = 0, fast = 0;
+    gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_bind(gs, B.mq, &B.view);
+    for (uint32_t f = 0; f < frames; f++) {
+        for (uint32_t id = 0; id < n_chars; id++) {
+            if (rndn(2)) continue;
+            /* game code moves the character: mostly a step, now and then a long fall (the limbo teleport's trigger) */
+            const float *p = transform_pos(&A.e[id]->xform, NULL);
+            vec3 np = { p[0] + rndf(-1, 1), p[1] + (rndn(6) ? rndf(-0.5f, 0.5f) : -rndf(20, 60)), p[2] + rndf(-1, 1) };
+            ref_entity3d_position(A.e[id], np); entity3d_position(B.e[id], np);
+        }
+        vec3 cpos = { rndf(-50, 50), rndf(0, 30), rndf(-50, 50) };
+        quat cq; quat_from_euler_xyz(cq, rndf(-0.5f, 0.5f), rndf(-3, 3), 0);
+        view_set(&A, cpos, cq); view_set(&B, cpos, cq);
+        A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        vec3 before[4];
+        for (uint32_t id = 0; id < 4 && id < n_chars; id++) transform_pos(&A.e[id]->xform, before[id]);
+        ref_mq_update(A.mq);
+        mq_update(B.mq);
+        const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
+        batched += st->batched; host += st->host; fast += gpu_scene_last_was_fast(gs);
+        bad += compare_frame(gs, f, &visible);
+        for (uint32_t id = 0; id < n_chars; id++) {
+            const struct character *a = &CA[id], *b = &CB[id];
+            int diff = !!memcmp(&a->history, &b->history, sizeof(a->history));
+            diff |= (a->state != b->state || a->jump != b->jump || a->airborne != b->airborne) << 1;
+            diff |= (memcmp(a->motion, b->motion, 12) || memcmp(a->velocity, b->velocity, 12) || memcmp(&a->lin_speed, &b->lin_speed, 4)) << 2;
+            diff |= (b->orig_update != default_update || B.e[id]->update != character_update) << 3;   /* the parked tail was put back */
+            if (diff && bad++ < 8) fprintf(stderr, "frame %u character %u: state mismatch 0x%x\n", f, id, diff);
+            teleports += !a->history.head && !a->history.wrapped && f == frames - 1;
+        }
+    }
+    printf("{\"mode\": \"characters\", \"frames\": %u, \"characters\": %u, \"props\": %u, \"batched_updates\": %llu, \"host_updates\": %llu, "
+           "\"fast_frames\": %llu, \"characters_teleported_by_last_frame\": %llu, \"notify\": %s, \"mismatches\": %llu}\n",
+           frames, n_chars, n_props, (unsigned long long)batched, (unsigned long long)host, (unsigned long long)fast,
+           (unsigned long long)teleports, opt_notify ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -674,6 +783,7 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
     struct gpu_particles *gp;
     int rc = gpu_particles_init(&gp, 0);
     if (rc) { fprintf(stderr, "gpu_particles_init: %d\n", rc); return 2; }
+    gpu_particles_bind(gp);
     struct pworld PA, PB, *W[2] = { &PA, &PB };
     const uint32_t cap = n_sys + frames + 4;
     pworld_init(&PA, cap);
@@ -709,8 +819,8 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
                 transform_pos(&PA.ps[s]->e->xform, c);
                 c[0] += rndf(-0.2f, 0.2f); c[1] += rndf(-0.2f, 0.2f); c[2] += rndf(-0.2f, 0.2f);
             }
-            particle_system_position(PA.ps[s], c);
-            gpu_particle_system_position(gp, PB.ps[s], c);
+            ref_particle_system_position(PA.ps[s], c);
+            particle_system_position(PB.ps[s], c);                       /* the engine's name, served by the binding */
         }
         if (f % 5 == 3) {
             const uint32_t s = rndn(PA.n_sys);
@@ -1188,6 +1298,8 @@ int main(int argc, char **argv)
         return cmd_anim((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "particles"))
         return cmd_particles((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
+    if (argc >= 5 && !strcmp(argv[1], "characters"))
+        return cmd_characters((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "test"))
         return cmd_test((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "bench"))

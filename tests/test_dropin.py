@@ -46,7 +46,8 @@ def test_dropin_checker_is_built_where_the_reference_is():
     defined = subprocess.run(["nm", "--defined-only", BIN], capture_output=True, text=True, check=True).stdout
     names = {l.split()[-1] for l in defined.splitlines() if " T " in l}
     for fn in ("mq_update", "view_entity_in_frustum", "view_calc_frustum", "light_grid_compute", "entity3d_position",
-               "entity3d_move", "entity3d_rotate", "entity3d_scale", "entity3d_visible"):
+               "entity3d_move", "entity3d_rotate", "entity3d_scale", "entity3d_visible", "entity3d_update", "entity3d_reset",
+               "particle_system_position"):
         assert fn in names and "ref_" + fn in names, fn
 
 
@@ -75,6 +76,7 @@ def test_binding_matches_reference_mq_update(n, frames, seed, notify):
     assert frac >= BATCHED_FLOOR["test"], f"only {frac:.2f} of the updates went through the device"
     assert r["written_back"] > 0 and r["retiles"] > 0
     assert 0 < r["visible_verdicts_true"]
+    assert r["entity3d_update_calls"] > 0          # entity3d_update / entity3d_reset between frames, engine names in world B
 
 
 @pytest.mark.gpu
@@ -116,6 +118,22 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     # is JOINT_TYPE_MAX is "no joint" to the reference itself and takes the first launch)
     assert r["attached_batched_updates"] == r["attached_expected"] and r["attached_expected"] >= frames * n_held > 0
     assert r["batched_updates"] >= frames * (n_chars + 2 * n_held)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
+@pytest.mark.parametrize("n_chars,frames,seed", [(7, 10, 1), (400, 16, 2), (5000, 8, 3)])
+def test_character_binding_matches_reference_character_update(n_chars, frames, seed, notify):
+    """Body-less characters: the reference's character_update -> default_update per entity against
+    the binding (clap_amd/binding/gpu-character.inc.c): the hook's host half -- limbo teleport out of the position
+    history, the controlled character's motion reset -- by the reference's OWN character_update with its chained tail
+    parked, the transform on the device; props below characters follow.  Entities' matrices, boxes, counters and each
+    character's history ring / state / motion fields bit for bit every frame; every update batched."""
+    r = _run("characters", n_chars, frames, seed, *(["notify"] if notify else []))
+    assert r["mismatches"] == 0
+    assert r["batched_updates"] == frames * (n_chars + n_chars // 3 + 1) and r["host_updates"] == 0
+    assert (r["fast_frames"] > 0) == notify
+    assert r["characters_teleported_by_last_frame"] > 0 or n_chars < 50
 
 
 @pytest.mark.gpu
