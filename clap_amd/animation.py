@@ -80,7 +80,7 @@ def skeleton_bind(invmx):
 class SkinnedModel:
     """Device copy of one model3d's skeleton, animations and (optionally) skinned mesh."""
 
-    def __init__(self, sk, anims, mesh=None, bind=None, device="cuda:0"):
+    def __init__(self, sk, anims, mesh=None, bind=None, device="cuda:0", pack=True):
         self.device = dev = torch.device(device)
         self.nr_joints = J = int(sk["nr_joints"])
         self.depth_host = joint_depths(sk["parent"])
@@ -100,7 +100,17 @@ class SkinnedModel:
                                        _ptr(self.root_pose), _ptr(self.invmx), _ptr(self.bind))
         self.anim_desc = _lib.Animations(len(anims), int(ct["times"].shape[0]), _ptr(self._ct["chan_table"]),
                                          _ptr(self._ct["times"]),
-                                         _ptr(self._ct["data"]))
+                                         _ptr(self._ct["data"]), None, 0, 0)
+        # the key-major copy of the pools (clapgpu_animations_pack): once per model, for skeletons of <= 64 joints
+        self.packed = None
+        max_keys = int(ct["chan_table"][..., 2].max()) if len(anims) else 0
+        if pack and J <= 64 and max_keys > 0:
+            nbytes = int(_lib.lib().clapgpu_animations_packed_bytes(len(anims), max_keys))
+            self.packed = torch.zeros((nbytes + 15) // 16 * 4, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().clapgpu_animations_pack(_stream(), C.byref(self.anim_desc), J, max_keys, _ptr(self.packed)),
+                       "clapgpu_animations_pack")
+            self.anim_desc.packed = _ptr(self.packed)
+            self.anim_desc.packed_keys = max_keys
         self.mesh = None
         if mesh is not None:
             self.mesh = dict(n_verts=int(mesh["n_verts"]), position=_dev(mesh["position"], dev, np.float32),

@@ -38,6 +38,10 @@ struct PoseArgs {
     const uint4    *chan_table;     // [n_anims][J][3] = (time_off, data_off, nr, 0)
     const float    *times, *data;
     uint32_t        n_times, n_anims;
+    // key-major copy of the pools (clapgpu_animations_pack), or nullptr: [anim][path][key row][64 lanes]
+    const float    *pk_times;       // rows padded to pk_kp (a power of two > the longest channel) with +INF
+    const float4   *pk_vals;        // pk_k rows of float4 (T / S: xyz, R: xyzw)
+    uint32_t        pk_k, pk_kp;
     // batch
     uint32_t        n_chars;
     const uint32_t *anim;
@@ -69,21 +73,40 @@ __device__ __forceinline__ void key_bracket(const float *t, int nr, float time, 
     next = wrap ? 0 : next;
 }
 
-// model.c:1312-1317.  The quotient uses the hardware reciprocal (<= 2 ulp): this path is held to
-// 1e-5, and the IEEE division sequence is 3x the instructions.
+// model.c:1312-1317.  The quotient is the hardware reciprocal (1 ulp) corrected by one Newton step on the residual:
+// correctly rounded but for rare ties, at 4 instructions instead of the IEEE division's ~12.  (The bare reciprocal put
+// a 1e-7 relative error into the key fraction, which a lerp between keys of opposite sign turns into 4e-6 of the result.)
 __device__ __forceinline__ float key_fac(float time, float p_time, float n_time)
 {
     if (p_time > n_time) return time < n_time ? 1.f : 0.f;
-    if (p_time < n_time) return (time - p_time) * __builtin_amdgcn_rcpf(n_time - p_time);   // __fdividef expands to the IEEE sequence here
+    if (p_time < n_time) {
+        const float d = n_time - p_time, x = time - p_time;
+        const float r = __builtin_amdgcn_rcpf(d);
+        const float q = x * r;
+        return __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+    }
     return 0.f;
 }
 
-// interp.h:25-29: a * (1.0 - blend) + b * blend.  The reference forms the first product and the sum
-// in double; in fp32 the result differs by <= 1 ulp of the larger operand (inside the 1e-5 bar) and
-// costs a third of the VALU time (fp64 converts and multiplies run at half rate).
-__device__ __forceinline__ float lerp_ref(float a, float b, float fac)
+// interp.h:25-29: (float)((double)a * (1.0 - (double)blend) + (double)(b * blend)) -- the first product and the sum in
+// double, b * blend a rounded fp32 product.  In fp32 with the residual of 1 - blend carried along:
+// 1 - blend = g + gl exactly (g the rounded difference, gl what the rounding dropped), so a * (1 - blend) + p1 =
+// a * g + p1 (one FMA: a single rounding of the sum, exact under cancellation) + a * gl (a second FMA for the 2^-25-sized
+// rest).  Within an ulp of the RESULT of the reference's value also where the two products cancel, which the plain
+// fp32 form b * f + a * (1 - f) was not (errors of an ulp of the operands: up to 4e-6 of a cancelled result).
+struct LerpFac { float f, g, gl; };
+__device__ __forceinline__ LerpFac lerp_fac(float fac)
 {
-    return b * fac + a * (1.0f - fac);
+    LerpFac l;
+    l.f = fac;
+    l.g = 1.0f - fac;
+    l.gl = (1.0f - l.g) - fac;          // exact: both differences are of neighbouring magnitudes
+    return l;
+}
+__device__ __forceinline__ float lerp_ref(float a, float b, const LerpFac l)
+{
+    const float p1 = __fmul_rn(b, l.f);                     // the reference rounds this product to fp32 on its own
+    return __builtin_fmaf(a, l.gl, __builtin_fmaf(a, l.g, p1));
 }
 
 // acos on [0, 1): the rational core of fdlibm's acosf (R(z) = z*P(z)/Q(z), |error| < 7e-9 on z <= 0.25)
@@ -174,7 +197,8 @@ typedef float key4 __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int POSE_WAVES = 3;           // three waves per SIMD (168 VGPRs) run as fast as four (measured): the registers go to the joint constants
 constexpr int G_STRIDE = 16;                 // floats per joint global in LDS
-constexpr int POSE_TIMES_LDS_MAX = 6144 - 96;  // key times kept in LDS when the model's pool fits (with the globals: 40 KiB per block)
+constexpr int POSE_TIMES_LDS_MAX = 6400;       // key times kept in LDS when the model's pool fits: 25 KiB (one animation of <= 31 keys per
+                                             // channel in key-major form with its key counts; with the globals and joint constants 47 KiB per block)
 
 // ---- the one-wavefront-per-character loop without store waits ---------------------------------------------------
 // gfx950 retires vector loads and stores through ONE counter, in issue order: waiting for a load means waiting for
@@ -246,8 +270,59 @@ __device__ __forceinline__ PoseKeys pose_gather_keys(const float *times, const f
     return k;
 }
 
-template <int CPB>
-__device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, const float *times, const float *kdata,
+// The same for the KEY-MAJOR pools (clapgpu_animations_pack): key k of (path, joint j) sits at row k, column j.
+//   * times in LDS, [path][row][64]: lane j's read of ANY row lands in bank j % 32 of its half-wave -- the searches'
+//     ds_read_b32 are conflict-free whatever rows the 64 lanes are at (in the channel-major pool a lane's address was
+//     its channel's offset + a data-dependent key: ~4 distinct addresses per bank, 48 % of all LDS cycles were conflicts);
+//   * rows past a channel's last key hold +INF, so the search needs no bounds test: lo = #{k : t[k] < time} by five
+//     (add, read, compare-select) steps for up to 31 keys;
+//   * values in memory as float4 [path][row][64]: lanes whose brackets are the same key -- all of them when the channels
+//     share their key times, as exported glTF samplers do -- read ONE contiguous 1 KiB row instead of 64 scattered 12-byte
+//     pieces 360 bytes apart.
+__device__ __forceinline__ PoseKeys pose_gather_keys_packed(const float *tl, const float4 *vals, const int kp, const int kk,
+                                                            const float time, const int n0, const int n1, const int n2,
+                                                            const int lane)
+{
+    PoseKeys k;
+    const float *t0 = tl + lane, *t1 = t0 + kp * WAVE, *t2 = t1 + kp * WAVE;
+    int l0 = 0, l1 = 0, l2 = 0;
+    for (int step = kp >> 1; step > 0; step >>= 1) {
+        const float a0 = t0[(l0 + step - 1) * WAVE], a1 = t1[(l1 + step - 1) * WAVE], a2 = t2[(l2 + step - 1) * WAVE];
+        l0 += a0 < time ? step : 0;
+        l1 += a1 < time ? step : 0;
+        l2 += a2 < time ? step : 0;
+    }
+    auto finish = [&](const float *t, int nr, int lo, int &prev, int &next, float &tp, float &tn) {
+        prev = lo > 0 ? lo - 1 : 0;
+        next = prev + 1 < nr - 1 ? prev + 1 : nr - 1;
+        tp = t[prev * WAVE]; tn = t[next * WAVE];
+        if (lo == nr || (lo == 0 && time < tp)) {                // model.c:1266-1288's wrap, as in pose_gather_keys
+            prev = nr - 1; next = 0;
+            tp = t[prev * WAVE]; tn = t[next * WAVE];
+        }
+    };
+    int p0, q0, p1, q1, p2, q2;
+    float tp0, tn0, tp1, tn1, tp2, tn2;
+    finish(t0, n0, l0, p0, q0, tp0, tn0); finish(t1, n1, l1, p1, q1, tp1, tn1); finish(t2, n2, l2, p2, q2, tp2, tn2);
+    const float4 *v0 = vals + lane, *v1 = v0 + kk * WAVE, *v2 = v1 + kk * WAVE;
+    const float4 ta = v0[p0 * WAVE], tb = v0[q0 * WAVE], ra = v1[p1 * WAVE], rb = v1[q1 * WAVE], sa = v2[p2 * WAVE], sb = v2[q2 * WAVE];
+    k.ta = key3{ ta.x, ta.y, ta.z }; k.tb = key3{ tb.x, tb.y, tb.z };
+    k.ra = key4{ ra.x, ra.y, ra.z, ra.w }; k.rb = key4{ rb.x, rb.y, rb.z, rb.w };
+    k.sa = key3{ sa.x, sa.y, sa.z }; k.sb = key3{ sb.x, sb.y, sb.z };
+    k.f0 = key_fac(time, tp0, tn0);
+    k.f1 = key_fac(time, tp1, tn1);
+    k.f2 = key_fac(time, tp2, tn2);
+    return k;
+}
+
+// PACKED: the key-major pools (times + key counts in LDS at `times`, values at a.pk_vals): no channel records are read
+// in the loop at all -- 48 bytes per lane and character that the channel-major form fetched from L2.
+// bits (1 ^ 3, 2) of the joint index: a bijection of bits (1, 2) for the stores' eight-lane groups and of bits (2, 3) for
+// the reads of ancestors that share their low two bits; 0 for the identity slot (joint 64)
+__device__ __forceinline__ int jump_swz(int j) { return (((j >> 1) ^ (j >> 3)) & 1) | ((j >> 1) & 2); }
+
+template <int CPB, bool PACKED>
+__device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, int *anc_lds, const float *times, const float *kdata,
                                                  const int top, uint4 e0, uint4 e1, uint4 e2, const float4 *jconst,
                                                  const int parent, const int j, const int cib_v)
 {
@@ -276,15 +351,28 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, co
     // v_readlane where joint positions are formed (as a scalar load its 64 bytes were waited for where they were asked for)
     float em_v = with_pos ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
     float tm_next = time_s[c1];
+    // PACKED: per animation 3 * kp rows of 64 key times, then (after all animations' times) 3 rows of 64 key counts
+    const int kp = (int)a.pk_kp, kk = (int)a.pk_k;
+    const uint32_t *nr_lds = reinterpret_cast<const uint32_t *>(times + (size_t)a.n_anims * 3 * kp * WAVE);
+    auto gather_packed = [&](uint32_t an, float tm) {
+        const uint32_t *nr = nr_lds + an * 3 * WAVE + lane;
+        return pose_gather_keys_packed(times + (size_t)an * 3 * kp * WAVE, a.pk_vals + (size_t)an * 3 * kk * WAVE, kp, kk, tm,
+                                       (int)nr[0], (int)nr[WAVE], (int)nr[2 * WAVE], lane);
+    };
+    uint32_t an_next = PACKED ? anim_of(c1) : 0u;
     // the first character's keys (its channel records were requested by the caller) -- waited for HERE, so that no
     // wait for them is left pending into the loop, where it would stand for "all but a few operations" on the way round
-    PoseKeys kv = pose_gather_keys(times, kdata, top, time_s[c0], e0, e1, e2);
-    {
+    PoseKeys kv;
+    if constexpr (PACKED) {
+        kv = gather_packed(anim_of(c0), time_s[c0]);
+        asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x), "v"(em_v));
+    } else {
+        kv = pose_gather_keys(times, kdata, top, time_s[c0], e0, e1, e2);
         const uint4 *tab = a.chan_table + ((size_t)anim_of(c1) * J + jc) * 3;
         e0 = tab[0]; e1 = tab[1]; e2 = tab[2];
+        asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x),
+                            "v"(e0.x), "v"(e1.x), "v"(e2.x), "v"(em_v));
     }
-    asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x),
-                        "v"(e0.x), "v"(e1.x), "v"(e2.x), "v"(em_v));
 
     for (; g < n_groups; g += gridDim.x) {
         const uint32_t c_raw = g * CPB + cib;
@@ -298,16 +386,18 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, co
 
         // ---- 1. this character's T, R, S from its keys
         float T[3], R[4], S[3];
-        T[0] = lerp_ref(kv.ta.x, kv.tb.x, kv.f0); T[1] = lerp_ref(kv.ta.y, kv.tb.y, kv.f0); T[2] = lerp_ref(kv.ta.z, kv.tb.z, kv.f0);
+        const LerpFac lt = lerp_fac(kv.f0), ls = lerp_fac(kv.f2);
+        T[0] = lerp_ref(kv.ta.x, kv.tb.x, lt); T[1] = lerp_ref(kv.ta.y, kv.tb.y, lt); T[2] = lerp_ref(kv.ta.z, kv.tb.z, lt);
         {
             const float qa[4] = { kv.ra.x, kv.ra.y, kv.ra.z, kv.ra.w };
             const float qb[4] = { kv.rb.x, kv.rb.y, kv.rb.z, kv.rb.w };
             slerp_ref(R, qa, qb, kv.f1);
         }
-        S[0] = lerp_ref(kv.sa.x, kv.sb.x, kv.f2); S[1] = lerp_ref(kv.sa.y, kv.sb.y, kv.f2); S[2] = lerp_ref(kv.sa.z, kv.sb.z, kv.f2);
+        S[0] = lerp_ref(kv.sa.x, kv.sb.x, ls); S[1] = lerp_ref(kv.sa.y, kv.sb.y, ls); S[2] = lerp_ref(kv.sa.z, kv.sb.z, ls);
 
         // ---- 2. the next character's key search (LDS) and key gathers, in flight under the hierarchy below
-        kv = pose_gather_keys(times, kdata, top, tm_next, e0, e1, e2);
+        if constexpr (PACKED) kv = gather_packed(an_next, tm_next);
+        else kv = pose_gather_keys(times, kdata, top, tm_next, e0, e1, e2);
 
         // ---- 3. hierarchy by pointer jumping, palette, joint position: as in the general loop
         Row M0, M1, M2;
@@ -322,20 +412,24 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, co
         }
         int anc = parent;
         {
+            // 64-byte slot per joint, its three rows XOR-swizzled by jump_swz(): the 16-byte stores of eight neighbouring
+            // lanes then cover all 32 banks (ds_write_b128 is serviced eight lanes at a time, bank = dword mod 32), and
+            // the 16-byte reads of sixteen different ancestors all 64 (ds_read_b128: dword mod 64).  The ancestor index
+            // travels in its own dword array: in the slot's fourth row its ds_write_b32 hit eight banks with 32 lanes.
             float4 *slots = reinterpret_cast<float4 *>(G);
-            const int sw_me = (j >> 2) & 3;
+            const int sw_me = jump_swz(j);
             for (uint32_t st = 0; st < a.n_jump_steps; st++) {
                 slots[4 * j + (0 ^ sw_me)] = f4_of(M0);
                 slots[4 * j + (1 ^ sw_me)] = f4_of(M1);
                 slots[4 * j + (2 ^ sw_me)] = f4_of(M2);
-                reinterpret_cast<int *>(&slots[4 * j + (3 ^ sw_me)])[0] = anc;
+                anc_lds[j] = anc;
                 wave_lds_fence();
                 const int src = anc >= 0 ? anc : LPC;
-                const int sw = (src >> 2) & 3;
+                const int sw = jump_swz(src);
                 const float4 A0 = slots[4 * src + (0 ^ sw)];
                 const float4 A1 = slots[4 * src + (1 ^ sw)];
                 const float4 A2 = slots[4 * src + (2 ^ sw)];
-                anc = reinterpret_cast<const int *>(&slots[4 * src + (3 ^ sw)])[0];
+                anc = anc_lds[src];
                 wave_lds_fence();
                 const Row B0 = M0, B1 = M1, B2 = M2;
                 M0 = affine_row(A0, B0, B1, B2);
@@ -384,8 +478,10 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, co
                 pos[r] = E_(em, 0, r) * mpos[0] + E_(em, 1, r) * mpos[1] + E_(em, 2, r) * mpos[2] + E_(em, 3, r) * mpos[3];
         }
 
-        // ---- 4. the channel records of the character after next, ahead of the stores
-        {
+        // ---- 4. the channel records of the character after next, ahead of the stores (PACKED: only its animation id)
+        if constexpr (PACKED) {
+            an_next = an2;
+        } else {
             const uint4 *tab = a.chan_table + ((size_t)an2 * J + jc) * 3;
             e0 = tab[0]; e1 = tab[1]; e2 = tab[2];
         }
@@ -435,10 +531,11 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, co
 // persistent (it strides over character groups), so the per-lane binary searches -- five
 // dependent loads per path -- run at LDS latency instead of L2 latency.  Skeleton constants of
 // the lane's joint (invmx, bind column 3, depth, parent) live in registers across characters.
-template <int LPC, int MODE, int BLOCK>
+template <int LPC, int MODE, int BLOCK, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? POSE_WAVES : 1)
 void k_pose(PoseArgs a)
 {
+    static_assert(!PACKED || (LPC == WAVE && MODE == 1), "the key-major pools serve the one-wavefront-per-character loop");
     constexpr int CPB = BLOCK / LPC;
     // joint globals, 4 KiB per wave; once a character's chain is done the same 4 KiB are the
     // wave's staging tile for its coalesced stores
@@ -449,6 +546,7 @@ void k_pose(PoseArgs a)
     __shared__ float times_lds[LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
     constexpr bool STREAM = LPC == WAVE && MODE == 1;            // pose_stream_loop's instantiation
     __shared__ float4 jconst_lds[STREAM ? 5 * WAVE : 1];         // per joint: the four columns of invmx, column 3 of bind
+    __shared__ int anc_lds[STREAM ? CPB : 1][STREAM ? WAVE + 4 : 1];   // the jump rounds' ancestor indices ([WAVE] = -1: the identity slot's)
 
     const int tid = threadIdx.x;
     const int cib = tid / LPC, j = tid % LPC;
@@ -467,6 +565,7 @@ void k_pose(PoseArgs a)
         idn[1] = make_float4(0.f, 1.f, 0.f, 0.f);
         idn[2] = make_float4(0.f, 0.f, 1.f, 0.f);
         idn[3] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+        if (STREAM) anc_lds[cib][WAVE] = -1;
     }
     // first step of the key searches: the highest set bit of the model's longest channel (block-uniform)
     __shared__ uint32_t nr_or, not_streamable;
@@ -482,7 +581,11 @@ void k_pose(PoseArgs a)
         if (m) atomicOr(&nr_or, m);
         if (bad || (lane_joint && !reachable)) atomicOr(&not_streamable, 1u);
     }
-    if (LDS_TIMES) {
+    if (PACKED) {                                                // key-major times of every animation, then the key counts
+        const uint32_t nt = a.n_anims * 3u * a.pk_kp * WAVE + a.n_anims * 3u * WAVE;
+        for (uint32_t q = tid; q < nt; q += blockDim.x)
+            times_lds[q] = a.pk_times[q];
+    } else if (LDS_TIMES) {
         for (uint32_t q = tid; q < a.n_times; q += blockDim.x)
             times_lds[q] = a.times[q];
     }
@@ -493,7 +596,9 @@ void k_pose(PoseArgs a)
         jconst_lds[4 * WAVE + tid] = a.bind[4 * jq + 3];
     }
     __syncthreads();
-    const float *times = LDS_TIMES ? times_lds : a.times;
+    // PACKED: the general loop below (taken when the skeleton is not streamable after all) searches the channel-major
+    // times in memory; LDS holds the key-major copy
+    const float *times = PACKED ? a.times : LDS_TIMES ? times_lds : a.times;
     const float *kdata = a.data;
     const int top = nr_or ? 1 << (31 - __clz((int)nr_or)) : 0;
 
@@ -537,7 +642,8 @@ void k_pose(PoseArgs a)
         // share nothing but the key times; there is no block barrier past this point.)
         const uint64_t out_bytes = (uint64_t)a.n_chars * J * 64u;
         if (!not_streamable && out_bytes < (1ull << 31)) {
-            pose_stream_loop<CPB>(a, G, times, kdata, top, cur.e0, cur.e1, cur.e2, jconst_lds, lane_joint ? parent : -1, j, cib);
+            pose_stream_loop<CPB, PACKED>(a, G, anc_lds[cib < CPB ? cib : 0], PACKED ? times_lds : times, kdata, top, cur.e0,
+                                          cur.e1, cur.e2, jconst_lds, lane_joint ? parent : -1, j, cib);
             return;
         }
     }
@@ -569,7 +675,8 @@ void k_pose(PoseArgs a)
                 const float fac = key_fac(time, t[p], t[q]);
                 const float *d = kdata + e0.y;
                 const key3 ka = *reinterpret_cast<const key3 *>(d + 3 * p), kb = *reinterpret_cast<const key3 *>(d + 3 * q);
-                T[0] = lerp_ref(ka.x, kb.x, fac); T[1] = lerp_ref(ka.y, kb.y, fac); T[2] = lerp_ref(ka.z, kb.z, fac);
+                const LerpFac lf = lerp_fac(fac);
+                T[0] = lerp_ref(ka.x, kb.x, lf); T[1] = lerp_ref(ka.y, kb.y, lf); T[2] = lerp_ref(ka.z, kb.z, lf);
             }
             if (n1 > 0) {
                 int p, q;
@@ -589,7 +696,8 @@ void k_pose(PoseArgs a)
                 const float fac = key_fac(time, t[p], t[q]);
                 const float *d = kdata + e2.y;
                 const key3 ka = *reinterpret_cast<const key3 *>(d + 3 * p), kb = *reinterpret_cast<const key3 *>(d + 3 * q);
-                S[0] = lerp_ref(ka.x, kb.x, fac); S[1] = lerp_ref(ka.y, kb.y, fac); S[2] = lerp_ref(ka.z, kb.z, fac);
+                const LerpFac lf = lerp_fac(fac);
+                S[0] = lerp_ref(ka.x, kb.x, lf); S[1] = lerp_ref(ka.y, kb.y, lf); S[2] = lerp_ref(ka.z, kb.z, lf);
             }
         }
 
@@ -724,6 +832,32 @@ void k_pose(PoseArgs a)
     }
 }
 
+// ---- key-major pools for the one-wavefront-per-character loop (clapgpu_animations_pack): once per model --------------
+// layout of `packed`: times [n_anims][3][kp][64] f32 (+INF past a channel's last key) | key counts [n_anims][3][64] u32 |
+// (16-byte aligned) values [n_anims][3][k][64] float4.  Lanes past the last joint repeat the last joint's channels, as
+// the loop's clamped joint index does.
+__global__ __launch_bounds__(256)
+void k_pose_pack(const uint4 *chan_table, const float *times, const float *data, uint32_t n_anims, uint32_t J, uint32_t kk,
+                 uint32_t kp, float *o_times, uint32_t *o_nr, float4 *o_vals)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;           // ((a * 3 + p) * kp + k) * 64 + lane
+    const uint32_t lane = q & 63u, k = (q >> 6) % kp, ap = (q >> 6) / kp;
+    if (ap >= n_anims * 3u) return;
+    const uint32_t an = ap / 3u, p = ap % 3u, j = lane < J ? lane : J - 1;
+    const uint4 e = chan_table[((size_t)an * J + j) * 3 + p];
+    const int nr = (int)e.z > 0 ? (int)e.z : 0;
+    o_times[q] = (int)k < nr ? times[e.x + k] : __builtin_inff();
+    if (k == 0) o_nr[ap * 64 + lane] = (uint32_t)nr;
+    if (k < kk) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)k < nr) {
+            const float *d = data + e.y + (p == 1 ? 4u : 3u) * k;
+            v = make_float4(d[0], d[1], d[2], p == 1 ? d[3] : 0.f);
+        }
+        o_vals[((size_t)ap * kk + k) * 64 + lane] = v;
+    }
+}
+
 // animated_update's clock (model.c:1563-1592): one lane per character
 __global__ __launch_bounds__(256)
 void k_animation_time(clapgpu_anim_clock k, double now, const double *now_dev)
@@ -773,6 +907,47 @@ static int animation_time_launch(void *stream, const clapgpu_anim_clock *clk, do
     return CLAPGPU_OK;
 }
 
+static uint32_t pack_kp(uint32_t max_keys)
+{
+    uint32_t kp = 2;
+    while (kp <= max_keys) kp <<= 1;                              // a power of two STRICTLY above the longest channel
+    return kp;
+}
+
+static size_t pack_vals_offset(uint32_t n_anims, uint32_t kp)
+{
+    const size_t head = ((size_t)n_anims * 3 * kp * 64 + (size_t)n_anims * 3 * 64) * 4;
+    return (head + 15) & ~(size_t)15;
+}
+
+extern "C" size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys)
+{
+    if (!n_anims || !max_keys) return 0;
+    return pack_vals_offset(n_anims, pack_kp(max_keys)) + (size_t)n_anims * 3 * max_keys * 64 * 16;
+}
+
+extern "C" int clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint32_t nr_joints, uint32_t max_keys,
+                                       void *packed)
+{
+    if (!an || !packed || !an->chan_table || !an->times || !an->data || !an->n_anims || !max_keys)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (nr_joints == 0 || nr_joints > 64)                        // one wavefront per character: the loop the pools are for
+        return CLAPGPU_ERR_NOT_SUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(packed) & 15u) != 0)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t kp = pack_kp(max_keys);
+    char *base = static_cast<char *>(packed);
+    float *o_times = reinterpret_cast<float *>(base);
+    uint32_t *o_nr = reinterpret_cast<uint32_t *>(o_times + (size_t)an->n_anims * 3 * kp * 64);
+    float4 *o_vals = reinterpret_cast<float4 *>(base + pack_vals_offset(an->n_anims, kp));
+    const uint32_t total = an->n_anims * 3u * kp * 64u;
+    hipLaunchKernelGGL(k_pose_pack, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const uint4 *>(an->chan_table), an->times, an->data, an->n_anims, nr_joints, max_keys, kp,
+                       o_times, o_nr, o_vals);
+    CLAPGPU_LAUNCH_CHECK("k_pose_pack");
+    return CLAPGPU_OK;
+}
+
 extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,
                                    const clapgpu_pose_batch *pb)
 {
@@ -816,6 +991,18 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
 
     const uint32_t lpc = (sk->nr_joints + 63) / 64 * 64;
     const bool lds_times = an->n_times > 0 && an->n_times <= (uint32_t)POSE_TIMES_LDS_MAX;
+    // the key-major pools, if the caller made them (clapgpu_animations_pack) and every animation's rows fit in LDS
+    a.pk_times = nullptr; a.pk_vals = nullptr; a.pk_k = a.pk_kp = 0;
+    bool packed = false;
+    if (an->packed && an->packed_keys && lpc == 64) {
+        const uint32_t kp = pack_kp(an->packed_keys);
+        if ((uint64_t)a.n_anims * (3u * kp * 64u + 192u) <= (uint64_t)POSE_TIMES_LDS_MAX) {
+            packed = true;
+            a.pk_times = static_cast<const float *>(an->packed);
+            a.pk_vals = reinterpret_cast<const float4 *>(static_cast<const char *>(an->packed) + pack_vals_offset(a.n_anims, kp));
+            a.pk_k = an->packed_keys; a.pk_kp = kp;
+        }
+    }
     hipStream_t s = as_stream(stream);
     static thread_local int n_cus = 0;
     if (!n_cus) {
@@ -825,7 +1012,16 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
         CLAPGPU_HIP(hipGetDeviceProperties(&prop, dev));
         n_cus = prop.multiProcessorCount;
     }
-    if (lds_times) {
+    if (packed) {
+        const uint32_t n_groups = (pb->n_chars + 3) / 4;
+        static thread_local uint32_t res_packed = 0;
+        if (!res_packed) {
+            int per_cu = 0;
+            CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pose<64, 1, 256, true>, 256, 0));
+            res_packed = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
+        }
+        hipLaunchKernelGGL((k_pose<64, 1, 256, true>), dim3(n_groups < res_packed ? n_groups : res_packed), dim3(256), 0, s, a);
+    } else if (lds_times) {
         // persistent blocks (24 KiB key times + 16 KiB joint globals each): exactly as many as are
         // resident at once, so no block waits for a slot while the others hold their LDS copy
         const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
