@@ -33,7 +33,7 @@ struct ga_model {
     model3d             *model;
     uint32_t            J, n_anims;
     int32_t             *depth_host;                      /* < 0: not under joint 0, never written (model.c:1583) */
-    void                *d_parent, *d_depth, *d_root_pose, *d_invmx, *d_bind, *d_chan_table, *d_times, *d_data;
+    void                *d_parent, *d_depth, *d_root_pose, *d_invmx, *d_bind, *d_chan_table, *d_times, *d_data, *d_packed;
     clapgpu_skeleton    sk;
     clapgpu_animations  an;
     /* the model's animated entities this frame, list order */
@@ -79,7 +79,7 @@ void gpu_anim_done(struct gpu_anim *ga)
     if (!ga) return;
     for (uint32_t k = 0; k < ga->n_models; k++) {
         struct ga_model *m = &ga->models[k];
-        void *dev[] = { m->d_parent, m->d_depth, m->d_root_pose, m->d_invmx, m->d_bind, m->d_chan_table, m->d_times, m->d_data };
+        void *dev[] = { m->d_parent, m->d_depth, m->d_root_pose, m->d_invmx, m->d_bind, m->d_chan_table, m->d_times, m->d_data, m->d_packed };
         for (unsigned i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
             if (dev[i]) clapgpu_free(dev[i]);
         ga_free_batch(m);
@@ -158,6 +158,9 @@ static int ga_model_build(struct ga_model *m, model3d *model)
     GA_CK(clapgpu_malloc(&m->d_chan_table, tb));         GA_CK(clapgpu_memcpy_h2d(m->d_chan_table, table, tb, NULL));
     GA_CK(clapgpu_malloc(&m->d_times, (t_at ? t_at : 1) * 4)); GA_CK(clapgpu_memcpy_h2d(m->d_times, times, t_at * 4, NULL));
     GA_CK(clapgpu_malloc(&m->d_data, (d_at ? d_at : 1) * 4));  GA_CK(clapgpu_memcpy_h2d(m->d_data, data, d_at * 4, NULL));
+    uint32_t max_keys = 0;
+    for (size_t q = 0; q < (size_t)(A ? A : 1) * J * 3; q++)
+        if (table[4 * q + 2] > max_keys) max_keys = table[4 * q + 2];
     GA_CK(clapgpu_stream_sync(NULL));
     m->depth_host = depth;
     free(parent); free(invmx); free(bind); free(table); free(times); free(data);
@@ -166,6 +169,15 @@ static int ga_model_build(struct ga_model *m, model3d *model)
                                 .root_pose = m->d_root_pose, .invmx = m->d_invmx, .bind = m->d_bind };
     m->an = (clapgpu_animations){ .n_anims = A, .n_times = (uint32_t)t_at, .chan_table = m->d_chan_table,
                                   .times = m->d_times, .data = m->d_data };
+    if (J <= 64 && A && max_keys) {
+        /* the key-major copy of the pools, once per model: the one-wavefront-per-character loop's searches then run
+         * without LDS bank conflicts and its key gathers are contiguous rows (clapgpu.h: clapgpu_animations_pack) */
+        GA_CK(clapgpu_malloc(&m->d_packed, clapgpu_animations_packed_bytes(A, max_keys)));
+        GA_CK(clapgpu_animations_pack(NULL, &m->an, J, max_keys, m->d_packed));
+        GA_CK(clapgpu_stream_sync(NULL));
+        m->an.packed = m->d_packed;
+        m->an.packed_keys = max_keys;
+    }
     return 0;
 }
 
