@@ -362,7 +362,10 @@ def extras(device, testbed=True):
     t_pose = time_launches(cb.pose_update, 200, warmup=100)
     t_skin = time_launches(cb.skin, 200, warmup=100)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
-                           "kernel": "k_pose<64>", "launches_timed": 200, "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<")}
+                           "kernel": "k_pose<64, 1, 256, true> (key-major pools)", "launches_timed": 200,
+                           "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<"),
+                           "note": "frac prices SURVEY 8d's 200 B/joint, of which 80 B are keyframes that are per MODEL and "
+                                   "come from LDS / L2: moved_frac (PMC bytes / this run's time / 8 TB/s) is the HBM utilisation"}
     # what a frame whose skinning runs on the device needs from the pose: the palette alone.  The joints' T/R/S and
     # world positions (56 B of the 120 B a joint writes) are host-visible state of animated_update; a caller that does
     # not read them back switches them off (clapgpu_pose_batch.skip)
@@ -537,9 +540,12 @@ def full_frame(device):
     except Exception as exc:                                 # informational leg: never fail the benchmark on it
         print(f"[bench] frame graph capture failed: {exc}", file=sys.stderr)
     return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t, "ms_per_frame_graph_replay": graph_ms,
+            "label": "physics WITHOUT contact response: not a whole clap_frame()",
             "contents": "1M entities (depth 8) + 50k characters x 64 joints + 10M skinned vertices + 262144 bodies "
-                        "(75k bound to entities; 2 broadphase passes, contacts, integrate) + 4M particles + 128 lights "
-                        "on a 4K light grid; one physics substep per frame",
+                        "(75k bound to entities; 2 broadphase passes, contact generation, integrate) + 4M particles + 128 "
+                        "lights on a 4K light grid; one physics substep per frame.  The bodies are integrated as "
+                        "constraint-free: the contact pairs the same frame generates are handed to nobody -- the SOR-LCP "
+                        "that would apply them is ODE's dWorldQuickStep (physics.c:769), outside this path's scope",
             "launches": "one stream, no host read-back inside the frame"}
 
 

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 OK = 0
 ERR_NOMEM = -1
@@ -205,7 +205,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "clapgpu_animation_time": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_double]),
     "clapgpu_animation_time_dev": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_void_p]),
-    "clapgpu_animations_packed_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "clapgpu_animations_packed_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "clapgpu_animations_pack": (C.c_int, [C.c_void_p, C.POINTER(Animations), C.c_uint32, C.c_uint32, C.c_void_p]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),

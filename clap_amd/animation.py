@@ -101,11 +101,11 @@ class SkinnedModel:
         self.anim_desc = _lib.Animations(len(anims), int(ct["times"].shape[0]), _ptr(self._ct["chan_table"]),
                                          _ptr(self._ct["times"]),
                                          _ptr(self._ct["data"]), None, 0, 0)
-        # the key-major copy of the pools (clapgpu_animations_pack): once per model, for skeletons of <= 64 joints
+        # the key-major copy of the pools (clapgpu_animations_pack): once per model
         self.packed = None
         max_keys = int(ct["chan_table"][..., 2].max()) if len(anims) else 0
-        if pack and J <= 64 and max_keys > 0:
-            nbytes = int(_lib.lib().clapgpu_animations_packed_bytes(len(anims), max_keys))
+        if pack and J <= 256 and max_keys > 0:
+            nbytes = int(_lib.lib().clapgpu_animations_packed_bytes(len(anims), max_keys, J))
             self.packed = torch.zeros((nbytes + 15) // 16 * 4, dtype=torch.float32, device=dev)
             _lib.check(_lib.lib().clapgpu_animations_pack(_stream(), C.byref(self.anim_desc), J, max_keys, _ptr(self.packed)),
                        "clapgpu_animations_pack")

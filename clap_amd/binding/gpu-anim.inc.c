@@ -169,10 +169,10 @@ static int ga_model_build(struct ga_model *m, model3d *model)
                                 .root_pose = m->d_root_pose, .invmx = m->d_invmx, .bind = m->d_bind };
     m->an = (clapgpu_animations){ .n_anims = A, .n_times = (uint32_t)t_at, .chan_table = m->d_chan_table,
                                   .times = m->d_times, .data = m->d_data };
-    if (J <= 64 && A && max_keys) {
+    if (J <= 256 && A && max_keys) {
         /* the key-major copy of the pools, once per model: the one-wavefront-per-character loop's searches then run
          * without LDS bank conflicts and its key gathers are contiguous rows (clapgpu.h: clapgpu_animations_pack) */
-        GA_CK(clapgpu_malloc(&m->d_packed, clapgpu_animations_packed_bytes(A, max_keys)));
+        GA_CK(clapgpu_malloc(&m->d_packed, clapgpu_animations_packed_bytes(A, max_keys, J)));
         GA_CK(clapgpu_animations_pack(NULL, &m->an, J, max_keys, m->d_packed));
         GA_CK(clapgpu_stream_sync(NULL));
         m->an.packed = m->d_packed;

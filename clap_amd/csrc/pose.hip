@@ -279,15 +279,17 @@ __device__ __forceinline__ PoseKeys pose_gather_keys(const float *times, const f
 //   * values in memory as float4 [path][row][64]: lanes whose brackets are the same key -- all of them when the channels
 //     share their key times, as exported glTF samplers do -- read ONE contiguous 1 KiB row instead of 64 scattered 12-byte
 //     pieces 360 bytes apart.
+template <int LPC>
 __device__ __forceinline__ PoseKeys pose_gather_keys_packed(const float *tl, const float4 *vals, const int kp, const int kk,
                                                             const float time, const int n0, const int n1, const int n2,
                                                             const int lane)
 {
+    constexpr int COLS = LPC;                                    // a row holds one key of every joint: LPC columns (64 per wavefront)
     PoseKeys k;
-    const float *t0 = tl + lane, *t1 = t0 + kp * WAVE, *t2 = t1 + kp * WAVE;
+    const float *t0 = tl + lane, *t1 = t0 + kp * COLS, *t2 = t1 + kp * COLS;
     int l0 = 0, l1 = 0, l2 = 0;
     for (int step = kp >> 1; step > 0; step >>= 1) {
-        const float a0 = t0[(l0 + step - 1) * WAVE], a1 = t1[(l1 + step - 1) * WAVE], a2 = t2[(l2 + step - 1) * WAVE];
+        const float a0 = t0[(l0 + step - 1) * COLS], a1 = t1[(l1 + step - 1) * COLS], a2 = t2[(l2 + step - 1) * COLS];
         l0 += a0 < time ? step : 0;
         l1 += a1 < time ? step : 0;
         l2 += a2 < time ? step : 0;
@@ -295,17 +297,17 @@ __device__ __forceinline__ PoseKeys pose_gather_keys_packed(const float *tl, con
     auto finish = [&](const float *t, int nr, int lo, int &prev, int &next, float &tp, float &tn) {
         prev = lo > 0 ? lo - 1 : 0;
         next = prev + 1 < nr - 1 ? prev + 1 : nr - 1;
-        tp = t[prev * WAVE]; tn = t[next * WAVE];
+        tp = t[prev * COLS]; tn = t[next * COLS];
         if (lo == nr || (lo == 0 && time < tp)) {                // model.c:1266-1288's wrap, as in pose_gather_keys
             prev = nr - 1; next = 0;
-            tp = t[prev * WAVE]; tn = t[next * WAVE];
+            tp = t[prev * COLS]; tn = t[next * COLS];
         }
     };
     int p0, q0, p1, q1, p2, q2;
     float tp0, tn0, tp1, tn1, tp2, tn2;
     finish(t0, n0, l0, p0, q0, tp0, tn0); finish(t1, n1, l1, p1, q1, tp1, tn1); finish(t2, n2, l2, p2, q2, tp2, tn2);
-    const float4 *v0 = vals + lane, *v1 = v0 + kk * WAVE, *v2 = v1 + kk * WAVE;
-    const float4 ta = v0[p0 * WAVE], tb = v0[q0 * WAVE], ra = v1[p1 * WAVE], rb = v1[q1 * WAVE], sa = v2[p2 * WAVE], sb = v2[q2 * WAVE];
+    const float4 *v0 = vals + lane, *v1 = v0 + kk * COLS, *v2 = v1 + kk * COLS;
+    const float4 ta = v0[p0 * COLS], tb = v0[q0 * COLS], ra = v1[p1 * COLS], rb = v1[q1 * COLS], sa = v2[p2 * COLS], sb = v2[q2 * COLS];
     k.ta = key3{ ta.x, ta.y, ta.z }; k.tb = key3{ tb.x, tb.y, tb.z };
     k.ra = key4{ ra.x, ra.y, ra.z, ra.w }; k.rb = key4{ rb.x, rb.y, rb.z, rb.w };
     k.sa = key3{ sa.x, sa.y, sa.z }; k.sb = key3{ sb.x, sb.y, sb.z };
@@ -321,13 +323,23 @@ __device__ __forceinline__ PoseKeys pose_gather_keys_packed(const float *tl, con
 // the reads of ancestors that share their low two bits; 0 for the identity slot (joint 64)
 __device__ __forceinline__ int jump_swz(int j) { return (((j >> 1) ^ (j >> 3)) & 1) | ((j >> 1) & 2); }
 
-template <int CPB, bool PACKED>
+// LDS hand-over between the wavefronts of one character (skeletons of more than 64 joints: 2-4 wavefronts each): the LDS
+// counter only -- __syncthreads() would also wait for the wavefront's global stores, the very wait this loop exists to avoid
+template <int LPC>
+__device__ __forceinline__ void pose_lds_sync()
+{
+    if (LPC == WAVE) wave_lds_fence();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int LPC, int CPB, bool PACKED>
 __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, int *anc_lds, const float *times, const float *kdata,
                                                  const int top, uint4 e0, uint4 e1, uint4 e2, const float4 *jconst,
                                                  const int parent, const int j, const int cib_v)
 {
-    constexpr int LPC = WAVE;
-    const int lane = j;
+    static_assert(LPC == WAVE || PACKED, "more than one wavefront per character: key-major pools only");
+    const int lane = j & (WAVE - 1);                             // lane of the wavefront; j = the joint (column of the pools)
+    const int row_j0 = j - lane;                                 // first joint of this wavefront's 64-joint row
     const uint32_t J = a.J;
     const uint32_t cib = (uint32_t)__builtin_amdgcn_readfirstlane(cib_v);
     const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
@@ -351,13 +363,13 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, in
     // v_readlane where joint positions are formed (as a scalar load its 64 bytes were waited for where they were asked for)
     float em_v = with_pos ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
     float tm_next = time_s[c1];
-    // PACKED: per animation 3 * kp rows of 64 key times, then (after all animations' times) 3 rows of 64 key counts
+    // PACKED: per animation 3 * kp rows of LPC key times, then (after all animations' times) 3 rows of LPC key counts
     const int kp = (int)a.pk_kp, kk = (int)a.pk_k;
-    const uint32_t *nr_lds = reinterpret_cast<const uint32_t *>(times + (size_t)a.n_anims * 3 * kp * WAVE);
+    const uint32_t *nr_lds = reinterpret_cast<const uint32_t *>(times + (size_t)a.n_anims * 3 * kp * LPC);
     auto gather_packed = [&](uint32_t an, float tm) {
-        const uint32_t *nr = nr_lds + an * 3 * WAVE + lane;
-        return pose_gather_keys_packed(times + (size_t)an * 3 * kp * WAVE, a.pk_vals + (size_t)an * 3 * kk * WAVE, kp, kk, tm,
-                                       (int)nr[0], (int)nr[WAVE], (int)nr[2 * WAVE], lane);
+        const uint32_t *nr = nr_lds + an * 3 * LPC + j;
+        return pose_gather_keys_packed<LPC>(times + (size_t)an * 3 * kp * LPC, a.pk_vals + (size_t)an * 3 * kk * LPC, kp, kk, tm,
+                                            (int)nr[0], (int)nr[LPC], (int)nr[2 * LPC], j);
     };
     uint32_t an_next = PACKED ? anim_of(c1) : 0u;
     // the first character's keys (its channel records were requested by the caller) -- waited for HERE, so that no
@@ -423,14 +435,14 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, in
                 slots[4 * j + (1 ^ sw_me)] = f4_of(M1);
                 slots[4 * j + (2 ^ sw_me)] = f4_of(M2);
                 anc_lds[j] = anc;
-                wave_lds_fence();
+                pose_lds_sync<LPC>();
                 const int src = anc >= 0 ? anc : LPC;
                 const int sw = jump_swz(src);
                 const float4 A0 = slots[4 * src + (0 ^ sw)];
                 const float4 A1 = slots[4 * src + (1 ^ sw)];
                 const float4 A2 = slots[4 * src + (2 ^ sw)];
                 anc = anc_lds[src];
-                wave_lds_fence();
+                pose_lds_sync<LPC>();
                 const Row B0 = M0, B1 = M1, B2 = M2;
                 M0 = affine_row(A0, B0, B1, B2);
                 M1 = affine_row(A1, B0, B1, B2);
@@ -454,13 +466,13 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, in
         float JT[16], pos[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
-            const float4 im = jconst[cc * WAVE + j];             // column cc of invmx
+            const float4 im = jconst[cc * LPC + j];              // column cc of invmx
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 E_(JT, cc, r) = E_(Gm, 0, r) * im.x + E_(Gm, 1, r) * im.y + E_(Gm, 2, r) * im.z + E_(Gm, 3, r) * im.w;
         }
         if (with_pos) {                                          // uniform
-            const float4 b3 = jconst[4 * WAVE + j];
+            const float4 b3 = jconst[4 * LPC + j];
             const float bv[4] = { b3.x, b3.y, b3.z, b3.w };
             float mpos[4];
 #pragma unroll
@@ -488,12 +500,15 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, in
         if (with_pos) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
         tm_next = tm_next2;
 
-        // ---- 5. stores: all lanes, no branch; the descriptors clip
-        const size_t row0 = (size_t)c * J;
-        const __amdgpu_buffer_rsrc_t rs_trs = __builtin_amdgcn_make_buffer_rsrc(a.trs + 10 * row0, 0, (c_ok && with_trs) ? (int)(J * 40u) : 0, POSE_RSRC_FLAGS);
-        const __amdgpu_buffer_rsrc_t rs_jt = __builtin_amdgcn_make_buffer_rsrc(a.joint_transforms + 16 * row0, 0, c_ok ? (int)(J * 64u) : 0, POSE_RSRC_FLAGS);
-        const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc(a.joint_pos ? a.joint_pos + 4 * row0 : a.joint_transforms, 0, (c_ok && with_pos) ? (int)(J * 16u) : 0, POSE_RSRC_FLAGS);
-        float *tile_f = G;
+        // ---- 5. stores: all lanes, no branch; the descriptors clip (each wavefront's own: its 64-joint row of the character)
+        const uint32_t rj0 = (uint32_t)__builtin_amdgcn_readfirstlane(row_j0);
+        const uint32_t nrow = c_ok && J > rj0 ? (J - rj0 < (uint32_t)WAVE ? J - rj0 : (uint32_t)WAVE) : 0u;
+        const size_t row0 = (size_t)c * J + rj0;
+        const __amdgpu_buffer_rsrc_t rs_trs = __builtin_amdgcn_make_buffer_rsrc(a.trs + 10 * row0, 0, with_trs ? (int)(nrow * 40u) : 0, POSE_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs_jt = __builtin_amdgcn_make_buffer_rsrc(a.joint_transforms + 16 * row0, 0, (int)(nrow * 64u), POSE_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc(a.joint_pos ? a.joint_pos + 4 * row0 : a.joint_transforms, 0, with_pos ? (int)(nrow * 16u) : 0, POSE_RSRC_FLAGS);
+        // this wavefront's 64-joint row of the character: its own 4 KiB of the character's slots as the staging tile
+        float *tile_f = G + row_j0 * G_STRIDE;
         float4 *tile = reinterpret_cast<float4 *>(tile_f);
         {
             const float trs_row[10] = { T[0], T[1], T[2], R[0], R[1], R[2], R[3], S[0], S[1], S[2] };
@@ -535,7 +550,7 @@ template <int LPC, int MODE, int BLOCK, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? POSE_WAVES : 1)
 void k_pose(PoseArgs a)
 {
-    static_assert(!PACKED || (LPC == WAVE && MODE == 1), "the key-major pools serve the one-wavefront-per-character loop");
+    static_assert(!PACKED || MODE == 1, "the key-major pools are staged in LDS");
     constexpr int CPB = BLOCK / LPC;
     // joint globals, 4 KiB per wave; once a character's chain is done the same 4 KiB are the
     // wave's staging tile for its coalesced stores
@@ -543,10 +558,11 @@ void k_pose(PoseArgs a)
     // its path keeps multiplying by it, so the jump rounds below have no divergent branch
     __shared__ __attribute__((aligned(16))) float g_lds[CPB][(LPC + 1) * G_STRIDE];
     constexpr bool LDS_TIMES = MODE >= 1;
-    __shared__ float times_lds[LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
-    constexpr bool STREAM = LPC == WAVE && MODE == 1;            // pose_stream_loop's instantiation
-    __shared__ float4 jconst_lds[STREAM ? 5 * WAVE : 1];         // per joint: the four columns of invmx, column 3 of bind
-    __shared__ int anc_lds[STREAM ? CPB : 1][STREAM ? WAVE + 4 : 1];   // the jump rounds' ancestor indices ([WAVE] = -1: the identity slot's)
+    // key-major pools: LPC columns per key row, so the budget grows with the wavefronts per character
+    __shared__ float times_lds[PACKED ? POSE_TIMES_LDS_MAX * (LPC / WAVE) : LDS_TIMES ? POSE_TIMES_LDS_MAX : 4];
+    constexpr bool STREAM = MODE == 1 && (LPC == WAVE || PACKED);   // pose_stream_loop's instantiations
+    __shared__ float4 jconst_lds[STREAM ? 5 * LPC : 1];          // per joint: the four columns of invmx, column 3 of bind
+    __shared__ int anc_lds[STREAM ? CPB : 1][STREAM ? LPC + 4 : 1];    // the jump rounds' ancestor indices ([LPC] = -1: the identity slot's)
 
     const int tid = threadIdx.x;
     const int cib = tid / LPC, j = tid % LPC;
@@ -565,7 +581,7 @@ void k_pose(PoseArgs a)
         idn[1] = make_float4(0.f, 1.f, 0.f, 0.f);
         idn[2] = make_float4(0.f, 0.f, 1.f, 0.f);
         idn[3] = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
-        if (STREAM) anc_lds[cib][WAVE] = -1;
+        if constexpr (STREAM) anc_lds[cib][LPC] = -1;
     }
     // first step of the key searches: the highest set bit of the model's longest channel (block-uniform)
     __shared__ uint32_t nr_or, not_streamable;
@@ -582,18 +598,18 @@ void k_pose(PoseArgs a)
         if (bad || (lane_joint && !reachable)) atomicOr(&not_streamable, 1u);
     }
     if (PACKED) {                                                // key-major times of every animation, then the key counts
-        const uint32_t nt = a.n_anims * 3u * a.pk_kp * WAVE + a.n_anims * 3u * WAVE;
+        const uint32_t nt = a.n_anims * 3u * a.pk_kp * LPC + a.n_anims * 3u * LPC;
         for (uint32_t q = tid; q < nt; q += blockDim.x)
             times_lds[q] = a.pk_times[q];
     } else if (LDS_TIMES) {
         for (uint32_t q = tid; q < a.n_times; q += blockDim.x)
             times_lds[q] = a.times[q];
     }
-    if (STREAM && tid < WAVE) {
+    if (STREAM && tid < LPC) {
         const uint32_t jq = (uint32_t)tid < J ? (uint32_t)tid : J - 1;
 #pragma unroll
-        for (int q = 0; q < 4; q++) jconst_lds[q * WAVE + tid] = a.invmx[4 * jq + q];
-        jconst_lds[4 * WAVE + tid] = a.bind[4 * jq + 3];
+        for (int q = 0; q < 4; q++) jconst_lds[q * LPC + tid] = a.invmx[4 * jq + q];
+        jconst_lds[4 * LPC + tid] = a.bind[4 * jq + 3];
     }
     __syncthreads();
     // PACKED: the general loop below (taken when the skeleton is not streamable after all) searches the channel-major
@@ -636,14 +652,14 @@ void k_pose(PoseArgs a)
         bv[0] = b3.x; bv[1] = b3.y; bv[2] = b3.z; bv[3] = b3.w;
     }
 
-    if constexpr (LPC == WAVE && MODE == 1) {
+    if constexpr (STREAM) {
         // One wavefront per character, every joint animated on all three paths and under joint 0, outputs within
         // 2 GB: the loop below, in which the wavefront never waits for its own stores.  (A block's four wavefronts
         // share nothing but the key times; there is no block barrier past this point.)
         const uint64_t out_bytes = (uint64_t)a.n_chars * J * 64u;
         if (!not_streamable && out_bytes < (1ull << 31)) {
-            pose_stream_loop<CPB, PACKED>(a, G, anc_lds[cib < CPB ? cib : 0], PACKED ? times_lds : times, kdata, top, cur.e0,
-                                          cur.e1, cur.e2, jconst_lds, lane_joint ? parent : -1, j, cib);
+            pose_stream_loop<LPC, CPB, PACKED>(a, G, anc_lds[cib < CPB ? cib : 0], PACKED ? times_lds : times, kdata, top, cur.e0,
+                                               cur.e1, cur.e2, jconst_lds, lane_joint ? parent : -1, j, cib);
             return;
         }
     }
@@ -833,28 +849,28 @@ void k_pose(PoseArgs a)
 }
 
 // ---- key-major pools for the one-wavefront-per-character loop (clapgpu_animations_pack): once per model --------------
-// layout of `packed`: times [n_anims][3][kp][64] f32 (+INF past a channel's last key) | key counts [n_anims][3][64] u32 |
-// (16-byte aligned) values [n_anims][3][k][64] float4.  Lanes past the last joint repeat the last joint's channels, as
-// the loop's clamped joint index does.
+// layout of `packed`: times [n_anims][3][kp][L] f32 (+INF past a channel's last key) | key counts [n_anims][3][L] u32 |
+// (16-byte aligned) values [n_anims][3][k][L] float4, L = the joints rounded up to whole wavefronts (64, 128, 192, 256).
+// Columns past the last joint repeat the last joint's channels, as the loop's clamped joint index does.
 __global__ __launch_bounds__(256)
 void k_pose_pack(const uint4 *chan_table, const float *times, const float *data, uint32_t n_anims, uint32_t J, uint32_t kk,
-                 uint32_t kp, float *o_times, uint32_t *o_nr, float4 *o_vals)
+                 uint32_t kp, uint32_t lanes, float *o_times, uint32_t *o_nr, float4 *o_vals)
 {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;           // ((a * 3 + p) * kp + k) * 64 + lane
-    const uint32_t lane = q & 63u, k = (q >> 6) % kp, ap = (q >> 6) / kp;
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;           // ((a * 3 + p) * kp + k) * lanes + lane
+    const uint32_t lane = q % lanes, k = (q / lanes) % kp, ap = (q / lanes) / kp;
     if (ap >= n_anims * 3u) return;
     const uint32_t an = ap / 3u, p = ap % 3u, j = lane < J ? lane : J - 1;
     const uint4 e = chan_table[((size_t)an * J + j) * 3 + p];
     const int nr = (int)e.z > 0 ? (int)e.z : 0;
     o_times[q] = (int)k < nr ? times[e.x + k] : __builtin_inff();
-    if (k == 0) o_nr[ap * 64 + lane] = (uint32_t)nr;
+    if (k == 0) o_nr[ap * lanes + lane] = (uint32_t)nr;
     if (k < kk) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((int)k < nr) {
             const float *d = data + e.y + (p == 1 ? 4u : 3u) * k;
             v = make_float4(d[0], d[1], d[2], p == 1 ? d[3] : 0.f);
         }
-        o_vals[((size_t)ap * kk + k) * 64 + lane] = v;
+        o_vals[((size_t)ap * kk + k) * lanes + lane] = v;
     }
 }
 
@@ -914,16 +930,17 @@ static uint32_t pack_kp(uint32_t max_keys)
     return kp;
 }
 
-static size_t pack_vals_offset(uint32_t n_anims, uint32_t kp)
+static size_t pack_vals_offset(uint32_t n_anims, uint32_t kp, uint32_t lanes)
 {
-    const size_t head = ((size_t)n_anims * 3 * kp * 64 + (size_t)n_anims * 3 * 64) * 4;
+    const size_t head = ((size_t)n_anims * 3 * kp * lanes + (size_t)n_anims * 3 * lanes) * 4;
     return (head + 15) & ~(size_t)15;
 }
 
-extern "C" size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys)
+extern "C" size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys, uint32_t nr_joints)
 {
-    if (!n_anims || !max_keys) return 0;
-    return pack_vals_offset(n_anims, pack_kp(max_keys)) + (size_t)n_anims * 3 * max_keys * 64 * 16;
+    if (!n_anims || !max_keys || !nr_joints || nr_joints > 256) return 0;
+    const uint32_t lanes = (nr_joints + 63) / 64 * 64;
+    return pack_vals_offset(n_anims, pack_kp(max_keys), lanes) + (size_t)n_anims * 3 * max_keys * lanes * 16;
 }
 
 extern "C" int clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint32_t nr_joints, uint32_t max_keys,
@@ -931,19 +948,19 @@ extern "C" int clapgpu_animations_pack(void *stream, const clapgpu_animations *a
 {
     if (!an || !packed || !an->chan_table || !an->times || !an->data || !an->n_anims || !max_keys)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    if (nr_joints == 0 || nr_joints > 64)                        // one wavefront per character: the loop the pools are for
-        return CLAPGPU_ERR_NOT_SUPPORTED;
+    if (nr_joints == 0 || nr_joints > 256)                       // JOINTS_MAX is 200 (shader_constants.h:6)
+        return CLAPGPU_ERR_TOO_LARGE;
     if ((reinterpret_cast<uintptr_t>(packed) & 15u) != 0)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    const uint32_t kp = pack_kp(max_keys);
+    const uint32_t kp = pack_kp(max_keys), lanes = (nr_joints + 63) / 64 * 64;
     char *base = static_cast<char *>(packed);
     float *o_times = reinterpret_cast<float *>(base);
-    uint32_t *o_nr = reinterpret_cast<uint32_t *>(o_times + (size_t)an->n_anims * 3 * kp * 64);
-    float4 *o_vals = reinterpret_cast<float4 *>(base + pack_vals_offset(an->n_anims, kp));
-    const uint32_t total = an->n_anims * 3u * kp * 64u;
+    uint32_t *o_nr = reinterpret_cast<uint32_t *>(o_times + (size_t)an->n_anims * 3 * kp * lanes);
+    float4 *o_vals = reinterpret_cast<float4 *>(base + pack_vals_offset(an->n_anims, kp, lanes));
+    const uint32_t total = an->n_anims * 3u * kp * lanes;
     hipLaunchKernelGGL(k_pose_pack, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const uint4 *>(an->chan_table), an->times, an->data, an->n_anims, nr_joints, max_keys, kp,
-                       o_times, o_nr, o_vals);
+                       lanes, o_times, o_nr, o_vals);
     CLAPGPU_LAUNCH_CHECK("k_pose_pack");
     return CLAPGPU_OK;
 }
@@ -994,12 +1011,12 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     // the key-major pools, if the caller made them (clapgpu_animations_pack) and every animation's rows fit in LDS
     a.pk_times = nullptr; a.pk_vals = nullptr; a.pk_k = a.pk_kp = 0;
     bool packed = false;
-    if (an->packed && an->packed_keys && lpc == 64) {
+    if (an->packed && an->packed_keys) {
         const uint32_t kp = pack_kp(an->packed_keys);
-        if ((uint64_t)a.n_anims * (3u * kp * 64u + 192u) <= (uint64_t)POSE_TIMES_LDS_MAX) {
+        if ((uint64_t)a.n_anims * (3u * kp + 3u) * lpc <= (uint64_t)POSE_TIMES_LDS_MAX * (lpc / 64)) {
             packed = true;
             a.pk_times = static_cast<const float *>(an->packed);
-            a.pk_vals = reinterpret_cast<const float4 *>(static_cast<const char *>(an->packed) + pack_vals_offset(a.n_anims, kp));
+            a.pk_vals = reinterpret_cast<const float4 *>(static_cast<const char *>(an->packed) + pack_vals_offset(a.n_anims, kp, lpc));
             a.pk_k = an->packed_keys; a.pk_kp = kp;
         }
     }
@@ -1013,14 +1030,24 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
         n_cus = prop.multiProcessorCount;
     }
     if (packed) {
-        const uint32_t n_groups = (pb->n_chars + 3) / 4;
-        static thread_local uint32_t res_packed = 0;
-        if (!res_packed) {
+        const uint32_t threads = lpc == 192 ? 192 : 256, cpb = threads / lpc;
+        const uint32_t n_groups = (pb->n_chars + cpb - 1) / cpb;
+        const void *fn = lpc == 64 ? (const void *)k_pose<64, 1, 256, true> : lpc == 128 ? (const void *)k_pose<128, 1, 256, true>
+                       : lpc == 192 ? (const void *)k_pose<192, 1, 192, true> : (const void *)k_pose<256, 1, 256, true>;
+        static thread_local uint32_t res_packed[4] = { 0, 0, 0, 0 };
+        uint32_t &res = res_packed[lpc / 64 - 1];
+        if (!res) {
             int per_cu = 0;
-            CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pose<64, 1, 256, true>, 256, 0));
-            res_packed = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
+            CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)threads, 0));
+            res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
         }
-        hipLaunchKernelGGL((k_pose<64, 1, 256, true>), dim3(n_groups < res_packed ? n_groups : res_packed), dim3(256), 0, s, a);
+        const dim3 grid(n_groups < res ? n_groups : res), block(threads);
+        switch (lpc) {
+        case 64:  hipLaunchKernelGGL((k_pose<64, 1, 256, true>), grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL((k_pose<128, 1, 256, true>), grid, block, 0, s, a); break;
+        case 192: hipLaunchKernelGGL((k_pose<192, 1, 192, true>), grid, block, 0, s, a); break;
+        default:  hipLaunchKernelGGL((k_pose<256, 1, 256, true>), grid, block, 0, s, a); break;
+        }
     } else if (lds_times) {
         // persistent blocks (24 KiB key times + 16 KiB joint globals each): exactly as many as are
         // resident at once, so no block waits for a slot while the others hold their LDS copy

@@ -420,17 +420,17 @@ typedef struct clapgpu_animations {
     const float    *times;
     const float    *data;
     /* optional (NULL / 0): the key-major copy of the pools made by clapgpu_animations_pack() for this model, and the
-     * max_keys it was made with.  Skeletons of <= 64 joints whose animations' key rows fit in LDS (one animation of
-     * <= 31 keys per channel, two of <= 15, ...) then take the loop whose per-lane key searches are free of LDS bank
-     * conflicts and whose key gathers are contiguous rows. */
+     * max_keys it was made with.  Skeletons whose animations' key rows fit in LDS (one animation of <= 31 keys per
+     * channel, two of <= 15, ...) then take the loop whose per-lane key searches are free of LDS bank conflicts, whose
+     * key gathers are contiguous rows and in which no wavefront waits for its own stores -- one wavefront per character
+     * up to 64 joints, two to four above. */
     const void     *packed;
     uint32_t        packed_keys, pad;
 } clapgpu_animations;
 
 /* Key-major pools, once per model (a device-side re-layout of chan_table / times / data; nothing is interpolated).
- * max_keys = the largest nr of any channel; packed: clapgpu_animations_packed_bytes() of device memory, 16-byte aligned.
- * nr_joints > 64: CLAPGPU_ERR_NOT_SUPPORTED (those skeletons take the general loop). */
-size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys);
+ * max_keys = the largest nr of any channel; packed: clapgpu_animations_packed_bytes() of device memory, 16-byte aligned. */
+size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys, uint32_t nr_joints);
 int    clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint32_t nr_joints, uint32_t max_keys, void *packed);
 
 /*

@@ -83,8 +83,11 @@ def test_pose_matches_reference_golden(path, cuda_device):
     (64, 8, dict(unreachable=6), dict(missing_frac=0.25, ragged=True)),
     (5, 3, {}, {}),
     (100, 12, {}, dict(ragged=True)),                                  # two wavefronts per character
-    (200, 20, dict(unreachable=3), dict(missing_frac=0.1)),            # JOINTS_MAX
-], ids=["c3_64j", "ragged_64j", "tiny_5j", "two_wave_100j", "joints_max_200j"])
+    (200, 20, dict(unreachable=3), dict(missing_frac=0.1)),            # JOINTS_MAX, general loop (missing channels)
+    (128, 10, {}, {}),                                                 # two full wavefronts per character, streaming loop
+    (192, 14, {}, dict(ragged=True)),                                  # three (192-thread workgroups)
+    (200, 16, {}, {}),                                                 # four, the last one 8 joints wide
+], ids=["c3_64j", "ragged_64j", "tiny_5j", "two_wave_100j", "joints_max_200j", "stream_128j", "stream_192j", "stream_200j"])
 def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
     from clap_amd import animation
     sk = synth.skeleton(J, depth, seed=11, **skw)
@@ -107,7 +110,7 @@ def test_pose_matches_oracle(J, depth, skw, akw, cuda_device):
         assert_pose_close(out, trs, jt, jp, reach, f"frame {f}", sk=sk, gl=gl, ent_mx=ch["char_mx"])
 
 
-@pytest.mark.parametrize("J", [64, 40, 1], ids=["64j", "40j_short_rows", "one_joint"])
+@pytest.mark.parametrize("J", [64, 40, 1, 100, 200], ids=["64j", "40j_short_rows", "one_joint", "100j_two_waves", "200j_four_waves"])
 def test_pose_streaming_loop_clips_rows_masks_and_tail(J, cuda_device):
     """The one-wavefront-per-character loop (every joint animated on all paths and reachable) stores through buffer
     descriptors that clip rows shorter than 64 joints, the characters past the end of the last group and masked

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k_pose at BASELINE configs[2] (50 000 characters x 64 joints), key-major pools (clapgpu_animations_pack) against the
-channel-major pools, alternating in one process: medians of HIP-event-timed launches.  python tools/pose_pack_ab.py [rounds]"""
+channel-major pools, alternating in one process: medians of HIP-event-timed launches.
+python tools/pose_pack_ab.py [rounds] [joints] [characters]"""
 import json
 import os
 import sys
@@ -16,8 +17,9 @@ def main():
     import torch
     from clap_amd import _lib, animation, synth
     _lib.check(_lib.lib().clapgpu_init(0), "clapgpu_init")
-    J, n = 64, 50_000
-    sk = synth.skeleton(J, 8, seed=3)
+    J = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 50_000
+    sk = synth.skeleton(J, 8 if J <= 64 else 12, seed=3)
     an = synth.animation(J, 30, 2.0, seed=3)
     ch = synth.characters(n, J, seed=3)
     batches = {}
@@ -45,7 +47,9 @@ def main():
         for _ in range(rounds):
             for name, cb in batches.items():
                 out[name].append((mode, *timed(cb)))
-    print(json.dumps({k: [dict(mode=m, median_us=a, best_us=b) for m, a, b in v] for k, v in out.items()}, indent=1))
+    res = {k: [dict(mode=m, median_us=a, best_us=b) for m, a, b in v] for k, v in out.items()}
+    res["joints"], res["characters"] = J, n
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
