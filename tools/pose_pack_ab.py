@@ -23,9 +23,13 @@ def main():
     an = synth.animation(J, 30, 2.0, seed=3)
     ch = synth.characters(n, J, seed=3)
     batches = {}
+    with_mesh = os.environ.get("POSE_AB_MESH") == "1"            # as bench.py's extras: a distinct 200-vertex mesh per character
+    mesh = synth.skinned_mesh(200, J, seed=3, copies=n) if with_mesh else None
+    vf = (np.arange(n, dtype=np.int64) * 200).astype(np.uint32) if with_mesh else None
+    vc = np.full(n, 200, np.uint32) if with_mesh else None
     for name, pack in (("key_major", True), ("channel_major", False)):
-        model = animation.SkinnedModel(sk, [an], device="cuda:0", pack=pack)
-        cb = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+        model = animation.SkinnedModel(sk, [an], mesh=mesh, device="cuda:0", pack=pack)
+        cb = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"], vert_first=vf, vert_count=vc)
         cb.set_frame_times(ch["phase"])
         batches[name] = cb
 
@@ -38,7 +42,7 @@ def main():
             a.record(); cb.pose_update(); b.record()
         torch.cuda.synchronize()
         t = np.asarray([a.elapsed_time(b) for a, b in ev]) * 1e3
-        return float(np.median(t)), float(t.min())
+        return float(np.median(t)), float(t.min()), float(t.mean())
 
     out = {k: [] for k in batches}
     for mode in ("all outputs", "palette only"):
@@ -47,7 +51,7 @@ def main():
         for _ in range(rounds):
             for name, cb in batches.items():
                 out[name].append((mode, *timed(cb)))
-    res = {k: [dict(mode=m, median_us=a, best_us=b) for m, a, b in v] for k, v in out.items()}
+    res = {k: [dict(mode=m, median_us=a, best_us=b, mean_us=c) for m, a, b, c in v] for k, v in out.items()}
     res["joints"], res["characters"] = J, n
     print(json.dumps(res, indent=1))
 
