@@ -207,12 +207,19 @@ def dropin_boundary():
 def cpu_baseline(scene, cam, frames):
     """Reported baseline, not the target: the reference (or the port) on one host core."""
     from oracle import binding as ob, refrun
+    if "OMP_NUM_THREADS" not in os.environ:                 # as many threads as the container may actually run at once (libgomp
+        quota = cgroup_cpu_limit()                          # read the environment when torch loaded it: set the team size directly)
+        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ob.omp_set_threads(max(1, min(aff, int(np.ceil(quota)) if quota else aff)))
     n_real = int(scene["n_real"])
     cores = 1
     if refrun.available():
         r = refrun.bench_entities(scene, cam, reps=frames)
+        # the boundary figure first: the all-cores leg leaves an OpenMP team behind, and a team wider than the container's
+        # CPU quota gets the whole cgroup throttled for the periods that follow
+        boundary = dropin_boundary()
         return dict(value=n_real / r["mean_s"], unit="entity updates/s", cores=cores, kind="reference",
-                    all_cores=cpu_all_cores(scene, cam), dropin_boundary=dropin_boundary(),
+                    all_cores=cpu_all_cores(scene, cam), dropin_boundary=boundary,
                     sample=f"{frames} frames of the same 1-GPU workload ({n_real} entities, all dirty): the reference's "
                            "default_update + view_entity_in_frustum (core/model.c, core/view.c; ROCm clang -O2 "
                            f"-ffp-contract=off), 1 thread; best frame {n_real / r['best_s']:.3e}/s")

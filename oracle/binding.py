@@ -152,6 +152,8 @@ def _declare(L):
                                                 F32P, F32P, F32P, F32P, C.POINTER(Frustum), C.c_void_p]
     L.clapo_entities_frame_tiles_mt.restype = C.c_uint32
     L.clapo_omp_max_threads.restype = C.c_uint32
+    L.clapo_omp_set_threads.argtypes = [C.c_uint32]
+    L.clapo_omp_set_threads.restype = None
     L.clapo_animation_time.argtypes = [C.c_uint32, C.c_uint32, U32P, F32P, F64P, F32P, U8P, C.c_double, F32P, U8P]
     L.clapo_characters_update.argtypes = [C.c_uint32, U32P, I32P, C.c_float, F32P, U32P, U8P, U8P, F32P, U32P,
                                           C.c_void_p, C.c_void_p, C.c_void_p, U8P]
@@ -606,6 +608,10 @@ def bodies_rotate_from_entities(link_body, link_entity, rot, parent, dirty, quat
 
 def omp_max_threads():
     return int(lib().clapo_omp_max_threads())
+
+
+def omp_set_threads(n):
+    lib().clapo_omp_set_threads(int(n))
 
 
 def entities_frame_tiles_mt(scene, st, fr, vis_mask):

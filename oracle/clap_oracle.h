@@ -216,6 +216,7 @@ uint64_t clapo_broadphase_static_pairs(uint32_t n_static, const double *static_a
 
 /* the frame on all host cores (OpenMP over tiles / mask words): context for the 1-thread baseline */
 uint32_t clapo_omp_max_threads(void);
+void clapo_omp_set_threads(uint32_t n);
 uint32_t clapo_entities_frame_tiles_mt(uint32_t n_tiles, const uint32_t *tile_row_start, uint32_t n,
                                        const float *pos_scale, const float *rot,
                                        const int32_t *parent, const int32_t *model,

@@ -283,6 +283,16 @@ uint32_t clapo_entities_cull(uint32_t n, const uint32_t *flags, const float *aab
  * (tile = contiguous range holding whole subtrees, parents first) parallelises over tiles, and the
  * frustum test over 64-entity words.  OpenMP; same arithmetic as clapo_entities_update / _cull.
  */
+/* bench.py caps the team at the container's CPU quota: libgomp read OMP_NUM_THREADS long before (torch loaded it) */
+void clapo_omp_set_threads(uint32_t n)
+{
+#ifdef _OPENMP
+    if (n) omp_set_num_threads((int)n);
+#else
+    (void)n;
+#endif
+}
+
 /* threads the OpenMP figure below really runs on (bench.py reports it beside the figure) */
 uint32_t clapo_omp_max_threads(void)
 {
