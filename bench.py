@@ -11,12 +11,16 @@ local slot; weak scaling, no data-path collective, and the only exchange is the 
 allgather of the compacted visible set (clapgpu_exchange_visible, C).  --c5 = BASELINE
 configs[4]'s sizing (2 M entities + 256 k particles per GPU: 16 M + 2 M at 8 GPUs).
 
+Started plainly with --gpus N > 1 (no torch.distributed.run environment) it is its own launcher: N fresh child
+processes, one per GPU, before this process makes any GPU call (launch_ranks).
+
 Prints ONE JSON line (rank 0).  `value` = entity updates / s over all GPUs.
-`roofline` = algorithmic bytes of the update kernel / its mean launch duration
-measured with HIP events around every launch (a separate pass after the timed
-region, same process, same data).  `cpu_baseline` = the reference's own
-default_update + view_entity_in_frustum (oracle/_ref, built from the reference
-sources) on one host core, or the oracle port if that binary is absent.
+`roofline` = algorithmic bytes of the update kernel / its launch-to-launch time, K launches back to
+back between one HIP event pair on the stream they are launched on (a separate pass after the timed
+region, same process, same data); `step_us` and `expand_launch_us` beside it make the line checkable
+against itself.  `cpu_baseline` = the reference's own default_update + view_entity_in_frustum
+(oracle/_ref, built from the reference sources) on one host core, or the oracle port if that binary
+is absent.
 """
 import argparse
 import json

@@ -26,6 +26,10 @@ static float frand(float a, float b) { return a + (b - a) * (float)((rnd() >> 11
 struct host_ent { uint32_t handle, parent /* index into ents[] or -1u */, model; float ps[4], rot[4]; uint32_t flags; int live; };
 static struct host_ent ents[MAXE];
 static uint32_t n_ents;
+/* joint attachments (clapgpu_scene_entity_set_attach / clapgpu_scene_attached_update): entity i rides joint * bind */
+static uint8_t att_on[MAXE];
+static float att_jt[MAXE][16], att_bind[MAXE][16];
+static uint32_t n_att_on;
 
 static void rand_trs(struct host_ent *e, int child)
 {
@@ -66,6 +70,21 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
         flags[k] = e->flags | CLAPO_E_DIRTY;         /* converged result == everything rebuilt from current TRS */
         seqs[k] = 0;
     }
+    if (n_att_on) {                                      /* model.c:1626-1641: mx = parent.mx * ((joint * bind) * local) */
+        static clapo_attach tab[MAXE];
+        static float jt_pool[MAXE * 16], bind_pool[MAXE * 16];
+        uint32_t na = 0;
+        for (uint32_t k = 0; k < n; k++) {               /* ascending k: the table is sorted by entity */
+            const uint32_t i = order[k];
+            if (!att_on[i] || ents[i].parent == UINT32_MAX) continue;
+            flags[k] |= CLAPO_E_JOINT_ATTACHED;
+            tab[na] = (clapo_attach){ .entity = k, .jt = na, .bind = na };
+            memcpy(jt_pool + 16 * na, att_jt[i], 64); memcpy(bind_pool + 16 * na, att_bind[i], 64);
+            na++;
+        }
+        clapo_entities_update_range(0, n, ps, rot, parent, model, &model_aabb[0][0], model_skip, flags, seqs, mx, inv, aabb, ctr,
+                                    na, tab, jt_pool, bind_pool);
+    } else
     clapo_entities_update(n, ps, rot, parent, model, &model_aabb[0][0], model_skip, flags, seqs, mx, inv, aabb, ctr);
     (void)o_mx_keep; (void)o_inv; (void)o_aabb; (void)o_ctr; (void)o_seqs; (void)o_flags_dirty;
     uint32_t vis_exp = 0;
@@ -204,6 +223,52 @@ int main(int argc, char **argv)
         }
         if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
         if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+    }
+    /* ---- joint attachments: the frame's SECOND launch.  Some children ride "a joint of their parent": mq_update computes
+     * everything else, attached_update (with the joints' matrices of the frame) the riders and everything below them. */
+    {
+        static uint32_t handles[MAXE];
+        static float jt[MAXE * 16], bind[MAXE * 16];
+        for (int frame = 0; frame < 3; frame++) {
+            uint32_t na = 0;
+            if (frame == 0) {
+                for (uint32_t i = 0; i < n_ents && n_att_on < 60; i++) {
+                    if (!ents[i].live || ents[i].parent == UINT32_MAX || att_on[ents[i].parent] || (rnd() % 5)) continue;
+                    uint32_t x = ents[i].parent; int nested = 0;
+                    while (x != UINT32_MAX) { if (att_on[x]) nested = 1; x = ents[x].parent; }
+                    if (nested) continue;
+                    att_on[i] = 1; n_att_on++;
+                    if (clapgpu_scene_entity_set_attach(s, ents[i].handle, 1)) return fail("set_attach", i);
+                }
+            }
+            for (uint32_t i = 0; i < n_ents; i++) {      /* this frame's joint matrices: a rigid-ish transform each */
+                if (!att_on[i]) continue;
+                for (int m = 0; m < 2; m++) {
+                    float *M = m ? att_bind[i] : att_jt[i];
+                    struct host_ent t; rand_trs(&t, 1);
+                    const float x = t.rot[0], y = t.rot[1], z = t.rot[2], w = t.rot[3];
+                    const float R[16] = { 1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w), 0,
+                                          2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w), 0,
+                                          2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y), 0,
+                                          t.ps[0], t.ps[1], t.ps[2], 1 };
+                    memcpy(M, R, 64);
+                }
+                handles[na] = ents[i].handle;
+                memcpy(jt + 16 * na, att_jt[i], 64); memcpy(bind + 16 * na, att_bind[i], 64);
+                na++;
+            }
+            for (int k = 0; k < 100; k++) {              /* and some entities move, riders and their parents among them */
+                struct host_ent *e = &ents[rnd() % n_ents];
+                if (!e->live) continue;
+                rand_trs(e, e->parent != UINT32_MAX);
+                clapgpu_scene_entity_transform(s, e->handle, e->ps, e->rot, e->ps[3]);
+            }
+            if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
+            if (clapgpu_scene_attached_update(s, na, handles, jt, bind)) { fprintf(stderr, "attached_update: %s\n", clapgpu_last_error()); return 2; }
+            if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+        }
+        if (n_att_on < 20) return fail("too few riders in the scenario", n_att_on);
+        printf("  %u joint riders through the second launch (%s)\n", n_att_on, clapgpu_scene_is_zero_copy(s) ? "small-frame path" : "staged path");
     }
     if (clapgpu_scene_entity_position(s, 0xdeadbeef, cpos) != CLAPGPU_ERR_INVALID_ARGUMENTS) return fail("bad handle", 0);
     clapgpu_scene_destroy(s);

@@ -75,12 +75,18 @@ def test_c_caller_of_the_flat_abi_matches_oracle(cuda_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["small_frames", "staged"])
 @pytest.mark.parametrize("mode", ["tiles", "wide"])
-def test_scene_mirror_frames_match_oracle(mode, cuda_device):
+def test_scene_mirror_frames_match_oracle(mode, path, cuda_device):
+    """Five frames of creations / moves / re-parenting / deletions, then three with joint riders through the frame's second
+    launch (clapgpu_scene_attached_update), every entity bit for bit against the oracle -- on the small-frame path (touched
+    records in through mapped memory, rebuilt rows out, polled completion word) and staged through device slabs."""
     build_c_test()
-    r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, CLAPGPU_SCENE_ZERO_COPY_SLOTS="0" if path == "staged" else "131072")
+    r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "PASS" in r.stdout and r.stdout.count("frame ok") == 5
+    assert "PASS" in r.stdout and r.stdout.count("frame ok") == 8
+    assert ("small-frame path" if path == "small_frames" else "staged path") in r.stdout
 
 
 def test_quat_from_angles_matches_reference(golden_dir):
