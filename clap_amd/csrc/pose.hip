@@ -547,7 +547,7 @@ __device__ __forceinline__ void pose_stream_loop(const PoseArgs &a, float *G, in
 // dependent loads per path -- run at LDS latency instead of L2 latency.  Skeleton constants of
 // the lane's joint (invmx, bind column 3, depth, parent) live in registers across characters.
 template <int LPC, int MODE, int BLOCK, bool PACKED = false>
-__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? POSE_WAVES : 1)
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !(PACKED && LPC > WAVE)) ? POSE_WAVES : 1)   // several wavefronts per character: LDS sets the occupancy
 void k_pose(PoseArgs a)
 {
     static_assert(!PACKED || MODE == 1, "the key-major pools are staged in LDS");
