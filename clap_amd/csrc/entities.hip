@@ -16,284 +16,9 @@
 #include <type_traits>
 #include "common.h"
 #include "lm_dev.h"
+#include "entities_row.h"
 
 namespace clapgpu {
-
-struct EntK {                    // kernel-argument copy of clapgpu_entities
-    const float4   *pos_scale;
-    const float4   *rot;
-    const int32_t  *parent;
-    const int32_t  *model;
-    const float4   *model_table;
-    uint32_t       *flags;
-    uint32_t       *seqs;
-    float          *mx;
-    float          *inv_mx;
-    float          *aabb;
-    float          *center;
-    uint64_t       *vis_mask;
-    uint8_t        *vis_row_pop;
-    uint32_t        n_attach;
-    const clapgpu_attach *attach;
-    const float    *jt_pool;
-    const float    *bind_pool;
-    float          *attach_local;    // [n_attach] mat4 = (jt * bind) * local, written by k_attach_prepare
-    // camera bounding-volume query (bv_on == 0: off); bv_result may be NULL when only the containment mask is wanted
-    float           bv_cam[3], bv_ctl[3];
-    uint32_t        bv_has_ctl, bv_ctl_entity, bv_on;
-    unsigned long long *bv_result;
-    uint64_t       *bv_inside;       // optional: one bit per entity, set where the query's boxes contain the point(s)
-    uint64_t       *rebuilt_mask;    // optional: one bit per entity, set where this launch rebuilt the entity
-    uint32_t        n, n_models;     // bounds of the two indices the caller supplies per entity
-};
-
-constexpr int ENT_BLOCK = 256;
-
-__device__ __forceinline__ void load_mat4(float (&m)[16], const float *src)
-{
-    const float4 *p = reinterpret_cast<const float4 *>(src);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float4 v = p[c];
-        m[4 * c] = v.x; m[4 * c + 1] = v.y; m[4 * c + 2] = v.z; m[4 * c + 3] = v.w;
-    }
-}
-
-// Per-lane inputs of one row, all loaded unconditionally so that a tile-walking wave
-// can issue the NEXT row's loads before it computes the current one.
-struct RowIn {
-    uint32_t fl, sq;
-    int32_t  p, mi;
-    float4   ps, q;
-};
-
-__device__ __forceinline__ RowIn load_row(const EntK &e, const int lane, const uint32_t row_first,
-                                          const uint32_t row_count)
-{
-    const uint32_t i = row_first + ((uint32_t)lane < row_count ? lane : 0);   // idle lanes re-read lane 0's entity
-    RowIn r;
-    r.fl = e.flags[i];
-    r.p = e.parent[i];
-    r.sq = e.seqs[i];
-    r.mi = e.model[i];
-    // a parent or model index outside the arrays would be a wild read: such an entity is treated as a
-    // root / as model 0 instead (the reference holds pointers here, which cannot be out of range)
-    if ((uint32_t)r.p >= e.n) r.p = -1;
-    if ((uint32_t)r.mi >= e.n_models) r.mi = 0;
-    r.ps = e.pos_scale[i];
-    r.q = e.rot[i];
-    return r;
-}
-
-// joint attachment of entity i: binary search of the (short, sorted) table; index or -1
-__device__ __forceinline__ int find_attach(const EntK &e, uint32_t i)
-{
-    uint32_t lo = 0, hi = e.n_attach;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (e.attach[mid].entity < i) lo = mid + 1; else hi = mid;
-    }
-    return (lo < e.n_attach && e.attach[lo].entity == i) ? (int)lo : -1;
-}
-
-__device__ __forceinline__ bool point_in_box(const float (&p)[3], const float (&bb)[6])
-{
-    return p[0] >= bb[0] && p[0] <= bb[3] && p[1] >= bb[1] && p[1] <= bb[4] && p[2] >= bb[2] && p[2] <= bb[5];
-}
-
-// One 64-entity row (= one vis_mask word) processed by one wave.
-//   row_first  first entity of the row (multiple of 64), row_count valid lanes (1..64)
-//   tile       8 KiB of wave-private LDS
-//   TILE       the wave walks a tile of consecutive rows (= hierarchy levels of a group of
-//              whole subtrees); a parent that sits in the previous row is taken from the
-//              registers of the lane that just computed it (16 cross-lane reads) instead of
-//              being re-read from HBM.  carry_* hold the previous row's results.
-template <bool CULL, bool TILE>
-__device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, float4 *tile, const int lane,
-                                            const uint32_t row_first, const uint32_t row_count,
-                                            const uint32_t mode, const lmd::FrustumK &fr,
-                                            const bool have_prev, const uint32_t prev_first,
-                                            float (&carry_mx)[16], uint32_t &carry_seq, bool &carry_valid)
-{
-    const bool in_range = (uint32_t)lane < row_count;
-    const uint32_t i = row_first + (in_range ? lane : 0);
-
-    const uint32_t fl = in.fl;
-    const bool alive = in_range && (fl & CLAPGPU_E_ALIVE);
-    const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
-    const int32_t p = in.p;
-    uint32_t seq = in.sq & 0xffffu, pseq = in.sq >> 16;
-
-    // ---- where does the parent live? ----
-    bool in_prev = false;
-    float pm[16];
-    uint32_t parent_seq_now = 0;
-    bool parent_in_regs = false;
-    if (TILE) {
-        in_prev = have_prev && p >= 0 && (uint32_t)p >= prev_first && (uint32_t)p < prev_first + WAVE;
-        const int src = in_prev ? (int)((uint32_t)p - prev_first) : lane;
-#pragma unroll
-        for (int k = 0; k < 16; k++) pm[k] = __shfl(carry_mx[k], src);
-        parent_seq_now = __shfl(carry_seq, src);
-        parent_in_regs = in_prev && (__shfl((int)carry_valid, src) != 0);
-    }
-    if (p >= 0 && !in_prev)
-        parent_seq_now = e.seqs[p] & 0xffffu;                    // parent updated by an earlier launch
-
-    // parent_transform_apply's skip test (model.c:1609-1611) / default_update's dirty test (1667)
-    bool rebuild = alive;
-    int at = -1;
-    if (alive && p >= 0 && (fl & CLAPGPU_E_JOINT_ATTACHED) && e.n_attach)
-        at = find_attach(e, i);
-    const bool attached = at >= 0;
-    if (p >= 0) {
-        if (!attached && pseq == parent_seq_now && !dirty)     // joint attachments are rebuilt every frame
-            rebuild = false;
-        else
-            pseq = parent_seq_now;
-    } else if (!dirty) {
-        rebuild = false;
-    }
-
-    float mx[16], inv[16], bb[6], ctr[3];
-    bool has_aabb = false;
-
-    if (rebuild) {
-        const float4 lo = e.model_table[2 * in.mi];              // min.xyz, skip_aabb bits
-        const float4 hi = e.model_table[2 * in.mi + 1];          // max.xyz, 0
-        float local_mx[16];
-        if (attached)                                            // (jt * bind) * local from k_attach_prepare
-            load_mat4(local_mx, e.attach_local + 16 * (size_t)at);
-        else
-            lmd::trs(local_mx, in.ps.x, in.ps.y, in.ps.z, in.ps.w, in.q.x, in.q.y, in.q.z, in.q.w);
-        if (p >= 0) {
-            if (!parent_in_regs)
-                load_mat4(pm, e.mx + 16 * (size_t)p);            // stored matrix of a parent not rebuilt here
-            lmd::mul(mx, pm, local_mx);                          // model.c:1625 / 1640
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) mx[k] = local_mx[k];
-        }
-#ifdef CLAPGPU_EXP_NO_INVERT                                     // sensitivity experiments only (tools/entities_sensitivity.sh): wrong results
-#pragma unroll
-        for (int k = 0; k < 16; k++) inv[k] = mx[k];
-#else
-        lmd::invert(inv, mx);
-#endif
-
-        has_aabb = __float_as_uint(lo.w) == 0u;                  // model.c:1204
-#ifdef CLAPGPU_EXP_NO_AABB
-        if (has_aabb) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) bb[k] = mx[12 + k % 3] + (k < 3 ? lo.x : hi.x);
-#pragma unroll
-            for (int k = 0; k < 3; k++) ctr[k] = mx[12 + k];
-        }
-#else
-        if (has_aabb)
-            lmd::world_aabb(bb, ctr, mx, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
-#endif
-
-        seq = (seq + 1) & 0xffffu;                               // uint16 wrap (model.h:404)
-        e.seqs[i] = seq | (pseq << 16);
-        if (!(mode & CLAPGPU_UPDATE_ALL_DIRTY) && (fl & CLAPGPU_E_DIRTY))
-            e.flags[i] = fl & ~CLAPGPU_E_DIRTY;                  // transform_clear_updated
-    }
-
-    if (TILE) {                                                  // hand this row to the next one
-#pragma unroll
-        for (int k = 0; k < 16; k++) carry_mx[k] = mx[k];
-        carry_seq = seq;
-        carry_valid = rebuild;
-    }
-
-    // ---- stores: whole-wave fast path when every valid lane rebuilt (the common case) ----
-    const uint64_t rebuilt_mask = __ballot(rebuild);
-    if (e.rebuilt_mask && lane == 0) e.rebuilt_mask[row_first >> 6] = rebuilt_mask;
-    const uint64_t aabb_mask = __ballot(rebuild && has_aabb);
-    const uint64_t full = row_count == WAVE ? ~0ull : ((1ull << row_count) - 1ull);
-    const size_t e0 = row_first;
-    float4 *tile_a = tile, *tile_b = tile + 256;                 // 2 x 4 KiB
-    float *tile_f = reinterpret_cast<float *>(tile);
-
-    if (rebuilt_mask == full) {
-        float4 va[4], vb[4];
-        stage_mat4(tile_a, mx, lane);
-        stage_mat4(tile_b, inv, lane);
-        wave_lds_fence();
-        unstage_mat4(tile_a, va, lane);
-        unstage_mat4(tile_b, vb, lane);
-        store_mat4_rows(e.mx + 16 * e0, va, lane, (int)row_count);
-        store_mat4_rows(e.inv_mx + 16 * e0, vb, lane, (int)row_count);
-        wave_lds_fence();
-    } else if (rebuild) {
-        float4 *dm = reinterpret_cast<float4 *>(e.mx + 16 * (size_t)i);
-        float4 *di = reinterpret_cast<float4 *>(e.inv_mx + 16 * (size_t)i);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            dm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
-            di[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
-        }
-    }
-    if (aabb_mask == full) {
-        stage_rows<6>(tile_f, bb, lane);                         // 1536 B
-        stage_rows<3>(tile_f + 6 * WAVE, ctr, lane);             //  768 B
-        wave_lds_fence();
-        store_rows<6>(tile_f, e.aabb + 6 * e0, lane, (int)row_count);
-        store_rows<3>(tile_f + 6 * WAVE, e.center + 3 * e0, lane, (int)row_count);
-        wave_lds_fence();
-    } else if (rebuild && has_aabb) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) e.aabb[6 * (size_t)i + k] = bb[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
-    }
-
-    const bool want_bv = e.bv_on != 0;
-    if (CULL || want_bv) {
-        // Entities that were not rebuilt (or whose model skips AABBs) use their stored box.
-        if (in_range && !(rebuild && has_aabb)) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) bb[k] = e.aabb[6 * (size_t)i + k];
-        }
-    }
-    if (want_bv) {                                               // model.c:1703-1713
-        bool inside = in_range && (fl & CLAPGPU_E_ALIVE) && point_in_box(e.bv_cam, bb);
-        if (!inside && e.bv_has_ctl)
-            inside = in_range && (fl & CLAPGPU_E_ALIVE) && point_in_box(e.bv_ctl, bb);
-        if (inside && e.bv_has_ctl && i == e.bv_ctl_entity)
-            inside = false;
-        const uint64_t inside_mask = __ballot(inside);
-        if (e.bv_inside && lane == 0) e.bv_inside[e0 >> 6] = inside_mask;
-        if (inside_mask) {                                       // rare: almost no box contains the camera
-            unsigned long long key = 0;
-            if (inside) {
-                const float4 lo = e.model_table[2 * in.mi], hi = e.model_table[2 * in.mi + 1];
-                const float X = fabsf(hi.x - lo.x) * in.ps.w, Y = fabsf(hi.y - lo.y) * in.ps.w,
-                            Z = fabsf(hi.z - lo.z) * in.ps.w;  // entity3d_aabb_X/Y/Z (model.c:1185-1198)
-                const float vol = X * Y * Z;
-                key = ((unsigned long long)__float_as_uint(vol) << 32) | (0xFFFFFFFFu - i);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(key, off);
-                key = o > key ? o : key;
-            }
-            if (lane == 0 && key && e.bv_result)
-                atomicMax(e.bv_result, key);
-        }
-    }
-    if (CULL) {
-        bool vis = in_range && (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);   // model.c:959-965
-        if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
-            vis = lmd::aabb_in_frustum_fast(fr, bb);                                  // model.c:967-971
-        const uint64_t m = __ballot(vis);
-        if (lane == 0) {
-            e.vis_mask[e0 >> 6] = m;
-            e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);       // feeds the single-launch compaction
-        }
-    }
-}
 
 // The common row of a tile walk, as straight-line code: all 64 lanes alive and rebuilt, every parent in the
 // previous row's registers (or none), no joint attachment, every model with a box (taken from the LDS copy `mt` of
@@ -415,7 +140,6 @@ void k_attach_prepare(EntK e)
         d[c] = make_float4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3]);
 }
 
-constexpr int LDS_F4_PER_WAVE = 512;                             // 8 KiB
 
 // One launch per hierarchy level: every parent was written by an earlier launch.
 // `first` is a multiple of 64, so each wave owns exactly one vis_mask word.
@@ -1080,6 +804,36 @@ extern "C" int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entit
     const uint32_t blocks = k.n_rows ? (k.n_rows + per_block - 1) / per_block : 1;
     hipLaunchKernelGGL(k_entities_export_rebuilt, dim3(blocks), dim3(ENT_BLOCK), 0, as_stream(stream), k);
     CLAPGPU_LAUNCH_CHECK("k_entities_export_rebuilt");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e,
+                                                    const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t mode,
+                                                    const clapgpu_frustum *frustum, const clapgpu_entities_hostio *io)
+{
+    int rc = check_entities(e, frustum != nullptr);
+    if (rc) return rc;
+    if (!io || !io->mx || !io->inv_mx || !io->aabb || !io->center || !io->rebuilt_mask || !io->counter || !io->done ||
+        (frustum && !io->vis_mask) || (io->touched && (!io->pos_scale || !io->rot || !io->flags)) || (n_tiles && !tile_row_start))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!aligned16(io->mx) || !aligned16(io->inv_mx) || (reinterpret_cast<uintptr_t>(io->aabb) & 7u) ||
+        (io->touched && (!aligned16(io->pos_scale) || !aligned16(io->rot))))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const lmd::FrustumK fr = make_frustum_k(frustum);
+    const EntK k = to_kernel_args(e);
+    if (k.bv_result)
+        CLAPGPU_HIP(hipMemsetAsync(k.bv_result, 0, sizeof(uint64_t), as_stream(stream)));
+    rc = prepare_attachments(stream, k);
+    if (rc) return rc;
+    HostIO h;
+    h.pos_scale = reinterpret_cast<const float4 *>(io->pos_scale); h.rot = reinterpret_cast<const float4 *>(io->rot);
+    h.flags = io->flags; h.touched = io->touched;
+    h.o_mx = io->mx; h.o_inv = io->inv_mx; h.o_aabb = io->aabb; h.o_center = io->center;
+    h.o_vis = io->vis_mask; h.o_rebuilt = io->rebuilt_mask; h.o_inside = io->inside_mask;
+    h.counter = io->counter; h.done = io->done; h.done_value = io->done_value;
+    const uint32_t tiles = e->n ? n_tiles : 0;
+    rc = launch_entities_tiles_host(as_stream(stream), frustum != nullptr, fr, k, h, tile_row_start, tiles, e->n, mode);
+    if (rc) return rc;
     return CLAPGPU_OK;
 }
 

@@ -63,15 +63,19 @@ struct clapgpu_scene {
      * (mx | inv_mx | aabb | center | vis_mask) */
     void       *h_in, *h_out, *d_in, *d_out;
     size_t      in_bytes, out_bytes;
-    /* small scenes (zero_copy): no copy calls and no blocking wait in a frame.  The touched entities' records go into
-     * a device-mapped host list which clapgpu_entities_apply_inputs scatters into the device arrays; the result slab
-     * h_out is device-mapped and clapgpu_entities_export_rebuilt writes what the update rebuilt (and the masks)
-     * straight into it, then raises *h_done, which mq_update polls.  At a testbed-sized scene (10 k entities) the
-     * three copies' fixed latencies and the blocking wait were 0.13 of a 0.15 ms device step around a 15-30 us kernel. */
+    /* small scenes (zero_copy): no copy calls and no blocking wait in a frame, and with the tile layout ONE launch:
+     * the upload image and the result slab are device-mapped, the frame's touched slots are flagged in h_touched, and
+     * clapgpu_entities_update_tiles_hostio reads the flagged inputs from the image, writes what it rebuilds (and the
+     * masks) into h_out as well and raises *h_done, which mq_update polls.  With the level layout (a tree wider than a
+     * wavefront) the touched records travel as a mapped list scattered by clapgpu_entities_apply_inputs and the results
+     * come back through clapgpu_entities_export_rebuilt.  At a testbed-sized scene (10 k entities) the three copies'
+     * fixed latencies and the blocking wait were 0.13 of a 0.15 ms device step around a 15-30 us kernel. */
     int         zero_copy;
     uint32_t    zero_copy_max_slots;
     clapgpu_entity_input *h_list; void *d_list; uint32_t cap_list;    /* mapped: host pointer / device alias */
     void       *d_out_host;                                            /* device alias of h_out */
+    void       *d_in_host;                                             /* device alias of h_in (zero_copy: the image is mapped) */
+    uint64_t   *h_touched;                                             /* behind the image: one bit per slot written since the last frame */
     uint32_t   *h_done, *d_done, *d_counter, frame_id;
     /* joint attachments (clapgpu_scene_attached_update): table + the two matrix pools + the kernel's work space */
     void       *h_att, *d_att; size_t att_bytes; uint32_t cap_att; int att_mapped;
@@ -121,6 +125,22 @@ static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
         if (slot < s->up_lo) s->up_lo = slot;
         if (slot >= s->up_hi) s->up_hi = slot + 1;
     }
+}
+
+/* the mapped side of a one-launch small frame: the image (and its touched bits) in, the result slab and the word out */
+static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with_inputs)
+{
+    const size_t cn = s->cap_slots;
+    const char *mi = s->d_in_host;
+    char *mo = s->d_out_host;
+    memset(io, 0, sizeof(*io));
+    io->pos_scale = (const float *)mi; io->rot = (const float *)(mi + cn * 16); io->flags = (const uint32_t *)(mi + cn * 32);
+    io->touched = with_inputs ? (const uint64_t *)(mi + cn * 36) : NULL;
+    io->mx = (float *)mo; io->inv_mx = (float *)(mo + cn * 64); io->aabb = (float *)(mo + cn * 128);
+    io->center = (float *)(mo + cn * 152); io->vis_mask = (uint64_t *)(mo + cn * 164);
+    io->rebuilt_mask = io->vis_mask + (cn / 64 + 2);
+    io->inside_mask = s->bv_on ? io->rebuilt_mask + (cn / 64 + 2) : NULL;
+    io->counter = s->d_counter; io->done = s->d_done; io->done_value = ++s->frame_id;
 }
 
 int clapgpu_scene_create(clapgpu_scene **out, int device)
@@ -388,10 +408,11 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->h_in = s->h_out = NULL;
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
     s->have_results = 0;
-    s->in_bytes = n * 36;
+    s->in_bytes = n * 36 + (n / 64 + 2) * 8;                 /* + the touched-slot bits */
     s->out_bytes = n * 164 + 3 * (n / 64 + 2) * 8;           /* + visibility, rebuilt and bounding-volume masks */
     s->zero_copy = cap <= s->zero_copy_max_slots;
-    CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
+    if (s->zero_copy) CK(clapgpu_host_malloc_mapped(&s->h_in, &s->d_in_host, s->in_bytes));
+    else CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
     if (s->zero_copy) {
         CK(clapgpu_host_malloc_mapped(&s->h_out, &s->d_out_host, s->out_bytes));
         if (!s->h_done) {
@@ -411,6 +432,8 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->h_pos_scale = (float *)hi;              s->d.pos_scale = (const float *)di;
     s->h_rot = (float *)(hi + n * 16);         s->d.rot = (const float *)(di + n * 16);
     s->h_flags = (uint32_t *)(hi + n * 32);    s->d.flags = (uint32_t *)(di + n * 32);
+    s->h_touched = (uint64_t *)(hi + n * 36);
+    memset(s->h_touched, 0, (n / 64 + 2) * 8);
     s->h_mx = (float *)ho;                     s->d.mx = (float *)dq;
     s->h_inv = (float *)(ho + n * 64);         s->d.inv_mx = (float *)(dq + n * 64);
     s->h_aabb = (float *)(ho + n * 128);       s->d.aabb = (float *)(dq + n * 128);
@@ -586,13 +609,14 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
 {
     if (!s) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     int upload = 0, full = 0;
-    uint32_t lo = 0xffffffffu, hi = 0, n_touched = 0;
+    uint32_t lo = 0xffffffffu, hi = 0, n_touched = 0, n_bits = 0;
     if (s->topology_dirty) {
         CK(retile(s));
         upload = full = 1;
     } else if (s->n_dirty) {
         /* the upload image was written as the verbs came in (mark_dirty); here only the bookkeeping */
-        if (s->zero_copy && s->n_dirty > s->cap_list) {  /* the mapped record list grows with the busiest frame seen */
+        const int bits = s->zero_copy && s->tiled;       /* one launch: the kernel reads the flagged slots from the image */
+        if (s->zero_copy && !bits && s->n_dirty > s->cap_list) {  /* the mapped record list grows with the busiest frame seen */
             uint32_t cap = s->cap_list ? s->cap_list : 1024;
             while (cap < s->n_dirty) cap *= 2;
             if (s->h_list) clapgpu_host_free(s->h_list);
@@ -605,7 +629,9 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
             const uint8_t was = e->dirty;
             e->dirty = 0;
             if (!e->live) continue;
-            if (s->zero_copy) {
+            if (bits) {
+                s->h_touched[e->slot >> 6] |= 1ull << (e->slot & 63);
+            } else if (s->zero_copy) {
                 clapgpu_entity_input *r = &s->h_list[n_touched];
                 r->slot = e->slot;
                 r->flags = img_flags(e, was & 2);
@@ -617,6 +643,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         lo = s->up_lo; hi = s->up_hi;
         s->n_dirty = 0;
         upload = n_touched != 0 && hi > lo;
+        if (bits) n_bits = n_touched;
     }
     const int bulk = s->bulk_dirty && !full;
     if (bulk) {                                          /* clapgpu_scene_entity_transform_mt wrote the image directly */
@@ -636,11 +663,18 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         s->models_dirty = 0;
         full = 1;
     }
-    if (s->n_models == 0) return CLAPGPU_OK;
+    if (s->n_models == 0) {
+        for (uint32_t k = 0; k < n_bits; k++) s->h_touched[s->dirty_list[k] >> 6] = 0;
+        return CLAPGPU_OK;
+    }
     const size_t n = s->n_slots;
     const size_t cap = s->cap_slots;
-    const int by_list = s->zero_copy && upload && !full && !bulk && n_touched <= s->cap_list;   /* same bytes as the image, no copy call */
-    if (by_list) {
+    const int fused = s->zero_copy && s->tiled;          /* update + export (+ the touched inputs) as one launch */
+    const int by_bits = fused && upload && !full && !bulk;
+    const int by_list = s->zero_copy && !fused && upload && !full && !bulk && n_touched <= s->cap_list;   /* same bytes as the image, no copy call */
+    if (by_bits) {
+        /* nothing to issue: h_touched says which slots of the mapped image the kernel has to take */
+    } else if (by_list) {
         CK(clapgpu_entities_apply_inputs(NULL, &s->d, (const clapgpu_entity_input *)s->d_list, n_touched));
     } else if (upload) {
         /* one copy of the whole input slab after a re-tile or when most of it changed; else the slot range */
@@ -666,12 +700,23 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     if (frustum) s->last_frustum = *frustum;
     s->d.n_attach = 0;                                   /* joint attachments ride the palettes of THIS frame: clapgpu_scene_attached_update */
     const double tt0 = scene_now_us();
-    if (s->tiled)
+    const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
+    if (fused) {
+        clapgpu_entities_hostio io;
+        scene_hostio(s, &io, by_bits);
+        CK(clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum, &io));
+        const double tt2 = scene_now_us();
+        CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (getenv("CLAPGPU_SCENE_TIMING"))
+            fprintf(stderr, "scene small frame: %u inputs by %s, one launch %.1f us, wait %.1f us\n", n_touched,
+                    by_bits ? "touched bits" : upload ? "copy" : "none", tt2 - tt0, scene_now_us() - tt2);
+    } else if (s->tiled)
         CK(clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum));
     else
         CK(clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, frustum));
-    const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
-    if (s->zero_copy) {
+    if (fused) {
+        /* results and masks are in h_out already */
+    } else if (s->zero_copy) {
         /* what the update rebuilt, and the masks, straight into the mapped result slab; then the completion word */
         char *mo = s->d_out_host;
         const size_t cn = cap;
@@ -701,6 +746,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
     }
     if (!s->zero_copy) CK(clapgpu_stream_sync(NULL));
+    for (uint32_t k = 0; k < n_bits; k++) s->h_touched[s->dirty_list[k] >> 6] = 0;   /* taken by this frame's launch or by its copy */
     if (!frustum)
         memset(s->h_mask, 0, mask_words * 8);
     if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
@@ -781,12 +827,21 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
     s->d.bind_pool = s->d.jt_pool + 16 * (size_t)n;
     s->d.attach_local = s->d_att_local;
     const clapgpu_frustum *fr = s->have_frustum ? &s->last_frustum : NULL;
-    int rc = s->tiled ? clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr)
+    const int fused = s->zero_copy && s->tiled;
+    int rc;
+    if (fused) {
+        clapgpu_entities_hostio io;
+        scene_hostio(s, &io, 0);
+        rc = clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr, &io);
+    } else
+        rc = s->tiled ? clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr)
                       : clapgpu_entities_update(NULL, &s->d, s->level_start_host, s->n_levels, 0, fr);
     s->d.n_attach = 0;
     if (rc) return rc;
     const size_t nn = s->n_slots, cap = s->cap_slots, mask_words = nn / 64, mask_stride = cap / 64 + 2;
-    if (s->zero_copy) {
+    if (fused) {
+        CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+    } else if (s->zero_copy) {
         char *mo = s->d_out_host;
         clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cap * 64), .aabb = (float *)(mo + cap * 128),
                                       .center = (float *)(mo + cap * 152), .vis_mask = (uint64_t *)(mo + cap * 164) };

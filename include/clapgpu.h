@@ -250,6 +250,29 @@ typedef struct clapgpu_entities_export {
 } clapgpu_entities_export;
 int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list, uint32_t n_list);
 int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x);
+
+/*
+ * The same small frame as ONE launch, for the tile layout: clapgpu_entities_update_tiles() that takes the inputs of the
+ * slots flagged in `touched` (one bit per slot, set by the host for this frame) from the mirror's device-mapped upload
+ * image (pos_scale / rot / flags in slot order, the bytes a copy would have carried) and stores them into the device
+ * arrays as it goes, writes every row it rebuilds into the mapped result arrays as well, the three masks with them, and
+ * raises *done = done_value when the last workgroup has finished (clapgpu_wait_word).  touched == NULL: no inputs this
+ * launch (a second launch behind a pose: clapgpu_scene_attached_update).  Three dependent launches of a few microseconds
+ * each cost a 10 k-entity frame 50 of its 68 us in launch-to-launch latency; this is one.
+ */
+typedef struct clapgpu_entities_hostio {
+    const float    *pos_scale, *rot;                       /* device aliases of the mapped upload image */
+    const uint32_t *flags;
+    const uint64_t *touched;                               /* device alias of the mapped touched-slot bits, or NULL */
+    float    *mx, *inv_mx, *aabb, *center;                 /* device aliases of the mapped result arrays */
+    uint64_t *vis_mask, *rebuilt_mask, *inside_mask;       /* vis_mask needed with a frustum; inside_mask may be NULL */
+    uint32_t *counter;                                     /* device scratch: one zeroed uint32 */
+    uint32_t *done;                                        /* device-mapped host word */
+    uint32_t  done_value, pad;
+} clapgpu_entities_hostio;
+int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e, const uint32_t *tile_row_start,
+                                         uint32_t n_tiles, uint32_t mode, const clapgpu_frustum *frustum,
+                                         const clapgpu_entities_hostio *io);
 /* Busy-wait until *word == value (a word a kernel stores into mapped host memory).  Checks `stream` every so often: if
  * it has drained and the word still differs, the signalling launch failed -> CLAPGPU_ERR_UNKNOWN instead of a hang. */
 int clapgpu_wait_word(const volatile uint32_t *word, uint32_t value, void *stream);
