@@ -200,11 +200,26 @@ def dropin_boundary():
             "reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
             "reference_mq_update_ms": r["reference_mq_update_ms"], "binding_mq_update_ms": r["binding_mq_update_ms"],
             "binding_ms": r["binding_ms"], "identical": r["mismatches"] == 0 and r["visible_equal"]}
+    # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
+    # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
+    for chars, joints, frames in ((500, 64, 14), (5_000, 64, 8)):
+        key = f"{chars}_characters_{joints}_joints"
+        try:
+            p = subprocess.run([exe, "anim", str(chars), str(joints), str(frames), "5", "notify"], capture_output=True, text=True,
+                               timeout=240)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out[key] = {"reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
+                        "worst_relative_error": r["worst_relative_error"], "within_1e-5": r["mismatches"] == 0}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     out["note"] = ("random forest (60 % of the entities parented, parents listed before their children); *_ms_per_frame = mq_update + one "
                    "frustum verdict per entity asked in list order like _models_render (the caller's walk of the lists is inside both "
                    "sides), *_mq_update_ms = the update call alone.  Binding through the engine's own names (mq_update, "
                    "view_entity_in_frustum, entity3d_move ...), notification mode: touched transforms up, kernel, results down, the "
-                   "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities")
+                   "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities.  "
+                   "*_characters_*: the frame's mq_update with every character's animated_update (keyframes, hierarchy, palette, joint "
+                   "positions) on the host against the binding (entities, pose on the device, T/R/S + palette + positions of every "
+                   "joint copied back into the entity3d structs, joint-attached props in a second launch); per-object 1e-5 bar")
     return out
 
 

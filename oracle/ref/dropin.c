@@ -1114,6 +1114,8 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
     uint64_t bad = 0, posed = 0, restarts = 0, held_checked = 0, attached_batched = 0, batched = 0;
     attached_expected *= frames;
     struct tol_stats ts = { 0 }, ts_held = { 0 };
+    double t_ref = 0, t_bind = 0, t_bind_mq = 0;
+    uint32_t n_timed = 0;
     for (uint32_t f = 0; f < frames; f++) {
         dbl_now = 10.0 + 0.37 * f + (f % 4 == 3 ? 0.0 : 0.013 * f);
         for (uint32_t id = 0; id < n; id++) {
@@ -1135,12 +1137,18 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
         const int anim_before = WA.e[0]->animation;
         (void)anim_before;
         gp_libc_state_set(WA.libc);
+        const double ta0 = now_s();
         ref_mq_update(&WA.scene->mq);                                       /* default_update -> animated_update per entity */
+        const double ta1 = now_s();
         WA.libc = gp_libc_state_get();
         gp_libc_state_set(WB.libc);
+        const double tb0 = now_s();
         rc = gpu_mq_update(gs, &WB.scene->mq, &WB.view);
+        const double tb1 = now_s();
         if (!rc) rc = gpu_anim_update(ga, gs, &WB.scene->mq, WB.scene);
+        const double tb2 = now_s();
         WB.libc = gp_libc_state_get();
+        if (f >= 2) { t_ref += ta1 - ta0; t_bind += tb2 - tb0; t_bind_mq += tb1 - tb0; n_timed++; }   /* frames 0-1: extraction, tiling, first uploads */
         attached_batched += gpu_scene_last_stats(gs)->attached;
         batched += gpu_scene_last_stats(gs)->batched;
         if (gpu_scene_last_stats(gs)->attach_failures) { fprintf(stderr, "frame %u: the joint-attached device pass failed\n", f); bad++; }
@@ -1210,11 +1218,14 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
            "\"animation_restarts\": %llu, \"worst_relative_error\": %.3g, \"cancelled_objects\": %llu, \"worst_cancelled_ulps\": %.3g, "
            "\"joint_attached_checks\": %llu, \"worst_joint_attached_error\": %.3g, \"joint_attached_cancelled\": %llu, "
            "\"worst_joint_attached_ulps\": %.3g, \"batched_updates\": %llu, \"attached_batched_updates\": %llu, \"attached_expected\": %llu, "
+           "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, \"binding_mq_update_ms\": %.4f, \"frames_timed\": %u, "
            "\"norm\": \"per object: each joint's T, R, S, palette 3x3 block, palette translation, world position against its own magnitude; "
            "cancelled sums against 64 fp32 ulps of their terms\", \"tolerance\": 1e-5, \"mismatches\": %llu}\n",
            frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, ts.worst_own, (unsigned long long)ts.cancelled,
            ts.worst_ulps, (unsigned long long)held_checked, ts_held.worst_own, (unsigned long long)ts_held.cancelled, ts_held.worst_ulps,
-           (unsigned long long)batched, (unsigned long long)attached_batched, (unsigned long long)attached_expected, (unsigned long long)bad);
+           (unsigned long long)batched, (unsigned long long)attached_batched, (unsigned long long)attached_expected,
+           n_timed ? 1e3 * t_ref / n_timed : 0.0, n_timed ? 1e3 * t_bind / n_timed : 0.0, n_timed ? 1e3 * t_bind_mq / n_timed : 0.0, n_timed,
+           (unsigned long long)bad);
     gpu_anim_done(ga);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
