@@ -111,6 +111,7 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     assert r["mismatches"] == 0
     assert r["worst_relative_error"] <= 1e-5 and r["worst_cancelled_ulps"] <= 64
     assert r["animation_restarts"] > 0 and r["joint_poses_compared"] == frames * n_chars * joints
+    assert r["frames_timed"] == max(frames - 2, 0) and (frames <= 2 or (r["reference_ms_per_frame"] > 0 and r["binding_ms_per_frame"] > 0))
     n_held = n_chars // 3 + 2
     assert r["joint_attached_checks"] == frames * 3 * n_held and r["worst_joint_attached_error"] <= 1e-5
     # of each triple (rider listed after its character, rider listed before it, plain child of the first) the first and
