@@ -212,6 +212,18 @@ def dropin_boundary():
                         "worst_relative_error": r["worst_relative_error"], "within_1e-5": r["mismatches"] == 0}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
+    # particle systems: one particles_update hook per system (core/particle.c:89-140) against gpu_particles_update
+    for systems, per, frames in ((64, 1024, 14), (1024, 1024, 8)):
+        key = f"{systems}_particle_systems_x_{per}"
+        try:
+            p = subprocess.run([exe, "particles", str(systems), str(per), str(frames), "4"], capture_output=True, text=True, timeout=240)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out[key] = {"reference_ms_per_frame": r["reference_ms_per_frame"],
+                        "binding_ms_per_frame": r["binding_ms_per_frame_positions_only"],
+                        "binding_ms_per_frame_with_particle_structs": r["binding_ms_per_frame_with_particle_structs"],
+                        "identical": r["mismatches"] == 0 and r["stream_draws_agree"]}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     out["note"] = ("random forest (60 % of the entities parented, parents listed before their children); *_ms_per_frame = mq_update + one "
                    "frustum verdict per entity asked in list order like _models_render (the caller's walk of the lists is inside both "
                    "sides), *_mq_update_ms = the update call alone.  Binding through the engine's own names (mq_update, "
@@ -219,7 +231,10 @@ def dropin_boundary():
                    "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities.  "
                    "*_characters_*: the frame's mq_update with every character's animated_update (keyframes, hierarchy, palette, joint "
                    "positions) on the host against the binding (entities, pose on the device, T/R/S + palette + positions of every "
-                   "joint copied back into the entity3d structs, joint-attached props in a second launch); per-object 1e-5 bar")
+                   "joint copied back into the entity3d structs, joint-attached props in a second launch); per-object 1e-5 bar.  "
+                   "*_particle_systems_*: binding_ms_per_frame = what a frame needs (every system's pos_array and billboard matrix back "
+                   "on the host, libc's drand48 position handed on), *_with_particle_structs = every struct particle's pos / velocity "
+                   "written back as well (only when the game reads them)")
     return out
 
 

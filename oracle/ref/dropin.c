@@ -810,6 +810,8 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
     }
 
     uint64_t bad = 0, respawn_checks = 0, particles = 0, respawns = 0;
+    double t_ref_p = 0, t_bind_pos = 0, t_bind_scatter = 0;
+    uint32_t n_timed_p = 0, n_pos = 0, n_scatter = 0;
     for (uint32_t f = 0; f < frames; f++) {
         /* the game: emitters move, now and then a system dies or a new one appears */
         for (uint32_t s = 0; s < PA.n_sys; s++) {
@@ -846,7 +848,9 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
 
         gp_libc_state_set(PA.libc);
         const uint64_t before = PA.libc;
+        const double tp0 = now_s();
         ref_mq_update(&PA.scene->mq);                                   /* the reference: one particles_update per system */
+        const double tp1 = now_s();
         PA.libc = libc_get();
         /* 7 draws per respawn; count them by stepping the LCG from `before` (bounded) */
         for (uint64_t x = before, k = 0; x != PA.libc && k < 40000000ull; k++) {
@@ -855,9 +859,16 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
         }
         const bool scatter = f % 3 != 1;
         gp_libc_state_set(PB.libc);
+        const double tp2 = now_s();
         rc = gpu_particles_update(gp, &PB.scene->mq, PB.scene, scatter);
+        const double tp3 = now_s();
         if (rc) { fprintf(stderr, "gpu_particles_update: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
         PB.libc = libc_get();
+        if (f >= 2) {                                                    /* frames 0-1: first uploads */
+            t_ref_p += tp1 - tp0;
+            if (scatter) { t_bind_scatter += tp3 - tp2; n_scatter++; } else { t_bind_pos += tp3 - tp2; n_pos++; }
+            n_timed_p++;
+        }
         if (!scatter && f + 1 == frames) gpu_particles_sync_host(gp);
 
         if (PA.libc != PB.libc) { fprintf(stderr, "frame %u: drand48 stream position differs\n", f); bad++; }
@@ -883,9 +894,12 @@ static int cmd_particles(uint32_t n_sys, uint32_t per_sys, uint32_t frames, uint
         }
     }
     printf("{\"mode\": \"particles\", \"frames\": %u, \"systems\": %u, \"particle_updates\": %llu, "
-           "\"particle_structs_compared\": %llu, \"respawns\": %llu, \"stream_draws_agree\": %s, \"mismatches\": %llu}\n",
+           "\"particle_structs_compared\": %llu, \"respawns\": %llu, \"stream_draws_agree\": %s, "
+           "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame_positions_only\": %.4f, \"binding_ms_per_frame_with_particle_structs\": %.4f, "
+           "\"frames_timed\": %u, \"mismatches\": %llu}\n",
            frames, PA.n_sys, (unsigned long long)particles, (unsigned long long)respawn_checks, (unsigned long long)respawns,
-           PA.libc == PB.libc ? "true" : "false", (unsigned long long)bad);
+           PA.libc == PB.libc ? "true" : "false", n_timed_p ? 1e3 * t_ref_p / n_timed_p : 0.0, n_pos ? 1e3 * t_bind_pos / n_pos : 0.0,
+           n_scatter ? 1e3 * t_bind_scatter / n_scatter : 0.0, n_timed_p, (unsigned long long)bad);
     gpu_particles_done(gp);
     return bad ? 1 : 0;
 }

@@ -89,6 +89,7 @@ def test_particle_binding_matches_reference_particles_update(n_sys, per_sys, fra
     r = _run("particles", n_sys, per_sys, frames, seed)
     assert r["mismatches"] == 0 and r["stream_draws_agree"] is True
     assert r["respawns"] > 0 and r["particle_structs_compared"] > 0
+    assert r["frames_timed"] == frames - 2 and r["reference_ms_per_frame"] > 0 and r["binding_ms_per_frame_with_particle_structs"] > 0
 
 
 @pytest.mark.gpu
