@@ -103,7 +103,7 @@ struct gpu_scene {
     uint32_t        *char_list; uint32_t n_char, cap_char;         /* batched characters in list order (last walk) */
     /* notification mode: the engine's mutators report what they touch (gpu_scene_touch / gpu_scene_topology) and
      * a frame costs O(touched + rebuilt + host-class entities) instead of two walks over every entity3d */
-    bool            notify, topology_pending, walked, last_fast;
+    bool            notify, topology_pending, walked, last_fast, verify;
     /* verdict table by queue position: entity, slot, 'the mask bit is the answer' -- 13 bytes per entity read in order
      * by _models_render's loop instead of a 64-byte record and the 448-byte entity */
     entity3d        **vq_e; uint32_t *vq_slot; uint8_t *vq_ok; uint32_t cap_vq;
@@ -224,6 +224,7 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     if (rc) { free(gs); return rc; }
     gs->default_hook = default_hook;
     gs->free_rec = NO_REC;
+    gs->verify = getenv("GPU_SCENE_VERIFY") != NULL;
     *out = gs;
     return 0;
 }
@@ -483,6 +484,22 @@ static int push_u32(uint32_t **arr, uint32_t *n, uint32_t *cap, uint32_t v)
 bool gpu_scene_last_was_fast(const struct gpu_scene *gs) { return gs->last_fast; }
 
 void gpu_scene_set_notify(struct gpu_scene *gs, bool on) { gs->notify = on; gs->topology_pending = true; }
+void gpu_scene_set_verify(struct gpu_scene *gs, bool on) { if (gs) gs->verify = on; }
+
+/* verification mode: batched entities whose transform was written past the mutators; they join the touched list */
+static unsigned int verify_untouched(struct gpu_scene *gs)
+{
+    unsigned int found = 0;
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        if ((r->cls != 1 && r->cls != 4) || !r->e || r->pending || !transform_is_updated(&r->e->xform)) continue;
+        if (found++ < 4)
+            fprintf(stderr, "gpu_scene: entity %p (queue position %u) has xform.updated set but was not reported: a transform_* "
+                            "write without gpu_scene_touch()\n", (void *)r->e, k);
+        gpu_scene_touch(gs, r->e);
+    }
+    return found;
+}
 
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
@@ -886,7 +903,9 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->gen++;
     if (gs->notify && gs->walked && !gs->topology_pending) {
         gs->gen--;                                                /* nothing entered or left the queue: the records' generation stands */
+        const unsigned int untouched = gs->verify ? verify_untouched(gs) : 0;
         const int rc = fast_frame(gs, mq, view);
+        st->untouched_writes = untouched;
         gs->last_fast = rc == 0;
         if (rc <= 0) return rc;
         gs->gen++;

@@ -30,6 +30,8 @@ struct gpu_scene_stats {
     unsigned int attached;      /* of `batched`: entities of joint-attached subtrees, updated by the frame's second launch
                                    (gpu_scene_run_deferred, behind the pose) */
     unsigned int attach_failures;
+    unsigned int untouched_writes;  /* verification mode: batched entities found with xform.updated set that nobody had
+                                       reported (a direct transform_* write without gpu_scene_touch) -- taken in this frame */
     unsigned int registered, deleted;
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
     double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
@@ -77,6 +79,14 @@ void gpu_scene_touch(struct gpu_scene *gs, entity3d *e);
 /* entity3d_update(e, data) / entity3d_reset(e) ran e's update on the host, outside the frame loop (gpu-exports.inc.c) */
 void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_topology(struct gpu_scene *gs);
+/*
+ * Verification aid for notification mode (also: environment GPU_SCENE_VERIFY=1 at gpu_scene_init): before every fast
+ * frame, look at each batched entity once for a transform somebody wrote WITHOUT telling the binding -- the engine moves
+ * entities past its entity3d_* mutators too (transform_set_angles in the inspector, scene.c:871,934) -- report the first
+ * few on stderr, count them in stats.untouched_writes, and take them in this frame as if they had been touched.  One pass
+ * over the records and a flag read per entity3d: meant for debug builds and for finding the call sites, not for release.
+ */
+void gpu_scene_set_verify(struct gpu_scene *gs, bool on);
 /* the scene, queue and view the engine-named entry points (mq_update, view_entity_in_frustum, ...) serve */
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view);
 struct gpu_scene *gpu_scene_bound(void);

@@ -515,8 +515,8 @@ static void mk(uint8_t model, uint32_t parent, bool hooked, bool positioned)
     if (parent != NONE) meta[parent].n_children++;
 }
 
-static bool edge_no_view, edge_no_scene, edge_notify;
-static uint64_t edge_fast_frames;
+static bool edge_no_view, edge_no_scene, edge_notify, edge_direct;
+static uint64_t edge_fast_frames, edge_untouched;
 static uint32_t edge_move_lo, edge_move_hi;   /* != 0: only entities [lo, hi) move (a short slot range is uploaded) */   /* gpu_mq_update(gs, mq, NULL) / a queue whose priv is NULL */
 
 static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t frames, uint32_t expect_batched_min)
@@ -526,7 +526,9 @@ static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t fra
         for (uint32_t id = 0; id < n_ids; id++)
             if (meta[id].alive && f && (edge_move_hi ? (id >= edge_move_lo && id < edge_move_hi) : rndn(2))) {
                 vec3 off = { rndf(-1, 1), 0, rndf(-1, 1) };
-                ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
+                ref_entity3d_move(A.e[id], off);
+                if (edge_direct) transform_move(&B.e[id]->xform, off);   /* past the mutators: nobody tells the binding */
+                else entity3d_move(B.e[id], off);
             }
         vec3 cpos = { 0, 2, 40 };
         quat cq; quat_identity(cq);
@@ -540,6 +542,7 @@ static uint64_t edge_frames(struct gpu_scene *gs, const char *name, uint32_t fra
         if (rc) { fprintf(stderr, "%s: gpu_mq_update: %d (%s)\n", name, rc, clapgpu_last_error()); return 1000; }
         batched += gpu_scene_last_stats(gs)->batched;
         edge_fast_frames += gpu_scene_last_was_fast(gs);
+        edge_untouched += gpu_scene_last_stats(gs)->untouched_writes;
         bad += compare_frame(gs, f, &visible);
     }
     if (batched < expect_batched_min) { fprintf(stderr, "%s: only %llu batched updates\n", name, (unsigned long long)batched); bad++; }
@@ -599,6 +602,23 @@ static int cmd_edge(void)
         if (edge_fast_frames < 6) { fprintf(stderr, "notify: only %llu fast frames of 8\n", (unsigned long long)edge_fast_frames); bad++; }
         gpu_scene_done(gs); cases++;
     }
+    /* transforms written past the mutators (transform_move on e->xform, as the inspector's transform_set_angles does):
+     * nothing reports them; verification mode finds them before the fast frame and takes them in the same frame */
+    edge_fast_frames = 0; edge_untouched = 0; edge_direct = true;
+    {
+        struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2;
+        edge_reset();
+        for (int i = 0; i < 60; i++) mk(i % 3, i >= 10 ? (uint32_t)(i % 10) : NONE, false, true);
+        gpu_scene_set_verify(gs, true);
+        bad += edge_frames(gs, "notify + verify: unreported transform writes", 8, 60);
+        if (edge_fast_frames < 6 || !edge_untouched) {
+            fprintf(stderr, "verify: %llu fast frames of 8, %llu unreported writes found\n", (unsigned long long)edge_fast_frames,
+                    (unsigned long long)edge_untouched);
+            bad++;
+        }
+        gpu_scene_done(gs); cases++;
+    }
+    edge_direct = false;
     edge_notify = false;
     edge_no_view = false; edge_no_scene = true;
     CASE("a queue without a scene (priv == NULL)", 57, { for (int i = 0; i < 20; i++) mk(i % 3, NONE, i == 7, true); });

@@ -157,10 +157,11 @@ def test_binding_edge_cases():
     three-level tree, no view to cull against, a queue whose priv is NULL, children listed
     before their parents (the reference's one-frame lag, reproduced on the host) -- also in notification mode with
     moves only, where frames are not walked and a host child listed before its BATCHED parent has to be shown that
-    parent's previous-frame matrix and seq although every batched result is already written back --, and a queue
-    emptied and repopulated."""
+    parent's previous-frame matrix and seq although every batched result is already written back --, transforms written
+    past the mutators in notification mode with the verification aid on (found, reported, taken in the same frame), and a
+    queue emptied and repopulated."""
     r = _run("edge")
-    assert r["mismatches"] == 0 and r["cases"] == 18
+    assert r["mismatches"] == 0 and r["cases"] == 19
 
 
 @pytest.mark.gpu
