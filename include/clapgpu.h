@@ -230,7 +230,7 @@ int clapgpu_entities_update_tiles(void *stream, const clapgpu_entities *e,
 int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum);
 
 /*
- * Small frames of a HOST mirror (what libclapgpu_scene does below CLAPGPU_SCENE_ZERO_COPY_SLOTS): the frame's touched
+ * Frames of a HOST mirror without copy calls (what libclapgpu_scene does for the level layout): the frame's touched
  * entities travel as one list of 40-byte records in device-mapped host memory (clapgpu_host_malloc_mapped) and are
  * scattered into pos_scale / rot / flags by clapgpu_entities_apply_inputs(); after the update,
  * clapgpu_entities_export_rebuilt() copies the rows of mx / inv_mx / aabb / center the update rebuilt (e->rebuilt_mask)

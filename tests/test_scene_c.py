@@ -82,7 +82,7 @@ def test_scene_mirror_frames_match_oracle(mode, path, cuda_device):
     launch (clapgpu_scene_attached_update), every entity bit for bit against the oracle -- on the small-frame path (touched
     records in through mapped memory, rebuilt rows out, polled completion word) and staged through device slabs."""
     build_c_test()
-    env = dict(os.environ, CLAPGPU_SCENE_ZERO_COPY_SLOTS="0" if path == "staged" else "131072")
+    env = dict(os.environ, CLAPGPU_SCENE_ZERO_COPY_SLOTS="0" if path == "staged" else "4294967295")
     r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout and r.stdout.count("frame ok") == 8
