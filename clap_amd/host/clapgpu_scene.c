@@ -306,6 +306,8 @@ int clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const f
         memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
         memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
         s->h_flags[e->slot] = img_flags(e, xform_updated);
+        if (s->zero_copy && s->tiled)                    /* one-launch frames read the flagged slots from the image: no bulk copy */
+            __atomic_fetch_or(&s->h_touched[e->slot >> 6], 1ull << (e->slot & 63), __ATOMIC_RELAXED);
     } else {
         e->dirty |= xform_updated ? 3 : 1;               /* picked up by the re-tile's full image */
     }
@@ -645,6 +647,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         upload = n_touched != 0 && hi > lo;
         if (bits) n_bits = n_touched;
     }
+    const int bulk_any = s->bulk_dirty;
     const int bulk = s->bulk_dirty && !full;
     if (bulk) {                                          /* clapgpu_scene_entity_transform_mt wrote the image directly */
         upload = 1; lo = 0; hi = s->n_slots; n_touched = s->n_slots;   /* whole image up, flags cleared linearly */
@@ -670,7 +673,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     const size_t n = s->n_slots;
     const size_t cap = s->cap_slots;
     const int fused = s->zero_copy && s->tiled;          /* update + export (+ the touched inputs) as one launch */
-    const int by_bits = fused && upload && !full && !bulk;
+    const int by_bits = fused && upload && !full;        /* bulk: clapgpu_scene_entity_transform_mt flagged its slots itself */
     const int by_list = s->zero_copy && !fused && upload && !full && !bulk && n_touched <= s->cap_list;   /* same bytes as the image, no copy call */
     if (by_bits) {
         /* nothing to issue: h_touched says which slots of the mapped image the kernel has to take */
@@ -747,6 +750,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     }
     if (!s->zero_copy) CK(clapgpu_stream_sync(NULL));
     for (uint32_t k = 0; k < n_bits; k++) s->h_touched[s->dirty_list[k] >> 6] = 0;   /* taken by this frame's launch or by its copy */
+    if (bulk_any && s->zero_copy) memset(s->h_touched, 0, (cap / 64 + 2) * 8);   /* what clapgpu_scene_entity_transform_mt flagged */
     if (!frustum)
         memset(s->h_mask, 0, mask_words * 8);
     if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
