@@ -28,7 +28,6 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
-#include <pthread.h>
 #include <stdio.h>
 #include "clapgpu.h"
 #include "gpu-scene.h"
@@ -227,8 +226,6 @@ static int ga_reserve(struct ga_model *m, uint32_t n)
 }
 
 #define GA_PAR_MIN 65536u
-struct ga_job { struct ga_model *m; uint32_t lo, hi; };
-
 /* characters [lo, hi) of a model: T / R / S, palette and world position of every joint from the downloaded arrays */
 static void ga_joints_back(struct ga_model *m, uint32_t lo, uint32_t hi)
 {
@@ -252,12 +249,7 @@ static void ga_joints_back(struct ga_model *m, uint32_t lo, uint32_t hi)
     }
 }
 
-static void *ga_joints_back_thread(void *arg)
-{
-    struct ga_job *j = arg;
-    ga_joints_back(j->m, j->lo, j->hi);
-    return NULL;
-}
+static void ga_joints_back_range(void *m, uint32_t lo, uint32_t hi) { ga_joints_back(m, lo, hi); }
 
 static int ga_threads(void)
 {
@@ -357,19 +349,8 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
     const int nt = joints_total >= GA_PAR_MIN ? ga_threads() : 1;
     for (uint32_t k = 0; k < ga->n_models; k++) {
         struct ga_model *m = &ga->models[k];
-        if (nt > 1 && m->n >= (uint32_t)nt) {
-            struct ga_job jobs[8];
-            pthread_t th[8];
-            bool started[8] = { false };
-            for (int t = 0; t < nt; t++)
-                jobs[t] = (struct ga_job){ m, (uint32_t)((uint64_t)m->n * t / nt), (uint32_t)((uint64_t)m->n * (t + 1) / nt) };
-            for (int t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, ga_joints_back_thread, &jobs[t]) == 0;
-            ga_joints_back(m, jobs[0].lo, jobs[0].hi);
-            for (int t = 1; t < nt; t++) {
-                if (started[t]) pthread_join(th[t], NULL);
-                else ga_joints_back(m, jobs[t].lo, jobs[t].hi);
-            }
-        }
+        if (nt > 1 && m->n >= (uint32_t)nt)
+            gpu_scene_par_for(ga_joints_back_range, m, m->n, nt);
         for (uint32_t c = 0; c < m->n; c++) {
             e = m->ents[c];
             if (!(nt > 1 && m->n >= (uint32_t)nt)) ga_joints_back(m, c, c + 1);

@@ -597,6 +597,7 @@ struct par_job {
     uint32_t count;             /* out: uploaded / written back */
     int need_walk, rc;
     uint32_t *deferred; uint32_t n_deferred, cap_deferred;       /* children whose parent lies in an earlier chunk */
+    void (*range_fn)(void *, uint32_t, uint32_t); void *ctx;     /* gpu_scene_par_for */
 };
 
 static int par_threads(void)
@@ -689,6 +690,25 @@ static void par_run(void *(*fn)(void *), struct par_job *jobs, int nt)
     for (int t = workers + 1; t < nt; t++) fn(&jobs[t]);        /* jobs no worker exists for */
     while (__atomic_load_n(&g_pool.pending, __ATOMIC_ACQUIRE) > 0)   /* the caller has nothing else to do: spin */
         __builtin_ia32_pause();
+}
+
+static void *par_range(void *arg)
+{
+    struct par_job *j = arg;
+    j->range_fn(j->ctx, j->lo, j->hi);
+    return NULL;
+}
+
+/* fn(ctx, lo, hi) over [0, n) split into `threads` contiguous ranges on the binding's workers (the caller takes the first) */
+void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads)
+{
+    if (threads > 8) threads = 8;
+    if (threads < 2 || n < (uint32_t)threads) { fn(ctx, 0, n); return; }
+    struct par_job jobs[8] = { 0 };
+    for (int t = 0; t < threads; t++)
+        jobs[t] = (struct par_job){ .lo = (uint32_t)((uint64_t)n * t / threads), .hi = (uint32_t)((uint64_t)n * (t + 1) / threads),
+                                    .range_fn = fn, .ctx = ctx };
+    par_run(par_range, jobs, threads);
 }
 
 static bool self_batchable(const struct gpu_scene *gs, entity3d *e);

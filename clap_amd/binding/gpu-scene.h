@@ -87,6 +87,10 @@ void gpu_scene_topology(struct gpu_scene *gs);
  * over the records and a flag read per entity3d: meant for debug builds and for finding the call sites, not for release.
  */
 void gpu_scene_set_verify(struct gpu_scene *gs, bool on);
+
+/* The binding's worker threads (kept between frames, at most seven beside the caller) for its other translation units:
+ * fn(ctx, lo, hi) over [0, n) in `threads` contiguous ranges, the caller taking the first; returns when all are done. */
+void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads);
 /* the scene, queue and view the engine-named entry points (mq_update, view_entity_in_frustum, ...) serve */
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view);
 struct gpu_scene *gpu_scene_bound(void);
