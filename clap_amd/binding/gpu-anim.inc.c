@@ -45,8 +45,10 @@ struct ga_model {
     double              *frame_time;
     int                 *anim_of;
     void                *d_anim, *d_ftime, *d_emx, *d_trs, *d_jt, *d_jpos;
-    uint32_t            *h_anim;                          /* page-locked staging */
+    uint32_t            *h_anim;                          /* page-locked staging, device-mapped: a_* are the device's aliases */
     float               *h_ftime, *h_emx, *h_trs, *h_jt, *h_jpos;
+    void                *a_anim, *a_ftime, *a_emx, *a_trs, *a_jt, *a_jpos;
+    bool                mapped_prev;                      /* the last frame ran on the aliases: T/R/S live in h_trs */
 };
 
 struct gpu_anim {
@@ -75,6 +77,7 @@ static void ga_free_batch(struct ga_model *m)
         if (host[i]) clapgpu_host_free(host[i]);
     m->d_anim = m->d_ftime = m->d_emx = m->d_trs = m->d_jt = m->d_jpos = NULL;
     m->h_anim = NULL; m->h_ftime = m->h_emx = m->h_trs = m->h_jt = m->h_jpos = NULL;
+    m->a_anim = m->a_ftime = m->a_emx = m->a_trs = m->a_jt = m->a_jpos = NULL;
 }
 
 void gpu_anim_done(struct gpu_anim *ga)
@@ -212,20 +215,23 @@ static int ga_reserve(struct ga_model *m, uint32_t n)
     if (!m->ents || !m->prev || !m->frame_time || !m->anim_of) return _CERR_NOMEM;
     ga_free_batch(m);
     const size_t cj = (size_t)cap * m->J;
-    GA_CK(clapgpu_malloc(&m->d_anim, (size_t)cap * 4));   GA_CK(clapgpu_host_malloc((void **)&m->h_anim, (size_t)cap * 4));
-    GA_CK(clapgpu_malloc(&m->d_ftime, (size_t)cap * 4));  GA_CK(clapgpu_host_malloc((void **)&m->h_ftime, (size_t)cap * 4));
-    GA_CK(clapgpu_malloc(&m->d_emx, (size_t)cap * 64));   GA_CK(clapgpu_host_malloc((void **)&m->h_emx, (size_t)cap * 64));
-    GA_CK(clapgpu_malloc(&m->d_trs, cj * 40));            GA_CK(clapgpu_host_malloc((void **)&m->h_trs, cj * 40));
-    GA_CK(clapgpu_malloc(&m->d_jt, cj * 64));             GA_CK(clapgpu_host_malloc((void **)&m->h_jt, cj * 64));
-    GA_CK(clapgpu_malloc(&m->d_jpos, cj * 16));           GA_CK(clapgpu_host_malloc((void **)&m->h_jpos, cj * 16));
+    GA_CK(clapgpu_malloc(&m->d_anim, (size_t)cap * 4));   GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_anim, &m->a_anim, (size_t)cap * 4));
+    GA_CK(clapgpu_malloc(&m->d_ftime, (size_t)cap * 4));  GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_ftime, &m->a_ftime, (size_t)cap * 4));
+    GA_CK(clapgpu_malloc(&m->d_emx, (size_t)cap * 64));   GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_emx, &m->a_emx, (size_t)cap * 64));
+    GA_CK(clapgpu_malloc(&m->d_trs, cj * 40));            GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_trs, &m->a_trs, cj * 40));
+    GA_CK(clapgpu_malloc(&m->d_jt, cj * 64));             GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_jt, &m->a_jt, cj * 64));
+    GA_CK(clapgpu_malloc(&m->d_jpos, cj * 16));           GA_CK(clapgpu_host_malloc_mapped((void **)&m->h_jpos, &m->a_jpos, cj * 16));
     GA_CK(clapgpu_memset(m->d_jt, 0, cj * 64, NULL));
     GA_CK(clapgpu_memset(m->d_jpos, 0, cj * 16, NULL));
+    memset(m->h_jt, 0, cj * 64);
+    memset(m->h_jpos, 0, cj * 16);
     m->cap = cap;
     m->n_prev = 0;                                         /* the device T/R/S are gone: upload again */
     return 0;
 }
 
 #define GA_PAR_MIN 65536u
+#define GA_MAPPED_MAX 65536u        /* joints of a model's batch up to which the pose works on the mapped staging arrays */
 /* characters [lo, hi) of a model: T / R / S, palette and world position of every joint from the downloaded arrays */
 static void ga_joints_back(struct ga_model *m, uint32_t lo, uint32_t hi)
 {
@@ -310,7 +316,14 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
         if (!m->n) continue;
         const uint32_t J = m->J;
         const size_t cj = (size_t)m->n * J;
-        bool same = m->n == m->n_prev;
+        /* Up to GA_MAPPED_MAX joints the pose kernel reads its per-character inputs from, and writes T/R/S, palettes and joint
+         * positions straight to, the page-locked staging arrays (their device aliases): one launch and one wait instead of
+         * three or four copies up, the launch, three copies down and the wait -- 10 characters x 64 joints 0.112 -> 0.081 ms a
+         * frame (the reference's host pose: 0.061), 200 characters 0.29 -> 0.21, 500 characters 0.48 -> 0.42; at 5 000
+         * characters the copies' link rate wins (3.6 ms staged, 4.2 mapped). */
+        const bool mapped = cj <= GA_MAPPED_MAX;
+        bool same = m->n == m->n_prev && mapped == m->mapped_prev;   /* the T/R/S state lives where the last frame left it */
+        m->mapped_prev = mapped;
         for (uint32_t c = 0; same && c < m->n; c++) same = m->ents[c] == m->prev[c];
         for (uint32_t c = 0; c < m->n; c++) {
             e = m->ents[c];
@@ -324,6 +337,13 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
                     memcpy(d + 3, e->joints[j].rotation, 16);
                     memcpy(d + 7, e->joints[j].scale, 12);
                 }
+        }
+        if (mapped) {
+            const clapgpu_pose_batch pb = { .n_chars = m->n, .anim = m->a_anim, .frame_time = m->a_ftime, .entity = NULL,
+                                            .entity_mx = m->a_emx, .trs = m->a_trs, .joint_transforms = m->a_jt,
+                                            .joint_pos = m->a_jpos };
+            GA_CK(clapgpu_pose_update(NULL, &m->sk, &m->an, &pb));
+            continue;
         }
         GA_CK(clapgpu_memcpy_h2d(m->d_anim, m->h_anim, (size_t)m->n * 4, NULL));
         GA_CK(clapgpu_memcpy_h2d(m->d_ftime, m->h_ftime, (size_t)m->n * 4, NULL));
