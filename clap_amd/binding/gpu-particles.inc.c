@@ -23,6 +23,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
 #include "clapgpu.h"
 
 struct gpu_particles {
@@ -32,10 +34,18 @@ struct gpu_particles {
     clapgpu_particles       d;                       /* device descriptor */
     void                    *d_sys;
     float                   *h_pos, *h_vel, *h_mx;   /* page-locked staging */
-    uint32_t                cap_n;
+    uint32_t                cap_n, cap_sys_dev;      /* particle slots / systems the buffers hold */
     uint64_t                h_rng[2];
     bool                    host_stale;              /* p->pos / p->velocity older than the device copy */
+    /* Up to GP_MAPPED_MAX particle slots the batch LIVES in page-locked, device-mapped host memory: positions, velocities,
+     * the system table, billboard matrices and the libc stream state are read and written by the kernels through their
+     * device aliases -- a frame is the three launches and one wait, none of the two copies up and three or four down that
+     * cost a testbed-sized frame (20 systems, 7 k particles) 0.25 ms against the reference's 0.10. */
+    bool                    mapped;
+    clapgpu_particle_system *m_sys;                  /* mapped copy of sys_host */
+    uint64_t                *m_rng;                  /* mapped libc stream state (2 words) */
 };
+#define GP_MAPPED_MAX 65536u
 
 #define GP_CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
@@ -66,14 +76,19 @@ static void gp_free_device(struct gpu_particles *gp)
     void *dev[] = { gp->d_sys, (void *)gp->d.row_sys, gp->d.pos, gp->d.vel, gp->d.rng_state, gp->d.billboard_mx,
                     gp->d.respawn_mask, gp->d.respawn_row_pop, gp->d.respawn_list, gp->d.respawn_count, gp->d.scratch,
                     gp->d.respawn_groups };
+    if (gp->mapped)                                  /* these five are device aliases of the host buffers freed below */
+        dev[0] = dev[2] = dev[3] = dev[4] = dev[5] = NULL;
     for (unsigned i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
         if (dev[i]) clapgpu_free(dev[i]);
-    void *host[] = { gp->h_pos, gp->h_vel, gp->h_mx };
+    void *host[] = { gp->h_pos, gp->h_vel, gp->h_mx, gp->m_sys, gp->m_rng };
     for (unsigned i = 0; i < sizeof(host) / sizeof(host[0]); i++)
         if (host[i]) clapgpu_host_free(host[i]);
     memset(&gp->d, 0, sizeof(gp->d));
     gp->d_sys = NULL;
     gp->h_pos = gp->h_vel = gp->h_mx = NULL;
+    gp->m_sys = NULL; gp->m_rng = NULL;
+    gp->mapped = false;
+    gp->cap_n = gp->cap_sys_dev = 0;
 }
 
 void gpu_particles_done(struct gpu_particles *gp)
@@ -95,7 +110,10 @@ static void gp_sys_record(clapgpu_particle_system *r, const particle_system *ps,
     r->first = first; r->count = ps->count;
 }
 
-/* (Re)build the device batch from the host lists: layout, particle state, work space. */
+/* (Re)build the device batch from the host lists: layout, particle state, work space.  Buffers are kept while they are
+ * large enough (a system appearing or dying re-lays the batch out, it should not cost a dozen allocations). */
+static uint32_t gp_pow2(uint32_t x, uint32_t lo) { uint32_t p = lo; while (p < x) p *= 2; return p; }
+
 static int gp_rebuild(struct gpu_particles *gp)
 {
     uint32_t n = 0;
@@ -104,14 +122,44 @@ static int gp_rebuild(struct gpu_particles *gp)
         n += (gp->ps[s]->count + 63u) & ~63u;
     }
     if (n == 0) n = 64;
-    gp_free_device(gp);
-    gp->n = gp->cap_n = n;
     const uint32_t rows = n / 64;
     uint32_t *row_sys = malloc(rows * sizeof(*row_sys));
     if (!row_sys) return _CERR_NOMEM;
-    GP_CK(clapgpu_host_malloc((void **)&gp->h_pos, (size_t)n * 12));
-    GP_CK(clapgpu_host_malloc((void **)&gp->h_vel, (size_t)n * 12));
-    GP_CK(clapgpu_host_malloc((void **)&gp->h_mx, (size_t)(gp->n_sys ? gp->n_sys : 1) * 64));
+    if (!gp->d.pos || n > gp->cap_n || gp->n_sys > gp->cap_sys_dev) {
+        gp_free_device(gp);
+        const uint32_t cap = gp_pow2(n, 4096), cap_rows = cap / 64, cap_sys = gp_pow2(gp->n_sys ? gp->n_sys : 1, 16);
+        const bool mapped = cap <= GP_MAPPED_MAX && !getenv("GPU_PARTICLES_STAGED");
+        const size_t sys_bytes = (size_t)cap_sys * sizeof(clapgpu_particle_system);
+        if (mapped) {
+            void *a_pos = NULL, *a_vel = NULL, *a_mx = NULL, *a_sys = NULL, *a_rng = NULL;
+            GP_CK(clapgpu_host_malloc_mapped((void **)&gp->h_pos, &a_pos, (size_t)cap * 12));
+            GP_CK(clapgpu_host_malloc_mapped((void **)&gp->h_vel, &a_vel, (size_t)cap * 12));
+            GP_CK(clapgpu_host_malloc_mapped((void **)&gp->h_mx, &a_mx, (size_t)cap_sys * 64));
+            GP_CK(clapgpu_host_malloc_mapped((void **)&gp->m_sys, &a_sys, sys_bytes));
+            GP_CK(clapgpu_host_malloc_mapped((void **)&gp->m_rng, &a_rng, 16));
+            gp->mapped = true;
+            gp->d_sys = a_sys; gp->d.pos = a_pos; gp->d.vel = a_vel; gp->d.rng_state = a_rng; gp->d.billboard_mx = a_mx;
+        } else {
+            GP_CK(clapgpu_host_malloc((void **)&gp->h_pos, (size_t)cap * 12));
+            GP_CK(clapgpu_host_malloc((void **)&gp->h_vel, (size_t)cap * 12));
+            GP_CK(clapgpu_host_malloc((void **)&gp->h_mx, (size_t)cap_sys * 64));
+            GP_CK(clapgpu_malloc(&gp->d_sys, sys_bytes));
+            GP_CK(clapgpu_malloc((void **)&gp->d.pos, (size_t)cap * 12));
+            GP_CK(clapgpu_malloc((void **)&gp->d.vel, (size_t)cap * 12));
+            GP_CK(clapgpu_malloc((void **)&gp->d.rng_state, 16));
+            GP_CK(clapgpu_malloc((void **)&gp->d.billboard_mx, (size_t)cap_sys * 64));
+        }
+        GP_CK(clapgpu_malloc((void **)&gp->d.row_sys, (size_t)cap_rows * 4));
+        GP_CK(clapgpu_malloc((void **)&gp->d.respawn_mask, (size_t)cap_rows * 8));
+        GP_CK(clapgpu_malloc((void **)&gp->d.respawn_row_pop, ((size_t)cap_rows + 15) / 16 * 16));
+        GP_CK(clapgpu_malloc((void **)&gp->d.respawn_list, (size_t)cap * 4));
+        GP_CK(clapgpu_malloc((void **)&gp->d.respawn_count, 4));
+        GP_CK(clapgpu_malloc(&gp->d.scratch, clapgpu_visible_scratch_bytes(cap) + 16));
+        GP_CK(clapgpu_malloc((void **)&gp->d.respawn_groups, CLAPGPU_RESPAWN_GROUP_WORDS * 4));
+        gp->cap_n = cap;
+        gp->cap_sys_dev = cap_sys;
+    }
+    gp->n = n;
     memset(gp->h_pos, 0, (size_t)n * 12);
     memset(gp->h_vel, 0, (size_t)n * 12);
     for (uint32_t r = 0; r < rows; r++) row_sys[r] = 0;
@@ -126,26 +174,15 @@ static int gp_rebuild(struct gpu_particles *gp)
             i++;
         }
     }
-    const size_t sys_bytes = (size_t)(gp->n_sys ? gp->n_sys : 1) * sizeof(clapgpu_particle_system);
-    GP_CK(clapgpu_malloc(&gp->d_sys, sys_bytes));
-    GP_CK(clapgpu_malloc((void **)&gp->d.row_sys, (size_t)rows * 4));
-    GP_CK(clapgpu_malloc((void **)&gp->d.pos, (size_t)n * 12));
-    GP_CK(clapgpu_malloc((void **)&gp->d.vel, (size_t)n * 12));
-    GP_CK(clapgpu_malloc((void **)&gp->d.rng_state, 16));
-    GP_CK(clapgpu_malloc((void **)&gp->d.billboard_mx, (size_t)(gp->n_sys ? gp->n_sys : 1) * 64));
-    GP_CK(clapgpu_malloc((void **)&gp->d.respawn_mask, (size_t)rows * 8));
-    GP_CK(clapgpu_malloc((void **)&gp->d.respawn_row_pop, ((size_t)rows + 15) / 16 * 16));
-    GP_CK(clapgpu_malloc((void **)&gp->d.respawn_list, (size_t)n * 4));
-    GP_CK(clapgpu_malloc((void **)&gp->d.respawn_count, 4));
-    GP_CK(clapgpu_malloc(&gp->d.scratch, clapgpu_visible_scratch_bytes(n) + 16));
-    GP_CK(clapgpu_malloc((void **)&gp->d.respawn_groups, CLAPGPU_RESPAWN_GROUP_WORDS * 4));
     GP_CK(clapgpu_memset(gp->d.respawn_groups, 0, CLAPGPU_RESPAWN_GROUP_WORDS * 4, NULL));
     GP_CK(clapgpu_memset(gp->d.respawn_mask, 0, (size_t)rows * 8, NULL));
     GP_CK(clapgpu_memset(gp->d.respawn_row_pop, 0, ((size_t)rows + 15) / 16 * 16, NULL));
     GP_CK(clapgpu_memset(gp->d.respawn_count, 0, 4, NULL));
     GP_CK(clapgpu_memcpy_h2d((void *)gp->d.row_sys, row_sys, (size_t)rows * 4, NULL));
-    GP_CK(clapgpu_memcpy_h2d(gp->d.pos, gp->h_pos, (size_t)n * 12, NULL));
-    GP_CK(clapgpu_memcpy_h2d(gp->d.vel, gp->h_vel, (size_t)n * 12, NULL));
+    if (!gp->mapped) {
+        GP_CK(clapgpu_memcpy_h2d(gp->d.pos, gp->h_pos, (size_t)n * 12, NULL));
+        GP_CK(clapgpu_memcpy_h2d(gp->d.vel, gp->h_vel, (size_t)n * 12, NULL));
+    }
     GP_CK(clapgpu_stream_sync(NULL));
     free(row_sys);
     gp->d.n = n;
@@ -159,9 +196,11 @@ static int gp_rebuild(struct gpu_particles *gp)
 int gpu_particles_sync_host(struct gpu_particles *gp)
 {
     if (!gp || !gp->host_stale) return 0;
-    GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
-    GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
-    GP_CK(clapgpu_stream_sync(NULL));
+    if (!gp->mapped) {                                /* mapped: h_pos / h_vel ARE the batch, and every update has waited for its kernels */
+        GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_stream_sync(NULL));
+    }
     for (uint32_t s = 0; s < gp->n_sys; s++) {
         if (!gp->ps[s]) continue;
         particle *p;
@@ -179,6 +218,9 @@ int gpu_particles_sync_host(struct gpu_particles *gp)
 int gpu_particles_update(struct gpu_particles *gp, struct mq *mq, struct scene *scene, bool scatter)
 {
     if (!gp || !mq || !scene) return _CERR_INVALID_ARGUMENTS;
+    const bool timing = getenv("GPU_PARTICLES_TIMING") != NULL;
+    struct timespec tp_[4];
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &tp_[0]);
 
     /* the queue's particle systems, list order */
     uint32_t k = 0;
@@ -224,17 +266,27 @@ int gpu_particles_update(struct gpu_particles *gp, struct mq *mq, struct scene *
     for (uint32_t s = 0; s < gp->n_sys; s++)
         gp_sys_record(&gp->sys_host[s], gp->ps[s], gp->sys_host[s].first);
     gp->h_rng[0] = gp->h_rng[1] = gp_libc_state_get();
-    GP_CK(clapgpu_memcpy_h2d(gp->d_sys, gp->sys_host, (size_t)gp->n_sys * sizeof(clapgpu_particle_system), NULL));
-    GP_CK(clapgpu_memcpy_h2d(gp->d.rng_state, gp->h_rng, 16, NULL));
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &tp_[1]);
+    if (gp->mapped) {
+        memcpy(gp->m_sys, gp->sys_host, (size_t)gp->n_sys * sizeof(clapgpu_particle_system));
+        gp->m_rng[0] = gp->m_rng[1] = gp->h_rng[0];
+        GP_CK(clapgpu_particles_update(NULL, &gp->d, (const float *)scene->camera->view.main.view_mx));
+        GP_CK(clapgpu_stream_sync(NULL));
+        gp->h_rng[0] = gp->m_rng[0]; gp->h_rng[1] = gp->m_rng[1];
+    } else {
+        GP_CK(clapgpu_memcpy_h2d(gp->d_sys, gp->sys_host, (size_t)gp->n_sys * sizeof(clapgpu_particle_system), NULL));
+        GP_CK(clapgpu_memcpy_h2d(gp->d.rng_state, gp->h_rng, 16, NULL));
 
-    GP_CK(clapgpu_particles_update(NULL, &gp->d, (const float *)scene->camera->view.main.view_mx));
+        GP_CK(clapgpu_particles_update(NULL, &gp->d, (const float *)scene->camera->view.main.view_mx));
 
-    GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
-    GP_CK(clapgpu_memcpy_d2h(gp->h_mx, gp->d.billboard_mx, (size_t)gp->n_sys * 64, NULL));
-    GP_CK(clapgpu_memcpy_d2h(gp->h_rng, gp->d.rng_state, 16, NULL));
-    if (scatter) GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
-    GP_CK(clapgpu_stream_sync(NULL));
+        GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_memcpy_d2h(gp->h_mx, gp->d.billboard_mx, (size_t)gp->n_sys * 64, NULL));
+        GP_CK(clapgpu_memcpy_d2h(gp->h_rng, gp->d.rng_state, 16, NULL));
+        if (scatter) GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_stream_sync(NULL));
+    }
 
+    if (timing) clock_gettime(CLOCK_MONOTONIC, &tp_[2]);
     gp_libc_state_set(gp->h_rng[1] & 0xffffffffffffull);                    /* other drand48() users go on from here */
     for (uint32_t s = 0; s < gp->n_sys; s++) {
         particle_system *ps = gp->ps[s];
@@ -252,6 +304,13 @@ int gpu_particles_update(struct gpu_particles *gp, struct mq *mq, struct scene *
         }
     }
     gp->host_stale = !scatter;
+    if (timing) {
+        clock_gettime(CLOCK_MONOTONIC, &tp_[3]);
+        double d[3];
+        for (int i = 0; i < 3; i++) d[i] = (tp_[i + 1].tv_sec - tp_[i].tv_sec) * 1e3 + (tp_[i + 1].tv_nsec - tp_[i].tv_nsec) * 1e-6;
+        fprintf(stderr, "gpu_particles_update: walk + records %.3f  device %.3f  back into the systems %.3f ms (%s)\n", d[0], d[1], d[2],
+                gp->mapped ? "mapped" : "staged");
+    }
     return 0;
 }
 
@@ -272,12 +331,16 @@ int gpu_particle_system_position(struct gpu_particles *gp, particle_system *ps, 
     transform_set_pos(&ps->e->xform, center);
     /* the system's slice of the device copy: down, the reference's own vec3_add, up */
     const size_t first = gp->sys_host[s].first, bytes = (size_t)ps->count * 12;
-    GP_CK(clapgpu_memcpy_d2h(gp->h_pos + 3 * first, gp->d.pos + 3 * first, bytes, NULL));
-    GP_CK(clapgpu_stream_sync(NULL));
+    if (!gp->mapped) {
+        GP_CK(clapgpu_memcpy_d2h(gp->h_pos + 3 * first, gp->d.pos + 3 * first, bytes, NULL));
+        GP_CK(clapgpu_stream_sync(NULL));
+    }
     for (size_t i = 0; i < ps->count; i++)
         vec3_add(gp->h_pos + 3 * (first + i), gp->h_pos + 3 * (first + i), delta);
-    GP_CK(clapgpu_memcpy_h2d(gp->d.pos + 3 * first, gp->h_pos + 3 * first, bytes, NULL));
-    GP_CK(clapgpu_stream_sync(NULL));
+    if (!gp->mapped) {
+        GP_CK(clapgpu_memcpy_h2d(gp->d.pos + 3 * first, gp->h_pos + 3 * first, bytes, NULL));
+        GP_CK(clapgpu_stream_sync(NULL));
+    }
     gp->host_stale = true;
     return 0;
 }
