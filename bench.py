@@ -213,7 +213,7 @@ def dropin_boundary():
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     # particle systems: one particles_update hook per system (core/particle.c:89-140) against gpu_particles_update
-    for systems, per, frames in ((64, 1024, 14), (1024, 1024, 8)):
+    for systems, per, frames in ((48, 1024, 32), (1024, 1024, 8)):
         key = f"{systems}_particle_systems_x_{per}"
         try:
             p = subprocess.run([exe, "particles", str(systems), str(per), str(frames), "4"], capture_output=True, text=True, timeout=240)
