@@ -219,7 +219,7 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
 constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
 constexpr int BP_TILE = 16;            // bodies per wavefront of the search
 constexpr int BP_WORK = 512;           // candidate entries listed per tile and round (256: spheres -2 us, capsules +5 us)
-constexpr int BP_EMIT_TILE = 256;      // bodies per tile of the pair-offset scan (= emit block)
+constexpr int BP_EMIT_TILE = 1024;     // bodies per tile of the pair-offset scan (= emit block; 256: +3 us, four times the look-back words)
 #ifndef BP_SEARCH_IN_FLIGHT
 #define BP_SEARCH_IN_FLIGHT 1            // candidate records gathered per lane and round
 #endif
