@@ -360,14 +360,15 @@ __device__ __forceinline__ uint32_t lb_exclusive(uint64_t *state, uint32_t b, ui
     return excl;
 }
 
-// Launch 2: wave w = block bucket w; a workgroup's four block totals enter the look-back scan as one tile
-__global__ __launch_bounds__(PB)
+// Launch 2: wave w = block bucket w; a workgroup's BP_CELLS_BLOCK / 64 block totals enter the look-back scan as one tile
+constexpr int BP_CELLS_BLOCK = 1024;   // 16 buckets a workgroup: 512 look-back words at 262 144 bodies (256: 2 048 words, +2 us)
+__global__ __launch_bounds__(BP_CELLS_BLOCK)
 void k_bp_cells(BpK k)
 {
-    __shared__ uint32_t tot[PB / WAVE];
+    __shared__ uint32_t tot[BP_CELLS_BLOCK / WAVE];
     __shared__ uint32_t excl_s;
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
-    const uint32_t b = blockIdx.x * (PB / WAVE) + wave;
+    const uint32_t b = blockIdx.x * (BP_CELLS_BLOCK / WAVE) + wave;
     uint32_t block_total = 0;
     if (b <= k.mask) {
         const uint32_t c = k.cell_cnt[(size_t)b * 64 + lane];
@@ -387,7 +388,7 @@ void k_bp_cells(BpK k)
     if (wave == 0) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int q = 0; q < PB / WAVE; q++) sum += tot[q];
+        for (int q = 0; q < BP_CELLS_BLOCK / WAVE; q++) sum += tot[q];
         const uint32_t excl = lb_exclusive(k.lb_cells, blockIdx.x, sum, k.ctrl[CTRL_EPOCH], k.ctrl + CTRL_STATUS);
         if (lane == 0) {
             excl_s = excl;
@@ -1236,7 +1237,7 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
     if (!statics) { k.n_static = 0; k.n_large = 0; if (static_pair_total) CLAPGPU_HIP(hipMemsetAsync(static_pair_total, 0, 4, s)); }
     hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_bin");
-    hipLaunchKernelGGL(k_bp_cells, dim3((bp->buckets + PB / WAVE - 1) / (PB / WAVE)), dim3(PB), 0, s, k);
+    hipLaunchKernelGGL(k_bp_cells, dim3((bp->buckets + BP_CELLS_BLOCK / WAVE - 1) / (BP_CELLS_BLOCK / WAVE)), dim3(BP_CELLS_BLOCK), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_cells");
     hipLaunchKernelGGL(k_bp_scatter, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
