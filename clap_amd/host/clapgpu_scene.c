@@ -36,7 +36,8 @@ static inline uint32_t img_flags(const struct ent *e, int xform_updated)
 
 struct clapgpu_scene {
     struct ent *e;  uint32_t n_handles, cap_handles;
-    uint32_t   *free_list;  uint32_t n_free;
+    uint32_t   *free_list;  uint32_t n_free, cap_free;
+    uint32_t   *dead_list;  uint32_t n_dead, cap_dead;           /* deleted since the last re-tile: handles not reusable yet */
     uint32_t   *dirty_list; uint32_t n_dirty, cap_dirty;
     float      *models;     uint32_t n_models, cap_models;       /* [m][8] model_table rows */
     int         topology_dirty, models_dirty, tiled, bulk_dirty;
@@ -109,8 +110,14 @@ static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
 {
     if (!s->e[h].dirty) {
         if (s->n_dirty == s->cap_dirty) {
-            s->cap_dirty = s->cap_dirty ? 2 * s->cap_dirty : 1024;
-            s->dirty_list = realloc(s->dirty_list, s->cap_dirty * sizeof(uint32_t));
+            const uint32_t cap = s->cap_dirty ? 2 * s->cap_dirty : 1024;
+            uint32_t *q = realloc(s->dirty_list, cap * sizeof(uint32_t));
+            if (!q) {                                            /* out of memory: the next frame uploads everything instead */
+                s->e[h].dirty |= xform_updated ? 3 : 1;
+                s->topology_dirty = 1;
+                return;
+            }
+            s->dirty_list = q; s->cap_dirty = cap;
         }
         s->dirty_list[s->n_dirty++] = h;
     }
@@ -183,7 +190,7 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (!s) return;
     free_device(s);
     if (s->d_models) clapgpu_free(s->d_models);
-    free(s->e); free(s->free_list); free(s->dirty_list); free(s->models); free(s->slot_handle);
+    free(s->e); free(s->free_list); free(s->dead_list); free(s->dirty_list); free(s->models); free(s->slot_handle);
     free(s->tile_row_start_host); free(s->level_start_host);
     if (s->h_in) clapgpu_host_free(s->h_in);
     if (s->h_out) clapgpu_host_free(s->h_out);
@@ -202,9 +209,10 @@ int clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aabb
 {
     if (!s || !aabb || !model) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (s->n_models == s->cap_models) {
-        s->cap_models = s->cap_models ? 2 * s->cap_models : 16;
-        s->models = realloc(s->models, (size_t)s->cap_models * 8 * sizeof(float));
-        if (!s->models) return CLAPGPU_ERR_NOMEM;
+        const uint32_t cap = s->cap_models ? 2 * s->cap_models : 16;
+        float *q = realloc(s->models, (size_t)cap * 8 * sizeof(float));
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->models = q; s->cap_models = cap;
     }
     float *row = s->models + 8 * (size_t)s->n_models;
     uint32_t skip = skip_aabb ? 1u : 0u;
@@ -224,9 +232,10 @@ int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint3
         h = s->free_list[--s->n_free];
     } else {
         if (s->n_handles == s->cap_handles) {
-            s->cap_handles = s->cap_handles ? 2 * s->cap_handles : 1024;
-            s->e = realloc(s->e, (size_t)s->cap_handles * sizeof(struct ent));
-            if (!s->e) return CLAPGPU_ERR_NOMEM;
+            const uint32_t cap = s->cap_handles ? 2 * s->cap_handles : 1024;
+            struct ent *q = realloc(s->e, (size_t)cap * sizeof(struct ent));
+            if (!q) return CLAPGPU_ERR_NOMEM;
+            s->e = q; s->cap_handles = cap;
         }
         h = s->n_handles++;
     }
@@ -248,13 +257,40 @@ int clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle)
 {
     struct ent *e = get(s, handle);
     if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    for (uint32_t h = 0; h < s->n_handles; h++)         /* orphans become roots, like a NULL e->parent */
-        if (s->e[h].live && s->e[h].parent == handle)
-            s->e[h].parent = CLAPGPU_NO_ENTITY;
+    /* Its children become roots (like a NULL e->parent) -- found by ONE pass for all of a frame's deletions when the layout
+     * is rebuilt (release_dead), not by a pass over every entity per deletion; until then the handle is not handed out again,
+     * so a child's parent field cannot come to name a stranger. */
+    if (s->n_dead == s->cap_dead) {
+        const uint32_t cap = s->cap_dead ? 2 * s->cap_dead : 256;
+        uint32_t *q = realloc(s->dead_list, (size_t)cap * sizeof(uint32_t));
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->dead_list = q; s->cap_dead = cap;
+    }
     e->live = 0;
-    s->free_list = realloc(s->free_list, ((size_t)s->n_free + 1) * sizeof(uint32_t));
-    s->free_list[s->n_free++] = handle;
+    s->dead_list[s->n_dead++] = handle;
     s->topology_dirty = 1;
+    return CLAPGPU_OK;
+}
+
+/* before a re-tile: orphans of the entities deleted since the last one become roots, their handles reusable */
+static int release_dead(clapgpu_scene *s)
+{
+    if (!s->n_dead) return CLAPGPU_OK;
+    for (uint32_t h = 0; h < s->n_handles; h++) {
+        struct ent *c = &s->e[h];
+        if (c->live && c->parent != CLAPGPU_NO_ENTITY && !(c->parent < s->n_handles && s->e[c->parent].live))
+            c->parent = CLAPGPU_NO_ENTITY;
+    }
+    if (s->n_free + s->n_dead > s->cap_free) {
+        uint32_t cap = s->cap_free ? s->cap_free : 256;
+        while (cap < s->n_free + s->n_dead) cap *= 2;
+        uint32_t *q = realloc(s->free_list, (size_t)cap * sizeof(uint32_t));
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->free_list = q; s->cap_free = cap;
+    }
+    memcpy(s->free_list + s->n_free, s->dead_list, (size_t)s->n_dead * sizeof(uint32_t));
+    s->n_free += s->n_dead;
+    s->n_dead = 0;
     return CLAPGPU_OK;
 }
 
@@ -484,6 +520,7 @@ static uint32_t compute_depths(clapgpu_scene *s, uint32_t *depth, uint32_t *root
 
 static int retile(clapgpu_scene *s)
 {
+    CK(release_dead(s));
     const uint32_t H = s->n_handles;
     uint32_t *depth = malloc(((size_t)H + 1) * 4), *root = malloc(((size_t)H + 1) * 4);
     uint32_t *tree_of = malloc(((size_t)H + 1) * 4);
