@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 OK = 0
 ERR_NOMEM = -1
@@ -228,6 +228,9 @@ SYMBOLS = {
     "clapgpu_bp_static_aabb": (C.c_void_p, [C.c_void_p]),
     "clapgpu_contacts_geoms": (C.c_int, [C.c_void_p, C.POINTER(Geoms), C.POINTER(Geoms), C.c_void_p, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_contacts_geoms_both": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Geoms), C.POINTER(Geoms), C.c_void_p, C.c_void_p,
+                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     "clapgpu_sweep_capsules": (C.c_int, [C.c_void_p, C.POINTER(Geoms), C.POINTER(Geoms), C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_bodies_rotate_from_entities": (C.c_int, [C.c_void_p, C.POINTER(Bodies), C.POINTER(Entities), C.c_uint32,

@@ -23,7 +23,13 @@ extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double 
             if (f->bp) {
                 FR(clapgpu_bp_collide(stream, f->bp, f->bodies->n, f->bodies->aabb, f->pairs, f->pair_capacity, f->pair_total,
                                       f->static_pairs, f->static_pair_capacity, f->static_pair_total));
-                if (f->body_geoms && f->contacts) {
+                if (f->body_geoms && f->contacts && f->static_geoms && f->static_contacts && f->static_pair_total &&
+                    f->pair_capacity < (1u << 24) && f->static_pair_capacity < (1u << 24)) {
+                    FR(clapgpu_contacts_geoms_both(stream, f->bp, f->body_geoms, f->static_geoms, f->pairs, f->pair_total,
+                                                   f->pair_capacity, f->contacts, f->contact_total, f->static_pairs,
+                                                   f->static_pair_total, f->static_pair_capacity, f->static_contacts,
+                                                   f->static_contact_total, f->bodies->bflags));
+                } else if (f->body_geoms && f->contacts) {
                     FR(clapgpu_contacts_geoms(stream, f->body_geoms, f->body_geoms, f->pairs, f->pair_total, f->pair_capacity,
                                               f->contacts, f->contact_total, f->bodies->bflags, f->bodies->bflags));
                     if (f->static_geoms && f->static_contacts && f->static_pair_total)

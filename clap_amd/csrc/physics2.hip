@@ -223,7 +223,7 @@ constexpr int BP_EMIT_TILE = 1024;     // bodies per tile of the pair-offset sca
 #ifndef BP_SEARCH_IN_FLIGHT
 #define BP_SEARCH_IN_FLIGHT 1            // candidate records gathered per lane and round
 #endif
-constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3;     // the frame counter lives on the device: a captured graph replays the same arguments
+constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3, CTRL_CONTACT_WORD = 8;   // [8..9]: clapgpu_contacts_geoms_both's ticket + counts, zero between launches     // the frame counter lives on the device: a captured graph replays the same arguments
 
 __host__ __device__ __forceinline__ uint32_t block_hash(int32_t bx, int32_t by, int32_t bz, uint32_t mask)
 {
@@ -801,6 +801,44 @@ __device__ __forceinline__ void contact_surface2(clapgpu_contact2 &c, const doub
     c.mu = mu; c.bounce = bounce; c.bounce_vel = bounce_vel; c.soft_erp = soft_erp; c.soft_cfm = soft_cfm;
 }
 
+// one candidate pair -> its record; true if the pair produced contacts (or is flagged deep)
+__device__ __forceinline__ bool contact_of_pair(const GeomsK &A, const GeomsK &B, const uint2 pr, clapgpu_contact2 *out,
+                                                uint32_t *flags_a, uint32_t *flags_b)
+{
+    clapgpu_contact2 c;
+    memset(&c, 0, sizeof(c));
+    bool counted = false;
+    if (pr.x < A.n && pr.y < B.n) {
+        phd::Geom ga, gb;
+        load_geom(A, pr.x, ga);
+        load_geom(B, pr.y, gb);
+        phd::CGeom c0, c1;
+        memset(&c0, 0, sizeof(c0));
+        memset(&c1, 0, sizeof(c1));
+        const int nc = phd::collide(ga, gb, c0, c1);
+        if (nc < 0) {
+            c.nc = CLAPGPU_CONTACT_DEEP;
+            counted = true;
+        } else if (nc > 0) {
+            for (int a = 0; a < 3; a++) { c.pos[a] = c0.pos[a]; c.normal[a] = c0.normal[a]; }
+            c.depth = c0.depth;
+            if (nc > 1) {
+                for (int a = 0; a < 3; a++) { c.pos2[a] = c1.pos[a]; c.normal2[a] = c1.normal[a]; }
+                c.depth2 = c1.depth;
+            }
+            contact_surface2(c, (A.material && B.material) ? A.material + 5 * (size_t)pr.x : nullptr,
+                             (A.material && B.material) ? B.material + 5 * (size_t)pr.y : nullptr);
+            c.nc = (uint32_t)nc;
+            counted = true;
+            // plain read-modify-write: every writer of this launch sets the same bit and nothing else changes the word
+            if (flags_a && !(flags_a[pr.x] & CLAPGPU_BODY_HAS_JOINT)) flags_a[pr.x] |= CLAPGPU_BODY_HAS_JOINT;
+            if (flags_b && !(flags_b[pr.y] & CLAPGPU_BODY_HAS_JOINT)) flags_b[pr.y] |= CLAPGPU_BODY_HAS_JOINT;
+        }
+    }
+    *out = c;
+    return counted;
+}
+
 __global__ __launch_bounds__(PB)
 void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity,
                       clapgpu_contact2 *out, uint32_t *contact_total, uint32_t *flags_a, uint32_t *flags_b)
@@ -811,43 +849,50 @@ void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pa
     uint32_t np = *pair_total;
     if (np > capacity) np = capacity;
     uint32_t mine = 0;
-    for (uint32_t p = blockIdx.x * PB + threadIdx.x; p < np; p += gridDim.x * PB) {
-        const uint2 pr = pairs[p];
-        clapgpu_contact2 c;
-        memset(&c, 0, sizeof(c));
-        if (pr.x < A.n && pr.y < B.n) {
-            phd::Geom ga, gb;
-            load_geom(A, pr.x, ga);
-            load_geom(B, pr.y, gb);
-            phd::CGeom c0, c1;
-            memset(&c0, 0, sizeof(c0));
-            memset(&c1, 0, sizeof(c1));
-            const int nc = phd::collide(ga, gb, c0, c1);
-            if (nc < 0) {
-                c.nc = CLAPGPU_CONTACT_DEEP;
-                mine++;
-            } else if (nc > 0) {
-                for (int a = 0; a < 3; a++) { c.pos[a] = c0.pos[a]; c.normal[a] = c0.normal[a]; }
-                c.depth = c0.depth;
-                if (nc > 1) {
-                    for (int a = 0; a < 3; a++) { c.pos2[a] = c1.pos[a]; c.normal2[a] = c1.normal[a]; }
-                    c.depth2 = c1.depth;
-                }
-                contact_surface2(c, (A.material && B.material) ? A.material + 5 * (size_t)pr.x : nullptr,
-                                 (A.material && B.material) ? B.material + 5 * (size_t)pr.y : nullptr);
-                c.nc = (uint32_t)nc;
-                mine++;
-                // plain read-modify-write: every writer of this launch sets the same bit and nothing else changes the word
-                if (flags_a && !(flags_a[pr.x] & CLAPGPU_BODY_HAS_JOINT)) flags_a[pr.x] |= CLAPGPU_BODY_HAS_JOINT;
-                if (flags_b && !(flags_b[pr.y] & CLAPGPU_BODY_HAS_JOINT)) flags_b[pr.y] |= CLAPGPU_BODY_HAS_JOINT;
-            }
-        }
-        out[p] = c;
-    }
+    for (uint32_t p = blockIdx.x * PB + threadIdx.x; p < np; p += gridDim.x * PB)
+        mine += contact_of_pair(A, B, pairs[p], out + p, flags_a, flags_b);
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if (lane_id() == 0 && mine) atomicAdd(&block_hits, mine);
     __syncthreads();
     if (threadIdx.x == 0 && block_hits && contact_total) atomicAdd(contact_total, block_hits);
+}
+
+// near_callback over BOTH lists of a step (bodies x bodies, bodies x statics: physics.c:751-753) in one launch, and
+// without a cleared counter in front of it: a workgroup adds (1, its static count, its body count) to ONE 64-bit word with one
+// atomic; the workgroup that finds every other ticket already taken holds the totals in what came back, stores them and
+// leaves the word at zero for the next launch.  Two launches and two counter fills were 62 us of a frame for 47 us of work.
+__global__ __launch_bounds__(PB)
+void k_contacts_geoms_both(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity,
+                           clapgpu_contact2 *out, uint32_t *contact_total, const uint2 *spairs, const uint32_t *spair_total,
+                           uint32_t scapacity, clapgpu_contact2 *sout, uint32_t *scontact_total, uint32_t *flags,
+                           unsigned long long *word)
+{
+    __shared__ uint32_t block_hits[2];
+    if (threadIdx.x < 2) block_hits[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t nb = *pair_total, ns = spair_total ? *spair_total : 0u;
+    if (nb > capacity) nb = capacity;
+    if (ns > scapacity) ns = scapacity;
+    uint32_t mine_b = 0, mine_s = 0;
+    for (uint32_t p = blockIdx.x * PB + threadIdx.x; p < nb + ns; p += gridDim.x * PB) {
+        if (p < nb) mine_b += contact_of_pair(A, A, pairs[p], out + p, flags, flags);
+        else mine_s += contact_of_pair(A, B, spairs[p - nb], sout + (p - nb), flags, nullptr);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mine_b += __shfl_xor(mine_b, o); mine_s += __shfl_xor(mine_s, o); }
+    if (lane_id() == 0) {
+        if (mine_b) atomicAdd(&block_hits[0], mine_b);
+        if (mine_s) atomicAdd(&block_hits[1], mine_s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long add = (1ull << 48) | ((unsigned long long)block_hits[1] << 24) | block_hits[0];
+        const unsigned long long old = atomicAdd(word, add);
+        if ((uint32_t)(old >> 48) == gridDim.x - 1) {                   // the last ticket: `old` holds everybody else's counts
+            if (contact_total) *contact_total = (uint32_t)(old & 0xffffffu) + block_hits[0];
+            if (scontact_total) *scontact_total = (uint32_t)((old >> 24) & 0xffffffu) + block_hits[1];
+            *word = 0;                                                   // ready for the next launch (stream order)
+        }
+    }
 }
 
 // phys_body_sweep_capsule: one wavefront per sweep, the candidates of a step spread over the lanes
@@ -1280,6 +1325,33 @@ extern "C" int clapgpu_contacts_geoms(void *stream, const clapgpu_geoms *A, cons
                        reinterpret_cast<const uint2 *>(pairs), pair_total, capacity, contacts, contact_total, body_flags_a,
                        body_flags_b);
     CLAPGPU_LAUNCH_CHECK("k_contacts_geoms");
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_contacts_geoms_both(void *stream, clapgpu_bp *bp, const clapgpu_geoms *bodies, const clapgpu_geoms *statics,
+                                           const uint32_t *pairs, const uint32_t *pair_total, uint32_t capacity,
+                                           clapgpu_contact2 *contacts, uint32_t *contact_total,
+                                           const uint32_t *static_pairs, const uint32_t *static_pair_total, uint32_t static_capacity,
+                                           clapgpu_contact2 *static_contacts, uint32_t *static_contact_total, uint32_t *body_flags)
+{
+    if (!bp || !bodies || !statics || !pair_total || !static_pair_total || (capacity && (!pairs || !contacts)) ||
+        (static_capacity && (!static_pairs || !static_contacts)))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (capacity >= (1u << 24) || static_capacity >= (1u << 24))         // the counts travel as 24-bit fields of one word
+        return CLAPGPU_ERR_TOO_LARGE;
+    hipStream_t s = as_stream(stream);
+    if (bodies->n == 0 || (capacity == 0 && static_capacity == 0)) {
+        if (contact_total) CLAPGPU_HIP(hipMemsetAsync(contact_total, 0, sizeof(uint32_t), s));
+        if (static_contact_total) CLAPGPU_HIP(hipMemsetAsync(static_contact_total, 0, sizeof(uint32_t), s));
+        return CLAPGPU_OK;
+    }
+    const uint32_t blocks = (capacity + static_capacity + PB - 1) / PB;
+    hipLaunchKernelGGL(k_contacts_geoms_both, dim3(blocks < 2048 ? blocks : 2048), dim3(PB), 0, s, geoms_k(bodies), geoms_k(statics),
+                       reinterpret_cast<const uint2 *>(pairs), pair_total, capacity, contacts, contact_total,
+                       reinterpret_cast<const uint2 *>(static_pairs), static_pair_total, statics->n ? static_capacity : 0u,
+                       static_contacts, static_contact_total, body_flags,
+                       reinterpret_cast<unsigned long long *>(bp->k.ctrl + CTRL_CONTACT_WORD));
+    CLAPGPU_LAUNCH_CHECK("k_contacts_geoms_both");
     return CLAPGPU_OK;
 }
 

@@ -8,9 +8,9 @@
 #include "lm_dev.h"
 
 #ifdef CLAPGPU_EXPERIMENT               // an A/B or sensitivity build (common.h): never loadable as the product
-#define CLAPGPU_ABI_VERSION (26u | 0x80000000u)
+#define CLAPGPU_ABI_VERSION (27u | 0x80000000u)
 #else
-#define CLAPGPU_ABI_VERSION 26u
+#define CLAPGPU_ABI_VERSION 27u
 #endif
 
 namespace clapgpu {

@@ -163,6 +163,19 @@ class PhysWorld:
                                                 _ptr(self.static_contact2_buf), _ptr(self.static_contact2_total), fl, 0),
                        "clapgpu_contacts_geoms(static)")
 
+    def contacts_geoms_both(self, set_joint_flags=True):
+        """contacts_geoms() as ONE launch over both lists (clapgpu_contacts_geoms_both): needs statics."""
+        L = _lib.lib()
+        self.alloc_contacts()
+        g, sg = self.body_geoms(), self.static_geoms()
+        fl = _ptr(self.bflags) if set_joint_flags else 0
+        _lib.check(L.clapgpu_contacts_geoms_both(_stream(), self._bp, C.byref(g), C.byref(sg), _ptr(self.pairs),
+                                                 _ptr(self.pair_total), self.capacity, _ptr(self.contact2_buf),
+                                                 _ptr(self.contact2_total), _ptr(self.static_pairs),
+                                                 _ptr(self.static_pair_total), self.static_capacity,
+                                                 _ptr(self.static_contact2_buf), _ptr(self.static_contact2_total), fl),
+                   "clapgpu_contacts_geoms_both")
+
     def download_contacts2(self, dtype):
         torch.cuda.synchronize(self.device)
         npairs = min(int(self.pair_total.item()), self.capacity)

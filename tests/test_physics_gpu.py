@@ -449,6 +449,39 @@ def test_capsule_contacts_match_restatement(cuda_device):
         assert np.array_equal((out["bflags"] & 16) != 0, hit), "CLAPGPU_BODY_HAS_JOINT on exactly the touching bodies"
 
 
+def test_contacts_of_both_lists_in_one_launch(cuda_device):
+    """clapgpu_contacts_geoms_both: the records, totals and joint flags of the two clapgpu_contacts_geoms calls it replaces
+    (near_callback over dSpaceCollide's and dSpaceCollide2's pairs, physics.c:751-753), byte for byte -- three frames in a
+    row, because its ticket-and-counts word has to be back at zero for the next launch, and once with a pair capacity
+    smaller than the list."""
+    import torch
+    from clap_amd import physics
+    n = 30_000
+    b = synth.capsule_bodies(n, box=30.0, seed=35)
+    statics = synth.static_boxes(48, 30.0)
+    mat, smat = _materials(n, 6), _materials(48, 7)
+    for cap in (16 * n, 9_000):
+        two = physics.PhysWorld(b, statics, pair_capacity=cap, device=cuda_device)
+        one = physics.PhysWorld(b, statics, pair_capacity=cap, device=cuda_device)
+        for w in (two, one):
+            w.set_materials(mat)
+            w.static_material = torch.from_numpy(smat).to(cuda_device)
+        for frame in range(3):
+            for w in (two, one):
+                w.world_step(1 / 120)
+                w.broadphase()
+            two.contacts_geoms()
+            one.contacts_geoms_both()
+            a, c = two.download_contacts2(ob.CONTACT2_DTYPE), one.download_contacts2(ob.CONTACT2_DTYPE)
+            oa, oc = two.download(), one.download()
+            assert np.array_equal(oa["pairs"], oc["pairs"]) and np.array_equal(oa["static_pairs"], oc["static_pairs"])
+            for which in ("body", "static"):
+                assert a[which][1] == c[which][1], f"cap {cap} frame {frame}: {which} contact total {a[which][1]} vs {c[which][1]}"
+                assert a[which][0].tobytes() == c[which][0].tobytes(), f"cap {cap} frame {frame}: {which} records"
+            assert a["body"][1] > 0 and a["static"][1] > 0
+            assert np.array_equal(oa["bflags"], oc["bflags"]), "CLAPGPU_BODY_HAS_JOINT"
+
+
 def test_static_sphere_and_capsule_colliders(cuda_device):
     """Static colliders the reference creates as capsule / sphere geoms (phys_body_new with a geom only, physics.c:
     980-991): narrowphase against their real shape, candidates from their AABBs."""

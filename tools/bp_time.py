@@ -13,4 +13,5 @@ for kind in (sys.argv[1:] or ("spheres","capsules")):
         torch.cuda.synchronize()
         return np.mean([a.elapsed_time(c) for a,c in ev])*1e3
     print(kind, "broadphase us", t(pw.broadphase), "pairs", int(pw.pair_total.item()), "static pairs", int(pw.static_pair_total.item()),
-          "contacts us", t(pw.contacts_geoms), "step us", t(lambda: pw.world_step(1/120)))
+          "contacts us", t(pw.contacts_geoms), "contacts (both lists, one launch) us", t(pw.contacts_geoms_both),
+          "step us", t(lambda: pw.world_step(1/120)))
