@@ -802,11 +802,9 @@ __device__ __forceinline__ void contact_surface2(clapgpu_contact2 &c, const doub
 }
 
 // one candidate pair -> its record; true if the pair produced contacts (or is flagged deep)
-__device__ __forceinline__ bool contact_of_pair(const GeomsK &A, const GeomsK &B, const uint2 pr, clapgpu_contact2 *out,
+__device__ __forceinline__ bool contact_of_pair(const GeomsK &A, const GeomsK &B, const uint2 pr, clapgpu_contact2 &c,
                                                 uint32_t *flags_a, uint32_t *flags_b)
 {
-    clapgpu_contact2 c;
-    memset(&c, 0, sizeof(c));
     bool counted = false;
     if (pr.x < A.n && pr.y < B.n) {
         phd::Geom ga, gb;
@@ -835,7 +833,36 @@ __device__ __forceinline__ bool contact_of_pair(const GeomsK &A, const GeomsK &B
             if (flags_b && !(flags_b[pr.y] & CLAPGPU_BODY_HAS_JOINT)) flags_b[pr.y] |= CLAPGPU_BODY_HAS_JOINT;
         }
     }
-    *out = c;
+    return counted;
+}
+
+// 64 consecutive pairs of one list on one wavefront: each lane's 160-byte record goes through a wave-private LDS tile
+// (rows padded to 176 bytes: the 16-byte writes of eight neighbouring lanes then fall on all 32 banks) and leaves as ten
+// 1 KiB stores -- written per lane, ten 16-byte pieces at a 160-byte stride touched 64 cache lines per instruction.
+constexpr int CONTACT_ROW = 11;                                          // uint4 per staged record (10 used)
+__device__ __forceinline__ uint32_t contacts_chunk(const GeomsK &A, const GeomsK &B, const uint2 *pairs, uint32_t p0, uint32_t np,
+                                                    clapgpu_contact2 *out, uint32_t *flags_a, uint32_t *flags_b, uint4 *tile)
+{
+    static_assert(sizeof(clapgpu_contact2) == 160, "ten 16-byte pieces");
+    const int lane = lane_id();
+    const uint32_t p = p0 + lane;
+    clapgpu_contact2 c;
+    memset(&c, 0, sizeof(c));
+    uint32_t counted = 0;
+    if (p < np) counted = contact_of_pair(A, B, pairs[p], c, flags_a, flags_b);
+    uint4 v[10];
+    memcpy(v, &c, sizeof(c));
+#pragma unroll
+    for (int k = 0; k < 10; k++) tile[lane * CONTACT_ROW + k] = v[k];
+    wave_lds_fence();
+    const uint32_t pieces = (np - p0 < (uint32_t)WAVE ? np - p0 : (uint32_t)WAVE) * 10u;
+    uint4 *o = reinterpret_cast<uint4 *>(out + p0);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const uint32_t idx = (uint32_t)(k * WAVE + lane);
+        if (idx < pieces) o[idx] = tile[(idx / 10u) * CONTACT_ROW + idx % 10u];
+    }
+    wave_lds_fence();
     return counted;
 }
 
@@ -844,13 +871,15 @@ void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pa
                       clapgpu_contact2 *out, uint32_t *contact_total, uint32_t *flags_a, uint32_t *flags_b)
 {
     __shared__ uint32_t block_hits;
+    __shared__ uint4 tile[PB / WAVE][WAVE * CONTACT_ROW];
     if (threadIdx.x == 0) block_hits = 0;
     __syncthreads();
     uint32_t np = *pair_total;
     if (np > capacity) np = capacity;
     uint32_t mine = 0;
-    for (uint32_t p = blockIdx.x * PB + threadIdx.x; p < np; p += gridDim.x * PB)
-        mine += contact_of_pair(A, B, pairs[p], out + p, flags_a, flags_b);
+    const uint32_t wave = threadIdx.x / WAVE;
+    for (uint32_t p0 = blockIdx.x * PB + wave * WAVE; p0 < np; p0 += gridDim.x * PB)      // wave-uniform
+        mine += contacts_chunk(A, B, pairs, p0, np, out, flags_a, flags_b, tile[wave]);
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if (lane_id() == 0 && mine) atomicAdd(&block_hits, mine);
     __syncthreads();
@@ -868,15 +897,18 @@ void k_contacts_geoms_both(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_
                            unsigned long long *word)
 {
     __shared__ uint32_t block_hits[2];
+    __shared__ uint4 tile[PB / WAVE][WAVE * CONTACT_ROW];
     if (threadIdx.x < 2) block_hits[threadIdx.x] = 0;
     __syncthreads();
     uint32_t nb = *pair_total, ns = spair_total ? *spair_total : 0u;
     if (nb > capacity) nb = capacity;
     if (ns > scapacity) ns = scapacity;
     uint32_t mine_b = 0, mine_s = 0;
-    for (uint32_t p = blockIdx.x * PB + threadIdx.x; p < nb + ns; p += gridDim.x * PB) {
-        if (p < nb) mine_b += contact_of_pair(A, A, pairs[p], out + p, flags, flags);
-        else mine_s += contact_of_pair(A, B, spairs[p - nb], sout + (p - nb), flags, nullptr);
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t cb = (nb + WAVE - 1) / WAVE, cs = (ns + WAVE - 1) / WAVE;   // 64-pair chunks: the bodies' list, then the statics'
+    for (uint32_t ch = blockIdx.x * (PB / WAVE) + wave; ch < cb + cs; ch += gridDim.x * (PB / WAVE)) {   // wave-uniform
+        if (ch < cb) mine_b += contacts_chunk(A, A, pairs, ch * WAVE, nb, out, flags, flags, tile[wave]);
+        else mine_s += contacts_chunk(A, B, spairs, (ch - cb) * WAVE, ns, sout, flags, nullptr, tile[wave]);
     }
     for (int o = 32; o > 0; o >>= 1) { mine_b += __shfl_xor(mine_b, o); mine_s += __shfl_xor(mine_s, o); }
     if (lane_id() == 0) {
