@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <time.h>
 #include "clapgpu.h"
+#include "gpu-scene.h"                               /* gpu_scene_par_for: the bindings' worker threads */
 
 struct gpu_particles {
     uint32_t                n_sys, cap_sys, n;       /* n = padded particle slots (systems start at multiples of 64) */
@@ -192,16 +193,13 @@ static int gp_rebuild(struct gpu_particles *gp)
     return 0;
 }
 
-/* Bring p->pos / p->velocity of every mirrored system up to date with the device copy. */
-int gpu_particles_sync_host(struct gpu_particles *gp)
+/* systems [lo, hi): every struct particle's pos / velocity from the staging arrays (a linked list per system: memory
+ * latency, split over the bindings' workers above GP_PAR_MIN particles -- 1 M particles: 10 ms on one core) */
+#define GP_PAR_MIN 65536u
+static void gp_structs_back(void *ctx, uint32_t lo, uint32_t hi)
 {
-    if (!gp || !gp->host_stale) return 0;
-    if (!gp->mapped) {                                /* mapped: h_pos / h_vel ARE the batch, and every update has waited for its kernels */
-        GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
-        GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
-        GP_CK(clapgpu_stream_sync(NULL));
-    }
-    for (uint32_t s = 0; s < gp->n_sys; s++) {
+    struct gpu_particles *gp = ctx;
+    for (uint32_t s = lo; s < hi; s++) {
         if (!gp->ps[s]) continue;
         particle *p;
         size_t i = gp->sys_host[s].first;
@@ -211,6 +209,23 @@ int gpu_particles_sync_host(struct gpu_particles *gp)
             i++;
         }
     }
+}
+
+static void gp_structs_back_all(struct gpu_particles *gp)
+{
+    gpu_scene_par_for(gp_structs_back, gp, gp->n_sys, gp->n >= GP_PAR_MIN && gp->n_sys >= 16 ? 8 : 1);
+}
+
+/* Bring p->pos / p->velocity of every mirrored system up to date with the device copy. */
+int gpu_particles_sync_host(struct gpu_particles *gp)
+{
+    if (!gp || !gp->host_stale) return 0;
+    if (!gp->mapped) {                                /* mapped: h_pos / h_vel ARE the batch, and every update has waited for its kernels */
+        GP_CK(clapgpu_memcpy_d2h(gp->h_pos, gp->d.pos, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_memcpy_d2h(gp->h_vel, gp->d.vel, (size_t)gp->n * 12, NULL));
+        GP_CK(clapgpu_stream_sync(NULL));
+    }
+    gp_structs_back_all(gp);
     gp->host_stale = false;
     return 0;
 }
@@ -293,16 +308,8 @@ int gpu_particles_update(struct gpu_particles *gp, struct mq *mq, struct scene *
         const size_t first = gp->sys_host[s].first;
         memcpy(ps->pos_array, gp->h_pos + 3 * first, (size_t)ps->count * sizeof(vec3));   /* particle.c:116 */
         memcpy(ps->e->mx, gp->h_mx + 16 * (size_t)s, sizeof(mat4x4));                     /* particle.c:93-100 */
-        if (scatter) {
-            particle *p;
-            size_t i = first;
-            list_for_each_entry(p, &ps->particles, entry) {
-                memcpy(p->pos, gp->h_pos + 3 * i, 12);
-                memcpy(p->velocity, gp->h_vel + 3 * i, 12);
-                i++;
-            }
-        }
     }
+    if (scatter) gp_structs_back_all(gp);
     gp->host_stale = !scatter;
     if (timing) {
         clock_gettime(CLOCK_MONOTONIC, &tp_[3]);

@@ -702,7 +702,7 @@ static void *par_range(void *arg)
 /* fn(ctx, lo, hi) over [0, n) split into `threads` contiguous ranges on the binding's workers (the caller takes the first) */
 void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads)
 {
-    if (threads > 8) threads = 8;
+    if (threads > par_threads()) threads = par_threads();
     if (threads < 2 || n < (uint32_t)threads) { fn(ctx, 0, n); return; }
     struct par_job jobs[8] = { 0 };
     for (int t = 0; t < threads; t++)
