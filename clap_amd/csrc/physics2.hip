@@ -252,9 +252,7 @@ struct BpK {
     uint32_t mask;                       // block buckets - 1
     const double *aabb;
     uint32_t *cell_cnt;                  // [buckets * 64] the bin pass's counters, zero between frames
-    uint32_t *cell_len;                  // [buckets * 64] bodies per cell
-    uint32_t *cell_prefix;               // [buckets * 64] exclusive prefix inside the block
-    uint32_t *block_start;               // [buckets + 1]
+    uint2    *cell_range;                // [buckets * 64] (first position in cell order, bodies) of every cell: one load per lookup
     uint32_t *key, *rank;                // [n] cell slot and rank inside the cell
     uint32_t *entries;                   // [n] body indices in cell order
     struct BpRec *recs;                  // [n] the same with the boxes: what the search reads
@@ -369,18 +367,17 @@ void k_bp_cells(BpK k)
     __shared__ uint32_t excl_s;
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const uint32_t b = blockIdx.x * (BP_CELLS_BLOCK / WAVE) + wave;
-    uint32_t block_total = 0;
+    uint32_t block_total = 0, c = 0, before = 0;                        // this lane's cell: bodies, bodies of the block's cells before it
     if (b <= k.mask) {
-        const uint32_t c = k.cell_cnt[(size_t)b * 64 + lane];
+        c = k.cell_cnt[(size_t)b * 64 + lane];
         k.cell_cnt[(size_t)b * 64 + lane] = 0;                          // ready for the next frame
-        k.cell_len[(size_t)b * 64 + lane] = c;
         uint32_t incl = c;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
             const uint32_t u = __shfl_up(incl, o);
             if (lane >= o) incl += u;
         }
-        k.cell_prefix[(size_t)b * 64 + lane] = incl - c;
+        before = incl - c;
         block_total = __shfl(incl, WAVE - 1);
     }
     if (lane == 0) tot[wave] = block_total;
@@ -390,16 +387,13 @@ void k_bp_cells(BpK k)
 #pragma unroll
         for (int q = 0; q < BP_CELLS_BLOCK / WAVE; q++) sum += tot[q];
         const uint32_t excl = lb_exclusive(k.lb_cells, blockIdx.x, sum, k.ctrl[CTRL_EPOCH], k.ctrl + CTRL_STATUS);
-        if (lane == 0) {
-            excl_s = excl;
-            if (blockIdx.x == gridDim.x - 1) k.block_start[k.mask + 1] = excl + sum;
-        }
+        if (lane == 0) excl_s = excl;
     }
     __syncthreads();
-    if (b <= k.mask && lane == 0) {
+    if (b <= k.mask) {
         uint32_t start = excl_s;
         for (int q = 0; q < wave; q++) start += tot[q];
-        k.block_start[b] = start;
+        k.cell_range[(size_t)b * 64 + lane] = make_uint2(start + before, c);
     }
 }
 
@@ -410,7 +404,7 @@ void k_bp_scatter(BpK k)
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
     if (i >= k.n) return;
     const uint32_t slot = k.key[i];
-    const uint32_t at = k.block_start[slot >> 6] + k.cell_prefix[slot] + k.rank[i];
+    const uint32_t at = k.cell_range[slot].x + k.rank[i];
     k.entries[at] = i;
     const double2 *p = reinterpret_cast<const double2 *>(k.aabb + 6 * (size_t)i);
     double2 *o = reinterpret_cast<double2 *>(k.recs + at);
@@ -509,13 +503,10 @@ void k_bp_search(BpK k)
         slot[r] = is_cell[r] ? cell_slot(d0 - 1 + (int32_t)(cq % 3), d1 - 1 + (int32_t)((cq / 3) % 3), d2 - 1 + (int32_t)(cq / 9), k.mask) : 0u;
         sidx[r] = is_stat[r] ? (uint32_t)d0 : 0u;
     }
-    uint32_t v_bs[LOOKUPS], v_cp[LOOKUPS], v_cl[LOOKUPS], v_s0[LOOKUPS], v_s1[LOOKUPS];
+    uint2 v_cr[LOOKUPS];
+    uint32_t v_s0[LOOKUPS], v_s1[LOOKUPS];
 #pragma unroll
-    for (int r = 0; r < LOOKUPS; r++) {
-        v_bs[r] = k.block_start[slot[r] >> 6];
-        v_cp[r] = k.cell_prefix[slot[r]];
-        v_cl[r] = k.cell_len[slot[r]];
-    }
+    for (int r = 0; r < LOOKUPS; r++) v_cr[r] = k.cell_range[slot[r]];
     if (statics) {                                                       // uniform
 #pragma unroll
         for (int r = 0; r < LOOKUPS; r++) { v_s0[r] = k.s_start[sidx[r]]; v_s1[r] = k.s_start[sidx[r] + 1]; }
@@ -525,8 +516,8 @@ void k_bp_search(BpK k)
     }
 #pragma unroll
     for (int r = 0; r < LOOKUPS; r++) {
-        b0[r] = is_cell[r] ? ((v_bs[r] + v_cp[r]) | (own[r] ? OWN : 0u)) : is_stat[r] ? (v_s0[r] | STAT) : 0u;
-        len[r] = is_cell[r] ? v_cl[r] : is_stat[r] ? v_s1[r] - v_s0[r] : 0u;
+        b0[r] = is_cell[r] ? (v_cr[r].x | (own[r] ? OWN : 0u)) : is_stat[r] ? (v_s0[r] | STAT) : 0u;
+        len[r] = is_cell[r] ? v_cr[r].y : is_stat[r] ? v_s1[r] - v_s0[r] : 0u;
         mylen += len[r];
     }
     uint32_t incl = mylen;
@@ -654,7 +645,8 @@ __device__ __forceinline__ void research_body(const BpK &k, uint32_t i, F &&emit
         uint32_t best = 0xffffffffu;
         for (int cq = 0; cq < 27; cq++) {
             const uint32_t slot = cell_slot(cx - 1 + cq % 3, cy - 1 + (cq / 3) % 3, cz - 1 + cq / 9, k.mask);
-            const uint32_t s0 = k.block_start[slot >> 6] + k.cell_prefix[slot], s1 = s0 + k.cell_len[slot];
+            const uint2 cr = k.cell_range[slot];
+            const uint32_t s0 = cr.x, s1 = cr.x + cr.y;
             for (uint32_t s = s0; s < s1; s++) {
                 const uint32_t j = k.entries[s];
                 if (j <= last || j >= best) continue;
@@ -1234,8 +1226,7 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     // one device allocation, carved
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_ccnt = take(4 * (size_t)nb * 64), o_cpre = take(4 * (size_t)nb * 64), o_clen = take(4 * (size_t)nb * 64);
-    const size_t o_bstart = take(4 * ((size_t)nb + 4));
+    const size_t o_ccnt = take(4 * (size_t)nb * 64), o_crange = take(8 * (size_t)nb * 64);
     const size_t o_key = take(4 * (size_t)n), o_ranks = take(4 * (size_t)n), o_entries = take(4 * (size_t)n), o_recs = take(64 * (size_t)n);
     const size_t o_cnt = take(4 * (size_t)n), o_scnt = take(4 * (size_t)n);
     const size_t o_part = take(4 * (size_t)BP_LIST * n), o_spart = take(4 * (size_t)BP_LIST * n);
@@ -1266,9 +1257,7 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     BpK &k = bp->k;
     memset(&k, 0, sizeof(k));
     k.cell = cell; k.mask = nb - 1;
-    k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt); k.cell_prefix = reinterpret_cast<uint32_t *>(d + o_cpre);
-    k.cell_len = reinterpret_cast<uint32_t *>(d + o_clen);
-    k.block_start = reinterpret_cast<uint32_t *>(d + o_bstart);
+    k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt); k.cell_range = reinterpret_cast<uint2 *>(d + o_crange);
     k.key = reinterpret_cast<uint32_t *>(d + o_key); k.rank = reinterpret_cast<uint32_t *>(d + o_ranks);
     k.entries = reinterpret_cast<uint32_t *>(d + o_entries); k.recs = reinterpret_cast<BpRec *>(d + o_recs);
     k.cnt = reinterpret_cast<uint32_t *>(d + o_cnt); k.scnt = reinterpret_cast<uint32_t *>(d + o_scnt);
