@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 OK = 0
 ERR_NOMEM = -1
@@ -86,7 +86,7 @@ class Skeleton(C.Structure):
 class Animations(C.Structure):
     _fields_ = [("n_anims", C.c_uint32), ("n_times", C.c_uint32), ("chan_table", C.c_void_p),
                 ("times", C.c_void_p), ("data", C.c_void_p), ("packed", C.c_void_p), ("packed_keys", C.c_uint32),
-                ("pad", C.c_uint32)]
+                ("packed_layout", C.c_uint32)]
 
 
 class PoseBatch(C.Structure):
@@ -179,6 +179,7 @@ SYMBOLS = {
     "clapgpu_device_count": (C.c_int, []),
     "clapgpu_init": (C.c_int, [C.c_int]),
     "clapgpu_last_error": (C.c_char_p, []),
+    "clapgpu_test_fail_after": (None, [C.c_int]),
     "clapgpu_abi_version": (C.c_uint32, []),
     "clapgpu_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "clapgpu_free": (C.c_int, [C.c_void_p]),
@@ -206,7 +207,7 @@ SYMBOLS = {
     "clapgpu_animation_time": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_double]),
     "clapgpu_animation_time_dev": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_void_p]),
     "clapgpu_animations_packed_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
-    "clapgpu_animations_pack": (C.c_int, [C.c_void_p, C.POINTER(Animations), C.c_uint32, C.c_uint32, C.c_void_p]),
+    "clapgpu_animations_pack": (C.c_int, [C.c_void_p, C.POINTER(Animations), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
     "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),

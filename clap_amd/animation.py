@@ -80,7 +80,7 @@ def skeleton_bind(invmx):
 class SkinnedModel:
     """Device copy of one model3d's skeleton, animations and (optionally) skinned mesh."""
 
-    def __init__(self, sk, anims, mesh=None, bind=None, device="cuda:0", pack=True):
+    def __init__(self, sk, anims, mesh=None, bind=None, device="cuda:0"):
         self.device = dev = torch.device(device)
         self.nr_joints = J = int(sk["nr_joints"])
         self.depth_host = joint_depths(sk["parent"])
@@ -101,16 +101,20 @@ class SkinnedModel:
         self.anim_desc = _lib.Animations(len(anims), int(ct["times"].shape[0]), _ptr(self._ct["chan_table"]),
                                          _ptr(self._ct["times"]),
                                          _ptr(self._ct["data"]), None, 0, 0)
-        # the key-major copy of the pools (clapgpu_animations_pack): once per model
+        # the key-major copy of the pools with the rotation intervals' constants (clapgpu_animations_pack): once per
+        # model, required by clapgpu_pose_update
         self.packed = None
         max_keys = int(ct["chan_table"][..., 2].max()) if len(anims) else 0
-        if pack and J <= 256 and max_keys > 0:
+        max_keys = max(max_keys, 1)                       # animations without a single key: every path keeps its value
+        if J <= 256 and len(anims):
             nbytes = int(_lib.lib().clapgpu_animations_packed_bytes(len(anims), max_keys, J))
             self.packed = torch.zeros((nbytes + 15) // 16 * 4, dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib().clapgpu_animations_pack(_stream(), C.byref(self.anim_desc), J, max_keys, _ptr(self.packed)),
-                       "clapgpu_animations_pack")
+            layout = C.c_uint32(0)
+            _lib.check(_lib.lib().clapgpu_animations_pack(_stream(), C.byref(self.anim_desc), J, max_keys, _ptr(self.packed),
+                                                          C.byref(layout)), "clapgpu_animations_pack")
             self.anim_desc.packed = _ptr(self.packed)
             self.anim_desc.packed_keys = max_keys
+            self.anim_desc.packed_layout = layout.value
         self.mesh = None
         if mesh is not None:
             self.mesh = dict(n_verts=int(mesh["n_verts"]), position=_dev(mesh["position"], dev, np.float32),

@@ -64,7 +64,9 @@ int gpu_anim_init(struct gpu_anim **out, int device)
     int rc = clapgpu_init(device);
     if (rc) return rc;
     *out = calloc(1, sizeof(**out));
-    return *out ? 0 : _CERR_NOMEM;
+    if (!*out) return _CERR_NOMEM;
+    gpu_scene_pool_ref();                                /* gpu_scene_par_for: the write-back of many characters */
+    return 0;
 }
 
 static void ga_free_batch(struct ga_model *m)
@@ -93,6 +95,7 @@ void gpu_anim_done(struct gpu_anim *ga)
     }
     free(ga->models);
     free(ga);
+    gpu_scene_pool_unref();
 }
 
 /* Skeleton constants and the keyframe pools of one model3d, uploaded once. */
@@ -175,14 +178,18 @@ static int ga_model_build(struct ga_model *m, model3d *model)
                                 .root_pose = m->d_root_pose, .invmx = m->d_invmx, .bind = m->d_bind };
     m->an = (clapgpu_animations){ .n_anims = A, .n_times = (uint32_t)t_at, .chan_table = m->d_chan_table,
                                   .times = m->d_times, .data = m->d_data };
-    if (J <= 256 && A && max_keys) {
-        /* the key-major copy of the pools, once per model: the one-wavefront-per-character loop's searches then run
-         * without LDS bank conflicts and its key gathers are contiguous rows (clapgpu.h: clapgpu_animations_pack) */
+    if (!max_keys) max_keys = 1;                          /* animations without a single key: every path keeps its value */
+    if (J <= 256 && A) {
+        /* the key-major copy of the pools, once per model, with what quat_slerp derives from each rotation key pair alone
+         * (acos of the inner product and its sine, by this host's libm as in interp.h:107-110): the pose kernel's searches
+         * then run without LDS bank conflicts, its key gathers are contiguous rows and its slerp is the reference's
+         * (clapgpu.h: clapgpu_animations_pack) */
+        uint32_t layout = 0;
         GA_CK(clapgpu_malloc(&m->d_packed, clapgpu_animations_packed_bytes(A, max_keys, J)));
-        GA_CK(clapgpu_animations_pack(NULL, &m->an, J, max_keys, m->d_packed));
-        GA_CK(clapgpu_stream_sync(NULL));
+        GA_CK(clapgpu_animations_pack(NULL, &m->an, J, max_keys, m->d_packed, &layout));
         m->an.packed = m->d_packed;
         m->an.packed_keys = max_keys;
+        m->an.packed_layout = layout;
     }
     return 0;
 }

@@ -40,9 +40,14 @@ void mq_update(struct mq *mq)
 {
     struct gpu_scene *gs = gpu_scene_bound();
     if (gs && mq == gpu_scene_bound_mq()) {
-        if (!gpu_mq_update(gs, mq, gpu_scene_bound_view()))
+        const int rc = gpu_mq_update(gs, mq, gpu_scene_bound_view());
+        if (!rc)
             return;
-        /* a device error is not fatal to the frame: the reference's loop still works on the same objects */
+        /* a device error is not fatal to the frame -- the reference's loop still works on the same objects -- but it is
+         * reported (once through the engine's log, every time in gpu_scene_last_stats()->device_errors) */
+        if (!gpu_scene_device_errors())
+            err("gpu_mq_update failed (%d): %s; mq_update falls back to the host loop\n", rc, clapgpu_last_error());
+        gpu_scene_device_error("gpu_mq_update", rc);
     }
     ref_mq_update(mq);
 }
@@ -62,8 +67,14 @@ void view_calc_frustum(clap_context *ctx, struct view *view)
 
 void light_grid_compute(struct light *light, struct view *view)
 {
-    if (g_bound_lights && !gpu_light_grid_compute(g_bound_lights, light, view))
-        return;
+    if (g_bound_lights) {
+        const int rc = gpu_light_grid_compute(g_bound_lights, light, view);
+        if (!rc)
+            return;
+        if (!gpu_scene_device_errors())
+            err("gpu_light_grid_compute failed (%d): %s; light_grid_compute falls back to the host loop\n", rc, clapgpu_last_error());
+        gpu_scene_device_error("gpu_light_grid_compute", rc);
+    }
     ref_light_grid_compute(light, view);
 }
 

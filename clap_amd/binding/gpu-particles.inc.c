@@ -69,7 +69,9 @@ int gpu_particles_init(struct gpu_particles **out, int device)
     int rc = clapgpu_init(device);
     if (rc) return rc;
     *out = calloc(1, sizeof(**out));
-    return *out ? 0 : _CERR_NOMEM;
+    if (!*out) return _CERR_NOMEM;
+    gpu_scene_pool_ref();                            /* gpu_scene_par_for: the struct particle write-back */
+    return 0;
 }
 
 static void gp_free_device(struct gpu_particles *gp)
@@ -98,6 +100,7 @@ void gpu_particles_done(struct gpu_particles *gp)
     gp_free_device(gp);
     free(gp->ps); free(gp->seen); free(gp->sys_host);
     free(gp);
+    gpu_scene_pool_unref();
 }
 
 static void gp_sys_record(clapgpu_particle_system *r, const particle_system *ps, uint32_t first)

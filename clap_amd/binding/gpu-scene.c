@@ -225,16 +225,15 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     gs->default_hook = default_hook;
     gs->free_rec = NO_REC;
     gs->verify = getenv("GPU_SCENE_VERIFY") != NULL;
+    gpu_scene_pool_ref();
     *out = gs;
     return 0;
 }
 
-static void pool_stop(void);
-
 void gpu_scene_done(struct gpu_scene *gs)
 {
     if (!gs) return;
-    pool_stop();
+    gpu_scene_pool_unref();
     clapgpu_scene_destroy(gs->scene);
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs->char_list);
@@ -244,7 +243,27 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs);
 }
 
-const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs) { return &gs->stats; }
+static unsigned g_device_errors;
+
+const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs)
+{
+    ((struct gpu_scene *)gs)->stats.device_errors = g_device_errors;
+    return &gs->stats;
+}
+
+void gpu_scene_device_error(const char *what, int rc)
+{
+    static const char *seen[8];
+    g_device_errors++;
+    for (unsigned k = 0; k < 8; k++) {
+        if (seen[k] == what) return;                                 /* this call site has been reported */
+        if (!seen[k]) { seen[k] = what; break; }
+    }
+    fprintf(stderr, "clap gpu binding: %s failed (%d): %s -- served by the engine's host path; further failures of this call are "
+                    "only counted (gpu_scene_device_errors())\n", what, rc, clapgpu_last_error());
+}
+
+unsigned gpu_scene_device_errors(void) { return g_device_errors; }
 
 void gpu_scene_animation_elsewhere(struct gpu_scene *gs, bool elsewhere) { gs->anim_elsewhere = elsewhere; }
 
@@ -614,7 +633,14 @@ static int par_threads(void)
  * parked worker still costs tens to hundreds of microseconds (the core has to leave its idle state), so the passes are
  * split only from GS_PAR_MIN entities up: at 10 000 entities a split pass measured four times SLOWER than one thread.
  * One pool per process: the passes of one frame follow each other, and every call of the binding is synchronous on the
- * engine's one thread.
+ * engine's one thread.  Every binding object that may split a pass (a gpu_scene, gpu_anim, gpu_particles) holds a
+ * reference (gpu_scene_pool_ref / _unref); the last one to go joins the workers.
+ *
+ * A pass is identified by its generation.  A worker serves exactly the generations that began after it was created:
+ * it starts with `seen` = the generation current at its creation (threads are created under the pool's mutex, so no
+ * pass can begin in between), and `pending` is set, under the same mutex, to the number of workers alive when the
+ * generation is raised -- a thread created later never decrements a count it was not part of, and never sees the
+ * function or the (stack-allocated) job array of a pass that has returned.
  */
 static struct {
     pthread_t th[7];
@@ -626,13 +652,18 @@ static struct {
     int nt;                                                      /* jobs of the current pass (job 0 is the caller's) */
     unsigned gen;
     int pending;                                                 /* workers still busy with the current pass */
-    bool quit, init;
-} g_pool;
+    int users;                                                   /* binding objects holding the pool */
+    bool quit;
+} g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .work = PTHREAD_COND_INITIALIZER };
+
+struct pool_arg { int me; unsigned seen; };
 
 static void *pool_worker(void *arg)
 {
-    const int me = (int)(intptr_t)arg;                           /* serves job me + 1 */
-    unsigned seen = 0;
+    const struct pool_arg pa = *(struct pool_arg *)arg;           /* serves job me + 1 */
+    free(arg);
+    const int me = pa.me;
+    unsigned seen = pa.seen;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
         while (g_pool.gen == seen && !g_pool.quit) pthread_cond_wait(&g_pool.work, &g_pool.mu);
@@ -649,43 +680,61 @@ static void *pool_worker(void *arg)
     return NULL;
 }
 
-static void pool_start(int workers)
+/* called with the pool's mutex held */
+static void pool_grow(int workers)
 {
-    if (!g_pool.init) {
-        pthread_mutex_init(&g_pool.mu, NULL);
-        pthread_cond_init(&g_pool.work, NULL);
-        g_pool.init = true;
-    }
     while (g_pool.n < workers && g_pool.n < 7) {
-        if (pthread_create(&g_pool.th[g_pool.n], NULL, pool_worker, (void *)(intptr_t)g_pool.n)) break;
+        struct pool_arg *pa = malloc(sizeof(*pa));
+        if (!pa) break;
+        *pa = (struct pool_arg){ .me = g_pool.n, .seen = g_pool.gen };
+        if (pthread_create(&g_pool.th[g_pool.n], NULL, pool_worker, pa)) { free(pa); break; }
         g_pool.n++;
     }
 }
 
 static void pool_stop(void)
 {
-    if (!g_pool.init || !g_pool.n) return;
     pthread_mutex_lock(&g_pool.mu);
+    const int n = g_pool.n;
     g_pool.quit = true;
     pthread_cond_broadcast(&g_pool.work);
     pthread_mutex_unlock(&g_pool.mu);
-    for (int t = 0; t < g_pool.n; t++) pthread_join(g_pool.th[t], NULL);
+    for (int t = 0; t < n; t++) pthread_join(g_pool.th[t], NULL);
+    pthread_mutex_lock(&g_pool.mu);
     g_pool.n = 0;
     g_pool.quit = false;
+    g_pool.fn = NULL; g_pool.jobs = NULL; g_pool.nt = 0;          /* nothing of a finished pass survives the workers */
+    g_pool.pending = 0;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+void gpu_scene_pool_ref(void)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.users++;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+void gpu_scene_pool_unref(void)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    const bool last = g_pool.users > 0 && --g_pool.users == 0;
+    pthread_mutex_unlock(&g_pool.mu);
+    if (last) pool_stop();                                       /* every call of the binding is on the engine's one thread: no pass is running */
 }
 
 static void par_run(void *(*fn)(void *), struct par_job *jobs, int nt)
 {
-    pool_start(nt - 1);
+    pthread_mutex_lock(&g_pool.mu);
+    pool_grow(nt - 1);
     const int workers = g_pool.n;                                /* fewer than asked for if thread creation failed */
     if (workers > 0) {
-        pthread_mutex_lock(&g_pool.mu);
         g_pool.fn = fn; g_pool.jobs = jobs; g_pool.nt = nt < workers + 1 ? nt : workers + 1;
-        __atomic_store_n(&g_pool.pending, workers, __ATOMIC_RELAXED);
+        __atomic_store_n(&g_pool.pending, workers, __ATOMIC_RELAXED);     /* exactly the workers that will see this generation */
         g_pool.gen++;
         pthread_cond_broadcast(&g_pool.work);
-        pthread_mutex_unlock(&g_pool.mu);
     }
+    pthread_mutex_unlock(&g_pool.mu);
     fn(&jobs[0]);
     for (int t = workers + 1; t < nt; t++) fn(&jobs[t]);        /* jobs no worker exists for */
     while (__atomic_load_n(&g_pool.pending, __ATOMIC_ACQUIRE) > 0)   /* the caller has nothing else to do: spin */

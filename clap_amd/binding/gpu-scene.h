@@ -35,6 +35,8 @@ struct gpu_scene_stats {
     unsigned int registered, deleted;
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
     double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
+    unsigned int device_errors; /* CUMULATIVE, process-wide: calls of the binding that failed on the device and were served by
+                                   the engine's host path instead (gpu_scene_device_errors()) */
 };
 
 /*
@@ -65,6 +67,12 @@ void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view);
 
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 
+/* A call of the binding failed (rc != 0) and the caller is about to take the engine's host path instead: counted for the
+ * life of the process; the first failure of each `what` is reported on stderr with clapgpu_last_error() (the engine-side
+ * exports, gpu-exports.inc.c, also put it through the engine's err()).  A dead device must not look like a slow frame. */
+void     gpu_scene_device_error(const char *what, int rc);
+unsigned gpu_scene_device_errors(void);
+
 /*
  * Notification mode.  The reference's mutators already mark what they change (transform_set_updated behind
  * entity3d_position / _move / _rotate / _scale, model.c:1810-1842); with CONFIG_GPU_SCENE they also tell the binding
@@ -91,6 +99,10 @@ void gpu_scene_set_verify(struct gpu_scene *gs, bool on);
 /* The binding's worker threads (kept between frames, at most seven beside the caller) for its other translation units:
  * fn(ctx, lo, hi) over [0, n) in `threads` contiguous ranges, the caller taking the first; returns when all are done. */
 void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads);
+/* The pool behind gpu_scene_par_for is shared by every binding object of the process: whoever may call it holds a
+ * reference from its _init to its _done (a gpu_scene does by itself); the last reference to go joins the workers. */
+void gpu_scene_pool_ref(void);
+void gpu_scene_pool_unref(void);
 /* the scene, queue and view the engine-named entry points (mq_update, view_entity_in_frustum, ...) serve */
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view);
 struct gpu_scene *gpu_scene_bound(void);

@@ -17,10 +17,12 @@ int hip_fail(hipError_t err, const char *what);
         if (err__ != hipSuccess) return ::clapgpu::hip_fail(err__, #call);  \
     } while (0)
 
-// Kernel launches return errors through hipGetLastError().
+// Kernel launches return errors through hipGetLastError() -- or, for the callers' failure-path tests, through
+// clapgpu_test_fail_after() (runtime.hip).
+hipError_t launch_error();
 #define CLAPGPU_LAUNCH_CHECK(name)                                          \
     do {                                                                    \
-        hipError_t err__ = hipGetLastError();                               \
+        hipError_t err__ = ::clapgpu::launch_error();                       \
         if (err__ != hipSuccess) return ::clapgpu::hip_fail(err__, name);   \
     } while (0)
 

@@ -8,9 +8,9 @@
 #include "lm_dev.h"
 
 #ifdef CLAPGPU_EXPERIMENT               // an A/B or sensitivity build (common.h): never loadable as the product
-#define CLAPGPU_ABI_VERSION (27u | 0x80000000u)
+#define CLAPGPU_ABI_VERSION (28u | 0x80000000u)
 #else
-#define CLAPGPU_ABI_VERSION 27u
+#define CLAPGPU_ABI_VERSION 28u
 #endif
 
 namespace clapgpu {
@@ -28,9 +28,22 @@ int hip_fail(hipError_t err, const char *what)
     return CLAPGPU_ERR_UNKNOWN;
 }
 
+// clapgpu_test_fail_after(): < 0 = off; otherwise the number of launch checks that still pass
+static int g_fail_after = -1;
+
+hipError_t launch_error()
+{
+    const hipError_t e = hipGetLastError();
+    if (g_fail_after < 0 || e != hipSuccess) return e;
+    if (g_fail_after > 0) { g_fail_after--; return e; }
+    return hipErrorLaunchFailure;                                // injected: the kernel itself ran
+}
+
 } // namespace clapgpu
 
 using namespace clapgpu;
+
+extern "C" void clapgpu_test_fail_after(int launches) { g_fail_after = launches; }
 
 extern "C" uint32_t clapgpu_abi_version(void) { return CLAPGPU_ABI_VERSION; }
 

@@ -50,6 +50,10 @@ int clapgpu_device_count(void);
 int clapgpu_init(int device);
 /* Text of the last HIP error seen by this library on the calling thread ("" if none). */
 const char *clapgpu_last_error(void);
+/* For the CALLERS' failure-path tests (oracle/ref/dropin.c `fail`, tests/test_dropin.py): after `launches` more kernel
+ * launches have been checked, every later launch of this process reports a launch failure (the kernel itself runs;
+ * the entry point returns CLAPGPU_ERR_UNKNOWN with clapgpu_last_error() set).  < 0 turns it off (the default). */
+void clapgpu_test_fail_after(int launches);
 /* ABI version: bumped whenever a signature or struct below changes. */
 uint32_t clapgpu_abi_version(void);
 
@@ -438,23 +442,28 @@ typedef struct clapgpu_skeleton {
  */
 typedef struct clapgpu_animations {
     uint32_t        n_anims;
-    uint32_t        n_times;        /* floats in times[]: pools of <= 6400 are kept in LDS */
+    uint32_t        n_times;        /* floats in times[] (0: unknown) */
     const uint32_t *chan_table;
     const float    *times;
     const float    *data;
-    /* optional (NULL / 0): the key-major copy of the pools made by clapgpu_animations_pack() for this model, and the
-     * max_keys it was made with.  Skeletons whose animations' key rows fit in LDS (one animation of <= 31 keys per
-     * channel, two of <= 15, ...) then take the loop whose per-lane key searches are free of LDS bank conflicts, whose
-     * key gathers are contiguous rows and in which no wavefront waits for its own stores -- one wavefront per character
-     * up to 64 joints, two to four above. */
+    /* the key-major copy of the pools made by clapgpu_animations_pack() for this model, the max_keys it was made with and
+     * the layout word pack() returned (lanes, animation count, whether some (joint, path) has no channel).  REQUIRED by
+     * clapgpu_pose_update(): besides the re-layout the copy holds, per rotation key pair, what quat_slerp (interp.h:91-118)
+     * derives from the pair alone -- acos of the inner product and its sine -- evaluated by the host's libm, the very calls
+     * the reference makes; the kernel has no other source for them.  Skeletons whose animations' key rows fit in LDS (one
+     * animation of <= 31 keys per channel, two of <= 15, ...) search them there; one wavefront per character up to
+     * 64 joints, two to four above. */
     const void     *packed;
-    uint32_t        packed_keys, pad;
+    uint32_t        packed_keys, packed_layout;
 } clapgpu_animations;
 
-/* Key-major pools, once per model (a device-side re-layout of chan_table / times / data; nothing is interpolated).
- * max_keys = the largest nr of any channel; packed: clapgpu_animations_packed_bytes() of device memory, 16-byte aligned. */
+/* Key-major pools, once per model: a HOST-side re-layout of chan_table / times / data (three synchronous copies on
+ * `stream`) plus the rotation intervals' constants.  max_keys = the largest nr of any channel; packed:
+ * clapgpu_animations_packed_bytes() of device memory, 16-byte aligned; *packed_layout goes into
+ * clapgpu_animations.packed_layout (clapgpu_pose_update rejects pools made for another skeleton class or animation count). */
 size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys, uint32_t nr_joints);
-int    clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint32_t nr_joints, uint32_t max_keys, void *packed);
+int    clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint32_t nr_joints, uint32_t max_keys, void *packed,
+                               uint32_t *packed_layout);
 
 /*
  * The animated entities of that model.

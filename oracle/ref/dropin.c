@@ -1330,9 +1330,27 @@ static int cmd_lights(uint32_t frames, uint64_t seed)
     return bad ? 1 : 0;
 }
 
+static int run(int argc, char **argv);
+
+/* Every mode also fails when any call of the binding failed on the device and was served by the engine's host path:
+ * the worlds still agree then (the reference's loop ran on both), which is exactly why the comparison alone must not pass. */
 int main(int argc, char **argv)
 {
+    int rc = run(argc, argv);
+    if (gpu_scene_device_errors()) {
+        fprintf(stderr, "clap_dropin: device_errors = %u -- the binding fell back to the host path (%s)\n", gpu_scene_device_errors(), clapgpu_last_error());
+        if (!rc) rc = 3;
+    }
+    return rc;
+}
+
+static int run(int argc, char **argv)
+{
     if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
+    if (argc >= 6 && !strcmp(argv[1], "fail")) {                        /* fail <launches> <entities> <frames> <seed>: `test` with the device failing after <launches> launches */
+        clapgpu_test_fail_after(atoi(argv[2]));
+        return cmd_test((uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
+    }
     if (argc >= 4 && !strcmp(argv[1], "snapshot"))
         return cmd_snapshot((uint32_t)atoi(argv[2]), argv[3]);
     if (argc >= 2 && !strcmp(argv[1], "edge"))

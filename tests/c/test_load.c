@@ -178,7 +178,15 @@ static int replay(clapgpu_snapshot *s)
     UP(d_vpos, vpos, 12 * V); UP(d_vnor, vnor, 12 * V); UP(d_vj, vj, 4 * V); UP(d_vw, vw, 16 * V); UP(d_vf, vf, 4 * nc); UP(d_vc, vc, 4 * nc);
     UP(d_op, NULL, (size_t)12 * V * nc); UP(d_on, NULL, (size_t)12 * V * nc);
     const clapgpu_skeleton sk = { J, levels, d_parent, d_depth, d_root, d_inv, d_bind };
-    const clapgpu_animations an = { n_anims, t_total, d_table, d_times, d_data };
+    clapgpu_animations an = { n_anims, t_total, d_table, d_times, d_data, NULL, 0, 0 };
+    {                                                                   /* the key-major pools (required): once per model */
+        uint32_t max_keys = 0, layout = 0;
+        void *d_packed;
+        for (size_t q = 0; q < (size_t)n_anims * J * 3; q++) if (table[4 * q + 2] > max_keys) max_keys = table[4 * q + 2];
+        CHECK(!clapgpu_malloc(&d_packed, clapgpu_animations_packed_bytes(n_anims, max_keys, J)), "malloc packed");
+        CHECK(!clapgpu_animations_pack(NULL, &an, J, max_keys, d_packed, &layout), "animations_pack: %s", clapgpu_last_error());
+        an.packed = d_packed; an.packed_keys = max_keys; an.packed_layout = layout;
+    }
     clapgpu_pose_batch pb = { nc, 0, d_anim, d_ft, NULL, d_cmx, d_trs, d_jt, d_jp };
     uint32_t *of = malloc(4 * nc);
     void *d_of;

@@ -201,3 +201,19 @@ def test_binding_bench_mode_is_consistent(notify):
     r = _run("bench", 10000, 5, 300, *(["notify"] if notify else []))
     assert r["mismatches"] == 0 and r["visible_equal"] is True
     assert r["binding_mq_update_ms"] > 0 and r["reference_mq_update_ms"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launches", [0, 7])
+def test_checker_refuses_to_pass_on_the_host_fallback(launches):
+    """A device that fails must not look like a slow frame.  `fail <launches>` runs the scripted game with every kernel
+    launch after the first <launches> reporting a launch failure (clapgpu_test_fail_after): the engine-side exports
+    (gpu-exports.inc.c) then serve mq_update from the reference's host loop -- the two worlds still agree bit for bit,
+    which is why the comparison alone would pass -- report it on stderr with clapgpu_last_error() and count it in
+    gpu_scene_last_stats()->device_errors; the checker (every mode ends on that counter) exits non-zero."""
+    if not os.access(BIN, os.X_OK):
+        pytest.skip("oracle/_ref/clap_dropin not built (needs the reference tree at build time)")
+    p = subprocess.run([BIN, "fail", str(launches), "2000", "8", "3"], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0, "the checker passed although the device path failed"
+    assert "device_errors" in p.stderr or "did not run" in p.stderr, p.stderr[-1500:]
+    assert "gpu_mq_update failed" in p.stderr or "clap gpu binding" in p.stderr or "did not run" in p.stderr, p.stderr[-1500:]
