@@ -9,7 +9,7 @@
 // Numerics (round 4): every operation of the path is the reference's operation, in the reference's
 // order, with the reference's roundings -- the file is compiled without FMA contraction like the
 // rest of the library:
-//   * key fraction: the fp32 quotient, correctly rounded (fdiv_cr);
+//   * key fraction: the fp32 quotient, correctly rounded (the compiler's IEEE division sequence);
 //   * lerp (interp.h:25-29): (float)((double)a * (1.0 - (double)f) + (double)(b * f)) in fp64 on the device;
 //   * slerp (interp.h:91-118): theta_0 = (float)acos(dot) and sin(theta_0) depend on the KEY PAIR alone, so
 //     clapgpu_animations_pack() evaluates them once per model ON THE HOST with the host's libm -- the very
@@ -76,21 +76,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---- the reference's scalar arithmetic ------------------------------------------------------------------------------
 
-// x / y rounded to nearest: reciprocal (1 ulp) + one Newton step, quotient + one residual correction (Markstein).
-// Equal to the IEEE quotient for every pair tried (3 * 10^8, tools/pose_exact_probe.c) in 6 instructions; operands here
-// are key-time differences and |v| of near-unit quaternions -- no denormals, no overflow.
-__device__ __forceinline__ float fdiv_cr(float x, float y)
-{
-    const float r0 = __builtin_amdgcn_rcpf(y);
-    const float r = __builtin_fmaf(__builtin_fmaf(-y, r0, 1.0f), r0, r0);
-    const float q = x * r;
-    return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
-}
-
 // model.c:1312-1317
 __device__ __forceinline__ float key_fac(float time, float p_time, float n_time)
 {
-    const float q = fdiv_cr(time - p_time, n_time - p_time);    // p_time == n_time: a NaN nobody reads
+    const float q = (time - p_time) / (n_time - p_time);        // the IEEE quotient (hipcc's default fp32 division is correctly rounded);
+                                                                // p_time == n_time: a NaN nobody reads
     return p_time < n_time ? q : (p_time > n_time && time < n_time ? 1.f : 0.f);
 }
 
@@ -151,8 +141,10 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
         p += t[1] * t[1];
         p += t[2] * t[2];
         p += t[3] * t[3];
-        const float len = __fsqrt_rn(p);
-        const float k = fdiv_cr(1.0f, len);                      // (float)(1.0 / (double)len): the fp32 reciprocal, rounded once
+        const float len = sqrtf(p);                                // correctly rounded (__fsqrt_rn is the bare v_sqrt_f32: 1 ulp)
+        // vec4_norm's k = 1.0 / len is a DOUBLE quotient rounded to float.  (A Newton / Markstein reciprocal in fp32 ties at
+        // len = 1 - 2^-24, the length rounding gives nearly-unit quaternions half of the time, and rounds it to even.)
+        const float k = (float)(1.0 / (double)len);
 #pragma unroll
         for (int i = 0; i < 4; i++) res[i] = t[i] * k;
         return;
