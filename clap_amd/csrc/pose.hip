@@ -15,13 +15,14 @@
 //     clapgpu_animations_pack() evaluates them once per model ON THE HOST with the host's libm -- the very
 //     calls the reference makes -- and stores them per key interval; sin(theta) and cos(theta) of the frame
 //     are fp64 polynomials on [0, pi/2] whose fp64 error (<= 2 ulp) flips the FLOAT the reference rounds
-//     them to about once in 10^8 evaluations (none in 2 * 10^8 against glibc, tools/pose_exact_probe.c);
-//     the two quotients by sin(theta_0) are fp64 products with its stored reciprocal, rounded to float
-//     (equal to the fp32 quotient but for the same 10^-8);
+//     them to less than once in 10^8 evaluations (none in 2 * 10^8 against glibc, tools/pose_exact_probe.c);
+//     the two quotients by sin(theta_0) are fp64 products with its stored reciprocal, rounded to float: the fp32
+//     quotient exactly (a quotient of two floats keeps 2^-49 away from every rounding boundary, the product errs by 2^-52);
 //   * hierarchy: global[j] = ((global[parent] * T) * R) * S, evaluated level by level in THAT association
 //     (model.c:1363-1383), then * invmx (model.c:1389), * bind's translation column, e->mx * (model.c:1392-1400).
-// T / R / S, the palette and the joint positions therefore come out bit-identical to the reference's for all but
-// a handful of joints per million, and those differ by one fp32 ulp of one slerp weight.
+// T / R / S, the palette and the joint positions therefore EQUAL the reference's, value for value: 0 of 3.2 M joints
+// differ at BASELINE configs[2] (tests/test_pose_skin_gpu.py, tools/pose_exact_check.py), and so do the skinned vertices.
+// (Values, not bit patterns: the "0.f +" that opens mat4x4_mul's sums turns a -0 sum into +0; the kernel leaves it out.)
 //
 // Mapping: one lane per joint, a 64-joint skeleton = one wavefront = one character for the keyframe work and the
 // palette; the hierarchy runs as "level passes": the joints of one level, FOUR LANES EACH (one per column of the
@@ -30,6 +31,8 @@
 // `global` is scratch); keyframes are per model: times in LDS, values in L2.
 // HBM: ~200 B / joint: T/R/S 40 B, joint_transforms 64 B, joint pos 16 B written.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "common.h"
@@ -314,8 +317,9 @@ void k_pose(PoseArgs a)
     // passes[p] = (first entry, entries) -- a level of w joints is ceil(w / SPP) passes
     __shared__ uint32_t order_lds[POSE_MAX_JOINTS];
     __shared__ uint2 passes_lds[POSE_MAX_JOINTS];
-    __shared__ int depth_lds[POSE_MAX_JOINTS];
-    __shared__ uint32_t lvl_w[POSE_MAX_JOINTS], lvl_start[POSE_MAX_JOINTS];
+    __shared__ int16_t depth_lds[POSE_MAX_JOINTS];
+    __shared__ uint32_t lvl_w[POSE_MAX_JOINTS];
+    __shared__ uint16_t lvl_start[POSE_MAX_JOINTS];
     __shared__ uint32_t n_passes_s;
     extern __shared__ uint32_t prog_lds[];                       // [prog_passes][LPC] program words (dynamic: sized by the host from n_levels)
 
@@ -327,7 +331,7 @@ void k_pose(PoseArgs a)
 
     // ---- once per (persistent) block: tables ---------------------------------------------------------------------------
     for (int q = tid; q < POSE_MAX_JOINTS; q += BLOCK) {
-        depth_lds[q] = (uint32_t)q < J ? a.depth[q] : -1;
+        depth_lds[q] = (int16_t)((uint32_t)q < J ? a.depth[q] : -1);
         lvl_w[q] = 0;
     }
     if (j == 0) {
@@ -354,7 +358,7 @@ void k_pose(PoseArgs a)
     if (tid == 0) {
         uint32_t at = 0, np = 0;
         for (uint32_t L = 0; L < J && lvl_w[L]; L++) {           // levels are contiguous from 0 (depth = 1 + the parent's)
-            lvl_start[L] = at;
+            lvl_start[L] = (uint16_t)at;
             for (uint32_t q = 0; q < lvl_w[L]; q += SPP)
                 passes_lds[np++] = make_uint2(at + q, lvl_w[L] - q < (uint32_t)SPP ? lvl_w[L] - q : (uint32_t)SPP);
             at += lvl_w[L];
@@ -779,6 +783,9 @@ static int pose_launch(hipStream_t s, PoseArgs &a, bool missing, bool times_lds,
         cache.dyn[slot] = dyn;
     }
     const dim3 grid(n_groups < res ? n_groups : res), block(BLOCK);
+    if (getenv("CLAPGPU_POSE_DEBUG"))
+        fprintf(stderr, "k_pose<%d, %d>: %u blocks resident (%u per CU), static LDS %zu + dynamic %u, %u program passes\n", LPC, BLOCK,
+                res, res / (uint32_t)n_cus, cache.stat[slot], dyn, want);
     if (missing) {
         if (times_lds) hipLaunchKernelGGL((k_pose<LPC, BLOCK, true, true>), grid, block, dyn, s, a);
         else hipLaunchKernelGGL((k_pose<LPC, BLOCK, true, false>), grid, block, dyn, s, a);
@@ -851,10 +858,15 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
             cus.n_cus = prop.multiProcessorCount;
         }
     }
+    // One block per CU, as many wavefronts as its LDS and the registers allow: the model's key times (25 KiB per 64 lanes)
+    // are staged once per block, each character in flight needs 8.2 KiB (globals + local columns) per 64 joints, and at
+    // ~160 VGPRs three wavefronts fit a SIMD -- 12 characters of <= 64 joints per block (136 + 3 KiB of the CU's 160).
+    // (Two blocks of 320 threads measured as ONE resident block per CU although 2 x 80.8 KB fit 160 KiB on paper; two of
+    // 256: 121 / 139 us against 112 / 136 for this form.)
     switch (lpc) {
-    case 64:  return pose_launch<64, 320>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
-    case 128: return pose_launch<128, 256>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
-    case 192: return pose_launch<192, 192>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
+    case 64:  return pose_launch<64, 768>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
+    case 128: return pose_launch<128, 512>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
+    case 192: return pose_launch<192, 384>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
     default:  return pose_launch<256, 256>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
     }
 }

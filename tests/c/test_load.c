@@ -8,7 +8,7 @@
  *    loaded, never crash (the sanitizer build of tests/test_load_scene.py runs exactly this, -DTEST_LOAD_NO_GPU);
  * 3. (GPU build) replays the loaded scene like the engine's frame would: entities through the C host mirror
  *    (clapgpu_scene_*) against the oracle's entity update, bit for bit; the two characters' pose and skinning through
- *    the flat ABI (clapgpu_pose_update, clapgpu_skin) against the oracle within 1e-5.
+ *    the flat ABI (clapgpu_pose_update, clapgpu_skin) against the oracle, value for value.
  * Built and run by tests/test_load_scene.py.  Exit code 0 and "PASS" = pass.
  */
 #include <math.h>
@@ -212,21 +212,19 @@ static int replay(clapgpu_snapshot *s)
         for (uint32_t c = 0; c < nc; c++) {
             clapo_pose_channels(&oan[a], ft[c], o_trs + (size_t)c * J * 10, cursor + (size_t)c * J * 3);
             clapo_pose_palette(&osk, o_trs + (size_t)c * J * 10, char_mx + 16 * c, o_gl + (size_t)c * J * 16, o_jt + (size_t)c * J * 16, o_jp + (size_t)c * J * 4);
-            double scale = 1.0, err = 0.0;
+            uint32_t differ = 0;                                        /* equal as values (the kernel's arithmetic is the reference's) */
             for (uint32_t k = 0; k < n_order; k++) for (int x = 0; x < 16; x++) {
                 const size_t at = ((size_t)c * J + (size_t)order[k]) * 16 + x;
-                if (fabs(o_jt[at]) > scale) scale = fabs(o_jt[at]);
-                if (fabs((double)g_jt[at] - o_jt[at]) > err) err = fabs((double)g_jt[at] - o_jt[at]);
+                differ += !(g_jt[at] == o_jt[at]);
             }
-            CHECK(err <= 1e-5 * scale, "frame %d character %u: palette differs by %.3g (scale %.3g)", f, c, err, scale);
+            CHECK(!differ, "frame %d character %u: %u palette floats differ from the oracle's", f, c, differ);
             clapo_skin(V, vpos, vnor, vj, vw, o_jt + (size_t)c * J * 16, o_op, o_on);
-            double ps_ = 1.0, pe = 0.0, ne = 0.0;
+            uint32_t pd = 0, nd = 0;
             for (uint32_t x = 0; x < 3 * V; x++) {
-                if (fabs(o_op[x]) > ps_) ps_ = fabs(o_op[x]);
-                if (fabs((double)g_op[(size_t)c * 3 * V + x] - o_op[x]) > pe) pe = fabs((double)g_op[(size_t)c * 3 * V + x] - o_op[x]);
-                if (fabs((double)g_on[(size_t)c * 3 * V + x] - o_on[x]) > ne) ne = fabs((double)g_on[(size_t)c * 3 * V + x] - o_on[x]);
+                pd += !(g_op[(size_t)c * 3 * V + x] == o_op[x]);
+                nd += !(g_on[(size_t)c * 3 * V + x] == o_on[x]);
             }
-            CHECK(pe <= 1e-5 * ps_ && ne <= 1e-5 * ps_, "frame %d character %u: skinned position / normal differ by %.3g / %.3g", f, c, pe, ne);
+            CHECK(!pd && !nd, "frame %d character %u: %u skinned position / %u normal floats differ from the oracle's", f, c, pd, nd);
         }
     }
     clapgpu_scene_destroy(sc);

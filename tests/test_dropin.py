@@ -98,23 +98,22 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     """default_update -> animated_update per entity (reference: clock, queue, channels_transform,
     one_joint_transform) vs gpu_mq_update + gpu_anim_update (binding -> HIP) on the reference's own model3d
     (model3d_add_skinning, animation_new / _add_channel), entities from ref_new(entity3d) and queues from
-    animation_push_by_name: transforms bit for bit; each joint's T, R, S, the 3x3 block and the translation column of
-    its palette matrix and its world position within 1e-5 of ITS OWN magnitude (sums that cancelled far below their
-    terms: within 64 fp32 ulps of those terms, counted and reported); e->animation, the queue length, ani_time and the
-    libc drand48 position (the random idle phase of animation_next) exactly; joints outside joint 0's tree untouched
-    on both sides.
+    animation_push_by_name: transforms bit for bit; each joint's T, R, S, its palette matrix and its world position EQUAL
+    to the reference's, value for value (round 4: the kernel performs the reference's arithmetic); e->animation, the queue
+    length, ani_time and the libc drand48 position (the random idle phase of animation_next) exactly; joints outside
+    joint 0's tree untouched on both sides.
     Entities riding a character's joint (e->parent_joint, model.c:1626-1641) and their children: those listed after the
     character get the joint transforms of the SAME frame -- on the DEVICE, by the frame's second entity launch behind
     the pose (gpu_scene_run_deferred -> clapgpu_scene_attached_update; counted in attached_batched_updates) --, those
-    listed before it the previous frame's, on the host, as in the reference; their matrices and boxes within the pose
-    bar, their seq counters exactly."""
+    listed before it the previous frame's, on the host, as in the reference; their matrices, boxes and seq counters
+    equal to the reference's."""
     r = _run("anim", n_chars, joints, frames, seed)
     assert r["mismatches"] == 0
-    assert r["worst_relative_error"] <= 1e-5 and r["worst_cancelled_ulps"] <= 64
+    assert r["worst_relative_error"] == 0 and r["differing_objects"] == 0 and r["tolerance"] == 0
     assert r["animation_restarts"] > 0 and r["joint_poses_compared"] == frames * n_chars * joints
     assert r["frames_timed"] == max(frames - 2, 0) and (frames <= 2 or (r["reference_ms_per_frame"] > 0 and r["binding_ms_per_frame"] > 0))
     n_held = n_chars // 3 + 2
-    assert r["joint_attached_checks"] == frames * 3 * n_held and r["worst_joint_attached_error"] <= 1e-5
+    assert r["joint_attached_checks"] == frames * 3 * n_held and r["worst_joint_attached_error"] == 0 and r["joint_attached_differing"] == 0
     # of each triple (rider listed after its character, rider listed before it, plain child of the first) the first and
     # the third go through the device's second launch, every frame (the checker counts them: a rider whose joint number
     # is JOINT_TYPE_MAX is "no joint" to the reference itself and takes the first launch)

@@ -264,7 +264,7 @@ C_FP, C_INT = _C.POINTER(_C.c_float), _C.c_int
 @pytest.mark.gpu
 def test_loaded_scene_replays_on_the_gpu(loaded, cuda_device):
     """The loaded scene through the kernels: entity update (tile layout) bit-exact against the oracle, then the
-    characters' pose (both animations, several times) and skinning within 1e-5."""
+    characters' pose (both animations, several times) and skinning, value for value."""
     from clap_amd import animation, entities, tiler
     comps, _exp, _js = loaded
     raw = dict(comps["entities"])
@@ -299,18 +299,16 @@ def test_loaded_scene_replays_on_the_gpu(loaded, cuda_device):
             cb.skin()
             got = cb.download()
             jt, _g, jp = ob.pose(sk, anims[a_id], t, char_mx, trs)
-            scale = max(float(np.abs(jt[:, reach]).max()), 1.0)
-            assert np.abs(got["joint_transforms"][:, reach] - jt[:, reach]).max() <= 1e-5 * scale
-            assert np.abs(got["joint_pos"][:, reach] - jp[:, reach]).max() <= 1e-5 * max(float(np.abs(jp).max()), 1.0)
+            assert np.array_equal(got["joint_transforms"][:, reach], jt[:, reach])          # equal as values (round 4)
+            assert np.array_equal(got["joint_pos"][:, reach], jp[:, reach])
             op, on = ob.skin(mesh, np.zeros(n, np.uint32), np.full(n, V, np.uint32), jt)
-            assert np.abs(got["out_position"] - op).max() <= 1e-5 * max(float(np.abs(op).max()), 1.0)
-            assert np.abs(got["out_normal"] - on).max() <= 1e-5 * max(float(np.abs(on).max()), 1.0)
+            assert np.array_equal(got["out_position"], op) and np.array_equal(got["out_normal"], on)
 
 
 @pytest.mark.gpu
 def test_c_program_loads_and_replays_the_fixture(tmp_path, cuda_device):
     """tests/c/test_load.c: load scene.json + hero.glb from C, replay entities through the C host mirror (bit-exact
-    against the oracle) and the characters' pose / skinning through the flat ABI (1e-5)."""
+    against the oracle) and the characters' pose / skinning through the flat ABI (equal values)."""
     ob.lib()                                                  # builds oracle/_build/libclap_oracle.so
     exe = str(tmp_path / "test_load")
     odir = os.path.join(ROOT, "oracle", "_build")
