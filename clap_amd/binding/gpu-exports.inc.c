@@ -19,6 +19,8 @@
  *       one entity's update outside the frame loop (instantiate_entity model.c:1872, terrain.c:551): the reference's
  *       body -- a single entity is host work -- + gpu_scene_host_updated(), which brings the device's copy of a
  *       batched entity (and, through its seq, its children) up to date with the next mq_update
+ *   void entity3d_set_lod(entity3d *e, int lod, bool force)         model.h:692   model.c:593-609
+ *       the reference's body + gpu_scene_lod_changed(): the per-pass LOD pick (gpu_scene_select_lod) runs on the device
  *   void particle_system_position(particle_system *ps, const vec3 c) particle.h:47  particle.c:132-157
  *       in gpu-particles.inc.c (the struct is private to particle.c): an attached, mirrored system carries its
  *       device-resident particles along
@@ -104,6 +106,15 @@ void entity3d_reset(entity3d *e)
 {
     ref_entity3d_reset(e);
     gpu_scene_host_updated(gpu_scene_bound(), e);
+}
+
+/* model.h:676-692, model.c:593-609: the reference's body, then the mirror of a batched entity learns its force_lod /
+ * cur_lod (gpu_scene_select_lod picks on the device from there on) */
+void ref_entity3d_set_lod(entity3d *e, int lod, bool force);
+void entity3d_set_lod(entity3d *e, int lod, bool force)
+{
+    ref_entity3d_set_lod(e, lod, force);
+    gpu_scene_lod_changed(gpu_scene_bound(), e);
 }
 
 #endif /* CONFIG_GPU_SCENE */

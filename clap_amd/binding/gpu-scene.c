@@ -50,6 +50,9 @@ bool ref_view_entity_in_frustum(struct view *view, entity3d *e);
 /* and so is entity3d_update: the hooks this file runs itself are the reference's dispatch, not a notification */
 void ref_entity3d_update(entity3d *e, void *data);
 #define entity3d_update ref_entity3d_update
+/* and entity3d_set_lod: the pick this file makes for a host-class entity is the reference's own, not a notification */
+void ref_entity3d_set_lod(entity3d *e, int lod, bool force);
+#define entity3d_set_lod ref_entity3d_set_lod
 #endif
 #include "clapgpu_scene.h"
 #include "clapgpu_snapshot.h"
@@ -78,9 +81,10 @@ struct gs_rec {
     uint8_t     host_done;      /* entity3d_update() / entity3d_reset() ran this entity's update on the host between frames: the device
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
+    int32_t     lod_force, lod_cur; /* e->force_lod / e->cur_lod as the mirror holds them (gpu_scene_select_lod) */
 };
 
-struct gs_model { model3d *model; uint32_t handle; };
+struct gs_model { model3d *model; uint32_t handle; unsigned int lod_min, lod_max; };
 
 static struct gpu_scene *g_bound;     /* the scene the engine-named entry points (gpu-exports.inc.c) serve */
 
@@ -125,6 +129,7 @@ struct gpu_scene {
     void            *hook_data;                                    /* mq->priv of the running gpu_mq_update(): what the hooks get as `data` */
     struct view     *culled_view;
     vec4            culled_planes[6];
+    entity3d        **draw; int32_t *draw_lod; uint32_t n_draw, cap_draw;   /* gpu_scene_select_lod's draw list */
     struct gpu_scene_stats stats;
 };
 
@@ -211,7 +216,9 @@ static int model_handle(struct gpu_scene *gs, model3d *m, uint32_t *out)
     const float aabb[6] = { m->aabb[0][0], m->aabb[0][1], m->aabb[0][2], m->aabb[1][0], m->aabb[1][1], m->aabb[1][2] };
     int rc = clapgpu_scene_model_new(gs->scene, aabb, m->skip_aabb, out);
     if (rc) return rc;
-    gs->models[gs->n_models++] = (struct gs_model){ m, *out };
+    rc = clapgpu_scene_model_lods(gs->scene, *out, m->lod_min, m->lod_max);
+    if (rc) return rc;
+    gs->models[gs->n_models++] = (struct gs_model){ m, *out, m->lod_min, m->lod_max };
     return 0;
 }
 
@@ -238,6 +245,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
+    free(gs->draw); free(gs->draw_lod);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -443,7 +451,12 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
         CK(clapgpu_scene_entity_new(gs->scene, mh, (void *)(uintptr_t)((uint32_t)(r - gs->rec) + 1u), &r->handle));
         r->model = model;
         r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;            /* what entity_new starts with */
+        r->lod_force = -1; r->lod_cur = 0;                        /* likewise (entity3d_make, model.c:1741) */
         st->registered++;
+    }
+    if (e->force_lod != r->lod_force || e->cur_lod != r->lod_cur) {   /* entity3d_set_lod since (model.c:593-609) */
+        CK(clapgpu_scene_entity_lod(gs->scene, r->handle, e->force_lod, e->cur_lod));
+        r->lod_force = e->force_lod; r->lod_cur = e->cur_lod;
     }
     const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
     if (flags != r->flags) {
@@ -1331,6 +1344,124 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
         }
     }
     return view_entity_in_frustum(view, e);
+}
+
+/*
+ * _models_render's per-entity block (model.c:959-992) for one entity on the host -- the engine's own predicates,
+ * entity3d_aabb_avg_edge and entity3d_set_lod around the five lines of glue between them -- for the entities the
+ * device does not hold (foreign hooks, physics bodies, ...).  Returns whether the pass draws the entity.
+ */
+static bool lod_pick_host(struct view *view, entity3d *e, const float *cam_pos)
+{
+    if (!entity3d_matches(e, ENTITY3D_ALIVE) || !entity3d_matches(e, ENTITY3D_VISIBLE))
+        return false;
+    if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && view && !view_entity_in_frustum(view, e))
+        return false;
+    if (cam_pos) {
+        if (e->force_lod >= 0) {
+            e->cur_lod = e->force_lod;
+        } else if (!aabb_point_is_inside(e->aabb, cam_pos)) {       /* only when the camera is outside the box */
+            vec3 dist;
+            vec3_sub(dist, e->aabb_center, cam_pos);
+            const float side = entity3d_aabb_avg_edge(e);
+            const float scale = fabsf(vec3_mul_inner(dist, dist) - side * side) / 3600.0;
+            entity3d_set_lod(e, (int)scale, false);
+        }
+    }
+    return true;
+}
+
+static int draw_push(struct gpu_scene *gs, entity3d *e, int lod)
+{
+    if (gs->n_draw == gs->cap_draw) {
+        const uint32_t cap = gs->cap_draw ? 2 * gs->cap_draw : 4096;
+        entity3d **d = realloc(gs->draw, (size_t)cap * sizeof(*d));
+        if (!d) return _CERR_NOMEM;
+        gs->draw = d;
+        int32_t *l = realloc(gs->draw_lod, (size_t)cap * sizeof(*l));
+        if (!l) return _CERR_NOMEM;
+        gs->draw_lod = l;
+        gs->cap_draw = cap;
+    }
+    gs->draw[gs->n_draw] = e;
+    gs->draw_lod[gs->n_draw++] = lod;
+    return 0;
+}
+
+void gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !e) return;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return;
+    struct gs_rec *r = &gs->rec[i];
+    if (r->handle == CLAPGPU_NO_ENTITY || (e->force_lod == r->lod_force && e->cur_lod == r->lod_cur)) return;
+    if (!clapgpu_scene_entity_lod(gs->scene, r->handle, e->force_lod, e->cur_lod)) {
+        r->lod_force = e->force_lod; r->lod_cur = e->cur_lod;
+    }
+}
+
+int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *cam_pos)
+{
+    if (!gs) return _CERR_INVALID_ARGUMENTS;
+    gs->n_draw = 0;
+    /* the frustum the device's mask answers for: the one of the last update, or a cull launch for this view's planes */
+    if (view) {
+        if (view != gs->culled_view || !gs->cull_checked || !gs->cull_ok) {
+            const bool same = view == gs->culled_view && !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+            if (!same) {
+                clapgpu_frustum fr;
+                frustum_of(view, &fr);
+                CK(clapgpu_scene_cull(gs->scene, &fr));
+                memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+                gs->culled_view = view;
+            }
+            gs->cull_checked = gs->cull_ok = true;
+        }
+    }
+    /* models whose LOD range moved since they were registered (model3d's mesh LODs are added at load time) */
+    for (uint32_t k = 0; k < gs->n_models; k++) {
+        struct gs_model *gm = &gs->models[k];
+        if (gm->lod_min != gm->model->lod_min || gm->lod_max != gm->model->lod_max) {
+            CK(clapgpu_scene_model_lods(gs->scene, gm->handle, gm->model->lod_min, gm->model->lod_max));
+            gm->lod_min = gm->model->lod_min; gm->lod_max = gm->model->lod_max;
+        }
+    }
+    /* a frame that is walked re-reads every batched entity's force_lod / cur_lod anyway (mirror()); in notification
+     * mode the engine's entity3d_set_lod reports them (gpu-exports.inc.c -> gpu_scene_lod_changed) */
+    uint32_t n = 0;
+    if (gs->n_batched) {
+        const int rc = clapgpu_scene_select_lod(gs->scene, cam_pos, &n);
+        if (rc && rc != CLAPGPU_ERR_NOT_SUPPORTED) return rc;
+    }
+    clapgpu_scene_arrays res;
+    const uint32_t *slots = NULL; const int32_t *lods = NULL;
+    if (n && !clapgpu_scene_results(gs->scene, &res) && clapgpu_scene_draw_list(gs->scene, &slots, &lods) == n) {
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t tag = (uint32_t)(uintptr_t)res.slot_user[slots[k]];
+            if (!tag) continue;
+            struct gs_rec *r = &gs->rec[tag - 1];
+            if (!r->e || r->gen != gs->gen || (r->cls != 1 && r->cls != 4)) continue;
+            r->e->cur_lod = lods[k];                                /* as model.c:977 / entity3d_set_lod leave it */
+            r->lod_cur = lods[k];
+            CK(draw_push(gs, r->e, lods[k]));
+        }
+    }
+    /* the entities the device does not hold, in list order, by the reference's own block */
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (!r->e || r->cls == 1 || r->cls == 4) continue;
+        if (lod_pick_host(view, r->e, cam_pos))
+            CK(draw_push(gs, r->e, r->e->cur_lod));
+    }
+    return 0;
+}
+
+uint32_t gpu_scene_visible(struct gpu_scene *gs, entity3d ***ents, const int32_t **lods)
+{
+    if (!gs) return 0;
+    if (ents) *ents = gs->draw;
+    if (lods) *lods = gs->draw_lod;
+    return gs->n_draw;
 }
 
 int gpu_scene_snapshot_begin(struct gpu_scene *gs, const char *path, struct clapgpu_snapshot_writer **out)

@@ -65,6 +65,26 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
  * route has to call this too. */
 void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view);
 
+/*
+ * One render pass of _models_render over the bound queue (model.c:958-992) without its per-entity host loop: which
+ * entities the pass draws -- ALIVE, VISIBLE and SKIP_CULLING or inside `view`'s frustum -- and the LOD each is drawn
+ * with, written to e->cur_lod exactly as the reference's block writes it: force_lod wins (model.c:976-977); inside the
+ * entity's box the LOD stays (model.c:982); otherwise entity3d_set_lod(e, (int)(|dist^2 - avg_edge^2| / 3600), false)
+ * (model.c:983-990, entity3d_aabb_avg_edge model.c:1261-1264, the clamp of model.c:63-66, 593-609).  Batched entities:
+ * two launches over the device's boxes (ordered visible list, LOD pick) and a write-back of the DRAWN entities only;
+ * host-class entities: the reference's own functions, on the host.  cam_pos = transform_pos(&camera->xform, NULL), NULL
+ * for a pass without a camera (model.c:974): the list alone.  `view` other than the one the last update culled
+ * against, or with planes that moved since (scene_cameras_calc runs after mq_update), costs one more cull launch.
+ * Call after gpu_mq_update() of the frame.  gpu_scene_visible(): the draw list of the last call -- batched entities in
+ * device order, then host-class entities in list order -- for _models_render to iterate instead of every entity3d of
+ * every txmodel (it binds per txmodel: e->txmodel of each entry says which).
+ * gpu_scene_lod_changed(): entity3d_set_lod() wrote e->force_lod / e->cur_lod outside a walked frame (the engine-side
+ * export reports it by itself, gpu-exports.inc.c).
+ */
+int      gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *cam_pos);
+uint32_t gpu_scene_visible(struct gpu_scene *gs, entity3d ***ents, const int32_t **lods);
+void     gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e);
+
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 
 /* A call of the binding failed (rc != 0) and the caller is about to take the engine's host path instead: counted for the

@@ -26,6 +26,7 @@ struct ent {
     uint32_t slot;
     void    *user;
     uint8_t  live, dirty, attached;   /* attached: rides a joint of its parent (e->parent_joint, model.c:1626-1641) */
+    int32_t  force_lod, cur_lod;      /* entity3d.force_lod / .cur_lod (model.h:415-416; entity3d_set_lod, model.c:593-609) */
 };
 
 /* the flags word of the upload image: the entity3d bits + what only the device knows */
@@ -89,6 +90,15 @@ struct clapgpu_scene {
     float      *d_models; uint32_t d_models_cap;
     int         have_results;
     uint32_t    layout_gen;
+
+    /* the render passes' LOD pick and draw list (clapgpu_scene_select_lod): force_lod / cur_lod in slot order on both
+     * sides (the host copy follows every pick, so a range of it can be pushed at any time), the ordered visible list
+     * and the LOD each entry is drawn with */
+    int32_t    *h_force_lod, *h_cur_lod;  int32_t *d_force_lod, *d_cur_lod;
+    uint32_t   *d_visible, *d_visible_count; int32_t *d_draw_lod; void *d_vis_scratch;
+    uint32_t   *h_draw_slot; int32_t *h_draw_lod; uint32_t *h_visible_count;     /* page-locked */
+    uint32_t    lod_cap, lod_lo, lod_hi, n_draw;                                  /* [lod_lo, lod_hi): host values not on the device yet */
+    uint32_t    lod_layout_gen;
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -174,8 +184,23 @@ void clapgpu_scene_set_zero_copy_slots(clapgpu_scene *s, uint32_t max_slots)
 
 int clapgpu_scene_is_zero_copy(const clapgpu_scene *s) { return s ? s->zero_copy : 0; }
 
+static void free_lod(clapgpu_scene *s)
+{
+    void *dev[] = { s->d_force_lod, s->d_cur_lod, s->d_visible, s->d_visible_count, s->d_draw_lod, s->d_vis_scratch };
+    for (unsigned i = 0; i < sizeof(dev) / sizeof(dev[0]); i++)
+        if (dev[i]) clapgpu_free(dev[i]);
+    void *host[] = { s->h_draw_slot, s->h_draw_lod, s->h_visible_count };
+    for (unsigned i = 0; i < sizeof(host) / sizeof(host[0]); i++)
+        if (host[i]) clapgpu_host_free(host[i]);
+    free(s->h_force_lod); free(s->h_cur_lod);
+    s->d_force_lod = s->d_cur_lod = s->d_draw_lod = NULL; s->d_visible = s->d_visible_count = NULL; s->d_vis_scratch = NULL;
+    s->h_draw_slot = NULL; s->h_draw_lod = NULL; s->h_visible_count = NULL; s->h_force_lod = s->h_cur_lod = NULL;
+    s->lod_cap = 0; s->n_draw = 0;
+}
+
 static void free_device(clapgpu_scene *s)
 {
+    free_lod(s);
     void *p[] = { s->d_in, s->d_out, (void *)s->d.parent, (void *)s->d.model, s->d.seqs, s->d.vis_row_pop,
                   s->d_tile_row_start };
     for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++)
@@ -218,8 +243,17 @@ int clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aabb
     uint32_t skip = skip_aabb ? 1u : 0u;
     row[0] = aabb[0]; row[1] = aabb[1]; row[2] = aabb[2];
     memcpy(&row[3], &skip, 4);
-    row[4] = aabb[3]; row[5] = aabb[4]; row[6] = aabb[5]; row[7] = 0.f;
+    row[4] = aabb[3]; row[5] = aabb[4]; row[6] = aabb[5]; row[7] = 0.f;     /* lod_min = lod_max = 0 until clapgpu_scene_model_lods */
     *model = s->n_models++;
+    s->models_dirty = 1;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_model_lods(clapgpu_scene *s, uint32_t model, unsigned int lod_min, unsigned int lod_max)
+{
+    if (!s || model >= s->n_models || lod_min > 255 || lod_max > 255) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t bits = lod_min | (lod_max << 8);
+    memcpy(&s->models[8 * (size_t)model + 7], &bits, 4);
     s->models_dirty = 1;
     return CLAPGPU_OK;
 }
@@ -248,6 +282,7 @@ int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint3
     e->model = model;
     e->user = user;
     e->live = 1;
+    e->force_lod = -1;                                  /* entity3d_make, model.c:1741; cur_lod 0 */
     s->topology_dirty = 1;
     *handle = h;
     return CLAPGPU_OK;
@@ -636,7 +671,9 @@ static int retile(clapgpu_scene *s)
     if (s->zero_copy) memset(s->h_out, 0, s->out_bytes);          /* the export kernel only writes what an update rebuilt */
     if (tiled)
         CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
-    for (uint32_t k = 0; k < s->n_dirty; k++) s->e[s->dirty_list[k]].dirty = 0;
+    /* every live handle, not only the listed ones: an entity marked dirty while the list could not grow (mark_dirty's
+     * out-of-memory path) would otherwise stay "queued" for ever and never be listed again */
+    for (uint32_t h = 0; h < H; h++) s->e[h].dirty = 0;
     s->n_dirty = 0;
     s->topology_dirty = 0;
     s->up_lo = 0xffffffffu; s->up_hi = 0;
@@ -987,6 +1024,102 @@ void clapgpu_scene_set_bv_points(clapgpu_scene *s, const float cam_pos[3], const
     s->bv_has_ctl = ctl_pos != NULL;
     if (ctl_pos) memcpy(s->bv_ctl, ctl_pos, 12);
     s->bv_ctl_handle = ctl_handle;
+}
+
+/* ---- the render passes' LOD pick and draw list (model.c:959-992) ------------------------------------------------------ */
+int clapgpu_scene_entity_lod(clapgpu_scene *s, uint32_t handle, int force_lod, int cur_lod)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    e->force_lod = force_lod;
+    e->cur_lod = cur_lod;
+    if (s->lod_cap && s->lod_layout_gen == s->layout_gen && !s->topology_dirty && e->slot < s->n_slots) {
+        s->h_force_lod[e->slot] = force_lod;
+        s->h_cur_lod[e->slot] = cur_lod;
+        if (e->slot < s->lod_lo) s->lod_lo = e->slot;
+        if (e->slot + 1 > s->lod_hi) s->lod_hi = e->slot + 1;
+    }
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_cur_lod(const clapgpu_scene *s, uint32_t handle)
+{
+    const struct ent *e = get(s, handle);
+    return e ? e->cur_lod : -1;
+}
+
+static int ensure_lod(clapgpu_scene *s)
+{
+    if (s->lod_cap < s->cap_slots) {
+        free_lod(s);
+        const size_t n = s->cap_slots;
+        s->h_force_lod = malloc(n * 4); s->h_cur_lod = malloc(n * 4);
+        if (!s->h_force_lod || !s->h_cur_lod) return CLAPGPU_ERR_NOMEM;
+        CK(clapgpu_malloc((void **)&s->d_force_lod, n * 4)); CK(clapgpu_malloc((void **)&s->d_cur_lod, n * 4));
+        CK(clapgpu_malloc((void **)&s->d_visible, n * 4));   CK(clapgpu_malloc((void **)&s->d_draw_lod, n * 4));
+        CK(clapgpu_malloc((void **)&s->d_visible_count, 16));
+        CK(clapgpu_malloc(&s->d_vis_scratch, clapgpu_visible_scratch_bytes((uint32_t)n)));
+        CK(clapgpu_host_malloc((void **)&s->h_draw_slot, n * 4)); CK(clapgpu_host_malloc((void **)&s->h_draw_lod, n * 4));
+        CK(clapgpu_host_malloc((void **)&s->h_visible_count, 16));
+        s->lod_cap = s->cap_slots;
+        s->lod_layout_gen = s->layout_gen - 1;                       /* force the fill below */
+    }
+    if (s->lod_layout_gen != s->layout_gen) {                        /* a re-tile moved the entities: slot order anew */
+        for (uint32_t i = 0; i < s->n_slots; i++) {
+            const uint32_t h = s->slot_handle[i];
+            s->h_force_lod[i] = h == CLAPGPU_NO_ENTITY ? -1 : s->e[h].force_lod;
+            s->h_cur_lod[i] = h == CLAPGPU_NO_ENTITY ? 0 : s->e[h].cur_lod;
+        }
+        s->lod_lo = 0; s->lod_hi = s->n_slots;
+        s->lod_layout_gen = s->layout_gen;
+    }
+    if (s->lod_lo < s->lod_hi) {
+        const size_t off = s->lod_lo, cnt = s->lod_hi - s->lod_lo;
+        CK(clapgpu_memcpy_h2d(s->d_force_lod + off, s->h_force_lod + off, cnt * 4, NULL));
+        CK(clapgpu_memcpy_h2d(s->d_cur_lod + off, s->h_cur_lod + off, cnt * 4, NULL));
+    }
+    s->lod_lo = 0xffffffffu; s->lod_hi = 0;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t *n_draw)
+{
+    if (!s || !n_draw) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    *n_draw = 0;
+    if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
+    if (s->n_slots == 0) { s->n_draw = 0; return CLAPGPU_OK; }
+    CK(ensure_lod(s));
+    /* the ordered visible list from the mask the last update / cull left on the device, then -- with a camera -- the LOD
+     * pick over it (one launch each); without one the pass keeps every cur_lod (model.c:974: `if (camera)`) */
+    CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, s->d_visible, s->d_visible_count, s->d_vis_scratch));
+    if (cam_pos)
+        CK(clapgpu_entities_lod(NULL, &s->d, s->d_visible, s->d_visible_count, 0, cam_pos, s->d_force_lod, s->d_cur_lod, s->d_draw_lod));
+    CK(clapgpu_memcpy_d2h(s->h_visible_count, s->d_visible_count, 4, NULL));
+    CK(clapgpu_stream_sync(NULL));
+    const uint32_t n = *s->h_visible_count;
+    if (n > s->n_slots) return CLAPGPU_ERR_UNKNOWN;
+    if (n) {
+        CK(clapgpu_memcpy_d2h(s->h_draw_slot, s->d_visible, (size_t)n * 4, NULL));
+        if (cam_pos) CK(clapgpu_memcpy_d2h(s->h_draw_lod, s->d_draw_lod, (size_t)n * 4, NULL));
+        CK(clapgpu_stream_sync(NULL));
+    }
+    for (uint32_t k = 0; k < n; k++) {                               /* the host copies follow the pick */
+        const uint32_t slot = s->h_draw_slot[k], h = s->slot_handle[slot];
+        if (!cam_pos) s->h_draw_lod[k] = s->h_cur_lod[slot];
+        s->h_cur_lod[slot] = s->h_draw_lod[k];
+        if (h != CLAPGPU_NO_ENTITY) s->e[h].cur_lod = s->h_draw_lod[k];
+    }
+    s->n_draw = n;
+    *n_draw = n;
+    return CLAPGPU_OK;
+}
+
+uint32_t clapgpu_scene_draw_list(const clapgpu_scene *s, const uint32_t **slots, const int32_t **lods)
+{
+    if (!s || !s->lod_cap) return 0;
+    if (slots) *slots = s->h_draw_slot;
+    if (lods) *lods = s->h_draw_lod;
+    return s->n_draw;
 }
 
 int clapgpu_scene_layout_is_tiled(const clapgpu_scene *s) { return s ? s->tiled : 0; }

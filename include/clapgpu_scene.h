@@ -127,6 +127,27 @@ uint32_t     clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle);
 void         clapgpu_scene_set_bv_points(clapgpu_scene *s, const float cam_pos[3], const float *ctl_pos, uint32_t ctl_handle);
 
 /* 1 = tiles (one launch), 0 = level-major (a tree wider than 64 at some level); after mq_update */
+/*
+ * The render passes' per-entity block of _models_render (model.c:959-992) as ONE call per pass: the entities that pass
+ * the draw predicate against the view of the last clapgpu_scene_mq_update / _cull, in ascending slot order (the
+ * reference's order is list order; the draw path binds per txmodel either way), and the LOD each is drawn with --
+ *   force_lod >= 0: that LOD (model.c:976-977); else, unless the camera is inside the entity's box (model.c:982), 
+ *   clamp((int)(| |aabb_center - cam|^2 - avg_edge^2 | / 3600), lod_min, lod_max) (entity3d_aabb_avg_edge model.c:1261-1264,
+ *   entity3d_set_lod / model3d_validate_lod model.c:593-609, 63-66); inside the box the entity keeps its cur_lod
+ * -- written to the entity's cur_lod as the reference writes e->cur_lod.  Entities that fail the predicate keep theirs.
+ *   clapgpu_scene_model_lods    model3d.lod_min / .lod_max (model.h:55-56), 0 / 0 until set
+ *   clapgpu_scene_entity_lod    the entity's force_lod (-1: none) and cur_lod as the engine holds them: after
+ *                               entity3d_make (force_lod -1, cur_lod 0: the defaults here) only entity3d_set_lod
+ *                               (model.c:593-609) changes them
+ *   clapgpu_scene_select_lod    cam_pos NULL = a pass without a camera (model.c:974): the list alone, cur_lod untouched
+ *   clapgpu_scene_draw_list     (slot, lod) of the last pick, n entries; slot_user[slot] (clapgpu_scene_results) is the entity
+ */
+int          clapgpu_scene_model_lods(clapgpu_scene *s, uint32_t model, unsigned int lod_min, unsigned int lod_max);
+int          clapgpu_scene_entity_lod(clapgpu_scene *s, uint32_t handle, int force_lod, int cur_lod);
+int          clapgpu_scene_entity_cur_lod(const clapgpu_scene *s, uint32_t handle);
+int          clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t *n_draw);
+uint32_t     clapgpu_scene_draw_list(const clapgpu_scene *s, const uint32_t **slots, const int32_t **lods);
+
 int          clapgpu_scene_layout_is_tiled(const clapgpu_scene *s);
 uint32_t     clapgpu_scene_slot_count(const clapgpu_scene *s);
 /* incremented every time mq_update rebuilds the layout: cached slots are stale when it changes */

@@ -34,6 +34,7 @@
  *   clap_dropin anim <characters> <joints> <frames> <seed>
  *   clap_dropin lights <frames> <seed>
  *   clap_dropin characters <characters> <frames> <seed>   body-less characters: character_update, host half + device
+ *   clap_dropin lod <entities> <frames> <seed>        the render passes' LOD pick + draw list: e->cur_lod of every entity
  *   clap_dropin edge                                  small hand-made scenes (empty queue, one entity, ...)
  *   clap_dropin snapshot <entities> <file>            dump a scene through the binding + the reference's results
  */
@@ -51,6 +52,7 @@
 #define entity3d_visible        ref_entity3d_visible
 #define entity3d_update         ref_entity3d_update
 #define entity3d_reset          ref_entity3d_reset
+#define entity3d_set_lod        ref_entity3d_set_lod
 #define view_entity_in_frustum  ref_view_entity_in_frustum
 #define view_calc_frustum       ref_view_calc_frustum
 #define light_grid_compute      ref_light_grid_compute
@@ -67,6 +69,7 @@
 #undef entity3d_visible
 #undef entity3d_update
 #undef entity3d_reset
+#undef entity3d_set_lod
 #undef view_entity_in_frustum
 #undef view_calc_frustum
 #undef light_grid_compute
@@ -349,6 +352,134 @@ static uint64_t compare_frame(struct gpu_scene *gs, uint32_t frame, uint64_t *n_
         bad++;
     }
     return bad;
+}
+
+/* ---------------------------------------------------------------- the render passes' LOD pick
+ * World A: the per-entity block of _models_render (model.c:959-992) in list order -- the reference's own predicates,
+ * ref_view_entity_in_frustum, entity3d_aabb_avg_edge and ref_entity3d_set_lod around the block's five lines of glue
+ * (the block sits inside a static function that needs a renderer: it has no callable form).  World B:
+ * gpu_scene_select_lod() (binding -> clapgpu_scene_select_lod -> two launches).  After every pass e->cur_lod of EVERY
+ * live entity and the set of drawn entities must agree.  The game moves, hides, deletes, re-parents and creates entities,
+ * forces and releases LODs through entity3d_set_lod (world B: the engine's name, served by gpu-exports.inc.c), and the
+ * camera flies a scripted path that keeps ending up inside some entity's box; every third frame renders a second pass
+ * from another camera, every fifth one without a camera (model.c:974). */
+static uint32_t lod_pass_ref(struct world *w, const float *cam_pos, uint8_t *drawn)
+{
+    uint32_t n = 0;
+    model3dtx *txm;
+    entity3d *e, *it;
+    list_for_each_entry(txm, &w->mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
+        if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && !ref_view_entity_in_frustum(&w->view, e)) continue;
+        if (cam_pos) {
+            if (e->force_lod >= 0) {
+                e->cur_lod = e->force_lod;
+            } else if (!aabb_point_is_inside(e->aabb, cam_pos)) {
+                vec3 dist;
+                vec3_sub(dist, e->aabb_center, cam_pos);
+                float side = entity3d_aabb_avg_edge(e);
+                float scale = fabsf(vec3_mul_inner(dist, dist) - side * side) / 3600.0;
+                ref_entity3d_set_lod(e, (int)scale, false);
+            }
+        }
+        for (uint32_t id = 0; id < n_ids; id++) if (w->e[id] == e) { drawn[id] = 1; break; }
+        n++;
+    }
+    return n;
+}
+
+static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
+{
+    struct gpu_scene *gs;
+    int rc = gpu_scene_init(&gs, 0, default_update);
+    if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
+    rng_state = seed;
+    cap_ids = n + frames * 64 + 16;
+    meta = calloc(cap_ids, sizeof(*meta));
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+    static const unsigned int lods[N_MODELS][3] = { { 0, 3, 4 }, { 1, 2, 4 }, { 0, 0, 1 }, { 0, 5, 6 } };   /* lod_min, lod_max, nr_lods */
+    for (int k = 0; k < N_MODELS; k++) {
+        A.model[k].lod_min = B.model[k].lod_min = lods[k][0];
+        A.model[k].lod_max = B.model[k].lod_max = lods[k][1];
+        A.model[k].nr_lods = B.model[k].nr_lods = lods[k][2];
+    }
+    while (n_ids < n) op_create(250.f, true);
+    A.scene->control = A.e[0];
+    B.scene->control = B.e[0];
+    gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_bind(gs, B.mq, &B.view);
+
+    uint8_t *drawn_a = calloc(cap_ids, 1), *drawn_b = calloc(cap_ids, 1);
+    uint64_t bad = 0, passes = 0, drawn_total = 0, forced = 0, inside = 0, lod_hist[8] = { 0 }, batched = 0, host = 0;
+    for (uint32_t f = 0; f < frames; f++) {
+        if (f) game_frame(f % 5 == 4 ? 0 : n / 16 + 1);
+        for (uint32_t k = 0; k < n / 50 + 1; k++) {                       /* the game forces / releases LODs */
+            const uint32_t id = pick_alive();
+            if (id == NONE) continue;
+            const int lod = (int)rndn(8) - 2;                            /* < 0 releases; beyond nr_lods is clamped */
+            ref_entity3d_set_lod(A.e[id], lod, true); entity3d_set_lod(B.e[id], lod, true);
+            if (rndn(3) == 0) { const int l2 = (int)rndn(6); ref_entity3d_set_lod(A.e[id], l2, false); entity3d_set_lod(B.e[id], l2, false); }
+            forced++;
+        }
+        vec3 cpos = { 120.f * cosf(0.37f * f), rndf(-10, 10), 120.f * sinf(0.37f * f) };
+        if (f % 2) {                                                     /* ... or sit inside some entity's box */
+            const uint32_t id = pick_alive();
+            if (id != NONE) memcpy(cpos, A.e[id]->aabb_center, sizeof(cpos));
+        }
+        quat cq; quat_from_euler_xyz(cq, rndf(-0.5f, 0.5f), rndf(-3, 3), 0);
+        view_set(&A, cpos, cq);
+        view_set(&B, cpos, cq);
+        A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        ref_mq_update(A.mq);
+        mq_update(B.mq);
+        const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
+        if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
+        batched += st->batched; host += st->host;
+        const int n_pass = 1 + (f % 3 == 2);
+        for (int pass = 0; pass < n_pass; pass++) {
+            if (pass) {                                                  /* a second pass from another camera: other planes, same boxes */
+                vec3 c2 = { -cpos[0] * 0.5f, cpos[1] + 5.f, -cpos[2] * 0.5f };
+                quat q2; quat_from_euler_xyz(q2, 0.2f, 1.f + 0.1f * f, 0);
+                memcpy(cpos, c2, sizeof(cpos));
+                view_set(&A, cpos, q2);
+                view_set(&B, cpos, q2);
+            }
+            const float *cam = f % 5 == 3 ? NULL : cpos;                 /* model.c:974: passes without a camera keep every LOD */
+            memset(drawn_a, 0, cap_ids); memset(drawn_b, 0, cap_ids);
+            const uint32_t na = lod_pass_ref(&A, cam, drawn_a);
+            rc = gpu_scene_select_lod(gs, &B.view, cam);
+            if (rc) { fprintf(stderr, "gpu_scene_select_lod: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+            entity3d **list; const int32_t *llod;
+            const uint32_t nb = gpu_scene_visible(gs, &list, &llod);
+            for (uint32_t k = 0; k < nb; k++) {
+                for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == list[k]) { drawn_b[id]++; break; }
+                if (llod[k] != list[k]->cur_lod && bad++ < 8) fprintf(stderr, "frame %u: draw list LOD %d but e->cur_lod %d\n", f, llod[k], list[k]->cur_lod);
+            }
+            if (na != nb && bad++ < 8) fprintf(stderr, "frame %u pass %d: %u entities drawn by the reference, %u on the list\n", f, pass, na, nb);
+            for (uint32_t id = 0; id < n_ids; id++) {
+                if (!meta[id].alive) continue;
+                const entity3d *a = A.e[id], *b = B.e[id];
+                int diff = (a->cur_lod != b->cur_lod) | (a->force_lod != b->force_lod) << 1 | (drawn_a[id] != drawn_b[id]) << 2;
+                if (diff && bad++ < 8)
+                    fprintf(stderr, "frame %u pass %d entity %u (model %u hooked %u batched %d): cur_lod %d / %d force %d / %d drawn %d / %d\n", f, pass, id,
+                            meta[id].model, meta[id].hooked, (int)gpu_scene_entity_is_batched(gs, B.e[id]), a->cur_lod, b->cur_lod,
+                            a->force_lod, b->force_lod, drawn_a[id], drawn_b[id]);
+                if (drawn_a[id]) { lod_hist[a->cur_lod & 7]++; inside += cam && aabb_point_is_inside(a->aabb, cam); }
+            }
+            drawn_total += na; passes++;
+        }
+    }
+    unsigned int distinct = 0;
+    for (int k = 0; k < 8; k++) distinct += lod_hist[k] > 0;
+    printf("{\"mode\": \"lod\", \"frames\": %u, \"passes\": %llu, \"entities_created\": %u, \"drawn\": %llu, \"lod_levels_seen\": %u, "
+           "\"forced_or_released\": %llu, \"drawn_with_camera_inside_box\": %llu, \"batched_updates\": %llu, \"host_updates\": %llu, "
+           "\"notify\": %s, \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
+           (unsigned long long)forced, (unsigned long long)inside, (unsigned long long)batched, (unsigned long long)host,
+           opt_notify ? "true" : "false", (unsigned long long)bad);
+    gpu_scene_done(gs);
+    return bad ? 1 : 0;
 }
 
 static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
@@ -1339,6 +1470,8 @@ static int run(int argc, char **argv)
         return cmd_particles((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "characters"))
         return cmd_characters((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
+    if (argc >= 5 && !strcmp(argv[1], "lod"))
+        return cmd_lod((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "test"))
         return cmd_test((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "bench"))

@@ -216,3 +216,22 @@ def test_checker_refuses_to_pass_on_the_host_fallback(launches):
     assert p.returncode != 0, "the checker passed although the device path failed"
     assert "device_errors" in p.stderr or "did not run" in p.stderr, p.stderr[-1500:]
     assert "gpu_mq_update failed" in p.stderr or "clap gpu binding" in p.stderr or "did not run" in p.stderr, p.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
+@pytest.mark.parametrize("n,frames,seed", [(300, 14, 1), (4000, 12, 2), (12000, 8, 3)])
+def test_lod_pick_and_draw_list_match_the_reference_block(n, frames, seed, notify):
+    """SURVEY 8f rank 1 through the boundary a CLAP maintainer uses: _models_render's per-entity block (model.c:959-992:
+    draw predicate, force_lod, camera-inside-box skip, entity3d_aabb_avg_edge + entity3d_set_lod's clamp) run per pass
+    over world A's lists with the reference's own functions, against gpu_scene_select_lod() / gpu_scene_visible() on
+    world B (binding -> clapgpu_scene_select_lod -> clapgpu_visible_compact + clapgpu_entities_lod; host-class entities
+    by the reference's functions on the host).  e->cur_lod and e->force_lod of EVERY live entity and the set of drawn
+    entities agree after every pass -- over a scripted camera path that keeps ending inside entity boxes, second passes
+    from another camera (a cull launch for its planes), passes without a camera, LODs forced / released / set through
+    entity3d_set_lod (the engine's name in world B), entities hidden, deleted, created and re-parented."""
+    r = _run("lod", n, frames, seed, *(["notify"] if notify else []))
+    assert r["mismatches"] == 0
+    assert r["passes"] > frames and r["drawn"] > 0 and r["lod_levels_seen"] >= 3
+    assert r["forced_or_released"] > 0 and r["drawn_with_camera_inside_box"] > 0
+    assert r["batched_updates"] > 0 and r["host_updates"] > 0 and r["notify"] is notify
