@@ -168,7 +168,8 @@ class Frame(C.Structure):
                 ("skin", C.POINTER(SkinBatch)),
                 ("particles", C.POINTER(Particles)),
                 ("index_base", C.c_uint32), ("visible", C.c_void_p), ("visible_count", C.c_void_p), ("visible_scratch", C.c_void_p),
-                ("cam_pos", C.c_float * 3), ("force_lod", C.c_void_p), ("cur_lod", C.c_void_p), ("draw_lod", C.c_void_p)]
+                ("cam_pos", C.c_float * 3), ("force_lod", C.c_void_p), ("cur_lod", C.c_void_p), ("draw_lod", C.c_void_p),
+                ("flags", C.c_uint32)]
 
 
 LIGHTS_MAX = 128
@@ -208,6 +209,7 @@ SYMBOLS = {
     "clapgpu_animation_time_dev": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_void_p]),
     "clapgpu_animations_packed_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "clapgpu_animations_pack": (C.c_int, [C.c_void_p, C.POINTER(Animations), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "clapgpu_joint_pos_world": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(PoseBatch)]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
     "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),

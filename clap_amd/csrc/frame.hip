@@ -2,9 +2,30 @@
 // (core/clap.c:551-665) -- phys_step (clap.c:604: per fixed substep the two broadphase passes, near_callback's
 // contact records, the world step) -> scene_update -> mq_update with every entity's hook in list order
 // (character_update in front of default_update: body read-back, rotation push to colliders, light hand-off, TRS
-// rebuild, animated_update; particles_update) -> light grid -> render-pass glue (visible list, LOD pick) -- issued
-// as a fixed sequence of launches on one stream.  Nothing is read back.  Every part is optional (NULL).
-// The caller keeps the time base (clapgpu_phys_step_schedule) and passes the number of substeps.
+// rebuild, animated_update; particles_update) -> light grid -> render-pass glue (visible list, LOD pick).
+// Nothing is read back.  Every part is optional (NULL).  The caller keeps the time base
+// (clapgpu_phys_step_schedule) and passes the number of substeps.
+//
+// Round 4: the frame as THREE CHAINS (opt-in: CLAPGPU_FRAME_OVERLAP).  What the reference runs in list order has only these
+// data dependences:
+//   A  physics substeps -> character hooks -> body read-back / rotation push / light hand-off -> entity update
+//      (a chain of ~12 launches at the launch floor and two dozen MB each: latency, HBM idle)
+//   B  animation clock -> keyframes + palette (k_pose) -> skinning (k_skin): 1.3 GB of HBM traffic, no input from A but
+//      ONE -- joint world positions are e->mx * mpos (model.c:1400) and e->mx is A's last product.  k_pose therefore
+//      leaves the model-space mpos (model.c:1392-1397) in joint_pos[] and a 16-byte-per-joint pass behind the join
+//      multiplies it by e->mx: the same two mat4x4_mul_vec4_post, bit for bit (clapgpu_joint_pos_world)
+//   C  particles (needs the view matrix alone)
+// A runs on the caller's stream, B and C on two helper streams forked from it by an event and joined by two; behind
+// the join: joint positions, light grid (needs A's light hand-off), visible list + LOD (need A's boxes).  Fork / join
+// by events is what stream capture records as graph edges, so FrameLoop.capture() captures the overlap as it is.
+// MEASURED (profiles/r04_a/frame_overlap.md): the chains do run at the same time -- 368 of a frame's 596 us have two or
+// more kernels in flight -- and the frame is no shorter: 0.64-0.65 ms against 0.62-0.63 ms on one stream.  The physics
+// chain is not idle time waiting to be filled: its kernels are bound by atomics, LDS and dependent loads on the SAME
+// CUs, and next to k_pose (whose persistent workgroups hold every CU's registers) or k_skin they run 2-10x longer
+// (k_bp_scatter 10 -> 110 us, k_bp_emit 20 -> 142 us).  Lower stream priority for B / C, a k_pose of 8 instead of 12
+// wavefronts per CU, and CU-masked helper streams (slower still) changed nothing.  The default therefore stays ONE
+// stream in the reference's order; the overlapped form is kept behind the flag, bit-identical (tests/test_frame_gpu.py).
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -12,12 +33,75 @@ using namespace clapgpu;
 
 #define FR(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
+namespace {
+struct FrameStreams { int dev; hipStream_t b, c; hipEvent_t fork, join_b, join_c; };
+thread_local FrameStreams g_fs = { -1, nullptr, nullptr, nullptr, nullptr, nullptr };
+
+int frame_streams(FrameStreams **out)
+{
+    int dev = 0;
+    CLAPGPU_HIP(hipGetDevice(&dev));
+    if (g_fs.dev != dev) {                                       // per thread and device, for the life of the process
+        FrameStreams n = { dev, nullptr, nullptr, nullptr, nullptr, nullptr };
+        CLAPGPU_HIP(hipStreamCreateWithFlags(&n.b, hipStreamNonBlocking));
+        CLAPGPU_HIP(hipStreamCreateWithFlags(&n.c, hipStreamNonBlocking));
+        CLAPGPU_HIP(hipEventCreateWithFlags(&n.fork, hipEventDisableTiming));
+        CLAPGPU_HIP(hipEventCreateWithFlags(&n.join_b, hipEventDisableTiming));
+        CLAPGPU_HIP(hipEventCreateWithFlags(&n.join_c, hipEventDisableTiming));
+        g_fs = n;
+    }
+    *out = &g_fs;
+    return CLAPGPU_OK;
+}
+} // namespace
+
 extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double now, uint32_t substeps)
 {
     if (!f || !f->entities) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const clapgpu_entities *e = f->entities;
+    const bool animated = f->skeleton && f->animations && f->pose;
+    const bool particles = f->particles && f->view_mx;
+    const bool overlap = (f->flags & CLAPGPU_FRAME_OVERLAP) && (animated || particles);
+    void *sb = stream, *sc = stream;                             // chains B and C: the caller's stream unless they overlap
+    FrameStreams *fs = nullptr;
+    if (overlap) {
+        FR(frame_streams(&fs));
+        CLAPGPU_HIP(hipEventRecord(fs->fork, as_stream(stream)));
+        if (animated) { CLAPGPU_HIP(hipStreamWaitEvent(fs->b, fs->fork, 0)); sb = fs->b; }
+        if (particles) { CLAPGPU_HIP(hipStreamWaitEvent(fs->c, fs->fork, 0)); sc = fs->c; }
+    }
+    // joint positions need e->mx: with the chains apart k_pose stops at the model-space position
+    clapgpu_pose_batch pose_b;
+    bool finish_pos = false;
+    if (animated) {
+        pose_b = *f->pose;
+        finish_pos = overlap && pose_b.joint_pos && !(pose_b.skip & CLAPGPU_POSE_SKIP_JOINT_POS);
+        if (finish_pos) pose_b.skip |= CLAPGPU_POSE_JOINT_POS_MODEL;
+    }
 
-    // ---- phys_step: per substep broadphase x2, contacts, dWorldQuickStep's body stage (physics.c:746-771) ----
+    // ---- chain B: animated_update -- clock, pose, palette; the vertex shader's skinning loop once per frame ----
+    auto chain_b = [&]() -> int {
+        if (!animated) return CLAPGPU_OK;
+        if (f->anim_clock) {
+            if (f->now_dev) FR(clapgpu_animation_time_dev(sb, f->anim_clock, f->now_dev));
+            else FR(clapgpu_animation_time(sb, f->anim_clock, now));
+        }
+        FR(clapgpu_pose_update(sb, f->skeleton, f->animations, &pose_b));
+        if (f->skin)
+            FR(clapgpu_skin(sb, f->skin));
+        return CLAPGPU_OK;
+    };
+    // ---- chain C: particles_update hooks ----
+    auto chain_c = [&]() -> int {
+        if (particles) FR(clapgpu_particles_update(sc, f->particles, f->view_mx));
+        return CLAPGPU_OK;
+    };
+    if (overlap) {                                               // issued first: their launches are in the queues while A's are made
+        FR(chain_b());
+        FR(chain_c());
+    }
+
+    // ---- chain A.  phys_step: per substep broadphase x2, contacts, dWorldQuickStep's body stage (physics.c:746-771) ----
     if (f->bodies && f->world) {
         for (uint32_t s = 0; s < substeps; s++) {
             if (f->bp) {
@@ -60,19 +144,15 @@ extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double 
         FR(clapgpu_entities_update_tiles(stream, e, f->tile_row_start, f->n_tiles, 0, f->frustum));
     else
         FR(clapgpu_entities_update(stream, e, f->level_start, f->n_levels, 0, f->frustum));
-    // ---- animated_update: clock, pose, palette; the vertex shader's skinning loop once per frame ----
-    if (f->skeleton && f->animations && f->pose) {
-        if (f->anim_clock) {
-            if (f->now_dev) FR(clapgpu_animation_time_dev(stream, f->anim_clock, f->now_dev));
-            else FR(clapgpu_animation_time(stream, f->anim_clock, now));
-        }
-        FR(clapgpu_pose_update(stream, f->skeleton, f->animations, f->pose));
-        if (f->skin)
-            FR(clapgpu_skin(stream, f->skin));
+
+    if (overlap) {                                               // join
+        if (animated) { CLAPGPU_HIP(hipEventRecord(fs->join_b, fs->b)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_b, 0)); }
+        if (particles) { CLAPGPU_HIP(hipEventRecord(fs->join_c, fs->c)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_c, 0)); }
+        if (finish_pos) FR(clapgpu_joint_pos_world(stream, f->skeleton->nr_joints, f->pose));
+    } else {
+        FR(chain_b());
+        FR(chain_c());
     }
-    // ---- particles_update hooks ----
-    if (f->particles && f->view_mx)
-        FR(clapgpu_particles_update(stream, f->particles, f->view_mx));
     // ---- scene_update: light_grid_compute ----
     if (f->lights && f->light_tiles && f->view_mx && f->proj_mx)
         FR(clapgpu_light_grid_compute(stream, f->lights, f->view_mx, f->proj_mx, f->light_width, f->light_height, f->light_cell,

@@ -392,6 +392,7 @@ void k_pose(PoseArgs a)
     const pose_cu32 anim_s = (pose_cu32)a.anim, entity_s = (pose_cu32)a.entity;
     const pose_cfloat time_s = (pose_cfloat)a.frame_time;
     const bool with_trs = !(a.skip & CLAPGPU_POSE_SKIP_TRS), with_pos = !(a.skip & CLAPGPU_POSE_SKIP_JOINT_POS);
+    const bool pos_world = with_pos && !(a.skip & CLAPGPU_POSE_JOINT_POS_MODEL);   // e->mx * mpos here, or later (clapgpu_joint_pos_world)
     const uint32_t cib_u = (uint32_t)__builtin_amdgcn_readfirstlane(cib);
     const uint32_t jc = (uint32_t)j < J ? (uint32_t)j : J - 1;
     // role in the level passes: joint entry q of the pass, column c of its global
@@ -416,7 +417,7 @@ void k_pose(PoseArgs a)
     const uint32_t c0 = char_of(g), c1 = char_of(g + gridDim.x);
     // the character's entity matrix: element (lane & 15) per lane, one vector load a character ahead, read back with
     // v_readlane where joint positions are formed
-    float em_v = with_pos ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
+    float em_v = pos_world ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
     float tm_next = time_s[c1];
     uint32_t an_next = anim_of(c1);
     // the first character's keys -- waited for HERE, so that no wait for them is left pending into the loop, where it
@@ -505,6 +506,10 @@ void k_pose(PoseArgs a)
             if (with_pos) {                                      // uniform
                 const float4 b3 = jconst_lds[4 * LPC + j];
                 const Col mp = comb4(JT0, JT1, JT2, JT3, b3.x, b3.y, b3.z, b3.w);
+                POS = mp;
+            }
+            if (pos_world) {                                     // uniform
+                const Col mp = POS;
                 float em[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) em[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(em_v), k));
@@ -520,7 +525,7 @@ void k_pose(PoseArgs a)
 
         // ---- 4. the scalars of the character after next move up
         an_next = an2;
-        if (with_pos) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
+        if (pos_world) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
         tm_next = tm_next2;
 
         // ---- 5. stores: all lanes, no branch; the descriptors clip (each wavefront's own: its 64-joint row of the character)
@@ -564,6 +569,18 @@ void k_pose(PoseArgs a)
             wave_lds_fence();
         }
     }
+}
+
+// model.c:1400 behind a pose that stopped at the model-space position (CLAPGPU_POSE_JOINT_POS_MODEL): one lane per joint
+__global__ __launch_bounds__(256)
+void k_joint_pos_world(uint32_t n_joints_total, uint32_t J, const uint32_t *entity, const float4 *entity_mx, float4 *joint_pos)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_joints_total) return;
+    const uint32_t c = q / J;
+    const float4 *em = entity_mx + 4 * (size_t)(entity ? entity[c] : c);
+    const float4 mp = joint_pos[q];
+    joint_pos[q] = f4_of(comb4(col_of(em[0]), col_of(em[1]), col_of(em[2]), col_of(em[3]), mp.x, mp.y, mp.z, mp.w));
 }
 
 // animated_update's clock (model.c:1563-1592): one lane per character
@@ -621,6 +638,21 @@ static int animation_time_launch(void *stream, const clapgpu_anim_clock *clk, do
 //   times  [n_anims][3][kp][L] f32 (+INF past a channel's last key) | key counts [n_anims][3][L] u32 |
 //   (16-byte aligned) values [n_anims][3][k][L] float4 | rotation interval constants [n_anims][k][L] RotConst
 // Columns past the last joint repeat the last joint's channels, as the loop's clamped joint index does.
+extern "C" int clapgpu_joint_pos_world(void *stream, uint32_t nr_joints, const clapgpu_pose_batch *pb)
+{
+    if (!pb || !nr_joints)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (pb->n_chars == 0 || !pb->joint_pos)
+        return CLAPGPU_OK;
+    if (!pb->entity_mx || (uint64_t)pb->n_chars * nr_joints > 0xffffffffull)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t total = pb->n_chars * nr_joints;
+    hipLaunchKernelGGL(k_joint_pos_world, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), total, nr_joints, pb->entity,
+                       reinterpret_cast<const float4 *>(pb->entity_mx), reinterpret_cast<float4 *>(pb->joint_pos));
+    CLAPGPU_LAUNCH_CHECK("k_joint_pos_world");
+    return CLAPGPU_OK;
+}
+
 static uint32_t pack_kp(uint32_t max_keys)
 {
     uint32_t kp = 2;
@@ -806,9 +838,10 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (pb->n_chars == 0)
         return CLAPGPU_OK;
-    if (!pb->anim || !pb->frame_time || !pb->trs || !pb->joint_transforms || (pb->joint_pos && !pb->entity_mx))
+    if (pb->skip & ~(uint32_t)(CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS | CLAPGPU_POSE_JOINT_POS_MODEL))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    if (pb->skip & ~(uint32_t)(CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS))
+    if (!pb->anim || !pb->frame_time || !pb->trs || !pb->joint_transforms ||
+        (pb->joint_pos && !pb->entity_mx && !(pb->skip & (CLAPGPU_POSE_SKIP_JOINT_POS | CLAPGPU_POSE_JOINT_POS_MODEL))))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (sk->nr_joints == 0 || sk->nr_joints > POSE_MAX_JOINTS)  // JOINTS_MAX is 200 (shader_constants.h:6)
         return CLAPGPU_ERR_TOO_LARGE;

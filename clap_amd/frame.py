@@ -141,6 +141,7 @@ class FrameLoop:
             self.lights._upload()                            # slot edits made on the host since the last frame
         # graph capture: the clock comes from a device double written before every replay
         f.now_dev = self.characters.now_dev.data_ptr() if (now is None and self.characters is not None) else None
+        f.flags = 1 if getattr(self, "overlap", False) else 0     # CLAPGPU_FRAME_OVERLAP: three chains on three streams (frame.hip)
         rc = _lib.lib().clapgpu_frame_issue(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(f),
                                             0.0 if now is None else float(now), int(steps))
         _lib.check(rc, "clapgpu_frame_issue")

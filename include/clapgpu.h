@@ -484,6 +484,10 @@ int    clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint3
  */
 #define CLAPGPU_POSE_SKIP_TRS        (1u << 0)
 #define CLAPGPU_POSE_SKIP_JOINT_POS  (1u << 1)
+/* joint_pos[] receives the MODEL-space position (model.c:1392-1397: column 3 of joint_transforms * bind) instead of
+ * e->mx times it, and entity_mx is not read: the pose no longer waits for the frame's entity update.
+ * clapgpu_joint_pos_world() finishes model.c:1400 afterwards -- the same mat4x4_mul_vec4_post, the same bits. */
+#define CLAPGPU_POSE_JOINT_POS_MODEL (1u << 2)
 typedef struct clapgpu_pose_batch {
     uint32_t        n_chars;
     uint32_t        skip;
@@ -526,6 +530,9 @@ int clapgpu_animation_time_dev(void *stream, const clapgpu_anim_clock *clk, cons
  * (model.c:1582-1583) for every character of the batch. */
 int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,
                         const clapgpu_pose_batch *pb);
+/* model.c:1400 for a batch posed with CLAPGPU_POSE_JOINT_POS_MODEL: joint_pos[c][j] = entity_mx[entity[c]] * joint_pos[c][j]
+ * (mat4x4_mul_vec4_post), in place, for every joint (those outside joint 0's tree hold whatever they held). */
+int clapgpu_joint_pos_world(void *stream, uint32_t nr_joints, const clapgpu_pose_batch *pb);
 
 /* ======================================================================== */
 /* Vertex skinning (shaders/model.vert:32-48)                                */
@@ -928,7 +935,15 @@ typedef struct clapgpu_frame {
     /* render-pass glue */
     uint32_t index_base; uint32_t *visible, *visible_count; void *visible_scratch;
     float cam_pos[3]; const int32_t *force_lod; int32_t *cur_lod, *draw_lod;
+    uint32_t flags;                            /* CLAPGPU_FRAME_* */
 } clapgpu_frame;
+
+/* Default (0): everything on the caller's stream in the reference's order.  CLAPGPU_FRAME_OVERLAP: the frame's three
+ * independent chains -- physics -> entity update; animation clock -> pose -> skinning; particles -- run on the caller's
+ * stream and two helper streams forked from and joined into it by events (graph capture records the same edges); joint
+ * world positions, light grid, visible list and LOD pick follow the join.  Results are identical either way; on one
+ * MI355X the overlapped frame is NOT shorter (0.64 against 0.62 ms at BASELINE sizes: csrc/frame.hip). */
+#define CLAPGPU_FRAME_OVERLAP 1u
 
 int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double now, uint32_t physics_substeps);
 

@@ -182,12 +182,14 @@ def test_captured_frame_graph_replays_the_same_frames(cuda_device):
         torch.cuda.synchronize()
         e, c, p, w = loop.batch.download(), loop.characters.download(), loop.particles.download(), loop.world.download()
         return dict(mx=e["mx"], visible=e["visible"], lod=loop.batch.draw_lod[:len(e["visible"])].cpu().numpy(),
-                    jt=c["joint_transforms"], skinned=c["out_position"], ani=loop.characters.download_clock()["ani_time"],
+                    jt=c["joint_transforms"], jpos=c["joint_pos"], skinned=c["out_position"], ani=loop.characters.download_clock()["ani_time"],
                     ppos=p["pos"], rng=np.asarray([p["rng_state"]], np.uint64), bpos=w["pos"], pairs=w["pairs"],
                     spairs=w["static_pairs"], tiles=loop.lights.download_tiles())
 
-    # eager / graph: the default one-stream frame; forked: statics pass and particles on a side stream, issued and replayed
+    # eager / graph: CLAPGPU_FRAME_OVERLAP -- three chains on the caller's stream and two helper streams, joined by events
+    # (frame.hip) -- issued and replayed; single: the default, every launch on one stream in the reference's order
     eager, graph, single = build(), build(), build()
+    eager.overlap = graph.overlap = True
     dt = 1.0 / 120.0
     eager.clap_frame(dt, dt)                                # frame 1 on all (capture() issues its warm-up frame eagerly)
     single.clap_frame(dt, dt)
@@ -199,13 +201,13 @@ def test_captured_frame_graph_replays_the_same_frames(cuda_device):
         a, b, c = state(eager), state(graph), state(single)
         for k in a:
             assert np.array_equal(a[k], b[k]), f"frame {f}: {k} (graph replay)"
-            assert np.array_equal(a[k], c[k]), f"frame {f}: {k} (two streams vs one)"
-    single.capture(dt, warmup_now=12 * dt)                  # the forked frame captures into one graph too
+            assert np.array_equal(a[k], c[k]), f"frame {f}: {k} (three chains vs one stream)"
+    single.capture(dt, warmup_now=12 * dt)                  # the one-stream frame captures into a graph too
     eager.clap_frame(12 * dt, dt)
     for f in range(13, 16):
         eager.clap_frame(f * dt, dt)
         single.clap_frame_replay(f * dt)
         a, c = state(eager), state(single)
         for k in a:
-            assert np.array_equal(a[k], c[k]), f"frame {f}: {k} (two-stream graph replay)"
+            assert np.array_equal(a[k], c[k]), f"frame {f}: {k} (one-stream graph replay)"
     assert (state(graph)["ani"] != 0).any(), "the 0.05 s animation restarted during the replayed frames"
