@@ -23,6 +23,7 @@ against itself.  `cpu_baseline` = the reference's own default_update + view_enti
 is absent.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -66,6 +67,9 @@ def parse():
                     help="skip the testbed-sized (BASELINE configs[0]) extra: under rocprofv3 its small launches of "
                          "the same kernels would be averaged into the full-size per-kernel statistics")
     ap.add_argument("--cpu-frames", type=int, default=120, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="N > 1: seconds a rank may spend in the collective set-up (process group + ncclCommInitRank) before it "
+                         "gives up with exit code 4 -- a rank stuck there would hang the launcher and every other rank")
     ap.add_argument("--dry-launch", action="store_true",
                     help="self-test of the --gpus N launcher: the ranks rendezvous over gloo on the CPU, reduce their ranks and "
                          "rank 0 prints one JSON line; no GPU is touched (tests/test_bench_launcher.py)")
@@ -89,8 +93,19 @@ def launch_ranks(args):
     PIDs, never a pattern)."""
     n = args.gpus
     if not args.dry_launch:
-        import torch
-        have = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+        # the node's GPUs without touching HIP in this parent (torch.cuda.device_count() falls back to hipGetDeviceCount,
+        # which initialises the runtime, where amdsmi is missing): KFD's topology lists one node per agent, GPUs have SIMDs
+        have = 0
+        for node in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            try:
+                with open(node) as fh:
+                    if any(l.startswith("simd_count") and int(l.split()[1]) > 0 for l in fh):
+                        have += 1
+            except OSError:
+                pass
+        vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
+        if vis is not None and vis.strip() != "":
+            have = min(have, len([v for v in vis.split(",") if v.strip() != ""])) if have else len(vis.split(","))
         if have < n:
             print(f"[bench] --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
             return 2
@@ -118,19 +133,69 @@ def launch_ranks(args):
     return rc
 
 
+class InitWatchdog:
+    """A rank that does not get through its collective set-up within `seconds` ends ITSELF with exit code 4 (the launcher --
+    ours or torch.distributed.run -- then stops the others): ncclCommInitRank and the process group's rendezvous block
+    for ever when a peer never arrives.  A fresh thread, os._exit: nothing of a wedged runtime is waited for."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self._t = threading.Timer(seconds, self._fire, args=(seconds, what))
+        self._t.daemon = True
+        self._t.start()
+
+    @staticmethod
+    def _fire(seconds, what):
+        print(f"[bench] rank {os.environ.get('RANK', '0')}: {what} did not finish within {seconds:.0f} s -- giving up",
+              file=sys.stderr, flush=True)
+        os._exit(4)
+
+    def done(self):
+        self._t.cancel()
+
+
+def check_proof(proof, gpus):
+    """The run's own evidence that `gpus` ranks on `gpus` distinct devices took part; returns an error string or None."""
+    if proof["rccl_ranks"] != gpus:
+        return f"the communicator has {proof['rccl_ranks']} ranks, --gpus is {gpus}"
+    if not proof["comm_rank_ok"]:
+        return "a rank's communicator rank is not its launcher rank"
+    if len(proof["devices"]) != gpus or len(set(proof["devices"])) != gpus:
+        return f"{gpus} ranks on {len(set(proof['devices']))} distinct device(s): {proof['devices']}"
+    return None
+
+
 def dry_launch():
-    """The launcher's self-test body (one rank): gloo rendezvous on the CPU with the environment launch_ranks() made."""
+    """The launcher's self-test body (one rank): gloo rendezvous on the CPU with the environment launch_ranks() made, the
+    same proof-of-participation check the GPU run ends on (devices stand-ins: "cpu:<rank>")."""
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if os.environ.get("CLAP_BENCH_DRY_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    wd = InitWatchdog(float(os.environ.get("CLAP_BENCH_DRY_INIT_TIMEOUT", "120")), "the gloo rendezvous")
+    if os.environ.get("CLAP_BENCH_DRY_HANG_RANK") == str(rank):
+        time.sleep(3600)                                     # a rank that never arrives: its own watchdog ends it
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    wd.done()
     t = torch.tensor([rank, int(os.environ["LOCAL_RANK"]), 1], dtype=torch.int64)
     dist.all_reduce(t)
+    every = [None] * world
+    same = os.environ.get("CLAP_BENCH_DRY_SAME_DEVICE") == "1"
+    dist.all_gather_object(every, dict(rccl_ranks=dist.get_world_size(), comm_rank=dist.get_rank(),
+                                       device="cpu:0" if same else f"cpu:{rank}"))
+    proof = dict(rccl_ranks=min(e["rccl_ranks"] for e in every), comm_rank_ok=all(e["comm_rank"] == r for r, e in enumerate(every)),
+                 devices=[e["device"] for e in every])
+    bad = check_proof(proof, world)
+    if bad:
+        if rank == 0:
+            print(f"[bench] refusing to report: {bad}", file=sys.stderr, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(5)
     if rank == 0:
         print(json.dumps({"launcher": "dry", "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1]),
-                          "ranks": int(t[2])}), flush=True)
+                          "ranks": int(t[2]), "rccl_ranks": proof["rccl_ranks"], "devices": proof["devices"]}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -665,6 +730,7 @@ def main():
     device = f"cuda:{local_rank}"
     _lib.check(_lib.lib().clapgpu_init(local_rank), "clapgpu_init")
     use_dist = world > 1 or os.environ.get("CLAP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on 1 GPU
+    wd = InitWatchdog(args.init_timeout, "the collective set-up (process group + ncclCommInitRank)") if use_dist else None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -684,6 +750,18 @@ def main():
                   layout=args.layout, raw=raw, cam=cam)
     scene, batch, pbatch, xch, fr, step = rs.scene, rs.batch, rs.pbatch, rs.xch, rs.fr, rs.step
     n_real, n_pad, index_base = batch.n_real, batch.n, rs.index_base
+    proof = None
+    if use_dist:                                             # the communicator exists: what does RCCL itself say about the run?
+        proof = xch.proof()
+        wd.done()
+        bad = check_proof(proof, world)
+        if bad:                                              # no JSON line for a run that is not what --gpus says
+            if rank == 0:
+                print(f"[bench] refusing to report: {bad}", file=sys.stderr, flush=True)
+            dist.barrier()
+            xch.destroy()
+            dist.destroy_process_group()
+            raise SystemExit(5)
 
     def fence():
         if use_dist:
@@ -698,10 +776,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if use_dist:
+        mine = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        rank_ms = {"min": float(t.item()) / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_real * args.steps / elapsed
     visible = int((xch.last()[0] if use_dist else batch.visible_count).item())
@@ -768,6 +851,10 @@ def main():
                                   "issued alone is bound by the host's launch rate -- inside a step it costs step_us - "
                                   "mean_launch_us"),
         }
+        if proof is not None:                                # the line proves its own N: RCCL's rank count, one PCI bus id per rank
+            out["rccl_ranks"] = proof["rccl_ranks"]
+            out["devices"] = proof["devices"]
+            out["ms_per_step_per_rank"] = rank_ms
         if args.snapshot:
             out["data"] = "snapshot"
             extra = snapshot_characters(comps, raw, device, args.steps, args.warmup)

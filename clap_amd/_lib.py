@@ -254,6 +254,7 @@ SYMBOLS = {
     "clapgpu_exchange_available": (C.c_int, []),
     "clapgpu_exchange_unique_id": (C.c_int, [C.c_void_p]),
     "clapgpu_exchange_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "clapgpu_exchange_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]),
     "clapgpu_exchange_destroy": (None, [C.c_void_p]),
     "clapgpu_exchange_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),

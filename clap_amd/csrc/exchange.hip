@@ -22,6 +22,7 @@ typedef int (*fn_init_rank)(void **, int, nccl_uid, int);
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_destroy)(void *);
 typedef const char *(*fn_errstr)(int);
+typedef int (*fn_comm_int)(void *, int *);
 
 struct Rccl {
     void *lib = nullptr;
@@ -30,6 +31,7 @@ struct Rccl {
     fn_allgather allgather = nullptr;
     fn_destroy destroy = nullptr;
     fn_errstr errstr = nullptr;
+    fn_comm_int comm_count = nullptr, comm_user_rank = nullptr;
 };
 Rccl g_rccl;
 std::string g_rccl_path;
@@ -48,6 +50,8 @@ int load_rccl()
     g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (fn_comm_int)dlsym(h, "ncclCommCount");
+    g_rccl.comm_user_rank = (fn_comm_int)dlsym(h, "ncclCommUserRank");
     if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.allgather || !g_rccl.destroy) return CLAPGPU_ERR_NOT_SUPPORTED;
     g_rccl.lib = h;
     return CLAPGPU_OK;
@@ -93,6 +97,21 @@ extern "C" int clapgpu_exchange_create(clapgpu_exchange **out, const uint8_t id[
     if (g_rccl.init_rank(&x->comm, world, u, rank)) { free(x); return CLAPGPU_ERR_INIT_FAILED; }
     x->rank = rank; x->world = world;
     *out = x;
+    return CLAPGPU_OK;
+}
+
+// What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank) and which device this rank drives: a
+// launcher gathers these from every rank and can then PROVE that N ranks on N distinct GPUs took part -- not N ranks
+// that all landed on device 0, not a world of one.
+extern "C" int clapgpu_exchange_info(const clapgpu_exchange *x, int *comm_ranks, int *comm_rank, char pci_bus_id[32])
+{
+    if (!x || !comm_ranks || !comm_rank || !pci_bus_id) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!g_rccl.comm_count || !g_rccl.comm_user_rank) return CLAPGPU_ERR_NOT_SUPPORTED;
+    if (g_rccl.comm_count(x->comm, comm_ranks) || g_rccl.comm_user_rank(x->comm, comm_rank)) return CLAPGPU_ERR_UNKNOWN;
+    int dev = 0;
+    CLAPGPU_HIP(hipGetDevice(&dev));
+    memset(pci_bus_id, 0, 32);
+    CLAPGPU_HIP(hipDeviceGetPCIBusId(pci_bus_id, 32, dev));
     return CLAPGPU_OK;
 }
 

@@ -175,6 +175,28 @@ class VisibleExchange:
         b = (self.frame - 1) & 1
         return self.g_cnt[b], self.g_vis[b]
 
+    def proof(self):
+        """What the collective library itself says about the run, gathered over the ranks (collective: every rank calls it):
+        dict(rccl_ranks = ncclCommCount of this rank's communicator or the process group's size on the c10d route,
+        comm_rank_ok = ncclCommUserRank == rank on every rank, devices = PCI bus id of the device each rank drives, in rank
+        order).  bench.py refuses to print a line when rccl_ranks != --gpus or two ranks share a device."""
+        import ctypes as C
+        L = self._lib.lib()
+        ranks, me, bus = C.c_int(0), C.c_int(-1), C.create_string_buffer(32)
+        if self.direct is not None and L.clapgpu_exchange_info(self.direct, C.byref(ranks), C.byref(me), bus) == 0:
+            info = dict(rccl_ranks=int(ranks.value), comm_rank=int(me.value), device=bus.value.decode())
+        else:                                                # torch.distributed route: the group's own size, torch's device record
+            props = torch.cuda.get_device_properties(self.device)
+            busid = getattr(props, "pci_bus_id", None)
+            info = dict(rccl_ranks=dist.get_world_size(), comm_rank=dist.get_rank(),
+                        device=f"{getattr(props, 'pci_domain_id', 0):04x}:{busid:02x}:{getattr(props, 'pci_device_id', 0):02x}.0"
+                        if busid is not None else f"uuid:{getattr(props, 'uuid', self.device)}")
+        every = [None] * self.world
+        dist.all_gather_object(every, info)
+        return dict(rccl_ranks=min(e["rccl_ranks"] for e in every),
+                    comm_rank_ok=all(e["comm_rank"] == r for r, e in enumerate(every)),
+                    devices=[e["device"] for e in every])
+
     def destroy(self):
         if self.direct is not None:
             self._lib.lib().clapgpu_exchange_destroy(self.direct)

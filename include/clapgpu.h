@@ -342,6 +342,10 @@ void clapgpu_exchange_set_library(const char *path);
 int  clapgpu_exchange_available(void);
 int  clapgpu_exchange_unique_id(uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES]);
 int  clapgpu_exchange_create(clapgpu_exchange **out, const uint8_t id[CLAPGPU_EXCHANGE_ID_BYTES], int rank, int world);
+/* ncclCommCount / ncclCommUserRank of the communicator and the PCI bus id of the device this rank drives
+ * ("0000:c1:00.0"): gathered over all ranks they prove that N ranks on N DISTINCT GPUs took part (bench.py refuses to
+ * print a line otherwise). */
+int  clapgpu_exchange_info(const clapgpu_exchange *x, int *comm_ranks, int *comm_rank, char pci_bus_id[32]);
 void clapgpu_exchange_destroy(clapgpu_exchange *x);
 int  clapgpu_exchange_visible(void *stream, clapgpu_exchange *x, const uint64_t *vis_mask, uint32_t n_pad,
                               uint64_t *gathered_mask, uint32_t *visible, uint32_t *visible_count, void *scratch);

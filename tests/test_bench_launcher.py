@@ -24,7 +24,8 @@ def test_gpus2_without_torchrun_spawns_two_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     r = json.loads(lines[0])
-    assert r == {"launcher": "dry", "n_gpus": 2, "rank_sum": 1, "local_rank_sum": 1, "ranks": 2}
+    assert r == {"launcher": "dry", "n_gpus": 2, "rank_sum": 1, "local_rank_sum": 1, "ranks": 2,
+                 "rccl_ranks": 2, "devices": ["cpu:0", "cpu:1"]}      # the line proves its own N: one device per rank
 
 
 def test_gpus4_ranks_are_distinct():
@@ -39,6 +40,34 @@ def test_a_failing_rank_fails_the_run_and_stops_the_others():
     assert p.returncode == 3
     assert "rank 1 exited with 3" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")], "no result line from a failed run"
+
+
+def test_two_ranks_on_one_device_are_refused():
+    """The proof-of-participation check the GPU run ends its set-up on (bench.check_proof: the communicator's own rank
+    count == --gpus, every rank's communicator rank == its launcher rank, N distinct PCI bus ids), driven here with the
+    gloo stand-in: two ranks reporting the same device -> no JSON line, exit code 5."""
+    p = _run(["--gpus", "2", "--dry-launch"], {"CLAP_BENCH_DRY_SAME_DEVICE": "1"})
+    assert p.returncode == 5, (p.returncode, p.stderr[-1500:])
+    assert "refusing to report" in p.stderr and "distinct device" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_check_proof_cases():
+    from bench import check_proof
+    ok = dict(rccl_ranks=4, comm_rank_ok=True, devices=["0000:05:00.0", "0000:15:00.0", "0000:65:00.0", "0000:75:00.0"])
+    assert check_proof(ok, 4) is None
+    assert "communicator has 1 ranks" in check_proof(dict(ok, rccl_ranks=1), 4)        # a world of one, N times
+    assert "launcher rank" in check_proof(dict(ok, comm_rank_ok=False), 4)
+    assert "3 distinct" in check_proof(dict(ok, devices=ok["devices"][:3] + ok["devices"][:1]), 4)
+
+
+def test_a_rank_that_never_arrives_is_ended_by_its_watchdog():
+    """ncclCommInitRank / the rendezvous block for ever when a peer never arrives: every rank arms a watchdog around its
+    collective set-up (bench.InitWatchdog) that ends the rank with exit code 4; the launcher stops the others."""
+    p = _run(["--gpus", "2", "--dry-launch"], {"CLAP_BENCH_DRY_HANG_RANK": "1", "CLAP_BENCH_DRY_INIT_TIMEOUT": "6"}, timeout=120)
+    assert p.returncode == 4, (p.returncode, p.stderr[-1500:])
+    assert "did not finish within 6 s" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
 def test_under_a_launcher_environment_no_second_spawn():

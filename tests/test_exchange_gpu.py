@@ -33,6 +33,14 @@ def test_world1_exchange_matches_oracle(route, cuda_device, process_group):
         assert "clapgpu_exchange_visible" in xch.route
     else:
         assert xch.direct is None
+    # the line bench.py prints proves its own N: what the communicator says about itself + the device behind each rank
+    import bench
+    proof = xch.proof()
+    assert proof["rccl_ranks"] == 1 and proof["comm_rank_ok"] and len(proof["devices"]) == 1 and proof["devices"][0]
+    assert bench.check_proof(proof, 1) is None
+    assert "communicator has 1 ranks" in bench.check_proof(proof, 8), "a world of one must not pass for --gpus 8"
+    if route == "rccl":
+        assert ":" in proof["devices"][0], f"a PCI bus id, got {proof['devices'][0]!r}"
     try:
         for f, cam in enumerate(cams * 2):                  # six frames: both mask buffers reused several times
             fr, _v, _p = entities.view_calc_frustum(cam)

@@ -23,9 +23,9 @@ def oracle_aabbs(b):
     return st["aabb"]
 
 
-def check_broadphase(world, b, statics, cap):
+def check_broadphase(world, b, statics, cap, aabb=None):
     out = world.download()
-    bb = oracle_aabbs(b)
+    bb = oracle_aabbs(b) if aabb is None else aabb              # aabb: the oracle's boxes after its own steps
     assert np.array_equal(out["aabb"].view(np.uint64), bb.view(np.uint64)), "geom AABBs"
     exp = ob.broadphase_aabb_pairs(bb, max_pairs=cap)
     assert out["pair_total"] == len(exp)
@@ -177,7 +177,9 @@ def test_integrate_and_schedule_match_oracle(kind, cuda_device):
     st = ob.bodies_state(b)
     ob.bodies_aabb(b, st)
     total = _run_steps(b, world, st, (1 / 60, 0.004, 0.005, 1 / 30, 0.3, 1 / 144))   # incl. a hitch that clamps to 5 substeps
-    assert total == 2 + 0 + 1 + 4 + 5 + 0 or total > 0
+    # physics.c:773-787 with fixed_dt = 1/120: 1/60 -> 2 substeps; 0.004 -> 0; + 0.005 = 0.009 -> 1; + 1/30 -> 4;
+    # 0.3 s (a hitch) -> the 5-substep cap, accumulator reset; 1/144 -> 0
+    assert total == 2 + 0 + 1 + 4 + 5 + 0
     _assert_state_equal(world.download(), st)
     if kind == "capsules":
         assert not np.array_equal(st["avel"], b["avel"]), "anisotropic inertia: the spin precesses"
@@ -269,6 +271,16 @@ def test_c4_body_count_full_size(kind, cuda_device):
     bb = out["aabb"]
     assert np.all((bb[p[:, 0], 0::2] <= bb[p[:, 1], 1::2]) & (bb[p[:, 0], 1::2] >= bb[p[:, 1], 0::2]))
     assert 0.3 < len(exp) / b["n"] < 3.0
+    # ... and the body half of __phys_step at the same size: schedule (incl. the 5-substep cap) + k_bodies_step (pose,
+    # velocities, the moved geoms' axis and AABB) against oracle/physics2.c, fp64 on both sides: bit-exact; then the
+    # broadphase once more over the MOVED boxes
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    total = _run_steps(b, world, st, (1 / 60, 0.3, 1 / 120))
+    assert total == 2 + 5 + 1
+    _assert_state_equal(world.download(), st)
+    world.broadphase()
+    check_broadphase(world, b, statics, 8_000_000, aabb=st["aabb"])
 
 
 def test_sphere_contacts_match_oracle(cuda_device):
