@@ -79,14 +79,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---- the reference's scalar arithmetic ------------------------------------------------------------------------------
 
-// model.c:1312-1317
-__device__ __forceinline__ float key_fac(float time, float p_time, float n_time)
-{
-    const float q = (time - p_time) / (n_time - p_time);        // the IEEE quotient (hipcc's default fp32 division is correctly rounded);
-                                                                // p_time == n_time: a NaN nobody reads
-    return p_time < n_time ? q : (p_time > n_time && time < n_time ? 1.f : 0.f);
-}
-
 // interp.h:25-29 linf_interp: a * (1.0 - blend) + b * blend with float a, b, blend -- the first product and the sum in
 // double, b * blend a float product.  g = 1.0 - (double)blend.
 __device__ __forceinline__ float lerp_ref(float a, float b, float blend, double g)
@@ -233,27 +225,31 @@ __device__ __forceinline__ PoseKeys pose_gather_keys(const float *tl, const floa
     } else {
         for (int step = kp >> 1; step > 0; step >>= 1) probe(step);
     }
-    auto finish = [&](const float *t, int nr, int lo, int &prev, int &next, float &tp, float &tn) {
+    // model.c:1266-1288 + 1312-1317 without a branch and without reading t[0] / t[nr - 1] again:
+    //   * inside the keys: prev = lo - 1 (0 at lo == 0: time == t[0]), next = min(prev + 1, nr - 1), fac the quotient
+    //     (0 where prev == next: one key, or time on the last key);
+    //   * wrapped -- lo == nr (time past the last key) or lo == 0 with time < t[0] (t[prev] IS t[0] then): the pair is
+    //     (nr - 1, 0), p_time > n_time for nr > 1, so fac = time < t[0] ? 1 : 0 -- which is "lo == 0" -- and 0 for nr == 1.
+    auto finish = [&](const float *t, int nr, int lo, int &prev, int &next, float &fac) {
         lo = lo < nr ? lo : nr;                                      // MISSING's stand-in count
-        prev = lo > 0 ? lo - 1 : 0;
-        next = prev + 1 < nr - 1 ? prev + 1 : nr - 1;
-        tp = t[prev * COLS]; tn = t[next * COLS];
-        if (lo == nr || (lo == 0 && time < tp)) {
-            prev = nr - 1; next = 0;
-            tp = t[prev * COLS]; tn = t[next * COLS];
-        }
+        const int pn = lo > 0 ? lo - 1 : 0;
+        const int nn = pn + 1 < nr - 1 ? pn + 1 : nr - 1;
+        const float tp = t[pn * COLS], tn = t[nn * COLS];
+        const bool wrap = lo == nr || (lo == 0 && time < tp);
+        const float q = (time - tp) / (tn - tp);                     // the IEEE quotient; tp == tn: a NaN nobody reads
+        const float inside = tp < tn ? q : 0.f;
+        const float outside = (lo == 0 && nr > 1) ? 1.f : 0.f;
+        prev = wrap ? nr - 1 : pn;
+        next = wrap ? 0 : nn;
+        fac = wrap ? outside : inside;
     };
     int p0, q0, p1, q1, p2, q2;
-    float tp0, tn0, tp1, tn1, tp2, tn2;
-    finish(t0, n0, l0, p0, q0, tp0, tn0); finish(t1, n1, l1, p1, q1, tp1, tn1); finish(t2, n2, l2, p2, q2, tp2, tn2);
+    finish(t0, n0, l0, p0, q0, k.f0); finish(t1, n1, l1, p1, q1, k.f1); finish(t2, n2, l2, p2, q2, k.f2);
     const float4 *v0 = vals + col, *v1 = v0 + kk * COLS, *v2 = v1 + kk * COLS;
     k.ta = v0[p0 * COLS]; k.tb = v0[q0 * COLS];
     k.ra = v1[p1 * COLS]; k.rb = v1[q1 * COLS];
     k.sa = v2[p2 * COLS]; k.sb = v2[q2 * COLS];
     k.rc = rc[p1 * COLS + col];
-    k.f0 = key_fac(time, tp0, tn0);
-    k.f1 = key_fac(time, tp1, tn1);
-    k.f2 = key_fac(time, tp2, tn2);
     return k;
 }
 
