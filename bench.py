@@ -468,18 +468,22 @@ def extras(device, testbed=True):
     t_pose = time_launches(cb.pose_update, 200, warmup=100)
     t_skin = time_launches(cb.skin, 200, warmup=100)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
-                           "kernel": "k_pose<64, 1, 256, true> (key-major pools)", "launches_timed": 200,
-                           "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "k_pose<"),
+                           "kernel": "k_pose<64, 768, false, true> (the reference's arithmetic: results equal its values)",
+                           "launches_timed": 200,
+                           "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "[all outputs]"),
                            "note": "frac prices SURVEY 8d's 200 B/joint, of which 80 B are keyframes that are per MODEL and "
-                                   "come from LDS / L2: moved_frac (PMC bytes / this run's time / 8 TB/s) is the HBM utilisation"}
+                                   "come from LDS / L2: moved_frac (PMC bytes of the ALL-OUTPUTS launches / this run's time / "
+                                   "8 TB/s) is the HBM utilisation"}
     # what a frame whose skinning runs on the device needs from the pose: the palette alone.  The joints' T/R/S and
     # world positions (56 B of the 120 B a joint writes) are host-visible state of animated_update; a caller that does
     # not read them back switches them off (clapgpu_pose_batch.skip)
     cb.set_outputs(trs=False, joint_pos=False)
     t_pal = time_launches(cb.pose_update, 200, warmup=100)
     cb.set_outputs(trs=True, joint_pos=True)
+    pal_traffic = pmc_kernel_traffic("[palette only]")
     out["pose_palette"]["palette_only"] = {"us": t_pal * 1e6, "joints_per_s": n_chars * J / t_pal,
-                                           "bytes_written_per_joint": 64,
+                                           "bytes_written_per_joint": 64, "traffic": pal_traffic,
+                                           "moved_frac": None if pal_traffic is None else pal_traffic / t_pal / 1e9 / HBM_PEAK_GBS,
                                            "note": "CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS"}
     out["skinning"] = {"skinned_verts_per_s": n_chars * vpc / t_skin, "vertices": n_chars * vpc,
                        "kernel": "k_skin", "roofline": roof(cb.skin_algorithmic_bytes(), t_skin, "k_skin"),

@@ -309,13 +309,16 @@ void k_pose(PoseArgs a)
     __shared__ __attribute__((aligned(16))) float4 loc_lds[CPB][LPC * 4];
     __shared__ float times_lds[TIMES_LDS ? POSE_TIMES_LDS_MAX * (LPC / WAVE) : 4];
     __shared__ float4 jconst_lds[5 * LPC];                       // per joint: the four columns of invmx, column 3 of bind
-    // level passes: order[] = the joints reachable from joint 0 sorted by (level, index) as joint | parent slot << 16,
-    // passes[p] = (first entry, entries) -- a level of w joints is ceil(w / SPP) passes
+    // level passes: order[] = the joints reachable from joint 0 in pass order as joint | parent slot << 16,
+    // passes[p] = (first entry, entries).  A pass holds up to SPP joints whose parents were done in EARLIER passes: the
+    // joints of a level, topped up with joints of the next level whose parents are already done (joints WITH children
+    // are taken first, so that what a level leaves over are leaves) -- configs[2]'s skeleton: 8 passes, not 9
     __shared__ uint32_t order_lds[POSE_MAX_JOINTS];
     __shared__ uint2 passes_lds[POSE_MAX_JOINTS];
     __shared__ int16_t depth_lds[POSE_MAX_JOINTS];
-    __shared__ uint32_t lvl_w[POSE_MAX_JOINTS];
-    __shared__ uint16_t lvl_start[POSE_MAX_JOINTS];
+    __shared__ int16_t done_pass[POSE_MAX_JOINTS + 1];          // the pass a joint is computed in (-1: not yet); [J..]: -1
+    __shared__ int16_t par_lds[POSE_MAX_JOINTS];
+    __shared__ uint32_t has_child[POSE_MAX_JOINTS];
     __shared__ uint32_t n_passes_s;
     extern __shared__ uint32_t prog_lds[];                       // [prog_passes][LPC] program words (dynamic: sized by the host from n_levels)
 
@@ -328,7 +331,10 @@ void k_pose(PoseArgs a)
     // ---- once per (persistent) block: tables ---------------------------------------------------------------------------
     for (int q = tid; q < POSE_MAX_JOINTS; q += BLOCK) {
         depth_lds[q] = (int16_t)((uint32_t)q < J ? a.depth[q] : -1);
-        lvl_w[q] = 0;
+        int32_t par = (uint32_t)q < J ? a.parent[q] : -1;
+        par_lds[q] = (int16_t)((par < 0 || par >= (int32_t)J) ? -1 : par);
+        has_child[q] = 0;
+        done_pass[q] = -1;
     }
     if (j == 0) {
         float4 *root = &g_lds[cib][4 * LPC];                     // slot_swz(LPC) == 0: columns unswizzled
@@ -348,26 +354,39 @@ void k_pose(PoseArgs a)
         jconst_lds[4 * LPC + tid] = a.bind[4 * jq + 3];
     }
     __syncthreads();
-    const int my_depth = (uint32_t)tid < J ? depth_lds[tid] : -1;
-    if (my_depth >= 0) atomicAdd(&lvl_w[my_depth], 1u);
+    if ((uint32_t)tid < J && depth_lds[tid] >= 0 && par_lds[tid] >= 0) atomicOr(&has_child[par_lds[tid]], 1u);
     __syncthreads();
-    if (tid == 0) {
+    if (tid < WAVE) {                                            // the first wavefront schedules: up to four joints per lane
         uint32_t at = 0, np = 0;
-        for (uint32_t L = 0; L < J && lvl_w[L]; L++) {           // levels are contiguous from 0 (depth = 1 + the parent's)
-            lvl_start[L] = (uint16_t)at;
-            for (uint32_t q = 0; q < lvl_w[L]; q += SPP)
-                passes_lds[np++] = make_uint2(at + q, lvl_w[L] - q < (uint32_t)SPP ? lvl_w[L] - q : (uint32_t)SPP);
-            at += lvl_w[L];
+        for (;;) {
+            uint32_t taken = 0;
+#pragma unroll
+            for (int cls = 1; cls >= 0; cls--) {                 // joints with children first, then leaves
+#pragma unroll
+                for (int r = 0; r < POSE_MAX_JOINTS / WAVE; r++) {
+                    const int jj = tid + WAVE * r;
+                    const int par = par_lds[jj];
+                    const bool ready = depth_lds[jj] >= 0 && done_pass[jj] < 0 && (int)(has_child[jj] != 0) == cls &&
+                                       (par < 0 || (done_pass[par] >= 0 && done_pass[par] < (int)np));
+                    const uint64_t m = __ballot(ready);
+                    const uint32_t rank = taken + (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
+                    if (ready && rank < (uint32_t)SPP) {
+                        order_lds[at + rank] = (uint32_t)jj | ((uint32_t)(par < 0 ? LPC : par) << 16);
+                        done_pass[jj] = (int16_t)np;
+                    }
+                    taken += (uint32_t)__popcll(m);
+                }
+            }
+            const uint32_t cnt = taken < (uint32_t)SPP ? taken : (uint32_t)SPP;
+            if (!cnt) break;                                     // everything reachable is scheduled
+            if (tid == 0) passes_lds[np] = make_uint2(at, cnt);
+            at += cnt;
+            np++;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        n_passes_s = np;
-    }
-    __syncthreads();
-    if (my_depth >= 0) {
-        uint32_t rank = 0;
-        for (int q = 0; q < tid; q++) rank += depth_lds[q] == my_depth;
-        int32_t par = a.parent[tid];
-        if (par < 0 || par >= (int32_t)J) par = LPC;             // a child of the root pose
-        order_lds[lvl_start[my_depth] + rank] = (uint32_t)tid | ((uint32_t)par << 16);
+        if (tid == 0) n_passes_s = np;
     }
     __syncthreads();
     const int n_passes = (int)n_passes_s;

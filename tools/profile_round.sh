@@ -24,6 +24,15 @@ wc=$(find "$out/write" -name '*counter_collection.csv' | head -1)
 if [ -n "$fc" ] && [ -n "$wc" ]; then
     python3 "$R/tools/pmc_summary.py" --all "$fc" "$wc" "$out/pmc_hbm_bytes.json" > /dev/null
 fi
+# k_pose per OUTPUT MASK (bench.py launches both masks under one kernel name and grid: the summary above can only mix them)
+for m in 0 3; do for c in FETCH_SIZE WRITE_SIZE; do
+    CLAP_POSE_SKIP=$m timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pose_${c}_$m" -- python3 "$R/tools/run_kernel.py" pose 8 > "$out/pose_${c}_$m.log" 2>&1
+done; done
+pf() { find "$out/pose_$1_$2" -name '*counter_collection.csv' | head -1; }
+if [ -n "$(pf FETCH_SIZE 0)" ] && [ -n "$(pf WRITE_SIZE 0)" ] && [ -n "$(pf FETCH_SIZE 3)" ] && [ -n "$(pf WRITE_SIZE 3)" ]; then
+    python3 "$R/tools/pose_pmc_masks.py" "$(pf FETCH_SIZE 0)" "$(pf WRITE_SIZE 0)" "$(pf FETCH_SIZE 3)" "$(pf WRITE_SIZE 3)" "$out/pmc_hbm_bytes.json" > "$out/pose_pmc_masks.txt"
+fi
+rm -rf "$out"/pose_FETCH_SIZE_* "$out"/pose_WRITE_SIZE_*
 # the headline kernel's traffic from headline-only passes: in the full bench the whole-frame extra launches the same grid
 # with only part of the scene dirty, which would pull the per-launch mean down
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/fetch_h" -- python3 "$R/bench.py" --steps 10 --warmup 2 --cpu-frames 0 --no-testbed --no-extras > "$out/bench_fetch_headline.log" 2>&1
