@@ -127,7 +127,7 @@ class Geoms(C.Structure):
                 ("material", C.c_void_p)]
 
 
-POSE_SKIP_TRS, POSE_SKIP_JOINT_POS = 1, 2
+POSE_SKIP_TRS, POSE_SKIP_JOINT_POS, POSE_JOINT_POS_MODEL = 1, 2, 4
 BODY_DISABLED, BODY_AUTO_DISABLE, BODY_NO_GRAVITY, BODY_GYROSCOPIC, BODY_HAS_JOINT = 1, 2, 4, 8, 16
 GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_OTHER = 0, 1, 2, 3
 CONTACT_DEEP = 0x80000000
@@ -209,7 +209,7 @@ SYMBOLS = {
     "clapgpu_animation_time_dev": (C.c_int, [C.c_void_p, C.POINTER(AnimClock), C.c_void_p]),
     "clapgpu_animations_packed_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "clapgpu_animations_pack": (C.c_int, [C.c_void_p, C.POINTER(Animations), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
-    "clapgpu_joint_pos_world": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(PoseBatch)]),
+    "clapgpu_joint_pos_world": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(PoseBatch)]),
     "clapgpu_pose_update": (C.c_int, [C.c_void_p, C.POINTER(Skeleton), C.POINTER(Animations), C.POINTER(PoseBatch)]),
     "clapgpu_skin": (C.c_int, [C.c_void_p, C.POINTER(SkinBatch)]),
     "clapgpu_phys_step_schedule": (C.c_int, [C.POINTER(C.c_double), C.c_double]),

@@ -219,6 +219,21 @@ class CharacterBatch:
         """Which host-visible by-products pose_update writes besides the palette (clapgpu_pose_batch.skip)."""
         self._pose_desc.skip = (0 if trs else _lib.POSE_SKIP_TRS) | (0 if joint_pos else _lib.POSE_SKIP_JOINT_POS)
 
+    def set_joint_pos_model_space(self, on=True):
+        """CLAPGPU_POSE_JOINT_POS_MODEL: pose_update leaves the model-space joint positions (model.c:1392-1397) in joint_pos
+        and does not read the entity matrices; joint_pos_world() finishes model.c:1400."""
+        if on:
+            self._pose_desc.skip |= _lib.POSE_JOINT_POS_MODEL
+        else:
+            self._pose_desc.skip &= ~_lib.POSE_JOINT_POS_MODEL
+
+    def joint_pos_world(self):
+        skip = self._pose_desc.skip
+        self._pose_desc.skip = skip & ~_lib.POSE_JOINT_POS_MODEL
+        rc = _lib.lib().clapgpu_joint_pos_world(_stream(), C.byref(self.model.skel_desc), C.byref(self._pose_desc))
+        self._pose_desc.skip = skip
+        _lib.check(rc, "clapgpu_joint_pos_world")
+
     def pose_update(self):
         rc = _lib.lib().clapgpu_pose_update(_stream(), C.byref(self.model.skel_desc), C.byref(self.model.anim_desc),
                                             C.byref(self._pose_desc))

@@ -148,7 +148,7 @@ extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double 
     if (overlap) {                                               // join
         if (animated) { CLAPGPU_HIP(hipEventRecord(fs->join_b, fs->b)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_b, 0)); }
         if (particles) { CLAPGPU_HIP(hipEventRecord(fs->join_c, fs->c)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_c, 0)); }
-        if (finish_pos) FR(clapgpu_joint_pos_world(stream, f->skeleton->nr_joints, f->pose));
+        if (finish_pos) FR(clapgpu_joint_pos_world(stream, f->skeleton, f->pose));
     } else {
         FR(chain_b());
         FR(chain_c());

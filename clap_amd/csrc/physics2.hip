@@ -1336,6 +1336,8 @@ extern "C" int clapgpu_contacts_geoms(void *stream, const clapgpu_geoms *A, cons
 {
     if (!A || !B || !pair_total || (capacity && (!pairs || !contacts)))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (reinterpret_cast<uintptr_t>(contacts) & 15u)                    // the records leave as 16-byte pieces (contacts_chunk)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
     hipStream_t s = as_stream(stream);
     if (contact_total)
         CLAPGPU_HIP(hipMemsetAsync(contact_total, 0, sizeof(uint32_t), s));
@@ -1358,8 +1360,11 @@ extern "C" int clapgpu_contacts_geoms_both(void *stream, clapgpu_bp *bp, const c
     if (!bp || !bodies || !statics || !pair_total || !static_pair_total || (capacity && (!pairs || !contacts)) ||
         (static_capacity && (!static_pairs || !static_contacts)))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if ((reinterpret_cast<uintptr_t>(contacts) | reinterpret_cast<uintptr_t>(static_contacts)) & 15u)   // 16-byte pieces
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (capacity >= (1u << 24) || static_capacity >= (1u << 24))         // the counts travel as 24-bit fields of one word
         return CLAPGPU_ERR_TOO_LARGE;
+    static_assert((CTRL_CONTACT_WORD * sizeof(uint32_t)) % 8 == 0, "the ticket word is a 64-bit atomic");
     hipStream_t s = as_stream(stream);
     if (bodies->n == 0 || (capacity == 0 && static_capacity == 0)) {
         if (contact_total) CLAPGPU_HIP(hipMemsetAsync(contact_total, 0, sizeof(uint32_t), s));

@@ -588,11 +588,13 @@ void k_pose(PoseArgs a)
 
 // model.c:1400 behind a pose that stopped at the model-space position (CLAPGPU_POSE_JOINT_POS_MODEL): one lane per joint
 __global__ __launch_bounds__(256)
-void k_joint_pos_world(uint32_t n_joints_total, uint32_t J, const uint32_t *entity, const float4 *entity_mx, float4 *joint_pos)
+void k_joint_pos_world(uint32_t n_joints_total, uint32_t J, const int32_t *depth, const uint32_t *entity, const float4 *entity_mx,
+                       float4 *joint_pos)
 {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_joints_total) return;
     const uint32_t c = q / J;
+    if (depth[q - c * J] < 0) return;                            // outside joint 0's tree: never written (model.c:1583)
     const float4 *em = entity_mx + 4 * (size_t)(entity ? entity[c] : c);
     const float4 mp = joint_pos[q];
     joint_pos[q] = f4_of(comb4(col_of(em[0]), col_of(em[1]), col_of(em[2]), col_of(em[3]), mp.x, mp.y, mp.z, mp.w));
@@ -653,16 +655,17 @@ static int animation_time_launch(void *stream, const clapgpu_anim_clock *clk, do
 //   times  [n_anims][3][kp][L] f32 (+INF past a channel's last key) | key counts [n_anims][3][L] u32 |
 //   (16-byte aligned) values [n_anims][3][k][L] float4 | rotation interval constants [n_anims][k][L] RotConst
 // Columns past the last joint repeat the last joint's channels, as the loop's clamped joint index does.
-extern "C" int clapgpu_joint_pos_world(void *stream, uint32_t nr_joints, const clapgpu_pose_batch *pb)
+extern "C" int clapgpu_joint_pos_world(void *stream, const clapgpu_skeleton *sk, const clapgpu_pose_batch *pb)
 {
-    if (!pb || !nr_joints)
+    if (!pb || !sk || !sk->nr_joints || !sk->depth)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t nr_joints = sk->nr_joints;
     if (pb->n_chars == 0 || !pb->joint_pos)
         return CLAPGPU_OK;
     if (!pb->entity_mx || (uint64_t)pb->n_chars * nr_joints > 0xffffffffull)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const uint32_t total = pb->n_chars * nr_joints;
-    hipLaunchKernelGGL(k_joint_pos_world, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), total, nr_joints, pb->entity,
+    hipLaunchKernelGGL(k_joint_pos_world, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), total, nr_joints, sk->depth, pb->entity,
                        reinterpret_cast<const float4 *>(pb->entity_mx), reinterpret_cast<float4 *>(pb->joint_pos));
     CLAPGPU_LAUNCH_CHECK("k_joint_pos_world");
     return CLAPGPU_OK;

@@ -535,8 +535,8 @@ int clapgpu_animation_time_dev(void *stream, const clapgpu_anim_clock *clk, cons
 int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, const clapgpu_animations *an,
                         const clapgpu_pose_batch *pb);
 /* model.c:1400 for a batch posed with CLAPGPU_POSE_JOINT_POS_MODEL: joint_pos[c][j] = entity_mx[entity[c]] * joint_pos[c][j]
- * (mat4x4_mul_vec4_post), in place, for every joint (those outside joint 0's tree hold whatever they held). */
-int clapgpu_joint_pos_world(void *stream, uint32_t nr_joints, const clapgpu_pose_batch *pb);
+ * (mat4x4_mul_vec4_post), in place, for every joint under joint 0 (the others are never written, as in the fused form). */
+int clapgpu_joint_pos_world(void *stream, const clapgpu_skeleton *sk, const clapgpu_pose_batch *pb);
 
 /* ======================================================================== */
 /* Vertex skinning (shaders/model.vert:32-48)                                */
@@ -757,7 +757,8 @@ const double *clapgpu_bp_static_aabb(const clapgpu_bp *bp);            /* the de
  * near_callback (physics.c:399-449) on candidate pairs (ia in A, ib in B; g1 = A's geom): dCollide for spheres,
  * capsules and axis-aligned boxes (dCollideSpheres, dCollideCapsuleSphere, dCollideCapsuleCapsule with its
  * two-contact parallel case, dCollideSphereBox, dCollideCapsuleBox; reversed like dCollide when only the
- * swapped collider exists) + phys_contact_surface (physics.c:291-330).  One 160-byte record per pair.
+ * swapped collider exists) + phys_contact_surface (physics.c:291-330).  One 160-byte record per pair; the record
+ * arrays must be 16-byte aligned (CLAPGPU_ERR_INVALID_ARGUMENTS otherwise: they are written as 16-byte pieces).
  * A capsule whose axis touches a box is where ODE switches to dBoxBox: flagged CLAPGPU_CONTACT_DEEP, nc bits 0.
  * body_flags_a / _b (may be NULL): bflags of the body sets behind A / B; touching pairs set CLAPGPU_BODY_HAS_JOINT.
  */

@@ -23,7 +23,8 @@ static uint64_t rnd(void) { uint64_t z = (rng_s += 0x9E3779B97F4A7C15ull); z = (
                             z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 static float frand(float a, float b) { return a + (b - a) * (float)((rnd() >> 11) * (1.0 / 9007199254740992.0)); }
 
-struct host_ent { uint32_t handle, parent /* index into ents[] or -1u */, model; float ps[4], rot[4]; uint32_t flags; int live; };
+struct host_ent { uint32_t handle, parent /* index into ents[] or -1u */, model; float ps[4], rot[4]; uint32_t flags; int live;
+                  int32_t force_lod, cur_lod; /* entity3d.force_lod / .cur_lod as the engine would hold them */ };
 static struct host_ent ents[MAXE];
 static uint32_t n_ents;
 /* joint attachments (clapgpu_scene_entity_set_attach / clapgpu_scene_attached_update): entity i rides joint * bind */
@@ -42,11 +43,18 @@ static void rand_trs(struct host_ent *e, int child)
 
 static int fail(const char *what, uint32_t i) { fprintf(stderr, "FAIL: %s (entity %u)\n", what, i); return 1; }
 
+/* the oracle's view of the last checked frame (parents-first order), kept for check_lod() */
+static uint32_t order[MAXE], o_n, o_vis[MAXE], o_nvis;
+static float ps[MAXE * 4], aabb[MAXE * 6], ctr[MAXE * 3];
+static int32_t model[MAXE];
+static const float model_aabb[2][6] = { { -1, -2, -3, 1, 2, 3 }, { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f } };
+static const uint8_t model_lod[2][2] = { { 0, 3 }, { 1, 2 } };       /* model3d.lod_min / lod_max */
+
 /* oracle on a parents-first ordering; compare with the scene mirror */
 static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_keep /* [MAXE][16] persistent oracle state */,
                        float *o_inv, float *o_aabb, float *o_ctr, uint32_t *o_seqs, uint32_t *o_flags_dirty)
 {
-    static uint32_t order[MAXE], pos_in_order[MAXE], depth[MAXE];
+    static uint32_t pos_in_order[MAXE], depth[MAXE];
     uint32_t n = 0, maxd = 0;
     for (uint32_t i = 0; i < n_ents; i++) {
         if (!ents[i].live) continue;
@@ -57,10 +65,9 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
     for (uint32_t d = 0; d <= maxd; d++)
         for (uint32_t i = 0; i < n_ents; i++)
             if (ents[i].live && depth[i] == d) { pos_in_order[i] = n; order[n++] = i; }
-    static float ps[MAXE * 4], rot[MAXE * 4], mx[MAXE * 16], inv[MAXE * 16], aabb[MAXE * 6], ctr[MAXE * 3];
-    static int32_t parent[MAXE], model[MAXE];
+    static float rot[MAXE * 4], mx[MAXE * 16], inv[MAXE * 16];
+    static int32_t parent[MAXE];
     static uint32_t flags[MAXE], seqs[MAXE];
-    static const float model_aabb[2][6] = { { -1, -2, -3, 1, 2, 3 }, { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f } };
     static const uint8_t model_skip[2] = { 0, 0 };
     for (uint32_t k = 0; k < n; k++) {
         const struct host_ent *e = &ents[order[k]];
@@ -111,11 +118,60 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
         if (clapgpu_scene_entity_in_frustum(s, e->handle) != exp) return fail("view_entity_in_frustum", order[k]);
         if ((int)((res.vis_mask[slot >> 6] >> (slot & 63)) & 1) != exp) return fail("bulk visibility mask", order[k]);
         if (clapgpu_scene_entity_user(s, e->handle) != (void *)e) return fail("user pointer", order[k]);
+        if (exp) o_vis[vis_exp] = k;
         vis_exp += exp;
     }
+    o_n = n; o_nvis = vis_exp;
     if (clapgpu_scene_visible(s, NULL, 0) != vis_exp) return fail("visible count", vis_exp);
     printf("  frame ok: %u live entities, %u visible, layout %s, %u slots\n", n, vis_exp,
            clapgpu_scene_layout_is_tiled(s) ? "tiles" : "levels", clapgpu_scene_slot_count(s));
+    return 0;
+}
+
+/* One render pass of _models_render (model.c:959-992) through the mirror: clapgpu_scene_select_lod over the frame check_frame
+ * just verified, against oracle/lod.c on the oracle's boxes -- the draw list as a set with its LODs, and every live
+ * entity's cur_lod (kept inside the box, kept when culled, forced when forced). */
+static int check_lod(clapgpu_scene *s, const float cam[3])
+{
+    static int32_t force[MAXE], cur[MAXE], draw[MAXE];
+    static uint8_t seen[MAXE];
+    for (uint32_t k = 0; k < o_n; k++) { force[k] = ents[order[k]].force_lod; cur[k] = ents[order[k]].cur_lod; }
+    clapo_entities_lod(o_nvis, o_vis, cam, aabb, ctr, ps, model, &model_aabb[0][0], &model_lod[0][0], force, cur, draw);
+    uint32_t n_draw = 0;
+    if (clapgpu_scene_select_lod(s, cam, &n_draw)) { fprintf(stderr, "select_lod: %s\n", clapgpu_last_error()); return 1; }
+    if (n_draw != o_nvis) return fail("draw list length", n_draw);
+    const uint32_t *slots; const int32_t *lods;
+    clapgpu_scene_arrays res;
+    if (clapgpu_scene_draw_list(s, &slots, &lods) != n_draw || clapgpu_scene_results(s, &res)) return fail("draw list", 0);
+    memset(seen, 0, sizeof(seen));
+    for (uint32_t k = 0; k < n_draw; k++) {
+        if (k && slots[k] <= slots[k - 1]) return fail("draw list not ascending", k);
+        const struct host_ent *e = res.slot_user[slots[k]];
+        if (!e || !e->live) return fail("draw list entry without an entity", k);
+        seen[e - ents] = 1;
+    }
+    uint32_t distinct[8] = { 0 }, inside = 0;
+    for (uint32_t v = 0; v < o_nvis; v++) {
+        const uint32_t k = o_vis[v], i = order[k];
+        if (!seen[i]) return fail("an entity the reference draws is not on the list", i);
+        distinct[draw[v] & 7]++;
+        const float *b = aabb + 6 * k;
+        inside += cam[0] >= b[0] && cam[0] <= b[3] && cam[1] >= b[1] && cam[1] <= b[4] && cam[2] >= b[2] && cam[2] <= b[5];
+    }
+    for (uint32_t k = 0; k < n_draw; k++) {
+        const struct host_ent *e = res.slot_user[slots[k]];
+        uint32_t ko = 0;
+        while (order[ko] != (uint32_t)(e - ents)) ko++;
+        if (lods[k] != cur[ko]) return fail("draw LOD", (uint32_t)(e - ents));
+    }
+    for (uint32_t k = 0; k < o_n; k++) {
+        struct host_ent *e = &ents[order[k]];
+        if (clapgpu_scene_entity_cur_lod(s, e->handle) != cur[k]) return fail("cur_lod", order[k]);
+        e->cur_lod = cur[k];                                 /* what the engine's entity3d would now hold */
+    }
+    uint32_t levels = 0;
+    for (int q = 0; q < 8; q++) levels += distinct[q] > 0;
+    printf("  lod pass ok: %u drawn, %u LOD levels, camera inside %u boxes\n", n_draw, levels, inside);
     return 0;
 }
 
@@ -127,6 +183,7 @@ static int add_entity(clapgpu_scene *s, uint32_t parent_idx)
     e->parent = parent_idx;
     e->flags = CLAPO_E_ALIVE | CLAPO_E_VISIBLE;
     e->live = 1;
+    e->force_lod = -1;                                   /* entity3d_make, model.c:1741 */
     rand_trs(e, parent_idx != UINT32_MAX);
     if (clapgpu_scene_entity_new(s, e->model, e, &e->handle)) return 1;
     if (n_ents & 1) {                                    /* the one-call form of the three pushes below */
@@ -145,6 +202,7 @@ int main(int argc, char **argv)
     const float a0[6] = { -1, -2, -3, 1, 2, 3 }, a1[6] = { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f };
     uint32_t m0, m1;
     if (clapgpu_scene_model_new(s, a0, 0, &m0) || clapgpu_scene_model_new(s, a1, 0, &m1) || m0 != 0 || m1 != 1) return 2;
+    if (clapgpu_scene_model_lods(s, m0, model_lod[0][0], model_lod[0][1]) || clapgpu_scene_model_lods(s, m1, model_lod[1][0], model_lod[1][1])) return 2;
 
     /* camera: scene.c:74-76 defaults */
     float view[16], proj[16];
@@ -221,8 +279,23 @@ int main(int argc, char **argv)
                 if (add_entity(s, p) || clapgpu_scene_entity_set_parent(s, ents[n_ents - 1].handle, ents[p].handle)) return 2;
             }
         }
+        for (int k = 0; k < 50; k++) {                   /* entity3d_set_lod(e, lod, true / false): forced, released, set */
+            struct host_ent *e = &ents[rnd() % n_ents];
+            if (!e->live) continue;
+            if (k % 3 == 0) e->force_lod = -1; else if (k % 3 == 1) e->force_lod = (int32_t)(rnd() % 4);
+            else e->cur_lod = model_lod[e->model][0];
+            if (e->force_lod >= 0) e->cur_lod = e->force_lod;
+            clapgpu_scene_entity_lod(s, e->handle, e->force_lod, e->cur_lod);
+        }
         if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
         if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+        /* render passes: the frame's camera, then a camera sitting inside some drawn entity's box */
+        if (check_lod(s, cpos)) return 1;
+        if (o_nvis) {
+            const float *c = ctr + 3 * o_vis[(frame * 7) % o_nvis];
+            const float inside[3] = { c[0], c[1], c[2] };
+            if (check_lod(s, inside)) return 1;
+        }
     }
     /* ---- joint attachments: the frame's SECOND launch.  Some children ride "a joint of their parent": mq_update computes
      * everything else, attached_update (with the joints' matrices of the frame) the riders and everything below them. */

@@ -351,3 +351,77 @@ def test_c3_full_size_pose_and_skin_match_oracle(cuda_device):
     exp_p, exp_n = ob.skin(mesh, vf, vc, jt)                           # end to end: the oracle's pose -> the oracle's skinning
     assert_vec_equal(out["out_position"], exp_p, "C3 full size pose -> skin positions", key="pose -> skin position")
     assert_vec_equal(out["out_normal"], exp_n, "C3 full size pose -> skin normals", key="pose -> skin normal")
+
+
+def test_pose_stops_at_model_space_and_joint_pos_world_finishes(cuda_device):
+    """CLAPGPU_POSE_JOINT_POS_MODEL (what the overlapped frame uses: the pose no longer waits for the frame's entity
+    update): joint_pos holds column 3 of joint_transforms * bind (model.c:1392-1397), the entity matrices are not read
+    (poisoned here), and clapgpu_joint_pos_world() then gives the bits of the fused path (model.c:1400)."""
+    import torch
+    from clap_amd import animation
+    J, n = 100, 777                                                   # two wavefronts per character, an entity index list
+    sk = synth.skeleton(J, 9, seed=41, unreachable=3)
+    an = synth.animation(J, 12, 1.5, seed=41)
+    ch = synth.characters(n, J, seed=41)
+    sk["bind"] = ob.skeleton_bind(sk)
+    rng = np.random.default_rng(8)
+    perm = rng.permutation(n + 5).astype(np.uint32)[:n]
+    ent_mx = rng.standard_normal((n + 5, 16)).astype(np.float32)
+    model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ent_mx, entity_index=perm)
+    t = ch["phase"].astype(np.float32)
+    batch.set_frame_times(t)
+    batch.pose_update()
+    fused = batch.download()
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    jt, _gl, jp = ob.pose(sk, an, t, ent_mx[perm], trs)
+    reach = sk["order"]
+    assert_pose_equal(fused, trs, jt, jp, reach, "fused")
+    batch.joint_pos.fill_(-5.0)
+    batch.set_joint_pos_model_space(True)
+    good = batch.entity_mx.clone()
+    batch.entity_mx.fill_(float("nan"))                               # must not be read
+    batch.pose_update()
+    batch.entity_mx.copy_(good)
+    model_space = batch.download()
+    assert np.array_equal(model_space["joint_transforms"], fused["joint_transforms"])
+    ident = np.tile(np.eye(4, dtype=np.float32).reshape(16), (n, 1))
+    _jt, _g, mp = ob.pose(sk, an, t, ident, np.tile(ch["trs0"], (n, 1, 1)))       # identity entity: pos == mpos
+    assert np.array_equal(model_space["joint_pos"][:, reach], mp[:, reach])
+    assert (model_space["joint_pos"][:, np.setdiff1d(np.arange(J), reach)] == -5.0).all()
+    batch.joint_pos_world()
+    torch.cuda.synchronize()
+    done = batch.download()["joint_pos"]
+    assert np.array_equal(done[:, reach], fused["joint_pos"][:, reach])
+    assert (done[:, np.setdiff1d(np.arange(J), reach)] == -5.0).all(), "joints outside joint 0's tree stay untouched"
+
+
+def test_pose_update_rejects_pools_made_for_something_else(cuda_device):
+    """clapgpu_pose_update needs the pools of clapgpu_animations_pack for THIS skeleton class and animation count (they hold
+    what the reference's slerp derives from each key pair with the host's libm): none, another joint class, another
+    animation count, a stale layout word -> CLAPGPU_ERR_INVALID_ARGUMENTS, nothing launched."""
+    import ctypes as C
+    from clap_amd import _lib, animation
+    sk64, sk100 = synth.skeleton(64, 6, seed=2), synth.skeleton(100, 6, seed=2)
+    an64, an100 = synth.animation(64, 8, 1.0, seed=2), synth.animation(100, 8, 1.0, seed=2)
+    m64 = animation.SkinnedModel(sk64, [an64], device=cuda_device)
+    m100 = animation.SkinnedModel(sk100, [an100], device=cuda_device)
+    ch = synth.characters(5, 64, seed=2)
+    batch = animation.CharacterBatch(m64, 5, ch["trs0"], ch["char_mx"])
+    batch.set_frame_times(ch["phase"])
+    L = _lib.lib()
+    call = lambda desc: L.clapgpu_pose_update(None, C.byref(m64.skel_desc), C.byref(desc), C.byref(batch._pose_desc))
+    assert call(m64.anim_desc) == 0
+    keep = (m64.anim_desc.packed, m64.anim_desc.packed_keys, m64.anim_desc.packed_layout, m64.anim_desc.n_anims)
+    m64.anim_desc.packed = None
+    assert call(m64.anim_desc) == _lib.ERR_INVALID_ARGUMENTS, "no pools"
+    m64.anim_desc.packed = keep[0]
+    m64.anim_desc.packed_layout = m100.anim_desc.packed_layout            # pools of a two-wavefront skeleton
+    assert call(m64.anim_desc) == _lib.ERR_INVALID_ARGUMENTS
+    m64.anim_desc.packed_layout = 0                                       # never packed
+    assert call(m64.anim_desc) == _lib.ERR_INVALID_ARGUMENTS
+    m64.anim_desc.packed_layout = keep[2]
+    m64.anim_desc.n_anims = 2                                             # another animation count than the pools were made for
+    assert call(m64.anim_desc) == _lib.ERR_INVALID_ARGUMENTS
+    m64.anim_desc.n_anims = keep[3]
+    assert call(m64.anim_desc) == 0
