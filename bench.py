@@ -106,6 +106,9 @@ def launch_ranks(args):
         vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
         if vis is not None and vis.strip() != "":
             have = min(have, len([v for v in vis.split(",") if v.strip() != ""])) if have else len(vis.split(","))
+        if have == 0 and os.path.isdir("/sys/class/kfd/kfd/topology/nodes") and not os.access("/sys/class/kfd/kfd/topology/nodes", os.R_OK | os.X_OK):
+            import torch                                     # the topology exists but cannot be read here: ask the runtime after all
+            have = torch.cuda.device_count()
         if have < n:
             print(f"[bench] --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
             return 2
