@@ -277,7 +277,8 @@ def dropin_boundary():
                                timeout=240)
             r = json.loads(p.stdout.strip().splitlines()[-1])
             out[key] = {"reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
-                        "worst_relative_error": r["worst_relative_error"], "within_1e-5": r["mismatches"] == 0}
+                        "worst_relative_error": r["worst_relative_error"], "differing_objects": r.get("differing_objects"),
+                        "equal_to_the_reference": r["mismatches"] == 0 and r.get("differing_objects") == 0}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     # particle systems: one particles_update hook per system (core/particle.c:89-140) against gpu_particles_update
@@ -299,7 +300,7 @@ def dropin_boundary():
                    "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities.  "
                    "*_characters_*: the frame's mq_update with every character's animated_update (keyframes, hierarchy, palette, joint "
                    "positions) on the host against the binding (entities, pose on the device, T/R/S + palette + positions of every "
-                   "joint copied back into the entity3d structs, joint-attached props in a second launch); per-object 1e-5 bar.  "
+                   "joint copied back into the entity3d structs, joint-attached props in a second launch); every float EQUAL to the reference's.  "
                    "*_particle_systems_*: binding_ms_per_frame = what a frame needs (every system's pos_array and billboard matrix back "
                    "on the host, libc's drand48 position handed on), *_with_particle_structs = every struct particle's pos / velocity "
                    "written back as well (only when the game reads them)")

@@ -62,7 +62,9 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_bounds.json"), "w") as f:
-            json.dump({"bar": 1e-5, "norm": "max|got-ref| over one object / max|ref| over the same object (floor 1e-30)",
+            json.dump({"bar": "equality of values (round 4); north_star's bar is 1e-5 relative",
+                       "norm": "per quantity: the worst max|got-ref| over one object / max|ref| over the same object (0.0 = every object "
+                               "equal) and the number of objects compared",
                        "worst": dict(sorted(PARITY_BOUNDS.items()))}, f, indent=1)
     except OSError:
         pass

@@ -1,7 +1,7 @@
 """GPU: the HIP particle path (through the C ABI) against the oracle and the reference's
 golden vectors.  Bar: pos_array / velocity / billboard matrix / drand48 state bit-exact
 (LIN, SQRT and CBRT radial distributions; POW075 goes through libm pow() in the reference
-and is held to 1e-5 relative)."""
+and is held to 1e-5 relative: pow(d, 0.75) is the one libm call of the path the device does not reproduce bit for bit)."""
 import glob
 import os
 
