@@ -117,14 +117,15 @@ class Bodies(C.Structure):
                 ("yoffset", C.c_void_p), ("bflags", C.c_void_p), ("adis_steps_left", C.c_void_p),
                 ("adis_time_left", C.c_void_p), ("body_entity", C.c_void_p),
                 ("length", C.c_void_p), ("inertia", C.c_void_p), ("geom_offset_R", C.c_double * 12),
-                ("aabb", C.c_void_p), ("axis", C.c_void_p), ("adis_samples", C.c_void_p), ("adis_counter", C.c_void_p)]
+                ("aabb", C.c_void_p), ("axis", C.c_void_p), ("adis_samples", C.c_void_p), ("adis_counter", C.c_void_p),
+                ("geom_records", C.c_void_p)]
 
 
 class Geoms(C.Structure):
     """clapgpu_geoms (include/clapgpu.h)."""
     _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("pos", C.c_void_p), ("axis", C.c_void_p),
                 ("radius", C.c_void_p), ("length", C.c_void_p), ("kind", C.c_void_p), ("aabb", C.c_void_p),
-                ("material", C.c_void_p)]
+                ("material", C.c_void_p), ("records", C.c_void_p)]
 
 
 POSE_SKIP_TRS, POSE_SKIP_JOINT_POS, POSE_JOINT_POS_MODEL = 1, 2, 4

@@ -32,6 +32,7 @@ struct CharK {
     uint32_t       *entity_flags;
     uint32_t        n_entities, n_bodies;
     double         *body_pos;
+    double         *body_geom_records;  // clapgpu_bodies.geom_records (or NULL): the narrowphase's copy of the position
     const double   *body_lvel, *body_yoffset;
 };
 
@@ -68,6 +69,10 @@ void k_characters_update(CharK k)
             k.body_pos[3 * (size_t)b + 0] = (double)ps.x;
             k.body_pos[3 * (size_t)b + 1] = (double)ps.y + k.body_yoffset[b];
             k.body_pos[3 * (size_t)b + 2] = (double)ps.z;
+            if (k.body_geom_records) {                              // the geom follows its body (dGeomSetBody): so does its record
+                double *r = k.body_geom_records + 8 * (size_t)b;
+                r[0] = (double)ps.x; r[1] = (double)ps.y + k.body_yoffset[b]; r[2] = (double)ps.z;
+            }
         }
     }
 
@@ -122,6 +127,7 @@ extern "C" int clapgpu_characters_update(void *stream, const clapgpu_characters 
     k.n_entities = e->n;
     k.n_bodies = b ? b->n : 0;
     k.body_pos = b ? b->pos : nullptr;
+    k.body_geom_records = b ? b->geom_records : nullptr;
     k.body_lvel = b ? b->lvel : nullptr;
     k.body_yoffset = b ? b->yoffset : nullptr;
     hipLaunchKernelGGL(k_characters_update, dim3((c->n + CHAR_BLOCK - 1) / CHAR_BLOCK), dim3(CHAR_BLOCK), 0,

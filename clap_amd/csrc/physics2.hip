@@ -45,16 +45,22 @@ struct BodiesK {
     double Roff[12];
     double *aabb, *axis, *adis_samples;
     uint32_t *adis_counter;
+    double *geom_records;
 };
 
 __device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const double (&p)[3], const double (&q)[4])
 {
-    if (!b.aabb && !b.axis) return;
+    if (!b.aabb && !b.axis && !b.geom_records) return;
     double R[12], axis[3], bb[6];
     phd::q_to_R(q, R);
     phd::capsule_axis(R, b.Roff, axis);
     const double lz = b.length ? b.length[i] : 0.0;
     phd::geom_aabb(p, b.radius[i], lz, axis, bb);
+    if (b.geom_records) {                                        // the narrowphase's view of this geom, one 64-byte sector
+        double2 *r = reinterpret_cast<double2 *>(b.geom_records + 8 * (size_t)i);
+        r[0] = make_double2(p[0], p[1]); r[1] = make_double2(p[2], axis[0]);
+        r[2] = make_double2(axis[1], axis[2]); r[3] = make_double2(b.radius[i], lz);
+    }
     if (b.axis) { double *a = b.axis + 3 * (size_t)i; a[0] = axis[0]; a[1] = axis[1]; a[2] = axis[2]; }
     if (b.aabb) {
         double2 *o = reinterpret_cast<double2 *>(b.aabb + 6 * (size_t)i);
@@ -761,10 +767,21 @@ struct GeomsK {
     uint32_t n;
     const double *pos, *axis, *radius, *length, *aabb, *material;
     const uint8_t *kind;
+    const double *rec;               // [n][8] (pos, axis, radius, length): only for sets without kind / aabb
 };
 
 __device__ __forceinline__ void load_geom(const GeomsK &g, uint32_t i, phd::Geom &o)
 {
+    if (g.rec) {                                                 // spheres and capsules: the whole geom in one 64-byte record
+        const double2 *r = reinterpret_cast<const double2 *>(g.rec + 8 * (size_t)i);
+        const double2 a = r[0], b = r[1], c = r[2], d = r[3];
+        o.pos[0] = a.x; o.pos[1] = a.y; o.pos[2] = b.x;
+        o.axis[0] = b.y; o.axis[1] = c.x; o.axis[2] = c.y;
+        o.radius = d.x; o.length = d.y;
+        o.kind = d.y != 0.0 ? CLAPGPU_GEOM_CAPSULE : CLAPGPU_GEOM_SPHERE;
+        for (int k = 0; k < 6; k++) o.aabb[k] = 0.0;
+        return;
+    }
     o.kind = g.kind ? g.kind[i] : ((g.length && g.length[i] != 0.0) ? CLAPGPU_GEOM_CAPSULE : CLAPGPU_GEOM_SPHERE);
     for (int a = 0; a < 3; a++) {
         o.pos[a] = g.pos ? g.pos[3 * (size_t)i + a] : 0.0;
@@ -1123,6 +1140,7 @@ static BodiesK bodies_k(const clapgpu_bodies *b)
     for (int i = 0; i < 12; i++) zero &= k.Roff[i] == 0.0;
     if (zero) k.Roff[0] = k.Roff[5] = k.Roff[10] = 1.0;                          // unset = no offset rotation
     k.aabb = b->aabb; k.axis = b->axis; k.adis_samples = b->adis_samples; k.adis_counter = b->adis_counter;
+    k.geom_records = (reinterpret_cast<uintptr_t>(b->geom_records) & 15u) ? nullptr : b->geom_records;
     return k;
 }
 
@@ -1327,6 +1345,8 @@ static GeomsK geoms_k(const clapgpu_geoms *g)
     GeomsK k;
     k.n = g->n; k.pos = g->pos; k.axis = g->axis; k.radius = g->radius; k.length = g->length; k.aabb = g->aabb;
     k.material = g->material; k.kind = g->kind;
+    // the one-sector records stand in for (pos, axis, radius, length) of sphere / capsule sets only
+    k.rec = (g->records && !g->kind && !g->aabb && !(reinterpret_cast<uintptr_t>(g->records) & 15u)) ? g->records : nullptr;
     return k;
 }
 

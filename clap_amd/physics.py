@@ -23,7 +23,7 @@ def _stream():
 
 
 class PhysWorld:
-    def __init__(self, bodies, statics=None, pair_capacity=None, device="cuda:0", static_pair_capacity=None):
+    def __init__(self, bodies, statics=None, pair_capacity=None, device="cuda:0", static_pair_capacity=None, geom_records=True):
         """bodies: dict from synth.sphere_bodies() / synth.capsule_bodies(); statics: float64 [ns, 6]
         (minx,maxx,miny,maxy,minz,maxz), host array: binned once by clapgpu_bp_create."""
         self.device = dev = torch.device(device)
@@ -56,6 +56,9 @@ class PhysWorld:
         _lib.lib().clapgpu_geom_offset_rotation(d.geom_offset_R)           # physics.c:974-978
         d.aabb, d.axis = _ptr(self.aabb), _ptr(self.axis)
         d.adis_samples, d.adis_counter = _ptr(self.adis_samples), _ptr(self.adis_counter)
+        # the narrowphase's one-sector view of every body geom (clapgpu_bodies.geom_records), kept by the step / aabb kernels
+        self.geom_records = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev) if geom_records else None
+        d.geom_records = _ptr(self.geom_records)
         self._desc = d
         self.capacity = int(pair_capacity if pair_capacity is not None else max(8 * n, 1024))
         self.static_capacity = int(static_pair_capacity if static_pair_capacity is not None else self.capacity)
@@ -104,7 +107,7 @@ class PhysWorld:
 
     def body_geoms(self):
         g = _lib.Geoms(self.n, 0, _ptr(self.pos), _ptr(self.axis), _ptr(self.radius), _ptr(self.length), 0, 0,
-                       _ptr(getattr(self, "material", None)))
+                       _ptr(getattr(self, "material", None)), _ptr(self.geom_records))
         return g
 
     def static_geoms(self):

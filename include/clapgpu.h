@@ -650,6 +650,12 @@ typedef struct clapgpu_bodies {
     double         *axis;
     double         *adis_samples;
     uint32_t       *adis_counter;
+    /* optional (NULL: none): [n][8] doubles -- position, capsule axis, radius, length of every body's geom in ONE
+     * 64-byte record, rewritten by clapgpu_bodies_step / clapgpu_bodies_aabb beside pos / axis whenever they move a geom.
+     * Hand the same pointer to the narrowphase as clapgpu_geoms.records: a candidate pair's PARTNER is then one 64-byte
+     * sector instead of four scattered ones (position, axis, radius, length) -- near_callback's gathers were 158 of the
+     * contact kernel's 231 MB at configs[3].  16-byte aligned. */
+    double         *geom_records;
 } clapgpu_bodies;
 
 /* host helpers for the set-up the reference does once per body (no device work) */
@@ -770,6 +776,9 @@ typedef struct clapgpu_geoms {
     const uint8_t  *kind;           /* [n] CLAPGPU_GEOM_*; NULL = sphere when length is 0, else capsule */
     const double   *aabb;           /* [n][6] boxes */
     const double   *material;       /* [n][5] bounce, bounce_vel, mu, soft_erp, soft_cfm (physics.c:77-81); may be NULL */
+    const double   *records;        /* optional: [n][8] = (pos, axis, radius, length) per geom, the SAME values as the arrays
+                                       above in one 64-byte record (clapgpu_bodies.geom_records); only read for geom sets
+                                       without kind / aabb (spheres and capsules: what bodies are).  16-byte aligned */
 } clapgpu_geoms;
 #define CLAPGPU_CONTACT_DEEP 0x80000000u
 typedef struct clapgpu_contact2 {

@@ -558,3 +558,33 @@ def test_capsule_sweeps_match_restatement(cuda_device):
         blocked += f < 1.0
     assert 30 < blocked < 300 and (frac[:5] == 1.0).all()
     assert (hit <= -2).any() and (hit >= 0).any(), "statics and bodies were both hit"
+
+
+def test_geom_records_give_the_same_contacts_as_the_arrays(cuda_device):
+    """clapgpu_bodies.geom_records / clapgpu_geoms.records: the narrowphase's one-sector view of every body geom (position,
+    axis, radius, length in 64 bytes, rewritten by the step and AABB kernels and by the character feeder's teleport) is a
+    CACHE of the arrays -- the contact records of both lists and the body flags come out byte for byte as without it,
+    before and after bodies have moved, and equal the oracle's."""
+    from clap_amd import physics
+    n = 30_000
+    b = synth.capsule_bodies(n, box=30.0, seed=19)
+    statics = synth.static_boxes(24, 30.0)
+    worlds = [physics.PhysWorld(b, statics, pair_capacity=16 * n, device=cuda_device, geom_records=r) for r in (True, False)]
+    assert worlds[0].geom_records is not None and worlds[1].geom_records is None
+    for step in range(3):
+        outs = []
+        for w in worlds:
+            w.broadphase()
+            w.contacts_geoms()
+            outs.append((w.download_contacts2(ob.CONTACT2_DTYPE), w.download()))
+        (c0, d0), (c1, d1) = outs
+        assert c0["body"][1] == c1["body"][1] > 0 and c0["static"][1] == c1["static"][1]
+        assert c0["body"][0].tobytes() == c1["body"][0].tobytes(), f"step {step}: body x body records"
+        assert c0["static"][0].tobytes() == c1["static"][0].tobytes(), f"step {step}: body x static records"
+        assert np.array_equal(d0["bflags"], d1["bflags"])
+        rec = worlds[0].geom_records.cpu().numpy()
+        assert np.array_equal(rec[:, 0:3], d0["pos"]) and np.array_equal(rec[:, 3:6], d0["axis"])
+        assert np.array_equal(rec[:, 6], b["radius"]) and np.array_equal(rec[:, 7], b["length"])
+        for w in worlds:
+            w.world_step(1.0 / 120.0)
+            w.world_step(1.0 / 120.0)

@@ -79,7 +79,7 @@ def main():
             b = synth.capsule_bodies(262_144, box=60.0, seed=4)
         pw = physics.PhysWorld(b, synth.static_boxes(64, 60.0), pair_capacity=2_000_000, device=dev)
         pw.broadphase()
-        fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.contacts_geoms if which == "contacts" else pw.broadphase
+        fn = (lambda: pw.world_step(1 / 120)) if which == "bodies" else pw.contacts_geoms if which == "contacts" else pw.contacts_geoms_both if which == "contacts_both" else pw.broadphase
     for _ in range(iters):
         fn()
     torch.cuda.synchronize()
