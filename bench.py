@@ -514,8 +514,15 @@ def extras(device, testbed=True):
     t_int = time_launches(lambda: pw.world_step(1.0 / 120.0), 200, warmup=100)
     t_bp = time_launches(pw.broadphase, 100, warmup=50)
     npairs = int(pw.pair_total.item())
+    t_con = time_launches(pw.contacts_geoms_both, 100, warmup=30)            # near_callback over both candidate lists
     out["bodies"] = {"bodies_per_s_integrate": pw.n / t_int, "bodies": pw.n, "kernel": "k_bodies_step",
                      "roofline": roof(pw.integrate_algorithmic_bytes(), t_int, "k_bodies_step"),
+                     "note": "the step also keeps the narrowphase's 64-byte geom record of every body (clapgpu_bodies.geom_records: "
+                             "+64 B / body written, outside SURVEY's 232 B): 18.5 -> 22.9 us here, 50 -> 39 us in the contact kernel",
+                     "contacts": {"us": t_con * 1e6, "kernel": "k_contacts_geoms_both", "candidate_pairs": npairs,
+                                  "static_candidate_pairs": int(pw.static_pair_total.item()),
+                                  "note": "both candidate lists of a substep in one launch, 160-byte records; a body geom is read as "
+                                          "one 64-byte record"},
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
                                     "launches": 5,
