@@ -820,6 +820,8 @@ static int pose_launch(hipStream_t s, PoseArgs &a, bool missing, bool times_lds,
     const size_t lds_total = 160u * 1024u;
     uint32_t want = (n_levels + (a.J + LPC / 4 - 1) / (LPC / 4) + 1);
     const size_t room = lds_total > cache.stat[slot] ? (lds_total - cache.stat[slot]) / ((size_t)LPC * 4) : 0;
+    if (want > room && times_lds)                               // the passes' program does not fit beside the key times in LDS:
+        return pose_launch<LPC, BLOCK>(s, a, missing, false, n_cus, n_levels);   // the times through L2 instead (passes computed on the fly cost more)
     if (want > room) want = (uint32_t)room;
     if (want > 2 * POSE_MAX_JOINTS) want = 2 * POSE_MAX_JOINTS;
     a.prog_passes = want;
@@ -896,6 +898,7 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     a.skip = pb->skip | (pb->joint_pos ? 0u : (uint32_t)CLAPGPU_POSE_SKIP_JOINT_POS);
 
     const bool missing = (an->packed_layout & POSE_LAYOUT_MISSING) != 0;
+    // key times in LDS whenever the model's rows fit (through L2 instead: 132 -> 147 us at 64 joints, 170 -> 202 at 128)
     const bool times_lds = (uint64_t)n_anims * (3u * kp + 3u) * lpc <= (uint64_t)POSE_TIMES_LDS_MAX * (lpc / 64);
     hipStream_t s = as_stream(stream);
     static thread_local struct { int dev, n_cus; } cus = { -1, 0 };
