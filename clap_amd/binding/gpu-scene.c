@@ -130,6 +130,10 @@ struct gpu_scene {
     struct view     *culled_view;
     vec4            culled_planes[6];
     entity3d        **draw; int32_t *draw_lod; uint32_t n_draw, cap_draw;   /* gpu_scene_select_lod's draw list */
+    /* the same list grouped by txmodel, in the order the txmodels first appear on it (gpu_scene_visible_of) */
+    entity3d        **draw_g; int32_t *draw_g_lod; uint32_t cap_draw_g;
+    struct gs_draw_group { const model3dtx *txm; uint32_t start, n; } *groups; uint32_t n_groups, cap_groups;
+    bool            groups_valid;
     struct gpu_scene_stats stats;
 };
 
@@ -245,7 +249,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
-    free(gs->draw); free(gs->draw_lod);
+    free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -1404,6 +1408,7 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
 {
     if (!gs) return _CERR_INVALID_ARGUMENTS;
     gs->n_draw = 0;
+    gs->groups_valid = false;
     /* the frustum the device's mask answers for: the one of the last update, or a cull launch for this view's planes */
     if (view) {
         if (view != gs->culled_view || !gs->cull_checked || !gs->cull_ok) {
@@ -1462,6 +1467,70 @@ uint32_t gpu_scene_visible(struct gpu_scene *gs, entity3d ***ents, const int32_t
     if (ents) *ents = gs->draw;
     if (lods) *lods = gs->draw_lod;
     return gs->n_draw;
+}
+
+/* the draw list grouped by txmodel (a stable counting sort, once per gpu_scene_select_lod and only when asked for) */
+static int draw_group(struct gpu_scene *gs)
+{
+    if (gs->groups_valid) return 0;
+    gs->n_groups = 0;
+    if (gs->n_draw > gs->cap_draw_g) {
+        entity3d **d = realloc(gs->draw_g, (size_t)gs->cap_draw * sizeof(*d));
+        if (!d) return _CERR_NOMEM;
+        gs->draw_g = d;
+        int32_t *l = realloc(gs->draw_g_lod, (size_t)gs->cap_draw * sizeof(*l));
+        if (!l) return _CERR_NOMEM;
+        gs->draw_g_lod = l;
+        gs->cap_draw_g = gs->cap_draw;
+    }
+    /* a scene has tens of txmodels and consecutive list entries mostly share theirs: the last hit first, then a scan */
+    uint32_t last = 0;
+    for (uint32_t k = 0; k < gs->n_draw; k++) {
+        const model3dtx *txm = gs->draw[k]->txmodel;
+        uint32_t g = last;
+        if (!gs->n_groups || gs->groups[g].txm != txm)
+            for (g = 0; g < gs->n_groups && gs->groups[g].txm != txm; g++)
+                ;
+        if (g == gs->n_groups) {
+            if (gs->n_groups == gs->cap_groups) {
+                const uint32_t cap = gs->cap_groups ? 2 * gs->cap_groups : 32;
+                struct gs_draw_group *q = realloc(gs->groups, (size_t)cap * sizeof(*q));
+                if (!q) return _CERR_NOMEM;
+                gs->groups = q; gs->cap_groups = cap;
+            }
+            gs->groups[gs->n_groups++] = (struct gs_draw_group){ .txm = txm, .start = 0, .n = 0 };
+        }
+        gs->groups[g].n++;
+        last = g;
+    }
+    uint32_t at = 0;
+    for (uint32_t g = 0; g < gs->n_groups; g++) { gs->groups[g].start = at; at += gs->groups[g].n; gs->groups[g].n = 0; }
+    last = 0;
+    for (uint32_t k = 0; k < gs->n_draw; k++) {
+        const model3dtx *txm = gs->draw[k]->txmodel;
+        uint32_t g = last;
+        if (gs->groups[g].txm != txm)
+            for (g = 0; gs->groups[g].txm != txm; g++)
+                ;
+        const uint32_t pos = gs->groups[g].start + gs->groups[g].n++;
+        gs->draw_g[pos] = gs->draw[k];
+        gs->draw_g_lod[pos] = gs->draw_lod[k];
+        last = g;
+    }
+    gs->groups_valid = true;
+    return 0;
+}
+
+uint32_t gpu_scene_visible_of(struct gpu_scene *gs, const model3dtx *txm, entity3d ***ents, const int32_t **lods)
+{
+    if (!gs || !txm || draw_group(gs)) return 0;
+    for (uint32_t g = 0; g < gs->n_groups; g++)
+        if (gs->groups[g].txm == txm) {
+            if (ents) *ents = gs->draw_g + gs->groups[g].start;
+            if (lods) *lods = gs->draw_g_lod + gs->groups[g].start;
+            return gs->groups[g].n;
+        }
+    return 0;
 }
 
 int gpu_scene_snapshot_begin(struct gpu_scene *gs, const char *path, struct clapgpu_snapshot_writer **out)

@@ -83,6 +83,10 @@ void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view);
  */
 int      gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *cam_pos);
 uint32_t gpu_scene_visible(struct gpu_scene *gs, entity3d ***ents, const int32_t **lods);
+/* ... and the part of it that belongs to one txmodel: what _models_render's loop body iterates, `txmodel` by `txmodel`
+ * (model.c:899-958 bind program, material and buffers per txmodel; the entity loop follows at 958).  Grouped lazily, once
+ * per gpu_scene_select_lod(); a txmodel with nothing drawn returns 0. */
+uint32_t gpu_scene_visible_of(struct gpu_scene *gs, const model3dtx *txm, entity3d ***ents, const int32_t **lods);
 void     gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e);
 
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);

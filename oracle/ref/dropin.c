@@ -458,6 +458,19 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
                 if (llod[k] != list[k]->cur_lod && bad++ < 8) fprintf(stderr, "frame %u: draw list LOD %d but e->cur_lod %d\n", f, llod[k], list[k]->cur_lod);
             }
             if (na != nb && bad++ < 8) fprintf(stderr, "frame %u pass %d: %u entities drawn by the reference, %u on the list\n", f, pass, na, nb);
+            {   /* the list txmodel by txmodel, as _models_render would walk it: every entry of its txmodel, the segments add up */
+                uint32_t seg_total = 0;
+                model3dtx *txm;
+                list_for_each_entry(txm, &B.mq->txmodels, entry) {
+                    entity3d **seg; const int32_t *slod;
+                    const uint32_t ns = gpu_scene_visible_of(gs, txm, &seg, &slod);
+                    for (uint32_t k = 0; k < ns; k++)
+                        if ((seg[k]->txmodel != txm || slod[k] != seg[k]->cur_lod) && bad++ < 8)
+                            fprintf(stderr, "frame %u pass %d: a draw-list segment holds a foreign entity or a stale LOD\n", f, pass);
+                    seg_total += ns;
+                }
+                if (seg_total != nb && bad++ < 8) fprintf(stderr, "frame %u pass %d: per-txmodel segments hold %u of %u entries\n", f, pass, seg_total, nb);
+            }
             for (uint32_t id = 0; id < n_ids; id++) {
                 if (!meta[id].alive) continue;
                 const entity3d *a = A.e[id], *b = B.e[id];
