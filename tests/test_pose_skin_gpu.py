@@ -425,3 +425,68 @@ def test_pose_update_rejects_pools_made_for_something_else(cuda_device):
     assert call(m64.anim_desc) == _lib.ERR_INVALID_ARGUMENTS
     m64.anim_desc.n_anims = keep[3]
     assert call(m64.anim_desc) == 0
+
+
+def _skeleton_with_parents(parent, seed):
+    """A synth.skeleton() whose tree is replaced by `parent` (joint 0 the root; -2 = not under joint 0)."""
+    J = len(parent)
+    sk = synth.skeleton(J, 2, seed=seed)
+    parent = np.asarray(parent, np.int32)
+    depth = np.full(J, -1, np.int32)
+    depth[0] = 0
+    order = [0]
+    for _ in range(J):
+        for j in range(1, J):
+            if depth[j] < 0 and parent[j] >= 0 and depth[parent[j]] >= 0:
+                depth[j] = depth[parent[j]] + 1
+    reach = [j for j in np.argsort(depth, kind="stable") if depth[j] >= 0]
+    sk["parent"] = np.where(parent == -2, -1, parent).astype(np.int32)
+    sk["depth"] = depth
+    sk["order"] = np.asarray(reach, np.int32)
+    return sk
+
+
+@pytest.mark.parametrize("shape", ["chain_64", "star_64", "chain_200", "comb_150", "two_roots_40", "understated_levels"])
+def test_pose_level_passes_on_odd_trees(shape, cuda_device):
+    """The hierarchy runs as level passes of up to LPC / 4 joints scheduled on the device from parent[] / depth[] (joints with
+    children first, left-over slots topped up from the next level), with a per-lane program in dynamic LDS sized by the
+    host from n_levels: a 64-level chain (64 passes of one joint), a star (63 siblings: four passes of one level), a
+    200-level chain (more passes than the LDS left beside the key times holds: the times go through L2; what still does
+    not fit is computed on the fly), a comb (a spine with a tooth per vertebra: every pass mixes two levels), a second
+    root whose subtree joint 0 does not hold, and a caller that understates n_levels -- all EQUAL to the oracle."""
+    from clap_amd import animation
+    if shape == "chain_64":
+        parent = [-1] + list(range(63))
+    elif shape == "star_64":
+        parent = [-1] + [0] * 63
+    elif shape == "chain_200":
+        parent = [-1] + list(range(199))
+    elif shape == "comb_150":
+        parent = [-1] + [(j - 1) if j % 2 else (j - 2) for j in range(1, 150)]       # odd joints: the spine's teeth
+        parent = [-1] + [max(p, 0) for p in parent[1:]]
+    elif shape == "two_roots_40":
+        parent = [-1] + [int(j // 2) for j in range(1, 30)] + [-2] + list(range(30, 39))
+    else:
+        parent = [-1] + [int((j - 1) // 3) for j in range(1, 90)]
+    sk = _skeleton_with_parents(parent, seed=61)
+    J, n = sk["nr_joints"], 41
+    an = synth.animation(J, 9, 1.5, seed=61)
+    ch = synth.characters(n, J, seed=61)
+    sk["bind"] = ob.skeleton_bind(sk)
+    model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
+    if shape == "understated_levels":
+        model.skel_desc.n_levels = 1                                     # the program table is then too small: the rest on the fly
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    reach = sk["order"]
+    for f, t in enumerate((ch["phase"], (ch["phase"] * 0.7 + 0.31) % 1.6)):
+        t = t.astype(np.float32)
+        jt, _gl, jp = ob.pose(sk, an, t, ch["char_mx"], trs)
+        batch.set_frame_times(t)
+        batch.pose_update()
+        out = batch.download()
+        assert_pose_equal(out, trs, jt, jp, reach, f"{shape} frame {f}")
+    unreach = np.setdiff1d(np.arange(J), reach)
+    assert not out["joint_transforms"][:, unreach].any(), "joints outside joint 0's tree stay untouched"
+    if shape == "two_roots_40":
+        assert len(unreach) == 10
