@@ -20,9 +20,10 @@
 //     quotient exactly (a quotient of two floats keeps 2^-49 away from every rounding boundary, the product errs by 2^-52);
 //   * hierarchy: global[j] = ((global[parent] * T) * R) * S, evaluated level by level in THAT association
 //     (model.c:1363-1383), then * invmx (model.c:1389), * bind's translation column, e->mx * (model.c:1392-1400).
-// T / R / S, the palette and the joint positions therefore EQUAL the reference's, value for value: 0 of 3.2 M joints
+// T / R / S, the palette and the joint positions therefore EQUAL the reference's, bit for bit: 0 of 3.2 M joints
 // differ at BASELINE configs[2] (tests/test_pose_skin_gpu.py, tools/pose_exact_check.py), and so do the skinned vertices.
-// (Values, not bit patterns: the "0.f +" that opens mat4x4_mul's sums turns a -0 sum into +0; the kernel leaves it out.)
+// (Signed zeros included: the "0.f +" that opens mat4x4_mul's sums and turns a -0 sum into +0 is the zero addend of the
+// v_pk_fma_f32 that forms the first product -- comb4<true>.)
 //
 // Mapping: one lane per joint, a 64-joint skeleton = one wavefront = one character for the keyframe work and the
 // palette; the hierarchy runs as "level passes": the joints of one level, FOUR LANES EACH (one per column of the
@@ -157,15 +158,23 @@ __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], 
 }
 
 // One matrix column as two register pairs; out = ((A0 x + A1 y) + A2 z) + A3 w is mat4x4_mul's / mat4x4_mul_vec4_post's
-// sum for one column (linmath.h:506-516, 297-305; the leading "0.f +" of mat4x4_mul only turns a -0 sum into +0), with
-// separately rounded products and sums: 4 v_pk_mul_f32 + 3 v_pk_add_f32 per pair of rows.
+// sum for one column (linmath.h:506-516, 297-305), with separately rounded products and sums: 4 v_pk_mul_f32 (or one
+// v_pk_fma_f32 with a zero addend and 3 v_pk_mul_f32) + 3 v_pk_add_f32 per pair of rows.
 struct Col { v2f lo, hi; };
 __device__ __forceinline__ Col col_of(const float4 v) { Col r; r.lo = v2f{v.x, v.y}; r.hi = v2f{v.z, v.w}; return r; }
 __device__ __forceinline__ float4 f4_of(const Col r) { return make_float4(r.lo.x, r.lo.y, r.hi.x, r.hi.y); }
+// ZERO_FIRST: mat4x4_mul's "t = 0.f; t += ..." (linmath.h:506-516) -- the add that turns a -0 first product into +0, so that
+// a sum of zeros comes out +0 as the reference's does; mat4x4_mul_vec4_post (linmath.h:297-305) has no such add.
+template <bool ZERO_FIRST>
 __device__ __forceinline__ Col comb4(const Col A0, const Col A1, const Col A2, const Col A3, float x, float y, float z, float w)
 {
     Col o;
-    o.lo = A0.lo * x; o.hi = A0.hi * x;
+    if (ZERO_FIRST) {                                            // fma(a, x, +0) = round(a * x) with -0 turned into +0: "0.f + a * x" in one v_pk_fma_f32
+        o.lo = __builtin_elementwise_fma(A0.lo, v2f{ x, x }, v2f{ 0.f, 0.f });
+        o.hi = __builtin_elementwise_fma(A0.hi, v2f{ x, x }, v2f{ 0.f, 0.f });
+    } else {
+        o.lo = A0.lo * x; o.hi = A0.hi * x;
+    }
     o.lo = o.lo + A1.lo * y; o.hi = o.hi + A1.hi * y;
     o.lo = o.lo + A2.lo * z; o.hi = o.hi + A2.hi * z;
     o.lo = o.lo + A3.lo * w; o.hi = o.hi + A3.hi * w;
@@ -490,7 +499,7 @@ void k_pose(PoseArgs a)
             const uint32_t vi = w & 0x3ffu, pa = (w >> 10) & 0x7ffu, oi = w >> 21;
             const float4 v = LOC[vi];
             const Col P0 = col_of(G[pa]), P1 = col_of(G[pa ^ 1u]), P2 = col_of(G[pa ^ 2u]), P3 = col_of(G[pa ^ 3u]);
-            Col o = comb4(P0, P1, P2, P3, v.x, v.y, v.z, v3);
+            Col o = comb4<true>(P0, P1, P2, P3, v.x, v.y, v.z, v3);
             o.lo = o.lo * v.w; o.hi = o.hi * v.w;
             G[oi] = f4_of(o);
             pose_lds_sync<LPC>();
@@ -513,14 +522,14 @@ void k_pose(PoseArgs a)
             const Col G0 = col_of(G[4 * j + (0 ^ sw)]), G1 = col_of(G[4 * j + (1 ^ sw)]);
             const Col G2 = col_of(G[4 * j + (2 ^ sw)]), G3 = col_of(G[4 * j + (3 ^ sw)]);
             const float4 i0 = jconst_lds[0 * LPC + j], i1 = jconst_lds[1 * LPC + j], i2 = jconst_lds[2 * LPC + j], i3 = jconst_lds[3 * LPC + j];
-            JT0 = comb4(G0, G1, G2, G3, i0.x, i0.y, i0.z, i0.w);
-            JT1 = comb4(G0, G1, G2, G3, i1.x, i1.y, i1.z, i1.w);
-            JT2 = comb4(G0, G1, G2, G3, i2.x, i2.y, i2.z, i2.w);
-            JT3 = comb4(G0, G1, G2, G3, i3.x, i3.y, i3.z, i3.w);
+            JT0 = comb4<true>(G0, G1, G2, G3, i0.x, i0.y, i0.z, i0.w);
+            JT1 = comb4<true>(G0, G1, G2, G3, i1.x, i1.y, i1.z, i1.w);
+            JT2 = comb4<true>(G0, G1, G2, G3, i2.x, i2.y, i2.z, i2.w);
+            JT3 = comb4<true>(G0, G1, G2, G3, i3.x, i3.y, i3.z, i3.w);
             POS.lo = v2f{ 0.f, 0.f }; POS.hi = v2f{ 0.f, 0.f };
             if (with_pos) {                                      // uniform
                 const float4 b3 = jconst_lds[4 * LPC + j];
-                const Col mp = comb4(JT0, JT1, JT2, JT3, b3.x, b3.y, b3.z, b3.w);
+                const Col mp = comb4<true>(JT0, JT1, JT2, JT3, b3.x, b3.y, b3.z, b3.w);    // column 3 of mat4x4_mul(joint_transforms, bind)
                 POS = mp;
             }
             if (pos_world) {                                     // uniform
@@ -533,7 +542,7 @@ void k_pose(PoseArgs a)
                 E1.lo = v2f{ em[4], em[5] };   E1.hi = v2f{ em[6], em[7] };
                 E2.lo = v2f{ em[8], em[9] };   E2.hi = v2f{ em[10], em[11] };
                 E3.lo = v2f{ em[12], em[13] }; E3.hi = v2f{ em[14], em[15] };
-                POS = comb4(E0, E1, E2, E3, mp.lo.x, mp.lo.y, mp.hi.x, mp.hi.y);
+                POS = comb4<false>(E0, E1, E2, E3, mp.lo.x, mp.lo.y, mp.hi.x, mp.hi.y);
             }
         }
         pose_lds_sync<LPC>();                                    // every lane has its joint's global: the slots become staging tiles
@@ -597,7 +606,7 @@ void k_joint_pos_world(uint32_t n_joints_total, uint32_t J, const int32_t *depth
     if (depth[q - c * J] < 0) return;                            // outside joint 0's tree: never written (model.c:1583)
     const float4 *em = entity_mx + 4 * (size_t)(entity ? entity[c] : c);
     const float4 mp = joint_pos[q];
-    joint_pos[q] = f4_of(comb4(col_of(em[0]), col_of(em[1]), col_of(em[2]), col_of(em[3]), mp.x, mp.y, mp.z, mp.w));
+    joint_pos[q] = f4_of(comb4<false>(col_of(em[0]), col_of(em[1]), col_of(em[2]), col_of(em[3]), mp.x, mp.y, mp.z, mp.w));
 }
 
 // animated_update's clock (model.c:1563-1592): one lane per character

@@ -1176,9 +1176,9 @@ static double rel_own(const float *a, const float *b, const int *idx, int n)
     const double m = obj_mag(a, idx, n);
     return obj_abs(a, b, idx, n) / (m > 1e-30 ? m : 1e-30);
 }
-/* The pose path is held to EQUALITY of values since round 4 (the kernel performs the reference's operations in the
+/* The pose path is held to EQUALITY of bit patterns since round 4 (the kernel performs the reference's operations in the
  * reference's order, clap_amd/csrc/pose.hip): every float of T, R, S, of the palette, of the joint positions and of what
- * rides a joint equals the reference's (-0 == +0: mat4x4_mul's leading "0.f +" turns a -0 sum into +0).  worst_own records
+ * rides a joint is the reference's, signed zeros included (a NaN may meet any NaN).  worst_own records
  * the worst per-object relative difference seen, 0 when everything agrees. */
 struct tol_stats { double worst_own; uint64_t differing; };
 static bool same(struct tol_stats *ts, const float *a, const float *b, const int *idx, int n)
@@ -1186,7 +1186,7 @@ static bool same(struct tol_stats *ts, const float *a, const float *b, const int
     bool eq = true;
     for (int k = 0; k < n; k++) {
         const float x = a[idx ? idx[k] : k], y = b[idx ? idx[k] : k];
-        eq &= x == y || (x != x && y != y);
+        eq &= !memcmp(&x, &y, sizeof(x)) || (x != x && y != y);       /* the same bits: -0 is not +0 */
     }
     if (!eq) {
         const double rel = rel_own(a, b, idx, n);

@@ -212,17 +212,17 @@ static int replay(clapgpu_snapshot *s)
         for (uint32_t c = 0; c < nc; c++) {
             clapo_pose_channels(&oan[a], ft[c], o_trs + (size_t)c * J * 10, cursor + (size_t)c * J * 3);
             clapo_pose_palette(&osk, o_trs + (size_t)c * J * 10, char_mx + 16 * c, o_gl + (size_t)c * J * 16, o_jt + (size_t)c * J * 16, o_jp + (size_t)c * J * 4);
-            uint32_t differ = 0;                                        /* equal as values (the kernel's arithmetic is the reference's) */
+            uint32_t differ = 0;                                        /* the same bits (the kernel's arithmetic is the reference's) */
             for (uint32_t k = 0; k < n_order; k++) for (int x = 0; x < 16; x++) {
                 const size_t at = ((size_t)c * J + (size_t)order[k]) * 16 + x;
-                differ += !(g_jt[at] == o_jt[at]);
+                differ += !!memcmp(&g_jt[at], &o_jt[at], 4);
             }
             CHECK(!differ, "frame %d character %u: %u palette floats differ from the oracle's", f, c, differ);
             clapo_skin(V, vpos, vnor, vj, vw, o_jt + (size_t)c * J * 16, o_op, o_on);
             uint32_t pd = 0, nd = 0;
             for (uint32_t x = 0; x < 3 * V; x++) {
-                pd += !(g_op[(size_t)c * 3 * V + x] == o_op[x]);
-                nd += !(g_on[(size_t)c * 3 * V + x] == o_on[x]);
+                pd += !!memcmp(&g_op[(size_t)c * 3 * V + x], &o_op[x], 4);
+                nd += !!memcmp(&g_on[(size_t)c * 3 * V + x], &o_on[x], 4);
             }
             CHECK(!pd && !nd, "frame %d character %u: %u skinned position / %u normal floats differ from the oracle's", f, c, pd, nd);
         }

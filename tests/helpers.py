@@ -51,9 +51,9 @@ def apply_frame(scene, st, frame):
 # for cancelled sums (objects whose error exceeded 1e-5 of their own magnitude passed on 64 fp32 ulps of their TERMS): the
 # kernel's arithmetic differed from the reference's (FMA contraction, polynomial slerp, a re-associated hierarchy), and
 # no tolerance relative to the result survives a cancellation.  Round 4's kernel performs the reference's operations in
-# the reference's order (clap_amd/csrc/pose.hip), so the clause is gone and the comparison is equality of VALUES,
-# element by element: T / R / S, the palette, joint positions, skinned positions and normals.  (-0.0 == +0.0: the
-# "0.f +" that opens every sum of mat4x4_mul, linmath.h:506-516, turns a -0 sum into +0; the kernel omits that add.
+# the reference's order (clap_amd/csrc/pose.hip), so the clause is gone and the comparison is equality of BIT PATTERNS,
+# element by element: T / R / S, the palette, joint positions, skinned positions and normals.  (-0.0 is not +0.0: the
+# "0.f +" that opens every sum of mat4x4_mul, linmath.h:506-516, turns a -0 sum into +0, and the kernel performs it.
 # A NaN must meet a NaN.)  What is recorded per quantity: the worst per-object relative difference (0.0 when the
 # test passes) and the number of objects compared.
 RTOL = 1e-5                                      # north_star's bar, for the rows that are still held to it (body state after N steps)
@@ -76,13 +76,14 @@ def _rel_objects(got, exp, idx=None):
 
 
 def assert_values_equal(got, exp, what, key=None, idx=None):
-    """(..., k) float arrays of k-component objects (vectors, quaternions, matrix blocks): EQUAL as values."""
+    """(..., k) float arrays of k-component objects (vectors, quaternions, matrix blocks): the same bit patterns
+    (a NaN for a NaN)."""
     g = np.ascontiguousarray(got, np.float32)
     e = np.ascontiguousarray(exp, np.float32)
     assert g.shape == e.shape, f"{what}: shape {g.shape} != {e.shape}"
     if idx is not None:
         g, e = g[..., list(idx)], e[..., list(idx)]
-    same = (g == e) | (np.isnan(g) & np.isnan(e))
+    same = (g.view(np.uint32) == e.view(np.uint32)) | (np.isnan(g) & np.isnan(e))          # the same BITS: -0 is not +0
     key = what if key is None else key
     n_obj = int(np.prod(g.shape[:-1])) if g.ndim > 1 else g.size
     PARITY_BOUNDS[key + " | objects compared"] = PARITY_BOUNDS.get(key + " | objects compared", 0) + n_obj

@@ -120,10 +120,10 @@ def test_hip_matches_oracle_with_pose_in_between(layout, cuda_device):
     batch.mq_update(fr)                  # ... and are rebuilt (always) with this frame's palette
     batch.compact_visible()
     out = batch.download()
-    assert np.array_equal(out["mx"], st["mx"]), "riders of a GPU palette: equal as values since round 4 (the pose is the reference's arithmetic)"
+    assert_bits_equal(out["mx"], st["mx"], "riders of a GPU palette: bit-exact since round 4 (the pose is the reference's arithmetic)")
     nonprop = np.ones(n, bool)
     desc = props.copy()
-    for _ in range(8):                   # props' subtrees depend on the palette (equal as values; a -0 may arrive as +0)
+    for _ in range(8):                   # props' subtrees depend on the palette (bit-exact since round 4)
         desc = np.union1d(desc, np.flatnonzero(np.isin(scene["parent"], desc)))
     nonprop[desc] = False
     assert_bits_equal(out["mx"][nonprop], st["mx"][nonprop], "entities not under a prop stay bit-exact")

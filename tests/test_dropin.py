@@ -99,7 +99,7 @@ def test_animation_binding_matches_reference_animated_update(n_chars, joints, fr
     one_joint_transform) vs gpu_mq_update + gpu_anim_update (binding -> HIP) on the reference's own model3d
     (model3d_add_skinning, animation_new / _add_channel), entities from ref_new(entity3d) and queues from
     animation_push_by_name: transforms bit for bit; each joint's T, R, S, its palette matrix and its world position EQUAL
-    to the reference's, value for value (round 4: the kernel performs the reference's arithmetic); e->animation, the queue
+    to the reference's, bit for bit (round 4: the kernel performs the reference's arithmetic); e->animation, the queue
     length, ani_time and the libc drand48 position (the random idle phase of animation_next) exactly; joints outside
     joint 0's tree untouched on both sides.
     Entities riding a character's joint (e->parent_joint, model.c:1626-1641) and their children: those listed after the

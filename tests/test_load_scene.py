@@ -15,6 +15,7 @@ import pytest
 
 from clap_amd import _lib, snapshot, synth
 from oracle import binding as ob
+from helpers import bits_equal
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "scene_fixture")
@@ -264,7 +265,7 @@ C_FP, C_INT = _C.POINTER(_C.c_float), _C.c_int
 @pytest.mark.gpu
 def test_loaded_scene_replays_on_the_gpu(loaded, cuda_device):
     """The loaded scene through the kernels: entity update (tile layout) bit-exact against the oracle, then the
-    characters' pose (both animations, several times) and skinning, value for value."""
+    characters' pose (both animations, several times) and skinning, bit for bit."""
     from clap_amd import animation, entities, tiler
     comps, _exp, _js = loaded
     raw = dict(comps["entities"])
@@ -299,10 +300,10 @@ def test_loaded_scene_replays_on_the_gpu(loaded, cuda_device):
             cb.skin()
             got = cb.download()
             jt, _g, jp = ob.pose(sk, anims[a_id], t, char_mx, trs)
-            assert np.array_equal(got["joint_transforms"][:, reach], jt[:, reach])          # equal as values (round 4)
-            assert np.array_equal(got["joint_pos"][:, reach], jp[:, reach])
+            assert bits_equal(got["joint_transforms"][:, reach], jt[:, reach])              # bit-exact (round 4)
+            assert bits_equal(got["joint_pos"][:, reach], jp[:, reach])
             op, on = ob.skin(mesh, np.zeros(n, np.uint32), np.full(n, V, np.uint32), jt)
-            assert np.array_equal(got["out_position"], op) and np.array_equal(got["out_normal"], on)
+            assert bits_equal(got["out_position"], op) and bits_equal(got["out_normal"], on)
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@ the reference's golden vectors.
 BASELINE.json north_star asks for "within 1e-5 relative for float transforms/positions".  Since round 4 the kernel performs
 the reference's operations in the reference's order and roundings (clap_amd/csrc/pose.hip: IEEE quotients, fp64 lerp,
 the slerp's acos / sin of each key pair from the host's libm at model build, fp64 sin / cos of the frame's angle, the
-hierarchy level by level in the association of model.c:1363-1383), so every comparison here is EQUALITY of values:
+hierarchy level by level in the association of model.c:1363-1383), so every comparison here is EQUALITY of bit patterns:
 each joint's T, R and S, its palette matrix, its world position, each skinned vertex position and normal -- against the
 oracle and against the golden vectors of the reference itself (tests/helpers.py assert_values_equal; what was compared
 goes to gpurun_out/parity_bounds.json).
@@ -326,7 +326,7 @@ def test_c3_shape_properties(cuda_device):
 def test_c3_full_size_pose_and_skin_match_oracle(cuda_device):
     """BASELINE configs[2] at FULL size, the launch bench.py times: 50 000 characters x 64 joints, one distinct
     200-vertex mesh per character (10 M vertices, 50 000 distinct vert_first offsets), pose_update + skin against
-    the oracle on EVERY output, value for value -- the persistent grid wrapping 50 000 characters over the resident blocks,
+    the oracle on EVERY output, bit for bit -- the persistent grid wrapping 50 000 characters over the resident blocks,
     the ragged last block and the per-character vertex windows are all inside the comparison."""
     from clap_amd import animation
     J, n, vpc = 64, 50_000, 200
@@ -490,3 +490,59 @@ def test_pose_level_passes_on_odd_trees(shape, cuda_device):
     assert not out["joint_transforms"][:, unreach].any(), "joints outside joint 0's tree stay untouched"
     if shape == "two_roots_40":
         assert len(unreach) == 10
+
+
+def test_pose_signed_zeros_are_the_references(cuda_device):
+    """mat4x4_mul starts every sum from +0 (linmath.h:506-516 "t = 0.f; t += ..."), so a sum of zero products is +0 there
+    whatever their signs, while mat4x4_scale_aniso and mat4x4_mul_vec4_post keep a -0.  A model made of exact zeros,
+    ones and negative numbers -- identity and half-turn rotations, zero and negative translations, mirrored scales,
+    axis-aligned bind and entity matrices -- makes most products a signed zero: the same BITS as the oracle (the palette
+    holds thousands of zeros and not one -0; a kernel that sums from the first product would have returned hundreds)."""
+    from clap_amd import animation
+    rng = np.random.default_rng(77)
+    J, n = 48, 37
+    sk = synth.skeleton(J, 7, seed=77)
+    quats = np.array([[0, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, -1], [-1, 0, 0, 0]], np.float32)
+
+    def axis_mats(k, tr):
+        m = np.zeros((k, 4, 4), np.float32)                             # [col][row]: a signed permutation + a translation
+        for i in range(k):
+            perm = rng.permutation(3)
+            for c in range(3):
+                m[i, c, perm[c]] = rng.choice([-1.0, 1.0, 2.0, -0.5])
+            m[i, 3, :3] = rng.choice(tr, 3)
+            m[i, 3, 3] = 1.0
+        return m.reshape(k, 16)
+
+    sk["invmx"] = axis_mats(J, [0.0, -0.0, 1.0, -2.0])
+    sk["root_pose"] = axis_mats(1, [0.0, -1.0])[0]
+    sk["bind"] = ob.skeleton_bind(sk)
+    an = synth.animation(J, 5, 1.0, seed=77, missing_frac=0.2)
+    data, off = an["data"].copy(), 0
+    for c in range(an["n_channels"]):                                   # every key an exact value: lerps of equal ends, slerps of axis quaternions
+        k, p, o = int(an["ch_nr"][c]), int(an["ch_path"][c]), int(an["ch_data_off"][c])
+        if p == 1:
+            data[o:o + 4 * k] = quats[rng.integers(0, len(quats), k)].ravel()
+        elif p == 0:
+            data[o:o + 3 * k] = np.tile(rng.choice([0.0, -0.0, -1.0, 0.5], 3), k)
+        else:
+            data[o:o + 3 * k] = np.tile(rng.choice([1.0, -1.0, 2.0], 3), k)
+    an["data"] = data.astype(np.float32)
+    ch = synth.characters(n, J, seed=77)
+    ch["char_mx"] = axis_mats(n, [0.0, -0.0, 3.0, -4.0])
+    ch["trs0"][:, 0:3] = rng.choice([0.0, -0.0, 1.0], (J, 3))
+    ch["trs0"][:, 3:7] = quats[rng.integers(0, len(quats), J)]
+    ch["trs0"][:, 7:10] = rng.choice([1.0, -1.0], (J, 3))
+    model = animation.SkinnedModel(sk, [an], bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ch["char_mx"])
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    t = ch["phase"].astype(np.float32) % 1.0
+    t[:5] = [0.0, 1.0, 0.5, 0.25, 0.75]
+    jt, _gl, jp = ob.pose(sk, an, t, ch["char_mx"], trs)
+    batch.set_frame_times(t)
+    batch.pose_update()
+    out = batch.download()
+    neg0 = lambda a: int(((a == 0) & np.signbit(a)).sum())
+    assert neg0(trs) > 1000 and neg0(jt) == 0 and ((jt == 0) & ~np.signbit(jt)).sum() > 5000, \
+        "the case is meant to hold -0 inputs, and mat4x4_mul never returns one"
+    assert_pose_equal(out, trs, jt, jp, sk["order"], "signed zeros")
