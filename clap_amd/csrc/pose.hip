@@ -326,83 +326,114 @@ void k_pose(PoseArgs a)
     __shared__ uint2 passes_lds[POSE_MAX_JOINTS];
     __shared__ int16_t depth_lds[POSE_MAX_JOINTS];
     __shared__ int16_t done_pass[POSE_MAX_JOINTS + 1];          // the pass a joint is computed in (-1: not yet); [J..]: -1
-    __shared__ int16_t par_lds[POSE_MAX_JOINTS];
     __shared__ uint32_t has_child[POSE_MAX_JOINTS];
     __shared__ uint32_t n_passes_s;
     extern __shared__ uint32_t prog_lds[];                       // [prog_passes][LPC] program words (dynamic: sized by the host from n_levels)
 
     const int tid = threadIdx.x;
     const int cib = tid / LPC, j = tid % LPC;                    // character in block, joint (BLOCK is a multiple of LPC)
+#ifdef CLAPGPU_POSE_PROF                                         // tools/build_variant.sh prof pose.hip -DCLAPGPU_POSE_PROF: block 0 prints its phases
+    unsigned long long pt[8]; int pn = 0;                        // (10 ns units): setup, program, first gather, characters 1-3, the rest
+#define PT() do { pt[pn++] = wall_clock64(); } while (0)
+    PT();
+#else
+#define PT() do {} while (0)
+#endif
     const int lane = lane_id();
     const uint32_t J = a.J;
     const int kp = (int)a.pk_kp, kk = (int)a.pk_k;
 
-    // ---- once per (persistent) block: tables ---------------------------------------------------------------------------
-    for (int q = tid; q < POSE_MAX_JOINTS; q += BLOCK) {
-        depth_lds[q] = (int16_t)((uint32_t)q < J ? a.depth[q] : -1);
-        int32_t par = (uint32_t)q < J ? a.parent[q] : -1;
-        par_lds[q] = (int16_t)((par < 0 || par >= (int32_t)J) ? -1 : par);
-        has_child[q] = 0;
-        done_pass[q] = -1;
-    }
+    // ---- once per (persistent) block: the first wavefront schedules the level passes while the others fill the tables ----
     if (j == 0) {
         float4 *root = &g_lds[cib][4 * LPC];                     // slot_swz(LPC) == 0: columns unswizzled
 #pragma unroll
         for (int q = 0; q < 4; q++)
             root[q] = make_float4(a.root_pose[4 * q], a.root_pose[4 * q + 1], a.root_pose[4 * q + 2], a.root_pose[4 * q + 3]);
     }
-    if (TIMES_LDS) {                                             // key-major times of every animation, then the key counts
-        const uint32_t nt = a.n_anims * 3u * a.pk_kp * LPC + a.n_anims * 3u * LPC;
-        for (uint32_t q = tid; q < nt; q += BLOCK)
-            times_lds[q] = a.pk_times[q];
-    }
-    if (tid < LPC) {
-        const uint32_t jq = (uint32_t)tid < J ? (uint32_t)tid : J - 1;
+    if (tid < WAVE) {
+        // up to four joints per lane (tid, tid + 64, ...), their state in registers; what a pass reads from LDS is only
+        // "when was my parent done".  DS operations of one wavefront execute in issue order: no barrier inside.
+        constexpr int ROWS = POSE_MAX_JOINTS / WAVE;
+        const int rows = (int)((J + WAVE - 1) / WAVE);           // uniform
+        int par_r[ROWS];
+        bool live_r[ROWS], hc_r[ROWS];
 #pragma unroll
-        for (int q = 0; q < 4; q++) jconst_lds[q * LPC + tid] = a.invmx[4 * jq + q];
-        jconst_lds[4 * LPC + tid] = a.bind[4 * jq + 3];
-    }
-    __syncthreads();
-    if ((uint32_t)tid < J && depth_lds[tid] >= 0 && par_lds[tid] >= 0) atomicOr(&has_child[par_lds[tid]], 1u);
-    __syncthreads();
-    if (tid < WAVE) {                                            // the first wavefront schedules: up to four joints per lane
+        for (int r = 0; r < ROWS; r++) {
+            const int jj = tid + WAVE * r;
+            const int d = (uint32_t)jj < J ? a.depth[jj] : -1;
+            const int32_t par = (uint32_t)jj < J ? a.parent[jj] : -1;
+            par_r[r] = (par < 0 || par >= (int32_t)J) ? -1 : par;
+            live_r[r] = d >= 0;                                    // reachable and not yet scheduled
+            depth_lds[jj] = (int16_t)d;
+            has_child[jj] = 0;
+            done_pass[jj] = -1;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+            if (live_r[r] && par_r[r] >= 0) atomicOr(&has_child[par_r[r]], 1u);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) hc_r[r] = has_child[tid + WAVE * r] != 0;
+        const uint64_t below = (1ull << tid) - 1ull;
         uint32_t at = 0, np = 0;
         for (;;) {
-            uint32_t taken = 0;
+            bool ready_r[ROWS];
 #pragma unroll
-            for (int cls = 1; cls >= 0; cls--) {                 // joints with children first, then leaves
-#pragma unroll
-                for (int r = 0; r < POSE_MAX_JOINTS / WAVE; r++) {
-                    const int jj = tid + WAVE * r;
-                    const int par = par_lds[jj];
-                    const bool ready = depth_lds[jj] >= 0 && done_pass[jj] < 0 && (int)(has_child[jj] != 0) == cls &&
-                                       (par < 0 || (done_pass[par] >= 0 && done_pass[par] < (int)np));
-                    const uint64_t m = __ballot(ready);
-                    const uint32_t rank = taken + (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
-                    if (ready && rank < (uint32_t)SPP) {
-                        order_lds[at + rank] = (uint32_t)jj | ((uint32_t)(par < 0 ? LPC : par) << 16);
-                        done_pass[jj] = (int16_t)np;
-                    }
-                    taken += (uint32_t)__popcll(m);
+            for (int r = 0; r < ROWS; r++) {
+                ready_r[r] = false;
+                if (r < rows) {                                  // uniform
+                    const int dp = par_r[r] >= 0 ? done_pass[par_r[r]] : 0;
+                    ready_r[r] = live_r[r] && (par_r[r] < 0 || (dp >= 0 && dp < (int)np));
                 }
             }
+            uint32_t taken = 0;
+#pragma unroll
+            for (int cls = 1; cls >= 0; cls--)                   // joints with children first, then leaves; rows in order
+#pragma unroll
+                for (int r = 0; r < ROWS; r++)
+                    if (r < rows) {                              // uniform
+                        const bool mine = ready_r[r] && (int)hc_r[r] == cls;
+                        const uint64_t m = __ballot(mine);
+                        const uint32_t rank = taken + (uint32_t)__popcll(m & below);
+                        if (mine && rank < (uint32_t)SPP) {
+                            const int jj = tid + WAVE * r;
+                            order_lds[at + rank] = (uint32_t)jj | ((uint32_t)(par_r[r] < 0 ? LPC : par_r[r]) << 16);
+                            done_pass[jj] = (int16_t)np;
+                            live_r[r] = false;
+                        }
+                        taken += (uint32_t)__popcll(m);
+                    }
             const uint32_t cnt = taken < (uint32_t)SPP ? taken : (uint32_t)SPP;
             if (!cnt) break;                                     // everything reachable is scheduled
             if (tid == 0) passes_lds[np] = make_uint2(at, cnt);
             at += cnt;
             np++;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_lds_fence();
         }
         if (tid == 0) n_passes_s = np;
+    } else {
+        const int t1 = tid - WAVE, nt1 = BLOCK - WAVE;
+        if (TIMES_LDS) {                                         // key-major times of every animation, then the key counts
+            const uint32_t nt = a.n_anims * 3u * a.pk_kp * LPC + a.n_anims * 3u * LPC;
+            for (uint32_t q = t1; q < nt; q += nt1)
+                times_lds[q] = a.pk_times[q];
+        }
+        for (int q = t1; q < LPC; q += nt1) {
+            const uint32_t jq = (uint32_t)q < J ? (uint32_t)q : J - 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) jconst_lds[k * LPC + q] = a.invmx[4 * jq + k];
+            jconst_lds[4 * LPC + q] = a.bind[4 * jq + 3];
+        }
     }
     __syncthreads();
+    PT();
     const int n_passes = (int)n_passes_s;
     const int prog_passes = n_passes < (int)a.prog_passes ? n_passes : (int)a.prog_passes;
     for (int q = tid; q < prog_passes * LPC; q += BLOCK)
         prog_lds[q] = pose_prog_word<LPC>(passes_lds, order_lds, q / LPC, (q % LPC) >> 2, q & 3);
     __syncthreads();
+    PT();
 
     // ---- per lane ------------------------------------------------------------------------------------------------------
     float4 *G = g_lds[cib];
@@ -448,6 +479,7 @@ void k_pose(PoseArgs a)
     // would stand for "all but a few operations" on the way round
     PoseKeys kv = gather(anim_of(c0), time_s[c0]);
     asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x), "v"(kv.rc.x), "v"(em_v));
+    PT();
 
     for (; g < n_groups; g += gridDim.x) {
         const uint32_t c_raw = g * CPB + cib_u;
@@ -592,7 +624,19 @@ void k_pose(PoseArgs a)
             buffer_store4(f4_of(POS), rs_pos, reachable ? (uint32_t)lane * 16u : POSE_CLIPPED, false);
             wave_lds_fence();
         }
+#ifdef CLAPGPU_POSE_PROF
+        if (pn < 7) PT();
+#endif
     }
+#ifdef CLAPGPU_POSE_PROF
+    asm volatile("s_waitcnt vmcnt(0)");
+    PT();
+    if (tid == 0 && blockIdx.x == 0) {
+        printf("pose prof (x10 ns):");
+        for (int q = 1; q < pn; q++) printf(" %llu", pt[q] - pt[q - 1]);
+        printf("\n");
+    }
+#endif
 }
 
 // model.c:1400 behind a pose that stopped at the model-space position (CLAPGPU_POSE_JOINT_POS_MODEL): one lane per joint

@@ -1338,7 +1338,7 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
             diff |= !!memcmp(a->aabb, b->aabb, sizeof(a->aabb)) << 1;
             diff |= (a->seq != b->seq) << 2;
             if (id >= n_plain) {                                  /* rides a palette computed on the device: the reference's values */
-                diff &= ~3;                                       /* (as values: a -0 of the palette may arrive as +0) */
+                diff &= ~3;                                       /* (the same bits since round 4; counted apart) */
                 bool ok = same(&ts_held, (const float *)a->mx, (const float *)b->mx, NULL, 16);
                 for (int h = 0; h < 2; h++)
                     ok &= same(&ts_held, (const float *)a->aabb[h], (const float *)b->aabb[h], NULL, 3);
@@ -1373,7 +1373,7 @@ static int cmd_anim(uint32_t n_chars, uint32_t J, uint32_t frames, uint64_t seed
            "\"joint_attached_checks\": %llu, \"worst_joint_attached_error\": %.3g, \"joint_attached_differing\": %llu, "
            "\"batched_updates\": %llu, \"attached_batched_updates\": %llu, \"attached_expected\": %llu, "
            "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, \"binding_mq_update_ms\": %.4f, \"frames_timed\": %u, "
-           "\"norm\": \"equality of values, float by float: each joint's T, R, S, palette matrix, world position; matrices and boxes of what rides a joint\", "
+           "\"norm\": \"equality of bit patterns, float by float: each joint's T, R, S, palette matrix, world position; matrices and boxes of what rides a joint\", "
            "\"tolerance\": 0, \"mismatches\": %llu}\n",
            frames, n_chars, J, (unsigned long long)posed, (unsigned long long)restarts, ts.worst_own, (unsigned long long)ts.differing,
            (unsigned long long)held_checked, ts_held.worst_own, (unsigned long long)ts_held.differing,
