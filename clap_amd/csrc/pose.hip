@@ -187,8 +187,6 @@ constexpr int POSE_TIMES_LDS_MAX = 6400;     // key times kept in LDS when the m
 constexpr int POSE_MAX_JOINTS = 256;
 
 typedef int pose_v4i __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) float *pose_cfloat;
-typedef const __attribute__((address_space(4))) uint32_t *pose_cu32;
 constexpr int POSE_RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit data format
 constexpr uint32_t POSE_CLIPPED = 0x7ffffff0u;                   // an offset past every descriptor's range: the store is dropped
 
@@ -339,6 +337,12 @@ void k_pose(PoseArgs a)
 #else
 #define PT() do {} while (0)
 #endif
+#ifdef CLAPGPU_POSE_PROF_ITER                                    // the phases of ONE character (the block's fourth) by s_memtime (core clocks)
+    unsigned long long qt[10]; int qn = 0; int iter_no = 0;
+#define QT() do { if (iter_no == 3 && qn < 10) qt[qn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define QT() do {} while (0)
+#endif
     const int lane = lane_id();
     const uint32_t J = a.J;
     const int kp = (int)a.pk_kp, kk = (int)a.pk_k;
@@ -360,8 +364,11 @@ void k_pose(PoseArgs a)
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int jj = tid + WAVE * r;
-            const int d = (uint32_t)jj < J ? a.depth[jj] : -1;
-            const int32_t par = (uint32_t)jj < J ? a.parent[jj] : -1;
+            const uint32_t jq = (uint32_t)jj < J ? (uint32_t)jj : J - 1;   // loads under no lane test: all in flight together
+            const int d_ld = a.depth[jq];
+            const int32_t par_ld = a.parent[jq];
+            const int d = (uint32_t)jj < J ? d_ld : -1;
+            const int32_t par = (uint32_t)jj < J ? par_ld : -1;
             par_r[r] = (par < 0 || par >= (int32_t)J) ? -1 : par;
             live_r[r] = d >= 0;                                    // reachable and not yet scheduled
             depth_lds[jj] = (int16_t)d;
@@ -444,8 +451,6 @@ void k_pose(PoseArgs a)
     const uint64_t reach_row = __ballot(reachable);              // this wavefront's 64-joint row
     const int row_j0 = j - lane;                                 // first joint of this wavefront's row
     const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
-    const pose_cu32 anim_s = (pose_cu32)a.anim, entity_s = (pose_cu32)a.entity;
-    const pose_cfloat time_s = (pose_cfloat)a.frame_time;
     const bool with_trs = !(a.skip & CLAPGPU_POSE_SKIP_TRS), with_pos = !(a.skip & CLAPGPU_POSE_SKIP_JOINT_POS);
     const bool pos_world = with_pos && !(a.skip & CLAPGPU_POSE_JOINT_POS_MODEL);   // e->mx * mpos here, or later (clapgpu_joint_pos_world)
     const uint32_t cib_u = (uint32_t)__builtin_amdgcn_readfirstlane(cib);
@@ -454,43 +459,50 @@ void k_pose(PoseArgs a)
     const int pq = j >> 2, pc = j & 3;
     const float v3 = pc == 3 ? 1.f : 0.f;
 
-    auto char_of = [&](uint32_t g_) {                            // past the end: a valid character whose stores are clipped
-        const uint32_t c_ = g_ * CPB + cib_u;
-        return c_ < a.n_chars ? c_ : a.n_chars - 1;
+    // Per-character scalars (animation, frame time, entity): lane L of a wavefront holds those of the character the
+    // wavefront works on L iterations after `it0` -- three vector loads per 64 iterations -- and an iteration takes its
+    // own with v_readlane.  (Scalar loads would share lgkmcnt with the LDS operations: every wait for an LDS result in
+    // the loop would also wait for the scalar cache's miss to L2 -- 4 us of the 94 of a palette-only launch.)
+    uint32_t v_an = 0, v_ent = 0;
+    float v_tm = 0.f;
+    auto load_scalars = [&](uint32_t it0) {
+        uint64_t c64 = ((uint64_t)blockIdx.x + (uint64_t)(it0 + (uint32_t)lane) * gridDim.x) * CPB + cib_u;
+        const uint32_t cL = c64 < a.n_chars ? (uint32_t)c64 : a.n_chars - 1;     // past the end: a valid character whose stores are clipped
+        const uint32_t an = a.anim[cL];
+        v_an = an < a.n_anims ? an : 0u;
+        v_tm = a.frame_time[cL];
+        v_ent = a.entity ? a.entity[cL] : cL;
     };
-    auto anim_of = [&](uint32_t c_) { const uint32_t an = anim_s[c_]; return an < a.n_anims ? an : 0u; };
-    auto entity_of = [&](uint32_t c_) { return a.entity ? entity_s[c_] : c_; };
+    auto lane_u32 = [&](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+    auto lane_f32 = [&](float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); };
     auto gather = [&](uint32_t an, float tm) {
         const uint32_t *nr = nr_tab + an * 3 * LPC + j;
         return pose_gather_keys<LPC, MISSING, TIMES_LDS>(times + (size_t)an * 3 * kp * LPC, a.pk_vals + (size_t)an * 3 * kk * LPC,
                                               a.pk_rc + (size_t)an * kk * LPC, kp, kk, tm, (int)nr[0], (int)nr[LPC], (int)nr[2 * LPC], j);
     };
 
-    // Per-character scalars travel one character ahead in SGPRs: a scalar load consumed where it is issued costs its
-    // round trip to L2 (the scalar cache does not hold 50 000 characters' worth).
-    uint32_t g = blockIdx.x;
-    const uint32_t c0 = char_of(g), c1 = char_of(g + gridDim.x);
+    uint32_t g = blockIdx.x, it = 0;
+    load_scalars(0);
     // the character's entity matrix: element (lane & 15) per lane, one vector load a character ahead, read back with
     // v_readlane where joint positions are formed
-    float em_v = pos_world ? a.entity_mx[16 * (size_t)entity_of(c0) + (lane & 15)] : 0.f;
-    float tm_next = time_s[c1];
-    uint32_t an_next = anim_of(c1);
+    float em_v = pos_world ? a.entity_mx[16 * (size_t)lane_u32(v_ent, 0) + (lane & 15)] : 0.f;
     // the first character's keys -- waited for HERE, so that no wait for them is left pending into the loop, where it
     // would stand for "all but a few operations" on the way round
-    PoseKeys kv = gather(anim_of(c0), time_s[c0]);
+    PoseKeys kv = gather(lane_u32(v_an, 0), lane_f32(v_tm, 0));
     asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x), "v"(kv.rc.x), "v"(em_v));
     PT();
 
-    for (; g < n_groups; g += gridDim.x) {
+    for (; g < n_groups; g += gridDim.x, it++) {
         const uint32_t c_raw = g * CPB + cib_u;
         const bool c_ok = c_raw < a.n_chars;                     // wave-uniform
         const uint32_t c = c_ok ? c_raw : a.n_chars - 1;
-        // scalars of the characters after this one: issued now, consumed a phase or a character later
-        const uint32_t c2 = char_of(g + 2 * gridDim.x);
-        const uint32_t an2 = anim_of(c2);
-        const float tm_next2 = time_s[c2];
-        const uint32_t ei_next = entity_of(char_of(g + gridDim.x));
+        // the scalars of the character after this one
+        const uint32_t nx = (it + 1) & (uint32_t)(WAVE - 1);
+        if (nx == 0) load_scalars(it + 1);                       // uniform: once per 64 iterations
+        const uint32_t an_next = lane_u32(v_an, nx), ei_next = lane_u32(v_ent, nx);
+        const float tm_next = lane_f32(v_tm, nx);
 
+        QT();
         // ---- 1. channels_transform: this character's T, R, S from its keys (model.c:1290-1350)
         float T[3], R[4], S[3];
         {
@@ -508,9 +520,11 @@ void k_pose(PoseArgs a)
             if (!(kv.has & 4u)) { S[0] = st[7]; S[1] = st[8]; S[2] = st[9]; }
         }
 
+        QT();
         // ---- 2. the next character's key search (LDS) and key gathers, in flight under the level passes below
         kv = gather(an_next, tm_next);
 
+        QT();
         // ---- 3. one_joint_transform (model.c:1352-1404).  The joint's local columns: R = mat4x4_from_quat(rotation)
         // (linmath.h:959-987), column c with scale[c] beside it; the translation with 1 beside it.
         {
@@ -523,6 +537,7 @@ void k_pose(PoseArgs a)
             LOC[4 * j + (3 ^ sw)] = make_float4(T[0], T[1], T[2], 1.0f);
         }
         pose_lds_sync<LPC>();                                    // (also: every wavefront is past the previous character's staging reads)
+        QT();
         // Level passes.  global = ((parent * T) * R) * S column by column: with P the parent's global,
         //   column c < 3:  ((P0 R[c][0] + P1 R[c][1]) + P2 R[c][2]) + P3' * 0, then * scale[c]   (mat4x4_mul by R, mat4x4_scale_aniso)
         //   column 3:      ((P0 tx + P1 ty) + P2 tz) + P3 * 1                                  (mat4x4_mul by T; R and S leave it alone)
@@ -546,6 +561,7 @@ void k_pose(PoseArgs a)
             for (int p = prog_passes; p < n_passes; p++)                        // a skeleton deeper than the host was told
                 level_pass(pose_prog_word<LPC>(passes_lds, order_lds, p, pq, pc));
         }
+        QT();
         // joint_transforms = global * invmx (model.c:1389); mpos = column 3 of joint_transforms * bind (model.c:1392-1397);
         // pos = e->mx * mpos (model.c:1400)
         Col JT0, JT1, JT2, JT3, POS;
@@ -579,10 +595,9 @@ void k_pose(PoseArgs a)
         }
         pose_lds_sync<LPC>();                                    // every lane has its joint's global: the slots become staging tiles
 
-        // ---- 4. the scalars of the character after next move up
-        an_next = an2;
+        QT();
+        // ---- 4. the next character's entity matrix
         if (pos_world) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
-        tm_next = tm_next2;
 
         // ---- 5. stores: all lanes, no branch; the descriptors clip (each wavefront's own: its 64-joint row of the character)
         const uint32_t rj0 = (uint32_t)__builtin_amdgcn_readfirstlane(row_j0);
@@ -624,10 +639,21 @@ void k_pose(PoseArgs a)
             buffer_store4(f4_of(POS), rs_pos, reachable ? (uint32_t)lane * 16u : POSE_CLIPPED, false);
             wave_lds_fence();
         }
+        QT();
+#ifdef CLAPGPU_POSE_PROF_ITER
+        iter_no++;
+#endif
 #ifdef CLAPGPU_POSE_PROF
         if (pn < 7) PT();
 #endif
     }
+#ifdef CLAPGPU_POSE_PROF_ITER
+    if (tid == 0 && blockIdx.x == 0) {
+        printf("pose iter (cycles): trs, gather issue, loc, passes, tail, stores:");
+        for (int q = 1; q < qn; q++) printf(" %llu", qt[q] - qt[q - 1]);
+        printf("\n");
+    }
+#endif
 #ifdef CLAPGPU_POSE_PROF
     asm volatile("s_waitcnt vmcnt(0)");
     PT();
@@ -887,7 +913,12 @@ static int pose_launch(hipStream_t s, PoseArgs &a, bool missing, bool times_lds,
         res = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)n_cus;
         cache.dyn[slot] = dyn;
     }
-    const dim3 grid(n_groups < res ? n_groups : res), block(BLOCK);
+    uint32_t blocks = n_groups < res ? n_groups : res;
+    if (const char *cap = getenv("CLAPGPU_POSE_BLOCKS")) {      // tests: a few persistent blocks take many characters each
+        const long v = strtol(cap, nullptr, 10);
+        if (v > 0 && (uint32_t)v < blocks) blocks = (uint32_t)v;
+    }
+    const dim3 grid(blocks), block(BLOCK);
     if (getenv("CLAPGPU_POSE_DEBUG"))
         fprintf(stderr, "k_pose<%d, %d>: %u blocks resident (%u per CU), static LDS %zu + dynamic %u, %u program passes\n", LPC, BLOCK,
                 res, res / (uint32_t)n_cus, cache.stat[slot], dyn, want);

@@ -546,3 +546,32 @@ def test_pose_signed_zeros_are_the_references(cuda_device):
     assert neg0(trs) > 1000 and neg0(jt) == 0 and ((jt == 0) & ~np.signbit(jt)).sum() > 5000, \
         "the case is meant to hold -0 inputs, and mat4x4_mul never returns one"
     assert_pose_equal(out, trs, jt, jp, sk["order"], "signed zeros")
+
+
+def test_pose_blocks_that_take_hundreds_of_characters(cuda_device, monkeypatch):
+    """A persistent block keeps the per-character scalars (animation, frame time, entity) of its next 64 characters in the
+    lanes of three registers and reloads them every 64 iterations; at BASELINE sizes a block sees 17 characters per slot.
+    Two blocks for 3 000 characters (CLAPGPU_POSE_BLOCKS) make 125 iterations each: two animations, per-character
+    entity indices, bit for bit."""
+    from clap_amd import animation
+    monkeypatch.setenv("CLAPGPU_POSE_BLOCKS", "2")
+    J, n = 64, 3000
+    sk = synth.skeleton(J, 8, seed=5)
+    anims = [synth.animation(J, 12, 2.0, seed=5), synth.animation(J, 7, 1.1, seed=6, ragged=True)]
+    ch = synth.characters(n, J, seed=5)
+    sk["bind"] = ob.skeleton_bind(sk)
+    rng = np.random.default_rng(5)
+    which = rng.integers(0, 2, n).astype(np.uint32)
+    ent = rng.permutation(n + 50)[:n].astype(np.uint32)                 # the characters' entities: any rows of a larger table
+    ent_mx = np.zeros((n + 50, 16), np.float32)
+    ent_mx[ent] = ch["char_mx"]
+    model = animation.SkinnedModel(sk, anims, bind=sk["bind"], device=cuda_device)
+    batch = animation.CharacterBatch(model, n, ch["trs0"], ent_mx, entity_index=ent)
+    batch.anim.copy_(torch.from_numpy(which.astype(np.int32)).to(batch.anim.dtype))
+    trs = np.tile(ch["trs0"], (n, 1, 1))
+    t = ch["phase"].astype(np.float32)
+    jt, _gl, jp = oracle_pose(sk, anims, which, t, ch["char_mx"], trs)
+    batch.set_frame_times(t)
+    batch.pose_update()
+    out = batch.download()
+    assert_pose_equal(out, trs, jt, jp, sk["order"], "125 characters per block slot")
