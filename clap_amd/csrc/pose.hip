@@ -252,11 +252,17 @@ __device__ __forceinline__ PoseKeys pose_gather_keys(const float *tl, const floa
     };
     int p0, q0, p1, q1, p2, q2;
     finish(t0, n0, l0, p0, q0, k.f0); finish(t1, n1, l1, p1, q1, k.f1); finish(t2, n2, l2, p2, q2, k.f2);
-    const float4 *v0 = vals + col, *v1 = v0 + kk * COLS, *v2 = v1 + kk * COLS;
-    k.ta = v0[p0 * COLS]; k.tb = v0[q0 * COLS];
-    k.ra = v1[p1 * COLS]; k.rb = v1[q1 * COLS];
-    k.sa = v2[p2 * COLS]; k.sb = v2[q2 * COLS];
-    k.rc = rc[p1 * COLS + col];
+    // uniform base + unsigned 32-bit byte offset per lane: the loads take their base from SGPRs (no 64-bit vector adds)
+    const float4 *v1 = vals + kk * COLS, *v2 = v1 + kk * COLS;
+    auto row16 = [&](const void *base, int row) {
+        const uint32_t off = (uint32_t)(row * COLS + col) * 16u;
+        return *reinterpret_cast<const float4 *>(static_cast<const char *>(base) + off);
+    };
+    k.ta = row16(vals, p0); k.tb = row16(vals, q0);
+    k.ra = row16(v1, p1);   k.rb = row16(v1, q1);
+    k.sa = row16(v2, p2);   k.sb = row16(v2, q2);
+    const float4 rcv = row16(rc, p1);
+    k.rc = make_uint4(__float_as_uint(rcv.x), __float_as_uint(rcv.y), __float_as_uint(rcv.z), __float_as_uint(rcv.w));
     return k;
 }
 
