@@ -91,35 +91,41 @@ __device__ __forceinline__ float lerp_ref(float a, float b, float blend, double 
 
 // sin and cos of x in [0, pi/2] in fp64: Taylor to x^21 / x^22 (|error| < 2 ulp of the double; rounded to float the
 // results equal glibc's in 2 * 10^8 of 2 * 10^8 samples).  No range reduction: theta = fac * acos(dot), fac in [0, 1], dot >= 0.
+// fma(a, b, c) with the coefficient c taken from an SGPR pair.  (Left to itself the compiler keeps the polynomials' 19
+// coefficients in 38 VGPRs for the life of the kernel and copies one with v_mov_b64 in front of every v_fmac_f64.)
+__device__ __forceinline__ double fma_coef(double a, double b, double c_uniform)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
 __device__ __forceinline__ void sincos_halfpi(double x, double &sn, double &cs)
 {
     const double z = x * x;
     double ps = -1.9572941063391263e-20;                                   // -1/21!
-    ps = __builtin_fma(ps, z, 8.2206352466243295e-18);
-    ps = __builtin_fma(ps, z, -2.8114572543455206e-15);
-    ps = __builtin_fma(ps, z, 7.6471637318198164e-13);
-    ps = __builtin_fma(ps, z, -1.6059043836821613e-10);
-    ps = __builtin_fma(ps, z, 2.5052108385441720e-08);
-    ps = __builtin_fma(ps, z, -2.7557319223985893e-06);
-    ps = __builtin_fma(ps, z, 1.9841269841269841e-04);
-    ps = __builtin_fma(ps, z, -8.3333333333333332e-03);
-    ps = __builtin_fma(ps, z, 1.6666666666666666e-01);
+    ps = fma_coef(ps, z, 8.2206352466243295e-18);
+    ps = fma_coef(ps, z, -2.8114572543455206e-15);
+    ps = fma_coef(ps, z, 7.6471637318198164e-13);
+    ps = fma_coef(ps, z, -1.6059043836821613e-10);
+    ps = fma_coef(ps, z, 2.5052108385441720e-08);
+    ps = fma_coef(ps, z, -2.7557319223985893e-06);
+    ps = fma_coef(ps, z, 1.9841269841269841e-04);
+    ps = fma_coef(ps, z, -8.3333333333333332e-03);
+    ps = fma_coef(ps, z, 1.6666666666666666e-01);
     sn = __builtin_fma(-(x * z), ps, x);
     double pc = -8.8967913924505741e-22;                                   // -1/22!
-    pc = __builtin_fma(pc, z, 4.1103176233121648e-19);
-    pc = __builtin_fma(pc, z, -1.5619206968586225e-16);
-    pc = __builtin_fma(pc, z, 4.7794773323873853e-14);
-    pc = __builtin_fma(pc, z, -1.1470745597729725e-11);
-    pc = __builtin_fma(pc, z, 2.0876756987868100e-09);
-    pc = __builtin_fma(pc, z, -2.7557319223985888e-07);
-    pc = __builtin_fma(pc, z, 2.4801587301587302e-05);
-    pc = __builtin_fma(pc, z, -1.3888888888888889e-03);
-    pc = __builtin_fma(pc, z, 4.1666666666666664e-02);
+    pc = fma_coef(pc, z, 4.1103176233121648e-19);
+    pc = fma_coef(pc, z, -1.5619206968586225e-16);
+    pc = fma_coef(pc, z, 4.7794773323873853e-14);
+    pc = fma_coef(pc, z, -1.1470745597729725e-11);
+    pc = fma_coef(pc, z, 2.0876756987868100e-09);
+    pc = fma_coef(pc, z, -2.7557319223985888e-07);
+    pc = fma_coef(pc, z, 2.4801587301587302e-05);
+    pc = fma_coef(pc, z, -1.3888888888888889e-03);
+    pc = fma_coef(pc, z, 4.1666666666666664e-02);
     pc = __builtin_fma(pc, z, -0.5);
     cs = __builtin_fma(z, pc, 1.0);
 }
-
-// interp.h:67-118 quat_slerp / quat_interp, with the key pair's constants from the pool
 __device__ __forceinline__ void slerp_ref(float (&res)[4], const float (&a)[4], const float (&b_in)[4], float fac, const uint4 rcw)
 {
     const float theta0 = __uint_as_float(rcw.x);
@@ -282,17 +288,18 @@ __device__ __forceinline__ void pose_lds_sync()
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// The level passes' per-lane program: for pass p the lane with role (entry q, column c) reads the local column LOC[v],
-// the parent's four columns G[pa ^ k] and writes G[o] -- one word (v | pa << 10 | o << 21, in 16-byte units) that depends
-// on the skeleton alone.  Idle lanes work on the scratch slot.
+// The level passes' per-lane program: for pass p the lane with role (entry q, column c) reads its joint's local column
+// -- at the same place of the character's LOC half as the global column it writes has in the G half -- and the parent's
+// four columns at pa ^ 16 k: one word (own column | pa << 16, byte offsets inside the character's G half) that depends on
+// the skeleton alone, so that a pass spends 8 instead of 15 instructions on addresses.  Idle lanes work on the scratch
+// slot.
 template <int LPC>
 __device__ __forceinline__ uint32_t pose_prog_word(const uint2 *passes, const uint32_t *order, int p, int q, int c)
 {
     const uint2 pr = passes[p];
     const uint32_t e = (uint32_t)q < pr.y ? order[pr.x + q] : ((uint32_t)(LPC + 1) | ((uint32_t)LPC << 16));
-    const uint32_t jj = e & 0xffffu, pp = e >> 16, jl = jj < (uint32_t)LPC ? jj : 0u;
-    return (4u * jl + ((uint32_t)c ^ (uint32_t)slot_swz((int)jl))) | ((4u * pp + (uint32_t)slot_swz((int)pp)) << 10) |
-           ((4u * jj + ((uint32_t)c ^ (uint32_t)slot_swz((int)jj))) << 21);
+    const uint32_t jj = e & 0xffffu, pp = e >> 16;
+    return 16u * (4u * jj + ((uint32_t)c ^ (uint32_t)slot_swz((int)jj))) | (16u * (4u * pp + (uint32_t)slot_swz((int)pp))) << 16;
 }
 
 // ---- the loop: one wavefront per 64 joints, no wavefront ever waits for its own stores -------------------------------
@@ -315,11 +322,14 @@ void k_pose(PoseArgs a)
 {
     constexpr int CPB = BLOCK / LPC;
     constexpr int SPP = LPC / 4;                                 // joints per level pass: four lanes each
-    // per character: the joints' globals, four 16-byte columns each (XOR-swizzled), + the root pose's slot [LPC] + the
-    // idle lanes' scratch slot [LPC + 1]; each wavefront's own 4 KiB of it is afterwards the staging tile of its stores
-    __shared__ __attribute__((aligned(16))) float4 g_lds[CPB][(LPC + 2) * 4];
-    // per character: the joints' local columns (R column c, scale c) for c < 3 and (translation, 1)
-    __shared__ __attribute__((aligned(16))) float4 loc_lds[CPB][LPC * 4];
+    // per character, the G half: the joints' globals, four 16-byte columns each (XOR-swizzled), + the root pose's slot
+    // [LPC] + the idle lanes' scratch slot [LPC + 1]; each wavefront's own 4 KiB of it is afterwards the staging tile of
+    // its stores.  The LOC half, the same slots HALF bytes on: the joints' local columns (R column c, scale c) for c < 3
+    // and (translation, 1).  A character's halves start on a 64-byte boundary (pa ^ 16 k addresses the parent's columns).
+    constexpr int HALF_SLOTS = (LPC + 2) * 4;
+    constexpr uint32_t HALF = HALF_SLOTS * 16u;
+    static_assert(HALF % 64u == 0 && 2u * HALF < 65536u, "a character's halves: 64-byte aligned, LOC within a DS offset of G");
+    __shared__ __attribute__((aligned(64))) float4 gl_lds[CPB][2 * HALF_SLOTS];
     __shared__ float times_lds[TIMES_LDS ? POSE_TIMES_LDS_MAX * (LPC / WAVE) : 4];
     __shared__ float4 jconst_lds[5 * LPC];                       // per joint: the four columns of invmx, column 3 of bind
     // level passes: order[] = the joints reachable from joint 0 in pass order as joint | parent slot << 16,
@@ -344,8 +354,8 @@ void k_pose(PoseArgs a)
 #define PT() do {} while (0)
 #endif
 #ifdef CLAPGPU_POSE_PROF_ITER                                    // the phases of ONE character (the block's fourth) by s_memtime (core clocks)
-    unsigned long long qt[10]; int qn = 0; int iter_no = 0;
-#define QT() do { if (iter_no == 3 && qn < 10) qt[qn++] = __builtin_readcyclecounter(); } while (0)
+    unsigned long long qt[12]; int qn = 0; int iter_no = 0;
+#define QT() do { if (iter_no == 3 && qn < 12) qt[qn++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define QT() do {} while (0)
 #endif
@@ -355,7 +365,7 @@ void k_pose(PoseArgs a)
 
     // ---- once per (persistent) block: the first wavefront schedules the level passes while the others fill the tables ----
     if (j == 0) {
-        float4 *root = &g_lds[cib][4 * LPC];                     // slot_swz(LPC) == 0: columns unswizzled
+        float4 *root = &gl_lds[cib][4 * LPC];                    // slot_swz(LPC) == 0: columns unswizzled
 #pragma unroll
         for (int q = 0; q < 4; q++)
             root[q] = make_float4(a.root_pose[4 * q], a.root_pose[4 * q + 1], a.root_pose[4 * q + 2], a.root_pose[4 * q + 3]);
@@ -449,8 +459,9 @@ void k_pose(PoseArgs a)
     PT();
 
     // ---- per lane ------------------------------------------------------------------------------------------------------
-    float4 *G = g_lds[cib];
-    float4 *LOC = loc_lds[cib];
+    float4 *G = gl_lds[cib];
+    float4 *LOC = G + HALF_SLOTS;
+    const uint32_t char_off = (uint32_t)cib * 2u * HALF;       // this character's G half, in bytes from gl_lds
     const float *times = TIMES_LDS ? times_lds : a.pk_times;
     const uint32_t *nr_tab = reinterpret_cast<const uint32_t *>(times + (size_t)a.n_anims * 3 * kp * LPC);
     const bool reachable = (uint32_t)j < J && depth_lds[j < POSE_MAX_JOINTS ? j : 0] >= 0;
@@ -509,14 +520,26 @@ void k_pose(PoseArgs a)
         const float tm_next = lane_f32(v_tm, nx);
 
         QT();
+#ifdef CLAPGPU_POSE_PROF_ITER                                    // how long the keys gathered a character ago are still waited for
+        asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x), "v"(kv.rc.x));
+        QT();
+#endif
         // ---- 1. channels_transform: this character's T, R, S from its keys (model.c:1290-1350)
         float T[3], R[4], S[3];
         {
             const double g0 = 1.0 - (double)kv.f0, g2 = 1.0 - (double)kv.f2;
             T[0] = lerp_ref(kv.ta.x, kv.tb.x, kv.f0, g0); T[1] = lerp_ref(kv.ta.y, kv.tb.y, kv.f0, g0); T[2] = lerp_ref(kv.ta.z, kv.tb.z, kv.f0, g0);
+#ifdef CLAPGPU_POSE_PROF_ITER
+            asm volatile("" : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]) : : "memory");
+            QT();
+#endif
             const float qa[4] = { kv.ra.x, kv.ra.y, kv.ra.z, kv.ra.w };
             const float qb[4] = { kv.rb.x, kv.rb.y, kv.rb.z, kv.rb.w };
             slerp_ref(R, qa, qb, kv.f1, kv.rc);
+#ifdef CLAPGPU_POSE_PROF_ITER
+            asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) : : "memory");
+            QT();
+#endif
             S[0] = lerp_ref(kv.sa.x, kv.sb.x, kv.f2, g2); S[1] = lerp_ref(kv.sa.y, kv.sb.y, kv.f2, g2); S[2] = lerp_ref(kv.sa.z, kv.sb.z, kv.f2, g2);
         }
         if (MISSING) {                                           // a path without a channel keeps its value (model.c:1301)
@@ -526,6 +549,9 @@ void k_pose(PoseArgs a)
             if (!(kv.has & 4u)) { S[0] = st[7]; S[1] = st[8]; S[2] = st[9]; }
         }
 
+#ifdef CLAPGPU_POSE_PROF_ITER
+        asm volatile("" : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(S[0]), "+v"(S[1]), "+v"(S[2]) : : "memory");
+#endif
         QT();
         // ---- 2. the next character's key search (LDS) and key gathers, in flight under the level passes below
         kv = gather(an_next, tm_next);
@@ -549,12 +575,14 @@ void k_pose(PoseArgs a)
         //   column 3:      ((P0 tx + P1 ty) + P2 tz) + P3 * 1                                  (mat4x4_mul by T; R and S leave it alone)
         // -- the products with the 0s and 1s of T and R that are left out are exact, the sums with their zeros too.
         auto level_pass = [&](const uint32_t w) {
-            const uint32_t vi = w & 0x3ffu, pa = (w >> 10) & 0x7ffu, oi = w >> 21;
-            const float4 v = LOC[vi];
-            const Col P0 = col_of(G[pa]), P1 = col_of(G[pa ^ 1u]), P2 = col_of(G[pa ^ 2u]), P3 = col_of(G[pa ^ 3u]);
+            char *const base = reinterpret_cast<char *>(&gl_lds[0][0]);
+            const uint32_t own = char_off + (w & 0xffffu), pa = char_off + (w >> 16);
+            const float4 v = *reinterpret_cast<const float4 *>(base + own + HALF);
+            const Col P0 = col_of(*reinterpret_cast<const float4 *>(base + pa)), P1 = col_of(*reinterpret_cast<const float4 *>(base + (pa ^ 16u)));
+            const Col P2 = col_of(*reinterpret_cast<const float4 *>(base + (pa ^ 32u))), P3 = col_of(*reinterpret_cast<const float4 *>(base + (pa ^ 48u)));
             Col o = comb4<true>(P0, P1, P2, P3, v.x, v.y, v.z, v3);
             o.lo = o.lo * v.w; o.hi = o.hi * v.w;
-            G[oi] = f4_of(o);
+            *reinterpret_cast<float4 *>(base + own) = f4_of(o);
             pose_lds_sync<LPC>();
         };
         {
@@ -655,7 +683,7 @@ void k_pose(PoseArgs a)
     }
 #ifdef CLAPGPU_POSE_PROF_ITER
     if (tid == 0 && blockIdx.x == 0) {
-        printf("pose iter (cycles): trs, gather issue, loc, passes, tail, stores:");
+        printf("pose iter (cycles): wait for keys, T, R, S, gather issue, loc, passes, tail, stores:");
         for (int q = 1; q < qn; q++) printf(" %llu", qt[q] - qt[q - 1]);
         printf("\n");
     }
