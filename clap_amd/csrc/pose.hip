@@ -187,7 +187,13 @@ __device__ __forceinline__ Col comb4(const Col A0, const Col A1, const Col A2, c
     return o;
 }
 
-constexpr int POSE_WAVES = 3;                // wavefronts per SIMD the registers are budgeted for (168 VGPRs)
+#ifndef POSE_WAVES_PER_SIMD
+#define POSE_WAVES_PER_SIMD 3
+#endif
+#ifndef POSE_BLOCK64
+#define POSE_BLOCK64 768
+#endif
+constexpr int POSE_WAVES = POSE_WAVES_PER_SIMD;   // wavefronts per SIMD the registers are budgeted for (168 VGPRs)
 constexpr int POSE_TIMES_LDS_MAX = 6400;     // key times kept in LDS when the model's rows fit: 25 KiB per 64 lanes (one animation of <= 31 keys
                                              // per channel with its key counts)
 constexpr int POSE_MAX_JOINTS = 256;
@@ -1036,7 +1042,7 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
     // (Two blocks of 320 threads measured as ONE resident block per CU although 2 x 80.8 KB fit 160 KiB on paper; two of
     // 256: 121 / 139 us against 112 / 136 for this form.)
     switch (lpc) {
-    case 64:  return pose_launch<64, 768>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
+    case 64:  return pose_launch<64, POSE_BLOCK64>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
     case 128: return pose_launch<128, 512>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
     case 192: return pose_launch<192, 384>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
     default:  return pose_launch<256, 256>(s, a, missing, times_lds, cus.n_cus, sk->n_levels);
