@@ -270,7 +270,8 @@ def dropin_boundary():
             "binding_ms": r["binding_ms"], "identical": r["mismatches"] == 0 and r["visible_equal"]}
     # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
     # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
-    for chars, joints, frames in ((500, 64, 14), (5_000, 64, 8)):
+    # (10 x 64 over 400 frames: the testbed's own scale, core/clap.c's demo scenes -- three device round trips a frame)
+    for chars, joints, frames in ((10, 64, 400), (500, 64, 14), (5_000, 64, 8)):
         key = f"{chars}_characters_{joints}_joints"
         try:
             p = subprocess.run([exe, "anim", str(chars), str(joints), str(frames), "5", "notify"], capture_output=True, text=True,
@@ -282,7 +283,7 @@ def dropin_boundary():
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
     # particle systems: one particles_update hook per system (core/particle.c:89-140) against gpu_particles_update
-    for systems, per, frames in ((48, 1024, 32), (1024, 1024, 8)):
+    for systems, per, frames in ((20, 512, 400), (48, 1024, 32), (1024, 1024, 8)):
         key = f"{systems}_particle_systems_x_{per}"
         try:
             p = subprocess.run([exe, "particles", str(systems), str(per), str(frames), "4"], capture_output=True, text=True, timeout=240)
