@@ -99,11 +99,17 @@ __device__ __forceinline__ double fma_coef(double a, double b, double c_uniform)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
     return r;
 }
+// fma(c0, z, c1) with both coefficients from SGPR pairs (one scalar operand per VALU instruction: c0 goes through a move)
+__device__ __forceinline__ double fma_coef2(double c0_uniform, double z, double c1_uniform)
+{
+    double r;
+    asm("v_mov_b64 %0, %2\n\tv_fma_f64 %0, %0, %1, %3" : "=&v"(r) : "v"(z), "s"(c0_uniform), "s"(c1_uniform));
+    return r;
+}
 __device__ __forceinline__ void sincos_halfpi(double x, double &sn, double &cs)
 {
     const double z = x * x;
-    double ps = -1.9572941063391263e-20;                                   // -1/21!
-    ps = fma_coef(ps, z, 8.2206352466243295e-18);
+    double ps = fma_coef2(-1.9572941063391263e-20, z, 8.2206352466243295e-18);          // -1/21!, 1/19!
     ps = fma_coef(ps, z, -2.8114572543455206e-15);
     ps = fma_coef(ps, z, 7.6471637318198164e-13);
     ps = fma_coef(ps, z, -1.6059043836821613e-10);
@@ -113,8 +119,7 @@ __device__ __forceinline__ void sincos_halfpi(double x, double &sn, double &cs)
     ps = fma_coef(ps, z, -8.3333333333333332e-03);
     ps = fma_coef(ps, z, 1.6666666666666666e-01);
     sn = __builtin_fma(-(x * z), ps, x);
-    double pc = -8.8967913924505741e-22;                                   // -1/22!
-    pc = fma_coef(pc, z, 4.1103176233121648e-19);
+    double pc = fma_coef2(-8.8967913924505741e-22, z, 4.1103176233121648e-19);           // -1/22!, 1/20!
     pc = fma_coef(pc, z, -1.5619206968586225e-16);
     pc = fma_coef(pc, z, 4.7794773323873853e-14);
     pc = fma_coef(pc, z, -1.1470745597729725e-11);
@@ -202,11 +207,13 @@ typedef int pose_v4i __attribute__((ext_vector_type(4)));
 constexpr int POSE_RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit data format
 constexpr uint32_t POSE_CLIPPED = 0x7ffffff0u;                   // an offset past every descriptor's range: the store is dropped
 
-__device__ __forceinline__ void buffer_store4(const float4 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off, bool stream)
+// byte_off: the lane's offset; uniform_off: a wave-uniform part that travels as the instruction's scalar offset (one lane
+// offset register then serves every 1 KiB piece of a row)
+__device__ __forceinline__ void buffer_store4(const float4 v, __amdgpu_buffer_rsrc_t r, uint32_t byte_off, bool stream, uint32_t uniform_off = 0)
 {
     const pose_v4i d = { __float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w) };
-    if (stream) __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 2);      // nt
-    else __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 0);
+    if (stream) __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, (int)uniform_off, 2);      // nt
+    else __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, (int)uniform_off, 0);
 }
 
 struct PoseKeys { float4 ta, tb, ra, rb, sa, sb; uint4 rc; float f0, f1, f2; uint32_t has; };
@@ -508,7 +515,12 @@ void k_pose(PoseArgs a)
     load_scalars(0);
     // the character's entity matrix: element (lane & 15) per lane, one vector load a character ahead, read back with
     // v_readlane where joint positions are formed
-    float em_v = pos_world ? a.entity_mx[16 * (size_t)lane_u32(v_ent, 0) + (lane & 15)] : 0.f;
+    const uint32_t em_lane_off = (uint32_t)(lane & 15) * 4u;
+    auto load_em = [&](uint32_t ei) {                             // (a buffer load: the 64-byte matrix is the descriptor's range, its base scalar)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.entity_mx) + 16 * (size_t)ei, 0, 64, POSE_RSRC_FLAGS);
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)em_lane_off, 0, 0));
+    };
+    float em_v = pos_world ? load_em(lane_u32(v_ent, 0)) : 0.f;
     // the first character's keys -- waited for HERE, so that no wait for them is left pending into the loop, where it
     // would stand for "all but a few operations" on the way round
     PoseKeys kv = gather(lane_u32(v_an, 0), lane_f32(v_tm, 0));
@@ -637,7 +649,7 @@ void k_pose(PoseArgs a)
 
         QT();
         // ---- 4. the next character's entity matrix
-        if (pos_world) em_v = a.entity_mx[16 * (size_t)ei_next + (lane & 15)];
+        if (pos_world) em_v = load_em(ei_next);
 
         // ---- 5. stores: all lanes, no branch; the descriptors clip (each wavefront's own: its 64-joint row of the character)
         const uint32_t rj0 = (uint32_t)__builtin_amdgcn_readfirstlane(row_j0);
@@ -655,7 +667,7 @@ void k_pose(PoseArgs a)
             wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < 3; k++)                           // 160 16-byte pieces; the third round's upper half lies past the row
-                buffer_store4(tile[k * WAVE + lane], rs_trs, (uint32_t)(k * WAVE + lane) * 16u, true);
+                buffer_store4(tile[k * WAVE + lane], rs_trs, (uint32_t)lane * 16u, true, (uint32_t)k * WAVE * 16u);
             wave_lds_fence();
         }
         {
@@ -674,7 +686,7 @@ void k_pose(PoseArgs a)
             for (int k = 0; k < 4; k++) {
                 const uint32_t piece = (uint32_t)(k * WAVE + lane);
                 const bool wr = (reach_row >> (piece >> 2)) & 1ull;
-                buffer_store4(v[k], rs_jt, wr ? piece * 16u : POSE_CLIPPED, false);
+                buffer_store4(v[k], rs_jt, wr ? (uint32_t)lane * 16u : POSE_CLIPPED, false, (uint32_t)k * WAVE * 16u);
             }
             buffer_store4(f4_of(POS), rs_pos, reachable ? (uint32_t)lane * 16u : POSE_CLIPPED, false);
             wave_lds_fence();
