@@ -480,7 +480,11 @@ void k_pose(PoseArgs a)
     const bool reachable = (uint32_t)j < J && depth_lds[j < POSE_MAX_JOINTS ? j : 0] >= 0;
     const uint64_t reach_row = __ballot(reachable);              // this wavefront's 64-joint row
     const int row_j0 = j - lane;                                 // first joint of this wavefront's row
-    const uint32_t n_groups = (a.n_chars + CPB - 1) / CPB;
+    // Character of (round it, block b, character slot cib): it * (blocks * CPB) + cib * blocks + b -- the characters of the
+    // last, partial round are spread over ALL blocks, a few wavefronts each, instead of filling some blocks and leaving the
+    // others idle (a round with 4 of 12 wavefronts busy is through sooner than a full one)
+    const uint32_t per_round = gridDim.x * (uint32_t)CPB;
+    const uint32_t n_rounds = (a.n_chars + per_round - 1) / per_round;
     const bool with_trs = !(a.skip & CLAPGPU_POSE_SKIP_TRS), with_pos = !(a.skip & CLAPGPU_POSE_SKIP_JOINT_POS);
     const bool pos_world = with_pos && !(a.skip & CLAPGPU_POSE_JOINT_POS_MODEL);   // e->mx * mpos here, or later (clapgpu_joint_pos_world)
     const uint32_t cib_u = (uint32_t)__builtin_amdgcn_readfirstlane(cib);
@@ -496,7 +500,7 @@ void k_pose(PoseArgs a)
     uint32_t v_an = 0, v_ent = 0;
     float v_tm = 0.f;
     auto load_scalars = [&](uint32_t it0) {
-        uint64_t c64 = ((uint64_t)blockIdx.x + (uint64_t)(it0 + (uint32_t)lane) * gridDim.x) * CPB + cib_u;
+        uint64_t c64 = (uint64_t)(it0 + (uint32_t)lane) * per_round + (uint64_t)cib_u * gridDim.x + blockIdx.x;
         const uint32_t cL = c64 < a.n_chars ? (uint32_t)c64 : a.n_chars - 1;     // past the end: a valid character whose stores are clipped
         const uint32_t an = a.anim[cL];
         v_an = an < a.n_anims ? an : 0u;
@@ -511,7 +515,7 @@ void k_pose(PoseArgs a)
                                               a.pk_rc + (size_t)an * kk * LPC, kp, kk, tm, (int)nr[0], (int)nr[LPC], (int)nr[2 * LPC], j);
     };
 
-    uint32_t g = blockIdx.x, it = 0;
+    uint32_t it = 0;
     load_scalars(0);
     // the character's entity matrix: element (lane & 15) per lane, one vector load a character ahead, read back with
     // v_readlane where joint positions are formed
@@ -527,10 +531,10 @@ void k_pose(PoseArgs a)
     asm volatile("" : : "v"(kv.ta.x), "v"(kv.tb.x), "v"(kv.ra.x), "v"(kv.rb.x), "v"(kv.sa.x), "v"(kv.sb.x), "v"(kv.rc.x), "v"(em_v));
     PT();
 
-    for (; g < n_groups; g += gridDim.x, it++) {
-        const uint32_t c_raw = g * CPB + cib_u;
+    for (; it < n_rounds; it++) {
+        const uint64_t c_raw = (uint64_t)it * per_round + (uint64_t)cib_u * gridDim.x + blockIdx.x;
         const bool c_ok = c_raw < a.n_chars;                     // wave-uniform
-        const uint32_t c = c_ok ? c_raw : a.n_chars - 1;
+        const uint32_t c = c_ok ? (uint32_t)c_raw : a.n_chars - 1;
         // the scalars of the character after this one
         const uint32_t nx = (it + 1) & (uint32_t)(WAVE - 1);
         if (nx == 0) load_scalars(it + 1);                       // uniform: once per 64 iterations
