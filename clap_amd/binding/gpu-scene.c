@@ -1434,9 +1434,11 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     /* a frame that is walked re-reads every batched entity's force_lod / cur_lod anyway (mirror()); in notification
      * mode the engine's entity3d_set_lod reports them (gpu-exports.inc.c -> gpu_scene_lod_changed) */
     uint32_t n = 0;
+    bool device_ok = true;                                       /* false: no update has run on the device yet -- everything below by the host block */
     if (gs->n_batched) {
         const int rc = clapgpu_scene_select_lod(gs->scene, cam_pos, &n);
         if (rc && rc != CLAPGPU_ERR_NOT_SUPPORTED) return rc;
+        device_ok = !rc;
     }
     clapgpu_scene_arrays res;
     const uint32_t *slots = NULL; const int32_t *lods = NULL;
@@ -1454,7 +1456,7 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     /* the entities the device does not hold, in list order, by the reference's own block */
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
-        if (!r->e || r->cls == 1 || r->cls == 4) continue;
+        if (!r->e || (device_ok && (r->cls == 1 || r->cls == 4))) continue;
         if (lod_pick_host(view, r->e, cam_pos))
             CK(draw_push(gs, r->e, r->e->cur_lod));
     }
