@@ -1409,6 +1409,9 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     if (!gs) return _CERR_INVALID_ARGUMENTS;
     gs->n_draw = 0;
     gs->groups_valid = false;
+    /* entities came or went since the frame's update (notification mode knows): the list would miss what the reference's
+     * walk of the txmodels draws -- this pass is the reference's */
+    if (gs->notify && gs->topology_pending) return _CERR_NOT_SUPPORTED;
     /* the frustum the device's mask answers for: the one of the last update, or a cull launch for this view's planes */
     if (view) {
         if (view != gs->culled_view || !gs->cull_checked || !gs->cull_ok) {

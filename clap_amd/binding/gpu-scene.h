@@ -75,7 +75,10 @@ void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view);
  * host-class entities: the reference's own functions, on the host.  cam_pos = transform_pos(&camera->xform, NULL), NULL
  * for a pass without a camera (model.c:974): the list alone.  `view` other than the one the last update culled
  * against, or with planes that moved since (scene_cameras_calc runs after mq_update), costs one more cull launch.
- * Call after gpu_mq_update() of the frame.  gpu_scene_visible(): the draw list of the last call -- batched entities in
+ * Call after gpu_mq_update() of the frame; entities created or destroyed between that update and the pass are not
+ * known to the list: in notification mode the call then returns _CERR_NOT_SUPPORTED with an empty list and the pass
+ * takes the reference's loop (a queue that is walked every frame has no way to notice: do not create entities between
+ * update and render there).  gpu_scene_visible(): the draw list of the last call -- batched entities in
  * device order, then host-class entities in list order -- for _models_render to iterate instead of every entity3d of
  * every txmodel (it binds per txmodel: e->txmodel of each entry says which).
  * gpu_scene_lod_changed(): entity3d_set_lod() wrote e->force_lod / e->cur_lod outside a walked frame (the engine-side
