@@ -301,7 +301,7 @@ def dropin_boundary():
                    "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities.  "
                    "*_characters_*: the frame's mq_update with every character's animated_update (keyframes, hierarchy, palette, joint "
                    "positions) on the host against the binding (entities, pose on the device, T/R/S + palette + positions of every "
-                   "joint copied back into the entity3d structs, joint-attached props in a second launch); every float EQUAL to the reference's.  "
+                   "joint copied back into the entity3d structs, joint-attached props in a second launch); every float the reference's, bit for bit.  "
                    "*_particle_systems_*: binding_ms_per_frame = what a frame needs (every system's pos_array and billboard matrix back "
                    "on the host, libc's drand48 position handed on), *_with_particle_structs = every struct particle's pos / velocity "
                    "written back as well (only when the game reads them)")
@@ -473,7 +473,7 @@ def extras(device, testbed=True):
     t_pose = time_launches(cb.pose_update, 200, warmup=100)
     t_skin = time_launches(cb.skin, 200, warmup=100)
     out["pose_palette"] = {"joints_per_s": n_chars * J / t_pose, "characters": n_chars, "joints": J,
-                           "kernel": "k_pose<64, 768, false, true> (the reference's arithmetic: results equal its values)",
+                           "kernel": "k_pose<64, 768, false, true> (the reference's arithmetic: results bit-exact, signed zeros included)",
                            "launches_timed": 200,
                            "roofline": roof(cb.pose_algorithmic_bytes(), t_pose, "[all outputs]"),
                            "note": "frac prices SURVEY 8d's 200 B/joint, of which 80 B are keyframes that are per MODEL and "

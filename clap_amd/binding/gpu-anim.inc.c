@@ -22,7 +22,7 @@
  *
  * Not mirrored: joint.off[] (the search cursor, irrelevant for strictly increasing key times),
  * joint.global (scratch).  Parity bar of this row: 1e-5 relative; since round 4 the kernel performs the
- * reference's own arithmetic and every float comes back EQUAL to the reference's (clap_dropin anim: tolerance 0).
+ * reference's own arithmetic and every float comes back with the reference's bits (clap_dropin anim: tolerance 0, -0 is not +0).
  */
 #include <stdint.h>
 #include <stdlib.h>
