@@ -80,23 +80,27 @@ void light_grid_compute(struct light *light, struct view *view)
     ref_light_grid_compute(light, view);
 }
 
-#define GPU_EXPORT_MUTATOR(name, params, args)                  \
+#define GPU_EXPORT_MUTATOR(name, params, args, notify)           \
     void ref_##name params;                                     \
     void name params                                            \
     {                                                           \
         ref_##name args;                                        \
-        gpu_scene_touch(gpu_scene_bound(), e);                  \
+        notify(gpu_scene_bound(), e);                           \
     }
 
-GPU_EXPORT_MUTATOR(entity3d_position, (entity3d *e, vec3 pos), (e, pos))
-GPU_EXPORT_MUTATOR(entity3d_move, (entity3d *e, vec3 off), (e, off))
-GPU_EXPORT_MUTATOR(entity3d_rotate, (entity3d *e, float rx, float ry, float rz), (e, rx, ry, rz))
-GPU_EXPORT_MUTATOR(entity3d_scale, (entity3d *e, float scale), (e, scale))
-GPU_EXPORT_MUTATOR(entity3d_visible, (entity3d *e, unsigned int visible), (e, visible))
+/* the four that write the transform alone leave the entity's address; entity3d_visible writes e->flags */
+GPU_EXPORT_MUTATOR(entity3d_position, (entity3d *e, vec3 pos), (e, pos), gpu_scene_touch_xform)
+GPU_EXPORT_MUTATOR(entity3d_move, (entity3d *e, vec3 off), (e, off), gpu_scene_touch_xform)
+GPU_EXPORT_MUTATOR(entity3d_rotate, (entity3d *e, float rx, float ry, float rz), (e, rx, ry, rz), gpu_scene_touch_xform)
+GPU_EXPORT_MUTATOR(entity3d_scale, (entity3d *e, float scale), (e, scale), gpu_scene_touch_xform)
+GPU_EXPORT_MUTATOR(entity3d_visible, (entity3d *e, unsigned int visible), (e, visible), gpu_scene_touch)
+
+static void gpu_before_host_update(entity3d *e) { gpu_scene_host_update_begin(gpu_scene_bound(), e); }
 
 void ref_entity3d_update(entity3d *e, void *data);
 void entity3d_update(entity3d *e, void *data)
 {
+    gpu_before_host_update(e);
     ref_entity3d_update(e, data);
     gpu_scene_host_updated(gpu_scene_bound(), e);
 }
@@ -104,6 +108,7 @@ void entity3d_update(entity3d *e, void *data)
 void ref_entity3d_reset(entity3d *e);
 void entity3d_reset(entity3d *e)
 {
+    gpu_before_host_update(e);
     ref_entity3d_reset(e);
     gpu_scene_host_updated(gpu_scene_bound(), e);
 }

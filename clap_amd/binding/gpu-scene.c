@@ -80,6 +80,10 @@ struct gs_rec {
     uint8_t     pending;        /* on the touched list (notification mode) */
     uint8_t     host_done;      /* entity3d_update() / entity3d_reset() ran this entity's update on the host between frames: the device
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
+    uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
+                                   gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
+    uint16_t    host_bump, seq_mark;   /* seq steps entity3d_update / _reset took on the HOST since the last frame (the device catches up
+                                   with ONE rebuild in the next frame, its children follow only then) / e->seq when such an update began */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
     int32_t     lod_force, lod_cur; /* e->force_lod / e->cur_lod as the mirror holds them (gpu_scene_select_lod) */
 };
@@ -113,6 +117,11 @@ struct gpu_scene {
     entity3d        **vq_e; uint32_t *vq_slot; uint8_t *vq_ok; uint32_t cap_vq;
     bool            cull_checked, cull_ok;                         /* the culled view's planes were compared since they last changed */
     uint32_t        *touched; uint32_t n_touched, cap_touched;
+    /* transform-only notifications (gpu_scene_touch_xform): the entity's address is all a mutator leaves behind -- no
+     * look-up, no cache miss beside the entity it has just written; the frame's mirror pass resolves the addresses
+     * through a flat table (address -> record, mirror handle) rebuilt by every walk, on all worker threads */
+    entity3d        **xptr; uint32_t n_xptr, cap_xptr;
+    struct gs_fast { uint64_t key; uint32_t rec, handle; } *ftab; uint32_t ftab_mask, ftab_cap;
     uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
     uint32_t        *deferred; uint32_t n_deferred, cap_deferred;  /* class 3 records in list order (last walk) */
     uint32_t        *att_list; uint32_t n_att, cap_att;            /* class 4 records in list order (last walk) */
@@ -134,6 +143,11 @@ struct gpu_scene {
     entity3d        **draw_g; int32_t *draw_g_lod; uint32_t cap_draw_g;
     struct gs_draw_group { const model3dtx *txm; uint32_t start, n; } *groups; uint32_t n_groups, cap_groups;
     bool            groups_valid;
+    /* GPU_SCATTER_DRAWN: rebuilds of a slot the host has not been shown yet (e->seq lags by this much, uint16 like seq) */
+    bool            scatter_drawn, drawn_now;                      /* the policy; it is in force for the frame being run (a fast frame) */
+    uint16_t        *pend; uint32_t cap_pend; bool any_pend;
+    entity3d        *last_control;
+    uint32_t        fetch_seen;                                    /* clapgpu_scene_arrays.fetch_serial already copied out */
     struct gpu_scene_stats stats;
 };
 
@@ -236,6 +250,8 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     gs->default_hook = default_hook;
     gs->free_rec = NO_REC;
     gs->verify = getenv("GPU_SCENE_VERIFY") != NULL;
+    const char *sp = getenv("GPU_SCENE_SCATTER");
+    gs->scatter_drawn = sp && !strcmp(sp, "drawn");
     gpu_scene_pool_ref();
     *out = gs;
     return 0;
@@ -249,7 +265,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
-    free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups);
+    free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->xptr); free(gs->ftab);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -291,6 +307,7 @@ void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int
  * joint transforms of the frame exist.  Called by gpu_anim_update(); a frame driver without it calls this itself. */
 static void bv_pick(struct scene *scene, entity3d *e);
 static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq);
+static void consume_fetched(struct gpu_scene *gs);
 
 /* The frame's second entity launch: the subtrees riding a batched character's joint (class 4), now that the palettes of
  * the frame are in the entities (e->parent->joint_transforms[e->parent_joint], model.c:1633-1640). */
@@ -456,6 +473,7 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
         r->model = model;
         r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;            /* what entity_new starts with */
         r->lod_force = -1; r->lod_cur = 0;                        /* likewise (entity3d_make, model.c:1741) */
+        r->keep = 0;
         st->registered++;
     }
     if (e->force_lod != r->lod_force || e->cur_lod != r->lod_cur) {   /* entity3d_set_lod since (model.c:593-609) */
@@ -468,6 +486,8 @@ static int mirror_one(struct gpu_scene *gs, struct gs_rec *r)
         r->flags = flags;
     }
     r->xform_dirty = transform_is_updated(&e->xform);
+    if (r->host_done && r->xform_dirty) r->host_done = 2;        /* written again since the host updated it */
+    if (gs->drawn_now && r->xform_dirty) transform_clear_updated(&e->xform);   /* its write-back may not come: default_update's clear (model.c:1615, 1668) here */
     if (r->xform_dirty || fresh || r->host_done) {       /* host_done: the flag is already cleared, the device copy is not yet current */
         CK(clapgpu_scene_entity_transform(gs->scene, r->handle, transform_pos(&e->xform, NULL),
                                           transform_rotation_quat(&e->xform), e->scale));
@@ -563,6 +583,101 @@ void gpu_scene_touch(struct gpu_scene *gs, entity3d *e)
     if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) gs->topology_pending = true;
 }
 
+/* entity3d_position / _move / _rotate / _scale changed e's transform and nothing else (transform_set_updated is set,
+ * model.c:1810-1842): remembered by address.  Whoever changes e->flags, e->parent or e->update says so through
+ * gpu_scene_touch() / gpu_scene_topology() as before -- this path does not look for it (the verification aid does: with
+ * it on, every notification takes the checked path). */
+void gpu_scene_touch_xform(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !gs->notify || gs->topology_pending) return;      /* a pending walk re-reads every transform anyway */
+    if (gs->verify || !gs->ftab) { gpu_scene_touch(gs, e); return; }
+    if (gs->n_xptr == gs->cap_xptr) {
+        /* an entity may be written several times a frame; a list four times the queue says the game re-writes everything
+         * all the time: the walk is the cheaper frame then */
+        const uint64_t limit = 4ull * gs->n_order + 65536;
+        if (gs->cap_xptr >= limit) { gs->topology_pending = true; return; }
+        uint64_t cap = gs->cap_xptr ? 2ull * gs->cap_xptr : 4096;
+        if (cap > limit) cap = limit;
+        entity3d **q = realloc(gs->xptr, cap * sizeof(*q));
+        if (!q) { gs->topology_pending = true; return; }
+        gs->xptr = q; gs->cap_xptr = (uint32_t)cap;
+    }
+    gs->xptr[gs->n_xptr++] = e;
+}
+
+static inline uint32_t ftab_home(const struct gpu_scene *gs, const void *e) { return ptr_hash(e) & gs->ftab_mask; }
+
+static int ftab_build(struct gpu_scene *gs)
+{
+    uint32_t cap = 1024;
+    while (cap < 2 * gs->n_order) cap *= 2;
+    if (cap != gs->ftab_cap) {
+        struct gs_fast *t = realloc(gs->ftab, (size_t)cap * sizeof(*t));
+        if (!t) { free(gs->ftab); gs->ftab = NULL; gs->ftab_cap = 0; return _CERR_NOMEM; }
+        gs->ftab = t; gs->ftab_cap = cap;
+    }
+    gs->ftab_mask = cap - 1;
+    memset(gs->ftab, 0, (size_t)cap * sizeof(*gs->ftab));
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        uint32_t h = ftab_home(gs, r->e);
+        while (gs->ftab[h].key) h = (h + 1) & gs->ftab_mask;
+        gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)r->e, gs->order[k], (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY };
+    }
+    return 0;
+}
+
+/* the mirror pass over [lo, hi) of the address list: table line asked for sixteen entries ahead, entity eight ahead */
+struct xptr_ctx { struct gpu_scene *gs; int mt, rc; uint32_t pushed; };
+static void xptr_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct xptr_ctx *xc = ctx;
+    struct gpu_scene *gs = xc->gs;
+    uint32_t ring[8];                                            /* table positions of entries k .. k + 7 */
+    uint32_t pushed = 0;
+    for (uint32_t k = lo; k < hi + 8; k++) {
+        if (k + 8 < hi) __builtin_prefetch(&gs->ftab[ftab_home(gs, gs->xptr[k + 8])], 0, 1);
+        if (k >= lo + 8) {                                       /* entry k - 8: resolved eight steps ago, its entity asked for then */
+            const uint32_t h = ring[(k - 8) & 7];
+            if (h != NO_REC) {
+                const struct gs_fast *f = &gs->ftab[h];
+                entity3d *e = (entity3d *)(uintptr_t)f->key;
+                const bool upd = transform_is_updated(&e->xform);
+                const int rc = xc->mt ? clapgpu_scene_entity_xform_mt(gs->scene, f->handle, transform_pos(&e->xform, NULL),
+                                                                      transform_rotation_quat(&e->xform), e->scale, upd)
+                                      : (upd ? clapgpu_scene_entity_transform(gs->scene, f->handle, transform_pos(&e->xform, NULL),
+                                                                              transform_rotation_quat(&e->xform), e->scale) : 0);
+                if (rc) xc->rc = rc;
+                if (gs->drawn_now && upd) transform_clear_updated(&e->xform);   /* see mirror_one */
+                pushed++;
+            }
+        }
+        if (k < hi) {
+            const entity3d *e = gs->xptr[k];
+            uint32_t h = ftab_home(gs, e);
+            while (gs->ftab[h].key && gs->ftab[h].key != (uint64_t)(uintptr_t)e) h = (h + 1) & gs->ftab_mask;
+            if (gs->ftab[h].key && gs->ftab[h].handle != CLAPGPU_NO_ENTITY) {   /* ours, and on the device */
+                ring[k & 7] = h;
+                __builtin_prefetch(&e->xform, 1, 1);
+            } else
+                ring[k & 7] = NO_REC;                            /* another queue's entity, or a host-class one: its own hook reads the transform */
+        }
+    }
+    __atomic_fetch_add(&xc->pushed, pushed, __ATOMIC_RELAXED);
+}
+
+/* entity3d_update(e, data) / entity3d_reset(e) is about to run e's update on the host: under GPU_SCATTER_DRAWN the
+ * reference's body reads e->parent->mx / ->seq and advances e's own counters (model.c:1609-1616), so both entities are
+ * shown what the device has first; e->seq is noted so that gpu_scene_host_updated() knows how far the host moved it */
+void gpu_scene_host_update_begin(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !e) return;
+    if (e->parent) gpu_scene_fetch(gs, e->parent);
+    gpu_scene_fetch(gs, e);
+    const uint32_t i = rec_find(gs, e);
+    if (i != NO_REC) gs->rec[i].seq_mark = e->seq;
+}
+
 /* entity3d_update(e, data) / entity3d_reset(e) (model.c:1793, 1726; callers outside the frame loop: instantiate_entity
  * model.c:1872, terrain.c:551) ran e's update on the host just now: mx, inverse_mx, aabb, seq, xform.updated are final, as
  * the reference leaves them.  The device's copy of a batched entity is not: it gets the transform with the next update and
@@ -574,7 +689,11 @@ void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e)
     if (i == NO_REC) return;
     struct gs_rec *r = &gs->rec[i];
     if (r->cls != 1 && r->cls != 4) return;                      /* host-class: nothing is mirrored */
+    r->host_bump = (uint16_t)(r->host_bump + (uint16_t)(e->seq - r->seq_mark));   /* gpu_scene_host_update_begin() noted e->seq */
+    r->seq_mark = e->seq;
     r->host_done = 1;
+    /* GPU_SCATTER_DRAWN: the host counted this rebuild itself; the device's must come back to be reconciled with it */
+    if (gs->scatter_drawn && !r->keep && r->handle != CLAPGPU_NO_ENTITY && !clapgpu_scene_entity_keep(gs->scene, r->handle, 1)) r->keep = 1;
     if (!gs->notify || r->pending) return;
     r->pending = 1;
     if (r->order_pos < gs->n_order && gs->vq_ok) gs->vq_ok[r->order_pos] = 0;
@@ -597,24 +716,170 @@ static inline void light_hand_off(struct gpu_scene *gs, entity3d *e)
     light_set_pos(&scene->light, e->light_idx, pos);
 }
 
-static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq)
+/* GPU_SCATTER_DRAWN: rebuilds of `slot` the entity3d has not been shown (0 under GPU_SCATTER_ALL) */
+static inline uint16_t pend_of(const struct gpu_scene *gs, uint32_t slot)
 {
-    entity3d *e = r->e, *parent = e->parent;
-    if (r->host_done) {                                          /* gpu_scene_host_updated(): the host wrote these fields itself */
-        r->host_done = 0;
-        if (!transform_is_updated(&e->xform) && !(parent && e->parent_seq != parent->seq)) return;
-        /* ... but it was touched again since (or its parent moved): an ordinary rebuild */
+    return (gs->any_pend && slot < gs->cap_pend) ? gs->pend[slot] : 0;
+}
+
+/* what r's parent's seq counter WOULD read had the parent been written back every frame (model.c:1613 copies it) */
+static inline uint16_t parent_seq_now(const struct gpu_scene *gs, const struct gs_rec *r, const entity3d *parent)
+{
+    uint16_t seq = parent->seq;
+    if (r->parent_rec != NO_REC) {
+        const struct gs_rec *pr = &gs->rec[r->parent_rec];
+        /* + the rebuilds the parent's entity3d was not shown; - the steps a host update (entity3d_update / _reset) took since
+         * the last frame: the child copied the parent's counter when IT was last rebuilt, and follows a host update of its
+         * parent only in the next frame (model.c:1609-1613) */
+        if (pr->e == parent && (pr->cls == 1 || pr->cls == 4)) seq = (uint16_t)(seq + pend_of(gs, pr->slot) - pr->host_bump);
     }
-    if (parent && parent_seq) e->parent_seq = parent->seq;                     /* model.c:1613 (parents sit in lower slots: already advanced) */
-    if (transform_is_updated(&e->xform)) transform_clear_updated(&e->xform);
-    e->seq++;                                                    /* model.c:1616, 1669 */
+    return seq;
+}
+
+static void copy_rows(struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot)
+{
+    entity3d *e = r->e;
     memcpy(e->mx, res->mx + 16 * slot, sizeof(mat4x4));
     memcpy(e->inverse_mx, res->inverse_mx + 16 * slot, sizeof(mat4x4));
     if (!r->model->skip_aabb) {                                  /* entity3d_aabb_update, model.c:1204-1205 */
         memcpy(e->aabb, res->aabb + 6 * slot, sizeof(e->aabb));
         memcpy(e->aabb_center, res->aabb_center + 3 * slot, sizeof(vec3));
     }
+}
+
+static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq)
+{
+    entity3d *e = r->e, *parent = e->parent;
+    if (r->host_done) {                                          /* gpu_scene_host_updated(): the host wrote these fields itself */
+        const uint8_t hd = r->host_done;                         /* 2: its transform was written again since (the mirror pass saw it) */
+        r->host_done = 0;
+        r->host_bump = 0;                                        /* the device has caught up; children scattered after this one copy e->seq as it is */
+        if (hd == 1 && !transform_is_updated(&e->xform) && !(parent && e->parent_seq != parent_seq_now(gs, r, parent))) return;
+        /* ... but it was touched again since (or its parent moved): an ordinary rebuild */
+    }
+    if (parent && parent_seq) e->parent_seq = parent_seq_now(gs, r, parent);   /* model.c:1613 (parents sit in lower slots: already advanced) */
+    if (transform_is_updated(&e->xform)) transform_clear_updated(&e->xform);
+    e->seq = (uint16_t)(e->seq + 1 + pend_of(gs, (uint32_t)slot));  /* model.c:1616, 1669 (+ the rebuilds it was not shown) */
+    if (gs->any_pend && slot < gs->cap_pend) gs->pend[slot] = 0;
+    copy_rows(r, res, slot);
     light_hand_off(gs, e);
+}
+
+/* GPU_SCATTER_DRAWN: an entity the device rebuilt in earlier frames without telling the host, fetched now (it came into
+ * view, or somebody asked): the rows, and the counters as the reference would have left them -- seq advanced once per
+ * rebuild, parent_seq equal to the parent's (model.c:1613-1616: a child is rebuilt whenever its parent was). */
+static void scatter_fetched(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot)
+{
+    entity3d *e = r->e, *parent = e->parent;
+    const uint16_t k = pend_of(gs, (uint32_t)slot);
+    if (k) {
+        e->seq = (uint16_t)(e->seq + k);
+        gs->pend[slot] = 0;
+        if (parent) e->parent_seq = parent_seq_now(gs, r, parent);
+    }
+    copy_rows(r, res, slot);
+}
+
+/* the rows the mirror's last call fetched (clapgpu_scene_arrays.fetched_mask) into their entity3d */
+static void consume_fetched(struct gpu_scene *gs)
+{
+    clapgpu_scene_arrays res;
+    if (clapgpu_scene_results(gs->scene, &res)) return;
+    gs->res = res;
+    if (!res.n_fetched || res.fetch_serial == gs->fetch_seen) return;   /* nothing new: an earlier fetch's rows may be older than the host's by now */
+    gs->fetch_seen = res.fetch_serial;
+    const uint32_t words = res.n_slots / 64;
+    for (uint32_t w = 0; w < words; w++) {
+        uint64_t m = res.fetched_mask[w];
+        while (m) {
+            const uint32_t slot = w * 64 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uintptr_t u = (uintptr_t)res.slot_user[slot];
+            if (!u) continue;
+            struct gs_rec *r = &gs->rec[u - 1];
+            if (!r->e || (r->cls != 1 && r->cls != 4)) continue;
+            scatter_fetched(gs, r, &res, slot);
+            gs->stats.fetched++;
+        }
+    }
+}
+
+void gpu_scene_set_scatter(struct gpu_scene *gs, int policy)
+{
+    if (!gs) return;
+    const bool drawn = policy == GPU_SCATTER_DRAWN;
+    if (gs->scatter_drawn && !drawn) gpu_scene_fetch_all(gs);    /* back to "everything is always current" */
+    gs->scatter_drawn = drawn;
+}
+
+static inline bool slot_is_stale(const struct gpu_scene *gs, uint32_t slot)
+{
+    return gs->res.n_stale_words && gs->res.stale_mask && slot < gs->res.n_slots && ((gs->res.stale_mask[slot >> 6] >> (slot & 63)) & 1);
+}
+
+bool gpu_scene_entity_is_stale(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !gs->any_pend) return false;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC || (gs->rec[i].cls != 1 && gs->rec[i].cls != 4)) return false;
+    clapgpu_scene_arrays res;
+    if (clapgpu_scene_results(gs->scene, &res)) return false;
+    gs->res = res;
+    return slot_is_stale(gs, gs->rec[i].slot);
+}
+
+int gpu_scene_fetch(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !e) return _CERR_INVALID_ARGUMENTS;
+    if (!gs->any_pend) return 0;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return 0;
+    struct gs_rec *r = &gs->rec[i];
+    if ((r->cls != 1 && r->cls != 4) || r->handle == CLAPGPU_NO_ENTITY) return 0;
+    CK(clapgpu_scene_fetch_entity(gs->scene, r->handle));
+    consume_fetched(gs);
+    return 0;
+}
+
+int gpu_scene_fetch_all(struct gpu_scene *gs)
+{
+    if (!gs) return _CERR_INVALID_ARGUMENTS;
+    if (!gs->any_pend) return 0;
+    uint32_t n = 0;
+    CK(clapgpu_scene_fetch(gs->scene, NULL, &n));
+    consume_fetched(gs);
+    gs->any_pend = false;                                        /* every counter was consumed with its row */
+    if (gs->verify)                                              /* the aid's own check: nothing is owed after a full fetch */
+        for (uint32_t i = 0; i < gs->cap_pend; i++)
+            if (gs->pend[i]) { fprintf(stderr, "gpu_scene: slot %u still owes %u seq steps after gpu_scene_fetch_all\n", i, gs->pend[i]); gs->pend[i] = 0; }
+    return 0;
+}
+
+/* one line about e's record, for a checker's mismatch report */
+void gpu_scene_describe(struct gpu_scene *gs, entity3d *e, char *buf, size_t len)
+{
+    const uint32_t i = gs ? rec_find(gs, e) : NO_REC;
+    if (i == NO_REC) { snprintf(buf, len, "no record"); return; }
+    const struct gs_rec *r = &gs->rec[i];
+    clapgpu_scene_arrays res;
+    const bool have = !clapgpu_scene_results(gs->scene, &res);
+    if (have) gs->res = res;
+    snprintf(buf, len, "class %u slot %u keep %u user_keep %u host_child %u host_done %u pend %u stale %d parent_rec %d order_pos %u",
+             r->cls, r->slot, r->keep, r->user_keep, r->host_child, r->host_done, pend_of(gs, r->slot),
+             have ? (int)slot_is_stale(gs, r->slot) : -1, r->parent_rec == NO_REC ? -1 : (int)r->parent_rec, r->order_pos);
+}
+
+void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep)
+{
+    if (!gs || !e) return;
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return;
+    struct gs_rec *r = &gs->rec[i];
+    r->user_keep = keep;
+    if (keep && !r->keep && r->handle != CLAPGPU_NO_ENTITY && !clapgpu_scene_entity_keep(gs->scene, r->handle, 1)) {
+        r->keep = 1;
+        gpu_scene_fetch(gs, e);                                  /* from now on it is always current: starting now */
+    }
 }
 
 /*
@@ -628,6 +893,7 @@ static inline void prefetch_entity(const entity3d *e);
 struct par_job {
     struct gpu_scene *gs;
     const clapgpu_scene_arrays *res;
+    const uint64_t *scat;       /* which slots' rows came back this frame */
     uint32_t lo, hi;            /* range of touched[] or order[] */
     int phase;
     uint32_t count;             /* out: uploaded / written back */
@@ -790,6 +1056,7 @@ static void *par_mirror(void *arg)
             if (a->e) { __builtin_prefetch(&a->e->xform, 0, 1); __builtin_prefetch(&a->e->flags, 0, 1); }
         }
         r->pending = 0;
+        r->xform_dirty = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
         /* the entity's OWN criteria as the last walk saw them (self_ok): a plain entity that is host-class only because of
@@ -804,6 +1071,8 @@ static void *par_mirror(void *arg)
         r->flags = flags;
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
         r->xform_dirty = transform_is_updated(&e->xform);
+        if (r->host_done && r->xform_dirty) r->host_done = 2;
+        if (gs->drawn_now && r->xform_dirty) transform_clear_updated(&e->xform);
         const int rc = clapgpu_scene_entity_transform_mt(gs->scene, r->handle, transform_pos(&e->xform, NULL),
                                                          transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty || r->host_done);
         if (rc) j->rc = rc;
@@ -826,14 +1095,14 @@ static void *par_scatter(void *arg)
         struct gs_rec *r = &gs->rec[gs->order[k]];
         if (k + 8 < j->hi) {
             const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
-            if (a->cls == 1 && a->slot < res->n_slots && ((res->rebuilt_mask[a->slot >> 6] >> (a->slot & 63)) & 1)) {
+            if (a->cls == 1 && a->slot < res->n_slots && ((j->scat[a->slot >> 6] >> (a->slot & 63)) & 1)) {
                 prefetch_entity(a->e);
                 __builtin_prefetch(res->mx + 16 * (size_t)a->slot, 0, 0);
                 __builtin_prefetch(res->inverse_mx + 16 * (size_t)a->slot, 0, 0);
                 __builtin_prefetch(res->aabb + 6 * (size_t)a->slot, 0, 0);
             }
         }
-        if (r->cls != 1 || r->slot >= res->n_slots || !((res->rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+        if (r->cls != 1 || r->slot >= res->n_slots || !((j->scat[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
         bool here = true;
         if (r->e->parent) {
             const uint32_t pr = r->parent_rec;
@@ -856,10 +1125,35 @@ static void *par_deferred(void *arg)
             __builtin_prefetch(&a->parent_seq, 1, 1);
             __builtin_prefetch(&a->parent->seq, 0, 1);
         }
-        entity3d *c = gs->rec[j->deferred[d]].e;
-        c->parent_seq = c->parent->seq;                          /* model.c:1613: every parent is final by now */
+        const struct gs_rec *cr = &gs->rec[j->deferred[d]];
+        entity3d *c = cr->e;
+        c->parent_seq = parent_seq_now(gs, cr, c->parent);       /* model.c:1613: every parent is final by now */
     }
     return NULL;
+}
+
+/* GPU_SCATTER_DRAWN, after a fast frame's launch: every slot the device rebuilt without writing it back */
+struct pend_ctx { struct gpu_scene *gs; const clapgpu_scene_arrays *res; uint32_t left; };
+static void pend_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct pend_ctx *pc = ctx;
+    struct gpu_scene *gs = pc->gs;
+    const clapgpu_scene_arrays *res = pc->res;
+    uint32_t left = 0;
+    for (uint32_t w = lo; w < hi; w++) {
+        uint64_t m = res->rebuilt_mask[w] & ~res->exported_mask[w];
+        left += (uint32_t)__builtin_popcountll(m);
+        while (m) {
+            const uint32_t slot = w * 64 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            gs->pend[slot]++;
+            if (gs->verify) {                                    /* a read nobody announced must show: poison what went stale */
+                const uintptr_t u = (uintptr_t)res->slot_user[slot];
+                if (u && gs->rec[u - 1].e) gs->rec[u - 1].e->mx[0][0] = __builtin_nanf("");
+            }
+        }
+    }
+    __atomic_fetch_add(&pc->left, left, __ATOMIC_RELAXED);
 }
 
 /*
@@ -874,6 +1168,13 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
     const double t0 = now_ms();
+    clapgpu_scene_set_export(gs->scene, gs->scatter_drawn ? CLAPGPU_SCENE_EXPORT_DRAWN : CLAPGPU_SCENE_EXPORT_ALL);
+    gs->drawn_now = clapgpu_scene_export_is_drawn(gs->scene);
+    if (gs->drawn_now && scene && scene->control != gs->last_control) {
+        /* the control entity is read every frame (camera target, camera.c:191-205; the bounding-volume pick): a standing reader */
+        gs->last_control = scene->control;
+        if (scene->control) gpu_scene_keep(gs, scene->control, true);
+    }
     /* batched characters: the host half of character_update (limbo teleport, motion reset), which may touch them */
     for (uint32_t k = 0; k < gs->n_char; k++) {
         struct gs_rec *r = &gs->rec[gs->char_list[k]];
@@ -889,15 +1190,29 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         int need_walk = 0;
         for (int t = 0; t < nt; t++) { need_walk |= jobs[t].need_walk; st->uploaded += jobs[t].count; if (jobs[t].rc) return jobs[t].rc; }
         clapgpu_scene_mark_all_dirty(gs->scene);
-        if (need_walk) { gs->n_touched = 0; return 1; }
+        if (need_walk) {
+            if (gs->drawn_now)                                   /* the walk decides by xform.updated: give back what this pass cleared */
+                for (uint32_t k = 0; k < gs->n_touched; k++) {
+                    struct gs_rec *r = &gs->rec[gs->touched[k]];
+                    if (r->e && r->xform_dirty) transform_set_updated(&r->e->xform);
+                }
+            gs->n_touched = 0;
+            return 1;
+        }
     } else
     for (uint32_t k = 0; k < gs->n_touched; k++) {
         struct gs_rec *r = &gs->rec[gs->touched[k]];
         r->pending = 0;
+        r->xform_dirty = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
         if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
             ((r->cls == 1 || r->cls == 4) && r->model != e->txmodel->model)) {
+            if (gs->drawn_now)                                   /* the walk decides by xform.updated: give back what this pass cleared */
+                for (uint32_t j = 0; j < k; j++) {
+                    struct gs_rec *q = &gs->rec[gs->touched[j]];
+                    if (q->e && q->xform_dirty) transform_set_updated(&q->e->xform);
+                }
             for (k++; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
             gs->n_touched = 0;
             return 1;
@@ -906,6 +1221,17 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
     }
     gs->n_touched = 0;
+    if (gs->n_xptr) {
+        struct xptr_ctx xc = { .gs = gs, .mt = gs->n_xptr >= GS_PAR_MIN };
+        if (xc.mt) {
+            gpu_scene_par_for(xptr_range, &xc, gs->n_xptr, par_threads());
+            clapgpu_scene_mark_all_dirty(gs->scene);
+        } else
+            xptr_range(&xc, 0, gs->n_xptr);
+        gs->n_xptr = 0;
+        if (xc.rc) return xc.rc;
+        st->uploaded += xc.pushed;
+    }
     if (scene && scene->camera)
         clapgpu_scene_set_bv_points(gs->scene, transform_pos(&scene->camera->xform, NULL),
                                     scene->control ? transform_pos(&scene->control->xform, NULL) : NULL, CLAPGPU_NO_ENTITY);
@@ -933,14 +1259,29 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
      * entity and its rows prefetched a few steps ahead.  Many: in LIST order -- the entity3d structs lie in memory in
      * creation order, a slot-order pass over most of them would miss the caches on every one. */
     const uint32_t words = res.n_slots / 64;
+    /* GPU_SCATTER_DRAWN: the rows that came back are the ones somebody reads (exported_mask); a slot rebuilt without
+     * coming back is owed one more seq step when its entity3d is next written */
+    const uint64_t *scat = res.exported_mask ? res.exported_mask : res.rebuilt_mask;
+    if (gs->drawn_now && res.rebuilt_mask && scat != res.rebuilt_mask) {
+        if (res.n_slots > gs->cap_pend) {
+            uint16_t *pn = realloc(gs->pend, (size_t)res.n_slots * sizeof(*pn));
+            if (!pn) return _CERR_NOMEM;
+            memset(pn + gs->cap_pend, 0, ((size_t)res.n_slots - gs->cap_pend) * sizeof(*pn));
+            gs->pend = pn; gs->cap_pend = res.n_slots;
+        }
+        struct pend_ctx pc = { gs, &res };
+        gpu_scene_par_for(pend_range, &pc, words, words >= 2048 ? par_threads() : 1);
+        st->left_stale = pc.left;
+        if (pc.left) gs->any_pend = true;
+    }
     uint64_t n_rebuilt = 0;
-    if (res.rebuilt_mask)
-        for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(res.rebuilt_mask[w]);
+    if (scat)
+        for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(scat[w]);
     if (n_rebuilt >= 2 * GS_PAR_MIN && par_threads() > 1) {
         const int nt = par_threads();
         struct par_job jobs[8] = { 0 };
         for (int t = 0; t < nt; t++)
-            jobs[t] = (struct par_job){ .gs = gs, .res = &res, .lo = (uint32_t)((uint64_t)gs->n_order * t / nt),
+            jobs[t] = (struct par_job){ .gs = gs, .res = &res, .scat = scat, .lo = (uint32_t)((uint64_t)gs->n_order * t / nt),
                                         .hi = (uint32_t)((uint64_t)gs->n_order * (t + 1) / nt) };
         par_run(par_scatter, jobs, nt);
         par_run(par_deferred, jobs, nt);
@@ -957,14 +1298,14 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
             struct gs_rec *r = &gs->rec[gs->order[k]];
             if (k + 8 < gs->n_order) {
                 const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
-                if (a->cls == 1 && a->slot < res.n_slots && ((res.rebuilt_mask[a->slot >> 6] >> (a->slot & 63)) & 1)) {
+                if (a->cls == 1 && a->slot < res.n_slots && ((scat[a->slot >> 6] >> (a->slot & 63)) & 1)) {
                     prefetch_entity(a->e);
                     __builtin_prefetch(res.mx + 16 * (size_t)a->slot, 0, 0);
                     __builtin_prefetch(res.inverse_mx + 16 * (size_t)a->slot, 0, 0);
                     __builtin_prefetch(res.aabb + 6 * (size_t)a->slot, 0, 0);
                 }
             }
-            if (r->cls != 1 || r->slot >= res.n_slots || !((res.rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+            if (r->cls != 1 || r->slot >= res.n_slots || !((scat[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
             scatter_one(gs, r, &res, r->slot, true);
             st->written_back++;
         }
@@ -973,7 +1314,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
          * steps ahead and, once that has arrived, for the entity four steps ahead */
         uint32_t R = 0;
         for (uint32_t w = 0; w < words; w++) {
-            uint64_t m = res.rebuilt_mask ? res.rebuilt_mask[w] : 0;
+            uint64_t m = scat ? scat[w] : 0;
             while (m) {
                 const uint32_t slot = w * 64 + (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
@@ -996,6 +1337,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
             st->written_back++;
         }
     }
+    consume_fetched(gs);                                         /* came into view (or contain the camera) after frames of being left out */
     const double t3 = now_ms();
     /* host hooks + bounding-volume pick, merged in list order */
     /* candidates come off the mask in slot order; list order is restored through a bitmap over the walk's positions
@@ -1072,8 +1414,14 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         gs->gen++;
         memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
     }
+    /* a walked frame writes everything back, and it may re-tile: whatever GPU_SCATTER_DRAWN left on the device comes over
+     * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's */
+    if (gs->any_pend) CK(gpu_scene_fetch_all(gs));
+    clapgpu_scene_set_export(gs->scene, CLAPGPU_SCENE_EXPORT_ALL);
+    gs->drawn_now = false;
     for (uint32_t k = 0; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
     gs->n_touched = 0;
+    gs->n_xptr = 0;                                              /* the walk reads every transform itself */
     gs->topology_pending = false;
     gs->last_fast = false;
     gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0; gs->n_char = 0;
@@ -1141,6 +1489,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 }
             } else if (!e->parent) {
                 r->cls = 1;
+                r->parent_e = NULL; r->parent_rec = NO_REC;       /* (a detached child: else every later touch reads as "re-parented") */
             } else {
                 /* NO_REC unless already met in THIS walk.  A child that precedes its parent in list order sees the
                  * parent's matrix of the previous frame in the reference (model.c:1911-1922 walks creation order):
@@ -1245,6 +1594,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         entity3d *parent = e->parent;
         const bool rebuilt = parent ? (r->xform_dirty || e->parent_seq != parent->seq) : r->xform_dirty;
         r->host_done = 0;                                        /* the host fields decide here: a host-updated entity is simply not dirty */
+        r->host_bump = 0;
         if (rebuilt) {
             const size_t slot = r->slot;
             if (parent) e->parent_seq = parent->seq;             /* model.c:1613 */
@@ -1277,6 +1627,27 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     for (uint32_t k = 0; k < gs->n_order; k++) {
         const struct gs_rec *r = &gs->rec[gs->order[k]];
         gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
+    }
+    if (gs->notify && ftab_build(gs)) gs->n_xptr = 0;            /* without the table gpu_scene_touch_xform takes the checked path */
+    /* GPU_SCATTER_DRAWN: the standing host readers (gpu-scene.h).  A host-class entity's hook reads its parent's mx / seq
+     * (parent_transform_apply, model.c:1609-1641) -- also when that parent comes later in the list (lag_parent) */
+    if (gs->scatter_drawn && gs->notify) {
+        for (uint32_t k = 0; k < gs->n_order; k++) gs->rec[gs->order[k]].host_child = 0;
+        for (uint32_t k = 0; k < gs->n_order; k++) {
+            const struct gs_rec *r = &gs->rec[gs->order[k]];
+            if ((r->cls != 2 && r->cls != 3) || !r->e->parent) continue;
+            const uint32_t pr = rec_find(gs, r->e->parent);
+            if (pr != NO_REC) gs->rec[pr].host_child = 1;
+        }
+        gs->last_control = scene ? scene->control : NULL;
+        for (uint32_t k = 0; k < gs->n_order; k++) {
+            struct gs_rec *r = &gs->rec[gs->order[k]];
+            if ((r->cls != 1 && r->cls != 4) || r->handle == CLAPGPU_NO_ENTITY) continue;
+            const entity3d *e = r->e;
+            const uint8_t keep = r->user_keep || r->host_child || r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook ||
+                                 entity_animated((entity3d *)e) || (scene && e == scene->control);
+            if (keep != r->keep && !clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
+        }
     }
     /* host-class children that precede their BATCHED parent in the list (see lag_parent above) */
     gs->n_lag = 0;
@@ -1317,6 +1688,7 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
                 if (!clapgpu_scene_cull(gs->scene, &fr)) {
                     memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
                     gs->cull_ok = true;
+                    consume_fetched(gs);                         /* GPU_SCATTER_DRAWN: what the new planes bring into view */
                 }
             }
         }
@@ -1347,6 +1719,9 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
             }
         }
     }
+    /* the reference's test reads e->aabb: under GPU_SCATTER_DRAWN an entity nobody draws (hidden, or asked about out of
+     * turn) may not have been shown its latest box yet */
+    if (gs && gs->any_pend) gpu_scene_fetch(gs, e);
     return view_entity_in_frustum(view, e);
 }
 
@@ -1420,6 +1795,7 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
                 clapgpu_frustum fr;
                 frustum_of(view, &fr);
                 CK(clapgpu_scene_cull(gs->scene, &fr));
+                consume_fetched(gs);                             /* GPU_SCATTER_DRAWN: what the new planes bring into view */
                 memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
                 gs->culled_view = view;
             }
@@ -1438,6 +1814,13 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
      * mode the engine's entity3d_set_lod reports them (gpu-exports.inc.c -> gpu_scene_lod_changed) */
     uint32_t n = 0;
     bool device_ok = true;                                       /* false: no update has run on the device yet -- everything below by the host block */
+    if (!view) {
+        /* A pass without a view draws every ALIVE and VISIBLE entity (model.c:969-970: `view && !view_entity_in_frustum`);
+         * the device's mask answers for the frustum of the last update, not for "no frustum": the reference's own block
+         * for every entity, batched ones included (their mirrored LODs follow below), on current host fields */
+        CK(gpu_scene_fetch_all(gs));
+        device_ok = false;
+    } else
     if (gs->n_batched) {
         const int rc = clapgpu_scene_select_lod(gs->scene, cam_pos, &n);
         if (rc && rc != CLAPGPU_ERR_NOT_SUPPORTED) return rc;
@@ -1462,6 +1845,10 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
         if (!r->e || (device_ok && (r->cls == 1 || r->cls == 4))) continue;
         if (lod_pick_host(view, r->e, cam_pos))
             CK(draw_push(gs, r->e, r->e->cur_lod));
+        if ((r->cls == 1 || r->cls == 4) && r->handle != CLAPGPU_NO_ENTITY && r->e->cur_lod != r->lod_cur &&
+            !clapgpu_scene_entity_lod(gs->scene, r->handle, r->e->force_lod, r->e->cur_lod)) {
+            r->lod_force = r->e->force_lod; r->lod_cur = r->e->cur_lod;   /* the host block picked for a batched entity: the mirror follows */
+        }
     }
     return 0;
 }

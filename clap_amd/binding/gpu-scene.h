@@ -35,6 +35,8 @@ struct gpu_scene_stats {
     unsigned int registered, deleted;
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
     double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
+    unsigned int fetched;       /* GPU_SCATTER_DRAWN: entities brought over after the fact this frame (came into view, asked for) */
+    unsigned int left_stale;    /* GPU_SCATTER_DRAWN: entities the device rebuilt this frame whose entity3d was not written */
     unsigned int device_errors; /* CUMULATIVE, process-wide: calls of the binding that failed on the device and were served by
                                    the engine's host path instead (gpu_scene_device_errors()) */
 };
@@ -94,6 +96,39 @@ void     gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e);
 
 const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 
+/*
+ * Write-back policy (notification mode; a frame that walks the queue writes everything back whatever the policy).
+ *
+ * GPU_SCATTER_ALL (default): after gpu_mq_update() every entity3d the reference would have rebuilt holds the reference's
+ * mx / inverse_mx / aabb / aabb_center / seq / parent_seq, whether anybody reads them or not.
+ *
+ * GPU_SCATTER_DRAWN: a fast frame writes back what is READ -- the draw path reads e->mx / e->inverse_mx of the entities a
+ * pass draws (model.c:1022-1028) and their aabb / aabb_center for the LOD (model.c:975-992); default_update's side
+ * effects read a few more -- and leaves the rest on the device.  Written back when rebuilt:
+ *   - entities that pass the draw predicate of the view the update culls against (all of them without a view),
+ *   - entities whose box contains the camera / control position (the bounding-volume pick reads e->aabb),
+ *   - entities with a standing host reader, found by the walk: batched parents of host-class children (their hooks read
+ *     parent->mx / ->seq), light carriers, the control entity, characters, animated entities, joint riders,
+ *     entities updated on the spot by entity3d_update / _reset, and whatever gpu_scene_keep() names.
+ * An entity left out is STALE: its entity3d keeps older mx / inverse_mx / aabb / aabb_center / seq / parent_seq until
+ *   - it comes into view: the update, gpu_view_entity_in_frustum()'s and gpu_scene_select_lod()'s re-cull fetch it
+ *     before they return (everything a pass draws is current), or
+ *   - somebody asks: gpu_scene_fetch(gs, e) / gpu_scene_fetch_all(gs) (code that reads e->mx of an entity it does not
+ *     draw -- a gameplay query, a debugger -- calls one of them first; the engine-side exports do so for
+ *     entity3d_update / entity3d_reset), or
+ *   - the queue is walked (topology change): everything is fetched first.
+ * After a fetch the entity3d equals the reference's bit for bit, seq counters included.  With the verification aid on
+ * (gpu_scene_set_verify / GPU_SCENE_VERIFY) a stale entity's mx[0][0] is poisoned with a NaN so that a read nobody
+ * announced shows on the screen instead of lagging a frame.  Also: environment GPU_SCENE_SCATTER=drawn at gpu_scene_init.
+ */
+enum { GPU_SCATTER_ALL = 0, GPU_SCATTER_DRAWN = 1 };
+void gpu_scene_set_scatter(struct gpu_scene *gs, int policy);
+int  gpu_scene_fetch(struct gpu_scene *gs, entity3d *e);       /* 0, or a negative cerr_enum value */
+int  gpu_scene_fetch_all(struct gpu_scene *gs);
+void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep);   /* a standing host reader of e exists (takes effect with the next walk or at once) */
+bool gpu_scene_entity_is_stale(struct gpu_scene *gs, entity3d *e);
+void gpu_scene_describe(struct gpu_scene *gs, entity3d *e, char *buf, size_t len);   /* e's record in one line (checkers' reports) */
+
 /* A call of the binding failed (rc != 0) and the caller is about to take the engine's host path instead: counted for the
  * life of the process; the first failure of each `what` is reported on stderr with clapgpu_last_error() (the engine-side
  * exports, gpu-exports.inc.c, also put it through the engine's err()).  A dead device must not look like a slow frame. */
@@ -111,7 +146,12 @@ unsigned gpu_scene_device_errors(void);
 void gpu_scene_set_notify(struct gpu_scene *gs, bool on);
 bool gpu_scene_last_was_fast(const struct gpu_scene *gs);      /* the last gpu_mq_update() did not walk the queue */
 void gpu_scene_touch(struct gpu_scene *gs, entity3d *e);
-/* entity3d_update(e, data) / entity3d_reset(e) ran e's update on the host, outside the frame loop (gpu-exports.inc.c) */
+/* ... its transform alone (what entity3d_position / _move / _rotate / _scale change): O(1), no look-up -- the address is
+ * queued and resolved by the frame's mirror pass.  A write to e->flags is reported with gpu_scene_touch(). */
+void gpu_scene_touch_xform(struct gpu_scene *gs, entity3d *e);
+/* entity3d_update(e, data) / entity3d_reset(e) run e's update on the host, outside the frame loop (gpu-exports.inc.c):
+ * _begin before the reference's body (shows e and its parent what the device has, notes e->seq), _updated after it */
+void gpu_scene_host_update_begin(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_topology(struct gpu_scene *gs);
 /*

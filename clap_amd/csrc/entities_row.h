@@ -87,6 +87,11 @@ struct HostIO {
     float          *o_mx, *o_inv, *o_aabb, *o_center;    // device-mapped host result arrays
     uint64_t       *o_vis, *o_rebuilt, *o_inside;
     uint32_t       *counter, *done, done_value;
+    // Export policy (clapgpu_entities_hostio.keep_mask): NULL = every rebuilt row goes to the host; else only the rebuilt
+    // rows somebody reads this frame -- drawn (vis_mask), containing a bounding-volume point, or flagged in keep[] --
+    // and o_exported says which those were.
+    const uint64_t *keep;
+    uint64_t       *o_exported;
 };
 
 // load_row with the touched lanes' (flags, TRS) taken from the host image instead
@@ -165,6 +170,13 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
 {
     const bool in_range = (uint32_t)lane < row_count;
     const uint32_t i = row_first + (in_range ? lane : 0);
+    // HOST: which of this row's rebuilt lanes the mirror wants back (asked for now, used after the cull)
+    uint64_t host_want = ~0ull;
+    bool host_filter = false;
+    if constexpr (HOST) {
+        host_filter = hio->keep != nullptr;
+        host_want = host_filter ? hio->keep[row_first >> 6] : ~0ull;
+    }
 
     const uint32_t fl = in.fl;
     const bool alive = in_range && (fl & CLAPGPU_E_ALIVE);
@@ -313,25 +325,6 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
         for (int k = 0; k < 3; k++) e.center[3 * (size_t)i + k] = ctr[k];
     }
 
-    if constexpr (HOST) {                                        // the mirror's copy of what this row rebuilt, and which lanes those are
-        if (rebuild) {
-            float4 *hm = reinterpret_cast<float4 *>(hio->o_mx + 16 * (size_t)i);
-            float4 *hi = reinterpret_cast<float4 *>(hio->o_inv + 16 * (size_t)i);
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                hm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
-                hi[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
-            }
-            if (has_aabb) {
-                float2 *hb = reinterpret_cast<float2 *>(hio->o_aabb + 6 * (size_t)i);
-                hb[0] = make_float2(bb[0], bb[1]); hb[1] = make_float2(bb[2], bb[3]); hb[2] = make_float2(bb[4], bb[5]);
-                float *hc = hio->o_center + 3 * (size_t)i;
-                hc[0] = ctr[0]; hc[1] = ctr[1]; hc[2] = ctr[2];
-            }
-        }
-        if (lane == 0) hio->o_rebuilt[row_first >> 6] = rebuilt_mask;
-    }
-
     const bool want_bv = e.bv_on != 0;
     if (CULL || want_bv) {
         // Entities that were not rebuilt (or whose model skips AABBs) use their stored box.
@@ -352,7 +345,10 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
             inside = false;
         const uint64_t inside_mask = __ballot(inside);
         if (e.bv_inside && lane == 0) e.bv_inside[e0 >> 6] = inside_mask;
-        if constexpr (HOST) { if (hio->o_inside && lane == 0) hio->o_inside[e0 >> 6] = inside_mask; }
+        if constexpr (HOST) {
+            if (hio->o_inside && lane == 0) hio->o_inside[e0 >> 6] = inside_mask;
+            host_want |= inside_mask;                            // default_update's pick reads the box on the host
+        }
         if (inside_mask) {                                       // rare: almost no box contains the camera
             unsigned long long key = 0;
             if (inside) {
@@ -380,6 +376,32 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
             e.vis_mask[e0 >> 6] = m;
             e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);       // feeds the single-launch compaction
             if constexpr (HOST) hio->o_vis[e0 >> 6] = m;
+        }
+        if constexpr (HOST) host_want |= m;                      // what the render passes draw
+    } else {
+        if constexpr (HOST) host_want = ~0ull;                   // no frustum: a pass without a camera draws everything (model.c:969)
+    }
+
+    if constexpr (HOST) {                                        // the mirror's copy of what this row rebuilt, and which lanes those are
+        const uint64_t exported = host_filter ? (rebuilt_mask & host_want) : rebuilt_mask;
+        if (rebuild && ((exported >> lane) & 1ull)) {
+            float4 *hm = reinterpret_cast<float4 *>(hio->o_mx + 16 * (size_t)i);
+            float4 *hi = reinterpret_cast<float4 *>(hio->o_inv + 16 * (size_t)i);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                hm[c] = make_float4(mx[4 * c], mx[4 * c + 1], mx[4 * c + 2], mx[4 * c + 3]);
+                hi[c] = make_float4(inv[4 * c], inv[4 * c + 1], inv[4 * c + 2], inv[4 * c + 3]);
+            }
+            if (has_aabb) {
+                float2 *hb = reinterpret_cast<float2 *>(hio->o_aabb + 6 * (size_t)i);
+                hb[0] = make_float2(bb[0], bb[1]); hb[1] = make_float2(bb[2], bb[3]); hb[2] = make_float2(bb[4], bb[5]);
+                float *hc = hio->o_center + 3 * (size_t)i;
+                hc[0] = ctr[0]; hc[1] = ctr[1]; hc[2] = ctr[2];
+            }
+        }
+        if (lane == 0) {
+            hio->o_rebuilt[row_first >> 6] = rebuilt_mask;
+            if (hio->o_exported) hio->o_exported[row_first >> 6] = exported;
         }
     }
 }

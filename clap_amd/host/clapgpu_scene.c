@@ -26,6 +26,7 @@ struct ent {
     uint32_t slot;
     void    *user;
     uint8_t  live, dirty, attached;   /* attached: rides a joint of its parent (e->parent_joint, model.c:1626-1641) */
+    uint8_t  keep;                    /* clapgpu_scene_entity_keep: a standing host reader, exported whenever rebuilt */
     int32_t  force_lod, cur_lod;      /* entity3d.force_lod / .cur_lod (model.h:415-416; entity3d_set_lod, model.c:593-609) */
 };
 
@@ -83,6 +84,14 @@ struct clapgpu_scene {
     void       *h_att, *d_att; size_t att_bytes; uint32_t cap_att; int att_mapped;
     float      *d_att_local;
     clapgpu_frustum last_frustum; int have_frustum;
+    /* export policy (clapgpu_scene_set_export): with EXPORT_DRAWN a one-launch frame writes back only the rebuilt rows
+     * somebody reads (drawn, containing a bounding-volume point, kept); the others go stale in h_out -- the device arrays
+     * hold them -- and are fetched when they come into view or when asked for (clapgpu_scene_fetch) */
+    int         export_drawn;
+    uint64_t   *h_keep, *d_keep; int keep_dirty;                       /* slot order; the device copy follows before a launch */
+    uint64_t   *h_exported;                                            /* mapped, behind the three masks of h_out */
+    uint64_t   *h_stale, *h_fetched; uint32_t n_stale_words, n_fetched, fetch_serial; /* plain host memory, cap_slots / 64 + 2 words */
+    uint64_t   *h_select; void *d_select;                              /* mapped: the rows a fetch asks for */
 
     /* device */
     clapgpu_entities d;
@@ -145,7 +154,7 @@ static void mark_dirty(clapgpu_scene *s, uint32_t h, int xform_updated)
 }
 
 /* the mapped side of a one-launch small frame: the image (and its touched bits) in, the result slab and the word out */
-static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with_inputs)
+static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with_inputs, int filtered)
 {
     const size_t cn = s->cap_slots;
     const char *mi = s->d_in_host;
@@ -157,7 +166,57 @@ static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with
     io->center = (float *)(mo + cn * 152); io->vis_mask = (uint64_t *)(mo + cn * 164);
     io->rebuilt_mask = io->vis_mask + (cn / 64 + 2);
     io->inside_mask = s->bv_on ? io->rebuilt_mask + (cn / 64 + 2) : NULL;
+    io->exported_mask = io->rebuilt_mask + 2 * (cn / 64 + 2);
+    io->keep_mask = filtered ? s->d_keep : NULL;
     io->counter = s->d_counter; io->done = s->d_done; io->done_value = ++s->frame_id;
+}
+
+/* After a one-launch frame: rows the launch rebuilt but did not write back are stale in h_out, rows it wrote are fresh. */
+static void stale_after_launch(clapgpu_scene *s)
+{
+    const size_t words = s->n_slots / 64;
+    uint32_t nz = 0;
+    for (size_t w = 0; w < words; w++) {
+        const uint64_t st = (s->h_stale[w] | s->h_rebuilt[w]) & ~s->h_exported[w];
+        s->h_stale[w] = st;
+        nz += st != 0;
+    }
+    s->n_stale_words = nz;
+}
+
+/* rows = stale & want (NULL: every stale row): over from the device arrays into h_out, named in h_fetched */
+static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, const uint64_t *w2)
+{
+    const size_t words = s->n_slots / 64;
+    /* fetched_mask names the rows of THIS call only: a caller copies them out once (fetch_serial says whether there is
+     * anything new); rows of an earlier call may since have been superseded on the host */
+    if (s->n_fetched) { memset(s->h_fetched, 0, words * 8); s->n_fetched = 0; }
+    if (!s->n_stale_words || !s->h_select) return CLAPGPU_OK;
+    uint32_t cnt = 0;
+    for (size_t w = 0; w < words; w++) {
+        uint64_t sel = s->h_stale[w];
+        if (sel && (w0 || w1 || w2)) sel &= (w0 ? w0[w] : 0) | (w1 ? w1[w] : 0) | (w2 ? w2[w] : 0);
+        s->h_select[w] = sel;
+        cnt += (uint32_t)__builtin_popcountll(sel);
+    }
+    if (!cnt) return CLAPGPU_OK;
+    char *mo = s->d_out_host;
+    const size_t cn = s->cap_slots;
+    clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cn * 64), .aabb = (float *)(mo + cn * 128),
+                                  .center = (float *)(mo + cn * 152) };
+    x.counter = s->d_counter; x.done = s->d_done; x.done_value = ++s->frame_id;
+    CK(clapgpu_entities_export_rows(NULL, &s->d, &x, s->d_select));
+    CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+    uint32_t nz = 0;
+    for (size_t w = 0; w < words; w++) {
+        s->h_fetched[w] = s->h_select[w];
+        s->h_stale[w] &= ~s->h_select[w];
+        nz += s->h_stale[w] != 0;
+    }
+    s->n_stale_words = nz;
+    s->n_fetched = cnt;
+    s->fetch_serial++;
+    return CLAPGPU_OK;
 }
 
 int clapgpu_scene_create(clapgpu_scene **out, int device)
@@ -227,6 +286,9 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->h_att) clapgpu_host_free(s->h_att);
     if (s->d_att && !s->att_mapped) clapgpu_free(s->d_att);
     if (s->d_att_local) clapgpu_free(s->d_att_local);
+    if (s->d_keep) clapgpu_free(s->d_keep);
+    if (s->h_select) clapgpu_host_free(s->h_select);
+    free(s->h_keep); free(s->h_stale); free(s->h_fetched);
     free(s);
 }
 
@@ -385,6 +447,28 @@ int clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const f
     return CLAPGPU_OK;
 }
 
+/* The transform alone (entity3d_position / _move / _rotate / _scale leave the flags as they are), same threading rules;
+ * xform_updated is OR-ed in, so pushing an entity twice in a frame -- the second time with its flag already taken -- is
+ * harmless.  Finish with clapgpu_scene_mark_all_dirty(). */
+int clapgpu_scene_entity_xform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float q[4], float scale, int xform_updated)
+{
+    struct ent *e = get(s, handle);
+    if (!e || !pos || !q) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    memcpy(e->pos_scale, pos, 12);
+    e->pos_scale[3] = scale;
+    memcpy(e->rot, q, 16);
+    if (!s->topology_dirty && s->h_in && e->slot < s->n_slots) {
+        memcpy(s->h_pos_scale + 4 * (size_t)e->slot, e->pos_scale, 16);
+        memcpy(s->h_rot + 4 * (size_t)e->slot, e->rot, 16);
+        if (xform_updated) s->h_flags[e->slot] |= CLAPGPU_E_DIRTY;
+        if (s->zero_copy && s->tiled)
+            __atomic_fetch_or(&s->h_touched[e->slot >> 6], 1ull << (e->slot & 63), __ATOMIC_RELAXED);
+    } else if (xform_updated) {
+        e->dirty |= 3;                                   /* picked up by the re-tile's full image */
+    }
+    return CLAPGPU_OK;
+}
+
 void clapgpu_scene_mark_all_dirty(clapgpu_scene *s) { if (s) s->bulk_dirty = 1; }
 
 int clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float q[4])
@@ -482,7 +566,7 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
     s->have_results = 0;
     s->in_bytes = n * 36 + (n / 64 + 2) * 8;                 /* + the touched-slot bits */
-    s->out_bytes = n * 164 + 3 * (n / 64 + 2) * 8;           /* + visibility, rebuilt and bounding-volume masks */
+    s->out_bytes = n * 164 + 4 * (n / 64 + 2) * 8;           /* + visibility, rebuilt, bounding-volume and exported masks */
     s->zero_copy = cap <= s->zero_copy_max_slots;
     if (s->zero_copy) CK(clapgpu_host_malloc_mapped(&s->h_in, &s->d_in_host, s->in_bytes));
     else CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
@@ -514,6 +598,19 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     s->h_mask = (uint64_t *)(ho + n * 164);    s->d.vis_mask = (uint64_t *)(dq + n * 164);
     s->h_rebuilt = s->h_mask + (n / 64 + 2);   s->d.rebuilt_mask = s->d.vis_mask + (n / 64 + 2);
     s->h_inside = s->h_rebuilt + (n / 64 + 2); s->bvq.inside_mask = s->d.rebuilt_mask + (n / 64 + 2);
+    s->h_exported = s->h_inside + (n / 64 + 2);
+    {
+        const size_t mw = n / 64 + 2;
+        if (s->d_keep) clapgpu_free(s->d_keep);
+        if (s->h_select) clapgpu_host_free(s->h_select);
+        s->d_keep = NULL; s->h_select = NULL; s->d_select = NULL;
+        free(s->h_keep); free(s->h_stale); free(s->h_fetched);
+        s->h_keep = calloc(mw, 8); s->h_stale = calloc(mw, 8); s->h_fetched = calloc(mw, 8);
+        if (!s->h_keep || !s->h_stale || !s->h_fetched) return CLAPGPU_ERR_NOMEM;
+        CK(clapgpu_malloc((void **)&s->d_keep, mw * 8));
+        if (s->zero_copy) CK(clapgpu_host_malloc_mapped((void **)&s->h_select, &s->d_select, mw * 8));
+        s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;
+    }
     void **dp[] = { (void **)&s->d.parent, (void **)&s->d.model, (void **)&s->d.seqs, (void **)&s->d.vis_row_pop,
                     (void **)&s->d_tile_row_start };
     size_t sz[] = { n * 4, n * 4, n * 4, (n / 64 + 16) / 16 * 16, (n / 64 + 2) * 4 };
@@ -642,10 +739,17 @@ static int retile(clapgpu_scene *s)
         }
         s->slot_handle[s->e[h].slot] = h;
     }
+    /* the slots moved: what was stale under the old layout is rebuilt (and exported or marked stale again) by the launch
+     * that follows; the standing readers' bits are laid out anew */
+    memset(s->h_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
+    memset(s->h_fetched, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
+    memset(s->h_keep, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
+    s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;
     /* full staging image */
     for (uint32_t i = 0; i < s->n_slots; i++) {
         const uint32_t h = s->slot_handle[i];
         s->slot_user[i] = h == CLAPGPU_NO_ENTITY ? NULL : s->e[h].user;
+        if (h != CLAPGPU_NO_ENTITY && s->e[h].keep) s->h_keep[i >> 6] |= 1ull << (i & 63);
         if (h == CLAPGPU_NO_ENTITY) {
             const float id[4] = { 0, 0, 0, 1 };
             memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
@@ -780,10 +884,16 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
     if (fused) {
         clapgpu_entities_hostio io;
-        scene_hostio(s, &io, by_bits);
+        if (s->keep_dirty && s->export_drawn) {
+            CK(clapgpu_memcpy_h2d(s->d_keep, s->h_keep, (n / 64) * 8, NULL));
+            CK(clapgpu_stream_sync(NULL));                 /* h_keep is pageable and may change right after this call */
+            s->keep_dirty = 0;
+        }
+        scene_hostio(s, &io, by_bits, s->export_drawn);
         CK(clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum, &io));
         const double tt2 = scene_now_us();
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (s->export_drawn || s->n_stale_words) stale_after_launch(s);
         if (getenv("CLAPGPU_SCENE_TIMING"))
             fprintf(stderr, "scene small frame: %u inputs by %s, one launch %.1f us, wait %.1f us\n", n_touched,
                     by_bits ? "touched bits" : upload ? "copy" : "none", tt2 - tt0, scene_now_us() - tt2);
@@ -828,6 +938,12 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     if (!frustum)
         memset(s->h_mask, 0, mask_words * 8);
     if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
+    /* EXPORT_DRAWN: whoever is read this frame and was left stale by an earlier one -- an entity that came into view, a
+     * box that now contains the camera, a reader registered since -- comes over now */
+    if (fused) {
+        if (frustum) CK(fetch_rows(s, s->h_mask, s->bv_on ? s->h_inside : NULL, s->h_keep));
+        else CK(fetch_rows(s, NULL, NULL, NULL));      /* a pass without a camera draws everything (model.c:969) */
+    }
     if (full || 4 * (size_t)n_touched > n)
         for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */
     else
@@ -909,7 +1025,7 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
     int rc;
     if (fused) {
         clapgpu_entities_hostio io;
-        scene_hostio(s, &io, 0);
+        scene_hostio(s, &io, 0, 0);                   /* the few attached subtrees: every rebuilt row comes back */
         rc = clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr, &io);
     } else
         rc = s->tiled ? clapgpu_entities_update_tiles(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, fr)
@@ -919,6 +1035,7 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
     const size_t nn = s->n_slots, cap = s->cap_slots, mask_words = nn / 64, mask_stride = cap / 64 + 2;
     if (fused) {
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (s->n_stale_words) stale_after_launch(s);
     } else if (s->zero_copy) {
         char *mo = s->d_out_host;
         clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cap * 64), .aabb = (float *)(mo + cap * 128),
@@ -950,8 +1067,10 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
 }
 
 /* ---------------------------------------------------------------- results */
+/* under EXPORT_DRAWN a row nobody has read since it was rebuilt is fetched by the first accessor that asks for it */
 #define RESULT(field, stride)                                                        \
     const struct ent *e = get(s, handle);                                            \
+    if (e && s->n_stale_words && clapgpu_scene_fetch_entity((clapgpu_scene *)s, handle)) return NULL; \
     return (e && s->have_results && e->slot < s->n_slots) ? s->field + (stride) * (size_t)e->slot : NULL
 
 const float *clapgpu_scene_entity_mx(const clapgpu_scene *s, uint32_t handle)          { RESULT(h_mx, 16); }
@@ -1001,7 +1120,57 @@ int clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out)
     out->mx = s->h_mx; out->inverse_mx = s->h_inv; out->aabb = s->h_aabb; out->aabb_center = s->h_center;
     out->vis_mask = s->h_mask; out->rebuilt_mask = s->h_rebuilt; out->inside_mask = s->h_inside;
     out->slot_user = (void *const *)s->slot_user;
+    out->exported_mask = (s->zero_copy && s->tiled) ? s->h_exported : s->h_rebuilt;
+    out->stale_mask = s->h_stale; out->fetched_mask = s->h_fetched;
+    out->n_stale_words = s->n_stale_words; out->n_fetched = s->n_fetched; out->fetch_serial = s->fetch_serial;
     return CLAPGPU_OK;
+}
+
+void clapgpu_scene_set_export(clapgpu_scene *s, int policy)
+{
+    if (s) s->export_drawn = policy == CLAPGPU_SCENE_EXPORT_DRAWN;
+}
+
+int clapgpu_scene_export_is_drawn(const clapgpu_scene *s) { return s && s->export_drawn && s->zero_copy && s->tiled; }
+
+int clapgpu_scene_entity_keep(clapgpu_scene *s, uint32_t handle, int keep)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (e->keep == (keep ? 1 : 0)) return CLAPGPU_OK;
+    e->keep = keep ? 1 : 0;
+    if (!s->topology_dirty && s->h_keep && e->slot < s->n_slots) {   /* else the re-tile lays the bits out */
+        if (keep) s->h_keep[e->slot >> 6] |= 1ull << (e->slot & 63);
+        else s->h_keep[e->slot >> 6] &= ~(1ull << (e->slot & 63));
+        s->keep_dirty = 1;
+    }
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_fetch(clapgpu_scene *s, const uint64_t *want, uint32_t *n_rows)
+{
+    if (!s) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (n_rows) *n_rows = 0;
+    if (!s->have_results || s->topology_dirty) return s->n_stale_words ? CLAPGPU_ERR_NOT_SUPPORTED : CLAPGPU_OK;
+    CK(fetch_rows(s, want, NULL, NULL));
+    if (n_rows) *n_rows = s->n_fetched;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_fetch_entity(clapgpu_scene *s, uint32_t handle)
+{
+    const struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!s->n_stale_words || e->slot >= s->n_slots || !((s->h_stale[e->slot >> 6] >> (e->slot & 63)) & 1)) return CLAPGPU_OK;
+    if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;
+    /* one row: a one-bit `want` (n / 64 words, zeroed) beside a device round trip */
+    const size_t words = s->n_slots / 64;
+    uint64_t *want = calloc(words ? words : 1, 8);
+    if (!want) return CLAPGPU_ERR_NOMEM;
+    want[e->slot >> 6] = 1ull << (e->slot & 63);
+    const int rc = fetch_rows(s, want, NULL, NULL);
+    free(want);
+    return rc;
 }
 
 /* view_entity_in_frustum for a frustum other than the one of the last mq_update (the engine recomputes its frusta in
@@ -1013,6 +1182,7 @@ int clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum)
     CK(clapgpu_entities_cull(NULL, &s->d, frustum));
     CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, ((size_t)s->n_slots / 64) * 8, NULL));
     CK(clapgpu_stream_sync(NULL));
+    CK(fetch_rows(s, s->h_mask, NULL, NULL));         /* EXPORT_DRAWN: what this view draws and an earlier frame left stale */
     return CLAPGPU_OK;
 }
 

@@ -254,6 +254,14 @@ typedef struct clapgpu_entities_export {
 } clapgpu_entities_export;
 int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list, uint32_t n_list);
 int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x);
+/*
+ * The rows a mirror asks for after the fact (a mirror that takes back only what is drawn, clapgpu_entities_hostio.keep_mask,
+ * fetches the rest on demand: an entity that comes into view, entity3d_update() on a hidden one, ...): copies the rows of
+ * mx / inv_mx / aabb / center flagged in select_mask (e->n / 64 words, device-readable: device memory or a mapped host
+ * alias) into x's mapped arrays and raises *x->done = x->done_value.  x's three mask pointers are not used.
+ */
+int clapgpu_entities_export_rows(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x,
+                                 const uint64_t *select_mask);
 
 /*
  * The same small frame as ONE launch, for the tile layout: clapgpu_entities_update_tiles() that takes the inputs of the
@@ -273,6 +281,16 @@ typedef struct clapgpu_entities_hostio {
     uint32_t *counter;                                     /* device scratch: one zeroed uint32 */
     uint32_t *done;                                        /* device-mapped host word */
     uint32_t  done_value, pad;
+    /* Export policy.  keep_mask == NULL: every rebuilt row is written to the mapped result arrays (what _models_render and
+     * every other reader of e->mx / e->inverse_mx / e->aabb finds in the reference after mq_update, model.c:1022-1028,
+     * 975-998).  keep_mask != NULL (device-readable, e->n / 64 words): only the rebuilt rows a reader exists for THIS
+     * frame -- entities that pass the draw predicate (vis_mask; all of them without a frustum), entities whose box contains
+     * a bounding-volume point (inside_mask), entities flagged in keep_mask (the mirror's standing readers: parents of
+     * host-updated children, light carriers, the control entity ...).  The device arrays hold every row either way;
+     * clapgpu_entities_export_rows() brings any of them over later.  exported_mask (mapped, may be NULL): bit i = row i was
+     * written by this launch. */
+    const uint64_t *keep_mask;
+    uint64_t       *exported_mask;
 } clapgpu_entities_hostio;
 int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e, const uint32_t *tile_row_start,
                                          uint32_t n_tiles, uint32_t mode, const clapgpu_frustum *frustum,

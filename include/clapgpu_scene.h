@@ -62,6 +62,8 @@ int  clapgpu_scene_entity_transform(clapgpu_scene *s, uint32_t handle, const flo
  * creation / deletion / re-parenting meanwhile); finish with clapgpu_scene_mark_all_dirty() */
 int  clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float quat_xyzw[4],
                                        float scale, uint32_t flags, int xform_updated);
+int  clapgpu_scene_entity_xform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float quat_xyzw[4],
+                                   float scale, int xform_updated);   /* the transform alone; xform_updated is OR-ed in */
 void clapgpu_scene_mark_all_dirty(clapgpu_scene *s);
 /* entity3d_move / entity3d_rotate (radians) / entity3d_visible (model.c:1810-1842) */
 int  clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3]);
@@ -115,9 +117,39 @@ typedef struct clapgpu_scene_arrays {
                                        all a binding has to copy back.  Parents sit in lower slots than their children. */
     const uint64_t *inside_mask;    /* same indexing: the slot's box contains a bounding-volume point (clapgpu_scene_set_bv_points) */
     void *const    *slot_user;      /* [n_slots] the `user` pointer given to clapgpu_scene_entity_new, NULL for padding slots */
+    /* export policy (clapgpu_scene_set_export), same indexing; without EXPORT_DRAWN exported == rebuilt, nothing is stale */
+    const uint64_t *exported_mask;  /* the rows of the arrays above the last mq_update / attached_update wrote */
+    const uint64_t *stale_mask;     /* rows rebuilt on the device since they were last written here: the arrays hold older values */
+    const uint64_t *fetched_mask;   /* rows the last mq_update / cull / fetch brought over because somebody reads them now */
+    uint32_t        n_stale_words, n_fetched;   /* non-zero words of stale_mask; rows in fetched_mask */
+    uint32_t        fetch_serial;   /* advances with every call that fetched something: fetched_mask is to be copied out once per value */
 } clapgpu_scene_arrays;
 int          clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out);
 uint32_t     clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle);
+
+/*
+ * Export policy: which rebuilt rows a frame writes back to the host.  The draw path reads e->mx / e->inverse_mx of what it
+ * DRAWS (model.c:1022-1028) and the LOD block e->aabb / e->aabb_center of the same entities (model.c:975-992); at a million
+ * entities writing back every rebuilt row -- 164 bytes over PCIe and a scatter into a 448-byte entity3d each -- costs two
+ * hundred times the kernel.  CLAPGPU_SCENE_EXPORT_DRAWN (one-launch frames only: zero-copy + tile layout; otherwise the
+ * call is remembered and has no effect) writes back the rebuilt rows of
+ *   - entities that pass the draw predicate against the frustum of this mq_update (all of them when it has none),
+ *   - entities whose box contains a bounding-volume point (clapgpu_scene_set_bv_points),
+ *   - entities with a standing host reader (clapgpu_scene_entity_keep),
+ * marks the other rebuilt rows STALE (stale_mask) and, in the same call, fetches every row that is read now and was left
+ * stale earlier (an entity that came into view): after clapgpu_scene_mq_update() and after clapgpu_scene_cull() every
+ * drawn, containing or kept entity's rows are current; exported_mask | fetched_mask names the rows that changed.
+ * clapgpu_scene_fetch(want) brings over the stale rows flagged in `want` (n_slots / 64 words; NULL: all of them) and
+ * leaves them in fetched_mask; clapgpu_scene_fetch_entity() one entity's; the per-entity accessors above fetch by
+ * themselves.  The default is CLAPGPU_SCENE_EXPORT_ALL: nothing changes unless asked for.
+ */
+#define CLAPGPU_SCENE_EXPORT_ALL   0
+#define CLAPGPU_SCENE_EXPORT_DRAWN 1
+void         clapgpu_scene_set_export(clapgpu_scene *s, int policy);
+int          clapgpu_scene_export_is_drawn(const clapgpu_scene *s);     /* the policy is DRAWN and the layout supports it */
+int          clapgpu_scene_entity_keep(clapgpu_scene *s, uint32_t handle, int keep);
+int          clapgpu_scene_fetch(clapgpu_scene *s, const uint64_t *want, uint32_t *n_rows);
+int          clapgpu_scene_fetch_entity(clapgpu_scene *s, uint32_t handle);
 
 /*
  * default_update's camera bounding-volume pick (model.c:1703-1713): the points to test every entity's box against in

@@ -201,6 +201,8 @@ static uint32_t n_ids, cap_ids;
  * (model.c:1911-1922): the binding has to reproduce that too. */
 static bool parents_first;                 /* bench: every parent also precedes its children in the queue */
 static bool opt_notify;                    /* the engine reports what it touches (gpu_scene_touch / _topology): O(dirty) frames */
+static bool opt_drawn;                     /* GPU_SCATTER_DRAWN: fast frames write back what is read; the rest is fetched on demand */
+static uint64_t n_stale_seen, n_partial_frames;
 static bool may_parent(uint32_t p, uint32_t c)
 {
     if (parents_first)
@@ -254,11 +256,15 @@ static uint32_t pick_alive(void)
 }
 
 static uint64_t n_host_updates;            /* entity3d_update / entity3d_reset calls between frames */
+static bool opt_steady, no_topology;       /* `steady`: three frames out of four only move / turn / scale / hide entities -- frames
+                                              a notified binding runs without walking the queue, where GPU_SCATTER_DRAWN lives */
 static void game_frame(uint32_t n_ops)
 {
     for (uint32_t k = 0; k < n_ops; k++) {
-        const uint32_t what = rndn(1000), id = pick_alive();
+        uint32_t what = rndn(1000);
+        const uint32_t id = pick_alive();
         if (id == NONE) continue;
+        if (no_topology && what >= 920) what = what % 920;
         if (what < 600) {
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
             ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
@@ -305,12 +311,34 @@ static void game_frame(uint32_t n_ops)
     }
 }
 
+/* Under GPU_SCATTER_DRAWN (`drawn`) three frames out of four compare only what the reference's render pass would READ
+ * -- ALIVE, VISIBLE and SKIP_CULLING or in the frustum (model.c:959-973) -- as the binding left it, WITHOUT a fetch: that
+ * is the policy's promise; what it left stale is counted.  Every fourth frame (and the last) everything is fetched
+ * first and every entity compared, seq counters included: what was left out for several frames must catch up exactly. */
+static uint64_t compare_frame_ex(struct gpu_scene *gs, uint32_t frame, uint64_t *n_visible, bool full);
 static uint64_t compare_frame(struct gpu_scene *gs, uint32_t frame, uint64_t *n_visible)
 {
+    return compare_frame_ex(gs, frame, n_visible, !opt_drawn || frame % 4 == 3);
+}
+
+static uint64_t compare_frame_ex(struct gpu_scene *gs, uint32_t frame, uint64_t *n_visible, bool full)
+{
     uint64_t bad = 0;
+    if (opt_drawn && full) {
+        const int rc = gpu_scene_fetch_all(gs);
+        if (rc) { fprintf(stderr, "frame %u: gpu_scene_fetch_all: %d (%s)\n", frame, rc, clapgpu_last_error()); bad++; }
+    }
+    n_partial_frames += !full;
     for (uint32_t id = 0; id < n_ids; id++) {
         if (!meta[id].alive) continue;
         entity3d *a = A.e[id], *b = B.e[id];
+        if (!full) {
+            const bool drawn = entity3d_matches(a, ENTITY3D_VISIBLE) &&
+                               (entity3d_matches(a, ENTITY3D_SKIP_CULLING) || ref_view_entity_in_frustum(&A.view, a));
+            if (!drawn) { n_stale_seen += gpu_scene_entity_is_stale(gs, b); continue; }
+            if (gpu_scene_entity_is_stale(gs, b) && bad++ < 8)
+                fprintf(stderr, "frame %u entity %u: drawn by the reference but left stale by the binding\n", frame, id);
+        }
         const bool va = ref_view_entity_in_frustum(&A.view, a), vb = view_entity_in_frustum(&B.view, b);
         int diff = 0;
         diff |= !!memcmp(a->mx, b->mx, sizeof(mat4x4)) << 0;
@@ -322,9 +350,14 @@ static uint64_t compare_frame(struct gpu_scene *gs, uint32_t frame, uint64_t *n_
         diff |= (va != vb) << 6;
         diff |= !!memcmp(&a->xform, &b->xform, sizeof(transform_t)) << 7;
         *n_visible += va;
-        if (diff && bad++ < 8)
-            fprintf(stderr, "frame %u entity %u (model %u parent %d hooked %u): mismatch mask 0x%02x\n",
-                    frame, id, meta[id].model, (int)meta[id].parent, meta[id].hooked, diff);
+        if (diff && bad++ < 8) {
+            char what[256], whatp[256] = "";
+            gpu_scene_describe(gs, b, what, sizeof(what));
+            if (b->parent) gpu_scene_describe(gs, b->parent, whatp, sizeof(whatp));
+            fprintf(stderr, "frame %u entity %u (model %u parent %d hooked %u): mismatch mask 0x%02x%s; seq %u / %u parent_seq %u / %u; record: %s; parent's: %s\n",
+                    frame, id, meta[id].model, (int)meta[id].parent, meta[id].hooked, diff, full ? "" : " (not fetched)",
+                    a->seq, b->seq, a->parent_seq, b->parent_seq, what, whatp);
+        }
     }
     entity3d *bva = A.scene->camera->bv, *bvb = B.scene->camera->bv;
     uint32_t ia = NONE, ib = NONE;
@@ -409,11 +442,13 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
     A.scene->control = A.e[0];
     B.scene->control = B.e[0];
     gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
 
     uint8_t *drawn_a = calloc(cap_ids, 1), *drawn_b = calloc(cap_ids, 1);
     uint64_t bad = 0, passes = 0, drawn_total = 0, forced = 0, inside = 0, lod_hist[8] = { 0 }, batched = 0, host = 0;
     for (uint32_t f = 0; f < frames; f++) {
+        no_topology = opt_steady && f % 4 != 1;
         if (f) game_frame(f % 5 == 4 ? 0 : n / 16 + 1);
         for (uint32_t k = 0; k < n / 50 + 1; k++) {                       /* the game forces / releases LODs */
             const uint32_t id = pick_alive();
@@ -454,7 +489,16 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
             entity3d **list; const int32_t *llod;
             const uint32_t nb = gpu_scene_visible(gs, &list, &llod);
             for (uint32_t k = 0; k < nb; k++) {
-                for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == list[k]) { drawn_b[id]++; break; }
+                for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == list[k]) {
+                    drawn_b[id]++;
+                    /* what the draw reads of a listed entity (model.c:1022-1028) is current -- whichever camera brought it
+                     * into view, under either write-back policy, without anybody fetching it */
+                    const entity3d *a = A.e[id], *b = list[k];
+                    if ((memcmp(a->mx, b->mx, 64) || memcmp(a->inverse_mx, b->inverse_mx, 64) || memcmp(a->aabb, b->aabb, 24) ||
+                         memcmp(a->aabb_center, b->aabb_center, 12) || a->seq != b->seq || a->parent_seq != b->parent_seq) && bad++ < 8)
+                        fprintf(stderr, "frame %u pass %d entity %u: on the draw list with fields that are not the reference's\n", f, pass, id);
+                    break;
+                }
                 if (llod[k] != list[k]->cur_lod && bad++ < 8) fprintf(stderr, "frame %u: draw list LOD %d but e->cur_lod %d\n", f, llod[k], list[k]->cur_lod);
             }
             if (na != nb && bad++ < 8) fprintf(stderr, "frame %u pass %d: %u entities drawn by the reference, %u on the list\n", f, pass, na, nb);
@@ -488,9 +532,9 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
     for (int k = 0; k < 8; k++) distinct += lod_hist[k] > 0;
     printf("{\"mode\": \"lod\", \"frames\": %u, \"passes\": %llu, \"entities_created\": %u, \"drawn\": %llu, \"lod_levels_seen\": %u, "
            "\"forced_or_released\": %llu, \"drawn_with_camera_inside_box\": %llu, \"batched_updates\": %llu, \"host_updates\": %llu, "
-           "\"notify\": %s, \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
+           "\"notify\": %s, \"scatter\": \"%s\", \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
            (unsigned long long)forced, (unsigned long long)inside, (unsigned long long)batched, (unsigned long long)host,
-           opt_notify ? "true" : "false", (unsigned long long)bad);
+           opt_notify ? "true" : "false", opt_drawn ? "drawn" : "all", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -510,10 +554,12 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
     A.scene->control = A.e[0];
     B.scene->control = B.e[0];
 
-    uint64_t bad = 0, visible = 0, batched = 0, host = 0, written = 0, retiles = 0, fast_frames = 0;
+    uint64_t bad = 0, visible = 0, batched = 0, host = 0, written = 0, retiles = 0, fast_frames = 0, fetched = 0, left_stale = 0;
     gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
     for (uint32_t f = 0; f < frames; f++) {
+        no_topology = opt_steady && f % 4 != 1;
         if (f) game_frame(f % 5 == 4 ? 0 : n / 8 + 1);                  /* every fifth frame nothing moves */
         vec3 cpos = { rndf(-50, 50), rndf(-10, 10), rndf(-50, 50) };
         quat cq; quat_from_euler_xyz(cq, rndf(-0.5f, 0.5f), rndf(-3, 3), 0);
@@ -528,17 +574,35 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
         const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
         if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
         batched += st->batched; host += st->host; written += st->written_back; retiles += st->retiled;
+        fetched += st->fetched; left_stale += st->left_stale;
         fast_frames += gpu_scene_last_was_fast(gs);
-        bad += compare_frame(gs, f, &visible);
+        if (getenv("DROPIN_TRACE")) {                                    /* one entity's counters after every frame, before any fetch */
+            const uint32_t id = (uint32_t)atoi(getenv("DROPIN_TRACE"));
+            if (id < n_ids && meta[id].alive) {
+                char what[256], whatp[256] = "";
+                gpu_scene_describe(gs, B.e[id], what, sizeof(what));
+                if (B.e[id]->parent) gpu_scene_describe(gs, B.e[id]->parent, whatp, sizeof(whatp));
+                fprintf(stderr, "trace frame %u (%s): entity %u seq %u / %u parent_seq %u / %u updated %d / %d vis %d; %s; parent (seq %u / %u): %s\n", f,
+                        gpu_scene_last_was_fast(gs) ? "fast" : "walk", id, A.e[id]->seq, B.e[id]->seq, A.e[id]->parent_seq, B.e[id]->parent_seq,
+                        (int)transform_is_updated(&A.e[id]->xform), (int)transform_is_updated(&B.e[id]->xform),
+                        (int)ref_view_entity_in_frustum(&A.view, A.e[id]), what,
+                        A.e[id]->parent ? A.e[id]->parent->seq : 0, B.e[id]->parent ? B.e[id]->parent->seq : 0, whatp);
+            }
+        }
+        bad += f + 1 == frames ? compare_frame_ex(gs, f, &visible, true) : compare_frame(gs, f, &visible);
     }
     uint32_t alive = 0;
     for (uint32_t id = 0; id < n_ids; id++) alive += meta[id].alive;
     printf("{\"mode\": \"test\", \"frames\": %u, \"entities_created\": %u, \"entities_alive\": %u, "
            "\"batched_updates\": %llu, \"host_updates\": %llu, \"written_back\": %llu, \"retiles\": %llu, "
-           "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"entity3d_update_calls\": %llu, \"mismatches\": %llu}\n",
+           "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"entity3d_update_calls\": %llu, "
+           "\"scatter\": \"%s\", \"left_stale\": %llu, \"fetched_on_view\": %llu, \"stale_seen_by_checker\": %llu, \"partial_compare_frames\": %llu, "
+           "\"mismatches\": %llu}\n",
            frames, n_ids, alive, (unsigned long long)batched, (unsigned long long)host,
            (unsigned long long)written, (unsigned long long)retiles, (unsigned long long)visible,
-           opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates, (unsigned long long)bad);
+           opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates,
+           opt_drawn ? "drawn" : "all", (unsigned long long)left_stale, (unsigned long long)fetched, (unsigned long long)n_stale_seen,
+           (unsigned long long)n_partial_frames, (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -827,6 +891,42 @@ static int cmd_snapshot(uint32_t n, const char *path)
 }
 
 /* Frame cost at the boundary, host structs to host structs (PCIe and scatter-back included). */
+/* What a render pass does with an entity it draws: reads the matrices it uploads (model.c:1022-1028).  Order-independent
+ * (the reference draws in list order, the binding's list is grouped by txmodel): a wrapping sum of bit patterns. */
+static inline uint64_t draw_read(const entity3d *e, int lod)
+{
+    uint32_t w[4];
+    memcpy(w, e->mx[3], 12); memcpy(&w[3], e->inverse_mx[3], 4);
+    return (uint64_t)w[0] + ((uint64_t)w[1] << 7) + ((uint64_t)w[2] << 13) + ((uint64_t)w[3] << 19) + (uint64_t)(uint32_t)lod * 0x9e3779b97f4a7c15ull;
+}
+
+/* _models_render's per-entity block (model.c:958-992) over every entity of every txmodel, with the engine's own
+ * predicates (world A: the reference's; world B: the same names, served by the binding) */
+static uint32_t render_block_ref(struct world *w, const float *cam_pos, uint64_t *acc, bool world_b)
+{
+    uint32_t n = 0;
+    model3dtx *txm;
+    entity3d *e, *it;
+    list_for_each_entry(txm, &w->mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
+        if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) &&
+            !(world_b ? view_entity_in_frustum(&w->view, e) : ref_view_entity_in_frustum(&w->view, e))) continue;
+        if (e->force_lod >= 0) {
+            e->cur_lod = e->force_lod;
+        } else if (!aabb_point_is_inside(e->aabb, cam_pos)) {
+            vec3 dist;
+            vec3_sub(dist, e->aabb_center, cam_pos);
+            float side = entity3d_aabb_avg_edge(e);
+            float scale = fabsf(vec3_mul_inner(dist, dist) - side * side) / 3600.0;
+            if (world_b) entity3d_set_lod(e, (int)scale, false); else ref_entity3d_set_lod(e, (int)scale, false);
+        }
+        *acc += draw_read(e, e->cur_lod);
+        n++;
+    }
+    return n;
+}
+
 static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
 {
     struct gpu_scene *gs;
@@ -838,26 +938,53 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     meta = calloc(cap_ids, sizeof(*meta));
     world_init(&A, cap_ids);
     world_init(&B, cap_ids);
+    static const unsigned int lods[N_MODELS][3] = { { 0, 3, 4 }, { 0, 2, 3 }, { 0, 0, 1 }, { 0, 5, 6 } };   /* lod_min, lod_max, nr_lods */
+    for (int k = 0; k < N_MODELS; k++) {
+        A.model[k].lod_min = B.model[k].lod_min = lods[k][0];
+        A.model[k].lod_max = B.model[k].lod_max = lods[k][1];
+        A.model[k].nr_lods = B.model[k].nr_lods = lods[k][2];
+    }
     while (n_ids < n) op_create(500.f, false);
     vec3 cpos = { 3, 5, 7 };                                             /* not the origin: the never-computed boxes of the skip_aabb model contain it */
     quat cq; quat_identity(cq);
     view_set(&A, cpos, cq);
     view_set(&B, cpos, cq);
     gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
 
     double t_ref = 0, t_gpu = 0, t_ref_upd = 0, t_gpu_upd = 0, t_step[4] = { 0, 0, 0, 0 };
-    uint64_t vis_a = 0, vis_b = 0;
+    double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0;
+    uint64_t vis_a = 0, vis_b = 0, drawn_a = 0, drawn_b = 0, drawn_l = 0, acc_a = 0, acc_b = 0, acc_l = 0, left_stale = 0, fetched = 0;
+    uint64_t bad = 0;
     for (uint32_t f = 0; f < frames + 2; f++) {                          /* two untimed warm-up frames */
+        /* the game's own writes: the same numbers to both worlds (world B through the engine's names, i.e. with the
+         * notification) -- timed apart, since the notification is a cost the binding adds to the mutators */
+        const uint64_t rs = rng_state;
+        double m0 = now_s();
         for (uint32_t id = 0; id < n; id++) {
             if (f && rndn(1000) >= dirty_permille) continue;
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
-            ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
+            ref_entity3d_move(A.e[id], off);
         }
+        double m1 = now_s();
+        rng_state = rs;
+        for (uint32_t id = 0; id < n; id++) {
+            if (f && rndn(1000) >= dirty_permille) continue;
+            vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
+            entity3d_move(B.e[id], off);
+        }
+        double m2 = now_s();
+        /* the camera drifts: every frame a few entities come into view that were not drawn before */
+        cpos[0] += 0.75f; cpos[2] -= 0.5f;
+        quat_from_euler_xyz(cq, 0, 0.01f * f, 0);
+        view_set(&A, cpos, cq);
+        view_set(&B, cpos, cq);
+
         double t0 = now_s();
         ref_mq_update(A.mq);
         double t0b = now_s();
-        { model3dtx *txm; entity3d *e, *it;                              /* asked the way _models_render asks: list order (model.c:958-973) */
+        { model3dtx *txm; entity3d *e, *it;                              /* consumer 1: one verdict per entity, asked the way _models_render asks: list order (model.c:958-973) */
           list_for_each_entry(txm, &A.mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry)
               vis_a += ref_view_entity_in_frustum(&A.view, e); }
         double t1 = now_s();
@@ -867,25 +994,65 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
           list_for_each_entry(txm, &B.mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry)
               vis_b += view_entity_in_frustum(&B.view, e); }
         double t2 = now_s();
+        /* consumer 2: the whole per-entity block of a render pass (verdict + LOD + the draw's reads).  World A: the
+         * reference's loop.  World B twice: the same loop under the engine's names (verdicts from the device's mask),
+         * then gpu_scene_select_lod() + the draw list txmodel by txmodel -- no per-entity loop over what is not drawn */
+        uint64_t aa = 0, ab = 0, al = 0;
+        double b0 = now_s();
+        const uint32_t na = render_block_ref(&A, cpos, &aa, false);
+        double b1 = now_s();
+        const uint32_t nb = render_block_ref(&B, cpos, &ab, true);
+        double b2 = now_s();
+        uint32_t nl = 0;
+        rc = gpu_scene_select_lod(gs, &B.view, cpos);
+        if (rc) { fprintf(stderr, "gpu_scene_select_lod: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+        { model3dtx *txm;
+          list_for_each_entry(txm, &B.mq->txmodels, entry) {
+              entity3d **seg; const int32_t *slod;
+              const uint32_t ns = gpu_scene_visible_of(gs, txm, &seg, &slod);
+              for (uint32_t k = 0; k < ns; k++) al += draw_read(seg[k], slod[k]);
+              nl += ns;
+          } }
+        double b3 = now_s();
+        if (na != nb || na != nl || aa != ab || aa != al) {
+            if (bad++ < 8) fprintf(stderr, "frame %u: render block draws %u / %u / %u entities, reads %016llx / %016llx / %016llx\n", f, na, nb, nl,
+                                   (unsigned long long)aa, (unsigned long long)ab, (unsigned long long)al);
+        }
         if (f >= 2) { t_ref_upd += t0b - t0; t_gpu_upd += t1b - t1; }
         if (!gpu_scene_last_stats(gs)->batched) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
         if (f >= 2) {
             const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
             t_ref += t1 - t0; t_gpu += t2 - t1;
+            t_ref_mut += m1 - m0; t_gpu_mut += m2 - m1;
+            t_ref_blk += b1 - b0; t_gpu_blk += b2 - b1; t_gpu_list += b3 - b2;
+            drawn_a += na; drawn_b += nb; drawn_l += nl; acc_a += aa; acc_b += ab; acc_l += al;
+            left_stale += st->left_stale; fetched += st->fetched;
             t_step[0] += st->ms_walk; t_step[1] += st->ms_mirror; t_step[2] += st->ms_device; t_step[3] += st->ms_scatter;
         }
     }
-    uint64_t bad = 0;
+    if (opt_drawn && (rc = gpu_scene_fetch_all(gs))) { fprintf(stderr, "gpu_scene_fetch_all: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
     for (uint32_t id = 0; id < n; id++)
-        bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24);
+        bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24) || A.e[id]->seq != B.e[id]->seq ||
+               A.e[id]->parent_seq != B.e[id]->parent_seq || A.e[id]->cur_lod != B.e[id]->cur_lod;
+    const double F = frames;
     printf("{\"mode\": \"bench\", \"entities\": %u, \"frames\": %u, \"dirty_permille\": %u, "
            "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, "
            "\"reference_mq_update_ms\": %.4f, \"binding_mq_update_ms\": %.4f, "
-           "\"binding_ms\": {\"walk\": %.4f, \"mirror\": %.4f, \"device\": %.4f, \"scatter\": %.4f}, \"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
-           "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone\"}\n",
-           n, frames, dirty_permille, 1e3 * t_ref / frames, 1e3 * t_gpu / frames, 1e3 * t_ref_upd / frames, 1e3 * t_gpu_upd / frames,
-           t_step[0] / frames, t_step[1] / frames, t_step[2] / frames, t_step[3] / frames, opt_notify ? "true" : "false",
-           vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
+           "\"binding_ms\": {\"walk\": %.4f, \"mirror\": %.4f, \"device\": %.4f, \"scatter\": %.4f}, "
+           "\"reference_mutate_ms\": %.4f, \"binding_mutate_ms\": %.4f, "
+           "\"reference_render_block_ms\": %.4f, \"binding_render_block_ms\": %.4f, \"binding_draw_list_ms\": %.4f, "
+           "\"reference_frame_ms\": %.4f, \"binding_frame_block_ms\": %.4f, \"binding_frame_draw_list_ms\": %.4f, "
+           "\"drawn_per_frame\": %.1f, \"draw_sets_equal\": %s, \"draw_reads_equal\": %s, "
+           "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, "
+           "\"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
+           "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
+           n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
+           t_step[0] / F, t_step[1] / F, t_step[2] / F, t_step[3] / F,
+           1e3 * t_ref_mut / F, 1e3 * t_gpu_mut / F, 1e3 * t_ref_blk / F, 1e3 * t_gpu_blk / F, 1e3 * t_gpu_list / F,
+           1e3 * (t_ref_mut + t_ref_upd + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_list) / F,
+           drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
+           opt_drawn ? "drawn" : "all", left_stale / F, fetched / F,
+           opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;
 }
@@ -1466,7 +1633,12 @@ int main(int argc, char **argv)
 
 static int run(int argc, char **argv)
 {
-    if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
+    for (;;) {                                                           /* trailing options, any order */
+        if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
+        else if (argc > 2 && !strcmp(argv[argc - 1], "drawn")) { opt_drawn = true; argc--; }
+        else if (argc > 2 && !strcmp(argv[argc - 1], "steady")) { opt_steady = true; argc--; }
+        else break;
+    }
     if (argc >= 6 && !strcmp(argv[1], "fail")) {                        /* fail <launches> <entities> <frames> <seed>: `test` with the device failing after <launches> launches */
         clapgpu_test_fail_after(atoi(argv[2]));
         return cmd_test((uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));

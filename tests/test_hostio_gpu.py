@@ -18,7 +18,8 @@ class Hostio(C.Structure):
     _fields_ = [("pos_scale", C.c_void_p), ("rot", C.c_void_p), ("flags", C.c_void_p), ("touched", C.c_void_p),
                 ("mx", C.c_void_p), ("inv_mx", C.c_void_p), ("aabb", C.c_void_p), ("center", C.c_void_p),
                 ("vis_mask", C.c_void_p), ("rebuilt_mask", C.c_void_p), ("inside_mask", C.c_void_p),
-                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32)]
+                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32),
+                ("keep_mask", C.c_void_p), ("exported_mask", C.c_void_p)]
 
 
 class Mapped:
