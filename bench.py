@@ -37,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ROUND = "r03"
+ROUND = "r05"
 
 
 def parse():
@@ -256,18 +256,27 @@ def dropin_boundary():
     if not os.access(exe, os.X_OK):
         return None
     out = {}
+    fields = ("reference_ms_per_frame", "binding_ms_per_frame", "reference_mq_update_ms", "binding_mq_update_ms", "binding_ms",
+              "reference_mutate_ms", "binding_mutate_ms", "reference_render_block_ms", "binding_render_block_ms",
+              "binding_draw_list_ms", "reference_frame_ms", "binding_frame_block_ms", "binding_frame_draw_list_ms",
+              "drawn_per_frame", "left_stale_per_frame", "fetched_on_view_per_frame")
+
+    def one(n, frames, permille, *policy):
+        p = subprocess.run([exe, "bench", str(n), str(frames), str(permille), "notify", *policy], capture_output=True, text=True,
+                           timeout=240)
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        d = {k: r[k] for k in fields}
+        d["identical"] = (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"])
+        return d
+
     for n, frames, permille in ((10_000, 50, 1000), (10_000, 50, 100), (1_000_000, 5, 1000)):
+        key = f"{n}_entities_{permille // 10}pct_dirty"
         try:
-            p = subprocess.run([exe, "bench", str(n), str(frames), str(permille), "notify"], capture_output=True, text=True,
-                               timeout=240)
-            r = json.loads(p.stdout.strip().splitlines()[-1])
+            # the default policy (every rebuilt entity3d written back) and GPU_SCATTER_DRAWN (what is read is written back)
+            out[key] = dict(one(n, frames, permille), policy="GPU_SCATTER_ALL")
+            out[key]["scatter_drawn"] = dict(one(n, frames, permille, "drawn"), policy="GPU_SCATTER_DRAWN")
         except Exception as e:                                   # a figure for context: never fail the bench on it
-            out[f"{n}_entities_{permille // 10}pct_dirty"] = {"error": repr(e)[:200]}
-            continue
-        out[f"{n}_entities_{permille // 10}pct_dirty"] = {
-            "reference_ms_per_frame": r["reference_ms_per_frame"], "binding_ms_per_frame": r["binding_ms_per_frame"],
-            "reference_mq_update_ms": r["reference_mq_update_ms"], "binding_mq_update_ms": r["binding_mq_update_ms"],
-            "binding_ms": r["binding_ms"], "identical": r["mismatches"] == 0 and r["visible_equal"]}
+            out.setdefault(key, {})["error"] = repr(e)[:200]
     # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
     # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
     # (10 x 64 over 400 frames: the testbed's own scale, core/clap.c's demo scenes -- three device round trips a frame)
@@ -294,11 +303,16 @@ def dropin_boundary():
                         "identical": r["mismatches"] == 0 and r["stream_draws_agree"]}
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
-    out["note"] = ("random forest (60 % of the entities parented, parents listed before their children); *_ms_per_frame = mq_update + one "
-                   "frustum verdict per entity asked in list order like _models_render (the caller's walk of the lists is inside both "
-                   "sides), *_mq_update_ms = the update call alone.  Binding through the engine's own names (mq_update, "
-                   "view_entity_in_frustum, entity3d_move ...), notification mode: touched transforms up, kernel, results down, the "
-                   "rebuilt entities scattered back into their entity3d structs; worker threads (<= 8) for frames that touch > 64 k entities.  "
+    out["note"] = ("random forest (60 % of the entities parented, parents listed before their children), camera drifting; *_ms_per_frame = "
+                   "mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's walk of the lists is "
+                   "inside both sides), *_mq_update_ms = the update call alone, *_mutate_ms = the frame's entity3d_move calls (the binding's "
+                   "carry the notification), *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the "
+                   "draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over "
+                   "gpu_scene_visible_of() per txmodel, *_frame_* = mutate + mq_update + that consumer.  Binding through the engine's own "
+                   "names (mq_update, view_entity_in_frustum, entity3d_move ...), notification mode: touched transforms up, kernel, results "
+                   "down, scattered back into the entity3d structs -- every rebuilt entity (GPU_SCATTER_ALL, the default) or what is read: "
+                   "drawn / containing the camera / standing host readers, the rest fetched when it comes into view or on demand "
+                   "(scatter_drawn: GPU_SCATTER_DRAWN); worker threads (<= 16) for frames that touch > 64 k entities.  "
                    "*_characters_*: the frame's mq_update with every character's animated_update (keyframes, hierarchy, palette, joint "
                    "positions) on the host against the binding (entities, pose on the device, T/R/S + palette + positions of every "
                    "joint copied back into the entity3d structs, joint-attached props in a second launch); every float the reference's, bit for bit.  "

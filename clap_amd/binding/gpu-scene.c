@@ -139,6 +139,11 @@ struct gpu_scene {
     struct view     *culled_view;
     vec4            culled_planes[6];
     entity3d        **draw; int32_t *draw_lod; uint32_t n_draw, cap_draw;   /* gpu_scene_select_lod's draw list */
+    uint16_t        *draw_txm;                                     /* ... and each entry's txmodel, as an index into txms[] */
+    /* by device slot, laid out by every walk: the entity, its txmodel's index and the cur_lod its entity3d holds -- a pass's
+     * draw list is built from these three streams without touching an entity3d (or a record) unless its LOD changed */
+    entity3d        **slot_ent; uint16_t *slot_txm; int8_t *slot_lod; uint32_t cap_slot_arrays;
+    const model3dtx **txms; uint32_t n_txms, cap_txms;
     /* the same list grouped by txmodel, in the order the txmodels first appear on it (gpu_scene_visible_of) */
     entity3d        **draw_g; int32_t *draw_g_lod; uint32_t cap_draw_g;
     struct gs_draw_group { const model3dtx *txm; uint32_t start, n; } *groups; uint32_t n_groups, cap_groups;
@@ -266,6 +271,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->xptr); free(gs->ftab);
+    free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -605,6 +611,50 @@ void gpu_scene_touch_xform(struct gpu_scene *gs, entity3d *e)
     gs->xptr[gs->n_xptr++] = e;
 }
 
+/* a scene has tens of txmodels: the last hit first, then a scan */
+static uint32_t txm_index(struct gpu_scene *gs, const model3dtx *txm)
+{
+    static uint32_t last;
+    if (last < gs->n_txms && gs->txms[last] == txm) return last;
+    for (uint32_t g = 0; g < gs->n_txms; g++)
+        if (gs->txms[g] == txm) return last = g;
+    if (gs->n_txms == gs->cap_txms) {
+        const uint32_t cap = gs->cap_txms ? 2 * gs->cap_txms : 32;
+        const model3dtx **q = realloc(gs->txms, (size_t)cap * sizeof(*q));
+        if (!q || cap > 65535) return 0xffffffffu;
+        gs->txms = q; gs->cap_txms = cap;
+    }
+    gs->txms[gs->n_txms] = txm;
+    return last = gs->n_txms++;
+}
+
+static int slot_arrays_build(struct gpu_scene *gs)
+{
+    const uint32_t n = clapgpu_scene_slot_count(gs->scene);
+    if (n > gs->cap_slot_arrays) {
+        entity3d **a = realloc(gs->slot_ent, (size_t)n * sizeof(*a));
+        if (a) gs->slot_ent = a;
+        uint16_t *b = realloc(gs->slot_txm, (size_t)n * sizeof(*b));
+        if (b) gs->slot_txm = b;
+        int8_t *c = realloc(gs->slot_lod, n);
+        if (c) gs->slot_lod = c;
+        if (!a || !b || !c) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }
+        gs->cap_slot_arrays = n;
+    }
+    if (n) memset(gs->slot_ent, 0, (size_t)n * sizeof(*gs->slot_ent));
+    gs->n_txms = 0;
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if ((r->cls != 1 && r->cls != 4) || r->slot >= n) continue;
+        const uint32_t g = txm_index(gs, r->e->txmodel);
+        if (g == 0xffffffffu || r->e->cur_lod < -128 || r->e->cur_lod > 127) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }   /* the record path then */
+        gs->slot_ent[r->slot] = r->e;
+        gs->slot_txm[r->slot] = (uint16_t)g;
+        gs->slot_lod[r->slot] = (int8_t)r->e->cur_lod;
+    }
+    return 0;
+}
+
 static inline uint32_t ftab_home(const struct gpu_scene *gs, const void *e) { return ptr_hash(e) & gs->ftab_mask; }
 
 static int ftab_build(struct gpu_scene *gs)
@@ -902,11 +952,18 @@ struct par_job {
     void (*range_fn)(void *, uint32_t, uint32_t); void *ctx;     /* gpu_scene_par_for */
 };
 
+#define GS_MAX_THREADS 16
 static int par_threads(void)
 {
-    long n = sysconf(_SC_NPROCESSORS_ONLN);
-    if (n > 8) n = 8;
-    return n < 1 ? 1 : (int)n;
+    static int cached;
+    if (!cached) {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        const char *env = getenv("GPU_SCENE_THREADS");           /* the passes are memory latency: they scale with the cores until DRAM says no */
+        if (env && atoi(env) > 0) n = atoi(env);
+        if (n > GS_MAX_THREADS) n = GS_MAX_THREADS;
+        cached = n < 1 ? 1 : (int)n;
+    }
+    return cached;
 }
 
 /*
@@ -926,7 +983,7 @@ static int par_threads(void)
  * function or the (stack-allocated) job array of a pass that has returned.
  */
 static struct {
-    pthread_t th[7];
+    pthread_t th[GS_MAX_THREADS - 1];
     int n;                                                       /* workers running */
     pthread_mutex_t mu;
     pthread_cond_t work;
@@ -966,7 +1023,7 @@ static void *pool_worker(void *arg)
 /* called with the pool's mutex held */
 static void pool_grow(int workers)
 {
-    while (g_pool.n < workers && g_pool.n < 7) {
+    while (g_pool.n < workers && g_pool.n < GS_MAX_THREADS - 1) {
         struct pool_arg *pa = malloc(sizeof(*pa));
         if (!pa) break;
         *pa = (struct pool_arg){ .me = g_pool.n, .seen = g_pool.gen };
@@ -1036,7 +1093,7 @@ void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32
 {
     if (threads > par_threads()) threads = par_threads();
     if (threads < 2 || n < (uint32_t)threads) { fn(ctx, 0, n); return; }
-    struct par_job jobs[8] = { 0 };
+    struct par_job jobs[GS_MAX_THREADS] = { 0 };
     for (int t = 0; t < threads; t++)
         jobs[t] = (struct par_job){ .lo = (uint32_t)((uint64_t)n * t / threads), .hi = (uint32_t)((uint64_t)n * (t + 1) / threads),
                                     .range_fn = fn, .ctx = ctx };
@@ -1181,7 +1238,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE)) gs->char_half(r->e, mq->priv);
     }
     if (gs->n_touched >= GS_PAR_MIN) {
-        struct par_job jobs[8] = { 0 };
+        struct par_job jobs[GS_MAX_THREADS] = { 0 };
         const int nt = par_threads();
         for (int t = 0; t < nt; t++)
             jobs[t] = (struct par_job){ .gs = gs, .lo = (uint32_t)((uint64_t)gs->n_touched * t / nt),
@@ -1279,7 +1336,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(scat[w]);
     if (n_rebuilt >= 2 * GS_PAR_MIN && par_threads() > 1) {
         const int nt = par_threads();
-        struct par_job jobs[8] = { 0 };
+        struct par_job jobs[GS_MAX_THREADS] = { 0 };
         for (int t = 0; t < nt; t++)
             jobs[t] = (struct par_job){ .gs = gs, .res = &res, .scat = scat, .lo = (uint32_t)((uint64_t)gs->n_order * t / nt),
                                         .hi = (uint32_t)((uint64_t)gs->n_order * (t + 1) / nt) };
@@ -1629,6 +1686,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
     }
     if (gs->notify && ftab_build(gs)) gs->n_xptr = 0;            /* without the table gpu_scene_touch_xform takes the checked path */
+    slot_arrays_build(gs);                                       /* on failure the draw list goes through the records */
     /* GPU_SCATTER_DRAWN: the standing host readers (gpu-scene.h).  A host-class entity's hook reads its parent's mx / seq
      * (parent_transform_apply, model.c:1609-1641) -- also when that parent comes later in the list (lag_parent) */
     if (gs->scatter_drawn && gs->notify) {
@@ -1750,7 +1808,7 @@ static bool lod_pick_host(struct view *view, entity3d *e, const float *cam_pos)
     return true;
 }
 
-static int draw_push(struct gpu_scene *gs, entity3d *e, int lod)
+static int draw_push(struct gpu_scene *gs, entity3d *e, int lod, uint32_t txm)
 {
     if (gs->n_draw == gs->cap_draw) {
         const uint32_t cap = gs->cap_draw ? 2 * gs->cap_draw : 4096;
@@ -1760,9 +1818,14 @@ static int draw_push(struct gpu_scene *gs, entity3d *e, int lod)
         int32_t *l = realloc(gs->draw_lod, (size_t)cap * sizeof(*l));
         if (!l) return _CERR_NOMEM;
         gs->draw_lod = l;
+        uint16_t *t = realloc(gs->draw_txm, (size_t)cap * sizeof(*t));
+        if (!t) return _CERR_NOMEM;
+        gs->draw_txm = t;
         gs->cap_draw = cap;
     }
+    if (txm == 0xffffffffu && (txm = txm_index(gs, e->txmodel)) == 0xffffffffu) return _CERR_NOMEM;
     gs->draw[gs->n_draw] = e;
+    gs->draw_txm[gs->n_draw] = (uint16_t)txm;
     gs->draw_lod[gs->n_draw++] = lod;
     return 0;
 }
@@ -1776,6 +1839,10 @@ void gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e)
     if (r->handle == CLAPGPU_NO_ENTITY || (e->force_lod == r->lod_force && e->cur_lod == r->lod_cur)) return;
     if (!clapgpu_scene_entity_lod(gs->scene, r->handle, e->force_lod, e->cur_lod)) {
         r->lod_force = e->force_lod; r->lod_cur = e->cur_lod;
+        if (r->slot < gs->cap_slot_arrays) {
+            if (e->cur_lod >= -128 && e->cur_lod <= 127) gs->slot_lod[r->slot] = (int8_t)e->cur_lod;
+            else gs->cap_slot_arrays = 0;                        /* out of the byte's range: the record path */
+        }
     }
 }
 
@@ -1829,14 +1896,29 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     clapgpu_scene_arrays res;
     const uint32_t *slots = NULL; const int32_t *lods = NULL;
     if (n && !clapgpu_scene_results(gs->scene, &res) && clapgpu_scene_draw_list(gs->scene, &slots, &lods) == n) {
+        const bool by_slot = gs->cap_slot_arrays >= res.n_slots;
         for (uint32_t k = 0; k < n; k++) {
-            const uint32_t tag = (uint32_t)(uintptr_t)res.slot_user[slots[k]];
+            const uint32_t slot = slots[k];
+            if (by_slot) {
+                /* three arrays read in ascending slot order; an entity3d (and its record) only when the pick changed its LOD */
+                entity3d *e = gs->slot_ent[slot];
+                if (!e) continue;
+                if (lods[k] != gs->slot_lod[slot] && lods[k] >= -128 && lods[k] <= 127) {
+                    e->cur_lod = lods[k];                           /* as model.c:977 / entity3d_set_lod leave it */
+                    gs->slot_lod[slot] = (int8_t)lods[k];
+                    const uint32_t tag = (uint32_t)(uintptr_t)res.slot_user[slot];
+                    if (tag) gs->rec[tag - 1].lod_cur = lods[k];
+                }
+                CK(draw_push(gs, e, lods[k], gs->slot_txm[slot]));
+                continue;
+            }
+            const uint32_t tag = (uint32_t)(uintptr_t)res.slot_user[slot];
             if (!tag) continue;
             struct gs_rec *r = &gs->rec[tag - 1];
             if (!r->e || r->gen != gs->gen || (r->cls != 1 && r->cls != 4)) continue;
             r->e->cur_lod = lods[k];                                /* as model.c:977 / entity3d_set_lod leave it */
             r->lod_cur = lods[k];
-            CK(draw_push(gs, r->e, lods[k]));
+            CK(draw_push(gs, r->e, lods[k], 0xffffffffu));
         }
     }
     /* the entities the device does not hold, in list order, by the reference's own block */
@@ -1844,10 +1926,11 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
         struct gs_rec *r = &gs->rec[gs->order[k]];
         if (!r->e || (device_ok && (r->cls == 1 || r->cls == 4))) continue;
         if (lod_pick_host(view, r->e, cam_pos))
-            CK(draw_push(gs, r->e, r->e->cur_lod));
+            CK(draw_push(gs, r->e, r->e->cur_lod, 0xffffffffu));
         if ((r->cls == 1 || r->cls == 4) && r->handle != CLAPGPU_NO_ENTITY && r->e->cur_lod != r->lod_cur &&
             !clapgpu_scene_entity_lod(gs->scene, r->handle, r->e->force_lod, r->e->cur_lod)) {
             r->lod_force = r->e->force_lod; r->lod_cur = r->e->cur_lod;   /* the host block picked for a batched entity: the mirror follows */
+            if (r->slot < gs->cap_slot_arrays && r->e->cur_lod >= -128 && r->e->cur_lod <= 127) gs->slot_lod[r->slot] = (int8_t)r->e->cur_lod;
         }
     }
     return 0;
@@ -1875,39 +1958,22 @@ static int draw_group(struct gpu_scene *gs)
         gs->draw_g_lod = l;
         gs->cap_draw_g = gs->cap_draw;
     }
-    /* a scene has tens of txmodels and consecutive list entries mostly share theirs: the last hit first, then a scan */
-    uint32_t last = 0;
-    for (uint32_t k = 0; k < gs->n_draw; k++) {
-        const model3dtx *txm = gs->draw[k]->txmodel;
-        uint32_t g = last;
-        if (!gs->n_groups || gs->groups[g].txm != txm)
-            for (g = 0; g < gs->n_groups && gs->groups[g].txm != txm; g++)
-                ;
-        if (g == gs->n_groups) {
-            if (gs->n_groups == gs->cap_groups) {
-                const uint32_t cap = gs->cap_groups ? 2 * gs->cap_groups : 32;
-                struct gs_draw_group *q = realloc(gs->groups, (size_t)cap * sizeof(*q));
-                if (!q) return _CERR_NOMEM;
-                gs->groups = q; gs->cap_groups = cap;
-            }
-            gs->groups[gs->n_groups++] = (struct gs_draw_group){ .txm = txm, .start = 0, .n = 0 };
-        }
-        gs->groups[g].n++;
-        last = g;
+    /* a stable counting sort over the entries' txmodel indices: the entities themselves are not read */
+    if (gs->n_txms > gs->cap_groups) {
+        struct gs_draw_group *q = realloc(gs->groups, (size_t)gs->n_txms * sizeof(*q));
+        if (!q) return _CERR_NOMEM;
+        gs->groups = q; gs->cap_groups = gs->n_txms;
     }
+    gs->n_groups = gs->n_txms;
+    for (uint32_t g = 0; g < gs->n_groups; g++) gs->groups[g] = (struct gs_draw_group){ .txm = gs->txms[g], .start = 0, .n = 0 };
+    for (uint32_t k = 0; k < gs->n_draw; k++) gs->groups[gs->draw_txm[k]].n++;
     uint32_t at = 0;
     for (uint32_t g = 0; g < gs->n_groups; g++) { gs->groups[g].start = at; at += gs->groups[g].n; gs->groups[g].n = 0; }
-    last = 0;
     for (uint32_t k = 0; k < gs->n_draw; k++) {
-        const model3dtx *txm = gs->draw[k]->txmodel;
-        uint32_t g = last;
-        if (gs->groups[g].txm != txm)
-            for (g = 0; gs->groups[g].txm != txm; g++)
-                ;
-        const uint32_t pos = gs->groups[g].start + gs->groups[g].n++;
+        struct gs_draw_group *grp = &gs->groups[gs->draw_txm[k]];
+        const uint32_t pos = grp->start + grp->n++;
         gs->draw_g[pos] = gs->draw[k];
         gs->draw_g_lod[pos] = gs->draw_lod[k];
-        last = g;
     }
     gs->groups_valid = true;
     return 0;

@@ -1273,10 +1273,12 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
         if (cam_pos) CK(clapgpu_memcpy_d2h(s->h_draw_lod, s->d_draw_lod, (size_t)n * 4, NULL));
         CK(clapgpu_stream_sync(NULL));
     }
-    for (uint32_t k = 0; k < n; k++) {                               /* the host copies follow the pick */
-        const uint32_t slot = s->h_draw_slot[k], h = s->slot_handle[slot];
-        if (!cam_pos) s->h_draw_lod[k] = s->h_cur_lod[slot];
+    for (uint32_t k = 0; k < n; k++) {                               /* the host copies follow the pick: where it changed something */
+        const uint32_t slot = s->h_draw_slot[k];
+        if (!cam_pos) { s->h_draw_lod[k] = s->h_cur_lod[slot]; continue; }
+        if (s->h_cur_lod[slot] == s->h_draw_lod[k]) continue;
         s->h_cur_lod[slot] = s->h_draw_lod[k];
+        const uint32_t h = s->slot_handle[slot];
         if (h != CLAPGPU_NO_ENTITY) s->e[h].cur_lod = s->h_draw_lod[k];
     }
     s->n_draw = n;

@@ -396,6 +396,7 @@ static uint64_t compare_frame_ex(struct gpu_scene *gs, uint32_t frame, uint64_t 
  * forces and releases LODs through entity3d_set_lod (world B: the engine's name, served by gpu-exports.inc.c), and the
  * camera flies a scripted path that keeps ending up inside some entity's box; every third frame renders a second pass
  * from another camera, every fifth one without a camera (model.c:974). */
+static bool lod_no_view;                   /* this pass has neither camera nor light: `view` is NULL (model.c:969: every ALIVE, VISIBLE entity is drawn) */
 static uint32_t lod_pass_ref(struct world *w, const float *cam_pos, uint8_t *drawn)
 {
     uint32_t n = 0;
@@ -404,7 +405,7 @@ static uint32_t lod_pass_ref(struct world *w, const float *cam_pos, uint8_t *dra
     list_for_each_entry(txm, &w->mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
         if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
         if (!entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
-        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && !ref_view_entity_in_frustum(&w->view, e)) continue;
+        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && !lod_no_view && !ref_view_entity_in_frustum(&w->view, e)) continue;
         if (cam_pos) {
             if (e->force_lod >= 0) {
                 e->cur_lod = e->force_lod;
@@ -446,7 +447,7 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
     gpu_scene_bind(gs, B.mq, &B.view);
 
     uint8_t *drawn_a = calloc(cap_ids, 1), *drawn_b = calloc(cap_ids, 1);
-    uint64_t bad = 0, passes = 0, drawn_total = 0, forced = 0, inside = 0, lod_hist[8] = { 0 }, batched = 0, host = 0;
+    uint64_t bad = 0, passes = 0, drawn_total = 0, forced = 0, inside = 0, lod_hist[8] = { 0 }, batched = 0, host = 0, no_view_passes = 0;
     for (uint32_t f = 0; f < frames; f++) {
         no_topology = opt_steady && f % 4 != 1;
         if (f) game_frame(f % 5 == 4 ? 0 : n / 16 + 1);
@@ -472,9 +473,10 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
         const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
         if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
         batched += st->batched; host += st->host;
-        const int n_pass = 1 + (f % 3 == 2);
+        const int n_pass = 1 + (f % 3 == 2) + (f % 4 == 1);
         for (int pass = 0; pass < n_pass; pass++) {
-            if (pass) {                                                  /* a second pass from another camera: other planes, same boxes */
+            lod_no_view = pass && pass == n_pass - 1 && f % 4 == 1;       /* the frame's last pass has no view at all */
+            if (pass && !lod_no_view) {                                  /* a second pass from another camera: other planes, same boxes */
                 vec3 c2 = { -cpos[0] * 0.5f, cpos[1] + 5.f, -cpos[2] * 0.5f };
                 quat q2; quat_from_euler_xyz(q2, 0.2f, 1.f + 0.1f * f, 0);
                 memcpy(cpos, c2, sizeof(cpos));
@@ -484,8 +486,9 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
             const float *cam = f % 5 == 3 ? NULL : cpos;                 /* model.c:974: passes without a camera keep every LOD */
             memset(drawn_a, 0, cap_ids); memset(drawn_b, 0, cap_ids);
             const uint32_t na = lod_pass_ref(&A, cam, drawn_a);
-            rc = gpu_scene_select_lod(gs, &B.view, cam);
+            rc = gpu_scene_select_lod(gs, lod_no_view ? NULL : &B.view, cam);
             if (rc) { fprintf(stderr, "gpu_scene_select_lod: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+            no_view_passes += lod_no_view;
             entity3d **list; const int32_t *llod;
             const uint32_t nb = gpu_scene_visible(gs, &list, &llod);
             for (uint32_t k = 0; k < nb; k++) {
@@ -532,9 +535,9 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
     for (int k = 0; k < 8; k++) distinct += lod_hist[k] > 0;
     printf("{\"mode\": \"lod\", \"frames\": %u, \"passes\": %llu, \"entities_created\": %u, \"drawn\": %llu, \"lod_levels_seen\": %u, "
            "\"forced_or_released\": %llu, \"drawn_with_camera_inside_box\": %llu, \"batched_updates\": %llu, \"host_updates\": %llu, "
-           "\"notify\": %s, \"scatter\": \"%s\", \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
+           "\"passes_without_a_view\": %llu, \"notify\": %s, \"scatter\": \"%s\", \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
            (unsigned long long)forced, (unsigned long long)inside, (unsigned long long)batched, (unsigned long long)host,
-           opt_notify ? "true" : "false", opt_drawn ? "drawn" : "all", (unsigned long long)bad);
+           (unsigned long long)no_view_passes, opt_notify ? "true" : "false", opt_drawn ? "drawn" : "all", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -1055,6 +1058,51 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;
+}
+
+/* Scene objects come and go (a level change): three binding scenes over the same two worlds, one after the other, each
+ * created, driven through frames that move EVERY entity (the worker-thread passes from 65 536 touched entities up) and
+ * destroyed again -- the last reference to the worker pool goes with each, the next scene starts it anew (the sequence a
+ * use-after-return in the pool was once found on).  Meant to be run under -fsanitize=thread / address (tests/test_sanitize_host.py). */
+static int cmd_recreate(uint32_t n)
+{
+    rng_state = 11;
+    parents_first = true;
+    cap_ids = n;
+    meta = calloc(cap_ids, sizeof(*meta));
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+    uint64_t bad = 0, fast = 0;
+    for (int round = 0; round < 3; round++) {
+        struct gpu_scene *gs;
+        int rc = gpu_scene_init(&gs, 0, default_update);
+        if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
+        gpu_scene_set_notify(gs, true);
+        gpu_scene_set_scatter(gs, round == 1 ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
+        gpu_scene_bind(gs, B.mq, &B.view);
+        while (n_ids < n) op_create(500.f, false);                       /* (round 0; under the engine's names, i.e. notified) */
+        vec3 cpos = { 3, 5, 7 };
+        quat cq; quat_identity(cq);
+        view_set(&A, cpos, cq);
+        view_set(&B, cpos, cq);
+        for (int f = 0; f < 3; f++) {
+            for (uint32_t id = 0; id < n; id++) {
+                vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
+                ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
+            }
+            ref_mq_update(A.mq);
+            mq_update(B.mq);
+            fast += gpu_scene_last_was_fast(gs);
+        }
+        if ((rc = gpu_scene_fetch_all(gs))) { fprintf(stderr, "gpu_scene_fetch_all: %d\n", rc); return 2; }
+        for (uint32_t id = 0; id < n; id++)
+            bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24) || A.e[id]->seq != B.e[id]->seq;
+        gpu_scene_bind(NULL, NULL, NULL);
+        gpu_scene_done(gs);
+    }
+    printf("{\"mode\": \"recreate\", \"entities\": %u, \"scenes\": 3, \"fast_frames\": %llu, \"mismatches\": %llu}\n", n,
+           (unsigned long long)fast, (unsigned long long)bad);
+    return bad ? 1 : 0;
 }
 
 /* ---------------------------------------------------------------- particle systems */
@@ -1647,6 +1695,8 @@ static int run(int argc, char **argv)
         return cmd_snapshot((uint32_t)atoi(argv[2]), argv[3]);
     if (argc >= 2 && !strcmp(argv[1], "edge"))
         return cmd_edge();
+    if (argc >= 3 && !strcmp(argv[1], "recreate"))
+        return cmd_recreate((uint32_t)atoi(argv[2]));
     if (argc >= 4 && !strcmp(argv[1], "lights"))
         return cmd_lights((uint32_t)atoi(argv[2]), strtoull(argv[3], NULL, 0));
     if (argc >= 6 && !strcmp(argv[1], "anim"))

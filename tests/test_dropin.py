@@ -80,6 +80,38 @@ def test_binding_matches_reference_mq_update(n, frames, seed, notify):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,frames,seed,steady", [(300, 12, 1, False), (300, 24, 1, True), (5000, 24, 2, True), (40000, 12, 3, True),
+                                                  (2000, 40, 7, True), (300000, 6, 5, True)])
+def test_drawn_write_back_policy_matches_reference(n, frames, seed, steady):
+    """GPU_SCATTER_DRAWN (clap_amd/binding/gpu-scene.h): a fast frame writes back only what is READ -- what the view
+    draws, what contains the camera / control position, what has a standing host reader (batched parents of host-class
+    children, light carriers, the control entity, entities updated on the spot) -- and leaves the other rebuilt entities
+    on the device.  `steady`: three frames out of four the game only moves / turns / scales / hides entities, so most
+    frames are fast frames (the scripted game of `test` changes the queue's make-up almost every frame, and a walked
+    frame writes everything back).  Checked by clap_dropin: three frames out of four every entity the REFERENCE'S pass
+    would draw (ALIVE, VISIBLE, SKIP_CULLING or in the frustum: model.c:959-973) is compared bit for bit WITHOUT any
+    fetch -- mx, inverse_mx, aabb, aabb_center, seq, parent_seq, xform.updated, verdict -- and must not be stale; every
+    fourth frame and after the last, everything is fetched (gpu_scene_fetch_all) and EVERY entity compared: what was
+    left out for several frames catches up exactly, seq counters included (entity3d_update / _reset on stale entities
+    and on their parents, re-parenting, deletions and walks in between)."""
+    r = _run("test", n, frames, seed, "notify", "drawn", *(["steady"] if steady else []))
+    assert r["mismatches"] == 0 and r["scatter"] == "drawn" and r["notify"] is True
+    assert r["partial_compare_frames"] > 0 and r["fast_frames"] > 0
+    assert r["left_stale"] > 0 and r["stale_seen_by_checker"] > 0, "the policy left nothing out: nothing was tested"
+    assert r["fetched_on_view"] > 0, "nothing ever came into view after being left out"
+    assert r["entity3d_update_calls"] > 0
+    if steady:
+        assert r["fast_frames"] >= frames // 2
+
+
+@pytest.mark.gpu
+def test_drawn_policy_without_notifications_is_the_default_policy():
+    """A queue that is walked every frame writes everything back whatever the policy says."""
+    r = _run("test", 5000, 12, 2, "drawn")
+    assert r["mismatches"] == 0 and r["fast_frames"] == 0 and r["left_stale"] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_sys,per_sys,frames,seed", [(3, 100, 6, 1), (40, 300, 12, 2), (512, 1024, 8, 3)])
 def test_particle_binding_matches_reference_particles_update(n_sys, per_sys, frames, seed):
     """particles_update hooks + libc drand48 (reference) vs gpu_particles_update (binding -> HIP) on the
@@ -195,11 +227,22 @@ def test_scene_dumped_by_the_binding_replays_to_the_reference_bits(tmp_path, cud
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
-def test_binding_bench_mode_is_consistent(notify):
-    r = _run("bench", 10000, 5, 300, *(["notify"] if notify else []))
+@pytest.mark.parametrize("mode", [(), ("notify",), ("notify", "drawn")], ids=["walk", "notify", "notify-drawn"])
+def test_binding_bench_mode_is_consistent(mode):
+    """`bench`: both consumers of a frame on both worlds -- one verdict per entity in list order, and _models_render's
+    whole per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) as the reference's
+    loop (world A), as the same loop under the engine's names (world B) and as gpu_scene_select_lod() + the draw list
+    per txmodel (world B): the three draw the same entities and read the same bits, every frame, with a drifting camera;
+    after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared."""
+    r = _run("bench", 20000, 6, 300, *mode)
     assert r["mismatches"] == 0 and r["visible_equal"] is True
+    assert r["draw_sets_equal"] is True and r["draw_reads_equal"] is True and r["drawn_per_frame"] > 0
     assert r["binding_mq_update_ms"] > 0 and r["reference_mq_update_ms"] > 0
+    assert r["binding_draw_list_ms"] > 0 and r["reference_render_block_ms"] > 0
+    if "drawn" in mode:
+        assert r["scatter"] == "drawn" and r["left_stale_per_frame"] > 0 and r["fetched_on_view_per_frame"] > 0
+    else:
+        assert r["left_stale_per_frame"] == 0
 
 
 @pytest.mark.gpu
@@ -219,9 +262,9 @@ def test_checker_refuses_to_pass_on_the_host_fallback(launches):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("notify", [False, True], ids=["walk", "notify"])
+@pytest.mark.parametrize("mode", [(), ("notify",), ("notify", "drawn", "steady")], ids=["walk", "notify", "notify-drawn-steady"])
 @pytest.mark.parametrize("n,frames,seed", [(300, 14, 1), (4000, 12, 2), (12000, 8, 3)])
-def test_lod_pick_and_draw_list_match_the_reference_block(n, frames, seed, notify):
+def test_lod_pick_and_draw_list_match_the_reference_block(n, frames, seed, mode):
     """SURVEY 8f rank 1 through the boundary a CLAP maintainer uses: _models_render's per-entity block (model.c:959-992:
     draw predicate, force_lod, camera-inside-box skip, entity3d_aabb_avg_edge + entity3d_set_lod's clamp) run per pass
     over world A's lists with the reference's own functions, against gpu_scene_select_lod() / gpu_scene_visible() on
@@ -229,9 +272,13 @@ def test_lod_pick_and_draw_list_match_the_reference_block(n, frames, seed, notif
     by the reference's functions on the host).  e->cur_lod and e->force_lod of EVERY live entity and the set of drawn
     entities agree after every pass -- over a scripted camera path that keeps ending inside entity boxes, second passes
     from another camera (a cull launch for its planes), passes without a camera, LODs forced / released / set through
-    entity3d_set_lod (the engine's name in world B), entities hidden, deleted, created and re-parented."""
-    r = _run("lod", n, frames, seed, *(["notify"] if notify else []))
+    entity3d_set_lod (the engine's name in world B), entities hidden, deleted, created and re-parented.  Every entity ON
+    the list also holds the reference's mx / inverse_mx / aabb / aabb_center / seq / parent_seq -- under GPU_SCATTER_DRAWN
+    too (`drawn`), where a second camera's cull launch has to fetch what its planes bring into view."""
+    r = _run("lod", n, frames, seed, *mode)
     assert r["mismatches"] == 0
     assert r["passes"] > frames and r["drawn"] > 0 and r["lod_levels_seen"] >= 3
+    assert r["passes_without_a_view"] > 0          # view == NULL: every ALIVE, VISIBLE entity is drawn, whatever the last frustum was
     assert r["forced_or_released"] > 0 and r["drawn_with_camera_inside_box"] > 0
-    assert r["batched_updates"] > 0 and r["host_updates"] > 0 and r["notify"] is notify
+    assert r["batched_updates"] > 0 and r["host_updates"] > 0 and r["notify"] is ("notify" in mode)
+    assert r["scatter"] == ("drawn" if "drawn" in mode else "all")
