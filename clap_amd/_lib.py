@@ -86,7 +86,7 @@ class Skeleton(C.Structure):
 class Animations(C.Structure):
     _fields_ = [("n_anims", C.c_uint32), ("n_times", C.c_uint32), ("chan_table", C.c_void_p),
                 ("times", C.c_void_p), ("data", C.c_void_p), ("packed", C.c_void_p), ("packed_keys", C.c_uint32),
-                ("packed_layout", C.c_uint32)]
+                ("packed_layout", C.c_uint32), ("n_data", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class PoseBatch(C.Structure):
@@ -260,6 +260,12 @@ SYMBOLS = {
     "clapgpu_exchange_destroy": (None, [C.c_void_p]),
     "clapgpu_exchange_visible": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
+    "clapgpu_exchange_visible_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "clapgpu_visible_compact_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]),
+    "clapgpu_visible_expand_ranges_host": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "clapgpu_shard_bases": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "clapgpu_mat4_invert": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "clapgpu_mat4_from_quat": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "clapgpu_frame_issue": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_double, C.c_uint32]),

@@ -100,7 +100,7 @@ class SkinnedModel:
                                        _ptr(self.root_pose), _ptr(self.invmx), _ptr(self.bind))
         self.anim_desc = _lib.Animations(len(anims), int(ct["times"].shape[0]), _ptr(self._ct["chan_table"]),
                                          _ptr(self._ct["times"]),
-                                         _ptr(self._ct["data"]), None, 0, 0)
+                                         _ptr(self._ct["data"]), None, 0, 0, int(ct["data"].shape[0]), 0)
         # the key-major copy of the pools with the rotation intervals' constants (clapgpu_animations_pack): once per
         # model, required by clapgpu_pose_update
         self.packed = None

@@ -178,7 +178,7 @@ static int ga_model_build(struct ga_model *m, model3d *model)
     m->sk = (clapgpu_skeleton){ .nr_joints = J, .n_levels = n_levels, .parent = m->d_parent, .depth = m->d_depth,
                                 .root_pose = m->d_root_pose, .invmx = m->d_invmx, .bind = m->d_bind };
     m->an = (clapgpu_animations){ .n_anims = A, .n_times = (uint32_t)t_at, .chan_table = m->d_chan_table,
-                                  .times = m->d_times, .data = m->d_data };
+                                  .times = m->d_times, .data = m->d_data, .n_data = (uint32_t)d_at };
     if (!max_keys) max_keys = 1;                          /* animations without a single key: every path keeps its value */
     if (J <= 256 && A) {
         /* the key-major copy of the pools, once per model, with what quat_slerp derives from each rotation key pair alone

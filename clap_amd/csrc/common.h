@@ -10,6 +10,8 @@ namespace clapgpu {
 
 // Records the HIP error text for clapgpu_last_error() and maps it to a cerr code.
 int hip_fail(hipError_t err, const char *what);
+// ... and a refusal of our own (an asset or an argument combination the exactness does not cover)
+void set_last_error(const char *what);
 
 #define CLAPGPU_HIP(call)                                                   \
     do {                                                                    \

@@ -368,6 +368,62 @@ void k_visible_expand(const uint64_t *vis_mask, uint32_t n, const uint32_t *grou
         *count = pre + incl;
 }
 
+// ---- the same over a GATHERED mask: one segment of cap_words words per rank, rank r's slot i has global id base[r] + i ----
+// (clapgpu_visible_compact_ranges: shards cut from one scene by clapgpu_shard_tile_range are uneven; every rank sends a
+// mask of the common capacity, only its first n_words[r] words count)
+constexpr int MAX_SEGMENTS = 64;
+struct SegK { uint32_t cap_words, n_seg; uint32_t base[MAX_SEGMENTS], n_words[MAX_SEGMENTS]; };
+
+__device__ __forceinline__ uint64_t load_seg_word(const uint64_t *mask, const SegK &sg, uint32_t w, uint32_t *id_base)
+{
+    const uint32_t r = w / sg.cap_words, lw = w - r * sg.cap_words;
+    if (r >= sg.n_seg || lw >= sg.n_words[r]) { *id_base = 0; return 0ull; }
+    *id_base = sg.base[r] + lw * 64u;
+    return mask[w];
+}
+
+__global__ __launch_bounds__(WAVE)
+void k_mask_group_count_seg(const uint64_t *mask, SegK sg, uint32_t *group_count)
+{
+    uint32_t idb;
+    const uint32_t c = wave_sum(__popcll(load_seg_word(mask, sg, blockIdx.x * GROUP_WORDS + threadIdx.x, &idb)));
+    if (threadIdx.x == 0)
+        group_count[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(WAVE)
+void k_visible_expand_seg(const uint64_t *mask, SegK sg, const uint32_t *group_count, uint32_t n_groups, uint32_t *visible,
+                          uint32_t *count)
+{
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    uint32_t pre = 0;
+    for (uint32_t j = lane; j < g; j += WAVE)
+        pre += group_count[j];
+    pre = wave_sum(pre);
+    uint32_t idb;
+    const uint64_t word = load_seg_word(mask, sg, g * GROUP_WORDS + lane, &idb);
+    const uint32_t cnt = __popcll(word);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - cnt;
+    for (int k = 0; k < GROUP_WORDS; k++) {
+        const uint64_t wk = __shfl(word, k);
+        if (wk == 0) continue;                        // wave-uniform
+        const uint32_t base = pre + __shfl(excl, k), ids = __shfl(idb, k);
+        if ((wk >> lane) & 1ull) {
+            const uint32_t rank = __popcll(wk & ((1ull << lane) - 1ull));
+            visible[base + rank] = ids + lane;
+        }
+    }
+    if (g == n_groups - 1 && lane == WAVE - 1)
+        *count = pre + incl;
+}
+
 // Single-launch compaction for up to RP_MAX_ROWS rows: the update / cull kernels leave one
 // popcount byte per 64-entity row, so a wave gets the number of visible entities before its
 // first row from at most RP_MAX_ROWS / 1024 16-byte loads per lane -- no separate count pass.
@@ -893,6 +949,64 @@ extern "C" int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, c
                        group_count, n_groups, index_base, visible, count);
     CLAPGPU_LAUNCH_CHECK("k_visible_expand");
     return CLAPGPU_OK;
+}
+
+static int check_ranges(uint32_t n_ranges, uint32_t cap_pad, const uint32_t *base, const uint32_t *n_pad)
+{
+    if (!n_ranges || n_ranges > (uint32_t)MAX_SEGMENTS || !cap_pad || (cap_pad & 63u) || !base) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    uint64_t end = 0;
+    for (uint32_t r = 0; r < n_ranges; r++) {
+        const uint32_t np = n_pad ? n_pad[r] : cap_pad;
+        if ((np & 63u) || np > cap_pad || (base[r] & 63u) || base[r] < end) return CLAPGPU_ERR_INVALID_ARGUMENTS;   /* ascending, disjoint */
+        end = (uint64_t)base[r] + np;
+        if (end > 0xffffffffull) return CLAPGPU_ERR_TOO_LARGE;
+    }
+    return CLAPGPU_OK;
+}
+
+extern "C" int clapgpu_visible_compact_ranges(void *stream, const uint64_t *gathered_mask, uint32_t n_ranges, uint32_t cap_pad,
+                                              const uint32_t *base, const uint32_t *n_pad, uint32_t *visible, uint32_t *count,
+                                              void *scratch)
+{
+    if (!gathered_mask || !visible || !count || !scratch) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    int rc = check_ranges(n_ranges, cap_pad, base, n_pad);
+    if (rc) return rc;
+    SegK sg = {};
+    sg.cap_words = cap_pad / 64; sg.n_seg = n_ranges;
+    for (uint32_t r = 0; r < n_ranges; r++) { sg.base[r] = base[r]; sg.n_words[r] = (n_pad ? n_pad[r] : cap_pad) / 64; }
+    const uint64_t total_words = (uint64_t)sg.cap_words * n_ranges;
+    if (total_words * 64 > 0xffffffffull) return CLAPGPU_ERR_TOO_LARGE;
+    const uint32_t n_groups = (uint32_t)((total_words + GROUP_WORDS - 1) / GROUP_WORDS);
+    uint32_t *group_count = static_cast<uint32_t *>(scratch);       // clapgpu_visible_scratch_bytes(n_ranges * cap_pad)
+    hipLaunchKernelGGL(k_mask_group_count_seg, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), gathered_mask, sg, group_count);
+    CLAPGPU_LAUNCH_CHECK("k_mask_group_count_seg");
+    hipLaunchKernelGGL(k_visible_expand_seg, dim3(n_groups), dim3(WAVE), 0, as_stream(stream), gathered_mask, sg, group_count, n_groups,
+                       visible, count);
+    CLAPGPU_LAUNCH_CHECK("k_visible_expand_seg");
+    return CLAPGPU_OK;
+}
+
+// The same expansion on the host: what a rank without the device list needs, and the checker of the kernels above
+// (tests/test_shard_cpu.py runs eight gloo ranks through it).  Returns the number of ids; writes at most `capacity`.
+extern "C" uint32_t clapgpu_visible_expand_ranges_host(const uint64_t *gathered_mask, uint32_t n_ranges, uint32_t cap_pad,
+                                                       const uint32_t *base, const uint32_t *n_pad, uint32_t *visible, uint32_t capacity)
+{
+    if (!gathered_mask || check_ranges(n_ranges, cap_pad, base, n_pad)) return 0;
+    const uint32_t cap_words = cap_pad / 64;
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < n_ranges; r++) {
+        const uint32_t words = (n_pad ? n_pad[r] : cap_pad) / 64;
+        for (uint32_t w = 0; w < words; w++) {
+            uint64_t m = gathered_mask[(size_t)r * cap_words + w];
+            while (m) {
+                const uint32_t id = base[r] + w * 64u + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (visible && cnt < capacity) visible[cnt] = id;
+                cnt++;
+            }
+        }
+    }
+    return cnt;
 }
 
 extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t *visible,

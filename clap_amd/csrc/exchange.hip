@@ -136,6 +136,42 @@ extern "C" int clapgpu_exchange_visible(void *stream, clapgpu_exchange *x, const
     return clapgpu_visible_compact(stream, gathered_mask, nullptr, n_pad * (uint32_t)x->world, 0, visible, visible_count, scratch);
 }
 
+// Uneven shards (what clapgpu_shard_tile_range cuts from a real scene): every rank sends cap_pad / 64 words -- its own mask,
+// zero beyond its n_pad -- and expands the gathered array with rank r's slot i numbered base[r] + i: scene-global ids, the
+// identical ascending list on every rank.  base / n_pad: HOST arrays of `world` entries, the same on every rank
+// (clapgpu_shard_bases).
+extern "C" int clapgpu_exchange_visible_ranges(void *stream, clapgpu_exchange *x, const uint64_t *vis_mask, uint32_t cap_pad,
+                                               const uint32_t *base, const uint32_t *n_pad, uint64_t *gathered_mask,
+                                               uint32_t *visible, uint32_t *visible_count, void *scratch)
+{
+    if (!x || !vis_mask || !gathered_mask || !base || !cap_pad || (cap_pad & 63u)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (g_rccl.allgather(vis_mask, gathered_mask, cap_pad / 64, NCCL_UINT64, x->comm, clapgpu::as_stream(stream)))
+        return CLAPGPU_ERR_UNKNOWN;
+    if (!visible) return CLAPGPU_OK;                             // the caller only wants the gathered mask
+    if (!visible_count || !scratch) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    return clapgpu_visible_compact_ranges(stream, gathered_mask, (uint32_t)x->world, cap_pad, base, n_pad, visible, visible_count, scratch);
+}
+
+// Every rank's first global id and padded size for the cut clapgpu_shard_tile_range makes (rank r owns rows
+// [tile_row_start[first_r], tile_row_start[end_r])), and the common capacity = the largest shard.  Host code.
+extern "C" int clapgpu_shard_bases(const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t world, uint32_t *base, uint32_t *n_pad,
+                                   uint32_t *cap_pad)
+{
+    if (!tile_row_start || !base || !n_pad || !world) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    uint32_t cap = 64;
+    for (uint32_t r = 0; r < world; r++) {
+        uint32_t t0, t1;
+        int rc = clapgpu_shard_tile_range(tile_row_start, n_tiles, r, world, &t0, &t1);
+        if (rc) return rc;
+        const uint64_t b = (uint64_t)(tile_row_start[t0] - tile_row_start[0]) * 64, n = (uint64_t)(tile_row_start[t1] - tile_row_start[t0]) * 64;
+        if (b + n > 0xffffffffull) return CLAPGPU_ERR_TOO_LARGE;
+        base[r] = (uint32_t)b; n_pad[r] = (uint32_t)n;
+        if (n > cap) cap = (uint32_t)n;
+    }
+    if (cap_pad) *cap_pad = cap;
+    return CLAPGPU_OK;
+}
+
 // Contiguous tile ranges of (nearly) equal row count: whole tiles = whole subtrees stay on one rank, so the update needs
 // no collective.  tile_row_start: n_tiles + 1 ascending row offsets (host).
 extern "C" int clapgpu_shard_tile_range(const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t rank, uint32_t world,

@@ -43,11 +43,19 @@ int frame_streams(FrameStreams **out)
     CLAPGPU_HIP(hipGetDevice(&dev));
     if (g_fs.dev != dev) {                                       // per thread and device, for the life of the process
         FrameStreams n = { dev, nullptr, nullptr, nullptr, nullptr, nullptr };
-        CLAPGPU_HIP(hipStreamCreateWithFlags(&n.b, hipStreamNonBlocking));
-        CLAPGPU_HIP(hipStreamCreateWithFlags(&n.c, hipStreamNonBlocking));
-        CLAPGPU_HIP(hipEventCreateWithFlags(&n.fork, hipEventDisableTiming));
-        CLAPGPU_HIP(hipEventCreateWithFlags(&n.join_b, hipEventDisableTiming));
-        CLAPGPU_HIP(hipEventCreateWithFlags(&n.join_c, hipEventDisableTiming));
+        hipError_t err = hipStreamCreateWithFlags(&n.b, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&n.c, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&n.fork, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&n.join_b, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&n.join_c, hipEventDisableTiming);
+        if (err != hipSuccess) {                                 // nothing half-made is kept (or leaked)
+            if (n.b) (void)hipStreamDestroy(n.b);
+            if (n.c) (void)hipStreamDestroy(n.c);
+            if (n.fork) (void)hipEventDestroy(n.fork);
+            if (n.join_b) (void)hipEventDestroy(n.join_b);
+            if (n.join_c) (void)hipEventDestroy(n.join_c);
+            return hip_fail(err, "clapgpu_frame_issue: helper streams");
+        }
         g_fs = n;
     }
     *out = &g_fs;
@@ -55,10 +63,16 @@ int frame_streams(FrameStreams **out)
 }
 } // namespace
 
+// Everything between the fork and the join of an overlapped frame.  Whatever it returns, the caller joins the helper
+// streams before it returns itself: a failed launch in chain A must not leave the caller's stream unordered behind pose,
+// skinning and particles work that is still writing (and, under stream capture, must not leave forked streams unjoined:
+// EndCapture would fail and invalidate the capture).
+static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t substeps, bool overlap, FrameStreams *fs,
+                      void *sb, void *sc, bool *joined);
+
 extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double now, uint32_t substeps)
 {
     if (!f || !f->entities) return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    const clapgpu_entities *e = f->entities;
     const bool animated = f->skeleton && f->animations && f->pose;
     const bool particles = f->particles && f->view_mx;
     const bool overlap = (f->flags & CLAPGPU_FRAME_OVERLAP) && (animated || particles);
@@ -67,9 +81,38 @@ extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double 
     if (overlap) {
         FR(frame_streams(&fs));
         CLAPGPU_HIP(hipEventRecord(fs->fork, as_stream(stream)));
-        if (animated) { CLAPGPU_HIP(hipStreamWaitEvent(fs->b, fs->fork, 0)); sb = fs->b; }
-        if (particles) { CLAPGPU_HIP(hipStreamWaitEvent(fs->c, fs->fork, 0)); sc = fs->c; }
+        if (animated) {
+            const hipError_t err = hipStreamWaitEvent(fs->b, fs->fork, 0);
+            if (err != hipSuccess) return hip_fail(err, "clapgpu_frame_issue: fork");      // nothing forked yet
+            sb = fs->b;
+        }
+        if (particles) {
+            const hipError_t err = hipStreamWaitEvent(fs->c, fs->fork, 0);
+            if (err != hipSuccess) {
+                if (animated) {                                  // b is forked already: join it before giving up
+                    (void)hipEventRecord(fs->join_b, fs->b);
+                    (void)hipStreamWaitEvent(as_stream(stream), fs->join_b, 0);
+                }
+                return hip_fail(err, "clapgpu_frame_issue: fork");
+            }
+            sc = fs->c;
+        }
     }
+    bool joined = false;
+    const int rc = frame_body(stream, f, now, substeps, overlap, fs, sb, sc, &joined);
+    if (overlap && !joined) {                                    // an early exit: the one join every path goes through
+        if (animated) { (void)hipEventRecord(fs->join_b, fs->b); (void)hipStreamWaitEvent(as_stream(stream), fs->join_b, 0); }
+        if (particles) { (void)hipEventRecord(fs->join_c, fs->c); (void)hipStreamWaitEvent(as_stream(stream), fs->join_c, 0); }
+    }
+    return rc;
+}
+
+static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t substeps, bool overlap, FrameStreams *fs,
+                      void *sb, void *sc, bool *joined)
+{
+    const clapgpu_entities *e = f->entities;
+    const bool animated = f->skeleton && f->animations && f->pose;
+    const bool particles = f->particles && f->view_mx;
     // joint positions need e->mx: with the chains apart k_pose stops at the model-space position
     clapgpu_pose_batch pose_b;
     bool finish_pos = false;
@@ -146,6 +189,7 @@ extern "C" int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double 
         FR(clapgpu_entities_update(stream, e, f->level_start, f->n_levels, 0, f->frustum));
 
     if (overlap) {                                               // join
+        *joined = true;                                          // (a failure inside these four calls cannot be joined any better by the caller)
         if (animated) { CLAPGPU_HIP(hipEventRecord(fs->join_b, fs->b)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_b, 0)); }
         if (particles) { CLAPGPU_HIP(hipEventRecord(fs->join_c, fs->c)); CLAPGPU_HIP(hipStreamWaitEvent(as_stream(stream), fs->join_c, 0)); }
         if (finish_pos) FR(clapgpu_joint_pos_world(stream, f->skeleton, f->pose));

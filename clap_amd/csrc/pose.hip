@@ -891,12 +891,29 @@ extern "C" int clapgpu_animations_pack(void *stream, const clapgpu_animations *a
         if ((size_t)t_off + nr > n_times) n_times = (size_t)t_off + nr;
         if ((size_t)d_off + (size_t)nr * stride > n_data) n_data = (size_t)d_off + (size_t)nr * stride;
     }
-    if (an->n_times && n_times > an->n_times)
-        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if ((an->n_times && n_times > an->n_times) || (an->n_data && n_data > an->n_data))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;                     // a channel record that reads past its pool
     std::vector<float> times(n_times ? n_times : 1), data(n_data ? n_data : 1);
     if (n_times) CLAPGPU_HIP(hipMemcpyAsync(times.data(), an->times, n_times * 4, hipMemcpyDeviceToHost, s));
     if (n_data) CLAPGPU_HIP(hipMemcpyAsync(data.data(), an->data, n_data * 4, hipMemcpyDeviceToHost, s));
     CLAPGPU_HIP(hipStreamSynchronize(s));
+
+    // The kernel's bracket search counts the keys below the time (lo = #{t[k] < time}); that is channel_time_to_idx
+    // (model.c:1266-1288) for strictly increasing key times and for nothing else: the reference's cursor-dependent scan
+    // gives other pairs on equal or descending times.  Such an asset is refused here, once, not mis-posed every frame.
+    for (size_t q = 0; q < (size_t)A * J * 3; q++) {
+        const uint32_t nr = tab[4 * q + 2];
+        if ((int32_t)nr <= 1) continue;
+        const float *t = times.data() + tab[4 * q];
+        for (uint32_t k = 0; k + 1 < nr; k++)
+            if (!(t[k] < t[k + 1])) {
+                char msg[160];
+                snprintf(msg, sizeof(msg), "clapgpu_animations_pack: key times of animation %zu joint %zu path %zu are not strictly increasing at key %u",
+                         q / (3 * (size_t)J), (q / 3) % J, q % 3, k);
+                set_last_error(msg);
+                return CLAPGPU_ERR_INVALID_ARGUMENTS;
+            }
+    }
 
     const size_t total = clapgpu_animations_packed_bytes(A, kk, J);
     std::vector<unsigned char> img(total, 0);
@@ -1000,6 +1017,13 @@ extern "C" int clapgpu_pose_update(void *stream, const clapgpu_skeleton *sk, con
         return CLAPGPU_OK;
     if (pb->skip & ~(uint32_t)(CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS | CLAPGPU_POSE_JOINT_POS_MODEL))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    // A (joint, path) without a channel keeps the joint's last interpolated value (model.c:1301): the kernel re-reads it
+    // from trs[], so a model with such paths cannot run with trs[] left unwritten -- a character that switches from an
+    // animation with the channel to one without would pose from the values of its first frame.
+    if ((pb->skip & CLAPGPU_POSE_SKIP_TRS) && (an->packed_layout & POSE_LAYOUT_TAG) && (an->packed_layout & POSE_LAYOUT_MISSING)) {
+        set_last_error("clapgpu_pose_update: CLAPGPU_POSE_SKIP_TRS with a model some of whose (joint, path) pairs have no channel");
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    }
     if (!pb->anim || !pb->frame_time || !pb->trs || !pb->joint_transforms ||
         (pb->joint_pos && !pb->entity_mx && !(pb->skip & (CLAPGPU_POSE_SKIP_JOINT_POS | CLAPGPU_POSE_JOINT_POS_MODEL))))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <string>
+#include <atomic>
 #include "common.h"
 #include "lm_dev.h"
 
@@ -28,22 +29,33 @@ int hip_fail(hipError_t err, const char *what)
     return CLAPGPU_ERR_UNKNOWN;
 }
 
-// clapgpu_test_fail_after(): < 0 = off; otherwise the number of launch checks that still pass
-static int g_fail_after = -1;
+void set_last_error(const char *what) { g_last_error = what; }
+
+// clapgpu_test_fail_after(): < 0 = off; otherwise the number of launch checks that still pass.  Read by every launch
+// check on any thread (the bindings' workers, a frame thread): atomic, and armed only in a process that asked for the
+// hook in its environment -- a stray call in a shipping process must not turn a healthy device into permanent host
+// fallback.
+static std::atomic<int> g_fail_after{-1};
 
 hipError_t launch_error()
 {
     const hipError_t e = hipGetLastError();
-    if (g_fail_after < 0 || e != hipSuccess) return e;
-    if (g_fail_after > 0) { g_fail_after--; return e; }
-    return hipErrorLaunchFailure;                                // injected: the kernel itself ran
+    int left = g_fail_after.load(std::memory_order_relaxed);
+    if (left < 0 || e != hipSuccess) return e;
+    while (left > 0)
+        if (g_fail_after.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) return e;
+    return left == 0 ? hipErrorLaunchFailure : e;                // injected: the kernel itself ran
 }
 
 } // namespace clapgpu
 
 using namespace clapgpu;
 
-extern "C" void clapgpu_test_fail_after(int launches) { g_fail_after = launches; }
+extern "C" void clapgpu_test_fail_after(int launches)
+{
+    static const bool armed = getenv("CLAPGPU_TEST_HOOKS") != nullptr;   // tests/test_dropin.py, oracle/ref/dropin.c `fail` set it
+    if (armed || launches < 0) g_fail_after.store(launches, std::memory_order_relaxed);
+}
 
 extern "C" uint32_t clapgpu_abi_version(void) { return CLAPGPU_ABI_VERSION; }
 

@@ -28,6 +28,32 @@ def shard_tile_ranges(rows_per_tile, world):
     return out
 
 
+def shard_bases(tile_row_start, world):
+    """(base[world], n_pad[world], cap_pad) of the cut shard_tile_ranges() makes: every rank's first scene-global id, its
+    padded size and the largest size (clapgpu_shard_bases, host C: the same arithmetic every rank runs)."""
+    import ctypes as C
+    from . import _lib
+    trs = np.ascontiguousarray(tile_row_start, np.uint32)
+    base, n_pad, cap = np.zeros(world, np.uint32), np.zeros(world, np.uint32), C.c_uint32()
+    _lib.check(_lib.lib().clapgpu_shard_bases(trs.ctypes.data, len(trs) - 1, world, base.ctypes.data, n_pad.ctypes.data,
+                                              C.byref(cap)), "clapgpu_shard_bases")
+    return base, n_pad, int(cap.value)
+
+
+def expand_ranges_host(gathered_mask, world, cap_pad, base, n_pad):
+    """The gathered per-rank masks (world * cap_pad / 64 words, rank-major) as the ascending scene-global id list:
+    clapgpu_visible_expand_ranges_host, the host twin of the expansion kernel (same id arithmetic)."""
+    from . import _lib
+    g = np.ascontiguousarray(gathered_mask).view(np.uint64)
+    base, n_pad = np.ascontiguousarray(base, np.uint32), np.ascontiguousarray(n_pad, np.uint32)
+    L = _lib.lib()
+    n = L.clapgpu_visible_expand_ranges_host(g.ctypes.data, world, cap_pad, base.ctypes.data, n_pad.ctypes.data, None, 0)
+    out = np.zeros(max(int(n), 1), np.uint32)
+    got = L.clapgpu_visible_expand_ranges_host(g.ctypes.data, world, cap_pad, base.ctypes.data, n_pad.ctypes.data, out.ctypes.data, int(n))
+    assert got == n
+    return out[:n]
+
+
 def allgather_visible(visible, count, world, counts_buf=None, gather_buf=None, pad_to=4096, group=None):
     """visible: this rank's ascending global ids (capacity >= its count), count: 1-element tensor.
     Returns (counts[world] on device, gathered[world, cap] tensor); rank r's ids are
@@ -80,13 +106,28 @@ class VisibleExchange:
         self._C, self._lib = C, _lib
         self.batch, self.rank, self.world, self.device = batch, rank, world, device
         self.n_pad = batch.n
-        n_words = batch.vis_mask.numel()
-        self.masks = [batch.vis_mask, torch.zeros_like(batch.vis_mask)]
+        # shards need not be equal (clapgpu_shard_tile_range cuts whole tiles; a rank may be empty): every rank's padded
+        # size, its first scene-global id (ascending ranges in rank order) and the common capacity the collective carries
+        sizes = torch.zeros(world, dtype=torch.int64, device=device)
+        sizes[rank] = self.n_pad
+        dist.all_reduce(sizes)
+        self.n_pad_all = np.ascontiguousarray(sizes.cpu().numpy(), np.uint32)
+        self.base = np.ascontiguousarray(np.concatenate([[0], np.cumsum(self.n_pad_all.astype(np.int64))[:-1]]), np.uint32)
+        self.cap_pad = max(64, int(self.n_pad_all.max()))
+        if int(self.n_pad_all.astype(np.int64).sum()) > 0xffffffff:
+            raise ValueError("the scene's global ids do not fit 32 bits")
+        n_words = self.cap_pad // 64
+        own = batch.vis_mask.numel()
+
+        def mask_buf():                                      # cap_pad / 64 words, zero beyond this rank's own
+            return torch.zeros(n_words, dtype=batch.vis_mask.dtype, device=device)
+        self.masks = [mask_buf(), mask_buf()]
+        self.masks[0][:own].copy_(batch.vis_mask)
         self.pops = [batch.vis_row_pop, torch.zeros_like(batch.vis_row_pop)]
         self.g_mask = [torch.zeros(world * n_words, dtype=torch.int64, device=device) for _ in range(2)]
-        self.g_vis = [torch.zeros(world * self.n_pad, dtype=torch.int32, device=device) for _ in range(2)]
+        self.g_vis = [torch.zeros(world * self.cap_pad, dtype=torch.int32, device=device) for _ in range(2)]
         self.g_cnt = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
-        nscratch = _lib.lib().clapgpu_visible_scratch_bytes(world * self.n_pad)
+        nscratch = _lib.lib().clapgpu_visible_scratch_bytes(world * self.cap_pad)
         self.g_scratch = torch.zeros(nscratch // 4 + 4, dtype=torch.int32, device=device)
         self.comm = torch.cuda.Stream(device=device)
         self.ev_upd = [torch.cuda.Event() for _ in range(2)]
@@ -156,17 +197,19 @@ class VisibleExchange:
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ev_upd[b])
             if self.direct is not None:                    # allgather + expansion: one C call on the side stream
-                rc = _lib.lib().clapgpu_exchange_visible(C.c_void_p(self.comm.cuda_stream), self.direct,
-                                                         self.masks[b].data_ptr(), self.n_pad, self.g_mask[b].data_ptr(),
-                                                         self.g_vis[b].data_ptr(), self.g_cnt[b].data_ptr(),
-                                                         self.g_scratch.data_ptr())
-                _lib.check(rc, "clapgpu_exchange_visible")
+                rc = _lib.lib().clapgpu_exchange_visible_ranges(C.c_void_p(self.comm.cuda_stream), self.direct,
+                                                                self.masks[b].data_ptr(), self.cap_pad, self.base.ctypes.data,
+                                                                self.n_pad_all.ctypes.data, self.g_mask[b].data_ptr(),
+                                                                self.g_vis[b].data_ptr(), self.g_cnt[b].data_ptr(),
+                                                                self.g_scratch.data_ptr())
+                _lib.check(rc, "clapgpu_exchange_visible_ranges")
             else:
                 allgather_visible_mask(self.masks[b], self.world, self.g_mask[b])
-                rc = _lib.lib().clapgpu_visible_compact(C.c_void_p(self.comm.cuda_stream), self.g_mask[b].data_ptr(), None,
-                                                        self.world * self.n_pad, 0, self.g_vis[b].data_ptr(),
-                                                        self.g_cnt[b].data_ptr(), self.g_scratch.data_ptr())
-                _lib.check(rc, "clapgpu_visible_compact(global)")
+                rc = _lib.lib().clapgpu_visible_compact_ranges(C.c_void_p(self.comm.cuda_stream), self.g_mask[b].data_ptr(),
+                                                               self.world, self.cap_pad, self.base.ctypes.data,
+                                                               self.n_pad_all.ctypes.data, self.g_vis[b].data_ptr(),
+                                                               self.g_cnt[b].data_ptr(), self.g_scratch.data_ptr())
+                _lib.check(rc, "clapgpu_visible_compact_ranges(global)")
             self.ev_comm[b].record(self.comm)
 
     def last(self):

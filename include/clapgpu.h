@@ -52,7 +52,8 @@ int clapgpu_init(int device);
 const char *clapgpu_last_error(void);
 /* For the CALLERS' failure-path tests (oracle/ref/dropin.c `fail`, tests/test_dropin.py): after `launches` more kernel
  * launches have been checked, every later launch of this process reports a launch failure (the kernel itself runs;
- * the entry point returns CLAPGPU_ERR_UNKNOWN with clapgpu_last_error() set).  < 0 turns it off (the default). */
+ * the entry point returns CLAPGPU_ERR_UNKNOWN with clapgpu_last_error() set).  < 0 turns it off (the default).  Armed only
+ * in a process started with CLAPGPU_TEST_HOOKS in its environment: anywhere else the call does nothing. */
 void clapgpu_test_fail_after(int launches);
 /* ABI version: bumped whenever a signature or struct below changes. */
 uint32_t clapgpu_abi_version(void);
@@ -367,6 +368,22 @@ int  clapgpu_exchange_info(const clapgpu_exchange *x, int *comm_ranks, int *comm
 void clapgpu_exchange_destroy(clapgpu_exchange *x);
 int  clapgpu_exchange_visible(void *stream, clapgpu_exchange *x, const uint64_t *vis_mask, uint32_t n_pad,
                               uint64_t *gathered_mask, uint32_t *visible, uint32_t *visible_count, void *scratch);
+/* ... for shards of DIFFERENT sizes (the ranges clapgpu_shard_tile_range cuts from one scene are only nearly equal; a rank
+ * may even be empty): every rank sends cap_pad / 64 words -- its own mask, zero beyond its n_pad[rank] -- and rank r's slot i
+ * gets the scene-global id base[r] + i.  base / n_pad: HOST arrays of `world` entries, identical on every rank, ascending and
+ * disjoint (clapgpu_shard_bases makes them); gathered_mask: world * cap_pad / 64 words; visible / scratch sized for
+ * world * cap_pad entities (clapgpu_visible_scratch_bytes).  clapgpu_visible_compact_ranges is the expansion alone (the
+ * exchange's second half: testable on one GPU), clapgpu_visible_expand_ranges_host the same on the host. */
+int  clapgpu_exchange_visible_ranges(void *stream, clapgpu_exchange *x, const uint64_t *vis_mask, uint32_t cap_pad,
+                                     const uint32_t *base, const uint32_t *n_pad, uint64_t *gathered_mask,
+                                     uint32_t *visible, uint32_t *visible_count, void *scratch);
+int  clapgpu_visible_compact_ranges(void *stream, const uint64_t *gathered_mask, uint32_t n_ranges, uint32_t cap_pad,
+                                    const uint32_t *base, const uint32_t *n_pad, uint32_t *visible, uint32_t *count, void *scratch);
+uint32_t clapgpu_visible_expand_ranges_host(const uint64_t *gathered_mask, uint32_t n_ranges, uint32_t cap_pad,
+                                            const uint32_t *base, const uint32_t *n_pad, uint32_t *visible, uint32_t capacity);
+/* first global id, padded size of every rank's shard and the largest of them, for clapgpu_shard_tile_range's cut (host) */
+int  clapgpu_shard_bases(const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t world, uint32_t *base, uint32_t *n_pad,
+                         uint32_t *cap_pad);
 
 /* ======================================================================== */
 /* Particle systems: advect / respawn / billboard (core/particle.c)          */
@@ -477,10 +494,14 @@ typedef struct clapgpu_animations {
      * 64 joints, two to four above. */
     const void     *packed;
     uint32_t        packed_keys, packed_layout;
+    uint32_t        n_data, pad;    /* floats in data[] (0: unknown): with it clapgpu_animations_pack() refuses a channel that reads past the pool */
 } clapgpu_animations;
 
 /* Key-major pools, once per model: a HOST-side re-layout of chan_table / times / data (three synchronous copies on
- * `stream`) plus the rotation intervals' constants.  max_keys = the largest nr of any channel; packed:
+ * `stream`) plus the rotation intervals' constants.  Checks what the kernel's exactness rests on: every channel's key times
+ * strictly increasing (glTF requires it; the kernel's branch-free bracket equals channel_time_to_idx, model.c:1266-1288, only
+ * then -- a channel with equal or descending times returns CLAPGPU_ERR_INVALID_ARGUMENTS and the caller keeps such a model on
+ * the host path), no channel longer than max_keys or reaching past n_times / n_data.  max_keys = the largest nr of any channel; packed:
  * clapgpu_animations_packed_bytes() of device memory, 16-byte aligned; *packed_layout goes into
  * clapgpu_animations.packed_layout (clapgpu_pose_update rejects pools made for another skeleton class or animation count). */
 size_t clapgpu_animations_packed_bytes(uint32_t n_anims, uint32_t max_keys, uint32_t nr_joints);
@@ -501,8 +522,10 @@ int    clapgpu_animations_pack(void *stream, const clapgpu_animations *an, uint3
  *   skip           CLAPGPU_POSE_SKIP_*: outputs nothing reads this frame.  struct joint's translation / rotation / scale
  *                  and pos are host-visible state whose only per-frame reader is one_joint_transform itself
  *                  (model.c:1352-1404) and camera_target (camera.c:191-205); the draw path consumes joint_transforms
- *                  alone (model.c:1020-1022).  With SKIP_TRS the blended T/R/S stay in registers (trs is still read
- *                  for paths no channel drives); that is 40 of the 120 bytes a joint writes, joint_pos another 16.
+ *                  alone (model.c:1020-1022).  With SKIP_TRS the blended T/R/S stay in registers; that is 40 of the 120
+ *                  bytes a joint writes, joint_pos another 16.  SKIP_TRS is refused (CLAPGPU_ERR_INVALID_ARGUMENTS) for a
+ *                  model some of whose (joint, path) pairs have no channel in some animation: such a path keeps the
+ *                  joint's LAST interpolated value (model.c:1301), which lives in trs[].
  */
 #define CLAPGPU_POSE_SKIP_TRS        (1u << 0)
 #define CLAPGPU_POSE_SKIP_JOINT_POS  (1u << 1)

@@ -1688,6 +1688,7 @@ static int run(int argc, char **argv)
         else break;
     }
     if (argc >= 6 && !strcmp(argv[1], "fail")) {                        /* fail <launches> <entities> <frames> <seed>: `test` with the device failing after <launches> launches */
+        setenv("CLAPGPU_TEST_HOOKS", "1", 1);                            /* the hook is armed only where the environment asks for it */
         clapgpu_test_fail_after(atoi(argv[2]));
         return cmd_test((uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     }

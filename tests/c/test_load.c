@@ -178,7 +178,7 @@ static int replay(clapgpu_snapshot *s)
     UP(d_vpos, vpos, 12 * V); UP(d_vnor, vnor, 12 * V); UP(d_vj, vj, 4 * V); UP(d_vw, vw, 16 * V); UP(d_vf, vf, 4 * nc); UP(d_vc, vc, 4 * nc);
     UP(d_op, NULL, (size_t)12 * V * nc); UP(d_on, NULL, (size_t)12 * V * nc);
     const clapgpu_skeleton sk = { J, levels, d_parent, d_depth, d_root, d_inv, d_bind };
-    clapgpu_animations an = { n_anims, t_total, d_table, d_times, d_data, NULL, 0, 0 };
+    clapgpu_animations an = { n_anims, t_total, d_table, d_times, d_data, NULL, 0, 0, d_total, 0 };
     {                                                                   /* the key-major pools (required): once per model */
         uint32_t max_keys = 0, layout = 0;
         void *d_packed;

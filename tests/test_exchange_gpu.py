@@ -95,3 +95,48 @@ def test_gathered_mask_expands_with_index_base(cuda_device, process_group):
     vis, _mask = _oracle_visible(scene, cam)
     got = out[:int(cnt.item())].cpu().numpy().astype(np.int64)
     assert np.array_equal(got, vis.astype(np.int64) + base)
+
+
+def test_gathered_masks_of_uneven_shards_expand_to_scene_global_ids(cuda_device):
+    """The second half of clapgpu_exchange_visible_ranges on one GPU: eight ranks' masks as a gathered array -- uneven
+    shards cut by clapgpu_shard_tile_range, two of them empty, every segment padded to the common capacity, garbage
+    beyond each rank's own words (a sender zeroes them; the expansion must not depend on it) -- expanded by
+    clapgpu_visible_compact_ranges into the ascending scene-global list, against the host twin
+    (clapgpu_visible_expand_ranges_host, which test_shard_cpu.py runs over eight gloo ranks) and the oracle's
+    single-scene visible set."""
+    import ctypes as C
+    import torch
+    from clap_amd import _lib, shard
+    world = 8
+    scene, _tl = tiler.tiled_scene(synth.entities_forest(1100, seed=77, max_depth=7))
+    trs = scene["tile_row_start"].astype(np.int64)
+    base, n_pad, cap_pad = shard.shard_bases(trs, world)
+    assert (n_pad == 0).any() and len(set(int(x) for x in n_pad if x)) > 1
+    cam = synth.camera(pos=(0, 5, 60))
+    vis, mask = _oracle_visible(scene, cam)
+    cw = cap_pad // 64
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 2 ** 63, world * cw, dtype=np.int64).view(np.uint64)       # garbage everywhere ...
+    for r in range(world):
+        w0, nw = int(base[r]) // 64, int(n_pad[r]) // 64
+        g[r * cw:r * cw + nw] = mask[w0:w0 + nw]                                    # ... but each rank's own words
+    host = shard.expand_ranges_host(g, world, cap_pad, base, n_pad)
+    assert np.array_equal(host, vis.astype(np.uint32))
+    L = _lib.lib()
+    d_g = torch.from_numpy(g.view(np.int64).copy()).to(cuda_device)
+    out = torch.zeros(world * cap_pad, dtype=torch.int32, device=cuda_device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    scratch = torch.zeros(L.clapgpu_visible_scratch_bytes(world * cap_pad) // 4 + 4, dtype=torch.int32, device=cuda_device)
+    rc = L.clapgpu_visible_compact_ranges(C.c_void_p(torch.cuda.current_stream().cuda_stream), d_g.data_ptr(), world, cap_pad,
+                                          base.ctypes.data, n_pad.ctypes.data, out.data_ptr(), cnt.data_ptr(), scratch.data_ptr())
+    _lib.check(rc, "clapgpu_visible_compact_ranges")
+    torch.cuda.synchronize()
+    got = out[:int(cnt.item())].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, vis.astype(np.uint32))
+    # refusals: overlapping or descending ranges, a size that is not a whole row
+    bad = base.copy(); bad[2] = bad[0]
+    assert L.clapgpu_visible_compact_ranges(None, d_g.data_ptr(), world, cap_pad, bad.ctypes.data, n_pad.ctypes.data, out.data_ptr(),
+                                            cnt.data_ptr(), scratch.data_ptr()) == _lib.ERR_INVALID_ARGUMENTS
+    odd = n_pad.copy(); odd[0] += 1
+    assert L.clapgpu_visible_compact_ranges(None, d_g.data_ptr(), world, cap_pad, base.ctypes.data, odd.ctypes.data, out.data_ptr(),
+                                            cnt.data_ptr(), scratch.data_ptr()) == _lib.ERR_INVALID_ARGUMENTS

@@ -427,6 +427,58 @@ def test_pose_update_rejects_pools_made_for_something_else(cuda_device):
     assert call(m64.anim_desc) == 0
 
 
+def test_pack_refuses_key_times_that_are_not_strictly_increasing(cuda_device):
+    """The kernel's branch-free bracket (the number of keys below the time) equals channel_time_to_idx
+    (core/model.c:1266-1288) for strictly increasing key times only; the reference's cursor-dependent scan gives other
+    pairs on equal or descending times.  clapgpu_animations_pack has every channel on the host once per model: it
+    refuses such an asset (so that the caller keeps the model on the host path) instead of mis-posing it every frame;
+    likewise a channel record that reaches past its pool."""
+    from clap_amd import _lib, animation
+    sk = synth.skeleton(64, 6, seed=5)
+    good = synth.animation(64, 8, 1.0, seed=5)
+    animation.SkinnedModel(sk, [good], device=cuda_device)                  # packs
+    for kind in ("equal", "descending"):
+        bad = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in good.items()}
+        c = 40                                                              # some channel in the middle
+        off, nr = int(bad["ch_time_off"][c]), int(bad["ch_nr"][c])
+        assert nr >= 4
+        if kind == "equal":
+            bad["times"][off + 2] = bad["times"][off + 1]
+        else:
+            bad["times"][off + 1], bad["times"][off + 2] = bad["times"][off + 2], bad["times"][off + 1]
+        with pytest.raises(Exception) as ei:
+            animation.SkinnedModel(sk, [bad], device=cuda_device)
+        assert "clapgpu_animations_pack" in str(ei.value)
+        assert "strictly increasing" in _lib.lib().clapgpu_last_error().decode()
+    past = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in good.items()}
+    past["ch_data_off"][-1] += 8                                            # the last channel's values end past data[]
+    with pytest.raises(Exception):
+        animation.SkinnedModel(sk, [past], device=cuda_device)
+
+
+def test_palette_only_mode_is_refused_where_a_path_has_no_channel(cuda_device):
+    """A (joint, path) without a channel keeps the joint's LAST interpolated value (core/model.c:1301), which lives in
+    trs[]: with CLAPGPU_POSE_SKIP_TRS trs[] is never written, and a character that switches from an animation with the
+    channel to one without it would pose from its first frame's values.  The combination is refused."""
+    import ctypes as C
+    from clap_amd import _lib, animation
+    sk = synth.skeleton(64, 6, seed=6)
+    full, holes = synth.animation(64, 8, 1.0, seed=6), synth.animation(64, 8, 1.0, seed=7, missing_frac=0.2)
+    ch = synth.characters(4, 64, seed=6)
+    L = _lib.lib()
+    for anims, ok in (([full], True), ([full, holes], False)):
+        m = animation.SkinnedModel(sk, anims, device=cuda_device)
+        b = animation.CharacterBatch(m, 4, ch["trs0"], ch["char_mx"])
+        b.set_frame_times(ch["phase"])
+        b.set_outputs(trs=False, joint_pos=True)
+        rc = L.clapgpu_pose_update(None, C.byref(m.skel_desc), C.byref(m.anim_desc), C.byref(b._pose_desc))
+        assert rc == (0 if ok else _lib.ERR_INVALID_ARGUMENTS)
+        if not ok:
+            assert "no channel" in L.clapgpu_last_error().decode()
+            b.set_outputs(trs=True, joint_pos=True)
+            assert L.clapgpu_pose_update(None, C.byref(m.skel_desc), C.byref(m.anim_desc), C.byref(b._pose_desc)) == 0
+
+
 def _skeleton_with_parents(parent, seed):
     """A synth.skeleton() whose tree is replaced by `parent` (joint 0 the root; -2 = not under joint 0)."""
     J = len(parent)

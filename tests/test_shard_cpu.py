@@ -87,6 +87,67 @@ def test_sharded_update_and_visible_allgather_world2():
     assert sorted(r[4] for r in res)[0][0] == 0
 
 
+def _worker_ranges(rank, world, port, q):
+    """World 8, UNEVEN shards, one of them EMPTY: the masks travel at the common capacity and are expanded with per-rank
+    bases -- clapgpu_shard_bases + clapgpu_visible_expand_ranges_host, the id arithmetic of clapgpu_exchange_visible_ranges."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as ob
+        scene, tl = tiler.tiled_scene(synth.entities_forest(1100, seed=77, max_depth=7))
+        trs = scene["tile_row_start"].astype(np.int64)
+        n_tiles = len(trs) - 1
+        cuts = shard.shard_tile_ranges(np.diff(trs), world)
+        base, n_pad, cap_pad = shard.shard_bases(trs, world)
+        t0, t1 = cuts[rank]
+        lo, hi = int(trs[t0]) * 64, int(trs[t1]) * 64
+        assert base[rank] == lo and n_pad[rank] == hi - lo and cap_pad == max(64, int(n_pad.max()))
+        cam = synth.camera(pos=(0, 5, 60))
+        fr, _v, _p = ob.frustum_from_camera(cam)
+        local = np.zeros(cap_pad // 64, np.uint64)               # zero beyond this rank's own words (all of it on an empty rank)
+        n_vis = 0
+        if hi > lo:
+            sub = {k: (scene[k][lo:hi].copy() if isinstance(scene[k], np.ndarray) and scene[k].shape[:1] == (scene["n"],)
+                       else scene[k]) for k in scene}
+            sub["n"] = hi - lo
+            sub["parent"] = np.where(sub["parent"] >= 0, sub["parent"] - lo, -1).astype(np.int32)
+            assert np.all(sub["parent"][sub["parent"] >= 0] < sub["n"]), "a subtree crosses a shard border"
+            st = ob.entity_state(sub)
+            ob.entities_update(sub, st)
+            vis, mask = ob.entities_cull(sub["n"], st["flags"], st["aabb"], fr)
+            local[:len(mask)] = mask
+            n_vis = len(vis)
+        g = shard.allgather_visible_mask(torch.from_numpy(local.view(np.int64)), world).numpy().view(np.uint64)
+        ids = shard.expand_ranges_host(g, world, cap_pad, base, n_pad)
+        st_all = ob.entity_state(scene)
+        ob.entities_update(scene, st_all)
+        vis_all, _m = ob.entities_cull(scene["n"], st_all["flags"], st_all["aabb"], fr)
+        ok = np.array_equal(ids, vis_all.astype(np.uint32)) and bool(np.all(np.diff(ids.astype(np.int64)) > 0))
+        q.put((rank, ok, n_vis, len(vis_all), int(n_pad[rank]), n_tiles, int(cap_pad)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_and_empty_shards_allgather_world8():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ranges, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [r[4] for r in res]
+    assert all(r[1] for r in res), "a rank's expanded global list differs from the single-process visible set"
+    assert sum(r[2] for r in res) == res[0][3] > 0
+    assert min(sizes) == 0, f"one shard was to be empty: {sizes} ({res[0][5]} tiles)"
+    assert len(set(s for s in sizes if s)) > 1, f"shards were to be uneven: {sizes}"
+    assert res[0][6] == max(sizes)
+
+
 def test_shard_tile_ranges_cover_and_balance():
     rows = np.asarray([8] * 100 + [1] * 37 + [3] * 11)
     for world in (1, 2, 3, 4, 8):
