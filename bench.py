@@ -37,6 +37,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# key order of the ONE line (short scalars first, the long sections last: a record that keeps the head of the line keeps
+# `summary` and `c5`), and the keys of the second leg an N > 1 run times beside the headline (BASELINE configs[4]'s share)
+LINE_ORDER = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "rccl_ranks", "devices", "ms_per_step_per_rank", "summary", "c5", "config", "roofline",
+              "cpu_baseline", "extra"]
+C5_KEYS = ["workload", "value", "unit", "particle_updates_per_s", "ms_per_step", "ms_per_step_per_rank", "steps", "warmup",
+           "entities_per_gpu", "particles_per_gpu", "visible", "global_ids", "scaling"]
 ROUND = "r05"
 
 
@@ -197,8 +204,14 @@ def dry_launch():
         dist.destroy_process_group()
         raise SystemExit(5)
     if rank == 0:
+        args = parse()
+        two_legs = world > 1 and args.chains == 125_000 and args.depth == 8 and args.particles == 0 and not args.c5 and not args.snapshot
         print(json.dumps({"launcher": "dry", "n_gpus": world, "rank_sum": int(t[0]), "local_rank_sum": int(t[1]),
-                          "ranks": int(t[2]), "rccl_ranks": proof["rccl_ranks"], "devices": proof["devices"]}), flush=True)
+                          "ranks": int(t[2]), "rccl_ranks": proof["rccl_ranks"], "devices": proof["devices"],
+                          # the shape of the line the GPU run of the same command prints: headline = configs[1] per GPU
+                          # (weak scaling), and with N > 1 and no explicit sizing the configs[4] share as a second leg
+                          "line_keys": [k for k in LINE_ORDER if k not in ("extra", "cpu_baseline") and (two_legs or k != "c5")],
+                          "c5_keys": C5_KEYS if two_legs else None}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -691,6 +704,36 @@ def full_frame(device):
                         "helper streams (CLAPGPU_FRAME_OVERLAP): they overlap and the frame is no shorter (csrc/frame.hip)"}
 
 
+def summary(out, extra):
+    """<= 12 scalars: what the long `extra` / `cpu_baseline` sections say, where a record that keeps only the head of the
+    line (or drops `extra`) still has them.  Microseconds per launch unless the key says otherwise."""
+    s = {}
+
+    def put(key, fn):
+        try:
+            v = fn()
+            if v is not None:
+                s[key] = round(float(v), 3)
+        except (KeyError, TypeError, IndexError):
+            pass
+    e = extra or {}
+    put("pose_us", lambda: e["pose_palette"]["characters"] * e["pose_palette"]["joints"] / e["pose_palette"]["joints_per_s"] * 1e6)
+    put("pose_palette_us", lambda: e["pose_palette"]["palette_only"]["us"])
+    put("skin_us", lambda: e["skinning"]["vertices"] / e["skinning"]["skinned_verts_per_s"] * 1e6)
+    put("particles_us", lambda: e["particles"]["particles"] / e["particles"]["particles_per_s"] * 1e6)
+    put("step_us", lambda: e["bodies"]["bodies"] / e["bodies"]["bodies_per_s_integrate"] * 1e6)
+    put("bp_us", lambda: e["bodies"]["broadphase"]["ms"] * 1e3)
+    put("contacts_us", lambda: e["bodies"]["contacts"]["us"])
+    put("frame_ms", lambda: e["full_frame"]["ms_per_frame"])
+    b = ((out.get("cpu_baseline") or {}).get("dropin_boundary") or {}).get("1000000_entities_100pct_dirty") or {}
+    d = b.get("scatter_drawn") or {}
+    put("boundary_1m_frame_ms", lambda: d["binding_frame_draw_list_ms"])
+    put("boundary_1m_mq_update_ms", lambda: d["binding_mq_update_ms"])
+    put("boundary_1m_frame_ms_scatter_all", lambda: b["binding_frame_draw_list_ms"])
+    put("boundary_1m_reference_frame_ms", lambda: b["reference_frame_ms"])
+    return s
+
+
 class RankStep:
     """One rank's share of the workload and its step, exactly what the timed loop runs (tests/test_c5_gpu.py drives this same
     object at BASELINE configs[4]'s per-rank size against the oracle).  Rank r owns block r of ONE global forest
@@ -701,7 +744,7 @@ class RankStep:
     side stream under the update of frame f + 1 (two mask buffers)."""
 
     def __init__(self, chains, depth, particles, rank, world, device, use_dist, route="rccl", layout="tiles", raw=None,
-                 cam=None, block=None):
+                 cam=None, block=None, share=None):
         from clap_amd import entities, shard, synth, tiler
         self.rank, self.world, self.use_dist = rank, world, use_dist
         comm_rank = rank
@@ -723,7 +766,8 @@ class RankStep:
             self.pstate0 = synth.DRAND48_DEFAULT_STATE + rank
             ppos, pvel, pstate = synth.particles_spawn(self.psys, self.pstate0)
             self.pbatch = particles_mod.ParticleBatch(self.psys, ppos, pvel, pstate, device)
-        self.xch = shard.VisibleExchange(self.batch, comm_rank, world, device, route=route) if use_dist else None
+        # `share`: a second workload of the same run rides the communicator the first one made (one ncclCommInitRank per run)
+        self.xch = shard.VisibleExchange(self.batch, comm_rank, world, device, route=route, share=share) if use_dist else None
 
     def step(self):
         if self.pbatch is not None:
@@ -798,26 +842,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    rank_ms = None
-    if use_dist:
-        mine = elapsed
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        t = torch.tensor([mine], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        rank_ms = {"min": float(t.item()) / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
+    def timed_leg(step_fn):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over ranks."""
+        for _ in range(args.warmup):
+            step_fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        fence()
+        mine = worst = time.perf_counter() - t0
+        per_rank = None
+        if use_dist:
+            t = torch.tensor([mine], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
+            t = torch.tensor([mine], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            per_rank = {"min": float(t.item()) / args.steps * 1e3, "max": worst / args.steps * 1e3}
+        return worst, per_rank
+
+    elapsed, rank_ms = timed_leg(step)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_real * args.steps / elapsed
     visible = int((xch.last()[0] if use_dist else batch.visible_count).item())
+
+    # ---- N > 1, no explicit sizing: BASELINE configs[4]'s per-rank share as a SECOND timed leg of the same run, the same
+    #      process group and the same communicator (16 M entities + 2 M particles at 8 GPUs).  The headline above stays
+    #      configs[1] per GPU -- comparable with the N = 1 line, which is what a scaling curve needs -- and the first run on
+    #      an N-GPU node measures the named 8-GPU configuration too, instead of leaving it to a second lease.
+    c5 = None
+    default_sizing = (args.chains == 125_000 and args.depth == 8 and args.particles == 0 and not args.c5 and not args.snapshot)
+    if use_dist and default_sizing and os.environ.get("CLAP_BENCH_NO_C5") != "1":
+        rs5 = RankStep(250_000, 8, 262_144, rank, world, device, use_dist=True, route=args.exchange, layout=args.layout, cam=cam,
+                       share=xch)
+        e5, rank_ms5 = timed_leg(rs5.step)
+        vis5 = int(rs5.xch.last()[0].item())
+        c5 = {"workload": f"BASELINE configs[4] per-GPU share: {rs5.batch.n_real} entities (250 000 chains x depth 8) + "
+                          f"{rs5.pbatch.n_real} particles per GPU = {world * rs5.batch.n_real} entities + "
+                          f"{world * rs5.pbatch.n_real} particles on {world} GPU(s); every step: particles_update, entity update + "
+                          "cull, allgather of the visibility masks, expansion to the global id list",
+              "value": world * rs5.batch.n_real * args.steps / e5, "unit": "entity updates/s",
+              "particle_updates_per_s": world * rs5.pbatch.n_real * args.steps / e5,
+              "ms_per_step": e5 / args.steps * 1e3, "ms_per_step_per_rank": rank_ms5, "steps": args.steps, "warmup": args.warmup,
+              "entities_per_gpu": rs5.batch.n_real, "particles_per_gpu": rs5.pbatch.n_real, "visible": vis5,
+              "global_ids": int(rs5.xch.n_pad_all.astype(np.int64).sum()), "scaling": "weak"}
+        rs5.xch.destroy()
+        rs5 = None
+        torch.cuda.empty_cache()
 
     # ---- roofline pass: HIP events around every launch of the dominant kernel (same stream) ----
     if batch.tiled:
@@ -885,19 +957,28 @@ def main():
             out["rccl_ranks"] = proof["rccl_ranks"]
             out["devices"] = proof["devices"]
             out["ms_per_step_per_rank"] = rank_ms
+        if c5 is not None:
+            out["c5"] = c5
+        extra = None
         if args.snapshot:
             out["data"] = "snapshot"
-            extra = snapshot_characters(comps, raw, device, args.steps, args.warmup)
-            if extra:
-                out["extra"] = {"snapshot_characters": extra}
+            ex = snapshot_characters(comps, raw, device, args.steps, args.warmup)
+            if ex:
+                extra = {"snapshot_characters": ex}
         if world == 1 and not args.no_extras and not args.snapshot:
             if xch is not None:
                 xch.destroy()
             xch = batch = pbatch = step = rs = None           # the extras want the HBM the headline scene holds
             torch.cuda.empty_cache()
-            out["extra"] = extras(device, testbed=not args.no_testbed)
+            extra = extras(device, testbed=not args.no_testbed)
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
+        # the secondary numbers a reader of a truncated record needs, as a dozen scalars BEFORE the long sections
+        out["summary"] = summary(out, extra)
+        if extra is not None:
+            out["extra"] = extra
+        assert c5 is None or list(c5) == C5_KEYS
+        out = {k: out[k] for k in LINE_ORDER if k in out} | {k: v for k, v in out.items() if k not in LINE_ORDER}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

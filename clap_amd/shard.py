@@ -100,7 +100,7 @@ class VisibleExchange:
     of frame f + 1: `begin()` hands the update kernel the mask buffer of this frame, `submit()` queues
     the exchange behind it.  Requires an initialised default process group."""
 
-    def __init__(self, batch, rank, world, device, route="rccl"):
+    def __init__(self, batch, rank, world, device, route="rccl", share=None):
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
@@ -134,7 +134,10 @@ class VisibleExchange:
         self.ev_comm = [torch.cuda.Event() for _ in range(2)]
         self.frame = 0
         self.direct = None
-        if route == "rccl":
+        self.owns_direct = True
+        if share is not None:                                # another workload of the same run: its communicator, its route
+            self.direct, self.owns_direct = share.direct, False
+        elif route == "rccl":
             import os
             import sys
             L = _lib.lib()
@@ -241,6 +244,6 @@ class VisibleExchange:
                     devices=[e["device"] for e in every])
 
     def destroy(self):
-        if self.direct is not None:
+        if self.direct is not None and self.owns_direct:
             self._lib.lib().clapgpu_exchange_destroy(self.direct)
-            self.direct = None
+        self.direct = None

@@ -24,8 +24,27 @@ def test_gpus2_without_torchrun_spawns_two_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     r = json.loads(lines[0])
+    shape = {k: r.pop(k) for k in ("line_keys", "c5_keys")}
     assert r == {"launcher": "dry", "n_gpus": 2, "rank_sum": 1, "local_rank_sum": 1, "ranks": 2,
                  "rccl_ranks": 2, "devices": ["cpu:0", "cpu:1"]}      # the line proves its own N: one device per rank
+    assert "c5" in shape["line_keys"] and shape["c5_keys"]
+
+
+def test_gpus8_line_has_the_configs4_leg_beside_the_weak_scaling_headline():
+    """What the driver runs on an 8-GPU node is plain `bench.py --gpus 8`: the headline stays BASELINE configs[1] per GPU
+    (comparable with N = 1: weak scaling), and the same run times configs[4]'s per-rank share -- 16 M entities + 2 M
+    particles in all -- as a second leg reported under `c5`; `summary` and `c5` come before the long sections.  An
+    explicit sizing (--c5, --chains ...) is one leg, as asked."""
+    p = _run(["--gpus", "8", "--dry-launch"], timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["rccl_ranks"] == 8 and len(set(r["devices"])) == 8
+    keys = r["line_keys"]
+    assert keys.index("summary") < keys.index("c5") < keys.index("config") < keys.index("roofline")
+    assert {"value", "ms_per_step", "entities_per_gpu", "particles_per_gpu", "visible", "particle_updates_per_s"} <= set(r["c5_keys"])
+    p = _run(["--gpus", "2", "--dry-launch", "--c5"])
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["c5_keys"] is None and "c5" not in r["line_keys"]
 
 
 def test_gpus4_ranks_are_distinct():

@@ -124,3 +124,30 @@ def test_16m_id_global_expansion_matches_numpy(cuda_device):
     e2 = expect[expect < n_odd]
     assert int(cnt_t.item()) == e2.size
     assert np.array_equal(out_t[:e2.size].cpu().numpy().view(np.uint32), e2)
+
+
+def test_bench_line_carries_the_configs4_leg_when_distributed(tmp_path):
+    """`bench.py --gpus N` with N > 1 (here: a world of one with the collective path forced, CLAP_BENCH_FORCE_DIST=1 -- the
+    same code the ranks of an 8-GPU run execute) times TWO legs in one process group over one communicator: the weak-scaling
+    headline (configs[1] per GPU) and BASELINE configs[4]'s per-rank share, reported under `c5`; `summary` and `c5` precede
+    the long sections of the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(CLAP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-frames", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["value"] > 0
+    assert r["config"]["entities_per_gpu"] == 1_000_000, "the headline stays configs[1] per GPU"
+    c5 = r["c5"]
+    assert list(c5) == bench.C5_KEYS
+    assert c5["entities_per_gpu"] == 2_000_000 and c5["particles_per_gpu"] == C5_PARTICLES and c5["value"] > 0 and c5["visible"] > 100_000
+    assert c5["global_ids"] >= 2_000_000 and c5["ms_per_step"] > 0 and c5["particle_updates_per_s"] > 0
+    keys = list(r)
+    assert keys.index("summary") < keys.index("c5") < keys.index("config") < keys.index("roofline")
