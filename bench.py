@@ -670,13 +670,17 @@ def full_frame(device):
     ps = synth.particle_systems(n_sys=4096, count=1024, radius=10.0, velocity=0.005, dist=synth.PART_DIST_SQRT)
     pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
-    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True)
+    # no reader of the joints' T / R / S or positions inside the frame: the skinning takes the palette (model.c:1020-1022)
+    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True, pose_readers=())
     now = [0.0]
 
     def one():
         now[0] += 1.0 / 120.0
         loop.clap_frame(now[0], 1.0 / 120.0)                 # one physics substep per frame
     t = time_launches(one, 40, warmup=40)                   # the first frames of a process run several times slower
+    cb.set_outputs(trs=True, joint_pos=True)                # ... and with every by-product of the pose written (round 4's frame)
+    t_all_outputs = time_launches(one, 40, warmup=10)
+    cb.set_outputs(trs=False, joint_pos=False)
     loop.overlap = True                                     # the same frame as three chains on three streams (frame.hip)
     t_overlap = time_launches(one, 40, warmup=10)
     loop.overlap = False
@@ -692,7 +696,9 @@ def full_frame(device):
     except Exception as exc:                                 # informational leg: never fail the benchmark on it
         print(f"[bench] frame graph capture failed: {exc}", file=sys.stderr)
     return {"ms_per_frame": t * 1e3, "frames_per_s": 1.0 / t, "ms_per_frame_three_streams": t_overlap * 1e3,
-            "ms_per_frame_graph_replay": graph_ms,
+            "ms_per_frame_graph_replay": graph_ms, "ms_per_frame_all_pose_outputs": t_all_outputs * 1e3,
+            "pose": "palette only (CLAPGPU_POSE_SKIP_TRS | CLAPGPU_POSE_SKIP_JOINT_POS): nothing in the frame reads the joints' "
+                    "T / R / S or world positions; ms_per_frame_all_pose_outputs = with them written (round 4's frame)",
             "label": "physics WITHOUT contact response: not a whole clap_frame()",
             "contents": "1M entities (depth 8) + 50k characters x 64 joints + 10M skinned vertices + 262144 bodies "
                         "(75k bound to entities; 2 broadphase passes, contact generation, integrate) + 4M particles + 128 "

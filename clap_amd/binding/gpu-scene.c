@@ -82,8 +82,6 @@ struct gs_rec {
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
     uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
                                    gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
-    uint16_t    host_bump, seq_mark;   /* seq steps entity3d_update / _reset took on the HOST since the last frame (the device catches up
-                                   with ONE rebuild in the next frame, its children follow only then) / e->seq when such an update began */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
     int32_t     lod_force, lod_cur; /* e->force_lod / e->cur_lod as the mirror holds them (gpu_scene_select_lod) */
 };
@@ -151,8 +149,14 @@ struct gpu_scene {
     /* GPU_SCATTER_DRAWN: rebuilds of a slot the host has not been shown yet (e->seq lags by this much, uint16 like seq) */
     bool            scatter_drawn, drawn_now;                      /* the policy; it is in force for the frame being run (a fast frame) */
     uint16_t        *pend; uint32_t cap_pend; bool any_pend;
+    /* ... and the seq each batched entity's entity3d was last GIVEN by a frame (walk, write-back or fetch; a host update in
+     * between -- entity3d_update / _reset -- does not count: the device catches up with one rebuild in the next frame and
+     * the children follow only then).  shown[p] + pend[p] is what a child of p copied into parent_seq when it was last
+     * rebuilt on the device (model.c:1613), whatever has happened to e->parent or to p's entity3d on the host since */
+    uint16_t        *shown;
     entity3d        *last_control;
     uint32_t        fetch_seen;                                    /* clapgpu_scene_arrays.fetch_serial already copied out */
+    uint64_t        *walk_fetch; uint32_t cap_walk_fetch; bool walk_fetch_on;   /* rows fetched for a walk, applied as the walk meets each entity */
     struct gpu_scene_stats stats;
 };
 
@@ -270,8 +274,8 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->rec); free(gs->bucket); free(gs->order); free(gs->prev_order); free(gs->models);
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
-    free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->xptr); free(gs->ftab);
-    free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
+    free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->shown); free(gs->xptr); free(gs->ftab);
+    free(gs->walk_fetch); free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
     free(gs);
@@ -724,8 +728,6 @@ void gpu_scene_host_update_begin(struct gpu_scene *gs, entity3d *e)
     if (!gs || !e) return;
     if (e->parent) gpu_scene_fetch(gs, e->parent);
     gpu_scene_fetch(gs, e);
-    const uint32_t i = rec_find(gs, e);
-    if (i != NO_REC) gs->rec[i].seq_mark = e->seq;
 }
 
 /* entity3d_update(e, data) / entity3d_reset(e) (model.c:1793, 1726; callers outside the frame loop: instantiate_entity
@@ -739,8 +741,6 @@ void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e)
     if (i == NO_REC) return;
     struct gs_rec *r = &gs->rec[i];
     if (r->cls != 1 && r->cls != 4) return;                      /* host-class: nothing is mirrored */
-    r->host_bump = (uint16_t)(r->host_bump + (uint16_t)(e->seq - r->seq_mark));   /* gpu_scene_host_update_begin() noted e->seq */
-    r->seq_mark = e->seq;
     r->host_done = 1;
     /* GPU_SCATTER_DRAWN: the host counted this rebuild itself; the device's must come back to be reconciled with it */
     if (gs->scatter_drawn && !r->keep && r->handle != CLAPGPU_NO_ENTITY && !clapgpu_scene_entity_keep(gs->scene, r->handle, 1)) r->keep = 1;
@@ -772,18 +772,22 @@ static inline uint16_t pend_of(const struct gpu_scene *gs, uint32_t slot)
     return (gs->any_pend && slot < gs->cap_pend) ? gs->pend[slot] : 0;
 }
 
-/* what r's parent's seq counter WOULD read had the parent been written back every frame (model.c:1613 copies it) */
+/* what r's parent's seq counter read when the DEVICE last rebuilt r's entity (model.c:1613 copies it into parent_seq): by
+ * the parent's record as the last walk linked it -- not by e->parent, which the game may have cleared or the engine freed
+ * since -- and without the steps a host update took since the last frame.  GPU_SCATTER_ALL: the parent's own counter. */
 static inline uint16_t parent_seq_now(const struct gpu_scene *gs, const struct gs_rec *r, const entity3d *parent)
 {
-    uint16_t seq = parent->seq;
-    if (r->parent_rec != NO_REC) {
+    if (gs->shown && r->parent_rec != NO_REC) {
         const struct gs_rec *pr = &gs->rec[r->parent_rec];
-        /* + the rebuilds the parent's entity3d was not shown; - the steps a host update (entity3d_update / _reset) took since
-         * the last frame: the child copied the parent's counter when IT was last rebuilt, and follows a host update of its
-         * parent only in the next frame (model.c:1609-1613) */
-        if (pr->e == parent && (pr->cls == 1 || pr->cls == 4)) seq = (uint16_t)(seq + pend_of(gs, pr->slot) - pr->host_bump);
+        if ((pr->cls == 1 || pr->cls == 4) && pr->slot < gs->cap_pend)
+            return (uint16_t)(gs->shown[pr->slot] + gs->pend[pr->slot]);
     }
-    return seq;
+    return parent ? parent->seq : 0;
+}
+
+static inline void seq_shown(struct gpu_scene *gs, size_t slot, uint16_t seq)
+{
+    if (gs->shown && slot < gs->cap_pend) gs->shown[slot] = seq;
 }
 
 static void copy_rows(struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot)
@@ -803,14 +807,17 @@ static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_sc
     if (r->host_done) {                                          /* gpu_scene_host_updated(): the host wrote these fields itself */
         const uint8_t hd = r->host_done;                         /* 2: its transform was written again since (the mirror pass saw it) */
         r->host_done = 0;
-        r->host_bump = 0;                                        /* the device has caught up; children scattered after this one copy e->seq as it is */
-        if (hd == 1 && !transform_is_updated(&e->xform) && !(parent && e->parent_seq != parent_seq_now(gs, r, parent))) return;
+        if (hd == 1 && !transform_is_updated(&e->xform) && !(parent && e->parent_seq != parent_seq_now(gs, r, parent))) {
+            seq_shown(gs, slot, e->seq);                         /* the device has caught up with what the host did */
+            return;
+        }
         /* ... but it was touched again since (or its parent moved): an ordinary rebuild */
     }
     if (parent && parent_seq) e->parent_seq = parent_seq_now(gs, r, parent);   /* model.c:1613 (parents sit in lower slots: already advanced) */
     if (transform_is_updated(&e->xform)) transform_clear_updated(&e->xform);
     e->seq = (uint16_t)(e->seq + 1 + pend_of(gs, (uint32_t)slot));  /* model.c:1616, 1669 (+ the rebuilds it was not shown) */
     if (gs->any_pend && slot < gs->cap_pend) gs->pend[slot] = 0;
+    seq_shown(gs, slot, e->seq);
     copy_rows(r, res, slot);
     light_hand_off(gs, e);
 }
@@ -825,8 +832,9 @@ static void scatter_fetched(struct gpu_scene *gs, struct gs_rec *r, const clapgp
     if (k) {
         e->seq = (uint16_t)(e->seq + k);
         gs->pend[slot] = 0;
-        if (parent) e->parent_seq = parent_seq_now(gs, r, parent);
+        if (r->parent_e) e->parent_seq = parent_seq_now(gs, r, parent);   /* the parent it had when those rebuilds ran */
     }
+    seq_shown(gs, slot, e->seq);
     copy_rows(r, res, slot);
 }
 
@@ -859,6 +867,7 @@ void gpu_scene_set_scatter(struct gpu_scene *gs, int policy)
     if (!gs) return;
     const bool drawn = policy == GPU_SCATTER_DRAWN;
     if (gs->scatter_drawn && !drawn) gpu_scene_fetch_all(gs);    /* back to "everything is always current" */
+    if (drawn && !gs->scatter_drawn) gs->topology_pending = true; /* its per-slot counters are laid out by a walk: the next frame is one */
     gs->scatter_drawn = drawn;
 }
 
@@ -895,6 +904,9 @@ int gpu_scene_fetch_all(struct gpu_scene *gs)
 {
     if (!gs) return _CERR_INVALID_ARGUMENTS;
     if (!gs->any_pend) return 0;
+    /* entities were created or DELETED since the last update (gpu_scene_topology): a record may name freed memory, and only
+     * the walk of the next gpu_mq_update() finds out which -- it fetches everything itself, as it meets the entities */
+    if (gs->topology_pending) return _CERR_NOT_SUPPORTED;
     uint32_t n = 0;
     CK(clapgpu_scene_fetch(gs->scene, NULL, &n));
     consume_fetched(gs);
@@ -1320,12 +1332,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
      * coming back is owed one more seq step when its entity3d is next written */
     const uint64_t *scat = res.exported_mask ? res.exported_mask : res.rebuilt_mask;
     if (gs->drawn_now && res.rebuilt_mask && scat != res.rebuilt_mask) {
-        if (res.n_slots > gs->cap_pend) {
-            uint16_t *pn = realloc(gs->pend, (size_t)res.n_slots * sizeof(*pn));
-            if (!pn) return _CERR_NOMEM;
-            memset(pn + gs->cap_pend, 0, ((size_t)res.n_slots - gs->cap_pend) * sizeof(*pn));
-            gs->pend = pn; gs->cap_pend = res.n_slots;
-        }
+        if (res.n_slots > gs->cap_pend || !gs->shown) return _CERR_INVALID_ARGUMENTS;   /* laid out by the walk that made this layout */
         struct pend_ctx pc = { gs, &res };
         gpu_scene_par_for(pend_range, &pc, words, words >= 2048 ? par_threads() : 1);
         st->left_stale = pc.left;
@@ -1472,8 +1479,27 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
     }
     /* a walked frame writes everything back, and it may re-tile: whatever GPU_SCATTER_DRAWN left on the device comes over
-     * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's */
-    if (gs->any_pend) CK(gpu_scene_fetch_all(gs));
+     * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's.  The rows
+     * only: an entity3d is written when the walk MEETS it -- what was deleted since the last frame (the reason for many a
+     * walk) is freed memory, and nothing but the queue's own lists says which entities those are */
+    gs->walk_fetch_on = false;
+    if (gs->any_pend) {
+        uint32_t n_rows = 0;
+        CK(clapgpu_scene_fetch(gs->scene, NULL, &n_rows));
+        clapgpu_scene_arrays fr;
+        if (n_rows && !clapgpu_scene_results(gs->scene, &fr)) {
+            const uint32_t words = fr.n_slots / 64;
+            if (words > gs->cap_walk_fetch) {
+                uint64_t *q = realloc(gs->walk_fetch, (size_t)words * 8);
+                if (!q) return _CERR_NOMEM;
+                gs->walk_fetch = q; gs->cap_walk_fetch = words;
+            }
+            memcpy(gs->walk_fetch, fr.fetched_mask, (size_t)words * 8);
+            gs->res = fr;
+            gs->fetch_seen = fr.fetch_serial;
+            gs->walk_fetch_on = true;
+        }
+    }
     clapgpu_scene_set_export(gs->scene, CLAPGPU_SCENE_EXPORT_ALL);
     gs->drawn_now = false;
     for (uint32_t k = 0; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
@@ -1524,6 +1550,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 gs->cap_order = cap;
             }
             struct gs_rec *r = &gs->rec[i];
+            if (gs->walk_fetch_on && (r->cls == 1 || r->cls == 4) && r->slot < gs->res.n_slots &&
+                ((gs->walk_fetch[r->slot >> 6] >> (r->slot & 63)) & 1)) {
+                scatter_fetched(gs, r, &gs->res, r->slot);       /* (its class and slot are still last walk's) */
+                st->fetched++;
+            }
             r->gen = gs->gen;
             r->order_pos = gs->n_order;
             gs->order[gs->n_order++] = i;
@@ -1579,6 +1610,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             }
         }
     }
+    if (gs->any_pend) {                                          /* what the walk did not meet is gone, and its counters with it */
+        if (gs->pend) memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));
+        gs->any_pend = false;
+        gs->walk_fetch_on = false;
+    }
     const double t1 = now_ms();
     /* entities that left the queue (entity3d_delete, model.c:1787): met last frame, not this one */
     if (gs->n_live != gs->n_order) {
@@ -1610,6 +1646,21 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         memset(&res, 0, sizeof(res));
     gs->res = res;
 
+    if (gs->scatter_drawn && gs->notify && res.n_slots) {        /* the counters GPU_SCATTER_DRAWN keeps per slot, for this layout */
+        if (res.n_slots > gs->cap_pend) {
+            uint16_t *pn = realloc(gs->pend, (size_t)res.n_slots * sizeof(*pn));
+            if (pn) gs->pend = pn;
+            uint16_t *sn = realloc(gs->shown, (size_t)res.n_slots * sizeof(*sn));
+            if (sn) gs->shown = sn;
+            if (!pn || !sn) return _CERR_NOMEM;
+            gs->cap_pend = res.n_slots;
+        } else if (!gs->shown) {
+            gs->shown = malloc((size_t)gs->cap_pend * sizeof(*gs->shown));
+            if (!gs->shown) return _CERR_NOMEM;
+        }
+        memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));
+        memset(gs->shown, 0, (size_t)gs->cap_pend * sizeof(*gs->shown));
+    }
     const double t3 = now_ms();
     /* 5: results and host hooks, list order */
     for (uint32_t k = 0; k < gs->n_order; k++) {
@@ -1631,6 +1682,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             gs->n_batched++;
             if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
                 r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
+            seq_shown(gs, r->slot, e->seq);
             if (push_u32(&gs->att_list, &gs->n_att, &gs->cap_att, gs->order[k])) return _CERR_NOMEM;
             continue;
         }
@@ -1651,7 +1703,6 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         entity3d *parent = e->parent;
         const bool rebuilt = parent ? (r->xform_dirty || e->parent_seq != parent->seq) : r->xform_dirty;
         r->host_done = 0;                                        /* the host fields decide here: a host-updated entity is simply not dirty */
-        r->host_bump = 0;
         if (rebuilt) {
             const size_t slot = r->slot;
             if (parent) e->parent_seq = parent->seq;             /* model.c:1613 */
@@ -1666,6 +1717,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             light_hand_off(gs, e);
             st->written_back++;
         }
+        seq_shown(gs, r->slot, e->seq);
         if (scene)
             bv_pick(scene, e);
     }

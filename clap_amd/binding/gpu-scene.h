@@ -124,6 +124,8 @@ const struct gpu_scene_stats *gpu_scene_last_stats(const struct gpu_scene *gs);
 enum { GPU_SCATTER_ALL = 0, GPU_SCATTER_DRAWN = 1 };
 void gpu_scene_set_scatter(struct gpu_scene *gs, int policy);
 int  gpu_scene_fetch(struct gpu_scene *gs, entity3d *e);       /* 0, or a negative cerr_enum value */
+/* _CERR_NOT_SUPPORTED between a gpu_scene_topology() report and the next gpu_mq_update(): entities may have been deleted,
+ * a record may name freed memory, and only the walk of that update finds out which (it fetches everything as it goes) */
 int  gpu_scene_fetch_all(struct gpu_scene *gs);
 void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep);   /* a standing host reader of e exists (takes effect with the next walk or at once) */
 bool gpu_scene_entity_is_stale(struct gpu_scene *gs, entity3d *e);

@@ -33,6 +33,7 @@ struct WorldK2 {
     int32_t pad;
 };
 static_assert(sizeof(WorldK2) == sizeof(clapgpu_world), "world layout");
+static_assert(true, "");
 
 struct BodiesK {
     uint32_t n, samples;
@@ -48,7 +49,13 @@ struct BodiesK {
     double *geom_records;
 };
 
-__device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const double (&p)[3], const double (&q)[4])
+// The next broadphase's first launch (k_bp_bin: one atomic per body on its cell's counter) done by the step that writes the
+// box it would read: clapgpu_bodies_step_prebin.  key == nullptr: off.
+struct BinK { double cell; uint32_t mask; uint32_t *key, *rank, *cell_cnt, *ctrl; };
+__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t i, const double (&bb)[6]);
+
+__device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const double (&p)[3], const double (&q)[4],
+                                           double (*bb_out)[6] = nullptr)
 {
     if (!b.aabb && !b.axis && !b.geom_records) return;
     double R[12], axis[3], bb[6];
@@ -66,6 +73,18 @@ __device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const d
         double2 *o = reinterpret_cast<double2 *>(b.aabb + 6 * (size_t)i);
         o[0] = make_double2(bb[0], bb[1]); o[1] = make_double2(bb[2], bb[3]); o[2] = make_double2(bb[4], bb[5]);
     }
+    if (bb_out)
+#pragma unroll
+        for (int a = 0; a < 6; a++) (*bb_out)[a] = bb[a];
+}
+
+// a body the step leaves alone keeps its stored box: binned from there
+__device__ __forceinline__ void bin_stored(const BinK &bin, const BodiesK &b, uint32_t i)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(b.aabb + 6 * (size_t)i);
+    const double2 x = p[0], y = p[1], z = p[2];
+    const double bb[6] = { x.x, x.y, y.x, y.y, z.x, z.y };
+    bin_body(bin, i, bb);
 }
 
 __global__ __launch_bounds__(PB)
@@ -78,13 +97,15 @@ void k_bodies_aabb(BodiesK b)
     write_geom(b, i, p, q);
 }
 
+template <bool BIN>
 __global__ __launch_bounds__(PB)
-void k_bodies_step(BodiesK b, WorldK2 w, double h)
+void k_bodies_step(BodiesK b, WorldK2 w, double h, BinK bin)
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (BIN && i == 0) bin.ctrl[3] = bin.ctrl[3] + 1;                   // CTRL_EPOCH: what k_bp_bin's first thread does
     if (i >= b.n) return;
     uint32_t fl = b.bflags[i];
-    if (fl & CLAPGPU_BODY_DISABLED) return;
+    if (fl & CLAPGPU_BODY_DISABLED) { if (BIN) bin_stored(bin, b, i); return; }
     double *pp = b.pos + 3 * (size_t)i, *qp = b.quat + 4 * (size_t)i, *vp = b.lvel + 3 * (size_t)i, *op = b.avel + 3 * (size_t)i;
     double v[3] = { vp[0], vp[1], vp[2] }, om[3] = { op[0], op[1], op[2] };
 
@@ -124,6 +145,7 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
             b.bflags[i] = (fl | CLAPGPU_BODY_DISABLED) & ~CLAPGPU_BODY_HAS_JOINT;
             vp[0] = vp[1] = vp[2] = 0;
             op[0] = op[1] = op[2] = 0;
+            if (BIN) bin_stored(bin, b, i);
             return;
         }
     }
@@ -199,7 +221,12 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h)
         }
     }
     vp[0] = v[0]; vp[1] = v[1]; vp[2] = v[2];
-    write_geom(b, i, p, q);
+    if (BIN) {
+        double bb[6];
+        write_geom(b, i, p, q, &bb);
+        bin_body(bin, i, bb);
+    } else
+        write_geom(b, i, p, q);
 }
 
 // ================================================================================== broadphase
@@ -300,7 +327,18 @@ __device__ __forceinline__ bool boxes_overlap(const double (&a)[6], const double
     return !(a[0] > b[1] || a[1] < b[0] || a[2] > b[3] || a[3] < b[2] || a[4] > b[5] || a[5] < b[4]);
 }
 
-// Launch 1
+__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t i, const double (&bb)[6])
+{
+    if (bb[1] - bb[0] > bin.cell || bb[3] - bb[2] > bin.cell || bb[5] - bb[4] > bin.cell)
+        atomicOr(&bin.ctrl[CTRL_STATUS], 1u);
+    int32_t cx, cy, cz;
+    box_cell(bb, bin.cell, cx, cy, cz);
+    const uint32_t slot = cell_slot(cx, cy, cz, bin.mask);
+    bin.key[i] = slot;
+    bin.rank[i] = atomicAdd(&bin.cell_cnt[slot], 1u);
+}
+
+// Launch 1 (skipped when the step before it has binned the boxes it wrote: clapgpu_bodies_step_prebin)
 __global__ __launch_bounds__(PB)
 void k_bp_bin(BpK k)
 {

@@ -19,16 +19,24 @@ from . import entities as ent_mod
 
 class FrameLoop:
     def __init__(self, batch, cam, world=None, feed=None, body_links=None, lights=None, characters=None,
-                 particles=None, contacts=False):
+                 particles=None, contacts=False, pose_readers=("trs", "joint_pos")):
         """batch: EntityBatch.  world: PhysWorld (dynamic bodies write their entities through
         body_entity; character bodies have body_entity = -1).  feed: CharacterFeed.  body_links:
         (link_body, link_entity) of characters / static colliders whose rotation follows the entity.
         lights: LightSet (with carriers).  characters: CharacterBatch (pose + skin).  particles:
-        ParticleBatch."""
+        ParticleBatch.  pose_readers: which of the pose's host-visible by-products somebody reads this frame --
+        "trs" (struct joint's translation / rotation / scale) and "joint_pos" (struct joint.pos: camera_target,
+        camera.c:191-205); the draw path and the skinning consume joint_transforms alone (model.c:1020-1022), so a frame
+        whose skinning runs on the device registers none and the pose writes 64 of its 120 bytes per joint
+        (clapgpu_pose_batch.skip).  A model with (joint, path) pairs that have no channel keeps "trs": such a path's
+        value lives there (model.c:1301)."""
         self.batch, self.world, self.feed, self.lights = batch, world, feed, lights
         self.characters, self.particles = characters, particles
         self.body_links, self.contacts = body_links, contacts
         self._desc = None
+        if characters is not None:
+            missing = bool(characters.model.anim_desc.packed_layout & 0x010)        # POSE_LAYOUT_MISSING (pose.hip)
+            characters.set_outputs(trs=("trs" in pose_readers) or missing, joint_pos="joint_pos" in pose_readers)
         self.set_camera(cam)
 
     def set_camera(self, cam):

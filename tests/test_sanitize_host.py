@@ -68,6 +68,11 @@ def test_binding_and_mirror_under_asan_ubsan():
     the reference's bits everywhere."""
     exe = _build("asan")
     assert _run(exe, "test", 2500, 12, 1, "notify", "drawn", "steady")["mismatches"] == 0
+    # found by this very set-up: a stale entity deleted before the walk that would have fetched it (use after free), a
+    # detached child whose parent_seq has to come from the parent it HAD, a host update of a stale entity's parent
+    assert _run(exe, "test", 2000, 40, 7, "notify", "drawn", "steady")["mismatches"] == 0
+    assert _run(exe, "test", 200, 40, 13, "notify", "drawn")["mismatches"] == 0
+    assert _run(exe, "test", 6000, 16, 33, "notify", "drawn", "steady")["mismatches"] == 0
     assert _run(exe, "test", 1500, 10, 2)["mismatches"] == 0
     assert _run(exe, "test", 1500, 10, 3, "notify")["mismatches"] == 0
     assert _run(exe, "lod", 1500, 8, 1, "notify", "drawn", "steady")["mismatches"] == 0
