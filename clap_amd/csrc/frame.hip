@@ -165,7 +165,10 @@ static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t
                                                   f->bodies->bflags, nullptr));
                 }
             }
-            FR(clapgpu_bodies_step(stream, f->bodies, f->world, 1.0 / 120.0));          // fixed_dt, physics.c:775
+            if ((f->flags & CLAPGPU_FRAME_PREBIN) && f->bp && f->bodies->aabb)
+                FR(clapgpu_bodies_step_prebin(stream, f->bodies, f->world, 1.0 / 120.0, f->bp));
+            else
+                FR(clapgpu_bodies_step(stream, f->bodies, f->world, 1.0 / 120.0));      // fixed_dt, physics.c:775
         }
     }
     // ---- character_update hooks (character.c:583-611) ----

@@ -1200,7 +1200,7 @@ extern "C" int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const 
     if (b->n == 0) return CLAPGPU_OK;
     WorldK2 wk;
     memcpy(&wk, w, sizeof(wk));
-    hipLaunchKernelGGL(k_bodies_step, dim3((b->n + PB - 1) / PB), dim3(PB), 0, as_stream(stream), bodies_k(b), wk, h);
+    hipLaunchKernelGGL(k_bodies_step<false>, dim3((b->n + PB - 1) / PB), dim3(PB), 0, as_stream(stream), bodies_k(b), wk, h, BinK{});
     CLAPGPU_LAUNCH_CHECK("k_bodies_step");
     return CLAPGPU_OK;
 }
@@ -1211,7 +1211,45 @@ struct clapgpu_bp {
     double cell;
     void *dev;                     // one allocation
     BpK k;                         // device pointers filled in
+    // clapgpu_bodies_step_prebin: the step that wrote these boxes has also binned them (key / rank / cell counters / epoch):
+    // the next clapgpu_bp_collide over the same array skips its first launch
+    const double *prebinned_aabb;
+    uint32_t prebinned_n;
 };
+
+// The step + the NEXT broadphase's bin pass in one launch (the bin pass reads nothing but the box the step has in
+// registers, and its one atomic per body hides under the step's fp64 traffic): -1 launch and the boxes' re-read per substep.
+extern "C" int clapgpu_bodies_step_prebin(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h, clapgpu_bp *bp)
+{
+    int rc = check_bodies2(b);
+    if (rc) return rc;
+    if (!w || !bp) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!b->aabb || b->n > bp->n_max) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (b->n == 0) return CLAPGPU_OK;
+    if (bp->prebinned_aabb) {                                    // a step binned already and no collide consumed it: start over
+        rc = clapgpu_bp_invalidate(stream, bp);
+        if (rc) return rc;
+    }
+    WorldK2 wk;
+    memcpy(&wk, w, sizeof(wk));
+    BinK bin = { bp->cell, bp->k.mask, bp->k.key, bp->k.rank, bp->k.cell_cnt, bp->k.ctrl };
+    hipLaunchKernelGGL(k_bodies_step<true>, dim3((b->n + PB - 1) / PB), dim3(PB), 0, as_stream(stream), bodies_k(b), wk, h, bin);
+    CLAPGPU_LAUNCH_CHECK("k_bodies_step<prebin>");
+    bp->prebinned_aabb = b->aabb;
+    bp->prebinned_n = b->n;
+    return CLAPGPU_OK;
+}
+
+// The boxes a step pre-binned were changed by somebody else (clapgpu_bodies_aabb, an upload, another body count): the cell
+// counters go back to zero -- what k_bp_cells leaves between frames -- and the next collide bins for itself.
+extern "C" int clapgpu_bp_invalidate(void *stream, clapgpu_bp *bp)
+{
+    if (!bp) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!bp->prebinned_aabb) return CLAPGPU_OK;
+    bp->prebinned_aabb = nullptr; bp->prebinned_n = 0;
+    CLAPGPU_HIP(hipMemsetAsync(bp->k.cell_cnt, 0, (size_t)bp->buckets * 64 * sizeof(uint32_t), as_stream(stream)));
+    return CLAPGPU_OK;
+}
 
 static uint32_t buckets_for(uint32_t n)
 {
@@ -1350,15 +1388,23 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
     if (n == 0) {
         CLAPGPU_HIP(hipMemsetAsync(pair_total, 0, sizeof(uint32_t), s));
         if (static_pair_total) CLAPGPU_HIP(hipMemsetAsync(static_pair_total, 0, sizeof(uint32_t), s));
-        return CLAPGPU_OK;
+        return clapgpu_bp_invalidate(stream, bp);
     }
     BpK k = bp->k;
     k.n = n; k.aabb = aabb; k.n_tiles = (n + BP_EMIT_TILE - 1) / BP_EMIT_TILE;
     k.pairs = pairs; k.capacity = capacity; k.pair_total = pair_total;
     k.spairs = static_pairs; k.scapacity = static_capacity; k.spair_total = static_pair_total;
     if (!statics) { k.n_static = 0; k.n_large = 0; if (static_pair_total) CLAPGPU_HIP(hipMemsetAsync(static_pair_total, 0, 4, s)); }
-    hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
-    CLAPGPU_LAUNCH_CHECK("k_bp_bin");
+    if (bp->prebinned_aabb == aabb && bp->prebinned_n == n) {
+        bp->prebinned_aabb = nullptr; bp->prebinned_n = 0;       // the step that wrote these boxes binned them: launch 1 is done
+    } else {
+        if (bp->prebinned_aabb) {                                // binned for other boxes: undo
+            int rc = clapgpu_bp_invalidate(stream, bp);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
+        CLAPGPU_LAUNCH_CHECK("k_bp_bin");
+    }
     hipLaunchKernelGGL(k_bp_cells, dim3((bp->buckets + BP_CELLS_BLOCK / WAVE - 1) / (BP_CELLS_BLOCK / WAVE)), dim3(BP_CELLS_BLOCK), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_cells");
     hipLaunchKernelGGL(k_bp_scatter, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);

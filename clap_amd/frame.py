@@ -19,7 +19,7 @@ from . import entities as ent_mod
 
 class FrameLoop:
     def __init__(self, batch, cam, world=None, feed=None, body_links=None, lights=None, characters=None,
-                 particles=None, contacts=False, pose_readers=("trs", "joint_pos")):
+                 particles=None, contacts=False, pose_readers=("trs", "joint_pos"), prebin=False):
         """batch: EntityBatch.  world: PhysWorld (dynamic bodies write their entities through
         body_entity; character bodies have body_entity = -1).  feed: CharacterFeed.  body_links:
         (link_body, link_entity) of characters / static colliders whose rotation follows the entity.
@@ -33,6 +33,7 @@ class FrameLoop:
         self.batch, self.world, self.feed, self.lights = batch, world, feed, lights
         self.characters, self.particles = characters, particles
         self.body_links, self.contacts = body_links, contacts
+        self.prebin = prebin        # CLAPGPU_FRAME_PREBIN: the step bins its boxes for the next frame's broadphase (nothing else writes them)
         self._desc = None
         if characters is not None:
             missing = bool(characters.model.anim_desc.packed_layout & 0x010)        # POSE_LAYOUT_MISSING (pose.hip)
@@ -149,7 +150,8 @@ class FrameLoop:
             self.lights._upload()                            # slot edits made on the host since the last frame
         # graph capture: the clock comes from a device double written before every replay
         f.now_dev = self.characters.now_dev.data_ptr() if (now is None and self.characters is not None) else None
-        f.flags = 1 if getattr(self, "overlap", False) else 0     # CLAPGPU_FRAME_OVERLAP: three chains on three streams (frame.hip)
+        # CLAPGPU_FRAME_OVERLAP: three chains on three streams (frame.hip); CLAPGPU_FRAME_PREBIN
+        f.flags = (1 if getattr(self, "overlap", False) else 0) | (2 if self.prebin else 0)
         rc = _lib.lib().clapgpu_frame_issue(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(f),
                                             0.0 if now is None else float(now), int(steps))
         _lib.check(rc, "clapgpu_frame_issue")

@@ -87,7 +87,12 @@ class PhysWorld:
                 pass
 
     # ---- __phys_step pieces -----------------------------------------------------------
+    def bp_invalidate(self):
+        """Boxes a step pre-binned (world_step(prebin=True) / FrameLoop(prebin=True)) were rewritten by something else."""
+        _lib.check(_lib.lib().clapgpu_bp_invalidate(_stream(), self._bp), "clapgpu_bp_invalidate")
+
     def bodies_aabb(self):
+        self.bp_invalidate()
         """Geom axis + AABB of every body from its pose (after the host moved bodies; world_step keeps them current)."""
         _lib.check(_lib.lib().clapgpu_bodies_aabb(_stream(), C.byref(self._desc)), "clapgpu_bodies_aabb")
 
@@ -255,7 +260,12 @@ class PhysWorld:
         npairs = min(int(self.pair_total.item()), self.capacity)
         return self.contact_buf[:npairs].cpu().numpy().view(dtype).reshape(-1), int(self.contact_total.item())
 
-    def world_step(self, h):
+    def world_step(self, h, prebin=False):
+        """quickstep's body stage; prebin: also the bin pass of the next broadphase() over the boxes it writes."""
+        if prebin:
+            _lib.check(_lib.lib().clapgpu_bodies_step_prebin(_stream(), C.byref(self._desc), C.byref(self.world), h, self._bp),
+                       "clapgpu_bodies_step_prebin")
+            return
         _lib.check(_lib.lib().clapgpu_bodies_step(_stream(), C.byref(self._desc), C.byref(self.world), h),
                    "clapgpu_bodies_step")
 

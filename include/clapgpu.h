@@ -720,6 +720,14 @@ void clapgpu_world_defaults(clapgpu_world *w);
  * the moved geom's axis and AABB.
  */
 int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h);
+/* The same step, which ALSO does the first launch of the next clapgpu_bp_collide(bp, b->n, b->aabb) -- the bin pass reads
+ * nothing but the box the step has just computed: one launch and one pass over the boxes less per substep.  The collide
+ * call recognises the pre-binned array by (pointer, count) and skips its bin launch; if b->aabb is changed by anything
+ * else in between (clapgpu_bodies_aabb, an upload) call clapgpu_bp_invalidate(bp) first.  Results are the same pairs
+ * (the list is canonical whatever order the bin atomics took).  b->aabb is required. */
+struct clapgpu_bp;
+int clapgpu_bodies_step_prebin(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h, struct clapgpu_bp *bp);
+int clapgpu_bp_invalidate(void *stream, struct clapgpu_bp *bp);
 
 /*
  * phys_body_update() for every body (physics.c:789-812, 96-109): writes entity pos
@@ -999,6 +1007,10 @@ typedef struct clapgpu_frame {
  * world positions, light grid, visible list and LOD pick follow the join.  Results are identical either way; on one
  * MI355X the overlapped frame is NOT shorter (0.64 against 0.62 ms at BASELINE sizes: csrc/frame.hip). */
 #define CLAPGPU_FRAME_OVERLAP 1u
+/* CLAPGPU_FRAME_PREBIN: every substep's body step also bins the boxes it writes for the NEXT broadphase pass
+ * (clapgpu_bodies_step_prebin): one launch less per substep.  The caller promises that nothing but this frame call writes
+ * bodies->aabb between frames (or calls clapgpu_bp_invalidate after doing so). */
+#define CLAPGPU_FRAME_PREBIN  2u
 
 int clapgpu_frame_issue(void *stream, const clapgpu_frame *f, double now, uint32_t physics_substeps);
 

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 E_DIRTY = 1 << 16
 
 
-def test_frames_match_oracle_sequence(cuda_device):
+@pytest.mark.parametrize("prebin", [False, True], ids=["plain", "prebin"])
+def test_frames_match_oracle_sequence(prebin, cuda_device):
+    """prebin: CLAPGPU_FRAME_PREBIN -- every substep's body step also bins its boxes for the next broadphase pass."""
     import torch
     from clap_amd import animation, characters, entities, frame, lights, particles, physics
 
@@ -70,7 +72,8 @@ def test_frames_match_oracle_sequence(cuda_device):
     cb.start_clock(ani_time=start, speed=np.full(n_char, 1.2, np.float32), repeat=np.ones(n_char, np.uint8))
     pb = particles.ParticleBatch(ps, ppos.copy(), pvel.copy(), pst, cuda_device)
     loop = frame.FrameLoop(batch, cam, world=world, feed=cf, body_links=(link_body, link_entity), lights=ls,
-                           characters=cb, particles=pb, contacts=True)
+                           characters=cb, particles=pb, contacts=True, prebin=prebin)
+    ref_world = physics.PhysWorld(bodies, synth.static_boxes(8, 30.0), device=cuda_device) if prebin else None
 
     # ================= oracle side (same order)
     o_scene = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
@@ -142,6 +145,14 @@ def test_frames_match_oracle_sequence(cuda_device):
             st["flags"][idx] |= np.uint32(E_DIRTY)
             batch.set_transforms(idx, newp, o_scene["rot"][idx])
     assert world.download()["pair_total"] >= 0
+    if prebin:                                               # the last frame's pairs against a plain broadphase over the same boxes
+        wd = world.download()
+        ref_world.aabb[:world.n].copy_(world.aabb[:world.n])
+        # the frame's collide ran BEFORE its step: redo it on both over the final boxes (the frame's step pre-binned them)
+        world.broadphase(); ref_world.broadphase()
+        a, b = world.download(), ref_world.download()
+        assert a["pair_total"] == b["pair_total"] and np.array_equal(a["pairs"], b["pairs"])
+        assert np.array_equal(a["static_pairs"], b["static_pairs"])
 
 
 def test_captured_frame_graph_replays_the_same_frames(cuda_device):

@@ -588,3 +588,53 @@ def test_geom_records_give_the_same_contacts_as_the_arrays(cuda_device):
         for w in worlds:
             w.world_step(1.0 / 120.0)
             w.world_step(1.0 / 120.0)
+
+
+@pytest.mark.parametrize("kind", ["spheres", "capsules"])
+def test_step_that_bins_for_the_next_broadphase_gives_the_same_pairs(kind, cuda_device):
+    """clapgpu_bodies_step_prebin: the substep's body step also runs the NEXT broadphase's first launch over the boxes it
+    writes (k_bp_bin: cell slot, rank in the cell, the cell counters, the epoch), and clapgpu_bp_collide skips that launch.
+    Two worlds from the same bodies -- A: collide, step; B: collide, step + pre-bin -- over eight substeps: body state bit
+    for bit, both pair lists identical every substep (the emitted list is canonical whatever order the atomics took).
+    Bodies go to sleep on the way (auto-disable: a disabled body is binned from its stored box).  Then boxes rewritten
+    behind the pre-binned step's back (clapgpu_bodies_aabb -> clapgpu_bp_invalidate): the next collide bins for itself."""
+    import torch
+    from clap_amd import physics
+    n = 20_000
+    b = synth.sphere_bodies(n, box=40.0, seed=21) if kind == "spheres" else synth.capsule_bodies(n, box=40.0, seed=21)
+    b["lvel"][: n // 3] *= 1e-4                                           # a third nearly at rest: these fall asleep
+    b["avel"][: n // 3] *= 1e-4
+    stat = synth.static_boxes(32, 40.0)
+    A = physics.PhysWorld(b, stat, pair_capacity=400_000, device=cuda_device)
+    B = physics.PhysWorld(b, stat, pair_capacity=400_000, device=cuda_device)
+    for w in (A, B):
+        w.world.adis_steps = 3                                           # short fuse: disabling happens inside the test
+    for s in range(8):
+        A.broadphase(); B.broadphase()
+        da, db = A.download(), B.download()
+        assert da["pair_total"] == db["pair_total"] > 0 and np.array_equal(da["pairs"], db["pairs"]), f"substep {s}: body pairs"
+        assert da["static_pair_total"] == db["static_pair_total"] and np.array_equal(da["static_pairs"], db["static_pairs"]), f"substep {s}: static pairs"
+        assert A.broadphase_status() == B.broadphase_status() == 0
+        if s in (2, 5):                                                  # contacts in between set HAS_JOINT: the auto-disable path runs
+            A.alloc_contacts(); B.alloc_contacts()
+            A.contacts_geoms_both(); B.contacts_geoms_both()
+        A.world_step(1.0 / 120.0)
+        B.world_step(1.0 / 120.0, prebin=True)
+        da, db = A.download(), B.download()
+        for k in ("pos", "quat", "lvel", "avel", "aabb"):
+            assert np.array_equal(da[k].view(np.uint64), db[k].view(np.uint64)), f"substep {s}: {k}"
+        assert np.array_equal(da["bflags"], db["bflags"])
+    # boxes rewritten behind the pre-binned step's back
+    B.pos += 0.25
+    A.pos += 0.25
+    A.bodies_aabb(); B.bodies_aabb()                                     # (B.bodies_aabb invalidates the pre-binned state)
+    A.broadphase(); B.broadphase()
+    da, db = A.download(), B.download()
+    assert da["pair_total"] == db["pair_total"] and np.array_equal(da["pairs"], db["pairs"])
+    assert np.array_equal(da["static_pairs"], db["static_pairs"])
+    # two pre-binning steps in a row without a collide in between: the second starts over
+    B.world_step(1.0 / 120.0, prebin=True); B.world_step(1.0 / 120.0, prebin=True)
+    A.world_step(1.0 / 120.0); A.world_step(1.0 / 120.0)
+    A.broadphase(); B.broadphase()
+    da, db = A.download(), B.download()
+    assert da["pair_total"] == db["pair_total"] and np.array_equal(da["pairs"], db["pairs"])
