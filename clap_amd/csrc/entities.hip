@@ -496,46 +496,101 @@ __device__ __forceinline__ float cbrtf_glibc(float x)
     return ldexpf(x > 0.0f ? ym : -ym, xe / 3);
 }
 
+struct LodK {                       // what the pick reads (model.c:975-992) and writes
+    float cx, cy, cz;
+    const float *aabb, *center;
+    const float4 *pos_scale;
+    const int32_t *model;
+    const float4 *model_table;
+    const int32_t *force_lod;
+    int32_t *cur_lod;
+    uint32_t n_models;
+};
+
+// the LOD entity i is drawn with; cur_lod[i] follows (entity3d_set_lod writes e->cur_lod)
+__device__ __forceinline__ int32_t lod_pick(const LodK &k, uint32_t i)
+{
+    int32_t lod = k.cur_lod[i];
+    const int32_t forced = k.force_lod ? k.force_lod[i] : -1;
+    if (forced >= 0) {
+        lod = forced;                                                   // model.c:976-977
+    } else {
+        const float *b = k.aabb + 6 * (size_t)i;
+        const bool inside = k.cx >= b[0] && k.cx <= b[3] && k.cy >= b[1] && k.cy <= b[4] && k.cz >= b[2] && k.cz <= b[5];
+        if (!inside) {                                                  // model.c:982-990
+            const float *c = k.center + 3 * (size_t)i;
+            const float dx = c[0] - k.cx, dy = c[1] - k.cy, dz = c[2] - k.cz;
+            float dd = 0.f;
+            dd += dx * dx;
+            dd += dy * dy;
+            dd += dz * dz;
+            const int32_t mraw = k.model[i];
+            const int32_t mi = (uint32_t)mraw < k.n_models ? mraw : 0;
+            const float4 lo = k.model_table[2 * mi], hi = k.model_table[2 * mi + 1];
+            const float s = k.pos_scale[i].w;
+            const float X = fabsf(hi.x - lo.x) * s, Y = fabsf(hi.y - lo.y) * s, Z = fabsf(hi.z - lo.z) * s;
+            const float side = cbrtf_glibc(X * Y * Z);                  // entity3d_aabb_avg_edge
+            const float scale = (float)((double)fabsf(dd - side * side) / 3600.0);
+            const uint32_t lm = __float_as_uint(hi.w);                  // lod_min | lod_max << 8
+            const int lmin = (int)(lm & 0xffu), lmax = (int)((lm >> 8) & 0xffu);
+            const int req = (int)scale;
+            lod = req < lmin ? lmin : (req > lmax ? lmax : req);        // model3d_validate_lod
+        }
+    }
+    k.cur_lod[i] = lod;
+    return lod;
+}
+
 __global__ __launch_bounds__(ENT_BLOCK)
-void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t index_base, float cx, float cy, float cz,
-                    const float *aabb, const float *center, const float4 *pos_scale, const int32_t *model,
-                    const float4 *model_table, const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod,
-                    uint32_t n, uint32_t n_models)
+void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t index_base, LodK lk, int32_t *draw_lod, uint32_t n)
 {
     const uint32_t total = *count < n ? *count : n;                       // a count beyond the batch would walk off the list
     for (uint32_t k = blockIdx.x * ENT_BLOCK + threadIdx.x; k < total; k += gridDim.x * ENT_BLOCK) {
         const uint32_t i = visible[k] - index_base;
         if (i >= n) { draw_lod[k] = 0; continue; }                          // an id of another shard
-        int32_t lod = cur_lod[i];
-        const int32_t forced = force_lod ? force_lod[i] : -1;
-        if (forced >= 0) {
-            lod = forced;                                                   // model.c:976-977
-        } else {
-            const float *b = aabb + 6 * (size_t)i;
-            const bool inside = cx >= b[0] && cx <= b[3] && cy >= b[1] && cy <= b[4] && cz >= b[2] && cz <= b[5];
-            if (!inside) {                                                  // model.c:982-990
-                const float *c = center + 3 * (size_t)i;
-                const float dx = c[0] - cx, dy = c[1] - cy, dz = c[2] - cz;
-                float dd = 0.f;
-                dd += dx * dx;
-                dd += dy * dy;
-                dd += dz * dz;
-                const int32_t mraw = model[i];
-                const int32_t mi = (uint32_t)mraw < n_models ? mraw : 0;
-                const float4 lo = model_table[2 * mi], hi = model_table[2 * mi + 1];
-                const float s = pos_scale[i].w;
-                const float X = fabsf(hi.x - lo.x) * s, Y = fabsf(hi.y - lo.y) * s, Z = fabsf(hi.z - lo.z) * s;
-                const float side = cbrtf_glibc(X * Y * Z);                  // entity3d_aabb_avg_edge
-                const float scale = (float)((double)fabsf(dd - side * side) / 3600.0);
-                const uint32_t lm = __float_as_uint(hi.w);                  // lod_min | lod_max << 8
-                const int lmin = (int)(lm & 0xffu), lmax = (int)((lm >> 8) & 0xffu);
-                const int req = (int)scale;
-                lod = req < lmin ? lmin : (req > lmax ? lmax : req);        // model3d_validate_lod
-            }
-        }
-        cur_lod[i] = lod;
-        draw_lod[k] = lod;
+        draw_lod[k] = lod_pick(lk, i);
     }
+}
+
+// k_visible_expand_rp that also picks the LOD of every id it writes: a render pass's list and its LODs in ONE launch
+// (the pick reads what the entity update of the same frame left in L2; as its own launch it cost a dependent launch's
+// latency on top of ~10 us).  Same list, same LODs as the two launches.
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_visible_expand_rp_lod(const uint64_t *vis_mask, const uint8_t *row_pop, uint32_t n, uint32_t index_base, uint32_t *visible,
+                             uint32_t *count, LodK lk, int32_t *draw_lod)
+{
+    const int lane = lane_id();
+    const uint32_t g = blockIdx.x * (ENT_BLOCK / WAVE) + threadIdx.x / WAVE;
+    const uint32_t n_rows = (n + 63) / 64;
+    const uint32_t row0 = g * RP_ROWS;
+    if (row0 >= n_rows)
+        return;
+    const uint32_t pre = wave_byte_sum(row_pop, row0, lane);
+    const uint64_t word = lane < RP_ROWS ? load_mask_word(vis_mask, row0 + lane, n) : 0ull;
+    const uint32_t cnt = __popcll(word);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < RP_ROWS; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t excl = incl - cnt;
+    const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+#pragma unroll 1                                // the pick is ~300 instructions: sixteen copies would not fit the instruction cache
+    for (int k = 0; k < RP_ROWS; k++) {
+        const uint64_t wk = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, k) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32);
+        if (wk == 0) continue;                        // scalar branch
+        const uint32_t base = pre + (uint32_t)__builtin_amdgcn_readlane(excl, k);
+        if ((wk >> lane) & 1ull) {
+            const uint32_t rank = __popcll(wk & ((1ull << lane) - 1ull));
+            const uint32_t i = (row0 + k) * 64u + lane;
+            visible[base + rank] = index_base + i;
+            draw_lod[base + rank] = lod_pick(lk, i);
+        }
+    }
+    if (row0 + RP_ROWS >= n_rows && lane == RP_ROWS - 1)
+        *count = pre + incl;
 }
 
 // ---- a host mirror's small frames: touched inputs in, rebuilt outputs out, through device-mapped host memory -----------
@@ -1009,6 +1064,19 @@ extern "C" uint32_t clapgpu_visible_expand_ranges_host(const uint64_t *gathered_
     return cnt;
 }
 
+static LodK lod_args(const clapgpu_entities *e, const float cam_pos[3], const int32_t *force_lod, int32_t *cur_lod)
+{
+    LodK k;
+    k.cx = cam_pos[0]; k.cy = cam_pos[1]; k.cz = cam_pos[2];
+    k.aabb = e->aabb; k.center = e->center;
+    k.pos_scale = reinterpret_cast<const float4 *>(e->pos_scale);
+    k.model = e->model;
+    k.model_table = reinterpret_cast<const float4 *>(e->model_table);
+    k.force_lod = force_lod; k.cur_lod = cur_lod;
+    k.n_models = e->n_models ? e->n_models : 1;
+    return k;
+}
+
 extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t *visible,
                                     const uint32_t *count, uint32_t index_base, const float cam_pos[3],
                                     const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod)
@@ -1021,10 +1089,29 @@ extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, con
     uint32_t blocks = (e->n + ENT_BLOCK - 1) / ENT_BLOCK;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_entities_lod, dim3(blocks), dim3(ENT_BLOCK), 0, as_stream(stream), visible, count, index_base,
-                       cam_pos[0], cam_pos[1], cam_pos[2], e->aabb, e->center,
-                       reinterpret_cast<const float4 *>(e->pos_scale), e->model,
-                       reinterpret_cast<const float4 *>(e->model_table), force_lod, cur_lod, draw_lod, e->n,
-                       e->n_models ? e->n_models : 1);
+                       lod_args(e, cam_pos, force_lod, cur_lod), draw_lod, e->n);
     CLAPGPU_LAUNCH_CHECK("k_entities_lod");
     return CLAPGPU_OK;
+}
+
+// clapgpu_visible_compact + clapgpu_entities_lod of this shard's own entities as one launch where the single-launch
+// compaction applies (vis_row_pop, <= 4M entities); two launches otherwise.  Same outputs.
+extern "C" int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities *e, uint32_t index_base, const float cam_pos[3],
+                                           const int32_t *force_lod, int32_t *cur_lod, uint32_t *visible, uint32_t *count,
+                                           int32_t *draw_lod, void *scratch)
+{
+    if (!e || !count || !cam_pos || !cur_lod || !draw_lod || (e->n && (!e->vis_mask || !visible)) || !e->aabb || !e->center ||
+        !e->pos_scale || !e->model || !e->model_table)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t n = e->n, n_rows = (n + 63) / 64;
+    if (n && e->vis_row_pop && n_rows <= RP_MAX_ROWS && aligned16(e->vis_row_pop)) {
+        const uint32_t waves = (n_rows + RP_ROWS - 1) / RP_ROWS, per_block = ENT_BLOCK / WAVE;
+        hipLaunchKernelGGL(k_visible_expand_rp_lod, dim3((waves + per_block - 1) / per_block), dim3(ENT_BLOCK), 0, as_stream(stream),
+                           e->vis_mask, e->vis_row_pop, n, index_base, visible, count, lod_args(e, cam_pos, force_lod, cur_lod), draw_lod);
+        CLAPGPU_LAUNCH_CHECK("k_visible_expand_rp_lod");
+        return CLAPGPU_OK;
+    }
+    int rc = clapgpu_visible_compact(stream, e->vis_mask, e->vis_row_pop, n, index_base, visible, count, scratch);
+    if (rc) return rc;
+    return clapgpu_entities_lod(stream, e, visible, count, index_base, cam_pos, force_lod, cur_lod, draw_lod);
 }

@@ -206,11 +206,12 @@ static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t
                                       f->light_tiles));
     // ---- render pass glue: ordered visible list + LOD pick ----
     if (f->frustum && f->visible && f->visible_count && f->visible_scratch) {
-        FR(clapgpu_visible_compact(stream, e->vis_mask, e->vis_row_pop, e->n, f->index_base, f->visible, f->visible_count,
-                                   f->visible_scratch));
-        if (f->cur_lod && f->draw_lod)
-            FR(clapgpu_entities_lod(stream, e, f->visible, f->visible_count, f->index_base, f->cam_pos, f->force_lod, f->cur_lod,
-                                    f->draw_lod));
+        if (f->cur_lod && f->draw_lod)                           // list + LODs in one launch
+            FR(clapgpu_visible_compact_lod(stream, e, f->index_base, f->cam_pos, f->force_lod, f->cur_lod, f->visible,
+                                           f->visible_count, f->draw_lod, f->visible_scratch));
+        else
+            FR(clapgpu_visible_compact(stream, e->vis_mask, e->vis_row_pop, e->n, f->index_base, f->visible, f->visible_count,
+                                       f->visible_scratch));
     }
     return CLAPGPU_OK;
 }

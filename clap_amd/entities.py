@@ -199,6 +199,18 @@ class EntityBatch:
                                              _ptr(self.cur_lod), _ptr(self.draw_lod))
         _lib.check(rc, "clapgpu_entities_lod")
 
+    def compact_visible_lod(self, cam_pos, force_lod=None, index_base=0):
+        """compact_visible() + select_lod() as ONE launch (clapgpu_visible_compact_lod): the render pass's ordered list and
+        the LOD of every entry."""
+        self.alloc_lod()
+        if force_lod is not None:
+            self.force_lod = torch.from_numpy(np.ascontiguousarray(force_lod, np.int32)).to(self.device)
+        cp = (C.c_float * 3)(*[float(v) for v in cam_pos])
+        rc = _lib.lib().clapgpu_visible_compact_lod(_stream(), C.byref(self._desc), index_base, cp, _ptr(self.force_lod),
+                                                    _ptr(self.cur_lod), _ptr(self.visible), _ptr(self.visible_count),
+                                                    _ptr(self.draw_lod), _ptr(self.scratch))
+        _lib.check(rc, "clapgpu_visible_compact_lod")
+
     def view_entity_in_frustum(self, idx):
         """Served from the precomputed visibility bitmask (host sync)."""
         w = int(self.vis_mask[idx >> 6].item()) & 0xFFFFFFFFFFFFFFFF

@@ -1261,9 +1261,11 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
     CK(ensure_lod(s));
     /* the ordered visible list from the mask the last update / cull left on the device, then -- with a camera -- the LOD
      * pick over it (one launch each); without one the pass keeps every cur_lod (model.c:974: `if (camera)`) */
-    CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, s->d_visible, s->d_visible_count, s->d_vis_scratch));
     if (cam_pos)
-        CK(clapgpu_entities_lod(NULL, &s->d, s->d_visible, s->d_visible_count, 0, cam_pos, s->d_force_lod, s->d_cur_lod, s->d_draw_lod));
+        CK(clapgpu_visible_compact_lod(NULL, &s->d, 0, cam_pos, s->d_force_lod, s->d_cur_lod, s->d_visible, s->d_visible_count,
+                                       s->d_draw_lod, s->d_vis_scratch));
+    else
+        CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, s->d_visible, s->d_visible_count, s->d_vis_scratch));
     CK(clapgpu_memcpy_d2h(s->h_visible_count, s->d_visible_count, 4, NULL));
     CK(clapgpu_stream_sync(NULL));
     const uint32_t n = *s->h_visible_count;

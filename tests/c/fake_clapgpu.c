@@ -310,3 +310,13 @@ int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t
     free(none); free(maabb); free(mskip); free(mlod);
     return CLAPGPU_OK;
 }
+
+int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities *e, uint32_t index_base, const float cam_pos[3],
+                                const int32_t *force_lod, int32_t *cur_lod, uint32_t *visible, uint32_t *count, int32_t *draw_lod,
+                                void *scratch)
+{
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    int rc = clapgpu_visible_compact(stream, e->vis_mask, e->vis_row_pop, e->n, index_base, visible, count, scratch);
+    if (rc) return rc;
+    return clapgpu_entities_lod(stream, e, visible, count, index_base, cam_pos, force_lod, cur_lod, draw_lod);
+}

@@ -79,3 +79,16 @@ def test_hip_lod_matches_oracle(layout, cuda_device):
         assert np.array_equal(got_draw, draw), f"draw list LODs, camera {cam_pos}"
         assert np.array_equal(batch.cur_lod.cpu().numpy()[:scene["n"]], cur), "entity3d.cur_lod"
     assert len(np.unique(draw)) >= 3
+    # the list and its LODs as ONE launch (clapgpu_visible_compact_lod, what a frame issues): the same list, the same picks
+    fused = entities.EntityBatch(scene, cuda_device)
+    fused.mq_update(fr)
+    cur2 = np.zeros(scene["n"], np.int32)
+    for cam_pos in ((30, 5, 40), (-100, 20, 300), tuple(st["center"][vis[5]])):
+        draw = ob.entities_lod(scene, st, vis, cam_pos, scene["model_lod"], force, cur2)
+        fused.visible.fill_(-1)
+        fused.compact_visible_lod(cam_pos, force)
+        torch.cuda.synchronize()
+        assert int(fused.visible_count.item()) == len(vis)
+        assert np.array_equal(fused.visible[:len(vis)].cpu().numpy().view(np.uint32), vis), "the fused launch's list"
+        assert np.array_equal(fused.draw_lod[:len(vis)].cpu().numpy(), draw), f"the fused launch's LODs, camera {cam_pos}"
+        assert np.array_equal(fused.cur_lod.cpu().numpy()[:scene["n"]], cur2)

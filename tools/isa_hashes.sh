@@ -19,7 +19,9 @@ for l in open(sys.argv[1]).read().splitlines():
             cur = None; continue
         s = l.split(';')[0].rstrip()
         if s.strip() and not s.strip().startswith('.'):
-            body[cur].append(s)
+            # block labels carry the function's ordinal in the translation unit (.LBB7_3): adding a kernel elsewhere
+            # in the file renumbers them without moving an instruction
+            body[cur].append(re.sub(r'\.LBB\d+_', '.LBB_', s))
 for k, v in sorted(body.items()):
     print(hashlib.md5('\n'.join(v).encode()).hexdigest()[:12], len(v), k)
 PY
