@@ -671,7 +671,9 @@ def full_frame(device):
     pos, vel, st = spawn_cached(ps, synth.DRAND48_DEFAULT_STATE)
     pb = particles.ParticleBatch(ps, pos, vel, st, device)
     # no reader of the joints' T / R / S or positions inside the frame: the skinning takes the palette (model.c:1020-1022)
-    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True, pose_readers=())
+    # ... and nothing but the frame writes the bodies' boxes: the step bins them for the next broadphase (CLAPGPU_FRAME_PREBIN)
+    loop = frame.FrameLoop(batch, cam, world=world, feed=cf, lights=ls, characters=cb, particles=pb, contacts=True, pose_readers=(),
+                           prebin=True)
     now = [0.0]
 
     def one():

@@ -36,11 +36,42 @@ struct CharK {
     const double   *body_lvel, *body_yoffset;
 };
 
+__device__ __forceinline__ void character_update(const CharK &k, uint32_t c);
+
 __global__ __launch_bounds__(CHAR_BLOCK)
 void k_characters_update(CharK k)
 {
     const uint32_t c = blockIdx.x * CHAR_BLOCK + threadIdx.x;
     if (c >= k.n) return;
+    character_update(k, c);
+}
+
+// The character hooks and animated_update's clock (model.c:1563-1592; k_animation_time in pose.hip: the same four lines)
+// as ONE launch: two per-character passes over different state, neither reads what the other writes, and both sit in
+// front of kernels that need them (entity update / pose) -- as two launches the second cost a dependent launch's latency
+// for 7 us of work.  Blocks [0, char_blocks) run the hooks, the rest the clock.
+__global__ __launch_bounds__(CHAR_BLOCK)
+void k_characters_update_clock(CharK k, uint32_t char_blocks, clapgpu_anim_clock clk, double now, const double *now_dev)
+{
+    if (blockIdx.x < char_blocks) {
+        const uint32_t c = blockIdx.x * CHAR_BLOCK + threadIdx.x;
+        if (c < k.n) character_update(k, c);
+        return;
+    }
+    const uint32_t c = (blockIdx.x - char_blocks) * CHAR_BLOCK + threadIdx.x;
+    if (c >= clk.n_chars) return;
+    if (now_dev) now = *now_dev;
+    const double ft = (now - clk.ani_time[c]) * (double)clk.speed[c];
+    clk.frame_time[c] = (float)ft;
+    const uint32_t an = clk.anim[c];
+    const bool ended = an < clk.n_anims && ft >= (double)clk.time_end[an];
+    clk.ended[c] = ended ? 1 : 0;
+    if (ended && clk.restart[c])
+        clk.ani_time[c] = now;                                      // animation_next -> animation_start
+}
+
+__device__ __forceinline__ void character_update(const CharK &k, uint32_t c)
+{
     const uint32_t e = k.entity[c];
     if (e >= k.n_entities) return;
     int32_t b = k.body ? k.body[c] : -1;
@@ -105,6 +136,8 @@ void k_characters_update(CharK k)
 
 using namespace clapgpu;
 
+static int char_args(const clapgpu_characters *c, const clapgpu_entities *e, const clapgpu_bodies *b, CharK &k);
+
 extern "C" int clapgpu_characters_update(void *stream, const clapgpu_characters *c, const clapgpu_entities *e,
                                          const clapgpu_bodies *b)
 {
@@ -112,12 +145,43 @@ extern "C" int clapgpu_characters_update(void *stream, const clapgpu_characters 
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (c->n == 0)
         return CLAPGPU_OK;
+    CharK k;
+    int rc = char_args(c, e, b, k);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_characters_update, dim3((c->n + CHAR_BLOCK - 1) / CHAR_BLOCK), dim3(CHAR_BLOCK), 0,
+                       as_stream(stream), k);
+    CLAPGPU_LAUNCH_CHECK("k_characters_update");
+    return CLAPGPU_OK;
+}
+
+// clapgpu_characters_update + clapgpu_animation_time(_dev) in one launch (now_dev != NULL: the clock's `now` from a device
+// double, as clapgpu_animation_time_dev).  Either part may be empty.
+extern "C" int clapgpu_characters_update_clock(void *stream, const clapgpu_characters *c, const clapgpu_entities *e,
+                                               const clapgpu_bodies *b, const clapgpu_anim_clock *clk, double now, const double *now_dev)
+{
+    if (!c || !e || !clk)
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (clk->n_chars && (!clk->anim || !clk->time_end || !clk->ani_time || !clk->speed || !clk->restart || !clk->frame_time || !clk->ended))
+        return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CharK k = {};
+    if (c->n) {
+        int rc = char_args(c, e, b, k);
+        if (rc) return rc;
+    }
+    const uint32_t cb = (c->n + CHAR_BLOCK - 1) / CHAR_BLOCK, tb = (clk->n_chars + CHAR_BLOCK - 1) / CHAR_BLOCK;
+    if (cb + tb == 0) return CLAPGPU_OK;
+    hipLaunchKernelGGL(k_characters_update_clock, dim3(cb + tb), dim3(CHAR_BLOCK), 0, as_stream(stream), k, cb, *clk, now, now_dev);
+    CLAPGPU_LAUNCH_CHECK("k_characters_update_clock");
+    return CLAPGPU_OK;
+}
+
+static int char_args(const clapgpu_characters *c, const clapgpu_entities *e, const clapgpu_bodies *b, CharK &k)
+{
     if (!c->entity || !c->hist_pos || !c->hist_head || !c->hist_wrapped || !c->airborne || !c->moved ||
         !e->pos_scale || !e->flags)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (b && b->n && (!b->pos || !b->lvel || !b->yoffset))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    CharK k;
     k.n = c->n; k.limbo_height = c->limbo_height;
     k.entity = c->entity; k.body = c->body;
     k.hist_pos = c->hist_pos; k.hist_head = c->hist_head; k.hist_wrapped = c->hist_wrapped;
@@ -130,8 +194,5 @@ extern "C" int clapgpu_characters_update(void *stream, const clapgpu_characters 
     k.body_geom_records = b ? b->geom_records : nullptr;
     k.body_lvel = b ? b->lvel : nullptr;
     k.body_yoffset = b ? b->yoffset : nullptr;
-    hipLaunchKernelGGL(k_characters_update, dim3((c->n + CHAR_BLOCK - 1) / CHAR_BLOCK), dim3(CHAR_BLOCK), 0,
-                       as_stream(stream), k);
-    CLAPGPU_LAUNCH_CHECK("k_characters_update");
     return CLAPGPU_OK;
 }

@@ -123,9 +123,11 @@ static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t
     }
 
     // ---- chain B: animated_update -- clock, pose, palette; the vertex shader's skinning loop once per frame ----
+    // one stream: the clock rides the character hooks' launch (two per-character passes over different state)
+    const bool clock_with_hooks = !overlap && animated && f->anim_clock && f->characters;
     auto chain_b = [&]() -> int {
         if (!animated) return CLAPGPU_OK;
-        if (f->anim_clock) {
+        if (f->anim_clock && !clock_with_hooks) {
             if (f->now_dev) FR(clapgpu_animation_time_dev(sb, f->anim_clock, f->now_dev));
             else FR(clapgpu_animation_time(sb, f->anim_clock, now));
         }
@@ -172,7 +174,9 @@ static int frame_body(void *stream, const clapgpu_frame *f, double now, uint32_t
         }
     }
     // ---- character_update hooks (character.c:583-611) ----
-    if (f->characters)
+    if (clock_with_hooks)
+        FR(clapgpu_characters_update_clock(stream, f->characters, e, f->bodies, f->anim_clock, now, f->now_dev));
+    else if (f->characters)
         FR(clapgpu_characters_update(stream, f->characters, e, f->bodies));
     // ---- default_update: phys_body_update of dynamic bodies (model.c:1659-1665), rotation push (1680-1687),
     //      light hand-off (1689-1694) ----

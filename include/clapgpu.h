@@ -910,6 +910,10 @@ typedef struct clapgpu_characters {
  */
 int clapgpu_characters_update(void *stream, const clapgpu_characters *c, const clapgpu_entities *e,
                               const clapgpu_bodies *b);
+/* ... and animated_update's clock (clapgpu_animation_time; now_dev != NULL: clapgpu_animation_time_dev) in the same launch:
+ * two per-character passes over different state, both in front of kernels that wait for them.  Same results. */
+int clapgpu_characters_update_clock(void *stream, const clapgpu_characters *c, const clapgpu_entities *e, const clapgpu_bodies *b,
+                                    const clapgpu_anim_clock *clk, double now, const double *now_dev);
 
 /* ======================================================================== */
 /* Clustered lighting: lights x screen tiles bitmask (core/light.c)           */
