@@ -683,6 +683,8 @@ def full_frame(device):
     cb.set_outputs(trs=True, joint_pos=True)                # ... and with every by-product of the pose written (round 4's frame)
     t_all_outputs = time_launches(one, 40, warmup=10)
     cb.set_outputs(trs=False, joint_pos=False)
+    if os.environ.get("CLAP_FRAME_ONE_STREAM_ONLY") == "1":  # a kernel trace of the one-stream frame alone (tools/r05/prof_frame.sh)
+        return {"ms_per_frame": t * 1e3}
     loop.overlap = True                                     # the same frame as three chains on three streams (frame.hip)
     t_overlap = time_launches(one, 40, warmup=10)
     loop.overlap = False

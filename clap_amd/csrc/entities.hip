@@ -552,47 +552,6 @@ void k_entities_lod(const uint32_t *visible, const uint32_t *count, uint32_t ind
     }
 }
 
-// k_visible_expand_rp that also picks the LOD of every id it writes: a render pass's list and its LODs in ONE launch
-// (the pick reads what the entity update of the same frame left in L2; as its own launch it cost a dependent launch's
-// latency on top of ~10 us).  Same list, same LODs as the two launches.
-__global__ __launch_bounds__(ENT_BLOCK)
-void k_visible_expand_rp_lod(const uint64_t *vis_mask, const uint8_t *row_pop, uint32_t n, uint32_t index_base, uint32_t *visible,
-                             uint32_t *count, LodK lk, int32_t *draw_lod)
-{
-    const int lane = lane_id();
-    const uint32_t g = blockIdx.x * (ENT_BLOCK / WAVE) + threadIdx.x / WAVE;
-    const uint32_t n_rows = (n + 63) / 64;
-    const uint32_t row0 = g * RP_ROWS;
-    if (row0 >= n_rows)
-        return;
-    const uint32_t pre = wave_byte_sum(row_pop, row0, lane);
-    const uint64_t word = lane < RP_ROWS ? load_mask_word(vis_mask, row0 + lane, n) : 0ull;
-    const uint32_t cnt = __popcll(word);
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int off = 1; off < RP_ROWS; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    const uint32_t excl = incl - cnt;
-    const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
-#pragma unroll 1                                // the pick is ~300 instructions: sixteen copies would not fit the instruction cache
-    for (int k = 0; k < RP_ROWS; k++) {
-        const uint64_t wk = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, k) |
-                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32);
-        if (wk == 0) continue;                        // scalar branch
-        const uint32_t base = pre + (uint32_t)__builtin_amdgcn_readlane(excl, k);
-        if ((wk >> lane) & 1ull) {
-            const uint32_t rank = __popcll(wk & ((1ull << lane) - 1ull));
-            const uint32_t i = (row0 + k) * 64u + lane;
-            visible[base + rank] = index_base + i;
-            draw_lod[base + rank] = lod_pick(lk, i);
-        }
-    }
-    if (row0 + RP_ROWS >= n_rows && lane == RP_ROWS - 1)
-        *count = pre + incl;
-}
-
 // ---- a host mirror's small frames: touched inputs in, rebuilt outputs out, through device-mapped host memory -----------
 // A frame of a testbed-sized scene (BASELINE configs[0]: 10 k entities) is a 15-30 us kernel; staged through device
 // slabs it paid three copies' fixed latencies and a blocking wait on top (0.15 ms).  Letting the update kernel itself
@@ -1094,8 +1053,10 @@ extern "C" int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, con
     return CLAPGPU_OK;
 }
 
-// clapgpu_visible_compact + clapgpu_entities_lod of this shard's own entities as one launch where the single-launch
-// compaction applies (vis_row_pop, <= 4M entities); two launches otherwise.  Same outputs.
+// clapgpu_visible_compact + clapgpu_entities_lod of this batch's own entities: the render pass's list and its LODs by one
+// call.  Two launches: a single kernel that picks the LOD of every id as it writes it was built and measured (round 5,
+// profiles/r05_experiments/lod_in_expand.md) -- the expansion walks sixteen mask rows per wavefront one after the other,
+// and with the pick's chain of dependent loads under every row it took 42 us against 6 + 10 us for the two.
 extern "C" int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities *e, uint32_t index_base, const float cam_pos[3],
                                            const int32_t *force_lod, int32_t *cur_lod, uint32_t *visible, uint32_t *count,
                                            int32_t *draw_lod, void *scratch)
@@ -1103,14 +1064,7 @@ extern "C" int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities 
     if (!e || !count || !cam_pos || !cur_lod || !draw_lod || (e->n && (!e->vis_mask || !visible)) || !e->aabb || !e->center ||
         !e->pos_scale || !e->model || !e->model_table)
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
-    const uint32_t n = e->n, n_rows = (n + 63) / 64;
-    if (n && e->vis_row_pop && n_rows <= RP_MAX_ROWS && aligned16(e->vis_row_pop)) {
-        const uint32_t waves = (n_rows + RP_ROWS - 1) / RP_ROWS, per_block = ENT_BLOCK / WAVE;
-        hipLaunchKernelGGL(k_visible_expand_rp_lod, dim3((waves + per_block - 1) / per_block), dim3(ENT_BLOCK), 0, as_stream(stream),
-                           e->vis_mask, e->vis_row_pop, n, index_base, visible, count, lod_args(e, cam_pos, force_lod, cur_lod), draw_lod);
-        CLAPGPU_LAUNCH_CHECK("k_visible_expand_rp_lod");
-        return CLAPGPU_OK;
-    }
+    const uint32_t n = e->n;
     int rc = clapgpu_visible_compact(stream, e->vis_mask, e->vis_row_pop, n, index_base, visible, count, scratch);
     if (rc) return rc;
     return clapgpu_entities_lod(stream, e, visible, count, index_base, cam_pos, force_lod, cur_lod, draw_lod);

@@ -200,7 +200,7 @@ class EntityBatch:
         _lib.check(rc, "clapgpu_entities_lod")
 
     def compact_visible_lod(self, cam_pos, force_lod=None, index_base=0):
-        """compact_visible() + select_lod() as ONE launch (clapgpu_visible_compact_lod): the render pass's ordered list and
+        """compact_visible() + select_lod() by one C call (clapgpu_visible_compact_lod): the render pass's ordered list and
         the LOD of every entry."""
         self.alloc_lod()
         if force_lod is not None:

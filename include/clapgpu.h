@@ -327,9 +327,8 @@ int clapgpu_visible_compact(void *stream, const uint64_t *vis_mask, const uint8_
 int clapgpu_entities_lod(void *stream, const clapgpu_entities *e, const uint32_t *visible,
                          const uint32_t *count, uint32_t index_base, const float cam_pos[3],
                          const int32_t *force_lod, int32_t *cur_lod, int32_t *draw_lod);
-/* clapgpu_visible_compact + clapgpu_entities_lod over this batch's own vis_mask as ONE launch (where the single-launch
- * compaction applies: vis_row_pop present, <= 4M entities; two launches otherwise): the ordered visible list of a render
- * pass and the LOD each entry is drawn with.  Same outputs as the two calls. */
+/* clapgpu_visible_compact + clapgpu_entities_lod over this batch's own vis_mask by one call: the ordered visible list of a
+ * render pass and the LOD each entry is drawn with.  (Two launches: the single-kernel form was measured slower.) */
 int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities *e, uint32_t index_base, const float cam_pos[3],
                                 const int32_t *force_lod, int32_t *cur_lod, uint32_t *visible, uint32_t *count,
                                 int32_t *draw_lod, void *scratch);

@@ -79,7 +79,7 @@ def test_hip_lod_matches_oracle(layout, cuda_device):
         assert np.array_equal(got_draw, draw), f"draw list LODs, camera {cam_pos}"
         assert np.array_equal(batch.cur_lod.cpu().numpy()[:scene["n"]], cur), "entity3d.cur_lod"
     assert len(np.unique(draw)) >= 3
-    # the list and its LODs as ONE launch (clapgpu_visible_compact_lod, what a frame issues): the same list, the same picks
+    # the list and its LODs by one call (clapgpu_visible_compact_lod, what a frame issues): the same list, the same picks
     fused = entities.EntityBatch(scene, cuda_device)
     fused.mq_update(fr)
     cur2 = np.zeros(scene["n"], np.int32)
