@@ -199,8 +199,11 @@ __device__ __forceinline__ Col comb4(const Col A0, const Col A1, const Col A2, c
 #define POSE_BLOCK64 768
 #endif
 constexpr int POSE_WAVES = POSE_WAVES_PER_SIMD;   // wavefronts per SIMD the registers are budgeted for (168 VGPRs)
-constexpr int POSE_TIMES_LDS_MAX = 6400;     // key times kept in LDS when the model's rows fit: 25 KiB per 64 lanes (one animation of <= 31 keys
-                                             // per channel with its key counts)
+#ifndef POSE_TIMES_LDS_FLOATS
+#define POSE_TIMES_LDS_FLOATS 6400             // (an occupancy experiment builds with less: profiles/r05_experiments/pose_occupancy.md)
+#endif
+constexpr int POSE_TIMES_LDS_MAX = POSE_TIMES_LDS_FLOATS;   // key times kept in LDS when the model's rows fit: 25 KiB per 64 lanes (one
+                                             // animation of <= 31 keys per channel with its key counts)
 constexpr int POSE_MAX_JOINTS = 256;
 
 typedef int pose_v4i __attribute__((ext_vector_type(4)));
