@@ -119,7 +119,7 @@ struct gpu_scene {
      * look-up, no cache miss beside the entity it has just written; the frame's mirror pass resolves the addresses
      * through a flat table (address -> record, mirror handle) rebuilt by every walk, on all worker threads */
     entity3d        **xptr; uint32_t n_xptr, cap_xptr;
-    struct gs_fast { uint64_t key; uint32_t rec, handle; } *ftab; uint32_t ftab_mask, ftab_cap;
+    struct gs_fast { uint64_t key; uint32_t handle, slot; } *ftab; uint32_t ftab_mask, ftab_cap;
     uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
     uint32_t        *deferred; uint32_t n_deferred, cap_deferred;  /* class 3 records in list order (last walk) */
     uint32_t        *att_list; uint32_t n_att, cap_att;            /* class 4 records in list order (last walk) */
@@ -676,7 +676,7 @@ static int ftab_build(struct gpu_scene *gs)
         const struct gs_rec *r = &gs->rec[gs->order[k]];
         uint32_t h = ftab_home(gs, r->e);
         while (gs->ftab[h].key) h = (h + 1) & gs->ftab_mask;
-        gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)r->e, gs->order[k], (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY };
+        gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)r->e, (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY, r->slot };
     }
     return 0;
 }
@@ -713,6 +713,8 @@ static void xptr_range(void *ctx, uint32_t lo, uint32_t hi)
             if (gs->ftab[h].key && gs->ftab[h].handle != CLAPGPU_NO_ENTITY) {   /* ours, and on the device */
                 ring[k & 7] = h;
                 __builtin_prefetch(&e->xform, 1, 1);
+                __builtin_prefetch((const char *)&e->xform + 32, 1, 1);  /* (transform_t + scale may straddle a line) */
+                clapgpu_scene_entity_xform_prefetch(gs->scene, gs->ftab[h].handle, gs->ftab[h].slot);
             } else
                 ring[k & 7] = NO_REC;                            /* another queue's entity, or a host-class one: its own hook reads the transform */
         }
@@ -964,7 +966,7 @@ struct par_job {
     void (*range_fn)(void *, uint32_t, uint32_t); void *ctx;     /* gpu_scene_par_for */
 };
 
-#define GS_MAX_THREADS 16
+#define GS_MAX_THREADS 32
 static int par_threads(void)
 {
     static int cached;
@@ -972,6 +974,7 @@ static int par_threads(void)
         long n = sysconf(_SC_NPROCESSORS_ONLN);
         const char *env = getenv("GPU_SCENE_THREADS");           /* the passes are memory latency: they scale with the cores until DRAM says no */
         if (env && atoi(env) > 0) n = atoi(env);
+        else if (n > 24) n = 24;                                 /* measured on a 128-core host: 8 -> 16 -> 24 threads 26 -> 15 -> 12 ms, 32: 14 */
         if (n > GS_MAX_THREADS) n = GS_MAX_THREADS;
         cached = n < 1 ? 1 : (int)n;
     }

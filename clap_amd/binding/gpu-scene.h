@@ -165,7 +165,7 @@ void gpu_scene_topology(struct gpu_scene *gs);
  */
 void gpu_scene_set_verify(struct gpu_scene *gs, bool on);
 
-/* The binding's worker threads (kept between frames, at most fifteen beside the caller; GPU_SCENE_THREADS caps the total) for its other translation units:
+/* The binding's worker threads (kept between frames, at most 31 beside the caller, 23 by default; GPU_SCENE_THREADS sets the total) for its other translation units:
  * fn(ctx, lo, hi) over [0, n) in `threads` contiguous ranges, the caller taking the first; returns when all are done. */
 void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads);
 /* The pool behind gpu_scene_par_for is shared by every binding object of the process: whoever may call it holds a

@@ -469,6 +469,18 @@ int clapgpu_scene_entity_xform_mt(clapgpu_scene *s, uint32_t handle, const float
     return CLAPGPU_OK;
 }
 
+/* what the call above will touch for (handle, slot), asked for ahead of time: the mirror's own record and the three rows of
+ * the upload image -- four cache lines nothing else would bring in before the call stalls on each in turn */
+void clapgpu_scene_entity_xform_prefetch(const clapgpu_scene *s, uint32_t handle, uint32_t slot)
+{
+    if (!s || handle >= s->n_handles) return;
+    __builtin_prefetch(&s->e[handle], 1, 1);
+    if (s->topology_dirty || !s->h_in || slot >= s->n_slots) return;
+    __builtin_prefetch(s->h_pos_scale + 4 * (size_t)slot, 1, 1);
+    __builtin_prefetch(s->h_rot + 4 * (size_t)slot, 1, 1);
+    __builtin_prefetch(s->h_flags + slot, 1, 1);
+}
+
 void clapgpu_scene_mark_all_dirty(clapgpu_scene *s) { if (s) s->bulk_dirty = 1; }
 
 int clapgpu_scene_entity_rotation(clapgpu_scene *s, uint32_t handle, const float q[4])

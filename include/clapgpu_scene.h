@@ -64,6 +64,7 @@ int  clapgpu_scene_entity_transform_mt(clapgpu_scene *s, uint32_t handle, const 
                                        float scale, uint32_t flags, int xform_updated);
 int  clapgpu_scene_entity_xform_mt(clapgpu_scene *s, uint32_t handle, const float pos[3], const float quat_xyzw[4],
                                    float scale, int xform_updated);   /* the transform alone; xform_updated is OR-ed in */
+void clapgpu_scene_entity_xform_prefetch(const clapgpu_scene *s, uint32_t handle, uint32_t slot);   /* the lines the call above writes */
 void clapgpu_scene_mark_all_dirty(clapgpu_scene *s);
 /* entity3d_move / entity3d_rotate (radians) / entity3d_visible (model.c:1810-1842) */
 int  clapgpu_scene_entity_move(clapgpu_scene *s, uint32_t handle, const float off[3]);
