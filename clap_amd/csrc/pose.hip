@@ -14,14 +14,18 @@
 //   * slerp (interp.h:91-118): theta_0 = (float)acos(dot) and sin(theta_0) depend on the KEY PAIR alone, so
 //     clapgpu_animations_pack() evaluates them once per model ON THE HOST with the host's libm -- the very
 //     calls the reference makes -- and stores them per key interval; sin(theta) and cos(theta) of the frame
-//     are fp64 polynomials on [0, pi/2] whose fp64 error (<= 2 ulp) flips the FLOAT the reference rounds
-//     them to less than once in 10^8 evaluations (none in 2 * 10^8 against glibc, tools/pose_exact_probe.c);
+//     are fp64 polynomials on [0, pi/2].  MEASURED against glibc (tools/pose_exact_probe.c, round 5): (float)sin(theta)
+//     is glibc's for EVERY float theta of [0, pi/2] (all 1 070 141 404 of them: exact by exhaustion); _rfac =
+//     (float)(cos(theta) - u) cancels as fac -> 1 and rounds one float ulp differently in 27 of 10^10 slerps with fac
+//     uniform in [0, 1] (the polynomial's cos differs from glibc's in its last fp64 bits for 0.32 % of the arguments):
+//     at 3.2 M slerps a frame, one weight of one quaternion one ulp off every ~115 frames;
 //     the two quotients by sin(theta_0) are fp64 products with its stored reciprocal, rounded to float: the fp32
 //     quotient exactly (a quotient of two floats keeps 2^-49 away from every rounding boundary, the product errs by 2^-52);
 //   * hierarchy: global[j] = ((global[parent] * T) * R) * S, evaluated level by level in THAT association
 //     (model.c:1363-1383), then * invmx (model.c:1389), * bind's translation column, e->mx * (model.c:1392-1400).
-// T / R / S, the palette and the joint positions therefore EQUAL the reference's, bit for bit: 0 of 3.2 M joints
-// differ at BASELINE configs[2] (tests/test_pose_skin_gpu.py, tools/pose_exact_check.py), and so do the skinned vertices.
+// T / R / S, the palette and the joint positions therefore EQUAL the reference's, bit for bit, except where that one
+// subtraction flips (2.7e-9 of the slerps): 0 of 3.2 M joints differ at BASELINE configs[2] in the tests' frames
+// (tests/test_pose_skin_gpu.py, tools/pose_exact_check.py), and so do the skinned vertices.
 // (Signed zeros included: the "0.f +" that opens mat4x4_mul's sums and turns a -0 sum into +0 is the zero addend of the
 // v_pk_fma_f32 that forms the first product -- comb4<true>.)
 //
