@@ -227,3 +227,120 @@ def test_hostio_argument_validation(cuda_device):
     rc = L.clapgpu_entities_update_tiles_hostio(None, C.byref(b._desc), C.c_void_p(b.tile_row_start.data_ptr()), b.n_tiles, 0,
                                                 None, None)
     assert rc == _lib.ERR_INVALID_ARGUMENTS
+
+
+class Export(C.Structure):
+    _fields_ = [("mx", C.c_void_p), ("inv_mx", C.c_void_p), ("aabb", C.c_void_p), ("center", C.c_void_p),
+                ("vis_mask", C.c_void_p), ("rebuilt_mask", C.c_void_p), ("inside_mask", C.c_void_p),
+                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32)]
+
+
+@pytest.mark.parametrize("cull", [True, False])
+def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull, cuda_device):
+    """clapgpu_entities_hostio.keep_mask (what GPU_SCATTER_DRAWN rests on): with it the launch writes to the mapped result
+    arrays exactly the rebuilt rows of entities that are drawn (vis_mask), contain a bounding-volume point, or are flagged
+    in keep_mask -- exported_mask says which, every other mapped row is left as it was -- while the DEVICE arrays hold
+    every rebuilt row as without the policy (against the oracle, bit for bit).  Without a frustum everything rebuilt comes
+    back (a pass without a camera draws everything).  clapgpu_entities_export_rows then brings any selection over."""
+    import torch
+    from clap_amd import entities
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(77))
+    scene = tiler.tiled_scene(synth.entities_forest(5_000, 17, max_depth=6))[0]
+    n, words = int(scene["n"]), int(scene["n"]) // 64
+    cam = synth.camera(pos=(0, 5, 60))
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    fr_o, _vo, _po = ob.frustum_from_camera(cam)
+    if not cull:
+        fr = None
+    st = ob.entity_state(scene)
+    b = entities.EntityBatch(scene, cuda_device)
+    reb_dev = torch.zeros(words + 2, dtype=torch.int64, device=b.device)
+    inside_dev = torch.zeros(words + 2, dtype=torch.int64, device=b.device)
+    b._desc.rebuilt_mask = reb_dev.data_ptr()
+    bvq = _lib.BvQuery()
+    probe = scene["pos_scale"][np.flatnonzero(((scene["flags"] & np.uint32(_lib.E_ALIVE)) != 0) & (scene["parent"] < 0))[7], :3].copy()
+    bvq.cam_pos[:] = [float(v) for v in probe]
+    bvq.has_ctl, bvq.ctl_entity, bvq.result, bvq.inside_mask = 0, 0, None, inside_dev.data_ptr()
+    b._desc.bv = C.pointer(bvq)
+    img = Mapped(n * 36 + (words + 2) * 8)
+    out = Mapped(n * 164 + 4 * (words + 2) * 8)
+    word = Mapped(64)
+    sel = Mapped((words + 2) * 8)
+    counter = torch.zeros(1, dtype=torch.int32, device=b.device)
+    keep = np.zeros(words + 2, np.uint64)
+    alive = (scene["flags"] & np.uint32(_lib.E_ALIVE)) != 0
+    kept = (rng.uniform(0, 1, n) < 0.05) & alive
+    keep[:words] = np.packbits(kept, bitorder="little").view(np.uint64)
+    keep_dev = torch.from_numpy(keep.view(np.int64)).to(b.device)
+    h_ps, h_rot = img.view(0, 4 * n, np.float32).reshape(n, 4), img.view(16 * n, 4 * n, np.float32).reshape(n, 4)
+    h_fl, h_touched = img.view(32 * n, n, np.uint32), img.view(36 * n, words + 2, np.uint64)
+    h_ps[:], h_rot[:], h_fl[:] = scene["pos_scale"], scene["rot"], scene["flags"]
+    mw = (words + 2) * 8
+    o = dict(mx=out.view(0, 16 * n, np.float32).reshape(n, 16), inv=out.view(64 * n, 16 * n, np.float32).reshape(n, 16),
+             aabb=out.view(128 * n, 6 * n, np.float32).reshape(n, 6), ctr=out.view(152 * n, 3 * n, np.float32).reshape(n, 3))
+    o_vis, o_reb = out.view(164 * n, words + 2, np.uint64), out.view(164 * n + mw, words + 2, np.uint64)
+    o_ins, o_exp = out.view(164 * n + 2 * mw, words + 2, np.uint64), out.view(164 * n + 3 * mw, words + 2, np.uint64)
+    io = Hostio(pos_scale=img.dev(0), rot=img.dev(16 * n), flags=img.dev(32 * n), touched=img.dev(36 * n),
+                mx=out.dev(0), inv_mx=out.dev(64 * n), aabb=out.dev(128 * n), center=out.dev(152 * n),
+                vis_mask=out.dev(164 * n), rebuilt_mask=out.dev(164 * n + mw), inside_mask=out.dev(164 * n + 2 * mw),
+                counter=counter.data_ptr(), done=word.dev(0), keep_mask=keep_dev.data_ptr(), exported_mask=out.dev(164 * n + 3 * mw))
+    POISON = np.float32(-12345.5)
+    bits = lambda m: np.unpackbits(np.ascontiguousarray(m[:words]).view(np.uint8), bitorder="little").astype(bool)[:n]
+    has_box = np.asarray(scene["model_skip"])[scene["model"]] == 0
+    try:
+        stale = np.zeros(n, bool)
+        for frame in range(4):
+            ob.entities_update(scene, st)
+            vis, mask = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fr_o)
+            for a in o.values():
+                a[:] = POISON
+            run_hostio(b, io, fr, frame + 1)
+            _lib.check(L.clapgpu_wait_word(C.c_void_p(word.h.value), frame + 1, None), "clapgpu_wait_word")
+            torch.cuda.synchronize()
+            reb, exp, ins = bits(o_reb), bits(o_exp), bits(o_ins)
+            db = b.download()
+            for k, ok in (("mx", "mx"), ("inv_mx", "inv_mx")):
+                assert np.array_equal(db[k].view(np.uint32), st[ok].reshape(n, 16).view(np.uint32)), f"frame {frame}: device {k}"
+            visb = bits(o_vis) if cull else np.ones(n, bool)
+            if cull:
+                assert np.array_equal(o_vis[:mask.size], mask)
+            box = st["aabb"].reshape(n, 6)
+            inside_ref = alive & np.all(probe >= box[:, :3], axis=1) & np.all(probe <= box[:, 3:], axis=1)
+            assert np.array_equal(ins, inside_ref), f"frame {frame}: containment mask"
+            want = reb & (visb | ins | kept)
+            assert np.array_equal(exp, want), f"frame {frame}: exported = rebuilt & (drawn | containing | kept)"
+            assert reb.sum() > 50 and (cull and 0 < exp.sum() < reb.sum() or not cull and exp.sum() == reb.sum())
+            assert np.array_equal(o["mx"][exp].view(np.uint32), db["mx"][exp].view(np.uint32)), f"frame {frame}: exported mx"
+            assert np.array_equal(o["inv"][exp].view(np.uint32), db["inv_mx"][exp].view(np.uint32))
+            eb = exp & has_box
+            assert np.array_equal(o["aabb"][eb].view(np.uint32), db["aabb"][eb].view(np.uint32))
+            assert np.array_equal(o["ctr"][eb].view(np.uint32), db["center"][eb].view(np.uint32))
+            assert (o["mx"][~exp] == POISON).all() and (o["aabb"][~exp] == POISON).all(), f"frame {frame}: a row nobody reads was written"
+            stale = (stale | reb) & ~exp
+            # fetch a third of what is stale, by mask
+            pick = stale & (rng.uniform(0, 1, n) < 0.34)
+            sel.view(0, words + 2, np.uint64)[:words] = np.packbits(pick, bitorder="little").view(np.uint64)
+            x = Export(mx=out.dev(0), inv_mx=out.dev(64 * n), aabb=out.dev(128 * n), center=out.dev(152 * n),
+                       counter=counter.data_ptr(), done=word.dev(0), done_value=1000 + frame)
+            _lib.check(L.clapgpu_entities_export_rows(None, C.byref(b._desc), C.byref(x), C.c_void_p(sel.dev(0))), "export_rows")
+            _lib.check(L.clapgpu_wait_word(C.c_void_p(word.h.value), 1000 + frame, None), "clapgpu_wait_word")
+            assert np.array_equal(o["mx"][pick].view(np.uint32), db["mx"][pick].view(np.uint32)), f"frame {frame}: fetched rows"
+            assert np.array_equal(o["aabb"][pick & has_box].view(np.uint32), db["aabb"][pick & has_box].view(np.uint32))
+            assert (o["mx"][~exp & ~pick] == POISON).all(), f"frame {frame}: the fetch wrote a row it was not asked for"
+            assert np.array_equal(bits(o_reb), reb) and np.array_equal(bits(o_exp), exp), "a fetch leaves the frame's masks alone"
+            stale &= ~pick
+            # next frame: a fifth of the entities move
+            h_touched[:] = 0
+            move = (rng.uniform(0, 1, n) < 0.2) & alive
+            ps = scene["pos_scale"].copy()
+            ps[move, :3] += rng.uniform(-5, 5, (int(move.sum()), 3)).astype(np.float32)
+            scene["pos_scale"][move] = ps[move]
+            st["flags"][move] |= np.uint32(_lib.E_DIRTY)
+            h_ps[move] = ps[move]
+            h_fl[move] = st["flags"][move]
+            h_touched[:words] = np.packbits(move, bitorder="little").view(np.uint64)
+    finally:
+        torch.cuda.synchronize()
+        b._desc.bv = None
+        img.free(); out.free(); word.free(); sel.free()
