@@ -202,6 +202,7 @@ static uint32_t n_ids, cap_ids;
 static bool parents_first;                 /* bench: every parent also precedes its children in the queue */
 static bool opt_notify;                    /* the engine reports what it touches (gpu_scene_touch / _topology): O(dirty) frames */
 static bool opt_drawn;                     /* GPU_SCATTER_DRAWN: fast frames write back what is read; the rest is fetched on demand */
+static uint32_t opt_churn;                 /* bench: entities deleted AND created per frame (a queue whose make-up changes every frame) */
 static uint64_t n_stale_seen, n_partial_frames;
 static bool may_parent(uint32_t p, uint32_t c)
 {
@@ -937,7 +938,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
     rng_state = 7;
     parents_first = true;
-    cap_ids = n;
+    cap_ids = n + (frames + 2) * opt_churn;
     meta = calloc(cap_ids, sizeof(*meta));
     world_init(&A, cap_ids);
     world_init(&B, cap_ids);
@@ -965,19 +966,32 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
          * notification) -- timed apart, since the notification is a cost the binding adds to the mutators */
         const uint64_t rs = rng_state;
         double m0 = now_s();
-        for (uint32_t id = 0; id < n; id++) {
+        for (uint32_t id = 0; id < n_ids; id++) {
             if (f && rndn(1000) >= dirty_permille) continue;
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
-            ref_entity3d_move(A.e[id], off);
+            if (A.e[id]) ref_entity3d_move(A.e[id], off);
         }
         double m1 = now_s();
         rng_state = rs;
-        for (uint32_t id = 0; id < n; id++) {
+        for (uint32_t id = 0; id < n_ids; id++) {
             if (f && rndn(1000) >= dirty_permille) continue;
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
-            entity3d_move(B.e[id], off);
+            if (B.e[id]) entity3d_move(B.e[id], off);
         }
         double m2 = now_s();
+        for (uint32_t c = 0; f && c < opt_churn; c++) {                  /* the queue's make-up changes: leaves go, new entities come */
+            for (int tries = 0; tries < 64; tries++) {
+                const uint32_t id = rndn(n_ids);
+                if (!meta[id].alive || meta[id].n_children || id == 0) continue;
+                if (meta[id].parent != NONE) meta[meta[id].parent].n_children--;
+                meta[id].alive = 0;
+                entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);
+                gpu_scene_topology(gpu_scene_bound());
+                A.e[id] = B.e[id] = NULL;
+                break;
+            }
+            op_create(500.f, false);
+        }
         /* the camera drifts: every frame a few entities come into view that were not drawn before */
         cpos[0] += 0.75f; cpos[2] -= 0.5f;
         quat_from_euler_xyz(cq, 0, 0.01f * f, 0);
@@ -1034,9 +1048,10 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
         }
     }
     if (opt_drawn && (rc = gpu_scene_fetch_all(gs))) { fprintf(stderr, "gpu_scene_fetch_all: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
-    for (uint32_t id = 0; id < n; id++)
-        bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24) || A.e[id]->seq != B.e[id]->seq ||
-               A.e[id]->parent_seq != B.e[id]->parent_seq || A.e[id]->cur_lod != B.e[id]->cur_lod;
+    for (uint32_t id = 0; id < n_ids; id++)
+        if (A.e[id])
+            bad += !!memcmp(A.e[id]->mx, B.e[id]->mx, 64) || !!memcmp(A.e[id]->aabb, B.e[id]->aabb, 24) || A.e[id]->seq != B.e[id]->seq ||
+                   A.e[id]->parent_seq != B.e[id]->parent_seq || A.e[id]->cur_lod != B.e[id]->cur_lod;
     const double F = frames;
     printf("{\"mode\": \"bench\", \"entities\": %u, \"frames\": %u, \"dirty_permille\": %u, "
            "\"reference_ms_per_frame\": %.4f, \"binding_ms_per_frame\": %.4f, "
@@ -1046,7 +1061,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"reference_render_block_ms\": %.4f, \"binding_render_block_ms\": %.4f, \"binding_draw_list_ms\": %.4f, "
            "\"reference_frame_ms\": %.4f, \"binding_frame_block_ms\": %.4f, \"binding_frame_draw_list_ms\": %.4f, "
            "\"drawn_per_frame\": %.1f, \"draw_sets_equal\": %s, \"draw_reads_equal\": %s, "
-           "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, "
+           "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, \"churn_per_frame\": %u, "
            "\"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
            "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
@@ -1054,7 +1069,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            1e3 * t_ref_mut / F, 1e3 * t_gpu_mut / F, 1e3 * t_ref_blk / F, 1e3 * t_gpu_blk / F, 1e3 * t_gpu_list / F,
            1e3 * (t_ref_mut + t_ref_upd + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_list) / F,
            drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
-           opt_drawn ? "drawn" : "all", left_stale / F, fetched / F,
+           opt_drawn ? "drawn" : "all", left_stale / F, fetched / F, opt_churn,
            opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;
@@ -1685,6 +1700,7 @@ static int run(int argc, char **argv)
         if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "drawn")) { opt_drawn = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "steady")) { opt_steady = true; argc--; }
+        else if (argc > 3 && !strcmp(argv[argc - 2], "churn")) { opt_churn = (uint32_t)atoi(argv[argc - 1]); argc -= 2; }
         else break;
     }
     if (argc >= 6 && !strcmp(argv[1], "fail")) {                        /* fail <launches> <entities> <frames> <seed>: `test` with the device failing after <launches> launches */
