@@ -21,6 +21,9 @@
  *       batched entity (and, through its seq, its children) up to date with the next mq_update
  *   void entity3d_set_lod(entity3d *e, int lod, bool force)         model.h:692   model.c:593-609
  *       the reference's body + gpu_scene_lod_changed(): the per-pass LOD pick (gpu_scene_select_lod) runs on the device
+ *   void entity3d_delete(entity3d *e)                               model.h       model.c:1787-1791
+ *       gpu_scene_entity_deleting() + the reference's body: a queue that loses (and, through the one line in
+ *       entity3d_make, gains) a few entities a frame is not walked for it
  *   void particle_system_position(particle_system *ps, const vec3 c) particle.h:47  particle.c:132-157
  *       in gpu-particles.inc.c (the struct is private to particle.c): an attached, mirrored system carries its
  *       device-resident particles along
@@ -120,6 +123,16 @@ void entity3d_set_lod(entity3d *e, int lod, bool force)
 {
     ref_entity3d_set_lod(e, lod, force);
     gpu_scene_lod_changed(gpu_scene_bound(), e);
+}
+
+/* model.h, model.c:1787-1791: the binding hears of it BEFORE the entity goes (a batched leaf is taken out of the standing
+ * device layout without a walk of the queue, gpu_scene_entity_deleting), then the reference's body.  entity3d_make and
+ * entity3d_drop are static in model.c: the maintainer's patch gives each its one line. */
+void ref_entity3d_delete(entity3d *e);
+void entity3d_delete(entity3d *e)
+{
+    gpu_scene_entity_deleting(gpu_scene_bound(), e);
+    ref_entity3d_delete(e);
 }
 
 #endif /* CONFIG_GPU_SCENE */

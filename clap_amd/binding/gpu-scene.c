@@ -83,6 +83,8 @@ struct gs_rec {
     uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
                                    gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
+    uint64_t    order_key;      /* its place in the queue: txmodel's rank << 32 | position in that txmodel's list (order_pos is the
+                                   place in order[], where entities taken in without a walk stand at the end) */
     int32_t     lod_force, lod_cur; /* e->force_lod / e->cur_lod as the mirror holds them (gpu_scene_select_lod) */
 };
 
@@ -157,6 +159,15 @@ struct gpu_scene {
     entity3d        *last_control;
     uint32_t        fetch_seen;                                    /* clapgpu_scene_arrays.fetch_serial already copied out */
     uint64_t        *walk_fetch; uint32_t cap_walk_fetch; bool walk_fetch_on;   /* rows fetched for a walk, applied as the walk meets each entity */
+    /* creation / deletion without a walk (gpu_scene_entity_created / _deleting) */
+    entity3d        **created; uint32_t n_created, cap_created;    /* reported since the last update, in creation order */
+    uint32_t        *dead_recs; uint32_t n_dead_recs, cap_dead_recs;   /* records of entities taken out in place: tombstones in order[] until the next walk */
+    struct gs_wtxm { const model3dtx *txm; uint32_t next; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
+    bool            incremental;
+    bool            appended;                                      /* order[] is no longer in list order: entities were taken in since the last walk */
+    uint32_t        ftab_count;
+    struct gs_cand { uint64_t key; uint32_t rec; } *cands; uint32_t cap_cands;
+    uint32_t        inc_placed, inc_removed;
     struct gpu_scene_stats stats;
 };
 
@@ -261,6 +272,8 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     gs->verify = getenv("GPU_SCENE_VERIFY") != NULL;
     const char *sp = getenv("GPU_SCENE_SCATTER");
     gs->scatter_drawn = sp && !strcmp(sp, "drawn");
+    const char *ip = getenv("GPU_SCENE_INCREMENTAL");
+    gs->incremental = !(ip && !strcmp(ip, "0"));
     gpu_scene_pool_ref();
     *out = gs;
     return 0;
@@ -275,6 +288,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->shown); free(gs->xptr); free(gs->ftab);
+    free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands);
     free(gs->walk_fetch); free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
@@ -459,6 +473,7 @@ static inline void prefetch_entity(const entity3d *e)
     /* sizeof(entity3d) is seven cache lines and both passes touch most of them; the record array
      * tells us which entity comes eight steps later without chasing the list */
     const char *p = (const char *)e;
+    if (!p) return;                                              /* a tombstone of order[] (gpu_scene_entity_deleting) */
     for (unsigned o = 0; o < sizeof(entity3d); o += 64)
         __builtin_prefetch(p + o, 1, 1);
 }
@@ -552,7 +567,19 @@ static int push_u32(uint32_t **arr, uint32_t *n, uint32_t *cap, uint32_t v)
 
 bool gpu_scene_last_was_fast(const struct gpu_scene *gs) { return gs->last_fast; }
 
-void gpu_scene_set_notify(struct gpu_scene *gs, bool on) { gs->notify = on; gs->topology_pending = true; }
+void gpu_scene_set_notify(struct gpu_scene *gs, bool on)
+{
+    gs->notify = on; gs->topology_pending = true;
+    clapgpu_scene_set_incremental(gs->scene, on && gs->incremental);   /* re-tiles leave room for entities taken in without a walk */
+}
+
+void gpu_scene_set_incremental(struct gpu_scene *gs, bool on)
+{
+    if (!gs) return;
+    gs->incremental = on;
+    if (!on && (gs->n_created || gs->n_dead_recs)) gs->topology_pending = true;
+    clapgpu_scene_set_incremental(gs->scene, on && gs->notify);
+}
 void gpu_scene_set_verify(struct gpu_scene *gs, bool on) { if (gs) gs->verify = on; }
 
 /* verification mode: batched entities whose transform was written past the mutators; they join the touched list */
@@ -672,12 +699,30 @@ static int ftab_build(struct gpu_scene *gs)
     }
     gs->ftab_mask = cap - 1;
     memset(gs->ftab, 0, (size_t)cap * sizeof(*gs->ftab));
+    gs->ftab_count = 0;
     for (uint32_t k = 0; k < gs->n_order; k++) {
         const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (!r->e) continue;                                      /* taken out in place since the walk */
+        gs->ftab_count++;
         uint32_t h = ftab_home(gs, r->e);
         while (gs->ftab[h].key) h = (h + 1) & gs->ftab_mask;
         gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)r->e, (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY, r->slot };
     }
+    return 0;
+}
+
+/* an entity taken in (or out: handle CLAPGPU_NO_ENTITY -- the key stays, the probe chains run through it) without a walk */
+static int ftab_set(struct gpu_scene *gs, const entity3d *e, uint32_t handle, uint32_t slot)
+{
+    if (!gs->ftab) return 0;
+    uint32_t h = ftab_home(gs, e);
+    while (gs->ftab[h].key && gs->ftab[h].key != (uint64_t)(uintptr_t)e) h = (h + 1) & gs->ftab_mask;
+    if (!gs->ftab[h].key) {
+        if (handle == CLAPGPU_NO_ENTITY) return 0;
+        if (10ull * (gs->ftab_count + 1) > 7ull * gs->ftab_cap) return ftab_build(gs);   /* (order[] holds the new record already) */
+        gs->ftab_count++;
+    }
+    gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)e, handle, slot };
     return 0;
 }
 
@@ -755,6 +800,202 @@ void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e)
 /* entity3d_make / entity3d_delete, e->parent = ..., e->update = ..., a body / light / joint attached: the next
  * gpu_mq_update() walks the queue once */
 void gpu_scene_topology(struct gpu_scene *gs) { if (gs) gs->topology_pending = true; }
+
+/* ---- creation / deletion without a walk (gpu-scene.h) ------------------------------------------------------------------ */
+void gpu_scene_entity_created(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !e) return;
+    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) { gs->topology_pending = true; return; }
+    if (gs->n_created == gs->cap_created) {
+        const uint32_t cap = gs->cap_created ? 2 * gs->cap_created : 64;
+        entity3d **q = cap > (1u << 20) ? NULL : realloc(gs->created, (size_t)cap * sizeof(*q));   /* a level load: the walk is the cheaper frame */
+        if (!q) { gs->topology_pending = true; return; }
+        gs->created = q; gs->cap_created = cap;
+    }
+    gs->created[gs->n_created++] = e;
+}
+
+void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
+{
+    if (!gs || !e) return;
+    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) { gs->topology_pending = true; return; }
+    for (uint32_t k = gs->n_created; k-- > 0;)                   /* made and gone between two frames: never seen */
+        if (gs->created[k] == e) {
+            memmove(gs->created + k, gs->created + k + 1, (size_t)(gs->n_created - k - 1) * sizeof(*gs->created));
+            gs->n_created--;
+            return;
+        }
+    const uint32_t i = rec_find(gs, e);
+    if (i == NO_REC) return;                                     /* another queue's entity */
+    struct gs_rec *r = &gs->rec[i];
+    const struct scene *scene = gs->hook_data;
+    /* in place: a batched leaf nobody depends on -- no batched child (the mirror knows), no host-class child reading its
+     * matrix, not the control entity, no hook half of its own, no joint */
+    if (r->cls != 1 || r->host_child || r->att || r->handle == CLAPGPU_NO_ENTITY || e->update != gs->default_hook ||
+        e == gs->last_control || (scene && e == scene->control) ||
+        push_u32(&gs->dead_recs, &gs->n_dead_recs, &gs->cap_dead_recs, i)) {
+        gs->topology_pending = true;
+        return;
+    }
+    if (clapgpu_scene_entity_delete_placed(gs->scene, r->handle)) {
+        gs->n_dead_recs--;
+        gs->topology_pending = true;
+        return;
+    }
+    const uint32_t slot = r->slot;
+    if (gs->pend && slot < gs->cap_pend) { gs->pend[slot] = 0; if (gs->shown) gs->shown[slot] = 0; }
+    if (slot < gs->cap_slot_arrays) gs->slot_ent[slot] = NULL;
+    if (gs->vq_e && r->order_pos < gs->cap_vq) { gs->vq_e[r->order_pos] = NULL; gs->vq_ok[r->order_pos] = 0; }
+    ftab_set(gs, e, CLAPGPU_NO_ENTITY, 0);
+    /* the record stays where order[] names it, as a tombstone, until the next walk: out of the hash, no entity, no class */
+    uint32_t *link = &gs->bucket[ptr_hash(e) & (gs->n_bucket - 1)];
+    while (*link != i) link = &gs->rec[*link].next;
+    *link = r->next;
+    r->e = NULL; r->cls = 0; r->self_ok = 0; r->keep = r->user_keep = 0;
+    r->handle = r->parent_handle = CLAPGPU_NO_ENTITY;
+    r->parent_e = NULL; r->parent_rec = NO_REC;
+    gs->n_live--;
+    if (gs->n_batched) gs->n_batched--;
+    gs->inc_removed++;
+}
+
+static int ensure_order(struct gpu_scene *gs, uint32_t n)
+{
+    if (n > gs->cap_order) {
+        uint32_t cap = gs->cap_order ? gs->cap_order : 4096;
+        while (cap < n) cap *= 2;
+        uint32_t *o = realloc(gs->order, (size_t)cap * sizeof(*o));
+        if (o) gs->order = o;
+        uint32_t *po = realloc(gs->prev_order, (size_t)cap * sizeof(*po));
+        if (po) gs->prev_order = po;
+        if (!o || !po) return _CERR_NOMEM;
+        gs->cap_order = cap;
+    }
+    if (gs->cap_order > gs->cap_vq) {
+        const uint32_t cap = gs->cap_order;
+        entity3d **ve = realloc(gs->vq_e, (size_t)cap * sizeof(*ve));
+        if (ve) gs->vq_e = ve;
+        uint32_t *vs = realloc(gs->vq_slot, (size_t)cap * 4);
+        if (vs) gs->vq_slot = vs;
+        uint8_t *vo = realloc(gs->vq_ok, cap);
+        if (vo) gs->vq_ok = vo;
+        if (!ve || !vs || !vo) return _CERR_NOMEM;
+        gs->cap_vq = cap;
+    }
+    return 0;
+}
+
+/* the per-slot state of a fast frame, for a layout that grew at its end (a growth tile) */
+static int ensure_slot_state(struct gpu_scene *gs, uint32_t n_slots)
+{
+    if (gs->pend && gs->shown && n_slots > gs->cap_pend) {
+        uint16_t *pn = realloc(gs->pend, (size_t)n_slots * sizeof(*pn));
+        if (pn) gs->pend = pn;
+        uint16_t *sn = realloc(gs->shown, (size_t)n_slots * sizeof(*sn));
+        if (sn) gs->shown = sn;
+        if (!pn || !sn) return _CERR_NOMEM;
+        memset(gs->pend + gs->cap_pend, 0, (size_t)(n_slots - gs->cap_pend) * sizeof(*pn));
+        memset(gs->shown + gs->cap_pend, 0, (size_t)(n_slots - gs->cap_pend) * sizeof(*sn));
+        gs->cap_pend = n_slots;
+    }
+    if (gs->cap_slot_arrays && n_slots > gs->cap_slot_arrays) {
+        const uint32_t old = gs->cap_slot_arrays;
+        entity3d **a = realloc(gs->slot_ent, (size_t)n_slots * sizeof(*a));
+        if (a) gs->slot_ent = a;
+        uint16_t *b = realloc(gs->slot_txm, (size_t)n_slots * sizeof(*b));
+        if (b) gs->slot_txm = b;
+        int8_t *c = realloc(gs->slot_lod, n_slots);
+        if (c) gs->slot_lod = c;
+        if (!a || !b || !c) { gs->cap_slot_arrays = 0; return 0; }   /* the draw list goes through the records then */
+        memset(gs->slot_ent + old, 0, (size_t)(n_slots - old) * sizeof(*a));
+        gs->cap_slot_arrays = n_slots;
+    }
+    return 0;
+}
+
+/*
+ * The entities reported by gpu_scene_entity_created() since the last update, in creation order (= list order inside a
+ * txmodel: entity3d_make appends, model.c:1759): each gets a record, a place in the standing device layout and a seat at
+ * the end of order[]; its transform and flags travel with this frame's touched entities.  Returns 1 when one of them has
+ * to be met by a walk instead (then the frame is a walk: records made so far are found by it like any other).
+ */
+static int take_created(struct gpu_scene *gs, struct mq *mq)
+{
+    const struct scene *scene = mq->priv;
+    for (uint32_t k = 0; k < gs->n_created; k++) {
+        entity3d *e = gs->created[k];
+        if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;      /* the walk would not meet it either */
+        uint32_t rank = 0xffffffffu;
+        for (uint32_t t = gs->n_wtxm; t-- > 0;)
+            if (gs->wtxm[t].txm == e->txmodel) { rank = t; break; }
+        if (rank == 0xffffffffu) {
+            model3dtx *txm;
+            bool ours = false;
+            list_for_each_entry(txm, &mq->txmodels, entry) if (txm == e->txmodel) { ours = true; break; }
+            if (ours) return 1;                                  /* a txmodel the last walk has not seen */
+            continue;                                            /* another queue's entity */
+        }
+        if (e->update != gs->default_hook || !self_batchable(gs, e) || entity_animated(e) || e->parent_joint != JOINT_TYPE_MAX ||
+            !transform_is_updated(&e->xform) || rec_find(gs, e) != NO_REC)
+            return 1;
+        const uint64_t key = ((uint64_t)rank << 32) | gs->wtxm[rank].next;
+        uint32_t pi = NO_REC;
+        if (e->parent) {
+            pi = rec_find(gs, e->parent);
+            if (pi == NO_REC || gs->rec[pi].cls != 1 || gs->rec[pi].handle == CLAPGPU_NO_ENTITY || gs->rec[pi].order_key > key)
+                return 1;
+        }
+        uint32_t mh;
+        CK(model_handle(gs, e->txmodel->model, &mh));
+        CK(ensure_order(gs, gs->n_order + 1));
+        const uint32_t i = rec_add(gs, e);
+        if (i == NO_REC) return _CERR_NOMEM;
+        struct gs_rec *r = &gs->rec[i];
+        uint32_t handle, slot;
+        const int rc = clapgpu_scene_entity_new_placed(gs->scene, mh, (void *)(uintptr_t)(i + 1u),
+                                                       pi == NO_REC ? CLAPGPU_NO_ENTITY : gs->rec[pi].handle, &handle, &slot);
+        if (rc) {
+            rec_del(gs, i);
+            if (rc == CLAPGPU_ERR_NOT_SUPPORTED) return 1;       /* no room where it would have to go: the walk re-tiles */
+            return rc;
+        }
+        gs->wtxm[rank].next++;
+        r->model = e->txmodel->model;
+        r->handle = handle; r->slot = slot;
+        r->parent_e = e->parent; r->parent_rec = pi;
+        r->parent_handle = pi == NO_REC ? CLAPGPU_NO_ENTITY : gs->rec[pi].handle;
+        r->flags = ENTITY3D_ALIVE | ENTITY3D_VISIBLE;            /* what the mirror's entity starts with; the touched pass brings e->flags */
+        r->lod_force = -1; r->lod_cur = 0;
+        if (e->force_lod != -1 || e->cur_lod != 0) {
+            CK(clapgpu_scene_entity_lod(gs->scene, handle, e->force_lod, e->cur_lod));
+            r->lod_force = e->force_lod; r->lod_cur = e->cur_lod;
+        }
+        r->gen = gs->gen;
+        r->cls = 1; r->self_ok = 1;
+        r->order_key = key;
+        r->order_pos = gs->n_order;
+        gs->order[gs->n_order++] = i;
+        gs->appended = true;
+        CK(ensure_slot_state(gs, clapgpu_scene_slot_count(gs->scene)));
+        if (gs->pend && slot < gs->cap_pend) { gs->pend[slot] = 0; gs->shown[slot] = e->seq; }
+        if (slot < gs->cap_slot_arrays) {
+            const uint32_t g = txm_index(gs, e->txmodel);
+            if (g == 0xffffffffu || e->cur_lod < -128 || e->cur_lod > 127) gs->cap_slot_arrays = 0;
+            else { gs->slot_ent[slot] = e; gs->slot_txm[slot] = (uint16_t)g; gs->slot_lod[slot] = (int8_t)e->cur_lod; }
+        }
+        gs->vq_e[r->order_pos] = e; gs->vq_slot[r->order_pos] = slot; gs->vq_ok[r->order_pos] = 0;   /* until the touched pass has its flags */
+        CK(ftab_set(gs, e, handle, slot));
+        if (gs->scatter_drawn && (e->light_idx >= 0 || (scene && e == scene->control)) &&
+            !clapgpu_scene_entity_keep(gs->scene, handle, 1))
+            r->keep = 1;
+        r->pending = 1;
+        if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) return _CERR_NOMEM;
+        gs->n_batched++;
+        gs->inc_placed++;
+    }
+    gs->n_created = 0;
+    return 0;
+}
 
 /* A rebuilt entity WITHOUT a parent hands its position to the light it carries (model.c:1687-1692).  At most LIGHTS_MAX
  * entities do, each to its own slot, so this is safe from the scatter workers. */
@@ -1228,8 +1469,30 @@ static void pend_range(void *ctx, uint32_t lo, uint32_t hi)
     __atomic_fetch_add(&pc->left, left, __ATOMIC_RELAXED);
 }
 
+/* a host-class entity's own hook in a fast frame */
+static void host_hook(struct gpu_scene *gs, struct mq *mq, struct gs_rec *hr)
+{
+    if (hr->lag) {
+        /* listed before its batched parent: the reference has not updated that parent yet when this hook runs */
+        struct lag_keep *kp = &gs->lag_keep[hr->lag - 1], now;
+        entity3d *p = gs->rec[gs->lag_parent[hr->lag - 1]].e;
+        memcpy(now.mx, p->mx, sizeof(mat4x4)); now.seq = p->seq;
+        memcpy(p->mx, kp->mx, sizeof(mat4x4)); p->seq = kp->seq;
+        entity3d_update(hr->e, mq->priv);
+        memcpy(p->mx, now.mx, sizeof(mat4x4)); p->seq = now.seq;
+    } else
+        entity3d_update(hr->e, mq->priv);
+}
+
+static int cand_cmp(const void *a, const void *b)
+{
+    const struct gs_cand *x = a, *y = b;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+
 /*
- * One frame in notification mode, nothing created / deleted / re-parented since the last walk:
+ * One frame in notification mode, nothing re-parented or re-hooked since the last walk (entities made or deleted since are
+ * taken in / out in place where that is possible, gpu_scene_entity_created / _deleting):
  *   touched batched entities -> flags + transform to the mirror; the device; the slots the kernel reports as rebuilt
  *   -> back into their entity3d (ascending slot = parents first); host-class entities' own hooks and the camera
  *   bounding-volume pick of the few entities whose box contains a query point, merged in list order.
@@ -1240,6 +1503,13 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
     const double t0 = now_ms();
+    if (gs->n_created) {                                         /* entities made since the last frame: into the standing layout, or a walk */
+        const int rc = take_created(gs, mq);
+        if (rc) return rc;
+    }
+    st->placed = gs->inc_placed; st->removed = gs->inc_removed;
+    st->registered += gs->inc_placed; st->deleted += gs->inc_removed;
+    gs->inc_placed = gs->inc_removed = 0;
     clapgpu_scene_set_export(gs->scene, gs->scatter_drawn ? CLAPGPU_SCENE_EXPORT_DRAWN : CLAPGPU_SCENE_EXPORT_ALL);
     gs->drawn_now = clapgpu_scene_export_is_drawn(gs->scene);
     if (gs->drawn_now && scene && scene->control != gs->last_control) {
@@ -1411,6 +1681,40 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
      * (one bit per queue position: 125 KB per million entities), which the merge below scans upwards */
     uint32_t n_cand = 0;
     const uint32_t pos_words = (gs->n_order + 63) / 64;
+    if (gs->appended) {
+        /* order[] is not the list any more (entities taken in since the walk stand at its end): the candidates -- few --
+         * are sorted by their place in the queue instead, and merged with the host-class entities by that */
+        if (scene && res.inside_mask)
+            for (uint32_t w = 0; w < words; w++) {
+                uint64_t m = res.inside_mask[w];
+                while (m) {
+                    const size_t slot = (size_t)w * 64 + (size_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uintptr_t u = (uintptr_t)res.slot_user[slot];
+                    if (!u) continue;
+                    if (n_cand == gs->cap_cands) {
+                        const uint32_t cap = gs->cap_cands ? 2 * gs->cap_cands : 256;
+                        struct gs_cand *q = realloc(gs->cands, (size_t)cap * sizeof(*q));
+                        if (!q) return _CERR_NOMEM;
+                        gs->cands = q; gs->cap_cands = cap;
+                    }
+                    gs->cands[n_cand++] = (struct gs_cand){ gs->rec[u - 1].order_key, (uint32_t)(u - 1) };
+                }
+            }
+        if (n_cand > 1) qsort(gs->cands, n_cand, sizeof(*gs->cands), cand_cmp);
+        uint32_t hc = 0, ci = 0;
+        for (;;) {
+            const uint64_t ck = ci < n_cand ? gs->cands[ci].key : UINT64_MAX;
+            const uint64_t hk = hc < gs->n_host ? gs->rec[gs->host_list[hc]].order_key : UINT64_MAX;
+            if (ck == UINT64_MAX && hk == UINT64_MAX) break;
+            if (hk < ck)
+                host_hook(gs, mq, &gs->rec[gs->host_list[hc++]]);
+            else {
+                const struct gs_rec *cr = &gs->rec[gs->cands[ci++].rec];
+                if (cr->cls == 1 && cr->e) bv_pick(scene, cr->e);
+            }
+        }
+    } else {
     if (scene && res.inside_mask) {
         if (pos_words > gs->cap_posmap) {
             uint64_t *pm = realloc(gs->posmap, (size_t)pos_words * 8);
@@ -1440,22 +1744,13 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         const uint32_t ho = hc < gs->n_host ? gs->rec[gs->host_list[hc]].order_pos : 0xffffffffu;
         if (co == 0xffffffffu && ho == 0xffffffffu) break;
         if (ho < co) {
-            struct gs_rec *hr = &gs->rec[gs->host_list[hc++]];
-            if (hr->lag) {
-                /* listed before its batched parent: the reference has not updated that parent yet when this hook runs */
-                struct lag_keep *kp = &gs->lag_keep[hr->lag - 1], now;
-                entity3d *p = gs->rec[gs->lag_parent[hr->lag - 1]].e;
-                memcpy(now.mx, p->mx, sizeof(mat4x4)); now.seq = p->seq;
-                memcpy(p->mx, kp->mx, sizeof(mat4x4)); p->seq = kp->seq;
-                entity3d_update(hr->e, mq->priv);
-                memcpy(p->mx, now.mx, sizeof(mat4x4)); p->seq = now.seq;
-            } else
-                entity3d_update(hr->e, mq->priv);
+            host_hook(gs, mq, &gs->rec[gs->host_list[hc++]]);
         } else {
             cm &= cm - 1;
             if (gs->rec[gs->order[co]].cls == 1)                 /* class 4 boxes are last frame's until the second launch */
                 bv_pick(scene, gs->rec[gs->order[co]].e);
         }
+    }
     }
     st->batched = gs->n_batched; st->host = gs->n_host + gs->n_deferred;
     if (getenv("GPU_SCENE_TIMING")) fprintf(stderr, "fast_frame: mirror %.3f device %.3f scatter %.3f (rebuilt %llu) hooks+bv %.3f (cand %u host %u)\n", t1 - t0, t2 - t1, t3 - t2, (unsigned long long)n_rebuilt, now_ms() - t3, n_cand, gs->n_host);
@@ -1508,6 +1803,12 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     for (uint32_t k = 0; k < gs->n_touched; k++) gs->rec[gs->touched[k]].pending = 0;
     gs->n_touched = 0;
     gs->n_xptr = 0;                                              /* the walk reads every transform itself */
+    gs->n_created = 0;                                           /* ... and meets every entity made since the last one */
+    gs->appended = false;
+    gs->n_wtxm = 0;
+    st->placed = gs->inc_placed; st->removed = gs->inc_removed;  /* (taken in / out in place before something else asked for the walk) */
+    st->registered += gs->inc_placed; st->deleted += gs->inc_removed;
+    gs->inc_placed = gs->inc_removed = 0;
     gs->topology_pending = false;
     gs->last_fast = false;
     gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0; gs->n_char = 0;
@@ -1527,6 +1828,14 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     model3dtx *txm;
     entity3d *e, *it;
     list_for_each_entry(txm, &mq->txmodels, entry) {
+        if (gs->n_wtxm == gs->cap_wtxm) {
+            const uint32_t cap = gs->cap_wtxm ? 2 * gs->cap_wtxm : 32;
+            struct gs_wtxm *q = realloc(gs->wtxm, (size_t)cap * sizeof(*q));
+            if (!q) return _CERR_NOMEM;
+            gs->wtxm = q; gs->cap_wtxm = cap;
+        }
+        const uint32_t rank = gs->n_wtxm++;
+        gs->wtxm[rank] = (struct gs_wtxm){ txm, 0 };
         list_for_each_entry_iter(e, it, &txm->entities, entry) {
             if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
             uint32_t i;
@@ -1560,6 +1869,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             }
             r->gen = gs->gen;
             r->order_pos = gs->n_order;
+            r->order_key = ((uint64_t)rank << 32) | gs->wtxm[rank].next++;
             gs->order[gs->n_order++] = i;
             r->self_ok = self_batchable(gs, e);
             const bool rides_joint = e->parent && e->parent_joint != JOINT_TYPE_MAX;
@@ -1619,6 +1929,13 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         gs->walk_fetch_on = false;
     }
     const double t1 = now_ms();
+    for (uint32_t k = 0; k < gs->n_dead_recs; k++) {             /* taken out in place since the last walk: order[] no longer names them */
+        struct gs_rec *r = &gs->rec[gs->dead_recs[k]];
+        if (r->e) continue;                                      /* (cannot be: nothing hands a tombstone out before this) */
+        r->next = gs->free_rec;
+        gs->free_rec = gs->dead_recs[k];
+    }
+    gs->n_dead_recs = 0;
     /* entities that left the queue (entity3d_delete, model.c:1787): met last frame, not this one */
     if (gs->n_live != gs->n_order) {
         for (uint32_t k = 0; k < gs->n_prev; k++) {
@@ -1744,7 +2061,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     slot_arrays_build(gs);                                       /* on failure the draw list goes through the records */
     /* GPU_SCATTER_DRAWN: the standing host readers (gpu-scene.h).  A host-class entity's hook reads its parent's mx / seq
      * (parent_transform_apply, model.c:1609-1641) -- also when that parent comes later in the list (lag_parent) */
-    if (gs->scatter_drawn && gs->notify) {
+    if (gs->notify) {                                            /* (also: such a parent cannot be taken out of the layout in place) */
         for (uint32_t k = 0; k < gs->n_order; k++) gs->rec[gs->order[k]].host_child = 0;
         for (uint32_t k = 0; k < gs->n_order; k++) {
             const struct gs_rec *r = &gs->rec[gs->order[k]];
@@ -1752,6 +2069,8 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             const uint32_t pr = rec_find(gs, r->e->parent);
             if (pr != NO_REC) gs->rec[pr].host_child = 1;
         }
+    }
+    if (gs->scatter_drawn && gs->notify) {
         gs->last_control = scene ? scene->control : NULL;
         for (uint32_t k = 0; k < gs->n_order; k++) {
             struct gs_rec *r = &gs->rec[gs->order[k]];
@@ -1908,7 +2227,7 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     gs->groups_valid = false;
     /* entities came or went since the frame's update (notification mode knows): the list would miss what the reference's
      * walk of the txmodels draws -- this pass is the reference's */
-    if (gs->notify && gs->topology_pending) return _CERR_NOT_SUPPORTED;
+    if (gs->notify && (gs->topology_pending || gs->n_created)) return _CERR_NOT_SUPPORTED;
     /* the frustum the device's mask answers for: the one of the last update, or a cull launch for this view's planes */
     if (view) {
         if (view != gs->culled_view || !gs->cull_checked || !gs->cull_ok) {

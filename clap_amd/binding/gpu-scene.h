@@ -33,6 +33,8 @@ struct gpu_scene_stats {
     unsigned int untouched_writes;  /* verification mode: batched entities found with xform.updated set that nobody had
                                        reported (a direct transform_* write without gpu_scene_touch) -- taken in this frame */
     unsigned int registered, deleted;
+    unsigned int placed, removed;   /* of those: entities created / deleted since the last frame that were put into / taken out of the
+                                   standing device layout, without a walk of the queue (gpu_scene_entity_created / _deleting) */
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
     double       ms_walk, ms_mirror, ms_device, ms_scatter;   /* steps 1, 2+3, 4, 5 of gpu_mq_update() */
     unsigned int fetched;       /* GPU_SCATTER_DRAWN: entities brought over after the fact this frame (came into view, asked for) */
@@ -156,6 +158,23 @@ void gpu_scene_touch_xform(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_host_update_begin(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_host_updated(struct gpu_scene *gs, entity3d *e);
 void gpu_scene_topology(struct gpu_scene *gs);
+/*
+ * Creation and deletion without a walk.  A queue whose make-up changes by a few entities a frame (pickups, projectiles,
+ * effects) would otherwise walk every entity3d and lay the device's tiles out anew each time -- at a million entities
+ * more than the reference's whole update.  entity3d_make reports the new entity with gpu_scene_entity_created() (the last
+ * line of model.c:1730-1762; whatever the game sets afterwards -- position, e->parent, a light -- is read when the next
+ * gpu_mq_update() takes the entity in), entity3d_delete / entity3d_drop report gpu_scene_entity_deleting() BEFORE the
+ * entity goes (model.c:1765-1791; gpu-exports.inc.c does it for entity3d_delete).  A plain entity -- default_update, no
+ * skeleton, body or joint, without a parent or below a batched one that comes earlier in the list -- is then placed into
+ * the standing layout (a free lane of its parent's tile, or a growth tile), a batched leaf nobody depends on is taken out
+ * of it, and the frame stays O(touched).  Anything else -- a custom hook, a txmodel the queue has not seen, a parent with
+ * no room below it, an entity with children -- falls back to gpu_scene_topology() by itself.  Both are no-ops for entities
+ * of other queues.  Without notification mode they equal gpu_scene_topology().
+ */
+void gpu_scene_entity_created(struct gpu_scene *gs, entity3d *e);
+void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e);
+/* on by default; off (also: environment GPU_SCENE_INCREMENTAL=0 at gpu_scene_init): both calls above equal gpu_scene_topology() */
+void gpu_scene_set_incremental(struct gpu_scene *gs, bool on);
 /*
  * Verification aid for notification mode (also: environment GPU_SCENE_VERIFY=1 at gpu_scene_init): before every fast
  * frame, look at each batched entity once for a transform somebody wrote WITHOUT telling the binding -- the engine moves

@@ -27,6 +27,7 @@ struct ent {
     void    *user;
     uint8_t  live, dirty, attached;   /* attached: rides a joint of its parent (e->parent_joint, model.c:1626-1641) */
     uint8_t  keep;                    /* clapgpu_scene_entity_keep: a standing host reader, exported whenever rebuilt */
+    uint32_t n_children;              /* live entities whose parent this is (an entity with children cannot be deleted in place) */
     int32_t  force_lod, cur_lod;      /* entity3d.force_lod / .cur_lod (model.h:415-416; entity3d_set_lod, model.c:593-609) */
 };
 
@@ -92,6 +93,17 @@ struct clapgpu_scene {
     uint64_t   *h_exported;                                            /* mapped, behind the three masks of h_out */
     uint64_t   *h_stale, *h_fetched; uint32_t n_stale_words, n_fetched, fetch_serial; /* plain host memory, cap_slots / 64 + 2 words */
     uint64_t   *h_select; void *d_select;                              /* mapped: the rows a fetch asks for */
+    /* the layout edited in place (clapgpu_scene_entity_new_placed / _delete_placed): a queue whose make-up changes by a few
+     * entities a frame keeps its tiles; a re-tile is the fall-back */
+    uint32_t    max_depth;                                             /* rows of the deepest tree at the last re-tile */
+    uint32_t    grow_tile;                                             /* the tile new roots go into (NO_ENTITY: none yet) */
+    uint32_t    cap_tiles;                                             /* entries tile_row_start_host can hold, minus one */
+    int         incremental;                                           /* clapgpu_scene_set_incremental: re-tiles leave room for edits */
+    uint32_t   *free_roots; uint32_t n_free_roots, cap_free_roots;     /* first-row slots freed by deletions */
+    uint32_t   *raw_words; uint32_t n_raw, cap_raw, raw_lo, raw_hi;    /* words of h_touched set outside the dirty list (tombstones); their slot range */
+    uint32_t   *edits; uint32_t n_edits, cap_edits, edit_lo, edit_hi;  /* slots whose parent / model the device has not been given yet */
+    uint32_t    grown_from, tiles_from;                                /* first slot / tile appended since the device last saw the layout (NO_ENTITY: none) */
+    uint32_t   *limbo; uint32_t n_limbo, cap_limbo;                    /* handles deleted in place: reusable once the frame's dirty list is spent */
 
     /* device */
     clapgpu_entities d;
@@ -184,6 +196,8 @@ static void stale_after_launch(clapgpu_scene *s)
     s->n_stale_words = nz;
 }
 
+static int apply_edits(clapgpu_scene *s);
+
 /* rows = stale & want (NULL: every stale row): over from the device arrays into h_out, named in h_fetched */
 static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, const uint64_t *w2)
 {
@@ -200,6 +214,7 @@ static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, 
         cnt += (uint32_t)__builtin_popcountll(sel);
     }
     if (!cnt) return CLAPGPU_OK;
+    CK(apply_edits(s));
     char *mo = s->d_out_host;
     const size_t cn = s->cap_slots;
     clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cn * 64), .aabb = (float *)(mo + cn * 128),
@@ -226,6 +241,7 @@ int clapgpu_scene_create(clapgpu_scene **out, int device)
     clapgpu_scene *s = calloc(1, sizeof(*s));
     if (!s) return CLAPGPU_ERR_NOMEM;
     s->topology_dirty = 1;
+    s->grow_tile = s->grown_from = s->tiles_from = CLAPGPU_NO_ENTITY;
     s->zero_copy_max_slots = CLAPGPU_SCENE_ZERO_COPY_SLOTS;
     const char *zc = getenv("CLAPGPU_SCENE_ZERO_COPY_SLOTS");   /* tuning knob: 0 = always copy */
     if (zc) s->zero_copy_max_slots = (uint32_t)strtoul(zc, NULL, 0);
@@ -288,7 +304,7 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->d_att_local) clapgpu_free(s->d_att_local);
     if (s->d_keep) clapgpu_free(s->d_keep);
     if (s->h_select) clapgpu_host_free(s->h_select);
-    free(s->h_keep); free(s->h_stale); free(s->h_fetched);
+    free(s->h_keep); free(s->h_stale); free(s->h_fetched); free(s->free_roots); free(s->raw_words); free(s->edits); free(s->limbo);
     free(s);
 }
 
@@ -320,9 +336,8 @@ int clapgpu_scene_model_lods(clapgpu_scene *s, uint32_t model, unsigned int lod_
     return CLAPGPU_OK;
 }
 
-int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle)
+static int new_handle(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle)
 {
-    if (!s || !handle || model >= s->n_models) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     uint32_t h;
     if (s->n_free) {
         h = s->free_list[--s->n_free];
@@ -345,8 +360,15 @@ int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint3
     e->user = user;
     e->live = 1;
     e->force_lod = -1;                                  /* entity3d_make, model.c:1741; cur_lod 0 */
-    s->topology_dirty = 1;
     *handle = h;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle)
+{
+    if (!s || !handle || model >= s->n_models) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    CK(new_handle(s, model, user, handle));
+    s->topology_dirty = 1;
     return CLAPGPU_OK;
 }
 
@@ -364,6 +386,8 @@ int clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle)
         s->dead_list = q; s->cap_dead = cap;
     }
     e->live = 0;
+    if (e->parent != CLAPGPU_NO_ENTITY && e->parent < s->n_handles && s->e[e->parent].live && s->e[e->parent].n_children)
+        s->e[e->parent].n_children--;
     s->dead_list[s->n_dead++] = handle;
     s->topology_dirty = 1;
     return CLAPGPU_OK;
@@ -397,9 +421,241 @@ int clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t 
     if (!e || (parent != CLAPGPU_NO_ENTITY && (!get(s, parent) || parent == handle)))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (e->parent != parent) {
+        if (e->parent != CLAPGPU_NO_ENTITY && e->parent < s->n_handles && s->e[e->parent].live && s->e[e->parent].n_children)
+            s->e[e->parent].n_children--;
+        if (parent != CLAPGPU_NO_ENTITY) s->e[parent].n_children++;
         e->parent = parent;
         s->topology_dirty = 1;
     }
+    return CLAPGPU_OK;
+}
+
+/* ---- the standing layout edited in place ---------------------------------------------------------------------------------
+ * A queue that gains and loses a few entities a frame (pickups, projectiles, effects) would pay for a re-tile -- every
+ * entity's depth, a new packing, the whole upload image, every slot moved under the caller -- each time.  These two verbs
+ * edit the tile layout where it stands instead: a new root takes a free first-row lane (one a deleted root left, or one of
+ * a growth tile appended behind the others), a new child a free lane of the row below its parent in the parent's own tile
+ * (the kernel hands a parent's matrix to the next row through registers: that is the only place a child can be), a deleted
+ * leaf becomes a lane that is not ALIVE.  No other entity moves: slots, masks and the caller's per-slot state stand.
+ * Either verb returns CLAPGPU_ERR_NOT_SUPPORTED, having changed nothing, when the edit does not fit (no free lane, no row
+ * below, out of capacity, a layout that is not the one-launch tile form): the caller then uses the plain verbs and the next
+ * mq_update re-tiles.  The device is told with the next mq_update (the new lanes' inputs through the touched bits like any
+ * moved entity's, parent / model indices by a small copy): until then results for such an entity are not defined. */
+void clapgpu_scene_set_incremental(clapgpu_scene *s, int on)
+{
+    if (s) s->incremental = on != 0;                     /* from the next re-tile on */
+}
+
+static int push_list(uint32_t **arr, uint32_t *n, uint32_t *cap, uint32_t v)
+{
+    if (*n == *cap) {
+        const uint32_t c = *cap ? 2 * *cap : 64;
+        uint32_t *q = realloc(*arr, (size_t)c * sizeof(uint32_t));
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        *arr = q; *cap = c;
+    }
+    (*arr)[(*n)++] = v;
+    return CLAPGPU_OK;
+}
+
+static int layout_editable(const clapgpu_scene *s)
+{
+    return !s->topology_dirty && s->tiled && s->zero_copy && s->have_results && s->h_in && s->n_tiles && s->n_models;
+}
+
+static uint32_t tile_of_row(const clapgpu_scene *s, uint32_t row)
+{
+    uint32_t lo = 0, hi = s->n_tiles;                    /* tile_row_start_host[lo] <= row < tile_row_start_host[hi] */
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s->tile_row_start_host[mid] <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+static int free_lane(const clapgpu_scene *s, uint32_t row)
+{
+    const uint32_t *sh = s->slot_handle + (size_t)row * WAVE;
+    for (int l = 0; l < (int)WAVE; l++)
+        if (sh[l] == CLAPGPU_NO_ENTITY) return l;
+    return -1;
+}
+
+static void touch_raw(clapgpu_scene *s, uint32_t slot)
+{
+    s->h_touched[slot >> 6] |= 1ull << (slot & 63);
+    if (!s->n_raw || slot < s->raw_lo) s->raw_lo = slot;
+    if (!s->n_raw || slot + 1 > s->raw_hi) s->raw_hi = slot + 1;
+    if (push_list(&s->raw_words, &s->n_raw, &s->cap_raw, slot >> 6))
+        s->bulk_dirty = 1;                               /* cannot remember the word: the next frame clears them all */
+}
+
+/* a tile of max_depth (+ spare) empty rows behind the others; the device hears of it in apply_edits() */
+static int append_tile(clapgpu_scene *s)
+{
+    const uint32_t rows = s->max_depth + ((s->incremental && s->max_depth > 1) ? 1 : 0);
+    if (!rows || (uint64_t)(s->n_rows + rows) * WAVE > s->cap_slots) return CLAPGPU_ERR_NOT_SUPPORTED;
+    if (s->n_tiles + 1 > s->cap_tiles) {
+        const uint32_t cap = 2 * s->cap_tiles + 16;
+        uint32_t *q = realloc(s->tile_row_start_host, ((size_t)cap + 1) * 4);
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->tile_row_start_host = q; s->cap_tiles = cap;
+    }
+    const uint32_t first = s->n_slots, end = first + rows * WAVE;
+    static const float id[4] = { 0, 0, 0, 1 };
+    for (uint32_t i = first; i < end; i++) {
+        s->slot_handle[i] = CLAPGPU_NO_ENTITY; s->slot_user[i] = NULL;
+        memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
+        memcpy(s->h_rot + 4 * (size_t)i, id, 16);
+        s->h_parent[i] = -1; s->h_model[i] = 0; s->h_flags[i] = 0;
+    }
+    if (s->lod_cap >= end && s->lod_layout_gen == s->layout_gen) {
+        for (uint32_t i = first; i < end; i++) { s->h_force_lod[i] = -1; s->h_cur_lod[i] = 0; }
+        if (first < s->lod_lo) s->lod_lo = first;
+        if (end > s->lod_hi) s->lod_hi = end;
+    }
+    if (s->grown_from == CLAPGPU_NO_ENTITY) { s->grown_from = first; s->tiles_from = s->n_tiles; }
+    s->grow_tile = s->n_tiles;
+    s->tile_row_start_host[s->n_tiles] = s->n_rows;      /* (it was the end of the last tile already) */
+    s->n_tiles++;
+    s->n_rows += rows;
+    s->tile_row_start_host[s->n_tiles] = s->n_rows;
+    s->n_slots = s->n_rows * WAVE;
+    return CLAPGPU_OK;
+}
+
+/* parent / model indices of the edited slots, and appended tiles, to the device: before anything is launched on the layout */
+static int apply_edits(clapgpu_scene *s)
+{
+    if (s->grown_from == CLAPGPU_NO_ENTITY && !s->n_edits) return CLAPGPU_OK;
+    if (s->grown_from != CLAPGPU_NO_ENTITY) {
+        const size_t a = s->grown_from, cnt = s->n_slots - a;
+        CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + a, s->h_parent + a, cnt * 4, NULL));
+        CK(clapgpu_memcpy_h2d((int32_t *)s->d.model + a, s->h_model + a, cnt * 4, NULL));
+        CK(clapgpu_memset(s->d.flags + a, 0, cnt * 4, NULL));           /* nothing ALIVE there until the image says so */
+        CK(clapgpu_memset(s->d.seqs + a, 0, cnt * 4, NULL));
+        CK(clapgpu_memcpy_h2d(s->d_tile_row_start + s->tiles_from, s->tile_row_start_host + s->tiles_from,
+                              ((size_t)s->n_tiles + 1 - s->tiles_from) * 4, NULL));
+        s->d.n = s->n_slots;
+        s->grown_from = s->tiles_from = CLAPGPU_NO_ENTITY;
+    }
+    for (uint32_t k = 0; k < s->n_edits; k++) {
+        /* a model without a box (skip_aabb) never writes one: the lane's last tenant's must not stay (a fresh entity3d's
+         * is all zeros, and so is every row after a re-tile) */
+        if (!(s->edits[k] & 0x80000000u)) continue;
+        const size_t i = s->edits[k] &= 0x7fffffffu;
+        CK(clapgpu_memset(s->d.aabb + 6 * i, 0, 24, NULL));
+        CK(clapgpu_memset(s->d.center + 3 * i, 0, 12, NULL));
+    }
+    if (s->n_edits) {
+        /* few edits far apart: one word each; many, or close together: the range that spans them (a copy call is ~10 us,
+         * the range moves at ~10 GB/s) */
+        const size_t span = (size_t)s->edit_hi - s->edit_lo;
+        if ((double)s->n_edits * 10.0 < 10.0 + (double)span * 4.0 / 1e4) {
+            for (uint32_t k = 0; k < s->n_edits; k++) {
+                const size_t i = s->edits[k];
+                CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + i, s->h_parent + i, 4, NULL));
+                CK(clapgpu_memcpy_h2d((int32_t *)s->d.model + i, s->h_model + i, 4, NULL));
+            }
+        } else {
+            CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + s->edit_lo, s->h_parent + s->edit_lo, span * 4, NULL));
+            CK(clapgpu_memcpy_h2d((int32_t *)s->d.model + s->edit_lo, s->h_model + s->edit_lo, span * 4, NULL));
+        }
+        s->n_edits = 0;
+    }
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_new_placed(clapgpu_scene *s, uint32_t model, void *user, uint32_t parent, uint32_t *handle, uint32_t *slot_out)
+{
+    if (!s || !handle || model >= s->n_models || (parent != CLAPGPU_NO_ENTITY && !get(s, parent))) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!layout_editable(s)) return CLAPGPU_ERR_NOT_SUPPORTED;
+    uint32_t slot = CLAPGPU_NO_ENTITY;
+    if (parent == CLAPGPU_NO_ENTITY) {
+        while (s->n_free_roots && slot == CLAPGPU_NO_ENTITY) {
+            const uint32_t c = s->free_roots[--s->n_free_roots];
+            if (c < s->n_slots && s->slot_handle[c] == CLAPGPU_NO_ENTITY) slot = c;
+        }
+        if (slot == CLAPGPU_NO_ENTITY && s->grow_tile != CLAPGPU_NO_ENTITY) {
+            const uint32_t row = s->tile_row_start_host[s->grow_tile];
+            const int l = free_lane(s, row);
+            if (l >= 0) slot = row * WAVE + (uint32_t)l;
+        }
+        if (slot == CLAPGPU_NO_ENTITY) {
+            CK(append_tile(s));
+            slot = s->tile_row_start_host[s->grow_tile] * WAVE;
+        }
+    } else {
+        const struct ent *pe = &s->e[parent];
+        if (pe->slot >= s->n_slots || pe->attached) return CLAPGPU_ERR_NOT_SUPPORTED;
+        const uint32_t row = pe->slot / WAVE + 1, t = tile_of_row(s, row - 1);
+        if (row >= s->tile_row_start_host[t + 1]) return CLAPGPU_ERR_NOT_SUPPORTED;     /* the parent sits in its tile's last row */
+        const int l = free_lane(s, row);
+        if (l < 0) return CLAPGPU_ERR_NOT_SUPPORTED;
+        slot = row * WAVE + (uint32_t)l;
+    }
+    if (s->n_edits == s->cap_edits) {                    /* before anything is changed: the list must be able to take the slot */
+        const uint32_t c = s->cap_edits ? 2 * s->cap_edits : 64;
+        uint32_t *q = realloc(s->edits, (size_t)c * 4);
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->edits = q; s->cap_edits = c;
+    }
+    const int32_t parent_slot = parent == CLAPGPU_NO_ENTITY ? -1 : (int32_t)s->e[parent].slot;
+    CK(new_handle(s, model, user, handle));              /* (may move s->e) */
+    struct ent *e = &s->e[*handle];
+    e->slot = slot;
+    e->parent = parent;
+    if (parent != CLAPGPU_NO_ENTITY) s->e[parent].n_children++;
+    s->slot_handle[slot] = *handle;
+    s->slot_user[slot] = user;
+    s->h_parent[slot] = parent_slot;
+    s->h_model[slot] = (int32_t)model;
+    if (!s->n_edits || slot < s->edit_lo) s->edit_lo = slot;
+    if (!s->n_edits || slot + 1 > s->edit_hi) s->edit_hi = slot + 1;
+    uint32_t skip_bits;
+    memcpy(&skip_bits, &s->models[8 * (size_t)model + 3], 4);
+    s->edits[s->n_edits++] = slot | (skip_bits ? 0x80000000u : 0);
+    const uint64_t bit = 1ull << (slot & 63);
+    if (s->h_stale[slot >> 6] & bit) { s->h_stale[slot >> 6] &= ~bit; if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--; }
+    if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
+    s->h_fetched[slot >> 6] &= ~bit;
+    if (s->lod_cap > slot && s->lod_layout_gen == s->layout_gen) {
+        s->h_force_lod[slot] = -1; s->h_cur_lod[slot] = 0;
+        if (slot < s->lod_lo) s->lod_lo = slot;
+        if (slot + 1 > s->lod_hi) s->lod_hi = slot + 1;
+    }
+    mark_dirty(s, *handle, 1);                           /* its inputs into the image; the launch takes them by the touched bit */
+    if (slot_out) *slot_out = slot;
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_entity_delete_placed(clapgpu_scene *s, uint32_t handle)
+{
+    struct ent *e = get(s, handle);
+    if (!e) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!layout_editable(s) || e->n_children || e->attached || e->slot >= s->n_slots) return CLAPGPU_ERR_NOT_SUPPORTED;
+    if (s->n_limbo == s->cap_limbo) {
+        const uint32_t c = s->cap_limbo ? 2 * s->cap_limbo : 64;
+        uint32_t *q = realloc(s->limbo, (size_t)c * 4);
+        if (!q) return CLAPGPU_ERR_NOMEM;
+        s->limbo = q; s->cap_limbo = c;
+    }
+    const uint32_t slot = e->slot;
+    s->h_flags[slot] = 0;                                /* not ALIVE: never rebuilt, drawn or picked again */
+    touch_raw(s, slot);
+    s->slot_handle[slot] = CLAPGPU_NO_ENTITY;
+    s->slot_user[slot] = NULL;
+    const uint64_t bit = 1ull << (slot & 63);
+    if (s->h_stale[slot >> 6] & bit) { s->h_stale[slot >> 6] &= ~bit; if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--; }
+    if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
+    s->h_fetched[slot >> 6] &= ~bit;
+    if (e->parent != CLAPGPU_NO_ENTITY && e->parent < s->n_handles && s->e[e->parent].live && s->e[e->parent].n_children)
+        s->e[e->parent].n_children--;
+    const uint32_t row = slot / WAVE;
+    if (s->tile_row_start_host[tile_of_row(s, row)] == row)
+        push_list(&s->free_roots, &s->n_free_roots, &s->cap_free_roots, slot);   /* (a failure only loses the lane until the next re-tile) */
+    e->live = 0;
+    s->limbo[s->n_limbo++] = handle;
     return CLAPGPU_OK;
 }
 
@@ -665,6 +921,8 @@ static uint32_t compute_depths(clapgpu_scene *s, uint32_t *depth, uint32_t *root
 static int retile(clapgpu_scene *s)
 {
     CK(release_dead(s));
+    if (s->h_in)                                         /* tombstones of in-place deletions: the whole image follows anyway */
+        for (uint32_t k = 0; k < s->n_raw; k++) s->h_touched[s->raw_words[k]] = 0;
     const uint32_t H = s->n_handles;
     uint32_t *depth = malloc(((size_t)H + 1) * 4), *root = malloc(((size_t)H + 1) * 4);
     uint32_t *tree_of = malloc(((size_t)H + 1) * 4);
@@ -690,6 +948,13 @@ static int retile(clapgpu_scene *s)
     free(s->tile_row_start_host);
     free(s->level_start_host);
     s->tile_row_start_host = malloc(((size_t)n_trees + 2) * 4);      /* at most one tile per tree */
+    s->cap_tiles = n_trees + 1;
+    s->max_depth = maxd; s->grow_tile = CLAPGPU_NO_ENTITY; s->n_free_roots = 0;
+    s->n_raw = 0; s->n_edits = 0; s->grown_from = s->tiles_from = CLAPGPU_NO_ENTITY;
+    /* a mirror that is edited in place (clapgpu_scene_set_incremental) leaves every row an eighth of its lanes and every tile
+     * of a hierarchy one row: room for the children that come before the next re-tile */
+    const uint32_t row_limit = s->incremental ? WAVE - WAVE / 8 : WAVE;
+    const uint32_t spare_rows = (s->incremental && maxd > 1) ? 1 : 0;
     s->level_start_host = malloc(((size_t)maxd + 2) * 4);
     if (!row_of_tree || !s->tile_row_start_host || !s->level_start_host) return CLAPGPU_ERR_NOMEM;
     if (tiled) {
@@ -701,10 +966,10 @@ static int retile(clapgpu_scene *s)
             const uint32_t *w = width + (size_t)t * maxd;
             int fits = 1;
             uint32_t rows = 0;
-            for (uint32_t d = 0; d < maxd; d++) { if (fill[d] + w[d] > WAVE) fits = 0; if (w[d]) rows = d + 1; }
+            for (uint32_t d = 0; d < maxd; d++) { if (fill[d] && fill[d] + w[d] > row_limit) fits = 0; if (w[d]) rows = d + 1; }
             if (!fits) {                                            /* close the tile */
                 s->tile_row_start_host[s->n_tiles++] = tile_first_row;
-                tile_first_row += tile_rows;
+                tile_first_row += tile_rows + spare_rows;
                 tile_rows = 0;
                 memset(fill, 0, maxd * 4);
             }
@@ -712,7 +977,7 @@ static int retile(clapgpu_scene *s)
             if (rows > tile_rows) tile_rows = rows;
             row_of_tree[t] = tile_first_row;
         }
-        if (n_trees) { s->tile_row_start_host[s->n_tiles++] = tile_first_row; tile_first_row += tile_rows; }
+        if (n_trees) { s->tile_row_start_host[s->n_tiles++] = tile_first_row; tile_first_row += tile_rows + spare_rows; }
         s->tile_row_start_host[s->n_tiles] = tile_first_row;
         n_rows = tile_first_row;
         free(fill);
@@ -805,7 +1070,9 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     if (s->topology_dirty) {
         CK(retile(s));
         upload = full = 1;
-    } else if (s->n_dirty) {
+    } else
+        CK(apply_edits(s));
+    if (!full && s->n_dirty) {
         /* the upload image was written as the verbs came in (mark_dirty); here only the bookkeeping */
         const int bits = s->zero_copy && s->tiled;       /* one launch: the kernel reads the flagged slots from the image */
         if (s->zero_copy && !bits && s->n_dirty > s->cap_list) {  /* the mapped record list grows with the busiest frame seen */
@@ -836,6 +1103,24 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         s->n_dirty = 0;
         upload = n_touched != 0 && hi > lo;
         if (bits) n_bits = n_touched;
+    }
+    if (s->n_limbo) {                                    /* deleted in place: nothing lists these handles any more */
+        if (s->n_free + s->n_limbo > s->cap_free) {
+            uint32_t cap = s->cap_free ? s->cap_free : 256;
+            while (cap < s->n_free + s->n_limbo) cap *= 2;
+            uint32_t *q = realloc(s->free_list, (size_t)cap * sizeof(uint32_t));
+            if (!q) return CLAPGPU_ERR_NOMEM;
+            s->free_list = q; s->cap_free = cap;
+        }
+        memcpy(s->free_list + s->n_free, s->limbo, (size_t)s->n_limbo * sizeof(uint32_t));
+        s->n_free += s->n_limbo;
+        s->n_limbo = 0;
+    }
+    const uint32_t n_raw = full ? 0 : s->n_raw;          /* tombstones: flags words flagged outside the dirty list */
+    if (n_raw) {
+        if (!upload || s->raw_lo < lo) lo = s->raw_lo;
+        if (!upload || s->raw_hi > hi) hi = s->raw_hi;
+        upload = 1;
     }
     const int bulk_any = s->bulk_dirty;
     const int bulk = s->bulk_dirty && !full;
@@ -946,6 +1231,8 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     }
     if (!s->zero_copy) CK(clapgpu_stream_sync(NULL));
     for (uint32_t k = 0; k < n_bits; k++) s->h_touched[s->dirty_list[k] >> 6] = 0;   /* taken by this frame's launch or by its copy */
+    for (uint32_t k = 0; k < s->n_raw; k++) s->h_touched[s->raw_words[k]] = 0;
+    s->n_raw = 0;
     if (bulk_any && s->zero_copy) memset(s->h_touched, 0, (cap / 64 + 2) * 8);   /* what clapgpu_scene_entity_transform_mt flagged */
     if (!frustum)
         memset(s->h_mask, 0, mask_words * 8);
@@ -994,6 +1281,7 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
     if (!s || (n && (!handles || !jt || !bind))) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!n) return CLAPGPU_OK;
     if (s->topology_dirty || !s->have_results || !s->n_models) return CLAPGPU_ERR_NOT_SUPPORTED;   /* mq_update first */
+    CK(apply_edits(s));
     const size_t need = (size_t)n * (sizeof(clapgpu_attach) + 128);
     if (n > s->cap_att || s->att_mapped != s->zero_copy) {
         uint32_t cap = s->cap_att ? s->cap_att : 64;
@@ -1191,6 +1479,7 @@ int clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum)
 {
     if (!s || !frustum) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
+    CK(apply_edits(s));
     CK(clapgpu_entities_cull(NULL, &s->d, frustum));
     CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, ((size_t)s->n_slots / 64) * 8, NULL));
     CK(clapgpu_stream_sync(NULL));
@@ -1270,6 +1559,7 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
     *n_draw = 0;
     if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
     if (s->n_slots == 0) { s->n_draw = 0; return CLAPGPU_OK; }
+    CK(apply_edits(s));
     CK(ensure_lod(s));
     /* the ordered visible list from the mask the last update / cull left on the device, then -- with a camera -- the LOD
      * pick over it (one launch each); without one the pass keeps every cur_lod (model.c:974: `if (camera)`) */

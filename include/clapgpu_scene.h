@@ -48,6 +48,18 @@ int  clapgpu_scene_model_new(clapgpu_scene *s, const float aabb[6], int skip_aab
 int  clapgpu_scene_entity_new(clapgpu_scene *s, uint32_t model, void *user, uint32_t *handle);
 /* entity3d_delete (model.c:1787): the slot becomes a tombstone until the next re-tile */
 int  clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle);
+/* The two verbs above and set_parent change the queue's make-up: the next mq_update lays the entities out anew (every slot
+ * moves).  A queue that gains and loses a few entities a frame uses these instead: the STANDING tile layout is edited --
+ * a new root takes a free first-row lane (of a growth tile appended behind the others if need be), a new child a free lane
+ * of the row below its parent in the parent's tile, a deleted leaf's lane stops being ALIVE -- and nothing else moves:
+ * slots, masks and a caller's per-slot state stand, layout_generation does not advance, slot counts may grow (at the end).
+ * CLAPGPU_ERR_NOT_SUPPORTED = it does not fit (no free lane or row, capacity, an entity with children or riding a joint, not
+ * the one-launch tile form, nothing on the device yet) and NOTHING was changed: use the plain verbs then.
+ * clapgpu_scene_set_incremental(s, 1) makes re-tiles leave room for such edits (an eighth of every row's lanes, one spare row
+ * per tile of a hierarchy).  The edits reach the device with the next mq_update. */
+void clapgpu_scene_set_incremental(clapgpu_scene *s, int on);
+int  clapgpu_scene_entity_new_placed(clapgpu_scene *s, uint32_t model, void *user, uint32_t parent, uint32_t *handle, uint32_t *slot);
+int  clapgpu_scene_entity_delete_placed(clapgpu_scene *s, uint32_t handle);
 /* e->parent = p (jointless attachment, model.h:386-402); CLAPGPU_NO_ENTITY detaches */
 int  clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t parent);
 

@@ -53,6 +53,7 @@
 #define entity3d_update         ref_entity3d_update
 #define entity3d_reset          ref_entity3d_reset
 #define entity3d_set_lod        ref_entity3d_set_lod
+#define entity3d_delete         ref_entity3d_delete
 #define view_entity_in_frustum  ref_view_entity_in_frustum
 #define view_calc_frustum       ref_view_calc_frustum
 #define light_grid_compute      ref_light_grid_compute
@@ -70,6 +71,7 @@
 #undef entity3d_update
 #undef entity3d_reset
 #undef entity3d_set_lod
+#undef entity3d_delete
 #undef view_entity_in_frustum
 #undef view_calc_frustum
 #undef light_grid_compute
@@ -241,7 +243,7 @@ static void op_create(float spread, bool allow_hook)
             cres(int) li = light_get(&w->scene->light);
             if (!IS_CERR(li)) { e->light_idx = li.val; e->light = &w->scene->light; memcpy(e->light_off, loff, sizeof(loff)); }
         }
-        if (k) gpu_scene_topology(gpu_scene_bound());              /* what entity3d_make does under CONFIG_GPU_SCENE */
+        if (k) gpu_scene_entity_created(gpu_scene_bound(), e);     /* what entity3d_make does under CONFIG_GPU_SCENE (its last line) */
         w->e[id] = e;
     }
     if (parent != NONE) { m->parent = parent; meta[parent].n_children++; }
@@ -257,6 +259,7 @@ static uint32_t pick_alive(void)
 }
 
 static uint64_t n_host_updates;            /* entity3d_update / entity3d_reset calls between frames */
+static bool opt_comeandgo;
 static bool opt_steady, no_topology;       /* `steady`: three frames out of four only move / turn / scale / hide entities -- frames
                                               a notified binding runs without walking the queue, where GPU_SCATTER_DRAWN lives */
 static void game_frame(uint32_t n_ops)
@@ -265,7 +268,7 @@ static void game_frame(uint32_t n_ops)
         uint32_t what = rndn(1000);
         const uint32_t id = pick_alive();
         if (id == NONE) continue;
-        if (no_topology && what >= 920) what = what % 920;
+        if (no_topology && what >= (opt_comeandgo ? 975u : 920u)) what = what % 920;   /* `comeandgo`: entities are still made and deleted in those frames */
         if (what < 600) {
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
             ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
@@ -292,8 +295,7 @@ static void game_frame(uint32_t n_ops)
             if (meta[id].n_children || id == 0) continue;           /* leaves only: no dangling e->parent; id 0 is scene->control */
             if (meta[id].parent != NONE) meta[meta[id].parent].n_children--;
             meta[id].alive = 0;
-            entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);
-            gpu_scene_topology(gpu_scene_bound());
+            ref_entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);   /* (world B: the engine's name, which tells the binding) */
             A.e[id] = B.e[id] = NULL;
         } else if (what < 975) {
             op_create(500.f, true);
@@ -559,6 +561,7 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
     B.scene->control = B.e[0];
 
     uint64_t bad = 0, visible = 0, batched = 0, host = 0, written = 0, retiles = 0, fast_frames = 0, fetched = 0, left_stale = 0;
+    uint64_t placed = 0, removed = 0;
     gpu_scene_set_notify(gs, opt_notify);
     gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
@@ -579,6 +582,7 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
         if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
         batched += st->batched; host += st->host; written += st->written_back; retiles += st->retiled;
         fetched += st->fetched; left_stale += st->left_stale;
+        placed += st->placed; removed += st->removed;
         fast_frames += gpu_scene_last_was_fast(gs);
         if (getenv("DROPIN_TRACE")) {                                    /* one entity's counters after every frame, before any fetch */
             const uint32_t id = (uint32_t)atoi(getenv("DROPIN_TRACE"));
@@ -601,12 +605,12 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
            "\"batched_updates\": %llu, \"host_updates\": %llu, \"written_back\": %llu, \"retiles\": %llu, "
            "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"entity3d_update_calls\": %llu, "
            "\"scatter\": \"%s\", \"left_stale\": %llu, \"fetched_on_view\": %llu, \"stale_seen_by_checker\": %llu, \"partial_compare_frames\": %llu, "
-           "\"mismatches\": %llu}\n",
+           "\"placed_in_layout\": %llu, \"removed_in_place\": %llu, \"mismatches\": %llu}\n",
            frames, n_ids, alive, (unsigned long long)batched, (unsigned long long)host,
            (unsigned long long)written, (unsigned long long)retiles, (unsigned long long)visible,
            opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates,
            opt_drawn ? "drawn" : "all", (unsigned long long)left_stale, (unsigned long long)fetched, (unsigned long long)n_stale_seen,
-           (unsigned long long)n_partial_frames, (unsigned long long)bad);
+           (unsigned long long)n_partial_frames, (unsigned long long)placed, (unsigned long long)removed, (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -840,7 +844,7 @@ static int cmd_edge(void)
         edge_reset();
         for (int i = 0; i < 30; i++) mk(i % 3, NONE, false, true);
         bad += edge_frames(gs, "before the wipe", 2, 60);
-        for (uint32_t id = 0; id < 30; id++) { entity3d_delete(A.e[id]); entity3d_delete(B.e[id]); A.e[id] = B.e[id] = NULL; meta[id].alive = 0; }
+        for (uint32_t id = 0; id < 30; id++) { ref_entity3d_delete(A.e[id]); entity3d_delete(B.e[id]); A.e[id] = B.e[id] = NULL; meta[id].alive = 0; }
         bad += edge_frames(gs, "after deleting everything", 2, 0);
         for (int i = 0; i < 17; i++) mk(i % 3, NONE, false, true);
         bad += edge_frames(gs, "a new population", 2, 34);
@@ -960,7 +964,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     double t_ref = 0, t_gpu = 0, t_ref_upd = 0, t_gpu_upd = 0, t_step[4] = { 0, 0, 0, 0 };
     double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0;
     uint64_t vis_a = 0, vis_b = 0, drawn_a = 0, drawn_b = 0, drawn_l = 0, acc_a = 0, acc_b = 0, acc_l = 0, left_stale = 0, fetched = 0;
-    uint64_t bad = 0;
+    uint64_t bad = 0, n_fast = 0, n_retiled = 0, n_placed = 0, n_removed = 0;
     for (uint32_t f = 0; f < frames + 2; f++) {                          /* two untimed warm-up frames */
         /* the game's own writes: the same numbers to both worlds (world B through the engine's names, i.e. with the
          * notification) -- timed apart, since the notification is a cost the binding adds to the mutators */
@@ -985,8 +989,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
                 if (!meta[id].alive || meta[id].n_children || id == 0) continue;
                 if (meta[id].parent != NONE) meta[meta[id].parent].n_children--;
                 meta[id].alive = 0;
-                entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);
-                gpu_scene_topology(gpu_scene_bound());
+                ref_entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);
                 A.e[id] = B.e[id] = NULL;
                 break;
             }
@@ -1044,6 +1047,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
             t_ref_blk += b1 - b0; t_gpu_blk += b2 - b1; t_gpu_list += b3 - b2;
             drawn_a += na; drawn_b += nb; drawn_l += nl; acc_a += aa; acc_b += ab; acc_l += al;
             left_stale += st->left_stale; fetched += st->fetched;
+            n_fast += gpu_scene_last_was_fast(gs); n_retiled += st->retiled; n_placed += st->placed; n_removed += st->removed;
             t_step[0] += st->ms_walk; t_step[1] += st->ms_mirror; t_step[2] += st->ms_device; t_step[3] += st->ms_scatter;
         }
     }
@@ -1062,6 +1066,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"reference_frame_ms\": %.4f, \"binding_frame_block_ms\": %.4f, \"binding_frame_draw_list_ms\": %.4f, "
            "\"drawn_per_frame\": %.1f, \"draw_sets_equal\": %s, \"draw_reads_equal\": %s, "
            "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, \"churn_per_frame\": %u, "
+           "\"fast_frames\": %llu, \"retiles\": %llu, \"placed_in_layout\": %llu, \"removed_in_place\": %llu, "
            "\"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
            "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
@@ -1070,6 +1075,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            1e3 * (t_ref_mut + t_ref_upd + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_list) / F,
            drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
            opt_drawn ? "drawn" : "all", left_stale / F, fetched / F, opt_churn,
+           (unsigned long long)n_fast, (unsigned long long)n_retiled, (unsigned long long)n_placed, (unsigned long long)n_removed,
            opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;
@@ -1700,6 +1706,7 @@ static int run(int argc, char **argv)
         if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "drawn")) { opt_drawn = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "steady")) { opt_steady = true; argc--; }
+        else if (argc > 2 && !strcmp(argv[argc - 1], "comeandgo")) { opt_steady = opt_comeandgo = true; argc--; }
         else if (argc > 3 && !strcmp(argv[argc - 2], "churn")) { opt_churn = (uint32_t)atoi(argv[argc - 1]); argc -= 2; }
         else break;
     }

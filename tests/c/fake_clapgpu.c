@@ -320,3 +320,14 @@ int clapgpu_visible_compact_lod(void *stream, const clapgpu_entities *e, uint32_
     if (rc) return rc;
     return clapgpu_entities_lod(stream, e, visible, count, index_base, cam_pos, force_lod, cur_lod, draw_lod);
 }
+
+/* the host-side view helpers (tests/c/test_scene.c builds its frustum with them): the oracle's */
+void clapgpu_view_matrix(const float pos[3], const float quat[4], float view_mx[16]) { clapo_view_matrix(pos, quat, view_mx); }
+void clapgpu_perspective(float fov, float aspect, float near_plane, float far_plane, int ndc_z_zero_one, float proj_mx[16])
+{
+    clapo_perspective(fov, aspect, near_plane, far_plane, ndc_z_zero_one, proj_mx);
+}
+void clapgpu_frustum_calc(const float view_mx[16], const float proj_mx[16], int ndc_z_zero_one, clapgpu_frustum *out)
+{
+    clapo_frustum_calc(view_mx, proj_mx, ndc_z_zero_one, (clapo_frustum *)out);
+}

@@ -297,6 +297,76 @@ int main(int argc, char **argv)
             if (check_lod(s, inside)) return 1;
         }
     }
+    /* ---- the standing layout edited in place (clapgpu_scene_entity_new_placed / _delete_placed): leaves go, roots and
+     * children come, nothing else moves -- no re-tile in a frame whose edits all fitted; where one does not (or the layout is
+     * not the one-launch tile form) the plain verbs take over and the frame re-tiles as before. */
+    {
+        clapgpu_scene_set_incremental(s, 1);
+        uint32_t placed = 0, removed = 0, fell_back = 0, quiet_frames = 0;
+        for (int frame = 0; frame < 4; frame++) {
+            if (frame == 0) {                                /* one plain edit: the re-tile that leaves room */
+                if (add_entity(s, UINT32_MAX)) return 2;
+                if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
+            }
+            const uint32_t gen0 = clapgpu_scene_layout_generation(s);
+            uint32_t fb = 0;
+            for (int k = 0; k < 50; k++) {
+                uint32_t i = (uint32_t)(rnd() % n_ents);
+                int has_child = 0;
+                for (uint32_t c = 0; c < n_ents; c++) if (ents[c].live && ents[c].parent == i) has_child = 1;
+                if (!ents[i].live || has_child || i == 0) continue;
+                const int rc = clapgpu_scene_entity_delete_placed(s, ents[i].handle);
+                if (rc == CLAPGPU_ERR_NOT_SUPPORTED) { fb++; if (clapgpu_scene_entity_delete(s, ents[i].handle)) return 2; }
+                else if (rc) return fail("delete_placed", i);
+                else removed++;
+                ents[i].live = 0;
+            }
+            for (int k = 0; k < 90 && n_ents < MAXE; k++) {
+                uint32_t p = (k % 3 == 0) ? UINT32_MAX : (uint32_t)(rnd() % n_ents);
+                if (p != UINT32_MAX) {
+                    uint32_t d = 0, x = p;
+                    while (ents[x].parent != UINT32_MAX) { x = ents[x].parent; d++; }
+                    if (!ents[p].live || d > 5) continue;
+                }
+                struct host_ent *e = &ents[n_ents];
+                memset(e, 0, sizeof(*e));
+                e->model = (uint32_t)(rnd() & 1);
+                e->parent = p;
+                e->flags = CLAPO_E_ALIVE | CLAPO_E_VISIBLE;
+                e->live = 1;
+                e->force_lod = -1;
+                rand_trs(e, p != UINT32_MAX);
+                uint32_t slot = 0;
+                const int rc = clapgpu_scene_entity_new_placed(s, e->model, e, p == UINT32_MAX ? CLAPGPU_NO_ENTITY : ents[p].handle, &e->handle, &slot);
+                if (rc == CLAPGPU_ERR_NOT_SUPPORTED) {
+                    fb++;
+                    if (clapgpu_scene_entity_new(s, e->model, e, &e->handle)) return 2;
+                    if (p != UINT32_MAX && clapgpu_scene_entity_set_parent(s, e->handle, ents[p].handle)) return 2;
+                } else if (rc) return fail("new_placed", n_ents);
+                else placed++;
+                if (clapgpu_scene_entity_transform(s, e->handle, e->ps, e->rot, e->ps[3])) return 2;
+                if (k % 7 == 0) { e->flags &= ~CLAPO_E_VISIBLE; clapgpu_scene_entity_visible(s, e->handle, 0); }
+                n_ents++;
+            }
+            for (int k = 0; k < 200; k++) {
+                struct host_ent *e = &ents[rnd() % n_ents];
+                if (!e->live) continue;
+                rand_trs(e, e->parent != UINT32_MAX);
+                clapgpu_scene_entity_transform(s, e->handle, e->ps, e->rot, e->ps[3]);
+            }
+            if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
+            if (!fb && clapgpu_scene_layout_generation(s) != gen0) return fail("a frame whose edits all fitted re-tiled", (uint32_t)frame);
+            quiet_frames += !fb;
+            fell_back += fb;
+            if (check_frame(s, &fr, 0, 0, 0, 0, 0, 0)) return 1;
+            if (check_lod(s, cpos)) return 1;
+        }
+        const int editable = clapgpu_scene_is_zero_copy(s) && clapgpu_scene_layout_is_tiled(s);
+        if (editable && (placed < 100 || removed < 60 || !quiet_frames)) return fail("too few in-place edits in the scenario", placed);
+        if (!editable && (placed || removed)) return fail("in-place edits on a layout that does not take them", placed);
+        printf("  layout edited in place: %u entities placed, %u removed, %u edits fell back to a re-tile, %u of 4 frames without one\n",
+               placed, removed, fell_back, quiet_frames);
+    }
     /* ---- joint attachments: the frame's SECOND launch.  Some children ride "a joint of their parent": mq_update computes
      * everything else, attached_update (with the joints' matrices of the frame) the riders and everything below them. */
     {

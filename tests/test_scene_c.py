@@ -78,14 +78,19 @@ def test_c_caller_of_the_flat_abi_matches_oracle(cuda_device):
 @pytest.mark.parametrize("path", ["small_frames", "staged"])
 @pytest.mark.parametrize("mode", ["tiles", "wide"])
 def test_scene_mirror_frames_match_oracle(mode, path, cuda_device):
-    """Five frames of creations / moves / re-parenting / deletions, then three with joint riders through the frame's second
+    """Five frames of creations / moves / re-parenting / deletions, four of creations / deletions that edit the standing
+    layout in place (clapgpu_scene_entity_new_placed / _delete_placed), then three with joint riders through the frame's second
     launch (clapgpu_scene_attached_update), every entity bit for bit against the oracle -- on the small-frame path (touched
     records in through mapped memory, rebuilt rows out, polled completion word) and staged through device slabs."""
     build_c_test()
     env = dict(os.environ, CLAPGPU_SCENE_ZERO_COPY_SLOTS="0" if path == "staged" else "4294967295")
     r = subprocess.run([TEST_BIN] + (["wide"] if mode == "wide" else []), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "PASS" in r.stdout and r.stdout.count("frame ok") == 8
+    assert "PASS" in r.stdout and r.stdout.count("frame ok") == 12
+    # the four frames of in-place creations / deletions: where the layout takes them (one-launch tile form) most fit
+    assert "layout edited in place" in r.stdout
+    if mode != "wide" and path == "small_frames":
+        assert " 0 entities placed" not in r.stdout
     assert ("small-frame path" if path == "small_frames" else "staged path") in r.stdout
 
 
