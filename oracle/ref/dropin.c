@@ -260,6 +260,8 @@ static uint32_t pick_alive(void)
 
 static uint64_t n_host_updates;            /* entity3d_update / entity3d_reset calls between frames */
 static bool opt_comeandgo;
+static bool opt_plain;                     /* `plain`: what the game makes while it runs is plain (default hook) and listed behind its parent:
+                                              the entities a binding can take into the standing device layout without a walk */
 static bool opt_steady, no_topology;       /* `steady`: three frames out of four only move / turn / scale / hide entities -- frames
                                               a notified binding runs without walking the queue, where GPU_SCATTER_DRAWN lives */
 static void game_frame(uint32_t n_ops)
@@ -298,7 +300,7 @@ static void game_frame(uint32_t n_ops)
             ref_entity3d_delete(A.e[id]); entity3d_delete(B.e[id]);   /* (world B: the engine's name, which tells the binding) */
             A.e[id] = B.e[id] = NULL;
         } else if (what < 975) {
-            op_create(500.f, true);
+            op_create(500.f, !opt_plain);
         } else {
             const uint32_t p = rndn(2) ? rndn(n_ids) : NONE;         /* re-parent or detach */
             if (p != NONE && !may_parent(p, id)) continue;
@@ -1707,6 +1709,7 @@ static int run(int argc, char **argv)
         else if (argc > 2 && !strcmp(argv[argc - 1], "drawn")) { opt_drawn = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "steady")) { opt_steady = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "comeandgo")) { opt_steady = opt_comeandgo = true; argc--; }
+        else if (argc > 2 && !strcmp(argv[argc - 1], "plain")) { opt_plain = parents_first = true; argc--; }
         else if (argc > 3 && !strcmp(argv[argc - 2], "churn")) { opt_churn = (uint32_t)atoi(argv[argc - 1]); argc -= 2; }
         else break;
     }

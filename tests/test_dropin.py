@@ -47,7 +47,7 @@ def test_dropin_checker_is_built_where_the_reference_is():
     names = {l.split()[-1] for l in defined.splitlines() if " T " in l}
     for fn in ("mq_update", "view_entity_in_frustum", "view_calc_frustum", "light_grid_compute", "entity3d_position",
                "entity3d_move", "entity3d_rotate", "entity3d_scale", "entity3d_visible", "entity3d_update", "entity3d_reset",
-               "particle_system_position"):
+               "entity3d_delete", "particle_system_position"):
         assert fn in names and "ref_" + fn in names, fn
 
 
@@ -243,6 +243,34 @@ def test_binding_bench_mode_is_consistent(mode):
         assert r["scatter"] == "drawn" and r["left_stale_per_frame"] > 0 and r["fetched_on_view_per_frame"] > 0
     else:
         assert r["left_stale_per_frame"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [(), ("drawn",)], ids=["all", "drawn"])
+@pytest.mark.parametrize("n,frames,churn", [(3000, 30, 5), (20000, 12, 40), (300000, 6, 200)])
+def test_entities_made_and_deleted_between_frames_are_not_walked(n, frames, churn, policy):
+    """A queue that gains and loses `churn` entities EVERY frame (roots, children of random earlier entities, light
+    carriers; leaves deleted): gpu_scene_entity_created / _deleting take them into / out of the standing device layout --
+    no frame walks the queue, none re-tiles -- and every consumer still sees the reference's bits (verdicts in list order,
+    the render block, the draw list; after the last frame every entity's mx / aabb / seq / parent_seq / cur_lod)."""
+    r = _run("bench", n, frames, 100, "notify", *policy, "churn", churn)
+    assert r["mismatches"] == 0 and r["visible_equal"] is True and r["draw_sets_equal"] is True and r["draw_reads_equal"] is True
+    assert r["fast_frames"] == frames and r["retiles"] == 0, r
+    assert r["placed_in_layout"] >= 0.97 * frames * churn and r["removed_in_place"] >= 0.97 * frames * churn, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("notify", "drawn", "comeandgo", "plain"), ("notify", "comeandgo", "plain"), ("notify", "drawn", "comeandgo")],
+                         ids=["drawn-plain", "all-plain", "drawn-any"])
+@pytest.mark.parametrize("n,frames,seed", [(300, 80, 5), (2500, 16, 1), (40000, 12, 3)])
+def test_scripted_game_with_entities_coming_and_going(n, frames, seed, mode):
+    """The scripted game with creations and deletions in the frames that are not walked (`comeandgo`), moves, hides,
+    host updates and -- every fourth frame -- re-parenting (a walk) in between; `plain`: what the game makes is plain and
+    listed behind its parent, i.e. placeable; without it hooked entities and children listed before their parents make most
+    creations fall back to a walk.  Every frame compared field by field, seq counters included."""
+    r = _run("test", n, frames, seed, *mode)
+    assert r["mismatches"] == 0 and r["fast_frames"] > 0
+    assert r["removed_in_place"] > 0 and (r["placed_in_layout"] > 0 or "plain" not in mode)
 
 
 @pytest.mark.gpu

@@ -84,6 +84,45 @@ def test_binding_and_mirror_under_asan_ubsan():
 
 
 @pytest.mark.timeout(1500)
+def test_creation_and_deletion_in_place_under_asan_ubsan():
+    """Entities made and deleted while the queue is NOT walked (gpu_scene_entity_created / _deleting; the mirror's
+    clapgpu_scene_entity_new_placed / _delete_placed): tombstone records, lanes and addresses reused by the next entity,
+    growth tiles, the per-slot counters of the drawn policy, the draw list by slot -- the places where a freed entity3d or a
+    recycled slot would show.  `comeandgo`: entities come and go in the frames that are not walked; `plain`: what the game
+    makes is what the binding can place (default hook, listed behind its parent)."""
+    exe = _build("asan")
+    for args in (("test", 2500, 16, 1, "notify", "drawn", "comeandgo", "plain"), ("test", 2000, 40, 7, "notify", "comeandgo", "plain"),
+                 ("test", 300, 80, 5, "notify", "drawn", "comeandgo", "plain"), ("test", 2500, 16, 1, "notify", "drawn", "comeandgo")):
+        r = _run(exe, *args)
+        assert r["mismatches"] == 0 and r["placed_in_layout"] > 0 and r["removed_in_place"] > 0, (args, r)
+    assert _run(exe, "lod", 1500, 10, 3, "notify", "drawn", "comeandgo", "plain")["mismatches"] == 0
+    r = _run(exe, "bench", 6000, 12, 300, "notify", "drawn", "churn", 40)
+    assert r["mismatches"] == 0 and r["draw_reads_equal"] is True
+    assert r["fast_frames"] == 12 and r["retiles"] == 0 and r["placed_in_layout"] >= 470 and r["removed_in_place"] >= 470, r
+    # the same frames through a walk and a re-tile (the switch a maintainer has): same bits
+    r = _run(exe, "bench", 6000, 6, 300, "notify", "drawn", "churn", 40, env={"GPU_SCENE_INCREMENTAL": "0"})
+    assert r["mismatches"] == 0 and r["fast_frames"] == 0 and r["placed_in_layout"] == 0
+
+
+def test_mirror_edits_in_place_under_asan_ubsan():
+    """tests/c/test_scene.c -- the host mirror driven like CLAP's frame loop, every frame against the oracle -- linked
+    against the CPU stand-in and run under the sanitizers: its four frames of clapgpu_scene_entity_new_placed /
+    _delete_placed edit the standing layout (growth tiles included) without a re-tile."""
+    exe = os.path.join(OUT, "test_scene_fake")
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(ROOT, "tests", "c", "test_scene.c"), os.path.join(ROOT, "clap_amd", "host", "clapgpu_scene.c"),
+            os.path.join(ROOT, "clap_amd", "host", "clapgpu_snapshot.c"), os.path.join(ROOT, "tests", "c", "fake_clapgpu.c"),
+            os.path.join(ROOT, "oracle", "entity.c"), os.path.join(ROOT, "oracle", "lod.c")]
+    p = subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-w", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "oracle"), *srcs, "-o", exe, "-lm"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert p.returncode == 0 and "PASS" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
+    assert "0 edits fell back to a re-tile, 4 of 4 frames without one" in p.stdout and " 0 entities placed" not in p.stdout
+
+
+@pytest.mark.timeout(1500)
 def test_worker_pool_passes_under_tsan():
     """Frames that touch >= 65 536 entities split the mirror pass (the address list), the pending-count pass and the
     write-back over the worker pool; scenes are destroyed and re-created in between (the pool's last reference goes and
@@ -95,3 +134,6 @@ def test_worker_pool_passes_under_tsan():
     assert r["mismatches"] == 0
     r = _run(exe, "recreate", 70000, env={"GPU_SCENE_THREADS": "6"})
     assert r["mismatches"] == 0 and r["fast_frames"] > 0
+    # ... with entities made and deleted between the frames: tombstone records and appended ones under the split passes
+    r = _run(exe, "bench", 140000, 3, 1000, "notify", "drawn", "churn", 50, env={"GPU_SCENE_THREADS": "6"})
+    assert r["mismatches"] == 0 and r["fast_frames"] == 3 and r["placed_in_layout"] > 100
