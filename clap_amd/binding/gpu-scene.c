@@ -163,7 +163,7 @@ struct gpu_scene {
     entity3d        **created; uint32_t n_created, cap_created;    /* reported since the last update, in creation order */
     uint32_t        *dead_recs; uint32_t n_dead_recs, cap_dead_recs;   /* records of entities taken out in place: tombstones in order[] until the next walk */
     struct gs_wtxm { const model3dtx *txm; uint32_t next; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
-    bool            incremental;
+    bool            incremental, roomy;                            /* allowed; the mirror's re-tiles leave room (from the first entity that came or went between frames) */
     bool            appended;                                      /* order[] is no longer in list order: entities were taken in since the last walk */
     uint32_t        ftab_count;
     struct gs_cand { uint64_t key; uint32_t rec; } *cands; uint32_t cap_cands;
@@ -570,7 +570,19 @@ bool gpu_scene_last_was_fast(const struct gpu_scene *gs) { return gs->last_fast;
 void gpu_scene_set_notify(struct gpu_scene *gs, bool on)
 {
     gs->notify = on; gs->topology_pending = true;
-    clapgpu_scene_set_incremental(gs->scene, on && gs->incremental);   /* re-tiles leave room for entities taken in without a walk */
+    if (!on) { gs->roomy = false; clapgpu_scene_set_incremental(gs->scene, 0); }
+}
+
+/* The first entity that comes or goes between two frames says what kind of queue this is: that frame is walked and
+ * re-tiled as it always was, and from that re-tile on the mirror leaves room for such edits (an eighth of every row's lanes,
+ * a spare row per tile of a hierarchy).  A queue whose make-up never changes stays packed tight and pays nothing (1 M
+ * entities, all moving: the room costs ~10 % of a frame). */
+static void want_room(struct gpu_scene *gs)
+{
+    if (gs->roomy) return;
+    gs->roomy = true;
+    clapgpu_scene_set_incremental(gs->scene, 1);
+    gs->topology_pending = true;
 }
 
 void gpu_scene_set_incremental(struct gpu_scene *gs, bool on)
@@ -578,7 +590,7 @@ void gpu_scene_set_incremental(struct gpu_scene *gs, bool on)
     if (!gs) return;
     gs->incremental = on;
     if (!on && (gs->n_created || gs->n_dead_recs)) gs->topology_pending = true;
-    clapgpu_scene_set_incremental(gs->scene, on && gs->notify);
+    if (!on) { gs->roomy = false; clapgpu_scene_set_incremental(gs->scene, 0); }
 }
 void gpu_scene_set_verify(struct gpu_scene *gs, bool on) { if (gs) gs->verify = on; }
 
@@ -805,6 +817,7 @@ void gpu_scene_topology(struct gpu_scene *gs) { if (gs) gs->topology_pending = t
 void gpu_scene_entity_created(struct gpu_scene *gs, entity3d *e)
 {
     if (!gs || !e) return;
+    if (gs->notify && gs->incremental && gs->walked) want_room(gs);
     if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) { gs->topology_pending = true; return; }
     if (gs->n_created == gs->cap_created) {
         const uint32_t cap = gs->cap_created ? 2 * gs->cap_created : 64;
@@ -818,6 +831,7 @@ void gpu_scene_entity_created(struct gpu_scene *gs, entity3d *e)
 void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
 {
     if (!gs || !e) return;
+    if (gs->notify && gs->incremental && gs->walked) want_room(gs);
     if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) { gs->topology_pending = true; return; }
     for (uint32_t k = gs->n_created; k-- > 0;)                   /* made and gone between two frames: never seen */
         if (gs->created[k] == e) {
@@ -829,6 +843,28 @@ void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
     if (i == NO_REC) return;                                     /* another queue's entity */
     struct gs_rec *r = &gs->rec[i];
     const struct scene *scene = gs->hook_data;
+    if (r->cls == 2 && !r->lag && e != gs->last_control && !(scene && e == scene->control)) {
+        /* a host-class entity (its own hook, or below such a one): nothing of it is on the device; it leaves the list of
+         * hooks a fast frame runs -- unless another host-class entity hangs below it (the walk sorts that out) */
+        uint32_t at = NO_REC;
+        for (uint32_t k = 0; k < gs->n_host; k++) {
+            const struct gs_rec *h = &gs->rec[gs->host_list[k]];
+            if (gs->host_list[k] == i) at = k;
+            else if (h->e && h->parent_e == e) { gs->topology_pending = true; return; }
+        }
+        if (at == NO_REC || push_u32(&gs->dead_recs, &gs->n_dead_recs, &gs->cap_dead_recs, i)) { gs->topology_pending = true; return; }
+        memmove(gs->host_list + at, gs->host_list + at + 1, (size_t)(gs->n_host - at - 1) * sizeof(*gs->host_list));
+        gs->n_host--;
+        if (gs->vq_e && r->order_pos < gs->cap_vq) { gs->vq_e[r->order_pos] = NULL; gs->vq_ok[r->order_pos] = 0; }
+        uint32_t *hl = &gs->bucket[ptr_hash(e) & (gs->n_bucket - 1)];
+        while (*hl != i) hl = &gs->rec[*hl].next;
+        *hl = r->next;
+        r->e = NULL; r->cls = 0; r->self_ok = 0;
+        r->parent_e = NULL; r->parent_rec = NO_REC;
+        gs->n_live--;
+        gs->inc_removed++;
+        return;
+    }
     /* in place: a batched leaf nobody depends on -- no batched child (the mirror knows), no host-class child reading its
      * matrix, not the control entity, no hook half of its own, no joint */
     if (r->cls != 1 || r->host_child || r->att || r->handle == CLAPGPU_NO_ENTITY || e->update != gs->default_hook ||
@@ -935,15 +971,58 @@ static int take_created(struct gpu_scene *gs, struct mq *mq)
             if (ours) return 1;                                  /* a txmodel the last walk has not seen */
             continue;                                            /* another queue's entity */
         }
-        if (e->update != gs->default_hook || !self_batchable(gs, e) || entity_animated(e) || e->parent_joint != JOINT_TYPE_MAX ||
-            !transform_is_updated(&e->xform) || rec_find(gs, e) != NO_REC)
-            return 1;
+        if ((e->parent && e->parent_joint != JOINT_TYPE_MAX) || rec_find(gs, e) != NO_REC) return 1;
+        /* plain: what the device can hold without anything else being set up.  Batchable in another way (a body-less
+         * character, an animated entity whose pose runs elsewhere): the walk registers those.  Everything else is
+         * host-class -- its own hook runs it, at its place in the list */
+        const bool selfb = self_batchable(gs, e);
+        const bool plain = selfb && e->update == gs->default_hook && !entity_animated(e);
+        if (selfb && !plain) return 1;
         const uint64_t key = ((uint64_t)rank << 32) | gs->wtxm[rank].next;
         uint32_t pi = NO_REC;
         if (e->parent) {
+            /* below a parent the last walk met, listed earlier (one listed later is read a frame late: the walk's lag
+             * machinery), batched or host-class (not one of the frame's second launch) */
             pi = rec_find(gs, e->parent);
-            if (pi == NO_REC || gs->rec[pi].cls != 1 || gs->rec[pi].handle == CLAPGPU_NO_ENTITY || gs->rec[pi].order_key > key)
+            if (pi == NO_REC || (gs->rec[pi].cls != 1 && gs->rec[pi].cls != 2) || gs->rec[pi].order_key > key ||
+                (gs->rec[pi].cls == 1 && gs->rec[pi].handle == CLAPGPU_NO_ENTITY))
                 return 1;
+        }
+        if (!plain || (pi != NO_REC && gs->rec[pi].cls == 2)) {
+            /* host-class: a record, a seat in order[] and, by its place in the queue, in the list of hooks */
+            CK(ensure_order(gs, gs->n_order + 1));
+            if (gs->n_host == gs->cap_host) {
+                if (push_u32(&gs->host_list, &gs->n_host, &gs->cap_host, 0)) return _CERR_NOMEM;
+                gs->n_host--;
+            }
+            const uint32_t i = rec_add(gs, e);
+            if (i == NO_REC) return _CERR_NOMEM;
+            struct gs_rec *r = &gs->rec[i];
+            gs->wtxm[rank].next++;
+            r->model = e->txmodel->model;
+            r->parent_e = e->parent; r->parent_rec = pi;
+            r->gen = gs->gen;
+            r->cls = 2; r->self_ok = selfb;
+            r->order_key = key;
+            r->order_pos = gs->n_order;
+            gs->order[gs->n_order++] = i;
+            gs->appended = true;
+            gs->vq_e[r->order_pos] = e; gs->vq_slot[r->order_pos] = CLAPGPU_NO_ENTITY; gs->vq_ok[r->order_pos] = 0;
+            uint32_t at = gs->n_host;
+            while (at && gs->rec[gs->host_list[at - 1]].order_key > key) at--;
+            memmove(gs->host_list + at + 1, gs->host_list + at, (size_t)(gs->n_host - at) * sizeof(*gs->host_list));
+            gs->host_list[at] = i;
+            gs->n_host++;
+            if (pi != NO_REC && gs->rec[pi].cls == 1) {          /* its hook reads that parent's mx / seq every frame: a standing reader */
+                struct gs_rec *pr = &gs->rec[pi];
+                pr->host_child = 1;
+                if (gs->scatter_drawn && !pr->keep && !clapgpu_scene_entity_keep(gs->scene, pr->handle, 1)) {
+                    pr->keep = 1;
+                    gpu_scene_fetch(gs, pr->e);
+                }
+            }
+            gs->inc_placed++;
+            continue;
         }
         uint32_t mh;
         CK(model_handle(gs, e->txmodel->model, &mh));
@@ -988,6 +1067,13 @@ static int take_created(struct gpu_scene *gs, struct mq *mq)
         if (gs->scatter_drawn && (e->light_idx >= 0 || (scene && e == scene->control)) &&
             !clapgpu_scene_entity_keep(gs->scene, handle, 1))
             r->keep = 1;
+        if (!transform_is_updated(&e->xform)) {
+            /* never positioned, or updated on the spot already (entity3d_update / _reset before its first frame): the host
+             * fields are final as they are; the device builds its copy, the write-back leaves the entity3d alone unless its
+             * parent moved on (gpu_scene_host_updated) */
+            r->host_done = 1;
+            if (gs->scatter_drawn && !r->keep && !clapgpu_scene_entity_keep(gs->scene, handle, 1)) r->keep = 1;
+        }
         r->pending = 1;
         if (push_u32(&gs->touched, &gs->n_touched, &gs->cap_touched, i)) return _CERR_NOMEM;
         gs->n_batched++;

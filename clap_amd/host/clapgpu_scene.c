@@ -294,7 +294,9 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     free(s->tile_row_start_host); free(s->level_start_host);
     if (s->h_in) clapgpu_host_free(s->h_in);
     if (s->h_out) clapgpu_host_free(s->h_out);
-    free(s->h_parent); free(s->h_model); free(s->slot_user);
+    if (s->h_parent) clapgpu_host_free(s->h_parent);
+    if (s->h_model) clapgpu_host_free(s->h_model);
+    free(s->slot_user);
     if (s->d_bv_result) clapgpu_free(s->d_bv_result);
     if (s->h_list) clapgpu_host_free(s->h_list);
     if (s->h_done) clapgpu_host_free(s->h_done);
@@ -548,10 +550,10 @@ static int apply_edits(clapgpu_scene *s)
         CK(clapgpu_memset(s->d.center + 3 * i, 0, 12, NULL));
     }
     if (s->n_edits) {
-        /* few edits far apart: one word each; many, or close together: the range that spans them (a copy call is ~10 us,
-         * the range moves at ~10 GB/s) */
+        /* few edits far apart: one word each; many, or close together: the range that spans them (queueing a copy from
+         * page-locked memory is ~4 us, the range moves at ~25 GB/s) */
         const size_t span = (size_t)s->edit_hi - s->edit_lo;
-        if ((double)s->n_edits * 10.0 < 10.0 + (double)span * 4.0 / 1e4) {
+        if ((double)s->n_edits * 8.0 < 8.0 + (double)span * 8.0 / 2.5e4) {
             for (uint32_t k = 0; k < s->n_edits; k++) {
                 const size_t i = s->edits[k];
                 CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + i, s->h_parent + i, 4, NULL));
@@ -823,7 +825,7 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     uint32_t cap = (n_slots + n_slots / 8 + 4095u) & ~4095u;
     size_t n = cap;                                     /* a multiple of 64: every sub-array below starts 16-B aligned */
 #define RE(p, bytes) do { void *q__ = realloc(p, bytes); if (!q__) return CLAPGPU_ERR_NOMEM; p = q__; } while (0)
-    RE(s->h_parent, n * 4); RE(s->h_model, n * 4); RE(s->slot_handle, n * 4); RE(s->slot_user, n * sizeof(void *));
+    RE(s->slot_handle, n * 4); RE(s->slot_user, n * sizeof(void *));
 #undef RE
     /* retile() rewrites the upload image in full and downloads are overwritten by the next frame, so
      * nothing has to survive the growth */
@@ -831,6 +833,12 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     if (s->h_in) clapgpu_host_free(s->h_in);
     if (s->h_out) clapgpu_host_free(s->h_out);
     s->h_in = s->h_out = NULL;
+    /* page-locked: the small copies that carry an in-place edit's parent / model index are then queued, not staged and waited for */
+    if (s->h_parent) clapgpu_host_free(s->h_parent);
+    if (s->h_model) clapgpu_host_free(s->h_model);
+    s->h_parent = s->h_model = NULL;
+    CK(clapgpu_host_malloc((void **)&s->h_parent, n * 4));
+    CK(clapgpu_host_malloc((void **)&s->h_model, n * 4));
     s->models_dirty = 1;                                /* free_device() dropped d.model_table */
     s->have_results = 0;
     s->in_bytes = n * 36 + (n / 64 + 2) * 8;                 /* + the touched-slot bits */

@@ -251,8 +251,10 @@ def test_binding_bench_mode_is_consistent(mode):
 def test_entities_made_and_deleted_between_frames_are_not_walked(n, frames, churn, policy):
     """A queue that gains and loses `churn` entities EVERY frame (roots, children of random earlier entities, light
     carriers; leaves deleted): gpu_scene_entity_created / _deleting take them into / out of the standing device layout --
-    no frame walks the queue, none re-tiles -- and every consumer still sees the reference's bits (verdicts in list order,
-    the render block, the draw list; after the last frame every entity's mx / aabb / seq / parent_seq / cur_lod)."""
+    the frames are not walked and do not re-tile (but for the FIRST such frame, one of the bench's warm-up frames: the queue
+    was packed tight until then, and that walk's re-tile makes room for the rest) -- and every consumer still sees the
+    reference's bits (verdicts in list order, the render block, the draw list; after the last frame every entity's
+    mx / aabb / seq / parent_seq / cur_lod)."""
     r = _run("bench", n, frames, 100, "notify", *policy, "churn", churn)
     assert r["mismatches"] == 0 and r["visible_equal"] is True and r["draw_sets_equal"] is True and r["draw_reads_equal"] is True
     assert r["fast_frames"] == frames and r["retiles"] == 0, r
@@ -270,7 +272,9 @@ def test_scripted_game_with_entities_coming_and_going(n, frames, seed, mode):
     creations fall back to a walk.  Every frame compared field by field, seq counters included."""
     r = _run("test", n, frames, seed, *mode)
     assert r["mismatches"] == 0 and r["fast_frames"] > 0
-    assert r["removed_in_place"] > 0 and (r["placed_in_layout"] > 0 or "plain" not in mode)
+    # (at 40 000 entities the unrestricted game makes ~125 entities a frame, a third of the children listed BEFORE their
+    # parents: some creation of every frame needs the walk)
+    assert r["removed_in_place"] > 0 and (r["placed_in_layout"] > 0 or ("plain" not in mode and n >= 40000))
 
 
 @pytest.mark.gpu
