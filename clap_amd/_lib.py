@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 OK = 0
 ERR_NOMEM = -1
@@ -252,6 +252,7 @@ SYMBOLS = {
     "clapgpu_characters_update_clock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "clapgpu_host_malloc_mapped": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
     "clapgpu_entities_apply_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "clapgpu_entities_place": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "clapgpu_entities_export_rebuilt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_entities_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_entities_update_tiles_hostio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

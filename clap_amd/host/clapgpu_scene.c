@@ -102,6 +102,7 @@ struct clapgpu_scene {
     uint32_t   *free_roots; uint32_t n_free_roots, cap_free_roots;     /* first-row slots freed by deletions */
     uint32_t   *raw_words; uint32_t n_raw, cap_raw, raw_lo, raw_hi;    /* words of h_touched set outside the dirty list (tombstones); their slot range */
     uint32_t   *edits; uint32_t n_edits, cap_edits, edit_lo, edit_hi;  /* slots whose parent / model the device has not been given yet */
+    clapgpu_entity_place *h_place; void *d_place; uint32_t cap_place;  /* ... as the mapped list clapgpu_entities_place takes */
     uint32_t    grown_from, tiles_from;                                /* first slot / tile appended since the device last saw the layout (NO_ENTITY: none) */
     uint32_t   *limbo; uint32_t n_limbo, cap_limbo;                    /* handles deleted in place: reusable once the frame's dirty list is spent */
 
@@ -307,6 +308,7 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->d_keep) clapgpu_free(s->d_keep);
     if (s->h_select) clapgpu_host_free(s->h_select);
     free(s->h_keep); free(s->h_stale); free(s->h_fetched); free(s->free_roots); free(s->raw_words); free(s->edits); free(s->limbo);
+    if (s->h_place) clapgpu_host_free(s->h_place);
     free(s);
 }
 
@@ -541,28 +543,25 @@ static int apply_edits(clapgpu_scene *s)
         s->d.n = s->n_slots;
         s->grown_from = s->tiles_from = CLAPGPU_NO_ENTITY;
     }
-    for (uint32_t k = 0; k < s->n_edits; k++) {
-        /* a model without a box (skip_aabb) never writes one: the lane's last tenant's must not stay (a fresh entity3d's
-         * is all zeros, and so is every row after a re-tile) */
-        if (!(s->edits[k] & 0x80000000u)) continue;
-        const size_t i = s->edits[k] &= 0x7fffffffu;
-        CK(clapgpu_memset(s->d.aabb + 6 * i, 0, 24, NULL));
-        CK(clapgpu_memset(s->d.center + 3 * i, 0, 12, NULL));
-    }
     if (s->n_edits) {
-        /* few edits far apart: one word each; many, or close together: the range that spans them (queueing a copy from
-         * page-locked memory is ~4 us, the range moves at ~25 GB/s) */
-        const size_t span = (size_t)s->edit_hi - s->edit_lo;
-        if ((double)s->n_edits * 8.0 < 8.0 + (double)span * 8.0 / 2.5e4) {
-            for (uint32_t k = 0; k < s->n_edits; k++) {
-                const size_t i = s->edits[k];
-                CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + i, s->h_parent + i, 4, NULL));
-                CK(clapgpu_memcpy_h2d((int32_t *)s->d.model + i, s->h_model + i, 4, NULL));
-            }
-        } else {
-            CK(clapgpu_memcpy_h2d((int32_t *)s->d.parent + s->edit_lo, s->h_parent + s->edit_lo, span * 4, NULL));
-            CK(clapgpu_memcpy_h2d((int32_t *)s->d.model + s->edit_lo, s->h_model + s->edit_lo, span * 4, NULL));
+        /* the frame's edited lanes as one mapped list, one small launch (two copies and two fills each, queued one behind
+         * the other in front of the update, cost a 10 k-entity frame 35 us).  zero_box: a model without a box (skip_aabb)
+         * never writes one, so the lane's last tenant's must not stay (a fresh entity3d's is all zeros, and so is every
+         * row after a re-tile) */
+        if (s->n_edits > s->cap_place) {
+            uint32_t cap = s->cap_place ? s->cap_place : 64;
+            while (cap < s->n_edits) cap *= 2;
+            if (s->h_place) clapgpu_host_free(s->h_place);
+            s->h_place = NULL; s->cap_place = 0;
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_place, &s->d_place, (size_t)cap * sizeof(*s->h_place)));
+            s->cap_place = cap;
         }
+        for (uint32_t k = 0; k < s->n_edits; k++) {
+            const uint32_t i = s->edits[k] & 0x7fffffffu;
+            s->h_place[k] = (clapgpu_entity_place){ .slot = i, .parent = s->h_parent[i], .model = s->h_model[i],
+                                                    .zero_box = s->edits[k] >> 31 };
+        }
+        CK(clapgpu_entities_place(NULL, &s->d, (const clapgpu_entity_place *)s->d_place, s->n_edits));
         s->n_edits = 0;
     }
     return CLAPGPU_OK;

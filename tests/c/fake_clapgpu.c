@@ -191,6 +191,21 @@ int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const
     return CLAPGPU_OK;
 }
 
+int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list)
+{
+    (void)stream;
+    if (!e || !e->parent || !e->model || !e->aabb || !e->center || (n_list && !list)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!launch_ok("k_entities_place (fake)")) return CLAPGPU_ERR_UNKNOWN;
+    for (uint32_t k = 0; k < n_list; k++) {
+        const uint32_t slot = list[k].slot;
+        if (slot >= e->n) continue;
+        ((int32_t *)e->parent)[slot] = list[k].parent;
+        ((int32_t *)e->model)[slot] = list[k].model;
+        if (list[k].zero_box) { memset(e->aabb + 6 * (size_t)slot, 0, 24); memset(e->center + 3 * (size_t)slot, 0, 12); }
+    }
+    return CLAPGPU_OK;
+}
+
 static void copy_rows(const clapgpu_entities *e, float *o_mx, float *o_inv, float *o_aabb, float *o_center, const uint64_t *mask)
 {
     for (uint32_t i = 0; i < e->n; i++) {
