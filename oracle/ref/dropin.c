@@ -230,6 +230,9 @@ static void op_create(float spread, bool allow_hook)
         if (may_parent(p, id)) parent = p;
     }
     if (parent != NONE) { pos[0] = rndf(-2, 2); pos[1] = rndf(-2, 2); pos[2] = rndf(-2, 2); }
+    /* instantiate_entity (model.c:1863-1874): made, positioned and updated on the spot by a DIRECT call of default_update --
+     * no mutator, no wrapper tells the binding; the entity arrives with xform.updated cleared and seq == 1 */
+    const bool instantiated = !m->hooked && parent == NONE && rndn(6) == 0;
     const bool carries = rndn(24) == 0;                            /* light carriers: batched; the binding hands the position on */
     const vec3 loff = { rndf(-1, 1), rndf(0, 3), rndf(-1, 1) };
     for (int k = 0; k < 2; k++) {
@@ -244,6 +247,7 @@ static void op_create(float spread, bool allow_hook)
             if (!IS_CERR(li)) { e->light_idx = li.val; e->light = &w->scene->light; memcpy(e->light_off, loff, sizeof(loff)); }
         }
         if (k) gpu_scene_entity_created(gpu_scene_bound(), e);     /* what entity3d_make does under CONFIG_GPU_SCENE (its last line) */
+        if (instantiated) default_update(e, w->scene);
         w->e[id] = e;
     }
     if (parent != NONE) { m->parent = parent; meta[parent].n_children++; }
