@@ -80,6 +80,8 @@ struct gs_rec {
     uint8_t     pending;        /* on the touched list (notification mode) */
     uint8_t     host_done;      /* entity3d_update() / entity3d_reset() ran this entity's update on the host between frames: the device
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
+    uint8_t     gone;           /* gpu_scene_entity_deleting() named this entity and it was not taken out in place: whatever the next walk
+                                   meets at this address is ANOTHER entity (malloc hands a freed entity3d's memory to the next one) */
     uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
                                    gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
@@ -832,7 +834,15 @@ void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
 {
     if (!gs || !e) return;
     if (gs->notify && gs->incremental && gs->walked) want_room(gs);
-    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) { gs->topology_pending = true; return; }
+    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) {
+        /* the next update walks the queue.  If the allocator hands this entity3d's memory to a new entity before then, the walk
+         * meets a familiar address: the record says that it is not the entity it knew (same model, xform.updated cleared by an
+         * instantiate_entity-style default_update: nothing else would tell, and the device would keep the old transform) */
+        const uint32_t g = rec_find(gs, e);
+        if (g != NO_REC) gs->rec[g].gone = 1;
+        gs->topology_pending = true;
+        return;
+    }
     for (uint32_t k = gs->n_created; k-- > 0;)                   /* made and gone between two frames: never seen */
         if (gs->created[k] == e) {
             memmove(gs->created + k, gs->created + k + 1, (size_t)(gs->n_created - k - 1) * sizeof(*gs->created));
@@ -850,9 +860,9 @@ void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
         for (uint32_t k = 0; k < gs->n_host; k++) {
             const struct gs_rec *h = &gs->rec[gs->host_list[k]];
             if (gs->host_list[k] == i) at = k;
-            else if (h->e && h->parent_e == e) { gs->topology_pending = true; return; }
+            else if (h->e && h->parent_e == e) { r->gone = 1; gs->topology_pending = true; return; }
         }
-        if (at == NO_REC || push_u32(&gs->dead_recs, &gs->n_dead_recs, &gs->cap_dead_recs, i)) { gs->topology_pending = true; return; }
+        if (at == NO_REC || push_u32(&gs->dead_recs, &gs->n_dead_recs, &gs->cap_dead_recs, i)) { r->gone = 1; gs->topology_pending = true; return; }
         memmove(gs->host_list + at, gs->host_list + at + 1, (size_t)(gs->n_host - at - 1) * sizeof(*gs->host_list));
         gs->n_host--;
         if (gs->vq_e && r->order_pos < gs->cap_vq) { gs->vq_e[r->order_pos] = NULL; gs->vq_ok[r->order_pos] = 0; }
@@ -870,11 +880,13 @@ void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
     if (r->cls != 1 || r->host_child || r->att || r->handle == CLAPGPU_NO_ENTITY || e->update != gs->default_hook ||
         e == gs->last_control || (scene && e == scene->control) ||
         push_u32(&gs->dead_recs, &gs->n_dead_recs, &gs->cap_dead_recs, i)) {
+        r->gone = 1;
         gs->topology_pending = true;
         return;
     }
     if (clapgpu_scene_entity_delete_placed(gs->scene, r->handle)) {
         gs->n_dead_recs--;
+        r->gone = 1;
         gs->topology_pending = true;
         return;
     }
@@ -1255,9 +1267,17 @@ void gpu_scene_describe(struct gpu_scene *gs, entity3d *e, char *buf, size_t len
     clapgpu_scene_arrays res;
     const bool have = !clapgpu_scene_results(gs->scene, &res);
     if (have) gs->res = res;
-    snprintf(buf, len, "class %u slot %u keep %u user_keep %u host_child %u host_done %u pend %u stale %d parent_rec %d order_pos %u",
+    int n = snprintf(buf, len, "class %u slot %u keep %u user_keep %u host_child %u host_done %u pend %u stale %d parent_rec %d order_pos %u",
              r->cls, r->slot, r->keep, r->user_keep, r->host_child, r->host_done, pend_of(gs, r->slot),
              have ? (int)slot_is_stale(gs, r->slot) : -1, r->parent_rec == NO_REC ? -1 : (int)r->parent_rec, r->order_pos);
+    if (have && n > 0 && (size_t)n < len && r->slot < res.n_slots && (r->cls == 1 || r->cls == 4)) {   /* the row the mirror holds, beside the entity3d's */
+        const float *b = res.aabb + 6 * (size_t)r->slot;
+        snprintf(buf + n, len - (size_t)n, "; mirror box %.9g %.9g %.9g %.9g %.9g %.9g vis %d rebuilt %d, entity3d box %.9g %.9g %.9g %.9g %.9g %.9g flags %x/%x",
+                 b[0], b[1], b[2], b[3], b[4], b[5], (int)((res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1),
+                 (int)((res.rebuilt_mask[r->slot >> 6] >> (r->slot & 63)) & 1),
+                 ((const float *)e->aabb)[0], ((const float *)e->aabb)[1], ((const float *)e->aabb)[2], ((const float *)e->aabb)[3],
+                 ((const float *)e->aabb)[4], ((const float *)e->aabb)[5], (unsigned)r->flags, (unsigned)(e->flags & (ENTITY3D_ALIVE | 0xffffu)));
+    }
 }
 
 void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep)
@@ -1948,6 +1968,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 gs->cap_order = cap;
             }
             struct gs_rec *r = &gs->rec[i];
+            if (r->gone) {                                       /* the entity this record knew was deleted: e is a new one at its address */
+                CK(unbatch(gs, r));
+                *r = (struct gs_rec){ .e = e, .next = r->next, .parent_rec = NO_REC, .handle = CLAPGPU_NO_ENTITY, .slot = CLAPGPU_NO_ENTITY,
+                                      .parent_handle = CLAPGPU_NO_ENTITY };
+            }
             if (gs->walk_fetch_on && (r->cls == 1 || r->cls == 4) && r->slot < gs->res.n_slots &&
                 ((gs->walk_fetch[r->slot >> 6] >> (r->slot & 63)) & 1)) {
                 scatter_fetched(gs, r, &gs->res, r->slot);       /* (its class and slot are still last walk's) */

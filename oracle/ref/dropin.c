@@ -360,7 +360,7 @@ static uint64_t compare_frame_ex(struct gpu_scene *gs, uint32_t frame, uint64_t 
         diff |= !!memcmp(&a->xform, &b->xform, sizeof(transform_t)) << 7;
         *n_visible += va;
         if (diff && bad++ < 8) {
-            char what[256], whatp[256] = "";
+            char what[640], whatp[640] = "";
             gpu_scene_describe(gs, b, what, sizeof(what));
             if (b->parent) gpu_scene_describe(gs, b->parent, whatp, sizeof(whatp));
             fprintf(stderr, "frame %u entity %u (model %u parent %d hooked %u): mismatch mask 0x%02x%s; seq %u / %u parent_seq %u / %u; record: %s; parent's: %s\n",
@@ -593,7 +593,7 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
         if (getenv("DROPIN_TRACE")) {                                    /* one entity's counters after every frame, before any fetch */
             const uint32_t id = (uint32_t)atoi(getenv("DROPIN_TRACE"));
             if (id < n_ids && meta[id].alive) {
-                char what[256], whatp[256] = "";
+                char what[640], whatp[640] = "";
                 gpu_scene_describe(gs, B.e[id], what, sizeof(what));
                 if (B.e[id]->parent) gpu_scene_describe(gs, B.e[id]->parent, whatp, sizeof(whatp));
                 fprintf(stderr, "trace frame %u (%s): entity %u seq %u / %u parent_seq %u / %u updated %d / %d vis %d; %s; parent (seq %u / %u): %s\n", f,

@@ -39,7 +39,7 @@ def _build(kind):
         [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
         return exe
-    san = {"asan": ["-fsanitize=address,undefined"], "tsan": ["-fsanitize=thread"]}[kind]
+    san = {"asan": ["-fsanitize=address,undefined"], "tsan": ["-fsanitize=thread"], "plain": []}[kind]
     cmd = [CL, "-std=gnu23", "-D_GNU_SOURCE", "-O1", "-g", "-fno-omit-frame-pointer", "-ffp-contract=off", "-Wno-everything", *san,
            "-I", GEN, "-I", os.path.join(REF, "core"), "-I", os.path.join(REF, "compat"), "-include", os.path.join(REF, "compat", "compat.h"),
            "-DCONFIG_GPU_SCENE=1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "clap_amd", "binding"),
@@ -103,6 +103,21 @@ def test_creation_and_deletion_in_place_under_asan_ubsan():
     # the same frames through a walk and a re-tile (the switch a maintainer has): same bits
     r = _run(exe, "bench", 6000, 6, 300, "notify", "drawn", "churn", 40, env={"GPU_SCENE_INCREMENTAL": "0"})
     assert r["mismatches"] == 0 and r["fast_frames"] == 0 and r["placed_in_layout"] == 0
+
+
+@pytest.mark.timeout(1500)
+def test_recycled_entity_addresses_without_a_sanitizer():
+    """The sanitizers' allocators never hand a freed block out again soon, malloc does at once: a deleted entity3d's address
+    is the next new entity's.  The same checker WITHOUT a sanitizer: a record looked up by address must not be taken for
+    the entity it knew (found here: a new entity of the same model, updated on the spot like instantiate_entity does --
+    xform.updated cleared -- kept the DELETED entity's transform on the device, in a walked frame; the deletion
+    notification now marks the record)."""
+    exe = _build("plain")
+    for args in (("test", 5000, 16, 2), ("test", 5000, 16, 2, "notify"), ("test", 2500, 16, 1, "notify", "drawn", "comeandgo", "plain"),
+                 ("test", 300, 80, 5, "notify", "drawn", "comeandgo"), ("test", 20000, 10, 9, "notify", "drawn", "comeandgo", "plain")):
+        assert _run(exe, *args)["mismatches"] == 0, args
+    r = _run(exe, "bench", 20000, 12, 300, "notify", "drawn", "churn", 60)
+    assert r["mismatches"] == 0 and r["fast_frames"] == 12 and r["draw_reads_equal"] is True
 
 
 def test_mirror_edits_in_place_under_asan_ubsan():
