@@ -290,6 +290,21 @@ def dropin_boundary():
             out[key]["scatter_drawn"] = dict(one(n, frames, permille, "drawn"), policy="GPU_SCATTER_DRAWN")
         except Exception as e:                                   # a figure for context: never fail the bench on it
             out.setdefault(key, {})["error"] = repr(e)[:200]
+    # a queue whose make-up changes EVERY frame (10 entities made -- roots, children of random earlier entities, light carriers --
+    # and 10 leaves deleted; 10 % of the entities moving): gpu_scene_entity_created / _deleting place them into / take them out of
+    # the standing device layout; before round 5 each such frame walked the queue and re-tiled it (1 M: 257-267 ms)
+    for n, frames in ((10_000, 60), (1_000_000, 6)):
+        key = f"{n}_entities_10pct_dirty_10_made_10_deleted_a_frame"
+        try:
+            p = subprocess.run([exe, "bench", str(n), str(frames), "100", "notify", "drawn", "churn", "10"], capture_output=True, text=True,
+                               timeout=240)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out[key] = {k: r[k] for k in ("reference_mq_update_ms", "binding_mq_update_ms", "binding_ms", "reference_frame_ms",
+                                          "binding_frame_draw_list_ms", "fast_frames", "retiles", "placed_in_layout", "removed_in_place")}
+            out[key]["identical"] = (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"])
+            out[key]["policy"] = "GPU_SCATTER_DRAWN"
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
     # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
     # (10 x 64 over 400 frames: the testbed's own scale, core/clap.c's demo scenes -- three device round trips a frame)
@@ -715,7 +730,7 @@ def full_frame(device):
 
 
 def summary(out, extra):
-    """<= 12 scalars: what the long `extra` / `cpu_baseline` sections say, where a record that keeps only the head of the
+    """<= 14 scalars: what the long `extra` / `cpu_baseline` sections say, where a record that keeps only the head of the
     line (or drops `extra`) still has them.  Microseconds per launch unless the key says otherwise."""
     s = {}
 
@@ -741,6 +756,9 @@ def summary(out, extra):
     put("boundary_1m_mq_update_ms", lambda: d["binding_mq_update_ms"])
     put("boundary_1m_frame_ms_scatter_all", lambda: b["binding_frame_draw_list_ms"])
     put("boundary_1m_reference_frame_ms", lambda: b["reference_frame_ms"])
+    c = ((out.get("cpu_baseline") or {}).get("dropin_boundary") or {}).get("1000000_entities_10pct_dirty_10_made_10_deleted_a_frame") or {}
+    put("boundary_1m_churn_mq_update_ms", lambda: c["binding_mq_update_ms"])
+    put("boundary_1m_churn_reference_mq_update_ms", lambda: c["reference_mq_update_ms"])
     return s
 
 

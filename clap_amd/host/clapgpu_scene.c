@@ -847,6 +847,7 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     else CK(clapgpu_host_malloc(&s->h_in, s->in_bytes));
     if (s->zero_copy) {
         CK(clapgpu_host_malloc_mapped(&s->h_out, &s->d_out_host, s->out_bytes));
+        memset(s->h_out, 0, s->out_bytes);
         if (!s->h_done) {
             void *dd = NULL;
             CK(clapgpu_host_malloc_mapped((void **)&s->h_done, &dd, 64));
@@ -1056,7 +1057,9 @@ static int retile(clapgpu_scene *s)
     CK(clapgpu_memcpy_h2d((void *)s->d.model, s->h_model, n * 4, NULL));
     CK(clapgpu_memset(s->d.seqs, 0, n * 4, NULL));
     CK(clapgpu_memset(s->d_out, 0, s->out_bytes, NULL));
-    if (s->zero_copy) memset(s->h_out, 0, s->out_bytes);          /* the export kernel only writes what an update rebuilt */
+    /* the host's result slab is NOT cleared here (at a million entities that alone was 15 ms of a re-tile): the launch that
+     * follows rebuilds and exports every live row and writes every mask word of the layout; padding rows are never read
+     * (no slot_user), and a box-less model's rows are never copied out.  It is zeroed once, where it is allocated. */
     if (tiled)
         CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
     /* every live handle, not only the listed ones: an entity marked dirty while the list could not grow (mark_dirty's
