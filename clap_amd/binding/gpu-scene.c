@@ -82,6 +82,7 @@ struct gs_rec {
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
     uint8_t     gone;           /* gpu_scene_entity_deleting() named this entity and it was not taken out in place: whatever the next walk
                                    meets at this address is ANOTHER entity (malloc hands a freed entity3d's memory to the next one) */
+    uint8_t     keep_auto;      /* a standing host reader the walk can see on the entity itself (light carrier, hook half of its own, animated, joint rider) */
     uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
                                    gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
     uint32_t    lag;            /* host-class entity listed BEFORE its batched parent: index + 1 into gs->lag_*[], else 0 */
@@ -687,15 +688,28 @@ static int slot_arrays_build(struct gpu_scene *gs)
         gs->cap_slot_arrays = n;
     }
     if (n) memset(gs->slot_ent, 0, (size_t)n * sizeof(*gs->slot_ent));
+    /* from the records alone (an entity3d is 448 bytes somewhere else): the txmodel is the walk's rank of it (order_key), the
+     * LOD what mirror_one() last saw in e->cur_lod */
     gs->n_txms = 0;
+    if (gs->n_wtxm > 65535) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }
+    for (uint32_t t = 0; t < gs->n_wtxm; t++) {
+        gs->n_txms = t;                                          /* (txm_index appends at n_txms) */
+        if (gs->n_txms == gs->cap_txms) {
+            const uint32_t cap = gs->cap_txms ? 2 * gs->cap_txms : 32;
+            const model3dtx **q = realloc(gs->txms, (size_t)cap * sizeof(*q));
+            if (!q) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }
+            gs->txms = q; gs->cap_txms = cap;
+        }
+        gs->txms[t] = gs->wtxm[t].txm;
+    }
+    gs->n_txms = gs->n_wtxm;
     for (uint32_t k = 0; k < gs->n_order; k++) {
         const struct gs_rec *r = &gs->rec[gs->order[k]];
         if ((r->cls != 1 && r->cls != 4) || r->slot >= n) continue;
-        const uint32_t g = txm_index(gs, r->e->txmodel);
-        if (g == 0xffffffffu || r->e->cur_lod < -128 || r->e->cur_lod > 127) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }   /* the record path then */
+        if (r->lod_cur < -128 || r->lod_cur > 127) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }   /* the record path then */
         gs->slot_ent[r->slot] = r->e;
-        gs->slot_txm[r->slot] = (uint16_t)g;
-        gs->slot_lod[r->slot] = (int8_t)r->e->cur_lod;
+        gs->slot_txm[r->slot] = (uint16_t)(r->order_key >> 32);
+        gs->slot_lod[r->slot] = (int8_t)r->lod_cur;
     }
     return 0;
 }
@@ -2022,6 +2036,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
                 }
             }
             if (r->cls == 1 || r->cls == 4) {
+                r->keep_auto = r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook || entity_animated(e);
                 if (e->update != gs->default_hook) {             /* a body-less character: its hook's host half, at its place in the list */
                     gs->char_half(e, mq->priv);
                     if (push_u32(&gs->char_list, &gs->n_char, &gs->cap_char, i)) return _CERR_NOMEM;
@@ -2186,9 +2201,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         for (uint32_t k = 0; k < gs->n_order; k++) {
             struct gs_rec *r = &gs->rec[gs->order[k]];
             if ((r->cls != 1 && r->cls != 4) || r->handle == CLAPGPU_NO_ENTITY) continue;
-            const entity3d *e = r->e;
-            const uint8_t keep = r->user_keep || r->host_child || r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook ||
-                                 entity_animated((entity3d *)e) || (scene && e == scene->control);
+            const uint8_t keep = r->user_keep || r->host_child || r->keep_auto || (scene && r->e == scene->control);   /* (the records alone: keep_auto was taken while the entity was at hand) */
             if (keep != r->keep && !clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
         }
     }
