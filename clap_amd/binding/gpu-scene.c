@@ -1618,6 +1618,8 @@ static int cand_cmp(const void *a, const void *b)
  *   bounding-volume pick of the few entities whose box contains a query point, merged in list order.
  * Returns 1 if the frame has to be done by the full walk after all (a touched entity changed class or parent).
  */
+static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scene_arrays *resp, double t0, double t1, double t2);
+
 static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
     struct gpu_scene_stats *st = &gs->stats;
@@ -1710,7 +1712,22 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     clapgpu_scene_arrays res = { 0 };
     if (clapgpu_scene_results(gs->scene, &res)) memset(&res, 0, sizeof(res));
     gs->res = res;
-    const double t2 = now_ms();
+    return frame_results(gs, mq, &res, t0, t1, now_ms());
+}
+
+/*
+ * The second half of a frame whose device step did not re-tile: what the kernel rebuilt goes back into the entity3d structs
+ * (by the device's masks, on the workers when there is much of it), then the host-class entities' own hooks and the camera
+ * bounding-volume pick, merged in list order.  A notified frame ends here, and so does a WALKED one whose layout stood (a
+ * frame without notifications, or one that only had to look at the queue again): the device rebuilds exactly what the
+ * reference's own tests would (model.c:1609-1616, 1667: xform.updated, or a parent that was rebuilt), so its mask is the
+ * walk's answer too -- instead of a second serial pass over every entity3d (1 M entities: 41-53 ms of a walked frame).
+ */
+static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scene_arrays *resp, double t0, double t1, double t2)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    struct scene *scene = mq->priv;
+    const clapgpu_scene_arrays res = *resp;
     for (uint32_t k = 0; k < gs->n_lag; k++) {                  /* last frame's bits of the parents some host child still has to see */
         const entity3d *p = gs->rec[gs->lag_parent[k]].e;
         memcpy(gs->lag_keep[k].mx, p->mx, sizeof(mat4x4));
@@ -1932,7 +1949,11 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     gs->topology_pending = false;
     gs->last_fast = false;
     gs->n_host = 0; gs->n_batched = 0; gs->n_deferred = 0; gs->n_att = 0; gs->n_char = 0;
-    clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);   /* the walk does the pick per entity */
+    if (scene && scene->camera)                                  /* the device's containment mask: what the second half goes by when the layout stands */
+        clapgpu_scene_set_bv_points(gs->scene, transform_pos(&scene->camera->xform, NULL),
+                                    scene->control ? transform_pos(&scene->control->xform, NULL) : NULL, CLAPGPU_NO_ENTITY);
+    else
+        clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);
 
     const double t0 = now_ms();
     /*
@@ -2076,6 +2097,31 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         }
     }
 
+    /* the lists the second half of the frame goes by, in list order -- from the records: the classes are settled */
+    for (uint32_t k = 0; k < gs->n_order; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (r->cls == 1) { gs->n_batched++; continue; }
+        if (r->cls == 4) { gs->n_batched++; if (push_u32(&gs->att_list, &gs->n_att, &gs->cap_att, gs->order[k])) return _CERR_NOMEM; }
+        else if (r->cls == 3) { if (push_u32(&gs->deferred, &gs->n_deferred, &gs->cap_deferred, gs->order[k])) return _CERR_NOMEM; }
+        else if (push_u32(&gs->host_list, &gs->n_host, &gs->cap_host, gs->order[k])) return _CERR_NOMEM;
+    }
+    /* host-class children that precede their BATCHED parent in the list (see lag_parent above) */
+    gs->n_lag = 0;
+    for (uint32_t k = 0; k < gs->n_host; k++) {
+        struct gs_rec *r = &gs->rec[gs->host_list[k]];
+        r->lag = 0;
+        if (!r->e->parent) continue;
+        const uint32_t pr = rec_find(gs, r->e->parent);
+        if (pr == NO_REC || gs->rec[pr].gen != gs->gen || gs->rec[pr].cls != 1 || gs->rec[pr].order_pos < r->order_pos) continue;
+        if (push_u32(&gs->lag_parent, &gs->n_lag, &gs->cap_lag, pr)) return _CERR_NOMEM;
+        r->lag = gs->n_lag;
+    }
+    if (gs->n_lag) {
+        struct lag_keep *lk = realloc(gs->lag_keep, (size_t)gs->cap_lag * sizeof(*lk));
+        if (!lk) return _CERR_NOMEM;
+        gs->lag_keep = lk;
+    }
+
     const double t2 = now_ms();
     /* 4: the device */
     const uint32_t layout_before = clapgpu_scene_layout_generation(gs->scene);
@@ -2092,7 +2138,9 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         memset(&res, 0, sizeof(res));
     gs->res = res;
 
+    bool shown_stands = true;                                    /* shown[] of the last frames still describes this layout's slots */
     if (gs->scatter_drawn && gs->notify && res.n_slots) {        /* the counters GPU_SCATTER_DRAWN keeps per slot, for this layout */
+        shown_stands = !st->retiled && gs->shown && gs->cap_pend >= res.n_slots;
         if (res.n_slots > gs->cap_pend) {
             uint16_t *pn = realloc(gs->pend, (size_t)res.n_slots * sizeof(*pn));
             if (pn) gs->pend = pn;
@@ -2104,11 +2152,19 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             gs->shown = malloc((size_t)gs->cap_pend * sizeof(*gs->shown));
             if (!gs->shown) return _CERR_NOMEM;
         }
-        memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));
-        memset(gs->shown, 0, (size_t)gs->cap_pend * sizeof(*gs->shown));
+        memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));   /* (every counter was consumed with the walk's fetch) */
+        if (!shown_stands) memset(gs->shown, 0, (size_t)gs->cap_pend * sizeof(*gs->shown));
     }
     const double t3 = now_ms();
-    /* 5: results and host hooks, list order */
+    if (!st->retiled && gs->walked && shown_stands && res.n_slots) {
+        /* 5, the layout stood: the device's masks say what was rebuilt and which boxes hold the camera -- the second half of
+         * a notified frame (frame_results), on the workers where there is much to write back */
+        const int rc = frame_results(gs, mq, &res, t0, t2, t3);
+        if (rc) return rc;
+        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
+    } else {
+    /* 5, after a re-tile (the device rebuilt EVERYTHING; the host fields say what the reference would have): results and
+     * host hooks, list order */
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
         e = r->e;
@@ -2125,25 +2181,18 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         }
         if (r->cls == 4) {                                       /* after the pose, from the second launch: gpu_scene_run_deferred() */
             st->batched++;
-            gs->n_batched++;
             if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
                 r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
             seq_shown(gs, r->slot, e->seq);
-            if (push_u32(&gs->att_list, &gs->n_att, &gs->cap_att, gs->order[k])) return _CERR_NOMEM;
             continue;
         }
         if (r->cls != 1) {
             st->host++;
-            if (r->cls == 3) {                                   /* after the pose: gpu_scene_run_deferred() */
-                if (push_u32(&gs->deferred, &gs->n_deferred, &gs->cap_deferred, gs->order[k])) return _CERR_NOMEM;
-                continue;
-            }
+            if (r->cls == 3) continue;                           /* after the pose: gpu_scene_run_deferred() */
             entity3d_update(e, mq->priv);
-            if (gs->notify && push_u32(&gs->host_list, &gs->n_host, &gs->cap_host, gs->order[k])) return _CERR_NOMEM;
             continue;
         }
         st->batched++;
-        gs->n_batched++;
         if (st->retiled || r->slot == CLAPGPU_NO_ENTITY)
             r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
         entity3d *parent = e->parent;
@@ -2168,6 +2217,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             bv_pick(scene, e);
     }
     st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1; st->ms_device = t3 - t2; st->ms_scatter = now_ms() - t3;
+    }
     if (gs->n_order > gs->cap_vq) {
         const uint32_t cap = gs->cap_order;
         entity3d **ve = realloc(gs->vq_e, (size_t)cap * sizeof(*ve));
@@ -2204,22 +2254,6 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             const uint8_t keep = r->user_keep || r->host_child || r->keep_auto || (scene && r->e == scene->control);   /* (the records alone: keep_auto was taken while the entity was at hand) */
             if (keep != r->keep && !clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
         }
-    }
-    /* host-class children that precede their BATCHED parent in the list (see lag_parent above) */
-    gs->n_lag = 0;
-    for (uint32_t k = 0; k < gs->n_host; k++) {
-        struct gs_rec *r = &gs->rec[gs->host_list[k]];
-        r->lag = 0;
-        if (!r->e->parent) continue;
-        const uint32_t pr = rec_find(gs, r->e->parent);
-        if (pr == NO_REC || gs->rec[pr].gen != gs->gen || gs->rec[pr].cls != 1 || gs->rec[pr].order_pos < r->order_pos) continue;
-        if (push_u32(&gs->lag_parent, &gs->n_lag, &gs->cap_lag, pr)) return _CERR_NOMEM;
-        r->lag = gs->n_lag;
-    }
-    if (gs->n_lag) {
-        struct lag_keep *lk = realloc(gs->lag_keep, (size_t)gs->cap_lag * sizeof(*lk));
-        if (!lk) return _CERR_NOMEM;
-        gs->lag_keep = lk;
     }
     gs->walked = true;
     return 0;
