@@ -82,6 +82,7 @@ struct gs_rec {
                                    still has to rebuild it (its children follow its seq), the host fields are already final */
     uint8_t     gone;           /* gpu_scene_entity_deleting() named this entity and it was not taken out in place: whatever the next walk
                                    meets at this address is ANOTHER entity (malloc hands a freed entity3d's memory to the next one) */
+    uint8_t     rides, animated; /* e->parent_joint names a joint / entity_animated(e), as the last walk saw them (inputs of its class) */
     uint8_t     keep_auto;      /* a standing host reader the walk can see on the entity itself (light carrier, hook half of its own, animated, joint rider) */
     uint8_t     keep, user_keep, host_child;   /* GPU_SCATTER_DRAWN: written back whenever rebuilt (as the mirror holds it) / asked for by
                                    gpu_scene_keep() / a host-class child reads this entity's mx and seq (last walk) */
@@ -165,7 +166,8 @@ struct gpu_scene {
     /* creation / deletion without a walk (gpu_scene_entity_created / _deleting) */
     entity3d        **created; uint32_t n_created, cap_created;    /* reported since the last update, in creation order */
     uint32_t        *dead_recs; uint32_t n_dead_recs, cap_dead_recs;   /* records of entities taken out in place: tombstones in order[] until the next walk */
-    struct gs_wtxm { const model3dtx *txm; uint32_t next; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
+    struct gs_wtxm { const model3dtx *txm; uint32_t next, first; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
+    bool            replay;                                        /* frames without notifications may go by the records (queue_unchanged) */
     bool            incremental, roomy;                            /* allowed; the mirror's re-tiles leave room (from the first entity that came or went between frames) */
     bool            appended;                                      /* order[] is no longer in list order: entities were taken in since the last walk */
     uint32_t        ftab_count;
@@ -277,6 +279,8 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     gs->scatter_drawn = sp && !strcmp(sp, "drawn");
     const char *ip = getenv("GPU_SCENE_INCREMENTAL");
     gs->incremental = !(ip && !strcmp(ip, "0"));
+    const char *rp = getenv("GPU_SCENE_REPLAY");
+    gs->replay = !(rp && !strcmp(rp, "0"));
     gpu_scene_pool_ref();
     *out = gs;
     return 0;
@@ -1028,7 +1032,7 @@ static int take_created(struct gpu_scene *gs, struct mq *mq)
             r->model = e->txmodel->model;
             r->parent_e = e->parent; r->parent_rec = pi;
             r->gen = gs->gen;
-            r->cls = 2; r->self_ok = selfb;
+            r->cls = 2; r->self_ok = selfb; r->animated = entity_animated(e);
             r->order_key = key;
             r->order_pos = gs->n_order;
             gs->order[gs->n_order++] = i;
@@ -1478,6 +1482,16 @@ void gpu_scene_par_for(void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32
 
 static bool self_batchable(const struct gpu_scene *gs, entity3d *e);
 
+/* What a walk would decide an entity's class from, against what the last walk saw: its own criteria (hook, flags, animation:
+ * self_ok; a plain entity that is host-class only because of where its parent stands in the list -- cls 2, self_ok 1 -- may be
+ * touched without forcing a walk), its parent, whether it rides a joint, its model; a batched one must still be on the device */
+static inline bool class_inputs_changed(const struct gpu_scene *gs, const struct gs_rec *r, entity3d *e)
+{
+    return !entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
+           (e->parent && e->parent_joint != JOINT_TYPE_MAX) != (bool)r->rides || entity_animated(e) != (bool)r->animated ||
+           ((r->cls == 1 || r->cls == 4) && (r->model != e->txmodel->model || r->handle == CLAPGPU_NO_ENTITY));
+}
+
 static void *par_mirror(void *arg)
 {
     struct par_job *j = arg;
@@ -1492,19 +1506,20 @@ static void *par_mirror(void *arg)
         r->xform_dirty = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
-        /* the entity's OWN criteria as the last walk saw them (self_ok): a plain entity that is host-class only because of
-         * where its parent stands in the list (cls 2, self_ok 1) may be touched without forcing a walk */
-        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
-            ((r->cls == 1 || r->cls == 4) && (r->model != e->txmodel->model || r->handle == CLAPGPU_NO_ENTITY))) {
+        if (class_inputs_changed(gs, r, e)) {
             j->need_walk = 1;
             continue;
         }
         if (r->cls != 1 && r->cls != 4) continue;
+        if (e->force_lod != r->lod_force || e->cur_lod != r->lod_cur)   /* entity3d_set_lod since (model.c:593-609): after the join, on one thread */
+            if (push_u32(&j->deferred, &j->n_deferred, &j->cap_deferred, gs->touched[k])) j->rc = _CERR_NOMEM;
         const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
+        const bool same_flags = flags == r->flags;
         r->flags = flags;
         if (gs->vq_ok && r->order_pos < gs->n_order) gs->vq_ok[r->order_pos] = verdict_ok(r);
         r->xform_dirty = transform_is_updated(&e->xform);
         if (r->host_done && r->xform_dirty) r->host_done = 2;
+        if (!r->xform_dirty && !r->host_done && same_flags) continue;   /* (a frame that looks at EVERY record: most have nothing to say) */
         if (gs->drawn_now && r->xform_dirty) transform_clear_updated(&e->xform);
         const int rc = clapgpu_scene_entity_transform_mt(gs->scene, r->handle, transform_pos(&e->xform, NULL),
                                                          transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty || r->host_done);
@@ -1632,7 +1647,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     st->placed = gs->inc_placed; st->removed = gs->inc_removed;
     st->registered += gs->inc_placed; st->deleted += gs->inc_removed;
     gs->inc_placed = gs->inc_removed = 0;
-    clapgpu_scene_set_export(gs->scene, gs->scatter_drawn ? CLAPGPU_SCENE_EXPORT_DRAWN : CLAPGPU_SCENE_EXPORT_ALL);
+    clapgpu_scene_set_export(gs->scene, gs->scatter_drawn && gs->notify ? CLAPGPU_SCENE_EXPORT_DRAWN : CLAPGPU_SCENE_EXPORT_ALL);   /* (the policy lives on notifications: gpu-scene.h) */
     gs->drawn_now = clapgpu_scene_export_is_drawn(gs->scene);
     if (gs->drawn_now && scene && scene->control != gs->last_control) {
         /* the control entity is read every frame (camera target, camera.c:191-205; the bounding-volume pick): a standing reader */
@@ -1651,8 +1666,23 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
             jobs[t] = (struct par_job){ .gs = gs, .lo = (uint32_t)((uint64_t)gs->n_touched * t / nt),
                                         .hi = (uint32_t)((uint64_t)gs->n_touched * (t + 1) / nt) };
         par_run(par_mirror, jobs, nt);
-        int need_walk = 0;
-        for (int t = 0; t < nt; t++) { need_walk |= jobs[t].need_walk; st->uploaded += jobs[t].count; if (jobs[t].rc) return jobs[t].rc; }
+        int need_walk = 0, prc = 0;
+        for (int t = 0; t < nt; t++) {
+            need_walk |= jobs[t].need_walk; st->uploaded += jobs[t].count;
+            if (jobs[t].rc) prc = jobs[t].rc;
+            for (uint32_t d = 0; d < jobs[t].n_deferred && !prc; d++) {          /* LODs set since: the mirror's copy follows */
+                struct gs_rec *r = &gs->rec[jobs[t].deferred[d]];
+                if (!r->e || r->handle == CLAPGPU_NO_ENTITY) continue;
+                prc = clapgpu_scene_entity_lod(gs->scene, r->handle, r->e->force_lod, r->e->cur_lod);
+                r->lod_force = r->e->force_lod; r->lod_cur = r->e->cur_lod;
+                if (r->slot < gs->cap_slot_arrays) {
+                    if (r->lod_cur >= -128 && r->lod_cur <= 127) gs->slot_lod[r->slot] = (int8_t)r->lod_cur;
+                    else gs->cap_slot_arrays = 0;
+                }
+            }
+            free(jobs[t].deferred); jobs[t].deferred = NULL; jobs[t].n_deferred = jobs[t].cap_deferred = 0;
+        }
+        if (prc) return prc;
         clapgpu_scene_mark_all_dirty(gs->scene);
         if (need_walk) {
             if (gs->drawn_now)                                   /* the walk decides by xform.updated: give back what this pass cleared */
@@ -1670,8 +1700,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         r->xform_dirty = 0;
         if (!r->e) continue;
         entity3d *e = r->e;
-        if (!entity3d_matches(e, ENTITY3D_ALIVE) || self_batchable(gs, e) != (bool)r->self_ok || e->parent != r->parent_e ||
-            ((r->cls == 1 || r->cls == 4) && r->model != e->txmodel->model)) {
+        if (class_inputs_changed(gs, r, e)) {
             if (gs->drawn_now)                                   /* the walk decides by xform.updated: give back what this pass cleared */
                 for (uint32_t j = 0; j < k; j++) {
                     struct gs_rec *q = &gs->rec[gs->touched[j]];
@@ -1895,6 +1924,52 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
     return 0;
 }
 
+/*
+ * Frames WITHOUT notifications.  Nothing tells the binding what changed, so the reference's way is to look at every entity --
+ * but not necessarily by chasing the lists on one core: if the queue is still the one the last walk met (every entity's list
+ * successor is the next record's entity, every txmodel's list starts and ends where it did: checked on the workers, one
+ * list node per entity) the frame goes by the records -- every record "touched", the mirror pass on the workers re-reading
+ * what a walk would read (flags, xform.updated, the inputs of the entity's class, its LODs) -- and falls back to the walk
+ * the moment anything a walk would have classified differently shows up.  1 M entities: 72 ms of list walk -> a few ms.
+ */
+struct quc_ctx { struct gpu_scene *gs; int changed; };
+static void queue_unchanged_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct quc_ctx *qc = ctx;
+    struct gpu_scene *gs = qc->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (k + 8 < hi) __builtin_prefetch(&gs->rec[gs->order[k + 8]].e->entry, 0, 1);
+        const uint32_t rank = (uint32_t)(r->order_key >> 32);
+        const struct list *head = &gs->wtxm[rank].txm->entities;
+        const struct list *n = r->e->entry.next;                 /* the next ALIVE entity behind it in its txmodel's list */
+        while (n != head && !entity3d_matches(list_entry((struct list *)n, entity3d, entry), ENTITY3D_ALIVE)) n = n->next;
+        const entity3d *want = (k + 1 < gs->n_order && (uint32_t)(gs->rec[gs->order[k + 1]].order_key >> 32) == rank)
+                               ? gs->rec[gs->order[k + 1]].e : NULL;
+        const entity3d *got = n == head ? NULL : list_entry((struct list *)n, entity3d, entry);
+        if (got != want) { __atomic_store_n(&qc->changed, 1, __ATOMIC_RELAXED); return; }
+    }
+}
+
+static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
+{
+    uint32_t t = 0;
+    model3dtx *txm;
+    list_for_each_entry(txm, &mq->txmodels, entry) {             /* the txmodels, and where each one's list starts */
+        if (t >= gs->n_wtxm || gs->wtxm[t].txm != txm) return false;
+        const struct list *head = &txm->entities, *n = head->next;
+        while (n != head && !entity3d_matches(list_entry((struct list *)n, entity3d, entry), ENTITY3D_ALIVE)) n = n->next;
+        const entity3d *first = n == head ? NULL : list_entry((struct list *)n, entity3d, entry);
+        const entity3d *want = gs->wtxm[t].next ? gs->rec[gs->order[gs->wtxm[t].first]].e : NULL;
+        if (first != want) return false;
+        t++;
+    }
+    if (t != gs->n_wtxm) return false;
+    struct quc_ctx qc = { gs, 0 };
+    gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, gs->n_order >= GS_PAR_MIN ? par_threads() : 1);
+    return !qc.changed;
+}
+
 int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
     if (!gs || !mq) return _CERR_INVALID_ARGUMENTS;
@@ -1912,6 +1987,21 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (rc <= 0) return rc;
         gs->gen++;
         memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
+    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order && !gs->n_touched && queue_unchanged(gs, mq)) {
+        /* no notifications, and the queue is the one the last walk met: the frame by the records (see queue_unchanged) */
+        if (gs->n_order > gs->cap_touched) {
+            uint32_t *q = realloc(gs->touched, (size_t)gs->cap_order * sizeof(*q));
+            if (!q) return _CERR_NOMEM;
+            gs->touched = q; gs->cap_touched = gs->cap_order;
+        }
+        memcpy(gs->touched, gs->order, (size_t)gs->n_order * sizeof(*gs->touched));
+        gs->n_touched = gs->n_order;
+        gs->gen--;
+        const int rc = fast_frame(gs, mq, view);
+        gs->last_fast = false;                                    /* (the word is kept for frames that looked at what was reported only) */
+        if (rc <= 0) { st->replayed = rc == 0; return rc; }
+        gs->gen++;
+        memset(st, 0, sizeof(*st));                               /* an entity would be classified differently now: walk */
     }
     /* a walked frame writes everything back, and it may re-tile: whatever GPU_SCATTER_DRAWN left on the device comes over
      * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's.  The rows
@@ -1976,7 +2066,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             gs->wtxm = q; gs->cap_wtxm = cap;
         }
         const uint32_t rank = gs->n_wtxm++;
-        gs->wtxm[rank] = (struct gs_wtxm){ txm, 0 };
+        gs->wtxm[rank] = (struct gs_wtxm){ txm, 0, gs->n_order };
         list_for_each_entry_iter(e, it, &txm->entities, entry) {
             if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
             uint32_t i;
@@ -2019,6 +2109,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
             gs->order[gs->n_order++] = i;
             r->self_ok = self_batchable(gs, e);
             const bool rides_joint = e->parent && e->parent_joint != JOINT_TYPE_MAX;
+            r->rides = rides_joint; r->animated = entity_animated(e);
             if (!r->self_ok) {
                 r->cls = 2;
                 r->parent_e = e->parent; r->parent_rec = NO_REC;

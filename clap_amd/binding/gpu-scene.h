@@ -33,6 +33,9 @@ struct gpu_scene_stats {
     unsigned int untouched_writes;  /* verification mode: batched entities found with xform.updated set that nobody had
                                        reported (a direct transform_* write without gpu_scene_touch) -- taken in this frame */
     unsigned int registered, deleted;
+    int          replayed;      /* without notifications: the queue was found to be the one the last walk met (same entities, same
+                                   order, same classes), so the frame went by the records -- every pass on the worker threads --
+                                   instead of walking the lists */
     unsigned int placed, removed;   /* of those: entities created / deleted since the last frame that were put into / taken out of the
                                    standing device layout, without a walk of the queue (gpu_scene_entity_created / _deleting) */
     int          retiled;       /* the device layout was rebuilt (creation, deletion, re-parenting) */
@@ -148,6 +151,12 @@ unsigned gpu_scene_device_errors(void);
  * next update then walks the queue once, as without notifications.
  */
 void gpu_scene_set_notify(struct gpu_scene *gs, bool on);
+/* Without notifications a frame still need not chase the lists on one core: when the queue is found to be the one the last
+ * walk met -- every entity's list successor is the next record's entity: one list node per entity, read on the worker
+ * threads -- the frame goes by the records (every entity's flags, xform.updated, class inputs and LODs re-read on the
+ * workers) and falls back to the walk when anything would be classified differently.  The check reads the entities the
+ * last walk met: one that was FREED since must have been reported (the exported entity3d_delete / the line in entity3d_drop
+ * do that; gpu_scene_topology() is enough).  Environment GPU_SCENE_REPLAY=0 keeps the serial walk for every frame. */
 bool gpu_scene_last_was_fast(const struct gpu_scene *gs);      /* the last gpu_mq_update() did not walk the queue */
 void gpu_scene_touch(struct gpu_scene *gs, entity3d *e);
 /* ... its transform alone (what entity3d_position / _move / _rotate / _scale change): O(1), no look-up -- the address is

@@ -567,7 +567,7 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
     B.scene->control = B.e[0];
 
     uint64_t bad = 0, visible = 0, batched = 0, host = 0, written = 0, retiles = 0, fast_frames = 0, fetched = 0, left_stale = 0;
-    uint64_t placed = 0, removed = 0;
+    uint64_t placed = 0, removed = 0, replayed = 0;
     gpu_scene_set_notify(gs, opt_notify);
     gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
@@ -589,6 +589,7 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
         batched += st->batched; host += st->host; written += st->written_back; retiles += st->retiled;
         fetched += st->fetched; left_stale += st->left_stale;
         placed += st->placed; removed += st->removed;
+        replayed += st->replayed;
         fast_frames += gpu_scene_last_was_fast(gs);
         if (getenv("DROPIN_TRACE")) {                                    /* one entity's counters after every frame, before any fetch */
             const uint32_t id = (uint32_t)atoi(getenv("DROPIN_TRACE"));
@@ -611,12 +612,12 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
            "\"batched_updates\": %llu, \"host_updates\": %llu, \"written_back\": %llu, \"retiles\": %llu, "
            "\"visible_verdicts_true\": %llu, \"notify\": %s, \"fast_frames\": %llu, \"entity3d_update_calls\": %llu, "
            "\"scatter\": \"%s\", \"left_stale\": %llu, \"fetched_on_view\": %llu, \"stale_seen_by_checker\": %llu, \"partial_compare_frames\": %llu, "
-           "\"placed_in_layout\": %llu, \"removed_in_place\": %llu, \"mismatches\": %llu}\n",
+           "\"placed_in_layout\": %llu, \"removed_in_place\": %llu, \"frames_by_the_records\": %llu, \"mismatches\": %llu}\n",
            frames, n_ids, alive, (unsigned long long)batched, (unsigned long long)host,
            (unsigned long long)written, (unsigned long long)retiles, (unsigned long long)visible,
            opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates,
            opt_drawn ? "drawn" : "all", (unsigned long long)left_stale, (unsigned long long)fetched, (unsigned long long)n_stale_seen,
-           (unsigned long long)n_partial_frames, (unsigned long long)placed, (unsigned long long)removed, (unsigned long long)bad);
+           (unsigned long long)n_partial_frames, (unsigned long long)placed, (unsigned long long)removed, (unsigned long long)replayed, (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -970,7 +971,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     double t_ref = 0, t_gpu = 0, t_ref_upd = 0, t_gpu_upd = 0, t_step[4] = { 0, 0, 0, 0 };
     double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0;
     uint64_t vis_a = 0, vis_b = 0, drawn_a = 0, drawn_b = 0, drawn_l = 0, acc_a = 0, acc_b = 0, acc_l = 0, left_stale = 0, fetched = 0;
-    uint64_t bad = 0, n_fast = 0, n_retiled = 0, n_placed = 0, n_removed = 0;
+    uint64_t bad = 0, n_fast = 0, n_retiled = 0, n_placed = 0, n_removed = 0, n_replayed = 0;
     for (uint32_t f = 0; f < frames + 2; f++) {                          /* two untimed warm-up frames */
         /* the game's own writes: the same numbers to both worlds (world B through the engine's names, i.e. with the
          * notification) -- timed apart, since the notification is a cost the binding adds to the mutators */
@@ -1054,6 +1055,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
             drawn_a += na; drawn_b += nb; drawn_l += nl; acc_a += aa; acc_b += ab; acc_l += al;
             left_stale += st->left_stale; fetched += st->fetched;
             n_fast += gpu_scene_last_was_fast(gs); n_retiled += st->retiled; n_placed += st->placed; n_removed += st->removed;
+            n_replayed += st->replayed;
             t_step[0] += st->ms_walk; t_step[1] += st->ms_mirror; t_step[2] += st->ms_device; t_step[3] += st->ms_scatter;
         }
     }
@@ -1072,7 +1074,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"reference_frame_ms\": %.4f, \"binding_frame_block_ms\": %.4f, \"binding_frame_draw_list_ms\": %.4f, "
            "\"drawn_per_frame\": %.1f, \"draw_sets_equal\": %s, \"draw_reads_equal\": %s, "
            "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, \"churn_per_frame\": %u, "
-           "\"fast_frames\": %llu, \"retiles\": %llu, \"placed_in_layout\": %llu, \"removed_in_place\": %llu, "
+           "\"fast_frames\": %llu, \"frames_by_the_records\": %llu, \"retiles\": %llu, \"placed_in_layout\": %llu, \"removed_in_place\": %llu, "
            "\"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
            "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
@@ -1081,7 +1083,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            1e3 * (t_ref_mut + t_ref_upd + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_list) / F,
            drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
            opt_drawn ? "drawn" : "all", left_stale / F, fetched / F, opt_churn,
-           (unsigned long long)n_fast, (unsigned long long)n_retiled, (unsigned long long)n_placed, (unsigned long long)n_removed,
+           (unsigned long long)n_fast, (unsigned long long)n_replayed, (unsigned long long)n_retiled, (unsigned long long)n_placed, (unsigned long long)n_removed,
            opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;

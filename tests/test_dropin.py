@@ -51,10 +51,10 @@ def test_dropin_checker_is_built_where_the_reference_is():
         assert fn in names and "ref_" + fn in names, fn
 
 
-def _run(*args):
+def _run(*args, env=None):
     if not os.access(BIN, os.X_OK):
         pytest.skip("oracle/_ref/clap_dropin not built (needs the reference tree at build time)")
-    p = subprocess.run([BIN, *map(str, args)], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([BIN, *map(str, args)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, f"clap_dropin {args}: rc {p.returncode}\n{p.stderr[-2000:]}"
     return json.loads(p.stdout.strip().splitlines()[-1])
 
@@ -243,6 +243,22 @@ def test_binding_bench_mode_is_consistent(mode):
         assert r["scatter"] == "drawn" and r["left_stale_per_frame"] > 0 and r["fetched_on_view_per_frame"] > 0
     else:
         assert r["left_stale_per_frame"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,frames,permille", [(3000, 30, 100), (100000, 8, 1000), (300000, 5, 100)])
+def test_frames_without_notifications_go_by_the_records(n, frames, permille):
+    """No notifications at all (the minimal patch): a frame whose queue is the one the last walk met -- checked entity by
+    entity through the list nodes, on the workers -- goes by the records instead of chasing the lists on one core, and
+    reads what a walk would read; same bits as the serial walk (GPU_SCENE_REPLAY=0), same bits as the reference."""
+    r = _run("bench", n, frames, permille)
+    assert r["mismatches"] == 0 and r["visible_equal"] is True and r["draw_sets_equal"] is True and r["draw_reads_equal"] is True
+    assert r["notify"] is False and r["fast_frames"] == 0 and r["frames_by_the_records"] == frames and r["retiles"] == 0
+    w = _run("bench", n, frames, permille, env={"GPU_SCENE_REPLAY": "0"})
+    assert w["mismatches"] == 0 and w["frames_by_the_records"] == 0 and w["drawn_per_frame"] == r["drawn_per_frame"]
+    # the scripted game without notifications: frames with creations / deletions / re-parenting walk, the others do not
+    g = _run("test", min(n, 40000), 24, 7, "steady")
+    assert g["mismatches"] == 0 and g["fast_frames"] == 0 and g["frames_by_the_records"] >= 12 and g["retiles"] > 0
 
 
 @pytest.mark.gpu

@@ -74,6 +74,8 @@ def test_binding_and_mirror_under_asan_ubsan():
     assert _run(exe, "test", 200, 40, 13, "notify", "drawn")["mismatches"] == 0
     assert _run(exe, "test", 6000, 16, 33, "notify", "drawn", "steady")["mismatches"] == 0
     assert _run(exe, "test", 1500, 10, 2)["mismatches"] == 0
+    r = _run(exe, "test", 2000, 24, 1, "steady")                # no notifications: the frames whose queue stood go by the records
+    assert r["mismatches"] == 0 and r["frames_by_the_records"] >= 12 and r["fast_frames"] == 0
     assert _run(exe, "test", 1500, 10, 3, "notify")["mismatches"] == 0
     assert _run(exe, "lod", 1500, 8, 1, "notify", "drawn", "steady")["mismatches"] == 0
     assert _run(exe, "lod", 800, 8, 2)["mismatches"] == 0
@@ -150,6 +152,9 @@ def test_worker_pool_passes_under_tsan():
     assert r["mismatches"] == 0
     r = _run(exe, "recreate", 70000, env={"GPU_SCENE_THREADS": "6"})
     assert r["mismatches"] == 0 and r["fast_frames"] > 0
+    # no notifications: the queue check and the mirror pass over EVERY record on the workers
+    r = _run(exe, "bench", 140000, 3, 1000, env={"GPU_SCENE_THREADS": "6"})
+    assert r["mismatches"] == 0 and r["frames_by_the_records"] == 3
     # ... with entities made and deleted between the frames: tombstone records and appended ones under the split passes
     r = _run(exe, "bench", 140000, 3, 1000, "notify", "drawn", "churn", 50, env={"GPU_SCENE_THREADS": "6"})
     assert r["mismatches"] == 0 and r["fast_frames"] == 3 and r["placed_in_layout"] > 100
