@@ -305,6 +305,17 @@ def dropin_boundary():
             out[key]["policy"] = "GPU_SCATTER_DRAWN"
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
+    # NO notifications (the minimal patch): the queue is verified against the last walk's records on the workers and the frame
+    # goes by the records; round 4 walked every entity3d twice on one core (1 M: 111 ms)
+    try:
+        p = subprocess.run([exe, "bench", "1000000", "5", "100"], capture_output=True, text=True, timeout=240)
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        out["1000000_entities_10pct_dirty_no_notifications"] = {
+            **{k: r[k] for k in ("reference_mq_update_ms", "binding_mq_update_ms", "binding_ms", "reference_frame_ms",
+                                 "binding_frame_draw_list_ms", "frames_by_the_records", "retiles")},
+            "identical": (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"])}
+    except Exception as e:
+        out["1000000_entities_10pct_dirty_no_notifications"] = {"error": repr(e)[:200]}
     # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
     # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
     # (10 x 64 over 400 frames: the testbed's own scale, core/clap.c's demo scenes -- three device round trips a frame)
@@ -730,7 +741,7 @@ def full_frame(device):
 
 
 def summary(out, extra):
-    """<= 14 scalars: what the long `extra` / `cpu_baseline` sections say, where a record that keeps only the head of the
+    """<= 15 scalars: what the long `extra` / `cpu_baseline` sections say, where a record that keeps only the head of the
     line (or drops `extra`) still has them.  Microseconds per launch unless the key says otherwise."""
     s = {}
 
@@ -759,6 +770,8 @@ def summary(out, extra):
     c = ((out.get("cpu_baseline") or {}).get("dropin_boundary") or {}).get("1000000_entities_10pct_dirty_10_made_10_deleted_a_frame") or {}
     put("boundary_1m_churn_mq_update_ms", lambda: c["binding_mq_update_ms"])
     put("boundary_1m_churn_reference_mq_update_ms", lambda: c["reference_mq_update_ms"])
+    w = ((out.get("cpu_baseline") or {}).get("dropin_boundary") or {}).get("1000000_entities_10pct_dirty_no_notifications") or {}
+    put("boundary_1m_no_notify_mq_update_ms", lambda: w["binding_mq_update_ms"])
     return s
 
 
