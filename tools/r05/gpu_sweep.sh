@@ -5,7 +5,7 @@ bad=0; n=0
 : > $O/gpu_sweep.log
 for seed in $(seq 300 339); do
   for cfg in "200 50" "1500 20" "12000 10"; do
-    for pol in "notify drawn comeandgo plain" "notify comeandgo" "notify drawn comeandgo" "notify drawn steady" ""; do
+    for pol in "notify drawn comeandgo plain" "notify comeandgo" "notify drawn comeandgo" "notify drawn steady" "" "steady" "comeandgo plain"; do
       set -- $cfg
       out=$(timeout -k 10 120 $D test $1 $2 $seed $pol 2>$O/gpu_sweep_err.txt | tail -1)
       n=$((n+1))
