@@ -1966,7 +1966,9 @@ static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
     }
     if (t != gs->n_wtxm) return false;
     struct quc_ctx qc = { gs, 0 };
+    const double q0 = getenv("GPU_SCENE_TIMING") ? now_ms() : 0;
     gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, gs->n_order >= GS_PAR_MIN ? par_threads() : 1);
+    if (q0 != 0) fprintf(stderr, "queue_unchanged: %u entities in %.3f ms (%s)\n", gs->n_order, now_ms() - q0, qc.changed ? "changed" : "the same");
     return !qc.changed;
 }
 
