@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 OK = 0
 ERR_NOMEM = -1

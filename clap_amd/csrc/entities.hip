@@ -602,6 +602,7 @@ struct ExportK {
     const float *mx, *inv_mx, *aabb, *center;            // device (the update's outputs)
     const uint64_t *vis_mask, *rebuilt_mask, *inside_mask;
     const uint64_t *select;                              // clapgpu_entities_export_rows: these rows, and no masks
+    uint64_t *stale;                                     // ... whose stale bits (clapgpu_entities_hostio.stale_mask) are cleared
     float *o_mx, *o_inv, *o_aabb, *o_center;             // device-mapped host memory
     uint64_t *o_vis, *o_rebuilt, *o_inside;
     uint32_t *counter, *done, done_value, n_rows;
@@ -614,6 +615,7 @@ void k_entities_export_rebuilt(ExportK x)
     const uint32_t row = blockIdx.x * (ENT_BLOCK / WAVE) + threadIdx.x / WAVE;
     if (row < x.n_rows) {
         const uint64_t m = x.select ? x.select[row] : x.rebuilt_mask[row];
+        if (lane == 0 && x.select && x.stale && m) x.stale[row] &= ~m;
         if (lane == 0 && !x.select) {
             x.o_rebuilt[row] = m;
             if (x.vis_mask) x.o_vis[row] = x.vis_mask[row];
@@ -898,7 +900,7 @@ extern "C" int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entit
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     ExportK k;
     k.mx = e->mx; k.inv_mx = e->inv_mx; k.aabb = e->aabb; k.center = e->center;
-    k.vis_mask = e->vis_mask; k.rebuilt_mask = e->rebuilt_mask; k.select = nullptr;
+    k.vis_mask = e->vis_mask; k.rebuilt_mask = e->rebuilt_mask; k.select = nullptr; k.stale = nullptr;
     k.inside_mask = (e->bv && e->bv->inside_mask) ? e->bv->inside_mask : nullptr;
     k.o_mx = x->mx; k.o_inv = x->inv_mx; k.o_aabb = x->aabb; k.o_center = x->center;
     k.o_vis = x->vis_mask; k.o_rebuilt = x->rebuilt_mask; k.o_inside = x->inside_mask;
@@ -920,7 +922,7 @@ extern "C" int clapgpu_entities_export_rows(void *stream, const clapgpu_entities
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     ExportK k = {};
     k.mx = e->mx; k.inv_mx = e->inv_mx; k.aabb = e->aabb; k.center = e->center;
-    k.select = select_mask;
+    k.select = select_mask; k.stale = x->stale_mask;
     k.o_mx = x->mx; k.o_inv = x->inv_mx; k.o_aabb = x->aabb; k.o_center = x->center;
     k.counter = x->counter; k.done = x->done; k.done_value = x->done_value; k.n_rows = e->n / 64;
     const uint32_t per_block = ENT_BLOCK / WAVE;
@@ -954,7 +956,8 @@ extern "C" int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_
     h.o_mx = io->mx; h.o_inv = io->inv_mx; h.o_aabb = io->aabb; h.o_center = io->center;
     h.o_vis = io->vis_mask; h.o_rebuilt = io->rebuilt_mask; h.o_inside = io->inside_mask;
     h.counter = io->counter; h.done = io->done; h.done_value = io->done_value;
-    h.keep = io->keep_mask; h.o_exported = io->exported_mask;
+    h.keep = io->keep_mask; h.o_exported = io->exported_mask; h.stale = io->stale_mask;
+    h.late_ok = io->options & CLAPGPU_HOSTIO_EXPORT_STALE_READ;
     const uint32_t tiles = e->n ? n_tiles : 0;
     rc = launch_entities_tiles_host(as_stream(stream), frustum != nullptr, fr, k, h, tile_row_start, tiles, e->n, mode);
     if (rc) return rc;

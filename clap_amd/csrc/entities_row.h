@@ -84,6 +84,8 @@ struct HostIO {
     const float4   *pos_scale, *rot;                     // device-mapped host image of the inputs (slot order)
     const uint32_t *flags;
     const uint64_t *touched;                             // mapped: one bit per slot the host rewrote for this frame; NULL: none
+    uint64_t *stale;                                     // device: rows the host holds an older copy of (kept here); NULL: not tracked
+    uint32_t late_ok;                                    // CLAPGPU_HOSTIO_EXPORT_STALE_READ: stale rows with a reader now are exported too
     float          *o_mx, *o_inv, *o_aabb, *o_center;    // device-mapped host result arrays
     uint64_t       *o_vis, *o_rebuilt, *o_inside;
     uint32_t       *counter, *done, done_value;
@@ -173,9 +175,11 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
     // HOST: which of this row's rebuilt lanes the mirror wants back (asked for now, used after the cull)
     uint64_t host_want = ~0ull;
     bool host_filter = false;
+    uint64_t stale_w = 0;
     if constexpr (HOST) {
         host_filter = hio->keep != nullptr;
         host_want = host_filter ? hio->keep[row_first >> 6] : ~0ull;
+        if (hio->stale) stale_w = hio->stale[row_first >> 6];   // (asked for now, used after the cull)
     }
 
     const uint32_t fl = in.fl;
@@ -399,9 +403,30 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
                 hc[0] = ctr[0]; hc[1] = ctr[1]; hc[2] = ctr[2];
             }
         }
+        // Rows the host was left an older copy of by earlier launches and that have a reader NOW (came into view, contain
+        // the camera, were flagged since): over from the device arrays in this same pass -- rare lanes, plain loads
+        const uint64_t late = hio->late_ok ? stale_w & host_want & ~rebuilt_mask & __ballot(alive) : 0ull;
+        if ((late >> lane) & 1ull) {
+            const float4 *sm = reinterpret_cast<const float4 *>(e.mx + 16 * (size_t)i);
+            const float4 *si = reinterpret_cast<const float4 *>(e.inv_mx + 16 * (size_t)i);
+            float4 *hm = reinterpret_cast<float4 *>(hio->o_mx + 16 * (size_t)i);
+            float4 *hi = reinterpret_cast<float4 *>(hio->o_inv + 16 * (size_t)i);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { hm[c] = sm[c]; hi[c] = si[c]; }
+            const float2 *sb = reinterpret_cast<const float2 *>(e.aabb + 6 * (size_t)i);
+            float2 *hb = reinterpret_cast<float2 *>(hio->o_aabb + 6 * (size_t)i);
+            hb[0] = sb[0]; hb[1] = sb[1]; hb[2] = sb[2];
+            const float *sc = e.center + 3 * (size_t)i;
+            float *hc = hio->o_center + 3 * (size_t)i;
+            hc[0] = sc[0]; hc[1] = sc[1]; hc[2] = sc[2];
+        }
         if (lane == 0) {
             hio->o_rebuilt[row_first >> 6] = rebuilt_mask;
-            if (hio->o_exported) hio->o_exported[row_first >> 6] = exported;
+            if (hio->o_exported) hio->o_exported[row_first >> 6] = exported | late;
+            if (hio->stale) {
+                const uint64_t ns = (stale_w | rebuilt_mask) & ~(exported | late);
+                if (ns != stale_w) hio->stale[row_first >> 6] = ns;
+            }
         }
     }
 }

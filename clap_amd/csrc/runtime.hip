@@ -9,9 +9,9 @@
 #include "lm_dev.h"
 
 #ifdef CLAPGPU_EXPERIMENT               // an A/B or sensitivity build (common.h): never loadable as the product
-#define CLAPGPU_ABI_VERSION (30u | 0x80000000u)
+#define CLAPGPU_ABI_VERSION (31u | 0x80000000u)
 #else
-#define CLAPGPU_ABI_VERSION 30u
+#define CLAPGPU_ABI_VERSION 31u
 #endif
 
 namespace clapgpu {

@@ -93,6 +93,9 @@ struct clapgpu_scene {
     uint64_t   *h_exported;                                            /* mapped, behind the three masks of h_out */
     uint64_t   *h_stale, *h_fetched; uint32_t n_stale_words, n_fetched, fetch_serial; /* plain host memory, cap_slots / 64 + 2 words */
     uint64_t   *h_select; void *d_select;                              /* mapped: the rows a fetch asks for */
+    int         fetch_accumulate;                                      /* fetch_rows adds to the rows this mq_update's launch already brought over */
+    uint64_t   *d_stale;                                               /* device twin of h_stale, kept by the launches themselves (clapgpu_entities_hostio.stale_mask) */
+    uint32_t   *stale_fix; uint32_t n_stale_fix, cap_stale_fix;        /* words of h_stale an in-place edit changed: the device twin follows before the next launch */
     /* the layout edited in place (clapgpu_scene_entity_new_placed / _delete_placed): a queue whose make-up changes by a few
      * entities a frame keeps its tiles; a re-tile is the fall-back */
     uint32_t    max_depth;                                             /* rows of the deepest tree at the last re-tile */
@@ -181,6 +184,7 @@ static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with
     io->inside_mask = s->bv_on ? io->rebuilt_mask + (cn / 64 + 2) : NULL;
     io->exported_mask = io->rebuilt_mask + 2 * (cn / 64 + 2);
     io->keep_mask = filtered ? s->d_keep : NULL;
+    io->stale_mask = s->d_stale;
     io->counter = s->d_counter; io->done = s->d_done; io->done_value = ++s->frame_id;
 }
 
@@ -188,13 +192,24 @@ static void scene_hostio(clapgpu_scene *s, clapgpu_entities_hostio *io, int with
 static void stale_after_launch(clapgpu_scene *s)
 {
     const size_t words = s->n_slots / 64;
-    uint32_t nz = 0;
+    uint32_t nz = 0, late_rows = 0;
+    /* fetched_mask names the rows of THIS call only (fetch_rows): here the ones the launch itself brought over although it
+     * did not rebuild them -- stale rows that have a reader now (exported, not rebuilt); exported_mask goes back to "rebuilt
+     * and written", which is what a caller scatters as this frame's rebuilds */
+    if (s->n_fetched) { memset(s->h_fetched, 0, words * 8); s->n_fetched = 0; }
     for (size_t w = 0; w < words; w++) {
-        const uint64_t st = (s->h_stale[w] | s->h_rebuilt[w]) & ~s->h_exported[w];
+        const uint64_t ex = s->h_exported[w], rb = s->h_rebuilt[w], late = ex & ~rb;
+        const uint64_t st = (s->h_stale[w] | rb) & ~ex;
         s->h_stale[w] = st;
         nz += st != 0;
+        if (late) {
+            s->h_fetched[w] = late;
+            s->h_exported[w] = ex & rb;
+            late_rows += (uint32_t)__builtin_popcountll(late);
+        }
     }
     s->n_stale_words = nz;
+    if (late_rows) { s->n_fetched = late_rows; s->fetch_serial++; }
 }
 
 static int apply_edits(clapgpu_scene *s);
@@ -205,7 +220,7 @@ static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, 
     const size_t words = s->n_slots / 64;
     /* fetched_mask names the rows of THIS call only: a caller copies them out once (fetch_serial says whether there is
      * anything new); rows of an earlier call may since have been superseded on the host */
-    if (s->n_fetched) { memset(s->h_fetched, 0, words * 8); s->n_fetched = 0; }
+    if (s->n_fetched && !s->fetch_accumulate) { memset(s->h_fetched, 0, words * 8); s->n_fetched = 0; }
     if (!s->n_stale_words || !s->h_select) return CLAPGPU_OK;
     uint32_t cnt = 0;
     for (size_t w = 0; w < words; w++) {
@@ -221,16 +236,17 @@ static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, 
     clapgpu_entities_export x = { .mx = (float *)mo, .inv_mx = (float *)(mo + cn * 64), .aabb = (float *)(mo + cn * 128),
                                   .center = (float *)(mo + cn * 152) };
     x.counter = s->d_counter; x.done = s->d_done; x.done_value = ++s->frame_id;
+    x.stale_mask = s->d_stale;
     CK(clapgpu_entities_export_rows(NULL, &s->d, &x, s->d_select));
     CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
     uint32_t nz = 0;
     for (size_t w = 0; w < words; w++) {
-        s->h_fetched[w] = s->h_select[w];
+        s->h_fetched[w] = s->fetch_accumulate ? (s->h_fetched[w] | s->h_select[w]) : s->h_select[w];
         s->h_stale[w] &= ~s->h_select[w];
         nz += s->h_stale[w] != 0;
     }
     s->n_stale_words = nz;
-    s->n_fetched = cnt;
+    s->n_fetched = s->fetch_accumulate ? s->n_fetched + cnt : cnt;
     s->fetch_serial++;
     return CLAPGPU_OK;
 }
@@ -309,6 +325,8 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     if (s->h_select) clapgpu_host_free(s->h_select);
     free(s->h_keep); free(s->h_stale); free(s->h_fetched); free(s->free_roots); free(s->raw_words); free(s->edits); free(s->limbo);
     if (s->h_place) clapgpu_host_free(s->h_place);
+    if (s->d_stale) clapgpu_free(s->d_stale);
+    free(s->stale_fix);
     free(s);
 }
 
@@ -531,6 +549,9 @@ static int append_tile(clapgpu_scene *s)
 /* parent / model indices of the edited slots, and appended tiles, to the device: before anything is launched on the layout */
 static int apply_edits(clapgpu_scene *s)
 {
+    for (uint32_t k = 0; k < s->n_stale_fix; k++)        /* (rare: the lane's last tenant had been left stale) */
+        CK(clapgpu_memcpy_h2d(s->d_stale + s->stale_fix[k], s->h_stale + s->stale_fix[k], 8, NULL));
+    if (s->n_stale_fix) { CK(clapgpu_stream_sync(NULL)); s->n_stale_fix = 0; }   /* h_stale is pageable and changes with the next launch */
     if (s->grown_from == CLAPGPU_NO_ENTITY && !s->n_edits) return CLAPGPU_OK;
     if (s->grown_from != CLAPGPU_NO_ENTITY) {
         const size_t a = s->grown_from, cnt = s->n_slots - a;
@@ -617,7 +638,11 @@ int clapgpu_scene_entity_new_placed(clapgpu_scene *s, uint32_t model, void *user
     memcpy(&skip_bits, &s->models[8 * (size_t)model + 3], 4);
     s->edits[s->n_edits++] = slot | (skip_bits ? 0x80000000u : 0);
     const uint64_t bit = 1ull << (slot & 63);
-    if (s->h_stale[slot >> 6] & bit) { s->h_stale[slot >> 6] &= ~bit; if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--; }
+    if (s->h_stale[slot >> 6] & bit) {
+        s->h_stale[slot >> 6] &= ~bit;
+        if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--;
+        if (push_list(&s->stale_fix, &s->n_stale_fix, &s->cap_stale_fix, slot >> 6)) s->topology_dirty = 1;   /* (cannot tell the device: a re-tile clears both) */
+    }
     if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
     s->h_fetched[slot >> 6] &= ~bit;
     if (s->lod_cap > slot && s->lod_layout_gen == s->layout_gen) {
@@ -647,7 +672,11 @@ int clapgpu_scene_entity_delete_placed(clapgpu_scene *s, uint32_t handle)
     s->slot_handle[slot] = CLAPGPU_NO_ENTITY;
     s->slot_user[slot] = NULL;
     const uint64_t bit = 1ull << (slot & 63);
-    if (s->h_stale[slot >> 6] & bit) { s->h_stale[slot >> 6] &= ~bit; if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--; }
+    if (s->h_stale[slot >> 6] & bit) {
+        s->h_stale[slot >> 6] &= ~bit;
+        if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--;
+        if (push_list(&s->stale_fix, &s->n_stale_fix, &s->cap_stale_fix, slot >> 6)) s->topology_dirty = 1;   /* (cannot tell the device: a re-tile clears both) */
+    }
     if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
     s->h_fetched[slot >> 6] &= ~bit;
     if (e->parent != CLAPGPU_NO_ENTITY && e->parent < s->n_handles && s->e[e->parent].live && s->e[e->parent].n_children)
@@ -884,6 +913,10 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
         s->h_keep = calloc(mw, 8); s->h_stale = calloc(mw, 8); s->h_fetched = calloc(mw, 8);
         if (!s->h_keep || !s->h_stale || !s->h_fetched) return CLAPGPU_ERR_NOMEM;
         CK(clapgpu_malloc((void **)&s->d_keep, mw * 8));
+        if (s->d_stale) clapgpu_free(s->d_stale);
+        s->d_stale = NULL;
+        CK(clapgpu_malloc((void **)&s->d_stale, mw * 8));
+        CK(clapgpu_memset(s->d_stale, 0, mw * 8, NULL));
         if (s->zero_copy) CK(clapgpu_host_malloc_mapped((void **)&s->h_select, &s->d_select, mw * 8));
         s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;
     }
@@ -1027,6 +1060,8 @@ static int retile(clapgpu_scene *s)
     /* the slots moved: what was stale under the old layout is rebuilt (and exported or marked stale again) by the launch
      * that follows; the standing readers' bits are laid out anew */
     memset(s->h_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
+    CK(clapgpu_memset(s->d_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8, NULL));
+    s->n_stale_fix = 0;
     memset(s->h_fetched, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     memset(s->h_keep, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;
@@ -1197,10 +1232,12 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
             s->keep_dirty = 0;
         }
         scene_hostio(s, &io, by_bits, s->export_drawn);
+        io.options |= CLAPGPU_HOSTIO_EXPORT_STALE_READ;    /* what an earlier frame left stale and this one reads comes over in the same launch */
         CK(clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum, &io));
         const double tt2 = scene_now_us();
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
         if (s->export_drawn || s->n_stale_words) stale_after_launch(s);
+        else if (s->n_fetched) { memset(s->h_fetched, 0, (n / 64) * 8); s->n_fetched = 0; }
         if (getenv("CLAPGPU_SCENE_TIMING"))
             fprintf(stderr, "scene small frame: %u inputs by %s, one launch %.1f us, wait %.1f us\n", n_touched,
                     by_bits ? "touched bits" : upload ? "copy" : "none", tt2 - tt0, scene_now_us() - tt2);
@@ -1250,8 +1287,13 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     /* EXPORT_DRAWN: whoever is read this frame and was left stale by an earlier one -- an entity that came into view, a
      * box that now contains the camera, a reader registered since -- comes over now */
     if (fused) {
-        if (frustum) CK(fetch_rows(s, s->h_mask, s->bv_on ? s->h_inside : NULL, s->h_keep));
-        else CK(fetch_rows(s, NULL, NULL, NULL));      /* a pass without a camera draws everything (model.c:969) */
+        /* (the launch has brought over what it found stale and read -- stale_after_launch; this catches what it could not
+         * know: nothing, unless a caller's masks changed behind it) */
+        s->fetch_accumulate = 1;
+        const int frc = frustum ? fetch_rows(s, s->h_mask, s->bv_on ? s->h_inside : NULL, s->h_keep)
+                                : fetch_rows(s, NULL, NULL, NULL);      /* a pass without a camera draws everything (model.c:969) */
+        s->fetch_accumulate = 0;
+        CK(frc);
     }
     if (full || 4 * (size_t)n_touched > n)
         for (size_t i = 0; i < n; i++) s->h_flags[i] &= ~CLAPGPU_E_DIRTY;   /* the kernel cleared its copy too */

@@ -252,6 +252,7 @@ typedef struct clapgpu_entities_export {
     uint32_t *counter;                                     /* device scratch */
     uint32_t *done;                                        /* device-mapped host word */
     uint32_t  done_value, pad;
+    uint64_t *stale_mask;                                  /* clapgpu_entities_export_rows: clapgpu_entities_hostio.stale_mask, or NULL */
 } clapgpu_entities_export;
 int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list, uint32_t n_list);
 int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, const clapgpu_entities_export *x);
@@ -281,6 +282,7 @@ int clapgpu_entities_export_rows(void *stream, const clapgpu_entities *e, const 
  * launch (a second launch behind a pose: clapgpu_scene_attached_update).  Three dependent launches of a few microseconds
  * each cost a 10 k-entity frame 50 of its 68 us in launch-to-launch latency; this is one.
  */
+#define CLAPGPU_HOSTIO_EXPORT_STALE_READ 1u
 typedef struct clapgpu_entities_hostio {
     const float    *pos_scale, *rot;                       /* device aliases of the mapped upload image */
     const uint32_t *flags;
@@ -289,7 +291,7 @@ typedef struct clapgpu_entities_hostio {
     uint64_t *vis_mask, *rebuilt_mask, *inside_mask;       /* vis_mask needed with a frustum; inside_mask may be NULL */
     uint32_t *counter;                                     /* device scratch: one zeroed uint32 */
     uint32_t *done;                                        /* device-mapped host word */
-    uint32_t  done_value, pad;
+    uint32_t  done_value, options;                         /* CLAPGPU_HOSTIO_* bits */
     /* Export policy.  keep_mask == NULL: every rebuilt row is written to the mapped result arrays (what _models_render and
      * every other reader of e->mx / e->inverse_mx / e->aabb finds in the reference after mq_update, model.c:1022-1028,
      * 975-998).  keep_mask != NULL (device-readable, e->n / 64 words): only the rebuilt rows a reader exists for THIS
@@ -300,6 +302,14 @@ typedef struct clapgpu_entities_hostio {
      * written by this launch. */
     const uint64_t *keep_mask;
     uint64_t       *exported_mask;
+    /* stale_mask (DEVICE memory, e->n / 64 words, zeroed by the caller once; may be NULL): bit i = the mirror's copy of row i is
+     * older than the device's.  The launch keeps it -- a row it rebuilds without exporting becomes stale, one it exports stops
+     * being so -- and, with CLAPGPU_HOSTIO_EXPORT_STALE_READ in `options`, also writes every stale row that has a reader NOW
+     * (drawn by this launch's frustum, holding a bounding-volume point, flagged in keep_mask; every one without keep_mask)
+     * although it did not rebuild it: what came into view is current when the launch is, without a second launch asking for
+     * it.  Such rows are flagged in exported_mask and NOT in rebuilt_mask.  clapgpu_entities_export_rows() clears the bits
+     * of what it hands over. */
+    uint64_t       *stale_mask;
 } clapgpu_entities_hostio;
 int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e, const uint32_t *tile_row_start,
                                          uint32_t n_tiles, uint32_t mode, const clapgpu_frustum *frustum,

@@ -243,6 +243,8 @@ int clapgpu_entities_export_rows(void *stream, const clapgpu_entities *e, const 
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!launch_ok("k_entities_export_rows (fake)")) return CLAPGPU_ERR_UNKNOWN;
     copy_rows(e, x->mx, x->inv_mx, x->aabb, x->center, select_mask);
+    if (x->stale_mask)
+        for (uint32_t w = 0; w < e->n / 64; w++) x->stale_mask[w] &= ~select_mask[w];
     *x->done = x->done_value;
     return CLAPGPU_OK;
 }
@@ -275,7 +277,14 @@ int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e
             want = io->keep_mask[w] | (inside ? inside[w] : 0);
             want = frustum ? (want | e->vis_mask[w]) : ~0ull;
         }
-        const uint64_t ex = rb[w] & want;
+        uint64_t ex = rb[w] & want, alive = 0;
+        for (uint32_t l = 0; l < 64; l++) alive |= (uint64_t)((e->flags[w * 64 + l] & CLAPGPU_E_ALIVE) != 0) << l;
+        if (io->stale_mask) {                                        /* the device's twin of the mirror's stale mask, and the rows read now */
+            const uint64_t st = io->stale_mask[w];
+            const uint64_t late = (io->options & CLAPGPU_HOSTIO_EXPORT_STALE_READ) ? st & want & ~rb[w] & alive : 0;
+            io->stale_mask[w] = (st | rb[w]) & ~(ex | late);
+            ex |= late;
+        }
         io->rebuilt_mask[w] = rb[w];
         if (io->exported_mask) io->exported_mask[w] = ex;
         if (frustum) io->vis_mask[w] = e->vis_mask[w];

@@ -18,8 +18,8 @@ class Hostio(C.Structure):
     _fields_ = [("pos_scale", C.c_void_p), ("rot", C.c_void_p), ("flags", C.c_void_p), ("touched", C.c_void_p),
                 ("mx", C.c_void_p), ("inv_mx", C.c_void_p), ("aabb", C.c_void_p), ("center", C.c_void_p),
                 ("vis_mask", C.c_void_p), ("rebuilt_mask", C.c_void_p), ("inside_mask", C.c_void_p),
-                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32),
-                ("keep_mask", C.c_void_p), ("exported_mask", C.c_void_p)]
+                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("options", C.c_uint32),
+                ("keep_mask", C.c_void_p), ("exported_mask", C.c_void_p), ("stale_mask", C.c_void_p)]
 
 
 class Mapped:
@@ -232,16 +232,21 @@ def test_hostio_argument_validation(cuda_device):
 class Export(C.Structure):
     _fields_ = [("mx", C.c_void_p), ("inv_mx", C.c_void_p), ("aabb", C.c_void_p), ("center", C.c_void_p),
                 ("vis_mask", C.c_void_p), ("rebuilt_mask", C.c_void_p), ("inside_mask", C.c_void_p),
-                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32)]
+                ("counter", C.c_void_p), ("done", C.c_void_p), ("done_value", C.c_uint32), ("pad", C.c_uint32),
+                ("stale_mask", C.c_void_p)]
 
 
+@pytest.mark.parametrize("track", [False, True], ids=["plain", "stale-tracked"])
 @pytest.mark.parametrize("cull", [True, False])
-def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull, cuda_device):
+def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull, track, cuda_device):
     """clapgpu_entities_hostio.keep_mask (what GPU_SCATTER_DRAWN rests on): with it the launch writes to the mapped result
     arrays exactly the rebuilt rows of entities that are drawn (vis_mask), contain a bounding-volume point, or are flagged
     in keep_mask -- exported_mask says which, every other mapped row is left as it was -- while the DEVICE arrays hold
     every rebuilt row as without the policy (against the oracle, bit for bit).  Without a frustum everything rebuilt comes
-    back (a pass without a camera draws everything).  clapgpu_entities_export_rows then brings any selection over."""
+    back (a pass without a camera draws everything).  clapgpu_entities_export_rows then brings any selection over.
+    stale-tracked: the launch also keeps clapgpu_entities_hostio.stale_mask on the device (rebuilt and not written = stale,
+    written = not) and, with CLAPGPU_HOSTIO_EXPORT_STALE_READ, writes the stale rows that have a reader NOW although it did
+    not rebuild them (the standing readers change every frame here): flagged in exported_mask, not in rebuilt_mask."""
     import torch
     from clap_amd import entities
     L = _lib.lib()
@@ -285,6 +290,9 @@ def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull
                 mx=out.dev(0), inv_mx=out.dev(64 * n), aabb=out.dev(128 * n), center=out.dev(152 * n),
                 vis_mask=out.dev(164 * n), rebuilt_mask=out.dev(164 * n + mw), inside_mask=out.dev(164 * n + 2 * mw),
                 counter=counter.data_ptr(), done=word.dev(0), keep_mask=keep_dev.data_ptr(), exported_mask=out.dev(164 * n + 3 * mw))
+    stale_dev = torch.zeros(words + 2, dtype=torch.int64, device=b.device)
+    if track:
+        io.stale_mask, io.options = stale_dev.data_ptr(), 1
     POISON = np.float32(-12345.5)
     bits = lambda m: np.unpackbits(np.ascontiguousarray(m[:words]).view(np.uint8), bitorder="little").astype(bool)[:n]
     has_box = np.asarray(scene["model_skip"])[scene["model"]] == 0
@@ -308,9 +316,15 @@ def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull
             box = st["aabb"].reshape(n, 6)
             inside_ref = alive & np.all(probe >= box[:, :3], axis=1) & np.all(probe <= box[:, 3:], axis=1)
             assert np.array_equal(ins, inside_ref), f"frame {frame}: containment mask"
-            want = reb & (visb | ins | kept)
-            assert np.array_equal(exp, want), f"frame {frame}: exported = rebuilt & (drawn | containing | kept)"
-            assert reb.sum() > 50 and (cull and 0 < exp.sum() < reb.sum() or not cull and exp.sum() == reb.sum())
+            read_now = (visb | ins | kept)
+            late = (stale & read_now & ~reb & alive) if track else np.zeros(n, bool)
+            want = (reb & read_now) | late
+            assert np.array_equal(exp, want), f"frame {frame}: exported = rebuilt & (drawn | containing | kept) [+ stale rows read now]"
+            assert reb.sum() > 50 and (cull and 0 < (exp & reb).sum() < reb.sum() or not cull and (exp & reb).sum() == reb.sum())
+            if track and cull and frame:
+                assert late.sum() > 0, "the scenario has no stale row with a new reader"
+            if track:
+                assert np.array_equal(bits(stale_dev.cpu().numpy().view(np.uint64)), (stale | reb) & ~exp), f"frame {frame}: device stale mask"
             assert np.array_equal(o["mx"][exp].view(np.uint32), db["mx"][exp].view(np.uint32)), f"frame {frame}: exported mx"
             assert np.array_equal(o["inv"][exp].view(np.uint32), db["inv_mx"][exp].view(np.uint32))
             eb = exp & has_box
@@ -322,7 +336,8 @@ def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull
             pick = stale & (rng.uniform(0, 1, n) < 0.34)
             sel.view(0, words + 2, np.uint64)[:words] = np.packbits(pick, bitorder="little").view(np.uint64)
             x = Export(mx=out.dev(0), inv_mx=out.dev(64 * n), aabb=out.dev(128 * n), center=out.dev(152 * n),
-                       counter=counter.data_ptr(), done=word.dev(0), done_value=1000 + frame)
+                       counter=counter.data_ptr(), done=word.dev(0), done_value=1000 + frame,
+                       stale_mask=stale_dev.data_ptr() if track else None)
             _lib.check(L.clapgpu_entities_export_rows(None, C.byref(b._desc), C.byref(x), C.c_void_p(sel.dev(0))), "export_rows")
             _lib.check(L.clapgpu_wait_word(C.c_void_p(word.h.value), 1000 + frame, None), "clapgpu_wait_word")
             assert np.array_equal(o["mx"][pick].view(np.uint32), db["mx"][pick].view(np.uint32)), f"frame {frame}: fetched rows"
@@ -330,6 +345,12 @@ def test_export_policy_writes_back_what_is_read_and_the_rest_can_be_fetched(cull
             assert (o["mx"][~exp & ~pick] == POISON).all(), f"frame {frame}: the fetch wrote a row it was not asked for"
             assert np.array_equal(bits(o_reb), reb) and np.array_equal(bits(o_exp), exp), "a fetch leaves the frame's masks alone"
             stale &= ~pick
+            if track:
+                torch.cuda.synchronize()
+                assert np.array_equal(bits(stale_dev.cpu().numpy().view(np.uint64)), stale), f"frame {frame}: a fetch clears the stale bits of what it hands over"
+                kept = (rng.uniform(0, 1, n) < 0.05) & alive            # other standing readers next frame
+                keep[:words] = np.packbits(kept, bitorder="little").view(np.uint64)
+                keep_dev.copy_(torch.from_numpy(keep.view(np.int64)))
             # next frame: a fifth of the entities move
             h_touched[:] = 0
             move = (rng.uniform(0, 1, n) < 0.2) & alive
