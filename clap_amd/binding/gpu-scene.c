@@ -167,7 +167,7 @@ struct gpu_scene {
     entity3d        **created; uint32_t n_created, cap_created;    /* reported since the last update, in creation order */
     uint32_t        *dead_recs; uint32_t n_dead_recs, cap_dead_recs;   /* records of entities taken out in place: tombstones in order[] until the next walk */
     struct gs_wtxm { const model3dtx *txm; uint32_t next, first; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
-    bool            replay;                                        /* frames without notifications may go by the records (queue_unchanged) */
+    bool            replay, replaying;                             /* frames without notifications may go by the records (queue_unchanged); this frame does */
     bool            incremental, roomy;                            /* allowed; the mirror's re-tiles leave room (from the first entity that came or went between frames) */
     bool            appended;                                      /* order[] is no longer in list order: entities were taken in since the last walk */
     uint32_t        ftab_count;
@@ -1317,6 +1317,16 @@ void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep)
  * the binding may use workers as long as every call is synchronous, SURVEY 8b "Threading").
  */
 #define GS_PAR_MIN 65536u
+/* A frame without notifications goes by the records only where that is done on the workers: on one thread the two passes it
+ * takes (queue check, mirror pass, both through records in list order over entities that lie in creation order) LOSE to
+ * the plain list walk -- 20 k entities 0.95 vs 0.78 ms, 64 k 6.1 vs 3.9 --, split over the workers they win from ~16 k
+ * entities on (two wake-ups of the pool, ~0.1 ms, against a walk of 0.35 ms and up). */
+#define GS_REPLAY_MIN 16384u
+/* rebuilt rows from which the write-back is split over the workers (a row is ~60 ns on one thread -- a 448-byte entity3d
+ * and its 164 bytes of results, both cold --, a wake-up of the pool ~0.05 ms): 70 k entities, 13 k rebuilt: 0.87 ms serial */
+#define GS_SCATTER_PAR_MIN 12288u
+/* touched entities (reported one by one, or by address) from which the mirror pass is split over the workers */
+#define GS_MIRROR_PAR_MIN 16384u
 static inline void prefetch_entity(const entity3d *e);
 
 struct par_job {
@@ -1659,7 +1669,12 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
         struct gs_rec *r = &gs->rec[gs->char_list[k]];
         if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE)) gs->char_half(r->e, mq->priv);
     }
-    if (gs->n_touched >= GS_PAR_MIN) {
+    static uint32_t mirror_par_min;
+    if (!mirror_par_min) {
+        const char *mp = getenv("GPU_SCENE_MIRROR_PAR_MIN");     /* tuning knob */
+        mirror_par_min = mp && atoi(mp) > 0 ? (uint32_t)atoi(mp) : GS_MIRROR_PAR_MIN;
+    }
+    if (gs->n_touched >= mirror_par_min || (gs->replaying && par_threads() > 1)) {
         struct par_job jobs[GS_MAX_THREADS] = { 0 };
         const int nt = par_threads();
         for (int t = 0; t < nt; t++)
@@ -1715,7 +1730,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     }
     gs->n_touched = 0;
     if (gs->n_xptr) {
-        struct xptr_ctx xc = { .gs = gs, .mt = gs->n_xptr >= GS_PAR_MIN };
+        struct xptr_ctx xc = { .gs = gs, .mt = gs->n_xptr >= mirror_par_min && par_threads() > 1 };
         if (xc.mt) {
             gpu_scene_par_for(xptr_range, &xc, gs->n_xptr, par_threads());
             clapgpu_scene_mark_all_dirty(gs->scene);
@@ -1780,7 +1795,12 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
     uint64_t n_rebuilt = 0;
     if (scat)
         for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(scat[w]);
-    if (n_rebuilt >= 2 * GS_PAR_MIN && par_threads() > 1) {
+    static uint64_t scatter_par_min;
+    if (!scatter_par_min) {
+        const char *sp = getenv("GPU_SCENE_SCATTER_PAR_MIN");    /* tuning knob */
+        scatter_par_min = sp && atoll(sp) > 0 ? (uint64_t)atoll(sp) : GS_SCATTER_PAR_MIN;
+    }
+    if (n_rebuilt >= scatter_par_min && par_threads() > 1) {
         const int nt = par_threads();
         struct par_job jobs[GS_MAX_THREADS] = { 0 };
         for (int t = 0; t < nt; t++)
@@ -1967,7 +1987,7 @@ static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
     if (t != gs->n_wtxm) return false;
     struct quc_ctx qc = { gs, 0 };
     const double q0 = getenv("GPU_SCENE_TIMING") ? now_ms() : 0;
-    gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, gs->n_order >= GS_PAR_MIN ? par_threads() : 1);
+    gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, par_threads());
     if (q0 != 0) fprintf(stderr, "queue_unchanged: %u entities in %.3f ms (%s)\n", gs->n_order, now_ms() - q0, qc.changed ? "changed" : "the same");
     return !qc.changed;
 }
@@ -1989,7 +2009,8 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (rc <= 0) return rc;
         gs->gen++;
         memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
-    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order && !gs->n_touched && queue_unchanged(gs, mq)) {
+    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order >= GS_REPLAY_MIN && par_threads() > 1 &&
+               !gs->n_touched && queue_unchanged(gs, mq)) {
         /* no notifications, and the queue is the one the last walk met: the frame by the records (see queue_unchanged) */
         if (gs->n_order > gs->cap_touched) {
             uint32_t *q = realloc(gs->touched, (size_t)gs->cap_order * sizeof(*q));
@@ -1999,7 +2020,9 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         memcpy(gs->touched, gs->order, (size_t)gs->n_order * sizeof(*gs->touched));
         gs->n_touched = gs->n_order;
         gs->gen--;
+        gs->replaying = true;
         const int rc = fast_frame(gs, mq, view);
+        gs->replaying = false;
         gs->last_fast = false;                                    /* (the word is kept for frames that looked at what was reported only) */
         if (rc <= 0) { st->replayed = rc == 0; return rc; }
         gs->gen++;
