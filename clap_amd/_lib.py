@@ -252,7 +252,7 @@ SYMBOLS = {
     "clapgpu_characters_update_clock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "clapgpu_host_malloc_mapped": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t]),
     "clapgpu_entities_apply_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
-    "clapgpu_entities_place": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "clapgpu_entities_place": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "clapgpu_entities_export_rebuilt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_entities_export_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "clapgpu_entities_update_tiles_hostio": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

@@ -581,7 +581,7 @@ void k_entities_apply_inputs(float4 *pos_scale, float4 *rot, uint32_t *flags, co
 // The lanes of a standing layout that got a new tenant between two frames (clapgpu_entities_place): 16-byte records.
 __global__ __launch_bounds__(WAVE)
 void k_entities_place(int32_t *parent, int32_t *model, float *aabb, float *center, const clapgpu_entity_place *list, uint32_t n_list,
-                      uint32_t n)
+                      uint32_t n, unsigned long long *stale)
 {
     const uint32_t k = blockIdx.x * WAVE + threadIdx.x;
     if (k >= n_list) return;
@@ -590,7 +590,9 @@ void k_entities_place(int32_t *parent, int32_t *model, float *aabb, float *cente
     if (slot >= n) return;
     parent[slot] = (int32_t)r.y;
     model[slot] = (int32_t)r.z;
-    if (r.w) {
+    if ((r.w & CLAPGPU_PLACE_CLEAR_STALE) && stale)
+        atomicAnd(&stale[slot >> 6], ~(1ull << (slot & 63)));
+    if (r.w & CLAPGPU_PLACE_ZERO_BOX) {
         float2 *b = reinterpret_cast<float2 *>(aabb + 6 * (size_t)slot);
         b[0] = b[1] = b[2] = make_float2(0.f, 0.f);
         float *c = center + 3 * (size_t)slot;
@@ -879,14 +881,16 @@ extern "C" int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entitie
     return CLAPGPU_OK;
 }
 
-extern "C" int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list)
+extern "C" int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list,
+                                      uint64_t *stale_mask)
 {
     if (!e || !e->parent || !e->model || !e->aabb || !e->center || (n_list && !list))
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!n_list || !e->n)
         return CLAPGPU_OK;
     hipLaunchKernelGGL(k_entities_place, dim3((n_list + WAVE - 1) / WAVE), dim3(WAVE), 0, as_stream(stream),
-                       const_cast<int32_t *>(e->parent), const_cast<int32_t *>(e->model), e->aabb, e->center, list, n_list, e->n);
+                       const_cast<int32_t *>(e->parent), const_cast<int32_t *>(e->model), e->aabb, e->center, list, n_list, e->n,
+                       reinterpret_cast<unsigned long long *>(stale_mask));
     CLAPGPU_LAUNCH_CHECK("k_entities_place");
     return CLAPGPU_OK;
 }

@@ -95,7 +95,6 @@ struct clapgpu_scene {
     uint64_t   *h_select; void *d_select;                              /* mapped: the rows a fetch asks for */
     int         fetch_accumulate;                                      /* fetch_rows adds to the rows this mq_update's launch already brought over */
     uint64_t   *d_stale;                                               /* device twin of h_stale, kept by the launches themselves (clapgpu_entities_hostio.stale_mask) */
-    uint32_t   *stale_fix; uint32_t n_stale_fix, cap_stale_fix;        /* words of h_stale an in-place edit changed: the device twin follows before the next launch */
     /* the layout edited in place (clapgpu_scene_entity_new_placed / _delete_placed): a queue whose make-up changes by a few
      * entities a frame keeps its tiles; a re-tile is the fall-back */
     uint32_t    max_depth;                                             /* rows of the deepest tree at the last re-tile */
@@ -326,7 +325,6 @@ void clapgpu_scene_destroy(clapgpu_scene *s)
     free(s->h_keep); free(s->h_stale); free(s->h_fetched); free(s->free_roots); free(s->raw_words); free(s->edits); free(s->limbo);
     if (s->h_place) clapgpu_host_free(s->h_place);
     if (s->d_stale) clapgpu_free(s->d_stale);
-    free(s->stale_fix);
     free(s);
 }
 
@@ -549,9 +547,6 @@ static int append_tile(clapgpu_scene *s)
 /* parent / model indices of the edited slots, and appended tiles, to the device: before anything is launched on the layout */
 static int apply_edits(clapgpu_scene *s)
 {
-    for (uint32_t k = 0; k < s->n_stale_fix; k++)        /* (rare: the lane's last tenant had been left stale) */
-        CK(clapgpu_memcpy_h2d(s->d_stale + s->stale_fix[k], s->h_stale + s->stale_fix[k], 8, NULL));
-    if (s->n_stale_fix) { CK(clapgpu_stream_sync(NULL)); s->n_stale_fix = 0; }   /* h_stale is pageable and changes with the next launch */
     if (s->grown_from == CLAPGPU_NO_ENTITY && !s->n_edits) return CLAPGPU_OK;
     if (s->grown_from != CLAPGPU_NO_ENTITY) {
         const size_t a = s->grown_from, cnt = s->n_slots - a;
@@ -578,11 +573,12 @@ static int apply_edits(clapgpu_scene *s)
             s->cap_place = cap;
         }
         for (uint32_t k = 0; k < s->n_edits; k++) {
-            const uint32_t i = s->edits[k] & 0x7fffffffu;
+            const uint32_t i = s->edits[k] & 0x3fffffffu;
             s->h_place[k] = (clapgpu_entity_place){ .slot = i, .parent = s->h_parent[i], .model = s->h_model[i],
-                                                    .zero_box = s->edits[k] >> 31 };
+                                                    .flags = ((s->edits[k] >> 31) ? CLAPGPU_PLACE_ZERO_BOX : 0) |
+                                                             ((s->edits[k] & 0x40000000u) ? CLAPGPU_PLACE_CLEAR_STALE : 0) };
         }
-        CK(clapgpu_entities_place(NULL, &s->d, (const clapgpu_entity_place *)s->d_place, s->n_edits));
+        CK(clapgpu_entities_place(NULL, &s->d, (const clapgpu_entity_place *)s->d_place, s->n_edits, s->d_stale));
         s->n_edits = 0;
     }
     return CLAPGPU_OK;
@@ -636,13 +632,14 @@ int clapgpu_scene_entity_new_placed(clapgpu_scene *s, uint32_t model, void *user
     if (!s->n_edits || slot + 1 > s->edit_hi) s->edit_hi = slot + 1;
     uint32_t skip_bits;
     memcpy(&skip_bits, &s->models[8 * (size_t)model + 3], 4);
-    s->edits[s->n_edits++] = slot | (skip_bits ? 0x80000000u : 0);
     const uint64_t bit = 1ull << (slot & 63);
+    int was_stale = 0;
     if (s->h_stale[slot >> 6] & bit) {
         s->h_stale[slot >> 6] &= ~bit;
         if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--;
-        if (push_list(&s->stale_fix, &s->n_stale_fix, &s->cap_stale_fix, slot >> 6)) s->topology_dirty = 1;   /* (cannot tell the device: a re-tile clears both) */
+        was_stale = 1;                                   /* the device's twin follows with the frame's place list */
     }
+    s->edits[s->n_edits++] = slot | (skip_bits ? 0x80000000u : 0) | (was_stale ? 0x40000000u : 0);
     if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
     s->h_fetched[slot >> 6] &= ~bit;
     if (s->lod_cap > slot && s->lod_layout_gen == s->layout_gen) {
@@ -675,7 +672,8 @@ int clapgpu_scene_entity_delete_placed(clapgpu_scene *s, uint32_t handle)
     if (s->h_stale[slot >> 6] & bit) {
         s->h_stale[slot >> 6] &= ~bit;
         if (!s->h_stale[slot >> 6] && s->n_stale_words) s->n_stale_words--;
-        if (push_list(&s->stale_fix, &s->n_stale_fix, &s->cap_stale_fix, slot >> 6)) s->topology_dirty = 1;   /* (cannot tell the device: a re-tile clears both) */
+        /* the device's twin follows with the frame's place list (parent / model as they are) */
+        if (push_list(&s->edits, &s->n_edits, &s->cap_edits, slot | 0x40000000u)) s->topology_dirty = 1;   /* (a re-tile clears both) */
     }
     if (s->h_keep[slot >> 6] & bit) { s->h_keep[slot >> 6] &= ~bit; s->keep_dirty = 1; }
     s->h_fetched[slot >> 6] &= ~bit;
@@ -1061,7 +1059,6 @@ static int retile(clapgpu_scene *s)
      * that follows; the standing readers' bits are laid out anew */
     memset(s->h_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     CK(clapgpu_memset(s->d_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8, NULL));
-    s->n_stale_fix = 0;
     memset(s->h_fetched, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     memset(s->h_keep, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;

@@ -259,11 +259,14 @@ int clapgpu_entities_export_rebuilt(void *stream, const clapgpu_entities *e, con
 /*
  * A standing layout edited in place (entity3d_make / entity3d_delete between two frames, model.c:1730-1791; libclapgpu_scene's
  * clapgpu_scene_entity_new_placed): the lanes that got a new tenant, as one list in device-mapped host memory -- parent[slot]
- * and model[slot] are set; zero_box also clears the lane's aabb / center rows (a model with skip_aabb never writes them, and
- * a fresh entity3d's are zeros, not the last tenant's).  One small launch instead of two copies and two fills per edit.
+ * and model[slot] are set; CLAPGPU_PLACE_ZERO_BOX also clears the lane's aabb / center rows (a model with skip_aabb never writes
+ * them, and a fresh entity3d's are zeros, not the last tenant's).  One small launch instead of two copies and two fills per edit.
  */
-typedef struct clapgpu_entity_place { uint32_t slot; int32_t parent, model; uint32_t zero_box; } clapgpu_entity_place;
-int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list);
+typedef struct clapgpu_entity_place { uint32_t slot; int32_t parent, model; uint32_t flags; } clapgpu_entity_place;
+#define CLAPGPU_PLACE_ZERO_BOX    1u    /* clear the lane's aabb / center rows */
+#define CLAPGPU_PLACE_CLEAR_STALE 2u    /* clear the lane's bit in stale_mask (clapgpu_entities_hostio.stale_mask; the lane's last tenant's) */
+int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list,
+                           uint64_t *stale_mask);
 /*
  * The rows a mirror asks for after the fact (a mirror that takes back only what is drawn, clapgpu_entities_hostio.keep_mask,
  * fetches the rest on demand: an entity that comes into view, entity3d_update() on a hidden one, ...): copies the rows of

@@ -191,7 +191,7 @@ int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const
     return CLAPGPU_OK;
 }
 
-int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list)
+int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgpu_entity_place *list, uint32_t n_list, uint64_t *stale_mask)
 {
     (void)stream;
     if (!e || !e->parent || !e->model || !e->aabb || !e->center || (n_list && !list)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
@@ -201,7 +201,8 @@ int clapgpu_entities_place(void *stream, const clapgpu_entities *e, const clapgp
         if (slot >= e->n) continue;
         ((int32_t *)e->parent)[slot] = list[k].parent;
         ((int32_t *)e->model)[slot] = list[k].model;
-        if (list[k].zero_box) { memset(e->aabb + 6 * (size_t)slot, 0, 24); memset(e->center + 3 * (size_t)slot, 0, 12); }
+        if ((list[k].flags & CLAPGPU_PLACE_CLEAR_STALE) && stale_mask) stale_mask[slot >> 6] &= ~(1ull << (slot & 63));
+        if (list[k].flags & CLAPGPU_PLACE_ZERO_BOX) { memset(e->aabb + 6 * (size_t)slot, 0, 24); memset(e->center + 3 * (size_t)slot, 0, 12); }
     }
     return CLAPGPU_OK;
 }
