@@ -273,6 +273,7 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     int rc = clapgpu_scene_create(&gs->scene, device);
     if (rc) { free(gs); return rc; }
     gs->default_hook = default_hook;
+    clapgpu_scene_set_lod_sync(gs->scene, 1);                    /* gpu_scene_select_lod reports the LODs a pick changed itself */
     gs->free_rec = NO_REC;
     gs->verify = getenv("GPU_SCENE_VERIFY") != NULL;
     const char *sp = getenv("GPU_SCENE_SCATTER");
@@ -2478,6 +2479,46 @@ static int draw_push(struct gpu_scene *gs, entity3d *e, int lod, uint32_t txm)
     return 0;
 }
 
+static int draw_reserve(struct gpu_scene *gs, uint32_t n)
+{
+    if (n <= gs->cap_draw) return 0;
+    uint32_t cap = gs->cap_draw ? gs->cap_draw : 4096;
+    while (cap < n) cap *= 2;
+    entity3d **d = realloc(gs->draw, (size_t)cap * sizeof(*d));
+    if (d) gs->draw = d;
+    int32_t *l = realloc(gs->draw_lod, (size_t)cap * sizeof(*l));
+    if (l) gs->draw_lod = l;
+    uint16_t *t = realloc(gs->draw_txm, (size_t)cap * sizeof(*t));
+    if (t) gs->draw_txm = t;
+    if (!d || !l || !t) return _CERR_NOMEM;
+    gs->cap_draw = cap;
+    return 0;
+}
+
+/* entries [lo, hi) of the device's draw list into the binding's (gpu_scene_select_lod, a list too long for one thread) */
+struct draw_ctx { struct gpu_scene *gs; const clapgpu_scene_arrays *res; const uint32_t *slots; const int32_t *lods; uint32_t holes; };
+static void draw_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct draw_ctx *dc = ctx;
+    struct gpu_scene *gs = dc->gs;
+    uint32_t holes = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t slot = dc->slots[k];
+        const int32_t lod = dc->lods[k];
+        entity3d *e = gs->slot_ent[slot];
+        if (e && lod != gs->slot_lod[slot] && lod >= -128 && lod <= 127) {
+            e->cur_lod = lod;                                    /* as model.c:977 / entity3d_set_lod leave it */
+            gs->slot_lod[slot] = (int8_t)lod;
+            const uint32_t tag = (uint32_t)(uintptr_t)dc->res->slot_user[slot];
+            if (tag) gs->rec[tag - 1].lod_cur = lod;
+            clapgpu_scene_lod_picked(gs->scene, slot, lod);
+        }
+        gs->draw[k] = e; gs->draw_lod[k] = lod; gs->draw_txm[k] = e ? gs->slot_txm[slot] : 0;
+        holes += !e;
+    }
+    if (holes) __atomic_fetch_add(&dc->holes, holes, __ATOMIC_RELAXED);
+}
+
 void gpu_scene_lod_changed(struct gpu_scene *gs, entity3d *e)
 {
     if (!gs || !e) return;
@@ -2545,17 +2586,33 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     const uint32_t *slots = NULL; const int32_t *lods = NULL;
     if (n && !clapgpu_scene_results(gs->scene, &res) && clapgpu_scene_draw_list(gs->scene, &slots, &lods) == n) {
         const bool by_slot = gs->cap_slot_arrays >= res.n_slots;
+        if (by_slot && cam_pos && n >= GS_MIRROR_PAR_MIN && par_threads() > 1 && !draw_reserve(gs, n)) {
+            /* a long list: the gather on the workers (entry k -> draw[k]: nothing shared but the arrays) */
+            struct draw_ctx dc = { gs, &res, slots, lods, 0 };
+            gpu_scene_par_for(draw_range, &dc, n, par_threads());
+            gs->n_draw = n;
+            if (dc.holes) {                                      /* lanes vacated since the update (gpu_scene_entity_deleting): out */
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < n; k++) {
+                    if (!gs->draw[k]) continue;
+                    gs->draw[w] = gs->draw[k]; gs->draw_lod[w] = gs->draw_lod[k]; gs->draw_txm[w] = gs->draw_txm[k];
+                    w++;
+                }
+                gs->n_draw = w;
+            }
+        } else
         for (uint32_t k = 0; k < n; k++) {
             const uint32_t slot = slots[k];
             if (by_slot) {
                 /* three arrays read in ascending slot order; an entity3d (and its record) only when the pick changed its LOD */
                 entity3d *e = gs->slot_ent[slot];
                 if (!e) continue;
-                if (lods[k] != gs->slot_lod[slot] && lods[k] >= -128 && lods[k] <= 127) {
+                if (cam_pos && lods[k] != gs->slot_lod[slot] && lods[k] >= -128 && lods[k] <= 127) {
                     e->cur_lod = lods[k];                           /* as model.c:977 / entity3d_set_lod leave it */
                     gs->slot_lod[slot] = (int8_t)lods[k];
                     const uint32_t tag = (uint32_t)(uintptr_t)res.slot_user[slot];
                     if (tag) gs->rec[tag - 1].lod_cur = lods[k];
+                    clapgpu_scene_lod_picked(gs->scene, slot, lods[k]);
                 }
                 CK(draw_push(gs, e, lods[k], gs->slot_txm[slot]));
                 continue;
@@ -2564,15 +2621,30 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
             if (!tag) continue;
             struct gs_rec *r = &gs->rec[tag - 1];
             if (!r->e || r->gen != gs->gen || (r->cls != 1 && r->cls != 4)) continue;
+            if (cam_pos && r->lod_cur != lods[k]) clapgpu_scene_lod_picked(gs->scene, slot, lods[k]);
             r->e->cur_lod = lods[k];                                /* as model.c:977 / entity3d_set_lod leave it */
             r->lod_cur = lods[k];
             CK(draw_push(gs, r->e, lods[k], 0xffffffffu));
         }
     }
-    /* the entities the device does not hold, in list order, by the reference's own block */
+    /* the entities the device does not hold, in list order, by the reference's own block: the host-class ones -- the two
+     * lists the walk keeps of them (own hook now / behind the pose), merged by their place in the queue; NOT a scan of every
+     * record for the few that are not batched (1 M records: 3-4 ms of a 5 ms call) */
+    if (device_ok) {
+        uint32_t a = 0, b = 0;
+        while (a < gs->n_host || b < gs->n_deferred) {
+            const uint64_t ka = a < gs->n_host ? gs->rec[gs->host_list[a]].order_key : UINT64_MAX;
+            const uint64_t kb = b < gs->n_deferred ? gs->rec[gs->deferred[b]].order_key : UINT64_MAX;
+            struct gs_rec *r = ka <= kb ? &gs->rec[gs->host_list[a++]] : &gs->rec[gs->deferred[b++]];
+            if (!r->e || r->cls == 1 || r->cls == 4) continue;
+            if (lod_pick_host(view, r->e, cam_pos))
+                CK(draw_push(gs, r->e, r->e->cur_lod, 0xffffffffu));
+        }
+        return 0;
+    }
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
-        if (!r->e || (device_ok && (r->cls == 1 || r->cls == 4))) continue;
+        if (!r->e) continue;
         if (lod_pick_host(view, r->e, cam_pos))
             CK(draw_push(gs, r->e, r->e->cur_lod, 0xffffffffu));
         if ((r->cls == 1 || r->cls == 4) && r->handle != CLAPGPU_NO_ENTITY && r->e->cur_lod != r->lod_cur &&

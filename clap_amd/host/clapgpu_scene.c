@@ -123,6 +123,7 @@ struct clapgpu_scene {
     uint32_t   *h_draw_slot; int32_t *h_draw_lod; uint32_t *h_visible_count;     /* page-locked */
     uint32_t    lod_cap, lod_lo, lod_hi, n_draw;                                  /* [lod_lo, lod_hi): host values not on the device yet */
     uint32_t    lod_layout_gen;
+    int         lod_sync_by_caller;                                               /* clapgpu_scene_set_lod_sync */
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -1626,7 +1627,7 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
         if (cam_pos) CK(clapgpu_memcpy_d2h(s->h_draw_lod, s->d_draw_lod, (size_t)n * 4, NULL));
         CK(clapgpu_stream_sync(NULL));
     }
-    for (uint32_t k = 0; k < n; k++) {                               /* the host copies follow the pick: where it changed something */
+    for (uint32_t k = 0; k < n && !(cam_pos && s->lod_sync_by_caller); k++) {   /* the host copies follow the pick: where it changed something */
         const uint32_t slot = s->h_draw_slot[k];
         if (!cam_pos) { s->h_draw_lod[k] = s->h_cur_lod[slot]; continue; }
         if (s->h_cur_lod[slot] == s->h_draw_lod[k]) continue;
@@ -1637,6 +1638,19 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
     s->n_draw = n;
     *n_draw = n;
     return CLAPGPU_OK;
+}
+
+/* A caller that walks the draw list anyway (and knows every entity's last LOD) tells the mirror where the pick changed one,
+ * instead of the mirror comparing every entry itself: clapgpu_scene_set_lod_sync(s, 1), then clapgpu_scene_lod_picked() for
+ * each changed entry of every list picked with a camera -- distinct slots may be reported from several threads at once. */
+void clapgpu_scene_set_lod_sync(clapgpu_scene *s, int by_caller) { if (s) s->lod_sync_by_caller = by_caller != 0; }
+
+void clapgpu_scene_lod_picked(clapgpu_scene *s, uint32_t slot, int lod)
+{
+    if (!s || !s->lod_cap || slot >= s->n_slots) return;
+    s->h_cur_lod[slot] = lod;
+    const uint32_t h = s->slot_handle[slot];
+    if (h != CLAPGPU_NO_ENTITY) s->e[h].cur_lod = lod;
 }
 
 uint32_t clapgpu_scene_draw_list(const clapgpu_scene *s, const uint32_t **slots, const int32_t **lods)

@@ -191,6 +191,12 @@ int          clapgpu_scene_model_lods(clapgpu_scene *s, uint32_t model, unsigned
 int          clapgpu_scene_entity_lod(clapgpu_scene *s, uint32_t handle, int force_lod, int cur_lod);
 int          clapgpu_scene_entity_cur_lod(const clapgpu_scene *s, uint32_t handle);
 int          clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t *n_draw);
+/* A caller that walks the draw list anyway and knows every entity's last LOD can take over the bookkeeping the call above does
+ * per entry (is this entity's cur_lod still what the mirror holds?): clapgpu_scene_set_lod_sync(s, 1), then
+ * clapgpu_scene_lod_picked(s, slot, lod) for each entry of a list picked WITH a camera whose LOD changed (distinct slots may
+ * be reported from several threads at once). */
+void         clapgpu_scene_set_lod_sync(clapgpu_scene *s, int by_caller);
+void         clapgpu_scene_lod_picked(clapgpu_scene *s, uint32_t slot, int lod);
 uint32_t     clapgpu_scene_draw_list(const clapgpu_scene *s, const uint32_t **slots, const int32_t **lods);
 
 int          clapgpu_scene_layout_is_tiled(const clapgpu_scene *s);

@@ -969,7 +969,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     gpu_scene_bind(gs, B.mq, &B.view);
 
     double t_ref = 0, t_gpu = 0, t_ref_upd = 0, t_gpu_upd = 0, t_step[4] = { 0, 0, 0, 0 };
-    double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0;
+    double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0, t_gpu_select = 0;
     uint64_t vis_a = 0, vis_b = 0, drawn_a = 0, drawn_b = 0, drawn_l = 0, acc_a = 0, acc_b = 0, acc_l = 0, left_stale = 0, fetched = 0;
     uint64_t bad = 0, n_fast = 0, n_retiled = 0, n_placed = 0, n_removed = 0, n_replayed = 0;
     for (uint32_t f = 0; f < frames + 2; f++) {                          /* two untimed warm-up frames */
@@ -1033,6 +1033,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
         uint32_t nl = 0;
         rc = gpu_scene_select_lod(gs, &B.view, cpos);
         if (rc) { fprintf(stderr, "gpu_scene_select_lod: %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+        if (f >= 2) t_gpu_select += now_s() - b2;
         { model3dtx *txm;
           list_for_each_entry(txm, &B.mq->txmodels, entry) {
               entity3d **seg; const int32_t *slod;
@@ -1070,7 +1071,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"reference_mq_update_ms\": %.4f, \"binding_mq_update_ms\": %.4f, "
            "\"binding_ms\": {\"walk\": %.4f, \"mirror\": %.4f, \"device\": %.4f, \"scatter\": %.4f}, "
            "\"reference_mutate_ms\": %.4f, \"binding_mutate_ms\": %.4f, "
-           "\"reference_render_block_ms\": %.4f, \"binding_render_block_ms\": %.4f, \"binding_draw_list_ms\": %.4f, "
+           "\"reference_render_block_ms\": %.4f, \"binding_render_block_ms\": %.4f, \"binding_draw_list_ms\": %.4f, \"binding_select_lod_ms\": %.4f, "
            "\"reference_frame_ms\": %.4f, \"binding_frame_block_ms\": %.4f, \"binding_frame_draw_list_ms\": %.4f, "
            "\"drawn_per_frame\": %.1f, \"draw_sets_equal\": %s, \"draw_reads_equal\": %s, "
            "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, \"churn_per_frame\": %u, "
@@ -1079,7 +1080,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
            t_step[0] / F, t_step[1] / F, t_step[2] / F, t_step[3] / F,
-           1e3 * t_ref_mut / F, 1e3 * t_gpu_mut / F, 1e3 * t_ref_blk / F, 1e3 * t_gpu_blk / F, 1e3 * t_gpu_list / F,
+           1e3 * t_ref_mut / F, 1e3 * t_gpu_mut / F, 1e3 * t_ref_blk / F, 1e3 * t_gpu_blk / F, 1e3 * t_gpu_list / F, 1e3 * t_gpu_select / F,
            1e3 * (t_ref_mut + t_ref_upd + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_list) / F,
            drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
            opt_drawn ? "drawn" : "all", left_stale / F, fetched / F, opt_churn,
