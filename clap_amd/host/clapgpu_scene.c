@@ -124,6 +124,9 @@ struct clapgpu_scene {
     uint32_t    lod_cap, lod_lo, lod_hi, n_draw;                                  /* [lod_lo, lod_hi): host values not on the device yet */
     uint32_t    lod_layout_gen;
     int         lod_sync_by_caller;                                               /* clapgpu_scene_set_lod_sync */
+    /* a small scene's draw list lands in device-mapped host memory: the two launches write it (and its length) where the host
+     * reads it, one wait -- no length copy, wait, list copies, wait (two round trips of ~35 us around two ~8 us launches) */
+    int         lod_mapped; void *a_draw_slot, *a_draw_lod, *a_visible_count;
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -1580,8 +1583,15 @@ static int ensure_lod(clapgpu_scene *s)
         CK(clapgpu_malloc((void **)&s->d_visible, n * 4));   CK(clapgpu_malloc((void **)&s->d_draw_lod, n * 4));
         CK(clapgpu_malloc((void **)&s->d_visible_count, 16));
         CK(clapgpu_malloc(&s->d_vis_scratch, clapgpu_visible_scratch_bytes((uint32_t)n)));
-        CK(clapgpu_host_malloc((void **)&s->h_draw_slot, n * 4)); CK(clapgpu_host_malloc((void **)&s->h_draw_lod, n * 4));
-        CK(clapgpu_host_malloc((void **)&s->h_visible_count, 16));
+        s->lod_mapped = s->zero_copy && n <= CLAPGPU_SCENE_LOD_MAPPED_SLOTS;
+        if (s->lod_mapped) {
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_draw_slot, &s->a_draw_slot, n * 4));
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_draw_lod, &s->a_draw_lod, n * 4));
+            CK(clapgpu_host_malloc_mapped((void **)&s->h_visible_count, &s->a_visible_count, 16));
+        } else {
+            CK(clapgpu_host_malloc((void **)&s->h_draw_slot, n * 4)); CK(clapgpu_host_malloc((void **)&s->h_draw_lod, n * 4));
+            CK(clapgpu_host_malloc((void **)&s->h_visible_count, 16));
+        }
         s->lod_cap = s->cap_slots;
         s->lod_layout_gen = s->layout_gen - 1;                       /* force the fill below */
     }
@@ -1613,16 +1623,17 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
     CK(ensure_lod(s));
     /* the ordered visible list from the mask the last update / cull left on the device, then -- with a camera -- the LOD
      * pick over it (one launch each); without one the pass keeps every cur_lod (model.c:974: `if (camera)`) */
+    uint32_t *out_slot = s->lod_mapped ? s->a_draw_slot : s->d_visible, *out_count = s->lod_mapped ? s->a_visible_count : s->d_visible_count;
+    int32_t *out_lod = s->lod_mapped ? s->a_draw_lod : s->d_draw_lod;
     if (cam_pos)
-        CK(clapgpu_visible_compact_lod(NULL, &s->d, 0, cam_pos, s->d_force_lod, s->d_cur_lod, s->d_visible, s->d_visible_count,
-                                       s->d_draw_lod, s->d_vis_scratch));
+        CK(clapgpu_visible_compact_lod(NULL, &s->d, 0, cam_pos, s->d_force_lod, s->d_cur_lod, out_slot, out_count, out_lod, s->d_vis_scratch));
     else
-        CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, s->d_visible, s->d_visible_count, s->d_vis_scratch));
-    CK(clapgpu_memcpy_d2h(s->h_visible_count, s->d_visible_count, 4, NULL));
+        CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, out_slot, out_count, s->d_vis_scratch));
+    if (!s->lod_mapped) CK(clapgpu_memcpy_d2h(s->h_visible_count, s->d_visible_count, 4, NULL));
     CK(clapgpu_stream_sync(NULL));
     const uint32_t n = *s->h_visible_count;
     if (n > s->n_slots) return CLAPGPU_ERR_UNKNOWN;
-    if (n) {
+    if (n && !s->lod_mapped) {
         CK(clapgpu_memcpy_d2h(s->h_draw_slot, s->d_visible, (size_t)n * 4, NULL));
         if (cam_pos) CK(clapgpu_memcpy_d2h(s->h_draw_lod, s->d_draw_lod, (size_t)n * 4, NULL));
         CK(clapgpu_stream_sync(NULL));

@@ -34,6 +34,8 @@ typedef struct clapgpu_scene clapgpu_scene;
  * 0.31 ms, 1 M 8.8 / 3.0 ms; all moving, 1 M: 9.3 / 8.8 ms -- the mapped form moves only what changed and is never the
  * slower one, so by default every scene takes it; the staged form stays for hosts where mapped memory is not wanted. */
 #define CLAPGPU_SCENE_ZERO_COPY_SLOTS 0xffffffffu
+/* up to this many slots clapgpu_scene_select_lod's draw list is written by the device straight into mapped host memory */
+#define CLAPGPU_SCENE_LOD_MAPPED_SLOTS 131072u
 int  clapgpu_scene_create(clapgpu_scene **out, int device);
 void clapgpu_scene_destroy(clapgpu_scene *s);
 /* 0 = always stage through device slabs; takes effect at the next layout rebuild (the call forces one).  The
