@@ -1326,6 +1326,7 @@ void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep)
 /* rebuilt rows from which the write-back is split over the workers (a row is ~60 ns on one thread -- a 448-byte entity3d
  * and its 164 bytes of results, both cold --, a wake-up of the pool ~0.05 ms): 70 k entities, 13 k rebuilt: 0.87 ms serial */
 #define GS_SCATTER_PAR_MIN 12288u
+#define GS_SCATTER_SPARSE 8              /* ... off the mask words when GS_SCATTER_SPARSE * rebuilt <= entities in the queue, else in list order */
 /* touched entities (reported one by one, or by address) from which the mirror pass is split over the workers */
 #define GS_MIRROR_PAR_MIN 16384u
 static inline void prefetch_entity(const entity3d *e);
@@ -1837,12 +1838,12 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
         scatter_par_min = sp && atoll(sp) > 0 ? (uint64_t)atoll(sp) : GS_SCATTER_PAR_MIN;
     }
     static int by_mask = -1;
-    if (by_mask < 0) { const char *bm = getenv("GPU_SCENE_SCATTER_BY_MASK"); by_mask = !(bm && !strcmp(bm, "0")); }   /* tuning knob */
+    if (by_mask < 0) { const char *bm = getenv("GPU_SCENE_SCATTER_BY_MASK"); by_mask = bm ? atoi(bm) : GS_SCATTER_SPARSE; }   /* tuning knob: 0 = never, k = when k * rebuilt <= queue */
     if (n_rebuilt >= scatter_par_min && par_threads() > 1) {
         const int nt = par_threads();
         struct par_job jobs[GS_MAX_THREADS] = { 0 };
         /* most of the queue: in LIST order (the entity3d structs lie in creation order); a small part of it: off the mask */
-        const bool sparse = by_mask && 8 * n_rebuilt <= gs->n_order;
+        const bool sparse = by_mask > 0 && (uint64_t)by_mask * n_rebuilt <= gs->n_order;
         const uint32_t span = sparse ? words : gs->n_order;
         for (int t = 0; t < nt; t++)
             jobs[t] = (struct par_job){ .gs = gs, .res = &res, .scat = scat, .lo = (uint32_t)((uint64_t)span * t / nt),
