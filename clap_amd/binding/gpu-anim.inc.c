@@ -267,9 +267,15 @@ static void ga_joints_back_range(void *m, uint32_t lo, uint32_t hi) { ga_joints_
 
 static int ga_threads(void)
 {
-    long n = sysconf(_SC_NPROCESSORS_ONLN);
-    if (n > 8) n = 8;
-    return n < 1 ? 1 : (int)n;
+    static int cached;
+    if (!cached) {
+        long n = sysconf(_SC_NPROCESSORS_ONLN);
+        const char *env = getenv("GPU_ANIM_THREADS");            /* tuning knob (gpu_scene_par_for clamps to the pool's size) */
+        if (env && atoi(env) > 0) n = atoi(env);
+        else if (n > 24) n = 24;
+        cached = n < 1 ? 1 : (int)n;
+    }
+    return cached;
 }
 
 int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, struct scene *s)
