@@ -55,6 +55,7 @@ struct ga_model {
 struct gpu_anim {
     struct ga_model *models;
     uint32_t        n_models, cap_models;
+    uint32_t        walk_seen; bool walk_seen_valid;     /* gpu_scene_walk_generation() at the last update */
 };
 
 #define GA_CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -211,6 +212,13 @@ static struct ga_model *ga_model_of(struct gpu_anim *ga, model3d *model, int *rc
     return m;
 }
 
+static struct ga_model *ga_model_peek(struct gpu_anim *ga, const model3d *model)
+{
+    for (uint32_t k = 0; k < ga->n_models; k++)
+        if (ga->models[k].model == model) return &ga->models[k];
+    return NULL;
+}
+
 static int ga_reserve(struct ga_model *m, uint32_t n)
 {
     if (n <= m->cap) return 0;
@@ -292,6 +300,9 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
         m->n_prev = m->n;
         m->n = 0;
     }
+    const uint32_t walk_now = gs ? gpu_scene_walk_generation(gs) : 0;
+    const bool same_walk = gs && ga->walk_seen == walk_now && ga->walk_seen_valid;
+    ga->walk_seen = walk_now; ga->walk_seen_valid = gs != NULL;
     /* animated_update's host part, list order (model.c:1563-1581) */
     model3dtx *txm;
     entity3d *e, *it;
@@ -303,7 +314,13 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
             if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
             /* whoever ran the entity's own hook ran its animated_update too; what gpu_mq_update batched (default_update
              * entities, and body-less characters, whose hook ends in default_update) is posed here */
-            if (gs ? !gpu_scene_entity_is_batched(gs, e) : e->update != default_update) continue;
+            /* (the same entity at the same place of its model's batch as last frame, and no walk of the queue since: it
+             * is still batched -- no look-up; 50 000 characters: 3 of the 5 ms this loop took were the hash) */
+            if (gs) {
+                struct ga_model *pm = m ? m : ga_model_peek(ga, model);
+                const bool known = same_walk && pm && pm->n < pm->n_prev && pm->prev[pm->n] == e;
+                if (!known && !gpu_scene_entity_is_batched(gs, e)) continue;
+            } else if (e->update != default_update) continue;
             if (e->animation < 0)
                 animation_next(e, s);
             struct queued_animation *qa = ani_current(e);

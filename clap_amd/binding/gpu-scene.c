@@ -416,6 +416,9 @@ void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq)
     }
 }
 
+/* advances with every walk of the queue: between two equal values no entity changed its class */
+uint32_t gpu_scene_walk_generation(const struct gpu_scene *gs) { return gs ? gs->gen : 0; }
+
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e)
 {
     const uint32_t i = rec_find(gs, e);

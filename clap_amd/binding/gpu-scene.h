@@ -232,6 +232,8 @@ void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int
                           int (*host_half)(entity3d *, void *));
 void gpu_scene_bind_characters(struct gpu_scene *gs);          /* gpu-character.inc.c */
 /* true if `e` was updated on the device by the last gpu_mq_update() */
+/* advances with every walk of the queue: between two equal values no entity has changed its class (batched or not) */
+uint32_t gpu_scene_walk_generation(const struct gpu_scene *gs);
 bool gpu_scene_entity_is_batched(struct gpu_scene *gs, entity3d *e);
 
 /*
