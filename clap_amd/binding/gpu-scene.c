@@ -125,6 +125,7 @@ struct gpu_scene {
      * look-up, no cache miss beside the entity it has just written; the frame's mirror pass resolves the addresses
      * through a flat table (address -> record, mirror handle) rebuilt by every walk, on all worker threads */
     entity3d        **xptr; uint32_t n_xptr, cap_xptr;
+    uint64_t        *claim; uint32_t cap_claim;                    /* one bit per slot: taken by a worker of this frame's address-list pass */
     struct gs_fast { uint64_t key; uint32_t handle, slot; } *ftab; uint32_t ftab_mask, ftab_cap;
     uint32_t        *host_list; uint32_t n_host, cap_host;         /* host-class records in list order (last walk) */
     uint32_t        *deferred; uint32_t n_deferred, cap_deferred;  /* class 3 records in list order (last walk) */
@@ -296,7 +297,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->shown); free(gs->xptr); free(gs->ftab);
-    free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands);
+    free(gs->claim); free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands);
     free(gs->walk_fetch); free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
@@ -777,14 +778,20 @@ static void xptr_range(void *ctx, uint32_t lo, uint32_t hi)
             if (h != NO_REC) {
                 const struct gs_fast *f = &gs->ftab[h];
                 entity3d *e = (entity3d *)(uintptr_t)f->key;
-                const bool upd = transform_is_updated(&e->xform);
-                const int rc = xc->mt ? clapgpu_scene_entity_xform_mt(gs->scene, f->handle, transform_pos(&e->xform, NULL),
-                                                                      transform_rotation_quat(&e->xform), e->scale, upd)
-                                      : (upd ? clapgpu_scene_entity_transform(gs->scene, f->handle, transform_pos(&e->xform, NULL),
-                                                                              transform_rotation_quat(&e->xform), e->scale) : 0);
-                if (rc) xc->rc = rc;
-                if (gs->drawn_now && upd) transform_clear_updated(&e->xform);   /* see mirror_one */
-                pushed++;
+                /* an entity moved twice this frame is on the list twice: between workers, whoever claims its slot first
+                 * takes it (every entry would push the same, final, transform; two workers on one entity3d race) */
+                const bool taken = xc->mt && f->slot < gs->cap_claim &&
+                    ((__atomic_fetch_or(&gs->claim[f->slot >> 6], 1ull << (f->slot & 63), __ATOMIC_RELAXED) >> (f->slot & 63)) & 1);
+                if (!taken) {
+                    const bool upd = transform_is_updated(&e->xform);
+                    const int rc = xc->mt ? clapgpu_scene_entity_xform_mt(gs->scene, f->handle, transform_pos(&e->xform, NULL),
+                                                                          transform_rotation_quat(&e->xform), e->scale, upd)
+                                          : (upd ? clapgpu_scene_entity_transform(gs->scene, f->handle, transform_pos(&e->xform, NULL),
+                                                                                  transform_rotation_quat(&e->xform), e->scale) : 0);
+                    if (rc) xc->rc = rc;
+                    if (gs->drawn_now && upd) transform_clear_updated(&e->xform);   /* see mirror_one */
+                    pushed++;
+                }
             }
         }
         if (k < hi) {
@@ -1343,6 +1350,7 @@ struct par_job {
     uint32_t count;             /* out: uploaded / written back */
     int need_walk, rc;
     uint32_t *deferred; uint32_t n_deferred, cap_deferred;       /* children whose parent lies in an earlier chunk */
+    uint32_t *whole; uint32_t n_whole, cap_whole;                /* entities updated on the host since the last frame (host_done): left out */
     void (*range_fn)(void *, uint32_t, uint32_t); void *ctx;     /* gpu_scene_par_for */
 };
 
@@ -1566,10 +1574,14 @@ static void *par_scatter(void *arg)
             }
         }
         if (r->cls != 1 || r->slot >= res->n_slots || !((j->scat[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+        if (r->host_done) {                                      /* see frame_results: after the join, on one thread */
+            if (push_u32(&j->whole, &j->n_whole, &j->cap_whole, gs->order[k])) j->rc = _CERR_NOMEM;
+            continue;
+        }
         bool here = true;
         if (r->e->parent) {
             const uint32_t pr = r->parent_rec;
-            here = pr != NO_REC && gs->rec[pr].e == r->e->parent && gs->rec[pr].order_pos >= j->lo;
+            here = pr != NO_REC && gs->rec[pr].e == r->e->parent && gs->rec[pr].order_pos >= j->lo && !gs->rec[pr].host_done;
             if (!here && push_u32(&j->deferred, &j->n_deferred, &j->cap_deferred, gs->order[k])) j->rc = _CERR_NOMEM;
         }
         scatter_one(gs, r, res, r->slot, here);
@@ -1600,10 +1612,15 @@ static void *par_scatter_mask(void *arg)
             if (!u) continue;
             struct gs_rec *r = &gs->rec[u - 1];
             if (r->cls != 1 || !r->e) continue;                  /* class 4: after the pose, from the second launch */
+            if (r->host_done) {
+                if (push_u32(&j->whole, &j->n_whole, &j->cap_whole, (uint32_t)(u - 1))) j->rc = _CERR_NOMEM;
+                continue;
+            }
             bool here = true;
             if (r->e->parent) {
                 const uint32_t pr = r->parent_rec;
-                here = pr != NO_REC && gs->rec[pr].e == r->e->parent && gs->rec[pr].slot >= j->lo * 64u && gs->rec[pr].slot < slot;
+                here = pr != NO_REC && gs->rec[pr].e == r->e->parent && gs->rec[pr].slot >= j->lo * 64u && gs->rec[pr].slot < slot &&
+                       !gs->rec[pr].host_done;
                 if (!here && push_u32(&j->deferred, &j->n_deferred, &j->cap_deferred, (uint32_t)(u - 1))) j->rc = _CERR_NOMEM;
             }
             scatter_one(gs, r, res, slot, here);
@@ -1611,6 +1628,13 @@ static void *par_scatter_mask(void *arg)
         }
     }
     return NULL;
+}
+
+static int rec_slot_cmp(const void *a, const void *b, void *ctx)
+{
+    const struct gpu_scene *gs = ctx;
+    const uint32_t x = gs->rec[*(const uint32_t *)a].slot, y = gs->rec[*(const uint32_t *)b].slot;
+    return x < y ? -1 : x > y;
 }
 
 static void *par_deferred(void *arg)
@@ -1772,6 +1796,13 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     if (gs->n_xptr) {
         struct xptr_ctx xc = { .gs = gs, .mt = gs->n_xptr >= mirror_par_min && par_threads() > 1 };
         if (xc.mt) {
+            const uint32_t need = clapgpu_scene_slot_count(gs->scene);
+            if (need > gs->cap_claim) {
+                uint64_t *q = realloc(gs->claim, ((size_t)need / 64 + 1) * 8);
+                if (!q) return _CERR_NOMEM;
+                gs->claim = q; gs->cap_claim = need;
+            }
+            memset(gs->claim, 0, ((size_t)gs->cap_claim / 64 + 1) * 8);
             gpu_scene_par_for(xptr_range, &xc, gs->n_xptr, par_threads());
             clapgpu_scene_mark_all_dirty(gs->scene);
         } else
@@ -1852,11 +1883,36 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
             jobs[t] = (struct par_job){ .gs = gs, .res = &res, .scat = scat, .lo = (uint32_t)((uint64_t)span * t / nt),
                                         .hi = (uint32_t)((uint64_t)span * (t + 1) / nt) };
         par_run(sparse ? par_scatter_mask : par_scatter, jobs, nt);
-        par_run(par_deferred, jobs, nt);
+        /* Entities updated on the host since the last frame (entity3d_update / _reset, instantiate_entity: few).  For them
+         * scatter_one DECIDES by the parent's counters -- did the parent move on since, or has the device merely caught up? --
+         * and that must not be read while another worker is half-way through writing them (found on the GPU box: the sum read
+         * between the two stores said "not moved", and a rebuild was dropped).  So the workers leave them out (and mark their
+         * children for the parent_seq pass below); here, with every other entity final, they follow on this thread, parents
+         * first (ascending slot); then the children's parent_seq, which reads final counters only. */
         int rc = 0;
+        uint32_t n_whole = 0;
+        for (int t = 0; t < nt; t++) { if (jobs[t].rc) rc = jobs[t].rc; n_whole += jobs[t].n_whole; }
+        if (n_whole && !rc) {
+            uint32_t *all = malloc((size_t)n_whole * sizeof(*all)), at = 0;
+            if (!all) rc = _CERR_NOMEM;
+            for (int t = 0; t < nt && all; t++) {
+                if (jobs[t].n_whole) memcpy(all + at, jobs[t].whole, (size_t)jobs[t].n_whole * sizeof(*all));
+                at += jobs[t].n_whole;
+            }
+            if (all) {
+                qsort_r(all, n_whole, sizeof(*all), rec_slot_cmp, gs);
+                for (uint32_t k = 0; k < n_whole; k++) {
+                    struct gs_rec *r = &gs->rec[all[k]];
+                    scatter_one(gs, r, &res, r->slot, true);
+                    st->written_back++;
+                }
+                free(all);
+            }
+        }
+        if (!rc) par_run(par_deferred, jobs, nt);
         for (int t = 0; t < nt; t++) {
             st->written_back += jobs[t].count;
-            free(jobs[t].deferred);
+            free(jobs[t].deferred); free(jobs[t].whole);
             if (jobs[t].rc) rc = jobs[t].rc;
         }
         if (rc) return rc;

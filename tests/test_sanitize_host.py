@@ -122,6 +122,11 @@ def test_recycled_entity_addresses_without_a_sanitizer():
         assert _run(exe, *args)["mismatches"] == 0, args
     r = _run(exe, "bench", 20000, 12, 300, "notify", "drawn", "churn", 60)
     assert r["mismatches"] == 0 and r["fast_frames"] == 12 and r["draw_reads_equal"] is True
+    # every worker pass from a few hundred entities on (the thresholds are environment knobs): the orderings the passes rely on
+    forced = {"GPU_SCENE_THREADS": "6", "GPU_SCENE_MIRROR_PAR_MIN": "200", "GPU_SCENE_SCATTER_PAR_MIN": "100"}
+    for args in (("test", 200000, 12, 11, "notify", "drawn", "comeandgo", "plain"), ("test", 17000, 8, 705, "notify", "drawn", "comeandgo"),
+                 ("test", 4000, 12, 720, "notify", "steady"), ("test", 17000, 8, 731, "steady")):
+        assert _run(exe, *args, env=forced)["mismatches"] == 0, args
 
 
 def test_mirror_edits_in_place_under_asan_ubsan():
@@ -157,6 +162,14 @@ def test_worker_pool_passes_under_tsan():
     # no notifications: the queue check and the mirror pass over EVERY record on the workers
     r = _run(exe, "bench", 140000, 3, 1000, env={"GPU_SCENE_THREADS": "6"})
     assert r["mismatches"] == 0 and r["frames_by_the_records"] == 3
+    # the scripted game (entities moved twice a frame, updated on the spot, made and deleted) with every pass FORCED onto the
+    # workers from a few hundred entities on: found on the GPU box and pinned here -- a child updated on the host read its
+    # parent's counters half-way through another worker's write-back; an entity that is twice on the address list was taken
+    # by two workers at once
+    forced = {"GPU_SCENE_THREADS": "6", "GPU_SCENE_MIRROR_PAR_MIN": "500", "GPU_SCENE_SCATTER_PAR_MIN": "300"}
+    for args in (("test", 30000, 10, 11, "notify", "drawn", "comeandgo", "plain"), ("test", 20000, 12, 13, "notify", "drawn", "steady"),
+                 ("test", 30000, 10, 12, "notify", "comeandgo"), ("test", 20000, 10, 14, "steady")):
+        assert _run(exe, *args, env=forced)["mismatches"] == 0, args
     # ... with entities made and deleted between the frames: tombstone records and appended ones under the split passes
     r = _run(exe, "bench", 140000, 3, 1000, "notify", "drawn", "churn", 50, env={"GPU_SCENE_THREADS": "6"})
     assert r["mismatches"] == 0 and r["fast_frames"] == 3 and r["placed_in_layout"] > 100
