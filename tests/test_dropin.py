@@ -282,7 +282,7 @@ def test_entities_made_and_deleted_between_frames_are_not_walked(n, frames, chur
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [("notify", "drawn", "comeandgo", "plain"), ("notify", "comeandgo", "plain"), ("notify", "drawn", "comeandgo")],
                          ids=["drawn-plain", "all-plain", "drawn-any"])
-@pytest.mark.parametrize("n,frames,seed", [(300, 80, 5), (2500, 16, 1), (40000, 12, 3)])
+@pytest.mark.parametrize("n,frames,seed", [(300, 80, 5), (2500, 16, 1), (40000, 12, 3), (200000, 24, 11)])
 def test_scripted_game_with_entities_coming_and_going(n, frames, seed, mode):
     """The scripted game with creations and deletions in the frames that are not walked (`comeandgo`), moves, hides,
     host updates and -- every fourth frame -- re-parenting (a walk) in between; `plain`: what the game makes is plain and
@@ -293,6 +293,21 @@ def test_scripted_game_with_entities_coming_and_going(n, frames, seed, mode):
     # (at 40 000 entities the unrestricted game makes ~125 entities a frame, a third of the children listed BEFORE their
     # parents: some creation of every frame needs the walk)
     assert r["removed_in_place"] > 0 and (r["placed_in_layout"] > 0 or ("plain" not in mode and n >= 40000))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("notify", "drawn", "comeandgo", "plain"), ("notify", "drawn", "steady"), ("notify", "comeandgo"), ("steady",)],
+                         ids=["drawn-plain", "drawn-steady", "all", "no-notify"])
+def test_worker_passes_forced_from_a_few_hundred_entities(mode):
+    """The binding's worker passes (mirror pass, address-list pass, write-back in list order / off the mask, the pass over
+    every record of a frame without notifications) start at 12-16 k entities; the thresholds are environment knobs, and with
+    them at a few hundred the scripted game -- entities moved twice a frame, updated on the spot, made and deleted -- puts
+    every ordering the passes rely on to the test on every run, on a host with many cores (where a soak of this game found a
+    child reading its parent's counters half-way through another worker's write-back)."""
+    forced = {"GPU_SCENE_MIRROR_PAR_MIN": "300", "GPU_SCENE_SCATTER_PAR_MIN": "200"}
+    for n, frames, seed in ((4000, 16, 21), (17000, 10, 22), (60000, 8, 23)):
+        r = _run("test", n, frames, seed, *mode, env=forced)
+        assert r["mismatches"] == 0, (n, frames, seed, mode)
 
 
 @pytest.mark.gpu
