@@ -17,7 +17,7 @@
 #include "clapgpu_scene.h"
 #include "clap_oracle.h"
 
-#define MAXE 6000
+#define MAXE 60000
 static uint64_t rng_s = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd(void) { uint64_t z = (rng_s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
                             z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
@@ -197,6 +197,9 @@ static int add_entity(clapgpu_scene *s, uint32_t parent_idx)
 int main(int argc, char **argv)
 {
     const int wide = argc > 1 && !strcmp(argv[1], "wide");
+    /* optional: test_scene [wide|tiles] <seed> <frames of in-place edits>  (a soak: tests/test_scene_c.py runs the defaults) */
+    if (argc > 2) rng_s ^= strtoull(argv[2], NULL, 0) * 0x9E3779B97F4A7C15ull;
+    const int inplace_frames = argc > 3 ? atoi(argv[3]) : 4;
     clapgpu_scene *s;
     if (clapgpu_scene_create(&s, 0)) { fprintf(stderr, "create: %s\n", clapgpu_last_error()); return 2; }
     const float a0[6] = { -1, -2, -3, 1, 2, 3 }, a1[6] = { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f };
@@ -303,7 +306,7 @@ int main(int argc, char **argv)
     {
         clapgpu_scene_set_incremental(s, 1);
         uint32_t placed = 0, removed = 0, fell_back = 0, quiet_frames = 0;
-        for (int frame = 0; frame < 4; frame++) {
+        for (int frame = 0; frame < inplace_frames; frame++) {
             if (frame == 0) {                                /* one plain edit: the re-tile that leaves room */
                 if (add_entity(s, UINT32_MAX)) return 2;
                 if (clapgpu_scene_mq_update(s, &fr)) { fprintf(stderr, "mq_update: %s\n", clapgpu_last_error()); return 2; }
@@ -321,7 +324,9 @@ int main(int argc, char **argv)
                 else removed++;
                 ents[i].live = 0;
             }
-            for (int k = 0; k < 90 && n_ents < MAXE; k++) {
+            uint32_t n_live_now = 0;
+            for (uint32_t c = 0; c < n_ents; c++) n_live_now += ents[c].live;
+            for (int k = 0; k < 90 && n_ents < MAXE && n_live_now + (uint32_t)k < 2600; k++) {   /* (a long run stays around a steady population) */
                 uint32_t p = (k % 3 == 0) ? UINT32_MAX : (uint32_t)(rnd() % n_ents);
                 if (p != UINT32_MAX) {
                     uint32_t d = 0, x = p;
@@ -364,8 +369,8 @@ int main(int argc, char **argv)
         const int editable = clapgpu_scene_is_zero_copy(s) && clapgpu_scene_layout_is_tiled(s);
         if (editable && (placed < 100 || removed < 60 || !quiet_frames)) return fail("too few in-place edits in the scenario", placed);
         if (!editable && (placed || removed)) return fail("in-place edits on a layout that does not take them", placed);
-        printf("  layout edited in place: %u entities placed, %u removed, %u edits fell back to a re-tile, %u of 4 frames without one\n",
-               placed, removed, fell_back, quiet_frames);
+        printf("  layout edited in place: %u entities placed, %u removed, %u edits fell back to a re-tile, %u of %d frames without one\n",
+               placed, removed, fell_back, quiet_frames, inplace_frames);
     }
     /* ---- joint attachments: the frame's SECOND launch.  Some children ride "a joint of their parent": mq_update computes
      * everything else, attached_update (with the joints' matrices of the frame) the riders and everything below them. */

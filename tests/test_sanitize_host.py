@@ -145,6 +145,10 @@ def test_mirror_edits_in_place_under_asan_ubsan():
     assert p.returncode == 0 and "PASS" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
     assert "0 edits fell back to a re-tile, 4 of 4 frames without one" in p.stdout and " 0 entities placed" not in p.stdout
+    # a long run: lanes recycled, growth tiles, rows that fill up (the edit falls back, the frame re-tiles, then in place again)
+    p = subprocess.run([exe, "tiles", "5", "80"], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert p.returncode == 0 and "PASS" in p.stdout and p.stdout.count("frame ok") == 88, p.stdout[-1500:] + p.stderr[-2000:]
+    assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
 
 
 @pytest.mark.timeout(1500)

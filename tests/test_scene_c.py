@@ -94,6 +94,19 @@ def test_scene_mirror_frames_match_oracle(mode, path, cuda_device):
     assert ("small-frame path" if path == "small_frames" else "staged path") in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [7, 8])
+def test_scene_mirror_long_run_of_in_place_edits(seed, cuda_device):
+    """120 frames of creations and deletions that edit the standing layout in place (growth tiles, recycled lanes, rows that
+    fill up and fall back to a re-tile, then in place again), every frame and every LOD pass against the oracle."""
+    build_c_test()
+    r = subprocess.run([TEST_BIN, "tiles", str(seed), "120"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, CLAPGPU_SCENE_ZERO_COPY_SLOTS="4294967295"))
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("frame ok") == 8 + 120
+    assert " 0 entities placed" not in r.stdout and "of 120 frames without one" in r.stdout
+
+
 def test_quat_from_angles_matches_reference(golden_dir):
     """transform_set_angles (clamp, degrees, euler xyz -> quaternion): the host helper against the
     reference's own function, bit-exact (same libm)."""
