@@ -1711,6 +1711,9 @@ int main(int argc, char **argv)
 
 static int run(int argc, char **argv)
 {
+    /* the policy may also come from the environment (gpu_scene_init reads GPU_SCENE_SCATTER): the comparisons then have to
+     * fetch before they look at what nobody draws, in every mode */
+    if (getenv("GPU_SCENE_SCATTER") && !strcmp(getenv("GPU_SCENE_SCATTER"), "drawn")) opt_drawn = true;
     for (;;) {                                                           /* trailing options, any order */
         if (argc > 2 && !strcmp(argv[argc - 1], "notify")) { opt_notify = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "drawn")) { opt_drawn = true; argc--; }

@@ -170,6 +170,18 @@ def test_character_binding_matches_reference_character_update(n_chars, frames, s
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args", [("characters", 5000, 30, 2, "notify"), ("characters", 7, 40, 1, "notify"), ("anim", 500, 64, 30, 5, "notify"),
+                                  ("anim", 50, 200, 20, 4, "notify")], ids=["characters-5000", "characters-7", "anim-500x64", "anim-50x200"])
+def test_characters_and_animation_under_the_drawn_write_back_policy(args):
+    """GPU_SCATTER_DRAWN forced through the environment (GPU_SCENE_SCATTER=drawn, as a maintainer would try it) for the modes
+    whose entities have standing host readers: body-less characters (their hook's host half reads the entity), animated
+    entities, the props riding their joints through the frame's second launch.  The checker fetches before it compares what
+    nobody draws; everything else must be current by the policy's own rules."""
+    r = _run(*args, env={"GPU_SCENE_SCATTER": "drawn"})
+    assert r["mismatches"] == 0 and r.get("differing_objects", 0) == 0 and r.get("joint_attached_differing", 0) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("frames,seed", [(30, 1), (60, 2)])
 def test_light_grid_binding_matches_reference_light_grid_compute(frames, seed):
     """light_grid_compute on the reference's own struct light vs gpu_light_grid_compute (binding -> HIP): the
