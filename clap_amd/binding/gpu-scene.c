@@ -168,6 +168,7 @@ struct gpu_scene {
     entity3d        **created; uint32_t n_created, cap_created;    /* reported since the last update, in creation order */
     uint32_t        *dead_recs; uint32_t n_dead_recs, cap_dead_recs;   /* records of entities taken out in place: tombstones in order[] until the next walk */
     struct gs_wtxm { const model3dtx *txm; uint32_t next, first; } *wtxm; uint32_t n_wtxm, cap_wtxm;   /* the queue's txmodels in list order (last walk); the next list position in each */
+    bool            in_frame;                                      /* gpu_mq_update() is running (its hooks may call back into the notifications) */
     bool            replay, replaying;                             /* frames without notifications may go by the records (queue_unchanged); this frame does */
     bool            incremental, roomy;                            /* allowed; the mirror's re-tiles leave room (from the first entity that came or went between frames) */
     bool            appended;                                      /* order[] is no longer in list order: entities were taken in since the last walk */
@@ -412,7 +413,7 @@ void gpu_scene_run_deferred(struct gpu_scene *gs, struct mq *mq)
     }
     for (uint32_t k = 0; k < gs->n_deferred; k++) {
         struct gs_rec *r = &gs->rec[gs->deferred[k]];
-        if (r->e && entity3d_matches(r->e, ENTITY3D_ALIVE))
+        if (r->e && !r->gone && entity3d_matches(r->e, ENTITY3D_ALIVE))
             entity3d_update(r->e, mq->priv);
     }
 }
@@ -863,7 +864,7 @@ void gpu_scene_entity_deleting(struct gpu_scene *gs, entity3d *e)
 {
     if (!gs || !e) return;
     if (gs->notify && gs->incremental && gs->walked) want_room(gs);
-    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending) {
+    if (!gs->notify || !gs->incremental || !gs->walked || gs->topology_pending || gs->in_frame) {
         /* the next update walks the queue.  If the allocator hands this entity3d's memory to a new entity before then, the walk
          * meets a familiar address: the record says that it is not the entity it knew (same model, xform.updated cleared by an
          * instantiate_entity-style default_update: nothing else would tell, and the device would keep the old transform) */
@@ -1681,6 +1682,7 @@ static void pend_range(void *ctx, uint32_t lo, uint32_t hi)
 /* a host-class entity's own hook in a fast frame */
 static void host_hook(struct gpu_scene *gs, struct mq *mq, struct gs_rec *hr)
 {
+    if (hr->gone || !hr->e) return;                              /* deleted by a hook that ran earlier in this frame */
     if (hr->lag) {
         /* listed before its batched parent: the reference has not updated that parent yet when this hook runs */
         struct lag_keep *kp = &gs->lag_keep[hr->lag - 1], now;
@@ -1998,7 +2000,7 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
                 host_hook(gs, mq, &gs->rec[gs->host_list[hc++]]);
             else {
                 const struct gs_rec *cr = &gs->rec[gs->cands[ci++].rec];
-                if (cr->cls == 1 && cr->e) bv_pick(scene, cr->e);
+                if (cr->cls == 1 && cr->e && !cr->gone) bv_pick(scene, cr->e);
             }
         }
     } else {
@@ -2034,7 +2036,7 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
             host_hook(gs, mq, &gs->rec[gs->host_list[hc++]]);
         } else {
             cm &= cm - 1;
-            if (gs->rec[gs->order[co]].cls == 1)                 /* class 4 boxes are last frame's until the second launch */
+            if (gs->rec[gs->order[co]].cls == 1 && !gs->rec[gs->order[co]].gone)   /* class 4 boxes are last frame's until the second launch */
                 bv_pick(scene, gs->rec[gs->order[co]].e);
         }
     }
@@ -2093,9 +2095,22 @@ static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
     return !qc.changed;
 }
 
+static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *view);
+
 int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
     if (!gs || !mq) return _CERR_INVALID_ARGUMENTS;
+    /* a hook that runs inside the frame may delete entities (the reference's list walk takes that in its stride): nothing is
+     * taken out of the lists the frame is iterating -- gpu_scene_entity_deleting() marks the record, the rest of the frame
+     * skips it, the next frame walks */
+    gs->in_frame = true;
+    const int rc = mq_update_frame(gs, mq, view);
+    gs->in_frame = false;
+    return rc;
+}
+
+static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
+{
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
     gs->hook_data = mq->priv;
@@ -2385,6 +2400,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
         e = r->e;
+        if (r->gone) continue;                                   /* deleted by a hook that ran earlier in this very pass: freed memory */
         if (k + 8 < gs->n_order) {
             /* the entity eight steps ahead, and its rows of the download (DMA left them out of the caches) */
             const struct gs_rec *a = &gs->rec[gs->order[k + 8]];
@@ -2406,7 +2422,7 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
         if (r->cls != 1) {
             st->host++;
             if (r->cls == 3) continue;                           /* after the pose: gpu_scene_run_deferred() */
-            entity3d_update(e, mq->priv);
+            if (!r->gone) entity3d_update(e, mq->priv);          /* (gone: deleted by a hook that ran earlier in this very pass) */
             continue;
         }
         st->batched++;

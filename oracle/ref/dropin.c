@@ -152,6 +152,13 @@ static int wobble_update(entity3d *e, void *data)
     return default_update(e, data);
 }
 
+/* A hook that deletes ANOTHER entity of the queue while the frame is running (a pickup collected, a projectile that hits):
+ * the reference's list walk unlinks it and goes on.  Fires on its `killer_at`-th call in each world. */
+static struct world A, B;
+static uint32_t killer_id = 0xffffffffu, killer_victim = 0xffffffffu, killer_at, killer_calls[2];
+static struct meta *meta;
+static int killer_update(entity3d *e, void *data);
+
 static void world_init(struct world *w, uint32_t cap)
 {
     static const float boxes[N_MODELS][6] = {
@@ -194,8 +201,19 @@ static void view_set(struct world *w, const float *pos, const float *quat)
 struct meta { uint8_t model; uint8_t alive; uint8_t hooked; uint32_t parent; uint32_t n_children; };
 #define NONE 0xffffffffu
 
-static struct world A, B;
-static struct meta *meta;
+/* (A, B and meta are declared above, before the hooks) */
+static int killer_update(entity3d *e, void *data)
+{
+    const int k = e == B.e[killer_id];                                   /* which world's killer */
+    struct world *w = k ? &B : &A;
+    if (++killer_calls[k] == killer_at && killer_victim != 0xffffffffu && w->e[killer_victim]) {
+        if (k) entity3d_delete(w->e[killer_victim]);                     /* the engine's name: the binding hears of it IN the frame */
+        else ref_entity3d_delete(w->e[killer_victim]);
+        w->e[killer_victim] = NULL;
+        if (k) meta[killer_victim].alive = 0;                            /* (world A's frame runs first) */
+    }
+    return default_update(e, data);
+}
 static uint32_t n_ids, cap_ids;
 
 /* Any live entity created earlier may be a parent (no cycles).  When its model list comes AFTER the child's,
@@ -842,6 +860,27 @@ static int cmd_edge(void)
         gpu_scene_done(gs); cases++;
     }
     edge_direct = false;
+    /* a hook deletes another entity while the frame runs: a batched one listed after it, then a host-class one; walked
+     * frames and notified ones.  The reference's walk unlinks the victim and goes on; the binding must not touch it again in
+     * this frame (its hook, its write-back, the bounding-volume pick) and meets the queue anew in the next */
+    for (int mode = 0; mode < 4; mode++) {
+        struct gpu_scene *gs; if (gpu_scene_init(&gs, 0, default_update)) return 2;
+        edge_reset();
+        edge_notify = mode & 1;
+        edge_fast_frames = 0;
+        mk(0, NONE, false, true);                                        /* id 0: the killer (list 0: first in the queue) */
+        for (int i = 1; i < 30; i++) mk(1 + i % 2, NONE, i % 7 == 0, true);   /* lists 1 and 2 behind it; every seventh hooked */
+        mk(1, 3, false, true); mk(2, 31 - 1, false, true);              /* some children */
+        killer_id = 0; killer_calls[0] = killer_calls[1] = 0; killer_at = 3;
+        killer_victim = (mode & 2) ? 7u : 5u;                            /* 7: hooked (host-class), 5: plain (batched) */
+        A.e[0]->update = killer_update; B.e[0]->update = killer_update; meta[0].hooked = 1;
+        gpu_scene_bind(gs, B.mq, &B.view);                               /* (the engine's entity3d_delete reports to the BOUND scene) */
+        bad += edge_frames(gs, mode == 0 ? "a hook deletes a batched entity in mid-frame (walk)" : mode == 1 ? "... (notify)" :
+                               mode == 2 ? "a hook deletes a host-class entity in mid-frame (walk)" : "... (notify)", 6, 60);
+        if (meta[killer_victim].alive) { fprintf(stderr, "the killer never fired\n"); bad++; }
+        killer_id = killer_victim = 0xffffffffu;
+        gpu_scene_done(gs); cases++;
+    }
     edge_notify = false;
     edge_no_view = false; edge_no_scene = true;
     CASE("a queue without a scene (priv == NULL)", 57, { for (int i = 0; i < 20; i++) mk(i % 3, NONE, i == 7, true); });

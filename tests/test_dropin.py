@@ -204,7 +204,7 @@ def test_binding_edge_cases():
     past the mutators in notification mode with the verification aid on (found, reported, taken in the same frame), and a
     queue emptied and repopulated."""
     r = _run("edge")
-    assert r["mismatches"] == 0 and r["cases"] == 19
+    assert r["mismatches"] == 0 and r["cases"] == 23         # (incl. four where a hook deletes another entity while the frame runs)
 
 
 @pytest.mark.gpu
