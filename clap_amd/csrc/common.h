@@ -76,9 +76,9 @@ __device__ __forceinline__ void unstage_mat4(const float4 *tile, float4 (&v)[4],
 // release build by a stray EXTRA= flag: every such macro requires -DCLAPGPU_EXPERIMENT, and an experiment build
 // reports an ABI version with the top bit set (runtime.hip), which clap_amd/_lib.py and any caller checking
 // clapgpu_abi_version() against its header refuse to load.
-#if defined(CLAPGPU_EXP_NO_INVERT) || defined(CLAPGPU_EXP_NO_AABB) || defined(CLAPGPU_PLAIN_STORES) || defined(BP_T) || defined(BP_MAXC) || defined(BP_WGS_PER_CU) || defined(BP_EXP_SKIP) || defined(BP_EXP_TIMING) || defined(BP_CAP_X) || defined(BP_OWN_UNROLL) || defined(BP_WAVES_PER_SIMD)
+#if defined(CLAPGPU_EXP_NO_INVERT) || defined(CLAPGPU_EXP_NO_AABB) || defined(CLAPGPU_PLAIN_STORES) || defined(BP_SEARCH_IN_FLIGHT)
 #  ifndef CLAPGPU_EXPERIMENT
-#    error "CLAPGPU_EXP_* / CLAPGPU_PLAIN_STORES / BP_* are experiment switches: add -DCLAPGPU_EXPERIMENT (the library then reports an experiment ABI version)"
+#    error "CLAPGPU_EXP_* / CLAPGPU_PLAIN_STORES / BP_SEARCH_IN_FLIGHT are experiment switches: add -DCLAPGPU_EXPERIMENT (the library then reports an experiment ABI version)"
 #  endif
 #endif
 

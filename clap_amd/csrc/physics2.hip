@@ -5,10 +5,9 @@
 //   k_bodies_step     dWorldQuickStep's body stage (quickstep.cpp stage 0 + dxStepBody + auto-disable), fused with
 //                     the moved geom's axis / AABB (dxCapsule::computeAABB)                      HBM-bound, 1 lane / body
 //   k_bp_*            dSpaceCollide2(ground, bodies) + dSpaceCollide(bodies) (physics.c:751-753) as ascending
-//                     candidate-pair lists, three launches for both passes (two when the step has binned): bodies
-//                     placed by AABB centre straight into a fixed-capacity cell table (hash grid of 4x4x4-cell blocks),
-//                     searched one workgroup per block with the block and its one-cell shell staged in LDS, emitted in
-//                     index order (section comment below)
+//                     candidate-pair lists, five launches for both passes: bodies binned by AABB centre into a hash
+//                     grid of 4x4x4-cell blocks, copied into cell order, searched one wavefront per 16-body tile with
+//                     the candidates of each distinct cell listed once in LDS (section comment below)
 //   k_contacts_geoms  near_callback's dCollide + phys_contact_surface (physics.c:399-449, 291-330)
 //   k_sweep_capsules  phys_body_sweep_capsule (physics.c:559-670), one wavefront per sweep
 // fp64 throughout (the reference builds ODE with dDOUBLE, physics.h:5-9), no FMA contraction.
@@ -16,7 +15,6 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
-#include <type_traits>
 #include "common.h"
 #include "phys_dev.h"
 
@@ -51,13 +49,10 @@ struct BodiesK {
     double *geom_records;
 };
 
-// The next broadphase's first launch (k_bp_bin: one atomic on the cell's counter and the body's 64-byte record into the
-// cell table) done by the step that writes the box it would read: clapgpu_bodies_step_prebin.
-struct BpRec;
-struct BinK { double cell; uint32_t mask, slots; uint32_t *cell_cnt; uint8_t *bflag; BpRec *table, *ovf; uint32_t *ctrl; };
-__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t par, uint32_t i, const double (&bb)[6]);
-__device__ __forceinline__ void bin_open(uint32_t *ctrl, uint32_t par);
-__device__ __forceinline__ uint32_t bin_parity(const uint32_t *ctrl);
+// The next broadphase's first launch (k_bp_bin: one atomic per body on its cell's counter) done by the step that writes the
+// box it would read: clapgpu_bodies_step_prebin.  key == nullptr: off.
+struct BinK { double cell; uint32_t mask; uint32_t *key, *rank, *cell_cnt, *ctrl; };
+__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t i, const double (&bb)[6]);
 
 __device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const double (&p)[3], const double (&q)[4],
                                            double (*bb_out)[6] = nullptr)
@@ -84,12 +79,12 @@ __device__ __forceinline__ void write_geom(const BodiesK &b, uint32_t i, const d
 }
 
 // a body the step leaves alone keeps its stored box: binned from there
-__device__ __forceinline__ void bin_stored(const BinK &bin, uint32_t par, const BodiesK &b, uint32_t i)
+__device__ __forceinline__ void bin_stored(const BinK &bin, const BodiesK &b, uint32_t i)
 {
     const double2 *p = reinterpret_cast<const double2 *>(b.aabb + 6 * (size_t)i);
     const double2 x = p[0], y = p[1], z = p[2];
     const double bb[6] = { x.x, x.y, y.x, y.y, z.x, z.y };
-    bin_body(bin, par, i, bb);
+    bin_body(bin, i, bb);
 }
 
 __global__ __launch_bounds__(PB)
@@ -107,14 +102,10 @@ __global__ __launch_bounds__(PB)
 void k_bodies_step(BodiesK b, WorldK2 w, double h, BinK bin)
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    uint32_t par = 0;
-    if (BIN) {
-        par = bin_parity(bin.ctrl);
-        if (i == 0) bin_open(bin.ctrl, par);                            // what k_bp_bin's first thread does
-    }
+    if (BIN && i == 0) bin.ctrl[3] = bin.ctrl[3] + 1;                   // CTRL_EPOCH: what k_bp_bin's first thread does
     if (i >= b.n) return;
     uint32_t fl = b.bflags[i];
-    if (fl & CLAPGPU_BODY_DISABLED) { if (BIN) bin_stored(bin, par, b, i); return; }
+    if (fl & CLAPGPU_BODY_DISABLED) { if (BIN) bin_stored(bin, b, i); return; }
     double *pp = b.pos + 3 * (size_t)i, *qp = b.quat + 4 * (size_t)i, *vp = b.lvel + 3 * (size_t)i, *op = b.avel + 3 * (size_t)i;
     double v[3] = { vp[0], vp[1], vp[2] }, om[3] = { op[0], op[1], op[2] };
 
@@ -154,7 +145,7 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h, BinK bin)
             b.bflags[i] = (fl | CLAPGPU_BODY_DISABLED) & ~CLAPGPU_BODY_HAS_JOINT;
             vp[0] = vp[1] = vp[2] = 0;
             op[0] = op[1] = op[2] = 0;
-            if (BIN) bin_stored(bin, par, b, i);
+            if (BIN) bin_stored(bin, b, i);
             return;
         }
     }
@@ -233,7 +224,7 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h, BinK bin)
     if (BIN) {
         double bb[6];
         write_geom(b, i, p, q, &bb);
-        bin_body(bin, par, i, bb);
+        bin_body(bin, i, bb);
     } else
         write_geom(b, i, p, q);
 }
@@ -241,61 +232,31 @@ void k_bodies_step(BodiesK b, WorldK2 w, double h, BinK bin)
 // ================================================================================== broadphase
 // Hash grid over the AABB centres, cell >= the largest body AABB edge, so a body's partners have their centres in
 // the 27 cells around its own.  Cells are grouped in 4x4x4 blocks: a cell's slot = (hash of its block) * 64 + its
-// position inside the block.  Every slot owns BP_CAP 64-byte records of ONE table: the pass that has a body's box in
-// registers (k_bodies_step<BIN>, or k_bp_bin for boxes somebody else wrote) takes a rank in the cell with one atomic
-// and stores the record -- box, index, cell coordinates -- straight at table[slot][rank]; the few bodies of a cell
-// beyond BP_CAP go to one overflow list.  No prefix over the cells, no copy into cell order.
-// Three launches for BOTH passes of __phys_step (bodies x bodies and statics x bodies), two when the step has binned:
-//   k_bp_bin      (or the step) one atomic + one 64-byte store per body
-//   k_bp_search   a fixed grid of workgroups shares the occupied buckets (the bin pass sets a byte per bucket; every
-//                 workgroup ranks the bytes for itself): the records of a block's 4x4x4 cells and of the one-cell shell around them
-//                 (6x6x6 slots, read once, 1 KiB apiece at most) are staged in LDS -- up to four blocks in one image
-//                 where the scene is sparse; one wavefront per row of four cells tests the row's bodies against the
-//                 nine rows of six cells around it -- candidates one per lane from LDS, the row's bodies one after the
-//                 other through the scalar cache -- and a body's partners with a LARGER index are written by ballot rank into its list:
-//                 every body's list has one writer, so there is no atomic and no counter to clear.  The large statics
-//                 are staged beside, a bucket's own are read from memory; overflow bodies near the blocks are read
-//                 from their list; then the overflow bodies themselves, one wavefront per body.
-//   k_bp_emit     one thread per body in index order: offset = tile offset (look-back scan over the 1024-body tiles) +
+// position inside the block, so the 64 cells of a block are neighbours in memory and the per-frame prefix work
+// splits into a wave-sized piece per block (k_bp_cells) and a scan over the block totals.
+// Five launches for BOTH passes of __phys_step (bodies x bodies and statics x bodies):
+//   k_bp_bin      one atomic per body on its cell's counter (the return value is its rank in the cell)
+//   k_bp_cells    one wavefront per block: exclusive prefix of its 64 cell counts; block starts by a single-pass scan
+//                 with decoupled look-back over the workgroups' totals
+//   k_bp_scatter  64-byte records (box, index, cell coordinates) into cell order
+//   k_bp_search   one wavefront per tile of 16 bodies in cell order; candidates (own cell: partners with a larger
+//                 index; the 13 cells after it; the statics registered for the block) listed once per DISTINCT cell /
+//                 block bucket of the tile in an LDS work list and tested against the tile's boxes; hits go to the
+//                 partner list of min(i, j); then the large statics from LDS
+//   k_bp_emit     one thread per body in index order: offset = tile offset (look-back scan over the 256-body tiles) +
 //                 scan inside the tile, its list written in ascending partner order, so the output is the canonical
-//                 ascending list whatever order the ranks took
+//                 ascending list whatever order the atomics took
 // Two different cells of one 3x3x3 neighbourhood never share a slot (same position inside a block means at least four
-// cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge).  A row of SIX cells
-// can meet one slot twice (x = -1 and x = 3 of neighbouring blocks whose hashes collide): a staged record counts only
-// under the cell it was binned for.
-// The cell counters are double-buffered by a parity kept on the device (a captured graph replays the same arguments):
-// the search of one pass clears the counters the NEXT bin will use, so nothing is cleared by a launch of its own.
+// cells apart), and a body from a far block that shares a slot cannot overlap (cell >= every edge), so candidates need
+// no cell check beyond the box test.
 constexpr int BP_LIST = 16;            // partners kept per body in its fixed slot
-#ifndef BP_CAP_X
-#define BP_CAP_X 16
-#endif
-constexpr int BP_CAP = BP_CAP_X;             // records per cell slot (configs[3]: 4-5 bodies per cell for the capsule mix, 12 at most for spheres)
+constexpr int BP_TILE = 16;            // bodies per wavefront of the search
+constexpr int BP_WORK = 512;           // candidate entries listed per tile and round (256: spheres -2 us, capsules +5 us)
 constexpr int BP_EMIT_TILE = 1024;     // bodies per tile of the pair-offset scan (= emit block; 256: +3 us, four times the look-back words)
-#ifndef BP_T
-#define BP_T 512                       // threads of a search workgroup
+#ifndef BP_SEARCH_IN_FLIGHT
+#define BP_SEARCH_IN_FLIGHT 1            // candidate records gathered per lane and round
 #endif
-#ifndef BP_MAXC
-#define BP_MAXC 1280                   // records staged per pass: 6x6x6 slots at ~5 bodies a cell; 80 KB of LDS, two workgroups a CU
-#endif
-#ifndef BP_WGS_PER_CU
-#define BP_WGS_PER_CU 2                // what the LDS image allows
-#endif
-#ifndef BP_WAVES_PER_SIMD
-#define BP_WAVES_PER_SIMD 4            // BP_WGS_PER_CU workgroups of BP_T threads on a CU's four SIMDs: the register budget
-#endif
-#ifndef BP_EXP_SKIP
-#define BP_EXP_SKIP 0                  // experiment builds only: 1 no body rounds, 2 no static rounds
-#endif
-#ifdef BP_EXP_TIMING                   // experiment builds only: thread 0 of every search workgroup adds its phase cycles (>> 4) to ctrl[32 + phase]
-#define BP_TICK(ph) do { if (tid == 0) { const uint64_t now__ = __builtin_readcyclecounter(); atomicAdd(&k.ctrl[32 + (ph)], (uint32_t)((now__ - tick__) >> 4)); tick__ = now__; } } while (0)
-#else
-#define BP_TICK(ph) do { } while (0)
-#endif
-constexpr int BP_MINE = 128;           // buckets of a search workgroup listed at a time
-constexpr int BP_NB = 4;               // buckets a search workgroup takes per trip (sparse scenes: their blocks share one LDS image)
-constexpr int BP_SMAX = 64;            // large statics staged per workgroup; more are read from memory
-constexpr int BP_OVL = 128;            // overflow bodies near a trip's blocks kept as an LDS index list; more: every one is tested
-constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3, CTRL_OVF = 4 /* [2] by parity */, CTRL_PAR_NEXT = 6, CTRL_PAR_CUR = 7, CTRL_CONTACT_WORD = 8;   // [8..9]: clapgpu_contacts_geoms_both's ticket + counts, zero between launches
+constexpr int CTRL_STATUS = 2, CTRL_EPOCH = 3, CTRL_CONTACT_WORD = 8;   // [8..9]: clapgpu_contacts_geoms_both's ticket + counts, zero between launches     // the frame counter lives on the device: a captured graph replays the same arguments
 
 __host__ __device__ __forceinline__ uint32_t block_hash(int32_t bx, int32_t by, int32_t bz, uint32_t mask)
 {
@@ -316,21 +277,22 @@ __host__ __device__ __forceinline__ uint32_t cell_slot(int32_t cx, int32_t cy, i
     return block_hash(cx >> 2, cy >> 2, cz >> 2, mask) << 6 | (uint32_t)(cx & 3) | (uint32_t)(cy & 3) << 2 | (uint32_t)(cz & 3) << 4;
 }
 
-struct BpRec { double bb[6]; uint32_t idx; int32_t cell[3]; };    // 64 bytes; cell = the box centre's cell
+struct BpRec { double bb[6]; uint32_t idx; int32_t cell[3]; };    // 64 bytes; cell = the box centre's cell (dynamic records)
 
 struct BpK {
     uint32_t n;
     double cell;
     uint32_t mask;                       // block buckets - 1
-    uint32_t slots;                      // buckets * 64
     const double *aabb;
-    uint32_t *cell_cnt;                  // [2][slots] bodies binned to a slot, by parity; the idle half is zero
-    uint8_t  *bflag;                     // [2][buckets] bucket has a body (plain byte stores by the bin pass; ranked by every search workgroup)
-    struct BpRec *table;                 // [slots][BP_CAP]
-    struct BpRec *ovf;                   // [n_max] bodies of cells beyond BP_CAP
-    uint32_t *cnt, *scnt;                // [n] partners (larger index) / statics per body: written by the search, one writer each
+    uint32_t *cell_cnt;                  // [buckets * 64] the bin pass's counters, zero between frames
+    uint2    *cell_range;                // [buckets * 64] (first position in cell order, bodies) of every cell: one load per lookup
+    uint32_t *key, *rank;                // [n] cell slot and rank inside the cell
+    uint32_t *entries;                   // [n] body indices in cell order
+    struct BpRec *recs;                  // [n] the same with the boxes: what the search reads
+    uint32_t *cnt, *scnt;                // [n] partners (larger index) / statics per body: atomics in the search
     uint32_t *partners, *spartners;      // [n][BP_LIST]
     uint64_t *lb_body, *lb_static;       // [tiles] look-back words of the pair-offset scan (k_bp_emit)
+    uint64_t *lb_cells;                  // [buckets / 4] look-back words of the block-start scan (k_bp_cells)
     uint32_t *ctrl;
     uint32_t n_tiles;
     // statics (binned on the host at create time)
@@ -338,7 +300,7 @@ struct BpK {
     const uint32_t *s_entries;
     const double *s_aabb;
     const uint32_t *s_large;
-    const struct BpRec *s_recs;          // s_entries with their boxes (what the search reads)
+    const struct BpRec *s_recs;          // s_entries with their boxes (what the search gathers)
     const struct BpRec *s_lrecs;         // the large statics with their boxes
     uint32_t n_large, n_static;
     // outputs
@@ -365,55 +327,37 @@ __device__ __forceinline__ bool boxes_overlap(const double (&a)[6], const double
     return !(a[0] > b[1] || a[1] < b[0] || a[2] > b[3] || a[3] < b[2] || a[4] > b[5] || a[5] < b[4]);
 }
 
-// the same test on the staged form (min, max) per axis; NaN boxes overlap everything, as in the line above
-__device__ __forceinline__ bool boxes_apart(const double2 ax, const double2 ay, const double2 az,
-                                            const double2 bx, const double2 by, const double2 bz)
-{
-    return (ax.x > bx.y) | (ax.y < bx.x) | (ay.x > by.y) | (ay.y < by.x) | (az.x > bz.y) | (az.y < bz.x);
-}
-
-// One atomic (the rank in the cell) and one 64-byte store per body.  `par` = the counters' parity of this pass.
-__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t par, uint32_t i, const double (&bb)[6])
+__device__ __forceinline__ void bin_body(const BinK &bin, uint32_t i, const double (&bb)[6])
 {
     if (bb[1] - bb[0] > bin.cell || bb[3] - bb[2] > bin.cell || bb[5] - bb[4] > bin.cell)
         atomicOr(&bin.ctrl[CTRL_STATUS], 1u);
     int32_t cx, cy, cz;
     box_cell(bb, bin.cell, cx, cy, cz);
     const uint32_t slot = cell_slot(cx, cy, cz, bin.mask);
-    const uint32_t r = atomicAdd(&bin.cell_cnt[(size_t)par * bin.slots + slot], 1u);
-    bin.bflag[(size_t)par * (bin.mask + 1u) + (slot >> 6)] = 1;             // the bucket has a body: a plain byte store, the search ranks the flags
-    BpRec *dst;
-    if (r < (uint32_t)BP_CAP) dst = bin.table + (size_t)slot * BP_CAP + r;
-    else dst = bin.ovf + atomicAdd(&bin.ctrl[CTRL_OVF + par], 1u);          // at most n bodies ever get here: the list holds n_max
-    double2 *o = reinterpret_cast<double2 *>(dst);
-    o[0] = make_double2(bb[0], bb[1]); o[1] = make_double2(bb[2], bb[3]); o[2] = make_double2(bb[4], bb[5]);
-    reinterpret_cast<int4 *>(o)[3] = make_int4((int)i, cx, cy, cz);
-}
-
-__device__ __forceinline__ uint32_t bin_parity(const uint32_t *ctrl) { return ctrl[CTRL_PAR_NEXT] & 1u; }   // written by the previous search: stable during a bin pass
-
-// what the first thread of a bin pass does: publish the parity the pass uses, open a new epoch for the look-back words
-__device__ __forceinline__ void bin_open(uint32_t *ctrl, uint32_t par)
-{
-    ctrl[CTRL_PAR_CUR] = par;
-    ctrl[CTRL_EPOCH] = ctrl[CTRL_EPOCH] + 1;
+    bin.key[i] = slot;
+    bin.rank[i] = atomicAdd(&bin.cell_cnt[slot], 1u);
 }
 
 // Launch 1 (skipped when the step before it has binned the boxes it wrote: clapgpu_bodies_step_prebin)
 __global__ __launch_bounds__(PB)
-void k_bp_bin(BpK k, BinK bin)
+void k_bp_bin(BpK k)
 {
     const uint32_t i = blockIdx.x * PB + threadIdx.x;
-    const uint32_t par = bin_parity(bin.ctrl);
-    if (i == 0) bin_open(bin.ctrl, par);
+    if (i == 0) k.ctrl[CTRL_EPOCH] = k.ctrl[CTRL_EPOCH] + 1;          // first launch of the frame; read by the later ones
     if (i >= k.n) return;
     double bb[6];
     load_box(k.aabb, i, bb);
-    bin_body(bin, par, i, bb);
+    if (bb[1] - bb[0] > k.cell || bb[3] - bb[2] > k.cell || bb[5] - bb[4] > k.cell)
+        atomicOr(&k.ctrl[CTRL_STATUS], 1u);
+    int32_t cx, cy, cz;
+    box_cell(bb, k.cell, cx, cy, cz);
+    const uint32_t slot = cell_slot(cx, cy, cz, k.mask);
+    k.key[i] = slot;
+    k.rank[i] = atomicAdd(&k.cell_cnt[slot], 1u);
 }
 
-// Single-pass scan with decoupled look-back (the pair offsets of the emit tiles): a tile's offset = the sum of everything
-// before it.  Tile b publishes (flag, epoch, value) as ONE 64-bit word -- its own sum first
+// Single-pass scans with decoupled look-back (the block starts in k_bp_cells, the pair offsets of the 256-body emit
+// tiles in k_bp_emit): a tile's offset = the sum of everything before it.  Tile b publishes (flag, epoch, value) as ONE 64-bit word -- its own sum first
 // (AGGREGATE), its inclusive prefix once known (PREFIX) -- and a wavefront walks back over its predecessors' words, 64 at
 // a time, until it meets a PREFIX.  Workgroups are dispatched in index order and wait only on lower indices, so the
 // walk always terminates; the frame's epoch in the word makes last frame's entries read as empty (no clearing pass).
@@ -458,500 +402,302 @@ __device__ __forceinline__ uint32_t lb_exclusive(uint64_t *state, uint32_t b, ui
     return excl;
 }
 
-// An opaque copy: what is computed from it inside a loop stays inside the loop.  (The compiler otherwise hoists the
-// per-thread LDS addresses of every unrolled staging step to the top of the kernel and spills them: 59 VGPRs to scratch, a
-// memory round trip at every reload.)
-__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
-
-__device__ __forceinline__ uint32_t lanes_below(uint64_t m)            // set bits of m below this lane
+// Launch 2: wave w = block bucket w; a workgroup's BP_CELLS_BLOCK / 64 block totals enter the look-back scan as one tile
+constexpr int BP_CELLS_BLOCK = 1024;   // 16 buckets a workgroup: 512 look-back words at 262 144 bodies (256: 2 048 words, +2 us)
+__global__ __launch_bounds__(BP_CELLS_BLOCK)
+void k_bp_cells(BpK k)
 {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// What a search workgroup keeps in LDS.
-constexpr int BP_CELLS = BP_NB * 216;
-template <int MAXC>
-struct BpLds {
-    double2  sx[MAXC], sy[MAXC], sz[MAXC];                // staged boxes: (min, max) per axis
-    uint32_t sidx[MAXC];                                  // body index; 0 for a record staged under a cell it was not binned for: never a
-                                                          // partner (j > i fails)
-    uint16_t owner[MAXC];                                 // the cell a staged record sits in
-    double2  tx[BP_SMAX], ty[BP_SMAX], tz[BP_SMAX];       // the large statics
-    uint32_t tidx[BP_SMAX];
-    uint32_t h_slot[BP_CELLS];                            // the 6x6x6 slots around each block of the trip
-    uint16_t p_start[BP_CELLS + 8];                       // prefix over their staged records
-    uint8_t  h_cnt[BP_CELLS];                             // bodies in them (<= BP_CAP)
-    uint8_t  own_cnt[BP_NB][64];                          // the trip's buckets: bodies per own slot,
-    uint32_t done[BP_NB][64];                             //   bit r = record r has had its pass
-    uint32_t ovl[BP_OVL];                                 // overflow records near the trip's blocks
-    int32_t  blk[BP_NB][4];                               // current block of each bucket (bx, by, bz), found
-    uint32_t ubucket[BP_NB], st0[BP_NB], nst[BP_NB];      // bucket, its statics (CSR range)
-    uint32_t mine[BP_MINE];                               // this workgroup's buckets
-    uint32_t wtot[16];
-    uint32_t n_ovl, n_occ;
-};
-
-// a 64-byte record through the scalar cache (uniform address; the table is written by the launch before this one)
-struct BpRecS { double x0, x1, y0, y1, z0, z1; uint32_t idx; int32_t cx, cy, cz; };
-__device__ __forceinline__ double dbl_of(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, (uint64_t)hi << 32 | lo); }
-__device__ __forceinline__ BpRecS sload_rec(const BpRec *p)
-{
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(4))) const u32x4 *cp4;
-    const uint64_t a64 = (uint64_t)(uintptr_t)p;                          // uniform by construction: tell the compiler
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a64), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a64 >> 32));
-    const cp4 c = (cp4)((uint64_t)hi << 32 | lo);
-    const u32x4 a = c[0], b = c[1], d = c[2], e = c[3];
-    BpRecS r;
-    r.x0 = dbl_of(a.x, a.y); r.x1 = dbl_of(a.z, a.w); r.y0 = dbl_of(b.x, b.y); r.y1 = dbl_of(b.z, b.w); r.z0 = dbl_of(d.x, d.y); r.z1 = dbl_of(d.z, d.w);
-    r.idx = e.x; r.cx = (int32_t)e.y; r.cy = (int32_t)e.z; r.cz = (int32_t)e.w;
-    return r;
-}
-
-// One body against everything around it, from memory: one wavefront per body (the overflow bodies, and the bodies of a block
-// whose 6x6x6 slots hold more records than the LDS image).
-__device__ __forceinline__ void bp_body_from_memory(const BpK &k, const uint32_t *ccnt, const uint32_t novf, const BpRecS &me)
-{
-    const int lane = (int)opaque((uint32_t)lane_id());
-    const bool statics = k.n_static != 0;
-    const double2 ax = make_double2(me.x0, me.x1), ay = make_double2(me.y0, me.y1), az = make_double2(me.z0, me.z1);
-    const uint32_t i = me.idx;
-    uint32_t acc = 0, sacc = 0;
-    auto one = [&](const BpRec &r, bool valid, bool is_static) {
-        const bool hit = valid & !boxes_apart(ax, ay, az, make_double2(r.bb[0], r.bb[1]), make_double2(r.bb[2], r.bb[3]),
-                                              make_double2(r.bb[4], r.bb[5])) & (is_static | (r.idx > i));
-        const uint64_t hm = __ballot(hit);
-        if (hm) {
-            uint32_t &a = is_static ? sacc : acc;
-            const uint32_t at = a + lanes_below(hm);
-            if (hit && at < (uint32_t)BP_LIST) (is_static ? k.spartners : k.partners)[(size_t)i * BP_LIST + at] = r.idx;
-            a += (uint32_t)__popcll(hm);
+    __shared__ uint32_t tot[BP_CELLS_BLOCK / WAVE];
+    __shared__ uint32_t excl_s;
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const uint32_t b = blockIdx.x * (BP_CELLS_BLOCK / WAVE) + wave;
+    uint32_t block_total = 0, c = 0, before = 0;                        // this lane's cell: bodies, bodies of the block's cells before it
+    if (b <= k.mask) {
+        c = k.cell_cnt[(size_t)b * 64 + lane];
+        k.cell_cnt[(size_t)b * 64 + lane] = 0;                          // ready for the next frame
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
         }
-    };
-    // the 27 cells around it, BP_CAP records each at most: lane = (cell, record)
-    uint32_t myslot = 0, mycnt = 0;
-    if (lane < 27) {
-        myslot = cell_slot(me.cx - 1 + lane % 3, me.cy - 1 + (lane / 3) % 3, me.cz - 1 + lane / 9, k.mask);
-        mycnt = ccnt[myslot];
-        if (mycnt > (uint32_t)BP_CAP) mycnt = BP_CAP;
+        before = incl - c;
+        block_total = __shfl(incl, WAVE - 1);
     }
-    for (int f0 = 0; f0 < 27 * BP_CAP; f0 += WAVE) {
-        const int f = f0 + lane, c = f / BP_CAP, e = f % BP_CAP;
-        const uint32_t sl = (uint32_t)__shfl((int)myslot, c < 27 ? c : 0), cn = (uint32_t)__shfl((int)mycnt, c < 27 ? c : 0);
-        const bool valid = c < 27 && (uint32_t)e < cn;
-        BpRec r;
-        memset(&r, 0, sizeof(r));
-        if (valid) r = k.table[(size_t)sl * BP_CAP + e];
-        one(r, valid, false);
+    if (lane == 0) tot[wave] = block_total;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < BP_CELLS_BLOCK / WAVE; q++) sum += tot[q];
+        const uint32_t excl = lb_exclusive(k.lb_cells, blockIdx.x, sum, k.ctrl[CTRL_EPOCH], k.ctrl + CTRL_STATUS);
+        if (lane == 0) excl_s = excl;
     }
-    for (uint32_t f0 = 0; f0 < novf; f0 += WAVE) {                      // the overflow bodies
-        const uint32_t f = f0 + lane;
-        const bool valid = f < novf;
-        BpRec r;
-        memset(&r, 0, sizeof(r));
-        if (valid) r = k.ovf[f];
-        one(r, valid, false);
-    }
-    if (statics) {
-        const uint32_t ob = block_hash(me.cx >> 2, me.cy >> 2, me.cz >> 2, k.mask);
-        const uint32_t s0 = k.s_start[ob], ns = k.s_start[ob + 1] - s0;
-        for (uint32_t f0 = 0; f0 < ns + k.n_large; f0 += WAVE) {
-            const uint32_t f = f0 + lane;
-            const bool valid = f < ns + k.n_large;
-            BpRec r;
-            memset(&r, 0, sizeof(r));
-            if (valid) r = f < ns ? k.s_recs[s0 + f] : k.s_lrecs[f - ns];
-            one(r, valid, true);
-        }
-    }
-    if (lane == 0) {
-        k.cnt[i] = acc;
-        if (statics) k.scnt[i] = sacc;
+    __syncthreads();
+    if (b <= k.mask) {
+        uint32_t start = excl_s;
+        for (int q = 0; q < wave; q++) start += tot[q];
+        k.cell_range[(size_t)b * 64 + lane] = make_uint2(start + before, c);
     }
 }
 
-// Launch 2.  A fixed grid of workgroups (two per CU: the LDS image) shares the occupied buckets round-robin (every
-// workgroup ranks the bin pass's bucket flags for itself: no list, no atomic), `nb` buckets a trip: their blocks' 6x6x6
-// slots are counted, prefixed and staged together when the records fit one LDS image (sparse scenes: the trip's dependent
-// memory steps are shared by up to four blocks), block by block otherwise; a block that does not fit alone goes body by
-// body from memory.  A wavefront takes a row of four cells: candidates one per lane from LDS, the row's own bodies one
-// after the other through the SCALAR cache straight from the table, so a test is six compares of a vector register
-// against scalar registers.  Then the overflow bodies, one wavefront each.
-template <int T, int MAXC>
-__global__ __launch_bounds__(T, BP_WAVES_PER_SIMD)
+// Launch 3
+__global__ __launch_bounds__(PB)
+void k_bp_scatter(BpK k)
+{
+    const uint32_t i = blockIdx.x * PB + threadIdx.x;
+    if (i >= k.n) return;
+    const uint32_t slot = k.key[i];
+    const uint32_t at = k.cell_range[slot].x + k.rank[i];
+    k.entries[at] = i;
+    const double2 *p = reinterpret_cast<const double2 *>(k.aabb + 6 * (size_t)i);
+    double2 *o = reinterpret_cast<double2 *>(k.recs + at);
+    const double2 b0 = p[0], b1 = p[1], b2 = p[2];
+    o[0] = b0; o[1] = b1; o[2] = b2;
+    // the cell coordinates travel with the record: the search would otherwise redo three fp64 divisions per body
+    const int32_t cx = cell_coord((b0.x + b0.y) * 0.5, k.cell), cy = cell_coord((b1.x + b1.y) * 0.5, k.cell),
+                  cz = cell_coord((b2.x + b2.y) * 0.5, k.cell);
+    reinterpret_cast<int4 *>(o)[3] = make_int4((int)i, cx, cy, cz);
+}
+
+// Launch 4.  One wavefront per tile of BP_TILE bodies that are neighbours in cell order.  Bodies of one cell have the
+// same 14 candidate cells, so the tile's candidates are listed per DISTINCT cell ("leader": the first body of each run
+// of equal cell coordinates), each entry with the range of tile bodies it has to be tested against: a candidate record is
+// gathered once per cell, not once per body, and the tile's own boxes are read back from LDS as broadcasts.  The
+// statics registered for a block are listed the same way, once per distinct block bucket.  Steps that depend on memory:
+// tile records (+ the large statics' records) -> cell / static ranges (up to four per lane, loaded together) -> the work
+// list in LDS -> candidate records, two per lane and round -> hit atomics.  Hits on bodies go to the partner list of
+// min(i, j) (global atomics); static hits count in LDS, because only this wavefront writes its bodies' static lists.
+__global__ __launch_bounds__(PB)
 void k_bp_search(BpK k)
 {
-    constexpr int W = T / WAVE;
-    static_assert(W >= BP_NB && W <= 16 && 2 * T >= BP_CELLS, "a wavefront per bucket of the trip; two cells a thread in the prefix");
-    __shared__ BpLds<MAXC> s;
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid / WAVE;
-    const uint32_t par = k.ctrl[CTRL_PAR_CUR] & 1u, buckets = k.mask + 1u;
-    const uint32_t *ccnt = k.cell_cnt + (size_t)par * k.slots;
+    constexpr int WAVES = PB / WAVE, T = BP_TILE, LOOKUPS = 4;          // lookups per lane: T * 14 + T <= 64 * LOOKUPS
+    constexpr uint32_t WL = BP_WORK, OWN = 0x80000000u, STAT = 0x40000000u, IDX = 0x3fffffffu;
+    constexpr int LARGE_TILE = 32;                                      // large statics staged per round (LDS <= 26 KB: six workgroups per CU)
+    constexpr uint32_t HITS = 64;                                       // body x body hits parked per round
+    static_assert(T * 15 <= WAVE * LOOKUPS && T <= 16, "tile lookups");
+    __shared__ __attribute__((aligned(8))) uint32_t work[WAVES][WL][2];  // (record | flags, a_lo | a_hi << 8)
+    __shared__ double abox[WAVES][T][6];
+    __shared__ uint32_t aidx[WAVES][T];
+    __shared__ int32_t lead[WAVES][2 * T][4];                           // cell leaders: (cx, cy, cz, range); then block leaders: (bucket, -, -, range)
+    __shared__ uint32_t shits[WAVES][T];
+    __shared__ uint32_t hits[WAVES][HITS][2], nhits[WAVES];
+    __shared__ BpRec large[LARGE_TILE];
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const uint32_t t0 = (blockIdx.x * WAVES + wave) * T;
+    const uint32_t nA = t0 < k.n ? (k.n - t0 < (uint32_t)T ? k.n - t0 : (uint32_t)T) : 0;
     const bool statics = k.n_static != 0;
-    const uint32_t novf = k.ctrl[CTRL_OVF + par];
-    const uint32_t G = gridDim.x;
-#ifdef BP_EXP_TIMING
-    uint64_t tick__ = __builtin_readcyclecounter();
-    const uint64_t wall0__ = wall_clock64();
-#endif
 
-    // ---- what the NEXT bin pass adds to: cell counters, bucket flags, the overflow count
-    {
-        uint32_t *oc = k.cell_cnt + (size_t)(par ^ 1u) * k.slots;
-        uint8_t *of = k.bflag + (size_t)(par ^ 1u) * buckets;
-        for (uint32_t q = blockIdx.x * T + tid; q < k.slots / 4; q += G * T) reinterpret_cast<uint4 *>(oc)[q] = make_uint4(0, 0, 0, 0);
-        for (uint32_t q = blockIdx.x * T + tid; q < buckets / 16; q += G * T) reinterpret_cast<uint4 *>(of)[q] = make_uint4(0, 0, 0, 0);
-        if (blockIdx.x == 0 && tid == 0) {
-            k.ctrl[CTRL_PAR_NEXT] = par ^ 1u;
-            k.ctrl[CTRL_OVF + (par ^ 1u)] = 0;
+    const uint32_t m0 = statics ? (k.n_large < LARGE_TILE ? k.n_large : LARGE_TILE) : 0;
+    if (threadIdx.x < m0) large[threadIdx.x] = k.s_lrecs[threadIdx.x];  // issued with the tile's own records: no extra step
+    // ---- the tile's bodies, cell leaders and block leaders
+    int32_t cx = 0, cy = 0, cz = 0;
+    uint32_t ob = 0;
+    const bool isA = (uint32_t)lane < nA;
+    if (isA) {
+        const BpRec me = k.recs[t0 + lane];
+#pragma unroll
+        for (int x = 0; x < 6; x++) abox[wave][lane][x] = me.bb[x];
+        aidx[wave][lane] = me.idx;
+        cx = me.cell[0]; cy = me.cell[1]; cz = me.cell[2];
+        ob = block_hash(cx >> 2, cy >> 2, cz >> 2, k.mask);
+    }
+    if (lane < T) shits[wave][lane] = 0;
+    if (lane == 0) nhits[wave] = 0;
+    const int32_t px = __shfl_up(cx, 1), py = __shfl_up(cy, 1), pz = __shfl_up(cz, 1);
+    const uint32_t pob = __shfl_up(ob, 1);
+    const bool cell_leader = isA && (lane == 0 || px != cx || py != cy || pz != cz);
+    const bool block_leader = isA && statics && (lane == 0 || pob != ob);
+    const uint32_t cmask = (uint32_t)__ballot(cell_leader), bmask = (uint32_t)__ballot(block_leader);
+    const uint32_t n_lead = __popc(cmask), n_blead = __popc(bmask);
+    if (isA) {
+        const uint32_t below = (1u << lane) - 1u;
+        if (cell_leader) {
+            const uint32_t above = cmask >> (lane + 1);
+            const uint32_t hi = above ? lane + 1 + __builtin_ctz(above) : nA;
+            int32_t *d = lead[wave][__popc(cmask & below)];
+            d[0] = cx; d[1] = cy; d[2] = cz; d[3] = (int32_t)((uint32_t)lane | hi << 8);
+        }
+        if (block_leader) {
+            const uint32_t above = bmask >> (lane + 1);
+            const uint32_t hi = above ? lane + 1 + __builtin_ctz(above) : nA;
+            int32_t *d = lead[wave][T + __popc(bmask & below)];
+            d[0] = (int32_t)ob; d[3] = (int32_t)((uint32_t)lane | hi << 8);
         }
     }
-    // ---- the statics every body is tested against
-    const bool lg_lds = statics && k.n_large <= (uint32_t)BP_SMAX;
-    if (lg_lds && (uint32_t)tid < k.n_large) {
-        const BpRec r = k.s_lrecs[tid];
-        s.tx[tid] = make_double2(r.bb[0], r.bb[1]); s.ty[tid] = make_double2(r.bb[2], r.bb[3]); s.tz[tid] = make_double2(r.bb[4], r.bb[5]);
-        s.tidx[tid] = r.idx;
+    wave_lds_fence();
+    // ---- candidate runs: (leader, cell) and (block leader) lookups, up to four per lane, loads in flight together
+    const uint32_t n_cell_runs = n_lead * 14u, n_runs = n_cell_runs + n_blead;
+    // All of a lane's lookups are addressed first and loaded together, under no lane test (a lookup that does not exist
+    // reads entry 0 and is given length 0): written as "if cell run ... else if block run ..." per lookup, each of the
+    // four became its own branch with its own waits -- eight dependent trips to L2 before the first candidate.
+    uint32_t b0[LOOKUPS], len[LOOKUPS], rng[LOOKUPS], mylen = 0;
+    uint32_t slot[LOOKUPS], sidx[LOOKUPS];
+    bool is_cell[LOOKUPS], is_stat[LOOKUPS], own[LOOKUPS];
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) {
+        const uint32_t u = lane + WAVE * r;
+        is_cell[r] = u < n_cell_runs;
+        is_stat[r] = !is_cell[r] && u < n_runs;
+        const uint32_t l = is_cell[r] ? u / 14u : 0u, cq = 13u + u % 14u;           // 13 = own cell, 14..26 = the cells after it
+        const int32_t *d = lead[wave][is_stat[r] ? T + (u - n_cell_runs) : l];
+        const int32_t d0 = d[0], d1 = d[1], d2 = d[2];
+        rng[r] = (is_cell[r] || is_stat[r]) ? (uint32_t)d[3] : 0u;
+        own[r] = is_cell[r] && cq == 13u;
+        slot[r] = is_cell[r] ? cell_slot(d0 - 1 + (int32_t)(cq % 3), d1 - 1 + (int32_t)((cq / 3) % 3), d2 - 1 + (int32_t)(cq / 9), k.mask) : 0u;
+        sidx[r] = is_stat[r] ? (uint32_t)d0 : 0u;
     }
+    uint2 v_cr[LOOKUPS];
+    uint32_t v_s0[LOOKUPS], v_s1[LOOKUPS];
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) v_cr[r] = k.cell_range[slot[r]];
+    if (statics) {                                                       // uniform
+#pragma unroll
+        for (int r = 0; r < LOOKUPS; r++) { v_s0[r] = k.s_start[sidx[r]]; v_s1[r] = k.s_start[sidx[r] + 1]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < LOOKUPS; r++) { v_s0[r] = 0; v_s1[r] = 0; }
+    }
+#pragma unroll
+    for (int r = 0; r < LOOKUPS; r++) {
+        b0[r] = is_cell[r] ? (v_cr[r].x | (own[r] ? OWN : 0u)) : is_stat[r] ? (v_s0[r] | STAT) : 0u;
+        len[r] = is_cell[r] ? v_cr[r].y : is_stat[r] ? v_s1[r] - v_s0[r] : 0u;
+        mylen += len[r];
+    }
+    uint32_t incl = mylen;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const uint32_t total = __shfl(incl, WAVE - 1);
+    const uint32_t first = incl - mylen;
 
-    // ---- this workgroup's buckets: every 16 flags a thread, ranked over the grid; rank % G == blockIdx is mine
-    const uint8_t *flags = k.bflag + (size_t)par * buckets;
-    for (uint32_t win = 0;; win++) {                                     // one window unless a workgroup has more than BP_MINE buckets
-        uint32_t running = 0;
-        for (uint32_t c0 = 0; c0 < buckets; c0 += T * 16) {              // uniform
-            const uint32_t at = c0 + opaque(tid) * 16;
-            uint4 f = make_uint4(0, 0, 0, 0);
-            if (at < buckets) f = *reinterpret_cast<const uint4 *>(flags + at);
-            const uint32_t fw[4] = { f.x, f.y, f.z, f.w };
-            uint32_t bits = 0;                                           // bit j: flag j of my 16 is set
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) bits |= ((fw[q] >> (8 * e)) & 0xffu) ? 1u << (4 * q + e) : 0u;
-            const uint32_t mycount = __popc(bits);
-            uint32_t incl = mycount;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const uint32_t u = __shfl_up(incl, o);
-                if (lane >= o) incl += u;
+    // A hit on another body needs one returning atomic on the partner count of min(i, j), ~2 us under load: hits are
+    // parked in LDS while the candidates are tested and their atomics issued together once per round.
+    auto flush_hits = [&]() {
+        wave_lds_fence();
+        const uint32_t nh = nhits[wave] < HITS ? nhits[wave] : HITS;
+        for (uint32_t h = lane; h < nh; h += WAVE) {
+            const uint32_t lo = hits[wave][h][0], hi = hits[wave][h][1];
+            const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
+            if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+        }
+        wave_lds_fence();
+        if (lane == 0) nhits[wave] = 0;
+        wave_lds_fence();
+    };
+    auto test = [&](uint32_t w, uint32_t range, const BpRec &r) {
+        const uint32_t j = r.idx, a_hi = range >> 8;
+        for (uint32_t x = range & 0xffu; x < a_hi; x++) {
+            const double2 *ab = reinterpret_cast<const double2 *>(abox[wave][x]);
+            const double2 a01 = ab[0], a23 = ab[1], a45 = ab[2];         // all six before any compare: one LDS wait per body
+            const bool apart = (a01.x > r.bb[1]) | (a01.y < r.bb[0]) | (a23.x > r.bb[3]) | (a23.y < r.bb[2]) |
+                               (a45.x > r.bb[5]) | (a45.y < r.bb[4]);
+            if (apart) continue;
+            const uint32_t i = aidx[wave][x];
+            if (w & STAT) {
+                const uint32_t at = atomicAdd(&shits[wave][x], 1u);
+                if (at < BP_LIST) k.spartners[(size_t)i * BP_LIST + at] = j;
+            } else if (j != i && (!(w & OWN) || j > i)) {
+                const uint32_t lo = i < j ? i : j, hi = i < j ? j : i;
+                const uint32_t h = atomicAdd(&nhits[wave], 1u);
+                if (h < HITS) { hits[wave][h][0] = lo; hits[wave][h][1] = hi; }
+                else {                                                   // list full (a pile-up): straight to memory
+                    const uint32_t at = atomicAdd(&k.cnt[lo], 1u);
+                    if (at < BP_LIST) k.partners[(size_t)lo * BP_LIST + at] = hi;
+                }
             }
-            __syncthreads();                                             // wtot of the chunk before has been read
-            if (lane == WAVE - 1) s.wtot[wave] = incl;
+        }
+    };
+
+    for (uint32_t base = 0; base < total; base += WL) {                 // one round unless > WL candidates (total is wave-uniform)
+        uint32_t off = first;
+#pragma unroll
+        for (int r = 0; r < LOOKUPS; r++) {
+            for (uint32_t e = 0; __any(e < len[r]); e++) {
+                if (e < len[r]) {
+                    const uint32_t o = off + e - base;                  // wraps below base: then >= WL
+                    if (o < WL) *reinterpret_cast<uint2 *>(work[wave][o]) = make_uint2(b0[r] + e, rng[r]);
+                }
+            }
+            off += len[r];
+        }
+        wave_lds_fence();
+        const uint32_t todo = total - base < WL ? total - base : WL;
+#if BP_SEARCH_IN_FLIGHT == 2
+        for (uint32_t e = lane; e < todo + lane; e += 2 * WAVE) {       // wave-uniform trip count; two records in flight per lane
+            const bool v0 = e < todo, v1 = e + WAVE < todo;
+            const uint2 e0 = v0 ? *reinterpret_cast<const uint2 *>(work[wave][e]) : make_uint2(0u, 0u);
+            const uint2 e1 = v1 ? *reinterpret_cast<const uint2 *>(work[wave][e + WAVE]) : make_uint2(0u, 0u);
+            const uint32_t w0 = e0.x, g0 = e0.y, w1 = e1.x, g1 = e1.y;
+            BpRec r0, r1;
+            if (v0) r0 = ((w0 & STAT) ? k.s_recs : k.recs)[w0 & IDX];
+            if (v1) r1 = ((w1 & STAT) ? k.s_recs : k.recs)[w1 & IDX];
+            if (v0) test(w0, g0, r0);
+            if (v1) test(w1, g1, r1);
+        }
+#else
+        for (uint32_t e = lane; e < todo; e += WAVE) {
+            const uint2 e0 = *reinterpret_cast<const uint2 *>(work[wave][e]);
+            const BpRec r0 = ((e0.x & STAT) ? k.s_recs : k.recs)[e0.x & IDX];
+            test(e0.x, e0.y, r0);
+        }
+#endif
+        flush_hits();
+    }
+    if (!statics) return;
+    // ---- the large statics (tested by every body), staged through LDS for the whole workgroup
+    for (uint32_t base = 0; base < k.n_large; base += LARGE_TILE) {
+        const uint32_t m = k.n_large - base < LARGE_TILE ? k.n_large - base : LARGE_TILE;
+        if (base) {
             __syncthreads();
-            uint32_t before = running, chunk = 0;
-            for (int w2 = 0; w2 < W; w2++) { if (w2 < wave) before += s.wtot[w2]; chunk += s.wtot[w2]; }
-            uint32_t rank = before + incl - mycount;
-            for (uint32_t b2 = bits; b2; b2 &= b2 - 1, rank++) {
-                if (rank % G == blockIdx.x) {
-                    const uint32_t li = rank / G;
-                    if (li >= win * BP_MINE && li < (win + 1) * BP_MINE) s.mine[li - win * BP_MINE] = at + (uint32_t)__builtin_ctz(b2);
-                }
-            }
-            running += chunk;
+            if (threadIdx.x < m) large[threadIdx.x] = k.s_lrecs[base + threadIdx.x];
         }
-        if (tid == 0) s.n_occ = running;
         __syncthreads();
-        const uint32_t nocc = s.n_occ;
-        const uint32_t my_total = nocc > blockIdx.x ? (nocc - blockIdx.x + G - 1) / G : 0u;       // buckets of rank blockIdx, blockIdx + G, ...
-        const uint32_t lo = win * BP_MINE, hi = my_total < lo + BP_MINE ? my_total : lo + BP_MINE;
-        uint32_t nb = (nocc + G - 1) / G;                                // buckets a trip: all workgroups busy before any takes two
-        nb = nb < 1u ? 1u : nb > (uint32_t)BP_NB ? (uint32_t)BP_NB : nb;
-        BP_TICK(0);
-
-        for (uint32_t base = lo; base < hi; base += nb) {
-            const uint32_t nu = hi - base < nb ? hi - base : nb;
-            // ---- the trip's buckets: own counts, and record 0 of every slot with them (garbage where the count is 0)
-            int4 first = make_int4(0, 0, 0, 0);
-            uint32_t my_c = 0;
-            const int lane = (int)opaque((uint32_t)lane_id()), wave = (int)opaque((uint32_t)tid) / WAVE;   // (shadow the kernel's: see opaque())
-            if ((uint32_t)wave < nu) {
-                const uint32_t b = s.mine[base - lo + wave];
-                const uint32_t slot = b * 64 + lane;
-                my_c = ccnt[slot];
-                first = reinterpret_cast<const int4 *>(k.table + (size_t)slot * BP_CAP)[3];
-                if (my_c > (uint32_t)BP_CAP) my_c = BP_CAP;
-                s.own_cnt[wave][lane] = (uint8_t)my_c;
-                s.done[wave][lane] = 0;
-                if (lane == 0) {
-                    s.ubucket[wave] = b;
-                    s.st0[wave] = statics ? k.s_start[b] : 0u;
-                    s.nst[wave] = statics ? k.s_start[b + 1] - k.s_start[b] : 0u;
+        const uint32_t x = lane % T;                                    // tile body of this lane; the large list is strided by WAVE / T
+        if (x < nA) {
+            double a[6];
+#pragma unroll
+            for (int y = 0; y < 6; y++) a[y] = abox[wave][x][y];
+            for (uint32_t e = lane / T; e < m; e += WAVE / T) {
+                double bs[6];
+#pragma unroll
+                for (int y = 0; y < 6; y++) bs[y] = large[e].bb[y];
+                if (boxes_overlap(a, bs)) {
+                    const uint32_t at = atomicAdd(&shits[wave][x], 1u);
+                    if (at < BP_LIST) k.spartners[(size_t)aidx[wave][x] * BP_LIST + at] = large[e].idx;
                 }
             }
-            for (bool first_block = true;; first_block = false) {
-                // ---- every bucket's next block with bodies that have not had their pass
-                if ((uint32_t)wave < nu) {
-                    wave_lds_fence();
-                    const uint32_t pend = (my_c ? (0xffffffffu >> (32 - my_c)) : 0u) & ~s.done[wave][lane];
-                    const uint64_t pm = __ballot(pend != 0);
-                    if (!pm) {
-                        if (lane == 0) s.blk[wave][3] = 0;
-                    } else {
-                        const int l = __builtin_ctzll(pm);
-                        const uint32_t r = (uint32_t)__builtin_ctz((uint32_t)__shfl((int)pend, l));
-                        int4 c4 = make_int4(__shfl(first.x, l), __shfl(first.y, l), __shfl(first.z, l), __shfl(first.w, l));
-                        if (!(first_block && r == 0))                     // uniform
-                            c4 = reinterpret_cast<const int4 *>(k.table + ((size_t)s.ubucket[wave] * 64 + l) * BP_CAP + r)[3];
-                        if (lane == 0) { s.blk[wave][0] = c4.y >> 2; s.blk[wave][1] = c4.z >> 2; s.blk[wave][2] = c4.w >> 2; s.blk[wave][3] = 1; }
-                    }
-                }
-                if (tid == 0) s.n_ovl = 0;
-                __syncthreads();
-                BP_TICK(1);
-                uint32_t found = 0;
-                for (uint32_t u = 0; u < nu; u++) found |= s.blk[u][3] ? 1u << u : 0u;
-                if (!found) break;
-                // ---- the 6x6x6 slots around each
-                for (uint32_t c = opaque(tid); c < (uint32_t)BP_CELLS; c += T) {
-                    const uint32_t u = c / 216u, t = c % 216u;
-                    uint32_t slot = 0, cn = 0;
-                    if (found >> u & 1u) {
-                        const int hx = t % 6, hy = (t / 6) % 6, hz = t / 36;
-                        slot = cell_slot(4 * s.blk[u][0] - 1 + hx, 4 * s.blk[u][1] - 1 + hy, 4 * s.blk[u][2] - 1 + hz, k.mask);
-                        cn = ccnt[slot];
-                        if (cn > (uint32_t)BP_CAP) cn = BP_CAP;
-                    }
-                    s.h_slot[c] = slot;
-                    s.h_cnt[c] = (uint8_t)cn;
-                }
-                // overflow bodies whose cell is one of them (none, as a rule)
-                for (uint32_t o = opaque(tid); o < novf; o += T) {
-                    const int4 c4 = reinterpret_cast<const int4 *>(k.ovf + o)[3];
-                    bool near = false;
-                    for (uint32_t u = 0; u < nu; u++) {
-                        const int32_t dx = c4.y - (4 * s.blk[u][0] - 1), dy = c4.z - (4 * s.blk[u][1] - 1), dz = c4.w - (4 * s.blk[u][2] - 1);
-                        near |= (found >> u & 1u) && dx >= 0 && dx < 6 && dy >= 0 && dy < 6 && dz >= 0 && dz < 6;
-                    }
-                    if (near) {
-                        const uint32_t at = atomicAdd(&s.n_ovl, 1u);
-                        if (at < (uint32_t)BP_OVL) s.ovl[at] = o;
-                    }
-                }
-                __syncthreads();
-                BP_TICK(2);
-
-                // Units [ua, ub) of the trip in one LDS image.  false: too many records (nothing done).
-                auto pass = [&](const uint32_t ua, const uint32_t ub) -> bool {
-                    // -- prefix over the cells (x fastest, then y, z, unit), two cells a thread; the cell of every staged position
-                    uint32_t v0 = 0, v1 = 0;
-                    const uint32_t tid2 = 2 * opaque(tid);
-                    {
-                        const uint32_t c = tid2;
-                        if (c < (uint32_t)BP_CELLS) {
-                            const uint32_t u = c / 216u;                 // 216 is even: both cells in one unit
-                            if (u >= ua && u < ub) { v0 = s.h_cnt[c]; v1 = s.h_cnt[c + 1]; }
-                        }
-                    }
-                    uint32_t incl = v0 + v1;
-#pragma unroll
-                    for (int o = 1; o < WAVE; o <<= 1) {
-                        const uint32_t u = __shfl_up(incl, o);
-                        if (lane >= o) incl += u;
-                    }
-                    if (lane == WAVE - 1) s.wtot[wave] = incl;
-                    __syncthreads();
-                    uint32_t before = 0, M = 0;
-                    for (int w2 = 0; w2 < W; w2++) { if (w2 < wave) before += s.wtot[w2]; M += s.wtot[w2]; }
-                    if (M > (uint32_t)MAXC) { __syncthreads(); return false; }
-                    {
-                        const uint32_t c = tid2, e0 = before + incl - v0 - v1;
-                        if (c < (uint32_t)BP_CELLS) {
-                            s.p_start[c] = (uint16_t)e0; s.p_start[c + 1] = (uint16_t)(e0 + v0);
-                            for (uint32_t e = 0; e < v0; e++) s.owner[e0 + e] = (uint16_t)c;
-                            for (uint32_t e = 0; e < v1; e++) s.owner[e0 + v0 + e] = (uint16_t)(c + 1);
-                        }
-                        if (tid == 0) s.p_start[BP_CELLS] = (uint16_t)M;
-                    }
-                    __syncthreads();
-                    BP_TICK(3);
-                    // -- stage: four lanes per record, the loads of a trip issued together
-                    constexpr int U = 5;
-                    for (uint32_t q0 = opaque(tid); q0 < 4 * M; q0 += T * U) {
-                        uint4 v[U];
-                        uint32_t cc[U];
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const uint32_t q = q0 + u * T, p = q >> 2;
-                            cc[u] = 0;
-                            if (q < 4 * M) {
-                                cc[u] = s.owner[p];
-                                v[u] = reinterpret_cast<const uint4 *>(k.table + (size_t)s.h_slot[cc[u]] * BP_CAP + (p - s.p_start[cc[u]]))[q & 3u];
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const uint32_t q = q0 + u * T, part = q & 3u, p = q >> 2;
-                            if (q < 4 * M) {
-                                double2 d;
-                                memcpy(&d, &v[u], sizeof(d));
-                                if (part == 0) s.sx[p] = d;
-                                else if (part == 1) s.sy[p] = d;
-                                else if (part == 2) s.sz[p] = d;
-                                else {
-                                    const uint32_t un = cc[u] / 216u, t = cc[u] % 216u;
-                                    const int hx = t % 6, hy = (t / 6) % 6, hz = t / 36;
-                                    const bool valid = (int32_t)v[u].y == 4 * s.blk[un][0] - 1 + hx && (int32_t)v[u].z == 4 * s.blk[un][1] - 1 + hy &&
-                                                       (int32_t)v[u].w == 4 * s.blk[un][2] - 1 + hz;
-                                    s.sidx[p] = valid ? v[u].x : 0u;
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    BP_TICK(4);
-                    // -- rows: a wavefront takes the four own cells (y, z) of a unit against nine runs of six slots
-                    for (uint32_t row = ua * 16u + wave; row < ub * 16u; row += W) {
-                        const uint32_t un = row >> 4, y = row & 3u, z = (row >> 2) & 3u;
-                        if (!(found >> un & 1u)) continue;
-                        const int32_t bx = s.blk[un][0], by = s.blk[un][1], bz = s.blk[un][2];
-                        const uint32_t pos0 = y << 2 | z << 4;               // own slots pos0 .. pos0 + 3
-                        uint32_t ocnt[4], oany = 0;
-#pragma unroll
-                        for (int x = 0; x < 4; x++) { ocnt[x] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.own_cnt[un][pos0 + x]); oany |= ocnt[x]; }
-                        if (!oany) continue;
-                        const BpRec *own_base = k.table + ((size_t)__builtin_amdgcn_readfirstlane((int)s.ubucket[un]) * 64 + pos0) * BP_CAP;
-                        uint32_t rs[9], cum[10];
-                        cum[0] = 0;
-#pragma unroll
-                        for (int r = 0; r < 9; r++) {
-                            const uint32_t c0 = un * 216u + 6u * (y + r % 3) + 36u * (z + r / 3);
-                            rs[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.p_start[c0]);
-                            cum[r + 1] = cum[r] + ((uint32_t)__builtin_amdgcn_readfirstlane((int)s.p_start[c0 + 6]) - rs[r]);
-                        }
-                        const uint32_t K = cum[9];
-                        const uint32_t novl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.n_ovl);
-                        const uint32_t n_ovl_c = novl == 0 ? 0u : novl <= (uint32_t)BP_OVL ? novl : novf;
-                        const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.st0[un]), nst = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.nst[un]);
-                        const uint32_t n_st = statics ? nst : 0u, n_lg = statics ? k.n_large : 0u;
-                        uint32_t acc = 0, sacc = 0, oidx = 0, ovalid = 0;   // lane 16 x + r: hit counts, index, validity of own record r of cell x
-                        uint32_t donem[4] = { 0, 0, 0, 0 };
-#pragma unroll 1
-                        for (int src = 0; src < 4; src++) {
-                            const bool is_static = src >= 2;
-                            const uint32_t nsrc = src == 0 ? ((BP_EXP_SKIP & 1) ? 0u : K) : src == 1 ? n_ovl_c : (BP_EXP_SKIP & 2) ? 0u : src == 2 ? n_st : n_lg;
-                            for (uint32_t base2 = 0; base2 < nsrc; base2 += WAVE) {
-                                // -- this lane's candidate
-                                const uint32_t f = base2 + lane;
-                                const bool valid = f < nsrc;
-                                double2 cx, cy, cz;
-                                uint32_t j;
-                                if (src == 0) {
-                                    uint32_t p = 0;
-#pragma unroll
-                                    for (int r = 0; r < 9; r++)
-                                        if (f >= cum[r] && f < cum[r + 1]) p = rs[r] + (f - cum[r]);
-                                    cx = s.sx[p]; cy = s.sy[p]; cz = s.sz[p]; j = s.sidx[p];
-                                } else if (src == 3 && lg_lds) {
-                                    const uint32_t q = valid ? f : 0u;
-                                    cx = s.tx[q]; cy = s.ty[q]; cz = s.tz[q]; j = s.tidx[q];
-                                } else {
-                                    BpRec r;
-                                    memset(&r, 0, sizeof(r));
-                                    if (valid) r = src == 1 ? k.ovf[novl <= (uint32_t)BP_OVL ? s.ovl[f] : f] : src == 2 ? k.s_recs[st0 + f] : k.s_lrecs[f];
-                                    cx = make_double2(r.bb[0], r.bb[1]); cy = make_double2(r.bb[2], r.bb[3]); cz = make_double2(r.bb[4], r.bb[5]); j = r.idx;
-                                }
-                                // -- against the row's own bodies, one after the other through the scalar cache
-#pragma unroll
-                                for (int x = 0; x < 4; x++) {
-                                    for (uint32_t r = 0; r < ocnt[x]; r++) {
-                                        const BpRecS o = sload_rec(own_base + x * BP_CAP + r);
-                                        if (o.cx != 4 * bx + x || o.cy != 4 * by + (int32_t)y || o.cz != 4 * bz + (int32_t)z) continue;   // another block's (uniform)
-                                        const int ol = 16 * x + (int)r;
-                                        if (lane == ol) { oidx = o.idx; ovalid = 1; }
-                                        donem[x] |= 1u << r;
-                                        const bool hit = valid & !((o.x0 > cx.y) | (o.x1 < cx.x) | (o.y0 > cy.y) | (o.y1 < cy.x) | (o.z0 > cz.y) | (o.z1 < cz.x)) &
-                                                         (is_static | (j > o.idx));
-                                        const uint64_t hm = __ballot(hit);
-                                        if (hm) {
-                                            uint32_t &a = is_static ? sacc : acc;
-                                            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)a, ol) + lanes_below(hm);
-                                            if (hit && at < (uint32_t)BP_LIST) (is_static ? k.spartners : k.partners)[(size_t)o.idx * BP_LIST + at] = j;
-                                            if (lane == ol) a += (uint32_t)__popcll(hm);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        if (ovalid) {
-                            k.cnt[oidx] = acc;
-                            if (statics) k.scnt[oidx] = sacc;
-                        }
-                        if (lane < 4) {
-                            const uint32_t dm = lane == 0 ? donem[0] : lane == 1 ? donem[1] : lane == 2 ? donem[2] : donem[3];
-                            if (dm) atomicOr(&s.done[un][pos0 + lane], dm);
-                        }
-                    }
-                    BP_TICK(5);
-                    __syncthreads();
-                    BP_TICK(6);
-                    return true;
-                };
-                if (!pass(0u, nu))
-                    for (uint32_t u = 0; u < nu; u++) {
-                        if (!(found >> u & 1u)) continue;
-                        if (nu > 1 && pass(u, u + 1)) continue;
-                        // the block alone has more records around it than the image holds: its bodies one by one, from memory
-                        for (uint32_t q = wave; q < 64u * BP_CAP; q += W) {
-                            const uint32_t pos = q / BP_CAP, r = q % BP_CAP;
-                            if (r >= s.own_cnt[u][pos]) continue;
-                            const BpRecS me = sload_rec(k.table + ((size_t)s.ubucket[u] * 64 + pos) * BP_CAP + r);
-                            if ((me.cx >> 2) != s.blk[u][0] || (me.cy >> 2) != s.blk[u][1] || (me.cz >> 2) != s.blk[u][2]) continue;
-                            bp_body_from_memory(k, ccnt, novf, me);
-                            if (lane == 0) atomicOr(&s.done[u][pos], 1u << r);
-                        }
-                        __syncthreads();
-                    }
-            }
-            __syncthreads();                                             // s.blk is rewritten by the next trip
         }
-        if ((win + 1) * BP_MINE >= my_total) break;
     }
-    BP_TICK(7);
-#ifdef BP_EXP_TIMING
-    if (tid == 0) {                                                      // 100 MHz ticks: first start, last end, longest, sum
-        const uint64_t wall1__ = wall_clock64();
-        atomicMin(&k.ctrl[48], (uint32_t)wall0__);
-        atomicMax(&k.ctrl[49], (uint32_t)wall1__);
-        atomicMax(&k.ctrl[50], (uint32_t)(wall1__ - wall0__));
-        atomicAdd(&k.ctrl[51], (uint32_t)(wall1__ - wall0__));
-    }
-#endif
-
-    // -------------------------------------------------------------------- overflow bodies: one wavefront per body
-    for (uint32_t o = blockIdx.x * W + wave; o < novf; o += G * W)
-        bp_body_from_memory(k, ccnt, novf, sload_rec(k.ovf + o));
+    wave_lds_fence();
+    if (isA) k.scnt[aidx[wave][lane]] = shits[wave][lane];
 }
 
 // all partners of body i (larger index) in ascending order, for a body whose list did not fit its slot: one lane
-// walks its 27 cells and the overflow list
+// walks its 27 cells
 template <typename F>
-__device__ __forceinline__ void research_body(const BpK &k, uint32_t par, uint32_t i, F &&emit_sorted)
+__device__ __forceinline__ void research_body(const BpK &k, uint32_t i, F &&emit_sorted)
 {
     double a[6];
     load_box(k.aabb, i, a);
     int32_t cx, cy, cz;
     box_cell(a, k.cell, cx, cy, cz);
-    const uint32_t *ccnt = k.cell_cnt + (size_t)par * k.slots;
-    const uint32_t novf = k.ctrl[CTRL_OVF + par];
     uint32_t last = i;                                                   // partners > i, ascending: repeated minimum search
     for (;;) {
         uint32_t best = 0xffffffffu;
         for (int cq = 0; cq < 27; cq++) {
             const uint32_t slot = cell_slot(cx - 1 + cq % 3, cy - 1 + (cq / 3) % 3, cz - 1 + cq / 9, k.mask);
-            uint32_t c = ccnt[slot];
-            if (c > (uint32_t)BP_CAP) c = BP_CAP;
-            for (uint32_t e = 0; e < c; e++) {
-                const BpRec *r = k.table + (size_t)slot * BP_CAP + e;
-                const uint32_t j = r->idx;
+            const uint2 cr = k.cell_range[slot];
+            const uint32_t s0 = cr.x, s1 = cr.x + cr.y;
+            for (uint32_t s = s0; s < s1; s++) {
+                const uint32_t j = k.entries[s];
                 if (j <= last || j >= best) continue;
-                if (boxes_overlap(a, r->bb)) best = j;
+                double bj[6];
+                load_box(k.aabb, j, bj);
+                if (boxes_overlap(a, bj)) best = j;
             }
-        }
-        for (uint32_t e = 0; e < novf; e++) {
-            const BpRec *r = k.ovf + e;
-            const uint32_t j = r->idx;
-            if (j <= last || j >= best) continue;
-            if (boxes_overlap(a, r->bb)) best = j;
         }
         if (best == 0xffffffffu) break;
         emit_sorted(best);
@@ -959,7 +705,7 @@ __device__ __forceinline__ void research_body(const BpK &k, uint32_t par, uint32
     }
 }
 
-// Launch 3
+// Launch 5
 __global__ __launch_bounds__(BP_EMIT_TILE)
 void k_bp_emit(BpK k)
 {
@@ -968,13 +714,13 @@ void k_bp_emit(BpK k)
     const uint32_t i = blockIdx.x * BP_EMIT_TILE + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const bool with_statics = k.n_static != 0;
-    const uint32_t par = k.ctrl[CTRL_PAR_CUR] & 1u;
     uint32_t c[2] = { 0, 0 };
     if (i < k.n) {
         c[0] = k.cnt[i];
-        if (with_statics) c[1] = k.scnt[i];
+        k.cnt[i] = 0;                                                    // ready for the next frame's atomics
+        if (with_statics) { c[1] = k.scnt[i]; k.scnt[i] = 0; }
     }
-    // the lists travel while the offsets are scanned
+    // the lists travel while the offsets are scanned: their loads do not depend on the look-back
     uint4 pl[2][BP_LIST / 4];
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -1016,6 +762,7 @@ void k_bp_emit(BpK k)
     uint32_t woff[2] = { 0, 0 };
     for (int qq = 0; qq < wave; qq++) { woff[0] += lds[0][qq]; woff[1] += lds[1][qq]; }
     if (i >= k.n) return;
+    // a list of n <= BP_LIST entries, out in ascending order: the rank of an entry = the entries below it
     auto ranked = [&](const uint4 (&l4)[BP_LIST / 4], uint32_t n, uint32_t off, uint2 *out, uint32_t cap) {
         uint32_t v[BP_LIST];
 #pragma unroll
@@ -1036,7 +783,7 @@ void k_bp_emit(BpK k)
         if (c[0] <= (uint32_t)BP_LIST) ranked(pl[0], c[0], off, out, k.capacity);
         else {
             uint32_t w = 0;
-            research_body(k, par, i, [&](uint32_t j) { if (off + w < k.capacity) out[off + w] = make_uint2(i, j); w++; });
+            research_body(k, i, [&](uint32_t j) { if (off + w < k.capacity) out[off + w] = make_uint2(i, j); w++; });
         }
     }
     if (c[1]) {
@@ -1477,25 +1224,18 @@ extern "C" int clapgpu_bodies_step(void *stream, const clapgpu_bodies *b, const 
 
 // ---------------------------------------------------------------------------------- broadphase object
 struct clapgpu_bp {
-    uint32_t n_max, buckets, n_static, n_large, n_tiles, grid;
+    uint32_t n_max, buckets, n_static, n_large, n_tiles;
     double cell;
     void *dev;                     // one allocation
     BpK k;                         // device pointers filled in
-    // clapgpu_bodies_step_prebin: the step that wrote these boxes has also binned them (table records, cell counters,
-    // parity, epoch): the next clapgpu_bp_collide over the same array skips its first launch
+    // clapgpu_bodies_step_prebin: the step that wrote these boxes has also binned them (key / rank / cell counters / epoch):
+    // the next clapgpu_bp_collide over the same array skips its first launch
     const double *prebinned_aabb;
     uint32_t prebinned_n;
 };
 
-static BinK bin_k(const clapgpu_bp *bp)
-{
-    BinK bin = { bp->cell, bp->k.mask, bp->k.slots, bp->k.cell_cnt, bp->k.bflag, bp->k.table, bp->k.ovf, bp->k.ctrl };
-    return bin;
-}
-
 // The step + the NEXT broadphase's bin pass in one launch (the bin pass reads nothing but the box the step has in
-// registers, and its one atomic and one record per body hide under the step's fp64 traffic): -1 launch and the boxes'
-// re-read per substep.
+// registers, and its one atomic per body hides under the step's fp64 traffic): -1 launch and the boxes' re-read per substep.
 extern "C" int clapgpu_bodies_step_prebin(void *stream, const clapgpu_bodies *b, const clapgpu_world *w, double h, clapgpu_bp *bp)
 {
     int rc = check_bodies2(b);
@@ -1509,7 +1249,8 @@ extern "C" int clapgpu_bodies_step_prebin(void *stream, const clapgpu_bodies *b,
     }
     WorldK2 wk;
     memcpy(&wk, w, sizeof(wk));
-    hipLaunchKernelGGL(k_bodies_step<true>, dim3((b->n + PB - 1) / PB), dim3(PB), 0, as_stream(stream), bodies_k(b), wk, h, bin_k(bp));
+    BinK bin = { bp->cell, bp->k.mask, bp->k.key, bp->k.rank, bp->k.cell_cnt, bp->k.ctrl };
+    hipLaunchKernelGGL(k_bodies_step<true>, dim3((b->n + PB - 1) / PB), dim3(PB), 0, as_stream(stream), bodies_k(b), wk, h, bin);
     CLAPGPU_LAUNCH_CHECK("k_bodies_step<prebin>");
     bp->prebinned_aabb = b->aabb;
     bp->prebinned_n = b->n;
@@ -1517,16 +1258,13 @@ extern "C" int clapgpu_bodies_step_prebin(void *stream, const clapgpu_bodies *b,
 }
 
 // The boxes a step pre-binned were changed by somebody else (clapgpu_bodies_aabb, an upload, another body count): the cell
-// counters of both parities and the overflow counts go back to zero -- what a search leaves behind for the next bin --
-// and the next collide bins for itself.
+// counters go back to zero -- what k_bp_cells leaves between frames -- and the next collide bins for itself.
 extern "C" int clapgpu_bp_invalidate(void *stream, clapgpu_bp *bp)
 {
     if (!bp) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!bp->prebinned_aabb) return CLAPGPU_OK;
     bp->prebinned_aabb = nullptr; bp->prebinned_n = 0;
-    CLAPGPU_HIP(hipMemsetAsync(bp->k.cell_cnt, 0, 2 * (size_t)bp->k.slots * sizeof(uint32_t), as_stream(stream)));
-    CLAPGPU_HIP(hipMemsetAsync(bp->k.bflag, 0, 2 * (size_t)bp->buckets, as_stream(stream)));
-    CLAPGPU_HIP(hipMemsetAsync(bp->k.ctrl + CTRL_OVF, 0, 2 * sizeof(uint32_t), as_stream(stream)));
+    CLAPGPU_HIP(hipMemsetAsync(bp->k.cell_cnt, 0, (size_t)bp->buckets * 64 * sizeof(uint32_t), as_stream(stream)));
     return CLAPGPU_OK;
 }
 
@@ -1548,14 +1286,6 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     const uint32_t n = n_max ? n_max : 1, nb = buckets_for(n);
     bp->n_max = n_max; bp->buckets = nb; bp->cell = cell; bp->n_static = n_static;
     bp->n_tiles = (n + BP_EMIT_TILE - 1) / BP_EMIT_TILE;
-    {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        bp->grid = (uint32_t)cus * BP_WGS_PER_CU;                 // the search's workgroups: as many as are resident at once
-    }
 
     // statics: every block whose own bodies could touch the static (its AABB grown by half a cell), as a CSR over
     // the same buckets; statics that would enter more than 64 blocks go to the large list
@@ -1604,29 +1334,26 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     if (ins.empty()) memset(&s_recs[0], 0, sizeof(BpRec));
     if (s_large.empty()) { memset(&s_lrecs[0], 0, sizeof(BpRec)); s_large.push_back(0); }
 
-    // one device allocation, carved; the table (slots x BP_CAP records) is the bulk of it and is never cleared: a record
-    // is read only below its cell's count
-    const size_t slots = (size_t)nb * 64;
+    // one device allocation, carved
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
-    const size_t o_ccnt = take(2 * 4 * slots), o_bflag = take(2 * (size_t)nb);
+    const size_t o_ccnt = take(4 * (size_t)nb * 64), o_crange = take(8 * (size_t)nb * 64);
+    const size_t o_key = take(4 * (size_t)n), o_ranks = take(4 * (size_t)n), o_entries = take(4 * (size_t)n), o_recs = take(64 * (size_t)n);
     const size_t o_cnt = take(4 * (size_t)n), o_scnt = take(4 * (size_t)n);
     const size_t o_part = take(4 * (size_t)BP_LIST * n), o_spart = take(4 * (size_t)BP_LIST * n);
-    const size_t o_lbb = take(8 * (size_t)bp->n_tiles), o_lbs = take(8 * (size_t)bp->n_tiles);
+    const size_t o_lbb = take(8 * (size_t)bp->n_tiles), o_lbs = take(8 * (size_t)bp->n_tiles), o_lbc = take(8 * ((size_t)nb / 4 + 1));
     const size_t o_ctrl = take(4 * 160);
     const size_t o_sstart = take(4 * ((size_t)nb + 1)), o_sent = take(4 * s_entries.size()), o_slarge = take(4 * s_large.size());
     const size_t o_saabb = take(48 * (size_t)(n_static ? n_static : 1));
     const size_t o_srecs = take(sizeof(BpRec) * s_recs.size()), o_slrecs = take(sizeof(BpRec) * s_lrecs.size());
-    const size_t cleared = off;
-    const size_t o_ovf = take(sizeof(BpRec) * (size_t)n), o_table = take(sizeof(BpRec) * slots * BP_CAP);
-    const size_t total = off;
-    if (hipMalloc(&bp->dev, total) != hipSuccess) {
+    const size_t fixed = off;
+    if (hipMalloc(&bp->dev, fixed) != hipSuccess) {
         (void)hipGetLastError();
         free(bp);
         return CLAPGPU_ERR_NOMEM;
     }
     char *d = static_cast<char *>(bp->dev);
-    if (hipMemset(d, 0, cleared) != hipSuccess ||
+    if (hipMemset(d, 0, fixed) != hipSuccess ||
         hipMemcpy(d + o_sstart, s_count.data(), 4 * ((size_t)nb + 1), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + o_sent, s_entries.data(), 4 * s_entries.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d + o_slarge, s_large.data(), 4 * s_large.size(), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1640,13 +1367,14 @@ extern "C" int clapgpu_bp_create(clapgpu_bp **out, uint32_t n_max, double cell, 
     }
     BpK &k = bp->k;
     memset(&k, 0, sizeof(k));
-    k.cell = cell; k.mask = nb - 1; k.slots = (uint32_t)slots;
-    k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt);
-    k.bflag = reinterpret_cast<uint8_t *>(d + o_bflag);
-    k.table = reinterpret_cast<BpRec *>(d + o_table); k.ovf = reinterpret_cast<BpRec *>(d + o_ovf);
+    k.cell = cell; k.mask = nb - 1;
+    k.cell_cnt = reinterpret_cast<uint32_t *>(d + o_ccnt); k.cell_range = reinterpret_cast<uint2 *>(d + o_crange);
+    k.key = reinterpret_cast<uint32_t *>(d + o_key); k.rank = reinterpret_cast<uint32_t *>(d + o_ranks);
+    k.entries = reinterpret_cast<uint32_t *>(d + o_entries); k.recs = reinterpret_cast<BpRec *>(d + o_recs);
     k.cnt = reinterpret_cast<uint32_t *>(d + o_cnt); k.scnt = reinterpret_cast<uint32_t *>(d + o_scnt);
     k.partners = reinterpret_cast<uint32_t *>(d + o_part); k.spartners = reinterpret_cast<uint32_t *>(d + o_spart);
     k.lb_body = reinterpret_cast<uint64_t *>(d + o_lbb); k.lb_static = reinterpret_cast<uint64_t *>(d + o_lbs);
+    k.lb_cells = reinterpret_cast<uint64_t *>(d + o_lbc);
     k.ctrl = reinterpret_cast<uint32_t *>(d + o_ctrl);
     k.s_start = reinterpret_cast<const uint32_t *>(d + o_sstart); k.s_entries = reinterpret_cast<const uint32_t *>(d + o_sent);
     k.s_large = reinterpret_cast<const uint32_t *>(d + o_slarge); k.s_aabb = reinterpret_cast<const double *>(d + o_saabb);
@@ -1691,10 +1419,14 @@ extern "C" int clapgpu_bp_collide(void *stream, clapgpu_bp *bp, uint32_t n, cons
             int rc = clapgpu_bp_invalidate(stream, bp);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k, bin_k(bp));
+        hipLaunchKernelGGL(k_bp_bin, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
         CLAPGPU_LAUNCH_CHECK("k_bp_bin");
     }
-    hipLaunchKernelGGL((k_bp_search<BP_T, BP_MAXC>), dim3(bp->grid), dim3(BP_T), 0, s, k);
+    hipLaunchKernelGGL(k_bp_cells, dim3((bp->buckets + BP_CELLS_BLOCK / WAVE - 1) / (BP_CELLS_BLOCK / WAVE)), dim3(BP_CELLS_BLOCK), 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_cells");
+    hipLaunchKernelGGL(k_bp_scatter, dim3((n + PB - 1) / PB), dim3(PB), 0, s, k);
+    CLAPGPU_LAUNCH_CHECK("k_bp_scatter");
+    hipLaunchKernelGGL(k_bp_search, dim3((n + (PB / WAVE) * BP_TILE - 1) / ((PB / WAVE) * BP_TILE)), dim3(PB), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_search");
     hipLaunchKernelGGL(k_bp_emit, dim3(k.n_tiles), dim3(BP_EMIT_TILE), 0, s, k);
     CLAPGPU_LAUNCH_CHECK("k_bp_emit");
@@ -1782,16 +1514,3 @@ extern "C" int clapgpu_sweep_capsules(void *stream, const clapgpu_geoms *A, cons
     CLAPGPU_LAUNCH_CHECK("k_sweep_capsules");
     return CLAPGPU_OK;
 }
-
-#ifdef BP_EXP_TIMING
-extern "C" void clapgpu_bp_debug_ctrl(clapgpu_bp *bp, uint32_t *out160)   // experiment builds: the control words, after a device sync
-{
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(out160, bp->k.ctrl, 160 * sizeof(uint32_t), hipMemcpyDeviceToHost);
-}
-extern "C" void clapgpu_bp_debug_set(clapgpu_bp *bp, uint32_t at, const uint32_t *v, uint32_t n)
-{
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(bp->k.ctrl + at, v, n * sizeof(uint32_t), hipMemcpyHostToDevice);
-}
-#endif
