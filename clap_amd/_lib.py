@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLAPGPU_LIB") or os.path.join(_HERE, "lib", "libclapgpu.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 OK = 0
 ERR_NOMEM = -1
@@ -50,6 +50,16 @@ class BvQuery(C.Structure):
                 ("ctl_entity", C.c_uint32), ("result", C.c_void_p), ("inside_mask", C.c_void_p)]
 
 
+EXTRA_VIEWS_MAX = 4
+
+
+class Views(C.Structure):
+    """clapgpu_views (include/clapgpu.h): the frame's other frusta, culled by the same launch as the main one."""
+    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("frustum", Frustum * EXTRA_VIEWS_MAX),
+                ("vis_mask", C.c_void_p * EXTRA_VIEWS_MAX), ("vis_row_pop", C.c_void_p * EXTRA_VIEWS_MAX),
+                ("host_vis_mask", C.c_void_p * EXTRA_VIEWS_MAX)]
+
+
 class Entities(C.Structure):
     """clapgpu_entities (include/clapgpu.h)."""
     _fields_ = [("n", C.c_uint32), ("n_models", C.c_uint32),
@@ -59,7 +69,8 @@ class Entities(C.Structure):
                 ("aabb", C.c_void_p), ("center", C.c_void_p), ("vis_mask", C.c_void_p),
                 ("vis_row_pop", C.c_void_p), ("n_attach", C.c_uint32), ("pad", C.c_uint32),
                 ("attach", C.c_void_p), ("jt_pool", C.c_void_p), ("bind_pool", C.c_void_p),
-                ("attach_local", C.c_void_p), ("bv", C.POINTER(BvQuery)), ("rebuilt_mask", C.c_void_p)]
+                ("attach_local", C.c_void_p), ("bv", C.POINTER(BvQuery)), ("rebuilt_mask", C.c_void_p),
+                ("views", C.POINTER(Views))]
 
 
 class Particles(C.Structure):

@@ -30,11 +30,11 @@ namespace clapgpu {
 // SIMD idled.  Here no vector load is issued between the prefetch of the next row and the hand-over, and the big
 // stores are unconditional, so the hand-over waits for "all but the last N operations" and the stores stay in
 // flight under the next row's arithmetic.
-template <bool CULL>
+template <bool CULL, bool XV = false>
 __device__ __forceinline__ void process_row_fast(const EntK &e, const RowIn &in, float4 *tile, const float4 *mt,
                                                  const int lane, const uint32_t row_first, const uint32_t mode,
                                                  const lmd::FrustumK &fr, const int src, const uint32_t parent_seq_now,
-                                                 float (&carry_mx)[16], uint32_t &carry_seq)
+                                                 float (&carry_mx)[16], uint32_t &carry_seq, const XViewsK *xv = nullptr)
 {
     const uint32_t i = row_first + lane;
     const uint32_t fl = in.fl;
@@ -116,6 +116,7 @@ __device__ __forceinline__ void process_row_fast(const EntK &e, const RowIn &in,
         const uint64_t m = __ballot(vis);
         e.vis_mask[e0 >> 6] = m;                                 // the same word from all 64 lanes: one request
         e.vis_row_pop[e0 >> 6] = (uint8_t)__popcll(m);
+        if constexpr (XV) cull_extra_views(*xv, (fl & CLAPGPU_E_VISIBLE) != 0, fl, bb, (uint32_t)(e0 >> 6), lane);
     }
 }
 
@@ -175,106 +176,74 @@ __global__ __launch_bounds__(ENT_BLOCK, ENT_TILE_WAVES)
 void k_entities_tiles(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
                       uint32_t mode)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)fr_arg;                                                // read at kernarg offset 0: see the static_assert behind this kernel
-    // kept in the constant address space through the laundering below: the planes then come through the scalar cache
-    // (s_load, counted with LDS), not as flat loads, whose wait is a wait for every vector store before them
-    typedef const __attribute__((address_space(4))) lmd::FrustumK *frustum_ptr;
-    frustum_ptr frp = (frustum_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    typedef const lmd::FrustumK *frustum_ptr;
-    frustum_ptr frp = &fr_arg;                                   // host pass of the compiler only
-#endif
-    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
-    __shared__ float4 mt_lds[2 * ENT_MT_CAP];                    // the model table, for process_row_fast
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // uniform, and known to be: the row loops stay scalar
-    const bool mt_cached = e.n_models <= (uint32_t)ENT_MT_CAP;
-    if (mt_cached)
-        for (uint32_t k = threadIdx.x; k < 2 * e.n_models; k += ENT_BLOCK) mt_lds[k] = e.model_table[k];
-    __syncthreads();                                             // the only workgroup barrier: ahead of every return
-    const uint32_t t = blockIdx.x * (ENT_BLOCK / WAVE) + wave;
-    if (t >= n_tiles)
-        return;
-    const uint32_t n_rows = (n + WAVE - 1) / WAVE;
-    uint32_t row = tile_row_start[t], row_end = tile_row_start[t + 1];
-    if (row_end > n_rows) row_end = n_rows;                      // never walk past the arrays
-    if (row >= row_end)
-        return;
+#define TILES_XV 0
+#define TILES_XV_PTR nullptr
+#include "entities_tiles_body.inc"
+#undef TILES_XV
+#undef TILES_XV_PTR
+}
 
+// ... with the frame's further views (clapgpu_entities.views): one more mask word per view and row
+__global__ __launch_bounds__(ENT_BLOCK, ENT_TILE_WAVES)
+void k_entities_tiles_xv(lmd::FrustumK fr_arg, EntK e, const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n,
+                         uint32_t mode, XViewsK xv)
+{
+    constexpr bool CULL = true;
+#define TILES_XV 1
+#define TILES_XV_PTR (&xv)
+#include "entities_tiles_body.inc"
+#undef TILES_XV
+#undef TILES_XV_PTR
+}
+
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_level_xv(EntK e, uint32_t first, uint32_t count, uint32_t mode, lmd::FrustumK fr, XViewsK xv)
+{
+    __shared__ float4 lds_tiles[ENT_BLOCK / WAVE][LDS_F4_PER_WAVE];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    const uint32_t wave_local0 = blockIdx.x * ENT_BLOCK + wave * WAVE;
+    if (wave_local0 >= count)
+        return;
+    const uint32_t row_count = count - wave_local0 < WAVE ? count - wave_local0 : WAVE;
     float carry_mx[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) carry_mx[k] = 0.f;
     uint32_t carry_seq = 0;
     bool carry_valid = false;
-    bool have_prev = false;
-
-    uint32_t row_first = row * WAVE;
-    uint32_t row_count = n - row_first < WAVE ? n - row_first : WAVE;
-    RowIn cur = load_row(e, lane, row_first, row_count);
-
-    // ---- rows that qualify for process_row_fast, until the first one that does not: the rest of the tile (and every
-    // tile of a launch with a camera query or a model table too large for LDS) goes through the general loop below.
-    // Two loops, not a branch inside one: the straight-line loop must never be re-entered from a path whose stores
-    // the compiler cannot count.
-    if (mt_cached && !e.bv_on) {
-        // the first row's inputs are waited for HERE: left pending into the loop, their wait would sit inside it and,
-        // on the way round, stand for "all but seven operations" -- the previous row's stores again
-        asm volatile("" : : "v"(cur.ps.w), "v"(cur.q.w), "v"(cur.fl), "v"(cur.sq), "v"(cur.mi), "v"(cur.p));
-        for (;;) {
-            const uint32_t fl = cur.fl;
-            const int32_t p = cur.p;
-            const bool in_prev = have_prev && p >= 0 && (uint32_t)p >= row_first - WAVE && (uint32_t)p < row_first;
-            const int src = in_prev ? (int)((uint32_t)p - (row_first - WAVE)) : lane;
-            const uint32_t parent_seq_now = __shfl(carry_seq, src);
-            const bool parent_ok = p < 0 || (in_prev && __shfl((int)carry_valid, src) != 0);
-            const bool dirty = (mode & CLAPGPU_UPDATE_ALL_DIRTY) ? true : (fl & CLAPGPU_E_DIRTY) != 0;
-            const bool rebuild = p >= 0 ? !((cur.sq >> 16) == parent_seq_now && !dirty) : dirty;
-            const bool lane_ok = (fl & CLAPGPU_E_ALIVE) && rebuild && parent_ok &&
-                                 !((fl & CLAPGPU_E_JOINT_ATTACHED) && e.n_attach) &&
-                                 __float_as_uint(mt_lds[2 * cur.mi].w) == 0u;
-            if (row_count != WAVE || __ballot(lane_ok) != ~0ull)
-                break;
-            const uint32_t next = row + 1;
-            const bool more = next < row_end;
-            const uint32_t nfirst = more ? next * WAVE : row_first;
-            const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
-            const RowIn nxt = load_row(e, lane, nfirst, ncount);
-            frustum_ptr frr = frp;
-            asm volatile("" : "+s"(frr));
-            process_row_fast<CULL>(e, cur, lds_tiles[wave], mt_lds, lane, row_first, mode, *(const lmd::FrustumK *)frr, src, parent_seq_now,
-                                   carry_mx, carry_seq);
-            carry_valid = true;
-            if (!more)
-                return;
-            have_prev = true;
-            cur = nxt;
-            row = next;
-            row_first = nfirst;
-            row_count = ncount;
-        }
-    }
-    for (;;) {
-        const uint32_t next = row + 1;
-        const bool more = next < row_end;
-        const uint32_t nfirst = more ? next * WAVE : row_first;  // last row: harmless re-load
-        const uint32_t ncount = n - nfirst < WAVE ? n - nfirst : WAVE;
-        const RowIn nxt = load_row(e, lane, nfirst, ncount);     // in flight during process_row
-        frustum_ptr frr = frp;
-        asm volatile("" : "+s"(frr));                            // the planes are re-read (scalar cache) each row
-        process_row<CULL, true>(e, cur, lds_tiles[wave], lane, row_first, row_count, mode, *(const lmd::FrustumK *)frr,
-                                have_prev, row_first - WAVE, carry_mx, carry_seq, carry_valid);
-        if (!more)
-            break;
-        have_prev = true;
-        cur = nxt;
-        row = next;
-        row_first = nfirst;
-        row_count = ncount;
-    }
+    const RowIn in = load_row(e, lane, first + wave_local0, row_count);
+    process_row<true, false, false, true>(e, in, lds_tiles[wave], lane, first + wave_local0, row_count, mode, fr,
+                                          false, 0, carry_mx, carry_seq, carry_valid, nullptr, nullptr, &xv);
 }
 
 // Cull-only pass over stored AABBs (one per render pass in the reference).
+// ... every view of the frame from one read of the boxes
+__global__ __launch_bounds__(ENT_BLOCK)
+void k_entities_cull_xv(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint8_t *vis_row_pop,
+                        uint32_t n, lmd::FrustumK fr, XViewsK xv)
+{
+    const uint32_t i = blockIdx.x * ENT_BLOCK + threadIdx.x;
+    const int lane = lane_id();
+    bool base = false, vis = false;
+    uint32_t fl = 0;
+    float bb[6] = { 0, 0, 0, 0, 0, 0 };
+    if (i < n) {
+        fl = flags[i];
+        base = (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE);
+        vis = base;
+        if (base && !(fl & CLAPGPU_E_SKIP_CULLING)) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) bb[k] = aabb[6 * (size_t)i + k];
+            vis = lmd::aabb_in_frustum_fast(fr, bb);
+        }
+    }
+    if ((i - lane) >= n) return;                                 // the whole wavefront is past the end
+    const uint64_t m = __ballot(vis);
+    if (lane == 0) {
+        vis_mask[i >> 6] = m;
+        vis_row_pop[i >> 6] = (uint8_t)__popcll(m);
+    }
+    cull_extra_views(xv, base, fl, bb, i >> 6, lane);
+}
+
 __global__ __launch_bounds__(ENT_BLOCK)
 void k_entities_cull(const uint32_t *flags, const float *aabb, uint64_t *vis_mask, uint8_t *vis_row_pop,
                      uint32_t n, lmd::FrustumK fr)
@@ -661,6 +630,7 @@ template <class R, class A0, class... A> struct first_param<R (*)(A0, A...)> { u
 static_assert(std::is_same<first_param<decltype(&k_entities_tiles<true>)>::type, lmd::FrustumK>::value &&
               std::is_same<first_param<decltype(&k_entities_tiles<false>)>::type, lmd::FrustumK>::value,
               "k_entities_tiles: the frustum must stay the first kernel argument (it is read at kernarg offset 0)");
+static_assert(std::is_same<first_param<decltype(&k_entities_tiles_xv)>::type, lmd::FrustumK>::value, "k_entities_tiles_xv: the same");
 static_assert(alignof(lmd::FrustumK) <= 8, "kernarg offset 0 holds for any alignment the segment start guarantees");
 
 } // namespace clapgpu
@@ -739,6 +709,25 @@ static lmd::FrustumK make_frustum_k(const clapgpu_frustum *frustum)
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// clapgpu_entities.views for the kernels; false: a count beyond the maximum, a missing plane
+namespace clapgpu {
+bool make_xviews_k(const clapgpu_entities *e, bool hostio, XViewsK *out)
+{
+    memset(out, 0, sizeof(*out));
+    const clapgpu_views *v = e->views;
+    if (!v || !v->n) return true;
+    if (v->n > CLAPGPU_EXTRA_VIEWS_MAX) return false;
+    out->n = v->n;
+    for (uint32_t k = 0; k < v->n; k++) {
+        if (!v->vis_mask[k] || !v->vis_row_pop[k]) return false;
+        out->mask[k] = v->vis_mask[k]; out->pop[k] = v->vis_row_pop[k];
+        out->o_mask[k] = hostio ? v->host_vis_mask[k] : nullptr;
+        out->fr[k] = make_frustum_k(&v->frustum[k]);
+    }
+    return true;
+}
+}
+
 static int check_entities(const clapgpu_entities *e, bool need_mask)
 {
     if (!e || !e->pos_scale || !e->rot || !e->parent || !e->model || !e->model_table || !e->flags ||
@@ -763,11 +752,13 @@ static int prepare_attachments(void *stream, const EntK &k)
 }
 
 static int launch_level(void *stream, const EntK &k, uint32_t first, uint32_t count, uint32_t mode,
-                        const clapgpu_frustum *frustum)
+                        const clapgpu_frustum *frustum, const XViewsK &xv)
 {
     const lmd::FrustumK fr = make_frustum_k(frustum);
     const dim3 grid((count + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
-    if (frustum)
+    if (frustum && xv.n)
+        hipLaunchKernelGGL(k_entities_level_xv, grid, block, 0, as_stream(stream), k, first, count, mode, fr, xv);
+    else if (frustum)
         hipLaunchKernelGGL(k_entities_level<true>, grid, block, 0, as_stream(stream), k, first, count, mode, fr);
     else
         hipLaunchKernelGGL(k_entities_level<false>, grid, block, 0, as_stream(stream), k, first, count, mode, fr);
@@ -788,9 +779,11 @@ extern "C" int clapgpu_entities_update_level(void *stream, const clapgpu_entitie
     if (!count)
         return CLAPGPU_OK;
     const EntK k = to_kernel_args(e);
+    XViewsK xv;
+    if (!make_xviews_k(e, false, &xv)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     rc = prepare_attachments(stream, k);
     if (rc) return rc;
-    return launch_level(stream, k, first, count, mode, frustum);
+    return launch_level(stream, k, first, count, mode, frustum, xv);
 }
 
 extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
@@ -810,6 +803,8 @@ extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
             return CLAPGPU_ERR_INVALID_ARGUMENTS;
 
     const EntK k = to_kernel_args(e);
+    XViewsK xv;
+    if (!make_xviews_k(e, false, &xv)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (k.bv_result)
         CLAPGPU_HIP(hipMemsetAsync(k.bv_result, 0, sizeof(uint64_t), as_stream(stream)));
     rc = prepare_attachments(stream, k);
@@ -818,7 +813,7 @@ extern "C" int clapgpu_entities_update(void *stream, const clapgpu_entities *e,
         const uint32_t first = level_start[l], count = level_start[l + 1] - first;
         if (!count)
             continue;
-        rc = launch_level(stream, k, first, count, mode, frustum);
+        rc = launch_level(stream, k, first, count, mode, frustum, xv);
         if (rc) return rc;
     }
     return CLAPGPU_OK;
@@ -836,13 +831,17 @@ extern "C" int clapgpu_entities_update_tiles(void *stream, const clapgpu_entitie
         return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const lmd::FrustumK fr = make_frustum_k(frustum);
     const EntK k = to_kernel_args(e);
+    XViewsK xv;
+    if (!make_xviews_k(e, false, &xv)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (k.bv_result)
         CLAPGPU_HIP(hipMemsetAsync(k.bv_result, 0, sizeof(uint64_t), as_stream(stream)));
     rc = prepare_attachments(stream, k);
     if (rc) return rc;
     const uint32_t per_block = ENT_BLOCK / WAVE;
     const dim3 grid((n_tiles + per_block - 1) / per_block), block(ENT_BLOCK);
-    if (frustum)
+    if (frustum && xv.n)
+        hipLaunchKernelGGL(k_entities_tiles_xv, grid, block, 0, as_stream(stream), fr, k, tile_row_start, n_tiles, e->n, mode, xv);
+    else if (frustum)
         hipLaunchKernelGGL(k_entities_tiles<true>, grid, block, 0, as_stream(stream), fr, k, tile_row_start, n_tiles,
                            e->n, mode);
     else
@@ -859,7 +858,13 @@ extern "C" int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, co
     if (e->n == 0)
         return CLAPGPU_OK;
     const lmd::FrustumK fr = make_frustum_k(frustum);
+    XViewsK xv;
+    if (!make_xviews_k(e, false, &xv)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     const dim3 grid((e->n + ENT_BLOCK - 1) / ENT_BLOCK), block(ENT_BLOCK);
+    if (xv.n)
+        hipLaunchKernelGGL(k_entities_cull_xv, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask,
+                           e->vis_row_pop, e->n, fr, xv);
+    else
     hipLaunchKernelGGL(k_entities_cull, grid, block, 0, as_stream(stream), e->flags, e->aabb, e->vis_mask,
                        e->vis_row_pop, e->n, fr);
     CLAPGPU_LAUNCH_CHECK("k_entities_cull");
@@ -963,7 +968,9 @@ extern "C" int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_
     h.keep = io->keep_mask; h.o_exported = io->exported_mask; h.stale = io->stale_mask;
     h.late_ok = io->options & CLAPGPU_HOSTIO_EXPORT_STALE_READ;
     const uint32_t tiles = e->n ? n_tiles : 0;
-    rc = launch_entities_tiles_host(as_stream(stream), frustum != nullptr, fr, k, h, tile_row_start, tiles, e->n, mode);
+    XViewsK xv;
+    if (!make_xviews_k(e, true, &xv)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    rc = launch_entities_tiles_host(as_stream(stream), frustum != nullptr, fr, k, h, tile_row_start, tiles, e->n, mode, xv);
     if (rc) return rc;
     return CLAPGPU_OK;
 }

@@ -39,6 +39,37 @@ struct EntK {                    // kernel-argument copy of clapgpu_entities
     uint32_t        n, n_models;     // bounds of the two indices the caller supplies per entity
 };
 
+// clapgpu_views as the kernels take it (by value, in the kernarg segment: a view's planes come through the scalar cache)
+struct XViewsK {
+    uint32_t n, pad;
+    uint64_t *mask[CLAPGPU_EXTRA_VIEWS_MAX];
+    uint8_t  *pop[CLAPGPU_EXTRA_VIEWS_MAX];
+    uint64_t *o_mask[CLAPGPU_EXTRA_VIEWS_MAX];       // HOST kernels: the mirror's mapped words, or NULL
+    lmd::FrustumK fr[CLAPGPU_EXTRA_VIEWS_MAX];
+};
+
+// The further views of a row whose main view has just been tested: `base` = the lanes that are ALIVE and VISIBLE (the
+// draw predicate without its frustum term), bb = the boxes the main view was tested against.  Returns the union of the
+// views' masks (what a host mirror counts as drawn).
+__device__ __forceinline__ uint64_t cull_extra_views(const XViewsK &xv, const bool base, const uint32_t fl, const float (&bb)[6],
+                                                     const uint32_t word, const int lane)
+{
+    uint64_t any = 0;
+    for (uint32_t v = 0; v < xv.n; v++) {                        // uniform: a view's 63 dwords are scalar loads
+        bool vis = base;
+        if (vis && !(fl & CLAPGPU_E_SKIP_CULLING))
+            vis = lmd::aabb_in_frustum_fast(xv.fr[v], bb);
+        const uint64_t m = __ballot(vis);
+        if (lane == 0) {
+            xv.mask[v][word] = m;
+            xv.pop[v][word] = (uint8_t)__popcll(m);
+            if (xv.o_mask[v]) xv.o_mask[v][word] = m;
+        }
+        any |= m;
+    }
+    return any;
+}
+
 constexpr int ENT_BLOCK = 256;
 constexpr int LDS_F4_PER_WAVE = 512;                             // 8 KiB of wave-private LDS: the rows' store staging
 
@@ -162,13 +193,15 @@ __device__ __forceinline__ bool point_in_box(const float (&p)[3], const float (&
 //              whole subtrees); a parent that sits in the previous row is taken from the
 //              registers of the lane that just computed it (16 cross-lane reads) instead of
 //              being re-read from HBM.  carry_* hold the previous row's results.
-template <bool CULL, bool TILE, bool HOST = false>
+//   XV         the launch culls further views (clapgpu_entities.views) with the main one
+template <bool CULL, bool TILE, bool HOST = false, bool XV = false>
 __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, float4 *tile, const int lane,
                                             const uint32_t row_first, const uint32_t row_count,
                                             const uint32_t mode, const lmd::FrustumK &fr,
                                             const bool have_prev, const uint32_t prev_first,
                                             float (&carry_mx)[16], uint32_t &carry_seq, bool &carry_valid,
-                                            const HostIO *hio = nullptr, const RowPre *pre = nullptr)
+                                            const HostIO *hio = nullptr, const RowPre *pre = nullptr,
+                                            const XViewsK *xv = nullptr)
 {
     const bool in_range = (uint32_t)lane < row_count;
     const uint32_t i = row_first + (in_range ? lane : 0);
@@ -382,6 +415,11 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
             if constexpr (HOST) hio->o_vis[e0 >> 6] = m;
         }
         if constexpr (HOST) host_want |= m;                      // what the render passes draw
+        if constexpr (XV) {
+            const uint64_t mx_any = cull_extra_views(*xv, in_range && (fl & CLAPGPU_E_ALIVE) && (fl & CLAPGPU_E_VISIBLE), fl, bb,
+                                                     (uint32_t)(e0 >> 6), lane);
+            if constexpr (HOST) host_want |= mx_any;             // ... in any of the frame's passes
+        }
     } else {
         if constexpr (HOST) host_want = ~0ull;                   // no frustum: a pass without a camera draws everything (model.c:969)
     }
@@ -434,6 +472,6 @@ __device__ __forceinline__ void process_row(const EntK &e, const RowIn &in, floa
 
 // entities_host.hip
 int launch_entities_tiles_host(hipStream_t stream, bool cull, const lmd::FrustumK &fr, const EntK &e, const HostIO &h,
-                               const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n, uint32_t mode);
+                               const uint32_t *tile_row_start, uint32_t n_tiles, uint32_t n, uint32_t mode, const XViewsK &xv);
 
 } // namespace clapgpu

@@ -9,9 +9,9 @@
 #include "lm_dev.h"
 
 #ifdef CLAPGPU_EXPERIMENT               // an A/B or sensitivity build (common.h): never loadable as the product
-#define CLAPGPU_ABI_VERSION (31u | 0x80000000u)
+#define CLAPGPU_ABI_VERSION (32u | 0x80000000u)
 #else
-#define CLAPGPU_ABI_VERSION 31u
+#define CLAPGPU_ABI_VERSION 32u
 #endif
 
 namespace clapgpu {

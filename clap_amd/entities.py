@@ -106,6 +106,29 @@ class EntityBatch:
         self._desc.vis_row_pop = vis_row_pop.data_ptr()
 
     # ---- optional inputs ---------------------------------------------------------------
+    def set_views(self, frusta):
+        """The frame's other frusta (one light view for the shadow passes, pipeline-builder.c:246-272): culled by the same
+        launch as the main one, each into its own mask plane (view_masks[v], view_row_pops[v]).  frusta: up to
+        _lib.EXTRA_VIEWS_MAX _lib.Frustum; an empty list takes them off again."""
+        dev = self.device
+        n_rows = (self.n + 63) // 64
+        self._views = _lib.Views()
+        self._views.n = len(frusta)
+        self.view_masks, self.view_row_pops = [], []
+        for v, fr in enumerate(frusta[:_lib.EXTRA_VIEWS_MAX]):
+            C.memmove(C.byref(self._views.frustum[v]), C.byref(fr), C.sizeof(_lib.Frustum))
+            m = torch.zeros((n_rows or 1,), dtype=torch.int64, device=dev)
+            p = torch.zeros(((n_rows + 15) // 16 * 16 or 16,), dtype=torch.uint8, device=dev)
+            self.view_masks.append(m); self.view_row_pops.append(p)
+            self._views.vis_mask[v] = m.data_ptr(); self._views.vis_row_pop[v] = p.data_ptr()
+        self._desc.views = C.pointer(self._views) if frusta else None
+
+    def compact_view(self, v, index_base=0):
+        """The ascending visible list of extra view v (visible[:visible_count]), as compact_visible for the main one."""
+        rc = _lib.lib().clapgpu_visible_compact(_stream(), _ptr(self.view_masks[v]), _ptr(self.view_row_pops[v]), self.n,
+                                                index_base, _ptr(self.visible), _ptr(self.visible_count), _ptr(self.scratch))
+        _lib.check(rc, "clapgpu_visible_compact")
+
     def set_attachments(self, attach, jt_pool, bind_pool):
         """Joint attachments (model.c:1626-1641).  attach: structured array (entity, jt, bind, pad)
         sorted by entity; jt_pool: device tensor of mat4 (e.g. CharacterBatch.joint_transforms);

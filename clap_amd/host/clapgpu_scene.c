@@ -127,6 +127,13 @@ struct clapgpu_scene {
     /* a small scene's draw list lands in device-mapped host memory: the two launches write it (and its length) where the host
      * reads it, one wait -- no length copy, wait, list copies, wait (two round trips of ~35 us around two ~8 us launches) */
     int         lod_mapped; void *a_draw_slot, *a_draw_lod, *a_visible_count;
+
+    /* the frame's other views (clapgpu_scene_set_views): frusta + device planes in xv (what clapgpu_entities.views points at),
+     * the host copies of the masks (device-mapped when the scene is zero-copy: the one-launch frame writes them itself) and
+     * the union of every view's mask for the export policy's fetches */
+    clapgpu_views xv; uint32_t xv_want, xv_cap_slots; int xv_mapped;
+    uint64_t   *h_xv_mask[CLAPGPU_EXTRA_VIEWS_MAX]; void *a_xv_mask[CLAPGPU_EXTRA_VIEWS_MAX];
+    uint64_t   *h_xv_union;
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -254,6 +261,73 @@ static int fetch_rows(clapgpu_scene *s, const uint64_t *w0, const uint64_t *w1, 
     return CLAPGPU_OK;
 }
 
+static void free_views(clapgpu_scene *s)
+{
+    for (int v = 0; v < CLAPGPU_EXTRA_VIEWS_MAX; v++) {
+        if (s->xv.vis_mask[v]) clapgpu_free(s->xv.vis_mask[v]);
+        if (s->xv.vis_row_pop[v]) clapgpu_free(s->xv.vis_row_pop[v]);
+        if (s->h_xv_mask[v]) clapgpu_host_free(s->h_xv_mask[v]);
+        s->xv.vis_mask[v] = NULL; s->xv.vis_row_pop[v] = NULL; s->xv.host_vis_mask[v] = NULL;
+        s->h_xv_mask[v] = NULL; s->a_xv_mask[v] = NULL;
+    }
+    free(s->h_xv_union); s->h_xv_union = NULL;
+    s->xv_cap_slots = 0;
+}
+
+/* the planes of the extra views, for the current capacity */
+static int ensure_views(clapgpu_scene *s)
+{
+    if (!s->xv_want) { s->xv.n = 0; return CLAPGPU_OK; }
+    if (s->xv_cap_slots != s->cap_slots || s->xv_mapped != s->zero_copy) {
+        free_views(s);
+        const size_t mw = (size_t)s->cap_slots / 64 + 2;
+        s->xv_mapped = s->zero_copy;
+        for (uint32_t v = 0; v < CLAPGPU_EXTRA_VIEWS_MAX; v++) {
+            CK(clapgpu_malloc((void **)&s->xv.vis_mask[v], mw * 8));
+            CK(clapgpu_malloc((void **)&s->xv.vis_row_pop[v], ((size_t)s->cap_slots / 64 + 16) / 16 * 16));
+            CK(clapgpu_memset(s->xv.vis_mask[v], 0, mw * 8, NULL));
+            if (s->xv_mapped) CK(clapgpu_host_malloc_mapped((void **)&s->h_xv_mask[v], &s->a_xv_mask[v], mw * 8));
+            else CK(clapgpu_host_malloc((void **)&s->h_xv_mask[v], mw * 8));
+            memset(s->h_xv_mask[v], 0, mw * 8);
+        }
+        s->h_xv_union = calloc(mw, 8);
+        if (!s->h_xv_union) return CLAPGPU_ERR_NOMEM;
+        s->xv_cap_slots = s->cap_slots;
+    }
+    s->xv.n = s->xv_want;
+    return CLAPGPU_OK;
+}
+
+/* what ANY view of the last launch draws: the main mask alone without extra views */
+static const uint64_t *views_union(clapgpu_scene *s)
+{
+    if (!s->xv.n || !s->h_xv_union) return s->h_mask;
+    const size_t words = s->n_slots / 64;
+    for (size_t w = 0; w < words; w++) {
+        uint64_t m = s->h_mask[w];
+        for (uint32_t v = 0; v < s->xv.n; v++) m |= s->h_xv_mask[v][w];
+        s->h_xv_union[w] = m;
+    }
+    return s->h_xv_union;
+}
+
+/* the extra views' masks of a launch that did not write them to the host itself */
+static int download_views(clapgpu_scene *s)
+{
+    for (uint32_t v = 0; v < s->xv.n; v++)
+        CK(clapgpu_memcpy_d2h(s->h_xv_mask[v], s->xv.vis_mask[v], ((size_t)s->n_slots / 64) * 8, NULL));
+    return CLAPGPU_OK;
+}
+
+int clapgpu_scene_set_views(clapgpu_scene *s, uint32_t n_extra, const clapgpu_frustum *extra)
+{
+    if (!s || n_extra > CLAPGPU_EXTRA_VIEWS_MAX || (n_extra && !extra)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    s->xv_want = n_extra;
+    for (uint32_t v = 0; v < n_extra; v++) s->xv.frustum[v] = extra[v];
+    if (!n_extra) s->xv.n = 0;
+    return CLAPGPU_OK;
+}
+
 int clapgpu_scene_create(clapgpu_scene **out, int device)
 {
     if (!out) return CLAPGPU_ERR_INVALID_ARGUMENTS;
@@ -307,6 +381,7 @@ static void free_device(clapgpu_scene *s)
 
 void clapgpu_scene_destroy(clapgpu_scene *s)
 {
+    if (s) free_views(s);
     if (!s) return;
     free_device(s);
     if (s->d_models) clapgpu_free(s->d_models);
@@ -1222,6 +1297,8 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     }
     s->have_frustum = frustum != NULL;
     if (frustum) s->last_frustum = *frustum;
+    if (frustum) CK(ensure_views(s)); else s->xv.n = 0;  /* the frame's other views ride the main one's launch */
+    s->d.views = s->xv.n ? &s->xv : NULL;
     s->d.n_attach = 0;                                   /* joint attachments ride the palettes of THIS frame: clapgpu_scene_attached_update */
     const double tt0 = scene_now_us();
     const size_t mask_words = n / 64, mask_stride = cap / 64 + 2;
@@ -1234,6 +1311,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         }
         scene_hostio(s, &io, by_bits, s->export_drawn);
         io.options |= CLAPGPU_HOSTIO_EXPORT_STALE_READ;    /* what an earlier frame left stale and this one reads comes over in the same launch */
+        for (uint32_t v = 0; v < s->xv.n; v++) s->xv.host_vis_mask[v] = s->a_xv_mask[v];   /* the launch writes the views' masks home itself */
         CK(clapgpu_entities_update_tiles_hostio(NULL, &s->d, s->d_tile_row_start, s->n_tiles, 0, frustum, &io));
         const double tt2 = scene_now_us();
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
@@ -1260,6 +1338,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         CK(clapgpu_entities_export_rebuilt(NULL, &s->d, &x));
         const double tt2 = scene_now_us();
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (s->xv.n) { CK(download_views(s)); CK(clapgpu_stream_sync(NULL)); }
         if (getenv("CLAPGPU_SCENE_TIMING"))
             fprintf(stderr, "scene small frame: %u inputs by %s, launches %.1f us, wait %.1f us\n", n_touched,
                     by_list ? "list" : upload ? "copy" : "none", tt2 - tt0, scene_now_us() - tt2);
@@ -1277,13 +1356,13 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
     } else {                                             /* masks only: visibility of this view, nothing rebuilt */
         CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
     }
-    if (!s->zero_copy) CK(clapgpu_stream_sync(NULL));
+    if (!s->zero_copy) { CK(download_views(s)); CK(clapgpu_stream_sync(NULL)); }
     for (uint32_t k = 0; k < n_bits; k++) s->h_touched[s->dirty_list[k] >> 6] = 0;   /* taken by this frame's launch or by its copy */
     for (uint32_t k = 0; k < s->n_raw; k++) s->h_touched[s->raw_words[k]] = 0;
     s->n_raw = 0;
     if (bulk_any && s->zero_copy) memset(s->h_touched, 0, (cap / 64 + 2) * 8);   /* what clapgpu_scene_entity_transform_mt flagged */
     if (!frustum)
-        memset(s->h_mask, 0, mask_words * 8);
+        memset(s->h_mask, 0, mask_words * 8);                /* (and no extra view has a mask: xv.n is 0 for this frame) */
     if (!s->bv_on) memset(s->h_inside, 0, mask_words * 8);
     /* EXPORT_DRAWN: whoever is read this frame and was left stale by an earlier one -- an entity that came into view, a
      * box that now contains the camera, a reader registered since -- comes over now */
@@ -1291,7 +1370,7 @@ int clapgpu_scene_mq_update(clapgpu_scene *s, const clapgpu_frustum *frustum)
         /* (the launch has brought over what it found stale and read -- stale_after_launch; this catches what it could not
          * know: nothing, unless a caller's masks changed behind it) */
         s->fetch_accumulate = 1;
-        const int frc = frustum ? fetch_rows(s, s->h_mask, s->bv_on ? s->h_inside : NULL, s->h_keep)
+        const int frc = frustum ? fetch_rows(s, views_union(s), s->bv_on ? s->h_inside : NULL, s->h_keep)
                                 : fetch_rows(s, NULL, NULL, NULL);      /* a pass without a camera draws everything (model.c:969) */
         s->fetch_accumulate = 0;
         CK(frc);
@@ -1398,9 +1477,11 @@ int clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t *
         x.counter = s->d_counter; x.done = s->d_done; x.done_value = ++s->frame_id;
         CK(clapgpu_entities_export_rebuilt(NULL, &s->d, &x));
         CK(clapgpu_wait_word(s->h_done, s->frame_id, NULL));
+        if (fr && s->xv.n) { CK(download_views(s)); CK(clapgpu_stream_sync(NULL)); }
     } else {
         /* staged: the masks first, then only the span of rows this launch rebuilt */
         CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, (2 * mask_stride + mask_words) * 8, NULL));
+        if (fr) CK(download_views(s));
         CK(clapgpu_stream_sync(NULL));
         size_t lo = mask_words, hi = 0;
         for (size_t w = 0; w < mask_words; w++)
@@ -1476,6 +1557,8 @@ int clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out)
     out->exported_mask = (s->zero_copy && s->tiled) ? s->h_exported : s->h_rebuilt;
     out->stale_mask = s->h_stale; out->fetched_mask = s->h_fetched;
     out->n_stale_words = s->n_stale_words; out->n_fetched = s->n_fetched; out->fetch_serial = s->fetch_serial;
+    out->n_views = s->xv.n;
+    for (uint32_t v = 0; v < CLAPGPU_EXTRA_VIEWS_MAX; v++) out->view_mask[v] = v < s->xv.n ? s->h_xv_mask[v] : NULL;
     return CLAPGPU_OK;
 }
 
@@ -1533,10 +1616,32 @@ int clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum)
     if (!s || !frustum) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
     CK(apply_edits(s));
-    CK(clapgpu_entities_cull(NULL, &s->d, frustum));
+    CK(ensure_views(s));
+    s->d.views = s->xv.n ? &s->xv : NULL;
+    for (uint32_t v = 0; v < s->xv.n; v++) s->xv.host_vis_mask[v] = NULL;
+    CK(clapgpu_entities_cull(NULL, &s->d, frustum));   /* every view of the frame from one read of the boxes */
     CK(clapgpu_memcpy_d2h(s->h_mask, s->d.vis_mask, ((size_t)s->n_slots / 64) * 8, NULL));
+    CK(download_views(s));
     CK(clapgpu_stream_sync(NULL));
-    CK(fetch_rows(s, s->h_mask, NULL, NULL));         /* EXPORT_DRAWN: what this view draws and an earlier frame left stale */
+    s->have_frustum = 1; s->last_frustum = *frustum;
+    CK(fetch_rows(s, views_union(s), NULL, NULL));     /* EXPORT_DRAWN: what the views draw and an earlier frame left stale */
+    return CLAPGPU_OK;
+}
+
+/* one extra view alone: its planes moved since the launch that culled it (light_update runs after mq_update, scene.c:1166-1171) */
+int clapgpu_scene_cull_view(clapgpu_scene *s, uint32_t view, const clapgpu_frustum *frustum)
+{
+    if (!s || !frustum || view >= s->xv_want) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;
+    CK(apply_edits(s));
+    CK(ensure_views(s));
+    s->xv.frustum[view] = *frustum;
+    clapgpu_entities one = s->d;
+    one.vis_mask = s->xv.vis_mask[view]; one.vis_row_pop = s->xv.vis_row_pop[view]; one.views = NULL;
+    CK(clapgpu_entities_cull(NULL, &one, frustum));
+    CK(clapgpu_memcpy_d2h(s->h_xv_mask[view], s->xv.vis_mask[view], ((size_t)s->n_slots / 64) * 8, NULL));
+    CK(clapgpu_stream_sync(NULL));
+    CK(fetch_rows(s, s->h_xv_mask[view], NULL, NULL));
     return CLAPGPU_OK;
 }
 
@@ -1615,7 +1720,12 @@ static int ensure_lod(clapgpu_scene *s)
 
 int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t *n_draw)
 {
-    if (!s || !n_draw) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    return clapgpu_scene_select_lod_view(s, CLAPGPU_SCENE_MAIN_VIEW, cam_pos, n_draw);
+}
+
+int clapgpu_scene_select_lod_view(clapgpu_scene *s, uint32_t view, const float cam_pos[3], uint32_t *n_draw)
+{
+    if (!s || !n_draw || (view != CLAPGPU_SCENE_MAIN_VIEW && view >= s->xv.n)) return CLAPGPU_ERR_INVALID_ARGUMENTS;
     *n_draw = 0;
     if (!s->have_results || s->topology_dirty) return CLAPGPU_ERR_NOT_SUPPORTED;   /* nothing on the device yet */
     if (s->n_slots == 0) { s->n_draw = 0; return CLAPGPU_OK; }
@@ -1625,10 +1735,12 @@ int clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t 
      * pick over it (one launch each); without one the pass keeps every cur_lod (model.c:974: `if (camera)`) */
     uint32_t *out_slot = s->lod_mapped ? s->a_draw_slot : s->d_visible, *out_count = s->lod_mapped ? s->a_visible_count : s->d_visible_count;
     int32_t *out_lod = s->lod_mapped ? s->a_draw_lod : s->d_draw_lod;
+    clapgpu_entities of_view = s->d;                     /* the plane the list is made from */
+    if (view != CLAPGPU_SCENE_MAIN_VIEW) { of_view.vis_mask = s->xv.vis_mask[view]; of_view.vis_row_pop = s->xv.vis_row_pop[view]; }
     if (cam_pos)
-        CK(clapgpu_visible_compact_lod(NULL, &s->d, 0, cam_pos, s->d_force_lod, s->d_cur_lod, out_slot, out_count, out_lod, s->d_vis_scratch));
+        CK(clapgpu_visible_compact_lod(NULL, &of_view, 0, cam_pos, s->d_force_lod, s->d_cur_lod, out_slot, out_count, out_lod, s->d_vis_scratch));
     else
-        CK(clapgpu_visible_compact(NULL, s->d.vis_mask, s->d.vis_row_pop, s->n_slots, 0, out_slot, out_count, s->d_vis_scratch));
+        CK(clapgpu_visible_compact(NULL, of_view.vis_mask, of_view.vis_row_pop, s->n_slots, 0, out_slot, out_count, s->d_vis_scratch));
     if (!s->lod_mapped) CK(clapgpu_memcpy_d2h(s->h_visible_count, s->d_visible_count, 4, NULL));
     CK(clapgpu_stream_sync(NULL));
     const uint32_t n = *s->h_visible_count;

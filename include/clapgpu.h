@@ -159,6 +159,26 @@ typedef struct clapgpu_bv_query {
     uint64_t *inside_mask;
 } clapgpu_bv_query;
 
+/*
+ * Extra views culled by the SAME launch as the main frustum: the frame's other render passes.  pipeline_render() runs one
+ * shadow pass per cascade with view = &light->view[0] and no camera (pipeline-builder.c:34-46, 246-272; model.c:752-760)
+ * before the model pass with the camera's view, and every pass asks view_entity_in_frustum(view, e) for every entity
+ * (model.c:966-973; the test reads view->main only, view.c:296-337): two frusta a frame, more with more shadowed lights.
+ * The rows' boxes are in registers when the main view is tested: a further view costs ~150 flops and 1/64 word per entity.
+ * Every view v gets its own vis_mask / vis_row_pop plane (same shapes as clapgpu_entities'), written exactly as the main
+ * plane is: bit i = entity i passes _models_render's draw predicate for that view.  Only read when the call has a main
+ * frustum.  host_vis_mask: clapgpu_entities_update_tiles_hostio only -- device aliases of mapped host words the launch
+ * writes as well (NULL: not wanted); such a view's drawn entities count as read for the export policy (keep_mask).
+ */
+#define CLAPGPU_EXTRA_VIEWS_MAX 4                          /* CASCADES_MAX, shader_constants.h:9 */
+typedef struct clapgpu_views {
+    uint32_t        n, pad;                                /* extra views: 0 .. CLAPGPU_EXTRA_VIEWS_MAX */
+    clapgpu_frustum frustum[CLAPGPU_EXTRA_VIEWS_MAX];
+    uint64_t       *vis_mask[CLAPGPU_EXTRA_VIEWS_MAX];     /* device */
+    uint8_t        *vis_row_pop[CLAPGPU_EXTRA_VIEWS_MAX];  /* device, 16-byte aligned */
+    uint64_t       *host_vis_mask[CLAPGPU_EXTRA_VIEWS_MAX];
+} clapgpu_views;
+
 typedef struct clapgpu_entities {
     uint32_t        n;
     uint32_t        n_models;
@@ -185,6 +205,7 @@ typedef struct clapgpu_entities {
     const clapgpu_bv_query *bv;          /* HOST pointer */
     uint64_t       *rebuilt_mask;        /* device, n / 64 words, may be NULL: bit i = this update rebuilt entity i
                                             (mx / inverse_mx / aabb / seq changed): what a host mirror has to copy back */
+    const clapgpu_views *views;          /* HOST pointer or NULL: the frame's other frusta, culled by the same launch */
 } clapgpu_entities;
 
 /* mode bits for clapgpu_entities_update */
@@ -230,7 +251,7 @@ int clapgpu_entities_update_tiles(void *stream, const clapgpu_entities *e,
 
 /*
  * Cull only: view_entity_in_frustum() over all entities from the stored aabb[]
- * (one call per render pass in the reference, model.c:969-970).  Writes vis_mask.
+ * (one call per render pass in the reference, model.c:969-970).  Writes vis_mask, and the planes of e->views with it.
  */
 int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu_frustum *frustum);
 

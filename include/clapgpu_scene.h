@@ -105,6 +105,18 @@ int  clapgpu_scene_attached_update(clapgpu_scene *s, uint32_t n, const uint32_t 
 /* the cull alone, against another frustum (scene_cameras_calc recomputes the frusta after mq_update, clap.c:614-616):
  * refreshes the visibility results below; CLAPGPU_ERR_NOT_SUPPORTED before the first mq_update */
 int  clapgpu_scene_cull(clapgpu_scene *s, const clapgpu_frustum *frustum);
+/*
+ * The frame's OTHER views.  pipeline_render() runs the shadow passes -- one per cascade, view = &light->view[0], no camera
+ * (pipeline-builder.c:34-46, 246-272; model.c:752-760) -- before the model pass with the camera's view, and each pass asks
+ * view_entity_in_frustum(view, e) for every entity (model.c:966-973): two frusta a frame.  The n_extra frusta given here
+ * (up to CLAPGPU_EXTRA_VIEWS_MAX; 0 takes them off) are culled by the SAME launch as the main frustum of every following
+ * clapgpu_scene_mq_update(frustum != NULL) and clapgpu_scene_cull(): clapgpu_scene_arrays.view_mask[v] answers for view v
+ * without a launch of its own, clapgpu_scene_select_lod_view(v) lists what it draws, and under CLAPGPU_SCENE_EXPORT_DRAWN
+ * an entity drawn by ANY of the views counts as read.  clapgpu_scene_cull_view(v) re-tests one extra view alone (its planes
+ * moved after the update).
+ */
+int  clapgpu_scene_set_views(clapgpu_scene *s, uint32_t n_extra, const clapgpu_frustum *extra);
+int  clapgpu_scene_cull_view(clapgpu_scene *s, uint32_t view, const clapgpu_frustum *frustum);
 
 /* results of the last mq_update; pointers stay valid until the next mq_update */
 const float *clapgpu_scene_entity_mx(const clapgpu_scene *s, uint32_t handle);          /* e->mx */
@@ -138,6 +150,9 @@ typedef struct clapgpu_scene_arrays {
     const uint64_t *fetched_mask;   /* rows the last mq_update / cull / fetch brought over because somebody reads them now */
     uint32_t        n_stale_words, n_fetched;   /* non-zero words of stale_mask; rows in fetched_mask */
     uint32_t        fetch_serial;   /* advances with every call that fetched something: fetched_mask is to be copied out once per value */
+    /* the frame's other views (clapgpu_scene_set_views): view_mask[v] as vis_mask, for extra view v of the last mq_update / cull */
+    uint32_t        n_views;
+    const uint64_t *view_mask[CLAPGPU_EXTRA_VIEWS_MAX];
 } clapgpu_scene_arrays;
 int          clapgpu_scene_results(const clapgpu_scene *s, clapgpu_scene_arrays *out);
 uint32_t     clapgpu_scene_entity_slot(const clapgpu_scene *s, uint32_t handle);
@@ -193,6 +208,9 @@ int          clapgpu_scene_model_lods(clapgpu_scene *s, uint32_t model, unsigned
 int          clapgpu_scene_entity_lod(clapgpu_scene *s, uint32_t handle, int force_lod, int cur_lod);
 int          clapgpu_scene_entity_cur_lod(const clapgpu_scene *s, uint32_t handle);
 int          clapgpu_scene_select_lod(clapgpu_scene *s, const float cam_pos[3], uint32_t *n_draw);
+/* ... over the mask of extra view `view` (clapgpu_scene_set_views); CLAPGPU_SCENE_MAIN_VIEW = the call above */
+#define CLAPGPU_SCENE_MAIN_VIEW 0xffffffffu
+int          clapgpu_scene_select_lod_view(clapgpu_scene *s, uint32_t view, const float cam_pos[3], uint32_t *n_draw);
 /* A caller that walks the draw list anyway and knows every entity's last LOD can take over the bookkeeping the call above does
  * per entry (is this entity's cur_lod still what the mirror holds?): clapgpu_scene_set_lod_sync(s, 1), then
  * clapgpu_scene_lod_picked(s, slot, lod) for each entry of a list picked WITH a camera whose LOD changed (distinct slots may

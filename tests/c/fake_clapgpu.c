@@ -92,6 +92,22 @@ static inline int in_box(const float p[3], const float *b)
 }
 
 /* one update launch: the oracle's pass, then the masks the kernels leave behind */
+/* clapgpu_entities.views: every further view's plane from the same boxes (and the mirror's mapped words, for a hostio launch) */
+static int cull_views(const clapgpu_entities *e, int hostio)
+{
+    const clapgpu_views *v = e->views;
+    if (!v || !v->n) return CLAPGPU_OK;
+    if (v->n > CLAPGPU_EXTRA_VIEWS_MAX) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+    const uint32_t words = (e->n + 63) / 64;
+    for (uint32_t k = 0; k < v->n; k++) {
+        if (!v->vis_mask[k] || !v->vis_row_pop[k]) return CLAPGPU_ERR_INVALID_ARGUMENTS;
+        clapo_entities_cull(e->n, e->flags, e->aabb, (const clapo_frustum *)&v->frustum[k], NULL, v->vis_mask[k]);
+        for (uint32_t w = 0; w < words; w++) v->vis_row_pop[k][w] = (uint8_t)__builtin_popcountll(v->vis_mask[k][w]);
+        if (hostio && v->host_vis_mask[k]) memcpy(v->host_vis_mask[k], v->vis_mask[k], (size_t)(e->n / 64) * 8);
+    }
+    return CLAPGPU_OK;
+}
+
 static int run_update(const clapgpu_entities *e, uint32_t mode, const clapgpu_frustum *fr, uint64_t *rebuilt_out)
 {
     if (mode) return CLAPGPU_ERR_NOT_SUPPORTED;
@@ -129,9 +145,10 @@ static int run_update(const clapgpu_entities *e, uint32_t mode, const clapgpu_fr
     if (fr) {
         clapo_entities_cull(n, e->flags, e->aabb, (const clapo_frustum *)fr, NULL, e->vis_mask);
         for (uint32_t w = 0; w < words; w++) e->vis_row_pop[w] = (uint8_t)__builtin_popcountll(e->vis_mask[w]);
+        rc = cull_views(e, rebuilt_out != NULL);
     }
     free(before); free(mi); free(maabb); free(mskip); free(mlod);
-    return CLAPGPU_OK;
+    return rc;
 }
 
 static int check_entities(const clapgpu_entities *e, int need_mask)
@@ -173,7 +190,7 @@ int clapgpu_entities_cull(void *stream, const clapgpu_entities *e, const clapgpu
     if (!launch_ok("k_entities_cull (fake)")) return CLAPGPU_ERR_UNKNOWN;
     clapo_entities_cull(e->n, e->flags, e->aabb, (const clapo_frustum *)frustum, NULL, e->vis_mask);
     for (uint32_t w = 0; w < (e->n + 63) / 64; w++) e->vis_row_pop[w] = (uint8_t)__builtin_popcountll(e->vis_mask[w]);
-    return CLAPGPU_OK;
+    return cull_views(e, 0);
 }
 
 int clapgpu_entities_apply_inputs(void *stream, const clapgpu_entities *e, const clapgpu_entity_input *list, uint32_t n_list)
@@ -277,6 +294,7 @@ int clapgpu_entities_update_tiles_hostio(void *stream, const clapgpu_entities *e
         if (io->keep_mask) {
             want = io->keep_mask[w] | (inside ? inside[w] : 0);
             want = frustum ? (want | e->vis_mask[w]) : ~0ull;
+            for (uint32_t k = 0; frustum && e->views && k < e->views->n; k++) want |= e->views->vis_mask[k][w];   /* drawn by any view */
         }
         uint64_t ex = rb[w] & want, alive = 0;
         for (uint32_t l = 0; l < 64; l++) alive |= (uint64_t)((e->flags[w * 64 + l] & CLAPGPU_E_ALIVE) != 0) << l;

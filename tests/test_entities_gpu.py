@@ -402,3 +402,78 @@ def test_out_of_range_indices_from_the_host_are_harmless(cuda_device):
     ob.entities_update(fixed, st)
     assert_bits_equal(out["mx"], st["mx"], "mx")
     assert_bits_equal(out["aabb"], st["aabb"], "aabb")
+
+
+# ---- the frame's other views culled by the same launch (clapgpu_entities.views) ------------------------------------------
+# pipeline_render() runs the shadow passes with the light's view and no camera, then the model pass with the camera's
+# (pipeline-builder.c:34-46, 246-272; model.c:752-760, 966-973): every view's mask and list must be what the oracle's cull
+# gives for that frustum alone.
+EXTRA_CAMS = [dict(pos=(40, 120, 30), quat=synth.quat_from_euler_xyz(-1.2, 0.3, 0.0), fov_deg=40.0, aspect=1.0, near=1.0, far=400.0),
+              dict(pos=(-200, 10, -50), quat=synth.quat_from_euler_xyz(0.1, 1.9, 0.0)),
+              dict(pos=(0, 0, 0), quat=synth.quat_from_euler_xyz(0.0, 3.1, 0.0), ndc_z_zero_one=1),
+              dict(pos=(5, 400, 5), quat=synth.quat_from_euler_xyz(-1.57, 0.0, 0.0), far=90.0)]
+
+
+@pytest.mark.parametrize("n_extra", [1, 4], ids=["two_frusta", "five_frusta"])
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_further_views_in_the_same_launch(layout, n_extra, cuda_device):
+    from clap_amd import entities
+    scene = lay_out(synth.entities_forest(12_000, 5, max_depth=7, n_models=4, hidden_frac=0.1), layout)
+    skip = np.flatnonzero(scene["flags"] & synth.E_ALIVE)[::17]
+    scene["flags"][skip] |= synth.E_SKIP_CULLING                  # drawn by every view, whatever its planes
+    cam = synth.camera(pos=(3, 4, 60))
+    cams = [synth.camera(**kw) for kw in EXTRA_CAMS[:n_extra]]
+    fr, _v, _p = entities.view_calc_frustum(cam)
+    frs = [entities.view_calc_frustum(c)[0] for c in cams]
+    fr_o = ob.frustum_from_camera(cam)[0]
+    frs_o = [ob.frustum_from_camera(c)[0] for c in cams]
+    st = ob.entity_state(scene)
+    batch = entities.EntityBatch(scene, cuda_device)
+    batch.set_views(frs)
+    rng = np.random.Generator(np.random.PCG64(11))
+    for frame in range(3):
+        if frame:                                               # a partial frame: most rows keep their stored boxes
+            idx = rng.choice(np.flatnonzero(scene["flags"] & synth.E_ALIVE), 300, replace=False)
+            scene["pos_scale"][idx, :3] += rng.uniform(-30, 30, (idx.size, 3)).astype(np.float32)
+            st["flags"][idx] |= synth.E_DIRTY
+            batch.set_transforms(idx, scene["pos_scale"][idx], scene["rot"][idx])
+        vis, mask = oracle_frame(scene, st, fr_o)
+        batch.mq_update(fr)
+        batch.compact_visible()
+        check_against(batch.download(), st, vis, mask, f"frame {frame} main view")
+        for v, fo in enumerate(frs_o):
+            vis_v, mask_v = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fo)
+            got = batch.view_masks[v].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got[:mask_v.size], mask_v), f"frame {frame} view {v} mask"
+            batch.compact_view(v)
+            out = batch.download()
+            assert np.array_equal(out["visible"], vis_v), f"frame {frame} view {v} list"
+            assert vis_v.size != vis.size or not np.array_equal(vis_v, vis), "a view that sees what the main one sees tests nothing"
+    # the stand-alone cull pass: every plane from one read of the boxes
+    for m in batch.view_masks: m.zero_()
+    batch.vis_mask.zero_()
+    batch.cull(fr)
+    for v, fo in enumerate(frs_o):
+        _vis_v, mask_v = ob.entities_cull(scene["n"], st["flags"], st["aabb"], fo)
+        assert np.array_equal(batch.view_masks[v].cpu().numpy().view(np.uint64)[:mask_v.size], mask_v), f"cull pass, view {v}"
+    assert np.array_equal(batch.download()["vis_mask"][:mask.size], mask)
+    # off again: the planes are left alone
+    batch.set_views([])
+    batch.mq_update(fr)
+    batch.compact_visible()
+    assert np.array_equal(batch.download()["visible"], vis)
+
+
+def test_views_argument_validation(cuda_device):
+    from clap_amd import entities, _lib
+    scene = synth.pad_levels(synth.entities_flat(200, 3))
+    batch = entities.EntityBatch(scene, cuda_device)
+    fr = entities.view_calc_frustum(synth.camera())[0]
+    batch.set_views([fr])
+    batch._views.n = _lib.EXTRA_VIEWS_MAX + 1
+    with pytest.raises(_lib.ClapGpuError):
+        batch.mq_update(fr)
+    batch._views.n = 1
+    batch._views.vis_mask[0] = None
+    with pytest.raises(_lib.ClapGpuError):
+        batch.mq_update(fr)
