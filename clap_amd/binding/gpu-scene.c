@@ -143,6 +143,13 @@ struct gpu_scene {
     void            *hook_data;                                    /* mq->priv of the running gpu_mq_update(): what the hooks get as `data` */
     struct view     *culled_view;
     vec4            culled_planes[6];
+    /* the frame's other views (gpu_scene_add_view): xview[k] registered; xslot[k] = its plane among the mirror's extra views
+     * in the last update (-1: it was the main view, or no view was culled), the planes that were culled, and whether a
+     * verdict has compared them since */
+    struct view     *xview[GPU_SCENE_EXTRA_VIEWS]; uint32_t n_xview;
+    int             xslot[GPU_SCENE_EXTRA_VIEWS];
+    vec4            xplanes[GPU_SCENE_EXTRA_VIEWS][6];
+    bool            xchecked[GPU_SCENE_EXTRA_VIEWS], xok[GPU_SCENE_EXTRA_VIEWS];
     entity3d        **draw; int32_t *draw_lod; uint32_t n_draw, cap_draw;   /* gpu_scene_select_lod's draw list */
     uint16_t        *draw_txm;                                     /* ... and each entry's txmodel, as an index into txms[] */
     /* by device slot, laid out by every walk: the entity, its txmodel's index and the cur_lod its entity3d holds -- a pass's
@@ -342,6 +349,59 @@ void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int
 static void bv_pick(struct scene *scene, entity3d *e);
 static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq);
 static void consume_fetched(struct gpu_scene *gs);
+
+static int frustum_of(const struct view *view, clapgpu_frustum *fr);
+
+/* the registered views ride the update's launch: their frusta to the mirror (those that are not the main view itself) */
+static int views_before_update(struct gpu_scene *gs, struct view *view)
+{
+    clapgpu_frustum xfr[GPU_SCENE_EXTRA_VIEWS];
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < gs->n_xview; k++) {
+        gs->xslot[k] = -1;
+        gs->xchecked[k] = gs->xok[k] = false;
+        if (!view || gs->xview[k] == view) continue;
+        frustum_of(gs->xview[k], &xfr[n]);
+        memcpy(gs->xplanes[k], gs->xview[k]->main.frustum_planes, sizeof(gs->xplanes[k]));
+        gs->xslot[k] = (int)n++;
+    }
+    gs->stats.views_culled = (view != NULL) + n;
+    return clapgpu_scene_set_views(gs->scene, n, n ? xfr : NULL);
+}
+
+/* which registered view is `view` (and has a mask from the last update)?  -1: none */
+static int xview_of(const struct gpu_scene *gs, const struct view *view)
+{
+    for (uint32_t k = 0; k < gs->n_xview; k++)
+        if (gs->xview[k] == view) return gs->xslot[k] >= 0 ? (int)k : -1;
+    return -1;
+}
+
+int gpu_scene_add_view(struct gpu_scene *gs, struct view *view)
+{
+    if (!gs || !view) return _CERR_INVALID_ARGUMENTS;
+    for (uint32_t k = 0; k < gs->n_xview; k++) if (gs->xview[k] == view) return 0;
+    if (gs->n_xview == GPU_SCENE_EXTRA_VIEWS) return _CERR_TOO_LARGE;
+    gs->xview[gs->n_xview] = view;
+    gs->xslot[gs->n_xview++] = -1;                               /* culled from the next update on */
+    return 0;
+}
+
+void gpu_scene_remove_view(struct gpu_scene *gs, struct view *view)
+{
+    if (!gs) return;
+    for (uint32_t k = 0; k < gs->n_xview; k++) {
+        if (gs->xview[k] != view) continue;
+        /* the mirror's planes keep their order until the next update: the others' slots stand */
+        for (uint32_t j = k; j + 1 < gs->n_xview; j++) {
+            gs->xview[j] = gs->xview[j + 1]; gs->xslot[j] = gs->xslot[j + 1];
+            memcpy(gs->xplanes[j], gs->xplanes[j + 1], sizeof(gs->xplanes[j]));
+            gs->xchecked[j] = gs->xchecked[j + 1]; gs->xok[j] = gs->xok[j + 1];
+        }
+        gs->n_xview--;
+        return;
+    }
+}
 
 /* The frame's second entity launch: the subtrees riding a batched character's joint (class 4), now that the palettes of
  * the frame are in the entities (e->parent->joint_transforms[e->parent_joint], model.c:1633-1640). */
@@ -1821,6 +1881,7 @@ static int fast_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
     const double t1 = now_ms();
     clapgpu_frustum fr;
     if (view) frustum_of(view, &fr);
+    CK(views_before_update(gs, view));
     CK(clapgpu_scene_mq_update(gs->scene, view ? &fr : NULL));
     gs->culled_view = view;
     gs->vis_cursor = 0;
@@ -2359,6 +2420,7 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
     const uint32_t layout_before = clapgpu_scene_layout_generation(gs->scene);
     clapgpu_frustum fr;
     if (view) frustum_of(view, &fr);
+    CK(views_before_update(gs, view));
     CK(clapgpu_scene_mq_update(gs->scene, view ? &fr : NULL));
     st->retiled = layout_before != clapgpu_scene_layout_generation(gs->scene);
     gs->culled_view = view;
@@ -2495,19 +2557,26 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
 /* view_calc_frustum() ran for `view` (view.c:291): the next verdict for it re-culls on the device if the planes changed */
 void gpu_scene_view_changed(struct gpu_scene *gs, struct view *view)
 {
-    if (gs && view == gs->culled_view) gs->cull_checked = false;
+    if (!gs) return;
+    if (view == gs->culled_view) gs->cull_checked = false;
+    for (uint32_t k = 0; k < gs->n_xview; k++)
+        if (gs->xview[k] == view) gs->xchecked[k] = false;
 }
 
-bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e)
+/* The mask that answers for `view`, current for the planes the view holds NOW: the main view's (the one the last update
+ * was given) or a registered view's own plane -- compared once per frustum, not per entity; planes that moved since the
+ * launch that culled them cost one cull launch (every view of the frame for the main one, the one view alone otherwise).
+ * NULL: the device has no answer for this view (not known to the last update, or the re-cull failed). */
+static const uint64_t *mask_for_view(struct gpu_scene *gs, struct view *view)
 {
-    if (gs && view == gs->culled_view) {
+    if (view == gs->culled_view) {
         if (!gs->cull_checked) {
-            /* once per frustum, not per entity: same planes as the fused cull of the last update, or one cull launch */
             gs->cull_checked = true;
             gs->cull_ok = !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
             if (!gs->cull_ok) {
                 clapgpu_frustum fr;
                 frustum_of(view, &fr);
+                gs->stats.cull_launches_after_update++;
                 if (!clapgpu_scene_cull(gs->scene, &fr)) {
                     memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
                     gs->cull_ok = true;
@@ -2515,14 +2584,38 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
                 }
             }
         }
-        if (gs->cull_ok && gs->notify && gs->vis_cursor < gs->n_order && gs->vq_e[gs->vis_cursor] == e) {
+        return gs->cull_ok ? gs->res.vis_mask : NULL;
+    }
+    const int k = xview_of(gs, view);
+    if (k < 0) return NULL;
+    if (!gs->xchecked[k]) {
+        gs->xchecked[k] = true;
+        gs->xok[k] = !memcmp(gs->xplanes[k], view->main.frustum_planes, sizeof(gs->xplanes[k]));
+        if (!gs->xok[k]) {
+            clapgpu_frustum fr;
+            frustum_of(view, &fr);
+            gs->stats.cull_launches_after_update++;
+            if (!clapgpu_scene_cull_view(gs->scene, (uint32_t)gs->xslot[k], &fr)) {
+                memcpy(gs->xplanes[k], view->main.frustum_planes, sizeof(gs->xplanes[k]));
+                gs->xok[k] = true;
+                consume_fetched(gs);
+            }
+        }
+    }
+    return (gs->xok[k] && (uint32_t)gs->xslot[k] < gs->res.n_views) ? gs->res.view_mask[gs->xslot[k]] : NULL;
+}
+
+bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e)
+{
+    const uint64_t *mask = gs ? mask_for_view(gs, view) : NULL;
+    if (mask) {
+        if (gs->notify && gs->vis_cursor < gs->n_order && gs->vq_e[gs->vis_cursor] == e) {
             /* notification mode, asked in list order (model.c:958-973): the table answers */
             const uint32_t c = gs->vis_cursor;
             gs->vis_cursor = c + 1 < gs->n_order ? c + 1 : 0;
             if (gs->vq_ok[c])
-                return (gs->res.vis_mask[gs->vq_slot[c] >> 6] >> (gs->vq_slot[c] & 63)) & 1;
-        } else
-        if (gs->cull_ok) {
+                return (mask[gs->vq_slot[c] >> 6] >> (gs->vq_slot[c] & 63)) & 1;
+        } else {
             /* _models_render asks in list order (model.c:958-973): try the next record of the walk first */
             uint32_t i;
             if (gs->vis_cursor < gs->n_order && gs->rec[gs->order[gs->vis_cursor]].e == e)
@@ -2538,7 +2631,7 @@ bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3
                 const uint32_t fl = (gs->notify && !r->pending) ? r->flags : (e->flags & (ENTITY3D_ALIVE | 0xffffu));
                 if (fl == r->flags &&
                     (fl & (ENTITY3D_ALIVE | ENTITY3D_VISIBLE | ENTITY3D_SKIP_CULLING)) == (ENTITY3D_ALIVE | ENTITY3D_VISIBLE))
-                    return (gs->res.vis_mask[r->slot >> 6] >> (r->slot & 63)) & 1;
+                    return (mask[r->slot >> 6] >> (r->slot & 63)) & 1;
             }
         }
     }
@@ -2659,19 +2752,25 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
     /* entities came or went since the frame's update (notification mode knows): the list would miss what the reference's
      * walk of the txmodels draws -- this pass is the reference's */
     if (gs->notify && (gs->topology_pending || gs->n_created)) return _CERR_NOT_SUPPORTED;
-    /* the frustum the device's mask answers for: the one of the last update, or a cull launch for this view's planes */
+    /* the mask that lists what the pass draws: the main view's or a registered view's own, re-culled if its planes moved; a
+     * view the last update did not know takes the main view's place (one cull launch, and the main mask is its from now on) */
+    uint32_t of_view = CLAPGPU_SCENE_MAIN_VIEW;
     if (view) {
-        if (view != gs->culled_view || !gs->cull_checked || !gs->cull_ok) {
-            const bool same = view == gs->culled_view && !memcmp(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
-            if (!same) {
-                clapgpu_frustum fr;
-                frustum_of(view, &fr);
-                CK(clapgpu_scene_cull(gs->scene, &fr));
-                consume_fetched(gs);                             /* GPU_SCATTER_DRAWN: what the new planes bring into view */
-                memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
-                gs->culled_view = view;
-            }
+        const int xk = view != gs->culled_view ? xview_of(gs, view) : -1;
+        if (xk >= 0) {
+            if (!mask_for_view(gs, view)) return _CERR_NOT_SUPPORTED;
+            of_view = (uint32_t)gs->xslot[xk];
+        } else if (view != gs->culled_view) {
+            clapgpu_frustum fr;
+            frustum_of(view, &fr);
+            gs->stats.cull_launches_after_update++;
+            CK(clapgpu_scene_cull(gs->scene, &fr));
+            consume_fetched(gs);                                 /* GPU_SCATTER_DRAWN: what the new planes bring into view */
+            memcpy(gs->culled_planes, view->main.frustum_planes, sizeof(gs->culled_planes));
+            gs->culled_view = view;
             gs->cull_checked = gs->cull_ok = true;
+        } else if (!mask_for_view(gs, view)) {
+            return _CERR_NOT_SUPPORTED;
         }
     }
     /* models whose LOD range moved since they were registered (model3d's mesh LODs are added at load time) */
@@ -2694,7 +2793,7 @@ int gpu_scene_select_lod(struct gpu_scene *gs, struct view *view, const float *c
         device_ok = false;
     } else
     if (gs->n_batched) {
-        const int rc = clapgpu_scene_select_lod(gs->scene, cam_pos, &n);
+        const int rc = clapgpu_scene_select_lod_view(gs->scene, of_view, cam_pos, &n);
         if (rc && rc != CLAPGPU_ERR_NOT_SUPPORTED) return rc;
         device_ok = !rc;
     }

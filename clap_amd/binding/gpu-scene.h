@@ -44,6 +44,9 @@ struct gpu_scene_stats {
     unsigned int left_stale;    /* GPU_SCATTER_DRAWN: entities the device rebuilt this frame whose entity3d was not written */
     unsigned int device_errors; /* CUMULATIVE, process-wide: calls of the binding that failed on the device and were served by
                                    the engine's host path instead (gpu_scene_device_errors()) */
+    unsigned int views_culled;  /* views the update's own launch culled: the one it was given + the registered ones (gpu_scene_add_view) */
+    unsigned int cull_launches_after_update;   /* cull launches since (a view whose planes moved, a view that is not registered):
+                                   0 in a frame whose passes use the views the update knew */
 };
 
 /*
@@ -65,6 +68,21 @@ int  gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view);
 /* view_entity_in_frustum(): bit lookup for batched entities tested against the view of the last
  * gpu_mq_update(); the engine's own function for anything else. */
 bool gpu_view_entity_in_frustum(struct gpu_scene *gs, struct view *view, entity3d *e);
+
+/*
+ * The frame's OTHER views.  pipeline_render() runs one shadow pass per cascade with view = &light->view[0] and no camera
+ * (pipeline-builder.c:34-46, 246-272; model.c:752-760) before the model pass with the camera's view, and every pass asks
+ * view_entity_in_frustum(view, e) for every entity (model.c:966-973; the test reads view->main alone, view.c:296-337).
+ * A view registered here (up to GPU_SCENE_EXTRA_VIEWS; the light's: gpu_scene_add_view(gs, &light->view[0])) is culled by
+ * the SAME launch as the view gpu_mq_update() is given, into a mask of its own: gpu_view_entity_in_frustum() and
+ * gpu_scene_select_lod() then answer for either view without a launch and without touching the other view's mask;
+ * under GPU_SCATTER_DRAWN an entity drawn by ANY of the views is written back.  A registered view whose planes moved
+ * since the update (light_update runs behind mq_update, scene.c:1166-1171) costs one cull launch of that view alone.
+ * _CERR_TOO_LARGE beyond the maximum; registering the same view twice is harmless.
+ */
+#define GPU_SCENE_EXTRA_VIEWS 4
+int  gpu_scene_add_view(struct gpu_scene *gs, struct view *view);
+void gpu_scene_remove_view(struct gpu_scene *gs, struct view *view);
 
 /* view_calc_frustum() ran for `view` (the engine recomputes its frusta in scene_cameras_calc, after mq_update,
  * clap.c:614-616): the first verdict asked for it afterwards compares the planes once and, if they differ from the ones

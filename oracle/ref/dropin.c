@@ -141,6 +141,7 @@ struct world {
     model3d         model[N_MODELS];
     model3dtx       txm[N_MODELS];
     struct view     view;
+    struct view     lview;          /* the light's view: what the shadow passes render with (pipeline-builder.c:34-46, model.c:752-760) */
     entity3d        **e;            /* by id; NULL once deleted */
 };
 
@@ -196,6 +197,22 @@ static void view_set(struct world *w, const float *pos, const float *quat)
     subview_calc_frustum(&w->view.main, NULL);                   /* what view_calc_frustum does per subview (view.c:291-294) */
     gpu_scene_view_changed(gpu_scene_bound(), &w->view);
 }
+
+/* the light's view of the frame (light_update -> view_update_perspective_projection + view_calc_frustum, light.c:398-420):
+ * a frustum other than the camera's over the same scene */
+static void light_view_set(struct world *w, const float *pos, const float *quat)
+{
+    transform_t cam;
+    transform_init(&cam);
+    transform_set_pos(&cam, pos);
+    transform_set_quat(&cam, quat);
+    transform_view_mat4x4(&cam, w->lview.main.view_mx);
+    mat4x4_invert(w->lview.main.inv_view_mx, w->lview.main.view_mx);
+    mat4x4_perspective_ndc_z_2(w->lview.main.proj_mx, 55.f * (float)M_PI / 180.f, 1.f, 1.f, 420.f);
+    subview_calc_frustum(&w->lview.main, NULL);
+    gpu_scene_view_changed(gpu_scene_bound(), &w->lview);
+}
+static uint32_t opt_shadow;                   /* `shadow <n>`: n shadow passes (the light's view, no camera) before the model pass, as pipeline_render runs them */
 
 /* ---- the scripted game: every operation is applied to both worlds with the same numbers ---- */
 struct meta { uint8_t model; uint8_t alive; uint8_t hooked; uint32_t parent; uint32_t n_children; };
@@ -424,7 +441,12 @@ static uint64_t compare_frame_ex(struct gpu_scene *gs, uint32_t frame, uint64_t 
  * camera flies a scripted path that keeps ending up inside some entity's box; every third frame renders a second pass
  * from another camera, every fifth one without a camera (model.c:974). */
 static bool lod_no_view;                   /* this pass has neither camera nor light: `view` is NULL (model.c:969: every ALIVE, VISIBLE entity is drawn) */
+static uint32_t lod_pass_ref_view(struct world *w, struct view *view, const float *cam_pos, uint8_t *drawn);
 static uint32_t lod_pass_ref(struct world *w, const float *cam_pos, uint8_t *drawn)
+{
+    return lod_pass_ref_view(w, lod_no_view ? NULL : &w->view, cam_pos, drawn);
+}
+static uint32_t lod_pass_ref_view(struct world *w, struct view *view, const float *cam_pos, uint8_t *drawn)
 {
     uint32_t n = 0;
     model3dtx *txm;
@@ -432,7 +454,7 @@ static uint32_t lod_pass_ref(struct world *w, const float *cam_pos, uint8_t *dra
     list_for_each_entry(txm, &w->mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
         if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
         if (!entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
-        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && !lod_no_view && !ref_view_entity_in_frustum(&w->view, e)) continue;
+        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && view && !ref_view_entity_in_frustum(view, e)) continue;
         if (cam_pos) {
             if (e->force_lod >= 0) {
                 e->cur_lod = e->force_lod;
@@ -472,9 +494,11 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
     gpu_scene_set_notify(gs, opt_notify);
     gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
+    if (opt_shadow && gpu_scene_add_view(gs, &B.lview)) { fprintf(stderr, "gpu_scene_add_view failed\n"); return 2; }
 
     uint8_t *drawn_a = calloc(cap_ids, 1), *drawn_b = calloc(cap_ids, 1);
     uint64_t bad = 0, passes = 0, drawn_total = 0, forced = 0, inside = 0, lod_hist[8] = { 0 }, batched = 0, host = 0, no_view_passes = 0;
+    uint64_t shadow_passes = 0, shadow_drawn = 0, shadow_verdicts = 0, culls_after = 0, light_moved_after = 0, views_culled = 0;
     for (uint32_t f = 0; f < frames; f++) {
         no_topology = opt_steady && f % 4 != 1;
         if (f) game_frame(f % 5 == 4 ? 0 : n / 16 + 1);
@@ -495,11 +519,60 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
         view_set(&A, cpos, cq);
         view_set(&B, cpos, cq);
         A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        vec3 lpos = { -90.f + 7.f * (f % 9), 130.f, 40.f - 5.f * (f % 7) };
+        quat lq; quat_from_euler_xyz(lq, -1.0f, -0.6f + 0.05f * (f % 11), 0);
+        if (opt_shadow) { light_view_set(&A, lpos, lq); light_view_set(&B, lpos, lq); }
         ref_mq_update(A.mq);
         mq_update(B.mq);
         const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
         if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
         batched += st->batched; host += st->host;
+        views_culled += st->views_culled;
+        if (opt_shadow) {
+            /* pipeline_render's order: the shadow passes (the light's view, no camera: no LOD pick) before the model pass.
+             * Every third frame the light has moved since the update (light_update runs behind mq_update, scene.c:1166-1171). */
+            const bool moved = f % 3 == 1;
+            if (moved) { lpos[0] += 11.f; light_view_set(&A, lpos, lq); light_view_set(&B, lpos, lq); light_moved_after++; }
+            for (uint32_t sp = 0; sp < opt_shadow; sp++) {
+                memset(drawn_a, 0, cap_ids); memset(drawn_b, 0, cap_ids);
+                const uint32_t na = lod_pass_ref_view(&A, &A.lview, NULL, drawn_a);
+                uint32_t nb = 0;
+                if (sp & 1) {                                            /* ... by the draw list */
+                    rc = gpu_scene_select_lod(gs, &B.lview, NULL);
+                    if (rc) { fprintf(stderr, "gpu_scene_select_lod(light view): %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+                    entity3d **list; const int32_t *llod;
+                    nb = gpu_scene_visible(gs, &list, &llod);
+                    for (uint32_t k = 0; k < nb; k++) {
+                        for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == list[k]) {
+                            drawn_b[id]++;
+                            const entity3d *a = A.e[id], *b = list[k];
+                            if ((memcmp(a->mx, b->mx, 64) || memcmp(a->inverse_mx, b->inverse_mx, 64) || a->seq != b->seq) && bad++ < 8)
+                                fprintf(stderr, "frame %u shadow pass %u entity %u: drawn with fields that are not the reference's\n", f, sp, id);
+                            break;
+                        }
+                        if (llod[k] != list[k]->cur_lod && bad++ < 8) fprintf(stderr, "frame %u shadow pass %u: list LOD %d but e->cur_lod %d\n", f, sp, llod[k], list[k]->cur_lod);
+                    }
+                } else {                                                 /* ... by one verdict per entity, asked in list order like _models_render (model.c:958-973) */
+                    model3dtx *txm; entity3d *e, *it;
+                    list_for_each_entry(txm, &B.mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
+                        if (!entity3d_matches(e, ENTITY3D_ALIVE) || !entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
+                        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) && !view_entity_in_frustum(&B.lview, e)) continue;
+                        for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == e) { drawn_b[id] = 1; break; }
+                        nb++;
+                    }
+                    shadow_verdicts++;
+                }
+                if (na != nb && bad++ < 8) fprintf(stderr, "frame %u shadow pass %u: %u entities drawn by the reference, %u by the binding\n", f, sp, na, nb);
+                for (uint32_t id = 0; id < n_ids; id++)
+                    if (meta[id].alive && (drawn_a[id] != drawn_b[id] || A.e[id]->cur_lod != B.e[id]->cur_lod) && bad++ < 8)
+                        fprintf(stderr, "frame %u shadow pass %u entity %u: drawn %d / %d cur_lod %d / %d\n", f, sp, id, drawn_a[id], drawn_b[id],
+                                A.e[id]->cur_lod, B.e[id]->cur_lod);
+                shadow_passes++; shadow_drawn += na;
+            }
+            /* the light's planes were the update's own unless it moved: then ONE launch for all its passes */
+            const unsigned int cl = gpu_scene_last_stats(gs)->cull_launches_after_update;
+            if (cl != (moved ? 1u : 0u) && bad++ < 8) fprintf(stderr, "frame %u: %u cull launches after the update (light moved: %d)\n", f, cl, (int)moved);
+        }
         const int n_pass = 1 + (f % 3 == 2) + (f % 4 == 1);
         for (int pass = 0; pass < n_pass; pass++) {
             lod_no_view = pass && pass == n_pass - 1 && f % 4 == 1;       /* the frame's last pass has no view at all */
@@ -556,15 +629,26 @@ static int cmd_lod(uint32_t n, uint32_t frames, uint64_t seed)
                 if (drawn_a[id]) { lod_hist[a->cur_lod & 7]++; inside += cam && aabb_point_is_inside(a->aabb, cam); }
             }
             drawn_total += na; passes++;
+            if (opt_shadow && pass == 0) {
+                /* the model pass came with the camera's planes of the update: the shadow passes did not take its mask away */
+                const unsigned int cl = gpu_scene_last_stats(gs)->cull_launches_after_update;
+                const unsigned int exp = (f % 3 == 1) ? 1u : 0u;
+                if (cl != exp && bad++ < 8) fprintf(stderr, "frame %u: %u cull launches by the end of the model pass (expected %u)\n", f, cl, exp);
+                culls_after += cl;
+            }
         }
     }
     unsigned int distinct = 0;
     for (int k = 0; k < 8; k++) distinct += lod_hist[k] > 0;
     printf("{\"mode\": \"lod\", \"frames\": %u, \"passes\": %llu, \"entities_created\": %u, \"drawn\": %llu, \"lod_levels_seen\": %u, "
            "\"forced_or_released\": %llu, \"drawn_with_camera_inside_box\": %llu, \"batched_updates\": %llu, \"host_updates\": %llu, "
-           "\"passes_without_a_view\": %llu, \"notify\": %s, \"scatter\": \"%s\", \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
+           "\"passes_without_a_view\": %llu, \"shadow_passes\": %llu, \"shadow_passes_by_verdicts\": %llu, \"drawn_by_shadow_passes\": %llu, "
+           "\"views_culled_by_the_updates\": %llu, \"frames_the_light_moved_after_the_update\": %llu, \"cull_launches_after_update\": %llu, "
+           "\"notify\": %s, \"scatter\": \"%s\", \"mismatches\": %llu}\n", frames, (unsigned long long)passes, n_ids, (unsigned long long)drawn_total, distinct,
            (unsigned long long)forced, (unsigned long long)inside, (unsigned long long)batched, (unsigned long long)host,
-           (unsigned long long)no_view_passes, opt_notify ? "true" : "false", opt_drawn ? "drawn" : "all", (unsigned long long)bad);
+           (unsigned long long)no_view_passes, (unsigned long long)shadow_passes, (unsigned long long)shadow_verdicts, (unsigned long long)shadow_drawn,
+           (unsigned long long)views_culled, (unsigned long long)light_moved_after, (unsigned long long)culls_after,
+           opt_notify ? "true" : "false", opt_drawn ? "drawn" : "all", (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -981,6 +1065,24 @@ static uint32_t render_block_ref(struct world *w, const float *cam_pos, uint64_t
     return n;
 }
 
+/* a shadow pass's per-entity block: the light's view, no camera (shadow_prepare sets params->camera = NULL,
+ * pipeline-builder.c:34-46) -- verdict and the draw's reads, every LOD kept */
+static uint32_t shadow_block_ref(struct world *w, uint64_t *acc, bool world_b)
+{
+    uint32_t n = 0;
+    model3dtx *txm;
+    entity3d *e, *it;
+    list_for_each_entry(txm, &w->mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
+        if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_VISIBLE)) continue;
+        if (!entity3d_matches(e, ENTITY3D_SKIP_CULLING) &&
+            !(world_b ? view_entity_in_frustum(&w->lview, e) : ref_view_entity_in_frustum(&w->lview, e))) continue;
+        *acc += draw_read(e, e->cur_lod);
+        n++;
+    }
+    return n;
+}
+
 static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
 {
     struct gpu_scene *gs;
@@ -1006,6 +1108,9 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
     gpu_scene_set_notify(gs, opt_notify);
     gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
     gpu_scene_bind(gs, B.mq, &B.view);
+    if (opt_shadow && gpu_scene_add_view(gs, &B.lview)) { fprintf(stderr, "gpu_scene_add_view failed\n"); return 2; }
+    double t_ref_sh = 0, t_gpu_sh = 0, t_gpu_sh_list = 0;
+    uint64_t sh_a = 0, sh_b = 0, sh_l = 0, sh_acc_a = 0, sh_acc_b = 0, sh_acc_l = 0, culls_after = 0, views_culled = 0;
 
     double t_ref = 0, t_gpu = 0, t_ref_upd = 0, t_gpu_upd = 0, t_step[4] = { 0, 0, 0, 0 };
     double t_ref_mut = 0, t_gpu_mut = 0, t_ref_blk = 0, t_gpu_blk = 0, t_gpu_list = 0, t_gpu_select = 0;
@@ -1046,6 +1151,12 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
         quat_from_euler_xyz(cq, 0, 0.01f * f, 0);
         view_set(&A, cpos, cq);
         view_set(&B, cpos, cq);
+        if (opt_shadow) {                                                /* the light follows the camera from above (light_update, light.c:398-420) */
+            vec3 lpos = { cpos[0] - 60.f, cpos[1] + 140.f, cpos[2] + 30.f };
+            quat lq; quat_from_euler_xyz(lq, -1.05f, -0.5f, 0);
+            light_view_set(&A, lpos, lq);
+            light_view_set(&B, lpos, lq);
+        }
 
         double t0 = now_s();
         ref_mq_update(A.mq);
@@ -1060,6 +1171,35 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
           list_for_each_entry(txm, &B.mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry)
               vis_b += view_entity_in_frustum(&B.view, e); }
         double t2 = now_s();
+        if (opt_shadow) {
+            /* pipeline_render: the shadow passes first, one per cascade, all with the light's view (pipeline-builder.c:246-272) */
+            uint64_t sa = 0, sb = 0, sl = 0;
+            uint32_t na = 0, nb = 0, nl = 0;
+            double s0 = now_s();
+            for (uint32_t sp = 0; sp < opt_shadow; sp++) na += shadow_block_ref(&A, &sa, false);
+            double s1 = now_s();
+            for (uint32_t sp = 0; sp < opt_shadow; sp++) nb += shadow_block_ref(&B, &sb, true);
+            double s2 = now_s();
+            for (uint32_t sp = 0; sp < opt_shadow; sp++) {
+                rc = gpu_scene_select_lod(gs, &B.lview, NULL);
+                if (rc) { fprintf(stderr, "gpu_scene_select_lod(light view): %d (%s)\n", rc, clapgpu_last_error()); return 2; }
+                model3dtx *txm;
+                list_for_each_entry(txm, &B.mq->txmodels, entry) {
+                    entity3d **seg; const int32_t *slod;
+                    const uint32_t ns = gpu_scene_visible_of(gs, txm, &seg, &slod);
+                    for (uint32_t k = 0; k < ns; k++) sl += draw_read(seg[k], slod[k]);
+                    nl += ns;
+                }
+            }
+            double s3 = now_s();
+            if ((na != nb || na != nl || sa != sb || sa != sl) && bad++ < 8)
+                fprintf(stderr, "frame %u: shadow passes draw %u / %u / %u entities, reads %016llx / %016llx / %016llx\n", f, na, nb, nl,
+                        (unsigned long long)sa, (unsigned long long)sb, (unsigned long long)sl);
+            if (f >= 2) {
+                t_ref_sh += s1 - s0; t_gpu_sh += s2 - s1; t_gpu_sh_list += s3 - s2;
+                sh_a += na; sh_b += nb; sh_l += nl; sh_acc_a += sa; sh_acc_b += sb; sh_acc_l += sl;
+            }
+        }
         /* consumer 2: the whole per-entity block of a render pass (verdict + LOD + the draw's reads).  World A: the
          * reference's loop.  World B twice: the same loop under the engine's names (verdicts from the device's mask),
          * then gpu_scene_select_lod() + the draw list txmodel by txmodel -- no per-entity loop over what is not drawn */
@@ -1096,6 +1236,7 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
             left_stale += st->left_stale; fetched += st->fetched;
             n_fast += gpu_scene_last_was_fast(gs); n_retiled += st->retiled; n_placed += st->placed; n_removed += st->removed;
             n_replayed += st->replayed;
+            culls_after += st->cull_launches_after_update; views_culled += st->views_culled;
             t_step[0] += st->ms_walk; t_step[1] += st->ms_mirror; t_step[2] += st->ms_device; t_step[3] += st->ms_scatter;
         }
     }
@@ -1116,7 +1257,11 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            "\"scatter\": \"%s\", \"left_stale_per_frame\": %.1f, \"fetched_on_view_per_frame\": %.1f, \"churn_per_frame\": %u, "
            "\"fast_frames\": %llu, \"frames_by_the_records\": %llu, \"retiles\": %llu, \"placed_in_layout\": %llu, \"removed_in_place\": %llu, "
            "\"notify\": %s, \"visible_equal\": %s, \"mismatches\": %llu, "
-           "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
+           "\"shadow_passes_per_frame\": %u, \"views_culled_per_update\": %.2f, \"cull_launches_after_update\": %llu, "
+           "\"reference_shadow_passes_ms\": %.4f, \"binding_shadow_passes_ms\": %.4f, \"binding_shadow_draw_lists_ms\": %.4f, "
+           "\"reference_pipeline_frame_ms\": %.4f, \"binding_pipeline_frame_block_ms\": %.4f, \"binding_pipeline_frame_draw_list_ms\": %.4f, "
+           "\"shadow_drawn_per_frame\": %.1f, \"shadow_sets_equal\": %s, "
+           "\"note\": \"host entity3d structs in, host entity3d structs out; *_ms_per_frame = mq_update + one frustum verdict per entity asked in list order like _models_render (the caller's own walk of the entity lists is inside both), *_mq_update_ms = the update call alone; *_mutate_ms = the frame's entity3d_move calls (world B's carry the notification); *_render_block_ms = _models_render's per-entity block (model.c:958-992: verdict, LOD pick, the draw's reads of mx / inverse_mx) over every entity, binding_draw_list_ms = gpu_scene_select_lod + the same reads over gpu_scene_visible_of() per txmodel; *_frame_* = mutate + mq_update + that consumer; *_shadow_* (with `shadow <n>`): n passes of the same block with the light's view and no camera before the model pass, as pipeline_render runs them (pipeline-builder.c:246-272); *_pipeline_frame_* = mutate + mq_update + the shadow passes + the model pass; after the last frame everything is fetched and mx / aabb / seq / parent_seq / cur_lod of every entity compared\"}\n",
            n, frames, dirty_permille, 1e3 * t_ref / F, 1e3 * t_gpu / F, 1e3 * t_ref_upd / F, 1e3 * t_gpu_upd / F,
            t_step[0] / F, t_step[1] / F, t_step[2] / F, t_step[3] / F,
            1e3 * t_ref_mut / F, 1e3 * t_gpu_mut / F, 1e3 * t_ref_blk / F, 1e3 * t_gpu_blk / F, 1e3 * t_gpu_list / F, 1e3 * t_gpu_select / F,
@@ -1124,7 +1269,12 @@ static int cmd_bench(uint32_t n, uint32_t frames, uint32_t dirty_permille)
            drawn_a / F, (drawn_a == drawn_b && drawn_a == drawn_l) ? "true" : "false", (acc_a == acc_b && acc_a == acc_l) ? "true" : "false",
            opt_drawn ? "drawn" : "all", left_stale / F, fetched / F, opt_churn,
            (unsigned long long)n_fast, (unsigned long long)n_replayed, (unsigned long long)n_retiled, (unsigned long long)n_placed, (unsigned long long)n_removed,
-           opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad);
+           opt_notify ? "true" : "false", vis_a == vis_b ? "true" : "false", (unsigned long long)bad,
+           opt_shadow, views_culled / F, (unsigned long long)culls_after,
+           1e3 * t_ref_sh / F, 1e3 * t_gpu_sh / F, 1e3 * t_gpu_sh_list / F,
+           1e3 * (t_ref_mut + t_ref_upd + t_ref_sh + t_ref_blk) / F, 1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_sh + t_gpu_blk) / F,
+           1e3 * (t_gpu_mut + t_gpu_upd + t_gpu_sh_list + t_gpu_list) / F,
+           sh_a / F, (sh_a == sh_b && sh_a == sh_l && sh_acc_a == sh_acc_b && sh_acc_a == sh_acc_l) ? "true" : "false");
     gpu_scene_done(gs);
     return bad || vis_a != vis_b;
 }
@@ -1760,6 +1910,7 @@ static int run(int argc, char **argv)
         else if (argc > 2 && !strcmp(argv[argc - 1], "comeandgo")) { opt_steady = opt_comeandgo = true; argc--; }
         else if (argc > 2 && !strcmp(argv[argc - 1], "plain")) { opt_plain = parents_first = true; argc--; }
         else if (argc > 3 && !strcmp(argv[argc - 2], "churn")) { opt_churn = (uint32_t)atoi(argv[argc - 1]); argc -= 2; }
+        else if (argc > 3 && !strcmp(argv[argc - 2], "shadow")) { opt_shadow = (uint32_t)atoi(argv[argc - 1]); argc -= 2; }
         else break;
     }
     if (argc >= 6 && !strcmp(argv[1], "fail")) {                        /* fail <launches> <entities> <frames> <seed>: `test` with the device failing after <launches> launches */

@@ -43,6 +43,12 @@ static void rand_trs(struct host_ent *e, int child)
 
 static int fail(const char *what, uint32_t i) { fprintf(stderr, "FAIL: %s (entity %u)\n", what, i); return 1; }
 
+/* the frame's second view (the light's, which the shadow passes render with: pipeline-builder.c:34-46, model.c:752-760):
+ * registered once with clapgpu_scene_set_views, culled by every mq_update's own launch */
+static clapgpu_frustum light_fr;
+static int light_on;
+static uint32_t light_checks, light_drawn;
+
 /* the oracle's view of the last checked frame (parents-first order), kept for check_lod() */
 static uint32_t order[MAXE], o_n, o_vis[MAXE], o_nvis;
 static float ps[MAXE * 4], aabb[MAXE * 6], ctr[MAXE * 3];
@@ -123,6 +129,35 @@ static int check_frame(clapgpu_scene *s, const clapgpu_frustum *fr, float *o_mx_
     }
     o_n = n; o_nvis = vis_exp;
     if (clapgpu_scene_visible(s, NULL, 0) != vis_exp) return fail("visible count", vis_exp);
+    if (light_on) {
+        /* the light's view: its mask from the same launch, then the shadow pass's list (no camera: no LOD pick, model.c:974) */
+        if (res.n_views != 1 || !res.view_mask[0]) return fail("extra view missing from the results", res.n_views);
+        static uint8_t exp_l[MAXE];
+        uint32_t n_l = 0;
+        for (uint32_t k = 0; k < n; k++) {
+            const struct host_ent *e = &ents[order[k]];
+            const uint32_t slot = clapgpu_scene_entity_slot(s, e->handle);
+            exp_l[k] = (e->flags & CLAPO_E_VISIBLE) &&
+                       ((e->flags & CLAPO_E_SKIP_CULLING) || clapo_aabb_in_frustum((const clapo_frustum *)&light_fr, aabb + 6 * k));
+            if ((int)((res.view_mask[0][slot >> 6] >> (slot & 63)) & 1) != exp_l[k]) return fail("light view mask", order[k]);
+            n_l += exp_l[k];
+        }
+        uint32_t n_draw = 0;
+        if (clapgpu_scene_select_lod_view(s, 0, NULL, &n_draw)) { fprintf(stderr, "select_lod_view: %s\n", clapgpu_last_error()); return 1; }
+        if (n_draw != n_l) return fail("shadow pass list length", n_draw);
+        const uint32_t *slots; const int32_t *lods;
+        if (clapgpu_scene_draw_list(s, &slots, &lods) != n_draw) return fail("shadow pass list", 0);
+        for (uint32_t k = 0; k < n_draw; k++) {
+            if (k && slots[k] <= slots[k - 1]) return fail("shadow pass list not ascending", k);
+            const struct host_ent *e = res.slot_user[slots[k]];
+            if (!e || !e->live) return fail("shadow pass entry without an entity", k);
+            uint32_t ko = 0;
+            while (order[ko] != (uint32_t)(e - ents)) ko++;
+            if (!exp_l[ko]) return fail("shadow pass draws what the light does not see", (uint32_t)(e - ents));
+            if (lods[k] != clapgpu_scene_entity_cur_lod(s, e->handle)) return fail("shadow pass changed a LOD", (uint32_t)(e - ents));
+        }
+        light_checks++; light_drawn += n_l;
+    }
     printf("  frame ok: %u live entities, %u visible, layout %s, %u slots\n", n, vis_exp,
            clapgpu_scene_layout_is_tiled(s) ? "tiles" : "levels", clapgpu_scene_slot_count(s));
     return 0;
@@ -214,6 +249,19 @@ int main(int argc, char **argv)
     clapgpu_view_matrix(cpos, cq, view);
     clapgpu_perspective(70.f * 3.14159265f / 180.f, 16.f / 9.f, 0.1f, 500.f, 0, proj);
     clapgpu_frustum_calc(view, proj, 0, &fr);
+
+    {   /* the light: above the scene, looking down and along +x, a narrower and shorter frustum than the camera's */
+        float lview[16], lproj[16];
+        const float lpos[3] = { -60, 90, 20 }, ang[3] = { -0.9f, -0.7f, 0.f };
+        float lq[4];
+        clapgpu_quat_from_angles(ang, 0, lq);
+        clapgpu_view_matrix(lpos, lq, lview);
+        clapgpu_perspective(50.f * 3.14159265f / 180.f, 1.f, 1.f, 260.f, 0, lproj);
+        clapgpu_frustum_calc(lview, lproj, 0, &light_fr);
+        if (clapgpu_scene_set_views(s, 1, &light_fr)) return 2;
+        if (clapgpu_scene_set_views(s, CLAPGPU_EXTRA_VIEWS_MAX + 1, &light_fr) != CLAPGPU_ERR_INVALID_ARGUMENTS) return fail("too many views", 0);
+        light_on = 1;
+    }
 
     /* creation order: children first for a third of the scene (parents are attached afterwards) */
     for (int i = 0; i < 1500; i++) if (add_entity(s, UINT32_MAX)) return 2;
@@ -417,6 +465,32 @@ int main(int argc, char **argv)
         }
         if (n_att_on < 20) return fail("too few riders in the scenario", n_att_on);
         printf("  %u joint riders through the second launch (%s)\n", n_att_on, clapgpu_scene_is_zero_copy(s) ? "small-frame path" : "staged path");
+    }
+    {   /* the light moved after the update (light_update runs behind mq_update, scene.c:1166-1171): its view alone again */
+        clapgpu_frustum moved;
+        float lview[16], lproj[16];
+        const float lpos[3] = { 40, 70, -30 }, lq[4] = { 0, 0, 0, 1 };
+        clapgpu_view_matrix(lpos, lq, lview);
+        clapgpu_perspective(60.f * 3.14159265f / 180.f, 1.f, 1.f, 300.f, 0, lproj);
+        clapgpu_frustum_calc(lview, lproj, 0, &moved);
+        if (clapgpu_scene_cull_view(s, 0, &moved)) { fprintf(stderr, "cull_view: %s\n", clapgpu_last_error()); return 2; }
+        if (clapgpu_scene_cull_view(s, 1, &moved) != CLAPGPU_ERR_INVALID_ARGUMENTS) return fail("cull_view of a view that is not registered", 1);
+        clapgpu_scene_arrays res;
+        if (clapgpu_scene_results(s, &res)) return fail("results after cull_view", 0);
+        uint32_t differs = 0;
+        for (uint32_t k = 0; k < o_n; k++) {
+            const struct host_ent *e = &ents[order[k]];
+            const uint32_t slot = clapgpu_scene_entity_slot(s, e->handle);
+            const int exp = (e->flags & CLAPO_E_VISIBLE) &&
+                            ((e->flags & CLAPO_E_SKIP_CULLING) || clapo_aabb_in_frustum((const clapo_frustum *)&moved, aabb + 6 * k));
+            if ((int)((res.view_mask[0][slot >> 6] >> (slot & 63)) & 1) != exp) return fail("light view mask after cull_view", order[k]);
+            differs += exp != (int)((res.vis_mask[slot >> 6] >> (slot & 63)) & 1);
+        }
+        if (!differs) return fail("the light sees exactly what the camera sees: the test shows nothing", 0);
+        if (!light_checks || !light_drawn) return fail("no light view checked", light_checks);
+        printf("  light view ok: %u frames, %u entities drawn by the shadow passes in all\n", light_checks, light_drawn);
+        if (clapgpu_scene_set_views(s, 0, NULL)) return 2;       /* off again */
+        if (clapgpu_scene_mq_update(s, &fr) || clapgpu_scene_results(s, &res) || res.n_views != 0) return fail("views not taken off", 0);
     }
     if (clapgpu_scene_entity_position(s, 0xdeadbeef, cpos) != CLAPGPU_ERR_INVALID_ARGUMENTS) return fail("bad handle", 0);
     clapgpu_scene_destroy(s);

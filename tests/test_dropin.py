@@ -359,3 +359,30 @@ def test_lod_pick_and_draw_list_match_the_reference_block(n, frames, seed, mode)
     assert r["forced_or_released"] > 0 and r["drawn_with_camera_inside_box"] > 0
     assert r["batched_updates"] > 0 and r["host_updates"] > 0 and r["notify"] is ("notify" in mode)
     assert r["scatter"] == ("drawn" if "drawn" in mode else "all")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [(), ("notify",), ("notify", "drawn", "steady")], ids=["walk", "notify", "notify-drawn-steady"])
+@pytest.mark.parametrize("n,frames,seed,passes", [(300, 14, 1, 2), (4000, 12, 2, 4), (30000, 9, 3, 1)])
+def test_shadow_passes_with_the_lights_view_before_the_model_pass(n, frames, seed, passes, mode):
+    """A frame as pipeline_render renders it: `passes` shadow passes with the LIGHT's view and no camera
+    (pipeline-builder.c:34-46, 246-272; model.c:752-760) before the model pass with the camera's.  The light's view is
+    registered (gpu_scene_add_view): the update's own launch culls it into a mask of its own, so the shadow passes --
+    by one verdict per entity under the engine's name, and by gpu_scene_select_lod's list -- and the model pass behind
+    them are all answered without a cull launch; a frame whose light moved after the update costs exactly one.  Draw sets,
+    LODs (untouched by a pass without a camera) and the drawn entities' fields against the reference's loop, both
+    write-back policies."""
+    r = _run("lod", n, frames, seed, *mode, "shadow", passes)
+    assert r["mismatches"] == 0
+    assert r["shadow_passes"] == frames * passes and r["drawn_by_shadow_passes"] > 0
+    assert r["views_culled_by_the_updates"] == 2 * frames                    # the camera's and the light's, every update
+    assert r["cull_launches_after_update"] == r["frames_the_light_moved_after_the_update"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("notify",), ("notify", "drawn")], ids=["notify", "notify-drawn"])
+def test_pipeline_shaped_frame_in_bench_mode(mode):
+    r = _run("bench", 30000, 6, 100, *mode, "shadow", 2)
+    assert r["mismatches"] == 0 and r["shadow_sets_equal"] is True and r["draw_reads_equal"] is True
+    assert r["views_culled_per_update"] == 2.0 and r["cull_launches_after_update"] == 0
+    assert r["shadow_drawn_per_frame"] > 0 and r["binding_pipeline_frame_draw_list_ms"] > 0

@@ -81,6 +81,12 @@ def test_binding_and_mirror_under_asan_ubsan():
     assert _run(exe, "test", 1500, 10, 3, "notify")["mismatches"] == 0
     assert _run(exe, "lod", 1500, 8, 1, "notify", "drawn", "steady")["mismatches"] == 0
     assert _run(exe, "lod", 800, 8, 2)["mismatches"] == 0
+    # a frame as pipeline_render renders it: shadow passes with the light's (registered) view, then the model pass
+    for args in (("lod", 1500, 9, 1, "notify", "drawn", "steady", "shadow", 2), ("lod", 800, 8, 2, "shadow", 3)):
+        r = _run(exe, *args)
+        assert r["mismatches"] == 0 and r["shadow_passes"] > 0 and r["cull_launches_after_update"] == r["frames_the_light_moved_after_the_update"], r
+    r = _run(exe, "bench", 6000, 4, 300, "notify", "drawn", "shadow", 2)
+    assert r["mismatches"] == 0 and r["shadow_sets_equal"] is True and r["cull_launches_after_update"] == 0
     assert _run(exe, "edge")["mismatches"] == 0
     r = _run(exe, "bench", 6000, 4, 300, "notify", "drawn")
     assert r["mismatches"] == 0 and r["draw_reads_equal"] is True
