@@ -305,6 +305,23 @@ def dropin_boundary():
             out[key]["policy"] = "GPU_SCATTER_DRAWN"
         except Exception as e:
             out[key] = {"error": repr(e)[:200]}
+    # a frame as pipeline_render renders it: two shadow passes with the LIGHT's view (registered: gpu_scene_add_view; culled by the
+    # update's own launch) and no camera, then the model pass with the camera's (pipeline-builder.c:34-46, 246-272; model.c:752-760)
+    for n, frames in ((10_000, 50), (1_000_000, 5)):
+        key = f"{n}_entities_10pct_dirty_pipeline_frame_2_shadow_passes"
+        try:
+            p = subprocess.run([exe, "bench", str(n), str(frames), "100", "notify", "drawn", "shadow", "2"], capture_output=True, text=True,
+                               timeout=300)
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out[key] = {k: r[k] for k in ("reference_pipeline_frame_ms", "binding_pipeline_frame_block_ms", "binding_pipeline_frame_draw_list_ms",
+                                          "reference_shadow_passes_ms", "binding_shadow_passes_ms", "binding_shadow_draw_lists_ms",
+                                          "reference_mq_update_ms", "binding_mq_update_ms", "views_culled_per_update",
+                                          "cull_launches_after_update", "shadow_drawn_per_frame", "drawn_per_frame")}
+            out[key]["identical"] = (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"] and
+                                     r["shadow_sets_equal"])
+            out[key]["policy"] = "GPU_SCATTER_DRAWN"
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     # NO notifications (the minimal patch): the queue is verified against the last walk's records on the workers and the frame
     # goes by the records; round 4 walked every entity3d twice on one core (1 M: 111 ms)
     try:
@@ -575,11 +592,15 @@ def extras(device, testbed=True):
                              "+64 B / body written, outside SURVEY's 232 B): 18.5 -> 22.9 us here, 50 -> 39 us in the contact kernel",
                      "contacts": {"us": t_con * 1e6, "kernel": "k_contacts_geoms_both", "candidate_pairs": npairs,
                                   "static_candidate_pairs": int(pw.static_pair_total.item()),
+                                  # per candidate pair: its 8 bytes, two 64-byte geoms read, one 160-byte record written
+                                  "roofline": roof((npairs + int(pw.static_pair_total.item())) * (8 + 2 * 64 + 160), t_con, "k_contacts_geoms_both"),
                                   "note": "both candidate lists of a substep in one launch, 160-byte records; a body geom is read as "
                                           "one 64-byte record"},
                      "broadphase": {"bodies_per_s": pw.n / t_bp, "pairs": npairs, "ms": t_bp * 1e3,
                                     "algorithmic_bytes": 24 * pw.n + 8 * npairs,
                                     "launches": 5,
+                                    "moved_frac": (lambda t: None if t is None else t / t_bp / 1e9 / HBM_PEAK_GBS)(
+                                        pmc_kernel_traffic("k_bp_bin", "k_bp_cells", "k_bp_scatter", "k_bp_search", "k_bp_emit")),
                                     "note": "both passes (bodies x bodies, statics x bodies) in the same five launches: "
                                             "k_bp_bin, k_bp_cells, k_bp_scatter, k_bp_search, k_bp_emit; bound "
                                             "by the fabric's atomic rate (bin), launch floors and the search's chain of "
@@ -773,6 +794,70 @@ def summary(out, extra):
     w = ((out.get("cpu_baseline") or {}).get("dropin_boundary") or {}).get("1000000_entities_10pct_dirty_no_notifications") or {}
     put("boundary_1m_no_notify_mq_update_ms", lambda: w["binding_mq_update_ms"])
     return s
+
+
+def secondary(out, extra):
+    """The secondary rows where the driver's record keeps them whole: inside `roofline` (its `parsed` drops `summary` and
+    `extra`).  Per kernel group {us, frac, moved_frac} -- microseconds per launch group, algorithmic bytes / time / 8 TB/s,
+    PMC bytes of the committed profile / this run's time / 8 TB/s -- the frame, and the boundary at a million entities."""
+    e = extra or {}
+    sec = {}
+
+    def grp(key, us, roofline):
+        try:
+            u = us()
+            r = roofline() or {}
+            sec[key] = {"us": round(float(u), 2), "frac": None if r.get("frac") is None else round(float(r["frac"]), 4),
+                        "moved_frac": None if r.get("moved_frac") is None else round(float(r["moved_frac"]), 4)}
+        except (KeyError, TypeError, IndexError, ZeroDivisionError):
+            pass
+    grp("pose", lambda: e["pose_palette"]["characters"] * e["pose_palette"]["joints"] / e["pose_palette"]["joints_per_s"] * 1e6,
+        lambda: e["pose_palette"]["roofline"])
+    grp("pose_palette", lambda: e["pose_palette"]["palette_only"]["us"],
+        lambda: {"frac": 64 * e["pose_palette"]["characters"] * e["pose_palette"]["joints"] / (e["pose_palette"]["palette_only"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "moved_frac": e["pose_palette"]["palette_only"]["moved_frac"]})
+    grp("skin", lambda: e["skinning"]["vertices"] / e["skinning"]["skinned_verts_per_s"] * 1e6, lambda: e["skinning"]["roofline"])
+    grp("particles", lambda: e["particles"]["particles"] / e["particles"]["particles_per_s"] * 1e6, lambda: e["particles"]["roofline"])
+    grp("step", lambda: e["bodies"]["bodies"] / e["bodies"]["bodies_per_s_integrate"] * 1e6, lambda: e["bodies"]["roofline"])
+    grp("bp", lambda: e["bodies"]["broadphase"]["ms"] * 1e3,
+        lambda: {"frac": e["bodies"]["broadphase"]["algorithmic_bytes"] / (e["bodies"]["broadphase"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "moved_frac": e["bodies"]["broadphase"].get("moved_frac")})
+    grp("contacts", lambda: e["bodies"]["contacts"]["us"], lambda: e["bodies"]["contacts"].get("roofline"))
+    try:
+        sec["frame_ms"] = round(float(e["full_frame"]["ms_per_frame"]), 4)
+    except (KeyError, TypeError):
+        pass
+    db = (out.get("cpu_baseline") or {}).get("dropin_boundary") or {}
+
+    def row(src, *keys):
+        d = {}
+        for name, path in keys:
+            try:
+                v = src
+                for k in path:
+                    v = v[k]
+                d[name] = round(float(v), 3)
+            except (KeyError, TypeError):
+                pass
+        return d
+    b = db.get("1000000_entities_100pct_dirty") or {}
+    c = db.get("1000000_entities_10pct_dirty_10_made_10_deleted_a_frame") or {}
+    w = db.get("1000000_entities_10pct_dirty_no_notifications") or {}
+    m = row(b, ("frame_ms", ("scatter_drawn", "binding_frame_draw_list_ms")), ("mq_update_ms", ("scatter_drawn", "binding_mq_update_ms")),
+            ("reference_frame_ms", ("reference_frame_ms",)), ("frame_ms_scatter_all", ("binding_frame_draw_list_ms",)))
+    m.update(row(c, ("churn_mq_update_ms", ("binding_mq_update_ms",)), ("churn_reference_mq_update_ms", ("reference_mq_update_ms",))))
+    m.update(row(w, ("no_notify_mq_update_ms", ("binding_mq_update_ms",)), ("no_notify_reference_mq_update_ms", ("reference_mq_update_ms",))))
+    if m:
+        sec["boundary_1m"] = m
+    for n, name in ((1_000_000, "pipeline_frame_1m"), (10_000, "pipeline_frame_10k")):
+        pf = db.get(f"{n}_entities_10pct_dirty_pipeline_frame_2_shadow_passes") or {}
+        r = row(pf, ("frame_ms", ("binding_pipeline_frame_draw_list_ms",)), ("frame_block_ms", ("binding_pipeline_frame_block_ms",)),
+                ("reference_frame_ms", ("reference_pipeline_frame_ms",)), ("mq_update_ms", ("binding_mq_update_ms",)),
+                ("views_culled_per_update", ("views_culled_per_update",)), ("cull_launches_after_update", ("cull_launches_after_update",)))
+        if r:
+            r["identical"] = bool(pf.get("identical"))
+            sec[name] = r
+    return sec
 
 
 class RankStep:
@@ -1016,6 +1101,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, cam, args.cpu_frames)
         # the secondary numbers a reader of a truncated record needs, as a dozen scalars BEFORE the long sections
         out["summary"] = summary(out, extra)
+        sec = secondary(out, extra)
+        if sec:
+            out["roofline"]["secondary"] = sec               # the one dict the driver's record keeps whole
         if extra is not None:
             out["extra"] = extra
         assert c5 is None or list(c5) == C5_KEYS

@@ -247,6 +247,16 @@ static int ga_reserve(struct ga_model *m, uint32_t n)
 }
 
 #define GA_PAR_MIN 65536u
+/* (GPU_ANIM_PAR_MIN: the same threshold from the environment -- the sanitizer runs force the worker path on small scenes) */
+static size_t ga_par_min(void)
+{
+    static size_t cached;
+    if (!cached) {
+        const char *env = getenv("GPU_ANIM_PAR_MIN");
+        cached = env && atol(env) > 0 ? (size_t)atol(env) : GA_PAR_MIN;
+    }
+    return cached;
+}
 #define GA_MAPPED_MAX 65536u        /* joints of a model's batch up to which the pose works on the mapped staging arrays */
 /* characters [lo, hi) of a model: T / R / S, palette and world position of every joint from the downloaded arrays */
 static void ga_joints_back(struct ga_model *m, uint32_t lo, uint32_t hi)
@@ -397,7 +407,7 @@ int gpu_anim_update(struct gpu_anim *ga, struct gpu_scene *gs, struct mq *mq, st
      * it as well, where the reference (and the one-thread path below that size) still shows it last frame's. */
     size_t joints_total = 0;
     for (uint32_t k = 0; k < ga->n_models; k++) joints_total += (size_t)ga->models[k].n * ga->models[k].J;
-    const int nt = joints_total >= GA_PAR_MIN ? ga_threads() : 1;
+    const int nt = joints_total >= ga_par_min() ? ga_threads() : 1;
     for (uint32_t k = 0; k < ga->n_models; k++) {
         struct ga_model *m = &ga->models[k];
         if (nt > 1 && m->n >= (uint32_t)nt)

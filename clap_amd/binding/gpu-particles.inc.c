@@ -216,7 +216,9 @@ static void gp_structs_back(void *ctx, uint32_t lo, uint32_t hi)
 
 static void gp_structs_back_all(struct gpu_particles *gp)
 {
-    gpu_scene_par_for(gp_structs_back, gp, gp->n_sys, gp->n >= GP_PAR_MIN && gp->n_sys >= 16 ? 8 : 1);
+    static uint32_t par_min;                             /* (GPU_PARTICLES_PAR_MIN: the threshold from the environment, for the sanitizer runs) */
+    if (!par_min) { const char *env = getenv("GPU_PARTICLES_PAR_MIN"); par_min = env && atol(env) > 0 ? (uint32_t)atol(env) : GP_PAR_MIN; }
+    gpu_scene_par_for(gp_structs_back, gp, gp->n_sys, gp->n >= par_min && gp->n_sys >= 16 ? 8 : 1);
 }
 
 /* Bring p->pos / p->velocity of every mirrored system up to date with the device copy. */

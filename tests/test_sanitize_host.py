@@ -33,7 +33,9 @@ def _build(kind):
     exe = os.path.join(OUT, f"clap_dropin_{kind}")
     srcs = [os.path.join(ROOT, "oracle", "ref", "dropin.c"), os.path.join(ROOT, "clap_amd", "binding", "gpu-scene.c"),
             os.path.join(ROOT, "clap_amd", "host", "clapgpu_scene.c"), os.path.join(ROOT, "clap_amd", "host", "clapgpu_snapshot.c"),
-            os.path.join(ROOT, "tests", "c", "fake_clapgpu.c"), os.path.join(ROOT, "oracle", "entity.c"), os.path.join(ROOT, "oracle", "lod.c")]
+            os.path.join(ROOT, "tests", "c", "fake_clapgpu.c"), os.path.join(ROOT, "tests", "c", "fake_clapgpu_anim.c"),
+            os.path.join(ROOT, "oracle", "entity.c"), os.path.join(ROOT, "oracle", "lod.c"), os.path.join(ROOT, "oracle", "pose.c"),
+            os.path.join(ROOT, "oracle", "particles.c"), os.path.join(ROOT, "oracle", "light.c")]
     ref_srcs = [os.path.join(REF, "core", f) for f in ("transform.c", "util.c", "scene.c", "memory.c", "error.c", "logger.c", "object.c")]
     deps = srcs + [os.path.join(ROOT, "clap_amd", "binding", f) for f in os.listdir(os.path.join(ROOT, "clap_amd", "binding"))] + \
         [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
@@ -133,6 +135,28 @@ def test_recycled_entity_addresses_without_a_sanitizer():
     for args in (("test", 200000, 12, 11, "notify", "drawn", "comeandgo", "plain"), ("test", 17000, 8, 705, "notify", "drawn", "comeandgo"),
                  ("test", 4000, 12, 720, "notify", "steady"), ("test", 17000, 8, 731, "steady")):
         assert _run(exe, *args, env=forced)["mismatches"] == 0, args
+
+
+@pytest.mark.timeout(1800)
+def test_animation_particle_character_and_light_bindings_under_the_sanitizers():
+    """The four bindings beside gpu-scene.c -- gpu-anim.inc.c (pools packed per model, the joints' write-back over the worker
+    pool), gpu-particles.inc.c (mapped staging, the struct particle write-back on the workers), gpu-character.inc.c,
+    gpu-light.inc.c -- had never run under a sanitizer: tests/c/fake_clapgpu_anim.c gives their device entry points a CPU
+    body (the oracle's pose / particles / light grid), and `clap_dropin anim | particles | characters | lights` run here
+    under ASan + UBSan, then under TSan with the worker paths forced on from a few dozen joints / particles
+    (GPU_ANIM_PAR_MIN, GPU_PARTICLES_PAR_MIN).  The fake computes with the oracle, so the reference's bits still have to
+    come out everywhere."""
+    exe = _build("asan")
+    for args in (("anim", 40, 24, 6, 1), ("anim", 300, 64, 8, 2, "notify"), ("anim", 30, 200, 4, 3), ("particles", 12, 200, 8, 1),
+                 ("particles", 3, 100, 6, 4), ("characters", 60, 10, 1), ("characters", 400, 12, 2, "notify"), ("lights", 12, 1)):
+        r = _run(exe, *args)
+        assert r["mismatches"] == 0 and r.get("differing_objects", 0) == 0 and r.get("stream_draws_agree", True), (args, r)
+    exe = _build("tsan")
+    forced = {"GPU_SCENE_THREADS": "6", "GPU_ANIM_THREADS": "6", "GPU_ANIM_PAR_MIN": "64", "GPU_PARTICLES_PAR_MIN": "512"}
+    for args in (("anim", 60, 24, 8, 3, "notify"), ("anim", 600, 32, 5, 4), ("particles", 40, 128, 8, 2), ("particles", 80, 1024, 4, 2),
+                 ("characters", 300, 8, 3, "notify"), ("lights", 6, 2)):
+        r = _run(exe, *args, env=forced)
+        assert r["mismatches"] == 0 and r.get("differing_objects", 0) == 0 and r.get("stream_draws_agree", True), (args, r)
 
 
 def test_mirror_edits_in_place_under_asan_ubsan():
