@@ -162,6 +162,9 @@ struct gpu_scene {
     bool            groups_valid;
     /* GPU_SCATTER_DRAWN: rebuilds of a slot the host has not been shown yet (e->seq lags by this much, uint16 like seq) */
     bool            scatter_drawn, drawn_now;                      /* the policy; it is in force for the frame being run (a fast frame) */
+    bool            shown_stale;                                   /* the policy was switched on: the next walk lays shown[] out anew */
+    bool            shown_live;                                    /* shown[] describes the CURRENT slots: laid out by the last walk (a walk under
+                                                                      GPU_SCATTER_ALL re-tiles without it) and kept by every write-back since */
     uint16_t        *pend; uint32_t cap_pend; bool any_pend;
     /* ... and the seq each batched entity's entity3d was last GIVEN by a frame (walk, write-back or fetch; a host update in
      * between -- entity3d_update / _reset -- does not count: the device catches up with one rebuild in the next frame and
@@ -349,6 +352,7 @@ void gpu_scene_characters(struct gpu_scene *gs, bool (*is_plain)(entity3d *, int
 static void bv_pick(struct scene *scene, entity3d *e);
 static void scatter_one(struct gpu_scene *gs, struct gs_rec *r, const clapgpu_scene_arrays *res, size_t slot, bool parent_seq);
 static void consume_fetched(struct gpu_scene *gs);
+static void fetch_met_in_queue(struct gpu_scene *gs, struct mq *mq);
 
 static int frustum_of(const struct view *view, clapgpu_frustum *fr);
 
@@ -685,7 +689,16 @@ static unsigned int verify_untouched(struct gpu_scene *gs)
 void gpu_scene_bind(struct gpu_scene *gs, struct mq *mq, struct view *view)
 {
     g_bound = gs;
-    if (gs) { gs->bound_mq = mq; gs->bound_view = view; }
+    if (!gs) return;
+    if (gs->bound_mq && mq != gs->bound_mq) {
+        /* the object serves another queue from now on: what GPU_SCATTER_DRAWN left on the device for the old one's entities
+         * comes over first (the new queue's walk meets none of them), and the next update walks.  With a topology report
+         * pending a record may name freed memory: then the rows go to the entities the OLD queue's lists still hold, as a
+         * walk would hand them out (found by `clap_dropin fuzz 305`: topology report, then another queue's frame) */
+        if (gs->any_pend && gpu_scene_fetch_all(gs) == _CERR_NOT_SUPPORTED) fetch_met_in_queue(gs, gs->bound_mq);
+        gs->topology_pending = true;
+    }
+    gs->bound_mq = mq; gs->bound_view = view;
 }
 
 struct gpu_scene *gpu_scene_bound(void) { return g_bound; }
@@ -1208,7 +1221,10 @@ static inline uint16_t pend_of(const struct gpu_scene *gs, uint32_t slot)
  * since -- and without the steps a host update took since the last frame.  GPU_SCATTER_ALL: the parent's own counter. */
 static inline uint16_t parent_seq_now(const struct gpu_scene *gs, const struct gs_rec *r, const entity3d *parent)
 {
-    if (gs->shown && r->parent_rec != NO_REC) {
+    /* (only while shown[] is kept: a walk under GPU_SCATTER_ALL does not lay it out, and a re-tile moves the slots under it --
+     * `clap_dropin fuzz 77`: drawn, back to all, a re-tile, then a child rebuilt in a frame that is not walked.  The policy
+     * alone does not say: rows left stale before a switch to GPU_SCATTER_ALL are still owed their counters -- fuzz 5016) */
+    if (gs->shown_live && gs->shown && r->parent_rec != NO_REC) {
         const struct gs_rec *pr = &gs->rec[r->parent_rec];
         if ((pr->cls == 1 || pr->cls == 4) && pr->slot < gs->cap_pend)
             return (uint16_t)(gs->shown[pr->slot] + gs->pend[pr->slot]);
@@ -1293,12 +1309,36 @@ static void consume_fetched(struct gpu_scene *gs)
     }
 }
 
+/* every stale row to the entity3d the queue's own lists still hold (not by the records: some may name freed memory) */
+static void fetch_met_in_queue(struct gpu_scene *gs, struct mq *mq)
+{
+    uint32_t n_rows = 0;
+    clapgpu_scene_arrays fr;
+    if (clapgpu_scene_fetch(gs->scene, NULL, &n_rows) || !n_rows || clapgpu_scene_results(gs->scene, &fr)) return;
+    gs->res = fr;
+    gs->fetch_seen = fr.fetch_serial;
+    model3dtx *txm;
+    entity3d *e, *it;
+    list_for_each_entry(txm, &mq->txmodels, entry) list_for_each_entry_iter(e, it, &txm->entities, entry) {
+        if (!entity3d_matches(e, ENTITY3D_ALIVE)) continue;
+        const uint32_t i = rec_find(gs, e);
+        if (i == NO_REC) continue;
+        struct gs_rec *r = &gs->rec[i];
+        if (r->gone || r->e != e || (r->cls != 1 && r->cls != 4) || r->slot >= fr.n_slots) continue;
+        if (!((fr.fetched_mask[r->slot >> 6] >> (r->slot & 63)) & 1)) continue;
+        scatter_fetched(gs, r, &fr, r->slot);
+        gs->stats.fetched++;
+    }
+    if (gs->pend) memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));
+    gs->any_pend = false;
+}
+
 void gpu_scene_set_scatter(struct gpu_scene *gs, int policy)
 {
     if (!gs) return;
     const bool drawn = policy == GPU_SCATTER_DRAWN;
     if (gs->scatter_drawn && !drawn) gpu_scene_fetch_all(gs);    /* back to "everything is always current" */
-    if (drawn && !gs->scatter_drawn) gs->topology_pending = true; /* its per-slot counters are laid out by a walk: the next frame is one */
+    if (drawn && !gs->scatter_drawn) { gs->topology_pending = true; gs->shown_stale = true; }   /* its per-slot counters are laid out by a walk: the next frame is one */
     gs->scatter_drawn = drawn;
 }
 
@@ -2434,7 +2474,8 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
 
     bool shown_stands = true;                                    /* shown[] of the last frames still describes this layout's slots */
     if (gs->scatter_drawn && gs->notify && res.n_slots) {        /* the counters GPU_SCATTER_DRAWN keeps per slot, for this layout */
-        shown_stands = !st->retiled && gs->shown && gs->cap_pend >= res.n_slots;
+        shown_stands = !st->retiled && gs->shown && gs->cap_pend >= res.n_slots && !gs->shown_stale;
+        gs->shown_stale = false;
         if (res.n_slots > gs->cap_pend) {
             uint16_t *pn = realloc(gs->pend, (size_t)res.n_slots * sizeof(*pn));
             if (pn) gs->pend = pn;
@@ -2449,6 +2490,7 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));   /* (every counter was consumed with the walk's fetch) */
         if (!shown_stands) memset(gs->shown, 0, (size_t)gs->cap_pend * sizeof(*gs->shown));
     }
+    gs->shown_live = gs->scatter_drawn && gs->notify && res.n_slots && gs->shown;
     const double t3 = now_ms();
     if (!st->retiled && gs->walked && shown_stands && res.n_slots) {
         /* 5, the layout stood: the device's masks say what was rebuilt and which boxes hold the camera -- the second half of

@@ -310,6 +310,7 @@ static void game_frame(uint32_t n_ops)
         const uint32_t id = pick_alive();
         if (id == NONE) continue;
         if (no_topology && what >= (opt_comeandgo ? 975u : 920u)) what = what % 920;   /* `comeandgo`: entities are still made and deleted in those frames */
+        if (getenv("DROPIN_GAME_TRACE")) fprintf(stderr, "game: op %u on entity %u (parent %d, n_ids %u)\n", what, id, (int)meta[id].parent, n_ids);
         if (what < 600) {
             vec3 off = { rndf(-1, 1), rndf(-1, 1), rndf(-1, 1) };
             ref_entity3d_move(A.e[id], off); entity3d_move(B.e[id], off);
@@ -720,6 +721,192 @@ static int cmd_test(uint32_t n, uint32_t frames, uint64_t seed)
            opt_notify ? "true" : "false", (unsigned long long)fast_frames, (unsigned long long)n_host_updates,
            opt_drawn ? "drawn" : "all", (unsigned long long)left_stale, (unsigned long long)fetched, (unsigned long long)n_stale_seen,
            (unsigned long long)n_partial_frames, (unsigned long long)placed, (unsigned long long)removed, (unsigned long long)replayed, (unsigned long long)bad);
+    gpu_scene_done(gs);
+    return bad ? 1 : 0;
+}
+
+
+/* ---------------------------------------------------------------- orderings of the binding's API, generated
+ * `test` is one scripted game with different seeds.  `fuzz <seed> <ops>` interleaves, between frames and in random order,
+ * every public call of gpu-scene.h a game or an engine maintainer can make: the mutators' notifications (also spurious
+ * ones: a touch of an entity nobody changed, a topology report without a change), entities made, deleted, re-parented,
+ * updated on the spot, standing readers named and dropped (gpu_scene_keep), fetches of one entity and of all, the
+ * write-back policy and the notification mode switched back and forth, the in-place-edit and verification switches, LODs
+ * forced and released, the camera's and the light's planes recomputed, the light's view registered and taken off, the
+ * binding bound to another (empty) queue for a frame and back, and the whole binding object destroyed and made again
+ * over the living entities -- then a frame, render passes with the camera's view, the light's or none, and both worlds
+ * compared.  Small scenes (a fuzzer wants many seeds): tests/test_sanitize_host.py runs thousands under ASan against the
+ * CPU stand-in, tests/test_dropin.py some hundreds on the device.  (core/input-fuzzer.c:17-91 is the reference's own.) */
+static int cmd_fuzz(uint64_t seed, uint32_t ops)
+{
+    struct gpu_scene *gs;
+    int rc = gpu_scene_init(&gs, 0, default_update);
+    if (rc) { fprintf(stderr, "gpu_scene_init: %d\n", rc); return 2; }
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 12345;
+    const uint32_t n0 = 20 + rndn(seed % 7 == 0 ? 1500 : 220);
+    cap_ids = n0 + ops * 2 + 64;
+    meta = calloc(cap_ids, sizeof(*meta));
+    static struct world C;                                          /* another queue of the same engine (the UI's): empty */
+    world_init(&A, cap_ids);
+    world_init(&B, cap_ids);
+    world_init(&C, 4);
+    static const unsigned int lods[N_MODELS][3] = { { 0, 3, 4 }, { 1, 2, 4 }, { 0, 0, 1 }, { 0, 5, 6 } };
+    for (int k = 0; k < N_MODELS; k++) {
+        A.model[k].lod_min = B.model[k].lod_min = lods[k][0];
+        A.model[k].lod_max = B.model[k].lod_max = lods[k][1];
+        A.model[k].nr_lods = B.model[k].nr_lods = lods[k][2];
+    }
+    opt_plain = rndn(2);
+    parents_first = opt_plain;
+    while (n_ids < n0) op_create(200.f, !opt_plain);
+    A.scene->control = A.e[0];
+    B.scene->control = B.e[0];
+    opt_notify = rndn(2); opt_drawn = rndn(2);
+    bool incremental = true, verify = false, light_on = false;
+    gpu_scene_set_notify(gs, opt_notify);
+    gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
+    gpu_scene_bind(gs, B.mq, &B.view);
+    vec3 cpos = { 0, 5, 60 }, lpos = { -40, 120, 10 };
+    quat cq, lq;
+    quat_identity(cq); quat_from_euler_xyz(lq, -1.1f, -0.4f, 0);
+    view_set(&A, cpos, cq); view_set(&B, cpos, cq);
+    light_view_set(&A, lpos, lq); light_view_set(&B, lpos, lq);
+
+    uint8_t *drawn_a = calloc(cap_ids, 1), *drawn_b = calloc(cap_ids, 1);
+    uint64_t bad = 0, visible = 0, frames = 0, passes = 0, op_count[20] = { 0 }, fast = 0, walked = 0, not_supported = 0;
+    uint32_t done_ops = 0;
+    while (done_ops < ops && !bad) {
+        /* ---- between two frames: a handful of calls in random order */
+        const uint32_t burst = 1 + rndn(10);
+        for (uint32_t k = 0; k < burst && done_ops < ops; k++, done_ops++) {
+            const uint32_t op = rndn(100);
+            const uint32_t id = pick_alive();
+            if (getenv("DROPIN_FUZZ_TRACE")) fprintf(stderr, "fuzz: frame %llu op %u (entity %d) notify %d drawn %d light %d\n", (unsigned long long)frames, op, (int)id, (int)opt_notify, (int)opt_drawn, (int)light_on);
+            if (op < 40) { no_topology = false; game_frame(1 + rndn(4)); op_count[0]++; }
+            else if (op < 44) { if (id != NONE) gpu_scene_touch(gs, B.e[id]); op_count[1]++; }
+            else if (op < 48) { if (id != NONE) gpu_scene_touch_xform(gs, B.e[id]); op_count[2]++; }
+            else if (op < 53) { if (id != NONE) gpu_scene_keep(gs, B.e[id], rndn(2)); op_count[3]++; }
+            else if (op < 58) {
+                if (id != NONE) { rc = gpu_scene_fetch(gs, B.e[id]); not_supported += rc == _CERR_NOT_SUPPORTED; if (rc && rc != _CERR_NOT_SUPPORTED) bad++; }
+                op_count[4]++;
+            }
+            else if (op < 61) { rc = gpu_scene_fetch_all(gs); not_supported += rc == _CERR_NOT_SUPPORTED; if (rc && rc != _CERR_NOT_SUPPORTED) bad++; op_count[5]++; }
+            else if (op < 65) { opt_drawn = !opt_drawn; gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL); op_count[6]++; }
+            else if (op < 68) { opt_notify = !opt_notify; gpu_scene_set_notify(gs, opt_notify); op_count[7]++; }
+            else if (op < 74) {
+                if (id != NONE) {
+                    const int lod = (int)rndn(8) - 2; const bool force = rndn(2);
+                    ref_entity3d_set_lod(A.e[id], lod, force); entity3d_set_lod(B.e[id], lod, force);
+                }
+                op_count[8]++;
+            }
+            else if (op < 80) {
+                cpos[0] += rndf(-20, 20); cpos[2] += rndf(-20, 20);
+                quat_from_euler_xyz(cq, rndf(-0.4f, 0.4f), rndf(-3, 3), 0);
+                view_set(&A, cpos, cq); view_set(&B, cpos, cq);
+                op_count[9]++;
+            }
+            else if (op < 86) {
+                const uint32_t w = rndn(3);
+                if (w == 0 && !light_on) { light_on = !gpu_scene_add_view(gs, &B.lview); }
+                else if (w == 1 && light_on) { gpu_scene_remove_view(gs, &B.lview); light_on = false; }
+                else { lpos[0] += rndf(-15, 15); light_view_set(&A, lpos, lq); light_view_set(&B, lpos, lq); }
+                op_count[10]++;
+            }
+            else if (op < 88) { gpu_scene_topology(gs); op_count[11]++; }
+            else if (op < 91) {
+                /* the engine updates another queue through the same binding object, then comes back */
+                gpu_scene_bind(gs, C.mq, &C.view);
+                mq_update(C.mq);
+                gpu_scene_bind(gs, B.mq, &B.view);
+                op_count[12]++;
+            }
+            else if (op < 93) {
+                /* the binding object goes and comes back over the living entities (a renderer restart): what it left on
+                 * the device is asked for first */
+                rc = gpu_scene_fetch_all(gs);
+                if (rc == _CERR_NOT_SUPPORTED) { op_count[13]++; continue; }    /* a walk is pending: not now */
+                if (rc) { bad++; break; }
+                gpu_scene_done(gs);
+                rc = gpu_scene_init(&gs, 0, default_update);
+                if (rc) { fprintf(stderr, "gpu_scene_init (again): %d\n", rc); return 2; }
+                gpu_scene_set_notify(gs, opt_notify);
+                gpu_scene_set_scatter(gs, opt_drawn ? GPU_SCATTER_DRAWN : GPU_SCATTER_ALL);
+                gpu_scene_set_incremental(gs, incremental);
+                gpu_scene_set_verify(gs, verify);
+                gpu_scene_bind(gs, B.mq, &B.view);
+                if (light_on) light_on = !gpu_scene_add_view(gs, &B.lview);
+                op_count[13]++;
+            }
+            else if (op < 96) { incremental = !incremental; gpu_scene_set_incremental(gs, incremental); op_count[14]++; }
+            else { verify = !verify; gpu_scene_set_verify(gs, verify); op_count[15]++; }
+        }
+        /* ---- the frame */
+        A.scene->camera->bv = NULL; B.scene->camera->bv = NULL;
+        ref_mq_update(A.mq);
+        mq_update(B.mq);
+        const struct gpu_scene_stats *st = gpu_scene_last_stats(gs);
+        if (!st->batched && !st->host) { fprintf(stderr, "mq_update: the binding did not run (%s)\n", clapgpu_last_error()); return 2; }
+        fast += gpu_scene_last_was_fast(gs); walked += !gpu_scene_last_was_fast(gs);
+        if (getenv("DROPIN_TRACE")) {                                    /* one entity's counters after every frame, before any fetch */
+            const uint32_t id = (uint32_t)atoi(getenv("DROPIN_TRACE"));
+            if (id < n_ids && meta[id].alive) {
+                char what[640], whatp[640] = "";
+                gpu_scene_describe(gs, B.e[id], what, sizeof(what));
+                if (B.e[id]->parent) gpu_scene_describe(gs, B.e[id]->parent, whatp, sizeof(whatp));
+                fprintf(stderr, "trace frame %llu (%s): entity %u seq %u / %u parent_seq %u / %u updated %d / %d; %s; parent (seq %u / %u): %s\n", (unsigned long long)frames,
+                        gpu_scene_last_was_fast(gs) ? "fast" : "walk", id, A.e[id]->seq, B.e[id]->seq, A.e[id]->parent_seq, B.e[id]->parent_seq,
+                        (int)transform_is_updated(&A.e[id]->xform), (int)transform_is_updated(&B.e[id]->xform), what,
+                        A.e[id]->parent ? A.e[id]->parent->seq : 0, B.e[id]->parent ? B.e[id]->parent->seq : 0, whatp);
+            }
+        }
+        /* ---- render passes, as pipeline_render orders them: the light's view without a camera, then the camera's */
+        const uint32_t n_pass = rndn(4);
+        for (uint32_t pass = 0; pass < n_pass && !bad; pass++) {
+            const uint32_t which = rndn(3);                              /* 0 the camera's view, 1 the light's (registered or not), 2 none */
+            if (getenv("DROPIN_FUZZ_TRACE")) fprintf(stderr, "fuzz: frame %llu pass %u view %u (%s frame)\n", (unsigned long long)frames, pass, which, gpu_scene_last_was_fast(gs) ? "fast" : "walked");
+            struct view *va = which == 0 ? &A.view : which == 1 ? &A.lview : NULL, *vb = which == 0 ? &B.view : which == 1 ? &B.lview : NULL;
+            const float *cam = which == 0 && rndn(4) ? cpos : NULL;
+            memset(drawn_a, 0, cap_ids); memset(drawn_b, 0, cap_ids);
+            const uint32_t na = lod_pass_ref_view(&A, va, cam, drawn_a);
+            rc = gpu_scene_select_lod(gs, vb, cam);
+            if (rc) { fprintf(stderr, "frame %llu pass %u: gpu_scene_select_lod: %d (%s)\n", (unsigned long long)frames, pass, rc, clapgpu_last_error()); bad++; break; }
+            entity3d **list; const int32_t *llod;
+            const uint32_t nb = gpu_scene_visible(gs, &list, &llod);
+            for (uint32_t k = 0; k < nb; k++) {
+                for (uint32_t id = 0; id < n_ids; id++) if (B.e[id] == list[k]) {
+                    drawn_b[id]++;
+                    const entity3d *a = A.e[id], *b = list[k];
+                    if ((memcmp(a->mx, b->mx, 64) || memcmp(a->inverse_mx, b->inverse_mx, 64) || memcmp(a->aabb, b->aabb, 24) || a->seq != b->seq) && bad++ < 8)
+                        fprintf(stderr, "frame %llu pass %u (view %u) entity %u: on the draw list with fields that are not the reference's\n",
+                                (unsigned long long)frames, pass, which, id);
+                    break;
+                }
+                if (llod[k] != list[k]->cur_lod && bad++ < 8) fprintf(stderr, "frame %llu pass %u: list LOD %d but e->cur_lod %d\n", (unsigned long long)frames, pass, llod[k], list[k]->cur_lod);
+            }
+            if (na != nb && bad++ < 8) fprintf(stderr, "frame %llu pass %u (view %u): %u entities drawn by the reference, %u on the list\n", (unsigned long long)frames, pass, which, na, nb);
+            for (uint32_t id = 0; id < n_ids; id++)
+                if (meta[id].alive && (drawn_a[id] != drawn_b[id] || A.e[id]->cur_lod != B.e[id]->cur_lod) && bad++ < 8)
+                    fprintf(stderr, "frame %llu pass %u (view %u) entity %u: drawn %d / %d cur_lod %d / %d\n", (unsigned long long)frames, pass, which, id,
+                            drawn_a[id], drawn_b[id], A.e[id]->cur_lod, B.e[id]->cur_lod);
+            passes++;
+        }
+        bad += compare_frame_ex(gs, (uint32_t)frames, &visible, !opt_drawn || rndn(2) || done_ops >= ops);
+        frames++;
+    }
+    if (!bad && opt_drawn) bad += compare_frame_ex(gs, (uint32_t)frames, &visible, true);
+    printf("{\"mode\": \"fuzz\", \"seed\": %llu, \"ops\": %u, \"entities_at_start\": %u, \"entities_created\": %u, \"frames\": %llu, \"fast_frames\": %llu, "
+           "\"walked_frames\": %llu, \"render_passes\": %llu, \"calls_refused_while_a_walk_is_pending\": %llu, "
+           "\"ops_by_kind\": {\"game\": %llu, \"touch\": %llu, \"touch_xform\": %llu, \"keep\": %llu, \"fetch\": %llu, \"fetch_all\": %llu, \"set_scatter\": %llu, "
+           "\"set_notify\": %llu, \"set_lod\": %llu, \"camera_planes\": %llu, \"light_view\": %llu, \"topology\": %llu, \"other_queue\": %llu, \"done_init\": %llu, "
+           "\"set_incremental\": %llu, \"set_verify\": %llu}, \"mismatches\": %llu}\n",
+           (unsigned long long)seed, ops, n0, n_ids, (unsigned long long)frames, (unsigned long long)fast, (unsigned long long)walked, (unsigned long long)passes,
+           (unsigned long long)not_supported,
+           (unsigned long long)op_count[0], (unsigned long long)op_count[1], (unsigned long long)op_count[2], (unsigned long long)op_count[3],
+           (unsigned long long)op_count[4], (unsigned long long)op_count[5], (unsigned long long)op_count[6], (unsigned long long)op_count[7],
+           (unsigned long long)op_count[8], (unsigned long long)op_count[9], (unsigned long long)op_count[10], (unsigned long long)op_count[11],
+           (unsigned long long)op_count[12], (unsigned long long)op_count[13], (unsigned long long)op_count[14], (unsigned long long)op_count[15],
+           (unsigned long long)bad);
     gpu_scene_done(gs);
     return bad ? 1 : 0;
 }
@@ -1932,6 +2119,8 @@ static int run(int argc, char **argv)
         return cmd_particles((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), strtoull(argv[5], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "characters"))
         return cmd_characters((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
+    if (argc >= 4 && !strcmp(argv[1], "fuzz"))
+        return cmd_fuzz(strtoull(argv[2], NULL, 0), (uint32_t)atoi(argv[3]));
     if (argc >= 5 && !strcmp(argv[1], "lod"))
         return cmd_lod((uint32_t)atoi(argv[2]), (uint32_t)atoi(argv[3]), strtoull(argv[4], NULL, 0));
     if (argc >= 5 && !strcmp(argv[1], "test"))

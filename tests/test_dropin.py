@@ -386,3 +386,19 @@ def test_pipeline_shaped_frame_in_bench_mode(mode):
     assert r["mismatches"] == 0 and r["shadow_sets_equal"] is True and r["draw_reads_equal"] is True
     assert r["views_culled_per_update"] == 2.0 and r["cull_launches_after_update"] == 0
     assert r["shadow_drawn_per_frame"] > 0 and r["binding_pipeline_frame_draw_list_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_api_orderings_fuzzed_on_the_device():
+    """The generated orderings of tests/test_sanitize_host.py::test_api_orderings_fuzzed_under_asan against the real
+    library: 200 seeds (the pinned ones among them), four processes at a time."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(305, 200), (77, 200), (5016, 1500), (1421, 200)] + [(s, 200) for s in range(1, 181)] + [(s, 1500) for s in range(5001, 5017)]
+
+    def one(job):
+        r = _run("fuzz", *job)
+        return job[0], r["mismatches"], r["fast_frames"], r["walked_frames"]
+    with ThreadPoolExecutor(4) as pool:
+        res = list(pool.map(one, jobs))
+    assert [s for s, bad, _f, _w in res if bad] == []
+    assert sum(f for _s, _b, f, _w in res) > 500 and sum(w for _s, _b, _f, w in res) > 500
