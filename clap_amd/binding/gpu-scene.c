@@ -1434,6 +1434,18 @@ void gpu_scene_keep(struct gpu_scene *gs, entity3d *e, bool keep)
  * the plain list walk -- 20 k entities 0.95 vs 0.78 ms, 64 k 6.1 vs 3.9 --, split over the workers they win from ~16 k
  * entities on (two wake-ups of the pool, ~0.1 ms, against a walk of 0.35 ms and up). */
 #define GS_REPLAY_MIN 16384u
+#define GS_REPLAY_MIN_DEFAULT 16384u
+/* the smallest queue whose frames without notifications go by the records (GPU_SCENE_REPLAY_MIN; below GS_REPLAY_MIN the
+ * check and the passes run on the calling thread) */
+static uint32_t replay_min(void)
+{
+    static uint32_t cached = 0xffffffffu;
+    if (cached == 0xffffffffu) {
+        const char *env = getenv("GPU_SCENE_REPLAY_MIN");
+        cached = env ? (uint32_t)strtoul(env, NULL, 0) : GS_REPLAY_MIN_DEFAULT;
+    }
+    return cached;
+}
 /* rebuilt rows from which the write-back is split over the workers (a row is ~60 ns on one thread -- a 448-byte entity3d
  * and its 164 bytes of results, both cold --, a wake-up of the pool ~0.05 ms): 70 k entities, 13 k rebuilt: 0.87 ms serial */
 #define GS_SCATTER_PAR_MIN 12288u
@@ -2191,7 +2203,8 @@ static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
     if (t != gs->n_wtxm) return false;
     struct quc_ctx qc = { gs, 0 };
     const double q0 = getenv("GPU_SCENE_TIMING") ? now_ms() : 0;
-    gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, par_threads());
+    /* a small queue on the calling thread: waking the workers costs more than looking at a few thousand list nodes */
+    gpu_scene_par_for(queue_unchanged_range, &qc, gs->n_order, gs->n_order >= GS_REPLAY_MIN ? par_threads() : 1);
     if (q0 != 0) fprintf(stderr, "queue_unchanged: %u entities in %.3f ms (%s)\n", gs->n_order, now_ms() - q0, qc.changed ? "changed" : "the same");
     return !qc.changed;
 }
@@ -2226,8 +2239,8 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         if (rc <= 0) return rc;
         gs->gen++;
         memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
-    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order >= GS_REPLAY_MIN && par_threads() > 1 &&
-               !gs->n_touched && queue_unchanged(gs, mq)) {
+    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order >= replay_min() &&
+               (par_threads() > 1 || gs->n_order < GS_REPLAY_MIN) && !gs->n_touched && queue_unchanged(gs, mq)) {
         /* no notifications, and the queue is the one the last walk met: the frame by the records (see queue_unchanged) */
         if (gs->n_order > gs->cap_touched) {
             uint32_t *q = realloc(gs->touched, (size_t)gs->cap_order * sizeof(*q));
