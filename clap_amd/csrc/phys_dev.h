@@ -238,13 +238,7 @@ PHD int collide_capsule_capsule(const double (&pos1)[3], const double (&ax1)[3],
                 for (int i = 0; i < 3; i++) { sphere1[i] = pos1[i] + lo * ax1[i]; sphere2[i] = pos2[i] + (lo + k) * axis2[i]; }
                 if (collide_spheres(sphere1, r1, sphere2, r2, c0)) {
                     for (int i = 0; i < 3; i++) { sphere1[i] = pos1[i] + hi * ax1[i]; sphere2[i] = pos2[i] + (hi + k) * axis2[i]; }
-                    // (kept from being merged with the call above: as one body storing through a SELECTED pointer -- c0 or c1 --
-                    // both contacts sat in a 56-byte private segment per lane; scratch is HBM traffic on gfx950)
-                    double r1b = r1;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" : "+v"(r1b));
-#endif
-                    if (collide_spheres(sphere1, r1b, sphere2, r2, c1))
+                    if (collide_spheres(sphere1, r1, sphere2, r2, c1))
                         return 2;
                 }
             }

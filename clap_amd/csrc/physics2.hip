@@ -1050,9 +1050,8 @@ void k_sweep_capsules(GeomsK A, GeomsK B, uint32_t n_sweeps, const uint32_t *swe
                     if (lane >= o) incl += u;
                 }
                 const uint32_t first = taken + incl - (uint32_t)nc;
-#pragma unroll
-                for (int i = 0; i < 2; i++) {                            // nc <= 2: unrolled, cg[] stays in registers
-                    if (i >= nc || first + i >= 16) break;
+                for (int i = 0; i < nc; i++) {
+                    if (first + i >= 16) break;
                     const float cn[3] = { (float)cg[i].normal[0], (float)cg[i].normal[1], (float)cg[i].normal[2] };
                     const float ndot = dir[0] * cn[0] + dir[1] * cn[1] + dir[2] * cn[2];
                     if (ndot > -0.1f) continue;
