@@ -185,8 +185,14 @@ struct gpu_scene {
     uint32_t        ftab_count;
     struct gs_cand { uint64_t key; uint32_t rec; } *cands; uint32_t cap_cands;
     uint32_t        inc_placed, inc_removed;
+    /* a walked frame that re-tiled: what the REFERENCE would have rebuilt, decided from the host fields on the workers (by_host_fields) */
+    struct gs_hf { uint32_t ppos; uint16_t seq0, pseq; uint8_t dirty, state; } *hf; uint32_t cap_hf;
+    uint64_t        *hf_mask; uint32_t cap_hf_mask;
+    uint32_t        *keep_changes; uint32_t cap_keep_changes;      /* scratch of a walk's last pass */
     struct gpu_scene_stats stats;
 };
+
+static int par_threads(void);
 
 static inline uint32_t ptr_hash(const void *p)
 {
@@ -295,6 +301,7 @@ int gpu_scene_init(struct gpu_scene **out, int device, int (*default_hook)(entit
     const char *rp = getenv("GPU_SCENE_REPLAY");
     gs->replay = !(rp && !strcmp(rp, "0"));
     gpu_scene_pool_ref();
+    clapgpu_scene_set_parallel_for(gs->scene, gpu_scene_par_for, par_threads());   /* the mirror's re-tile borrows the pool */
     *out = gs;
     return 0;
 }
@@ -308,7 +315,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->shown); free(gs->xptr); free(gs->ftab);
-    free(gs->claim); free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands);
+    free(gs->claim); free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands); free(gs->hf); free(gs->hf_mask); free(gs->keep_changes);
     free(gs->walk_fetch); free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
@@ -757,6 +764,23 @@ static uint32_t txm_index(struct gpu_scene *gs, const model3dtx *txm)
     return last = gs->n_txms++;
 }
 
+/* the tables a walk leaves behind are filled from the records on the workers (1 M entities: ~40 ms of a walked frame on one) */
+#define GS_TABLES_PAR_MIN 16384u
+struct walk_tables_ctx { struct gpu_scene *gs; uint32_t n_slots; int bad; uint32_t count; };
+static void slot_arrays_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct walk_tables_ctx *wc = ctx;
+    struct gpu_scene *gs = wc->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if ((r->cls != 1 && r->cls != 4) || r->slot >= wc->n_slots) continue;
+        if (r->lod_cur < -128 || r->lod_cur > 127) { __atomic_store_n(&wc->bad, 1, __ATOMIC_RELAXED); return; }
+        gs->slot_ent[r->slot] = r->e;                            /* (a slot has one record) */
+        gs->slot_txm[r->slot] = (uint16_t)(r->order_key >> 32);
+        gs->slot_lod[r->slot] = (int8_t)r->lod_cur;
+    }
+}
+
 static int slot_arrays_build(struct gpu_scene *gs)
 {
     const uint32_t n = clapgpu_scene_slot_count(gs->scene);
@@ -786,18 +810,35 @@ static int slot_arrays_build(struct gpu_scene *gs)
         gs->txms[t] = gs->wtxm[t].txm;
     }
     gs->n_txms = gs->n_wtxm;
-    for (uint32_t k = 0; k < gs->n_order; k++) {
-        const struct gs_rec *r = &gs->rec[gs->order[k]];
-        if ((r->cls != 1 && r->cls != 4) || r->slot >= n) continue;
-        if (r->lod_cur < -128 || r->lod_cur > 127) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }   /* the record path then */
-        gs->slot_ent[r->slot] = r->e;
-        gs->slot_txm[r->slot] = (uint16_t)(r->order_key >> 32);
-        gs->slot_lod[r->slot] = (int8_t)r->lod_cur;
-    }
+    struct walk_tables_ctx wc = { gs, n, 0, 0 };
+    gpu_scene_par_for(slot_arrays_range, &wc, gs->n_order, gs->n_order >= GS_TABLES_PAR_MIN ? par_threads() : 1);
+    if (wc.bad) { gs->cap_slot_arrays = 0; return _CERR_NOMEM; }   /* a LOD outside int8: the record path then */
     return 0;
 }
 
 static inline uint32_t ftab_home(const struct gpu_scene *gs, const void *e) { return ptr_hash(e) & gs->ftab_mask; }
+
+/* (every key is distinct and nobody looks anything up before the join: a home is claimed by its key, the rest follows) */
+static void ftab_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct walk_tables_ctx *wc = ctx;
+    struct gpu_scene *gs = wc->gs;
+    uint32_t count = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if (!r->e) continue;                                      /* taken out in place since the walk */
+        count++;
+        uint32_t h = ftab_home(gs, r->e);
+        for (;;) {
+            uint64_t none = 0;
+            if (__atomic_compare_exchange_n(&gs->ftab[h].key, &none, (uint64_t)(uintptr_t)r->e, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+            h = (h + 1) & gs->ftab_mask;
+        }
+        gs->ftab[h].handle = (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY;
+        gs->ftab[h].slot = r->slot;
+    }
+    __atomic_fetch_add(&wc->count, count, __ATOMIC_RELAXED);
+}
 
 static int ftab_build(struct gpu_scene *gs)
 {
@@ -810,15 +851,9 @@ static int ftab_build(struct gpu_scene *gs)
     }
     gs->ftab_mask = cap - 1;
     memset(gs->ftab, 0, (size_t)cap * sizeof(*gs->ftab));
-    gs->ftab_count = 0;
-    for (uint32_t k = 0; k < gs->n_order; k++) {
-        const struct gs_rec *r = &gs->rec[gs->order[k]];
-        if (!r->e) continue;                                      /* taken out in place since the walk */
-        gs->ftab_count++;
-        uint32_t h = ftab_home(gs, r->e);
-        while (gs->ftab[h].key) h = (h + 1) & gs->ftab_mask;
-        gs->ftab[h] = (struct gs_fast){ (uint64_t)(uintptr_t)r->e, (r->cls == 1 || r->cls == 4) ? r->handle : CLAPGPU_NO_ENTITY, r->slot };
-    }
+    struct walk_tables_ctx wc = { gs, 0, 0, 0 };
+    gpu_scene_par_for(ftab_range, &wc, gs->n_order, gs->n_order >= GS_TABLES_PAR_MIN ? par_threads() : 1);
+    gs->ftab_count = wc.count;
     return 0;
 }
 
@@ -2209,6 +2244,142 @@ static bool queue_unchanged(struct gpu_scene *gs, struct mq *mq)
     return !qc.changed;
 }
 
+/*
+ * A walked frame that RE-TILED.  The device has rebuilt every row of the new layout, so its mask cannot say what the reference
+ * would have rebuilt -- the host fields do (model.c:1609-1616, 1667): an entity is rebuilt if its transform was written, or if
+ * its parent_seq is not its parent's seq AS THE PARENT LEAVES THIS FRAME (the parent comes earlier in the list).  That is a
+ * recurrence up the ancestor chain -- rebuilt(e) = dirty(e) || parent_seq(e) != seq(parent) + rebuilt(parent) --, which one
+ * thread used to evaluate in list order over every entity3d (1 M entities: 45-50 ms).  Here: pass A copies the four values it
+ * needs out of every batched entity (on the workers), pass B walks each entity's chain over that compact array until it
+ * meets a decided ancestor (states are written once with the same value by whoever gets there first), and the result is a
+ * mask by slot of the NEW layout -- which frame_results() takes in place of the device's, write-back on the workers, hooks
+ * and bounding-volume pick merged in list order, exactly as after a frame whose layout stood.
+ */
+#define HF_NONE 0xffffffffu
+struct hf_ctx { struct gpu_scene *gs; uint32_t n_slots; };
+static void hf_collect_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct hf_ctx *hc = ctx;
+    struct gpu_scene *gs = hc->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        struct gs_hf *h = &gs->hf[k];
+        if (k + 8 < hi) prefetch_entity(gs->rec[gs->order[k + 8]].e);
+        h->state = 1; h->dirty = 0; h->ppos = HF_NONE; h->seq0 = h->pseq = 0;
+        if (r->gone || (r->cls != 1 && r->cls != 4)) continue;
+        const entity3d *e = r->e;
+        r->slot = clapgpu_scene_entity_slot(gs->scene, r->handle);
+        if (r->slot != CLAPGPU_NO_ENTITY) seq_shown(gs, r->slot, e->seq);    /* (rebuilt ones are shown their new seq by the write-back) */
+        if (r->cls == 4) continue;                               /* after the pose, from the second launch: gpu_scene_run_deferred() */
+        r->host_done = 0;                                        /* the host fields decide here: a host-updated entity is simply not dirty */
+        h->seq0 = e->seq; h->pseq = e->parent_seq; h->dirty = r->xform_dirty;
+        h->state = 0;
+        if (r->slot == CLAPGPU_NO_ENTITY || r->slot >= hc->n_slots) { h->state = 1; continue; }   /* (cannot be: the mirror holds every batched entity) */
+        if (h->dirty) h->state = 2;
+        else if (!e->parent) h->state = 1;
+        else if (r->parent_rec != NO_REC && gs->rec[r->parent_rec].e == e->parent && gs->rec[r->parent_rec].gen == gs->gen)
+            h->ppos = gs->rec[r->parent_rec].order_pos;          /* a batched entity's parent is batched and comes earlier (the class rules) */
+        else
+            h->state = e->parent_seq != e->parent->seq ? 2 : 1;  /* (cannot be either; by the parent as it stands) */
+    }
+}
+
+static uint8_t hf_decide(struct gs_hf *hf, uint32_t k)
+{
+    uint32_t chain[64], n = 0, cur = k;
+    uint8_t s;
+    for (;;) {
+        s = __atomic_load_n(&hf[cur].state, __ATOMIC_RELAXED);
+        if (s) break;
+        if (n == 64) { s = hf_decide(hf, cur); break; }           /* a chain deeper than the stack here: in pieces */
+        chain[n++] = cur;
+        cur = hf[cur].ppos;
+    }
+    while (n) {
+        const uint32_t c = chain[--n];
+        s = hf[c].pseq != (uint16_t)(hf[hf[c].ppos].seq0 + (s == 2)) ? 2 : 1;
+        __atomic_store_n(&hf[c].state, s, __ATOMIC_RELAXED);
+    }
+    return s;
+}
+
+static void hf_decide_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct hf_ctx *hc = ctx;
+    struct gpu_scene *gs = hc->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        if (hf_decide(gs->hf, k) != 2) continue;
+        const uint32_t slot = gs->rec[gs->order[k]].slot;
+        __atomic_fetch_or(&gs->hf_mask[slot >> 6], 1ull << (slot & 63), __ATOMIC_RELAXED);
+    }
+}
+
+static bool retile_by_mask(void)
+{
+    static int on = -1;
+    if (on < 0) { const char *v = getenv("GPU_SCENE_RETILE_BY_MASK"); on = v ? atoi(v) != 0 : 1; }   /* A/B switch: 0 = the serial pass */
+    return on;
+}
+
+static int by_host_fields(struct gpu_scene *gs, clapgpu_scene_arrays *res)
+{
+    if (gs->n_order > gs->cap_hf) {
+        struct gs_hf *q = realloc(gs->hf, (size_t)gs->cap_order * sizeof(*q));
+        if (!q) return _CERR_NOMEM;
+        gs->hf = q; gs->cap_hf = gs->cap_order;
+    }
+    const uint32_t words = res->n_slots / 64;
+    if (words > gs->cap_hf_mask) {
+        uint64_t *q = realloc(gs->hf_mask, (size_t)words * 8);
+        if (!q) return _CERR_NOMEM;
+        gs->hf_mask = q; gs->cap_hf_mask = words;
+    }
+    memset(gs->hf_mask, 0, (size_t)words * 8);
+    struct hf_ctx hc = { gs, res->n_slots };
+    const int nt = gs->n_order >= 8192 ? par_threads() : 1;
+    gpu_scene_par_for(hf_collect_range, &hc, gs->n_order, nt);
+    gpu_scene_par_for(hf_decide_range, &hc, gs->n_order, nt);
+    res->rebuilt_mask = gs->hf_mask;
+    res->exported_mask = NULL;                                   /* (a walked frame exports everything) */
+    return 0;
+}
+
+/* What a walk leaves behind for the frames that are not walked, from the records, on the workers: the verdict table in list
+ * order, which batched parents a host-class child reads, which entities are standing readers under GPU_SCATTER_DRAWN. */
+struct walk_tail_ctx { struct gpu_scene *gs; struct scene *scene; uint32_t n_changes; };
+static void tail_verdicts_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct gpu_scene *gs = ((struct walk_tail_ctx *)ctx)->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
+        r->host_child = 0;
+    }
+}
+
+static void tail_host_child_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct gpu_scene *gs = ((struct walk_tail_ctx *)ctx)->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if ((r->cls != 2 && r->cls != 3) || !r->e->parent) continue;
+        const uint32_t pr = rec_find(gs, r->e->parent);
+        if (pr != NO_REC) __atomic_store_n(&gs->rec[pr].host_child, 1, __ATOMIC_RELAXED);   /* (several children, one value) */
+    }
+}
+
+static void tail_keep_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct walk_tail_ctx *tc = ctx;
+    struct gpu_scene *gs = tc->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        if ((r->cls != 1 && r->cls != 4) || r->handle == CLAPGPU_NO_ENTITY) continue;
+        const uint8_t keep = r->user_keep || r->host_child || r->keep_auto || (tc->scene && r->e == tc->scene->control);   /* (the records alone: keep_auto was taken while the entity was at hand) */
+        if (keep != r->keep) gs->keep_changes[__atomic_fetch_add(&tc->n_changes, 1, __ATOMIC_RELAXED)] = gs->order[k];
+    }
+}
+
 static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *view);
 
 int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
@@ -2511,9 +2682,17 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         const int rc = frame_results(gs, mq, &res, t0, t2, t3);
         if (rc) return rc;
         st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
+    } else if (res.n_slots && retile_by_mask()) {
+        /* 5, after a re-tile (the device rebuilt EVERYTHING; the host fields say what the reference would have): the same second
+         * half, over a mask made from the host fields on the workers */
+        clapgpu_scene_arrays hres = res;
+        CK(by_host_fields(gs, &hres));
+        const int rc = frame_results(gs, mq, &hres, t0, t2, t3);
+        if (rc) return rc;
+        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
     } else {
-    /* 5, after a re-tile (the device rebuilt EVERYTHING; the host fields say what the reference would have): results and
-     * host hooks, list order */
+    /* 5, the same on one thread in list order (GPU_SCENE_RETILE_BY_MASK=0, and a queue with nothing batched): results and
+     * host hooks */
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
         e = r->e;
@@ -2579,30 +2758,27 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         if (!ve || !vs || !vo) return _CERR_NOMEM;
         gs->cap_vq = cap;
     }
-    for (uint32_t k = 0; k < gs->n_order; k++) {
-        const struct gs_rec *r = &gs->rec[gs->order[k]];
-        gs->vq_e[k] = r->e; gs->vq_slot[k] = r->slot; gs->vq_ok[k] = verdict_ok(r) && r->slot != CLAPGPU_NO_ENTITY;
-    }
+    struct walk_tail_ctx tc = { gs, scene, 0 };
+    const int tail_threads = gs->n_order >= GS_TABLES_PAR_MIN ? par_threads() : 1;
+    gpu_scene_par_for(tail_verdicts_range, &tc, gs->n_order, tail_threads);
     if (gs->notify && ftab_build(gs)) gs->n_xptr = 0;            /* without the table gpu_scene_touch_xform takes the checked path */
     slot_arrays_build(gs);                                       /* on failure the draw list goes through the records */
     /* GPU_SCATTER_DRAWN: the standing host readers (gpu-scene.h).  A host-class entity's hook reads its parent's mx / seq
      * (parent_transform_apply, model.c:1609-1641) -- also when that parent comes later in the list (lag_parent) */
-    if (gs->notify) {                                            /* (also: such a parent cannot be taken out of the layout in place) */
-        for (uint32_t k = 0; k < gs->n_order; k++) gs->rec[gs->order[k]].host_child = 0;
-        for (uint32_t k = 0; k < gs->n_order; k++) {
-            const struct gs_rec *r = &gs->rec[gs->order[k]];
-            if ((r->cls != 2 && r->cls != 3) || !r->e->parent) continue;
-            const uint32_t pr = rec_find(gs, r->e->parent);
-            if (pr != NO_REC) gs->rec[pr].host_child = 1;
-        }
-    }
+    if (gs->notify)                                              /* (also: such a parent cannot be taken out of the layout in place) */
+        gpu_scene_par_for(tail_host_child_range, &tc, gs->n_order, tail_threads);
     if (gs->scatter_drawn && gs->notify) {
         gs->last_control = scene ? scene->control : NULL;
-        for (uint32_t k = 0; k < gs->n_order; k++) {
-            struct gs_rec *r = &gs->rec[gs->order[k]];
-            if ((r->cls != 1 && r->cls != 4) || r->handle == CLAPGPU_NO_ENTITY) continue;
-            const uint8_t keep = r->user_keep || r->host_child || r->keep_auto || (scene && r->e == scene->control);   /* (the records alone: keep_auto was taken while the entity was at hand) */
-            if (keep != r->keep && !clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
+        if (gs->n_order > gs->cap_keep_changes) {
+            uint32_t *q = realloc(gs->keep_changes, (size_t)gs->cap_order * sizeof(*q));
+            if (!q) return _CERR_NOMEM;
+            gs->keep_changes = q; gs->cap_keep_changes = gs->cap_order;
+        }
+        gpu_scene_par_for(tail_keep_range, &tc, gs->n_order, tail_threads);
+        for (uint32_t c = 0; c < tc.n_changes; c++) {            /* the mirror's own bookkeeping: on this thread */
+            struct gs_rec *r = &gs->rec[gs->keep_changes[c]];
+            const uint8_t keep = !r->keep;
+            if (!clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
         }
     }
     gs->walked = true;

@@ -134,6 +134,9 @@ struct clapgpu_scene {
     clapgpu_views xv; uint32_t xv_want, xv_cap_slots; int xv_mapped;
     uint64_t   *h_xv_mask[CLAPGPU_EXTRA_VIEWS_MAX]; void *a_xv_mask[CLAPGPU_EXTRA_VIEWS_MAX];
     uint64_t   *h_xv_union;
+
+    /* a caller's thread pool for the re-tile's passes over every handle / slot (clapgpu_scene_set_parallel_for) */
+    clapgpu_scene_parallel_for par_for; int par_threads;
 };
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -540,6 +543,20 @@ int clapgpu_scene_entity_set_parent(clapgpu_scene *s, uint32_t handle, uint32_t 
  * below, out of capacity, a layout that is not the one-launch tile form): the caller then uses the plain verbs and the next
  * mq_update re-tiles.  The device is told with the next mq_update (the new lanes' inputs through the touched bits like any
  * moved entity's, parent / model indices by a small copy): until then results for such an entity are not defined. */
+void clapgpu_scene_set_parallel_for(clapgpu_scene *s, clapgpu_scene_parallel_for fn, int threads)
+{
+    if (!s) return;
+    s->par_for = threads > 1 ? fn : NULL;
+    s->par_threads = threads;
+}
+
+/* a pass over [0, n) on the caller's pool, or right here */
+static void run_ranges(const clapgpu_scene *s, void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n)
+{
+    if (s->par_for && n >= 16384) s->par_for(fn, ctx, n, s->par_threads);
+    else fn(ctx, 0, n);
+}
+
 void clapgpu_scene_set_incremental(clapgpu_scene *s, int on)
 {
     if (s) s->incremental = on != 0;                     /* from the next re-tile on */
@@ -1006,38 +1023,93 @@ static int ensure_slots(clapgpu_scene *s, uint32_t n_slots)
     return CLAPGPU_OK;
 }
 
-/* depth of every live entity under its root; returns max depth + 1, or 0 on a parent cycle */
-static uint32_t compute_depths(clapgpu_scene *s, uint32_t *depth, uint32_t *root)
+/* depth of every live entity under its root; returns max depth + 1, or 0 on a parent cycle.  Each range walks up from its
+ * handles to the first ancestor whose depth is known and assigns the chain; ranges that meet on a chain write the same values
+ * (root before depth, depth with release: whoever reads a depth finds its root). */
+#define DEPTH_UNK 0xffffffffu
+struct depth_ctx { clapgpu_scene *s; uint32_t *depth, *root; uint32_t maxd; int cycle; };
+static void depths_range(void *ctx, uint32_t lo, uint32_t hi)
 {
-    const uint32_t UNK = 0xffffffffu;
-    uint32_t maxd = 0;
-    for (uint32_t h = 0; h < s->n_handles; h++) depth[h] = UNK;
-    for (uint32_t h = 0; h < s->n_handles; h++) {
-        if (!s->e[h].live || depth[h] != UNK) continue;
-        uint32_t cur = h, steps = 0;                    /* walk up to a known ancestor */
-        while (s->e[cur].parent != CLAPGPU_NO_ENTITY && depth[s->e[cur].parent] == UNK) {
+    struct depth_ctx *dc = ctx;
+    clapgpu_scene *s = dc->s;
+    uint32_t *depth = dc->depth, *root = dc->root, maxd = 0;
+    for (uint32_t h = lo; h < hi; h++) {
+        if (!s->e[h].live || __atomic_load_n(&depth[h], __ATOMIC_ACQUIRE) != DEPTH_UNK) continue;
+        uint32_t cur = h, len = 0;                       /* walk up to a known ancestor (or the root) */
+        while (s->e[cur].parent != CLAPGPU_NO_ENTITY && __atomic_load_n(&depth[s->e[cur].parent], __ATOMIC_ACQUIRE) == DEPTH_UNK) {
             cur = s->e[cur].parent;
-            if (++steps > s->n_handles) return 0;
+            if (++len > s->n_handles) { __atomic_store_n(&dc->cycle, 1, __ATOMIC_RELAXED); return; }
         }
         uint32_t base_d, base_r;
         if (s->e[cur].parent == CLAPGPU_NO_ENTITY) { base_d = 0; base_r = cur; }
-        else { base_d = depth[s->e[cur].parent] + 1; base_r = root[s->e[cur].parent]; }
-        /* second walk: assign from h upward needs distances; count chain length first */
-        uint32_t len = 0;
-        for (uint32_t x = h; x != cur; x = s->e[x].parent) len++;
+        else { base_d = __atomic_load_n(&depth[s->e[cur].parent], __ATOMIC_ACQUIRE) + 1; base_r = __atomic_load_n(&root[s->e[cur].parent], __ATOMIC_RELAXED); }
         uint32_t x = h;
         for (uint32_t k = 0; k <= len; k++) {
-            depth[x] = base_d + (len - k);
-            root[x] = base_r;
-            if (depth[x] + 1 > maxd) maxd = depth[x] + 1;
+            const uint32_t d = base_d + (len - k);
+            __atomic_store_n(&root[x], base_r, __ATOMIC_RELAXED);
+            __atomic_store_n(&depth[x], d, __ATOMIC_RELEASE);
+            if (d + 1 > maxd) maxd = d + 1;
             x = s->e[x].parent;
         }
     }
-    return maxd ? maxd : 1;
+    uint32_t seen = __atomic_load_n(&dc->maxd, __ATOMIC_RELAXED);
+    while (maxd > seen && !__atomic_compare_exchange_n(&dc->maxd, &seen, maxd, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+}
+
+static uint32_t compute_depths(clapgpu_scene *s, uint32_t *depth, uint32_t *root)
+{
+    memset(depth, 0xff, (size_t)s->n_handles * 4);
+    struct depth_ctx dc = { s, depth, root, 0, 0 };
+    run_ranges(s, depths_range, &dc, s->n_handles);
+    if (dc.cycle) return 0;
+    return dc.maxd ? dc.maxd : 1;
+}
+
+/* the re-tile's other passes over every handle / slot */
+struct retile_ctx {
+    clapgpu_scene *s; const uint32_t *depth, *root, *tree_of; uint32_t *width; uint32_t maxd; int wide;
+};
+static void widths_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct retile_ctx *rc = ctx;
+    const clapgpu_scene *s = rc->s;
+    for (uint32_t h = lo; h < hi; h++)
+        if (s->e[h].live) {
+            const uint32_t t = rc->tree_of[rc->root[h]];
+            if (__atomic_add_fetch(&rc->width[(size_t)t * rc->maxd + rc->depth[h]], 1, __ATOMIC_RELAXED) > WAVE)
+                __atomic_store_n(&rc->wide, 1, __ATOMIC_RELAXED);
+        }
+}
+
+static void image_range(void *ctx, uint32_t lo, uint32_t hi)      /* in units of 64 slots: a range owns its words of h_keep */
+{
+    struct retile_ctx *rc = ctx;
+    clapgpu_scene *s = rc->s;
+    for (uint32_t i = lo * WAVE; i < hi * WAVE; i++) {
+        const uint32_t h = s->slot_handle[i];
+        s->slot_user[i] = h == CLAPGPU_NO_ENTITY ? NULL : s->e[h].user;
+        if (h != CLAPGPU_NO_ENTITY && s->e[h].keep) s->h_keep[i >> 6] |= 1ull << (i & 63);
+        if (h == CLAPGPU_NO_ENTITY) {
+            const float id[4] = { 0, 0, 0, 1 };
+            memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
+            memcpy(s->h_rot + 4 * (size_t)i, id, 16);
+            s->h_parent[i] = -1; s->h_model[i] = 0; s->h_flags[i] = 0;
+            continue;
+        }
+        const struct ent *e = &s->e[h];
+        memcpy(s->h_pos_scale + 4 * (size_t)i, e->pos_scale, 16);
+        memcpy(s->h_rot + 4 * (size_t)i, e->rot, 16);
+        s->h_parent[i] = e->parent == CLAPGPU_NO_ENTITY ? -1 : (int32_t)s->e[e->parent].slot;
+        s->h_model[i] = (int32_t)e->model;
+        s->h_flags[i] = img_flags(e, 1);                             /* everything is rebuilt after a re-tile */
+    }
 }
 
 static int retile(clapgpu_scene *s)
 {
+    const int timing = getenv("CLAPGPU_SCENE_TIMING") != NULL;
+    double tp[8] = { 0 };
+    tp[0] = timing ? scene_now_us() : 0;
     CK(release_dead(s));
     if (s->h_in)                                         /* tombstones of in-place deletions: the whole image follows anyway */
         for (uint32_t k = 0; k < s->n_raw; k++) s->h_touched[s->raw_words[k]] = 0;
@@ -1047,18 +1119,16 @@ static int retile(clapgpu_scene *s)
     if (!depth || !root || !tree_of) return CLAPGPU_ERR_NOMEM;
     uint32_t maxd = compute_depths(s, depth, root);
     if (!maxd) { free(depth); free(root); free(tree_of); return CLAPGPU_ERR_INVALID_ARGUMENTS; }
+    if (timing) tp[1] = scene_now_us();
 
     uint32_t n_trees = 0, n_live = 0;
     for (uint32_t h = 0; h < H; h++)
         if (s->e[h].live) { n_live++; if (s->e[h].parent == CLAPGPU_NO_ENTITY) tree_of[h] = n_trees++; }
     uint32_t *width = calloc((size_t)(n_trees ? n_trees : 1) * maxd, 4);
     if (!width) return CLAPGPU_ERR_NOMEM;
-    int tiled = 1;
-    for (uint32_t h = 0; h < H; h++)
-        if (s->e[h].live) {
-            uint32_t t = tree_of[root[h]];
-            if (++width[(size_t)t * maxd + depth[h]] > WAVE) tiled = 0;
-        }
+    struct retile_ctx rtc = { s, depth, root, tree_of, width, maxd, 0 };
+    run_ranges(s, widths_range, &rtc, H);
+    int tiled = !rtc.wide;
 
     uint32_t n_rows = 0;
     uint32_t *row_of_tree = malloc(((size_t)n_trees + 1) * 4);       /* first row of the tree's tile */
@@ -1111,6 +1181,7 @@ static int retile(clapgpu_scene *s)
         free(cnt);
     }
     if (n_rows == 0) n_rows = 1;
+    if (timing) tp[2] = scene_now_us();
     int rc = ensure_slots(s, n_rows * WAVE);
     if (rc) return rc;
     s->n_rows = n_rows;
@@ -1119,8 +1190,9 @@ static int retile(clapgpu_scene *s)
     if (!tiled) s->level_start_host[s->n_levels] = s->n_slots;      /* the kernel wants the last start == n */
 
     /* slots: handle order inside each row */
+    if (timing) tp[3] = scene_now_us();
     row_fill = calloc(n_rows, 4);
-    for (uint32_t i = 0; i < s->n_slots; i++) s->slot_handle[i] = CLAPGPU_NO_ENTITY;
+    memset(s->slot_handle, 0xff, (size_t)s->n_slots * 4);          /* CLAPGPU_NO_ENTITY */
     for (uint32_t h = 0; h < H; h++) {
         if (!s->e[h].live) continue;
         uint32_t row;
@@ -1136,31 +1208,16 @@ static int retile(clapgpu_scene *s)
     }
     /* the slots moved: what was stale under the old layout is rebuilt (and exported or marked stale again) by the launch
      * that follows; the standing readers' bits are laid out anew */
+    if (timing) tp[4] = scene_now_us();
     memset(s->h_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     CK(clapgpu_memset(s->d_stale, 0, ((size_t)s->cap_slots / 64 + 2) * 8, NULL));
     memset(s->h_fetched, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     memset(s->h_keep, 0, ((size_t)s->cap_slots / 64 + 2) * 8);
     s->n_stale_words = 0; s->n_fetched = 0; s->keep_dirty = 1;
     /* full staging image */
-    for (uint32_t i = 0; i < s->n_slots; i++) {
-        const uint32_t h = s->slot_handle[i];
-        s->slot_user[i] = h == CLAPGPU_NO_ENTITY ? NULL : s->e[h].user;
-        if (h != CLAPGPU_NO_ENTITY && s->e[h].keep) s->h_keep[i >> 6] |= 1ull << (i & 63);
-        if (h == CLAPGPU_NO_ENTITY) {
-            const float id[4] = { 0, 0, 0, 1 };
-            memcpy(s->h_pos_scale + 4 * (size_t)i, id, 16);
-            memcpy(s->h_rot + 4 * (size_t)i, id, 16);
-            s->h_parent[i] = -1; s->h_model[i] = 0; s->h_flags[i] = 0;
-            continue;
-        }
-        const struct ent *e = &s->e[h];
-        memcpy(s->h_pos_scale + 4 * (size_t)i, e->pos_scale, 16);
-        memcpy(s->h_rot + 4 * (size_t)i, e->rot, 16);
-        s->h_parent[i] = e->parent == CLAPGPU_NO_ENTITY ? -1 : (int32_t)s->e[e->parent].slot;
-        s->h_model[i] = (int32_t)e->model;
-        s->h_flags[i] = img_flags(e, 1);                             /* everything is rebuilt after a re-tile */
-    }
+    run_ranges(s, image_range, &rtc, s->n_slots / WAVE);
     free(depth); free(root); free(tree_of); free(width); free(row_of_tree); free(row_fill);
+    if (timing) tp[5] = scene_now_us();
 
     s->d.n = s->n_slots;
     const size_t n = s->n_slots;
@@ -1180,6 +1237,9 @@ static int retile(clapgpu_scene *s)
     s->topology_dirty = 0;
     s->up_lo = 0xffffffffu; s->up_hi = 0;
     s->layout_gen++;
+    if (timing)
+        fprintf(stderr, "retile: %u handles -> %u slots: dead %.0f us, depths %.0f, trees + packing %.0f, slabs %.0f, slots %.0f, image %.0f, uploads %.0f\n",
+                H, s->n_slots, 0.0, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], scene_now_us() - tp[5]);
     return CLAPGPU_OK;
 }
 

@@ -60,6 +60,16 @@ int  clapgpu_scene_entity_delete(clapgpu_scene *s, uint32_t handle);
  * clapgpu_scene_set_incremental(s, 1) makes re-tiles leave room for such edits (an eighth of every row's lanes, one spare row
  * per tile of a hierarchy).  The edits reach the device with the next mq_update. */
 void clapgpu_scene_set_incremental(clapgpu_scene *s, int on);
+
+/*
+ * A re-tile (any frame after clapgpu_scene_entity_new / _delete / _set_parent that could not be placed in the standing
+ * layout) walks every handle and every slot several times: depths, tree widths, the upload image.  The mirror owns no
+ * threads; a caller that has a pool lends it here -- `fn(range, ctx, n, threads)` must call range(ctx, lo, hi) over a
+ * partition of [0, n) and return when all of them have (gpu-scene.c passes gpu_scene_par_for).  NULL / threads < 2: on the
+ * calling thread.  The layout does not depend on it (same slots either way).
+ */
+typedef void (*clapgpu_scene_parallel_for)(void (*range)(void *ctx, uint32_t lo, uint32_t hi), void *ctx, uint32_t n, int threads);
+void clapgpu_scene_set_parallel_for(clapgpu_scene *s, clapgpu_scene_parallel_for fn, int threads);
 int  clapgpu_scene_entity_new_placed(clapgpu_scene *s, uint32_t model, void *user, uint32_t parent, uint32_t *handle, uint32_t *slot);
 int  clapgpu_scene_entity_delete_placed(clapgpu_scene *s, uint32_t handle);
 /* e->parent = p (jointless attachment, model.h:386-402); CLAPGPU_NO_ENTITY detaches */
