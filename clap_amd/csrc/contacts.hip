@@ -134,6 +134,83 @@ __device__ __forceinline__ uint32_t contacts_chunk(const GeomsK &A, const GeomsK
     return counted;
 }
 
+// ---- the one-launch form's loop: a wavefront takes several chunks, and a chunk's inputs are asked for while the chunk
+// before it is still being worked on (the chain per chunk is pair -> two geoms + two flag words -> arithmetic -> record;
+// measured: a wavefront of the one-chunk-per-wavefront kernel lives ~17 us, two thirds of it waiting, and the kernel is
+// two such rounds).  The next chunk's PAIR is requested before this chunk's arithmetic; the flag words come with the geoms.
+// (The next chunk's geoms as well, under this chunk's stores: 224 VGPRs and 152 bytes of scratch -- not kept.)
+struct PairInputs { uint2 pr; bool live; phd::Geom ga, gb; uint32_t fa, fb; };
+
+__device__ __forceinline__ void load_pair_inputs(const GeomsK &A, const GeomsK &B, uint2 pr, bool in_range, uint32_t *flags_a,
+                                                 uint32_t *flags_b, PairInputs &in)
+{
+    in.pr = pr;
+    in.live = in_range && pr.x < A.n && pr.y < B.n;
+    in.fa = in.fb = CLAPGPU_BODY_HAS_JOINT;
+    if (in.live) {
+        load_geom(A, pr.x, in.ga);
+        load_geom(B, pr.y, in.gb);
+        // the flag words early: every writer of this launch sets the same bit and nothing else changes the words
+        if (flags_a) in.fa = flags_a[pr.x];
+        if (flags_b) in.fb = flags_b[pr.y];
+    }
+}
+
+__device__ __forceinline__ uint32_t contact_from_inputs(const GeomsK &A, const GeomsK &B, const PairInputs &in, clapgpu_contact2 &c,
+                                                        uint32_t *flags_a, uint32_t *flags_b)
+{
+    if (!in.live) return 0;
+    phd::CGeom c0, c1;
+    memset(&c0, 0, sizeof(c0));
+    memset(&c1, 0, sizeof(c1));
+    const int nc = phd::collide(in.ga, in.gb, c0, c1);
+    if (nc < 0) { c.nc = CLAPGPU_CONTACT_DEEP; return 1; }
+    if (nc == 0) return 0;
+    for (int a = 0; a < 3; a++) { c.pos[a] = c0.pos[a]; c.normal[a] = c0.normal[a]; }
+    c.depth = c0.depth;
+    if (nc > 1) {
+        for (int a = 0; a < 3; a++) { c.pos2[a] = c1.pos[a]; c.normal2[a] = c1.normal[a]; }
+        c.depth2 = c1.depth;
+    }
+    contact_surface2(c, (A.material && B.material) ? A.material + 5 * (size_t)in.pr.x : nullptr,
+                     (A.material && B.material) ? B.material + 5 * (size_t)in.pr.y : nullptr);
+    c.nc = (uint32_t)nc;
+    if (flags_a && !(in.fa & CLAPGPU_BODY_HAS_JOINT)) flags_a[in.pr.x] = in.fa | CLAPGPU_BODY_HAS_JOINT;
+    if (flags_b && !(in.fb & CLAPGPU_BODY_HAS_JOINT)) flags_b[in.pr.y] = in.fb | CLAPGPU_BODY_HAS_JOINT;
+    return 1;
+}
+
+// a chunk's 64 records through the wave-private tile and out as ten 1 KiB stores (see contacts_chunk)
+__device__ __forceinline__ void store_chunk(const clapgpu_contact2 &c, clapgpu_contact2 *out, uint32_t p0, uint32_t np, uint4 *tile)
+{
+    const int lane = lane_id();
+    uint4 v[10];
+    memcpy(v, &c, sizeof(c));
+#pragma unroll
+    for (int k = 0; k < 10; k++) tile[lane * CONTACT_ROW + k] = v[k];
+    wave_lds_fence();
+    const uint32_t pieces = (np - p0 < (uint32_t)WAVE ? np - p0 : (uint32_t)WAVE) * 10u;
+    uint4 *o = reinterpret_cast<uint4 *>(out + p0);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        const uint32_t idx = (uint32_t)(k * WAVE + lane);
+        if (idx < pieces) o[idx] = tile[(idx / 10u) * CONTACT_ROW + idx % 10u];
+    }
+    wave_lds_fence();
+}
+
+__device__ __forceinline__ uint32_t chunk_from_pair(const GeomsK &A, const GeomsK &B, uint2 pr, bool in_range, uint32_t p0, uint32_t np,
+                                                     clapgpu_contact2 *out, uint32_t *flags_a, uint32_t *flags_b, uint4 *tile)
+{
+    PairInputs in;
+    load_pair_inputs(A, B, pr, in_range, flags_a, flags_b, in);
+    clapgpu_contact2 c;
+    memset(&c, 0, sizeof(c));
+    const uint32_t counted = contact_from_inputs(A, B, in, c, flags_a, flags_b);
+    store_chunk(c, out, p0, np, tile);
+    return counted;
+}
+
 __global__ __launch_bounds__(PB)
 void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity,
                       clapgpu_contact2 *out, uint32_t *contact_total, uint32_t *flags_a, uint32_t *flags_b)
@@ -158,7 +235,7 @@ void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pa
 // without a cleared counter in front of it: a workgroup adds (1, its static count, its body count) to ONE 64-bit word with one
 // atomic; the workgroup that finds every other ticket already taken holds the totals in what came back, stores them and
 // leaves the word at zero for the next launch.  Two launches and two counter fills were 62 us of a frame for 47 us of work.
-__global__ __launch_bounds__(PB)
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(3, 3)))   // three wavefronts a SIMD: what the LDS tile allows
 void k_contacts_geoms_both(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity,
                            clapgpu_contact2 *out, uint32_t *contact_total, const uint2 *spairs, const uint32_t *spair_total,
                            uint32_t scapacity, clapgpu_contact2 *sout, uint32_t *scontact_total, uint32_t *flags,
@@ -172,11 +249,29 @@ void k_contacts_geoms_both(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_
     if (nb > capacity) nb = capacity;
     if (ns > scapacity) ns = scapacity;
     uint32_t mine_b = 0, mine_s = 0;
-    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // in an SGPR: what is selected by chunk is scalar
     const uint32_t cb = (nb + WAVE - 1) / WAVE, cs = (ns + WAVE - 1) / WAVE;   // 64-pair chunks: the bodies' list, then the statics'
-    for (uint32_t ch = blockIdx.x * (PB / WAVE) + wave; ch < cb + cs; ch += gridDim.x * (PB / WAVE)) {   // wave-uniform
-        if (ch < cb) mine_b += contacts_chunk(A, A, pairs, ch * WAVE, nb, out, flags, flags, tile[wave]);
-        else mine_s += contacts_chunk(A, B, spairs, (ch - cb) * WAVE, ns, sout, flags, nullptr, tile[wave]);
+    const int lane = lane_id();
+    const uint32_t stride = gridDim.x * (PB / WAVE);
+    // the pair a lane takes from chunk `c` (wave-uniform choice of list: the bodies', then the statics')
+    auto pair_of = [&](uint32_t c, uint2 &pr) {
+        const uint2 *list = c < cb ? pairs : spairs;
+        const uint32_t p = (c < cb ? c : c - cb) * WAVE + lane, n = c < cb ? nb : ns;
+        pr = make_uint2(0, 0);
+        if (p < n) pr = list[p];
+        return p < n;
+    };
+    uint32_t ch = blockIdx.x * (PB / WAVE) + wave;
+    uint2 pr = make_uint2(0, 0);
+    bool pin = ch < cb + cs && pair_of(ch, pr);
+    while (ch < cb + cs) {
+        const uint2 cur_pr = pr;
+        const bool cur_in = pin;
+        const uint32_t next = ch + stride;
+        if (next < cb + cs) pin = pair_of(next, pr);                     // the next chunk's pair: under this chunk's geoms and arithmetic
+        if (ch < cb) mine_b += chunk_from_pair(A, A, cur_pr, cur_in, ch * WAVE, nb, out, flags, flags, tile[wave]);
+        else mine_s += chunk_from_pair(A, B, cur_pr, cur_in, (ch - cb) * WAVE, ns, sout, flags, nullptr, tile[wave]);
+        ch = next;
     }
     for (int o = 32; o > 0; o >>= 1) { mine_b += __shfl_xor(mine_b, o); mine_s += __shfl_xor(mine_s, o); }
     if (lane_id() == 0) {
@@ -360,7 +455,17 @@ extern "C" int clapgpu_contacts_geoms_both(void *stream, clapgpu_bp *bp, const c
         return CLAPGPU_OK;
     }
     const uint32_t blocks = (capacity + static_capacity + PB - 1) / PB;
-    hipLaunchKernelGGL(k_contacts_geoms_both, dim3(blocks < 2048 ? blocks : 2048), dim3(PB), 0, s, geoms_k(bodies), geoms_k(statics),
+    // as many workgroups as are resident at once: a wavefront then walks its chunks with the next one's inputs in flight
+    static uint32_t resident;
+    if (!resident) {
+        int per_cu = 0, cus = 0, dev = 0;
+        CLAPGPU_HIP(hipGetDevice(&dev));
+        CLAPGPU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        CLAPGPU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_contacts_geoms_both, PB, 0));
+        const char *g = getenv("CLAPGPU_CONTACTS_GRID");                  // tuning knob (workgroups)
+        resident = g && atoi(g) > 0 ? (uint32_t)atoi(g) : (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+    }
+    hipLaunchKernelGGL(k_contacts_geoms_both, dim3(blocks < resident ? blocks : resident), dim3(PB), 0, s, geoms_k(bodies), geoms_k(statics),
                        reinterpret_cast<const uint2 *>(pairs), pair_total, capacity, contacts, contact_total,
                        reinterpret_cast<const uint2 *>(static_pairs), static_pair_total, statics->n ? static_capacity : 0u,
                        static_contacts, static_contact_total, body_flags,
