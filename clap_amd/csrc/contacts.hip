@@ -414,16 +414,21 @@ static GeomsK geoms_k(const clapgpu_geoms *g)
     return k;
 }
 
-// workgroups of PB threads of `kernel` that fit the device at once (CLAPGPU_CONTACTS_GRID: tuning knob)
-static uint32_t resident_workgroups(const void *kernel)
+// workgroups of PB threads of `kernel` that fit the device at once (`cached`: per kernel, asked once).
+// CLAPGPU_CONTACTS_GRID, read at every call, overrides it: the A/B knob, and how the tests make every wavefront walk many chunks
+static uint32_t resident_workgroups(const void *kernel, uint32_t *cached)
 {
-    int per_cu = 0, cus = 0, dev = 0;
     const char *g = getenv("CLAPGPU_CONTACTS_GRID");
     if (g && atoi(g) > 0) return (uint32_t)atoi(g);
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PB, 0) != hipSuccess)
-        return 2048;
-    return (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+    if (!*cached) {
+        int per_cu = 0, cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PB, 0) != hipSuccess)
+            *cached = 2048;
+        else
+            *cached = (uint32_t)(per_cu > 0 ? per_cu : 1) * (uint32_t)(cus > 0 ? cus : 1);
+    }
+    return *cached;
 }
 
 extern "C" int clapgpu_contacts_geoms(void *stream, const clapgpu_geoms *A, const clapgpu_geoms *B, const uint32_t *pairs,
@@ -440,8 +445,8 @@ extern "C" int clapgpu_contacts_geoms(void *stream, const clapgpu_geoms *A, cons
     if (capacity == 0 || A->n == 0 || B->n == 0)
         return CLAPGPU_OK;
     const uint32_t blocks = (capacity + PB - 1) / PB;
-    static uint32_t resident;                                            // (see clapgpu_contacts_geoms_both)
-    if (!resident) resident = resident_workgroups(reinterpret_cast<const void *>(k_contacts_geoms));
+    static uint32_t cached;                                              // (see clapgpu_contacts_geoms_both)
+    const uint32_t resident = resident_workgroups(reinterpret_cast<const void *>(k_contacts_geoms), &cached);
     hipLaunchKernelGGL(k_contacts_geoms, dim3(blocks < resident ? blocks : resident), dim3(PB), 0, s, geoms_k(A), geoms_k(B),
                        reinterpret_cast<const uint2 *>(pairs), pair_total, capacity, contacts, contact_total, body_flags_a,
                        body_flags_b);
@@ -470,8 +475,8 @@ extern "C" int clapgpu_contacts_geoms_both(void *stream, clapgpu_bp *bp, const c
     }
     const uint32_t blocks = (capacity + static_capacity + PB - 1) / PB;
     // as many workgroups as are resident at once: a wavefront then walks its chunks with the next one's inputs in flight
-    static uint32_t resident;
-    if (!resident) resident = resident_workgroups(reinterpret_cast<const void *>(k_contacts_geoms_both));
+    static uint32_t cached;
+    const uint32_t resident = resident_workgroups(reinterpret_cast<const void *>(k_contacts_geoms_both), &cached);
     hipLaunchKernelGGL(k_contacts_geoms_both, dim3(blocks < resident ? blocks : resident), dim3(PB), 0, s, geoms_k(bodies), geoms_k(statics),
                        reinterpret_cast<const uint2 *>(pairs), pair_total, capacity, contacts, contact_total,
                        reinterpret_cast<const uint2 *>(static_pairs), static_pair_total, statics->n ? static_capacity : 0u,

@@ -553,7 +553,12 @@ void clapgpu_scene_set_parallel_for(clapgpu_scene *s, clapgpu_scene_parallel_for
 /* a pass over [0, n) on the caller's pool, or right here */
 static void run_ranges(const clapgpu_scene *s, void (*fn)(void *, uint32_t, uint32_t), void *ctx, uint32_t n)
 {
-    if (s->par_for && n >= 16384) s->par_for(fn, ctx, n, s->par_threads);
+    static uint32_t par_min;
+    if (!par_min) {
+        const char *v = getenv("CLAPGPU_SCENE_PAR_MIN");         /* tuning knob; the tests set 1 */
+        par_min = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 16384u;
+    }
+    if (s->par_for && n >= par_min) s->par_for(fn, ctx, n, s->par_threads);
     else fn(ctx, 0, n);
 }
 

@@ -229,6 +229,14 @@ static int add_entity(clapgpu_scene *s, uint32_t parent_idx)
     return 0;
 }
 
+/* TEST_SCENE_PAR_FOR: the re-tile's passes as seven ranges taken BACKWARDS (clapgpu_scene_set_parallel_for): the layout, and
+ * with it every frame below, may not depend on who takes which range in what order */
+static void ranges_backwards(void (*range)(void *, uint32_t, uint32_t), void *ctx, uint32_t n, int threads)
+{
+    for (int t = threads - 1; t >= 0; t--)
+        range(ctx, (uint32_t)((uint64_t)n * (uint32_t)t / (uint32_t)threads), (uint32_t)((uint64_t)n * ((uint32_t)t + 1) / (uint32_t)threads));
+}
+
 int main(int argc, char **argv)
 {
     const int wide = argc > 1 && !strcmp(argv[1], "wide");
@@ -237,6 +245,7 @@ int main(int argc, char **argv)
     const int inplace_frames = argc > 3 ? atoi(argv[3]) : 4;
     clapgpu_scene *s;
     if (clapgpu_scene_create(&s, 0)) { fprintf(stderr, "create: %s\n", clapgpu_last_error()); return 2; }
+    if (getenv("TEST_SCENE_PAR_FOR")) { clapgpu_scene_set_parallel_for(s, ranges_backwards, 7); printf("re-tile passes as 7 ranges, backwards\n"); }
     const float a0[6] = { -1, -2, -3, 1, 2, 3 }, a1[6] = { -0.5f, -0.5f, -0.5f, 2, 1, 0.5f };
     uint32_t m0, m1;
     if (clapgpu_scene_model_new(s, a0, 0, &m0) || clapgpu_scene_model_new(s, a1, 0, &m1) || m0 != 0 || m1 != 1) return 2;

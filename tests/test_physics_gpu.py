@@ -494,6 +494,38 @@ def test_contacts_of_both_lists_in_one_launch(cuda_device):
             assert np.array_equal(oa["bflags"], oc["bflags"]), "CLAPGPU_BODY_HAS_JOINT"
 
 
+@pytest.mark.parametrize("grid", ["3", "100000"])
+def test_contact_kernels_with_few_and_many_workgroups(grid, cuda_device, monkeypatch):
+    """The contact kernels launch as many workgroups as are resident and a wavefront walks its chunks of 64 pairs with the
+    next chunk's pairs in flight; at test sizes a wavefront has one chunk.  CLAPGPU_CONTACTS_GRID (read at every call) = 3
+    workgroups makes each of twelve wavefronts walk dozens of chunks of both lists; 100 000 gives every chunk its own
+    wavefront: the same records, totals and joint flags as the restatement either way, single-list and one-launch form."""
+    from clap_amd import physics
+    monkeypatch.setenv("CLAPGPU_CONTACTS_GRID", grid)
+    n = 20_000
+    b = synth.capsule_bodies(n, box=26.0, seed=41)
+    statics = synth.static_boxes(48, 26.0)
+    two = physics.PhysWorld(b, statics, pair_capacity=16 * n, device=cuda_device)
+    one = physics.PhysWorld(b, statics, pair_capacity=16 * n, device=cuda_device)
+    for w in (two, one):
+        w.broadphase()
+    two.contacts_geoms()
+    one.contacts_geoms_both()
+    a, c = two.download_contacts2(ob.CONTACT2_DTYPE), one.download_contacts2(ob.CONTACT2_DTYPE)
+    out, out1 = two.download(), one.download()
+    st = ob.bodies_state(b)
+    ob.bodies_aabb(b, st)
+    A = _oracle_body_geoms(b, st, None)
+    S = ob.geoms(48, kind=np.full(48, 2, np.uint8), aabb=statics, material=None)
+    exp, exp_total = ob.contacts_geoms(out["pairs"], A, A)
+    exp_s, exp_s_total = ob.contacts_geoms(out["static_pairs"], A, S)
+    assert len(out["pairs"]) > 64 * 12 * 4, "several chunks per wavefront at grid 3"
+    for got in (a, c):
+        assert got["body"][1] == exp_total and got["body"][0].tobytes() == exp.tobytes()
+        assert got["static"][1] == exp_s_total and got["static"][0].tobytes() == exp_s.tobytes()
+    assert np.array_equal(out["bflags"], out1["bflags"])
+
+
 def test_static_sphere_and_capsule_colliders(cuda_device):
     """Static colliders the reference creates as capsule / sphere geoms (phys_body_new with a geom only, physics.c:
     980-991): narrowphase against their real shape, candidates from their AABBs."""

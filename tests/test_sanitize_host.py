@@ -76,6 +76,9 @@ def test_binding_and_mirror_under_asan_ubsan():
     assert _run(exe, "test", 200, 40, 13, "notify", "drawn")["mismatches"] == 0
     assert _run(exe, "test", 6000, 16, 33, "notify", "drawn", "steady")["mismatches"] == 0
     assert _run(exe, "test", 1500, 10, 2)["mismatches"] == 0
+    # re-tiled frames with the serial second half (GPU_SCENE_RETILE_BY_MASK=0: the A/B switch keeps working)
+    assert _run(exe, "test", 2500, 12, 1, "notify", "drawn", "steady", env={"GPU_SCENE_RETILE_BY_MASK": "0"})["mismatches"] == 0
+    assert _run(exe, "test", 1500, 10, 2, env={"GPU_SCENE_RETILE_BY_MASK": "0"})["mismatches"] == 0
     r = _run(exe, "test", 20000, 12, 1, "steady")               # no notifications, >= 16 384 entities: the frames whose queue stood go by the records
     assert r["mismatches"] == 0 and r["frames_by_the_records"] >= 6 and r["fast_frames"] == 0
     r = _run(exe, "test", 2000, 24, 1, "steady")                # ... a small queue is walked (one thread would lose by the records)
@@ -203,6 +206,13 @@ def test_mirror_edits_in_place_under_asan_ubsan():
     assert p.returncode == 0 and "PASS" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
     assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
     assert "0 edits fell back to a re-tile, 4 of 4 frames without one" in p.stdout and " 0 entities placed" not in p.stdout
+    # the re-tile's passes over every handle / slot as ranges on a caller's pool (clapgpu_scene_set_parallel_for): here seven
+    # ranges taken backwards from one element up -- the same layout, the same frames
+    for mode in ([], ["wide"]):
+        p = subprocess.run([exe, *mode], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TEST_SCENE_PAR_FOR="1", CLAPGPU_SCENE_PAR_MIN="1"))
+        assert p.returncode == 0 and "PASS" in p.stdout and "7 ranges, backwards" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+        assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
     # a long run: lanes recycled, growth tiles, rows that fill up (the edit falls back, the frame re-tiles, then in place again)
     p = subprocess.run([exe, "tiles", "5", "80"], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert p.returncode == 0 and "PASS" in p.stdout and p.stdout.count("frame ok") == 88, p.stdout[-1500:] + p.stderr[-2000:]
