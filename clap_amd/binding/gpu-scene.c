@@ -2013,9 +2013,12 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
         st->left_stale = pc.left;
         if (pc.left) gs->any_pend = true;
     }
+    const bool timing = getenv("GPU_SCENE_TIMING") != NULL;
+    const double ts0 = timing ? now_ms() : 0;
     uint64_t n_rebuilt = 0;
     if (scat)
         for (uint32_t w = 0; w < words; w++) n_rebuilt += (uint64_t)__builtin_popcountll(scat[w]);
+    const double ts1 = timing ? now_ms() : 0;
     static uint64_t scatter_par_min;
     if (!scatter_par_min) {
         const char *sp = getenv("GPU_SCENE_SCATTER_PAR_MIN");    /* tuning knob */
@@ -2111,6 +2114,7 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
             st->written_back++;
         }
     }
+    const double ts2 = timing ? now_ms() : 0;
     consume_fetched(gs);                                         /* came into view (or contain the camera) after frames of being left out */
     const double t3 = now_ms();
     /* host hooks + bounding-volume pick, merged in list order */
@@ -2190,7 +2194,7 @@ static int frame_results(struct gpu_scene *gs, struct mq *mq, const clapgpu_scen
     }
     }
     st->batched = gs->n_batched; st->host = gs->n_host + gs->n_deferred;
-    if (getenv("GPU_SCENE_TIMING")) fprintf(stderr, "fast_frame: mirror %.3f device %.3f scatter %.3f (rebuilt %llu) hooks+bv %.3f (cand %u host %u)\n", t1 - t0, t2 - t1, t3 - t2, (unsigned long long)n_rebuilt, now_ms() - t3, n_cand, gs->n_host);
+    if (timing) fprintf(stderr, "fast_frame: mirror %.3f device %.3f scatter %.3f = lag+pend %.3f count %.3f rows %.3f fetched %.3f (rebuilt %llu) hooks+bv %.3f (cand %u host %u)\n", t1 - t0, t2 - t1, t3 - t2, ts0 - t2, ts1 - ts0, ts2 - ts1, t3 - ts2, (unsigned long long)n_rebuilt, now_ms() - t3, n_cand, gs->n_host);
     st->ms_walk = t1 - t0; st->ms_device = t2 - t1; st->ms_scatter = now_ms() - t2;
     return 0;
 }
