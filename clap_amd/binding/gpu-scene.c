@@ -2398,45 +2398,17 @@ int gpu_mq_update(struct gpu_scene *gs, struct mq *mq, struct view *view)
     return rc;
 }
 
-static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
+/* ---- a WALKED frame, in the order mq_update_frame() runs its parts -------------------------------------------------- */
+
+/* A walked frame writes everything back, and it may re-tile: whatever GPU_SCATTER_DRAWN left on the device comes over
+ * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's.  The rows
+ * only: an entity3d is written when the walk MEETS it -- what was deleted since the last frame (the reason for many a
+ * walk) is freed memory, and nothing but the queue's own lists says which entities those are.  Then the frame's lists and
+ * counters start empty. */
+static int walk_begin(struct gpu_scene *gs, struct mq *mq)
 {
     struct gpu_scene_stats *st = &gs->stats;
     struct scene *scene = mq->priv;
-    gs->hook_data = mq->priv;
-    memset(st, 0, sizeof(*st));
-    gs->gen++;
-    if (gs->notify && gs->walked && !gs->topology_pending) {
-        gs->gen--;                                                /* nothing entered or left the queue: the records' generation stands */
-        const unsigned int untouched = gs->verify ? verify_untouched(gs) : 0;
-        const int rc = fast_frame(gs, mq, view);
-        st->untouched_writes = untouched;
-        gs->last_fast = rc == 0;
-        if (rc <= 0) return rc;
-        gs->gen++;
-        memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
-    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order >= replay_min() &&
-               (par_threads() > 1 || gs->n_order < GS_REPLAY_MIN) && !gs->n_touched && queue_unchanged(gs, mq)) {
-        /* no notifications, and the queue is the one the last walk met: the frame by the records (see queue_unchanged) */
-        if (gs->n_order > gs->cap_touched) {
-            uint32_t *q = realloc(gs->touched, (size_t)gs->cap_order * sizeof(*q));
-            if (!q) return _CERR_NOMEM;
-            gs->touched = q; gs->cap_touched = gs->cap_order;
-        }
-        memcpy(gs->touched, gs->order, (size_t)gs->n_order * sizeof(*gs->touched));
-        gs->n_touched = gs->n_order;
-        gs->gen--;
-        gs->replaying = true;
-        const int rc = fast_frame(gs, mq, view);
-        gs->replaying = false;
-        gs->last_fast = false;                                    /* (the word is kept for frames that looked at what was reported only) */
-        if (rc <= 0) { st->replayed = rc == 0; return rc; }
-        gs->gen++;
-        memset(st, 0, sizeof(*st));                               /* an entity would be classified differently now: walk */
-    }
-    /* a walked frame writes everything back, and it may re-tile: whatever GPU_SCATTER_DRAWN left on the device comes over
-     * first, so that the host fields the walk decides by (xform.updated, seq / parent_seq) are the reference's.  The rows
-     * only: an entity3d is written when the walk MEETS it -- what was deleted since the last frame (the reason for many a
-     * walk) is freed memory, and nothing but the queue's own lists says which entities those are */
     gs->walk_fetch_on = false;
     if (gs->any_pend) {
         uint32_t n_rows = 0;
@@ -2475,7 +2447,12 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
     else
         clapgpu_scene_set_bv_points(gs->scene, NULL, NULL, CLAPGPU_NO_ENTITY);
 
-    const double t0 = now_ms();
+    return 0;
+}
+
+static int walk_queue(struct gpu_scene *gs, struct mq *mq)
+{
+    struct gpu_scene_stats *st = &gs->stats;
     /*
      * 1-3 in ONE walk of the queue (the entity structs are far larger than the caches, so every
      * extra pass over them costs as much as the reference's whole update).  prev_order[] is last
@@ -2596,7 +2573,13 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         gs->any_pend = false;
         gs->walk_fetch_on = false;
     }
-    const double t1 = now_ms();
+    return 0;
+}
+
+/* records of entities that left the queue since the last walk; the lists the second half of the frame goes by */
+static int walk_settle(struct gpu_scene *gs)
+{
+    struct gpu_scene_stats *st = &gs->stats;
     for (uint32_t k = 0; k < gs->n_dead_recs; k++) {             /* taken out in place since the last walk: order[] no longer names them */
         struct gs_rec *r = &gs->rec[gs->dead_recs[k]];
         if (r->e) continue;                                      /* (cannot be: nothing hands a tombstone out before this) */
@@ -2643,8 +2626,13 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         gs->lag_keep = lk;
     }
 
-    const double t2 = now_ms();
-    /* 4: the device */
+    return 0;
+}
+
+/* 4: the device -- and, under GPU_SCATTER_DRAWN, the per-slot counters laid out for the layout it left */
+static int walk_device(struct gpu_scene *gs, struct view *view, clapgpu_scene_arrays *out, bool *shown_stands_out)
+{
+    struct gpu_scene_stats *st = &gs->stats;
     const uint32_t layout_before = clapgpu_scene_layout_generation(gs->scene);
     clapgpu_frustum fr;
     if (view) frustum_of(view, &fr);
@@ -2679,24 +2667,18 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         if (!shown_stands) memset(gs->shown, 0, (size_t)gs->cap_pend * sizeof(*gs->shown));
     }
     gs->shown_live = gs->scatter_drawn && gs->notify && res.n_slots && gs->shown;
-    const double t3 = now_ms();
-    if (!st->retiled && gs->walked && shown_stands && res.n_slots) {
-        /* 5, the layout stood: the device's masks say what was rebuilt and which boxes hold the camera -- the second half of
-         * a notified frame (frame_results), on the workers where there is much to write back */
-        const int rc = frame_results(gs, mq, &res, t0, t2, t3);
-        if (rc) return rc;
-        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
-    } else if (res.n_slots && retile_by_mask()) {
-        /* 5, after a re-tile (the device rebuilt EVERYTHING; the host fields say what the reference would have): the same second
-         * half, over a mask made from the host fields on the workers */
-        clapgpu_scene_arrays hres = res;
-        CK(by_host_fields(gs, &hres));
-        const int rc = frame_results(gs, mq, &hres, t0, t2, t3);
-        if (rc) return rc;
-        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
-    } else {
-    /* 5, the same on one thread in list order (GPU_SCENE_RETILE_BY_MASK=0, and a queue with nothing batched): results and
-     * host hooks */
+    *out = res;
+    *shown_stands_out = shown_stands;
+    return 0;
+}
+
+/* 5 on one thread in list order (GPU_SCENE_RETILE_BY_MASK=0, and a queue with nothing batched): results and host hooks */
+static void second_half_serial(struct gpu_scene *gs, struct mq *mq, const clapgpu_scene_arrays *resp)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    struct scene *scene = mq->priv;
+    const clapgpu_scene_arrays res = *resp;
+    entity3d *e;
     for (uint32_t k = 0; k < gs->n_order; k++) {
         struct gs_rec *r = &gs->rec[gs->order[k]];
         e = r->e;
@@ -2749,8 +2731,11 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
         if (scene)
             bv_pick(scene, e);
     }
-    st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1; st->ms_device = t3 - t2; st->ms_scatter = now_ms() - t3;
-    }
+}
+
+/* what a walk leaves behind for the frames that are not walked: verdict table, address table, slot arrays, standing readers */
+static int walk_tail(struct gpu_scene *gs, struct scene *scene)
+{
     if (gs->n_order > gs->cap_vq) {
         const uint32_t cap = gs->cap_order;
         entity3d **ve = realloc(gs->vq_e, (size_t)cap * sizeof(*ve));
@@ -2785,6 +2770,73 @@ static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *vie
             if (!clapgpu_scene_entity_keep(gs->scene, r->handle, keep)) r->keep = keep;
         }
     }
+    return 0;
+}
+
+static int mq_update_frame(struct gpu_scene *gs, struct mq *mq, struct view *view)
+{
+    struct gpu_scene_stats *st = &gs->stats;
+    struct scene *scene = mq->priv;
+    gs->hook_data = mq->priv;
+    memset(st, 0, sizeof(*st));
+    gs->gen++;
+    if (gs->notify && gs->walked && !gs->topology_pending) {
+        gs->gen--;                                                /* nothing entered or left the queue: the records' generation stands */
+        const unsigned int untouched = gs->verify ? verify_untouched(gs) : 0;
+        const int rc = fast_frame(gs, mq, view);
+        st->untouched_writes = untouched;
+        gs->last_fast = rc == 0;
+        if (rc <= 0) return rc;
+        gs->gen++;
+        memset(st, 0, sizeof(*st));                               /* a touched entity changed class: walk */
+    } else if (!gs->notify && gs->replay && gs->walked && !gs->topology_pending && gs->n_order >= replay_min() &&
+               (par_threads() > 1 || gs->n_order < GS_REPLAY_MIN) && !gs->n_touched && queue_unchanged(gs, mq)) {
+        /* no notifications, and the queue is the one the last walk met: the frame by the records (see queue_unchanged) */
+        if (gs->n_order > gs->cap_touched) {
+            uint32_t *q = realloc(gs->touched, (size_t)gs->cap_order * sizeof(*q));
+            if (!q) return _CERR_NOMEM;
+            gs->touched = q; gs->cap_touched = gs->cap_order;
+        }
+        memcpy(gs->touched, gs->order, (size_t)gs->n_order * sizeof(*gs->touched));
+        gs->n_touched = gs->n_order;
+        gs->gen--;
+        gs->replaying = true;
+        const int rc = fast_frame(gs, mq, view);
+        gs->replaying = false;
+        gs->last_fast = false;                                    /* (the word is kept for frames that looked at what was reported only) */
+        if (rc <= 0) { st->replayed = rc == 0; return rc; }
+        gs->gen++;
+        memset(st, 0, sizeof(*st));                               /* an entity would be classified differently now: walk */
+    }
+    CK(walk_begin(gs, mq));
+    const double t0 = now_ms();
+    CK(walk_queue(gs, mq));                                      /* 1-3: the one serial pass over the lists */
+    const double t1 = now_ms();
+    CK(walk_settle(gs));
+    const double t2 = now_ms();
+    clapgpu_scene_arrays res = { 0 };
+    bool shown_stands = true;
+    CK(walk_device(gs, view, &res, &shown_stands));
+    const double t3 = now_ms();
+    if (!st->retiled && gs->walked && shown_stands && res.n_slots) {
+        /* 5, the layout stood: the device's masks say what was rebuilt and which boxes hold the camera -- the second half of
+         * a notified frame (frame_results), on the workers where there is much to write back */
+        const int rc = frame_results(gs, mq, &res, t0, t2, t3);
+        if (rc) return rc;
+        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
+    } else if (res.n_slots && retile_by_mask()) {
+        /* 5, after a re-tile (the device rebuilt EVERYTHING; the host fields say what the reference would have): the same second
+         * half, over a mask made from the host fields on the workers */
+        clapgpu_scene_arrays hres = res;
+        CK(by_host_fields(gs, &hres));
+        const int rc = frame_results(gs, mq, &hres, t0, t2, t3);
+        if (rc) return rc;
+        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1;
+    } else {
+        second_half_serial(gs, mq, &res);
+        st->ms_walk = t1 - t0; st->ms_mirror = t2 - t1; st->ms_device = t3 - t2; st->ms_scatter = now_ms() - t3;
+    }
+    CK(walk_tail(gs, scene));
     gs->walked = true;
     return 0;
 }
