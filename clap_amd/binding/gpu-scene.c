@@ -96,6 +96,7 @@ struct gs_model { model3d *model; uint32_t handle; unsigned int lod_min, lod_max
 
 static struct gpu_scene *g_bound;     /* the scene the engine-named entry points (gpu-exports.inc.c) serve */
 
+struct gs_wq;
 struct gpu_scene {
     clapgpu_scene   *scene;
     int             (*default_hook)(entity3d *, void *);
@@ -189,6 +190,7 @@ struct gpu_scene {
     struct gs_hf { uint32_t ppos; uint16_t seq0, pseq; uint8_t dirty, state; } *hf; uint32_t cap_hf;
     uint64_t        *hf_mask; uint32_t cap_hf_mask;
     uint32_t        *keep_changes; uint32_t cap_keep_changes;      /* scratch of a walk's last pass */
+    struct gs_wq    *wq; uint32_t cap_wq;                          /* a big queue's walk: per queue position, its steps 2 and 3 on the workers */
     struct gpu_scene_stats stats;
 };
 
@@ -315,7 +317,7 @@ void gpu_scene_done(struct gpu_scene *gs)
     free(gs->char_list);
     free(gs->lag_parent); free(gs->lag_keep); free(gs->att_list); free(gs->att_handles); free(gs->att_jt); free(gs->att_bind);
     free(gs->draw); free(gs->draw_lod); free(gs->draw_g); free(gs->draw_g_lod); free(gs->groups); free(gs->pend); free(gs->shown); free(gs->xptr); free(gs->ftab);
-    free(gs->claim); free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands); free(gs->hf); free(gs->hf_mask); free(gs->keep_changes);
+    free(gs->claim); free(gs->created); free(gs->dead_recs); free(gs->wtxm); free(gs->cands); free(gs->hf); free(gs->hf_mask); free(gs->keep_changes); free(gs->wq);
     free(gs->walk_fetch); free(gs->draw_txm); free(gs->slot_ent); free(gs->slot_txm); free(gs->slot_lod); free(gs->txms);
     free(gs->touched); free(gs->host_list); free(gs->deferred); free(gs->posmap); free(gs->slots); free(gs->vq_e); free(gs->vq_slot); free(gs->vq_ok);
     if (g_bound == gs) g_bound = NULL;
@@ -2450,6 +2452,214 @@ static int walk_begin(struct gpu_scene *gs, struct mq *mq)
     return 0;
 }
 
+/* steps 2 and 3 for ONE entity the walk has met and given its place in order[]: its class (from its own criteria and its
+ * parent's class, which is settled: the parent comes earlier or does not count), then what the class asks of the mirror */
+static int walk_act(struct gpu_scene *gs, struct mq *mq, uint32_t i);
+
+static int walk_classify(struct gpu_scene *gs, struct mq *mq, uint32_t i)
+{
+    struct gs_rec *r = &gs->rec[i];
+    entity3d *e = r->e;
+    r->self_ok = self_batchable(gs, e);
+    const bool rides_joint = e->parent && e->parent_joint != JOINT_TYPE_MAX;
+    r->rides = rides_joint; r->animated = entity_animated(e);
+    if (!r->self_ok) {
+        r->cls = 2;
+        r->parent_e = e->parent; r->parent_rec = NO_REC;
+        /* With the pose computed after this update (gpu_anim_update), an entity riding a parent's joint
+         * (model.c:1626-1641) must wait for it: the reference gives it the joint transforms of THIS frame,
+         * written by the parent's animated_update earlier in the list.  It -- and everything below it -- is
+         * run by gpu_scene_run_deferred(), which gpu_anim_update calls when the palettes are back. */
+        if (gs->anim_elsewhere && e->parent) {
+            /* only behind a parent that comes EARLIER in the list: one that comes later is read one frame late
+             * by the reference, joint transforms included, which running the hook right here reproduces */
+            const uint32_t p = rec_find(gs, e->parent);
+            if (p != NO_REC && gs->rec[p].gen == gs->gen &&
+                (rides_joint || gs->rec[p].cls == 3 || gs->rec[p].cls == 4))
+                r->cls = 3;
+        }
+    } else if (!e->parent) {
+        r->cls = 1;
+        r->parent_e = NULL; r->parent_rec = NO_REC;       /* (a detached child: else every later touch reads as "re-parented") */
+    } else {
+        /* NO_REC unless already met in THIS walk.  A child that precedes its parent in list order sees the
+         * parent's matrix of the previous frame in the reference (model.c:1911-1922 walks creation order):
+         * it stays on the host, where that lag is reproduced exactly, and so does everything below it. */
+        const uint32_t p = parent_rec(gs, r);
+        const uint8_t pc = p != NO_REC ? gs->rec[p].cls : 2;
+        if (!rides_joint) {
+            r->cls = pc;                                  /* 1, 4 (below a joint rider), or the parent's host class */
+            if (pc == 4 && entity_animated(e)) r->cls = 3;   /* its own pose would need its matrix before the second launch */
+        } else if (gs->anim_elsewhere && pc == 1 && !entity_animated(e)) {
+            /* rides a joint of a character whose palette the device computes this frame: the frame's second
+             * entity launch, behind the pose (gpu_scene_run_deferred) */
+            r->cls = 4;
+        } else {
+            /* the parent's hook runs on the host (its palette is fresh when it returns), or the rider is nested
+             * below another rider / animated itself: its own hook, deferred behind the pose when that runs elsewhere */
+            r->cls = (gs->anim_elsewhere && p != NO_REC) ? 3 : 2;
+        }
+    }
+    return walk_act(gs, mq, i);
+}
+
+static int walk_act(struct gpu_scene *gs, struct mq *mq, uint32_t i)
+{
+    struct gs_rec *r = &gs->rec[i];
+    entity3d *e = r->e;
+    if (r->cls == 1 || r->cls == 4) {
+        r->keep_auto = r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook || entity_animated(e);
+        if (e->update != gs->default_hook) {             /* a body-less character: its hook's host half, at its place in the list */
+            gs->char_half(e, mq->priv);
+            if (push_u32(&gs->char_list, &gs->n_char, &gs->cap_char, i)) return _CERR_NOMEM;
+            r = &gs->rec[i];
+        }
+        CK(mirror_one(gs, r));
+        CK(link_parent(gs, r));
+    } else {
+        CK(unbatch(gs, r));
+    }
+    return 0;
+}
+
+/*
+ * The same two steps for a big queue, on the workers.  The list chase is serial by nature; what the walk does per entity
+ * besides it is not, and at a million entities that was most of its 70 ms (four or five cache lines of every 448-byte
+ * entity3d, its record, the mirror's record, three rows of the upload image).  So the chase only matches records and fills
+ * order[], and then, over order[]:
+ *   A  every entity's own criteria and its parent's place in the list (own record only; the parents' records are read),
+ *   B  the classes: an entity's class is a function of its criteria and of its parent's class when that parent comes EARLIER
+ *      in the list -- a recurrence up the ancestor chain, walked per entity until it meets a decided ancestor (states are
+ *      written once, the same value by whoever gets there first),
+ *   C  what the class asks of the mirror, where that is a push of flags and transform (clapgpu_scene_entity_transform_mt:
+ *      nothing shared is touched); anything that changes the mirror's make-up -- a new handle, another model, another parent,
+ *      a joint attachment, a LOD, an entity that leaves the batch, a character's host half -- is noted and
+ *   D  done afterwards on this thread in list order by walk_act(), the serial walk's own code; so is the parent link of the
+ *      children of such entities.
+ */
+#define WQ_NONE 0xffffffffu
+struct gs_wq { uint32_t ppos; uint8_t state, todo; };             /* todo: 1 = walk_act on this thread, 2 = its parent link only */
+struct wq_ctx { struct gpu_scene *gs; int rc; uint32_t pushed; };
+
+static void wq_inputs_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct gpu_scene *gs = ((struct wq_ctx *)ctx)->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        struct gs_wq *w = &gs->wq[k];
+        if (k + 8 < hi) prefetch_entity(gs->rec[gs->order[k + 8]].e);
+        entity3d *e = r->e, *p = e->parent;
+        w->ppos = WQ_NONE; w->todo = 0;
+        r->self_ok = self_batchable(gs, e);
+        r->rides = p && e->parent_joint != JOINT_TYPE_MAX;
+        r->animated = entity_animated(e);
+        uint32_t pi = NO_REC;
+        if (!r->self_ok) {
+            r->parent_e = p; r->parent_rec = NO_REC;
+            if (p && gs->anim_elsewhere) pi = rec_find(gs, p);
+        } else if (!p) {
+            r->parent_e = NULL; r->parent_rec = NO_REC;
+        } else {
+            if (r->parent_e != p || r->parent_rec == NO_REC || gs->rec[r->parent_rec].e != p) {   /* (parent_rec()) */
+                r->parent_e = p;
+                r->parent_rec = rec_find(gs, p);
+            }
+            pi = r->parent_rec;
+        }
+        if (pi != NO_REC && gs->rec[pi].gen == gs->gen && gs->rec[pi].order_pos < k) w->ppos = gs->rec[pi].order_pos;   /* met EARLIER in this walk */
+        if (!r->self_ok) w->state = (w->ppos == WQ_NONE) ? 2 : r->rides ? 3 : 0;
+        else if (!p) w->state = 1;
+        else w->state = (w->ppos == WQ_NONE) ? 2 : 0;
+    }
+}
+
+static uint8_t wq_class(const struct gpu_scene *gs, uint32_t k)
+{
+    struct gs_wq *wq = gs->wq;
+    uint32_t chain[64], n = 0, cur = k;
+    uint8_t s;
+    for (;;) {
+        s = __atomic_load_n(&wq[cur].state, __ATOMIC_RELAXED);
+        if (s) break;
+        if (n == 64) { s = wq_class(gs, cur); break; }
+        chain[n++] = cur;
+        cur = wq[cur].ppos;
+    }
+    while (n) {
+        const uint32_t c = chain[--n];
+        const struct gs_rec *r = &gs->rec[gs->order[c]];
+        const uint8_t pc = s;                                    /* the class of c's parent, which comes earlier in the list */
+        if (!r->self_ok) s = (pc == 3 || pc == 4) ? 3 : 2;
+        else if (!r->rides) s = (pc == 4 && r->animated) ? 3 : pc;
+        else if (gs->anim_elsewhere && pc == 1 && !r->animated) s = 4;
+        else s = gs->anim_elsewhere ? 3 : 2;
+        __atomic_store_n(&wq[c].state, s, __ATOMIC_RELAXED);
+    }
+    return s;
+}
+
+static void wq_class_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    const struct gpu_scene *gs = ((struct wq_ctx *)ctx)->gs;
+    for (uint32_t k = lo; k < hi; k++) wq_class(gs, k);
+}
+
+static void wq_act_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct wq_ctx *wc = ctx;
+    struct gpu_scene *gs = wc->gs;
+    uint32_t pushed = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        struct gs_rec *r = &gs->rec[gs->order[k]];
+        struct gs_wq *w = &gs->wq[k];
+        entity3d *e = r->e;
+        r->cls = w->state;
+        if (r->cls != 1 && r->cls != 4) { w->todo = r->handle != CLAPGPU_NO_ENTITY; continue; }   /* leaves the batch: unbatch() */
+        r->keep_auto = r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook || r->animated;
+        const uint8_t att = r->cls == 4 && e->parent_joint != JOINT_TYPE_MAX;
+        const uint32_t ph = e->parent ? gs->rec[r->parent_rec].handle : CLAPGPU_NO_ENTITY;
+        if (e->update != gs->default_hook || r->handle == CLAPGPU_NO_ENTITY || r->model != e->txmodel->model ||
+            e->force_lod != r->lod_force || e->cur_lod != r->lod_cur || att != r->att || ph != r->parent_handle ||
+            (e->parent && ph == CLAPGPU_NO_ENTITY)) {
+            w->todo = 1;
+            continue;
+        }
+        /* mirror_one(), the part that changes nothing but this entity's own inputs */
+        const uint32_t flags = e->flags & (ENTITY3D_ALIVE | 0xffffu);
+        const bool same_flags = flags == r->flags;
+        r->flags = flags;
+        r->xform_dirty = transform_is_updated(&e->xform);
+        if (r->host_done && r->xform_dirty) r->host_done = 2;
+        if (!r->xform_dirty && !r->host_done && same_flags) continue;
+        const int rc = clapgpu_scene_entity_transform_mt(gs->scene, r->handle, transform_pos(&e->xform, NULL),
+                                                         transform_rotation_quat(&e->xform), e->scale, flags, r->xform_dirty || r->host_done);
+        if (rc) __atomic_store_n(&wc->rc, rc, __ATOMIC_RELAXED);
+        if (r->xform_dirty || r->host_done) pushed++;
+    }
+    __atomic_fetch_add(&wc->pushed, pushed, __ATOMIC_RELAXED);
+}
+
+/* children of entities whose handle is about to change (a new handle, another model): their parent link follows it */
+static void wq_links_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    struct gpu_scene *gs = ((struct wq_ctx *)ctx)->gs;
+    for (uint32_t k = lo; k < hi; k++) {
+        const struct gs_rec *r = &gs->rec[gs->order[k]];
+        struct gs_wq *w = &gs->wq[k];
+        if (__atomic_load_n(&w->todo, __ATOMIC_RELAXED) || (r->cls != 1 && r->cls != 4) || !r->e->parent) continue;
+        const struct gs_rec *pr = &gs->rec[r->parent_rec];
+        if (pr->order_pos < gs->n_order && __atomic_load_n(&gs->wq[pr->order_pos].todo, __ATOMIC_RELAXED) == 1)
+            __atomic_store_n(&w->todo, 2, __ATOMIC_RELAXED);     /* (a neighbour may be reading this one as ITS parent's: 0 or 2, never 1) */
+    }
+}
+
+static uint32_t walk_par_min(void)
+{
+    static uint32_t v;
+    if (!v) { const char *e = getenv("GPU_SCENE_WALK_PAR_MIN"); v = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u; }   /* tuning knob; the tests set 1 */
+    return v;
+}
+
 static int walk_queue(struct gpu_scene *gs, struct mq *mq)
 {
     struct gpu_scene_stats *st = &gs->stats;
@@ -2457,11 +2667,13 @@ static int walk_queue(struct gpu_scene *gs, struct mq *mq)
      * 1-3 in ONE walk of the queue (the entity structs are far larger than the caches, so every
      * extra pass over them costs as much as the reference's whole update).  prev_order[] is last
      * frame's walk: an unchanged queue is matched without hashing, and its entities are prefetched
-     * ahead of the list chase.
+     * ahead of the list chase.  A big queue's steps 2 and 3 follow on the workers (above).
      */
     { uint32_t *t = gs->prev_order; gs->prev_order = gs->order; gs->order = t; }
     gs->n_prev = gs->n_order;
     gs->n_order = 0;
+    const bool later = gs->n_prev >= walk_par_min() && par_threads() > 1;   /* (by last walk's size: a first walk goes one by one) */
+    const double t_chase = now_ms();
     uint32_t cursor = 0;
     model3dtx *txm;
     entity3d *e, *it;
@@ -2479,8 +2691,10 @@ static int walk_queue(struct gpu_scene *gs, struct mq *mq)
             uint32_t i;
             if (cursor < gs->n_prev && gs->rec[gs->prev_order[cursor]].e == e) {
                 i = gs->prev_order[cursor++];
-                if (cursor + 8 < gs->n_prev)
-                    prefetch_entity(gs->rec[gs->prev_order[cursor + 8]].e);
+                if (cursor + 8 < gs->n_prev) {
+                    if (later) __builtin_prefetch(&gs->rec[gs->prev_order[cursor + 8]].e->entry, 0, 1);   /* the chase reads the list node and the flags */
+                    else prefetch_entity(gs->rec[gs->prev_order[cursor + 8]].e);
+                }
             } else {
                 i = rec_find(gs, e);
                 if (i == NO_REC) {
@@ -2514,59 +2728,40 @@ static int walk_queue(struct gpu_scene *gs, struct mq *mq)
             r->order_pos = gs->n_order;
             r->order_key = ((uint64_t)rank << 32) | gs->wtxm[rank].next++;
             gs->order[gs->n_order++] = i;
-            r->self_ok = self_batchable(gs, e);
-            const bool rides_joint = e->parent && e->parent_joint != JOINT_TYPE_MAX;
-            r->rides = rides_joint; r->animated = entity_animated(e);
-            if (!r->self_ok) {
-                r->cls = 2;
-                r->parent_e = e->parent; r->parent_rec = NO_REC;
-                /* With the pose computed after this update (gpu_anim_update), an entity riding a parent's joint
-                 * (model.c:1626-1641) must wait for it: the reference gives it the joint transforms of THIS frame,
-                 * written by the parent's animated_update earlier in the list.  It -- and everything below it -- is
-                 * run by gpu_scene_run_deferred(), which gpu_anim_update calls when the palettes are back. */
-                if (gs->anim_elsewhere && e->parent) {
-                    /* only behind a parent that comes EARLIER in the list: one that comes later is read one frame late
-                     * by the reference, joint transforms included, which running the hook right here reproduces */
-                    const uint32_t p = rec_find(gs, e->parent);
-                    if (p != NO_REC && gs->rec[p].gen == gs->gen &&
-                        (rides_joint || gs->rec[p].cls == 3 || gs->rec[p].cls == 4))
-                        r->cls = 3;
-                }
-            } else if (!e->parent) {
-                r->cls = 1;
-                r->parent_e = NULL; r->parent_rec = NO_REC;       /* (a detached child: else every later touch reads as "re-parented") */
-            } else {
-                /* NO_REC unless already met in THIS walk.  A child that precedes its parent in list order sees the
-                 * parent's matrix of the previous frame in the reference (model.c:1911-1922 walks creation order):
-                 * it stays on the host, where that lag is reproduced exactly, and so does everything below it. */
-                const uint32_t p = parent_rec(gs, r);
-                const uint8_t pc = p != NO_REC ? gs->rec[p].cls : 2;
-                if (!rides_joint) {
-                    r->cls = pc;                                  /* 1, 4 (below a joint rider), or the parent's host class */
-                    if (pc == 4 && entity_animated(e)) r->cls = 3;   /* its own pose would need its matrix before the second launch */
-                } else if (gs->anim_elsewhere && pc == 1 && !entity_animated(e)) {
-                    /* rides a joint of a character whose palette the device computes this frame: the frame's second
-                     * entity launch, behind the pose (gpu_scene_run_deferred) */
-                    r->cls = 4;
-                } else {
-                    /* the parent's hook runs on the host (its palette is fresh when it returns), or the rider is nested
-                     * below another rider / animated itself: its own hook, deferred behind the pose when that runs elsewhere */
-                    r->cls = (gs->anim_elsewhere && p != NO_REC) ? 3 : 2;
-                }
-            }
-            if (r->cls == 1 || r->cls == 4) {
-                r->keep_auto = r->cls == 4 || e->light_idx >= 0 || e->update != gs->default_hook || entity_animated(e);
-                if (e->update != gs->default_hook) {             /* a body-less character: its hook's host half, at its place in the list */
-                    gs->char_half(e, mq->priv);
-                    if (push_u32(&gs->char_list, &gs->n_char, &gs->cap_char, i)) return _CERR_NOMEM;
-                    r = &gs->rec[i];
-                }
-                CK(mirror_one(gs, r));
-                CK(link_parent(gs, r));
-            } else {
-                CK(unbatch(gs, r));
-            }
+            if (!later) CK(walk_classify(gs, mq, i));
         }
+    }
+    if (later && gs->n_order) {
+        if (gs->n_order > gs->cap_wq) {
+            struct gs_wq *q = realloc(gs->wq, (size_t)gs->cap_order * sizeof(*q));
+            if (!q) return _CERR_NOMEM;
+            gs->wq = q; gs->cap_wq = gs->cap_order;
+        }
+        struct wq_ctx wc = { gs, 0, 0 };
+        const bool timing = getenv("GPU_SCENE_TIMING") != NULL;
+        double tw[6] = { 0 };
+        if (timing) tw[0] = now_ms();
+        gpu_scene_par_for(wq_inputs_range, &wc, gs->n_order, par_threads());
+        if (timing) tw[1] = now_ms();
+        gpu_scene_par_for(wq_class_range, &wc, gs->n_order, par_threads());
+        if (timing) tw[2] = now_ms();
+        gpu_scene_par_for(wq_act_range, &wc, gs->n_order, par_threads());
+        if (timing) tw[3] = now_ms();
+        gpu_scene_par_for(wq_links_range, &wc, gs->n_order, par_threads());
+        if (timing) tw[4] = now_ms();
+        if (wc.rc) return wc.rc;
+        st->uploaded += wc.pushed;
+        clapgpu_scene_mark_all_dirty(gs->scene);
+        uint32_t n_todo = 0;
+        for (uint32_t k = 0; k < gs->n_order; k++) {             /* D: what changes the mirror's make-up, in list order */
+            const uint8_t todo = gs->wq[k].todo;
+            if (todo == 1) CK(walk_act(gs, mq, gs->order[k]));
+            else if (todo == 2) CK(link_parent(gs, &gs->rec[gs->order[k]]));
+            n_todo += todo != 0;
+        }
+        if (timing)
+            fprintf(stderr, "walk: chase %.3f ms, criteria %.3f, classes %.3f, pushes %.3f, links %.3f, %u entities one by one %.3f\n",
+                    tw[0] - t_chase, tw[1] - tw[0], tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], n_todo, now_ms() - tw[4]);
     }
     if (gs->any_pend) {                                          /* what the walk did not meet is gone, and its counters with it */
         if (gs->pend) memset(gs->pend, 0, (size_t)gs->cap_pend * sizeof(*gs->pend));

@@ -179,15 +179,24 @@ def test_api_orderings_fuzzed_under_asan():
     for seed, ops in ((305, 200), (77, 200), (5016, 1500), (1421, 200)):
         assert _run(exe, "fuzz", seed, ops)["mismatches"] == 0, seed
 
+    # every fifth seed with a walked frame's steps 2 and 3 on the workers from the first entity up (GPU_SCENE_WALK_PAR_MIN=1:
+    # classes by the chase up the ancestor chain, flags / transforms pushed in parallel, the rest in list order afterwards)
+    forced = {"GPU_SCENE_WALK_PAR_MIN": "1", "GPU_SCENE_THREADS": "3"}
+
     def one(job):
         seed, ops = job
-        r = _run(exe, "fuzz", seed, ops, timeout=300)
+        r = _run(exe, "fuzz", seed, ops, timeout=300, env=forced if seed % 5 == 0 else None)
         return seed, r["mismatches"], r["frames"], r["render_passes"]
     jobs = [(s, 200) for s in range(1, 2501)] + [(s, 1500) for s in range(5001, 5301)]
     with ThreadPoolExecutor(6) as pool:
         res = list(pool.map(one, jobs))
     assert [s for s, bad, _f, _p in res if bad] == []
     assert sum(f for _s, _b, f, _p in res) > 50_000 and sum(p for _s, _b, _f, p in res) > 50_000
+    # ... and the scripted game the same way (creations, deletions, re-parenting, hooks, characters, joint riders)
+    for args in (("test", 2500, 12, 1, "notify", "drawn", "steady"), ("test", 2000, 40, 7, "notify", "drawn", "steady"), ("test", 1500, 10, 2),
+                 ("test", 2500, 16, 1, "notify", "drawn", "comeandgo"), ("lod", 1500, 8, 1, "notify", "drawn", "steady"), ("edge",),
+                 ("anim", 40, 64, 8, 3), ("characters", 200, 8, 3)):
+        assert _run(exe, *args, env=forced)["mismatches"] == 0, args
 
 
 def test_mirror_edits_in_place_under_asan_ubsan():
