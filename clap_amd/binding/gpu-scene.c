@@ -2692,8 +2692,9 @@ static int walk_queue(struct gpu_scene *gs, struct mq *mq)
             if (cursor < gs->n_prev && gs->rec[gs->prev_order[cursor]].e == e) {
                 i = gs->prev_order[cursor++];
                 if (cursor + 8 < gs->n_prev) {
-                    if (later) __builtin_prefetch(&gs->rec[gs->prev_order[cursor + 8]].e->entry, 0, 1);   /* the chase reads the list node and the flags */
-                    else prefetch_entity(gs->rec[gs->prev_order[cursor + 8]].e);
+                    const entity3d *ahead = gs->rec[gs->prev_order[cursor + 8]].e;   /* (NULL: a tombstone of order[]) */
+                    if (!later) prefetch_entity(ahead);
+                    else if (ahead) __builtin_prefetch(&ahead->entry, 0, 1);   /* the chase reads the list node and the flags */
                 }
             } else {
                 i = rec_find(gs, e);
