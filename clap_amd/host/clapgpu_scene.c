@@ -1110,6 +1110,70 @@ static void image_range(void *ctx, uint32_t lo, uint32_t hi)      /* in units of
     }
 }
 
+/* Slots in HANDLE order inside each row, as one thread would give them, from passes that have no order in them: the handles
+ * are cut into chunks; every chunk counts its entities per row (or per level), a pass over the rows turns the counts into
+ * each chunk's first lane, and every chunk then hands out its lanes in handle order. */
+static uint32_t rt_chunk(void)                                    /* handles per chunk (CLAPGPU_SCENE_RT_CHUNK: the tests set a few hundred) */
+{
+    static uint32_t v;
+    if (!v) { const char *e = getenv("CLAPGPU_SCENE_RT_CHUNK"); v = e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u; }
+    return v;
+}
+struct slots_ctx {
+    clapgpu_scene *s; const uint32_t *depth, *root, *tree_of, *row_of_tree; uint32_t *cnt; uint32_t n_cells, n_chunks, H, chunk; int tiled;
+};
+static inline uint32_t slots_cell(const struct slots_ctx *sc, uint32_t h)
+{
+    return sc->tiled ? sc->row_of_tree[sc->tree_of[sc->root[h]]] + sc->depth[h] : sc->s->level_start_host[sc->depth[h]] / WAVE;
+}
+
+static void slots_count_range(void *ctx, uint32_t lo, uint32_t hi)      /* in chunks */
+{
+    struct slots_ctx *sc = ctx;
+    for (uint32_t c = lo; c < hi; c++) {
+        uint32_t *cnt = sc->cnt + (size_t)c * sc->n_cells;
+        const uint32_t h1 = (c + 1) * sc->chunk < sc->H ? (c + 1) * sc->chunk : sc->H;
+        for (uint32_t h = c * sc->chunk; h < h1; h++)
+            if (sc->s->e[h].live) cnt[slots_cell(sc, h)]++;
+    }
+}
+
+static void slots_first_range(void *ctx, uint32_t lo, uint32_t hi)      /* in cells */
+{
+    struct slots_ctx *sc = ctx;
+    for (uint32_t cell = lo; cell < hi; cell++) {
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < sc->n_chunks; c++) {
+            uint32_t *p = sc->cnt + (size_t)c * sc->n_cells + cell;
+            const uint32_t t = *p;
+            *p = run; run += t;
+        }
+    }
+}
+
+static void slots_assign_range(void *ctx, uint32_t lo, uint32_t hi)     /* in chunks */
+{
+    struct slots_ctx *sc = ctx;
+    clapgpu_scene *s = sc->s;
+    for (uint32_t c = lo; c < hi; c++) {
+        uint32_t *cnt = sc->cnt + (size_t)c * sc->n_cells;
+        const uint32_t h1 = (c + 1) * sc->chunk < sc->H ? (c + 1) * sc->chunk : sc->H;
+        for (uint32_t h = c * sc->chunk; h < h1; h++) {
+            if (!s->e[h].live) continue;
+            const uint32_t cell = slots_cell(sc, h);
+            const uint32_t k = cnt[cell]++;
+            s->e[h].slot = (sc->tiled ? cell * WAVE : s->level_start_host[sc->depth[h]]) + k;
+            s->slot_handle[s->e[h].slot] = h;
+        }
+    }
+}
+
+static void undirty_range(void *ctx, uint32_t lo, uint32_t hi)
+{
+    clapgpu_scene *s = ctx;
+    for (uint32_t h = lo; h < hi; h++) s->e[h].dirty = 0;
+}
+
 static int retile(clapgpu_scene *s)
 {
     const int timing = getenv("CLAPGPU_SCENE_TIMING") != NULL;
@@ -1196,8 +1260,17 @@ static int retile(clapgpu_scene *s)
 
     /* slots: handle order inside each row */
     if (timing) tp[3] = scene_now_us();
-    row_fill = calloc(n_rows, 4);
     memset(s->slot_handle, 0xff, (size_t)s->n_slots * 4);          /* CLAPGPU_NO_ENTITY */
+    const uint32_t chunk = rt_chunk(), n_chunks = (H + chunk - 1) / chunk;
+    uint32_t *chunk_cnt = (s->par_for && n_chunks > 1 && (uint64_t)n_chunks * n_rows <= (64u << 20)) ? calloc((size_t)n_chunks * n_rows, 4) : NULL;
+    if (chunk_cnt) {
+        struct slots_ctx sc = { s, depth, root, tree_of, row_of_tree, chunk_cnt, n_rows, n_chunks, H, chunk, tiled };
+        s->par_for(slots_count_range, &sc, n_chunks, s->par_threads);
+        run_ranges(s, slots_first_range, &sc, n_rows);
+        s->par_for(slots_assign_range, &sc, n_chunks, s->par_threads);
+        free(chunk_cnt);
+    } else {
+    row_fill = calloc(n_rows, 4);
     for (uint32_t h = 0; h < H; h++) {
         if (!s->e[h].live) continue;
         uint32_t row;
@@ -1210,6 +1283,7 @@ static int retile(clapgpu_scene *s)
             s->e[h].slot = s->level_start_host[depth[h]] + k;
         }
         s->slot_handle[s->e[h].slot] = h;
+    }
     }
     /* the slots moved: what was stale under the old layout is rebuilt (and exported or marked stale again) by the launch
      * that follows; the standing readers' bits are laid out anew */
@@ -1237,14 +1311,18 @@ static int retile(clapgpu_scene *s)
         CK(clapgpu_memcpy_h2d(s->d_tile_row_start, s->tile_row_start_host, ((size_t)s->n_tiles + 1) * 4, NULL));
     /* every live handle, not only the listed ones: an entity marked dirty while the list could not grow (mark_dirty's
      * out-of-memory path) would otherwise stay "queued" for ever and never be listed again */
-    for (uint32_t h = 0; h < H; h++) s->e[h].dirty = 0;
+    run_ranges(s, undirty_range, s, H);
     s->n_dirty = 0;
     s->topology_dirty = 0;
     s->up_lo = 0xffffffffu; s->up_hi = 0;
     s->layout_gen++;
-    if (timing)
-        fprintf(stderr, "retile: %u handles -> %u slots: dead %.0f us, depths %.0f, trees + packing %.0f, slabs %.0f, slots %.0f, image %.0f, uploads %.0f\n",
-                H, s->n_slots, 0.0, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], scene_now_us() - tp[5]);
+    if (timing) {
+        const double t_end = scene_now_us();
+        uint64_t fnv = 1469598103934665603ull;                   /* the layout, for comparing runs (serial / on a pool) */
+        for (uint32_t i = 0; i < s->n_slots; i++) fnv = (fnv ^ s->slot_handle[i]) * 1099511628211ull;
+        fprintf(stderr, "retile: %u handles -> %u slots: depths %.0f us, trees + packing %.0f, slabs %.0f, slots %.0f, image %.0f, uploads %.0f; layout %016llx\n",
+                H, s->n_slots, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], t_end - tp[5], (unsigned long long)fnv);
+    }
     return CLAPGPU_OK;
 }
 

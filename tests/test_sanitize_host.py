@@ -217,11 +217,16 @@ def test_mirror_edits_in_place_under_asan_ubsan():
     assert "0 edits fell back to a re-tile, 4 of 4 frames without one" in p.stdout and " 0 entities placed" not in p.stdout
     # the re-tile's passes over every handle / slot as ranges on a caller's pool (clapgpu_scene_set_parallel_for): here seven
     # ranges taken backwards from one element up -- the same layout, the same frames
+    import re
     for mode in ([], ["wide"]):
+        base = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", CLAPGPU_SCENE_TIMING="1")
+        q = subprocess.run([exe, *mode], capture_output=True, text=True, timeout=600, env=base)
         p = subprocess.run([exe, *mode], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TEST_SCENE_PAR_FOR="1", CLAPGPU_SCENE_PAR_MIN="1"))
+                           env=dict(base, TEST_SCENE_PAR_FOR="1", CLAPGPU_SCENE_PAR_MIN="1", CLAPGPU_SCENE_RT_CHUNK="200"))
         assert p.returncode == 0 and "PASS" in p.stdout and "7 ranges, backwards" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
         assert "AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:]
+        layouts = re.findall(r"layout ([0-9a-f]{16})", p.stderr)
+        assert len(layouts) >= 4 and layouts == re.findall(r"layout ([0-9a-f]{16})", q.stderr), "slot for slot the serial re-tile's layout"
     # a long run: lanes recycled, growth tiles, rows that fill up (the edit falls back, the frame re-tiles, then in place again)
     p = subprocess.run([exe, "tiles", "5", "80"], capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert p.returncode == 0 and "PASS" in p.stdout and p.stdout.count("frame ok") == 88, p.stdout[-1500:] + p.stderr[-2000:]
