@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import torch
-    import bench
+    import bench_extras as bench
     from clap_amd import _lib
     _lib.check(_lib.lib().clapgpu_init(0), "init")
     orig = bench.time_launches

@@ -32,7 +32,7 @@ def main():
         print(f"{batch.n_real} entities, {batch.algorithmic_bytes()} algorithmic bytes per launch")
         return
     if which == "frame":                                        # one clap_frame() of everything, 23 times
-        import bench
+        import bench_extras as bench
         print(bench.full_frame(dev)["ms_per_frame"], "ms per frame")
         return
     if which in ("pose", "skin"):

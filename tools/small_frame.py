@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import torch
-    import bench
+    import bench_extras as bench
     from clap_amd import _lib, animation, characters, entities, frame, lights, particles, physics, synth, tiler
     from oracle import binding as ob
     _lib.check(_lib.lib().clapgpu_init(0), "init")
