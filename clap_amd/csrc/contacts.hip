@@ -235,7 +235,10 @@ void k_contacts_geoms(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pa
 // without a cleared counter in front of it: a workgroup adds (1, its static count, its body count) to ONE 64-bit word with one
 // atomic; the workgroup that finds every other ticket already taken holds the totals in what came back, stores them and
 // leaves the word at zero for the next launch.  Two launches and two counter fills were 62 us of a frame for 47 us of work.
-__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(3, 3)))   // three wavefronts a SIMD: what the LDS tile allows
+#ifndef CONTACTS_BOTH_WAVES
+#define CONTACTS_BOTH_WAVES 2                                            // wavefronts a SIMD (174 VGPRs, nothing spilled; 3 = 168 VGPRs + 24 B of scratch: 0.3 us faster)
+#endif
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(CONTACTS_BOTH_WAVES, CONTACTS_BOTH_WAVES)))
 void k_contacts_geoms_both(GeomsK A, GeomsK B, const uint2 *pairs, const uint32_t *pair_total, uint32_t capacity,
                            clapgpu_contact2 *out, uint32_t *contact_total, const uint2 *spairs, const uint32_t *spair_total,
                            uint32_t scapacity, clapgpu_contact2 *sout, uint32_t *scontact_total, uint32_t *flags,
