@@ -331,6 +331,20 @@ def dropin_boundary():
             "identical": (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"])}
     except Exception as e:
         out["1000000_entities_10pct_dirty_no_notifications"] = {"error": repr(e)[:200]}
+    # the two frame kinds that WALK the queue, at 1 M entities: every frame walked and re-tiled (GPU_SCENE_INCREMENTAL=0: what each
+    # frame with an edit cost before round 5; round 5: 200-214 ms, the one frame kind slower than the reference), and every frame
+    # walked with the layout standing (no notifications, GPU_SCENE_REPLAY=0).  The list chase on one thread, the rest on the workers
+    for key, env, args in (("1000000_entities_10pct_dirty_walked_and_retiled_every_frame", {"GPU_SCENE_INCREMENTAL": "0"},
+                            ["1000000", "5", "100", "notify", "churn", "10"]),
+                           ("1000000_entities_10pct_dirty_walked_every_frame", {"GPU_SCENE_REPLAY": "0"}, ["1000000", "5", "100"])):
+        try:
+            p = subprocess.run([exe, "bench", *args], capture_output=True, text=True, timeout=240, env=dict(os.environ, **env))
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            out[key] = {**{k: r[k] for k in ("reference_mq_update_ms", "binding_mq_update_ms", "binding_ms", "fast_frames", "retiles",
+                                             "frames_by_the_records")},
+                        "identical": (r["mismatches"] == 0 and r["visible_equal"] and r["draw_sets_equal"] and r["draw_reads_equal"])}
+        except Exception as e:
+            out[key] = {"error": repr(e)[:200]}
     # skeletal animation through the same boundary: animated_update per character on the host (clock, queue, channels_transform,
     # one_joint_transform: core/model.c:1266-1404, 1563-1591) against gpu_mq_update + gpu_anim_update
     # (10 x 64 over 400 frames: the testbed's own scale, core/clap.c's demo scenes -- three device round trips a frame)

@@ -455,6 +455,13 @@ def secondary(out, extra):
             ("reference_frame_ms", ("reference_frame_ms",)), ("frame_ms_scatter_all", ("binding_frame_draw_list_ms",)))
     m.update(row(c, ("churn_mq_update_ms", ("binding_mq_update_ms",)), ("churn_reference_mq_update_ms", ("reference_mq_update_ms",))))
     m.update(row(w, ("no_notify_mq_update_ms", ("binding_mq_update_ms",)), ("no_notify_reference_mq_update_ms", ("reference_mq_update_ms",))))
+    # the frames that walk the queue: walked + re-tiled every frame, and walked with the layout standing
+    rt = db.get("1000000_entities_10pct_dirty_walked_and_retiled_every_frame") or {}
+    wk = db.get("1000000_entities_10pct_dirty_walked_every_frame") or {}
+    m.update(row(rt, ("walked_retiled_mq_update_ms", ("binding_mq_update_ms",)), ("walked_retiled_walk_ms", ("binding_ms", "walk")),
+                 ("walked_retiled_reference_mq_update_ms", ("reference_mq_update_ms",))))
+    m.update(row(wk, ("walked_mq_update_ms", ("binding_mq_update_ms",)), ("walked_walk_ms", ("binding_ms", "walk")),
+                 ("walked_reference_mq_update_ms", ("reference_mq_update_ms",))))
     if m:
         sec["boundary_1m"] = m
     for n, name in ((1_000_000, "pipeline_frame_1m"), (10_000, "pipeline_frame_10k")):
