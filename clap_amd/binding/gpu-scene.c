@@ -2,7 +2,7 @@
  * gpu-scene.c -- CLAP-side binding of libclapgpu (see gpu-scene.h).  C23 like the engine,
  * compiled with the engine's flags against the engine's headers.
  *
- * Per gpu_mq_update():
+ * What one gpu_mq_update() has to achieve (the steps of a WALKED frame; most frames skip most of them, below):
  *   1. walk mq->txmodels -> txm->entities in list order (what mq_for_each_matching does,
  *      model.c:1911-1922); look every ALIVE entity up in a pointer -> record table;
  *   2. decide which entities are batched: hook == default_update, no skeleton animation
@@ -15,14 +15,23 @@
  *   3. mirror creations, deletions, e->parent, e->flags and -- where xform.updated is set --
  *      position / rotation / scale into libclapgpu_scene, clearing xform.updated as
  *      default_update does (model.c:1615, 1668);
- *   4. clapgpu_scene_mq_update(): tile, upload, ONE kernel launch (update + cull), download;
- *   5. second walk in list order: a batched entity that the reference would have rebuilt this
- *      frame (root: xform.updated; child: xform.updated or parent_seq != parent->seq,
- *      model.c:1609-1616) takes mx / inverse_mx / aabb / aabb_center from the download and has
- *      seq / parent_seq advanced the same way; the camera bounding-volume pick
- *      (model.c:1697-1713) is replayed per entity; every other entity runs its own hook here, so
- *      host entities see their device parents' fresh matrices and the list order of side effects
- *      is the reference's.
+ *   4. clapgpu_scene_mq_update(): ONE kernel launch (update + cull of the frame's views), results in mapped memory;
+ *   5. a batched entity that the reference would have rebuilt this frame (root: xform.updated; child: xform.updated or
+ *      parent_seq != parent->seq, model.c:1609-1616) takes mx / inverse_mx / aabb / aabb_center from the results and has
+ *      seq / parent_seq advanced the same way; the camera bounding-volume pick (model.c:1697-1713) is replayed for the
+ *      entities whose box holds a query point; every other entity runs its own hook, in list order, so host entities
+ *      see their device parents' fresh matrices and the order of side effects is the reference's.
+ *
+ * Where to find what (in file order): records and the pointer table; mirror_one / link_parent (step 3 for one entity);
+ * the draw-list arrays and the address table a walk leaves behind; notifications (gpu_scene_touch*, _entity_created /
+ * _deleting: entities placed into / taken out of the standing layout); scatter_one / scatter_fetched (step 5 for one
+ * entity, the GPU_SCATTER_DRAWN counters); the worker pool and gpu_scene_par_for; fast_frame (a NOTIFIED frame:
+ * O(touched + rebuilt)) and frame_results (the second half of every frame: write-back by mask on the workers, hooks
+ * and bounding-volume candidates merged in list order); queue_unchanged (frames WITHOUT notifications go by the
+ * records); by_host_fields (after a re-tile the mask comes from the host fields); the walked frame as named parts --
+ * walk_begin, walk_queue (the list chase on this thread, criteria / classes / pushes on the workers), walk_settle,
+ * walk_device, second_half_serial, walk_tail -- and mq_update_frame, which picks among them; then views, verdicts,
+ * LOD pick and draw list.
  *
  * A child that precedes its parent in list order lags one frame in the reference (model.c:1911-1922
  * walks creation order).  The device computes converged, parents-first results, so such a child -- and
