@@ -328,6 +328,20 @@ def test_cull_kernel_exact_on_adversarial_boxes(cuda_device):
         assert np.array_equal(out["vis_mask"], mask), camkw
         assert np.array_equal(out["visible"], vis), camkw
         assert 0 < vis.size < n
+        # the same boxes through the FURTHER views' test (no early exits, per-axis extremes computed once: entities_row.h) -- this
+        # camera registered four times over, next to three others: every plane of every view from one read of the boxes
+        others = [synth.camera(pos=(40, 10, -30), quat=synth.quat_from_euler_xyz(-0.4, 2.2, 0.1), fov_deg=40.0, far=300.0),
+                  synth.camera(pos=(-200, 5, 90), quat=synth.quat_from_euler_xyz(0.0, -np.pi / 2, 0.0), ndc_z_zero_one=1),
+                  synth.camera(pos=(0, 300, 0), quat=synth.quat_from_euler_xyz(-np.pi / 2, 0.0, 0.0), aspect=1.0, near=1.0, far=700.0)]
+        views = [cam] + others
+        batch.set_views([entities.view_calc_frustum(c)[0] for c in views])
+        batch.cull(fr)
+        for v, c in enumerate(views):
+            _vis_v, mask_v = ob.entities_cull(n, flags, aabb, ob.frustum_from_camera(c)[0])
+            got = batch.view_masks[v].cpu().numpy().view(np.uint64)[:mask_v.size]
+            assert np.array_equal(got, mask_v), (camkw, v)
+        assert np.array_equal(batch.view_masks[0].cpu().numpy().view(np.uint64)[:mask.size], mask), "the main view's own planes as a further view"
+        batch.set_views([])
 
 
 @pytest.mark.parametrize("layout", ["levels", "tiles"])
